@@ -1,0 +1,214 @@
+"""ctypes mirror of include/dmsa_hip.h (the C ABI of libdmsa_hip.so).
+
+The structures here are byte-for-byte the PODs declared in the header; the same
+classes are reused by the test-only oracle loader (oracle/oracle_py.py) because the
+oracle's C API takes the same problem descriptors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_uint32_p = C.POINTER(C.c_uint32)
+c_uint64_p = C.POINTER(C.c_uint64)
+
+DMSA_OK = 0
+DMSA_ERR_INVALID = -1
+DMSA_ERR_NO_DEVICE = -2
+DMSA_ERR_HIP = -3
+DMSA_ERR_DEPTH = -4
+DMSA_ERR_NOMEM = -5
+
+STOP_NUM_ITER, STOP_FEW_GAUSSIANS, STOP_NAN, STOP_NO_IMPROVEMENT, STOP_EPSILON = range(5)
+
+FLAG_POSE_TABLE_HOST = 0x1
+FLAG_FIXED_ITERS = 0x2
+
+
+class Settings(C.Structure):
+    """dmsa_settings == DmsaOptimSettings (DmsaOptimizer.h:25-39)."""
+
+    _fields_ = [
+        ("num_iter", C.c_int32),
+        ("epsilon", C.c_double),
+        ("use_analytic_jacobi", C.c_int32),
+        ("step_length_optim", C.c_double),
+        ("max_step", C.c_double),
+        ("gauss_split", C.c_int32),
+        ("grid_size_1_factor", C.c_float),
+        ("grid_size_2_factor", C.c_float),
+        ("min_num_points_per_set", C.c_int32),
+        ("min_num_gaussians", C.c_int32),
+        ("lambda_diag", C.c_float),
+        ("use_centralization", C.c_int32),
+    ]
+
+
+class WindowProblem(C.Structure):
+    _fields_ = [
+        ("num_control_poses", C.c_int32),
+        ("rel_orient", c_double_p),
+        ("rel_transl", c_double_p),
+        ("stamps", c_double_p),
+        ("n_total", C.c_int32),
+        ("traj_time", c_double_p),
+        ("num_points", C.c_int64),
+        ("xyz_local", c_float_p),
+        ("tform_idx", c_int32_p),
+        ("ring_id", c_int32_p),
+        ("num_static", C.c_int64),
+        ("xyz_static", c_float_p),
+        ("ring_id_static", c_int32_p),
+        ("min_grid_size", C.c_float),
+        ("use_imu", C.c_int32),
+        ("dt_res", C.c_double),
+        ("balancing_imu", C.c_double),
+        ("gravity", C.c_double * 3),
+        ("param_indices", c_int32_p),
+        ("preint_rot", c_double_p),
+        ("preint_pos", c_double_p),
+        ("preint_vel", c_double_p),
+        ("cov_pvrot_inv", c_double_p),
+    ]
+
+
+class KeyframeProblem(C.Structure):
+    _fields_ = [
+        ("num_frames", C.c_int32),
+        ("rel_orient", c_double_p),
+        ("rel_transl", c_double_p),
+        ("frame_offset", c_int64_p),
+        ("xyz_local", c_float_p),
+        ("normal_local", c_float_p),
+        ("ring_id", c_int32_p),
+        ("min_grid_size", C.c_float),
+        ("use_gravity", C.c_int32),
+        ("use_odometry", C.c_int32),
+        ("gravity", C.c_double * 3),
+        ("cov_grav_inv", C.c_double * 9),
+        ("balancing_grav", C.c_double),
+        ("balancing_odom", C.c_double),
+        ("measured_gravity", c_double_p),
+        ("gravity_plausible", c_int32_p),
+        ("odom_rel_transl", c_double_p),
+        ("odom_rel_orient_mat", c_double_p),
+        ("odom_transl_cov_inv", C.c_double * 9),
+        ("odom_orient_cov_inv", C.c_double * 9),
+    ]
+
+
+class Report(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("stop_reason", C.c_int32),
+        ("num_gaussians", C.c_int32),
+        ("num_gaussians_l1", C.c_int32),
+        ("num_memberships", C.c_int64),
+        ("error0", C.c_double),
+        ("last_step_norm", C.c_double),
+        ("last_line_search_k", C.c_int32),
+        ("evaluations", C.c_int32),
+    ]
+
+
+class VoxelLevelInfo(C.Structure):
+    _fields_ = [
+        ("resolution", C.c_double),
+        ("min_xyz", C.c_double * 3),
+        ("depth", C.c_int32),
+        ("num_events", C.c_int32),
+        ("num_leaves", C.c_int64),
+        ("num_valid", C.c_int64),
+    ]
+
+
+class Timing(C.Structure):
+    _fields_ = [
+        ("residual_kernel_ms", C.c_double),
+        ("residual_launches", C.c_int64),
+        ("residual_evaluations", C.c_int64),
+        ("voxelize_ms", C.c_double),
+        ("gaussian_fit_ms", C.c_double),
+        ("pose_table_ms", C.c_double),
+        ("normal_eq_ms", C.c_double),
+        ("total_ms", C.c_double),
+    ]
+
+
+def ptr(a: np.ndarray | None, ctype):
+    """numpy array -> typed ctypes pointer (None -> NULL). The caller keeps `a` alive."""
+    if a is None:
+        return C.cast(None, C.POINTER(ctype))
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdmsa_hip.so")
+
+_lib = None
+
+
+class DmsaLibraryMissing(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    """Load libdmsa_hip.so (built in-tree by __graft_entry__.build()).  No fallback: a missing
+    library is an error — the product path never routes through a CPU implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DmsaLibraryMissing(
+            f"{LIB_PATH} not found — run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950) first; there is no CPU fallback"
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    sig = {
+        "dmsa_create": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(vp)]),
+        "dmsa_destroy": (None, [vp]),
+        "dmsa_last_error": (C.c_char_p, [vp]),
+        "dmsa_default_settings": (None, [C.POINTER(Settings)]),
+        "dmsa_optimize_window": (C.c_int, [vp, C.POINTER(WindowProblem), C.POINTER(Settings), C.POINTER(Report)]),
+        "dmsa_optimize_keyframes": (C.c_int, [vp, C.POINTER(KeyframeProblem), C.POINTER(Settings), C.POINTER(Report)]),
+        "dmsa_get_global_points": (C.c_int, [vp, c_float_p, C.c_int64]),
+        "dmsa_window_upload": (C.c_int, [vp, C.POINTER(WindowProblem)]),
+        "dmsa_keyframes_upload": (C.c_int, [vp, C.POINTER(KeyframeProblem)]),
+        "dmsa_centralize": (C.c_int, [vp]),
+        "dmsa_decentralize": (C.c_int, [vp]),
+        "dmsa_get_params": (C.c_int, [vp, c_double_p, c_int32_p]),
+        "dmsa_set_params": (C.c_int, [vp, c_double_p]),
+        "dmsa_pose_tables": (C.c_int, [vp, C.c_int32, c_double_p, c_float_p]),
+        "dmsa_set_pose_tables": (C.c_int, [vp, C.c_int32, c_float_p]),
+        "dmsa_num_table_rows": (C.c_int, [vp, c_int32_p]),
+        "dmsa_transform_points": (C.c_int, [vp, C.c_int32, c_float_p]),
+        "dmsa_build_gaussians": (C.c_int, [vp, C.POINTER(Settings), c_int32_p, c_int64_p]),
+        "dmsa_eval_residuals": (C.c_int, [vp, c_double_p]),
+        "dmsa_normal_equations": (C.c_int, [vp, C.c_int32, C.c_int32, c_double_p, C.c_double, C.c_double, c_double_p, c_double_p]),
+        "dmsa_get_voxel_level": (C.c_int, [vp, C.c_int32, C.POINTER(VoxelLevelInfo), c_uint64_p, c_uint32_p, c_int32_p]),
+        "dmsa_get_gaussians": (C.c_int, [vp, c_int32_p, c_int32_p, c_float_p, c_float_p]),
+        "dmsa_get_timing": (C.c_int, [vp, C.POINTER(Timing), C.c_int32]),
+        "dmsa_synchronize": (C.c_int, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "dmsa_create dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
+    "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
+    "dmsa_set_params dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
+    "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize"
+).split()

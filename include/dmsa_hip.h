@@ -1,0 +1,218 @@
+/*
+ * dmsa_hip.h — C ABI of the MI355X-native DMSA inner loop.
+ *
+ * Drop-in boundary for ONE path of davidskdds/DMSA_LiDAR_SLAM: the body of
+ *   DmsaOptimizer<PointT>::optimizeSet            (include/DMSA/DmsaOptimizer.h:54-150)
+ * driven on the two concrete problem models
+ *   ContinuousTrajectory : OptimizablePointSet<PointStampId>   (ContinuousTrajectory.h:24-669)
+ *   MapManagement        : OptimizablePointSet<PointNormal>    (MapManagement.h:20-390)
+ *
+ * The reference has no FFI layer; its seam is a C++ template + nine virtuals
+ * (OptimizablePointSet.h:18-56).  A GPU library cannot call per-point virtuals
+ * back, so this ABI absorbs the two concrete models: the caller hands over the
+ * state those virtuals read (plain pointers, Eigen column-major layouts so real
+ * Eigen objects can be passed with .data()), the library owns all device memory.
+ *
+ * Conventions
+ *   - every entry point returns 0 (DMSA_OK) or a negative dmsa_status; nothing throws
+ *     across the ABI; no global state; one context per host thread / GPU.
+ *   - "3xn col-major double" == Eigen::Matrix3Xd::data().
+ *   - point arrays are float[n][4] == pcl PointXYZ-style data[4] (PointStampId.h:33-45),
+ *     the 4th float is ignored on input (the reference keeps it at 1.0f).
+ *   - the library FAILS (DMSA_ERR_NO_DEVICE) when no HIP device is usable; there is no
+ *     CPU fallback behind this ABI.
+ */
+#ifndef DMSA_HIP_H
+#define DMSA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dmsa_ctx dmsa_ctx;
+
+typedef enum dmsa_status {
+    DMSA_OK = 0,
+    DMSA_ERR_INVALID = -1,     /* bad argument / problem not uploaded                      */
+    DMSA_ERR_NO_DEVICE = -2,   /* no usable HIP device — never falls back to the CPU       */
+    DMSA_ERR_HIP = -3,         /* a HIP runtime call failed (dmsa_last_error has the text) */
+    DMSA_ERR_DEPTH = -4,       /* voxel lattice deeper than 21 levels (> 63-bit leaf code) */
+    DMSA_ERR_NOMEM = -5
+} dmsa_status;
+
+/* Why optimizeSet left its loop (DmsaOptimizer.h:89-93, :116-122, :130-134, :139-143). */
+typedef enum dmsa_stop_reason {
+    DMSA_STOP_NUM_ITER = 0,        /* ran settings.num_iter iterations                     */
+    DMSA_STOP_FEW_GAUSSIANS = 1,   /* numPointSets < min_num_gaussians                     */
+    DMSA_STOP_NAN = 2,             /* NaN in the LM step, parameters restored              */
+    DMSA_STOP_NO_IMPROVEMENT = 3,  /* adaptiveStepSize returned 0                          */
+    DMSA_STOP_EPSILON = 4          /* ||step|| < epsilon                                   */
+} dmsa_stop_reason;
+
+/* == DmsaOptimSettings (DmsaOptimizer.h:25-39), same defaults via dmsa_default_settings. */
+typedef struct dmsa_settings {
+    int32_t num_iter;                /* 15     */
+    double  epsilon;                 /* 1e-5   */
+    int32_t use_analytic_jacobi;     /* false — never read by the reference either (:29)  */
+    double  step_length_optim;       /* 0.05   */
+    double  max_step;                /* 0.01   */
+    int32_t gauss_split;             /* false  */
+    float   grid_size_1_factor;      /* 2.0    */
+    float   grid_size_2_factor;      /* 5.0    */
+    int32_t min_num_points_per_set;  /* 6      */
+    int32_t min_num_gaussians;       /* 30     */
+    float   lambda_diag;             /* 1e-5   */
+    int32_t use_centralization;      /* true   */
+} dmsa_settings;
+
+/* State of a ContinuousTrajectory that the hot path reads/writes.
+ * Replaces: get/setPoseParameters (ContinuousTrajectory.h:119-127), updateGlobalPoints (:129-156),
+ * updateTrajDenseTforms (:189-226), updateAdditionalErrors/updateImuError (:107-117, :603-663),
+ * centralize/decentralize (:75-100), getIdOfPoint (:665-668). */
+typedef struct dmsa_window_problem {
+    int32_t        num_control_poses;   /* C = controlPoses.numPoses                              */
+    double*        rel_orient;          /* 3xC col-major, controlPoses.relativePoses.Orientations — IN/OUT */
+    double*        rel_transl;          /* 3xC col-major, controlPoses.relativePoses.Translations — IN/OUT */
+    const double*  stamps;              /* C, controlPoses.stamps (strictly increasing)           */
+    int32_t        n_total;             /* dense pose count                                       */
+    const double*  traj_time;           /* n_total, trajTime                                      */
+    int64_t        num_points;          /* N window points (all clouds of regPcBuffer, chronological) */
+    const float*   xyz_local;           /* N x 4, local (sensor-frame) coordinates                */
+    const int32_t* tform_idx;           /* N, tformIdPerPoint flattened (registerPcBuffer :240-260) */
+    const int32_t* ring_id;             /* N, PointStampId::id                                    */
+    int64_t        num_static;          /* S static map points appended by addStaticPoints (:158-172) */
+    const float*   xyz_static;          /* S x 4, world frame, NOT yet centralised                */
+    const int32_t* ring_id_static;      /* S                                                      */
+    float          min_grid_size;       /* OptimizablePointSet::minGridSize                       */
+    /* IMU factor rows (updateImuError); ignored when use_imu == 0 */
+    int32_t        use_imu;             /* useImuErrorTerms                                       */
+    double         dt_res;
+    double         balancing_imu;
+    double         gravity[3];
+    const int32_t* param_indices;       /* C, paramIndices                                        */
+    const double*  preint_rot;          /* C x 9, preintImuRots[k] col-major (entry 0 unused)     */
+    const double*  preint_pos;          /* C x 3, preintRelPositions                              */
+    const double*  preint_vel;          /* C x 3, preintRelVelocity                               */
+    const double*  cov_pvrot_inv;       /* C x 81, CovPVRot_inv[k] col-major                      */
+} dmsa_window_problem;
+
+/* State of a MapManagement (sub)map that the hot path reads/writes.
+ * Replaces: get/setPoseParameters (MapManagement.h:192-202), updateGlobalPoints (:120-149),
+ * updateAdditionalErrors / Gravity / Odometry (:162-252), getIdOfPoint (:204-208). */
+typedef struct dmsa_keyframe_problem {
+    int32_t        num_frames;          /* keyframeDataBuffer.getNumElements()                    */
+    double*        rel_orient;          /* 3xF col-major keyframePoses.relativePoses.Orientations — IN/OUT */
+    double*        rel_transl;          /* 3xF col-major                                   — IN/OUT */
+    const int64_t* frame_offset;        /* F+1 prefix of points per keyframe                      */
+    const float*   xyz_local;           /* n x 4 local PointNormal xyz, keyframes concatenated    */
+    const float*   normal_local;        /* n x 4 local normals                                    */
+    const int32_t* ring_id;             /* n, MapManagement::ringIds                              */
+    float          min_grid_size;
+    int32_t        use_gravity;         /* useGravityErrorTerms                                   */
+    int32_t        use_odometry;        /* useOdometryErrorTerms                                  */
+    double         gravity[3];
+    double         cov_grav_inv[9];     /* col-major                                              */
+    double         balancing_grav;
+    double         balancing_odom;
+    const double*  measured_gravity;    /* F x 3                                                  */
+    const int32_t* gravity_plausible;   /* F                                                      */
+    const double*  odom_rel_transl;     /* F x 3, KeyframeData::relativeTransl                    */
+    const double*  odom_rel_orient_mat; /* F x 9 col-major, KeyframeData::relativeOrientMat       */
+    double         odom_transl_cov_inv[9];
+    double         odom_orient_cov_inv[9];
+} dmsa_keyframe_problem;
+
+typedef struct dmsa_report {
+    int32_t iterations;        /* loop bodies entered                                            */
+    int32_t stop_reason;       /* dmsa_stop_reason                                               */
+    int32_t num_gaussians;     /* M of the last iteration                                        */
+    int32_t num_gaussians_l1;  /* of which from the first resolution                             */
+    int64_t num_memberships;   /* Mm = sum of points over the Gaussians of the last iteration    */
+    double  error0;            /* e^T e at the start of the last iteration                       */
+    double  last_step_norm;
+    int32_t last_line_search_k;
+    int32_t evaluations;       /* forward evaluations done in total                              */
+} dmsa_report;
+
+/* context flags */
+#define DMSA_FLAG_POSE_TABLE_HOST 0x1u /* build dense pose tables in host double math (bit-reproducible
+                                          against the CPU oracle); default is the device kernel      */
+#define DMSA_FLAG_FIXED_ITERS     0x2u /* benchmarking: ignore the no-improvement / epsilon exits    */
+
+int  dmsa_create(int device, uint32_t flags, dmsa_ctx** out);
+void dmsa_destroy(dmsa_ctx* ctx);
+const char* dmsa_last_error(const dmsa_ctx* ctx);
+void dmsa_default_settings(dmsa_settings* s);
+
+/* ---- whole optimizeSet (the drop-in calls) ---------------------------------------------- */
+/* == slidingWindowOptimizer.optimizeSet(*currTraj, optimSettingsSlidingWindow)  DmsaSlam.h:166 */
+int dmsa_optimize_window(dmsa_ctx* ctx, dmsa_window_problem* p, const dmsa_settings* s, dmsa_report* rep);
+/* == keyframeMapOptimizer.optimizeSet(*currSubmap, optimSettingsMap)            DmsaSlam.h:228 */
+int dmsa_optimize_keyframes(dmsa_ctx* ctx, dmsa_keyframe_problem* p, const dmsa_settings* s, dmsa_report* rep);
+/* final globalPoints of the last optimize call (DmsaOptimizer.h:149); n x 4 floats */
+int dmsa_get_global_points(dmsa_ctx* ctx, float* xyz_out, int64_t capacity_points);
+
+/* ---- stage-level entry points (used by the parity tests and the benchmark) -------------- */
+int dmsa_window_upload(dmsa_ctx* ctx, const dmsa_window_problem* p);       /* points resident in HBM */
+int dmsa_keyframes_upload(dmsa_ctx* ctx, const dmsa_keyframe_problem* p);
+/* ContinuousTrajectory::centralize()/decentralize() on the uploaded problem (poses + static points) */
+int dmsa_centralize(dmsa_ctx* ctx);
+int dmsa_decentralize(dmsa_ctx* ctx);
+/* current parameter vector (getPoseParameters) of the uploaded problem, P doubles */
+int dmsa_get_params(dmsa_ctx* ctx, double* params, int32_t* P);
+int dmsa_set_params(dmsa_ctx* ctx, const double* params);
+/* Build B dense pose tables from B parameter vectors (B x P row-major doubles).
+ * tables_out (optional, host): B x n_rows x 12 floats, each row = 3x4 [R|t] row-major.
+ * == setPoseParameters + updateTrajDenseTforms (window) / per-keyframe transforms (keyframes). */
+int dmsa_pose_tables(dmsa_ctx* ctx, int32_t B, const double* params, float* tables_out);
+/* Same, but the caller supplies the tables (B x n_rows x 12 floats). */
+int dmsa_set_pose_tables(dmsa_ctx* ctx, int32_t B, const float* tables);
+int dmsa_num_table_rows(dmsa_ctx* ctx, int32_t* n_rows);
+/* updateGlobalPoints() with pose table b of the current batch; xyz_out optional (n x 4). */
+int dmsa_transform_points(dmsa_ctx* ctx, int32_t b, float* xyz_out);
+/* currentGauss.reset() + createGaussianSets at both resolutions + updateRebalancingWeights
+ * on the current global points (DmsaOptimizer.h:78-96). */
+int dmsa_build_gaussians(dmsa_ctx* ctx, const dmsa_settings* s, int32_t* M_out, int64_t* Mm_out);
+/* updateErrorTerms for the B tables of the current batch: e_out = B x M doubles (Gaussian rows only,
+ * row order = leaf DFS order, first resolution then second). */
+int dmsa_eval_residuals(dmsa_ctx* ctx, double* e_out);
+/* H = J^T J + lambda I, g = J^T e0 with J.col(k) = (e_{k+1} - e_0)/h from the last batch of 1+P evaluations;
+ * extra_rows (optional) = (1+P) x a additional error rows computed by the caller. H: P x P col-major. */
+int dmsa_normal_equations(dmsa_ctx* ctx, int32_t P, int32_t a, const double* extra_rows, double h, double lambda,
+                          double* H_out, double* g_out);
+
+/* introspection for the parity tests */
+typedef struct dmsa_voxel_level_info {
+    double  resolution;      /* octree resolution_ (float product widened, DmsaOptimizer.h:82)        */
+    double  min_xyz[3];      /* final min_x_/min_y_/min_z_                                             */
+    int32_t depth;           /* final octree_depth_                                                    */
+    int32_t num_events;      /* bounding-box growth events                                            */
+    int64_t num_leaves;      /* occupied leaves                                                       */
+    int64_t num_valid;       /* finite points inserted                                                */
+} dmsa_voxel_level_info;
+int dmsa_get_voxel_level(dmsa_ctx* ctx, int32_t level, dmsa_voxel_level_info* info,
+                         uint64_t* leaf_code /* n, per point, DFS code */, uint32_t* key_xyz /* n x 3 */,
+                         int32_t* sorted_point_idx /* n, leaf DFS order then ascending index */);
+int dmsa_get_gaussians(dmsa_ctx* ctx, int32_t* seg_offset /* M+1 */, int32_t* member_idx /* Mm */,
+                       float* info_mats /* M x 9 col-major */, float* weights /* M */);
+
+/* timing of the last optimize / stage calls, milliseconds measured with HIP events on the library stream */
+typedef struct dmsa_timing {
+    double residual_kernel_ms;   /* accumulated time inside the correspondence kernel                 */
+    int64_t residual_launches;
+    int64_t residual_evaluations;
+    double voxelize_ms;
+    double gaussian_fit_ms;
+    double pose_table_ms;
+    double normal_eq_ms;
+    double total_ms;
+} dmsa_timing;
+int dmsa_get_timing(dmsa_ctx* ctx, dmsa_timing* t, int32_t reset);
+int dmsa_synchronize(dmsa_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMSA_HIP_H */

@@ -1,0 +1,1287 @@
+// dmsa_oracle.cpp — CPU ORACLE for the DMSA inner loop.  TEST INFRASTRUCTURE ONLY.
+//
+// A plain C++17 restatement (no Eigen / PCL / Boost) of
+//   DmsaOptimizer<PointT>::optimizeSet and helpers   include/DMSA/DmsaOptimizer.h:54-363
+//   Gaussians / splitSet                              include/DMSA/Gaussians.h:19-202
+//   ContinuousTrajectory hot methods                  include/DMSA/ContinuousTrajectory.h:75-226, 570-668
+//   MapManagement hot methods                         include/DMSA/MapManagement.h:73-252
+//   Poses / ConsecutivePoses / helpers                include/DMSA/Poses.h:64-76, ConsecutivePoses.h:26-67, helpers.h:18-65
+// Every function cites the reference lines it follows.  Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may load this library; the product never links it.
+//
+// PARITY UNPINNED.  The reference has no tests and cannot be built here (Eigen 3.4, PCL 1.10,
+// Boost 1.71 and ROS are absent).  Third-party arithmetic is restated from the published algorithms:
+//   * pcl::octree::OctreePointCloud  — bounding-box growth, key generation, depth-first leaf order
+//   * boost::math::barycentric_rational (Floater–Hormann, d = 2)                                   
+//   * Eigen: skew().exp() == Rodrigues, R.log() via the unit quaternion, Quaterniond::slerp,
+//     AngleAxisd(q), Matrix3f::inverse() (cofactors), fixed-size product evaluation order        
+// Where Eigen's summation order cannot be known (dynamic-size vectorised reductions: colwise().mean(),
+// centered^T*centered, VectorXf::mean(), MatrixXd products) this file accumulates in double and rounds
+// once — the correctly rounded value every float order approximates.  EigenSolver<Matrix3f> (general
+// QR) is replaced by a fixed-sweep symmetric Jacobi iteration in float.  Build with -ffp-contract=off.
+
+#include "dmsa_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <numeric>
+#include <stdexcept>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// small fixed-size double algebra
+// ------------------------------------------------------------------------------------------------
+struct M3 {
+    double m[3][3];  // m[row][col]
+};
+static inline M3 eye3() { return M3{{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}}; }
+static inline M3 mul(const M3& a, const M3& b) {
+    M3 c;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+    return c;
+}
+static inline M3 transpose(const M3& a) {
+    M3 c;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c.m[i][j] = a.m[j][i];
+    return c;
+}
+static inline void matvec(const M3& a, const double* v, double* out) {
+    double r[3];
+    for (int i = 0; i < 3; ++i) r[i] = a.m[i][0] * v[0] + a.m[i][1] * v[1] + a.m[i][2] * v[2];
+    out[0] = r[0], out[1] = r[1], out[2] = r[2];
+}
+static inline double norm3(const double* a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+
+// helpers.h:51-57 axang2rotm: identity below EPSILON_ROT (helpers.h:18), else skew(axang).exp().
+// The matrix exponential of a skew matrix is Rodrigues' formula; 1-cos is written 2 sin^2(t/2).
+static M3 axang2rotm(const double* w) {
+    const double theta = norm3(w);
+    if (theta < 0.00001) return eye3();
+    const double s = std::sin(theta) / theta;
+    const double sh = std::sin(0.5 * theta);
+    const double c = 2.0 * sh * sh / (theta * theta);
+    const double x = w[0], y = w[1], z = w[2];
+    M3 R;
+    // I + s*K + c*K^2 with K^2 = w w^T - theta^2 I
+    R.m[0][0] = 1.0 + c * (x * x - theta * theta);
+    R.m[1][1] = 1.0 + c * (y * y - theta * theta);
+    R.m[2][2] = 1.0 + c * (z * z - theta * theta);
+    R.m[0][1] = c * x * y - s * z;
+    R.m[1][0] = c * x * y + s * z;
+    R.m[0][2] = c * x * z + s * y;
+    R.m[2][0] = c * x * z - s * y;
+    R.m[1][2] = c * y * z - s * x;
+    R.m[2][1] = c * y * z + s * x;
+    return R;
+}
+
+// helpers.h:59-65 rotm2axang: principal matrix logarithm of a rotation, read as (S(2,1), S(0,2), S(1,0)).
+// Restated through the unit quaternion (Shepperd) so that it stays accurate near 0 and near pi.
+static void rotm2axang(const M3& R, double* out) {
+    const double m00 = R.m[0][0], m11 = R.m[1][1], m22 = R.m[2][2];
+    const double tr = m00 + m11 + m22;
+    double qw, qx, qy, qz;
+    if (tr > 0.0) {
+        const double s = std::sqrt(tr + 1.0) * 2.0;
+        qw = 0.25 * s;
+        qx = (R.m[2][1] - R.m[1][2]) / s;
+        qy = (R.m[0][2] - R.m[2][0]) / s;
+        qz = (R.m[1][0] - R.m[0][1]) / s;
+    } else if (m00 > m11 && m00 > m22) {
+        const double s = std::sqrt(1.0 + m00 - m11 - m22) * 2.0;
+        qw = (R.m[2][1] - R.m[1][2]) / s;
+        qx = 0.25 * s;
+        qy = (R.m[0][1] + R.m[1][0]) / s;
+        qz = (R.m[0][2] + R.m[2][0]) / s;
+    } else if (m11 > m22) {
+        const double s = std::sqrt(1.0 + m11 - m00 - m22) * 2.0;
+        qw = (R.m[0][2] - R.m[2][0]) / s;
+        qx = (R.m[0][1] + R.m[1][0]) / s;
+        qy = 0.25 * s;
+        qz = (R.m[1][2] + R.m[2][1]) / s;
+    } else {
+        const double s = std::sqrt(1.0 + m22 - m00 - m11) * 2.0;
+        qw = (R.m[1][0] - R.m[0][1]) / s;
+        qx = (R.m[0][2] + R.m[2][0]) / s;
+        qy = (R.m[1][2] + R.m[2][1]) / s;
+        qz = 0.25 * s;
+    }
+    const double n = std::sqrt(qx * qx + qy * qy + qz * qz);
+    if (n == 0.0) {
+        out[0] = out[1] = out[2] = 0.0;
+        return;
+    }
+    const double angle = 2.0 * std::atan2(n, std::fabs(qw));
+    const double k = angle / (qw < 0.0 ? -n : n);
+    out[0] = qx * k, out[1] = qy * k, out[2] = qz * k;
+}
+
+// helpers.h:24-37 slerp of two axis-angle vectors, with Eigen 3.4 semantics of
+// Quaterniond(AngleAxisd(norm, normalized)), QuaternionBase::slerp and AngleAxisd(Quaterniond).
+static void slerp(const double* aa1, const double* aa2, double t, double* out) {
+    double q1[4], q2[4];  // w, x, y, z
+    const double* aas[2] = {aa1, aa2};
+    double* qs[2] = {q1, q2};
+    for (int i = 0; i < 2; ++i) {
+        const double* a = aas[i];
+        const double sq = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+        const double ang = std::sqrt(sq);
+        double ax[3] = {a[0], a[1], a[2]};
+        if (sq > 0.0) {  // Eigen normalized(): zero vector stays zero
+            ax[0] = a[0] / ang, ax[1] = a[1] / ang, ax[2] = a[2] / ang;
+        }
+        const double sh = std::sin(0.5 * ang);
+        qs[i][0] = std::cos(0.5 * ang);
+        qs[i][1] = sh * ax[0], qs[i][2] = sh * ax[1], qs[i][3] = sh * ax[2];
+    }
+    const double one = 1.0 - std::numeric_limits<double>::epsilon();
+    const double d = q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3];
+    const double absD = std::fabs(d);
+    double scale0, scale1;
+    if (absD >= one) {
+        scale0 = 1.0 - t;
+        scale1 = t;
+    } else {
+        const double theta = std::acos(absD);
+        const double sinTheta = std::sin(theta);
+        scale0 = std::sin((1.0 - t) * theta) / sinTheta;
+        scale1 = std::sin(t * theta) / sinTheta;
+    }
+    if (d < 0.0) scale1 = -scale1;
+    double q[4];
+    for (int i = 0; i < 4; ++i) q[i] = scale0 * q1[i] + scale1 * q2[i];
+    // AngleAxisd(q)
+    double n = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (n != 0.0) {
+        const double angle = 2.0 * std::atan2(n, std::fabs(q[0]));
+        if (q[0] < 0.0) n = -n;
+        out[0] = (q[1] / n) * angle, out[1] = (q[2] / n) * angle, out[2] = (q[3] / n) * angle;
+    } else {
+        out[0] = 0.0, out[1] = 0.0, out[2] = 0.0;  // angle 0, axis (1,0,0)
+    }
+}
+
+// boost::math::barycentric_rational<double> (ContinuousTrajectory.h:214-217): Floater–Hormann weights and
+// barycentric evaluation with the exact-node short-circuit.
+struct BarycentricRational {
+    std::vector<double> x, y, w;
+    BarycentricRational(const double* xs, const double* ys, int n, int d) : x(xs, xs + n), y(ys, ys + n), w(n, 0.0) {
+        for (int64_t k = 0; k < n; ++k) {
+            int64_t i_min = std::max<int64_t>(k - d, 0);
+            int64_t i_max = k;
+            if (k >= n - d) i_max = n - d - 1;
+            for (int64_t i = i_min; i <= i_max; ++i) {
+                double inv_product = 1.0;
+                const int64_t j_max = std::min<int64_t>(i + d, n - 1);
+                for (int64_t j = i; j <= j_max; ++j) {
+                    if (j == k) continue;
+                    const double diff = x[k] - x[j];
+                    if (std::fabs(diff) < std::numeric_limits<double>::min()) throw std::logic_error("coincident nodes");
+                    inv_product *= diff;
+                }
+                if (i % 2 == 0)
+                    w[k] += 1.0 / inv_product;
+                else
+                    w[k] -= 1.0 / inv_product;
+            }
+        }
+    }
+    double operator()(double t) const {
+        double numerator = 0.0, denominator = 0.0;
+        for (size_t i = 0; i < x.size(); ++i) {
+            if (t == x[i]) return y[i];
+            const double q = w[i] / (t - x[i]);
+            numerator += q * y[i];
+            denominator += q;
+        }
+        return numerator / denominator;
+    }
+};
+
+// Poses.h:16-76: 3xn column-major axis-angle + translations.
+struct Poses {
+    int n = 0;
+    std::vector<double> O, T;
+    void resize(int k) {
+        n = k;
+        O.assign(3 * (size_t)k, 0.0);
+        T.assign(3 * (size_t)k, 0.0);
+    }
+    // Poses.h:64-70: [Orientations cols 1..n-1 | Translations cols 1..n-1], pose 0 excluded
+    void getParamsAsVector(std::vector<double>& p) const {
+        p.resize(6 * (size_t)(n - 1));
+        std::copy(O.begin() + 3, O.end(), p.begin());
+        std::copy(T.begin() + 3, T.end(), p.begin() + 3 * (n - 1));
+    }
+    // Poses.h:72-76
+    void setParamsFromVector(const std::vector<double>& p) {
+        std::copy(p.begin(), p.begin() + 3 * (n - 1), O.begin() + 3);
+        std::copy(p.begin() + 3 * (n - 1), p.end(), T.begin() + 3);
+    }
+};
+
+// ConsecutivePoses.h:17-75
+struct ConsecutivePoses {
+    Poses rel, glob;
+    int numPoses = 0;
+    void resize(int n) {
+        rel.resize(n), glob.resize(n);
+        numPoses = n;
+    }
+    // ConsecutivePoses.h:26-43
+    void relative2global() {
+        M3 R = eye3();
+        double T[3] = {0, 0, 0};
+        for (int k = 0; k < numPoses; ++k) {
+            double rt[3];
+            matvec(R, &rel.T[3 * k], rt);
+            T[0] = T[0] + rt[0], T[1] = T[1] + rt[1], T[2] = T[2] + rt[2];
+            glob.T[3 * k] = T[0], glob.T[3 * k + 1] = T[1], glob.T[3 * k + 2] = T[2];
+            R = mul(R, axang2rotm(&rel.O[3 * k]));
+            rotm2axang(R, &glob.O[3 * k]);
+        }
+    }
+    // ConsecutivePoses.h:45-67
+    void global2relative() {
+        for (int c = 0; c < 3; ++c) rel.O[c] = glob.O[c], rel.T[c] = glob.T[c];
+        for (int k = numPoses - 1; k > 0; --k) {
+            const M3 R1 = axang2rotm(&glob.O[3 * (k - 1)]);
+            const M3 R2 = axang2rotm(&glob.O[3 * k]);
+            const M3 R1t = transpose(R1);
+            rotm2axang(mul(R1t, R2), &rel.O[3 * k]);
+            const double d[3] = {glob.T[3 * k] - glob.T[3 * (k - 1)], glob.T[3 * k + 1] - glob.T[3 * (k - 1) + 1],
+                                 glob.T[3 * k + 2] - glob.T[3 * (k - 1) + 2]};
+            matvec(R1t, d, &rel.T[3 * k]);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// float helpers that pin Eigen's fixed-size evaluation order (SURVEY 8(a) "evaluation-order assumptions")
+// ------------------------------------------------------------------------------------------------
+// Matrix4f * Vector4f with w = 1 (ContinuousTrajectory.h:151, MapManagement.h:142): ((c0*x + c1*y) + c2*z) + c3*1
+static inline void tform_point(const float* T /* 12: row-major 3x4 */, const float* p, float* out) {
+    for (int r = 0; r < 3; ++r) out[r] = ((T[4 * r + 0] * p[0] + T[4 * r + 1] * p[1]) + T[4 * r + 2] * p[2]) + T[4 * r + 3];
+}
+// 3-term fixed-size inner product: Eigen's unrolled redux splits in halves -> x0 + (x1 + x2)
+static inline float sum3(float a, float b, float c) { return a + (b + c); }
+// Matrix3f * Vector3f (MapManagement.h:144)
+static inline void rot_vec(const float* T, const float* v, float* out) {
+    for (int r = 0; r < 3; ++r) out[r] = sum3(T[4 * r + 0] * v[0], T[4 * r + 1] * v[1], T[4 * r + 2] * v[2]);
+}
+static inline float normf3(float x, float y, float z) { return std::sqrt(sum3(x * x, y * y, z * z)); }
+
+// Matrix3f::inverse(): cofactor closed form (Eigen/src/LU/InverseImpl.h, size 3)
+static void inverse3f(const float m[3][3], float inv[3][3]) {
+    auto cof = [&](int i, int j) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        return m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+    };
+    const float c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+    const float det = sum3(c0 * m[0][0], c1 * m[1][0], c2 * m[2][0]);
+    const float invdet = 1.0f / det;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) inv[r][c] = cof(c, r) * invdet;
+}
+
+// Gaussians.h:181-201 limitCovariance.  EigenSolver<Matrix3f> cannot be mirrored bitwise; on a
+// symmetric PSD input it equals a symmetric eigendecomposition up to rounding.  Fixed 6-sweep cyclic Jacobi
+// in float (+,-,*,/,sqrt only, so the HIP kernel reproduces it bit for bit), clamp >= 1e-4, V*D*V^T.
+static void limit_covariance(float c[3][3]) {
+    float a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) a[i][j] = c[i][j];
+    static const int PQ[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int sweep = 0; sweep < 6; ++sweep) {
+        for (int r = 0; r < 3; ++r) {
+            const int p = PQ[r][0], q = PQ[r][1];
+            const float apq = a[p][q];
+            if (apq == 0.0f) continue;
+            const float theta = (a[q][q] - a[p][p]) / (2.0f * apq);
+            const float at = std::fabs(theta);
+            float t = 1.0f / (at + std::sqrt(theta * theta + 1.0f));
+            if (theta < 0.0f) t = -t;
+            const float cs = 1.0f / std::sqrt(t * t + 1.0f);
+            const float sn = t * cs;
+            const int k = 3 - p - q;  // the remaining index
+            const float app = a[p][p], aqq = a[q][q];
+            a[p][p] = app - t * apq;
+            a[q][q] = aqq + t * apq;
+            a[p][q] = 0.0f, a[q][p] = 0.0f;
+            const float akp = a[k][p], akq = a[k][q];
+            a[k][p] = cs * akp - sn * akq;
+            a[p][k] = a[k][p];
+            a[k][q] = sn * akp + cs * akq;
+            a[q][k] = a[k][q];
+            for (int i = 0; i < 3; ++i) {
+                const float vip = v[i][p], viq = v[i][q];
+                v[i][p] = cs * vip - sn * viq;
+                v[i][q] = sn * vip + cs * viq;
+            }
+        }
+    }
+    float lam[3];
+    for (int k = 0; k < 3; ++k) lam[k] = std::max(a[k][k], 0.0001f);  // Gaussians.h:191-194
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[i][j] = sum3((v[i][0] * lam[0]) * v[j][0], (v[i][1] * lam[1]) * v[j][1], (v[i][2] * lam[2]) * v[j][2]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PCL OctreePointCloud, restated without building a tree.
+// ------------------------------------------------------------------------------------------------
+struct VoxelResult {
+    dmsa_voxel_level_info info{};
+    std::vector<uint64_t> code;   // per point, UINT64_MAX for skipped (non-finite) points
+    std::vector<uint32_t> key;    // per point x 3, final keys
+    std::vector<int32_t> order;   // valid point indices sorted by (code, index)
+};
+
+static int voxelize(const float* xyz4, int64_t n, double resolution, VoxelResult& out) {
+    const double eps = (double)std::numeric_limits<float>::epsilon();  // "minValue" in PCL
+    bool defined = false;
+    double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    unsigned depth = 0;
+    struct Event {
+        uint32_t shift[3];
+    };
+    std::vector<Event> events;
+    std::vector<int32_t> epoch((size_t)n, -1);
+    out.code.assign((size_t)n, UINT64_MAX);
+    out.key.assign((size_t)n * 3, 0u);
+    int64_t num_valid = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const float* p = xyz4 + 4 * i;
+        if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;  // addPointsFromInputCloud
+        // adoptBoundingBoxToPoint
+        while (true) {
+            bool lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) lo[a] = (double)p[a] < mn[a], hi[a] = (double)p[a] >= mx[a];
+            if (!(lo[0] || lo[1] || lo[2] || hi[0] || hi[1] || hi[2] || !defined)) break;
+            if (defined) {
+                double side = (double)(1u << depth) * resolution;
+                Event ev{};
+                for (int a = 0; a < 3; ++a) {
+                    if (!hi[a]) {
+                        mn[a] -= side;
+                        ev.shift[a] = 1u << depth;  // old root becomes the upper child on this axis
+                    }
+                }
+                events.push_back(ev);
+                depth += 1;
+                if (depth > 21) return DMSA_ERR_DEPTH;
+                side = (double)(1u << depth) * resolution - eps;
+                for (int a = 0; a < 3; ++a) mx[a] = mn[a] + side;
+            } else {
+                for (int a = 0; a < 3; ++a) {
+                    mn[a] = (double)p[a] - resolution / 2;
+                    mx[a] = (double)p[a] + resolution / 2;
+                }
+                // getKeyBitSize()
+                unsigned max_key[3];
+                for (int a = 0; a < 3; ++a) max_key[a] = (unsigned)std::ceil((mx[a] - mn[a] - eps) / resolution);
+                const unsigned max_voxels = std::max(std::max(std::max(max_key[0], max_key[1]), max_key[2]), 2u);
+                depth = std::max(std::min(32u, (unsigned)std::ceil(std::log((double)max_voxels) / std::log(2.0) - eps)), 0u);
+                const double side = (double)(1u << depth) * resolution;
+                for (int a = 0; a < 3; ++a) {  // leaf_count_ == 0
+                    const double oversize = (side - (mx[a] - mn[a])) / 2.0;
+                    if (oversize > eps) {
+                        mn[a] -= oversize;
+                        mx[a] += oversize;
+                    }
+                }
+                defined = true;
+            }
+        }
+        // genOctreeKeyforPoint, truncated to the tree depth at insertion time (createLeafRecursive only
+        // looks at depth_mask bits)
+        const uint32_t mask = (depth >= 32) ? 0xffffffffu : ((1u << depth) - 1u);
+        for (int a = 0; a < 3; ++a) out.key[3 * i + a] = (uint32_t)(((double)p[a] - mn[a]) / resolution) & mask;
+        epoch[i] = (int32_t)events.size();
+        ++num_valid;
+    }
+    // later growth re-roots the tree: add the shifts of all events after the insertion epoch
+    std::vector<Event> suffix(events.size() + 1, Event{});
+    for (int64_t e = (int64_t)events.size() - 1; e >= 0; --e)
+        for (int a = 0; a < 3; ++a) suffix[e].shift[a] = suffix[e + 1].shift[a] + events[e].shift[a];
+    out.order.clear();
+    out.order.reserve((size_t)num_valid);
+    for (int64_t i = 0; i < n; ++i) {
+        if (epoch[i] < 0) continue;
+        uint64_t code = 0;
+        uint32_t k[3];
+        for (int a = 0; a < 3; ++a) k[a] = out.key[3 * i + a] += suffix[epoch[i]].shift[a];
+        // depth-first leaf order, children visited 0..7 with child = (xbit<<2)|(ybit<<1)|zbit from the MSB down
+        for (int l = (int)depth - 1; l >= 0; --l) code = (code << 3) | (((k[0] >> l) & 1u) << 2) | (((k[1] >> l) & 1u) << 1) | ((k[2] >> l) & 1u);
+        out.code[i] = code;
+        out.order.push_back((int32_t)i);
+    }
+    std::stable_sort(out.order.begin(), out.order.end(), [&](int32_t a, int32_t b) { return out.code[a] < out.code[b]; });
+    int64_t leaves = 0;
+    for (size_t j = 0; j < out.order.size(); ++j)
+        if (j == 0 || out.code[out.order[j]] != out.code[out.order[j - 1]]) ++leaves;
+    out.info.resolution = resolution;
+    out.info.min_xyz[0] = mn[0], out.info.min_xyz[1] = mn[1], out.info.min_xyz[2] = mn[2];
+    out.info.depth = (int32_t)depth;
+    out.info.num_events = (int32_t)events.size();
+    out.info.num_leaves = leaves;
+    out.info.num_valid = num_valid;
+    return DMSA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gaussians (Gaussians.h:87-202)
+// ------------------------------------------------------------------------------------------------
+struct Gaussians {
+    std::vector<int32_t> segOffset{0};  // connectedPointIds, flattened
+    std::vector<int32_t> members;
+    std::vector<float> info;     // M x 9, column-major Matrix3f
+    std::vector<float> weights;  // rebalancingWeights
+    std::vector<float> obsWeights;
+    int numPointSets = 0;
+    int numLevel1 = 0;
+
+    void reset() {  // Gaussians.h:121-128
+        segOffset.assign(1, 0);
+        members.clear(), info.clear(), weights.clear(), obsWeights.clear();
+        numPointSets = 0;
+    }
+    // Gaussians.h:130-168
+    void addPointSet(const std::vector<int>& ids, const float* xyz4, float observationWeight) {
+        const size_t n = ids.size();
+        float mean[3];
+        for (int c = 0; c < 3; ++c) {
+            double s = 0.0;
+            for (size_t j = 0; j < n; ++j) s += (double)xyz4[4 * (size_t)ids[j] + c];
+            mean[c] = (float)(s / (double)n);
+        }
+        double acc[6] = {0, 0, 0, 0, 0, 0};  // xx xy xz yy yz zz
+        for (size_t j = 0; j < n; ++j) {
+            const float* p = xyz4 + 4 * (size_t)ids[j];
+            const float cx = p[0] - mean[0], cy = p[1] - mean[1], cz = p[2] - mean[2];
+            acc[0] += (double)cx * (double)cx, acc[1] += (double)cx * (double)cy, acc[2] += (double)cx * (double)cz;
+            acc[3] += (double)cy * (double)cy, acc[4] += (double)cy * (double)cz, acc[5] += (double)cz * (double)cz;
+        }
+        const double denom = (double)((long)n - 1);
+        float cov[3][3];
+        cov[0][0] = (float)(acc[0] / denom), cov[0][1] = cov[1][0] = (float)(acc[1] / denom);
+        cov[0][2] = cov[2][0] = (float)(acc[2] / denom), cov[1][1] = (float)(acc[3] / denom);
+        cov[1][2] = cov[2][1] = (float)(acc[4] / denom), cov[2][2] = (float)(acc[5] / denom);
+        limit_covariance(cov);
+        float inv[3][3];
+        inverse3f(cov, inv);
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r) info.push_back(inv[r][c]);
+        obsWeights.push_back(observationWeight);
+        members.insert(members.end(), ids.begin(), ids.end());
+        segOffset.push_back((int32_t)members.size());
+        ++numPointSets;
+    }
+    // Gaussians.h:170-179
+    void updateRebalancingWeights() {
+        weights.resize((size_t)numPointSets);
+        double s = 0.0;
+        for (int k = 0; k < numPointSets; ++k) {
+            const float nk = (float)(segOffset[k + 1] - segOffset[k]);
+            weights[k] = (1.0f / nk) * obsWeights[k];
+            s += (double)weights[k];
+        }
+        const float mean = (float)(s / (double)numPointSets);
+        for (int k = 0; k < numPointSets; ++k) weights[k] = weights[k] / mean;
+    }
+};
+
+// Gaussians.h:27-85 splitSet for PointNormal clouds
+static bool split_set(const float* nrm4, std::vector<int>& ids, std::vector<int>& ids2) {
+    float minDiff = std::numeric_limits<float>::max();
+    int best1 = 0, best2 = 0;
+    for (int id1 : ids) {
+        for (int id2 : ids) {
+            if (id1 == id2) continue;
+            const float* a = nrm4 + 4 * (size_t)id1;
+            const float* b = nrm4 + 4 * (size_t)id2;
+            const float d = normf3(a[0] + b[0], a[1] + b[1], a[2] + b[2]);
+            if (d < minDiff) minDiff = d, best1 = id1, best2 = id2;
+        }
+    }
+    if (minDiff > 0.5f) return false;
+    const float r1[3] = {nrm4[4 * (size_t)best1], nrm4[4 * (size_t)best1 + 1], nrm4[4 * (size_t)best1 + 2]};
+    const float r2[3] = {nrm4[4 * (size_t)best2], nrm4[4 * (size_t)best2 + 1], nrm4[4 * (size_t)best2 + 2]};
+    std::vector<int> s1, s2;
+    for (int id : ids) {
+        const float* v = nrm4 + 4 * (size_t)id;
+        const float d1 = normf3(r1[0] - v[0], r1[1] - v[1], r1[2] - v[2]);
+        const float d2 = normf3(r2[0] - v[0], r2[1] - v[1], r2[2] - v[2]);
+        if (d1 < d2)
+            s1.push_back(id);
+        else
+            s2.push_back(id);
+    }
+    ids = s1, ids2 = s2;
+    return true;
+}
+
+// DmsaOptimizer.h:275-350 createGaussianSets
+static int create_gaussian_sets(Gaussians& g, const float* xyz4, const float* nrm4, const int32_t* ids, int64_t n, float resolution,
+                                int minNumberPts, bool splitEnabled) {
+    VoxelResult vox;
+    const int rc = voxelize(xyz4, n, (double)resolution, vox);
+    if (rc != DMSA_OK) return rc;
+    std::vector<int> indices, indices2;
+    auto diverse = [&](const std::vector<int>& idx) {
+        if (idx.empty()) return false;
+        int mx = std::numeric_limits<int>::min(), mn = std::numeric_limits<int>::max();
+        for (int i : idx) mx = std::max(mx, ids[i]), mn = std::min(mn, ids[i]);
+        return mx != mn;
+    };
+    size_t j = 0;
+    const size_t total = vox.order.size();
+    while (j < total) {
+        size_t e = j + 1;
+        while (e < total && vox.code[vox.order[e]] == vox.code[vox.order[j]]) ++e;
+        indices.assign(vox.order.begin() + j, vox.order.begin() + e);
+        indices2.clear();
+        j = e;
+        if ((int)indices.size() >= minNumberPts && diverse(indices)) {
+            if (splitEnabled && nrm4 != nullptr && split_set(nrm4, indices, indices2)) {
+                // quirks kept: strict '>' and the second diversity test reads `indices`, not `indices2`
+                const bool div1 = diverse(indices);
+                if ((int)indices.size() > minNumberPts && div1) g.addPointSet(indices, xyz4, 1.0f);
+                if ((int)indices2.size() > minNumberPts && div1) g.addPointSet(indices2, xyz4, 1.0f);
+            } else {
+                g.addPointSet(indices, xyz4, 1.0f);
+            }
+        }
+    }
+    return DMSA_OK;
+}
+
+// DmsaOptimizer.h:242-268: point-to-Gaussian rows of updateErrorTerms
+static void eval_residuals(const Gaussians& g, const float* xyz4, double* e) {
+    for (int k = 0; k < g.numPointSets; ++k) {
+        const int32_t b = g.segOffset[k], en = g.segOffset[k + 1];
+        float mean[3] = {0.0f, 0.0f, 0.0f};
+        for (int32_t j = b; j < en; ++j) {
+            const float* p = xyz4 + 4 * (size_t)g.members[j];
+            mean[0] = mean[0] + p[0], mean[1] = mean[1] + p[1], mean[2] = mean[2] + p[2];
+        }
+        const float nf = (float)(en - b);
+        mean[0] = mean[0] / nf, mean[1] = mean[1] / nf, mean[2] = mean[2] / nf;
+        const float* A = &g.info[9 * (size_t)k];  // column-major: A(r,c) = A[3*c + r]
+        const float w = g.weights[k];
+        double acc = 0.0;
+        for (int32_t j = b; j < en; ++j) {
+            const float* p = xyz4 + 4 * (size_t)g.members[j];
+            const float d0 = p[0] - mean[0], d1 = p[1] - mean[1], d2 = p[2] - mean[2];
+            // ((float(w) * d^T) * A) * d, 3-term sums as x0 + (x1 + x2); the float 1x1 result is added to a double
+            const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
+            const float v0 = sum3(wd0 * A[0], wd1 * A[1], wd2 * A[2]);
+            const float v1 = sum3(wd0 * A[3], wd1 * A[4], wd2 * A[5]);
+            const float v2 = sum3(wd0 * A[6], wd1 * A[7], wd2 * A[8]);
+            const float q = sum3(v0 * d0, v1 * d1, v2 * d2);
+            acc += (double)q;
+        }
+        e[k] = std::sqrt(std::fabs(acc));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// OptimizablePointSet (OptimizablePointSet.h:18-56)
+// ------------------------------------------------------------------------------------------------
+struct PointSet {
+    std::vector<float> globalPoints;  // n x 4
+    std::vector<float> globalNormals; // n x 4 (keyframe model only)
+    std::vector<int32_t> ids;
+    float minGridSize = 0.3f;
+    bool hasNormals = false;
+    virtual ~PointSet() {}
+    virtual std::vector<double>& getAdditionalErrorTerms() = 0;
+    virtual void updateGlobalPoints() = 0;
+    virtual int updateAdditionalErrors() = 0;
+    virtual void getPoseParameters(std::vector<double>& p) = 0;
+    virtual void setPoseParameters(const std::vector<double>& p) = 0;
+    virtual void centralize() = 0;
+    virtual void decentralize() = 0;
+    int64_t numPoints() const { return (int64_t)ids.size(); }
+};
+
+// ContinuousTrajectory.h:24-669 (hot methods only)
+struct WindowModel : PointSet {
+    ConsecutivePoses controlPoses;
+    std::vector<double> stamps, trajTime;
+    int n_total = 0;
+    Poses denseGlobalPoses;
+    std::vector<float> denseTforms;  // n_total x 12
+    std::vector<float> local;        // N x 4
+    std::vector<int32_t> tformId;
+    int64_t N = 0, S = 0;
+    bool useImuErrorTerms = false;
+    double dt_res = 0.001, balancingImu = 0.001, gravity[3] = {0, 0, -9.805};
+    std::vector<int32_t> paramIndices;
+    std::vector<double> preintRot, preintPos, preintVel, covInv;
+    std::vector<double> imuFactorError;
+    double origin[3] = {0, 0, 0};
+
+    explicit WindowModel(const dmsa_window_problem& p) {
+        const int C = p.num_control_poses;
+        controlPoses.resize(C);
+        std::copy(p.rel_orient, p.rel_orient + 3 * C, controlPoses.rel.O.begin());
+        std::copy(p.rel_transl, p.rel_transl + 3 * C, controlPoses.rel.T.begin());
+        stamps.assign(p.stamps, p.stamps + C);
+        n_total = p.n_total;
+        trajTime.assign(p.traj_time, p.traj_time + n_total);
+        denseGlobalPoses.resize(n_total);
+        denseTforms.assign((size_t)n_total * 12, 0.0f);
+        N = p.num_points, S = p.num_static;
+        local.assign(p.xyz_local, p.xyz_local + 4 * N);
+        tformId.assign(p.tform_idx, p.tform_idx + N);
+        globalPoints.assign((size_t)(N + S) * 4, 1.0f);
+        ids.resize((size_t)(N + S));
+        std::copy(p.ring_id, p.ring_id + N, ids.begin());
+        for (int64_t k = 0; k < S; ++k) {  // addStaticPoints :158-172
+            for (int c = 0; c < 3; ++c) globalPoints[4 * (size_t)(N + k) + c] = p.xyz_static[4 * k + c];
+            ids[(size_t)(N + k)] = p.ring_id_static[k];
+        }
+        minGridSize = p.min_grid_size;
+        useImuErrorTerms = p.use_imu != 0;
+        if (useImuErrorTerms) {
+            dt_res = p.dt_res, balancingImu = p.balancing_imu;
+            for (int c = 0; c < 3; ++c) gravity[c] = p.gravity[c];
+            paramIndices.assign(p.param_indices, p.param_indices + C);
+            preintRot.assign(p.preint_rot, p.preint_rot + 9 * C);
+            preintPos.assign(p.preint_pos, p.preint_pos + 3 * C);
+            preintVel.assign(p.preint_vel, p.preint_vel + 3 * C);
+            covInv.assign(p.cov_pvrot_inv, p.cov_pvrot_inv + 81 * C);
+            imuFactorError.assign((size_t)(C - 1), 0.0);
+        }
+    }
+    // :75-88
+    void centralize() override {
+        for (int c = 0; c < 3; ++c) origin[c] = controlPoses.rel.T[c], controlPoses.rel.T[c] = 0.0;
+        controlPoses.relative2global();
+        for (int64_t k = N; k < N + S; ++k)
+            for (int c = 0; c < 3; ++c) globalPoints[4 * (size_t)k + c] = globalPoints[4 * (size_t)k + c] - (float)origin[c];
+    }
+    // :89-100
+    void decentralize() override {
+        controlPoses.global2relative();
+        for (int c = 0; c < 3; ++c) controlPoses.rel.T[c] = origin[c];
+        controlPoses.relative2global();
+        for (int64_t k = N; k < N + S; ++k)
+            for (int c = 0; c < 3; ++c) globalPoints[4 * (size_t)k + c] = globalPoints[4 * (size_t)k + c] + (float)origin[c];
+    }
+    std::vector<double>& getAdditionalErrorTerms() override { return imuFactorError; }
+    int updateAdditionalErrors() override {  // :107-117
+        if (useImuErrorTerms) {
+            updateImuError();
+            return (int)imuFactorError.size();
+        }
+        return 0;
+    }
+    void getPoseParameters(std::vector<double>& p) override { controlPoses.rel.getParamsAsVector(p); }
+    void setPoseParameters(const std::vector<double>& p) override { controlPoses.rel.setParamsFromVector(p); }
+    // :570-591
+    void getInterpRotation(double t, double* out) const {
+        const int C = controlPoses.numPoses;
+        const double* beg = stamps.data();
+        const double* it = std::lower_bound(beg, beg + C - 1, t);
+        const long rightIndex = it - beg;
+        if (rightIndex > 0) {
+            const double t_rel = (t - stamps[rightIndex - 1]) / (stamps[rightIndex] - stamps[rightIndex - 1]);
+            slerp(&controlPoses.glob.O[3 * (rightIndex - 1)], &controlPoses.glob.O[3 * rightIndex], t_rel, out);
+        } else {
+            for (int c = 0; c < 3; ++c) out[c] = controlPoses.glob.O[c];
+        }
+    }
+    // :189-226
+    void updateTrajDenseTforms() {
+        controlPoses.relative2global();
+        for (int k = 0; k < n_total; ++k) getInterpRotation(trajTime[k], &denseGlobalPoses.O[3 * (size_t)k]);
+        const int C = controlPoses.numPoses;
+        std::vector<double> tr((size_t)C);
+        for (int a = 0; a < 3; ++a) {
+            for (int k = 0; k < C; ++k) tr[k] = controlPoses.glob.T[3 * k + a];
+            BarycentricRational s(stamps.data(), tr.data(), C, 2);
+            for (int j = 0; j < n_total; ++j) denseGlobalPoses.T[3 * (size_t)j + a] = s(trajTime[j]);
+        }
+        for (int k = 0; k < n_total; ++k) {
+            const M3 R = axang2rotm(&denseGlobalPoses.O[3 * (size_t)k]);
+            float* T = &denseTforms[12 * (size_t)k];
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) T[4 * r + c] = (float)R.m[r][c];
+                T[4 * r + 3] = (float)denseGlobalPoses.T[3 * (size_t)k + r];
+            }
+        }
+    }
+    // :129-156
+    void updateGlobalPoints() override {
+        updateTrajDenseTforms();
+        for (int64_t i = 0; i < N; ++i) tform_point(&denseTforms[12 * (size_t)tformId[i]], &local[4 * (size_t)i], &globalPoints[4 * (size_t)i]);
+    }
+    // :603-663
+    void updateImuError() {
+        controlPoses.global2relative();
+        std::fill(imuFactorError.begin(), imuFactorError.end(), 0.0);
+        const double one_div_t_res = 1.0 / dt_res;
+        const int C = controlPoses.numPoses;
+        const double* DT = denseGlobalPoses.T.data();
+        for (int k = 1; k < C; ++k) {
+            const M3 Rs = axang2rotm(&controlPoses.glob.O[3 * (k - 1)]);
+            const M3 Rst = transpose(Rs);
+            const double delta_t = stamps[k] - stamps[k - 1];
+            double v_start[3], v_end[3], tmp[3], dp_model[3], dv_model[3], rot_err[3];
+            const int i0 = paramIndices[k - 1], i1 = paramIndices[k];
+            for (int c = 0; c < 3; ++c) {
+                v_start[c] = one_div_t_res * (DT[3 * (size_t)(i0 + 1) + c] - DT[3 * (size_t)i0 + c]);
+                v_end[c] = one_div_t_res * (DT[3 * (size_t)i1 + c] - DT[3 * (size_t)(i1 - 1) + c]);
+            }
+            const double half_dt2 = 0.5 * std::pow(delta_t, 2);
+            for (int c = 0; c < 3; ++c)
+                tmp[c] = controlPoses.glob.T[3 * k + c] - controlPoses.glob.T[3 * (k - 1) + c] - v_start[c] * delta_t - half_dt2 * gravity[c];
+            matvec(Rst, tmp, dp_model);
+            const M3 Rend = axang2rotm(&controlPoses.rel.O[3 * k]);
+            M3 P;  // preintImuRots[k], column-major storage
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) P.m[r][c] = preintRot[9 * (size_t)k + 3 * c + r];
+            rotm2axang(mul(transpose(P), Rend), rot_err);
+            for (int c = 0; c < 3; ++c) tmp[c] = v_end[c] - v_start[c] - gravity[c] * delta_t;
+            matvec(Rst, tmp, dv_model);
+            double ce[9];
+            for (int c = 0; c < 3; ++c) {
+                ce[c] = rot_err[c];
+                ce[3 + c] = dv_model[c] - preintVel[3 * (size_t)k + c];
+                ce[6 + c] = dp_model[c] - preintPos[3 * (size_t)k + c];
+            }
+            // combined_error^T * CovPVRot_inv[k] * combined_error
+            const double* Ci = &covInv[81 * (size_t)k];  // column-major 9x9
+            double row[9];
+            for (int j = 0; j < 9; ++j) {
+                double s = 0.0;
+                for (int i = 0; i < 9; ++i) s += ce[i] * Ci[9 * j + i];
+                row[j] = s;
+            }
+            double q = 0.0;
+            for (int j = 0; j < 9; ++j) q += row[j] * ce[j];
+            q *= balancingImu;
+            imuFactorError[(size_t)(k - 1)] = std::sqrt(q);
+        }
+    }
+};
+
+// MapManagement.h:20-390 (hot methods only)
+struct KeyframeModel : PointSet {
+    ConsecutivePoses keyframePoses;
+    int F = 0;
+    std::vector<int64_t> frameOffset;
+    std::vector<float> local, localNormals;
+    std::vector<float> tforms;  // F x 12
+    bool useGravity = false, useOdometry = false;
+    double gravity[3] = {0, 0, -9.805};
+    double covGravInv[9], balancingGrav = 1.0, balancingOdom = 1000.0;
+    std::vector<double> measuredGravity, odomTransl, odomOrientMat;
+    std::vector<int32_t> gravityPlausible;
+    double odomTranslCovInv[9], odomOrientCovInv[9];
+    std::vector<double> gravityErrorTerm, odometryErrorTerm, additionalErrors;
+
+    explicit KeyframeModel(const dmsa_keyframe_problem& p) {
+        F = p.num_frames;
+        keyframePoses.resize(F);
+        std::copy(p.rel_orient, p.rel_orient + 3 * F, keyframePoses.rel.O.begin());
+        std::copy(p.rel_transl, p.rel_transl + 3 * F, keyframePoses.rel.T.begin());
+        keyframePoses.relative2global();
+        frameOffset.assign(p.frame_offset, p.frame_offset + F + 1);
+        const int64_t n = frameOffset[F];
+        local.assign(p.xyz_local, p.xyz_local + 4 * n);
+        localNormals.assign(p.normal_local, p.normal_local + 4 * n);
+        ids.assign(p.ring_id, p.ring_id + n);
+        globalPoints.assign((size_t)n * 4, 1.0f);
+        globalNormals.assign((size_t)n * 4, 0.0f);
+        hasNormals = true;
+        tforms.assign((size_t)F * 12, 0.0f);
+        minGridSize = p.min_grid_size;
+        useGravity = p.use_gravity != 0, useOdometry = p.use_odometry != 0;
+        for (int c = 0; c < 3; ++c) gravity[c] = p.gravity[c];
+        std::copy(p.cov_grav_inv, p.cov_grav_inv + 9, covGravInv);
+        balancingGrav = p.balancing_grav, balancingOdom = p.balancing_odom;
+        if (useGravity) {
+            measuredGravity.assign(p.measured_gravity, p.measured_gravity + 3 * F);
+            gravityPlausible.assign(p.gravity_plausible, p.gravity_plausible + F);
+        }
+        if (useOdometry) {
+            odomTransl.assign(p.odom_rel_transl, p.odom_rel_transl + 3 * F);
+            odomOrientMat.assign(p.odom_rel_orient_mat, p.odom_rel_orient_mat + 9 * F);
+            std::copy(p.odom_transl_cov_inv, p.odom_transl_cov_inv + 9, odomTranslCovInv);
+            std::copy(p.odom_orient_cov_inv, p.odom_orient_cov_inv + 9, odomOrientCovInv);
+        }
+    }
+    void centralize() override {}    // MapManagement.h:73-79 returns immediately
+    void decentralize() override {}  // :80-86
+    // :120-149 (minGridSize is constant here: the per-keyframe gridSize values are folded into min_grid_size)
+    void updateGlobalPoints() override {
+        for (int k = 0; k < F; ++k) {
+            const M3 R = axang2rotm(&keyframePoses.glob.O[3 * k]);
+            float* T = &tforms[12 * (size_t)k];
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) T[4 * r + c] = (float)R.m[r][c];
+                T[4 * r + 3] = (float)keyframePoses.glob.T[3 * k + r];
+            }
+            for (int64_t i = frameOffset[k]; i < frameOffset[k + 1]; ++i) {
+                tform_point(T, &local[4 * (size_t)i], &globalPoints[4 * (size_t)i]);
+                rot_vec(T, &localNormals[4 * (size_t)i], &globalNormals[4 * (size_t)i]);
+            }
+        }
+    }
+    std::vector<double>& getAdditionalErrorTerms() override {  // :151-160
+        if (useGravity && !useOdometry) return gravityErrorTerm;
+        if (!useGravity && useOdometry) return odometryErrorTerm;
+        return additionalErrors;
+    }
+    int updateAdditionalErrors() override {  // :162-190
+        if (!useGravity && !useOdometry) return 0;
+        if (useGravity && !useOdometry) {
+            updateGravityErrors();
+            return (int)gravityErrorTerm.size();
+        }
+        if (!useGravity && useOdometry) {
+            updateOdometryErrors();
+            return (int)odometryErrorTerm.size();
+        }
+        updateGravityErrors();
+        updateOdometryErrors();
+        additionalErrors = gravityErrorTerm;
+        additionalErrors.insert(additionalErrors.end(), odometryErrorTerm.begin(), odometryErrorTerm.end());
+        return (int)additionalErrors.size();
+    }
+    void getPoseParameters(std::vector<double>& p) override { keyframePoses.rel.getParamsAsVector(p); }
+    void setPoseParameters(const std::vector<double>& p) override {  // :197-202
+        keyframePoses.rel.setParamsFromVector(p);
+        keyframePoses.relative2global();
+    }
+    static double quad3(const double* d, const double* Ci /* col-major 3x3 */) {
+        double row[3];
+        for (int j = 0; j < 3; ++j) row[j] = d[0] * Ci[3 * j] + d[1] * Ci[3 * j + 1] + d[2] * Ci[3 * j + 2];
+        return row[0] * d[0] + row[1] * d[1] + row[2] * d[2];
+    }
+    // :210-232
+    void updateGravityErrors() {
+        gravityErrorTerm.assign((size_t)F, 0.0);
+        for (int k = 1; k < F; ++k) {
+            if (!gravityPlausible[k]) continue;
+            double d[3];
+            matvec(axang2rotm(&keyframePoses.glob.O[3 * k]), &measuredGravity[3 * (size_t)k], d);
+            for (int c = 0; c < 3; ++c) d[c] -= gravity[c];
+            double q = quad3(d, covGravInv);
+            q *= balancingGrav;
+            gravityErrorTerm[(size_t)k] = std::sqrt(q);
+        }
+    }
+    // :234-252
+    void updateOdometryErrors() {
+        odometryErrorTerm.assign((size_t)(F - 1), 0.0);
+        for (int k = 1; k < F; ++k) {
+            double td[3], od[3];
+            for (int c = 0; c < 3; ++c) td[c] = odomTransl[3 * (size_t)k + c] - keyframePoses.rel.T[3 * k + c];
+            M3 Rm;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) Rm.m[r][c] = odomOrientMat[9 * (size_t)k + 3 * c + r];
+            rotm2axang(mul(transpose(axang2rotm(&keyframePoses.rel.O[3 * k])), Rm), od);
+            double q = 0.0;
+            q += quad3(td, odomTranslCovInv);
+            q += quad3(od, odomOrientCovInv);
+            q *= balancingOdom;
+            odometryErrorTerm[(size_t)(k - 1)] = std::sqrt(q);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// dense double algebra for the LM step (DmsaOptimizer.h:107-113)
+// ------------------------------------------------------------------------------------------------
+// MatrixXd::inverse() == partial-pivot LU; Gauss-Jordan with partial pivoting on [H | I]
+static bool invert_dense(std::vector<double> A /* col-major PxP */, int P, std::vector<double>& inv) {
+    inv.assign((size_t)P * P, 0.0);
+    for (int i = 0; i < P; ++i) inv[(size_t)i * P + i] = 1.0;
+    auto at = [&](std::vector<double>& M, int r, int c) -> double& { return M[(size_t)c * P + r]; };
+    for (int col = 0; col < P; ++col) {
+        int piv = col;
+        double best = std::fabs(at(A, col, col));
+        for (int r = col + 1; r < P; ++r)
+            if (std::fabs(at(A, r, col)) > best) best = std::fabs(at(A, r, col)), piv = r;
+        if (piv != col)
+            for (int c = 0; c < P; ++c) std::swap(at(A, col, c), at(A, piv, c)), std::swap(at(inv, col, c), at(inv, piv, c));
+        const double d = at(A, col, col);
+        for (int c = 0; c < P; ++c) at(A, col, c) /= d, at(inv, col, c) /= d;
+        for (int r = 0; r < P; ++r) {
+            if (r == col) continue;
+            const double f = at(A, r, col);
+            if (f == 0.0) continue;
+            for (int c = 0; c < P; ++c) at(A, r, c) -= f * at(A, col, c), at(inv, r, c) -= f * at(inv, col, c);
+        }
+    }
+    return true;
+}
+
+static void lm_step(const double* e0, const double* J /* col-major rows x P */, int rows, int P, double lambda, double alpha,
+                    std::vector<double>& H, std::vector<double>& g, std::vector<double>& step) {
+    H.assign((size_t)P * P, 0.0);
+    g.assign((size_t)P, 0.0);
+    for (int i = 0; i < P; ++i) {
+        const double* Ji = J + (size_t)i * rows;
+        for (int j = i; j < P; ++j) {
+            const double* Jj = J + (size_t)j * rows;
+            double s = 0.0;
+            for (int r = 0; r < rows; ++r) s += Ji[r] * Jj[r];
+            H[(size_t)j * P + i] = s, H[(size_t)i * P + j] = s;
+        }
+        double s = 0.0;
+        for (int r = 0; r < rows; ++r) s += Ji[r] * e0[r];
+        g[(size_t)i] = s;
+    }
+    for (int i = 0; i < P; ++i) H[(size_t)i * P + i] += lambda;  // :110
+    std::vector<double> Hinv;
+    invert_dense(H, P, Hinv);
+    // :113  step = -alpha * H^-1 * J^T * e   (evaluated as (-alpha*H^-1) * (J^T e))
+    step.assign((size_t)P, 0.0);
+    for (int i = 0; i < P; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < P; ++j) s += (-alpha * Hinv[(size_t)j * P + i]) * g[(size_t)j];
+        step[(size_t)i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DmsaOptimizer (DmsaOptimizer.h:41-364)
+// ------------------------------------------------------------------------------------------------
+struct Optimizer {
+    Gaussians currentGauss;
+    std::vector<double> Jacobian;  // col-major rows x P
+    int evaluations = 0;
+
+    // :234-273
+    void updateErrorTerms(PointSet& set, std::vector<double>& errorVec) {
+        const int numAdd = set.updateAdditionalErrors();
+        errorVec.resize((size_t)currentGauss.numPointSets + numAdd);
+        eval_residuals(currentGauss, set.globalPoints.data(), errorVec.data());
+        if (numAdd > 0) {
+            const std::vector<double>& add = set.getAdditionalErrorTerms();
+            std::copy(add.begin(), add.begin() + numAdd, errorVec.begin() + currentGauss.numPointSets);
+        }
+        ++evaluations;
+    }
+    static double dot(const std::vector<double>& a) {
+        double s = 0.0;
+        for (double v : a) s += v * v;
+        return s;
+    }
+    // :199-232
+    void calcNumericJacobian(std::vector<double>& error0, PointSet& set) {
+        std::vector<double> origin, loop, errorVec;
+        set.getPoseParameters(origin);
+        const size_t rows = error0.size(), P = origin.size();
+        Jacobian.assign(rows * P, 0.0);
+        const double increment = 1.0 * std::sqrt((double)std::numeric_limits<float>::epsilon());
+        const double one_div_incr = 1.0 / increment;
+        for (size_t k = 0; k < P; ++k) {
+            loop = origin;
+            loop[k] += increment;
+            set.setPoseParameters(loop);
+            set.updateGlobalPoints();
+            updateErrorTerms(set, errorVec);
+            for (size_t r = 0; r < rows; ++r) Jacobian[k * rows + r] = one_div_incr * (errorVec[r] - error0[r]);
+        }
+        set.setPoseParameters(origin);
+    }
+    // :152-182
+    int adaptiveStepSize(PointSet& set, std::vector<double>& params, const std::vector<double>& step, double error0) {
+        double minError = error0;
+        int best = 0;
+        const std::vector<double> raw = params;
+        std::vector<double> errorVec, test(raw.size());
+        for (int k = 1; k < 10; ++k) {
+            for (size_t i = 0; i < raw.size(); ++i) test[i] = raw[i] + 0.1 * (double)k * step[i];
+            set.setPoseParameters(test);
+            set.updateGlobalPoints();
+            updateErrorTerms(set, errorVec);
+            const double errorTest = dot(errorVec);
+            if (errorTest < minError) params = test, minError = errorTest, best = k;
+        }
+        return best;
+    }
+    // :54-150
+    int optimizeSet(PointSet& set, const dmsa_settings& s, dmsa_report* rep, orc_iter_trace* trace, int trace_cap, bool fixed_iters) {
+        std::vector<double> paramVec, errorVec, optimStep;
+        int stop = DMSA_STOP_NUM_ITER, iters = 0;
+        double error0 = 0.0, stepNorm = 0.0;
+        int bestK = 0;
+        if (s.use_centralization) set.centralize();
+        for (int iter = 0; iter < s.num_iter; ++iter) {
+            ++iters;
+            set.getPoseParameters(paramVec);
+            set.updateGlobalPoints();
+            currentGauss.reset();
+            const float* nrm = set.hasNormals ? set.globalNormals.data() : nullptr;
+            if (s.grid_size_1_factor > std::numeric_limits<float>::min()) {
+                const int rc = create_gaussian_sets(currentGauss, set.globalPoints.data(), nrm, set.ids.data(), set.numPoints(),
+                                                    s.grid_size_1_factor * set.minGridSize, s.min_num_points_per_set, s.gauss_split != 0);
+                if (rc != DMSA_OK) return rc;
+            }
+            currentGauss.numLevel1 = currentGauss.numPointSets;
+            if (s.grid_size_2_factor > std::numeric_limits<float>::min()) {
+                const int rc = create_gaussian_sets(currentGauss, set.globalPoints.data(), nrm, set.ids.data(), set.numPoints(),
+                                                    s.grid_size_2_factor * set.minGridSize, s.min_num_points_per_set, s.gauss_split != 0);
+                if (rc != DMSA_OK) return rc;
+            }
+            if (trace && iter < trace_cap) {
+                trace[iter] = orc_iter_trace{};
+                trace[iter].M = currentGauss.numPointSets, trace[iter].M1 = currentGauss.numLevel1;
+                trace[iter].Mm = (int64_t)currentGauss.members.size();
+            }
+            if (currentGauss.numPointSets < s.min_num_gaussians) {
+                stop = DMSA_STOP_FEW_GAUSSIANS;
+                break;
+            }
+            currentGauss.updateRebalancingWeights();
+            updateErrorTerms(set, errorVec);
+            error0 = dot(errorVec);
+            calcNumericJacobian(errorVec, set);
+            const int P = (int)paramVec.size(), rows = (int)errorVec.size();
+            std::vector<double> H, g;
+            lm_step(errorVec.data(), Jacobian.data(), rows, P, (double)s.lambda_diag, s.step_length_optim, H, g, optimStep);
+            bool anyNan = false;
+            for (double v : optimStep) anyNan = anyNan || std::isnan(v);
+            if (anyNan) {
+                set.setPoseParameters(paramVec);
+                stop = DMSA_STOP_NAN;
+                break;
+            }
+            double maxElem = 0.0;
+            {
+                double mx = -std::numeric_limits<double>::infinity(), mn = std::numeric_limits<double>::infinity();
+                for (double v : optimStep) mx = std::max(mx, v), mn = std::min(mn, v);
+                maxElem = std::max(mx, -mn);
+            }
+            if (maxElem > s.max_step)
+                for (double& v : optimStep) v = (s.max_step / maxElem) * v;
+            bestK = adaptiveStepSize(set, paramVec, optimStep, error0);
+            stepNorm = std::sqrt(dot(optimStep));
+            if (trace && iter < trace_cap) trace[iter].error0 = error0, trace[iter].step_norm = stepNorm, trace[iter].best_k = bestK;
+            if (bestK == 0 && !fixed_iters) {
+                stop = DMSA_STOP_NO_IMPROVEMENT;
+                break;
+            }
+            set.setPoseParameters(paramVec);
+            if (stepNorm < s.epsilon && !fixed_iters) {
+                stop = DMSA_STOP_EPSILON;
+                break;
+            }
+        }
+        if (s.use_centralization) set.decentralize();
+        set.updateGlobalPoints();
+        if (rep) {
+            rep->iterations = iters, rep->stop_reason = stop;
+            rep->num_gaussians = currentGauss.numPointSets, rep->num_gaussians_l1 = currentGauss.numLevel1;
+            rep->num_memberships = (int64_t)currentGauss.members.size();
+            rep->error0 = error0, rep->last_step_norm = stepNorm, rep->last_line_search_k = bestK;
+            rep->evaluations = evaluations;
+        }
+        return DMSA_OK;
+    }
+};
+
+}  // namespace
+
+// ====================================================================================================
+// C API
+// ====================================================================================================
+struct orc_gaussians {
+    Gaussians g;
+};
+
+extern "C" {
+
+void orc_axang2rotm(const double* w, double* R9) {
+    const M3 R = axang2rotm(w);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) R9[3 * c + r] = R.m[r][c];
+}
+void orc_rotm2axang(const double* R9, double* w) {
+    M3 R;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) R.m[r][c] = R9[3 * c + r];
+    rotm2axang(R, w);
+}
+void orc_slerp(const double* a, const double* b, double t, double* out) { slerp(a, b, t, out); }
+void orc_relative2global(int n, const double* ro, const double* rt, double* go, double* gt) {
+    ConsecutivePoses cp;
+    cp.resize(n);
+    std::copy(ro, ro + 3 * n, cp.rel.O.begin()), std::copy(rt, rt + 3 * n, cp.rel.T.begin());
+    cp.relative2global();
+    std::copy(cp.glob.O.begin(), cp.glob.O.end(), go), std::copy(cp.glob.T.begin(), cp.glob.T.end(), gt);
+}
+void orc_global2relative(int n, const double* go, const double* gt, double* ro, double* rt) {
+    ConsecutivePoses cp;
+    cp.resize(n);
+    std::copy(go, go + 3 * n, cp.glob.O.begin()), std::copy(gt, gt + 3 * n, cp.glob.T.begin());
+    cp.global2relative();
+    std::copy(cp.rel.O.begin(), cp.rel.O.end(), ro), std::copy(cp.rel.T.begin(), cp.rel.T.end(), rt);
+}
+int orc_barycentric_rational(const double* x, const double* y, int n, int d, const double* t, int nt, double* out) {
+    try {
+        BarycentricRational s(x, y, n, d);
+        for (int i = 0; i < nt; ++i) out[i] = s(t[i]);
+    } catch (const std::logic_error&) {
+        return DMSA_ERR_INVALID;
+    }
+    return DMSA_OK;
+}
+
+int orc_window_pose_table(const dmsa_window_problem* p, float* table, double* dense_transl) {
+    dmsa_window_problem q = *p;
+    q.num_points = 0, q.num_static = 0, q.use_imu = 0;
+    WindowModel m(q);
+    m.updateTrajDenseTforms();
+    std::copy(m.denseTforms.begin(), m.denseTforms.end(), table);
+    if (dense_transl) std::copy(m.denseGlobalPoses.T.begin(), m.denseGlobalPoses.T.end(), dense_transl);
+    return DMSA_OK;
+}
+int orc_keyframe_pose_table(const dmsa_keyframe_problem* p, float* table) {
+    ConsecutivePoses cp;
+    const int F = p->num_frames;
+    cp.resize(F);
+    std::copy(p->rel_orient, p->rel_orient + 3 * F, cp.rel.O.begin());
+    std::copy(p->rel_transl, p->rel_transl + 3 * F, cp.rel.T.begin());
+    cp.relative2global();
+    for (int k = 0; k < F; ++k) {
+        const M3 R = axang2rotm(&cp.glob.O[3 * k]);
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) table[12 * k + 4 * r + c] = (float)R.m[r][c];
+            table[12 * k + 4 * r + 3] = (float)cp.glob.T[3 * k + r];
+        }
+    }
+    return DMSA_OK;
+}
+void orc_transform_points(const float* table, const float* xyz4, const int32_t* row, int64_t n, float* out4) {
+    for (int64_t i = 0; i < n; ++i) {
+        tform_point(table + 12 * (size_t)row[i], xyz4 + 4 * i, out4 + 4 * i);
+        out4[4 * i + 3] = 1.0f;
+    }
+}
+
+int orc_voxelize(const float* xyz4, int64_t n, double resolution, dmsa_voxel_level_info* info, uint64_t* leaf_code, uint32_t* key_xyz,
+                 int32_t* sorted_point_idx) {
+    VoxelResult v;
+    const int rc = voxelize(xyz4, n, resolution, v);
+    if (rc != DMSA_OK) return rc;
+    if (info) *info = v.info;
+    if (leaf_code) std::copy(v.code.begin(), v.code.end(), leaf_code);
+    if (key_xyz) std::copy(v.key.begin(), v.key.end(), key_xyz);
+    if (sorted_point_idx) std::copy(v.order.begin(), v.order.end(), sorted_point_idx);
+    return DMSA_OK;
+}
+
+orc_gaussians* orc_build_gaussians(const float* xyz4, const float* normal4, const int32_t* ids, int64_t n, float min_grid_size,
+                                   const dmsa_settings* s) {
+    auto* h = new orc_gaussians();
+    h->g.reset();
+    // DmsaOptimizer.h:78-96
+    if (s->grid_size_1_factor > std::numeric_limits<float>::min())
+        create_gaussian_sets(h->g, xyz4, normal4, ids, n, s->grid_size_1_factor * min_grid_size, s->min_num_points_per_set, s->gauss_split != 0);
+    h->g.numLevel1 = h->g.numPointSets;
+    if (s->grid_size_2_factor > std::numeric_limits<float>::min())
+        create_gaussian_sets(h->g, xyz4, normal4, ids, n, s->grid_size_2_factor * min_grid_size, s->min_num_points_per_set, s->gauss_split != 0);
+    if (h->g.numPointSets > 0) h->g.updateRebalancingWeights();
+    return h;
+}
+void orc_gaussians_free(orc_gaussians* g) { delete g; }
+int32_t orc_gaussians_count(const orc_gaussians* g) { return g->g.numPointSets; }
+int32_t orc_gaussians_count_level1(const orc_gaussians* g) { return g->g.numLevel1; }
+int64_t orc_gaussians_memberships(const orc_gaussians* g) { return (int64_t)g->g.members.size(); }
+void orc_gaussians_get(const orc_gaussians* g, int32_t* seg_offset, int32_t* member_idx, float* info_mats, float* weights) {
+    if (seg_offset) std::copy(g->g.segOffset.begin(), g->g.segOffset.end(), seg_offset);
+    if (member_idx) std::copy(g->g.members.begin(), g->g.members.end(), member_idx);
+    if (info_mats) std::copy(g->g.info.begin(), g->g.info.end(), info_mats);
+    if (weights) std::copy(g->g.weights.begin(), g->g.weights.end(), weights);
+}
+void orc_gaussians_set_info(orc_gaussians* g, const float* info_mats, const float* weights) {
+    if (info_mats) std::copy(info_mats, info_mats + 9 * (size_t)g->g.numPointSets, g->g.info.begin());
+    if (weights) std::copy(weights, weights + (size_t)g->g.numPointSets, g->g.weights.begin());
+}
+void orc_eval_residuals(const orc_gaussians* g, const float* xyz4_global, double* e_out) { eval_residuals(g->g, xyz4_global, e_out); }
+
+int orc_optimize_window(dmsa_window_problem* p, const dmsa_settings* s, dmsa_report* rep, float* global_out, orc_iter_trace* trace,
+                        int32_t trace_capacity, int32_t fixed_iters) {
+    try {
+        WindowModel m(*p);
+        Optimizer opt;
+        const int rc = opt.optimizeSet(m, *s, rep, trace, trace_capacity, fixed_iters != 0);
+        if (rc != DMSA_OK) return rc;
+        const int C = p->num_control_poses;
+        std::copy(m.controlPoses.rel.O.begin(), m.controlPoses.rel.O.begin() + 3 * C, p->rel_orient);
+        std::copy(m.controlPoses.rel.T.begin(), m.controlPoses.rel.T.begin() + 3 * C, p->rel_transl);
+        if (global_out) std::copy(m.globalPoints.begin(), m.globalPoints.end(), global_out);
+    } catch (const std::exception&) {
+        return DMSA_ERR_INVALID;
+    }
+    return DMSA_OK;
+}
+int orc_optimize_keyframes(dmsa_keyframe_problem* p, const dmsa_settings* s, dmsa_report* rep, float* global_out, orc_iter_trace* trace,
+                           int32_t trace_capacity, int32_t fixed_iters) {
+    try {
+        KeyframeModel m(*p);
+        Optimizer opt;
+        const int rc = opt.optimizeSet(m, *s, rep, trace, trace_capacity, fixed_iters != 0);
+        if (rc != DMSA_OK) return rc;
+        const int F = p->num_frames;
+        std::copy(m.keyframePoses.rel.O.begin(), m.keyframePoses.rel.O.begin() + 3 * F, p->rel_orient);
+        std::copy(m.keyframePoses.rel.T.begin(), m.keyframePoses.rel.T.begin() + 3 * F, p->rel_transl);
+        if (global_out) std::copy(m.globalPoints.begin(), m.globalPoints.end(), global_out);
+    } catch (const std::exception&) {
+        return DMSA_ERR_INVALID;
+    }
+    return DMSA_OK;
+}
+
+int orc_window_additional_errors(const dmsa_window_problem* p, double* rows_out) {
+    dmsa_window_problem q = *p;
+    q.num_points = 0, q.num_static = 0;
+    WindowModel m(q);
+    m.updateTrajDenseTforms();
+    const int n = m.updateAdditionalErrors();
+    if (n > 0) std::copy(m.imuFactorError.begin(), m.imuFactorError.begin() + n, rows_out);
+    return n;
+}
+int orc_keyframe_additional_errors(const dmsa_keyframe_problem* p, double* rows_out) {
+    dmsa_keyframe_problem q = *p;
+    std::vector<int64_t> off((size_t)p->num_frames + 1, 0);
+    q.frame_offset = off.data();
+    KeyframeModel m(q);
+    const int n = m.updateAdditionalErrors();
+    if (n > 0) {
+        const std::vector<double>& a = m.getAdditionalErrorTerms();
+        std::copy(a.begin(), a.begin() + n, rows_out);
+    }
+    return n;
+}
+
+int orc_lm_step(const double* e0, const double* e_batch, int32_t rows, int32_t P, double h, double lambda, double alpha, double* H_out,
+                double* g_out, double* step_out) {
+    std::vector<double> J((size_t)rows * P);
+    const double one_div_incr = 1.0 / h;
+    for (int k = 0; k < P; ++k)
+        for (int r = 0; r < rows; ++r) J[(size_t)k * rows + r] = one_div_incr * (e_batch[(size_t)k * rows + r] - e0[r]);
+    std::vector<double> H, g, step;
+    lm_step(e0, J.data(), rows, P, lambda, alpha, H, g, step);
+    if (H_out) std::copy(H.begin(), H.end(), H_out);
+    if (g_out) std::copy(g.begin(), g.end(), g_out);
+    if (step_out) std::copy(step.begin(), step.end(), step_out);
+    return DMSA_OK;
+}
+
+}  // extern "C"

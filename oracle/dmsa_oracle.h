@@ -1,0 +1,87 @@
+/*
+ * dmsa_oracle.h — C API of the CPU ORACLE.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C++ restatement of the reference's
+ * DMSA inner loop; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  Nothing in dmsa_lidar_slam_amd/ links or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests/golden vectors for this path and its
+ * third-party arithmetic (PCL 1.10 OctreePointCloud, Eigen 3.4, Boost 1.71
+ * barycentric_rational) is not in /root/reference nor in this image, so it cannot be
+ * compiled here.  Those pieces are restated from their published algorithms (see
+ * SURVEY.md Appendix A) and cross-checked against numpy/scipy in tests/.
+ */
+#ifndef DMSA_ORACLE_H
+#define DMSA_ORACLE_H
+
+#include <stdint.h>
+#include "../include/dmsa_hip.h" /* POD problem/settings/report structs only */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- rotation / interpolation helpers (helpers.h:24-65, ConsecutivePoses.h:26-67) ---- */
+void orc_axang2rotm(const double* axang3, double* R9_colmajor);
+void orc_rotm2axang(const double* R9_colmajor, double* axang3);
+void orc_slerp(const double* aa1, const double* aa2, double t, double* out3);
+void orc_relative2global(int n, const double* rel_o, const double* rel_t, double* glob_o, double* glob_t);
+void orc_global2relative(int n, const double* glob_o, const double* glob_t, double* rel_o, double* rel_t);
+/* boost::math::barycentric_rational<double>(x, y, n, d)(t) for nt query points */
+int  orc_barycentric_rational(const double* x, const double* y, int n, int d, const double* t, int nt, double* out);
+
+/* ---- dense pose tables -------------------------------------------------------------- */
+/* updateTrajDenseTforms (ContinuousTrajectory.h:189-226) for the relative poses in p.
+ * table: n_total x 12 floats ([R|t] row-major 3x4); dense_transl (optional): 3 x n_total col-major doubles */
+int orc_window_pose_table(const dmsa_window_problem* p, float* table, double* dense_transl);
+/* per-keyframe transforms of MapManagement::updateGlobalPoints (MapManagement.h:128-138): F x 12 floats */
+int orc_keyframe_pose_table(const dmsa_keyframe_problem* p, float* table);
+/* p_g = T[row] * (x,y,z,1) exactly as Matrix4f*Vector4f evaluates (ContinuousTrajectory.h:151) */
+void orc_transform_points(const float* table, const float* xyz4, const int32_t* row, int64_t n, float* out4);
+
+/* ---- PCL-exact voxelisation (OctreePointCloud; DmsaOptimizer.h:282-298) ---------------- */
+int orc_voxelize(const float* xyz4, int64_t n, double resolution, dmsa_voxel_level_info* info,
+                 uint64_t* leaf_code /* n */, uint32_t* key_xyz /* n x 3 */, int32_t* sorted_point_idx /* n */);
+
+/* ---- Gaussians: reset + createGaussianSets x2 + updateRebalancingWeights --------------- */
+typedef struct orc_gaussians orc_gaussians;
+orc_gaussians* orc_build_gaussians(const float* xyz4, const float* normal4 /* or NULL */, const int32_t* ids, int64_t n,
+                                   float min_grid_size, const dmsa_settings* s);
+void    orc_gaussians_free(orc_gaussians* g);
+int32_t orc_gaussians_count(const orc_gaussians* g);
+int32_t orc_gaussians_count_level1(const orc_gaussians* g);
+int64_t orc_gaussians_memberships(const orc_gaussians* g);
+void    orc_gaussians_get(const orc_gaussians* g, int32_t* seg_offset, int32_t* member_idx, float* info_mats, float* weights);
+/* overwrite information matrices / weights (stage-level parity: feed the HIP path's Gaussians to the oracle) */
+void    orc_gaussians_set_info(orc_gaussians* g, const float* info_mats, const float* weights);
+/* updateErrorTerms rows 0..M-1 (DmsaOptimizer.h:242-268) on the given global points */
+void    orc_eval_residuals(const orc_gaussians* g, const float* xyz4_global, double* e_out);
+
+/* ---- whole optimizeSet ------------------------------------------------------------------- */
+typedef struct orc_iter_trace {
+    int32_t M, M1;
+    int64_t Mm;
+    double  error0;
+    double  step_norm;
+    int32_t best_k;
+    int32_t pad;
+} orc_iter_trace;
+/* global_out (optional): (N+S) x 4 floats after the final updateGlobalPoints; trace (optional): capacity entries.
+ * fixed_iters != 0 disables the no-improvement / epsilon exits (benchmarking, mirrors DMSA_FLAG_FIXED_ITERS). */
+int orc_optimize_window(dmsa_window_problem* p, const dmsa_settings* s, dmsa_report* rep, float* global_out,
+                        orc_iter_trace* trace, int32_t trace_capacity, int32_t fixed_iters);
+int orc_optimize_keyframes(dmsa_keyframe_problem* p, const dmsa_settings* s, dmsa_report* rep, float* global_out,
+                           orc_iter_trace* trace, int32_t trace_capacity, int32_t fixed_iters);
+
+/* additional error rows for given relative poses (updateImuError / Gravity / Odometry); returns row count */
+int orc_window_additional_errors(const dmsa_window_problem* p, double* rows_out);
+int orc_keyframe_additional_errors(const dmsa_keyframe_problem* p, double* rows_out);
+
+/* one numeric-Jacobian + LM step on given residual batches (DmsaOptimizer.h:107-113); for stage parity */
+int orc_lm_step(const double* e0, const double* e_batch /* P x rows */, int32_t rows, int32_t P, double h, double lambda,
+                double alpha, double* H_out /* PxP col-major */, double* g_out, double* step_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,241 @@
+"""ctypes loader for the CPU oracle (oracle/libdmsa_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg — never by the dmsa_lidar_slam_amd package.  See oracle/dmsa_oracle.h for what the oracle is
+(a CPU restatement of the reference's algorithm, parity unpinned by the reference itself).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from dmsa_lidar_slam_amd import _capi as capi
+from dmsa_lidar_slam_amd.problems import ContinuousTrajectory, DmsaOptimSettings, MapManagement
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "libdmsa_oracle.so")
+_lib = None
+
+
+class IterTrace(C.Structure):
+    _fields_ = [("M", C.c_int32), ("M1", C.c_int32), ("Mm", C.c_int64), ("error0", C.c_double), ("step_norm", C.c_double),
+                ("best_k", C.c_int32), ("pad", C.c_int32)]
+
+
+def build() -> None:
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        build()
+    L = C.CDLL(LIB)
+    dp, fp, ip, lp = capi.c_double_p, capi.c_float_p, capi.c_int32_p, capi.c_int64_p
+    vp = C.c_void_p
+    L.orc_axang2rotm.argtypes = [dp, dp]
+    L.orc_rotm2axang.argtypes = [dp, dp]
+    L.orc_slerp.argtypes = [dp, dp, C.c_double, dp]
+    L.orc_relative2global.argtypes = [C.c_int, dp, dp, dp, dp]
+    L.orc_global2relative.argtypes = [C.c_int, dp, dp, dp, dp]
+    L.orc_barycentric_rational.argtypes = [dp, dp, C.c_int, C.c_int, dp, C.c_int, dp]
+    L.orc_window_pose_table.argtypes = [C.POINTER(capi.WindowProblem), fp, dp]
+    L.orc_keyframe_pose_table.argtypes = [C.POINTER(capi.KeyframeProblem), fp]
+    L.orc_transform_points.argtypes = [fp, fp, ip, C.c_int64, fp]
+    L.orc_voxelize.argtypes = [fp, C.c_int64, C.c_double, C.POINTER(capi.VoxelLevelInfo), capi.c_uint64_p, capi.c_uint32_p, ip]
+    L.orc_build_gaussians.argtypes = [fp, fp, ip, C.c_int64, C.c_float, C.POINTER(capi.Settings)]
+    L.orc_build_gaussians.restype = vp
+    L.orc_gaussians_free.argtypes = [vp]
+    L.orc_gaussians_count.argtypes = [vp]
+    L.orc_gaussians_count_level1.argtypes = [vp]
+    L.orc_gaussians_memberships.argtypes = [vp]
+    L.orc_gaussians_memberships.restype = C.c_int64
+    L.orc_gaussians_get.argtypes = [vp, ip, ip, fp, fp]
+    L.orc_gaussians_set_info.argtypes = [vp, fp, fp]
+    L.orc_eval_residuals.argtypes = [vp, fp, dp]
+    L.orc_optimize_window.argtypes = [C.POINTER(capi.WindowProblem), C.POINTER(capi.Settings), C.POINTER(capi.Report), fp,
+                                      C.POINTER(IterTrace), C.c_int32, C.c_int32]
+    L.orc_optimize_keyframes.argtypes = [C.POINTER(capi.KeyframeProblem), C.POINTER(capi.Settings), C.POINTER(capi.Report), fp,
+                                         C.POINTER(IterTrace), C.c_int32, C.c_int32]
+    L.orc_window_additional_errors.argtypes = [C.POINTER(capi.WindowProblem), dp]
+    L.orc_keyframe_additional_errors.argtypes = [C.POINTER(capi.KeyframeProblem), dp]
+    L.orc_lm_step.argtypes = [dp, dp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, dp, dp, dp]
+    _lib = L
+    return L
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def axang2rotm(w):
+    w = _d(w)
+    out = np.zeros(9)
+    lib().orc_axang2rotm(capi.ptr(w, C.c_double), capi.ptr(out, C.c_double))
+    return out.reshape(3, 3).T.copy()
+
+
+def rotm2axang(R):
+    Rc = _d(np.asarray(R).T)
+    out = np.zeros(3)
+    lib().orc_rotm2axang(capi.ptr(Rc, C.c_double), capi.ptr(out, C.c_double))
+    return out
+
+
+def slerp(a, b, t):
+    a, b = _d(a), _d(b)
+    out = np.zeros(3)
+    lib().orc_slerp(capi.ptr(a, C.c_double), capi.ptr(b, C.c_double), float(t), capi.ptr(out, C.c_double))
+    return out
+
+
+def relative2global(ro, rt):
+    ro, rt = _d(ro), _d(rt)
+    go, gt = np.zeros_like(ro), np.zeros_like(rt)
+    lib().orc_relative2global(ro.shape[0], capi.ptr(ro, C.c_double), capi.ptr(rt, C.c_double), capi.ptr(go, C.c_double), capi.ptr(gt, C.c_double))
+    return go, gt
+
+
+def global2relative(go, gt):
+    go, gt = _d(go), _d(gt)
+    ro, rt = np.zeros_like(go), np.zeros_like(gt)
+    lib().orc_global2relative(go.shape[0], capi.ptr(go, C.c_double), capi.ptr(gt, C.c_double), capi.ptr(ro, C.c_double), capi.ptr(rt, C.c_double))
+    return ro, rt
+
+
+def barycentric_rational(x, y, t, d=2):
+    x, y, t = _d(x), _d(y), _d(t)
+    out = np.zeros_like(t)
+    rc = lib().orc_barycentric_rational(capi.ptr(x, C.c_double), capi.ptr(y, C.c_double), len(x), d, capi.ptr(t, C.c_double), len(t), capi.ptr(out, C.c_double))
+    if rc != 0:
+        raise ValueError("coincident nodes")
+    return out
+
+
+def window_pose_table(prob: ContinuousTrajectory):
+    n_t = prob.trajTime.shape[0]
+    table = np.zeros((n_t, 12), np.float32)
+    dense = np.zeros((n_t, 3))
+    cp = prob.to_c()
+    lib().orc_window_pose_table(C.byref(cp), capi.ptr(table, C.c_float), capi.ptr(dense, C.c_double))
+    return table, dense
+
+
+def keyframe_pose_table(prob: MapManagement):
+    table = np.zeros((prob.numFrames, 12), np.float32)
+    cp = prob.to_c()
+    lib().orc_keyframe_pose_table(C.byref(cp), capi.ptr(table, C.c_float))
+    return table
+
+
+def transform_points(table, xyz4, rows):
+    table = np.ascontiguousarray(table, np.float32)
+    xyz4 = np.ascontiguousarray(xyz4, np.float32)
+    rows = np.ascontiguousarray(rows, np.int32)
+    out = np.zeros_like(xyz4)
+    lib().orc_transform_points(capi.ptr(table, C.c_float), capi.ptr(xyz4, C.c_float), capi.ptr(rows, C.c_int32), xyz4.shape[0], capi.ptr(out, C.c_float))
+    return out
+
+
+def voxelize(xyz4, resolution: float):
+    xyz4 = np.ascontiguousarray(xyz4, np.float32)
+    n = xyz4.shape[0]
+    info = capi.VoxelLevelInfo()
+    code = np.zeros(n, np.uint64)
+    key = np.zeros((n, 3), np.uint32)
+    order = np.full(n, -1, np.int32)
+    rc = lib().orc_voxelize(capi.ptr(xyz4, C.c_float), n, float(resolution), C.byref(info), capi.ptr(code, C.c_uint64), capi.ptr(key, C.c_uint32), capi.ptr(order, C.c_int32))
+    if rc != 0:
+        raise RuntimeError(f"orc_voxelize rc={rc}")
+    return info, code, key, order[: info.num_valid]
+
+
+class Gaussians:
+    """Handle on the oracle's Gaussians for stage-level parity tests."""
+
+    def __init__(self, xyz4, ids, min_grid_size: float, settings: DmsaOptimSettings, normals4=None):
+        self._xyz = np.ascontiguousarray(xyz4, np.float32)
+        self._ids = np.ascontiguousarray(ids, np.int32)
+        self._nrm = None if normals4 is None else np.ascontiguousarray(normals4, np.float32)
+        cs = settings.to_c()
+        self._h = lib().orc_build_gaussians(capi.ptr(self._xyz, C.c_float), capi.ptr(self._nrm, C.c_float), capi.ptr(self._ids, C.c_int32),
+                                            self._xyz.shape[0], float(min_grid_size), C.byref(cs))
+        self.M = lib().orc_gaussians_count(self._h)
+        self.M1 = lib().orc_gaussians_count_level1(self._h)
+        self.Mm = lib().orc_gaussians_memberships(self._h)
+        self.seg_offset = np.zeros(self.M + 1, np.int32)
+        self.members = np.zeros(self.Mm, np.int32)
+        self.info = np.zeros((self.M, 9), np.float32)
+        self.weights = np.zeros(self.M, np.float32)
+        lib().orc_gaussians_get(self._h, capi.ptr(self.seg_offset, C.c_int32), capi.ptr(self.members, C.c_int32), capi.ptr(self.info, C.c_float), capi.ptr(self.weights, C.c_float))
+
+    def set_info(self, info, weights):
+        info = np.ascontiguousarray(info, np.float32)
+        weights = np.ascontiguousarray(weights, np.float32)
+        lib().orc_gaussians_set_info(self._h, capi.ptr(info, C.c_float), capi.ptr(weights, C.c_float))
+        self.info, self.weights = info.reshape(self.M, 9), weights
+
+    def residuals(self, xyz4_global):
+        x = np.ascontiguousarray(xyz4_global, np.float32)
+        e = np.zeros(self.M)
+        lib().orc_eval_residuals(self._h, capi.ptr(x, C.c_float), capi.ptr(e, C.c_double))
+        return e
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_gaussians_free(self._h)
+            self._h = None
+
+
+def _run(fn, prob, settings, fixed_iters, want_global, npts):
+    cp = prob.to_c()
+    cs = settings.to_c()
+    rep = capi.Report()
+    trace = (IterTrace * max(1, settings.num_iter))()
+    gl = np.zeros((npts, 4), np.float32) if want_global else None
+    rc = fn(C.byref(cp), C.byref(cs), C.byref(rep), capi.ptr(gl, C.c_float), trace, settings.num_iter, int(fixed_iters))
+    if rc != 0:
+        raise RuntimeError(f"oracle optimize rc={rc}")
+    tr = [dict(M=t.M, M1=t.M1, Mm=t.Mm, error0=t.error0, step_norm=t.step_norm, best_k=t.best_k) for t in trace[: rep.iterations]]
+    return rep, gl, tr
+
+
+def optimize_window(prob: ContinuousTrajectory, settings: DmsaOptimSettings, fixed_iters=False, want_global=False):
+    """Runs optimizeSet on `prob` IN PLACE (relOrientations / relTranslations are updated)."""
+    n = prob.localPoints.shape[0] + prob.staticPoints.shape[0]
+    return _run(lib().orc_optimize_window, prob, settings, fixed_iters, want_global, n)
+
+
+def optimize_keyframes(prob: MapManagement, settings: DmsaOptimSettings, fixed_iters=False, want_global=False):
+    return _run(lib().orc_optimize_keyframes, prob, settings, fixed_iters, want_global, prob.localPoints.shape[0])
+
+
+def window_additional_errors(prob: ContinuousTrajectory):
+    out = np.zeros(max(1, prob.numControlPoses))
+    cp = prob.to_c()
+    n = lib().orc_window_additional_errors(C.byref(cp), capi.ptr(out, C.c_double))
+    return out[:n]
+
+
+def keyframe_additional_errors(prob: MapManagement):
+    out = np.zeros(2 * prob.numFrames + 2)
+    cp = prob.to_c()
+    n = lib().orc_keyframe_additional_errors(C.byref(cp), capi.ptr(out, C.c_double))
+    return out[:n]
+
+
+def lm_step(e0, e_batch, h, lam, alpha):
+    e0 = _d(e0)
+    eb = _d(e_batch)
+    P, rows = eb.shape
+    H = np.zeros((P, P))
+    g = np.zeros(P)
+    step = np.zeros(P)
+    lib().orc_lm_step(capi.ptr(e0, C.c_double), capi.ptr(eb, C.c_double), rows, P, float(h), float(lam), float(alpha),
+                      capi.ptr(H, C.c_double), capi.ptr(g, C.c_double), capi.ptr(step, C.c_double))
+    return H, g, step

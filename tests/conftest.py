@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure).  Built on demand with g++."""
+    from oracle import oracle_py
+
+    oracle_py.lib()
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library through its C ABI.  Fails loudly if the HIP library is missing."""
+    from dmsa_lidar_slam_amd import api
+
+    return api

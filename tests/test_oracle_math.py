@@ -1,0 +1,169 @@
+"""Pin the oracle's third-party restatements against independent numpy/scipy implementations
+(the reference has no tests, so these are the oracle's known-answer checks)."""
+import numpy as np
+import pytest
+from scipy.interpolate import FloaterHormannInterpolator
+from scipy.linalg import expm, logm
+from scipy.spatial.transform import Rotation as Rot
+from scipy.spatial.transform import Slerp
+
+
+def skew(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+@pytest.mark.parametrize("scale", [1e-7, 0.99e-5, 1.01e-5, 2e-5, 1e-3, 0.3, 1.5, 3.0, 3.14])
+def test_axang2rotm_vs_expm(orc, scale):
+    rng = np.random.default_rng(int(scale * 1e7) + 1)
+    for _ in range(20):
+        w = rng.normal(size=3)
+        w = w / np.linalg.norm(w) * scale
+        R = orc.axang2rotm(w)
+        ref = np.eye(3) if np.linalg.norm(w) < 1e-5 else expm(skew(w))  # helpers.h:51-57
+        assert np.abs(R - ref).max() < 1e-14
+
+
+@pytest.mark.parametrize("scale", [1e-9, 1e-6, 1e-3, 0.5, 2.0, 3.0, 3.1415])
+def test_rotm2axang_vs_logm(orc, scale):
+    rng = np.random.default_rng(int(scale * 1e6) + 7)
+    for _ in range(20):
+        w = rng.normal(size=3)
+        w = w / np.linalg.norm(w) * scale
+        R = Rot.from_rotvec(w).as_matrix()
+        got = orc.rotm2axang(R)
+        assert np.abs(got - w).max() < 1e-9 * max(1.0, 1.0 / max(np.pi - scale, 1e-3))
+        if 1e-3 <= scale <= 3.0:
+            S = np.real(logm(R))  # helpers.h:59-65 reads (2,1), (0,2), (1,0)
+            assert np.abs(got - np.array([S[2, 1], S[0, 2], S[1, 0]])).max() < 1e-9
+
+
+def test_rotm2axang_roundtrip_identity(orc):
+    assert np.all(orc.rotm2axang(np.eye(3)) == 0.0)
+    w = np.array([0.3, -0.2, 0.9])
+    assert np.abs(orc.rotm2axang(orc.axang2rotm(w)) - w).max() < 1e-14
+
+
+def test_slerp_vs_scipy(orc):
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        a, b = rng.normal(size=3) * 0.8, rng.normal(size=3) * 0.8
+        t = rng.uniform()
+        s = Slerp([0.0, 1.0], Rot.from_rotvec(np.stack([a, b])))
+        ref = s([t]).as_rotvec()[0]
+        got = orc.slerp(a, b, t)
+        # compare as rotations (axis-angle of the same rotation may differ by sign conventions near pi)
+        d = (Rot.from_rotvec(got).inv() * Rot.from_rotvec(ref)).magnitude()
+        assert d < 1e-12
+
+
+def test_slerp_endpoints_and_zero(orc):
+    a, b = np.array([0.1, 0.2, -0.3]), np.array([-0.4, 0.1, 0.2])
+    assert np.abs(orc.slerp(a, b, 0.0) - a).max() < 1e-15
+    assert np.abs(orc.slerp(a, b, 1.0) - b).max() < 1e-15
+    z = np.zeros(3)
+    assert np.all(orc.slerp(z, z, 0.3) == 0.0)  # zero rotation: AngleAxis(q) falls in the n == 0 branch
+    assert np.abs(orc.slerp(z, b, 0.5) - 0.5 * b).max() < 1e-15
+
+
+@pytest.mark.parametrize("n", [3, 4, 6, 9])
+def test_barycentric_rational_vs_scipy(orc, n):
+    rng = np.random.default_rng(n)
+    x = np.sort(rng.uniform(0, 1, n))
+    x[0], x[-1] = 0.0, 1.0
+    y = rng.normal(size=n)
+    t = np.concatenate([rng.uniform(0, 1, 200), x])  # includes the exact-node short-circuit
+    ref = FloaterHormannInterpolator(x, y, d=2)(t)
+    got = orc.barycentric_rational(x, y, t, d=2)
+    assert np.abs(got - ref).max() < 1e-12
+    assert np.all(got[-n:] == y)
+
+
+def test_barycentric_reproduces_quadratics(orc):
+    x = np.linspace(0, 1.001, 6)
+    f = lambda s: 0.3 - 1.7 * s + 2.2 * s * s  # noqa: E731
+    t = np.linspace(0, 1.001, 1002)
+    assert np.abs(orc.barycentric_rational(x, f(x), t) - f(t)).max() < 1e-13
+
+
+def test_barycentric_coincident_nodes_rejected(orc):
+    with pytest.raises(ValueError):
+        orc.barycentric_rational(np.array([0.0, 0.5, 0.5, 1.0]), np.zeros(4), np.array([0.1]))
+
+
+def test_relative_global_roundtrip_and_chain(orc):
+    rng = np.random.default_rng(11)
+    n = 7
+    ro, rt = rng.normal(size=(n, 3)) * 0.3, rng.normal(size=(n, 3))
+    go, gt = orc.relative2global(ro, rt)
+    # independent chain (ConsecutivePoses.h:26-43)
+    R, T = np.eye(3), np.zeros(3)
+    for k in range(n):
+        T = T + R @ rt[k]
+        R = R @ Rot.from_rotvec(ro[k]).as_matrix()
+        assert np.abs(gt[k] - T).max() < 1e-13
+        assert (Rot.from_rotvec(go[k]).inv() * Rot.from_matrix(R)).magnitude() < 1e-13
+    ro2, rt2 = orc.global2relative(go, gt)
+    assert np.abs(ro2 - ro).max() < 1e-12 and np.abs(rt2 - rt).max() < 1e-12
+    # perturbing relative pose k leaves frames < k bit-identical
+    ro3 = ro.copy()
+    ro3[4, 1] += 1e-3
+    go3, gt3 = orc.relative2global(ro3, rt)
+    assert np.array_equal(go3[:4], go[:4]) and np.array_equal(gt3[:5], gt[:5])
+
+
+def test_window_pose_table_structure(orc):
+    from dmsa_lidar_slam_amd import synth
+
+    p = synth.window_problem(seed=5, scans=2, rings=8, az_steps=32, num_static=0)
+    table, dense = orc.window_pose_table(p)
+    n_t = p.trajTime.shape[0]
+    assert table.shape == (n_t, 12)
+    go, gt = orc.relative2global(p.relOrientations, p.relTranslations)
+    # translations: Floater-Hormann through the control translations, one interpolant per axis
+    for a in range(3):
+        ref = FloaterHormannInterpolator(p.stamps, gt[:, a], d=2)(p.trajTime)
+        assert np.abs(dense[:, a] - ref).max() < 1e-11
+    T = table.reshape(n_t, 3, 4)
+    assert np.array_equal(T[:, :, 3], dense.astype(np.float32))
+    # rotations: slerp between bracketing control poses; first entry == control pose 0 (q10)
+    assert np.abs(T[0, :, :3] - Rot.from_rotvec(go[0]).as_matrix()).max() < 1e-6
+    assert np.abs(T[-1, :, :3] - Rot.from_rotvec(go[-1]).as_matrix()).max() < 1e-6
+    for k in (1, n_t // 3, n_t // 2, n_t - 2):
+        t = p.trajTime[k]
+        ri = int(np.searchsorted(p.stamps[:-1], t, side="left"))  # lower_bound excluding the last stamp
+        t_rel = (t - p.stamps[ri - 1]) / (p.stamps[ri] - p.stamps[ri - 1])
+        ref = Slerp([0, 1], Rot.from_rotvec(go[ri - 1:ri + 1]))([t_rel]).as_matrix()[0]
+        assert np.abs(T[k, :, :3] - ref).max() < 1e-6
+    R = T[:, :, :3].astype(np.float64)
+    assert np.abs(R @ np.transpose(R, (0, 2, 1)) - np.eye(3)).max() < 1e-6
+
+
+def test_transform_points_float_order(orc):
+    rng = np.random.default_rng(2)
+    table = rng.normal(size=(5, 12)).astype(np.float32)
+    xyz = rng.normal(size=(100, 4)).astype(np.float32) * 10
+    xyz[:, 3] = 1.0
+    rows = rng.integers(0, 5, 100).astype(np.int32)
+    got = orc.transform_points(table, xyz, rows)
+    T = table.reshape(5, 3, 4)[rows]
+    f = np.float32
+    ref = ((T[:, :, 0] * xyz[:, 0:1]).astype(f) + (T[:, :, 1] * xyz[:, 1:2]).astype(f)).astype(f)
+    ref = (ref + (T[:, :, 2] * xyz[:, 2:3]).astype(f)).astype(f)
+    ref = (ref + T[:, :, 3]).astype(f)
+    assert np.array_equal(got[:, :3], ref)
+
+
+def test_lm_step_vs_numpy(orc):
+    rng = np.random.default_rng(4)
+    rows, P = 500, 12
+    e0 = rng.uniform(0.5, 2.0, rows)
+    eb = e0[None, :] + rng.normal(size=(P, rows)) * 1e-4
+    h = float(np.sqrt(np.finfo(np.float32).eps))
+    lam = float(np.float32(1e-5))
+    H, g, step = orc.lm_step(e0, eb, h, lam, 0.2)
+    J = ((eb - e0[None, :]) / h).T
+    Href = J.T @ J + lam * np.eye(P)
+    assert np.abs(H - Href).max() / np.abs(Href).max() < 1e-13
+    assert np.abs(g - J.T @ e0).max() / np.abs(g).max() < 1e-13
+    ref = -0.2 * np.linalg.solve(Href, J.T @ e0)
+    assert np.abs(step - ref).max() / np.abs(ref).max() < 1e-8
