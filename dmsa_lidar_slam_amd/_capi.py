@@ -1,7 +1,7 @@
 """ctypes mirror of include/dmsa_hip.h (the C ABI of libdmsa_hip.so).
 
 The structures here are byte-for-byte the PODs declared in the header; the same
-classes are reused by the test-only oracle loader (oracle/oracle_py.py) because the
+classes are reused by the test-only loader of the CPU checker (under oracle/) because the
 oracle's C API takes the same problem descriptors.
 """
 from __future__ import annotations

@@ -1,0 +1,182 @@
+"""Python face of the C ABI (include/dmsa_hip.h) — mirrors the reference's optimizer interface.
+
+    DmsaOptimizer().optimizeSet(pointSet, settings)      == DmsaOptimizer<PointT>::optimizeSet (DmsaOptimizer.h:54)
+
+`pointSet` is a problems.ContinuousTrajectory (sliding window) or problems.MapManagement (keyframe set); its
+relative poses are updated in place, exactly like the reference mutates the OptimizablePointSet it is given.
+All compute happens in libdmsa_hip.so on the GPU; there is no CPU fallback (a missing library or device raises).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from .problems import ContinuousTrajectory, DmsaOptimSettings, MapManagement
+
+
+class DmsaError(RuntimeError):
+    pass
+
+
+class DmsaOptimizer:
+    """One context == one GPU == one host thread (the reference's optimizer is not re-entrant either)."""
+
+    def __init__(self, device: int = 0, pose_table_host: bool = False, fixed_iters: bool = False):
+        self._lib = capi.load_library()
+        self._ctx = C.c_void_p()
+        flags = (capi.FLAG_POSE_TABLE_HOST if pose_table_host else 0) | (capi.FLAG_FIXED_ITERS if fixed_iters else 0)
+        rc = self._lib.dmsa_create(int(device), flags, C.byref(self._ctx))
+        if rc != capi.DMSA_OK:
+            self._ctx = None
+            raise DmsaError(f"dmsa_create(device={device}) failed with {rc} (no usable HIP device; there is no CPU fallback)")
+        self._problem = None
+        self._cprob = None
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.dmsa_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != capi.DMSA_OK:
+            msg = self._lib.dmsa_last_error(self._ctx)
+            raise DmsaError(f"{what} failed with {rc}: {msg.decode() if msg else ''}")
+
+    # -- the drop-in call ---------------------------------------------------------------------------
+    def optimizeSet(self, pointSetToOptimize, settings: DmsaOptimSettings | None = None) -> capi.Report:
+        settings = settings or DmsaOptimSettings()
+        cs = settings.to_c()
+        rep = capi.Report()
+        cp = pointSetToOptimize.to_c()
+        if isinstance(pointSetToOptimize, ContinuousTrajectory):
+            rc = self._lib.dmsa_optimize_window(self._ctx, C.byref(cp), C.byref(cs), C.byref(rep))
+        elif isinstance(pointSetToOptimize, MapManagement):
+            rc = self._lib.dmsa_optimize_keyframes(self._ctx, C.byref(cp), C.byref(cs), C.byref(rep))
+        else:
+            raise TypeError("pointSetToOptimize must be a ContinuousTrajectory or a MapManagement")
+        self._check(rc, "optimizeSet")
+        self._problem, self._cprob = pointSetToOptimize, cp
+        return rep
+
+    def globalPoints(self) -> np.ndarray:
+        n = self._num_points()
+        out = np.zeros((n, 4), np.float32)
+        self._check(self._lib.dmsa_get_global_points(self._ctx, capi.ptr(out, C.c_float), n), "get_global_points")
+        return out
+
+    # -- stage-level calls (parity tests, benchmark) ---------------------------------------------------
+    def upload(self, pointSet):
+        cp = pointSet.to_c()
+        if isinstance(pointSet, ContinuousTrajectory):
+            rc = self._lib.dmsa_window_upload(self._ctx, C.byref(cp))
+        else:
+            rc = self._lib.dmsa_keyframes_upload(self._ctx, C.byref(cp))
+        self._check(rc, "upload")
+        self._problem, self._cprob = pointSet, cp
+
+    def _num_points(self) -> int:
+        p = self._problem
+        if isinstance(p, ContinuousTrajectory):
+            return p.localPoints.shape[0] + p.staticPoints.shape[0]
+        return p.localPoints.shape[0]
+
+    def centralize(self):
+        self._check(self._lib.dmsa_centralize(self._ctx), "centralize")
+
+    def decentralize(self):
+        self._check(self._lib.dmsa_decentralize(self._ctx), "decentralize")
+
+    def getPoseParameters(self) -> np.ndarray:
+        P = C.c_int32()
+        self._check(self._lib.dmsa_get_params(self._ctx, None, C.byref(P)), "get_params")
+        out = np.zeros(P.value)
+        self._check(self._lib.dmsa_get_params(self._ctx, capi.ptr(out, C.c_double), C.byref(P)), "get_params")
+        return out
+
+    def setPoseParameters(self, params):
+        params = np.ascontiguousarray(params, np.float64)
+        self._check(self._lib.dmsa_set_params(self._ctx, capi.ptr(params, C.c_double)), "set_params")
+
+    def numTableRows(self) -> int:
+        r = C.c_int32()
+        self._check(self._lib.dmsa_num_table_rows(self._ctx, C.byref(r)), "num_table_rows")
+        return r.value
+
+    def poseTables(self, params, download: bool = True):
+        params = np.ascontiguousarray(np.atleast_2d(params), np.float64)
+        B = params.shape[0]
+        out = np.zeros((B, self.numTableRows(), 12), np.float32) if download else None
+        self._check(self._lib.dmsa_pose_tables(self._ctx, B, capi.ptr(params, C.c_double), capi.ptr(out, C.c_float)), "pose_tables")
+        return out
+
+    def setPoseTables(self, tables):
+        tables = np.ascontiguousarray(tables, np.float32)
+        if tables.ndim == 2:
+            tables = tables[None]
+        self._check(self._lib.dmsa_set_pose_tables(self._ctx, tables.shape[0], capi.ptr(tables, C.c_float)), "set_pose_tables")
+
+    def updateGlobalPoints(self, b: int = 0, download: bool = True):
+        out = np.zeros((self._num_points(), 4), np.float32) if download else None
+        self._check(self._lib.dmsa_transform_points(self._ctx, int(b), capi.ptr(out, C.c_float)), "transform_points")
+        return out
+
+    def buildGaussians(self, settings: DmsaOptimSettings):
+        cs = settings.to_c()
+        M, Mm = C.c_int32(), C.c_int64()
+        self._check(self._lib.dmsa_build_gaussians(self._ctx, C.byref(cs), C.byref(M), C.byref(Mm)), "build_gaussians")
+        self._M, self._Mm = M.value, Mm.value
+        return M.value, Mm.value
+
+    def voxelLevel(self, level: int):
+        n = self._num_points()
+        info = capi.VoxelLevelInfo()
+        code = np.zeros(n, np.uint64)
+        key = np.zeros((n, 3), np.uint32)
+        order = np.full(n, -1, np.int32)
+        self._check(self._lib.dmsa_get_voxel_level(self._ctx, int(level), C.byref(info), capi.ptr(code, C.c_uint64), capi.ptr(key, C.c_uint32),
+                                                   capi.ptr(order, C.c_int32)), "get_voxel_level")
+        return info, code, key, order[: info.num_valid]
+
+    def gaussians(self):
+        M, Mm = self._M, self._Mm
+        seg = np.zeros(M + 1, np.int32)
+        memb = np.zeros(Mm, np.int32)
+        info = np.zeros((M, 9), np.float32)
+        w = np.zeros(M, np.float32)
+        self._check(self._lib.dmsa_get_gaussians(self._ctx, capi.ptr(seg, C.c_int32), capi.ptr(memb, C.c_int32), capi.ptr(info, C.c_float),
+                                                 capi.ptr(w, C.c_float)), "get_gaussians")
+        return seg, memb, info, w
+
+    def evalResiduals(self, B: int, download: bool = True):
+        out = np.zeros((B, self._M)) if download else None
+        self._check(self._lib.dmsa_eval_residuals(self._ctx, capi.ptr(out, C.c_double)), "eval_residuals")
+        return out
+
+    def normalEquations(self, P: int, h: float, lam: float, extra_rows=None):
+        H = np.zeros((P, P))
+        g = np.zeros(P)
+        a = 0
+        er = None
+        if extra_rows is not None and np.size(extra_rows) > 0:
+            er = np.ascontiguousarray(extra_rows, np.float64)
+            a = er.shape[1]
+        self._check(self._lib.dmsa_normal_equations(self._ctx, P, a, capi.ptr(er, C.c_double), float(h), float(lam), capi.ptr(H, C.c_double),
+                                                    capi.ptr(g, C.c_double)), "normal_equations")
+        return H, g  # H is symmetric, so col-major == row-major
+
+    def timing(self, reset: bool = False) -> capi.Timing:
+        t = capi.Timing()
+        self._check(self._lib.dmsa_get_timing(self._ctx, C.byref(t), int(reset)), "get_timing")
+        return t
+
+    def synchronize(self):
+        self._check(self._lib.dmsa_synchronize(self._ctx), "synchronize")

@@ -1,0 +1,903 @@
+// dmsa_api.cpp — the C ABI of libdmsa_hip.so (include/dmsa_hip.h) and the host-side optimizeSet loop.
+//
+// Host/device split: the control flow of DmsaOptimizer::optimizeSet (DmsaOptimizer.h:54-150),
+// the control-pose chain, parameter vectors, additional error rows and the P x P solve run here in double;
+// every O(#points) stage is a HIP kernel on device-resident data (dmsa_kernels.hip).  Per iteration only pose
+// tables / control poses go to the device and (P+1)^2 + 9 doubles plus a few counters come back.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/dmsa_hip.h"
+#include "device_prims.h"
+#include "dmsa_kernels.h"
+#include "host_math.h"
+
+using namespace dmsa;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr, cap = 0;
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr, cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum Model { MODEL_NONE = 0, MODEL_WINDOW = 1, MODEL_KEYFRAMES = 2 };
+
+enum TimerSlot { T_RESIDUAL = 0, T_VOXEL, T_FIT, T_TABLE, T_NORMAL, T_TOTAL, T_COUNT };
+
+struct EventPair {
+    hipEvent_t a, b;
+    int slot;
+};
+
+}  // namespace
+
+struct dmsa_ctx {
+    int device = 0;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    Model model = MODEL_NONE;
+    int64_t n = 0, N = 0, S = 0;  // total points, moving points, static points
+    int rows = 0;                 // pose-table rows incl. the identity row (n_total+1 or F+1)
+    WindowHost win;
+    KeyframeHost key;
+    bool centralized = false;
+    float min_grid_size = 0.3f;
+
+    // device-resident problem
+    DevBuf d_local, d_nlocal, d_ring, d_global, d_nglobal;
+    // pose tables of the current batch
+    DevBuf d_tables, d_ctrl, d_stamps, d_fhw, d_trajtime;
+    int batch = 0;
+    std::vector<double> h_ctrl;
+    std::vector<float> h_tables;
+    // voxelisation
+    DevBuf d_aabb, d_lattice, d_code[2], d_idx[2], d_code_s[2], d_idx_s[2], d_head, d_leaf_incl[2], d_leaf_start[2], d_slot_acc, d_slot_cnt,
+        d_gauss_of_slot, d_memb_of_slot, d_pos_slot_rank, d_sort_tmp, d_scan_tmp, d_counts;
+    LatticeTable h_lattice[2];
+    double level_res[2] = {0, 0};
+    // Gaussians
+    DevBuf d_memb_local, d_memb_idx, d_seg_off, d_info12, d_wg_seg;
+    int M = 0, M1 = 0;
+    int64_t Mm = 0;
+    int num_wg = 0;
+    bool gaussians_valid = false;
+    // residual batches
+    DevBuf d_E, d_ne_partial, d_Hp, d_sq_partial, d_sq_out;
+    int64_t ldE = 0;
+    int extra_rows = 0;
+    // timing
+    std::vector<EventPair> pending;
+    std::vector<hipEvent_t> free_events;
+    double t_ms[T_COUNT] = {0, 0, 0, 0, 0, 0};
+    int64_t residual_launches = 0, residual_evals = 0;
+    int evaluations = 0;
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) {                                                                               \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(_e);                                     \
+            return DMSA_ERR_HIP;                                                                              \
+        }                                                                                                     \
+    } while (0)
+
+#define CHK(expr)                  \
+    do {                           \
+        int _rc = (expr);          \
+        if (_rc != DMSA_OK) return _rc; \
+    } while (0)
+
+hipEvent_t get_event(dmsa_ctx* ctx) {
+    if (!ctx->free_events.empty()) {
+        hipEvent_t e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ScopedTimer {
+    dmsa_ctx* ctx;
+    EventPair ev;
+    ScopedTimer(dmsa_ctx* c, int slot) : ctx(c) {
+        ev.a = get_event(c), ev.b = get_event(c), ev.slot = slot;
+        (void)hipEventRecord(ev.a, c->stream);
+    }
+    ~ScopedTimer() {
+        (void)hipEventRecord(ev.b, ctx->stream);
+        ctx->pending.push_back(ev);
+    }
+};
+// fold finished event pairs into the accumulators (call after a stream synchronisation)
+void drain_timers(dmsa_ctx* ctx) {
+    for (auto& ev : ctx->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) ctx->t_ms[ev.slot] += (double)ms;
+        ctx->free_events.push_back(ev.a), ctx->free_events.push_back(ev.b);
+    }
+    ctx->pending.clear();
+}
+
+int set_device(dmsa_ctx* ctx) {
+    HIPCHK(hipSetDevice(ctx->device));
+    return DMSA_OK;
+}
+
+int num_params(const dmsa_ctx* ctx) { return ctx->model == MODEL_WINDOW ? ctx->win.ctrl.num_params() : ctx->key.frames.num_params(); }
+PoseChain& chain(dmsa_ctx* ctx) { return ctx->model == MODEL_WINDOW ? ctx->win.ctrl : ctx->key.frames; }
+int num_extra_rows(const dmsa_ctx* ctx) { return ctx->model == MODEL_WINDOW ? ctx->win.num_extra_rows() : ctx->key.num_extra_rows(); }
+
+// allocate everything whose size depends only on the point count
+int alloc_point_buffers(dmsa_ctx* ctx) {
+    const size_t n = (size_t)ctx->n;
+    HIPCHK(ctx->d_global.ensure(n * 16));
+    const size_t nb = (n + kAabbBlock - 1) / kAabbBlock;
+    HIPCHK(ctx->d_aabb.ensure(nb * 8 * sizeof(float)));
+    HIPCHK(ctx->d_lattice.ensure(2 * sizeof(LatticeTable)));
+    for (int l = 0; l < 2; ++l) {
+        HIPCHK(ctx->d_code[l].ensure(n * 8));
+        HIPCHK(ctx->d_idx[l].ensure(n * 4));
+        HIPCHK(ctx->d_code_s[l].ensure(n * 8));
+        HIPCHK(ctx->d_idx_s[l].ensure(n * 4));
+        HIPCHK(ctx->d_leaf_incl[l].ensure(n * 4));
+        HIPCHK(ctx->d_leaf_start[l].ensure((n + 1) * 4));
+    }
+    HIPCHK(ctx->d_head.ensure(n * 4));
+    HIPCHK(ctx->d_slot_acc.ensure(2 * n * 4));
+    HIPCHK(ctx->d_slot_cnt.ensure(2 * n * 4));
+    HIPCHK(ctx->d_gauss_of_slot.ensure(2 * n * 4));
+    HIPCHK(ctx->d_memb_of_slot.ensure(2 * n * 4));
+    HIPCHK(ctx->d_sort_tmp.ensure(sort_pairs_temp_bytes(n)));
+    HIPCHK(ctx->d_scan_tmp.ensure(scan_temp_bytes(2 * n)));
+    HIPCHK(ctx->d_counts.ensure(sizeof(GaussCounts)));
+    // memberships: every point belongs to at most one set per resolution
+    HIPCHK(ctx->d_memb_local.ensure(2 * n * 16));
+    HIPCHK(ctx->d_memb_idx.ensure(2 * n * 4));
+    HIPCHK(ctx->d_seg_off.ensure((2 * n + 2) * 4));
+    HIPCHK(ctx->d_info12.ensure((2 * n / 2 + 16) * 48));  // sets have >= 2 members (two distinct ids)
+    HIPCHK(ctx->d_wg_seg.ensure(4096 * 4));
+    return DMSA_OK;
+}
+
+// ---- pose tables ------------------------------------------------------------------------------------------
+// `globs`: B x (C or F) x 6 doubles (axis-angle | translation) of the GLOBAL poses of every evaluation in the batch.
+int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs) {
+    ScopedTimer tm(ctx, T_TABLE);
+    const int rows = ctx->rows;
+    HIPCHK(ctx->d_tables.ensure((size_t)B * rows * 48));
+    const int np = ctx->model == MODEL_WINDOW ? ctx->win.ctrl.n : ctx->key.frames.n;
+    if (ctx->flags & DMSA_FLAG_POSE_TABLE_HOST) {
+        ctx->h_tables.resize((size_t)B * rows * 12);
+        PoseChain tmp;
+        tmp.resize(np);
+        for (int b = 0; b < B; ++b) {
+            for (int k = 0; k < np; ++k)
+                for (int c = 0; c < 3; ++c) {
+                    tmp.glob_o[3 * k + c] = globs[((size_t)b * np + k) * 6 + c];
+                    tmp.glob_t[3 * k + c] = globs[((size_t)b * np + k) * 6 + 3 + c];
+                }
+            float* T = &ctx->h_tables[(size_t)b * rows * 12];
+            if (ctx->model == MODEL_WINDOW)
+                window_dense_table(tmp, ctx->win.stamps, ctx->win.fh, ctx->win.traj_time, T);
+            else
+                keyframe_table(tmp, T);
+            float* id = T + (size_t)(rows - 1) * 12;  // identity row used by static points
+            const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+            std::memcpy(id, I, sizeof(I));
+        }
+        HIPCHK(hipMemcpyAsync(ctx->d_tables.p, ctx->h_tables.data(), ctx->h_tables.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // h_tables is reused by the next batch
+    } else {
+        HIPCHK(ctx->d_ctrl.ensure(globs.size() * 8));
+        HIPCHK(hipMemcpyAsync(ctx->d_ctrl.p, globs.data(), globs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // `globs` is caller-owned host memory
+        if (ctx->model == MODEL_WINDOW)
+            launch_window_pose_tables(ctx->d_ctrl.as<double>(), ctx->d_stamps.as<double>(), ctx->d_fhw.as<double>(), ctx->d_trajtime.as<double>(), B,
+                                      np, rows - 1, ctx->d_tables.as<float>(), ctx->stream);
+        else
+            launch_keyframe_pose_tables(ctx->d_ctrl.as<double>(), B, np, ctx->d_tables.as<float>(), ctx->stream);
+    }
+    ctx->batch = B;
+    return DMSA_OK;
+}
+
+void append_glob(const PoseChain& c, std::vector<double>& out) {
+    for (int k = 0; k < c.n; ++k) {
+        for (int a = 0; a < 3; ++a) out.push_back(c.glob_o[3 * k + a]);
+        for (int a = 0; a < 3; ++a) out.push_back(c.glob_t[3 * k + a]);
+    }
+}
+
+// one forward evaluation's host part for the CURRENT chain state: record global poses, compute additional rows
+void host_eval(dmsa_ctx* ctx, std::vector<double>& globs, std::vector<double>& extra) {
+    append_glob(chain(ctx), globs);
+    const int a = num_extra_rows(ctx);
+    if (a > 0) {
+        const size_t at = extra.size();
+        extra.resize(at + a);
+        if (ctx->model == MODEL_WINDOW)
+            ctx->win.imu_rows(&extra[at]);  // runs global_to_relative like updateImuError
+        else
+            ctx->key.additional_rows(&extra[at]);
+    }
+    ctx->evaluations += 1;
+}
+// setPoseParameters + the chain update of updateGlobalPoints for both models
+void host_set_params(dmsa_ctx* ctx, const double* p) {
+    chain(ctx).set_params(p);
+    chain(ctx).relative_to_global();
+}
+
+int transform_points(dmsa_ctx* ctx, int b) {
+    const float4* table = ctx->d_tables.as<float4>() + (size_t)b * ctx->rows * 3;
+    if (ctx->model == MODEL_KEYFRAMES)
+        launch_transform_normals(ctx->d_local.as<float4>(), ctx->d_nlocal.as<float4>(), table, ctx->d_global.as<float4>(), ctx->d_nglobal.as<float4>(),
+                                 ctx->n, ctx->stream);
+    else
+        launch_transform(ctx->d_local.as<float4>(), table, ctx->d_global.as<float4>(), ctx->n, ctx->stream);
+    HIPCHK(hipGetLastError());
+    return DMSA_OK;
+}
+
+// ---- Gaussians (DmsaOptimizer.h:78-96) ---------------------------------------------------------------------
+int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
+    const int64_t n = ctx->n;
+    ctx->gaussians_valid = false;
+    ctx->M = 0, ctx->M1 = 0, ctx->Mm = 0;
+    const bool lvl_on[2] = {s.grid_size_1_factor > std::numeric_limits<float>::min(), s.grid_size_2_factor > std::numeric_limits<float>::min()};
+    // createGaussianSets(set, factor * minGridSize, ...): float product, widened to double by the octree constructor
+    ctx->level_res[0] = (double)(s.grid_size_1_factor * ctx->min_grid_size);
+    ctx->level_res[1] = (double)(s.grid_size_2_factor * ctx->min_grid_size);
+    if (!lvl_on[0]) ctx->level_res[0] = ctx->level_res[1];
+    if (!lvl_on[1]) ctx->level_res[1] = ctx->level_res[0];
+    HIPCHK(hipMemsetAsync(ctx->d_counts.p, 0, sizeof(GaussCounts), ctx->stream));
+    {
+        ScopedTimer tm(ctx, T_VOXEL);
+        const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
+        launch_block_aabb(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), ctx->stream);
+        launch_lattice(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), nb, ctx->level_res[0], ctx->level_res[1], ctx->d_lattice.as<LatticeTable>(),
+                       ctx->stream);
+        HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #1: tree depths select the radix-sort bit range
+    }
+    for (int l = 0; l < 2; ++l)
+        if (lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
+    GaussCounts* counts = ctx->d_counts.as<GaussCounts>();
+    const bool split = s.gauss_split != 0 && ctx->model == MODEL_KEYFRAMES;
+    if (split) HIPCHK(ctx->d_pos_slot_rank.ensure((size_t)n * 4));
+    for (int l = 0; l < 2; ++l) {
+        if (!lvl_on[l]) continue;
+        const LatticeTable* tab = ctx->d_lattice.as<LatticeTable>() + l;
+        {
+            ScopedTimer tm(ctx, T_VOXEL);
+            launch_voxel_keys(ctx->d_global.as<float4>(), n, tab, ctx->level_res[l], ctx->d_code[l].as<uint64_t>(), ctx->d_idx[l].as<uint32_t>(), ctx->stream);
+            const unsigned end_bit = (unsigned)(3 * ctx->h_lattice[l].final_depth + 1);
+            HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp.p, ctx->d_sort_tmp.cap, ctx->d_code[l].as<uint64_t>(), ctx->d_code_s[l].as<uint64_t>(),
+                                      ctx->d_idx[l].as<uint32_t>(), ctx->d_idx_s[l].as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
+            launch_head_flags(ctx->d_code_s[l].as<uint64_t>(), n, tab, ctx->d_head.as<int32_t>(), ctx->stream);
+            HIPCHK(inclusive_scan_i32(ctx->d_scan_tmp.p, ctx->d_scan_tmp.cap, ctx->d_head.as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), (size_t)n, ctx->stream));
+            launch_leaf_starts(ctx->d_head.as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_code_s[l].as<uint64_t>(), tab, n,
+                               ctx->d_leaf_start[l].as<int32_t>(), &counts->level[l], ctx->stream);
+            launch_leaf_accept(ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(), &counts->level[l],
+                               s.min_num_points_per_set, n, ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(), ctx->stream);
+            if (split)
+                launch_leaf_split(ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(), ctx->d_nglobal.as<float4>(),
+                                  &counts->level[l], s.min_num_points_per_set, ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(),
+                                  ctx->d_pos_slot_rank.as<int32_t>(), ctx->stream);
+            HIPCHK(exclusive_scan_i32(ctx->d_scan_tmp.p, ctx->d_scan_tmp.cap, ctx->d_slot_acc.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(), (size_t)(2 * n), ctx->stream));
+            HIPCHK(exclusive_scan_i32(ctx->d_scan_tmp.p, ctx->d_scan_tmp.cap, ctx->d_slot_cnt.as<int32_t>(), ctx->d_memb_of_slot.as<int32_t>(), (size_t)(2 * n), ctx->stream));
+            launch_level_totals(ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(), ctx->d_memb_of_slot.as<int32_t>(),
+                                &counts->level[l], 2 * n, ctx->stream);
+            launch_gather_members(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(),
+                                  ctx->d_code_s[l].as<uint64_t>(), tab, ctx->d_slot_acc.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(),
+                                  ctx->d_memb_of_slot.as<int32_t>(), split ? ctx->d_pos_slot_rank.as<int32_t>() : nullptr, ctx->d_local.as<float4>(), counts,
+                                  l, n, ctx->d_memb_local.as<float4>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), ctx->stream);
+        }
+        {
+            ScopedTimer tm(ctx, T_FIT);
+            launch_gauss_fit(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(), counts, l, ctx->d_info12.as<float>(),
+                             ctx->stream);
+        }
+    }
+    {
+        ScopedTimer tm(ctx, T_FIT);
+        launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), nullptr, ctx->stream);
+    }
+    GaussCounts h{};
+    HIPCHK(hipMemcpyAsync(&h, ctx->d_counts.p, sizeof(GaussCounts), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #2: M sizes every later launch
+    HIPCHK(hipGetLastError());
+    ctx->M1 = h.level[0].num_gauss;
+    ctx->M = h.level[0].num_gauss + h.level[1].num_gauss;
+    ctx->Mm = (int64_t)h.level[0].num_memb + h.level[1].num_memb;
+    if (ctx->M > 0) {
+        // enough workgroups to fill 256 CUs several times over, but never more workgroups than Gaussians
+        int wg = 1024;
+        if (wg > ctx->M) wg = ctx->M;
+        ctx->num_wg = wg;
+        launch_segment_partition(ctx->d_seg_off.as<int32_t>(), ctx->M, wg, ctx->d_wg_seg.as<int32_t>(), ctx->stream);
+    }
+    ctx->gaussians_valid = true;
+    return DMSA_OK;
+}
+
+// ---- residual batches ----------------------------------------------------------------------------------------
+int ensure_E(dmsa_ctx* ctx, int B) {
+    const int a = num_extra_rows(ctx);
+    ctx->extra_rows = a;
+    const int64_t ld = (((int64_t)ctx->M + a) + 31) / 32 * 32;
+    ctx->ldE = ld;
+    HIPCHK(ctx->d_E.ensure((size_t)B * ld * 8));
+    return DMSA_OK;
+}
+int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
+    CHK(ensure_E(ctx, B));
+    {
+        ScopedTimer tm(ctx, T_RESIDUAL);
+        launch_residuals(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tables.as<float>(), ctx->rows, ctx->M,
+                         B, ctx->d_wg_seg.as<int32_t>(), ctx->num_wg, ctx->d_E.as<double>(), ctx->ldE, ctx->stream);
+    }
+    ctx->residual_launches += 1;
+    ctx->residual_evals += B;
+    HIPCHK(hipGetLastError());
+    const int a = ctx->extra_rows;
+    if (a > 0 && extra != nullptr) {
+        HIPCHK(hipMemcpy2DAsync(ctx->d_E.as<double>() + ctx->M, (size_t)ctx->ldE * 8, extra->data(), (size_t)a * 8, (size_t)a * 8, (size_t)B,
+                                hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return DMSA_OK;
+}
+
+int upload_common(dmsa_ctx* ctx) {
+    CHK(alloc_point_buffers(ctx));
+    ctx->gaussians_valid = false;
+    ctx->centralized = false;
+    ctx->batch = 0;
+    return DMSA_OK;
+}
+
+// ---- the optimizeSet loop (DmsaOptimizer.h:54-150) -------------------------------------------------------------
+int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
+    ScopedTimer total(ctx, T_TOTAL);
+    const bool fixed = (ctx->flags & DMSA_FLAG_FIXED_ITERS) != 0;
+    const int P = num_params(ctx);
+    std::vector<double> paramVec((size_t)P), origin((size_t)P), loop((size_t)P), step((size_t)P), test((size_t)P), globs, extra;
+    std::vector<double> Hp((size_t)(P + 1) * (P + 1)), H((size_t)P * P), g((size_t)P);
+    int stop = DMSA_STOP_NUM_ITER, iters = 0, bestK = 0;
+    double error0 = 0.0, stepNorm = 0.0;
+    ctx->evaluations = 0;
+    const double increment = 1.0 * std::sqrt((double)std::numeric_limits<float>::epsilon());
+    const double one_div_incr = 1.0 / increment;
+
+    if (s.use_centralization) CHK(dmsa_centralize(ctx));
+    for (int iter = 0; iter < s.num_iter; ++iter) {
+        ++iters;
+        chain(ctx).get_params(paramVec.data());  // :72
+        // :75 updateGlobalPoints (the window model re-chains here, the keyframe model did in setPoseParameters)
+        if (ctx->model == MODEL_WINDOW) chain(ctx).relative_to_global();
+        globs.clear();
+        append_glob(chain(ctx), globs);
+        CHK(build_tables(ctx, 1, globs));
+        CHK(transform_points(ctx, 0));
+        CHK(build_gaussians(ctx, s));  // :78-86, :96
+        if (ctx->M < s.min_num_gaussians) {  // :89-93
+            stop = DMSA_STOP_FEW_GAUSSIANS;
+            break;
+        }
+        // evaluation 0 (:99) and the P forward-difference evaluations of calcNumericJacobian (:199-232) as one batch
+        globs.clear(), extra.clear();
+        host_eval(ctx, globs, extra);
+        chain(ctx).get_params(origin.data());  // :204 (after updateImuError's global2relative round trip)
+        for (int k = 0; k < P; ++k) {
+            loop = origin;
+            loop[(size_t)k] += increment;
+            host_set_params(ctx, loop.data());
+            host_eval(ctx, globs, extra);
+        }
+        chain(ctx).set_params(origin.data());  // :231
+        CHK(build_tables(ctx, 1 + P, globs));
+        CHK(run_residuals(ctx, 1 + P, &extra));
+        const int rowsE = ctx->M + ctx->extra_rows;
+        {
+            ScopedTimer tm(ctx, T_NORMAL);
+            HIPCHK(ctx->d_ne_partial.ensure((size_t)normal_equations_partial_doubles(rowsE, P) * 8));
+            HIPCHK(ctx->d_Hp.ensure(Hp.size() * 8));
+            launch_normal_equations(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, one_div_incr, ctx->d_ne_partial.as<double>(), ctx->d_Hp.as<double>(), ctx->stream);
+        }
+        HIPCHK(hipMemcpyAsync(Hp.data(), ctx->d_Hp.p, Hp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #3
+        const int n1 = P + 1;
+        for (int j = 0; j < P; ++j)
+            for (int i = 0; i < P; ++i) H[(size_t)j * P + i] = Hp[(size_t)j * n1 + i];
+        for (int i = 0; i < P; ++i) g[(size_t)i] = Hp[(size_t)P * n1 + i];
+        error0 = Hp[(size_t)P * n1 + P];  // :101
+        for (int i = 0; i < P; ++i) H[(size_t)i * P + i] += (double)s.lambda_diag;  // :110
+        lm_solve(H.data(), g.data(), P, s.step_length_optim, step.data());             // :113
+        bool anyNan = false;
+        for (double v : step) anyNan = anyNan || std::isnan(v);
+        if (anyNan) {  // :116-122 setPoseParameters(paramVec); break
+            chain(ctx).set_params(paramVec.data());
+            if (ctx->model == MODEL_KEYFRAMES) chain(ctx).relative_to_global();
+            stop = DMSA_STOP_NAN;
+            break;
+        }
+        double mx = -std::numeric_limits<double>::infinity(), mn = std::numeric_limits<double>::infinity();
+        for (double v : step) mx = std::max(mx, v), mn = std::min(mn, v);
+        const double maxElem = std::max(mx, -mn);  // :125
+        if (maxElem > s.max_step)
+            for (double& v : step) v = (s.max_step / maxElem) * v;
+        // adaptiveStepSize (:152-182): nine trial evaluations in one batch
+        globs.clear(), extra.clear();
+        for (int k = 1; k < 10; ++k) {
+            for (int i = 0; i < P; ++i) test[(size_t)i] = paramVec[(size_t)i] + 0.1 * (double)k * step[(size_t)i];
+            host_set_params(ctx, test.data());
+            host_eval(ctx, globs, extra);
+        }
+        CHK(build_tables(ctx, 9, globs));
+        CHK(run_residuals(ctx, 9, &extra));
+        double errs[9];
+        {
+            ScopedTimer tm(ctx, T_NORMAL);
+            HIPCHK(ctx->d_sq_partial.ensure((size_t)squared_sums_partial_doubles(rowsE, 9) * 8));
+            HIPCHK(ctx->d_sq_out.ensure(16 * 8));
+            launch_squared_sums(ctx->d_E.as<double>(), ctx->ldE, rowsE, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
+        }
+        HIPCHK(hipMemcpyAsync(errs, ctx->d_sq_out.p, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #4
+        drain_timers(ctx);
+        double minError = error0;
+        bestK = 0;
+        const std::vector<double> raw = paramVec;
+        for (int k = 1; k < 10; ++k)
+            if (errs[k - 1] < minError) {
+                for (int i = 0; i < P; ++i) paramVec[(size_t)i] = raw[(size_t)i] + 0.1 * (double)k * step[(size_t)i];
+                minError = errs[k - 1], bestK = k;
+            }
+        double ss = 0.0;
+        for (double v : step) ss += v * v;
+        stepNorm = std::sqrt(ss);
+        if (bestK == 0 && !fixed) {  // :130-134 — the set is left at raw + 0.9*step (last trial), not restored
+            stop = DMSA_STOP_NO_IMPROVEMENT;
+            break;
+        }
+        // :136 setPoseParameters(paramVec): the keyframe model re-chains, the window model only rewrites the relative poses
+        chain(ctx).set_params(paramVec.data());
+        if (ctx->model == MODEL_KEYFRAMES) chain(ctx).relative_to_global();
+        if (stepNorm < s.epsilon && !fixed) {  // :139-143
+            stop = DMSA_STOP_EPSILON;
+            break;
+        }
+    }
+    if (s.use_centralization) CHK(dmsa_decentralize(ctx));
+    // :149 final updateGlobalPoints
+    if (ctx->model == MODEL_WINDOW) chain(ctx).relative_to_global();
+    globs.clear();
+    append_glob(chain(ctx), globs);
+    CHK(build_tables(ctx, 1, globs));
+    CHK(transform_points(ctx, 0));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (rep) {
+        rep->iterations = iters, rep->stop_reason = stop;
+        rep->num_gaussians = ctx->M, rep->num_gaussians_l1 = ctx->M1, rep->num_memberships = ctx->Mm;
+        rep->error0 = error0, rep->last_step_norm = stepNorm, rep->last_line_search_k = bestK;
+        rep->evaluations = ctx->evaluations;
+    }
+    return DMSA_OK;
+}
+
+void write_back_poses(const PoseChain& c, double* rel_o, double* rel_t) {
+    std::copy(c.rel_o.begin(), c.rel_o.end(), rel_o);
+    std::copy(c.rel_t.begin(), c.rel_t.end(), rel_t);
+}
+
+}  // namespace
+
+// ====================================================================================================================
+extern "C" {
+
+int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
+    if (!out) return DMSA_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return DMSA_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return DMSA_ERR_NO_DEVICE;
+    dmsa_ctx* ctx = new (std::nothrow) dmsa_ctx();
+    if (!ctx) return DMSA_ERR_NOMEM;
+    ctx->device = device, ctx->flags = flags;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return DMSA_ERR_HIP;
+    }
+    *out = ctx;
+    return DMSA_OK;
+}
+
+void dmsa_destroy(dmsa_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    drain_timers(ctx);
+    for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
+    DevBuf* bufs[] = {&ctx->d_local, &ctx->d_nlocal, &ctx->d_ring, &ctx->d_global, &ctx->d_nglobal, &ctx->d_tables, &ctx->d_ctrl, &ctx->d_stamps,
+                      &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
+                      &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_head, &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
+                      &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_slot_acc, &ctx->d_slot_cnt, &ctx->d_gauss_of_slot, &ctx->d_memb_of_slot,
+                      &ctx->d_pos_slot_rank, &ctx->d_sort_tmp, &ctx->d_scan_tmp, &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_seg_off,
+                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
+    for (DevBuf* b : bufs) b->release();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* dmsa_last_error(const dmsa_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+void dmsa_default_settings(dmsa_settings* s) {
+    if (!s) return;
+    s->num_iter = 15, s->epsilon = 1e-5, s->use_analytic_jacobi = 0, s->step_length_optim = 0.05, s->max_step = 0.01, s->gauss_split = 0;
+    s->grid_size_1_factor = 2.0f, s->grid_size_2_factor = 5.0f, s->min_num_points_per_set = 6, s->min_num_gaussians = 30;
+    s->lambda_diag = 0.00001f, s->use_centralization = 1;
+}
+
+int dmsa_window_upload(dmsa_ctx* ctx, const dmsa_window_problem* p) {
+    if (!ctx || !p || p->num_points < 0 || p->num_static < 0) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    if (!ctx->win.init(*p)) {
+        ctx->err = "invalid window problem (control poses / stamps)";
+        return DMSA_ERR_INVALID;
+    }
+    if (ctx->win.ctrl.n > 64) {
+        ctx->err = "more than 64 control poses";
+        return DMSA_ERR_INVALID;
+    }
+    ctx->model = MODEL_WINDOW;
+    ctx->N = p->num_points, ctx->S = p->num_static, ctx->n = ctx->N + ctx->S;
+    ctx->rows = p->n_total + 1;
+    const size_t n = (size_t)ctx->n;
+    // local points: (x, y, z, row index); static points ride along with the identity row
+    std::vector<float> loc(n * 4);
+    std::vector<int32_t> ring(n);
+    for (int64_t i = 0; i < ctx->N; ++i) {
+        loc[4 * i] = p->xyz_local[4 * i], loc[4 * i + 1] = p->xyz_local[4 * i + 1], loc[4 * i + 2] = p->xyz_local[4 * i + 2];
+        const int32_t row = p->tform_idx[i];
+        if (row < 0 || row >= p->n_total) {
+            ctx->err = "tform_idx out of range";
+            return DMSA_ERR_INVALID;
+        }
+        std::memcpy(&loc[4 * i + 3], &row, 4);
+        ring[(size_t)i] = p->ring_id[i];
+    }
+    const int32_t id_row = p->n_total;
+    for (int64_t k = 0; k < ctx->S; ++k) {
+        const size_t i = (size_t)(ctx->N + k);
+        loc[4 * i] = p->xyz_static[4 * k], loc[4 * i + 1] = p->xyz_static[4 * k + 1], loc[4 * i + 2] = p->xyz_static[4 * k + 2];
+        std::memcpy(&loc[4 * i + 3], &id_row, 4);
+        ring[i] = p->ring_id_static[k];
+    }
+    HIPCHK(ctx->d_local.ensure(n * 16 + 16));
+    HIPCHK(ctx->d_ring.ensure(n * 4 + 16));
+    HIPCHK(hipMemcpy(ctx->d_local.p, loc.data(), n * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_ring.p, ring.data(), n * 4, hipMemcpyHostToDevice));
+    const int C = ctx->win.ctrl.n;
+    HIPCHK(ctx->d_stamps.ensure((size_t)C * 8));
+    HIPCHK(ctx->d_fhw.ensure((size_t)C * 8));
+    HIPCHK(ctx->d_trajtime.ensure((size_t)p->n_total * 8));
+    HIPCHK(hipMemcpy(ctx->d_stamps.p, ctx->win.stamps.data(), (size_t)C * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_fhw.p, ctx->win.fh.w.data(), (size_t)C * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_trajtime.p, ctx->win.traj_time.data(), (size_t)p->n_total * 8, hipMemcpyHostToDevice));
+    ctx->win.ctrl.relative_to_global();
+    ctx->min_grid_size = p->min_grid_size;
+    return upload_common(ctx);
+}
+
+int dmsa_keyframes_upload(dmsa_ctx* ctx, const dmsa_keyframe_problem* p) {
+    if (!ctx || !p || p->num_frames < 2) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    if (!ctx->key.init(*p)) return DMSA_ERR_INVALID;
+    ctx->model = MODEL_KEYFRAMES;
+    const int F = p->num_frames;
+    ctx->n = p->frame_offset[F], ctx->N = ctx->n, ctx->S = 0;
+    ctx->rows = F + 1;
+    const size_t n = (size_t)ctx->n;
+    std::vector<float> loc(n * 4);
+    for (int k = 0; k < F; ++k)
+        for (int64_t i = p->frame_offset[k]; i < p->frame_offset[k + 1]; ++i) {
+            loc[4 * i] = p->xyz_local[4 * i], loc[4 * i + 1] = p->xyz_local[4 * i + 1], loc[4 * i + 2] = p->xyz_local[4 * i + 2];
+            const int32_t row = k;
+            std::memcpy(&loc[4 * i + 3], &row, 4);
+        }
+    HIPCHK(ctx->d_local.ensure(n * 16 + 16));
+    HIPCHK(ctx->d_nlocal.ensure(n * 16 + 16));
+    HIPCHK(ctx->d_nglobal.ensure(n * 16 + 16));
+    HIPCHK(ctx->d_ring.ensure(n * 4 + 16));
+    HIPCHK(hipMemcpy(ctx->d_local.p, loc.data(), n * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_nlocal.p, p->normal_local, n * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_ring.p, p->ring_id, n * 4, hipMemcpyHostToDevice));
+    ctx->min_grid_size = p->min_grid_size;
+    return upload_common(ctx);
+}
+
+int dmsa_centralize(dmsa_ctx* ctx) {
+    if (!ctx || ctx->model == MODEL_NONE) return DMSA_ERR_INVALID;
+    if (ctx->model == MODEL_KEYFRAMES) return DMSA_OK;  // MapManagement::centralize returns immediately (MapManagement.h:73-79)
+    CHK(set_device(ctx));
+    WindowHost& w = ctx->win;  // ContinuousTrajectory.h:75-88
+    w.origin = {w.ctrl.rel_t[0], w.ctrl.rel_t[1], w.ctrl.rel_t[2]};
+    w.ctrl.rel_t[0] = w.ctrl.rel_t[1] = w.ctrl.rel_t[2] = 0.0;
+    w.ctrl.relative_to_global();
+    launch_shift_points(ctx->d_local.as<float4>() + ctx->N, ctx->S, (float)w.origin.x, (float)w.origin.y, (float)w.origin.z, -1.0f, ctx->stream);
+    HIPCHK(hipGetLastError());
+    ctx->centralized = true;
+    return DMSA_OK;
+}
+
+int dmsa_decentralize(dmsa_ctx* ctx) {
+    if (!ctx || ctx->model == MODEL_NONE) return DMSA_ERR_INVALID;
+    if (ctx->model == MODEL_KEYFRAMES) return DMSA_OK;
+    CHK(set_device(ctx));
+    WindowHost& w = ctx->win;  // ContinuousTrajectory.h:89-100
+    w.ctrl.global_to_relative();
+    w.ctrl.rel_t[0] = w.origin.x, w.ctrl.rel_t[1] = w.origin.y, w.ctrl.rel_t[2] = w.origin.z;
+    w.ctrl.relative_to_global();
+    launch_shift_points(ctx->d_local.as<float4>() + ctx->N, ctx->S, (float)w.origin.x, (float)w.origin.y, (float)w.origin.z, 1.0f, ctx->stream);
+    HIPCHK(hipGetLastError());
+    ctx->centralized = false;
+    return DMSA_OK;
+}
+
+int dmsa_get_params(dmsa_ctx* ctx, double* params, int32_t* P) {
+    if (!ctx || ctx->model == MODEL_NONE) return DMSA_ERR_INVALID;
+    if (P) *P = num_params(ctx);
+    if (params) chain(ctx).get_params(params);
+    return DMSA_OK;
+}
+int dmsa_set_params(dmsa_ctx* ctx, const double* params) {
+    if (!ctx || ctx->model == MODEL_NONE || !params) return DMSA_ERR_INVALID;
+    host_set_params(ctx, params);
+    return DMSA_OK;
+}
+
+int dmsa_num_table_rows(dmsa_ctx* ctx, int32_t* n_rows) {
+    if (!ctx || ctx->model == MODEL_NONE || !n_rows) return DMSA_ERR_INVALID;
+    *n_rows = ctx->rows - 1;
+    return DMSA_OK;
+}
+
+// copy B tables to the host without the trailing identity row
+static int download_tables(dmsa_ctx* ctx, int B, float* out) {
+    const int rows = ctx->rows;
+    std::vector<float> tmp((size_t)B * rows * 12);
+    HIPCHK(hipMemcpyAsync(tmp.data(), ctx->d_tables.p, tmp.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < B; ++b) std::memcpy(out + (size_t)b * (rows - 1) * 12, tmp.data() + (size_t)b * rows * 12, (size_t)(rows - 1) * 48);
+    return DMSA_OK;
+}
+
+int dmsa_pose_tables(dmsa_ctx* ctx, int32_t B, const double* params, float* tables_out) {
+    if (!ctx || ctx->model == MODEL_NONE || B <= 0 || !params) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    const int P = num_params(ctx);
+    std::vector<double> globs;
+    for (int b = 0; b < B; ++b) {
+        host_set_params(ctx, params + (size_t)b * P);
+        append_glob(chain(ctx), globs);
+    }
+    CHK(build_tables(ctx, B, globs));
+    if (tables_out) CHK(download_tables(ctx, B, tables_out));
+    return DMSA_OK;
+}
+
+int dmsa_set_pose_tables(dmsa_ctx* ctx, int32_t B, const float* tables) {
+    if (!ctx || ctx->model == MODEL_NONE || B <= 0 || !tables) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    const int rows = ctx->rows;
+    std::vector<float> tmp((size_t)B * rows * 12);
+    const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int b = 0; b < B; ++b) {
+        std::memcpy(tmp.data() + (size_t)b * rows * 12, tables + (size_t)b * (rows - 1) * 12, (size_t)(rows - 1) * 48);
+        std::memcpy(tmp.data() + ((size_t)b * rows + rows - 1) * 12, I, sizeof(I));
+    }
+    HIPCHK(ctx->d_tables.ensure(tmp.size() * 4));
+    HIPCHK(hipMemcpyAsync(ctx->d_tables.p, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->batch = B;
+    return DMSA_OK;
+}
+
+int dmsa_transform_points(dmsa_ctx* ctx, int32_t b, float* xyz_out) {
+    if (!ctx || ctx->model == MODEL_NONE || b < 0 || b >= ctx->batch) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    CHK(transform_points(ctx, b));
+    if (xyz_out) {
+        HIPCHK(hipMemcpyAsync(xyz_out, ctx->d_global.p, (size_t)ctx->n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return DMSA_OK;
+}
+
+int dmsa_build_gaussians(dmsa_ctx* ctx, const dmsa_settings* s, int32_t* M_out, int64_t* Mm_out) {
+    if (!ctx || ctx->model == MODEL_NONE || !s) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    CHK(build_gaussians(ctx, *s));
+    if (M_out) *M_out = ctx->M;
+    if (Mm_out) *Mm_out = ctx->Mm;
+    return DMSA_OK;
+}
+
+int dmsa_eval_residuals(dmsa_ctx* ctx, double* e_out) {
+    if (!ctx || ctx->model == MODEL_NONE || !ctx->gaussians_valid || ctx->batch <= 0 || ctx->M <= 0) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    CHK(run_residuals(ctx, ctx->batch, nullptr));
+    if (e_out) {
+        HIPCHK(hipMemcpy2DAsync(e_out, (size_t)ctx->M * 8, ctx->d_E.p, (size_t)ctx->ldE * 8, (size_t)ctx->M * 8, (size_t)ctx->batch, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    drain_timers(ctx);
+    return DMSA_OK;
+}
+
+int dmsa_normal_equations(dmsa_ctx* ctx, int32_t P, int32_t a, const double* extra_rows, double h, double lambda, double* H_out, double* g_out) {
+    if (!ctx || !ctx->gaussians_valid || ctx->batch != P + 1 || (a != ctx->extra_rows && a != 0)) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    int rowsE = ctx->M;
+    if (a > 0 && extra_rows) {
+        if (a != ctx->extra_rows) return DMSA_ERR_INVALID;
+        HIPCHK(hipMemcpy2DAsync(ctx->d_E.as<double>() + ctx->M, (size_t)ctx->ldE * 8, extra_rows, (size_t)a * 8, (size_t)a * 8, (size_t)(P + 1),
+                                hipMemcpyHostToDevice, ctx->stream));
+        rowsE += a;
+    }
+    std::vector<double> Hp((size_t)(P + 1) * (P + 1));
+    {
+        ScopedTimer tm(ctx, T_NORMAL);
+        HIPCHK(ctx->d_ne_partial.ensure((size_t)normal_equations_partial_doubles(rowsE, P) * 8));
+        HIPCHK(ctx->d_Hp.ensure(Hp.size() * 8));
+        launch_normal_equations(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 1.0 / h, ctx->d_ne_partial.as<double>(), ctx->d_Hp.as<double>(), ctx->stream);
+    }
+    HIPCHK(hipMemcpyAsync(Hp.data(), ctx->d_Hp.p, Hp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    drain_timers(ctx);
+    const int n1 = P + 1;
+    if (H_out)
+        for (int j = 0; j < P; ++j)
+            for (int i = 0; i < P; ++i) H_out[(size_t)j * P + i] = Hp[(size_t)j * n1 + i] + (i == j ? lambda : 0.0);
+    if (g_out)
+        for (int i = 0; i < P; ++i) g_out[i] = Hp[(size_t)P * n1 + i];
+    return DMSA_OK;
+}
+
+int dmsa_get_voxel_level(dmsa_ctx* ctx, int32_t level, dmsa_voxel_level_info* info, uint64_t* leaf_code, uint32_t* key_xyz, int32_t* sorted_point_idx) {
+    if (!ctx || !ctx->gaussians_valid || level < 0 || level > 1) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    const size_t n = (size_t)ctx->n;
+    const LatticeTable& t = ctx->h_lattice[level];
+    const uint64_t invalid = 1ull << (3 * t.final_depth);
+    std::vector<uint64_t> code(n);
+    HIPCHK(hipMemcpy(code.data(), ctx->d_code[level].p, n * 8, hipMemcpyDeviceToHost));
+    int64_t valid = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const bool ok = code[i] != invalid;
+        valid += ok ? 1 : 0;
+        if (key_xyz) {
+            uint32_t k[3] = {0, 0, 0};
+            if (ok)
+                for (int l = 0; l < t.final_depth; ++l) {
+                    k[0] |= (uint32_t)((code[i] >> (3 * l + 2)) & 1ull) << l;
+                    k[1] |= (uint32_t)((code[i] >> (3 * l + 1)) & 1ull) << l;
+                    k[2] |= (uint32_t)((code[i] >> (3 * l)) & 1ull) << l;
+                }
+            key_xyz[3 * i] = k[0], key_xyz[3 * i + 1] = k[1], key_xyz[3 * i + 2] = k[2];
+        }
+        if (leaf_code) leaf_code[i] = ok ? code[i] : UINT64_MAX;
+    }
+    if (sorted_point_idx) HIPCHK(hipMemcpy(sorted_point_idx, ctx->d_idx_s[level].p, (size_t)valid * 4, hipMemcpyDeviceToHost));
+    if (info) {
+        GaussCounts h{};
+        HIPCHK(hipMemcpy(&h, ctx->d_counts.p, sizeof(h), hipMemcpyDeviceToHost));
+        info->resolution = ctx->level_res[level];
+        for (int a = 0; a < 3; ++a) info->min_xyz[a] = t.final_mn[a];
+        info->depth = t.final_depth, info->num_events = t.num_events;
+        info->num_leaves = h.level[level].num_leaves, info->num_valid = valid;
+    }
+    return DMSA_OK;
+}
+
+int dmsa_get_gaussians(dmsa_ctx* ctx, int32_t* seg_offset, int32_t* member_idx, float* info_mats, float* weights) {
+    if (!ctx || !ctx->gaussians_valid) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    const size_t M = (size_t)ctx->M;
+    if (seg_offset) HIPCHK(hipMemcpy(seg_offset, ctx->d_seg_off.p, (M + 1) * 4, hipMemcpyDeviceToHost));
+    if (member_idx && ctx->Mm > 0) HIPCHK(hipMemcpy(member_idx, ctx->d_memb_idx.p, (size_t)ctx->Mm * 4, hipMemcpyDeviceToHost));
+    if ((info_mats || weights) && M > 0) {
+        std::vector<float> tmp(M * 12);
+        HIPCHK(hipMemcpy(tmp.data(), ctx->d_info12.p, M * 48, hipMemcpyDeviceToHost));
+        for (size_t g = 0; g < M; ++g) {
+            if (info_mats) std::memcpy(info_mats + 9 * g, tmp.data() + 12 * g, 36);
+            if (weights) weights[g] = tmp[12 * g + 9];
+        }
+    }
+    return DMSA_OK;
+}
+
+int dmsa_get_global_points(dmsa_ctx* ctx, float* xyz_out, int64_t capacity_points) {
+    if (!ctx || ctx->model == MODEL_NONE || !xyz_out || capacity_points < ctx->n) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    HIPCHK(hipMemcpy(xyz_out, ctx->d_global.p, (size_t)ctx->n * 16, hipMemcpyDeviceToHost));
+    if (ctx->model == MODEL_WINDOW && ctx->S > 0) {
+        // static points are not moved by updateGlobalPoints; they sit (de-centralised again) in the local array
+        HIPCHK(hipMemcpy(xyz_out + 4 * ctx->N, ctx->d_local.as<float4>() + ctx->N, (size_t)ctx->S * 16, hipMemcpyDeviceToHost));
+        for (int64_t k = ctx->N; k < ctx->n; ++k) xyz_out[4 * k + 3] = 1.0f;
+    }
+    return DMSA_OK;
+}
+
+int dmsa_get_timing(dmsa_ctx* ctx, dmsa_timing* t, int32_t reset) {
+    if (!ctx) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    drain_timers(ctx);
+    if (t) {
+        t->residual_kernel_ms = ctx->t_ms[T_RESIDUAL], t->residual_launches = ctx->residual_launches, t->residual_evaluations = ctx->residual_evals;
+        t->voxelize_ms = ctx->t_ms[T_VOXEL], t->gaussian_fit_ms = ctx->t_ms[T_FIT], t->pose_table_ms = ctx->t_ms[T_TABLE];
+        t->normal_eq_ms = ctx->t_ms[T_NORMAL], t->total_ms = ctx->t_ms[T_TOTAL];
+    }
+    if (reset) {
+        for (double& v : ctx->t_ms) v = 0.0;
+        ctx->residual_launches = 0, ctx->residual_evals = 0;
+    }
+    return DMSA_OK;
+}
+
+int dmsa_synchronize(dmsa_ctx* ctx) {
+    if (!ctx) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return DMSA_OK;
+}
+
+int dmsa_optimize_window(dmsa_ctx* ctx, dmsa_window_problem* p, const dmsa_settings* s, dmsa_report* rep) {
+    if (!ctx || !p || !s) return DMSA_ERR_INVALID;
+    CHK(dmsa_window_upload(ctx, p));
+    CHK(optimize(ctx, *s, rep));
+    write_back_poses(ctx->win.ctrl, p->rel_orient, p->rel_transl);
+    return DMSA_OK;
+}
+
+int dmsa_optimize_keyframes(dmsa_ctx* ctx, dmsa_keyframe_problem* p, const dmsa_settings* s, dmsa_report* rep) {
+    if (!ctx || !p || !s) return DMSA_ERR_INVALID;
+    CHK(dmsa_keyframes_upload(ctx, p));
+    CHK(optimize(ctx, *s, rep));
+    write_back_poses(ctx->key.frames, p->rel_orient, p->rel_transl);
+    return DMSA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+// dmsa_kernels.h — launchers of the hand-written gfx950 kernels of the DMSA hot path.
+// All kernels are compiled with -ffp-contract=off: the float/double operation sequences that feed voxel keys and
+// parity checks must not be fused into FMAs (the reference is built -O1 without -march).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace dmsa {
+
+constexpr int kMaxLatticeEvents = 64;   // bounding-box doublings; depth <= 21 bounds this by 21 + first define
+constexpr int kAabbBlock = 1024;        // points per AABB block of the lattice pre-pass
+constexpr uint32_t kStaticRowFlag = 0;  // static points use row index == n_rows (identity row appended to every table)
+
+// Final state of PCL's incremental bounding box, as epochs: points inserted at epoch e were keyed with mn[e] at
+// depth[e]; suffix_shift[e] is what later re-rootings add to their keys.
+struct LatticeTable {
+    int32_t num_events;
+    int32_t final_depth;
+    int32_t status;      // 0 ok, DMSA_ERR_DEPTH if deeper than 21 levels
+    int32_t defined;
+    int64_t first_idx;   // first finite point
+    int64_t event_idx[kMaxLatticeEvents + 1];   // point index that triggered event e (ascending, repeats allowed)
+    double mn[kMaxLatticeEvents + 1][3];
+    uint32_t suffix_shift[kMaxLatticeEvents + 1][3];
+    int32_t depth[kMaxLatticeEvents + 1];
+    double final_mn[3];
+};
+
+// per-level device scalars produced by the segmentation stage
+struct LevelCounts {
+    int32_t num_leaves;
+    int32_t num_gauss;     // accepted point sets of this level
+    int32_t num_memb;      // their total membership
+    int32_t pad;
+};
+
+struct GaussCounts {       // both levels, read back once per iteration
+    LevelCounts level[2];
+    float weight_mean;
+    int32_t pad[3];
+};
+
+// ---- K0: rigid transforms -------------------------------------------------------------------------------
+// global[i] = T[row(i)] * local[i]  (Matrix4f*Vector4f order), local.w carries the row index as int bits.
+void launch_transform(const float4* local, const float4* table, float4* global, int64_t n, hipStream_t s);
+// keyframe model: also rotate normals
+void launch_transform_normals(const float4* local, const float4* nlocal, const float4* table, float4* global, float4* nglobal, int64_t n, hipStream_t s);
+// static points: xyz += sign * origin (float), ContinuousTrajectory::centralize/decentralize
+void launch_shift_points(float4* pts, int64_t n, float ox, float oy, float oz, float sign, hipStream_t s);
+
+// ---- K1: dense pose tables from global control poses (device variant) ------------------------------------
+// ctrl: B x C x 6 doubles (axis-angle, translation) ; stamps C ; fh_w C ; traj_time n_t ; out: B x (n_t+1) x 12 floats
+void launch_window_pose_tables(const double* ctrl, const double* stamps, const double* fh_w, const double* traj_time, int B, int C, int n_t,
+                               float* tables, hipStream_t s);
+// frames: B x F x 6 doubles global poses -> B x (F+1) x 12
+void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tables, hipStream_t s);
+
+// ---- K2: PCL-exact voxel lattice + keys -----------------------------------------------------------------
+void launch_block_aabb(const float4* global, int64_t n, float* aabb /* nb x 8 */, hipStream_t s);
+void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, LatticeTable* tables /* [2] */, hipStream_t s);
+void launch_voxel_keys(const float4* global, int64_t n, const LatticeTable* table, double res, uint64_t* code, uint32_t* idx, hipStream_t s);
+// ---- segmentation of the sorted (code, idx) arrays -------------------------------------------------------
+void launch_head_flags(const uint64_t* code_sorted, int64_t n, const LatticeTable* table, int32_t* head, hipStream_t s);
+void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const uint64_t* code_sorted, const LatticeTable* table, int64_t n,
+                        int32_t* leaf_start, LevelCounts* counts, hipStream_t s);
+void launch_leaf_accept(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const LevelCounts* counts, int min_pts,
+                        int64_t capacity /* leaves */, int32_t* slot_acc /* 2 per leaf */, int32_t* slot_cnt, hipStream_t s);
+// keyframe pass: splitSet on accepted leaves; rewrites slot_acc/slot_cnt and fills per-position (set, rank)
+void launch_leaf_split(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const float4* nglobal, const LevelCounts* counts,
+                       int min_pts, int32_t* slot_acc, int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s);
+void launch_level_totals(const int32_t* slot_acc, const int32_t* slot_cnt, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
+                         LevelCounts* counts /* this level */, int64_t nslots, hipStream_t s);
+void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start, const uint32_t* idx_sorted, const uint64_t* code_sorted,
+                           const LatticeTable* table, const int32_t* slot_acc, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
+                           const int32_t* pos_slot_rank /* or null */, const float4* local, const GaussCounts* counts, int level, int64_t n,
+                           float4* memb_local, int32_t* memb_idx, int32_t* seg_off, hipStream_t s);
+// ---- K3: Gaussian fit -------------------------------------------------------------------------------------
+void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const GaussCounts* counts, int level,
+                      float* info12, hipStream_t s);
+void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, double* scratch, hipStream_t s);
+// ---- K4: correspondence kernel ------------------------------------------------------------------------------
+void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t* wg_seg, hipStream_t s);
+void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
+                      const int32_t* wg_seg, int num_wg, double* E, int64_t ldE, hipStream_t s);
+// ---- K5: normal equations + squared-error sums -------------------------------------------------------------
+// Hp = [J | e0]^T [J | e0] of size (P+1)^2, col-major, J.col(k) = inv_h * (E[k+1] - E[0]) over `rows` rows
+void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s);
+int normal_equations_partial_doubles(int rows, int P);
+void launch_squared_sums(const double* E, int64_t ldE, int rows, int B, double* partial, double* out, hipStream_t s);
+int squared_sums_partial_doubles(int rows, int B);
+
+}  // namespace dmsa

@@ -1,0 +1,1052 @@
+// dmsa_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the DMSA hot path.
+//
+//   K0 transform           ContinuousTrajectory::updateGlobalPoints :137-155 / MapManagement::updateGlobalPoints :140-147
+//   K1 pose tables         ContinuousTrajectory::updateTrajDenseTforms :193-225 (control chain stays on the host)
+//   K2 voxel lattice/keys  pcl::octree::OctreePointCloud as used by DmsaOptimizer::createGaussianSets :282-298
+//   K3 Gaussian fit        Gaussians::addPointSet / limitCovariance / updateRebalancingWeights (Gaussians.h:130-201)
+//   K4 correspondence      DmsaOptimizer::updateErrorTerms :242-268 fused with the transform, B pose tables per launch
+//   K5 normal equations    DmsaOptimizer.h:107-113 (H = J^T J, g = J^T e) + e^T e for the line search :171
+//
+// Everything here is HBM/LDS-bound integer and fp32/fp64 vector work; none of it is a contraction worth MFMA at
+// P = 30.  Built with -ffp-contract=off (no FMA fusion: the transform and the voxel keys
+// must round exactly like the reference's separate multiply/add).
+#include "dmsa_kernels.h"
+
+#include <cfloat>
+#include <climits>
+#include <cmath>
+
+#include "../../include/dmsa_hip.h"
+
+namespace dmsa {
+
+// ------------------------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_allsum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_allsum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ int wave_allmin(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_allminf(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_allmaxf(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// Matrix4f * Vector4f with w == 1, evaluated column-wise like Eigen's packet product: ((c0*x + c1*y) + c2*z) + c3
+__device__ __forceinline__ float3 apply_row3(const float4 r0, const float4 r1, const float4 r2, const float x, const float y, const float z) {
+    float3 g;
+    g.x = ((r0.x * x + r0.y * y) + r0.z * z) + r0.w;
+    g.y = ((r1.x * x + r1.y * y) + r1.z * z) + r1.w;
+    g.z = ((r2.x * x + r2.y * y) + r2.z * z) + r2.w;
+    return g;
+}
+__device__ __forceinline__ float sum3f(float a, float b, float c) { return a + (b + c); }
+
+// ------------------------------------------------------------------------------------------------------------
+// K0 — transforms
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transform(const float4* __restrict__ local, const float4* __restrict__ table, float4* __restrict__ global,
+                                                   int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 p = local[i];
+        const int row = __float_as_int(p.w);
+        const float4 r0 = table[3 * row], r1 = table[3 * row + 1], r2 = table[3 * row + 2];
+        const float3 g = apply_row3(r0, r1, r2, p.x, p.y, p.z);
+        global[i] = make_float4(g.x, g.y, g.z, 1.0f);
+    }
+}
+__global__ __launch_bounds__(256) void k_transform_normals(const float4* __restrict__ local, const float4* __restrict__ nlocal,
+                                                           const float4* __restrict__ table, float4* __restrict__ global, float4* __restrict__ nglobal,
+                                                           int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 p = local[i];
+        const float4 v = nlocal[i];
+        const int row = __float_as_int(p.w);
+        const float4 r0 = table[3 * row], r1 = table[3 * row + 1], r2 = table[3 * row + 2];
+        const float3 g = apply_row3(r0, r1, r2, p.x, p.y, p.z);
+        global[i] = make_float4(g.x, g.y, g.z, 1.0f);
+        // Matrix3f * Vector3f: coefficient-wise 3-term inner products, x0 + (x1 + x2)
+        nglobal[i] = make_float4(sum3f(r0.x * v.x, r0.y * v.y, r0.z * v.z), sum3f(r1.x * v.x, r1.y * v.y, r1.z * v.z),
+                                 sum3f(r2.x * v.x, r2.y * v.y, r2.z * v.z), 0.0f);
+    }
+}
+__global__ __launch_bounds__(256) void k_shift_points(float4* __restrict__ pts, int64_t n, float ox, float oy, float oz, float sign) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pts[i];
+    if (sign > 0.0f)
+        p.x = p.x + ox, p.y = p.y + oy, p.z = p.z + oz;
+    else
+        p.x = p.x - ox, p.y = p.y - oy, p.z = p.z - oz;
+    pts[i] = p;
+}
+
+static inline int grid_for(int64_t n, int block, int cap = 256 * 8) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+void launch_transform(const float4* local, const float4* table, float4* global, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_transform, dim3(grid_for(n, 256)), dim3(256), 0, s, local, table, global, n);
+}
+void launch_transform_normals(const float4* local, const float4* nlocal, const float4* table, float4* global, float4* nglobal, int64_t n,
+                              hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_transform_normals, dim3(grid_for(n, 256)), dim3(256), 0, s, local, nlocal, table, global, nglobal, n);
+}
+void launch_shift_points(float4* pts, int64_t n, float ox, float oy, float oz, float sign, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_shift_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pts, n, ox, oy, oz, sign);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K1 — dense pose tables (double math, one thread per dense pose)
+// ------------------------------------------------------------------------------------------------------------
+struct D3 {
+    double x, y, z;
+};
+__device__ __forceinline__ void d_so3_exp(const D3 w, double R[9]) {
+    const double theta = sqrt(w.x * w.x + w.y * w.y + w.z * w.z);
+    if (theta < 0.00001) {
+        R[0] = 1, R[1] = 0, R[2] = 0, R[3] = 0, R[4] = 1, R[5] = 0, R[6] = 0, R[7] = 0, R[8] = 1;
+        return;
+    }
+    const double s = sin(theta) / theta;
+    const double sh = sin(0.5 * theta);
+    const double c = 2.0 * sh * sh / (theta * theta);
+    const double t2 = theta * theta;
+    R[0] = 1.0 + c * (w.x * w.x - t2);
+    R[4] = 1.0 + c * (w.y * w.y - t2);
+    R[8] = 1.0 + c * (w.z * w.z - t2);
+    R[1] = c * w.x * w.y - s * w.z;
+    R[3] = c * w.x * w.y + s * w.z;
+    R[2] = c * w.x * w.z + s * w.y;
+    R[6] = c * w.x * w.z - s * w.y;
+    R[5] = c * w.y * w.z - s * w.x;
+    R[7] = c * w.y * w.z + s * w.x;
+}
+__device__ __forceinline__ void d_quat_from_axang(const D3 a, double q[4]) {
+    const double sq = a.x * a.x + a.y * a.y + a.z * a.z;
+    const double ang = sqrt(sq);
+    D3 ax = a;
+    if (sq > 0.0) ax = D3{a.x / ang, a.y / ang, a.z / ang};
+    const double sh = sin(0.5 * ang);
+    q[0] = cos(0.5 * ang), q[1] = sh * ax.x, q[2] = sh * ax.y, q[3] = sh * ax.z;
+}
+__device__ __forceinline__ D3 d_slerp_axang(const D3 a, const D3 b, const double t) {
+    double q1[4], q2[4];
+    d_quat_from_axang(a, q1);
+    d_quat_from_axang(b, q2);
+    const double one = 1.0 - DBL_EPSILON;
+    const double d = q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3];
+    const double ad = fabs(d);
+    double s0, s1;
+    if (ad >= one) {
+        s0 = 1.0 - t, s1 = t;
+    } else {
+        const double th = acos(ad), sn = sin(th);
+        s0 = sin((1.0 - t) * th) / sn;
+        s1 = sin(t * th) / sn;
+    }
+    if (d < 0.0) s1 = -s1;
+    const double qw = s0 * q1[0] + s1 * q2[0], qx = s0 * q1[1] + s1 * q2[1], qy = s0 * q1[2] + s1 * q2[2], qz = s0 * q1[3] + s1 * q2[3];
+    double n = sqrt(qx * qx + qy * qy + qz * qz);
+    if (n == 0.0) return D3{0.0, 0.0, 0.0};
+    const double angle = 2.0 * atan2(n, fabs(qw));
+    if (qw < 0.0) n = -n;
+    return D3{(qx / n) * angle, (qy / n) * angle, (qz / n) * angle};
+}
+
+constexpr int kMaxCtrl = 64;  // control poses per window the table kernel keeps in LDS
+
+__global__ __launch_bounds__(256) void k_window_pose_tables(const double* __restrict__ ctrl, const double* __restrict__ stamps,
+                                                            const double* __restrict__ fh_w, const double* __restrict__ traj_time, int C, int n_t,
+                                                            float* __restrict__ tables) {
+    __shared__ double s_ctrl[kMaxCtrl * 6];
+    __shared__ double s_stamp[kMaxCtrl];
+    __shared__ double s_w[kMaxCtrl];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < C * 6; i += blockDim.x) s_ctrl[i] = ctrl[(size_t)b * C * 6 + i];
+    for (int i = threadIdx.x; i < C; i += blockDim.x) s_stamp[i] = stamps[i], s_w[i] = fh_w[i];
+    __syncthreads();
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    float* out = tables + ((size_t)b * (n_t + 1) + j) * 12;
+    if (j == n_t) {  // identity row for static points
+        out[0] = 1, out[1] = 0, out[2] = 0, out[3] = 0, out[4] = 0, out[5] = 1, out[6] = 0, out[7] = 0, out[8] = 0, out[9] = 0, out[10] = 1, out[11] = 0;
+        return;
+    }
+    if (j > n_t) return;
+    const double t = traj_time[j];
+    // getInterpRotation: lower_bound over stamps[0 .. C-2]
+    int right = 0;
+    while (right < C - 1 && s_stamp[right] < t) ++right;
+    D3 o;
+    if (right > 0) {
+        const double t_rel = (t - s_stamp[right - 1]) / (s_stamp[right] - s_stamp[right - 1]);
+        const double* a = &s_ctrl[6 * (right - 1)];
+        const double* bq = &s_ctrl[6 * right];
+        o = d_slerp_axang(D3{a[0], a[1], a[2]}, D3{bq[0], bq[1], bq[2]}, t_rel);
+    } else {
+        o = D3{s_ctrl[0], s_ctrl[1], s_ctrl[2]};
+    }
+    // Floater–Hormann evaluation with the exact-node short-circuit, one interpolant per axis (shared weights)
+    double tr[3];
+    for (int a = 0; a < 3; ++a) {
+        double num = 0.0, den = 0.0, exact = 0.0;
+        bool hit = false;
+        for (int i = 0; i < C; ++i) {
+            const double yi = s_ctrl[6 * i + 3 + a];
+            if (t == s_stamp[i]) {
+                if (!hit) exact = yi;
+                hit = true;
+            }
+            if (!hit) {
+                const double q = s_w[i] / (t - s_stamp[i]);
+                num += q * yi;
+                den += q;
+            }
+        }
+        tr[a] = hit ? exact : num / den;
+    }
+    double R[9];
+    d_so3_exp(o, R);
+    out[0] = (float)R[0], out[1] = (float)R[1], out[2] = (float)R[2], out[3] = (float)tr[0];
+    out[4] = (float)R[3], out[5] = (float)R[4], out[6] = (float)R[5], out[7] = (float)tr[1];
+    out[8] = (float)R[6], out[9] = (float)R[7], out[10] = (float)R[8], out[11] = (float)tr[2];
+}
+
+__global__ __launch_bounds__(256) void k_keyframe_pose_tables(const double* __restrict__ frames, int F, float* __restrict__ tables) {
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > F) return;
+    float* out = tables + ((size_t)b * (F + 1) + k) * 12;
+    if (k == F) {
+        out[0] = 1, out[1] = 0, out[2] = 0, out[3] = 0, out[4] = 0, out[5] = 1, out[6] = 0, out[7] = 0, out[8] = 0, out[9] = 0, out[10] = 1, out[11] = 0;
+        return;
+    }
+    const double* p = frames + ((size_t)b * F + k) * 6;
+    double R[9];
+    d_so3_exp(D3{p[0], p[1], p[2]}, R);
+    out[0] = (float)R[0], out[1] = (float)R[1], out[2] = (float)R[2], out[3] = (float)p[3];
+    out[4] = (float)R[3], out[5] = (float)R[4], out[6] = (float)R[5], out[7] = (float)p[4];
+    out[8] = (float)R[6], out[9] = (float)R[7], out[10] = (float)R[8], out[11] = (float)p[5];
+}
+
+void launch_window_pose_tables(const double* ctrl, const double* stamps, const double* fh_w, const double* traj_time, int B, int C, int n_t,
+                               float* tables, hipStream_t s) {
+    hipLaunchKernelGGL(k_window_pose_tables, dim3((n_t + 1 + 255) / 256, B), dim3(256), 0, s, ctrl, stamps, fh_w, traj_time, C, n_t, tables);
+}
+void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tables, hipStream_t s) {
+    hipLaunchKernelGGL(k_keyframe_pose_tables, dim3((F + 1 + 255) / 256, B), dim3(256), 0, s, frames, F, tables);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2 — PCL-exact voxel lattice
+// ------------------------------------------------------------------------------------------------------------
+// (a) axis-aligned bounds of every block of 1024 points: lets the sequential bounding-box logic skip whole blocks.
+__global__ __launch_bounds__(256) void k_block_aabb(const float4* __restrict__ global, int64_t n, float* __restrict__ aabb) {
+    __shared__ float s_red[4][6];
+    const int64_t base = (int64_t)blockIdx.x * kAabbBlock;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int k = 0; k < kAabbBlock / 256; ++k) {
+        const int64_t i = base + threadIdx.x + 256 * k;
+        if (i < n) {
+            const float4 p = global[i];
+            if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+                mn[0] = fminf(mn[0], p.x), mn[1] = fminf(mn[1], p.y), mn[2] = fminf(mn[2], p.z);
+                mx[0] = fmaxf(mx[0], p.x), mx[1] = fmaxf(mx[1], p.y), mx[2] = fmaxf(mx[2], p.z);
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = wave_allminf(mn[a]);
+        mx[a] = wave_allmaxf(mx[a]);
+    }
+    if (lane == 0)
+        for (int a = 0; a < 3; ++a) s_red[wave][a] = mn[a], s_red[wave][3 + a] = mx[a];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s_red[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, s_red[w][threadIdx.x]) : fmaxf(v, s_red[w][threadIdx.x]);
+        aabb[(size_t)blockIdx.x * 8 + threadIdx.x] = v;
+    }
+}
+void launch_block_aabb(const float4* global, int64_t n, float* aabb, hipStream_t s) {
+    if (n <= 0) return;
+    const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
+    hipLaunchKernelGGL(k_block_aabb, dim3(nb), dim3(256), 0, s, global, n, aabb);
+}
+
+// (b) the incremental bounding box of OctreePointCloud::adoptBoundingBoxToPoint, replayed by one workgroup per
+// resolution: blocks whose bounds fit the current box cannot trigger an event and are skipped 256 at a time; a
+// block that does not fit is searched in parallel for its first violating point, lane 0 applies PCL's growth loop
+// in double arithmetic, and the block is re-examined until it fits.
+struct LatticeRun {
+    double mn[3], mx[3];
+    int depth, defined, nev, status;
+};
+
+__device__ void lattice_adopt(LatticeRun& st, const float4 p, const double res, int64_t idx, LatticeTable* tab, uint32_t (*shifts)[3]) {
+    const double eps = (double)FLT_EPSILON;
+    const float pc[3] = {p.x, p.y, p.z};
+    while (true) {
+        bool lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) lo[a] = (double)pc[a] < st.mn[a], hi[a] = (double)pc[a] >= st.mx[a];
+        if (!(lo[0] || lo[1] || lo[2] || hi[0] || hi[1] || hi[2] || !st.defined)) break;
+        if (st.defined) {
+            if (st.nev >= kMaxLatticeEvents || st.depth >= 21) {
+                st.status = DMSA_ERR_DEPTH;
+                return;
+            }
+            double side = (double)(1u << st.depth) * res;
+            for (int a = 0; a < 3; ++a) {
+                uint32_t sh = 0;
+                if (!hi[a]) {
+                    st.mn[a] -= side;
+                    sh = 1u << st.depth;
+                }
+                shifts[st.nev][a] = sh;
+            }
+            st.depth += 1;
+            side = (double)(1u << st.depth) * res - eps;
+            for (int a = 0; a < 3; ++a) st.mx[a] = st.mn[a] + side;
+            tab->event_idx[st.nev] = idx;
+            st.nev += 1;
+            for (int a = 0; a < 3; ++a) tab->mn[st.nev][a] = st.mn[a];
+            tab->depth[st.nev] = st.depth;
+        } else {
+            for (int a = 0; a < 3; ++a) {
+                st.mn[a] = (double)pc[a] - res / 2;
+                st.mx[a] = (double)pc[a] + res / 2;
+            }
+            // getKeyBitSize()
+            unsigned mk[3];
+            for (int a = 0; a < 3; ++a) mk[a] = (unsigned)ceil((st.mx[a] - st.mn[a] - eps) / res);
+            const unsigned mv = max(max(max(mk[0], mk[1]), mk[2]), 2u);
+            st.depth = (int)max(min(32u, (unsigned)ceil(log((double)mv) / log(2.0) - eps)), 0u);
+            const double side = (double)(1u << st.depth) * res;
+            for (int a = 0; a < 3; ++a) {
+                const double over = (side - (st.mx[a] - st.mn[a])) / 2.0;
+                if (over > eps) {
+                    st.mn[a] -= over;
+                    st.mx[a] += over;
+                }
+            }
+            st.defined = 1;
+            tab->first_idx = idx;
+            for (int a = 0; a < 3; ++a) tab->mn[0][a] = st.mn[a];
+            tab->depth[0] = st.depth;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lattice(const float4* __restrict__ global, int64_t n, const float* __restrict__ aabb, int nb, double res0,
+                                                 double res1, LatticeTable* __restrict__ tables) {
+    __shared__ LatticeRun st;
+    __shared__ uint32_t s_shift[kMaxLatticeEvents][3];
+    __shared__ int s_red[4];
+    __shared__ int s_pick;
+    LatticeTable* tab = tables + blockIdx.x;
+    const double res = blockIdx.x == 0 ? res0 : res1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) {
+        st.defined = 0, st.depth = 0, st.nev = 0, st.status = 0;
+        for (int a = 0; a < 3; ++a) st.mn[a] = 0.0, st.mx[a] = 0.0;
+        tab->first_idx = -1;
+    }
+    __syncthreads();
+    int cursor = 0;
+    while (cursor < nb) {
+        // first block >= cursor whose bounds do not fit the current box
+        int found = INT_MAX;
+        for (int base = cursor; base < nb; base += 256) {
+            const int blk = base + tid;
+            int cand = INT_MAX;
+            if (blk < nb) {
+                const float* bb = aabb + (size_t)blk * 8;
+                const bool any_finite = bb[0] <= bb[3];
+                if (any_finite) {
+                    bool viol = !st.defined;
+                    for (int a = 0; a < 3; ++a) viol = viol || (double)bb[a] < st.mn[a] || (double)bb[3 + a] >= st.mx[a];
+                    if (viol) cand = blk;
+                }
+            }
+            cand = wave_allmin(cand);
+            if (lane == 0) s_red[wave] = cand;
+            __syncthreads();
+            const int m = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+            __syncthreads();
+            if (m != INT_MAX) {
+                found = m;
+                break;
+            }
+        }
+        if (found == INT_MAX) break;
+        // replay the block until none of its points violates the box
+        const int64_t pbase = (int64_t)found * kAabbBlock;
+        while (true) {
+            int cand = INT_MAX;
+#pragma unroll
+            for (int k = 0; k < kAabbBlock / 256; ++k) {
+                const int off = tid + 256 * k;
+                const int64_t i = pbase + off;
+                if (i < n) {
+                    const float4 p = global[i];
+                    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+                        bool viol = !st.defined;
+                        viol = viol || (double)p.x < st.mn[0] || (double)p.x >= st.mx[0];
+                        viol = viol || (double)p.y < st.mn[1] || (double)p.y >= st.mx[1];
+                        viol = viol || (double)p.z < st.mn[2] || (double)p.z >= st.mx[2];
+                        if (viol) cand = min(cand, off);
+                    }
+                }
+            }
+            cand = wave_allmin(cand);
+            if (lane == 0) s_red[wave] = cand;
+            __syncthreads();
+            const int m = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+            if (tid == 0) {
+                s_pick = m;
+                if (m != INT_MAX) lattice_adopt(st, global[pbase + m], res, pbase + m, tab, s_shift);
+            }
+            __syncthreads();
+            if (s_pick == INT_MAX || st.status != 0) break;
+        }
+        if (st.status != 0) break;
+        cursor = found + 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        tab->num_events = st.nev;
+        tab->final_depth = st.depth;
+        tab->status = st.status;
+        tab->defined = st.defined;
+        for (int a = 0; a < 3; ++a) tab->final_mn[a] = st.mn[a];
+        uint32_t acc[3] = {0, 0, 0};
+        for (int a = 0; a < 3; ++a) tab->suffix_shift[st.nev][a] = 0;
+        for (int e = st.nev - 1; e >= 0; --e)
+            for (int a = 0; a < 3; ++a) {
+                acc[a] += s_shift[e][a];
+                tab->suffix_shift[e][a] = acc[a];
+            }
+    }
+}
+void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, LatticeTable* tables, hipStream_t s) {
+    hipLaunchKernelGGL(k_lattice, dim3(2), dim3(256), 0, s, global, n, aabb, nb, res0, res1, tables);
+}
+
+// (c) genOctreeKeyforPoint with the bounding box in force when the point was inserted, plus the integer shifts of
+// later re-rootings; leaf code = x-major bit interleave at the final depth (depth-first leaf order).
+__device__ __forceinline__ uint64_t spread3(uint32_t v) {  // 21 bits -> every third bit
+    uint64_t x = v & 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ global, int64_t n, const LatticeTable* __restrict__ table, double res,
+                                                    uint64_t* __restrict__ code, uint32_t* __restrict__ idx) {
+    __shared__ LatticeTable t;
+    {
+        const int words = sizeof(LatticeTable) / 4;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(table);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int nev = t.num_events;
+    const uint64_t invalid = 1ull << (3 * t.final_depth);
+    const int64_t last_ev = nev > 0 ? t.event_idx[nev - 1] : -1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 p = global[i];
+        uint64_t c = invalid;
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            int e = nev;
+            if (i < last_ev) {
+                e = 0;
+                while (e < nev && t.event_idx[e] <= i) ++e;
+            }
+            const uint32_t mask = (1u << t.depth[e]) - 1u;
+            const uint32_t kx = ((uint32_t)(((double)p.x - t.mn[e][0]) / res) & mask) + t.suffix_shift[e][0];
+            const uint32_t ky = ((uint32_t)(((double)p.y - t.mn[e][1]) / res) & mask) + t.suffix_shift[e][1];
+            const uint32_t kz = ((uint32_t)(((double)p.z - t.mn[e][2]) / res) & mask) + t.suffix_shift[e][2];
+            c = (spread3(kx) << 2) | (spread3(ky) << 1) | spread3(kz);
+        }
+        code[i] = c;
+        idx[i] = (uint32_t)i;
+    }
+}
+void launch_voxel_keys(const float4* global, int64_t n, const LatticeTable* table, double res, uint64_t* code, uint32_t* idx, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_voxel_keys, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, code, idx);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// segmentation of the sorted arrays into leaves, acceptance, member gather
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_head_flags(const uint64_t* __restrict__ code, int64_t n, const LatticeTable* __restrict__ table,
+                                                    int32_t* __restrict__ head) {
+    const uint64_t invalid = 1ull << (3 * table->final_depth);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t c = code[i];
+        head[i] = (c != invalid && (i == 0 || code[i - 1] != c)) ? 1 : 0;
+    }
+}
+void launch_head_flags(const uint64_t* code_sorted, int64_t n, const LatticeTable* table, int32_t* head, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_head_flags, dim3(grid_for(n, 256)), dim3(256), 0, s, code_sorted, n, table, head);
+}
+
+__global__ __launch_bounds__(256) void k_leaf_starts(const int32_t* __restrict__ head, const int32_t* __restrict__ leaf_incl,
+                                                     const uint64_t* __restrict__ code, const LatticeTable* __restrict__ table, int64_t n,
+                                                     int32_t* __restrict__ leaf_start, LevelCounts* __restrict__ counts) {
+    const uint64_t invalid = 1ull << (3 * table->final_depth);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (head[i]) leaf_start[leaf_incl[i] - 1] = (int32_t)i;
+        if (code[i] != invalid && (i == n - 1 || code[i + 1] == invalid)) {
+            counts->num_leaves = leaf_incl[i];
+            leaf_start[leaf_incl[i]] = (int32_t)(i + 1);
+        }
+    }
+}
+void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const uint64_t* code_sorted, const LatticeTable* table, int64_t n,
+                        int32_t* leaf_start, LevelCounts* counts, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_leaf_starts, dim3(grid_for(n, 256)), dim3(256), 0, s, head, leaf_of_pos, code_sorted, table, n, leaf_start, counts);
+}
+
+// DmsaOptimizer.h:302-307: a leaf becomes a point set iff size >= minNumberPts and max(id) != min(id)
+__global__ __launch_bounds__(256) void k_leaf_accept(const int32_t* __restrict__ leaf_start, const uint32_t* __restrict__ idx_sorted,
+                                                     const int32_t* __restrict__ ring, const LevelCounts* __restrict__ counts, int min_pts,
+                                                     int64_t capacity, int32_t* __restrict__ slot_acc, int32_t* __restrict__ slot_cnt) {
+    const int nl = counts->num_leaves;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < capacity; l += stride) {
+        int acc = 0, cnt = 0;
+        if (l < nl) {
+            const int b = leaf_start[l], e = leaf_start[l + 1];
+            cnt = e - b;
+            if (cnt >= min_pts) {
+                const int first = ring[idx_sorted[b]];
+                for (int j = b + 1; j < e; ++j)
+                    if (ring[idx_sorted[j]] != first) {
+                        acc = 1;
+                        break;
+                    }
+            }
+        }
+        slot_acc[2 * l] = acc;
+        slot_cnt[2 * l] = acc ? cnt : 0;
+        slot_acc[2 * l + 1] = 0;
+        slot_cnt[2 * l + 1] = 0;
+    }
+}
+void launch_leaf_accept(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const LevelCounts* counts, int min_pts,
+                        int64_t capacity, int32_t* slot_acc, int32_t* slot_cnt, hipStream_t s) {
+    if (capacity <= 0) return;
+    hipLaunchKernelGGL(k_leaf_accept, dim3(grid_for(capacity, 256)), dim3(256), 0, s, leaf_start, idx_sorted, ring, counts, min_pts, capacity,
+                       slot_acc, slot_cnt);
+}
+
+// Gaussians.h:27-85 splitSet + the split branch of createGaussianSets (DmsaOptimizer.h:310-337), one wave per
+// accepted leaf.  pos_slot_rank[i] = rank within its set, sign bit set for the second set.
+__global__ __launch_bounds__(256) void k_leaf_split(const int32_t* __restrict__ leaf_start, const uint32_t* __restrict__ idx_sorted,
+                                                    const int32_t* __restrict__ ring, const float4* __restrict__ nglobal,
+                                                    const LevelCounts* __restrict__ counts, int min_pts, int32_t* __restrict__ slot_acc,
+                                                    int32_t* __restrict__ slot_cnt, int32_t* __restrict__ pos_slot_rank) {
+    const int nl = counts->num_leaves;
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int l = wave_global; l < nl; l += nwaves) {
+        if (!slot_acc[2 * l]) continue;  // wave-uniform
+        const int b = leaf_start[l], e = leaf_start[l + 1], cnt = e - b;
+        // most anti-parallel normal pair: min over ordered pairs (a outer, c inner, a != c) of |n_a + n_c|, first minimum wins
+        float best = FLT_MAX;
+        long long best_pair = LLONG_MAX;
+        const long long npairs = (long long)cnt * cnt;
+        for (long long q = lane; q < npairs; q += 64) {
+            const int a = (int)(q / cnt), c = (int)(q % cnt);
+            if (a == c) continue;
+            const float4 na = nglobal[idx_sorted[b + a]], nc = nglobal[idx_sorted[b + c]];
+            const float sx = na.x + nc.x, sy = na.y + nc.y, sz = na.z + nc.z;
+            const float d = sqrtf(sum3f(sx * sx, sy * sy, sz * sz));
+            if (d < best) best = d, best_pair = q;  // q ascends per lane, strict '<' keeps the first
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ob = __shfl_xor(best, m);
+            const long long op = __shfl_xor(best_pair, m);
+            if (ob < best || (ob == best && op < best_pair)) best = ob, best_pair = op;
+        }
+        int rank_base1 = 0, rank_base2 = 0;
+        if (!(best <= 0.5f)) {  // `minDiffFromZero > 0.5f` -> no split (also when there was no pair at all)
+            for (int j = b + lane; j < e; j += 64) pos_slot_rank[j] = j - b;
+            continue;  // slot 2l stays as accepted by k_leaf_accept
+        }
+        const int ia = (int)(best_pair / cnt), ic = (int)(best_pair % cnt);
+        const float4 r1 = nglobal[idx_sorted[b + ia]], r2 = nglobal[idx_sorted[b + ic]];
+        bool any1 = false;
+        int mn1 = INT_MAX, mx1 = INT_MIN;
+        for (int j0 = b; j0 < e; j0 += 64) {
+            const int j = j0 + lane;
+            bool in = j < e, first = false;
+            int id = 0;
+            if (in) {
+                const uint32_t pi = idx_sorted[j];
+                const float4 v = nglobal[pi];
+                const float d1 = sqrtf(sum3f((r1.x - v.x) * (r1.x - v.x), (r1.y - v.y) * (r1.y - v.y), (r1.z - v.z) * (r1.z - v.z)));
+                const float d2 = sqrtf(sum3f((r2.x - v.x) * (r2.x - v.x), (r2.y - v.y) * (r2.y - v.y), (r2.z - v.z) * (r2.z - v.z)));
+                first = d1 < d2;
+                id = ring[pi];
+            }
+            const unsigned long long m1 = __ballot(in && first), m2 = __ballot(in && !first);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (in) {
+                if (first) {
+                    pos_slot_rank[j] = rank_base1 + __popcll(m1 & below);
+                    mn1 = min(mn1, id), mx1 = max(mx1, id);
+                    any1 = true;
+                } else {
+                    pos_slot_rank[j] = (int32_t)(0x80000000u | (uint32_t)(rank_base2 + __popcll(m2 & below)));
+                }
+            }
+            rank_base1 += __popcll(m1);
+            rank_base2 += __popcll(m2);
+        }
+        (void)any1;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            mn1 = min(mn1, __shfl_xor(mn1, m));
+            mx1 = max(mx1, __shfl_xor(mx1, m));
+        }
+        // quirks kept: strict '>' on both sizes and BOTH diversity tests read the first set's ids
+        const bool div1 = rank_base1 > 0 && mx1 != mn1;
+        if (lane == 0) {
+            const int a1 = (rank_base1 > min_pts && div1) ? 1 : 0;
+            const int a2 = (rank_base2 > min_pts && div1) ? 1 : 0;
+            slot_acc[2 * l] = a1, slot_cnt[2 * l] = a1 ? rank_base1 : 0;
+            slot_acc[2 * l + 1] = a2, slot_cnt[2 * l + 1] = a2 ? rank_base2 : 0;
+        }
+    }
+}
+void launch_leaf_split(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const float4* nglobal, const LevelCounts* counts,
+                       int min_pts, int32_t* slot_acc, int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s) {
+    hipLaunchKernelGGL(k_leaf_split, dim3(1024), dim3(256), 0, s, leaf_start, idx_sorted, ring, nglobal, counts, min_pts, slot_acc, slot_cnt,
+                       pos_slot_rank);
+}
+
+__global__ void k_level_totals(const int32_t* __restrict__ slot_acc, const int32_t* __restrict__ slot_cnt, const int32_t* __restrict__ gauss_of_slot,
+                               const int32_t* __restrict__ memb_of_slot, LevelCounts* __restrict__ counts, int64_t nslots) {
+    counts->num_gauss = gauss_of_slot[nslots - 1] + slot_acc[nslots - 1];
+    counts->num_memb = memb_of_slot[nslots - 1] + slot_cnt[nslots - 1];
+}
+void launch_level_totals(const int32_t* slot_acc, const int32_t* slot_cnt, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
+                         LevelCounts* counts, int64_t nslots, hipStream_t s) {
+    hipLaunchKernelGGL(k_level_totals, dim3(1), dim3(1), 0, s, slot_acc, slot_cnt, gauss_of_slot, memb_of_slot, counts, nslots);
+}
+
+// members of accepted sets, physically regrouped in Gaussian order (leaf DFS order, ascending point index inside a
+// set): the correspondence kernel then streams contiguous float4s instead of gathering through index lists.
+__global__ __launch_bounds__(256) void k_gather_members(const int32_t* __restrict__ leaf_incl, const int32_t* __restrict__ leaf_start,
+                                                        const uint32_t* __restrict__ idx_sorted, const uint64_t* __restrict__ code,
+                                                        const LatticeTable* __restrict__ table, const int32_t* __restrict__ slot_acc,
+                                                        const int32_t* __restrict__ gauss_of_slot, const int32_t* __restrict__ memb_of_slot,
+                                                        const int32_t* __restrict__ pos_slot_rank, const float4* __restrict__ local,
+                                                        const GaussCounts* __restrict__ counts, int level, int64_t n, float4* __restrict__ memb_local,
+                                                        int32_t* __restrict__ memb_idx, int32_t* __restrict__ seg_off) {
+    const uint64_t invalid = 1ull << (3 * table->final_depth);
+    const int gbase = level == 0 ? 0 : counts->level[0].num_gauss;
+    const int mbase = level == 0 ? 0 : counts->level[0].num_memb;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid0 == 0) seg_off[gbase + counts->level[level].num_gauss] = mbase + counts->level[level].num_memb;
+    for (int64_t i = tid0; i < n; i += stride) {
+        if (code[i] == invalid) continue;
+        const int l = leaf_incl[i] - 1;
+        int set = 0, rank = (int)(i - leaf_start[l]);
+        if (pos_slot_rank != nullptr && slot_acc[2 * l] + slot_acc[2 * l + 1] > 0) {
+            // leaves that went through k_leaf_split carry explicit (set, rank); untouched leaves are rejected anyway
+            const int32_t v = pos_slot_rank[i];
+            set = v < 0 ? 1 : 0;
+            rank = v & 0x7fffffff;
+        }
+        const int slot = 2 * l + set;
+        if (!slot_acc[slot]) continue;
+        const int g = gbase + gauss_of_slot[slot];
+        const int dst = mbase + memb_of_slot[slot] + rank;
+        const uint32_t pi = idx_sorted[i];
+        memb_local[dst] = local[pi];
+        memb_idx[dst] = (int32_t)pi;
+        if (rank == 0) seg_off[g] = dst;
+    }
+}
+void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start, const uint32_t* idx_sorted, const uint64_t* code_sorted,
+                           const LatticeTable* table, const int32_t* slot_acc, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
+                           const int32_t* pos_slot_rank, const float4* local, const GaussCounts* counts, int level, int64_t n, float4* memb_local,
+                           int32_t* memb_idx, int32_t* seg_off, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_members, dim3(grid_for(n, 256)), dim3(256), 0, s, leaf_of_pos, leaf_start, idx_sorted, code_sorted, table, slot_acc,
+                       gauss_of_slot, memb_of_slot, pos_slot_rank, local, counts, level, n, memb_local, memb_idx, seg_off);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K3 — Gaussian fit: covariance (double accumulation, rounded once), eigenvalue clamp, information matrix
+// ------------------------------------------------------------------------------------------------------------
+__device__ void limit_covariance_f(float c[3][3]) {
+    float a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) a[i][j] = c[i][j];
+    for (int sweep = 0; sweep < 6; ++sweep) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int p = r == 2 ? 1 : 0, q = r == 0 ? 1 : 2;
+            const float apq = a[p][q];
+            if (apq == 0.0f) continue;
+            const float theta = (a[q][q] - a[p][p]) / (2.0f * apq);
+            const float at = fabsf(theta);
+            float t = 1.0f / (at + sqrtf(theta * theta + 1.0f));
+            if (theta < 0.0f) t = -t;
+            const float cs = 1.0f / sqrtf(t * t + 1.0f);
+            const float sn = t * cs;
+            const int k = 3 - p - q;
+            const float app = a[p][p], aqq = a[q][q];
+            a[p][p] = app - t * apq;
+            a[q][q] = aqq + t * apq;
+            a[p][q] = 0.0f, a[q][p] = 0.0f;
+            const float akp = a[k][p], akq = a[k][q];
+            a[k][p] = cs * akp - sn * akq;
+            a[p][k] = a[k][p];
+            a[k][q] = sn * akp + cs * akq;
+            a[q][k] = a[k][q];
+            for (int i = 0; i < 3; ++i) {
+                const float vip = v[i][p], viq = v[i][q];
+                v[i][p] = cs * vip - sn * viq;
+                v[i][q] = sn * vip + cs * viq;
+            }
+        }
+    }
+    float lam[3];
+    for (int k = 0; k < 3; ++k) lam[k] = fmaxf(a[k][k], 0.0001f);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[i][j] = sum3f((v[i][0] * lam[0]) * v[j][0], (v[i][1] * lam[1]) * v[j][1], (v[i][2] * lam[2]) * v[j][2]);
+}
+__device__ void inverse3_f(const float m[3][3], float inv[3][3]) {
+    float cof[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            cof[i][j] = m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+        }
+    const float det = sum3f(cof[0][0] * m[0][0], cof[1][0] * m[1][0], cof[2][0] * m[2][0]);
+    const float invdet = 1.0f / det;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) inv[r][c] = cof[c][r] * invdet;
+}
+
+__global__ __launch_bounds__(256) void k_gauss_fit(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
+                                                   const float4* __restrict__ global, const GaussCounts* __restrict__ counts, int level,
+                                                   float* __restrict__ info12) {
+    const int gbase = level == 0 ? 0 : counts->level[0].num_gauss;
+    const int gend = gbase + counts->level[level].num_gauss;
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int g = gbase + wave_global; g < gend; g += nwaves) {
+        const int b = seg_off[g], e = seg_off[g + 1], n = e - b;
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int j = b + lane; j < e; j += 64) {
+            const float4 p = global[memb_idx[j]];
+            sx += (double)p.x, sy += (double)p.y, sz += (double)p.z;
+        }
+        sx = wave_allsum(sx), sy = wave_allsum(sy), sz = wave_allsum(sz);
+        const float mx = (float)(sx / (double)n), my = (float)(sy / (double)n), mz = (float)(sz / (double)n);
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+        for (int j = b + lane; j < e; j += 64) {
+            const float4 p = global[memb_idx[j]];
+            const float cx = p.x - mx, cy = p.y - my, cz = p.z - mz;
+            a0 += (double)cx * (double)cx, a1 += (double)cx * (double)cy, a2 += (double)cx * (double)cz;
+            a3 += (double)cy * (double)cy, a4 += (double)cy * (double)cz, a5 += (double)cz * (double)cz;
+        }
+        a0 = wave_allsum(a0), a1 = wave_allsum(a1), a2 = wave_allsum(a2), a3 = wave_allsum(a3), a4 = wave_allsum(a4), a5 = wave_allsum(a5);
+        if (lane == 0) {
+            const double denom = (double)(n - 1);
+            float cov[3][3], inv[3][3];
+            cov[0][0] = (float)(a0 / denom), cov[0][1] = cov[1][0] = (float)(a1 / denom), cov[0][2] = cov[2][0] = (float)(a2 / denom);
+            cov[1][1] = (float)(a3 / denom), cov[1][2] = cov[2][1] = (float)(a4 / denom), cov[2][2] = (float)(a5 / denom);
+            limit_covariance_f(cov);
+            inverse3_f(cov, inv);
+            float* o = info12 + (size_t)g * 12;
+            for (int c = 0; c < 3; ++c)
+                for (int r = 0; r < 3; ++r) o[3 * c + r] = inv[r][c];
+            o[9] = 0.0f, o[10] = (float)n, o[11] = 0.0f;
+        }
+    }
+}
+void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const GaussCounts* counts, int level, float* info12,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_gauss_fit, dim3(2048), dim3(256), 0, s, seg_off, memb_idx, global, counts, level, info12);
+}
+
+// Gaussians.h:170-179: w_k = (1/n_k) * obsWeight_k, divided by the mean over all sets (double sum, rounded once)
+__global__ __launch_bounds__(1024) void k_rebalancing_weights(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts,
+                                                              float* __restrict__ info12) {
+    __shared__ double s_part[16];
+    const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
+    double s = 0.0;
+    for (int g = threadIdx.x; g < M; g += 1024) {
+        const float nk = (float)(seg_off[g + 1] - seg_off[g]);
+        const float w = (1.0f / nk) * 1.0f;
+        info12[(size_t)g * 12 + 9] = w;
+        s += (double)w;
+    }
+    s = wave_allsum(s);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < 16; ++w) tot += s_part[w];
+    const float mean = (float)(tot / (double)M);
+    if (threadIdx.x == 0) counts->weight_mean = mean;
+    for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = info12[(size_t)g * 12 + 9] / mean;
+}
+void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, double* scratch, hipStream_t s) {
+    (void)scratch;
+    hipLaunchKernelGGL(k_rebalancing_weights, dim3(1), dim3(1024), 0, s, seg_off, counts, info12);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K4 — correspondence kernel: fused rigid transform + per-Gaussian mean + sum of Mahalanobis terms
+// ------------------------------------------------------------------------------------------------------------
+// Work split: workgroup w owns the Gaussians whose first member falls into the w-th equal slice of the membership
+// array, so every workgroup streams about Mm / num_wg contiguous float4s.
+__global__ void k_segment_partition(const int32_t* __restrict__ seg_off, int M, int num_wg, int32_t* __restrict__ wg_seg) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > num_wg) return;
+    if (w == num_wg) {
+        wg_seg[w] = M;
+        return;
+    }
+    const long long Mm = seg_off[M];
+    const int target = (int)((Mm * w) / num_wg);
+    int lo = 0, hi = M;  // first g with seg_off[g] >= target
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (seg_off[mid] < target)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    wg_seg[w] = lo;
+}
+void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t* wg_seg, hipStream_t s) {
+    hipLaunchKernelGGL(k_segment_partition, dim3((num_wg + 1 + 255) / 256), dim3(256), 0, s, seg_off, M, num_wg, wg_seg);
+}
+
+// One wave per Gaussian; blockIdx.y selects the pose table (evaluation).  The dense pose table of that evaluation
+// sits in LDS ((n_t+1) x 48 B) so the per-point row lookup never leaves the CU.
+template <bool kTableInLds>
+__global__ __launch_bounds__(512) void k_residuals(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off,
+                                                   const float4* __restrict__ info12, const float4* __restrict__ tables, int rows, int M,
+                                                   const int32_t* __restrict__ wg_seg, double* __restrict__ E, int64_t ldE) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_tab[];
+    const int b = blockIdx.y;
+    const float4* gtab = tables + (size_t)b * rows * 3;
+    if (kTableInLds) {
+        for (int i = threadIdx.x; i < rows * 3; i += blockDim.x) s_tab[i] = gtab[i];
+        __syncthreads();
+    }
+    const float4* T = kTableInLds ? s_tab : gtab;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int g_end = wg_seg[blockIdx.x + 1];
+    for (int g = wg_seg[blockIdx.x] + wave; g < g_end; g += nw) {
+        const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
+        // pass 1: mean of the transformed members (float, DmsaOptimizer.h:247-254)
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (int j = lane; j < n; j += 64) {
+            const float4 p = memb[off0 + j];
+            const int row = __float_as_int(p.w);
+            const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p.x, p.y, p.z);
+            sx += q.x, sy += q.y, sz += q.z;
+        }
+        sx = wave_allsum(sx), sy = wave_allsum(sy), sz = wave_allsum(sz);
+        const float nf = (float)n;
+        const float mx = sx / nf, my = sy / nf, mz = sz / nf;
+        // information matrix (column-major) + rebalancing weight: 3 float4 per Gaussian
+        const float4 i0 = info12[3 * g], i1 = info12[3 * g + 1], i2 = info12[3 * g + 2];
+        const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
+        // pass 2: sum_j (float)((w d^T) A d) accumulated in double (DmsaOptimizer.h:259-264)
+        double acc = 0.0;
+        for (int j = lane; j < n; j += 64) {
+            const float4 p = memb[off0 + j];
+            const int row = __float_as_int(p.w);
+            const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p.x, p.y, p.z);
+            const float d0 = q.x - mx, d1 = q.y - my, d2 = q.z - mz;
+            const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
+            const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
+            const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
+            const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
+            acc += (double)sum3f(v0 * d0, v1 * d1, v2 * d2);
+        }
+        acc = wave_allsum(acc);
+        if (lane == 0) E[(size_t)b * ldE + g] = sqrt(fabs(acc));
+    }
+}
+void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
+                      const int32_t* wg_seg, int num_wg, double* E, int64_t ldE, hipStream_t s) {
+    if (M <= 0 || B <= 0) return;
+    const size_t lds = (size_t)rows * 48;
+    static bool attr_set = false;
+    if (lds <= 160 * 1024 - 1024) {
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_residuals<true>, dim3(num_wg, B), dim3(512), lds, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
+                           reinterpret_cast<const float4*>(tables), rows, M, wg_seg, E, ldE);
+    } else {
+        hipLaunchKernelGGL(k_residuals<false>, dim3(num_wg, B), dim3(512), 0, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
+                           reinterpret_cast<const float4*>(tables), rows, M, wg_seg, E, ldE);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K5 — normal equations and squared-error sums (fp64, deterministic two-stage reductions)
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kNeTile = 32;
+
+static inline int ne_rows_per_split(int rows, int P) {
+    int rs = 256;
+    if (P > 64) {
+        const int want = (rows + 31) / 32;  // at most 32 splits when the tile grid is already large
+        rs = ((want + 31) / 32) * 32;
+        if (rs < 256) rs = 256;
+    }
+    return rs;
+}
+int normal_equations_partial_doubles(int rows, int P) {
+    const int nt = (P + 1 + kNeTile - 1) / kNeTile;
+    const int rs = ne_rows_per_split(rows, P);
+    const int nsplit = (rows + rs - 1) / rs;
+    return nsplit * nt * nt * kNeTile * kNeTile;
+}
+
+// column k of A' = [J | e0] at row r
+__device__ __forceinline__ double ne_col(const double* __restrict__ E, int64_t ldE, int P, double inv_h, int k, int r, int rows) {
+    if (r >= rows || k > P) return 0.0;
+    const double e0 = E[r];
+    if (k == P) return e0;
+    return inv_h * (E[(size_t)(k + 1) * ldE + r] - e0);
+}
+
+__global__ __launch_bounds__(256) void k_normal_eq_partial(const double* __restrict__ E, int64_t ldE, int rows, int P, double inv_h, int rs, int nt,
+                                                           double* __restrict__ partial) {
+    __shared__ double s_a[kNeTile][kNeTile + 1];
+    __shared__ double s_b[kNeTile][kNeTile + 1];
+    const int tile = blockIdx.x, ti = tile % nt, tj = tile / nt;
+    const int split = blockIdx.y;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 2 x 2 outputs each
+    double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+    const int r_begin = split * rs, r_end = min(rows, r_begin + rs);
+    for (int r0 = r_begin; r0 < r_end; r0 += kNeTile) {
+        // stage 32 columns x 32 rows of both operands (row index fastest in global memory -> coalesced)
+        for (int q = threadIdx.x; q < kNeTile * kNeTile; q += 256) {
+            const int kk = q / kNeTile, rr = q % kNeTile;
+            const int r = r0 + rr;
+            const bool in = r < r_end;
+            s_a[kk][rr] = in ? ne_col(E, ldE, P, inv_h, ti * kNeTile + kk, r, rows) : 0.0;
+            s_b[kk][rr] = in ? ne_col(E, ldE, P, inv_h, tj * kNeTile + kk, r, rows) : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr = 0; rr < kNeTile; ++rr) {
+            const double a0 = s_a[2 * tx][rr], a1 = s_a[2 * tx + 1][rr];
+            const double b0 = s_b[2 * ty][rr], b1 = s_b[2 * ty + 1][rr];
+            c00 += a0 * b0, c01 += a0 * b1, c10 += a1 * b0, c11 += a1 * b1;
+        }
+        __syncthreads();
+    }
+    double* out = partial + ((size_t)split * nt * nt + tile) * kNeTile * kNeTile;
+    out[(2 * ty) * kNeTile + 2 * tx] = c00;
+    out[(2 * ty + 1) * kNeTile + 2 * tx] = c01;
+    out[(2 * ty) * kNeTile + 2 * tx + 1] = c10;
+    out[(2 * ty + 1) * kNeTile + 2 * tx + 1] = c11;
+}
+__global__ __launch_bounds__(256) void k_normal_eq_reduce(const double* __restrict__ partial, int nsplit, int nt, int P, double* __restrict__ Hp) {
+    const int n1 = P + 1;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n1 * n1) return;
+    const int i = q % n1, j = q / n1;  // Hp col-major: element (i, j)
+    const int ti = i / kNeTile, tj = j / kNeTile, li = i % kNeTile, lj = j % kNeTile;
+    double s = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) s += partial[(((size_t)sp * nt * nt) + (size_t)tj * nt + ti) * kNeTile * kNeTile + lj * kNeTile + li];
+    Hp[(size_t)j * n1 + i] = s;
+}
+void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s) {
+    const int nt = (P + 1 + kNeTile - 1) / kNeTile;
+    const int rs = ne_rows_per_split(rows, P);
+    const int nsplit = (rows + rs - 1) / rs;
+    hipLaunchKernelGGL(k_normal_eq_partial, dim3(nt * nt, nsplit), dim3(256), 0, s, E, ldE, rows, P, inv_h, rs, nt, partial);
+    const int n1 = P + 1;
+    hipLaunchKernelGGL(k_normal_eq_reduce, dim3((n1 * n1 + 255) / 256), dim3(256), 0, s, partial, nsplit, nt, P, Hp);
+}
+
+constexpr int kSqRows = 4096;
+int squared_sums_partial_doubles(int rows, int B) { return ((rows + kSqRows - 1) / kSqRows) * B; }
+__global__ __launch_bounds__(256) void k_squared_sums_partial(const double* __restrict__ E, int64_t ldE, int rows, double* __restrict__ partial) {
+    __shared__ double s_w[4];
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int r_end = min(rows, (sp + 1) * kSqRows);
+    double s = 0.0;
+    for (int r = sp * kSqRows + threadIdx.x; r < r_end; r += 256) {
+        const double v = E[(size_t)b * ldE + r];
+        s += v * v;
+    }
+    s = wave_allsum(s);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + sp] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+__global__ void k_squared_sums_reduce(const double* __restrict__ partial, int nsplit, int B, double* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) s += partial[(size_t)b * nsplit + sp];
+    out[b] = s;
+}
+void launch_squared_sums(const double* E, int64_t ldE, int rows, int B, double* partial, double* out, hipStream_t s) {
+    const int nsplit = (rows + kSqRows - 1) / kSqRows;
+    hipLaunchKernelGGL(k_squared_sums_partial, dim3(nsplit, B), dim3(256), 0, s, E, ldE, rows, partial);
+    hipLaunchKernelGGL(k_squared_sums_reduce, dim3((B + 63) / 64), dim3(64), 0, s, partial, nsplit, B, out);
+}
+
+}  // namespace dmsa

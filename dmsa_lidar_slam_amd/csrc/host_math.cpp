@@ -1,0 +1,385 @@
+// host_math.cpp — see host_math.h.  Compiled with -ffp-contract=off so that the double sequences here are
+// reproducible across compilers (the pose table built here feeds float casts and voxel keys downstream).
+#include "host_math.h"
+
+#include <algorithm>
+#include <cstring>
+#include <limits>
+
+namespace dmsa {
+
+Mat3 operator*(const Mat3& A, const Mat3& B) {
+    Mat3 C;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C(r, c) = A(r, 0) * B(0, c) + A(r, 1) * B(1, c) + A(r, 2) * B(2, c);
+    return C;
+}
+Vec3 operator*(const Mat3& A, Vec3 v) {
+    return {A(0, 0) * v.x + A(0, 1) * v.y + A(0, 2) * v.z, A(1, 0) * v.x + A(1, 1) * v.y + A(1, 2) * v.z,
+            A(2, 0) * v.x + A(2, 1) * v.y + A(2, 2) * v.z};
+}
+Mat3 transposed(const Mat3& A) {
+    Mat3 T;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) T(r, c) = A(c, r);
+    return T;
+}
+
+// exp of a skew matrix in closed form (Rodrigues).  Identity below EPSILON_ROT = 1e-5 (helpers.h:18,53).
+Mat3 so3_exp(Vec3 w) {
+    const double theta = length(w);
+    if (theta < 0.00001) return Mat3::identity();
+    const double s = std::sin(theta) / theta;
+    const double sh = std::sin(0.5 * theta);
+    const double c = 2.0 * sh * sh / (theta * theta);
+    const double t2 = theta * theta;
+    Mat3 R;
+    R(0, 0) = 1.0 + c * (w.x * w.x - t2);
+    R(1, 1) = 1.0 + c * (w.y * w.y - t2);
+    R(2, 2) = 1.0 + c * (w.z * w.z - t2);
+    R(0, 1) = c * w.x * w.y - s * w.z;
+    R(1, 0) = c * w.x * w.y + s * w.z;
+    R(0, 2) = c * w.x * w.z + s * w.y;
+    R(2, 0) = c * w.x * w.z - s * w.y;
+    R(1, 2) = c * w.y * w.z - s * w.x;
+    R(2, 1) = c * w.y * w.z + s * w.x;
+    return R;
+}
+
+// principal log of a rotation through its unit quaternion (largest-pivot extraction), angle in [0, pi].
+Vec3 so3_log(const Mat3& R) {
+    const double tr = R(0, 0) + R(1, 1) + R(2, 2);
+    double qw, qx, qy, qz;
+    if (tr > 0.0) {
+        const double s = std::sqrt(tr + 1.0) * 2.0;
+        qw = 0.25 * s;
+        qx = (R(2, 1) - R(1, 2)) / s;
+        qy = (R(0, 2) - R(2, 0)) / s;
+        qz = (R(1, 0) - R(0, 1)) / s;
+    } else if (R(0, 0) > R(1, 1) && R(0, 0) > R(2, 2)) {
+        const double s = std::sqrt(1.0 + R(0, 0) - R(1, 1) - R(2, 2)) * 2.0;
+        qw = (R(2, 1) - R(1, 2)) / s;
+        qx = 0.25 * s;
+        qy = (R(0, 1) + R(1, 0)) / s;
+        qz = (R(0, 2) + R(2, 0)) / s;
+    } else if (R(1, 1) > R(2, 2)) {
+        const double s = std::sqrt(1.0 + R(1, 1) - R(0, 0) - R(2, 2)) * 2.0;
+        qw = (R(0, 2) - R(2, 0)) / s;
+        qx = (R(0, 1) + R(1, 0)) / s;
+        qy = 0.25 * s;
+        qz = (R(1, 2) + R(2, 1)) / s;
+    } else {
+        const double s = std::sqrt(1.0 + R(2, 2) - R(0, 0) - R(1, 1)) * 2.0;
+        qw = (R(1, 0) - R(0, 1)) / s;
+        qx = (R(0, 2) + R(2, 0)) / s;
+        qy = (R(1, 2) + R(2, 1)) / s;
+        qz = 0.25 * s;
+    }
+    const double n = std::sqrt(qx * qx + qy * qy + qz * qz);
+    if (n == 0.0) return {0.0, 0.0, 0.0};
+    const double angle = 2.0 * std::atan2(n, std::fabs(qw));
+    const double k = angle / (qw < 0.0 ? -n : n);
+    return {qx * k, qy * k, qz * k};
+}
+
+namespace {
+struct Quat {
+    double w, x, y, z;
+};
+inline Quat quat_from_axang(Vec3 a) {
+    const double sq = a.x * a.x + a.y * a.y + a.z * a.z;
+    const double ang = std::sqrt(sq);
+    Vec3 ax = a;
+    if (sq > 0.0) ax = {a.x / ang, a.y / ang, a.z / ang};
+    const double sh = std::sin(0.5 * ang);
+    return {std::cos(0.5 * ang), sh * ax.x, sh * ax.y, sh * ax.z};
+}
+}  // namespace
+
+Vec3 slerp_axang(Vec3 a, Vec3 b, double t) {
+    const Quat q1 = quat_from_axang(a), q2 = quat_from_axang(b);
+    const double one = 1.0 - std::numeric_limits<double>::epsilon();
+    const double d = q1.w * q2.w + q1.x * q2.x + q1.y * q2.y + q1.z * q2.z;
+    const double ad = std::fabs(d);
+    double s0, s1;
+    if (ad >= one) {
+        s0 = 1.0 - t, s1 = t;
+    } else {
+        const double th = std::acos(ad), sn = std::sin(th);
+        s0 = std::sin((1.0 - t) * th) / sn;
+        s1 = std::sin(t * th) / sn;
+    }
+    if (d < 0.0) s1 = -s1;
+    const Quat q{s0 * q1.w + s1 * q2.w, s0 * q1.x + s1 * q2.x, s0 * q1.y + s1 * q2.y, s0 * q1.z + s1 * q2.z};
+    double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+    if (n == 0.0) return {0.0, 0.0, 0.0};
+    const double angle = 2.0 * std::atan2(n, std::fabs(q.w));
+    if (q.w < 0.0) n = -n;
+    return {(q.x / n) * angle, (q.y / n) * angle, (q.z / n) * angle};
+}
+
+// ---- PoseChain ------------------------------------------------------------------------------------
+void PoseChain::resize(int count) {
+    n = count;
+    rel_o.assign(3 * (size_t)n, 0.0), rel_t.assign(3 * (size_t)n, 0.0);
+    glob_o.assign(3 * (size_t)n, 0.0), glob_t.assign(3 * (size_t)n, 0.0);
+}
+static inline Vec3 col(const std::vector<double>& m, int k) { return {m[3 * k], m[3 * k + 1], m[3 * k + 2]}; }
+static inline void set_col(std::vector<double>& m, int k, Vec3 v) { m[3 * k] = v.x, m[3 * k + 1] = v.y, m[3 * k + 2] = v.z; }
+
+void PoseChain::relative_to_global() {
+    Mat3 R = Mat3::identity();
+    Vec3 T{0, 0, 0};
+    for (int k = 0; k < n; ++k) {
+        T = T + R * col(rel_t, k);
+        set_col(glob_t, k, T);
+        R = R * so3_exp(col(rel_o, k));
+        set_col(glob_o, k, so3_log(R));
+    }
+}
+void PoseChain::global_to_relative() {
+    set_col(rel_o, 0, col(glob_o, 0));
+    set_col(rel_t, 0, col(glob_t, 0));
+    for (int k = n - 1; k > 0; --k) {
+        const Mat3 R1t = transposed(so3_exp(col(glob_o, k - 1)));
+        const Mat3 R2 = so3_exp(col(glob_o, k));
+        set_col(rel_o, k, so3_log(R1t * R2));
+        set_col(rel_t, k, R1t * (col(glob_t, k) - col(glob_t, k - 1)));
+    }
+}
+void PoseChain::get_params(double* p) const {
+    std::copy(rel_o.begin() + 3, rel_o.end(), p);
+    std::copy(rel_t.begin() + 3, rel_t.end(), p + 3 * (n - 1));
+}
+void PoseChain::set_params(const double* p) {
+    std::copy(p, p + 3 * (n - 1), rel_o.begin() + 3);
+    std::copy(p + 3 * (n - 1), p + 6 * (n - 1), rel_t.begin() + 3);
+}
+
+// ---- FloaterHormann2 --------------------------------------------------------------------------------
+bool FloaterHormann2::build(const double* nodes, int n) {
+    const int d = 2;
+    x.assign(nodes, nodes + n);
+    w.assign((size_t)n, 0.0);
+    for (int k = 0; k < n; ++k) {
+        const int i_lo = std::max(k - d, 0);
+        const int i_hi = (k >= n - d) ? n - d - 1 : k;
+        for (int i = i_lo; i <= i_hi; ++i) {
+            double prod = 1.0;
+            const int j_hi = std::min(i + d, n - 1);
+            for (int j = i; j <= j_hi; ++j) {
+                if (j == k) continue;
+                const double diff = x[k] - x[j];
+                if (std::fabs(diff) < std::numeric_limits<double>::min()) return false;
+                prod *= diff;
+            }
+            if (i % 2 == 0)
+                w[k] += 1.0 / prod;
+            else
+                w[k] -= 1.0 / prod;
+        }
+    }
+    return true;
+}
+double FloaterHormann2::eval(const double* y, double t) const {
+    double num = 0.0, den = 0.0;
+    for (size_t i = 0; i < x.size(); ++i) {
+        if (t == x[i]) return y[i];
+        const double q = w[i] / (t - x[i]);
+        num += q * y[i];
+        den += q;
+    }
+    return num / den;
+}
+
+// ---- dense tables -----------------------------------------------------------------------------------
+static inline void store_row(float* T, const Mat3& R, Vec3 t) {
+    T[0] = (float)R(0, 0), T[1] = (float)R(0, 1), T[2] = (float)R(0, 2), T[3] = (float)t.x;
+    T[4] = (float)R(1, 0), T[5] = (float)R(1, 1), T[6] = (float)R(1, 2), T[7] = (float)t.y;
+    T[8] = (float)R(2, 0), T[9] = (float)R(2, 1), T[10] = (float)R(2, 2), T[11] = (float)t.z;
+}
+
+void window_dense_table(const PoseChain& ctrl, const std::vector<double>& stamps, const FloaterHormann2& fh,
+                        const std::vector<double>& traj_time, float* table) {
+    const int C = ctrl.n;
+    const int n_t = (int)traj_time.size();
+    std::vector<double> ax((size_t)C), ay((size_t)C), az((size_t)C);
+    for (int k = 0; k < C; ++k) ax[k] = ctrl.glob_t[3 * k], ay[k] = ctrl.glob_t[3 * k + 1], az[k] = ctrl.glob_t[3 * k + 2];
+    for (int j = 0; j < n_t; ++j) {
+        const double t = traj_time[j];
+        // getInterpRotation (ContinuousTrajectory.h:570-591): lower_bound over all stamps but the last
+        const int right = (int)(std::lower_bound(stamps.begin(), stamps.end() - 1, t) - stamps.begin());
+        Vec3 o;
+        if (right > 0) {
+            const double t_rel = (t - stamps[right - 1]) / (stamps[right] - stamps[right - 1]);
+            o = slerp_axang(col(ctrl.glob_o, right - 1), col(ctrl.glob_o, right), t_rel);
+        } else {
+            o = col(ctrl.glob_o, 0);
+        }
+        const Vec3 tr{fh.eval(ax.data(), t), fh.eval(ay.data(), t), fh.eval(az.data(), t)};
+        store_row(table + 12 * (size_t)j, so3_exp(o), tr);
+    }
+}
+
+void keyframe_table(const PoseChain& frames, float* table) {
+    for (int k = 0; k < frames.n; ++k) store_row(table + 12 * (size_t)k, so3_exp(col(frames.glob_o, k)), col(frames.glob_t, k));
+}
+
+// ---- WindowHost ---------------------------------------------------------------------------------------
+bool WindowHost::init(const dmsa_window_problem& p) {
+    const int C = p.num_control_poses;
+    if (C < 2 || p.n_total < 2) return false;
+    ctrl.resize(C);
+    std::copy(p.rel_orient, p.rel_orient + 3 * C, ctrl.rel_o.begin());
+    std::copy(p.rel_transl, p.rel_transl + 3 * C, ctrl.rel_t.begin());
+    stamps.assign(p.stamps, p.stamps + C);
+    traj_time.assign(p.traj_time, p.traj_time + p.n_total);
+    if (!fh.build(stamps.data(), C)) return false;
+    use_imu = p.use_imu != 0;
+    if (use_imu) {
+        dt_res = p.dt_res, balancing_imu = p.balancing_imu;
+        gravity = {p.gravity[0], p.gravity[1], p.gravity[2]};
+        param_indices.assign(p.param_indices, p.param_indices + C);
+        preint_rot.assign(p.preint_rot, p.preint_rot + 9 * C);
+        preint_pos.assign(p.preint_pos, p.preint_pos + 3 * C);
+        preint_vel.assign(p.preint_vel, p.preint_vel + 3 * C);
+        cov_inv.assign(p.cov_pvrot_inv, p.cov_pvrot_inv + 81 * C);
+    }
+    return true;
+}
+
+void WindowHost::imu_rows(double* rows) {
+    ctrl.global_to_relative();  // ContinuousTrajectory.h:606
+    const int C = ctrl.n;
+    std::vector<double> ax((size_t)C), ay((size_t)C), az((size_t)C);
+    for (int k = 0; k < C; ++k) ax[k] = ctrl.glob_t[3 * k], ay[k] = ctrl.glob_t[3 * k + 1], az[k] = ctrl.glob_t[3 * k + 2];
+    auto dense_t = [&](int j) { const double t = traj_time[(size_t)j]; return Vec3{fh.eval(ax.data(), t), fh.eval(ay.data(), t), fh.eval(az.data(), t)}; };
+    const double inv_dt = 1.0 / dt_res;
+    for (int k = 1; k < C; ++k) {
+        const Mat3 Rst = transposed(so3_exp(col(ctrl.glob_o, k - 1)));
+        const double delta_t = stamps[k] - stamps[k - 1];
+        const int i0 = param_indices[k - 1], i1 = param_indices[k];
+        const Vec3 v_start = inv_dt * (dense_t(i0 + 1) - dense_t(i0));
+        const Vec3 v_end = inv_dt * (dense_t(i1) - dense_t(i1 - 1));
+        const double half_dt2 = 0.5 * std::pow(delta_t, 2);
+        const Vec3 pk = col(ctrl.glob_t, k), pk1 = col(ctrl.glob_t, k - 1);
+        const Vec3 tmp_p{pk.x - pk1.x - v_start.x * delta_t - half_dt2 * gravity.x, pk.y - pk1.y - v_start.y * delta_t - half_dt2 * gravity.y,
+                         pk.z - pk1.z - v_start.z * delta_t - half_dt2 * gravity.z};
+        const Vec3 dp = Rst * tmp_p;
+        Mat3 P;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) P(r, c) = preint_rot[9 * (size_t)k + 3 * c + r];
+        const Vec3 rot_err = so3_log(transposed(P) * so3_exp(col(ctrl.rel_o, k)));
+        const Vec3 tmp_v{v_end.x - v_start.x - gravity.x * delta_t, v_end.y - v_start.y - gravity.y * delta_t, v_end.z - v_start.z - gravity.z * delta_t};
+        const Vec3 dv = Rst * tmp_v;
+        const double ce[9] = {rot_err.x, rot_err.y, rot_err.z,
+                              dv.x - preint_vel[3 * (size_t)k], dv.y - preint_vel[3 * (size_t)k + 1], dv.z - preint_vel[3 * (size_t)k + 2],
+                              dp.x - preint_pos[3 * (size_t)k], dp.y - preint_pos[3 * (size_t)k + 1], dp.z - preint_pos[3 * (size_t)k + 2]};
+        const double* Ci = &cov_inv[81 * (size_t)k];
+        double q = 0.0, left[9];
+        for (int j = 0; j < 9; ++j) {
+            double s = 0.0;
+            for (int i = 0; i < 9; ++i) s += ce[i] * Ci[9 * j + i];
+            left[j] = s;
+        }
+        for (int j = 0; j < 9; ++j) q += left[j] * ce[j];
+        q *= balancing_imu;
+        rows[k - 1] = std::sqrt(q);
+    }
+}
+
+// ---- KeyframeHost -------------------------------------------------------------------------------------
+bool KeyframeHost::init(const dmsa_keyframe_problem& p) {
+    const int F = p.num_frames;
+    if (F < 2) return false;
+    frames.resize(F);
+    std::copy(p.rel_orient, p.rel_orient + 3 * F, frames.rel_o.begin());
+    std::copy(p.rel_transl, p.rel_transl + 3 * F, frames.rel_t.begin());
+    frames.relative_to_global();
+    use_gravity = p.use_gravity != 0, use_odometry = p.use_odometry != 0;
+    gravity = {p.gravity[0], p.gravity[1], p.gravity[2]};
+    std::copy(p.cov_grav_inv, p.cov_grav_inv + 9, cov_grav_inv);
+    balancing_grav = p.balancing_grav, balancing_odom = p.balancing_odom;
+    if (use_gravity) {
+        measured_gravity.assign(p.measured_gravity, p.measured_gravity + 3 * F);
+        gravity_plausible.assign(p.gravity_plausible, p.gravity_plausible + F);
+    }
+    if (use_odometry) {
+        odom_transl.assign(p.odom_rel_transl, p.odom_rel_transl + 3 * F);
+        odom_orient_mat.assign(p.odom_rel_orient_mat, p.odom_rel_orient_mat + 9 * F);
+        std::copy(p.odom_transl_cov_inv, p.odom_transl_cov_inv + 9, odom_transl_cov_inv);
+        std::copy(p.odom_orient_cov_inv, p.odom_orient_cov_inv + 9, odom_orient_cov_inv);
+    }
+    return true;
+}
+int KeyframeHost::num_extra_rows() const { return (use_gravity ? frames.n : 0) + (use_odometry ? frames.n - 1 : 0); }
+
+static inline double quad_form3(Vec3 d, const double* Ci /* col-major */) {
+    const double l0 = d.x * Ci[0] + d.y * Ci[1] + d.z * Ci[2];
+    const double l1 = d.x * Ci[3] + d.y * Ci[4] + d.z * Ci[5];
+    const double l2 = d.x * Ci[6] + d.y * Ci[7] + d.z * Ci[8];
+    return l0 * d.x + l1 * d.y + l2 * d.z;
+}
+
+void KeyframeHost::additional_rows(double* rows) const {
+    const int F = frames.n;
+    int at = 0;
+    if (use_gravity) {  // MapManagement.h:210-232 — row 0 and implausible frames stay exactly 0
+        for (int k = 0; k < F; ++k) rows[at + k] = 0.0;
+        for (int k = 1; k < F; ++k) {
+            if (!gravity_plausible[(size_t)k]) continue;
+            const Vec3 m{measured_gravity[3 * (size_t)k], measured_gravity[3 * (size_t)k + 1], measured_gravity[3 * (size_t)k + 2]};
+            Vec3 d = so3_exp(col(frames.glob_o, k)) * m;
+            d = {d.x - gravity.x, d.y - gravity.y, d.z - gravity.z};
+            double q = quad_form3(d, cov_grav_inv);
+            q *= balancing_grav;
+            rows[at + k] = std::sqrt(q);
+        }
+        at += F;
+    }
+    if (use_odometry) {  // MapManagement.h:234-252
+        for (int k = 1; k < F; ++k) {
+            const Vec3 o{odom_transl[3 * (size_t)k], odom_transl[3 * (size_t)k + 1], odom_transl[3 * (size_t)k + 2]};
+            const Vec3 td = o - col(frames.rel_t, k);
+            Mat3 Rm;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) Rm(r, c) = odom_orient_mat[9 * (size_t)k + 3 * c + r];
+            const Vec3 od = so3_log(transposed(so3_exp(col(frames.rel_o, k))) * Rm);
+            double q = 0.0;
+            q += quad_form3(td, odom_transl_cov_inv);
+            q += quad_form3(od, odom_orient_cov_inv);
+            q *= balancing_odom;
+            rows[at + k - 1] = std::sqrt(q);
+        }
+    }
+}
+
+// ---- LM solve -----------------------------------------------------------------------------------------
+void lm_solve(const double* Hin, const double* g, int P, double alpha, double* step) {
+    std::vector<double> A(Hin, Hin + (size_t)P * P), inv((size_t)P * P, 0.0);
+    for (int i = 0; i < P; ++i) inv[(size_t)i * P + i] = 1.0;
+    auto at = [P](std::vector<double>& M, int r, int c) -> double& { return M[(size_t)c * P + r]; };
+    for (int c0 = 0; c0 < P; ++c0) {
+        int piv = c0;
+        double best = std::fabs(at(A, c0, c0));
+        for (int r = c0 + 1; r < P; ++r)
+            if (std::fabs(at(A, r, c0)) > best) best = std::fabs(at(A, r, c0)), piv = r;
+        if (piv != c0)
+            for (int c = 0; c < P; ++c) std::swap(at(A, c0, c), at(A, piv, c)), std::swap(at(inv, c0, c), at(inv, piv, c));
+        const double d = at(A, c0, c0);
+        for (int c = 0; c < P; ++c) at(A, c0, c) /= d, at(inv, c0, c) /= d;
+        for (int r = 0; r < P; ++r) {
+            if (r == c0) continue;
+            const double f = at(A, r, c0);
+            if (f == 0.0) continue;
+            for (int c = 0; c < P; ++c) at(A, r, c) -= f * at(A, c0, c), at(inv, r, c) -= f * at(inv, c0, c);
+        }
+    }
+    for (int i = 0; i < P; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < P; ++j) s += (-alpha * inv[(size_t)j * P + i]) * g[j];
+        step[i] = s;
+    }
+}
+
+}  // namespace dmsa

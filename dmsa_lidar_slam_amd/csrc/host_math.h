@@ -1,0 +1,106 @@
+// host_math.h — host-side double-precision pose math of the DMSA path (product code, no oracle dependency).
+//
+// What stays on the host: the control-pose chain, the parameter (de)vectorisation and the
+// few additional error rows.  They are O(#poses) per evaluation; everything O(#points) lives in HIP kernels.
+//   Poses / ConsecutivePoses      -> PoseChain          (Poses.h:64-76, ConsecutivePoses.h:26-67)
+//   helpers.h:24-65               -> so3_exp / so3_log / slerp_axang
+//   boost barycentric_rational    -> FloaterHormann2    (ContinuousTrajectory.h:214-217)
+//   updateTrajDenseTforms         -> window_dense_table (ContinuousTrajectory.h:189-226), host variant
+//   updateImuError                -> WindowHost::imu_rows          (ContinuousTrajectory.h:603-663)
+//   updateGravityErrors/Odometry  -> KeyframeHost::additional_rows (MapManagement.h:162-252)
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/dmsa_hip.h"
+
+namespace dmsa {
+
+struct Vec3 {
+    double x, y, z;
+};
+inline Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec3 operator*(double s, Vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline double length(Vec3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+
+struct Mat3 {
+    double a[9];  // row-major
+    double& operator()(int r, int c) { return a[3 * r + c]; }
+    double operator()(int r, int c) const { return a[3 * r + c]; }
+    static Mat3 identity() { return Mat3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
+};
+Mat3 operator*(const Mat3& A, const Mat3& B);
+Vec3 operator*(const Mat3& A, Vec3 v);
+Mat3 transposed(const Mat3& A);
+
+Mat3 so3_exp(Vec3 w);                         // axang2rotm, helpers.h:51-57
+Vec3 so3_log(const Mat3& R);                  // rotm2axang, helpers.h:59-65
+Vec3 slerp_axang(Vec3 a, Vec3 b, double t);   // helpers.h:24-37
+
+// Global <-> relative pose chains.  Columns are stored contiguously: pose k = o[3k..3k+2], t[3k..3k+2]
+// (identical to Eigen's 3xn column-major Matrix3Xd).
+struct PoseChain {
+    int n = 0;
+    std::vector<double> rel_o, rel_t, glob_o, glob_t;
+    void resize(int count);
+    void relative_to_global();  // ConsecutivePoses.h:26-43
+    void global_to_relative();  // ConsecutivePoses.h:45-67
+    int num_params() const { return 6 * (n - 1); }
+    void get_params(double* p) const;        // Poses.h:64-70
+    void set_params(const double* p);        // Poses.h:72-76
+};
+
+// Floater–Hormann rational interpolant of order 2 through (x_i, y_i) — the weights depend on x only,
+// so one weight set serves the three translation axes.
+struct FloaterHormann2 {
+    std::vector<double> x, w;
+    bool build(const double* nodes, int n);   // false on coincident nodes (boost throws std::logic_error)
+    double eval(const double* y, double t) const;
+};
+
+// Dense [R|t] table (n_total x 12 floats, row-major 3x4) from the GLOBAL control poses — host variant of the
+// pose-table kernel; bit-reproducible against the CPU oracle (DMSA_FLAG_POSE_TABLE_HOST).
+void window_dense_table(const PoseChain& ctrl, const std::vector<double>& stamps, const FloaterHormann2& fh,
+                        const std::vector<double>& traj_time, float* table);
+void keyframe_table(const PoseChain& frames, float* table);
+
+// ---- host state of the two problem models -------------------------------------------------------
+struct WindowHost {
+    PoseChain ctrl;
+    std::vector<double> stamps, traj_time;
+    FloaterHormann2 fh;
+    bool use_imu = false;
+    double dt_res = 1e-3, balancing_imu = 1e-3;
+    Vec3 gravity{0, 0, -9.805};
+    std::vector<int32_t> param_indices;
+    std::vector<double> preint_rot, preint_pos, preint_vel, cov_inv;  // as in dmsa_window_problem
+    Vec3 origin{0, 0, 0};
+
+    bool init(const dmsa_window_problem& p);
+    int num_extra_rows() const { return use_imu ? ctrl.n - 1 : 0; }
+    // updateImuError on the CURRENT chain state (runs global_to_relative first, like the reference)
+    void imu_rows(double* rows);
+};
+
+struct KeyframeHost {
+    PoseChain frames;
+    bool use_gravity = false, use_odometry = false;
+    Vec3 gravity{0, 0, -9.805};
+    double cov_grav_inv[9], balancing_grav = 1.0, balancing_odom = 1000.0;
+    std::vector<double> measured_gravity, odom_transl, odom_orient_mat;
+    std::vector<int32_t> gravity_plausible;
+    double odom_transl_cov_inv[9], odom_orient_cov_inv[9];
+
+    bool init(const dmsa_keyframe_problem& p);
+    int num_extra_rows() const;
+    void additional_rows(double* rows) const;  // MapManagement.h:162-252, gravity rows then odometry rows
+};
+
+// Dense symmetric solve for the LM step: step = -alpha * H^-1 * g with H^-1 from partial-pivot elimination
+// (DmsaOptimizer.h:113, MatrixXd::inverse()).
+void lm_solve(const double* H /* PxP col-major */, const double* g, int P, double alpha, double* step);
+
+}  // namespace dmsa

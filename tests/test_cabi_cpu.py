@@ -1,0 +1,71 @@
+"""CPU-side checks of the product boundary: the C-ABI library builds/loads, exports every symbol declared in
+include/dmsa_hip.h, and refuses to run without a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from dmsa_lidar_slam_amd import _capi as capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(capi.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return capi.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "dmsa_hip.h")).read()
+    declared = set(re.findall(r"\b(dmsa_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(capi.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_sizes_match_header_layout():
+    # natural-alignment layouts of the PODs in include/dmsa_hip.h (x86-64 SysV)
+    assert C.sizeof(capi.Settings) == 72
+    assert C.sizeof(capi.Report) == 48
+    assert C.sizeof(capi.VoxelLevelInfo) == 56
+    assert C.sizeof(capi.Timing) == 64
+    assert C.sizeof(capi.WindowProblem) == 192
+    assert C.sizeof(capi.KeyframeProblem) == 360
+
+
+def test_default_settings_match_reference_defaults(lib):
+    s = capi.Settings()
+    lib.dmsa_default_settings(C.byref(s))
+    # DmsaOptimizer.h:25-39
+    assert (s.num_iter, s.epsilon, s.step_length_optim, s.max_step) == (15, 1e-5, 0.05, 0.01)
+    assert (s.gauss_split, s.min_num_points_per_set, s.min_num_gaussians, s.use_centralization) == (0, 6, 30, 1)
+    assert abs(s.grid_size_1_factor - 2.0) < 1e-7 and abs(s.grid_size_2_factor - 5.0) < 1e-7 and abs(s.lambda_diag - 1e-5) < 1e-12
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    ctx = C.c_void_p()
+    assert lib.dmsa_create(0, 0, C.byref(ctx)) == capi.DMSA_ERR_NO_DEVICE
+    from dmsa_lidar_slam_amd.api import DmsaError, DmsaOptimizer
+
+    with pytest.raises(DmsaError):
+        DmsaOptimizer()
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under dmsa_lidar_slam_amd/ may load, link or include it."""
+    pkg = os.path.join(ROOT, "dmsa_lidar_slam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle_py" not in txt and "dmsa_oracle" not in txt and "libdmsa_oracle" not in txt, f

@@ -1,0 +1,257 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): bit-exact voxel keys / leaf order / member lists; residuals <= 1e-6 relative;
+poses within 1e-4 m / 1e-4 rad after the same iteration count.  Sizes are kept where the oracle finishes in seconds.
+"""
+import numpy as np
+import pytest
+
+from dmsa_lidar_slam_amd import synth
+from dmsa_lidar_slam_amd.problems import DmsaOptimSettings
+
+pytestmark = pytest.mark.gpu
+
+H_INCR = float(np.sqrt(np.finfo(np.float32).eps))
+
+
+@pytest.fixture(scope="module")
+def small_window():
+    return synth.window_problem(seed=7, scans=4, rings=32, az_steps=256, num_static=8000)
+
+
+@pytest.fixture(scope="module")
+def imu_window():
+    return synth.window_problem(seed=8, scans=3, rings=32, az_steps=192, num_static=5000, use_imu=True)
+
+
+@pytest.fixture(scope="module")
+def small_keyframes():
+    return synth.keyframe_problem(seed=3, frames=8, rings=24, az_steps=160, arc=0.5)
+
+
+def _global_points(orc, prob):
+    table, _ = orc.window_pose_table(prob)
+    g = orc.transform_points(table, prob.localPoints, prob.tformIdPerPoint)
+    return np.concatenate([g, prob.staticPoints]).astype(np.float32), table
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_pose_table_host_mode_bit_exact(hip, orc, small_window):
+    opt = hip.DmsaOptimizer(pose_table_host=True)
+    opt.upload(small_window)
+    got = opt.poseTables(small_window.getPoseParameters())[0]
+    ref, _ = orc.window_pose_table(small_window)
+    assert np.array_equal(got, ref)
+
+
+def test_pose_table_device_kernel(hip, orc, small_window):
+    opt = hip.DmsaOptimizer()
+    opt.upload(small_window)
+    rng = np.random.default_rng(0)
+    base = small_window.getPoseParameters()
+    params = np.stack([base, base + rng.normal(0, 1e-3, base.shape), base + H_INCR * np.eye(len(base))[3]])
+    got = opt.poseTables(params)
+    for b in range(3):
+        p = small_window.copy()
+        c = p.numControlPoses
+        p.relOrientations[1:] = params[b, :3 * (c - 1)].reshape(c - 1, 3)
+        p.relTranslations[1:] = params[b, 3 * (c - 1):].reshape(c - 1, 3)
+        ref, _ = orc.window_pose_table(p)
+        # device libm may differ from glibc by an ulp in double -> at most 1 float ulp after the cast
+        assert np.abs(got[b] - ref).max() <= 2.4e-7 * max(1.0, np.abs(ref).max())
+        assert np.mean(got[b] == ref) > 0.999
+
+
+def test_transform_bit_exact(hip, orc, small_window):
+    opt = hip.DmsaOptimizer(pose_table_host=True)
+    opt.upload(small_window)
+    opt.poseTables(small_window.getPoseParameters())
+    got = opt.updateGlobalPoints(0)
+    ref, _ = _global_points(orc, small_window)
+    n = small_window.localPoints.shape[0]
+    assert np.array_equal(got[:n, :3], ref[:n, :3])
+
+
+def _stage_setup(hip, orc, prob, settings):
+    opt = hip.DmsaOptimizer(pose_table_host=True)
+    opt.upload(prob)
+    opt.poseTables(prob.getPoseParameters())
+    opt.updateGlobalPoints(0, download=False)
+    M, Mm = opt.buildGaussians(settings)
+    glob, table = _global_points(orc, prob)
+    ids = np.concatenate([prob.ringIds, prob.staticRingIds])
+    return opt, glob, ids, table, M, Mm
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_voxel_keys_and_leaf_order_bit_exact(hip, orc, small_window, level):
+    s = DmsaOptimSettings.sliding_window()
+    opt, glob, ids, _, _, _ = _stage_setup(hip, orc, small_window, s)
+    factor = np.float32(s.grid_size_1_factor if level == 0 else s.grid_size_2_factor)
+    res = float(factor * np.float32(small_window.minGridSize))
+    info_r, code_r, key_r, order_r = orc.voxelize(glob, res)
+    info, code, key, order = opt.voxelLevel(level)
+    assert info.resolution == res
+    assert info.depth == info_r.depth and info.num_events == info_r.num_events
+    assert list(info.min_xyz) == list(info_r.min_xyz)
+    assert info.num_valid == info_r.num_valid and info.num_leaves == info_r.num_leaves
+    assert np.array_equal(key, key_r)
+    assert np.array_equal(code, code_r)
+    assert np.array_equal(order, order_r)
+
+
+def test_voxel_with_nonfinite_points(hip, orc):
+    prob = synth.window_problem(seed=11, scans=2, rings=16, az_steps=128, num_static=1000)
+    prob.localPoints[0, 0] = np.nan          # first point NaN: lattice anchors at the next finite point
+    prob.localPoints[500, 1] = np.inf
+    prob.staticPoints[3, 2] = -np.inf
+    s = DmsaOptimSettings.sliding_window()
+    opt, glob, ids, _, _, _ = _stage_setup(hip, orc, prob, s)
+    for level, f in ((0, s.grid_size_1_factor), (1, s.grid_size_2_factor)):
+        res = float(np.float32(f) * np.float32(prob.minGridSize))
+        info_r, code_r, key_r, order_r = orc.voxelize(glob, res)
+        info, code, key, order = opt.voxelLevel(level)
+        assert info.num_valid == info_r.num_valid == glob.shape[0] - 3
+        assert np.array_equal(code, code_r) and np.array_equal(order, order_r)
+        assert list(info.min_xyz) == list(info_r.min_xyz)
+
+
+def test_gaussian_sets_bit_exact_and_info_close(hip, orc, small_window):
+    s = DmsaOptimSettings.sliding_window()
+    opt, glob, ids, _, M, Mm = _stage_setup(hip, orc, small_window, s)
+    ref = orc.Gaussians(glob, ids, small_window.minGridSize, s)
+    assert (M, Mm) == (ref.M, ref.Mm)
+    seg, memb, info, w = opt.gaussians()
+    assert np.array_equal(seg, ref.seg_offset)
+    assert np.array_equal(memb, ref.members)
+    # same operation sequence (double accumulation, float Jacobi): equal up to the summation order of the double sums
+    scale = np.abs(ref.info).max(axis=1, keepdims=True)
+    assert (np.abs(info - ref.info) / scale).max() < 1e-5
+    assert np.mean(info == ref.info) > 0.99
+    assert np.abs(w - ref.weights).max() <= 1.2e-7 * np.abs(ref.weights).max()
+
+
+def test_residuals_vs_oracle(hip, orc, small_window):
+    s = DmsaOptimSettings.sliding_window()
+    opt, glob, ids, table, M, Mm = _stage_setup(hip, orc, small_window, s)
+    ref = orc.Gaussians(glob, ids, small_window.minGridSize, s)
+    seg, memb, info, w = opt.gaussians()
+    ref.set_info(info, w)  # same information matrices / weights on both sides: isolates the correspondence kernel
+    # three evaluations: base, a perturbed table, a second perturbation
+    base = small_window.getPoseParameters()
+    params = np.stack([base, base + H_INCR * np.eye(len(base))[0], base + H_INCR * np.eye(len(base))[len(base) - 1]])
+    tables = opt.poseTables(params)
+    e = opt.evalResiduals(3)
+    n = small_window.localPoints.shape[0]
+    for b in range(3):
+        g = orc.transform_points(tables[b], small_window.localPoints, small_window.tformIdPerPoint)
+        gl = np.concatenate([g, small_window.staticPoints]).astype(np.float32)
+        e_ref = ref.residuals(gl)
+        rel = np.abs(e[b] - e_ref) / np.maximum(np.abs(e_ref), 1e-12)
+        assert rel.max() < 1e-6, (b, rel.max())
+    # and against the oracle's own Gaussians (information matrices fitted independently on both sides)
+    ref2 = orc.Gaussians(glob, ids, small_window.minGridSize, s)
+    e_ref2 = ref2.residuals(glob)
+    rel = np.abs(e[0] - e_ref2) / np.maximum(np.abs(e_ref2), 1e-12)
+    assert rel.max() < 2e-4 and np.median(rel) < 1e-6
+
+
+def test_normal_equations(hip, orc, small_window):
+    s = DmsaOptimSettings.sliding_window()
+    opt, glob, ids, table, M, Mm = _stage_setup(hip, orc, small_window, s)
+    base = small_window.getPoseParameters()
+    P = len(base)
+    params = np.concatenate([base[None], base[None] + H_INCR * np.eye(P)])
+    opt.poseTables(params, download=False)
+    e = opt.evalResiduals(P + 1)
+    lam = float(np.float32(1e-5))
+    H, g = opt.normalEquations(P, H_INCR, lam)
+    H_ref, g_ref, step_ref = orc.lm_step(e[0], e[1:], H_INCR, lam, 0.2)
+    assert np.abs(H - H_ref).max() / np.abs(H_ref).max() < 1e-12
+    assert np.abs(g - g_ref).max() / np.abs(g_ref).max() < 1e-12
+
+
+def _pose_diff(orc, a, b):
+    ga_o, ga_t = orc.relative2global(a.relOrientations, a.relTranslations)
+    gb_o, gb_t = orc.relative2global(b.relOrientations, b.relTranslations)
+    return np.abs(ga_t - gb_t).max(), np.abs(ga_o - gb_o).max()
+
+
+@pytest.mark.parametrize("host_tables", [True, False])
+def test_optimize_window_matches_oracle(hip, orc, small_window, host_tables):
+    s = DmsaOptimSettings.sliding_window(num_iter=5)
+    p_ref, p_gpu = small_window.copy(), small_window.copy()
+    rep_ref, gl_ref, trace = orc.optimize_window(p_ref, s, want_global=True)
+    opt = hip.DmsaOptimizer(pose_table_host=host_tables)
+    rep = opt.optimizeSet(p_gpu, s)
+    assert rep.iterations == rep_ref.iterations and rep.stop_reason == rep_ref.stop_reason
+    assert rep.evaluations == rep_ref.evaluations
+    dt, dr = _pose_diff(orc, p_ref, p_gpu)
+    assert dt < 1e-4 and dr < 1e-4, (dt, dr)
+    gl = opt.globalPoints()
+    assert np.abs(gl[:, :3] - gl_ref[:, :3]).max() < 2e-4
+    # the optimisation moved the poses by much more than the tolerance (the check is not vacuous)
+    moved_t, moved_r = _pose_diff(orc, small_window, p_gpu)
+    assert moved_t > 1e-3 or moved_r > 1e-3
+
+
+def test_optimize_window_with_imu_rows(hip, orc, imu_window):
+    s = DmsaOptimSettings.sliding_window(use_imu=True, num_iter=4)
+    p_ref, p_gpu = imu_window.copy(), imu_window.copy()
+    rep_ref, _, _ = orc.optimize_window(p_ref, s)
+    rep = hip.DmsaOptimizer(pose_table_host=True).optimizeSet(p_gpu, s)
+    assert rep.iterations == rep_ref.iterations and rep.stop_reason == rep_ref.stop_reason
+    dt, dr = _pose_diff(orc, p_ref, p_gpu)
+    assert dt < 1e-4 and dr < 1e-4, (dt, dr)
+
+
+def test_few_gaussians_abort(hip, orc):
+    prob = synth.window_problem(seed=2, scans=2, rings=4, az_steps=16, num_static=0)
+    s = DmsaOptimSettings.sliding_window(num_iter=3)
+    p_ref, p_gpu = prob.copy(), prob.copy()
+    rep_ref, _, _ = orc.optimize_window(p_ref, s)
+    rep = hip.DmsaOptimizer(pose_table_host=True).optimizeSet(p_gpu, s)
+    assert rep_ref.stop_reason == 1 and rep.stop_reason == 1  # DMSA_STOP_FEW_GAUSSIANS
+    assert rep.iterations == rep_ref.iterations == 1
+    dt, dr = _pose_diff(orc, p_ref, p_gpu)
+    assert dt < 1e-12 and dr < 1e-12
+
+
+# ---- keyframe model -------------------------------------------------------------------------------------------------
+def test_keyframe_tables_and_split_gaussians(hip, orc, small_keyframes):
+    prob = small_keyframes
+    s = DmsaOptimSettings.keyframe_map()
+    opt = hip.DmsaOptimizer(pose_table_host=True)
+    opt.upload(prob)
+    tab = opt.poseTables(prob.getPoseParameters())[0]
+    ref_tab = orc.keyframe_pose_table(prob)
+    assert np.array_equal(tab, ref_tab)
+    glob = opt.updateGlobalPoints(0)
+    rows = np.repeat(np.arange(prob.numFrames, dtype=np.int32), np.diff(prob.frameOffsets))
+    g_ref = orc.transform_points(ref_tab, prob.localPoints, rows)
+    assert np.array_equal(glob[:, :3], g_ref[:, :3])
+    # normals rotated with the 3-term x0 + (x1 + x2) order
+    R = ref_tab.reshape(-1, 3, 4)[rows][:, :, :3]
+    nl = prob.localNormals[:, :3]
+    f = np.float32
+    t = (R * nl[:, None, :]).astype(f)
+    n_ref = (t[:, :, 0] + (t[:, :, 1] + t[:, :, 2]).astype(f)).astype(f)
+    n4 = np.concatenate([n_ref, np.zeros((n_ref.shape[0], 1), f)], axis=1)
+    M, Mm = opt.buildGaussians(s)
+    ref = orc.Gaussians(g_ref, prob.ringIds, prob.minGridSize, s, normals4=n4)
+    assert (M, Mm) == (ref.M, ref.Mm)
+    seg, memb, info, w = opt.gaussians()
+    assert np.array_equal(seg, ref.seg_offset) and np.array_equal(memb, ref.members)
+    # the split really happened somewhere (a set whose members are not one contiguous leaf run)
+    ref_nosplit = orc.Gaussians(g_ref, prob.ringIds, prob.minGridSize, DmsaOptimSettings(min_num_points_per_set=10), normals4=n4)
+    assert ref.M != ref_nosplit.M or ref.Mm != ref_nosplit.Mm
+
+
+def test_optimize_keyframes_matches_oracle(hip, orc, small_keyframes):
+    s = DmsaOptimSettings.keyframe_map(num_iter=3)
+    p_ref, p_gpu = small_keyframes.copy(), small_keyframes.copy()
+    rep_ref, _, _ = orc.optimize_keyframes(p_ref, s)
+    rep = hip.DmsaOptimizer(pose_table_host=True).optimizeSet(p_gpu, s)
+    assert rep.iterations == rep_ref.iterations and rep.stop_reason == rep_ref.stop_reason
+    dt, dr = _pose_diff(orc, p_ref, p_gpu)
+    assert dt < 1e-4 and dr < 1e-4, (dt, dr)
