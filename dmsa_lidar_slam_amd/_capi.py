@@ -29,6 +29,7 @@ STOP_NUM_ITER, STOP_FEW_GAUSSIANS, STOP_NAN, STOP_NO_IMPROVEMENT, STOP_EPSILON =
 
 FLAG_POSE_TABLE_HOST = 0x1
 FLAG_FIXED_ITERS = 0x2
+FLAG_MIRROR_SUMS = 0x4
 
 
 class Settings(C.Structure):
@@ -128,6 +129,11 @@ class VoxelLevelInfo(C.Structure):
     ]
 
 
+class IterTrace(C.Structure):
+    _fields_ = [("M", C.c_int32), ("M1", C.c_int32), ("Mm", C.c_int64), ("error0", C.c_double), ("step_norm", C.c_double),
+                ("best_k", C.c_int32), ("pad", C.c_int32)]
+
+
 class Timing(C.Structure):
     _fields_ = [
         ("residual_kernel_ms", C.c_double),
@@ -197,6 +203,7 @@ def load_library() -> C.CDLL:
         "dmsa_get_gaussians": (C.c_int, [vp, c_int32_p, c_int32_p, c_float_p, c_float_p]),
         "dmsa_get_timing": (C.c_int, [vp, C.POINTER(Timing), C.c_int32]),
         "dmsa_synchronize": (C.c_int, [vp]),
+        "dmsa_get_trace": (C.c_int, [vp, C.POINTER(IterTrace), C.c_int32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -210,5 +217,5 @@ EXPORTED_SYMBOLS = (
     "dmsa_create dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
     "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
     "dmsa_set_params dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
-    "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize"
+    "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace"
 ).split()

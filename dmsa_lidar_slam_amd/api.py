@@ -23,10 +23,11 @@ class DmsaError(RuntimeError):
 class DmsaOptimizer:
     """One context == one GPU == one host thread (the reference's optimizer is not re-entrant either)."""
 
-    def __init__(self, device: int = 0, pose_table_host: bool = False, fixed_iters: bool = False):
+    def __init__(self, device: int = 0, pose_table_host: bool = False, fixed_iters: bool = False, mirror_sums: bool = False):
         self._lib = capi.load_library()
         self._ctx = C.c_void_p()
         flags = (capi.FLAG_POSE_TABLE_HOST if pose_table_host else 0) | (capi.FLAG_FIXED_ITERS if fixed_iters else 0)
+        flags |= capi.FLAG_MIRROR_SUMS if mirror_sums else 0
         rc = self._lib.dmsa_create(int(device), flags, C.byref(self._ctx))
         if rc != capi.DMSA_OK:
             self._ctx = None
@@ -177,6 +178,11 @@ class DmsaOptimizer:
         t = capi.Timing()
         self._check(self._lib.dmsa_get_timing(self._ctx, C.byref(t), int(reset)), "get_timing")
         return t
+
+    def trace(self, capacity: int = 256):
+        buf = (capi.IterTrace * capacity)()
+        n = self._lib.dmsa_get_trace(self._ctx, buf, capacity)
+        return [dict(M=t.M, M1=t.M1, Mm=t.Mm, error0=t.error0, step_norm=t.step_norm, best_k=t.best_k) for t in buf[: max(n, 0)]]
 
     def synchronize(self):
         self._check(self._lib.dmsa_synchronize(self._ctx), "synchronize")

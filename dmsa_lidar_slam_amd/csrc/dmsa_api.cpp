@@ -96,6 +96,7 @@ struct dmsa_ctx {
     double t_ms[T_COUNT] = {0, 0, 0, 0, 0, 0};
     int64_t residual_launches = 0, residual_evals = 0;
     int evaluations = 0;
+    std::vector<dmsa_iter_trace> trace;
 };
 
 namespace {
@@ -325,12 +326,12 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
         {
             ScopedTimer tm(ctx, T_FIT);
             launch_gauss_fit(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(), counts, l, ctx->d_info12.as<float>(),
-                             ctx->stream);
+                             (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
         }
     }
     {
         ScopedTimer tm(ctx, T_FIT);
-        launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), nullptr, ctx->stream);
+        launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
     }
     GaussCounts h{};
     HIPCHK(hipMemcpyAsync(&h, ctx->d_counts.p, sizeof(GaussCounts), hipMemcpyDeviceToHost, ctx->stream));
@@ -364,7 +365,7 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
     {
         ScopedTimer tm(ctx, T_RESIDUAL);
         launch_residuals(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tables.as<float>(), ctx->rows, ctx->M,
-                         B, ctx->d_wg_seg.as<int32_t>(), ctx->num_wg, ctx->d_E.as<double>(), ctx->ldE, ctx->stream);
+                         B, ctx->d_wg_seg.as<int32_t>(), ctx->num_wg, ctx->d_E.as<double>(), ctx->ldE, (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
     }
     ctx->residual_launches += 1;
     ctx->residual_evals += B;
@@ -396,6 +397,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
     int stop = DMSA_STOP_NUM_ITER, iters = 0, bestK = 0;
     double error0 = 0.0, stepNorm = 0.0;
     ctx->evaluations = 0;
+    ctx->trace.clear();
     const double increment = 1.0 * std::sqrt((double)std::numeric_limits<float>::epsilon());
     const double one_div_incr = 1.0 / increment;
 
@@ -410,6 +412,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
         CHK(build_tables(ctx, 1, globs));
         CHK(transform_points(ctx, 0));
         CHK(build_gaussians(ctx, s));  // :78-86, :96
+        ctx->trace.push_back(dmsa_iter_trace{ctx->M, ctx->M1, ctx->Mm, 0.0, 0.0, 0, 0});
         if (ctx->M < s.min_num_gaussians) {  // :89-93
             stop = DMSA_STOP_FEW_GAUSSIANS;
             break;
@@ -486,6 +489,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
         double ss = 0.0;
         for (double v : step) ss += v * v;
         stepNorm = std::sqrt(ss);
+        ctx->trace.back().error0 = error0, ctx->trace.back().step_norm = stepNorm, ctx->trace.back().best_k = bestK;
         if (bestK == 0 && !fixed) {  // :130-134 — the set is left at raw + 0.9*step (last trial), not restored
             stop = DMSA_STOP_NO_IMPROVEMENT;
             break;
@@ -875,6 +879,13 @@ int dmsa_get_timing(dmsa_ctx* ctx, dmsa_timing* t, int32_t reset) {
         ctx->residual_launches = 0, ctx->residual_evals = 0;
     }
     return DMSA_OK;
+}
+
+int dmsa_get_trace(dmsa_ctx* ctx, dmsa_iter_trace* out, int32_t capacity) {
+    if (!ctx || !out || capacity < 0) return DMSA_ERR_INVALID;
+    const int n = std::min<int>(capacity, (int)ctx->trace.size());
+    for (int i = 0; i < n; ++i) out[i] = ctx->trace[(size_t)i];
+    return n;
 }
 
 int dmsa_synchronize(dmsa_ctx* ctx) {

@@ -75,13 +75,14 @@ void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start
                            const int32_t* pos_slot_rank /* or null */, const float4* local, const GaussCounts* counts, int level, int64_t n,
                            float4* memb_local, int32_t* memb_idx, int32_t* seg_off, hipStream_t s);
 // ---- K3: Gaussian fit -------------------------------------------------------------------------------------
+// mirror == true: sums run serially in member order (bit-reproducible against the CPU restatement)
 void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const GaussCounts* counts, int level,
-                      float* info12, hipStream_t s);
-void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, double* scratch, hipStream_t s);
+                      float* info12, bool mirror, hipStream_t s);
+void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, bool mirror, hipStream_t s);
 // ---- K4: correspondence kernel ------------------------------------------------------------------------------
 void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t* wg_seg, hipStream_t s);
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
-                      const int32_t* wg_seg, int num_wg, double* E, int64_t ldE, hipStream_t s);
+                      const int32_t* wg_seg, int num_wg, double* E, int64_t ldE, bool mirror, hipStream_t s);
 // ---- K5: normal equations + squared-error sums -------------------------------------------------------------
 // Hp = [J | e0]^T [J | e0] of size (P+1)^2, col-major, J.col(k) = inv_h * (E[k+1] - E[0]) over `rows` rows
 void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s);

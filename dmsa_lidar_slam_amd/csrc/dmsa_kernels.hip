@@ -774,6 +774,18 @@ __device__ void inverse3_f(const float m[3][3], float inv[3][3]) {
         for (int c = 0; c < 3; ++c) inv[r][c] = cof[c][r] * invdet;
 }
 
+__device__ void finish_gaussian(double a0, double a1, double a2, double a3, double a4, double a5, int n, float* o) {
+    const double denom = (double)(n - 1);
+    float cov[3][3], inv[3][3];
+    cov[0][0] = (float)(a0 / denom), cov[0][1] = cov[1][0] = (float)(a1 / denom), cov[0][2] = cov[2][0] = (float)(a2 / denom);
+    cov[1][1] = (float)(a3 / denom), cov[1][2] = cov[2][1] = (float)(a4 / denom), cov[2][2] = (float)(a5 / denom);
+    limit_covariance_f(cov);
+    inverse3_f(cov, inv);
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) o[3 * c + r] = inv[r][c];
+    o[9] = 0.0f, o[10] = (float)n, o[11] = 0.0f;
+}
+
 __global__ __launch_bounds__(256) void k_gauss_fit(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
                                                    const float4* __restrict__ global, const GaussCounts* __restrict__ counts, int level,
                                                    float* __restrict__ info12) {
@@ -799,23 +811,41 @@ __global__ __launch_bounds__(256) void k_gauss_fit(const int32_t* __restrict__ s
             a3 += (double)cy * (double)cy, a4 += (double)cy * (double)cz, a5 += (double)cz * (double)cz;
         }
         a0 = wave_allsum(a0), a1 = wave_allsum(a1), a2 = wave_allsum(a2), a3 = wave_allsum(a3), a4 = wave_allsum(a4), a5 = wave_allsum(a5);
-        if (lane == 0) {
-            const double denom = (double)(n - 1);
-            float cov[3][3], inv[3][3];
-            cov[0][0] = (float)(a0 / denom), cov[0][1] = cov[1][0] = (float)(a1 / denom), cov[0][2] = cov[2][0] = (float)(a2 / denom);
-            cov[1][1] = (float)(a3 / denom), cov[1][2] = cov[2][1] = (float)(a4 / denom), cov[2][2] = (float)(a5 / denom);
-            limit_covariance_f(cov);
-            inverse3_f(cov, inv);
-            float* o = info12 + (size_t)g * 12;
-            for (int c = 0; c < 3; ++c)
-                for (int r = 0; r < 3; ++r) o[3 * c + r] = inv[r][c];
-            o[9] = 0.0f, o[10] = (float)n, o[11] = 0.0f;
+        if (lane == 0) finish_gaussian(a0, a1, a2, a3, a4, a5, n, info12 + (size_t)g * 12);
+    }
+}
+
+// Mirror variant: one thread per Gaussian, sums in member order exactly like the CPU restatement (bit-reproducible).
+__global__ __launch_bounds__(256) void k_gauss_fit_mirror(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
+                                                          const float4* __restrict__ global, const GaussCounts* __restrict__ counts, int level,
+                                                          float* __restrict__ info12) {
+    const int gbase = level == 0 ? 0 : counts->level[0].num_gauss;
+    const int gend = gbase + counts->level[level].num_gauss;
+    const int stride = gridDim.x * blockDim.x;
+    for (int g = gbase + blockIdx.x * blockDim.x + threadIdx.x; g < gend; g += stride) {
+        const int b = seg_off[g], e = seg_off[g + 1], n = e - b;
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int j = b; j < e; ++j) {
+            const float4 p = global[memb_idx[j]];
+            sx += (double)p.x, sy += (double)p.y, sz += (double)p.z;
         }
+        const float mx = (float)(sx / (double)n), my = (float)(sy / (double)n), mz = (float)(sz / (double)n);
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+        for (int j = b; j < e; ++j) {
+            const float4 p = global[memb_idx[j]];
+            const float cx = p.x - mx, cy = p.y - my, cz = p.z - mz;
+            a0 += (double)cx * (double)cx, a1 += (double)cx * (double)cy, a2 += (double)cx * (double)cz;
+            a3 += (double)cy * (double)cy, a4 += (double)cy * (double)cz, a5 += (double)cz * (double)cz;
+        }
+        finish_gaussian(a0, a1, a2, a3, a4, a5, n, info12 + (size_t)g * 12);
     }
 }
 void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const GaussCounts* counts, int level, float* info12,
-                      hipStream_t s) {
-    hipLaunchKernelGGL(k_gauss_fit, dim3(2048), dim3(256), 0, s, seg_off, memb_idx, global, counts, level, info12);
+                      bool mirror, hipStream_t s) {
+    if (mirror)
+        hipLaunchKernelGGL(k_gauss_fit_mirror, dim3(1024), dim3(256), 0, s, seg_off, memb_idx, global, counts, level, info12);
+    else
+        hipLaunchKernelGGL(k_gauss_fit, dim3(2048), dim3(256), 0, s, seg_off, memb_idx, global, counts, level, info12);
 }
 
 // Gaussians.h:170-179: w_k = (1/n_k) * obsWeight_k, divided by the mean over all sets (double sum, rounded once)
@@ -839,9 +869,27 @@ __global__ __launch_bounds__(1024) void k_rebalancing_weights(const int32_t* __r
     if (threadIdx.x == 0) counts->weight_mean = mean;
     for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = info12[(size_t)g * 12 + 9] / mean;
 }
-void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, double* scratch, hipStream_t s) {
-    (void)scratch;
-    hipLaunchKernelGGL(k_rebalancing_weights, dim3(1), dim3(1024), 0, s, seg_off, counts, info12);
+__global__ __launch_bounds__(1024) void k_rebalancing_weights_mirror(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts,
+                                                                     float* __restrict__ info12) {
+    __shared__ float s_mean;
+    const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
+    for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = (1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int g = 0; g < M; ++g) s += (double)info12[(size_t)g * 12 + 9];
+        s_mean = (float)(s / (double)M);
+        counts->weight_mean = s_mean;
+    }
+    __syncthreads();
+    const float mean = s_mean;
+    for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = info12[(size_t)g * 12 + 9] / mean;
+}
+void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, bool mirror, hipStream_t s) {
+    if (mirror)
+        hipLaunchKernelGGL(k_rebalancing_weights_mirror, dim3(1), dim3(1024), 0, s, seg_off, counts, info12);
+    else
+        hipLaunchKernelGGL(k_rebalancing_weights, dim3(1), dim3(1024), 0, s, seg_off, counts, info12);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -921,11 +969,70 @@ __global__ __launch_bounds__(512) void k_residuals(const float4* __restrict__ me
         if (lane == 0) E[(size_t)b * ldE + g] = sqrt(fabs(acc));
     }
 }
+// Mirror variant: one thread per Gaussian; the float mean and the double sum run in member order exactly like
+// DmsaOptimizer.h:247-264 (bit-reproducible against the CPU restatement; used by the parity path).
+template <bool kTableInLds>
+__global__ __launch_bounds__(256) void k_residuals_mirror(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off,
+                                                          const float4* __restrict__ info12, const float4* __restrict__ tables, int rows, int M,
+                                                          double* __restrict__ E, int64_t ldE) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_tab[];
+    const int b = blockIdx.y;
+    const float4* gtab = tables + (size_t)b * rows * 3;
+    if (kTableInLds) {
+        for (int i = threadIdx.x; i < rows * 3; i += blockDim.x) s_tab[i] = gtab[i];
+        __syncthreads();
+    }
+    const float4* T = kTableInLds ? s_tab : gtab;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= M) return;
+    const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
+    float mx = 0.0f, my = 0.0f, mz = 0.0f;
+    for (int j = 0; j < n; ++j) {
+        const float4 p = memb[off0 + j];
+        const int row = __float_as_int(p.w);
+        const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p.x, p.y, p.z);
+        mx = mx + q.x, my = my + q.y, mz = mz + q.z;
+    }
+    const float nf = (float)n;
+    mx = mx / nf, my = my / nf, mz = mz / nf;
+    const float4 i0 = info12[3 * g], i1 = info12[3 * g + 1], i2 = info12[3 * g + 2];
+    const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
+    double acc = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const float4 p = memb[off0 + j];
+        const int row = __float_as_int(p.w);
+        const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p.x, p.y, p.z);
+        const float d0 = q.x - mx, d1 = q.y - my, d2 = q.z - mz;
+        const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
+        const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
+        const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
+        const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
+        acc += (double)sum3f(v0 * d0, v1 * d1, v2 * d2);
+    }
+    E[(size_t)b * ldE + g] = sqrt(fabs(acc));
+}
+
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
-                      const int32_t* wg_seg, int num_wg, double* E, int64_t ldE, hipStream_t s) {
+                      const int32_t* wg_seg, int num_wg, double* E, int64_t ldE, bool mirror, hipStream_t s) {
     if (M <= 0 || B <= 0) return;
     const size_t lds = (size_t)rows * 48;
     static bool attr_set = false;
+    if (mirror) {
+        static bool attr_set_m = false;
+        const dim3 grid((M + 255) / 256, B);
+        if (lds <= 160 * 1024 - 1024) {
+            if (!attr_set_m) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals_mirror<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+                attr_set_m = true;
+            }
+            hipLaunchKernelGGL(k_residuals_mirror<true>, grid, dim3(256), lds, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
+                               reinterpret_cast<const float4*>(tables), rows, M, E, ldE);
+        } else {
+            hipLaunchKernelGGL(k_residuals_mirror<false>, grid, dim3(256), 0, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
+                               reinterpret_cast<const float4*>(tables), rows, M, E, ldE);
+        }
+        return;
+    }
     if (lds <= 160 * 1024 - 1024) {
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);

@@ -136,10 +136,24 @@ typedef struct dmsa_report {
     int32_t evaluations;       /* forward evaluations done in total                              */
 } dmsa_report;
 
+/* per-iteration record of the last optimize call (diagnostics / parity tests) */
+typedef struct dmsa_iter_trace {
+    int32_t M, M1;             /* Gaussians in total / from the first resolution                  */
+    int64_t Mm;                /* memberships                                                     */
+    double  error0;            /* e^T e before the step                                           */
+    double  step_norm;         /* norm of the clamped LM step                                     */
+    int32_t best_k;            /* adaptiveStepSize result                                         */
+    int32_t pad;
+} dmsa_iter_trace;
+
 /* context flags */
 #define DMSA_FLAG_POSE_TABLE_HOST 0x1u /* build dense pose tables in host double math (bit-reproducible
                                           against the CPU oracle); default is the device kernel      */
 #define DMSA_FLAG_FIXED_ITERS     0x2u /* benchmarking: ignore the no-improvement / epsilon exits    */
+#define DMSA_FLAG_MIRROR_SUMS     0x4u /* parity path: per-Gaussian sums run serially in member order, exactly like the
+                                          reference's loops (DmsaOptimizer.h:247-264), instead of as wave reductions.
+                                          Bit-reproducible against the CPU oracle; slower.  The default (wave-parallel)
+                                          path differs only in float summation order (~1e-7 relative per residual).     */
 
 int  dmsa_create(int device, uint32_t flags, dmsa_ctx** out);
 void dmsa_destroy(dmsa_ctx* ctx);
@@ -211,6 +225,8 @@ typedef struct dmsa_timing {
 } dmsa_timing;
 int dmsa_get_timing(dmsa_ctx* ctx, dmsa_timing* t, int32_t reset);
 int dmsa_synchronize(dmsa_ctx* ctx);
+/* copies up to `capacity` per-iteration records of the last optimize call; returns the number written (>= 0) */
+int dmsa_get_trace(dmsa_ctx* ctx, dmsa_iter_trace* out, int32_t capacity);
 
 #ifdef __cplusplus
 }
