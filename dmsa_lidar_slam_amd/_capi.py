@@ -139,6 +139,7 @@ class Timing(C.Structure):
         ("residual_kernel_ms", C.c_double),
         ("residual_launches", C.c_int64),
         ("residual_evaluations", C.c_int64),
+        ("residual_algorithmic_bytes", C.c_double),
         ("voxelize_ms", C.c_double),
         ("gaussian_fit_ms", C.c_double),
         ("pose_table_ms", C.c_double),
@@ -186,6 +187,8 @@ def load_library() -> C.CDLL:
         "dmsa_optimize_window": (C.c_int, [vp, C.POINTER(WindowProblem), C.POINTER(Settings), C.POINTER(Report)]),
         "dmsa_optimize_keyframes": (C.c_int, [vp, C.POINTER(KeyframeProblem), C.POINTER(Settings), C.POINTER(Report)]),
         "dmsa_get_global_points": (C.c_int, [vp, c_float_p, C.c_int64]),
+        "dmsa_optimize_resident": (C.c_int, [vp, C.POINTER(Settings), C.POINTER(Report)]),
+        "dmsa_get_poses": (C.c_int, [vp, c_double_p, c_double_p]),
         "dmsa_window_upload": (C.c_int, [vp, C.POINTER(WindowProblem)]),
         "dmsa_keyframes_upload": (C.c_int, [vp, C.POINTER(KeyframeProblem)]),
         "dmsa_centralize": (C.c_int, [vp]),
@@ -217,5 +220,5 @@ EXPORTED_SYMBOLS = (
     "dmsa_create dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
     "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
     "dmsa_set_params dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
-    "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace"
+    "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_optimize_resident dmsa_get_poses"
 ).split()

@@ -68,6 +68,21 @@ class DmsaOptimizer:
         self._problem, self._cprob = pointSetToOptimize, cp
         return rep
 
+    def optimizeResident(self, settings: DmsaOptimSettings) -> capi.Report:
+        """optimizeSet on the problem already resident in HBM (after upload() or a previous optimizeSet)."""
+        cs = settings.to_c()
+        rep = capi.Report()
+        self._check(self._lib.dmsa_optimize_resident(self._ctx, C.byref(cs), C.byref(rep)), "optimize_resident")
+        return rep
+
+    def poses(self):
+        """Current relative poses (n,3),(n,3) of the resident problem."""
+        p = self._problem
+        n = p.relOrientations.shape[0]
+        ro, rt = np.zeros((n, 3)), np.zeros((n, 3))
+        self._check(self._lib.dmsa_get_poses(self._ctx, capi.ptr(ro, C.c_double), capi.ptr(rt, C.c_double)), "get_poses")
+        return ro, rt
+
     def globalPoints(self) -> np.ndarray:
         n = self._num_points()
         out = np.zeros((n, 4), np.float32)

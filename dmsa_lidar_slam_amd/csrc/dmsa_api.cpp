@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -85,6 +86,7 @@ struct dmsa_ctx {
     int M = 0, M1 = 0;
     int64_t Mm = 0;
     int num_wg = 0;
+    int cfg_num_wg = 768, cfg_big_n = 512;  // correspondence-kernel launch shape (DMSA_K4_WGS / DMSA_K4_BIG override)
     bool gaussians_valid = false;
     // residual batches
     DevBuf d_E, d_ne_partial, d_Hp, d_sq_partial, d_sq_out;
@@ -95,6 +97,7 @@ struct dmsa_ctx {
     std::vector<hipEvent_t> free_events;
     double t_ms[T_COUNT] = {0, 0, 0, 0, 0, 0};
     int64_t residual_launches = 0, residual_evals = 0;
+    double residual_bytes = 0.0;
     int evaluations = 0;
     std::vector<dmsa_iter_trace> trace;
 };
@@ -342,7 +345,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
     ctx->Mm = (int64_t)h.level[0].num_memb + h.level[1].num_memb;
     if (ctx->M > 0) {
         // enough workgroups to fill 256 CUs several times over, but never more workgroups than Gaussians
-        int wg = 1024;
+        int wg = ctx->cfg_num_wg;
         if (wg > ctx->M) wg = ctx->M;
         ctx->num_wg = wg;
         launch_segment_partition(ctx->d_seg_off.as<int32_t>(), ctx->M, wg, ctx->d_wg_seg.as<int32_t>(), ctx->stream);
@@ -365,10 +368,11 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
     {
         ScopedTimer tm(ctx, T_RESIDUAL);
         launch_residuals(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tables.as<float>(), ctx->rows, ctx->M,
-                         B, ctx->d_wg_seg.as<int32_t>(), ctx->num_wg, ctx->d_E.as<double>(), ctx->ldE, (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
+                         B, ctx->d_wg_seg.as<int32_t>(), ctx->num_wg, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE, (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
     }
     ctx->residual_launches += 1;
     ctx->residual_evals += B;
+    ctx->residual_bytes += 16.0 * (double)ctx->Mm + 48.0 * ctx->M + (double)B * (48.0 * ctx->rows + 8.0 * ctx->M);
     HIPCHK(hipGetLastError());
     const int a = ctx->extra_rows;
     if (a > 0 && extra != nullptr) {
@@ -538,6 +542,8 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     dmsa_ctx* ctx = new (std::nothrow) dmsa_ctx();
     if (!ctx) return DMSA_ERR_NOMEM;
     ctx->device = device, ctx->flags = flags;
+    if (const char* e = std::getenv("DMSA_K4_WGS")) ctx->cfg_num_wg = std::max(1, std::min(4000, std::atoi(e)));
+    if (const char* e = std::getenv("DMSA_K4_BIG")) ctx->cfg_big_n = std::max(1, std::atoi(e));
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return DMSA_ERR_HIP;
@@ -871,12 +877,13 @@ int dmsa_get_timing(dmsa_ctx* ctx, dmsa_timing* t, int32_t reset) {
     drain_timers(ctx);
     if (t) {
         t->residual_kernel_ms = ctx->t_ms[T_RESIDUAL], t->residual_launches = ctx->residual_launches, t->residual_evaluations = ctx->residual_evals;
+        t->residual_algorithmic_bytes = ctx->residual_bytes;
         t->voxelize_ms = ctx->t_ms[T_VOXEL], t->gaussian_fit_ms = ctx->t_ms[T_FIT], t->pose_table_ms = ctx->t_ms[T_TABLE];
         t->normal_eq_ms = ctx->t_ms[T_NORMAL], t->total_ms = ctx->t_ms[T_TOTAL];
     }
     if (reset) {
         for (double& v : ctx->t_ms) v = 0.0;
-        ctx->residual_launches = 0, ctx->residual_evals = 0;
+        ctx->residual_launches = 0, ctx->residual_evals = 0, ctx->residual_bytes = 0.0;
     }
     return DMSA_OK;
 }
@@ -900,6 +907,18 @@ int dmsa_optimize_window(dmsa_ctx* ctx, dmsa_window_problem* p, const dmsa_setti
     CHK(dmsa_window_upload(ctx, p));
     CHK(optimize(ctx, *s, rep));
     write_back_poses(ctx->win.ctrl, p->rel_orient, p->rel_transl);
+    return DMSA_OK;
+}
+
+int dmsa_optimize_resident(dmsa_ctx* ctx, const dmsa_settings* s, dmsa_report* rep) {
+    if (!ctx || !s || ctx->model == MODEL_NONE) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    return optimize(ctx, *s, rep);
+}
+
+int dmsa_get_poses(dmsa_ctx* ctx, double* rel_orient, double* rel_transl) {
+    if (!ctx || ctx->model == MODEL_NONE || !rel_orient || !rel_transl) return DMSA_ERR_INVALID;
+    write_back_poses(chain(ctx), rel_orient, rel_transl);
     return DMSA_OK;
 }
 

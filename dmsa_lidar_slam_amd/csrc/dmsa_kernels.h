@@ -82,7 +82,7 @@ void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, flo
 // ---- K4: correspondence kernel ------------------------------------------------------------------------------
 void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t* wg_seg, hipStream_t s);
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
-                      const int32_t* wg_seg, int num_wg, double* E, int64_t ldE, bool mirror, hipStream_t s);
+                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s);
 // ---- K5: normal equations + squared-error sums -------------------------------------------------------------
 // Hp = [J | e0]^T [J | e0] of size (P+1)^2, col-major, J.col(k) = inv_h * (E[k+1] - E[0]) over `rows` rows
 void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s);

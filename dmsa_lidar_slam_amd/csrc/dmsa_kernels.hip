@@ -920,33 +920,58 @@ void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t
     hipLaunchKernelGGL(k_segment_partition, dim3((num_wg + 1 + 255) / 256), dim3(256), 0, s, seg_off, M, num_wg, wg_seg);
 }
 
-// One wave per Gaussian; blockIdx.y selects the pose table (evaluation).  The dense pose table of that evaluation
-// sits in LDS ((n_t+1) x 48 B) so the per-point row lookup never leaves the CU.
+// blockIdx.y selects the pose table (evaluation); its dense table sits in LDS ((n_t+1) x 48 B) so the per-point row
+// lookup never leaves the CU.  Gaussians are very unevenly sized (median ~15 members, maximum > 10^4): sets below
+// `big_n` members are handled one per wave (round-robin over the workgroup's waves), larger ones by all waves of the
+// workgroup together with a fixed-order cross-wave combine through LDS — results do not depend on scheduling.
+struct ResidualAcc {
+    float sx, sy, sz;
+};
+
 template <bool kTableInLds>
 __global__ __launch_bounds__(512) void k_residuals(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off,
                                                    const float4* __restrict__ info12, const float4* __restrict__ tables, int rows, int M,
-                                                   const int32_t* __restrict__ wg_seg, double* __restrict__ E, int64_t ldE) {
-    extern __shared__ __attribute__((aligned(16))) float4 s_tab[];
+                                                   const int32_t* __restrict__ wg_seg, int big_n, double* __restrict__ E, int64_t ldE) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
+    // layout: [0, 256 B) cross-wave scratch, then the pose table
+    float* s_red = reinterpret_cast<float*>(s_dyn);            // 8 waves x 4 floats
+    double* s_redd = reinterpret_cast<double*>(s_dyn) + 16;    // 8 doubles at byte 128
+    float4* s_tab = s_dyn + 16;
     const int b = blockIdx.y;
     const float4* gtab = tables + (size_t)b * rows * 3;
     if (kTableInLds) {
         for (int i = threadIdx.x; i < rows * 3; i += blockDim.x) s_tab[i] = gtab[i];
-        __syncthreads();
     }
+    __syncthreads();
     const float4* T = kTableInLds ? s_tab : gtab;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int g_end = wg_seg[blockIdx.x + 1];
-    for (int g = wg_seg[blockIdx.x] + wave; g < g_end; g += nw) {
+    const int g_begin = wg_seg[blockIdx.x], g_end = wg_seg[blockIdx.x + 1];
+    int small_turn = 0;
+    for (int g = g_begin; g < g_end; ++g) {
         const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
+        const bool coop = n >= big_n;  // uniform over the workgroup
+        if (!coop) {
+            const bool mine = (small_turn % nw) == wave;
+            ++small_turn;
+            if (!mine) continue;
+        }
+        const int j0 = coop ? wave * 64 + lane : lane;
+        const int jstep = coop ? nw * 64 : 64;
         // pass 1: mean of the transformed members (float, DmsaOptimizer.h:247-254)
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-        for (int j = lane; j < n; j += 64) {
+        for (int j = j0; j < n; j += jstep) {
             const float4 p = memb[off0 + j];
             const int row = __float_as_int(p.w);
             const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p.x, p.y, p.z);
             sx += q.x, sy += q.y, sz += q.z;
         }
         sx = wave_allsum(sx), sy = wave_allsum(sy), sz = wave_allsum(sz);
+        if (coop) {
+            if (lane == 0) s_red[4 * wave] = sx, s_red[4 * wave + 1] = sy, s_red[4 * wave + 2] = sz;
+            __syncthreads();
+            sx = 0.0f, sy = 0.0f, sz = 0.0f;
+            for (int w = 0; w < nw; ++w) sx += s_red[4 * w], sy += s_red[4 * w + 1], sz += s_red[4 * w + 2];
+        }
         const float nf = (float)n;
         const float mx = sx / nf, my = sy / nf, mz = sz / nf;
         // information matrix (column-major) + rebalancing weight: 3 float4 per Gaussian
@@ -954,7 +979,7 @@ __global__ __launch_bounds__(512) void k_residuals(const float4* __restrict__ me
         const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
         // pass 2: sum_j (float)((w d^T) A d) accumulated in double (DmsaOptimizer.h:259-264)
         double acc = 0.0;
-        for (int j = lane; j < n; j += 64) {
+        for (int j = j0; j < n; j += jstep) {
             const float4 p = memb[off0 + j];
             const int row = __float_as_int(p.w);
             const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p.x, p.y, p.z);
@@ -966,9 +991,21 @@ __global__ __launch_bounds__(512) void k_residuals(const float4* __restrict__ me
             acc += (double)sum3f(v0 * d0, v1 * d1, v2 * d2);
         }
         acc = wave_allsum(acc);
-        if (lane == 0) E[(size_t)b * ldE + g] = sqrt(fabs(acc));
+        if (coop) {
+            if (lane == 0) s_redd[wave] = acc;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double tot = 0.0;
+                for (int w2 = 0; w2 < nw; ++w2) tot += s_redd[w2];
+                E[(size_t)b * ldE + g] = sqrt(fabs(tot));
+            }
+            __syncthreads();  // scratch is reused by the next cooperative Gaussian
+        } else if (lane == 0) {
+            E[(size_t)b * ldE + g] = sqrt(fabs(acc));
+        }
     }
 }
+
 // Mirror variant: one thread per Gaussian; the float mean and the double sum run in member order exactly like
 // DmsaOptimizer.h:247-264 (bit-reproducible against the CPU restatement; used by the parity path).
 template <bool kTableInLds>
@@ -1013,7 +1050,7 @@ __global__ __launch_bounds__(256) void k_residuals_mirror(const float4* __restri
 }
 
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
-                      const int32_t* wg_seg, int num_wg, double* E, int64_t ldE, bool mirror, hipStream_t s) {
+                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s) {
     if (M <= 0 || B <= 0) return;
     const size_t lds = (size_t)rows * 48;
     static bool attr_set = false;
@@ -1033,16 +1070,16 @@ void launch_residuals(const float4* memb_local, const int32_t* seg_off, const fl
         }
         return;
     }
-    if (lds <= 160 * 1024 - 1024) {
+    if (lds <= 160 * 1024 - 1280) {
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_residuals<true>, dim3(num_wg, B), dim3(512), lds, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
-                           reinterpret_cast<const float4*>(tables), rows, M, wg_seg, E, ldE);
+        hipLaunchKernelGGL(k_residuals<true>, dim3(num_wg, B), dim3(512), lds + 256, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
+                           reinterpret_cast<const float4*>(tables), rows, M, wg_seg, big_n, E, ldE);
     } else {
-        hipLaunchKernelGGL(k_residuals<false>, dim3(num_wg, B), dim3(512), 0, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
-                           reinterpret_cast<const float4*>(tables), rows, M, wg_seg, E, ldE);
+        hipLaunchKernelGGL(k_residuals<false>, dim3(num_wg, B), dim3(512), 256, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
+                           reinterpret_cast<const float4*>(tables), rows, M, wg_seg, big_n, E, ldE);
     }
 }
 

@@ -1,0 +1,55 @@
+"""Keyframe-neighbourhood sharding: one neighbourhood per GPU, one all-gather of relative poses.
+
+The reference optimises ONE neighbourhood (fromId..newest) per new keyframe.  The seam that makes sharding possible is
+already in it: keyframe poses are parameterised as RELATIVE poses (ConsecutivePoses.h:45-67) and
+MapManagement::getSubmap / updatePosesFromSubmap (MapManagement.h:254-288) cut out an independent problem whose first
+frame is fixed and write its relative poses back.  Here the ring buffer is cut into `world` contiguous neighbourhoods
+that share one boundary frame (to_i == from_{i+1}); rank i owns the relative-pose columns from_i+1..to_i, runs a full
+optimizeSet on its own GPU with only its frames resident, and the only exchange is ONE all-gather of
+(to_i - from_i) x 6 doubles per rank (<= 1.5 KB: latency-bound over xGMI, no collective inside the iterations).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .problems import DmsaOptimSettings, MapManagement
+
+
+def neighbourhood_ranges(num_frames: int, world: int):
+    """Contiguous [from, to] frame ranges (inclusive) sharing one boundary frame; every rank gets >= 2 frames."""
+    if world < 1 or num_frames < world + 1:
+        raise ValueError("need at least world + 1 keyframes")
+    edges = np.linspace(0, num_frames - 1, world + 1).round().astype(int)
+    return [(int(edges[i]), int(edges[i + 1])) for i in range(world)]
+
+
+def optimize_neighbourhoods(full_map: MapManagement, settings: DmsaOptimSettings, optimize_fn, rank: int = 0, world: int = 1,
+                            dist=None, device=None):
+    """Shard `full_map` over `world` ranks and optimise this rank's neighbourhood with `optimize_fn(submap, settings)`
+    (which updates the submap's relative poses in place).  With world > 1, `dist` is an initialised torch.distributed
+    module (backend nccl == RCCL on the GPU box, gloo in the CPU tests).  Every rank returns with the SAME updated
+    relative poses in full_map."""
+    ranges = neighbourhood_ranges(full_map.numFrames, world)
+    f0, f1 = ranges[rank]
+    sub = full_map.getSubmap(f0, f1)
+    report = optimize_fn(sub, settings)
+    width = max(t - f for f, t in ranges)
+    mine = np.zeros((width, 6))
+    mine[: f1 - f0, :3] = sub.relOrientations[1:]
+    mine[: f1 - f0, 3:] = sub.relTranslations[1:]
+    if world > 1:
+        import torch
+
+        t = torch.from_numpy(mine)
+        if device is not None:
+            t = t.to(device)
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)  # the one exchange step of the sharded pass
+        parts = [g.cpu().numpy() for g in gathered]
+    else:
+        parts = [mine]
+    for (f, t_), part in zip(ranges, parts):  # == updatePosesFromSubmap for every neighbourhood (disjoint columns)
+        k = t_ - f
+        full_map.relOrientations[f + 1:t_ + 1] = part[:k, :3]
+        full_map.relTranslations[f + 1:t_ + 1] = part[:k, 3:]
+    return report

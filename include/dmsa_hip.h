@@ -165,6 +165,11 @@ void dmsa_default_settings(dmsa_settings* s);
 int dmsa_optimize_window(dmsa_ctx* ctx, dmsa_window_problem* p, const dmsa_settings* s, dmsa_report* rep);
 /* == keyframeMapOptimizer.optimizeSet(*currSubmap, optimSettingsMap)            DmsaSlam.h:228 */
 int dmsa_optimize_keyframes(dmsa_ctx* ctx, dmsa_keyframe_problem* p, const dmsa_settings* s, dmsa_report* rep);
+/* Same loop on the problem already resident in HBM (dmsa_window_upload / dmsa_keyframes_upload or a previous optimize
+ * call); poses continue from the context's current state and are returned through dmsa_get_poses. */
+int dmsa_optimize_resident(dmsa_ctx* ctx, const dmsa_settings* s, dmsa_report* rep);
+/* current relative poses of the resident problem: 3 x n col-major doubles each (n = control poses / keyframes) */
+int dmsa_get_poses(dmsa_ctx* ctx, double* rel_orient, double* rel_transl);
 /* final globalPoints of the last optimize call (DmsaOptimizer.h:149); n x 4 floats */
 int dmsa_get_global_points(dmsa_ctx* ctx, float* xyz_out, int64_t capacity_points);
 
@@ -217,6 +222,7 @@ typedef struct dmsa_timing {
     double residual_kernel_ms;   /* accumulated time inside the correspondence kernel                 */
     int64_t residual_launches;
     int64_t residual_evaluations;
+    double residual_algorithmic_bytes; /* sum over launches of 16*Mm + 48*M + B*(48*rows + 8*M) */
     double voxelize_ms;
     double gaussian_fit_ms;
     double pose_table_ms;

@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Turn rocprofv3 output (rocpd sqlite db from --kernel-trace --stats, and/or --pmc counter CSVs) into the small text
+summaries committed under profiles/.
+
+    python scripts/summarize_profile.py stats gpurun_out/prof1/r1_results.db  > profiles/r01_kernel_stats.txt
+    python scripts/summarize_profile.py pmc   gpurun_out/pmc                  > profiles/r01_pmc_k_residuals.txt
+"""
+import collections
+import csv
+import glob
+import os
+import sqlite3
+import sys
+
+
+def stats(db_path):
+    db = sqlite3.connect(db_path)
+    cur = db.cursor()
+    rows = cur.execute(
+        "select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    print(f"# rocprofv3 --kernel-trace --stats summary of {os.path.basename(db_path)} (durations in us)")
+    print(f"# total kernel time {tot / 1e3:.1f} us over {sum(r[1] for r in rows)} dispatches")
+    print(f"{'kernel':72s} {'calls':>6s} {'total_us':>10s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
+    for name, n, total, avg, mn, mx in rows:
+        short = name.split("(")[0].replace("void ", "")
+        if "rocprim" in short:
+            short = "rocprim::" + short.split("::")[-1][:48] + "<...>"
+        print(f"{short[:72]:72s} {n:6d} {total / 1e3:10.1f} {avg / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * total / tot:6.2f}")
+    # per grid shape for the correspondence kernel
+    print("\n# k_residuals by launch shape (grid_y = evaluations per launch)")
+    for gy, n, avg in cur.execute(
+            "select grid_y, count(*), avg(end-start) from kernels where name like '%k_residuals%' group by grid_y order by grid_y"):
+        print(f"  evaluations/launch={gy:4d} launches={n:4d} avg_us={avg / 1e3:9.2f} us_per_evaluation={avg / 1e3 / max(1, gy):8.2f}")
+
+
+def pmc(root):
+    print(f"# rocprofv3 --pmc passes for kernels matching k_residuals ({root}); one pass per counter group, kernel-trace only")
+    per_shape = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in sorted(glob.glob(os.path.join(root, "*", "*_counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            per_shape[r["Grid_Size"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for shape, ctrs in per_shape.items():
+        print(f"\n## dispatch grid_size={shape} threads (workgroup 512)")
+        for name in sorted(ctrs):
+            v = ctrs[name]
+            print(f"  {name:24s} mean={sum(v) / len(v):14.5g}  n={len(v)}")
+        c = {k: sum(v) / len(v) for k, v in ctrs.items()}
+        if "FETCH_SIZE" in c:
+            # FETCH_SIZE is in KiB; on gfx950 it reports half of a wide coalesced stream (MI355X_MICROARCH.md, HBM) -> x2
+            print(f"  -> HBM read traffic ~ {c['FETCH_SIZE'] * 1024 * 2 / 1e6:.1f} MB per launch (FETCH_SIZE x 1024 x 2, gfx950 correction)")
+        if "WRITE_SIZE" in c:
+            print(f"  -> HBM write traffic ~ {c['WRITE_SIZE'] * 1024 / 1e6:.2f} MB per launch (uncalibrated)")
+        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+            print(f"  -> L2 hit rate {c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']):.3f}")
+        if "SQ_WAVE_CYCLES" in c:
+            for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
+                if k in c:
+                    print(f"  -> {k}/SQ_WAVE_CYCLES = {c[k] / c['SQ_WAVE_CYCLES']:.3f}")
+
+
+if __name__ == "__main__":
+    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
