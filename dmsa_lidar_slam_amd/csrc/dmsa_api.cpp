@@ -83,6 +83,9 @@ struct dmsa_ctx {
     double level_res[2] = {0, 0};
     // Gaussians
     DevBuf d_memb_local, d_memb_idx, d_seg_off, d_info12, d_wg_seg;
+    DevBuf d_memb_tile, d_tiles, d_tile_counts, d_tile_rows, d_fallback;
+    int num_tiles = 0, num_fallback = 0, tile_max_rows = 0;
+    bool use_tiles = true;  // DMSA_K4_TILES=0 selects the streaming kernel
     int M = 0, M1 = 0;
     int64_t Mm = 0;
     int num_wg = 0;
@@ -189,6 +192,14 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
     HIPCHK(ctx->d_seg_off.ensure((2 * n + 2) * 4));
     HIPCHK(ctx->d_info12.ensure((2 * n / 2 + 16) * 48));  // sets have >= 2 members (two distinct ids)
     HIPCHK(ctx->d_wg_seg.ensure(4096 * 4));
+    // tiled correspondence kernels: windows of T/2 members plus own-tile Gaussians (> T/2 members each):
+    // tiles <= 6*Mm/T + 1 with Mm <= 2n; one row list of `rows` entries per tile
+    const size_t max_tiles = 12 * n / (size_t)tile_points() + 64;
+    HIPCHK(ctx->d_memb_tile.ensure(2 * n * 16));
+    HIPCHK(ctx->d_tiles.ensure(max_tiles * sizeof(TileDesc)));
+    HIPCHK(ctx->d_tile_counts.ensure(sizeof(TileCounts)));
+    HIPCHK(ctx->d_tile_rows.ensure(max_tiles * (size_t)ctx->rows * 4));
+    HIPCHK(ctx->d_fallback.ensure((2 * n / 16384 + 16) * 8));
     return DMSA_OK;
 }
 
@@ -336,9 +347,19 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
         ScopedTimer tm(ctx, T_FIT);
         launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
     }
+    TileCounts htc{};
+    const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS);
+    if (tiles_on) {
+        ScopedTimer tm(ctx, T_FIT);
+        launch_build_tiles(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_memb_local.as<float4>(), ctx->rows, ctx->d_tiles.as<TileDesc>(),
+                           ctx->d_tile_counts.as<TileCounts>(), ctx->d_fallback.as<int2>(), ctx->d_memb_tile.as<float4>(), ctx->d_tile_rows.as<int32_t>(),
+                           ctx->stream);
+        HIPCHK(hipMemcpyAsync(&htc, ctx->d_tile_counts.p, sizeof(TileCounts), hipMemcpyDeviceToHost, ctx->stream));
+    }
     GaussCounts h{};
     HIPCHK(hipMemcpyAsync(&h, ctx->d_counts.p, sizeof(GaussCounts), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #2: M sizes every later launch
+    ctx->num_tiles = htc.num_tiles, ctx->num_fallback = htc.num_fallback, ctx->tile_max_rows = htc.max_rows;
     HIPCHK(hipGetLastError());
     ctx->M1 = h.level[0].num_gauss;
     ctx->M = h.level[0].num_gauss + h.level[1].num_gauss;
@@ -365,7 +386,14 @@ int ensure_E(dmsa_ctx* ctx, int B) {
 }
 int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
     CHK(ensure_E(ctx, B));
-    {
+    const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS) && ctx->num_tiles > 0;
+    if (tiles_on) {
+        ScopedTimer tm(ctx, T_RESIDUAL);
+        launch_residuals_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(),
+                               ctx->d_tables.as<float>(), ctx->rows, ctx->M, B, ctx->d_tiles.as<TileDesc>(), ctx->d_tile_rows.as<int32_t>(), ctx->num_tiles,
+                               ctx->tile_max_rows, ctx->d_fallback.as<int2>(), ctx->num_fallback, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE,
+                               ctx->stream);
+    } else {
         ScopedTimer tm(ctx, T_RESIDUAL);
         launch_residuals(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tables.as<float>(), ctx->rows, ctx->M,
                          B, ctx->d_wg_seg.as<int32_t>(), ctx->num_wg, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE, (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
@@ -544,6 +572,7 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     ctx->device = device, ctx->flags = flags;
     if (const char* e = std::getenv("DMSA_K4_WGS")) ctx->cfg_num_wg = std::max(1, std::min(4000, std::atoi(e)));
     if (const char* e = std::getenv("DMSA_K4_BIG")) ctx->cfg_big_n = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("DMSA_K4_TILES")) ctx->use_tiles = std::atoi(e) != 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return DMSA_ERR_HIP;
@@ -563,7 +592,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
                       &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_head, &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
                       &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_slot_acc, &ctx->d_slot_cnt, &ctx->d_gauss_of_slot, &ctx->d_memb_of_slot,
                       &ctx->d_pos_slot_rank, &ctx->d_sort_tmp, &ctx->d_scan_tmp, &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_seg_off,
-                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
+                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_counts, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

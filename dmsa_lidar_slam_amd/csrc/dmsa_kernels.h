@@ -34,6 +34,19 @@ struct LevelCounts {
     int32_t pad;
 };
 
+// tiles of whole Gaussians for the tiled correspondence kernels
+struct TileDesc {
+    int32_t g0, g1;        // Gaussians [g0, g1)
+    int32_t p0, p1;        // members [p0, p1) of the membership array
+    int32_t row_off;       // first entry of this tile's pose-table row list
+    int32_t nrows;         // distinct pose-table rows referenced by the tile
+    int32_t kind;          // 0: staged through LDS, 1: single Gaussian held in registers, 2: streaming fallback
+    int32_t pad;
+};
+struct TileCounts {
+    int32_t num_tiles, num_fallback, max_rows, pad;
+};
+
 struct GaussCounts {       // both levels, read back once per iteration
     LevelCounts level[2];
     float weight_mean;
@@ -82,7 +95,14 @@ void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, flo
 // ---- K4: correspondence kernel ------------------------------------------------------------------------------
 void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t* wg_seg, hipStream_t s);
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
-                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s);
+                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s, bool pairs = false);
+// tiled variant (default fast path): tiles + per-tile row lists are rebuilt once per iteration
+void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, int rows, TileDesc* tiles, TileCounts* tc,
+                        int2* fallback, float4* memb_tile, int32_t* tile_rows, hipStream_t s);
+int tile_points();
+void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables,
+                            int rows, int M, int B, const TileDesc* tiles, const int32_t* tile_rows, int num_tiles, int max_rows,
+                            const int2* fallback, int num_fallback, int big_n, double* E, int64_t ldE, hipStream_t s);
 // ---- K5: normal equations + squared-error sums -------------------------------------------------------------
 // Hp = [J | e0]^T [J | e0] of size (P+1)^2, col-major, J.col(k) = inv_h * (E[k+1] - E[0]) over `rows` rows
 void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s);

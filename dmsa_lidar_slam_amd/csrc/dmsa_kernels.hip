@@ -15,6 +15,7 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 
 #include "../../include/dmsa_hip.h"
 
@@ -23,15 +24,35 @@ namespace dmsa {
 // ------------------------------------------------------------------------------------------------------------
 // wave64 helpers
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_allsum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+// DPP (data-parallel primitive) lane movement keeps wave-wide sums in the VALU instead of round trips through the LDS
+// crossbar (ds_bpermute): row_shr:1/2/4/8 inside each 16-lane row, then row_bcast:15 / row_bcast:31 across rows (gfx9).
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, kRowMask, 0xf, true));
+}
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <class T>
+__device__ __forceinline__ T wave_incl_scan_dpp(T v) {
+    v += dpp_mov<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_mov<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_mov<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_mov<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_mov<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+    v += dpp_mov<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
     return v;
 }
+__device__ __forceinline__ float wave_allsum(float v) {
+    v = wave_incl_scan_dpp(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ double wave_allsum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+    v = wave_incl_scan_dpp(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 __device__ __forceinline__ int wave_allmin(int v) {
 #pragma unroll
@@ -931,7 +952,7 @@ struct ResidualAcc {
 template <bool kTableInLds>
 __global__ __launch_bounds__(512) void k_residuals(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off,
                                                    const float4* __restrict__ info12, const float4* __restrict__ tables, int rows, int M,
-                                                   const int32_t* __restrict__ wg_seg, int big_n, double* __restrict__ E, int64_t ldE) {
+                                                   const int32_t* __restrict__ wg_seg, int seg_stride, int big_n, double* __restrict__ E, int64_t ldE) {
     extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
     // layout: [0, 256 B) cross-wave scratch, then the pose table
     float* s_red = reinterpret_cast<float*>(s_dyn);            // 8 waves x 4 floats
@@ -945,7 +966,8 @@ __global__ __launch_bounds__(512) void k_residuals(const float4* __restrict__ me
     __syncthreads();
     const float4* T = kTableInLds ? s_tab : gtab;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int g_begin = wg_seg[blockIdx.x], g_end = wg_seg[blockIdx.x + 1];
+    // seg_stride 1: consecutive boundaries wg_seg[w], wg_seg[w+1]; seg_stride 2: explicit (begin, end) pairs
+    const int g_begin = wg_seg[blockIdx.x * seg_stride], g_end = wg_seg[blockIdx.x * seg_stride + 1];
     int small_turn = 0;
     for (int g = g_begin; g < g_end; ++g) {
         const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
@@ -1006,6 +1028,394 @@ __global__ __launch_bounds__(512) void k_residuals(const float4* __restrict__ me
     }
 }
 
+// ---- tiled correspondence kernels -----------------------------------------------------------------------------------
+// The membership array is cut into tiles of whole Gaussians (<= kTilePoints members).  A workgroup loads its tile ONCE
+// into registers and then loops over the pose tables of its evaluation chunk: per table it stages only the rows its
+// tile references (a few dozen of the ~1000, found once per iteration by k_tile_rows) into LDS, transforms every point
+// once into an LDS SoA buffer, and lets its waves sweep the Gaussians of the tile out of LDS.  HBM sees each member
+// once per launch; everything per evaluation runs out of registers and LDS.
+constexpr int kTilePoints = 4096;
+constexpr int kTileThreads = 512;
+constexpr int kTilePpt = kTilePoints / kTileThreads;   // 8 members per thread
+constexpr int kTileGauss = 512;                         // Gaussians per tile (10-bit local id)
+// packed .w of a tile member: bits 0-11 rank of its pose-table row in the tile's row list, bits 12-21 Gaussian index
+// inside the tile, bit 31 set on the last member of a Gaussian
+__device__ __forceinline__ int tw_row(int w) { return w & 0xfff; }
+__device__ __forceinline__ int tw_gauss(int w) { return (w >> 12) & 0x3ff; }
+__device__ __forceinline__ bool tw_end(int w) { return w < 0; }
+
+__global__ __launch_bounds__(1024) void k_build_tiles(const int32_t* __restrict__ seg_off, const GaussCounts* __restrict__ counts,
+                                                      TileDesc* __restrict__ tiles, TileCounts* __restrict__ tc, int2* __restrict__ fallback) {
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    __shared__ int s_nfb;
+    __shared__ int s_nbig;
+    const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
+    const int half = kTilePoints / 2;
+    if (threadIdx.x == 0) s_carry = 0, s_nfb = 0, s_nbig = 0;
+    __syncthreads();
+    auto own = [&](int g) { return seg_off[g + 1] - seg_off[g] > half; };
+    // a tile ends at own-tile Gaussians, at T/2-member window boundaries and every kTileGauss Gaussians
+    auto head = [&](int g) { return g == 0 || own(g) || own(g - 1) || (seg_off[g] / half) != (seg_off[g - 1] / half) || (g % kTileGauss) == 0; };
+    for (int base = 0; base < M; base += 1024) {
+        const int g = base + threadIdx.x;
+        const int h = (g < M && head(g)) ? 1 : 0;
+        // block inclusive scan of h
+        int v = h;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(v, d);
+            if (lane >= d) v += o;
+        }
+        if (lane == 63) s_wave[wave] = v;
+        __syncthreads();
+        int pre = s_carry;
+        for (int w = 0; w < wave; ++w) pre += s_wave[w];
+        const int incl = pre + v;
+        if (g < M) {
+            const int t = incl - 1;
+            if (h) {
+                const int n = seg_off[g + 1] - seg_off[g];
+                tiles[t].g0 = g, tiles[t].p0 = seg_off[g];
+                int kind = 0;
+                if (n > kTilePoints) kind = 1;  // streamed by k_residuals_big, any size
+                tiles[t].kind = kind;
+                tiles[t].row_off = 0, tiles[t].nrows = 0, tiles[t].pad = 0;
+                if (kind == 1) fallback[atomicAdd(&s_nbig, 1)] = make_int2(t, g);  // (tile index, Gaussian) of a streamed tile
+            }
+            if (g == M - 1 || head(g + 1)) tiles[t].g1 = g + 1, tiles[t].p1 = seg_off[g + 1];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tc->num_tiles = s_carry, tc->num_fallback = s_nbig, tc->max_rows = 0;
+}
+
+// Per tile: which pose-table rows do its members reference?  Writes the ascending row list, a copy of the members
+// whose .w is the rank of their row in that list, and the maximum list length (sizes the LDS table of the kernels).
+__global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles, TileCounts* __restrict__ tc, const float4* __restrict__ memb,
+                                                   const int32_t* __restrict__ seg_off, int rows, float4* __restrict__ memb_tile,
+                                                   int32_t* __restrict__ tile_rows) {
+    extern __shared__ uint32_t s_bm[];  // words bitmap, then words prefix
+    const int words = (rows + 31) / 32;
+    uint32_t* s_pre = s_bm + words;
+    const int nt = tc->num_tiles;
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        const int p0 = tiles[t].p0, p1 = tiles[t].p1, tg0 = tiles[t].g0, tg1 = tiles[t].g1;
+        for (int w = threadIdx.x; w < words; w += blockDim.x) s_bm[w] = 0u;
+        __syncthreads();
+        for (int i = p0 + threadIdx.x; i < p1; i += blockDim.x) {
+            const int row = __float_as_int(memb[i].w);
+            atomicOr(&s_bm[row >> 5], 1u << (row & 31));
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0;
+            for (int w = 0; w < words; ++w) {
+                s_pre[w] = acc;
+                acc += __popc(s_bm[w]);
+            }
+            tiles[t].row_off = t * rows;
+            tiles[t].nrows = (int)acc;
+            atomicMax(&tc->max_rows, (int)acc);
+        }
+        __syncthreads();
+        for (int w = threadIdx.x; w < words; w += blockDim.x) {
+            uint32_t bits = s_bm[w];
+            int k = (int)s_pre[w];
+            while (bits) {
+                const int bit = __ffs(bits) - 1;
+                tile_rows[(size_t)t * rows + k] = w * 32 + bit;
+                ++k;
+                bits &= bits - 1;
+            }
+        }
+        for (int i = p0 + threadIdx.x; i < p1; i += blockDim.x) {
+            float4 p = memb[i];
+            const int row = __float_as_int(p.w);
+            const int lrow = (int)s_pre[row >> 5] + __popc(s_bm[row >> 5] & ((1u << (row & 31)) - 1u));
+            int lo = tg0, hi = tg1 - 1;  // Gaussian containing member i: last g with seg_off[g] <= i
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (seg_off[mid] <= i)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            uint32_t packed = (uint32_t)lrow | ((uint32_t)(lo - tg0) << 12);
+            if (i + 1 == seg_off[lo + 1]) packed |= 0x80000000u;
+            p.w = __int_as_float((int)packed);
+            memb_tile[i] = p;
+        }
+        __syncthreads();
+    }
+}
+void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, int rows, TileDesc* tiles, TileCounts* tc,
+                        int2* fallback, float4* memb_tile, int32_t* tile_rows, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(1024), 0, s, seg_off, counts, tiles, tc, fallback);
+    const size_t lds = (size_t)((rows + 31) / 32) * 8;
+    hipLaunchKernelGGL(k_tile_rows, dim3(1024), dim3(256), lds, s, tiles, tc, memb, seg_off, rows, memb_tile, tile_rows);
+}
+int tile_points() { return kTilePoints; }
+
+// Balanced sweep: thread t owns the 8 consecutive members 8t..8t+7 of the tile, so every lane does the same work no matter
+// how the tile is cut into Gaussians.  Per-Gaussian sums come from workgroup-wide inclusive prefix sums in double that are
+// sampled at the last member of each Gaussian (sum_g = P[end_g] - P[end_{g-1}]); a double prefix over <= 4096 float terms
+// carries ~1e-12 relative error, far below the float rounding of the terms themselves, and the order is fixed.
+__device__ __forceinline__ double wave_incl_scan(double v, int) { return wave_incl_scan_dpp(v); }
+
+template <int kMinWaves>
+__global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(const float4* __restrict__ memb_tile, const int32_t* __restrict__ seg_off,
+                                                                  const float4* __restrict__ info12, const float4* __restrict__ tables, int rows,
+                                                                  const TileDesc* __restrict__ tiles, const int32_t* __restrict__ tile_rows, int B,
+                                                                  int b_chunk, double* __restrict__ E, int64_t ldE) {
+    const TileDesc td = tiles[blockIdx.x];
+    if (td.kind != 0) return;
+    extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
+    // LDS carve (bytes): info 512*48 | end-prefix 4 x 513 doubles | mean 3 x 512 floats | wave totals 8 x 4 doubles | pose rows
+    float4* s_info = s_dyn;                                                  // 3 float4 per Gaussian
+    double* s_end = reinterpret_cast<double*>(s_dyn + 3 * kTileGauss);       // [4][kTileGauss + 1], entry 0 == 0
+    float* s_mean = reinterpret_cast<float*>(s_end + 4 * (kTileGauss + 1));  // [3][kTileGauss]
+    float* s_nf = s_mean + 3 * kTileGauss;                                    // [kTileGauss] member counts
+    double* s_wave = reinterpret_cast<double*>(s_nf + kTileGauss + 4);        // 8 waves x 4 doubles; +4 floats keeps s_tab 16-B aligned
+    float4* s_tab = reinterpret_cast<float4*>(s_wave + 32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int np = td.p1 - td.p0, ng = td.g1 - td.g0;
+    float4 pt[kTilePpt];
+#pragma unroll
+    for (int k = 0; k < kTilePpt; ++k) {
+        const int i = kTilePpt * tid + k;
+        pt[k] = i < np ? memb_tile[td.p0 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int q = tid; q < 3 * ng; q += kTileThreads) s_info[q] = info12[3 * td.g0 + q];
+    for (int g = tid; g < ng; g += kTileThreads) s_nf[g] = (float)(seg_off[td.g0 + g + 1] - seg_off[td.g0 + g]);
+    if (tid < 4) s_end[tid * (kTileGauss + 1)] = 0.0;
+    const int32_t* my_rows = tile_rows + td.row_off;
+    const int b_begin = blockIdx.y * b_chunk, b_end = min(B, b_begin + b_chunk);
+    // pose-table rows of the NEXT evaluation are fetched into registers while the current one computes
+    const int nq = td.nrows * 3;
+    const bool prefetch = nq <= 2 * kTileThreads;
+    int src0 = -1, src1 = -1;
+    if (prefetch) {
+        if (tid < nq) src0 = 3 * my_rows[tid / 3] + (tid % 3);
+        if (tid + kTileThreads < nq) src1 = 3 * my_rows[(tid + kTileThreads) / 3] + ((tid + kTileThreads) % 3);
+    }
+    float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0;
+    if (prefetch && b_begin < b_end) {
+        const float4* gtab = tables + (size_t)b_begin * rows * 3;
+        if (src0 >= 0) nx0 = gtab[src0];
+        if (src1 >= 0) nx1 = gtab[src1];
+    }
+    for (int b = b_begin; b < b_end; ++b) {
+        const float4* gtab = tables + (size_t)b * rows * 3;
+        __syncthreads();  // previous evaluation finished reading s_tab / s_end / s_mean
+        if (prefetch) {
+            if (src0 >= 0) s_tab[tid] = nx0;
+            if (src1 >= 0) s_tab[tid + kTileThreads] = nx1;
+            if (b + 1 < b_end) {
+                const float4* ntab = tables + (size_t)(b + 1) * rows * 3;
+                if (src0 >= 0) nx0 = ntab[src0];
+                if (src1 >= 0) nx1 = ntab[src1];
+            }
+        } else {
+            for (int q = tid; q < nq; q += kTileThreads) s_tab[q] = gtab[3 * my_rows[q / 3] + (q % 3)];
+        }
+        __syncthreads();
+        // transform once, keep the global coordinates in registers for both passes
+        float gx[kTilePpt], gy[kTilePpt], gz[kTilePpt];
+        double tx = 0.0, ty = 0.0, tz = 0.0;
+#pragma unroll
+        for (int k = 0; k < kTilePpt; ++k) {
+            gx[k] = 0.f, gy[k] = 0.f, gz[k] = 0.f;
+            if (kTilePpt * tid + k < np) {
+                const int row = tw_row(__float_as_int(pt[k].w));
+                const float3 q = apply_row3(s_tab[3 * row], s_tab[3 * row + 1], s_tab[3 * row + 2], pt[k].x, pt[k].y, pt[k].z);
+                gx[k] = q.x, gy[k] = q.y, gz[k] = q.z;
+                tx += (double)q.x, ty += (double)q.y, tz += (double)q.z;
+            }
+        }
+        // pass 1: prefix sums of the coordinates, sampled at Gaussian ends
+        double ix = wave_incl_scan(tx, lane), iy = wave_incl_scan(ty, lane), iz = wave_incl_scan(tz, lane);
+        if (lane == 63) s_wave[4 * wave] = ix, s_wave[4 * wave + 1] = iy, s_wave[4 * wave + 2] = iz;
+        __syncthreads();
+        double rx = ix - tx, ry = iy - ty, rz = iz - tz;
+        for (int w2 = 0; w2 < wave; ++w2) rx += s_wave[4 * w2], ry += s_wave[4 * w2 + 1], rz += s_wave[4 * w2 + 2];
+#pragma unroll
+        for (int k = 0; k < kTilePpt; ++k) {
+            if (kTilePpt * tid + k < np) {
+                rx += (double)gx[k], ry += (double)gy[k], rz += (double)gz[k];
+                const int wv = __float_as_int(pt[k].w);
+                if (tw_end(wv)) {
+                    const int lg = tw_gauss(wv) + 1;
+                    s_end[lg] = rx, s_end[(kTileGauss + 1) + lg] = ry, s_end[2 * (kTileGauss + 1) + lg] = rz;
+                }
+            }
+        }
+        __syncthreads();
+        for (int g = tid; g < ng; g += kTileThreads) {
+            const float nf = s_nf[g];
+            s_mean[g] = (float)(s_end[g + 1] - s_end[g]) / nf;
+            s_mean[kTileGauss + g] = (float)(s_end[(kTileGauss + 1) + g + 1] - s_end[(kTileGauss + 1) + g]) / nf;
+            s_mean[2 * kTileGauss + g] = (float)(s_end[2 * (kTileGauss + 1) + g + 1] - s_end[2 * (kTileGauss + 1) + g]) / nf;
+        }
+        __syncthreads();
+        // pass 2: Mahalanobis terms (float, reference operation order), prefix-summed in double
+        double tq = 0.0;  // gx[k] is overwritten by the member's Mahalanobis term
+        int cur = -1;
+        float A00 = 0, A10 = 0, A20 = 0, A01 = 0, A11 = 0, A21 = 0, A02 = 0, A12 = 0, A22 = 0, w = 0, mx = 0, my = 0, mz = 0;
+#pragma unroll
+        for (int k = 0; k < kTilePpt; ++k) {
+            if (kTilePpt * tid + k < np) {
+                const int lg = tw_gauss(__float_as_int(pt[k].w));
+                if (lg != cur) {
+                    cur = lg;
+                    const float4 i0 = s_info[3 * lg], i1 = s_info[3 * lg + 1], i2 = s_info[3 * lg + 2];
+                    A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
+                    mx = s_mean[lg], my = s_mean[kTileGauss + lg], mz = s_mean[2 * kTileGauss + lg];
+                }
+                const float d0 = gx[k] - mx, d1 = gy[k] - my, d2 = gz[k] - mz;
+                const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
+                const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
+                const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
+                const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
+                gx[k] = sum3f(v0 * d0, v1 * d1, v2 * d2);
+                tq += (double)gx[k];
+            }
+        }
+        const double iq = wave_incl_scan(tq, lane);
+        if (lane == 63) s_wave[4 * wave + 3] = iq;
+        __syncthreads();
+        double rq = iq - tq;
+        for (int w2 = 0; w2 < wave; ++w2) rq += s_wave[4 * w2 + 3];
+#pragma unroll
+        for (int k = 0; k < kTilePpt; ++k) {
+            if (kTilePpt * tid + k < np) {
+                rq += (double)gx[k];
+                const int wv = __float_as_int(pt[k].w);
+                if (tw_end(wv)) s_end[3 * (kTileGauss + 1) + tw_gauss(wv) + 1] = rq;
+            }
+        }
+        __syncthreads();
+        for (int g = tid; g < ng; g += kTileThreads) {
+            const double tot = s_end[3 * (kTileGauss + 1) + g + 1] - s_end[3 * (kTileGauss + 1) + g];
+            E[(size_t)b * ldE + td.g0 + g] = sqrt(fabs(tot));
+        }
+    }
+}
+
+// Single-Gaussian tiles (more than kTilePoints members, ~30 % of all members at the benchmark size): one 1024-thread
+// workgroup per (Gaussian, evaluation) streams the members twice (second pass from L2) with four loads in flight per lane.
+constexpr int kBigThreads = 1024;
+__device__ __forceinline__ float3 big_point(const float4* __restrict__ s_tab, const float4 p) {
+    const int row = tw_row(__float_as_int(p.w));
+    return apply_row3(s_tab[3 * row], s_tab[3 * row + 1], s_tab[3 * row + 2], p.x, p.y, p.z);
+}
+__global__ __launch_bounds__(kBigThreads) void k_residuals_big(const float4* __restrict__ memb_tile, const float4* __restrict__ info12,
+                                                              const float4* __restrict__ tables, int rows, const TileDesc* __restrict__ tiles,
+                                                              const int2* __restrict__ big_list, const int32_t* __restrict__ tile_rows, int B,
+                                                              int b_chunk, double* __restrict__ E, int64_t ldE) {
+    const TileDesc td = tiles[big_list[blockIdx.x].x];
+    extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
+    float* s_red = reinterpret_cast<float*>(s_dyn);          // 16 waves x 4 floats (256 B)
+    double* s_redd = reinterpret_cast<double*>(s_dyn) + 32;  // 16 doubles (128 B)
+    float4* s_tab = s_dyn + 24;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int np = td.p1 - td.p0, g = td.g0;
+    const float4* mp = memb_tile + td.p0;
+    const float4 i0 = info12[3 * g], i1 = info12[3 * g + 1], i2 = info12[3 * g + 2];
+    const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
+    const int32_t* my_rows = tile_rows + td.row_off;
+    const int b_begin = blockIdx.y * b_chunk, b_end = min(B, b_begin + b_chunk);
+    for (int b = b_begin; b < b_end; ++b) {
+        const float4* gtab = tables + (size_t)b * rows * 3;
+        __syncthreads();
+        for (int q = tid; q < td.nrows * 3; q += kBigThreads) s_tab[q] = gtab[3 * my_rows[q / 3] + (q % 3)];
+        __syncthreads();
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        int j = tid;
+        for (; j + 3 * kBigThreads < np; j += 4 * kBigThreads) {
+            const float4 p0 = mp[j], p1 = mp[j + kBigThreads], p2 = mp[j + 2 * kBigThreads], p3 = mp[j + 3 * kBigThreads];
+            const float3 q0 = big_point(s_tab, p0), q1 = big_point(s_tab, p1), q2 = big_point(s_tab, p2), q3 = big_point(s_tab, p3);
+            sx += q0.x, sy += q0.y, sz += q0.z;
+            sx += q1.x, sy += q1.y, sz += q1.z;
+            sx += q2.x, sy += q2.y, sz += q2.z;
+            sx += q3.x, sy += q3.y, sz += q3.z;
+        }
+        for (; j < np; j += kBigThreads) {
+            const float3 q = big_point(s_tab, mp[j]);
+            sx += q.x, sy += q.y, sz += q.z;
+        }
+        sx = wave_allsum(sx), sy = wave_allsum(sy), sz = wave_allsum(sz);
+        if (lane == 0) s_red[4 * wave] = sx, s_red[4 * wave + 1] = sy, s_red[4 * wave + 2] = sz;
+        __syncthreads();
+        sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (int w2 = 0; w2 < kBigThreads / 64; ++w2) sx += s_red[4 * w2], sy += s_red[4 * w2 + 1], sz += s_red[4 * w2 + 2];
+        const float nf = (float)np;
+        const float mx = sx / nf, my = sy / nf, mz = sz / nf;
+        double acc = 0.0;
+        auto term = [&](const float4 p) {
+            const float3 q = big_point(s_tab, p);
+            const float d0 = q.x - mx, d1 = q.y - my, d2 = q.z - mz;
+            const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
+            const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
+            const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
+            const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
+            return (double)sum3f(v0 * d0, v1 * d1, v2 * d2);
+        };
+        j = tid;
+        for (; j + 3 * kBigThreads < np; j += 4 * kBigThreads) {
+            const float4 p0 = mp[j], p1 = mp[j + kBigThreads], p2 = mp[j + 2 * kBigThreads], p3 = mp[j + 3 * kBigThreads];
+            acc += term(p0);
+            acc += term(p1);
+            acc += term(p2);
+            acc += term(p3);
+        }
+        for (; j < np; j += kBigThreads) acc += term(mp[j]);
+        acc = wave_allsum(acc);
+        if (lane == 0) s_redd[wave] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int w2 = 0; w2 < kBigThreads / 64; ++w2) tot += s_redd[w2];
+            E[(size_t)b * ldE + g] = sqrt(fabs(tot));
+        }
+    }
+}
+
+void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables,
+                            int rows, int M, int B, const TileDesc* tiles, const int32_t* tile_rows, int num_tiles, int max_rows,
+                            const int2* fallback, int num_fallback, int big_n, double* E, int64_t ldE, hipStream_t s) {
+    if (M <= 0 || B <= 0 || num_tiles <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals_tiles<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals_tiles<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals_big), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        attr_set = true;
+    }
+    // evaluations are chunked so that tiles x chunks fills the chip several times over
+    static const int target_wgs = std::getenv("DMSA_K4_TARGET_WGS") ? std::atoi(std::getenv("DMSA_K4_TARGET_WGS")) : 2048;
+    int chunks = (target_wgs + num_tiles - 1) / num_tiles;
+    if (chunks > B) chunks = B;
+    if (chunks < 1) chunks = 1;
+    const int b_chunk = (B + chunks - 1) / chunks;
+    chunks = (B + b_chunk - 1) / b_chunk;
+    const size_t lds_tiles = (size_t)kTileGauss * 48 + (size_t)4 * (kTileGauss + 1) * 8 + (size_t)(4 * kTileGauss + 4) * 4 + 256 + (size_t)max_rows * 48;
+    const size_t lds_big = 384 + (size_t)max_rows * 48;
+    if (big_n == 2)
+        hipLaunchKernelGGL(k_residuals_tiles<2>, dim3(num_tiles, chunks), dim3(kTileThreads), lds_tiles, s, memb_tile, seg_off,
+                           reinterpret_cast<const float4*>(info12), reinterpret_cast<const float4*>(tables), rows, tiles, tile_rows, B, b_chunk, E, ldE);
+    else
+        hipLaunchKernelGGL(k_residuals_tiles<4>, dim3(num_tiles, chunks), dim3(kTileThreads), lds_tiles, s, memb_tile, seg_off,
+                           reinterpret_cast<const float4*>(info12), reinterpret_cast<const float4*>(tables), rows, tiles, tile_rows, B, b_chunk, E, ldE);
+    // the few single-Gaussian tiles are long: give every evaluation its own workgroup
+    if (num_fallback > 0)  // `fallback` lists the single-Gaussian (streamed) tiles
+        hipLaunchKernelGGL(k_residuals_big, dim3(num_fallback, B), dim3(kBigThreads), lds_big, s, memb_tile, reinterpret_cast<const float4*>(info12),
+                           reinterpret_cast<const float4*>(tables), rows, tiles, fallback, tile_rows, B, 1, E, ldE);
+}
+
 // Mirror variant: one thread per Gaussian; the float mean and the double sum run in member order exactly like
 // DmsaOptimizer.h:247-264 (bit-reproducible against the CPU restatement; used by the parity path).
 template <bool kTableInLds>
@@ -1050,8 +1460,9 @@ __global__ __launch_bounds__(256) void k_residuals_mirror(const float4* __restri
 }
 
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
-                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s) {
+                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s, bool pairs) {
     if (M <= 0 || B <= 0) return;
+    const int seg_stride = pairs ? 2 : 1;
     const size_t lds = (size_t)rows * 48;
     static bool attr_set = false;
     if (mirror) {
@@ -1076,10 +1487,10 @@ void launch_residuals(const float4* memb_local, const int32_t* seg_off, const fl
             attr_set = true;
         }
         hipLaunchKernelGGL(k_residuals<true>, dim3(num_wg, B), dim3(512), lds + 256, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
-                           reinterpret_cast<const float4*>(tables), rows, M, wg_seg, big_n, E, ldE);
+                           reinterpret_cast<const float4*>(tables), rows, M, wg_seg, seg_stride, big_n, E, ldE);
     } else {
         hipLaunchKernelGGL(k_residuals<false>, dim3(num_wg, B), dim3(512), 256, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
-                           reinterpret_cast<const float4*>(tables), rows, M, wg_seg, big_n, E, ldE);
+                           reinterpret_cast<const float4*>(tables), rows, M, wg_seg, seg_stride, big_n, E, ldE);
     }
 }
 
