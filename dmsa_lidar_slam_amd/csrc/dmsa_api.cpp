@@ -192,9 +192,9 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
     HIPCHK(ctx->d_seg_off.ensure((2 * n + 2) * 4));
     HIPCHK(ctx->d_info12.ensure((2 * n / 2 + 16) * 48));  // sets have >= 2 members (two distinct ids)
     HIPCHK(ctx->d_wg_seg.ensure(4096 * 4));
-    // tiled correspondence kernels: windows of T/2 members plus own-tile Gaussians (> T/2 members each):
-    // tiles <= 6*Mm/T + 1 with Mm <= 2n; one row list of `rows` entries per tile
-    const size_t max_tiles = 12 * n / (size_t)tile_points() + 64;
+    // tiled correspondence kernels: windows of 3T/4 members plus own-tile Gaussians (> T/4 members each) and their
+    // neighbours: tiles <= (4/3 + 8)*Mm/T + 1 with Mm <= 2n; one row list of `rows` entries per tile
+    const size_t max_tiles = 20 * n / (size_t)tile_points() + 64;
     HIPCHK(ctx->d_memb_tile.ensure(2 * n * 16));
     HIPCHK(ctx->d_tiles.ensure(max_tiles * sizeof(TileDesc)));
     HIPCHK(ctx->d_tile_counts.ensure(sizeof(TileCounts)));

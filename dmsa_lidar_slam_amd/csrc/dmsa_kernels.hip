@@ -1051,10 +1051,11 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const int32_t* __restrict_
     __shared__ int s_nfb;
     __shared__ int s_nbig;
     const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
-    const int half = kTilePoints / 2;
+    const int half = 3 * kTilePoints / 4;      // window of member positions that starts a new tile
+    const int own_n = kTilePoints / 4;         // Gaussians above this size get a tile of their own (tile <= window + own_n)
     if (threadIdx.x == 0) s_carry = 0, s_nfb = 0, s_nbig = 0;
     __syncthreads();
-    auto own = [&](int g) { return seg_off[g + 1] - seg_off[g] > half; };
+    auto own = [&](int g) { return seg_off[g + 1] - seg_off[g] > own_n; };
     // a tile ends at own-tile Gaussians, at T/2-member window boundaries and every kTileGauss Gaussians
     auto head = [&](int g) { return g == 0 || own(g) || own(g - 1) || (seg_off[g] / half) != (seg_off[g - 1] / half) || (g % kTileGauss) == 0; };
     for (int base = 0; base < M; base += 1024) {
@@ -1187,8 +1188,13 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
 #pragma unroll
     for (int k = 0; k < kTilePpt; ++k) {
         const int i = kTilePpt * tid + k;
-        pt[k] = i < np ? memb_tile[td.p0 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v = memb_tile[td.p0 + min(i, np - 1)];  // unconditional load + select keeps pt[] in registers
+        pt[k] = i < np ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    const bool wave_on = kTilePpt * 64 * wave < np;  // wave-uniform: does this wave own any member?
+    bool any_end = false;                               // does this THREAD own the last member of some Gaussian?
+#pragma unroll
+    for (int k = 0; k < kTilePpt; ++k) any_end = any_end || tw_end(__float_as_int(pt[k].w));
     for (int q = tid; q < 3 * ng; q += kTileThreads) s_info[q] = info12[3 * td.g0 + q];
     for (int g = tid; g < ng; g += kTileThreads) s_nf[g] = (float)(seg_off[td.g0 + g + 1] - seg_off[td.g0 + g]);
     if (tid < 4) s_end[tid * (kTileGauss + 1)] = 0.0;
@@ -1223,33 +1229,36 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
             for (int q = tid; q < nq; q += kTileThreads) s_tab[q] = gtab[3 * my_rows[q / 3] + (q % 3)];
         }
         __syncthreads();
-        // transform once, keep the global coordinates in registers for both passes
+        // Slots past the tile's last member hold (0,0,0,row 0): they transform to finite values that only enter the
+        // prefixes AFTER the last Gaussian end, so no per-slot range checks are needed; waves entirely past the end idle.
         float gx[kTilePpt], gy[kTilePpt], gz[kTilePpt];
-        double tx = 0.0, ty = 0.0, tz = 0.0;
+        float fx = 0.0f, fy = 0.0f, fz = 0.0f;
+        if (wave_on) {
 #pragma unroll
-        for (int k = 0; k < kTilePpt; ++k) {
-            gx[k] = 0.f, gy[k] = 0.f, gz[k] = 0.f;
-            if (kTilePpt * tid + k < np) {
+            for (int k = 0; k < kTilePpt; ++k) {
                 const int row = tw_row(__float_as_int(pt[k].w));
                 const float3 q = apply_row3(s_tab[3 * row], s_tab[3 * row + 1], s_tab[3 * row + 2], pt[k].x, pt[k].y, pt[k].z);
                 gx[k] = q.x, gy[k] = q.y, gz[k] = q.z;
-                tx += (double)q.x, ty += (double)q.y, tz += (double)q.z;
+                fx += q.x, fy += q.y, fz += q.z;  // float partial sums over the thread's 8 consecutive members
+                if (k & 1) asm volatile("" ::: "memory");  // no hoisting of later members' LDS reads: bounds live registers
             }
         }
-        // pass 1: prefix sums of the coordinates, sampled at Gaussian ends
-        double ix = wave_incl_scan(tx, lane), iy = wave_incl_scan(ty, lane), iz = wave_incl_scan(tz, lane);
+        // pass 1: workgroup prefix of the per-thread totals (fp64), sampled at Gaussian ends as D_t + float partial
+        const double tx = (double)fx, ty = (double)fy, tz = (double)fz;
+        const double ix = wave_incl_scan(tx, lane), iy = wave_incl_scan(ty, lane), iz = wave_incl_scan(tz, lane);
         if (lane == 63) s_wave[4 * wave] = ix, s_wave[4 * wave + 1] = iy, s_wave[4 * wave + 2] = iz;
         __syncthreads();
-        double rx = ix - tx, ry = iy - ty, rz = iz - tz;
-        for (int w2 = 0; w2 < wave; ++w2) rx += s_wave[4 * w2], ry += s_wave[4 * w2 + 1], rz += s_wave[4 * w2 + 2];
+        if (wave_on && any_end) {
+            double rx = ix - tx, ry = iy - ty, rz = iz - tz;
+            for (int w2 = 0; w2 < wave; ++w2) rx += s_wave[4 * w2], ry += s_wave[4 * w2 + 1], rz += s_wave[4 * w2 + 2];
+            fx = 0.0f, fy = 0.0f, fz = 0.0f;
 #pragma unroll
-        for (int k = 0; k < kTilePpt; ++k) {
-            if (kTilePpt * tid + k < np) {
-                rx += (double)gx[k], ry += (double)gy[k], rz += (double)gz[k];
+            for (int k = 0; k < kTilePpt; ++k) {
+                fx += gx[k], fy += gy[k], fz += gz[k];
                 const int wv = __float_as_int(pt[k].w);
                 if (tw_end(wv)) {
                     const int lg = tw_gauss(wv) + 1;
-                    s_end[lg] = rx, s_end[(kTileGauss + 1) + lg] = ry, s_end[2 * (kTileGauss + 1) + lg] = rz;
+                    s_end[lg] = rx + (double)fx, s_end[(kTileGauss + 1) + lg] = ry + (double)fy, s_end[2 * (kTileGauss + 1) + lg] = rz + (double)fz;
                 }
             }
         }
@@ -1261,40 +1270,40 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
             s_mean[2 * kTileGauss + g] = (float)(s_end[2 * (kTileGauss + 1) + g + 1] - s_end[2 * (kTileGauss + 1) + g]) / nf;
         }
         __syncthreads();
-        // pass 2: Mahalanobis terms (float, reference operation order), prefix-summed in double
-        double tq = 0.0;  // gx[k] is overwritten by the member's Mahalanobis term
-        int cur = -1;
-        float A00 = 0, A10 = 0, A20 = 0, A01 = 0, A11 = 0, A21 = 0, A02 = 0, A12 = 0, A22 = 0, w = 0, mx = 0, my = 0, mz = 0;
+        // pass 2: Mahalanobis terms (float, reference operation order); gx[k] is overwritten by the member's term
+        float fq = 0.0f;
+        if (wave_on) {
 #pragma unroll
-        for (int k = 0; k < kTilePpt; ++k) {
-            if (kTilePpt * tid + k < np) {
+            for (int k = 0; k < kTilePpt; ++k) {
+                // information matrix / weight / mean of this member's Gaussian straight from LDS (consecutive lanes and
+                // slots mostly hit the same Gaussian: broadcast reads)
                 const int lg = tw_gauss(__float_as_int(pt[k].w));
-                if (lg != cur) {
-                    cur = lg;
-                    const float4 i0 = s_info[3 * lg], i1 = s_info[3 * lg + 1], i2 = s_info[3 * lg + 2];
-                    A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
-                    mx = s_mean[lg], my = s_mean[kTileGauss + lg], mz = s_mean[2 * kTileGauss + lg];
-                }
+                const float4 i0 = s_info[3 * lg], i1 = s_info[3 * lg + 1], i2 = s_info[3 * lg + 2];
+                const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
+                const float mx = s_mean[lg], my = s_mean[kTileGauss + lg], mz = s_mean[2 * kTileGauss + lg];
                 const float d0 = gx[k] - mx, d1 = gy[k] - my, d2 = gz[k] - mz;
                 const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
                 const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
                 const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
                 const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
                 gx[k] = sum3f(v0 * d0, v1 * d1, v2 * d2);
-                tq += (double)gx[k];
+                fq += gx[k];
+                asm volatile("" ::: "memory");
             }
         }
+        const double tq = (double)fq;
         const double iq = wave_incl_scan(tq, lane);
         if (lane == 63) s_wave[4 * wave + 3] = iq;
         __syncthreads();
-        double rq = iq - tq;
-        for (int w2 = 0; w2 < wave; ++w2) rq += s_wave[4 * w2 + 3];
+        if (wave_on && any_end) {
+            double rq = iq - tq;
+            for (int w2 = 0; w2 < wave; ++w2) rq += s_wave[4 * w2 + 3];
+            fq = 0.0f;
 #pragma unroll
-        for (int k = 0; k < kTilePpt; ++k) {
-            if (kTilePpt * tid + k < np) {
-                rq += (double)gx[k];
+            for (int k = 0; k < kTilePpt; ++k) {
+                fq += gx[k];
                 const int wv = __float_as_int(pt[k].w);
-                if (tw_end(wv)) s_end[3 * (kTileGauss + 1) + tw_gauss(wv) + 1] = rq;
+                if (tw_end(wv)) s_end[3 * (kTileGauss + 1) + tw_gauss(wv) + 1] = rq + (double)fq;
             }
         }
         __syncthreads();
