@@ -199,7 +199,7 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
     HIPCHK(ctx->d_tiles.ensure(max_tiles * sizeof(TileDesc)));
     HIPCHK(ctx->d_tile_counts.ensure(sizeof(TileCounts)));
     HIPCHK(ctx->d_tile_rows.ensure(max_tiles * (size_t)ctx->rows * 4));
-    HIPCHK(ctx->d_fallback.ensure((2 * n / 16384 + 16) * 8));
+    HIPCHK(ctx->d_fallback.ensure((2 * n / (size_t)tile_points() + 16) * 8));  // single-Gaussian tiles: > T members each
     return DMSA_OK;
 }
 
@@ -307,6 +307,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
     for (int l = 0; l < 2; ++l)
         if (lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
     GaussCounts* counts = ctx->d_counts.as<GaussCounts>();
+    const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS);
     const bool split = s.gauss_split != 0 && ctx->model == MODEL_KEYFRAMES;
     if (split) HIPCHK(ctx->d_pos_slot_rank.ensure((size_t)n * 4));
     for (int l = 0; l < 2; ++l) {
@@ -337,18 +338,14 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
                                   ctx->d_memb_of_slot.as<int32_t>(), split ? ctx->d_pos_slot_rank.as<int32_t>() : nullptr, ctx->d_local.as<float4>(), counts,
                                   l, n, ctx->d_memb_local.as<float4>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), ctx->stream);
         }
-        {
+        if (!tiles_on) {
             ScopedTimer tm(ctx, T_FIT);
             launch_gauss_fit(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(), counts, l, ctx->d_info12.as<float>(),
                              (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
         }
     }
-    {
-        ScopedTimer tm(ctx, T_FIT);
-        launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
-    }
+    // Tiles of whole Gaussians for the fit and the correspondence kernel; their counts travel with M / Mm.
     TileCounts htc{};
-    const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS);
     if (tiles_on) {
         ScopedTimer tm(ctx, T_FIT);
         launch_build_tiles(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_memb_local.as<float4>(), ctx->rows, ctx->d_tiles.as<TileDesc>(),
@@ -360,6 +357,14 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
     HIPCHK(hipMemcpyAsync(&h, ctx->d_counts.p, sizeof(GaussCounts), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #2: M sizes every later launch
     ctx->num_tiles = htc.num_tiles, ctx->num_fallback = htc.num_fallback, ctx->tile_max_rows = htc.max_rows;
+    {
+        ScopedTimer tm(ctx, T_FIT);
+        if (tiles_on && ctx->num_tiles > 0)
+            launch_fit_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_tables.as<float>(), ctx->tile_max_rows,
+                             ctx->d_tiles.as<TileDesc>(), ctx->d_tile_counts.as<TileCounts>(), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
+                             ctx->d_info12.as<float>(), ctx->stream);
+        launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
+    }
     HIPCHK(hipGetLastError());
     ctx->M1 = h.level[0].num_gauss;
     ctx->M = h.level[0].num_gauss + h.level[1].num_gauss;

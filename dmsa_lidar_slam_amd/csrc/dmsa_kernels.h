@@ -100,6 +100,9 @@ void launch_residuals(const float4* memb_local, const int32_t* seg_off, const fl
 void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, int rows, TileDesc* tiles, TileCounts* tc,
                         int2* fallback, float4* memb_tile, int32_t* tile_rows, hipStream_t s);
 int tile_points();
+// Gaussian fit on the tiles (fast path): info12[g] = information matrix of every accepted set, base pose table = table0
+void launch_fit_tiled(const float4* memb_tile, const int32_t* seg_off, const float* table0, int max_rows, const TileDesc* tiles, const TileCounts* tc,
+                      const int2* big_list, const int32_t* tile_rows, float* info12, hipStream_t s);
 void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables,
                             int rows, int M, int B, const TileDesc* tiles, const int32_t* tile_rows, int num_tiles, int max_rows,
                             const int2* fallback, int num_fallback, int big_n, double* E, int64_t ldE, hipStream_t s);

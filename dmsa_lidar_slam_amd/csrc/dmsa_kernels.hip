@@ -1393,6 +1393,178 @@ __global__ __launch_bounds__(kBigThreads) void k_residuals_big(const float4* __r
     }
 }
 
+// ---- tiled Gaussian fit --------------------------------------------------------------------------------------------
+// Same tiles as the correspondence kernel, evaluated once per iteration on the base pose table: members are transformed
+// in registers (bit-identical to k_transform), column sums and centred products are accumulated in fp64 and turned into
+// per-Gaussian sums by workgroup prefix sums sampled at Gaussian ends — every lane does the same work however uneven the
+// Gaussians are.  Replaces the wave-per-Gaussian k_gauss_fit (random gathers, one wave per 10^4-member Gaussian).
+constexpr int kFitOffEnd = 0;
+constexpr int kFitOffMean = kFitOffEnd + 9 * (kTileGauss + 1) * 8;
+constexpr int kFitOffWave = (kFitOffMean + 3 * kTileGauss * 4 + 7) / 8 * 8;
+constexpr int kFitOffTab = (kFitOffWave + 8 * 9 * 8 + 15) / 16 * 16;
+__global__ __launch_bounds__(kTileThreads, 2) void k_fit_tiles(const float4* __restrict__ memb_tile, const int32_t* __restrict__ seg_off,
+                                                               const float4* __restrict__ table0, const TileDesc* __restrict__ tiles,
+                                                               const TileCounts* __restrict__ tc, const int32_t* __restrict__ tile_rows,
+                                                               float* __restrict__ info12) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
+    char* s_base = reinterpret_cast<char*>(s_dyn);
+    double* s_end = reinterpret_cast<double*>(s_base + kFitOffEnd);    // [9][kTileGauss + 1]
+    float* s_mean = reinterpret_cast<float*>(s_base + kFitOffMean);    // [3][kTileGauss]
+    double* s_wave = reinterpret_cast<double*>(s_base + kFitOffWave);  // 8 waves x 9
+    float4* s_tab = reinterpret_cast<float4*>(s_base + kFitOffTab);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = tc->num_tiles;
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        const TileDesc td = tiles[t];
+        if (td.kind != 0) continue;  // uniform
+        const int np = td.p1 - td.p0, ng = td.g1 - td.g0;
+        __syncthreads();
+        for (int q = tid; q < td.nrows * 3; q += kTileThreads) s_tab[q] = table0[3 * tile_rows[td.row_off + q / 3] + (q % 3)];
+        if (tid < 9) s_end[tid * (kTileGauss + 1)] = 0.0;
+        __syncthreads();
+        float gx[kTilePpt], gy[kTilePpt], gz[kTilePpt];
+        int wv[kTilePpt];
+        double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < kTilePpt; ++k) {
+            const int i = kTilePpt * tid + k;
+            const float4 v = memb_tile[td.p0 + min(i, np - 1)];
+            const float4 p = i < np ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[k] = __float_as_int(p.w);
+            const int row = tw_row(wv[k]);
+            const float3 q = apply_row3(s_tab[3 * row], s_tab[3 * row + 1], s_tab[3 * row + 2], p.x, p.y, p.z);
+            gx[k] = q.x, gy[k] = q.y, gz[k] = q.z;
+            acc[0] += (double)q.x, acc[1] += (double)q.y, acc[2] += (double)q.z;
+            asm volatile("" ::: "memory");
+        }
+        double run[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double inc = wave_incl_scan_dpp(acc[c]);
+            if (lane == 63) s_wave[9 * wave + c] = inc;
+            run[c] = inc - acc[c];
+        }
+        __syncthreads();
+        for (int w2 = 0; w2 < wave; ++w2)
+            for (int c = 0; c < 3; ++c) run[c] += s_wave[9 * w2 + c];
+#pragma unroll
+        for (int k = 0; k < kTilePpt; ++k) {
+            run[0] += (double)gx[k], run[1] += (double)gy[k], run[2] += (double)gz[k];
+            if (tw_end(wv[k])) {
+                const int lg = tw_gauss(wv[k]) + 1;
+                for (int c = 0; c < 3; ++c) s_end[c * (kTileGauss + 1) + lg] = run[c];
+            }
+        }
+        __syncthreads();
+        for (int g = tid; g < ng; g += kTileThreads) {
+            const double n = (double)(seg_off[td.g0 + g + 1] - seg_off[td.g0 + g]);
+            for (int c = 0; c < 3; ++c) s_mean[c * kTileGauss + g] = (float)((s_end[c * (kTileGauss + 1) + g + 1] - s_end[c * (kTileGauss + 1) + g]) / n);
+        }
+        __syncthreads();
+        double a6[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < kTilePpt; ++k) {
+            const int lg = tw_gauss(wv[k]);
+            const float cx = gx[k] - s_mean[lg], cy = gy[k] - s_mean[kTileGauss + lg], cz = gz[k] - s_mean[2 * kTileGauss + lg];
+            gx[k] = cx, gy[k] = cy, gz[k] = cz;
+            a6[0] += (double)cx * (double)cx, a6[1] += (double)cx * (double)cy, a6[2] += (double)cx * (double)cz;
+            a6[3] += (double)cy * (double)cy, a6[4] += (double)cy * (double)cz, a6[5] += (double)cz * (double)cz;
+        }
+        double run6[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double inc = wave_incl_scan_dpp(a6[c]);
+            if (lane == 63) s_wave[9 * wave + 3 + c] = inc;
+            run6[c] = inc - a6[c];
+        }
+        __syncthreads();
+        for (int w2 = 0; w2 < wave; ++w2)
+            for (int c = 0; c < 6; ++c) run6[c] += s_wave[9 * w2 + 3 + c];
+#pragma unroll
+        for (int k = 0; k < kTilePpt; ++k) {
+            const float cx = gx[k], cy = gy[k], cz = gz[k];
+            run6[0] += (double)cx * (double)cx, run6[1] += (double)cx * (double)cy, run6[2] += (double)cx * (double)cz;
+            run6[3] += (double)cy * (double)cy, run6[4] += (double)cy * (double)cz, run6[5] += (double)cz * (double)cz;
+            if (tw_end(wv[k])) {
+                const int lg = tw_gauss(wv[k]) + 1;
+                for (int c = 0; c < 6; ++c) s_end[(3 + c) * (kTileGauss + 1) + lg] = run6[c];
+            }
+        }
+        __syncthreads();
+        for (int g = tid; g < ng; g += kTileThreads) {
+            double a[6];
+            for (int c = 0; c < 6; ++c) a[c] = s_end[(3 + c) * (kTileGauss + 1) + g + 1] - s_end[(3 + c) * (kTileGauss + 1) + g];
+            finish_gaussian(a[0], a[1], a[2], a[3], a[4], a[5], seg_off[td.g0 + g + 1] - seg_off[td.g0 + g], info12 + (size_t)(td.g0 + g) * 12);
+        }
+    }
+}
+
+// single-Gaussian tiles: one 1024-thread workgroup streams the members (fp64 block reductions)
+__global__ __launch_bounds__(kBigThreads) void k_fit_big(const float4* __restrict__ memb_tile, const float4* __restrict__ table0,
+                                                        const TileDesc* __restrict__ tiles, const TileCounts* __restrict__ tc,
+                                                        const int2* __restrict__ big_list, const int32_t* __restrict__ tile_rows,
+                                                        float* __restrict__ info12) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
+    double* s_red = reinterpret_cast<double*>(s_dyn);  // 16 waves x 6 doubles (768 B)
+    float4* s_tab = s_dyn + 48;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbig = tc->num_fallback;
+    for (int bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+        const TileDesc td = tiles[big_list[bi].x];
+        const int np = td.p1 - td.p0, g = td.g0;
+        const float4* mp = memb_tile + td.p0;
+        __syncthreads();
+        for (int q = tid; q < td.nrows * 3; q += kBigThreads) s_tab[q] = table0[3 * tile_rows[td.row_off + q / 3] + (q % 3)];
+        __syncthreads();
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int j = tid; j < np; j += kBigThreads) {
+            const float3 q = big_point(s_tab, mp[j]);
+            sx += (double)q.x, sy += (double)q.y, sz += (double)q.z;
+        }
+        sx = wave_allsum(sx), sy = wave_allsum(sy), sz = wave_allsum(sz);
+        if (lane == 0) s_red[6 * wave] = sx, s_red[6 * wave + 1] = sy, s_red[6 * wave + 2] = sz;
+        __syncthreads();
+        sx = 0.0, sy = 0.0, sz = 0.0;
+        for (int w2 = 0; w2 < kBigThreads / 64; ++w2) sx += s_red[6 * w2], sy += s_red[6 * w2 + 1], sz += s_red[6 * w2 + 2];
+        const float mx = (float)(sx / (double)np), my = (float)(sy / (double)np), mz = (float)(sz / (double)np);
+        __syncthreads();
+        double a[6] = {0, 0, 0, 0, 0, 0};
+        for (int j = tid; j < np; j += kBigThreads) {
+            const float3 q = big_point(s_tab, mp[j]);
+            const float cx = q.x - mx, cy = q.y - my, cz = q.z - mz;
+            a[0] += (double)cx * (double)cx, a[1] += (double)cx * (double)cy, a[2] += (double)cx * (double)cz;
+            a[3] += (double)cy * (double)cy, a[4] += (double)cy * (double)cz, a[5] += (double)cz * (double)cz;
+        }
+        for (int c = 0; c < 6; ++c) {
+            a[c] = wave_allsum(a[c]);
+            if (lane == 0) s_red[6 * wave + c] = a[c];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double t6[6] = {0, 0, 0, 0, 0, 0};
+            for (int w2 = 0; w2 < kBigThreads / 64; ++w2)
+                for (int c = 0; c < 6; ++c) t6[c] += s_red[6 * w2 + c];
+            finish_gaussian(t6[0], t6[1], t6[2], t6[3], t6[4], t6[5], np, info12 + (size_t)g * 12);
+        }
+    }
+}
+
+void launch_fit_tiled(const float4* memb_tile, const int32_t* seg_off, const float* table0, int max_rows, const TileDesc* tiles, const TileCounts* tc,
+                      const int2* big_list, const int32_t* tile_rows, float* info12, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fit_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fit_big), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        attr_set = true;
+    }
+    const size_t lds_tiles = (size_t)kFitOffTab + (size_t)max_rows * 48;
+    const size_t lds_big = 768 + (size_t)max_rows * 48;
+    hipLaunchKernelGGL(k_fit_tiles, dim3(1024), dim3(kTileThreads), lds_tiles, s, memb_tile, seg_off, reinterpret_cast<const float4*>(table0), tiles, tc,
+                       tile_rows, info12);
+    hipLaunchKernelGGL(k_fit_big, dim3(256), dim3(kBigThreads), lds_big, s, memb_tile, reinterpret_cast<const float4*>(table0), tiles, tc, big_list,
+                       tile_rows, info12);
+}
+
 void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables,
                             int rows, int M, int B, const TileDesc* tiles, const int32_t* tile_rows, int num_tiles, int max_rows,
                             const int2* fallback, int num_fallback, int big_n, double* E, int64_t ldE, hipStream_t s) {
