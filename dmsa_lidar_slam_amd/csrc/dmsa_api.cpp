@@ -74,7 +74,10 @@ struct dmsa_ctx {
     // pose tables of the current batch
     DevBuf d_tables, d_ctrl, d_stamps, d_fhw, d_trajtime;
     int batch = 0;
-    std::vector<double> h_ctrl;
+    // pinned staging ring for the per-batch control poses (so the H2D copy needs no host synchronisation)
+    double* h_pin = nullptr;
+    size_t h_pin_slot = 0;  // doubles per slot
+    int h_pin_next = 0;
     std::vector<float> h_tables;
     // voxelisation
     DevBuf d_aabb, d_lattice, d_code[2], d_idx[2], d_code_s[2], d_idx_s[2], d_head, d_leaf_incl[2], d_leaf_start[2], d_slot_acc, d_slot_cnt,
@@ -82,9 +85,9 @@ struct dmsa_ctx {
     LatticeTable h_lattice[2];
     double level_res[2] = {0, 0};
     // Gaussians
-    DevBuf d_memb_local, d_memb_idx, d_seg_off, d_info12, d_wg_seg;
+    DevBuf d_memb_local, d_memb_idx, d_memb_g, d_seg_off, d_info12, d_wg_seg;
     DevBuf d_memb_tile, d_tiles, d_tile_counts, d_tile_rows, d_fallback;
-    int num_tiles = 0, num_fallback = 0, tile_max_rows = 0;
+    int num_tiles = 0, num_fallback = 0, tile_max_rows = 0, tile_max_gauss = 0;
     bool use_tiles = true;  // DMSA_K4_TILES=0 selects the streaming kernel
     int M = 0, M1 = 0;
     int64_t Mm = 0;
@@ -189,6 +192,7 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
     // memberships: every point belongs to at most one set per resolution
     HIPCHK(ctx->d_memb_local.ensure(2 * n * 16));
     HIPCHK(ctx->d_memb_idx.ensure(2 * n * 4));
+    HIPCHK(ctx->d_memb_g.ensure(2 * n * 4));
     HIPCHK(ctx->d_seg_off.ensure((2 * n + 2) * 4));
     HIPCHK(ctx->d_info12.ensure((2 * n / 2 + 16) * 48));  // sets have >= 2 members (two distinct ids)
     HIPCHK(ctx->d_wg_seg.ensure(4096 * 4));
@@ -233,8 +237,18 @@ int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs) {
         HIPCHK(hipStreamSynchronize(ctx->stream));  // h_tables is reused by the next batch
     } else {
         HIPCHK(ctx->d_ctrl.ensure(globs.size() * 8));
-        HIPCHK(hipMemcpyAsync(ctx->d_ctrl.p, globs.data(), globs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));  // `globs` is caller-owned host memory
+        constexpr int kPinSlots = 4;  // at least one stream synchronisation separates reuse of a slot (4 syncs per iteration)
+        if (globs.size() > ctx->h_pin_slot) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+            ctx->h_pin = nullptr;
+            ctx->h_pin_slot = globs.size() + globs.size() / 2 + 64;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), ctx->h_pin_slot * kPinSlots * sizeof(double), hipHostMallocDefault));
+        }
+        double* slot = ctx->h_pin + (size_t)ctx->h_pin_next * ctx->h_pin_slot;
+        ctx->h_pin_next = (ctx->h_pin_next + 1) % kPinSlots;
+        std::memcpy(slot, globs.data(), globs.size() * 8);
+        HIPCHK(hipMemcpyAsync(ctx->d_ctrl.p, slot, globs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         if (ctx->model == MODEL_WINDOW)
             launch_window_pose_tables(ctx->d_ctrl.as<double>(), ctx->d_stamps.as<double>(), ctx->d_fhw.as<double>(), ctx->d_trajtime.as<double>(), B,
                                       np, rows - 1, ctx->d_tables.as<float>(), ctx->stream);
@@ -329,14 +343,13 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
                 launch_leaf_split(ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(), ctx->d_nglobal.as<float4>(),
                                   &counts->level[l], s.min_num_points_per_set, ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(),
                                   ctx->d_pos_slot_rank.as<int32_t>(), ctx->stream);
-            HIPCHK(exclusive_scan_i32(ctx->d_scan_tmp.p, ctx->d_scan_tmp.cap, ctx->d_slot_acc.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(), (size_t)(2 * n), ctx->stream));
-            HIPCHK(exclusive_scan_i32(ctx->d_scan_tmp.p, ctx->d_scan_tmp.cap, ctx->d_slot_cnt.as<int32_t>(), ctx->d_memb_of_slot.as<int32_t>(), (size_t)(2 * n), ctx->stream));
-            launch_level_totals(ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(), ctx->d_memb_of_slot.as<int32_t>(),
-                                &counts->level[l], 2 * n, ctx->stream);
+            launch_leaf_scan(ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(), ctx->d_memb_of_slot.as<int32_t>(),
+                             &counts->level[l], ctx->stream);
             launch_gather_members(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(),
                                   ctx->d_code_s[l].as<uint64_t>(), tab, ctx->d_slot_acc.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(),
-                                  ctx->d_memb_of_slot.as<int32_t>(), split ? ctx->d_pos_slot_rank.as<int32_t>() : nullptr, ctx->d_local.as<float4>(), counts,
-                                  l, n, ctx->d_memb_local.as<float4>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), ctx->stream);
+                                  ctx->d_memb_of_slot.as<int32_t>(), split ? ctx->d_pos_slot_rank.as<int32_t>() : nullptr, ctx->d_local.as<float4>(),
+                                  ctx->d_slot_cnt.as<int32_t>(), counts, l, n, ctx->d_memb_local.as<float4>(), ctx->d_memb_idx.as<int32_t>(),
+                                  ctx->d_memb_g.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), ctx->stream);
         }
         if (!tiles_on) {
             ScopedTimer tm(ctx, T_FIT);
@@ -348,7 +361,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
     TileCounts htc{};
     if (tiles_on) {
         ScopedTimer tm(ctx, T_FIT);
-        launch_build_tiles(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_memb_local.as<float4>(), ctx->rows, ctx->d_tiles.as<TileDesc>(),
+        launch_build_tiles(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_memb_local.as<float4>(), ctx->d_memb_g.as<int32_t>(), ctx->rows, ctx->d_tiles.as<TileDesc>(),
                            ctx->d_tile_counts.as<TileCounts>(), ctx->d_fallback.as<int2>(), ctx->d_memb_tile.as<float4>(), ctx->d_tile_rows.as<int32_t>(),
                            ctx->stream);
         HIPCHK(hipMemcpyAsync(&htc, ctx->d_tile_counts.p, sizeof(TileCounts), hipMemcpyDeviceToHost, ctx->stream));
@@ -356,7 +369,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
     GaussCounts h{};
     HIPCHK(hipMemcpyAsync(&h, ctx->d_counts.p, sizeof(GaussCounts), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #2: M sizes every later launch
-    ctx->num_tiles = htc.num_tiles, ctx->num_fallback = htc.num_fallback, ctx->tile_max_rows = htc.max_rows;
+    ctx->num_tiles = htc.num_tiles, ctx->num_fallback = htc.num_fallback, ctx->tile_max_rows = htc.max_rows, ctx->tile_max_gauss = htc.max_gauss;
     {
         ScopedTimer tm(ctx, T_FIT);
         if (tiles_on && ctx->num_tiles > 0)
@@ -396,7 +409,7 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
         ScopedTimer tm(ctx, T_RESIDUAL);
         launch_residuals_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(),
                                ctx->d_tables.as<float>(), ctx->rows, ctx->M, B, ctx->d_tiles.as<TileDesc>(), ctx->d_tile_rows.as<int32_t>(), ctx->num_tiles,
-                               ctx->tile_max_rows, ctx->d_fallback.as<int2>(), ctx->num_fallback, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE,
+                               ctx->tile_max_rows, ctx->tile_max_gauss, ctx->d_fallback.as<int2>(), ctx->num_fallback, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE,
                                ctx->stream);
     } else {
         ScopedTimer tm(ctx, T_RESIDUAL);
@@ -592,11 +605,12 @@ void dmsa_destroy(dmsa_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     drain_timers(ctx);
     for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     DevBuf* bufs[] = {&ctx->d_local, &ctx->d_nlocal, &ctx->d_ring, &ctx->d_global, &ctx->d_nglobal, &ctx->d_tables, &ctx->d_ctrl, &ctx->d_stamps,
                       &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
                       &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_head, &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
                       &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_slot_acc, &ctx->d_slot_cnt, &ctx->d_gauss_of_slot, &ctx->d_memb_of_slot,
-                      &ctx->d_pos_slot_rank, &ctx->d_sort_tmp, &ctx->d_scan_tmp, &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_seg_off,
+                      &ctx->d_pos_slot_rank, &ctx->d_sort_tmp, &ctx->d_scan_tmp, &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_memb_g, &ctx->d_seg_off,
                       &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_counts, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(ctx->stream);
@@ -954,6 +968,23 @@ int dmsa_get_poses(dmsa_ctx* ctx, double* rel_orient, double* rel_transl) {
     if (!ctx || ctx->model == MODEL_NONE || !rel_orient || !rel_transl) return DMSA_ERR_INVALID;
     write_back_poses(chain(ctx), rel_orient, rel_transl);
     return DMSA_OK;
+}
+
+// Debug-only (not declared in include/dmsa_hip.h): phase cycle counters of k_residuals_tiles, -DDMSA_PHASE_CLOCKS builds.
+int dmsa_debug_phase_clocks(dmsa_ctx* ctx, long long* out, int capacity_tiles) {
+    static DevBuf buf;
+    if (!ctx) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    const size_t bytes = (size_t)capacity_tiles * 64 * sizeof(long long);
+    if (out == nullptr) {  // arm
+        HIPCHK(buf.ensure(bytes));
+        HIPCHK(hipMemset(buf.p, 0, bytes));
+        set_phase_clock_buffer(buf.as<long long>());
+        return DMSA_OK;
+    }
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, buf.p, bytes, hipMemcpyDeviceToHost));
+    return ctx->num_tiles;
 }
 
 int dmsa_optimize_keyframes(dmsa_ctx* ctx, dmsa_keyframe_problem* p, const dmsa_settings* s, dmsa_report* rep) {

@@ -44,7 +44,7 @@ struct TileDesc {
     int32_t pad;
 };
 struct TileCounts {
-    int32_t num_tiles, num_fallback, max_rows, pad;
+    int32_t num_tiles, num_fallback, max_rows, max_gauss;
 };
 
 struct GaussCounts {       // both levels, read back once per iteration
@@ -81,12 +81,14 @@ void launch_leaf_accept(const int32_t* leaf_start, const uint32_t* idx_sorted, c
 // keyframe pass: splitSet on accepted leaves; rewrites slot_acc/slot_cnt and fills per-position (set, rank)
 void launch_leaf_split(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const float4* nglobal, const LevelCounts* counts,
                        int min_pts, int32_t* slot_acc, int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s);
+void launch_leaf_scan(const int32_t* slot_acc, const int32_t* slot_cnt, int32_t* gauss_of_slot, int32_t* memb_of_slot, LevelCounts* counts,
+                      hipStream_t s);
 void launch_level_totals(const int32_t* slot_acc, const int32_t* slot_cnt, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
                          LevelCounts* counts /* this level */, int64_t nslots, hipStream_t s);
 void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start, const uint32_t* idx_sorted, const uint64_t* code_sorted,
                            const LatticeTable* table, const int32_t* slot_acc, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
-                           const int32_t* pos_slot_rank /* or null */, const float4* local, const GaussCounts* counts, int level, int64_t n,
-                           float4* memb_local, int32_t* memb_idx, int32_t* seg_off, hipStream_t s);
+                           const int32_t* pos_slot_rank /* or null */, const float4* local, const int32_t* slot_cnt, const GaussCounts* counts, int level,
+                           int64_t n, float4* memb_local, int32_t* memb_idx, int32_t* memb_g, int32_t* seg_off, hipStream_t s);
 // ---- K3: Gaussian fit -------------------------------------------------------------------------------------
 // mirror == true: sums run serially in member order (bit-reproducible against the CPU restatement)
 void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const GaussCounts* counts, int level,
@@ -97,14 +99,15 @@ void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
                       const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s, bool pairs = false);
 // tiled variant (default fast path): tiles + per-tile row lists are rebuilt once per iteration
-void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, int rows, TileDesc* tiles, TileCounts* tc,
-                        int2* fallback, float4* memb_tile, int32_t* tile_rows, hipStream_t s);
+void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, const int32_t* memb_g, int rows, TileDesc* tiles,
+                        TileCounts* tc, int2* fallback, float4* memb_tile, int32_t* tile_rows, hipStream_t s);
 int tile_points();
+void set_phase_clock_buffer(long long* p);  // debug instrumentation (-DDMSA_PHASE_CLOCKS builds only)
 // Gaussian fit on the tiles (fast path): info12[g] = information matrix of every accepted set, base pose table = table0
 void launch_fit_tiled(const float4* memb_tile, const int32_t* seg_off, const float* table0, int max_rows, const TileDesc* tiles, const TileCounts* tc,
                       const int2* big_list, const int32_t* tile_rows, float* info12, hipStream_t s);
 void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables,
-                            int rows, int M, int B, const TileDesc* tiles, const int32_t* tile_rows, int num_tiles, int max_rows,
+                            int rows, int M, int B, const TileDesc* tiles, const int32_t* tile_rows, int num_tiles, int max_rows, int max_gauss,
                             const int2* fallback, int num_fallback, int big_n, double* E, int64_t ldE, hipStream_t s);
 // ---- K5: normal equations + squared-error sums -------------------------------------------------------------
 // Hp = [J | e0]^T [J | e0] of size (P+1)^2, col-major, J.col(k) = inv_h * (E[k+1] - E[0]) over `rows` rows

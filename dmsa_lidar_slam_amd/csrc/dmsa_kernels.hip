@@ -570,11 +570,11 @@ void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const u
 __global__ __launch_bounds__(256) void k_leaf_accept(const int32_t* __restrict__ leaf_start, const uint32_t* __restrict__ idx_sorted,
                                                      const int32_t* __restrict__ ring, const LevelCounts* __restrict__ counts, int min_pts,
                                                      int64_t capacity, int32_t* __restrict__ slot_acc, int32_t* __restrict__ slot_cnt) {
-    const int nl = counts->num_leaves;
+    const int nl = counts->num_leaves;  // slots of leaves >= nl are never read (k_leaf_scan stops at nl)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < capacity; l += stride) {
+    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < nl; l += stride) {
         int acc = 0, cnt = 0;
-        if (l < nl) {
+        {
             const int b = leaf_start[l], e = leaf_start[l + 1];
             cnt = e - b;
             if (cnt >= min_pts) {
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void k_leaf_accept(const int32_t* __restrict__
 void launch_leaf_accept(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const LevelCounts* counts, int min_pts,
                         int64_t capacity, int32_t* slot_acc, int32_t* slot_cnt, hipStream_t s) {
     if (capacity <= 0) return;
-    hipLaunchKernelGGL(k_leaf_accept, dim3(grid_for(capacity, 256)), dim3(256), 0, s, leaf_start, idx_sorted, ring, counts, min_pts, capacity,
+    hipLaunchKernelGGL(k_leaf_accept, dim3(512), dim3(256), 0, s, leaf_start, idx_sorted, ring, counts, min_pts, capacity,
                        slot_acc, slot_cnt);
 }
 
@@ -687,6 +687,53 @@ void launch_leaf_split(const int32_t* leaf_start, const uint32_t* idx_sorted, co
                        pos_slot_rank);
 }
 
+// Exclusive prefix sums of (accepted, accepted member count) over the two slots of every leaf.  The leaf count lives on the
+// device, and there are only ~10^4..10^5 leaves, so one 1024-thread workgroup walks them 4096 slots at a time.
+__global__ __launch_bounds__(1024) void k_leaf_scan(const int32_t* __restrict__ slot_acc, const int32_t* __restrict__ slot_cnt,
+                                                    int32_t* __restrict__ gauss_of_slot, int32_t* __restrict__ memb_of_slot,
+                                                    LevelCounts* __restrict__ counts) {
+    __shared__ int s_w[16][2];
+    __shared__ int s_carry[2];
+    const int nslots = 2 * counts->num_leaves;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry[0] = 0, s_carry[1] = 0;
+    __syncthreads();
+    for (int base = 0; base < nslots; base += 4096) {
+        int a[4], c[4], ta = 0, tc2 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + 4 * tid + k;
+            a[k] = i < nslots ? slot_acc[i] : 0;
+            c[k] = i < nslots ? slot_cnt[i] : 0;
+            ta += a[k], tc2 += c[k];
+        }
+        int ia = ta, ic = tc2;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int oa = __shfl_up(ia, d), oc = __shfl_up(ic, d);
+            if (lane >= d) ia += oa, ic += oc;
+        }
+        if (lane == 63) s_w[wave][0] = ia, s_w[wave][1] = ic;
+        __syncthreads();
+        int ra = s_carry[0] + ia - ta, rc = s_carry[1] + ic - tc2;
+        for (int w = 0; w < wave; ++w) ra += s_w[w][0], rc += s_w[w][1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + 4 * tid + k;
+            if (i < nslots) gauss_of_slot[i] = ra, memb_of_slot[i] = rc;
+            ra += a[k], rc += c[k];
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry[0] = ra, s_carry[1] = rc;
+        __syncthreads();
+    }
+    if (tid == 0) counts->num_gauss = s_carry[0], counts->num_memb = s_carry[1];
+}
+void launch_leaf_scan(const int32_t* slot_acc, const int32_t* slot_cnt, int32_t* gauss_of_slot, int32_t* memb_of_slot, LevelCounts* counts,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_leaf_scan, dim3(1), dim3(1024), 0, s, slot_acc, slot_cnt, gauss_of_slot, memb_of_slot, counts);
+}
+
 __global__ void k_level_totals(const int32_t* __restrict__ slot_acc, const int32_t* __restrict__ slot_cnt, const int32_t* __restrict__ gauss_of_slot,
                                const int32_t* __restrict__ memb_of_slot, LevelCounts* __restrict__ counts, int64_t nslots) {
     counts->num_gauss = gauss_of_slot[nslots - 1] + slot_acc[nslots - 1];
@@ -704,8 +751,9 @@ __global__ __launch_bounds__(256) void k_gather_members(const int32_t* __restric
                                                         const LatticeTable* __restrict__ table, const int32_t* __restrict__ slot_acc,
                                                         const int32_t* __restrict__ gauss_of_slot, const int32_t* __restrict__ memb_of_slot,
                                                         const int32_t* __restrict__ pos_slot_rank, const float4* __restrict__ local,
-                                                        const GaussCounts* __restrict__ counts, int level, int64_t n, float4* __restrict__ memb_local,
-                                                        int32_t* __restrict__ memb_idx, int32_t* __restrict__ seg_off) {
+                                                        const int32_t* __restrict__ slot_cnt, const GaussCounts* __restrict__ counts, int level,
+                                                        int64_t n, float4* __restrict__ memb_local, int32_t* __restrict__ memb_idx,
+                                                        int32_t* __restrict__ memb_g, int32_t* __restrict__ seg_off) {
     const uint64_t invalid = 1ull << (3 * table->final_depth);
     const int gbase = level == 0 ? 0 : counts->level[0].num_gauss;
     const int mbase = level == 0 ? 0 : counts->level[0].num_memb;
@@ -729,16 +777,17 @@ __global__ __launch_bounds__(256) void k_gather_members(const int32_t* __restric
         const uint32_t pi = idx_sorted[i];
         memb_local[dst] = local[pi];
         memb_idx[dst] = (int32_t)pi;
+        memb_g[dst] = (int32_t)((uint32_t)g | (rank == slot_cnt[slot] - 1 ? 0x80000000u : 0u));  // Gaussian id, bit 31: last member
         if (rank == 0) seg_off[g] = dst;
     }
 }
 void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start, const uint32_t* idx_sorted, const uint64_t* code_sorted,
                            const LatticeTable* table, const int32_t* slot_acc, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
-                           const int32_t* pos_slot_rank, const float4* local, const GaussCounts* counts, int level, int64_t n, float4* memb_local,
-                           int32_t* memb_idx, int32_t* seg_off, hipStream_t s) {
+                           const int32_t* pos_slot_rank, const float4* local, const int32_t* slot_cnt, const GaussCounts* counts, int level, int64_t n,
+                           float4* memb_local, int32_t* memb_idx, int32_t* memb_g, int32_t* seg_off, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_gather_members, dim3(grid_for(n, 256)), dim3(256), 0, s, leaf_of_pos, leaf_start, idx_sorted, code_sorted, table, slot_acc,
-                       gauss_of_slot, memb_of_slot, pos_slot_rank, local, counts, level, n, memb_local, memb_idx, seg_off);
+                       gauss_of_slot, memb_of_slot, pos_slot_rank, local, slot_cnt, counts, level, n, memb_local, memb_idx, memb_g, seg_off);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1037,7 +1086,7 @@ __global__ __launch_bounds__(512) void k_residuals(const float4* __restrict__ me
 constexpr int kTilePoints = 4096;
 constexpr int kTileThreads = 512;
 constexpr int kTilePpt = kTilePoints / kTileThreads;   // 8 members per thread
-constexpr int kTileGauss = 512;                         // Gaussians per tile (10-bit local id)
+constexpr int kTileGauss = 128;                         // Gaussians per tile (keeps the per-Gaussian LDS arrays small)
 // packed .w of a tile member: bits 0-11 rank of its pose-table row in the tile's row list, bits 12-21 Gaussian index
 // inside the tile, bit 31 set on the last member of a Gaussian
 __device__ __forceinline__ int tw_row(int w) { return w & 0xfff; }
@@ -1091,13 +1140,13 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const int32_t* __restrict_
         if (threadIdx.x == 1023) s_carry = incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) tc->num_tiles = s_carry, tc->num_fallback = s_nbig, tc->max_rows = 0;
+    if (threadIdx.x == 0) tc->num_tiles = s_carry, tc->num_fallback = s_nbig, tc->max_rows = 0, tc->max_gauss = 0;
 }
 
 // Per tile: which pose-table rows do its members reference?  Writes the ascending row list, a copy of the members
 // whose .w is the rank of their row in that list, and the maximum list length (sizes the LDS table of the kernels).
 __global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles, TileCounts* __restrict__ tc, const float4* __restrict__ memb,
-                                                   const int32_t* __restrict__ seg_off, int rows, float4* __restrict__ memb_tile,
+                                                   const int32_t* __restrict__ memb_g, int rows, float4* __restrict__ memb_tile,
                                                    int32_t* __restrict__ tile_rows) {
     extern __shared__ uint32_t s_bm[];  // words bitmap, then words prefix
     const int words = (rows + 31) / 32;
@@ -1121,6 +1170,7 @@ __global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles,
             tiles[t].row_off = t * rows;
             tiles[t].nrows = (int)acc;
             atomicMax(&tc->max_rows, (int)acc);
+            atomicMax(&tc->max_gauss, tg1 - tg0);
         }
         __syncthreads();
         for (int w = threadIdx.x; w < words; w += blockDim.x) {
@@ -1137,27 +1187,19 @@ __global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles,
             float4 p = memb[i];
             const int row = __float_as_int(p.w);
             const int lrow = (int)s_pre[row >> 5] + __popc(s_bm[row >> 5] & ((1u << (row & 31)) - 1u));
-            int lo = tg0, hi = tg1 - 1;  // Gaussian containing member i: last g with seg_off[g] <= i
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (seg_off[mid] <= i)
-                    lo = mid;
-                else
-                    hi = mid - 1;
-            }
-            uint32_t packed = (uint32_t)lrow | ((uint32_t)(lo - tg0) << 12);
-            if (i + 1 == seg_off[lo + 1]) packed |= 0x80000000u;
+            const uint32_t gm = (uint32_t)memb_g[i];
+            const uint32_t packed = (uint32_t)lrow | (((gm & 0x7fffffffu) - (uint32_t)tg0) << 12) | (gm & 0x80000000u);
             p.w = __int_as_float((int)packed);
             memb_tile[i] = p;
         }
         __syncthreads();
     }
 }
-void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, int rows, TileDesc* tiles, TileCounts* tc,
-                        int2* fallback, float4* memb_tile, int32_t* tile_rows, hipStream_t s) {
+void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, const int32_t* memb_g, int rows, TileDesc* tiles,
+                        TileCounts* tc, int2* fallback, float4* memb_tile, int32_t* tile_rows, hipStream_t s) {
     hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(1024), 0, s, seg_off, counts, tiles, tc, fallback);
     const size_t lds = (size_t)((rows + 31) / 32) * 8;
-    hipLaunchKernelGGL(k_tile_rows, dim3(1024), dim3(256), lds, s, tiles, tc, memb, seg_off, rows, memb_tile, tile_rows);
+    hipLaunchKernelGGL(k_tile_rows, dim3(1024), dim3(256), lds, s, tiles, tc, memb, memb_g, rows, memb_tile, tile_rows);
 }
 int tile_points() { return kTilePoints; }
 
@@ -1167,21 +1209,35 @@ int tile_points() { return kTilePoints; }
 // carries ~1e-12 relative error, far below the float rounding of the terms themselves, and the order is fixed.
 __device__ __forceinline__ double wave_incl_scan(double v, int) { return wave_incl_scan_dpp(v); }
 
+// LDS carve of k_residuals_tiles (bytes).  Prefix samples and wave totals are double-buffered by evaluation parity so
+// that one evaluation needs only three workgroup barriers.
+constexpr int kRtOffInfo = 0;                                                  // 3 float4 per Gaussian
+constexpr int kRtOffEnd = kRtOffInfo + kTileGauss * 48;                        // [2][4][kTileGauss + 1] doubles
+constexpr int kRtOffEndW = kRtOffEnd + 2 * 4 * (kTileGauss + 1) * 8;           // [2][kTileGauss + 1] int (wave of the end member)
+constexpr int kRtOffWave = (kRtOffEndW + 2 * (kTileGauss + 1) * 4 + 7) / 8 * 8; // [2][8][4] doubles
+constexpr int kRtOffMean = kRtOffWave + 2 * 8 * 4 * 8;                          // [3][kTileGauss] floats
+constexpr int kRtOffNf = kRtOffMean + 3 * kTileGauss * 4;                       // [kTileGauss] floats
+constexpr int kRtOffTab = (kRtOffNf + kTileGauss * 4 + 15) / 16 * 16;           // [2][max_rows][3] float4
+
 template <int kMinWaves>
 __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(const float4* __restrict__ memb_tile, const int32_t* __restrict__ seg_off,
-                                                                  const float4* __restrict__ info12, const float4* __restrict__ tables, int rows,
-                                                                  const TileDesc* __restrict__ tiles, const int32_t* __restrict__ tile_rows, int B,
-                                                                  int b_chunk, double* __restrict__ E, int64_t ldE) {
+                                                                             const float4* __restrict__ info12, const float4* __restrict__ tables,
+                                                                             int rows, const TileDesc* __restrict__ tiles,
+                                                                             const int32_t* __restrict__ tile_rows, int B, int b_chunk, int max_rows, int max_gauss,
+                                                                             double* __restrict__ E, int64_t ldE, long long* __restrict__ phase_clk) {
     const TileDesc td = tiles[blockIdx.x];
     if (td.kind != 0) return;
     extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
-    // LDS carve (bytes): info 512*48 | end-prefix 4 x 513 doubles | mean 3 x 512 floats | wave totals 8 x 4 doubles | pose rows
-    float4* s_info = s_dyn;                                                  // 3 float4 per Gaussian
-    double* s_end = reinterpret_cast<double*>(s_dyn + 3 * kTileGauss);       // [4][kTileGauss + 1], entry 0 == 0
-    float* s_mean = reinterpret_cast<float*>(s_end + 4 * (kTileGauss + 1));  // [3][kTileGauss]
-    float* s_nf = s_mean + 3 * kTileGauss;                                    // [kTileGauss] member counts
-    double* s_wave = reinterpret_cast<double*>(s_nf + kTileGauss + 4);        // 8 waves x 4 doubles; +4 floats keeps s_tab 16-B aligned
-    float4* s_tab = reinterpret_cast<float4*>(s_wave + 32);
+    char* s_base = reinterpret_cast<char*>(s_dyn);
+    float4* s_info = reinterpret_cast<float4*>(s_base + kRtOffInfo);
+    double* s_end = reinterpret_cast<double*>(s_base + kRtOffEnd);
+    int* s_endw = reinterpret_cast<int*>(s_base + kRtOffEndW);
+    double* s_wave = reinterpret_cast<double*>(s_base + kRtOffWave);
+    float* s_mean = reinterpret_cast<float*>(s_base + kRtOffMean);
+    float* s_nf = reinterpret_cast<float*>(s_base + kRtOffNf);
+    float4* s_tab = reinterpret_cast<float4*>(s_base + kRtOffTab);
+    double* s_out = reinterpret_cast<double*>(s_tab + (size_t)2 * max_rows * 3);  // [b_chunk][max_gauss] residuals of this chunk
+    constexpr int kEndStride = kTileGauss + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int np = td.p1 - td.p0, ng = td.g1 - td.g0;
     float4 pt[kTilePpt];
@@ -1197,86 +1253,124 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
     for (int k = 0; k < kTilePpt; ++k) any_end = any_end || tw_end(__float_as_int(pt[k].w));
     for (int q = tid; q < 3 * ng; q += kTileThreads) s_info[q] = info12[3 * td.g0 + q];
     for (int g = tid; g < ng; g += kTileThreads) s_nf[g] = (float)(seg_off[td.g0 + g + 1] - seg_off[td.g0 + g]);
-    if (tid < 4) s_end[tid * (kTileGauss + 1)] = 0.0;
+    if (tid < 8) s_end[tid * kEndStride] = 0.0;  // prefix "before the first Gaussian", both parities x 4 components
+    if (tid < 2) s_endw[tid * kEndStride] = 0;
     const int32_t* my_rows = tile_rows + td.row_off;
     const int b_begin = blockIdx.y * b_chunk, b_end = min(B, b_begin + b_chunk);
-    // pose-table rows of the NEXT evaluation are fetched into registers while the current one computes
+    // pose-table rows: registers hold the rows of evaluation b+1 while b computes; LDS holds b (parity b&1)
     const int nq = td.nrows * 3;
-    const bool prefetch = nq <= 2 * kTileThreads;
-    int src0 = -1, src1 = -1;
-    if (prefetch) {
-        if (tid < nq) src0 = 3 * my_rows[tid / 3] + (tid % 3);
-        if (tid + kTileThreads < nq) src1 = 3 * my_rows[(tid + kTileThreads) / 3] + ((tid + kTileThreads) % 3);
-    }
-    float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0;
-    if (prefetch && b_begin < b_end) {
+    int src0 = -1, src1 = -1, src2 = -1;
+    if (tid < nq) src0 = 3 * my_rows[tid / 3] + (tid % 3);
+    if (tid + kTileThreads < nq) src1 = 3 * my_rows[(tid + kTileThreads) / 3] + ((tid + kTileThreads) % 3);
+    if (tid + 2 * kTileThreads < nq) src2 = 3 * my_rows[(tid + 2 * kTileThreads) / 3] + ((tid + 2 * kTileThreads) % 3);
+    const bool direct = nq > 3 * kTileThreads;  // tiles referencing > 512 rows: plain staging (two extra barriers)
+    float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0, nx2 = nx0;
+    if (b_begin < b_end && !direct) {
         const float4* gtab = tables + (size_t)b_begin * rows * 3;
-        if (src0 >= 0) nx0 = gtab[src0];
-        if (src1 >= 0) nx1 = gtab[src1];
-    }
-    for (int b = b_begin; b < b_end; ++b) {
-        const float4* gtab = tables + (size_t)b * rows * 3;
-        __syncthreads();  // previous evaluation finished reading s_tab / s_end / s_mean
-        if (prefetch) {
-            if (src0 >= 0) s_tab[tid] = nx0;
-            if (src1 >= 0) s_tab[tid + kTileThreads] = nx1;
-            if (b + 1 < b_end) {
-                const float4* ntab = tables + (size_t)(b + 1) * rows * 3;
-                if (src0 >= 0) nx0 = ntab[src0];
-                if (src1 >= 0) nx1 = ntab[src1];
-            }
-        } else {
-            for (int q = tid; q < nq; q += kTileThreads) s_tab[q] = gtab[3 * my_rows[q / 3] + (q % 3)];
+        float4* dst = s_tab + (size_t)(b_begin & 1) * max_rows * 3;
+        if (src0 >= 0) dst[tid] = gtab[src0];
+        if (src1 >= 0) dst[tid + kTileThreads] = gtab[src1];
+        if (src2 >= 0) dst[tid + 2 * kTileThreads] = gtab[src2];
+        if (b_begin + 1 < b_end) {
+            const float4* ntab = tables + (size_t)(b_begin + 1) * rows * 3;
+            if (src0 >= 0) nx0 = ntab[src0];
+            if (src1 >= 0) nx1 = ntab[src1];
+            if (src2 >= 0) nx2 = ntab[src2];
         }
-        __syncthreads();
-        // Slots past the tile's last member hold (0,0,0,row 0): they transform to finite values that only enter the
-        // prefixes AFTER the last Gaussian end, so no per-slot range checks are needed; waves entirely past the end idle.
+    }
+    __syncthreads();
+#ifdef DMSA_PHASE_CLOCKS
+    long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t_prev = clock64();
+#define PHASE(k) { const long long t_now = clock64(); pc[k] += t_now - t_prev; t_prev = t_now; }
+#else
+#define PHASE(k)
+#endif
+    PHASE(0)
+    for (int b = b_begin; b < b_end; ++b) {
+        const int pb = b & 1;
+        float4* tab = s_tab + (size_t)pb * max_rows * 3;
+        double* endp = s_end + (size_t)pb * 4 * kEndStride;
+        int* endw = s_endw + pb * kEndStride;
+        double* wavep = s_wave + pb * 32;
+        if (direct) {
+            __syncthreads();
+            const float4* gtab = tables + (size_t)b * rows * 3;
+            for (int q = tid; q < nq; q += kTileThreads) tab[q] = gtab[3 * my_rows[q / 3] + (q % 3)];
+            __syncthreads();
+        }
+        // ---- transform once (registers), float partial sums over the thread's 8 consecutive members --------------------
+        // Slots past the tile's last member hold (0,0,0,row 0): they transform to finite values that only enter prefixes
+        // AFTER the last Gaussian end, so no per-slot range checks are needed; waves entirely past the end idle.
         float gx[kTilePpt], gy[kTilePpt], gz[kTilePpt];
         float fx = 0.0f, fy = 0.0f, fz = 0.0f;
         if (wave_on) {
 #pragma unroll
             for (int k = 0; k < kTilePpt; ++k) {
                 const int row = tw_row(__float_as_int(pt[k].w));
-                const float3 q = apply_row3(s_tab[3 * row], s_tab[3 * row + 1], s_tab[3 * row + 2], pt[k].x, pt[k].y, pt[k].z);
+                const float3 q = apply_row3(tab[3 * row], tab[3 * row + 1], tab[3 * row + 2], pt[k].x, pt[k].y, pt[k].z);
                 gx[k] = q.x, gy[k] = q.y, gz[k] = q.z;
-                fx += q.x, fy += q.y, fz += q.z;  // float partial sums over the thread's 8 consecutive members
+                fx += q.x, fy += q.y, fz += q.z;
                 if (k & 1) asm volatile("" ::: "memory");  // no hoisting of later members' LDS reads: bounds live registers
             }
         }
-        // pass 1: workgroup prefix of the per-thread totals (fp64), sampled at Gaussian ends as D_t + float partial
-        const double tx = (double)fx, ty = (double)fy, tz = (double)fz;
-        const double ix = wave_incl_scan(tx, lane), iy = wave_incl_scan(ty, lane), iz = wave_incl_scan(tz, lane);
-        if (lane == 63) s_wave[4 * wave] = ix, s_wave[4 * wave + 1] = iy, s_wave[4 * wave + 2] = iz;
-        __syncthreads();
-        if (wave_on && any_end) {
-            double rx = ix - tx, ry = iy - ty, rz = iz - tz;
-            for (int w2 = 0; w2 < wave; ++w2) rx += s_wave[4 * w2], ry += s_wave[4 * w2 + 1], rz += s_wave[4 * w2 + 2];
-            fx = 0.0f, fy = 0.0f, fz = 0.0f;
+        PHASE(1)
+        // ---- pass 1: wave-local fp64 prefix of the thread totals, sampled at Gaussian ends ------------------------------
+        {
+            const double tx = (double)fx, ty = (double)fy, tz = (double)fz;
+            const double ix = wave_incl_scan_dpp(tx), iy = wave_incl_scan_dpp(ty), iz = wave_incl_scan_dpp(tz);
+            if (lane == 63) wavep[4 * wave] = ix, wavep[4 * wave + 1] = iy, wavep[4 * wave + 2] = iz;
+            if (wave_on && any_end) {
+                const double rx = ix - tx, ry = iy - ty, rz = iz - tz;
+                fx = 0.0f, fy = 0.0f, fz = 0.0f;
 #pragma unroll
-            for (int k = 0; k < kTilePpt; ++k) {
-                fx += gx[k], fy += gy[k], fz += gz[k];
-                const int wv = __float_as_int(pt[k].w);
-                if (tw_end(wv)) {
-                    const int lg = tw_gauss(wv) + 1;
-                    s_end[lg] = rx + (double)fx, s_end[(kTileGauss + 1) + lg] = ry + (double)fy, s_end[2 * (kTileGauss + 1) + lg] = rz + (double)fz;
+                for (int k = 0; k < kTilePpt; ++k) {
+                    fx += gx[k], fy += gy[k], fz += gz[k];
+                    const int wv = __float_as_int(pt[k].w);
+                    if (tw_end(wv)) {
+                        const int lg = tw_gauss(wv) + 1;
+                        endp[lg] = rx + (double)fx, endp[kEndStride + lg] = ry + (double)fy, endp[2 * kEndStride + lg] = rz + (double)fz;
+                        endw[lg] = wave;
+                    }
                 }
             }
         }
-        __syncthreads();
-        for (int g = tid; g < ng; g += kTileThreads) {
-            const float nf = s_nf[g];
-            s_mean[g] = (float)(s_end[g + 1] - s_end[g]) / nf;
-            s_mean[kTileGauss + g] = (float)(s_end[(kTileGauss + 1) + g + 1] - s_end[(kTileGauss + 1) + g]) / nf;
-            s_mean[2 * kTileGauss + g] = (float)(s_end[2 * (kTileGauss + 1) + g + 1] - s_end[2 * (kTileGauss + 1) + g]) / nf;
+        PHASE(2)
+        // stage the next evaluation's rows (other parity) and fetch the one after
+        if (!direct && b + 1 < b_end) {
+            float4* dst = s_tab + (size_t)(pb ^ 1) * max_rows * 3;
+            if (src0 >= 0) dst[tid] = nx0;
+            if (src1 >= 0) dst[tid + kTileThreads] = nx1;
+            if (src2 >= 0) dst[tid + 2 * kTileThreads] = nx2;
+            if (b + 2 < b_end) {
+                const float4* ntab = tables + (size_t)(b + 2) * rows * 3;
+                if (src0 >= 0) nx0 = ntab[src0];
+                if (src1 >= 0) nx1 = ntab[src1];
+                if (src2 >= 0) nx2 = ntab[src2];
+            }
         }
-        __syncthreads();
-        // pass 2: Mahalanobis terms (float, reference operation order); gx[k] is overwritten by the member's term
+        PHASE(3)
+        __syncthreads();  // B1
+        PHASE(4)
+        // Per-Gaussian sums: difference of two wave-local prefix samples; only a Gaussian that spans waves (at most seven
+        // per tile) adds the totals of the waves it crosses.
+        for (int g = tid; g < ng; g += kTileThreads) {
+            const int w1 = endw[g + 1], w0 = endw[g];
+            const float nf = s_nf[g];
+            double sx = endp[g + 1] - endp[g], sy = endp[kEndStride + g + 1] - endp[kEndStride + g],
+                   sz = endp[2 * kEndStride + g + 1] - endp[2 * kEndStride + g];
+            for (int w2 = w0; w2 < w1; ++w2) sx += wavep[4 * w2], sy += wavep[4 * w2 + 1], sz += wavep[4 * w2 + 2];
+            s_mean[g] = (float)sx / nf, s_mean[kTileGauss + g] = (float)sy / nf, s_mean[2 * kTileGauss + g] = (float)sz / nf;
+        }
+        PHASE(5)
+        __syncthreads();  // B2
+        PHASE(4)
+        // ---- pass 2: Mahalanobis terms (float, reference operation order); gx[k] is overwritten by the member's term ----
         float fq = 0.0f;
         if (wave_on) {
 #pragma unroll
             for (int k = 0; k < kTilePpt; ++k) {
-                // information matrix / weight / mean of this member's Gaussian straight from LDS (consecutive lanes and
-                // slots mostly hit the same Gaussian: broadcast reads)
+                // information matrix / weight / mean of this member's Gaussian straight from LDS (broadcast reads)
                 const int lg = tw_gauss(__float_as_int(pt[k].w));
                 const float4 i0 = s_info[3 * lg], i1 = s_info[3 * lg + 1], i2 = s_info[3 * lg + 2];
                 const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
@@ -1291,27 +1385,45 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
                 asm volatile("" ::: "memory");
             }
         }
-        const double tq = (double)fq;
-        const double iq = wave_incl_scan(tq, lane);
-        if (lane == 63) s_wave[4 * wave + 3] = iq;
-        __syncthreads();
-        if (wave_on && any_end) {
-            double rq = iq - tq;
-            for (int w2 = 0; w2 < wave; ++w2) rq += s_wave[4 * w2 + 3];
-            fq = 0.0f;
+        PHASE(6)
+        {
+            const double tq = (double)fq;
+            const double iq = wave_incl_scan_dpp(tq);
+            if (lane == 63) wavep[4 * wave + 3] = iq;
+            if (wave_on && any_end) {
+                const double rq = iq - tq;
+                fq = 0.0f;
 #pragma unroll
-            for (int k = 0; k < kTilePpt; ++k) {
-                fq += gx[k];
-                const int wv = __float_as_int(pt[k].w);
-                if (tw_end(wv)) s_end[3 * (kTileGauss + 1) + tw_gauss(wv) + 1] = rq + (double)fq;
+                for (int k = 0; k < kTilePpt; ++k) {
+                    fq += gx[k];
+                    const int wv = __float_as_int(pt[k].w);
+                    if (tw_end(wv)) endp[3 * kEndStride + tw_gauss(wv) + 1] = rq + (double)fq;
+                }
             }
         }
-        __syncthreads();
+        PHASE(7)
+        __syncthreads();  // B3
+        PHASE(4)
         for (int g = tid; g < ng; g += kTileThreads) {
-            const double tot = s_end[3 * (kTileGauss + 1) + g + 1] - s_end[3 * (kTileGauss + 1) + g];
-            E[(size_t)b * ldE + td.g0 + g] = sqrt(fabs(tot));
+            const int w1 = endw[g + 1], w0 = endw[g];
+            double tot = endp[3 * kEndStride + g + 1] - endp[3 * kEndStride + g];
+            for (int w2 = w0; w2 < w1; ++w2) tot += wavep[4 * w2 + 3];
+            s_out[(size_t)(b - b_begin) * max_gauss + g] = tot;  // sqrt(|.|) is applied when the chunk is written out
         }
+        // the next evaluation writes the other parity of endp / endw / wavep; s_mean is rewritten only after its B1
+        PHASE(5)
     }
+    // residuals leave the workgroup once, coalesced along the Gaussian index (no global stores inside the loop)
+    __syncthreads();
+    for (int q = tid; q < (b_end - b_begin) * ng; q += kTileThreads) {
+        const int bl = q / ng, g = q - bl * ng;
+        E[(size_t)(b_begin + bl) * ldE + td.g0 + g] = sqrt(fabs(s_out[(size_t)bl * max_gauss + g]));
+    }
+#ifdef DMSA_PHASE_CLOCKS
+    if (phase_clk != nullptr && lane == 0 && blockIdx.y == 0)
+        for (int k = 0; k < 8; ++k) phase_clk[((size_t)blockIdx.x * 8 + wave) * 8 + k] = pc[k];
+#endif
+#undef PHASE
 }
 
 // Single-Gaussian tiles (more than kTilePoints members, ~30 % of all members at the benchmark size): one 1024-thread
@@ -1565,8 +1677,11 @@ void launch_fit_tiled(const float4* memb_tile, const int32_t* seg_off, const flo
                        tile_rows, info12);
 }
 
+long long* g_phase_clk = nullptr;  // debug: per (tile, wave, phase) cycle counts when built with -DDMSA_PHASE_CLOCKS
+void set_phase_clock_buffer(long long* p) { g_phase_clk = p; }
+
 void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables,
-                            int rows, int M, int B, const TileDesc* tiles, const int32_t* tile_rows, int num_tiles, int max_rows,
+                            int rows, int M, int B, const TileDesc* tiles, const int32_t* tile_rows, int num_tiles, int max_rows, int max_gauss,
                             const int2* fallback, int num_fallback, int big_n, double* E, int64_t ldE, hipStream_t s) {
     if (M <= 0 || B <= 0 || num_tiles <= 0) return;
     static bool attr_set = false;
@@ -1581,16 +1696,18 @@ void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, c
     int chunks = (target_wgs + num_tiles - 1) / num_tiles;
     if (chunks > B) chunks = B;
     if (chunks < 1) chunks = 1;
-    const int b_chunk = (B + chunks - 1) / chunks;
+    int b_chunk = (B + chunks - 1) / chunks;
+    const int out_cap = (16 * 1024) / (8 * (max_gauss > 0 ? max_gauss : 1));  // s_out <= 16 KB of LDS
+    if (b_chunk > out_cap) b_chunk = out_cap > 0 ? out_cap : 1;
     chunks = (B + b_chunk - 1) / b_chunk;
-    const size_t lds_tiles = (size_t)kTileGauss * 48 + (size_t)4 * (kTileGauss + 1) * 8 + (size_t)(4 * kTileGauss + 4) * 4 + 256 + (size_t)max_rows * 48;
+    const size_t lds_tiles = (size_t)kRtOffTab + (size_t)2 * max_rows * 48 + (size_t)b_chunk * max_gauss * 8;
     const size_t lds_big = 384 + (size_t)max_rows * 48;
     if (big_n == 2)
         hipLaunchKernelGGL(k_residuals_tiles<2>, dim3(num_tiles, chunks), dim3(kTileThreads), lds_tiles, s, memb_tile, seg_off,
-                           reinterpret_cast<const float4*>(info12), reinterpret_cast<const float4*>(tables), rows, tiles, tile_rows, B, b_chunk, E, ldE);
+                           reinterpret_cast<const float4*>(info12), reinterpret_cast<const float4*>(tables), rows, tiles, tile_rows, B, b_chunk, max_rows, max_gauss, E, ldE, g_phase_clk);
     else
         hipLaunchKernelGGL(k_residuals_tiles<4>, dim3(num_tiles, chunks), dim3(kTileThreads), lds_tiles, s, memb_tile, seg_off,
-                           reinterpret_cast<const float4*>(info12), reinterpret_cast<const float4*>(tables), rows, tiles, tile_rows, B, b_chunk, E, ldE);
+                           reinterpret_cast<const float4*>(info12), reinterpret_cast<const float4*>(tables), rows, tiles, tile_rows, B, b_chunk, max_rows, max_gauss, E, ldE, g_phase_clk);
     // the few single-Gaussian tiles are long: give every evaluation its own workgroup
     if (num_fallback > 0)  // `fallback` lists the single-Gaussian (streamed) tiles
         hipLaunchKernelGGL(k_residuals_big, dim3(num_fallback, B), dim3(kBigThreads), lds_big, s, memb_tile, reinterpret_cast<const float4*>(info12),
