@@ -10,7 +10,9 @@ namespace dmsa {
 size_t sort_pairs_temp_bytes(size_t n) {
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 64);
-    return bytes;
+    size_t b32 = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, b32, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32);
+    return bytes > b32 ? bytes : b32;
 }
 size_t scan_temp_bytes(size_t n) {
     size_t a = 0, b = 0;
@@ -19,6 +21,10 @@ size_t scan_temp_bytes(size_t n) {
     return a > b ? a : b;
 }
 hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
+                              uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream) {
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, stream);
+}
+hipError_t sort_pairs_u32_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
                               uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream) {
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, stream);
 }

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <vector>
@@ -83,6 +84,8 @@ struct dmsa_ctx {
     DevBuf d_aabb, d_lattice, d_code[2], d_idx[2], d_code_s[2], d_idx_s[2], d_head, d_leaf_incl[2], d_leaf_start[2], d_slot_acc, d_slot_cnt,
         d_gauss_of_slot, d_memb_of_slot, d_pos_slot_rank, d_sort_tmp, d_scan_tmp, d_counts;
     LatticeTable h_lattice[2];
+    bool key32[2] = {false, false};  // leaf codes of this level are 32-bit (tree depth <= 10)
+    int depth_guess[2] = {-1, -1};   // tree depths of the previous voxelisation (speculation: saves one host sync)
     double level_res[2] = {0, 0};
     // Gaussians
     DevBuf d_memb_local, d_memb_idx, d_memb_g, d_seg_off, d_info12, d_wg_seg;
@@ -298,7 +301,9 @@ int transform_points(dmsa_ctx* ctx, int b) {
 }
 
 // ---- Gaussians (DmsaOptimizer.h:78-96) ---------------------------------------------------------------------
-int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
+// `overlap` (optional) runs on the host after every voxelisation kernel has been enqueued and before the counts are read
+// back: host work placed there hides behind the GPU.
+int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<int()>& overlap = nullptr, bool allow_speculation = true) {
     const int64_t n = ctx->n;
     ctx->gaussians_valid = false;
     ctx->M = 0, ctx->M1 = 0, ctx->Mm = 0;
@@ -309,6 +314,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
     if (!lvl_on[0]) ctx->level_res[0] = ctx->level_res[1];
     if (!lvl_on[1]) ctx->level_res[1] = ctx->level_res[0];
     HIPCHK(hipMemsetAsync(ctx->d_counts.p, 0, sizeof(GaussCounts), ctx->stream));
+    const bool speculate = allow_speculation && ctx->depth_guess[0] >= 0 && ctx->depth_guess[1] >= 0 && ctx->depth_guess[0] < 20 && ctx->depth_guess[1] < 20;
     {
         ScopedTimer tm(ctx, T_VOXEL);
         const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
@@ -316,10 +322,16 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
         launch_lattice(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), nb, ctx->level_res[0], ctx->level_res[1], ctx->d_lattice.as<LatticeTable>(),
                        ctx->stream);
         HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #1: tree depths select the radix-sort bit range
+        if (!speculate) HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #1: tree depths select the radix-sort bit range
     }
-    for (int l = 0; l < 2; ++l)
-        if (lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
+    // The sort only needs an UPPER bound of the tree depth.  From the second iteration on the previous depths are used
+    // without waiting for the lattice kernel; the true depths arrive with the counts (sync #2) and a too-small guess (the
+    // bounding box doubled between two iterations) re-runs the voxelisation synchronously.
+    int sort_depth[2];
+    for (int l = 0; l < 2; ++l) {
+        sort_depth[l] = speculate ? ctx->depth_guess[l] : ctx->h_lattice[l].final_depth;
+        if (!speculate && lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
+    }
     GaussCounts* counts = ctx->d_counts.as<GaussCounts>();
     const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS);
     const bool split = s.gauss_split != 0 && ctx->model == MODEL_KEYFRAMES;
@@ -329,13 +341,19 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
         const LatticeTable* tab = ctx->d_lattice.as<LatticeTable>() + l;
         {
             ScopedTimer tm(ctx, T_VOXEL);
-            launch_voxel_keys(ctx->d_global.as<float4>(), n, tab, ctx->level_res[l], ctx->d_code[l].as<uint64_t>(), ctx->d_idx[l].as<uint32_t>(), ctx->stream);
-            const unsigned end_bit = (unsigned)(3 * ctx->h_lattice[l].final_depth + 1);
-            HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp.p, ctx->d_sort_tmp.cap, ctx->d_code[l].as<uint64_t>(), ctx->d_code_s[l].as<uint64_t>(),
-                                      ctx->d_idx[l].as<uint32_t>(), ctx->d_idx_s[l].as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
-            launch_head_flags(ctx->d_code_s[l].as<uint64_t>(), n, tab, ctx->d_head.as<int32_t>(), ctx->stream);
+            const unsigned end_bit = (unsigned)(3 * sort_depth[l] + 1);
+            const bool k32 = end_bit <= 32;
+            ctx->key32[l] = k32;
+            launch_voxel_keys(ctx->d_global.as<float4>(), n, tab, ctx->level_res[l], ctx->d_code[l].p, k32, ctx->d_idx[l].as<uint32_t>(), ctx->stream);
+            if (k32)
+                HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp.p, ctx->d_sort_tmp.cap, ctx->d_code[l].as<uint32_t>(), ctx->d_code_s[l].as<uint32_t>(),
+                                          ctx->d_idx[l].as<uint32_t>(), ctx->d_idx_s[l].as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
+            else
+                HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp.p, ctx->d_sort_tmp.cap, ctx->d_code[l].as<uint64_t>(), ctx->d_code_s[l].as<uint64_t>(),
+                                          ctx->d_idx[l].as<uint32_t>(), ctx->d_idx_s[l].as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
+            launch_head_flags(ctx->d_code_s[l].p, k32, n, tab, ctx->d_head.as<int32_t>(), ctx->stream);
             HIPCHK(inclusive_scan_i32(ctx->d_scan_tmp.p, ctx->d_scan_tmp.cap, ctx->d_head.as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), (size_t)n, ctx->stream));
-            launch_leaf_starts(ctx->d_head.as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_code_s[l].as<uint64_t>(), tab, n,
+            launch_leaf_starts(ctx->d_head.as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_code_s[l].p, k32, tab, n,
                                ctx->d_leaf_start[l].as<int32_t>(), &counts->level[l], ctx->stream);
             launch_leaf_accept(ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(), &counts->level[l],
                                s.min_num_points_per_set, n, ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(), ctx->stream);
@@ -346,7 +364,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
             launch_leaf_scan(ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(), ctx->d_memb_of_slot.as<int32_t>(),
                              &counts->level[l], ctx->stream);
             launch_gather_members(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(),
-                                  ctx->d_code_s[l].as<uint64_t>(), tab, ctx->d_slot_acc.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(),
+                                  ctx->d_code_s[l].p, k32, tab, ctx->d_slot_acc.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(),
                                   ctx->d_memb_of_slot.as<int32_t>(), split ? ctx->d_pos_slot_rank.as<int32_t>() : nullptr, ctx->d_local.as<float4>(),
                                   ctx->d_slot_cnt.as<int32_t>(), counts, l, n, ctx->d_memb_local.as<float4>(), ctx->d_memb_idx.as<int32_t>(),
                                   ctx->d_memb_g.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), ctx->stream);
@@ -368,7 +386,16 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s) {
     }
     GaussCounts h{};
     HIPCHK(hipMemcpyAsync(&h, ctx->d_counts.p, sizeof(GaussCounts), hipMemcpyDeviceToHost, ctx->stream));
+    if (overlap) CHK(overlap());
     HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #2: M sizes every later launch
+    for (int l = 0; l < 2; ++l) {
+        if (lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
+        if (speculate && lvl_on[l] && ctx->h_lattice[l].final_depth > sort_depth[l]) {
+            ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
+            return build_gaussians(ctx, s, nullptr, false);  // mis-speculated: redo with the true depths (overlap work already ran)
+        }
+        ctx->depth_guess[l] = ctx->h_lattice[l].final_depth;
+    }
     ctx->num_tiles = htc.num_tiles, ctx->num_fallback = htc.num_fallback, ctx->tile_max_rows = htc.max_rows, ctx->tile_max_gauss = htc.max_gauss;
     {
         ScopedTimer tm(ctx, T_FIT);
@@ -434,6 +461,7 @@ int upload_common(dmsa_ctx* ctx) {
     ctx->gaussians_valid = false;
     ctx->centralized = false;
     ctx->batch = 0;
+    ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
     return DMSA_OK;
 }
 
@@ -452,6 +480,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
     const double one_div_incr = 1.0 / increment;
 
     if (s.use_centralization) CHK(dmsa_centralize(ctx));
+    HIPCHK(ctx->d_tables.ensure((size_t)(P + 1) * ctx->rows * 48));  // never reallocated while kernels read it
     for (int iter = 0; iter < s.num_iter; ++iter) {
         ++iters;
         chain(ctx).get_params(paramVec.data());  // :72
@@ -461,24 +490,41 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
         append_glob(chain(ctx), globs);
         CHK(build_tables(ctx, 1, globs));
         CHK(transform_points(ctx, 0));
-        CHK(build_gaussians(ctx, s));  // :78-86, :96
+        // Host part of evaluation 0 (:99) and of the P forward-difference evaluations of calcNumericJacobian (:199-232):
+        // one batch of 1+P pose tables.
+        auto jacobian_batch = [&]() -> int {
+            globs.clear(), extra.clear();
+            host_eval(ctx, globs, extra);
+            chain(ctx).get_params(origin.data());  // :204 (after updateImuError's global2relative round trip)
+            for (int k = 0; k < P; ++k) {
+                loop = origin;
+                loop[(size_t)k] += increment;
+                host_set_params(ctx, loop.data());
+                host_eval(ctx, globs, extra);
+            }
+            chain(ctx).set_params(origin.data());  // :231
+            return build_tables(ctx, 1 + P, globs);
+        };
+        // Fast path: the batch does not depend on the Gaussians, so its host math and pose-table kernel are issued while
+        // the GPU is still voxelising (table 0 of the batch equals the base table the fit reads).  The parity path keeps
+        // the reference's order of operations.
+        const bool overlap = !(ctx->flags & DMSA_FLAG_MIRROR_SUMS);
+        const int evals_before = ctx->evaluations;
+        if (overlap)
+            CHK(build_gaussians(ctx, s, jacobian_batch));  // :78-86, :96
+        else
+            CHK(build_gaussians(ctx, s));
         ctx->trace.push_back(dmsa_iter_trace{ctx->M, ctx->M1, ctx->Mm, 0.0, 0.0, 0, 0});
         if (ctx->M < s.min_num_gaussians) {  // :89-93
             stop = DMSA_STOP_FEW_GAUSSIANS;
+            if (overlap) {  // undo the speculative batch: the reference had not evaluated anything in this iteration
+                ctx->evaluations = evals_before;
+                chain(ctx).set_params(paramVec.data());
+                chain(ctx).relative_to_global();
+            }
             break;
         }
-        // evaluation 0 (:99) and the P forward-difference evaluations of calcNumericJacobian (:199-232) as one batch
-        globs.clear(), extra.clear();
-        host_eval(ctx, globs, extra);
-        chain(ctx).get_params(origin.data());  // :204 (after updateImuError's global2relative round trip)
-        for (int k = 0; k < P; ++k) {
-            loop = origin;
-            loop[(size_t)k] += increment;
-            host_set_params(ctx, loop.data());
-            host_eval(ctx, globs, extra);
-        }
-        chain(ctx).set_params(origin.data());  // :231
-        CHK(build_tables(ctx, 1 + P, globs));
+        if (!overlap) CHK(jacobian_batch());
         CHK(run_residuals(ctx, 1 + P, &extra));
         const int rowsE = ctx->M + ctx->extra_rows;
         {
@@ -860,7 +906,13 @@ int dmsa_get_voxel_level(dmsa_ctx* ctx, int32_t level, dmsa_voxel_level_info* in
     const LatticeTable& t = ctx->h_lattice[level];
     const uint64_t invalid = 1ull << (3 * t.final_depth);
     std::vector<uint64_t> code(n);
-    HIPCHK(hipMemcpy(code.data(), ctx->d_code[level].p, n * 8, hipMemcpyDeviceToHost));
+    if (ctx->key32[level]) {
+        std::vector<uint32_t> c32(n);
+        HIPCHK(hipMemcpy(c32.data(), ctx->d_code[level].p, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) code[i] = c32[i];
+    } else {
+        HIPCHK(hipMemcpy(code.data(), ctx->d_code[level].p, n * 8, hipMemcpyDeviceToHost));
+    }
     int64_t valid = 0;
     for (size_t i = 0; i < n; ++i) {
         const bool ok = code[i] != invalid;

@@ -71,10 +71,11 @@ void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tabl
 // ---- K2: PCL-exact voxel lattice + keys -----------------------------------------------------------------
 void launch_block_aabb(const float4* global, int64_t n, float* aabb /* nb x 8 */, hipStream_t s);
 void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, LatticeTable* tables /* [2] */, hipStream_t s);
-void launch_voxel_keys(const float4* global, int64_t n, const LatticeTable* table, double res, uint64_t* code, uint32_t* idx, hipStream_t s);
+// leaf codes are 32-bit (key32) when 3*depth + 1 <= 32, else 64-bit; the buffers are sized for 64-bit keys either way
+void launch_voxel_keys(const float4* global, int64_t n, const LatticeTable* table, double res, void* code, bool key32, uint32_t* idx, hipStream_t s);
 // ---- segmentation of the sorted (code, idx) arrays -------------------------------------------------------
-void launch_head_flags(const uint64_t* code_sorted, int64_t n, const LatticeTable* table, int32_t* head, hipStream_t s);
-void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const uint64_t* code_sorted, const LatticeTable* table, int64_t n,
+void launch_head_flags(const void* code_sorted, bool key32, int64_t n, const LatticeTable* table, int32_t* head, hipStream_t s);
+void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const void* code_sorted, bool key32, const LatticeTable* table, int64_t n,
                         int32_t* leaf_start, LevelCounts* counts, hipStream_t s);
 void launch_leaf_accept(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const LevelCounts* counts, int min_pts,
                         int64_t capacity /* leaves */, int32_t* slot_acc /* 2 per leaf */, int32_t* slot_cnt, hipStream_t s);
@@ -85,7 +86,7 @@ void launch_leaf_scan(const int32_t* slot_acc, const int32_t* slot_cnt, int32_t*
                       hipStream_t s);
 void launch_level_totals(const int32_t* slot_acc, const int32_t* slot_cnt, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
                          LevelCounts* counts /* this level */, int64_t nslots, hipStream_t s);
-void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start, const uint32_t* idx_sorted, const uint64_t* code_sorted,
+void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start, const uint32_t* idx_sorted, const void* code_sorted, bool key32,
                            const LatticeTable* table, const int32_t* slot_acc, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
                            const int32_t* pos_slot_rank /* or null */, const float4* local, const int32_t* slot_cnt, const GaussCounts* counts, int level,
                            int64_t n, float4* memb_local, int32_t* memb_idx, int32_t* memb_g, int32_t* seg_off, hipStream_t s);

@@ -492,8 +492,9 @@ __device__ __forceinline__ uint64_t spread3(uint32_t v) {  // 21 bits -> every t
     return x;
 }
 
+template <typename KeyT>  // uint32_t when the leaf code + invalid bit fit 32 bits (tree depth <= 10), else uint64_t
 __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ global, int64_t n, const LatticeTable* __restrict__ table, double res,
-                                                    uint64_t* __restrict__ code, uint32_t* __restrict__ idx) {
+                                                    KeyT* __restrict__ code, uint32_t* __restrict__ idx) {
     __shared__ LatticeTable t;
     {
         const int words = sizeof(LatticeTable) / 4;
@@ -521,36 +522,44 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ g
             const uint32_t kz = ((uint32_t)(((double)p.z - t.mn[e][2]) / res) & mask) + t.suffix_shift[e][2];
             c = (spread3(kx) << 2) | (spread3(ky) << 1) | spread3(kz);
         }
-        code[i] = c;
+        code[i] = (KeyT)c;
         idx[i] = (uint32_t)i;
     }
 }
-void launch_voxel_keys(const float4* global, int64_t n, const LatticeTable* table, double res, uint64_t* code, uint32_t* idx, hipStream_t s) {
+void launch_voxel_keys(const float4* global, int64_t n, const LatticeTable* table, double res, void* code, bool key32, uint32_t* idx, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_voxel_keys, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, code, idx);
+    if (key32)
+        hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint32_t*)code, idx);
+    else
+        hipLaunchKernelGGL(k_voxel_keys<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint64_t*)code, idx);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // segmentation of the sorted arrays into leaves, acceptance, member gather
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_head_flags(const uint64_t* __restrict__ code, int64_t n, const LatticeTable* __restrict__ table,
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_head_flags(const KeyT* __restrict__ code, int64_t n, const LatticeTable* __restrict__ table,
                                                     int32_t* __restrict__ head) {
-    const uint64_t invalid = 1ull << (3 * table->final_depth);
+    const KeyT invalid = (KeyT)(1ull << (3 * table->final_depth));
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t c = code[i];
+        const KeyT c = code[i];
         head[i] = (c != invalid && (i == 0 || code[i - 1] != c)) ? 1 : 0;
     }
 }
-void launch_head_flags(const uint64_t* code_sorted, int64_t n, const LatticeTable* table, int32_t* head, hipStream_t s) {
+void launch_head_flags(const void* code_sorted, bool key32, int64_t n, const LatticeTable* table, int32_t* head, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_head_flags, dim3(grid_for(n, 256)), dim3(256), 0, s, code_sorted, n, table, head);
+    if (key32)
+        hipLaunchKernelGGL(k_head_flags<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint32_t*)code_sorted, n, table, head);
+    else
+        hipLaunchKernelGGL(k_head_flags<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const uint64_t*)code_sorted, n, table, head);
 }
 
+template <typename KeyT>
 __global__ __launch_bounds__(256) void k_leaf_starts(const int32_t* __restrict__ head, const int32_t* __restrict__ leaf_incl,
-                                                     const uint64_t* __restrict__ code, const LatticeTable* __restrict__ table, int64_t n,
+                                                     const KeyT* __restrict__ code, const LatticeTable* __restrict__ table, int64_t n,
                                                      int32_t* __restrict__ leaf_start, LevelCounts* __restrict__ counts) {
-    const uint64_t invalid = 1ull << (3 * table->final_depth);
+    const KeyT invalid = (KeyT)(1ull << (3 * table->final_depth));
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         if (head[i]) leaf_start[leaf_incl[i] - 1] = (int32_t)i;
@@ -560,10 +569,15 @@ __global__ __launch_bounds__(256) void k_leaf_starts(const int32_t* __restrict__
         }
     }
 }
-void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const uint64_t* code_sorted, const LatticeTable* table, int64_t n,
+void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const void* code_sorted, bool key32, const LatticeTable* table, int64_t n,
                         int32_t* leaf_start, LevelCounts* counts, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_leaf_starts, dim3(grid_for(n, 256)), dim3(256), 0, s, head, leaf_of_pos, code_sorted, table, n, leaf_start, counts);
+    if (key32)
+        hipLaunchKernelGGL(k_leaf_starts<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, head, leaf_of_pos, (const uint32_t*)code_sorted, table, n,
+                           leaf_start, counts);
+    else
+        hipLaunchKernelGGL(k_leaf_starts<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, head, leaf_of_pos, (const uint64_t*)code_sorted, table, n,
+                           leaf_start, counts);
 }
 
 // DmsaOptimizer.h:302-307: a leaf becomes a point set iff size >= minNumberPts and max(id) != min(id)
@@ -746,15 +760,16 @@ void launch_level_totals(const int32_t* slot_acc, const int32_t* slot_cnt, const
 
 // members of accepted sets, physically regrouped in Gaussian order (leaf DFS order, ascending point index inside a
 // set): the correspondence kernel then streams contiguous float4s instead of gathering through index lists.
+template <typename KeyT>
 __global__ __launch_bounds__(256) void k_gather_members(const int32_t* __restrict__ leaf_incl, const int32_t* __restrict__ leaf_start,
-                                                        const uint32_t* __restrict__ idx_sorted, const uint64_t* __restrict__ code,
+                                                        const uint32_t* __restrict__ idx_sorted, const KeyT* __restrict__ code,
                                                         const LatticeTable* __restrict__ table, const int32_t* __restrict__ slot_acc,
                                                         const int32_t* __restrict__ gauss_of_slot, const int32_t* __restrict__ memb_of_slot,
                                                         const int32_t* __restrict__ pos_slot_rank, const float4* __restrict__ local,
                                                         const int32_t* __restrict__ slot_cnt, const GaussCounts* __restrict__ counts, int level,
                                                         int64_t n, float4* __restrict__ memb_local, int32_t* __restrict__ memb_idx,
                                                         int32_t* __restrict__ memb_g, int32_t* __restrict__ seg_off) {
-    const uint64_t invalid = 1ull << (3 * table->final_depth);
+    const KeyT invalid = (KeyT)(1ull << (3 * table->final_depth));
     const int gbase = level == 0 ? 0 : counts->level[0].num_gauss;
     const int mbase = level == 0 ? 0 : counts->level[0].num_memb;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -781,13 +796,19 @@ __global__ __launch_bounds__(256) void k_gather_members(const int32_t* __restric
         if (rank == 0) seg_off[g] = dst;
     }
 }
-void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start, const uint32_t* idx_sorted, const uint64_t* code_sorted,
+void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start, const uint32_t* idx_sorted, const void* code_sorted, bool key32,
                            const LatticeTable* table, const int32_t* slot_acc, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
                            const int32_t* pos_slot_rank, const float4* local, const int32_t* slot_cnt, const GaussCounts* counts, int level, int64_t n,
                            float4* memb_local, int32_t* memb_idx, int32_t* memb_g, int32_t* seg_off, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_gather_members, dim3(grid_for(n, 256)), dim3(256), 0, s, leaf_of_pos, leaf_start, idx_sorted, code_sorted, table, slot_acc,
-                       gauss_of_slot, memb_of_slot, pos_slot_rank, local, slot_cnt, counts, level, n, memb_local, memb_idx, memb_g, seg_off);
+    if (key32)
+        hipLaunchKernelGGL(k_gather_members<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, leaf_of_pos, leaf_start, idx_sorted,
+                           (const uint32_t*)code_sorted, table, slot_acc, gauss_of_slot, memb_of_slot, pos_slot_rank, local, slot_cnt, counts, level, n,
+                           memb_local, memb_idx, memb_g, seg_off);
+    else
+        hipLaunchKernelGGL(k_gather_members<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, leaf_of_pos, leaf_start, idx_sorted,
+                           (const uint64_t*)code_sorted, table, slot_acc, gauss_of_slot, memb_of_slot, pos_slot_rank, local, slot_cnt, counts, level, n,
+                           memb_local, memb_idx, memb_g, seg_off);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1428,7 +1449,8 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
 
 // Single-Gaussian tiles (more than kTilePoints members, ~30 % of all members at the benchmark size): one 1024-thread
 // workgroup per (Gaussian, evaluation) streams the members twice (second pass from L2) with four loads in flight per lane.
-constexpr int kBigThreads = 1024;
+constexpr int kBigThreads = 512;
+constexpr int kBigKeep = 8;  // transformed members kept in registers per thread (8192 per workgroup)
 __device__ __forceinline__ float3 big_point(const float4* __restrict__ s_tab, const float4 p) {
     const int row = tw_row(__float_as_int(p.w));
     return apply_row3(s_tab[3 * row], s_tab[3 * row + 1], s_tab[3 * row + 2], p.x, p.y, p.z);
@@ -1454,17 +1476,20 @@ __global__ __launch_bounds__(kBigThreads) void k_residuals_big(const float4* __r
         __syncthreads();
         for (int q = tid; q < td.nrows * 3; q += kBigThreads) s_tab[q] = gtab[3 * my_rows[q / 3] + (q % 3)];
         __syncthreads();
+        // the first kBigKeep members per thread stay in registers (transformed) for the second pass; the rest streams twice
+        float qx[kBigKeep], qy[kBigKeep], qz[kBigKeep];
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-        int j = tid;
-        for (; j + 3 * kBigThreads < np; j += 4 * kBigThreads) {
-            const float4 p0 = mp[j], p1 = mp[j + kBigThreads], p2 = mp[j + 2 * kBigThreads], p3 = mp[j + 3 * kBigThreads];
-            const float3 q0 = big_point(s_tab, p0), q1 = big_point(s_tab, p1), q2 = big_point(s_tab, p2), q3 = big_point(s_tab, p3);
-            sx += q0.x, sy += q0.y, sz += q0.z;
-            sx += q1.x, sy += q1.y, sz += q1.z;
-            sx += q2.x, sy += q2.y, sz += q2.z;
-            sx += q3.x, sy += q3.y, sz += q3.z;
+#pragma unroll
+        for (int k = 0; k < kBigKeep; ++k) {
+            const int j = tid + kBigThreads * k;
+            qx[k] = 0.f, qy[k] = 0.f, qz[k] = 0.f;
+            if (j < np) {
+                const float3 q = big_point(s_tab, mp[j]);
+                qx[k] = q.x, qy[k] = q.y, qz[k] = q.z;
+                sx += q.x, sy += q.y, sz += q.z;
+            }
         }
-        for (; j < np; j += kBigThreads) {
+        for (int j = tid + kBigThreads * kBigKeep; j < np; j += kBigThreads) {
             const float3 q = big_point(s_tab, mp[j]);
             sx += q.x, sy += q.y, sz += q.z;
         }
@@ -1476,24 +1501,21 @@ __global__ __launch_bounds__(kBigThreads) void k_residuals_big(const float4* __r
         const float nf = (float)np;
         const float mx = sx / nf, my = sy / nf, mz = sz / nf;
         double acc = 0.0;
-        auto term = [&](const float4 p) {
-            const float3 q = big_point(s_tab, p);
-            const float d0 = q.x - mx, d1 = q.y - my, d2 = q.z - mz;
+        auto term = [&](const float gx, const float gy, const float gz) {
+            const float d0 = gx - mx, d1 = gy - my, d2 = gz - mz;
             const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
             const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
             const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
             const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
             return (double)sum3f(v0 * d0, v1 * d1, v2 * d2);
         };
-        j = tid;
-        for (; j + 3 * kBigThreads < np; j += 4 * kBigThreads) {
-            const float4 p0 = mp[j], p1 = mp[j + kBigThreads], p2 = mp[j + 2 * kBigThreads], p3 = mp[j + 3 * kBigThreads];
-            acc += term(p0);
-            acc += term(p1);
-            acc += term(p2);
-            acc += term(p3);
+#pragma unroll
+        for (int k = 0; k < kBigKeep; ++k)
+            if (tid + kBigThreads * k < np) acc += term(qx[k], qy[k], qz[k]);
+        for (int j = tid + kBigThreads * kBigKeep; j < np; j += kBigThreads) {
+            const float3 q = big_point(s_tab, mp[j]);
+            acc += term(q.x, q.y, q.z);
         }
-        for (; j < np; j += kBigThreads) acc += term(mp[j]);
         acc = wave_allsum(acc);
         if (lane == 0) s_redd[wave] = acc;
         __syncthreads();
