@@ -113,9 +113,24 @@ def main():
         iters = rep.iterations
         value = world * iters / elapsed
         launches = max(1, tm.residual_launches)
+        evals = max(1, tm.residual_evaluations)
         avg_ms = tm.residual_kernel_ms / launches
-        bytes_per_launch = tm.residual_algorithmic_bytes / launches
+        # unit of work = one evaluation, bytes(1) = 16*Mm + 56*M + 48*(n_t+1); a launch processes B units.
+        unit_bytes = tm.residual_unit_bytes / evals
+        bytes_per_launch = tm.residual_unit_bytes / launches            # per-unit figure x units per launch
+        compulsory_per_launch = tm.residual_algorithmic_bytes / launches  # bytes(B): members read once per launch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tj = json.load(f)
+            if tj.get("workload") == wl:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+        # fp32 vector-ALU view of the same launches: 48 flop per member and evaluation, none fusable into FMA
+        flops = 48.0 * rep.num_memberships * evals
+        valu_tflops = flops / (tm.residual_kernel_ms * 1e-3) / 1e12 if tm.residual_kernel_ms > 0 else 0.0
         out = {
             "metric": "DMSA iterations/sec (10-scan window, 131072 pts/scan)",
             "value": round(value, 3),
@@ -141,17 +156,25 @@ def main():
                 "sharding": "independent windows per rank + pose all-gather" if world > 1 else "single GPU",
             },
             "roofline": {
-                "kernel": "k_residuals (correspondence kernel, B pose tables per launch)",
+                "kernel": "correspondence kernel (k_residuals_tiles + k_residuals_big), B evaluations per launch",
                 "bound": "hbm",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
                 "avg_launch_ms": round(avg_ms, 5),
                 "launches": int(tm.residual_launches),
                 "evaluations": int(tm.residual_evaluations),
+                "algorithmic_bytes_per_evaluation": round(unit_bytes, 1),
                 "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
+                "compulsory_bytes_per_launch": round(compulsory_per_launch, 1),
+                "us_per_evaluation": round(1e3 * tm.residual_kernel_ms / evals, 3),
+                "note": "achieved = (per-evaluation algorithmic bytes x evaluations per launch) / HIP-event launch time; a launch "
+                        "reads the members once for all its evaluations (compulsory_bytes_per_launch), so at B>1 the kernel is "
+                        "bound by fp32 vector issue, not HBM",
+                "valu": {"achieved_tflops": round(valu_tflops, 2), "peak_tflops_no_fma": 78.6,
+                         "frac": round(valu_tflops / 78.6, 4)},
             },
             "stage_ms_per_step": {
                 "residual_kernel": round(tm.residual_kernel_ms / max(1, iters), 4),

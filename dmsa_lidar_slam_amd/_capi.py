@@ -140,6 +140,7 @@ class Timing(C.Structure):
         ("residual_launches", C.c_int64),
         ("residual_evaluations", C.c_int64),
         ("residual_algorithmic_bytes", C.c_double),
+        ("residual_unit_bytes", C.c_double),
         ("voxelize_ms", C.c_double),
         ("gaussian_fit_ms", C.c_double),
         ("pose_table_ms", C.c_double),

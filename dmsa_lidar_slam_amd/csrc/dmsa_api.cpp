@@ -106,7 +106,7 @@ struct dmsa_ctx {
     std::vector<hipEvent_t> free_events;
     double t_ms[T_COUNT] = {0, 0, 0, 0, 0, 0};
     int64_t residual_launches = 0, residual_evals = 0;
-    double residual_bytes = 0.0;
+    double residual_bytes = 0.0, residual_unit_bytes = 0.0;
     int evaluations = 0;
     std::vector<dmsa_iter_trace> trace;
 };
@@ -446,6 +446,7 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
     ctx->residual_launches += 1;
     ctx->residual_evals += B;
     ctx->residual_bytes += 16.0 * (double)ctx->Mm + 48.0 * ctx->M + (double)B * (48.0 * ctx->rows + 8.0 * ctx->M);
+    ctx->residual_unit_bytes += (double)B * (16.0 * (double)ctx->Mm + 56.0 * ctx->M + 48.0 * ctx->rows);
     HIPCHK(hipGetLastError());
     const int a = ctx->extra_rows;
     if (a > 0 && extra != nullptr) {
@@ -978,12 +979,13 @@ int dmsa_get_timing(dmsa_ctx* ctx, dmsa_timing* t, int32_t reset) {
     if (t) {
         t->residual_kernel_ms = ctx->t_ms[T_RESIDUAL], t->residual_launches = ctx->residual_launches, t->residual_evaluations = ctx->residual_evals;
         t->residual_algorithmic_bytes = ctx->residual_bytes;
+        t->residual_unit_bytes = ctx->residual_unit_bytes;
         t->voxelize_ms = ctx->t_ms[T_VOXEL], t->gaussian_fit_ms = ctx->t_ms[T_FIT], t->pose_table_ms = ctx->t_ms[T_TABLE];
         t->normal_eq_ms = ctx->t_ms[T_NORMAL], t->total_ms = ctx->t_ms[T_TOTAL];
     }
     if (reset) {
         for (double& v : ctx->t_ms) v = 0.0;
-        ctx->residual_launches = 0, ctx->residual_evals = 0, ctx->residual_bytes = 0.0;
+        ctx->residual_launches = 0, ctx->residual_evals = 0, ctx->residual_bytes = 0.0, ctx->residual_unit_bytes = 0.0;
     }
     return DMSA_OK;
 }

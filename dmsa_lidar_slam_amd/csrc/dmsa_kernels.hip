@@ -1448,9 +1448,11 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
 }
 
 // Single-Gaussian tiles (more than kTilePoints members, ~30 % of all members at the benchmark size): one 1024-thread
-// workgroup per (Gaussian, evaluation) streams the members twice (second pass from L2) with four loads in flight per lane.
-constexpr int kBigThreads = 512;
-constexpr int kBigKeep = 8;  // transformed members kept in registers per thread (8192 per workgroup)
+// workgroup per (Gaussian, chunk of evaluations).  Its first 16384 members stay in registers (local coordinates) for
+// every evaluation of the chunk, so HBM/L2 sees them once per chunk; both passes transform on the fly.  Members beyond
+// that capacity are streamed per evaluation.
+constexpr int kBigThreads = 1024;
+constexpr int kBigKeep = 16;  // members kept in registers per thread
 __device__ __forceinline__ float3 big_point(const float4* __restrict__ s_tab, const float4 p) {
     const int row = tw_row(__float_as_int(p.w));
     return apply_row3(s_tab[3 * row], s_tab[3 * row + 1], s_tab[3 * row + 2], p.x, p.y, p.z);
@@ -1458,39 +1460,44 @@ __device__ __forceinline__ float3 big_point(const float4* __restrict__ s_tab, co
 __global__ __launch_bounds__(kBigThreads) void k_residuals_big(const float4* __restrict__ memb_tile, const float4* __restrict__ info12,
                                                               const float4* __restrict__ tables, int rows, const TileDesc* __restrict__ tiles,
                                                               const int2* __restrict__ big_list, const int32_t* __restrict__ tile_rows, int B,
-                                                              int b_chunk, double* __restrict__ E, int64_t ldE) {
+                                                              int b_chunk, int max_rows, double* __restrict__ E, int64_t ldE) {
     const TileDesc td = tiles[big_list[blockIdx.x].x];
     extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
     float* s_red = reinterpret_cast<float*>(s_dyn);          // 16 waves x 4 floats (256 B)
     double* s_redd = reinterpret_cast<double*>(s_dyn) + 32;  // 16 doubles (128 B)
-    float4* s_tab = s_dyn + 24;
+    float4* s_tab = s_dyn + 24;                              // [2][max_rows][3]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int np = td.p1 - td.p0, g = td.g0;
     const float4* mp = memb_tile + td.p0;
+    float4 pt[kBigKeep];
+#pragma unroll
+    for (int k = 0; k < kBigKeep; ++k) {
+        const int j = tid + kBigThreads * k;
+        const float4 v = mp[min(j, np - 1)];
+        pt[k] = v;
+    }
     const float4 i0 = info12[3 * g], i1 = info12[3 * g + 1], i2 = info12[3 * g + 2];
     const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
     const int32_t* my_rows = tile_rows + td.row_off;
+    const int nq = td.nrows * 3;
     const int b_begin = blockIdx.y * b_chunk, b_end = min(B, b_begin + b_chunk);
+    const float nf = (float)np;
     for (int b = b_begin; b < b_end; ++b) {
+        float4* tab = s_tab + (size_t)(b & 1) * max_rows * 3;  // double-buffered: one barrier covers staging and reuse
         const float4* gtab = tables + (size_t)b * rows * 3;
+        for (int q = tid; q < nq; q += kBigThreads) tab[q] = gtab[3 * my_rows[q / 3] + (q % 3)];
         __syncthreads();
-        for (int q = tid; q < td.nrows * 3; q += kBigThreads) s_tab[q] = gtab[3 * my_rows[q / 3] + (q % 3)];
-        __syncthreads();
-        // the first kBigKeep members per thread stay in registers (transformed) for the second pass; the rest streams twice
-        float qx[kBigKeep], qy[kBigKeep], qz[kBigKeep];
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
 #pragma unroll
         for (int k = 0; k < kBigKeep; ++k) {
-            const int j = tid + kBigThreads * k;
-            qx[k] = 0.f, qy[k] = 0.f, qz[k] = 0.f;
-            if (j < np) {
-                const float3 q = big_point(s_tab, mp[j]);
-                qx[k] = q.x, qy[k] = q.y, qz[k] = q.z;
+            if (tid + kBigThreads * k < np) {
+                const float3 q = big_point(tab, pt[k]);
                 sx += q.x, sy += q.y, sz += q.z;
             }
+            if ((k & 3) == 3) asm volatile("" ::: "memory");
         }
         for (int j = tid + kBigThreads * kBigKeep; j < np; j += kBigThreads) {
-            const float3 q = big_point(s_tab, mp[j]);
+            const float3 q = big_point(tab, mp[j]);
             sx += q.x, sy += q.y, sz += q.z;
         }
         sx = wave_allsum(sx), sy = wave_allsum(sy), sz = wave_allsum(sz);
@@ -1498,11 +1505,10 @@ __global__ __launch_bounds__(kBigThreads) void k_residuals_big(const float4* __r
         __syncthreads();
         sx = 0.0f, sy = 0.0f, sz = 0.0f;
         for (int w2 = 0; w2 < kBigThreads / 64; ++w2) sx += s_red[4 * w2], sy += s_red[4 * w2 + 1], sz += s_red[4 * w2 + 2];
-        const float nf = (float)np;
         const float mx = sx / nf, my = sy / nf, mz = sz / nf;
         double acc = 0.0;
-        auto term = [&](const float gx, const float gy, const float gz) {
-            const float d0 = gx - mx, d1 = gy - my, d2 = gz - mz;
+        auto term = [&](const float3 q) {
+            const float d0 = q.x - mx, d1 = q.y - my, d2 = q.z - mz;
             const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
             const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
             const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
@@ -1510,12 +1516,11 @@ __global__ __launch_bounds__(kBigThreads) void k_residuals_big(const float4* __r
             return (double)sum3f(v0 * d0, v1 * d1, v2 * d2);
         };
 #pragma unroll
-        for (int k = 0; k < kBigKeep; ++k)
-            if (tid + kBigThreads * k < np) acc += term(qx[k], qy[k], qz[k]);
-        for (int j = tid + kBigThreads * kBigKeep; j < np; j += kBigThreads) {
-            const float3 q = big_point(s_tab, mp[j]);
-            acc += term(q.x, q.y, q.z);
+        for (int k = 0; k < kBigKeep; ++k) {
+            if (tid + kBigThreads * k < np) acc += term(big_point(tab, pt[k]));
+            if ((k & 3) == 3) asm volatile("" ::: "memory");
         }
+        for (int j = tid + kBigThreads * kBigKeep; j < np; j += kBigThreads) acc += term(big_point(tab, mp[j]));
         acc = wave_allsum(acc);
         if (lane == 0) s_redd[wave] = acc;
         __syncthreads();
@@ -1524,6 +1529,7 @@ __global__ __launch_bounds__(kBigThreads) void k_residuals_big(const float4* __r
             for (int w2 = 0; w2 < kBigThreads / 64; ++w2) tot += s_redd[w2];
             E[(size_t)b * ldE + g] = sqrt(fabs(tot));
         }
+        // s_red / s_redd are rewritten only after the next evaluation's first barrier
     }
 }
 
@@ -1723,7 +1729,7 @@ void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, c
     if (b_chunk > out_cap) b_chunk = out_cap > 0 ? out_cap : 1;
     chunks = (B + b_chunk - 1) / b_chunk;
     const size_t lds_tiles = (size_t)kRtOffTab + (size_t)2 * max_rows * 48 + (size_t)b_chunk * max_gauss * 8;
-    const size_t lds_big = 384 + (size_t)max_rows * 48;
+    const size_t lds_big = 384 + (size_t)2 * max_rows * 48;
     if (big_n == 2)
         hipLaunchKernelGGL(k_residuals_tiles<2>, dim3(num_tiles, chunks), dim3(kTileThreads), lds_tiles, s, memb_tile, seg_off,
                            reinterpret_cast<const float4*>(info12), reinterpret_cast<const float4*>(tables), rows, tiles, tile_rows, B, b_chunk, max_rows, max_gauss, E, ldE, g_phase_clk);
@@ -1731,9 +1737,14 @@ void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, c
         hipLaunchKernelGGL(k_residuals_tiles<4>, dim3(num_tiles, chunks), dim3(kTileThreads), lds_tiles, s, memb_tile, seg_off,
                            reinterpret_cast<const float4*>(info12), reinterpret_cast<const float4*>(tables), rows, tiles, tile_rows, B, b_chunk, max_rows, max_gauss, E, ldE, g_phase_clk);
     // the few single-Gaussian tiles are long: give every evaluation its own workgroup
-    if (num_fallback > 0)  // `fallback` lists the single-Gaussian (streamed) tiles
-        hipLaunchKernelGGL(k_residuals_big, dim3(num_fallback, B), dim3(kBigThreads), lds_big, s, memb_tile, reinterpret_cast<const float4*>(info12),
-                           reinterpret_cast<const float4*>(tables), rows, tiles, fallback, tile_rows, B, 1, E, ldE);
+    if (num_fallback > 0) {  // `fallback` lists the single-Gaussian tiles
+        int bchunks = (512 + num_fallback - 1) / num_fallback;  // enough workgroups for two rounds of the chip
+        if (bchunks > B) bchunks = B;
+        const int bb = (B + bchunks - 1) / bchunks;
+        bchunks = (B + bb - 1) / bb;
+        hipLaunchKernelGGL(k_residuals_big, dim3(num_fallback, bchunks), dim3(kBigThreads), lds_big, s, memb_tile, reinterpret_cast<const float4*>(info12),
+                           reinterpret_cast<const float4*>(tables), rows, tiles, fallback, tile_rows, B, bb, max_rows, E, ldE);
+    }
 }
 
 // Mirror variant: one thread per Gaussian; the float mean and the double sum run in member order exactly like

@@ -222,7 +222,10 @@ typedef struct dmsa_timing {
     double residual_kernel_ms;   /* accumulated time inside the correspondence kernel                 */
     int64_t residual_launches;
     int64_t residual_evaluations;
-    double residual_algorithmic_bytes; /* sum over launches of 16*Mm + 48*M + B*(48*rows + 8*M) */
+    double residual_algorithmic_bytes; /* sum over launches of bytes(B) = 16*Mm + 48*M + B*(48*rows + 8*M):
+                                          what a launch of B evaluations must move when it reads the members once    */
+    double residual_unit_bytes;        /* sum over launches of B * bytes(1), bytes(1) = 16*Mm + 56*M + 48*rows: the per-unit
+                                          (per-evaluation) figure times the units each launch processed                */
     double voxelize_ms;
     double gaussian_fit_ms;
     double pose_table_ms;

@@ -34,7 +34,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(capi.Settings) == 72
     assert C.sizeof(capi.Report) == 48
     assert C.sizeof(capi.VoxelLevelInfo) == 56
-    assert C.sizeof(capi.Timing) == 72
+    assert C.sizeof(capi.Timing) == 80
     assert C.sizeof(capi.WindowProblem) == 192
     assert C.sizeof(capi.KeyframeProblem) == 360
 
