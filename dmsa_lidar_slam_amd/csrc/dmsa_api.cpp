@@ -160,6 +160,15 @@ void drain_timers(dmsa_ctx* ctx) {
     ctx->pending.clear();
 }
 
+// Host synchronisation on the critical path of an iteration: polling the stream avoids the ~20-30 us wake-up latency of a
+// blocking hipStreamSynchronize (there are four such points per iteration).
+hipError_t sync_spin(hipStream_t stream) {
+    hipError_t e;
+    while ((e = hipStreamQuery(stream)) == hipErrorNotReady) {
+    }
+    return e;
+}
+
 int set_device(dmsa_ctx* ctx) {
     HIPCHK(hipSetDevice(ctx->device));
     return DMSA_OK;
@@ -191,7 +200,7 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
     HIPCHK(ctx->d_memb_of_slot.ensure(2 * n * 4));
     HIPCHK(ctx->d_sort_tmp.ensure(sort_pairs_temp_bytes(n)));
     HIPCHK(ctx->d_scan_tmp.ensure(scan_temp_bytes(2 * n)));
-    HIPCHK(ctx->d_counts.ensure(sizeof(GaussCounts)));
+    HIPCHK(ctx->d_counts.ensure(sizeof(GaussCounts) + sizeof(TileCounts)));  // read back together
     // memberships: every point belongs to at most one set per resolution
     HIPCHK(ctx->d_memb_local.ensure(2 * n * 16));
     HIPCHK(ctx->d_memb_idx.ensure(2 * n * 4));
@@ -313,7 +322,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     ctx->level_res[1] = (double)(s.grid_size_2_factor * ctx->min_grid_size);
     if (!lvl_on[0]) ctx->level_res[0] = ctx->level_res[1];
     if (!lvl_on[1]) ctx->level_res[1] = ctx->level_res[0];
-    HIPCHK(hipMemsetAsync(ctx->d_counts.p, 0, sizeof(GaussCounts), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counts.p, 0, sizeof(GaussCounts) + sizeof(TileCounts), ctx->stream));
     const bool speculate = allow_speculation && ctx->depth_guess[0] >= 0 && ctx->depth_guess[1] >= 0 && ctx->depth_guess[0] < 20 && ctx->depth_guess[1] < 20;
     {
         ScopedTimer tm(ctx, T_VOXEL);
@@ -322,7 +331,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         launch_lattice(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), nb, ctx->level_res[0], ctx->level_res[1], ctx->d_lattice.as<LatticeTable>(),
                        ctx->stream);
         HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));
-        if (!speculate) HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #1: tree depths select the radix-sort bit range
+        if (!speculate) HIPCHK(sync_spin(ctx->stream));  // sync #1: tree depths select the radix-sort bit range
     }
     // The sort only needs an UPPER bound of the tree depth.  From the second iteration on the previous depths are used
     // without waiting for the lattice kernel; the true depths arrive with the counts (sync #2) and a too-small guess (the
@@ -380,14 +389,18 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     if (tiles_on) {
         ScopedTimer tm(ctx, T_FIT);
         launch_build_tiles(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_memb_local.as<float4>(), ctx->d_memb_g.as<int32_t>(), ctx->rows, ctx->d_tiles.as<TileDesc>(),
-                           ctx->d_tile_counts.as<TileCounts>(), ctx->d_fallback.as<int2>(), ctx->d_memb_tile.as<float4>(), ctx->d_tile_rows.as<int32_t>(),
+                           reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_memb_tile.as<float4>(), ctx->d_tile_rows.as<int32_t>(),
                            ctx->stream);
-        HIPCHK(hipMemcpyAsync(&htc, ctx->d_tile_counts.p, sizeof(TileCounts), hipMemcpyDeviceToHost, ctx->stream));
     }
-    GaussCounts h{};
-    HIPCHK(hipMemcpyAsync(&h, ctx->d_counts.p, sizeof(GaussCounts), hipMemcpyDeviceToHost, ctx->stream));
+    struct {
+        GaussCounts g;
+        TileCounts t;
+    } both{};
+    HIPCHK(hipMemcpyAsync(&both, ctx->d_counts.p, sizeof(both), hipMemcpyDeviceToHost, ctx->stream));
     if (overlap) CHK(overlap());
-    HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #2: M sizes every later launch
+    HIPCHK(sync_spin(ctx->stream));  // sync #2: M sizes every later launch
+    const GaussCounts h = both.g;
+    htc = both.t;
     for (int l = 0; l < 2; ++l) {
         if (lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
         if (speculate && lvl_on[l] && ctx->h_lattice[l].final_depth > sort_depth[l]) {
@@ -401,7 +414,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         ScopedTimer tm(ctx, T_FIT);
         if (tiles_on && ctx->num_tiles > 0)
             launch_fit_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_tables.as<float>(), ctx->tile_max_rows,
-                             ctx->d_tiles.as<TileDesc>(), ctx->d_tile_counts.as<TileCounts>(), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
+                             ctx->d_tiles.as<TileDesc>(), reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
                              ctx->d_info12.as<float>(), ctx->stream);
         launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
     }
@@ -535,7 +548,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             launch_normal_equations(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, one_div_incr, ctx->d_ne_partial.as<double>(), ctx->d_Hp.as<double>(), ctx->stream);
         }
         HIPCHK(hipMemcpyAsync(Hp.data(), ctx->d_Hp.p, Hp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #3
+        HIPCHK(sync_spin(ctx->stream));  // sync #3
         const int n1 = P + 1;
         for (int j = 0; j < P; ++j)
             for (int i = 0; i < P; ++i) H[(size_t)j * P + i] = Hp[(size_t)j * n1 + i];
@@ -573,7 +586,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             launch_squared_sums(ctx->d_E.as<double>(), ctx->ldE, rowsE, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
         }
         HIPCHK(hipMemcpyAsync(errs, ctx->d_sq_out.p, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));  // sync #4
+        HIPCHK(sync_spin(ctx->stream));  // sync #4
         drain_timers(ctx);
         double minError = error0;
         bestK = 0;

@@ -706,21 +706,35 @@ void launch_leaf_split(const int32_t* leaf_start, const uint32_t* idx_sorted, co
 __global__ __launch_bounds__(1024) void k_leaf_scan(const int32_t* __restrict__ slot_acc, const int32_t* __restrict__ slot_cnt,
                                                     int32_t* __restrict__ gauss_of_slot, int32_t* __restrict__ memb_of_slot,
                                                     LevelCounts* __restrict__ counts) {
+    constexpr int kPer = 16;  // slots per thread and round
     __shared__ int s_w[16][2];
     __shared__ int s_carry[2];
     const int nslots = 2 * counts->num_leaves;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_carry[0] = 0, s_carry[1] = 0;
     __syncthreads();
-    for (int base = 0; base < nslots; base += 4096) {
-        int a[4], c[4], ta = 0, tc2 = 0;
+    for (int base = 0; base < nslots; base += 1024 * kPer) {
+        int a[kPer], c[kPer], ta = 0, tc2 = 0;
+        const int first = base + kPer * tid;
+        if (first + kPer <= nslots) {  // vectorised: 4 x int4 per array
+            const int4* pa = reinterpret_cast<const int4*>(slot_acc + first);
+            const int4* pc = reinterpret_cast<const int4*>(slot_cnt + first);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + 4 * tid + k;
-            a[k] = i < nslots ? slot_acc[i] : 0;
-            c[k] = i < nslots ? slot_cnt[i] : 0;
-            ta += a[k], tc2 += c[k];
+            for (int k = 0; k < kPer / 4; ++k) {
+                const int4 va = pa[k], vc = pc[k];
+                a[4 * k] = va.x, a[4 * k + 1] = va.y, a[4 * k + 2] = va.z, a[4 * k + 3] = va.w;
+                c[4 * k] = vc.x, c[4 * k + 1] = vc.y, c[4 * k + 2] = vc.z, c[4 * k + 3] = vc.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                const int i = first + k;
+                a[k] = i < nslots ? slot_acc[i] : 0;
+                c[k] = i < nslots ? slot_cnt[i] : 0;
+            }
         }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) ta += a[k], tc2 += c[k];
         int ia = ta, ic = tc2;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -731,11 +745,24 @@ __global__ __launch_bounds__(1024) void k_leaf_scan(const int32_t* __restrict__ 
         __syncthreads();
         int ra = s_carry[0] + ia - ta, rc = s_carry[1] + ic - tc2;
         for (int w = 0; w < wave; ++w) ra += s_w[w][0], rc += s_w[w][1];
+        int oa[kPer], oc[kPer];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + 4 * tid + k;
-            if (i < nslots) gauss_of_slot[i] = ra, memb_of_slot[i] = rc;
+        for (int k = 0; k < kPer; ++k) {
+            oa[k] = ra, oc[k] = rc;
             ra += a[k], rc += c[k];
+        }
+        if (first + kPer <= nslots) {  // 16-byte stores: 4x fewer (lane-strided) store instructions
+            int4* qa = reinterpret_cast<int4*>(gauss_of_slot + first);
+            int4* qc = reinterpret_cast<int4*>(memb_of_slot + first);
+#pragma unroll
+            for (int k = 0; k < kPer / 4; ++k) {
+                qa[k] = make_int4(oa[4 * k], oa[4 * k + 1], oa[4 * k + 2], oa[4 * k + 3]);
+                qc[k] = make_int4(oc[4 * k], oc[4 * k + 1], oc[4 * k + 2], oc[4 * k + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPer; ++k)
+                if (first + k < nslots) gauss_of_slot[first + k] = oa[k], memb_of_slot[first + k] = oc[k];
         }
         __syncthreads();
         if (tid == 1023) s_carry[0] = ra, s_carry[1] = rc;
@@ -1114,54 +1141,58 @@ __device__ __forceinline__ int tw_row(int w) { return w & 0xfff; }
 __device__ __forceinline__ int tw_gauss(int w) { return (w >> 12) & 0x3ff; }
 __device__ __forceinline__ bool tw_end(int w) { return w < 0; }
 
-__global__ __launch_bounds__(1024) void k_build_tiles(const int32_t* __restrict__ seg_off, const GaussCounts* __restrict__ counts,
+constexpr int kBuildTilesLdsInts = 36 * 1024;  // 144 KB
+__global__ __launch_bounds__(1024) void k_build_tiles(const int32_t* __restrict__ seg_off_g, const GaussCounts* __restrict__ counts,
                                                       TileDesc* __restrict__ tiles, TileCounts* __restrict__ tc, int2* __restrict__ fallback) {
     __shared__ int s_wave[16];
-    __shared__ int s_carry;
-    __shared__ int s_nfb;
     __shared__ int s_nbig;
+    extern __shared__ int s_seg[];             // seg_off staged in LDS when it fits (coalesced read, random access after)
     const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
     const int half = 3 * kTilePoints / 4;      // window of member positions that starts a new tile
     const int own_n = kTilePoints / 4;         // Gaussians above this size get a tile of their own (tile <= window + own_n)
-    if (threadIdx.x == 0) s_carry = 0, s_nfb = 0, s_nbig = 0;
+    if (threadIdx.x == 0) s_nbig = 0;
+    const bool in_lds = M + 1 <= kBuildTilesLdsInts;
+    if (in_lds)
+        for (int i = threadIdx.x; i <= M; i += 1024) s_seg[i] = seg_off_g[i];
     __syncthreads();
+    const int32_t* seg_off = in_lds ? s_seg : seg_off_g;
     auto own = [&](int g) { return seg_off[g + 1] - seg_off[g] > own_n; };
-    // a tile ends at own-tile Gaussians, at T/2-member window boundaries and every kTileGauss Gaussians
+    // a tile ends at own-tile Gaussians, at window boundaries of the member positions and every kTileGauss Gaussians
     auto head = [&](int g) { return g == 0 || own(g) || own(g - 1) || (seg_off[g] / half) != (seg_off[g - 1] / half) || (g % kTileGauss) == 0; };
-    for (int base = 0; base < M; base += 1024) {
-        const int g = base + threadIdx.x;
-        const int h = (g < M && head(g)) ? 1 : 0;
-        // block inclusive scan of h
-        int v = h;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // every thread owns a contiguous run of Gaussians: count its tile heads, scan the counts once, then number the tiles
+    const int per = (M + 1023) / 1024;
+    const int g_lo = min(M, per * (int)threadIdx.x), g_hi = min(M, g_lo + per);
+    int cnt = 0;
+    for (int g = g_lo; g < g_hi; ++g) cnt += head(g) ? 1 : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int v = cnt;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(v, d);
-            if (lane >= d) v += o;
-        }
-        if (lane == 63) s_wave[wave] = v;
-        __syncthreads();
-        int pre = s_carry;
-        for (int w = 0; w < wave; ++w) pre += s_wave[w];
-        const int incl = pre + v;
-        if (g < M) {
-            const int t = incl - 1;
-            if (h) {
-                const int n = seg_off[g + 1] - seg_off[g];
-                tiles[t].g0 = g, tiles[t].p0 = seg_off[g];
-                int kind = 0;
-                if (n > kTilePoints) kind = 1;  // streamed by k_residuals_big, any size
-                tiles[t].kind = kind;
-                tiles[t].row_off = 0, tiles[t].nrows = 0, tiles[t].pad = 0;
-                if (kind == 1) fallback[atomicAdd(&s_nbig, 1)] = make_int2(t, g);  // (tile index, Gaussian) of a streamed tile
-            }
-            if (g == M - 1 || head(g + 1)) tiles[t].g1 = g + 1, tiles[t].p1 = seg_off[g + 1];
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = incl;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
     }
-    if (threadIdx.x == 0) tc->num_tiles = s_carry, tc->num_fallback = s_nbig, tc->max_rows = 0, tc->max_gauss = 0;
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    int t = v - cnt;  // tiles started before this thread's run
+    int total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) t += s_wave[w];
+        total += s_wave[w];
+    }
+    for (int g = g_lo; g < g_hi; ++g) {
+        if (head(g)) {
+            const int n = seg_off[g + 1] - seg_off[g];
+            tiles[t].g0 = g, tiles[t].p0 = seg_off[g];
+            const int kind = n > kTilePoints ? 1 : 0;  // 1: streamed by k_residuals_big, any size
+            tiles[t].kind = kind;
+            tiles[t].row_off = 0, tiles[t].nrows = 0, tiles[t].pad = 0;
+            if (kind == 1) fallback[atomicAdd(&s_nbig, 1)] = make_int2(t, g);
+            ++t;
+        }
+        if (g == M - 1 || head(g + 1)) tiles[t - 1].g1 = g + 1, tiles[t - 1].p1 = seg_off[g + 1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) tc->num_tiles = total, tc->num_fallback = s_nbig, tc->max_rows = 0, tc->max_gauss = 0;
 }
 
 // Per tile: which pose-table rows do its members reference?  Writes the ascending row list, a copy of the members
@@ -1177,9 +1208,18 @@ __global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles,
         const int p0 = tiles[t].p0, p1 = tiles[t].p1, tg0 = tiles[t].g0, tg1 = tiles[t].g1;
         for (int w = threadIdx.x; w < words; w += blockDim.x) s_bm[w] = 0u;
         __syncthreads();
-        for (int i = p0 + threadIdx.x; i < p1; i += blockDim.x) {
-            const int row = __float_as_int(memb[i].w);
-            atomicOr(&s_bm[row >> 5], 1u << (row & 31));
+        for (int i0 = p0 + threadIdx.x; i0 < p1; i0 += 4 * blockDim.x) {  // four independent loads in flight per lane
+            int row[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * blockDim.x;
+                row[u] = i < p1 ? __float_as_int(memb[i].w) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int prev = __shfl_up(row[u], 1);
+                if (row[u] >= 0 && ((threadIdx.x & 63) == 0 || prev != row[u])) atomicOr(&s_bm[row[u] >> 5], 1u << (row[u] & 31));
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1204,21 +1244,37 @@ __global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles,
                 bits &= bits - 1;
             }
         }
-        for (int i = p0 + threadIdx.x; i < p1; i += blockDim.x) {
-            float4 p = memb[i];
-            const int row = __float_as_int(p.w);
-            const int lrow = (int)s_pre[row >> 5] + __popc(s_bm[row >> 5] & ((1u << (row & 31)) - 1u));
-            const uint32_t gm = (uint32_t)memb_g[i];
-            const uint32_t packed = (uint32_t)lrow | (((gm & 0x7fffffffu) - (uint32_t)tg0) << 12) | (gm & 0x80000000u);
-            p.w = __int_as_float((int)packed);
-            memb_tile[i] = p;
+        for (int i0 = p0 + threadIdx.x; i0 < p1; i0 += 4 * blockDim.x) {
+            float4 pv[4];
+            uint32_t gm[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * blockDim.x;
+                if (i < p1) pv[u] = memb[i], gm[u] = (uint32_t)memb_g[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * blockDim.x;
+                if (i < p1) {
+                    const int row = __float_as_int(pv[u].w);
+                    const int lrow = (int)s_pre[row >> 5] + __popc(s_bm[row >> 5] & ((1u << (row & 31)) - 1u));
+                    const uint32_t packed = (uint32_t)lrow | (((gm[u] & 0x7fffffffu) - (uint32_t)tg0) << 12) | (gm[u] & 0x80000000u);
+                    pv[u].w = __int_as_float((int)packed);
+                    memb_tile[i] = pv[u];
+                }
+            }
         }
         __syncthreads();
     }
 }
 void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, const int32_t* memb_g, int rows, TileDesc* tiles,
                         TileCounts* tc, int2* fallback, float4* memb_tile, int32_t* tile_rows, hipStream_t s) {
-    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(1024), 0, s, seg_off, counts, tiles, tc, fallback);
+    static bool bt_attr = false;
+    if (!bt_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, kBuildTilesLdsInts * 4);
+        bt_attr = true;
+    }
+    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(1024), kBuildTilesLdsInts * 4, s, seg_off, counts, tiles, tc, fallback);
     const size_t lds = (size_t)((rows + 31) / 32) * 8;
     hipLaunchKernelGGL(k_tile_rows, dim3(1024), dim3(256), lds, s, tiles, tc, memb, memb_g, rows, memb_tile, tile_rows);
 }
