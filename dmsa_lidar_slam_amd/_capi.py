@@ -30,6 +30,7 @@ STOP_NUM_ITER, STOP_FEW_GAUSSIANS, STOP_NAN, STOP_NO_IMPROVEMENT, STOP_EPSILON =
 FLAG_POSE_TABLE_HOST = 0x1
 FLAG_FIXED_ITERS = 0x2
 FLAG_MIRROR_SUMS = 0x4
+FLAG_STAGE_TIMERS = 0x8
 
 
 class Settings(C.Structure):

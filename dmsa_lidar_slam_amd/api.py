@@ -23,11 +23,13 @@ class DmsaError(RuntimeError):
 class DmsaOptimizer:
     """One context == one GPU == one host thread (the reference's optimizer is not re-entrant either)."""
 
-    def __init__(self, device: int = 0, pose_table_host: bool = False, fixed_iters: bool = False, mirror_sums: bool = False):
+    def __init__(self, device: int = 0, pose_table_host: bool = False, fixed_iters: bool = False, mirror_sums: bool = False,
+                 stage_timers: bool = False):
         self._lib = capi.load_library()
         self._ctx = C.c_void_p()
         flags = (capi.FLAG_POSE_TABLE_HOST if pose_table_host else 0) | (capi.FLAG_FIXED_ITERS if fixed_iters else 0)
         flags |= capi.FLAG_MIRROR_SUMS if mirror_sums else 0
+        flags |= capi.FLAG_STAGE_TIMERS if stage_timers else 0
         rc = self._lib.dmsa_create(int(device), flags, C.byref(self._ctx))
         if rc != capi.DMSA_OK:
             self._ctx = None

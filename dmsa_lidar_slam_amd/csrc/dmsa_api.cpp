@@ -86,6 +86,8 @@ struct dmsa_ctx {
     LatticeTable h_lattice[2];
     bool key32[2] = {false, false};  // leaf codes of this level are 32-bit (tree depth <= 10)
     int depth_guess[2] = {-1, -1};   // tree depths of the previous voxelisation (speculation: saves one host sync)
+    int bits_guess[2] = {-1, -1};    // leaf-code widths of the previous voxelisation
+    bool compress_keys = true;       // drop the constant high key bits before sorting (DMSA_KEY_COMPRESS=0 disables)
     double level_res[2] = {0, 0};
     // Gaussians
     DevBuf d_memb_local, d_memb_idx, d_memb_g, d_seg_off, d_info12, d_wg_seg;
@@ -141,11 +143,16 @@ hipEvent_t get_event(dmsa_ctx* ctx) {
 struct ScopedTimer {
     dmsa_ctx* ctx;
     EventPair ev;
+    bool on;
     ScopedTimer(dmsa_ctx* c, int slot) : ctx(c) {
+        // the correspondence kernel is always timed (roofline contract); other stages only on request
+        on = slot == T_RESIDUAL || (c->flags & DMSA_FLAG_STAGE_TIMERS) != 0;
+        if (!on) return;
         ev.a = get_event(c), ev.b = get_event(c), ev.slot = slot;
         (void)hipEventRecord(ev.a, c->stream);
     }
     ~ScopedTimer() {
+        if (!on) return;
         (void)hipEventRecord(ev.b, ctx->stream);
         ctx->pending.push_back(ev);
     }
@@ -312,7 +319,8 @@ int transform_points(dmsa_ctx* ctx, int b) {
 // ---- Gaussians (DmsaOptimizer.h:78-96) ---------------------------------------------------------------------
 // `overlap` (optional) runs on the host after every voxelisation kernel has been enqueued and before the counts are read
 // back: host work placed there hides behind the GPU.
-int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<int()>& overlap = nullptr, bool allow_speculation = true) {
+int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<int()>& overlap = nullptr, bool allow_speculation = true,
+                    bool allow_compression = true) {
     const int64_t n = ctx->n;
     ctx->gaussians_valid = false;
     ctx->M = 0, ctx->M1 = 0, ctx->Mm = 0;
@@ -323,22 +331,26 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     if (!lvl_on[0]) ctx->level_res[0] = ctx->level_res[1];
     if (!lvl_on[1]) ctx->level_res[1] = ctx->level_res[0];
     HIPCHK(hipMemsetAsync(ctx->d_counts.p, 0, sizeof(GaussCounts) + sizeof(TileCounts), ctx->stream));
-    const bool speculate = allow_speculation && ctx->depth_guess[0] >= 0 && ctx->depth_guess[1] >= 0 && ctx->depth_guess[0] < 20 && ctx->depth_guess[1] < 20;
+    const bool compress = ctx->compress_keys && allow_compression;
+    const bool speculate = allow_speculation && ctx->depth_guess[0] >= 0 && ctx->depth_guess[1] >= 0 && ctx->depth_guess[0] < 20 && ctx->depth_guess[1] < 20 &&
+                           (!compress || (ctx->bits_guess[0] >= 0 && ctx->bits_guess[1] >= 0));
     {
         ScopedTimer tm(ctx, T_VOXEL);
         const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
         launch_block_aabb(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), ctx->stream);
-        launch_lattice(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), nb, ctx->level_res[0], ctx->level_res[1], ctx->d_lattice.as<LatticeTable>(),
-                       ctx->stream);
+        launch_lattice(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), nb, ctx->level_res[0], ctx->level_res[1], compress,
+                       ctx->d_lattice.as<LatticeTable>(), ctx->stream);
         HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));
         if (!speculate) HIPCHK(sync_spin(ctx->stream));  // sync #1: tree depths select the radix-sort bit range
     }
     // The sort only needs an UPPER bound of the tree depth.  From the second iteration on the previous depths are used
     // without waiting for the lattice kernel; the true depths arrive with the counts (sync #2) and a too-small guess (the
     // bounding box doubled between two iterations) re-runs the voxelisation synchronously.
-    int sort_depth[2];
+    int sort_depth[2], sort_bits[2];
     for (int l = 0; l < 2; ++l) {
         sort_depth[l] = speculate ? ctx->depth_guess[l] : ctx->h_lattice[l].final_depth;
+        // width of the leaf codes: all 3*depth bits, or (compressed) only the bits that vary over the points
+        sort_bits[l] = !compress ? 3 * sort_depth[l] : (speculate ? ctx->bits_guess[l] : ctx->h_lattice[l].total_bits);
         if (!speculate && lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
     }
     GaussCounts* counts = ctx->d_counts.as<GaussCounts>();
@@ -350,10 +362,11 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         const LatticeTable* tab = ctx->d_lattice.as<LatticeTable>() + l;
         {
             ScopedTimer tm(ctx, T_VOXEL);
-            const unsigned end_bit = (unsigned)(3 * sort_depth[l] + 1);
+            const unsigned end_bit = (unsigned)(sort_bits[l] + 1);
             const bool k32 = end_bit <= 32;
             ctx->key32[l] = k32;
-            launch_voxel_keys(ctx->d_global.as<float4>(), n, tab, ctx->level_res[l], ctx->d_code[l].p, k32, ctx->d_idx[l].as<uint32_t>(), ctx->stream);
+            launch_voxel_keys(ctx->d_global.as<float4>(), n, ctx->d_lattice.as<LatticeTable>() + l, ctx->level_res[l], ctx->d_code[l].p, k32,
+                              ctx->d_idx[l].as<uint32_t>(), ctx->stream);
             if (k32)
                 HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp.p, ctx->d_sort_tmp.cap, ctx->d_code[l].as<uint32_t>(), ctx->d_code_s[l].as<uint32_t>(),
                                           ctx->d_idx[l].as<uint32_t>(), ctx->d_idx_s[l].as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
@@ -397,17 +410,24 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         TileCounts t;
     } both{};
     HIPCHK(hipMemcpyAsync(&both, ctx->d_counts.p, sizeof(both), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));  // incl. out_of_range
     if (overlap) CHK(overlap());
     HIPCHK(sync_spin(ctx->stream));  // sync #2: M sizes every later launch
     const GaussCounts h = both.g;
     htc = both.t;
     for (int l = 0; l < 2; ++l) {
         if (lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
-        if (speculate && lvl_on[l] && ctx->h_lattice[l].final_depth > sort_depth[l]) {
+        const int true_bits = compress ? ctx->h_lattice[l].total_bits : 3 * ctx->h_lattice[l].final_depth;
+        if (lvl_on[l] && compress && ctx->h_lattice[l].out_of_range) {
             ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
-            return build_gaussians(ctx, s, nullptr, false);  // mis-speculated: redo with the true depths (overlap work already ran)
+            return build_gaussians(ctx, s, nullptr, false, false);  // a key left the predicted range: redo with full-width codes
+        }
+        if (speculate && lvl_on[l] && (ctx->h_lattice[l].final_depth > sort_depth[l] || true_bits > sort_bits[l])) {
+            ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
+            return build_gaussians(ctx, s, nullptr, false, allow_compression);  // mis-speculated: redo (overlap work already ran)
         }
         ctx->depth_guess[l] = ctx->h_lattice[l].final_depth;
+        ctx->bits_guess[l] = ctx->h_lattice[l].total_bits;
     }
     ctx->num_tiles = htc.num_tiles, ctx->num_fallback = htc.num_fallback, ctx->tile_max_rows = htc.max_rows, ctx->tile_max_gauss = htc.max_gauss;
     {
@@ -651,6 +671,7 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     if (const char* e = std::getenv("DMSA_K4_WGS")) ctx->cfg_num_wg = std::max(1, std::min(4000, std::atoi(e)));
     if (const char* e = std::getenv("DMSA_K4_BIG")) ctx->cfg_big_n = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("DMSA_K4_TILES")) ctx->use_tiles = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DMSA_KEY_COMPRESS")) ctx->compress_keys = std::atoi(e) != 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return DMSA_ERR_HIP;
@@ -918,7 +939,7 @@ int dmsa_get_voxel_level(dmsa_ctx* ctx, int32_t level, dmsa_voxel_level_info* in
     CHK(set_device(ctx));
     const size_t n = (size_t)ctx->n;
     const LatticeTable& t = ctx->h_lattice[level];
-    const uint64_t invalid = 1ull << (3 * t.final_depth);
+    const uint64_t invalid = lattice_invalid_code(t);
     std::vector<uint64_t> code(n);
     if (ctx->key32[level]) {
         std::vector<uint32_t> c32(n);
@@ -928,20 +949,36 @@ int dmsa_get_voxel_level(dmsa_ctx* ctx, int32_t level, dmsa_voxel_level_info* in
         HIPCHK(hipMemcpy(code.data(), ctx->d_code[level].p, n * 8, hipMemcpyDeviceToHost));
     }
     int64_t valid = 0;
+    const int nb3[3] = {t.nbits[0], t.nbits[1], t.nbits[2]};
+    const int maxb = std::max(nb3[0], std::max(nb3[1], nb3[2]));
     for (size_t i = 0; i < n; ++i) {
         const bool ok = code[i] != invalid;
         valid += ok ? 1 : 0;
-        if (key_xyz) {
-            uint32_t k[3] = {0, 0, 0};
-            if (ok)
+        uint32_t k[3] = {0, 0, 0};
+        uint64_t full = UINT64_MAX;
+        if (ok) {
+            if (t.compressed) {  // undo the compression: peel the bits off in reverse order of their insertion
+                uint64_t c = code[i];
+                uint32_t low[3] = {0, 0, 0};
+                for (int l = 0; l < maxb; ++l)
+                    for (int a = 2; a >= 0; --a)
+                        if (l < nb3[a]) {
+                            low[a] |= (uint32_t)(c & 1ull) << l;
+                            c >>= 1;
+                        }
+                for (int a = 0; a < 3; ++a) k[a] = (t.key_base[a] << nb3[a]) | low[a];
+            } else {
                 for (int l = 0; l < t.final_depth; ++l) {
                     k[0] |= (uint32_t)((code[i] >> (3 * l + 2)) & 1ull) << l;
                     k[1] |= (uint32_t)((code[i] >> (3 * l + 1)) & 1ull) << l;
                     k[2] |= (uint32_t)((code[i] >> (3 * l)) & 1ull) << l;
                 }
-            key_xyz[3 * i] = k[0], key_xyz[3 * i + 1] = k[1], key_xyz[3 * i + 2] = k[2];
+            }
+            full = 0;
+            for (int l = t.final_depth - 1; l >= 0; --l) full = (full << 3) | (((k[0] >> l) & 1u) << 2) | (((k[1] >> l) & 1u) << 1) | ((k[2] >> l) & 1u);
         }
-        if (leaf_code) leaf_code[i] = ok ? code[i] : UINT64_MAX;
+        if (key_xyz) key_xyz[3 * i] = k[0], key_xyz[3 * i + 1] = k[1], key_xyz[3 * i + 2] = k[2];
+        if (leaf_code) leaf_code[i] = full;
     }
     if (sorted_point_idx) HIPCHK(hipMemcpy(sorted_point_idx, ctx->d_idx_s[level].p, (size_t)valid * 4, hipMemcpyDeviceToHost));
     if (info) {

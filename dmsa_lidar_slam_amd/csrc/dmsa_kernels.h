@@ -24,7 +24,17 @@ struct LatticeTable {
     uint32_t suffix_shift[kMaxLatticeEvents + 1][3];
     int32_t depth[kMaxLatticeEvents + 1];
     double final_mn[3];
+    // Leaf-code compression: over all finite points the final key of axis a lies in [key_lo[a], key_hi[a]]; the bits above
+    // nbits[a] are the same for every point (key_base[a] = common prefix), so the depth-first code only needs the low
+    // nbits[a] bits of each axis, interleaved level by level (order-preserving).  total_bits = sum of nbits.
+    int32_t nbits[3];
+    int32_t total_bits;
+    uint32_t key_base[3];
+    int32_t compressed;    // 1: codes are the compressed form, invalid marker = 1 << total_bits; 0: full 3*depth-bit codes
+    int32_t out_of_range;  // set by k_voxel_keys if a key left [key_base << nbits, ...] (compression must be redone off)
+    int32_t pad3;
 };
+__host__ __device__ inline uint64_t lattice_invalid_code(const LatticeTable& t) { return 1ull << (t.compressed ? t.total_bits : 3 * t.final_depth); }
 
 // per-level device scalars produced by the segmentation stage
 struct LevelCounts {
@@ -70,9 +80,10 @@ void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tabl
 
 // ---- K2: PCL-exact voxel lattice + keys -----------------------------------------------------------------
 void launch_block_aabb(const float4* global, int64_t n, float* aabb /* nb x 8 */, hipStream_t s);
-void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, LatticeTable* tables /* [2] */, hipStream_t s);
+void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, bool compress, LatticeTable* tables /* [2] */,
+                    hipStream_t s);
 // leaf codes are 32-bit (key32) when 3*depth + 1 <= 32, else 64-bit; the buffers are sized for 64-bit keys either way
-void launch_voxel_keys(const float4* global, int64_t n, const LatticeTable* table, double res, void* code, bool key32, uint32_t* idx, hipStream_t s);
+void launch_voxel_keys(const float4* global, int64_t n, LatticeTable* table, double res, void* code, bool key32, uint32_t* idx, hipStream_t s);
 // ---- segmentation of the sorted (code, idx) arrays -------------------------------------------------------
 void launch_head_flags(const void* code_sorted, bool key32, int64_t n, const LatticeTable* table, int32_t* head, hipStream_t s);
 void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const void* code_sorted, bool key32, const LatticeTable* table, int64_t n,

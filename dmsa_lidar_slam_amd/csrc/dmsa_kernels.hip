@@ -386,7 +386,8 @@ __device__ void lattice_adopt(LatticeRun& st, const float4 p, const double res, 
 }
 
 __global__ __launch_bounds__(256) void k_lattice(const float4* __restrict__ global, int64_t n, const float* __restrict__ aabb, int nb, double res0,
-                                                 double res1, LatticeTable* __restrict__ tables) {
+                                                 double res1, int compress, LatticeTable* __restrict__ tables) {
+    __shared__ float s_glob[4][6];
     __shared__ LatticeRun st;
     __shared__ uint32_t s_shift[kMaxLatticeEvents][3];
     __shared__ int s_red[4];
@@ -398,6 +399,17 @@ __global__ __launch_bounds__(256) void k_lattice(const float4* __restrict__ glob
         st.defined = 0, st.depth = 0, st.nev = 0, st.status = 0;
         for (int a = 0; a < 3; ++a) st.mn[a] = 0.0, st.mx[a] = 0.0;
         tab->first_idx = -1;
+    }
+    {  // bounds of all finite points (for the key-range compression)
+        float g6[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int b2 = tid; b2 < nb; b2 += 256) {
+            const float* bb = aabb + (size_t)b2 * 8;
+            if (bb[0] <= bb[3])
+                for (int a = 0; a < 3; ++a) g6[a] = fminf(g6[a], bb[a]), g6[3 + a] = fmaxf(g6[3 + a], bb[3 + a]);
+        }
+        for (int a = 0; a < 3; ++a) g6[a] = wave_allminf(g6[a]), g6[3 + a] = wave_allmaxf(g6[3 + a]);
+        if (lane == 0)
+            for (int a = 0; a < 6; ++a) s_glob[wave][a] = g6[a];
     }
     __syncthreads();
     int cursor = 0;
@@ -467,6 +479,27 @@ __global__ __launch_bounds__(256) void k_lattice(const float4* __restrict__ glob
         tab->status = st.status;
         tab->defined = st.defined;
         for (int a = 0; a < 3; ++a) tab->final_mn[a] = st.mn[a];
+        // range of final keys per axis from the global bounds (one cell of slack on both sides: keys of earlier epochs were
+        // rounded against a different origin), common prefix -> number of varying low bits
+        int total = 0;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = fminf(fminf(s_glob[0][a], s_glob[1][a]), fminf(s_glob[2][a], s_glob[3][a]));
+            const float hi = fmaxf(fmaxf(s_glob[0][3 + a], s_glob[1][3 + a]), fmaxf(s_glob[2][3 + a], s_glob[3][3 + a]));
+            int bits = st.depth;
+            uint32_t base = 0;
+            if (st.defined && lo <= hi) {
+                const long long maxk = (1ll << st.depth) - 1;
+                long long klo = (long long)floor(((double)lo - st.mn[a]) / res) - 1, khi = (long long)floor(((double)hi - st.mn[a]) / res) + 1;
+                klo = klo < 0 ? 0 : klo, khi = khi > maxk ? maxk : khi;
+                bits = 0;
+                while (bits < st.depth && (klo >> bits) != (khi >> bits)) ++bits;
+                base = (uint32_t)(klo >> bits);
+            }
+            tab->nbits[a] = bits, tab->key_base[a] = base;
+            total += bits;
+        }
+        tab->compressed = compress, tab->out_of_range = 0;
+        tab->total_bits = total;
         uint32_t acc[3] = {0, 0, 0};
         for (int a = 0; a < 3; ++a) tab->suffix_shift[st.nev][a] = 0;
         for (int e = st.nev - 1; e >= 0; --e)
@@ -476,8 +509,9 @@ __global__ __launch_bounds__(256) void k_lattice(const float4* __restrict__ glob
             }
     }
 }
-void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, LatticeTable* tables, hipStream_t s) {
-    hipLaunchKernelGGL(k_lattice, dim3(2), dim3(256), 0, s, global, n, aabb, nb, res0, res1, tables);
+void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, bool compress, LatticeTable* tables,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(k_lattice, dim3(2), dim3(256), 0, s, global, n, aabb, nb, res0, res1, compress ? 1 : 0, tables);
 }
 
 // (c) genOctreeKeyforPoint with the bounding box in force when the point was inserted, plus the integer shifts of
@@ -493,7 +527,7 @@ __device__ __forceinline__ uint64_t spread3(uint32_t v) {  // 21 bits -> every t
 }
 
 template <typename KeyT>  // uint32_t when the leaf code + invalid bit fit 32 bits (tree depth <= 10), else uint64_t
-__global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ global, int64_t n, const LatticeTable* __restrict__ table, double res,
+__global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ global, int64_t n, LatticeTable* __restrict__ table, double res,
                                                     KeyT* __restrict__ code, uint32_t* __restrict__ idx) {
     __shared__ LatticeTable t;
     {
@@ -504,7 +538,9 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ g
     }
     __syncthreads();
     const int nev = t.num_events;
-    const uint64_t invalid = 1ull << (3 * t.final_depth);
+    const uint64_t invalid = lattice_invalid_code(t);
+    const int nx = t.nbits[0], ny = t.nbits[1], nz = t.nbits[2];
+    const int maxb = max(nx, max(ny, nz));
     const int64_t last_ev = nev > 0 ? t.event_idx[nev - 1] : -1;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -520,13 +556,26 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ g
             const uint32_t kx = ((uint32_t)(((double)p.x - t.mn[e][0]) / res) & mask) + t.suffix_shift[e][0];
             const uint32_t ky = ((uint32_t)(((double)p.y - t.mn[e][1]) / res) & mask) + t.suffix_shift[e][1];
             const uint32_t kz = ((uint32_t)(((double)p.z - t.mn[e][2]) / res) & mask) + t.suffix_shift[e][2];
-            c = (spread3(kx) << 2) | (spread3(ky) << 1) | spread3(kz);
+            if (t.compressed) {
+                // low nbits of every axis, interleaved level by level from the top (x, y, z order inside a level): same order as
+                // the full depth-first code because the dropped high bits are identical for all points
+                if ((kx >> nx) != t.key_base[0] || (ky >> ny) != t.key_base[1] || (kz >> nz) != t.key_base[2]) table->out_of_range = 1;
+                uint64_t cc = 0;
+                for (int l = maxb - 1; l >= 0; --l) {
+                    if (l < nx) cc = (cc << 1) | ((kx >> l) & 1u);
+                    if (l < ny) cc = (cc << 1) | ((ky >> l) & 1u);
+                    if (l < nz) cc = (cc << 1) | ((kz >> l) & 1u);
+                }
+                c = cc;
+            } else {
+                c = (spread3(kx) << 2) | (spread3(ky) << 1) | spread3(kz);
+            }
         }
         code[i] = (KeyT)c;
         idx[i] = (uint32_t)i;
     }
 }
-void launch_voxel_keys(const float4* global, int64_t n, const LatticeTable* table, double res, void* code, bool key32, uint32_t* idx, hipStream_t s) {
+void launch_voxel_keys(const float4* global, int64_t n, LatticeTable* table, double res, void* code, bool key32, uint32_t* idx, hipStream_t s) {
     if (n <= 0) return;
     if (key32)
         hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint32_t*)code, idx);
@@ -540,7 +589,7 @@ void launch_voxel_keys(const float4* global, int64_t n, const LatticeTable* tabl
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_head_flags(const KeyT* __restrict__ code, int64_t n, const LatticeTable* __restrict__ table,
                                                     int32_t* __restrict__ head) {
-    const KeyT invalid = (KeyT)(1ull << (3 * table->final_depth));
+    const KeyT invalid = (KeyT)lattice_invalid_code(*table);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const KeyT c = code[i];
@@ -559,7 +608,7 @@ template <typename KeyT>
 __global__ __launch_bounds__(256) void k_leaf_starts(const int32_t* __restrict__ head, const int32_t* __restrict__ leaf_incl,
                                                      const KeyT* __restrict__ code, const LatticeTable* __restrict__ table, int64_t n,
                                                      int32_t* __restrict__ leaf_start, LevelCounts* __restrict__ counts) {
-    const KeyT invalid = (KeyT)(1ull << (3 * table->final_depth));
+    const KeyT invalid = (KeyT)lattice_invalid_code(*table);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         if (head[i]) leaf_start[leaf_incl[i] - 1] = (int32_t)i;
@@ -796,7 +845,7 @@ __global__ __launch_bounds__(256) void k_gather_members(const int32_t* __restric
                                                         const int32_t* __restrict__ slot_cnt, const GaussCounts* __restrict__ counts, int level,
                                                         int64_t n, float4* __restrict__ memb_local, int32_t* __restrict__ memb_idx,
                                                         int32_t* __restrict__ memb_g, int32_t* __restrict__ seg_off) {
-    const KeyT invalid = (KeyT)(1ull << (3 * table->final_depth));
+    const KeyT invalid = (KeyT)lattice_invalid_code(*table);
     const int gbase = level == 0 ? 0 : counts->level[0].num_gauss;
     const int mbase = level == 0 ? 0 : counts->level[0].num_memb;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1204,6 +1253,7 @@ __global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles,
     const int words = (rows + 31) / 32;
     uint32_t* s_pre = s_bm + words;
     const int nt = tc->num_tiles;
+    int wg_max_rows = 0, wg_max_gauss = 0;  // thread 0 only; published once per workgroup
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         const int p0 = tiles[t].p0, p1 = tiles[t].p1, tg0 = tiles[t].g0, tg1 = tiles[t].g1;
         for (int w = threadIdx.x; w < words; w += blockDim.x) s_bm[w] = 0u;
@@ -1230,8 +1280,7 @@ __global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles,
             }
             tiles[t].row_off = t * rows;
             tiles[t].nrows = (int)acc;
-            atomicMax(&tc->max_rows, (int)acc);
-            atomicMax(&tc->max_gauss, tg1 - tg0);
+            wg_max_rows = max(wg_max_rows, (int)acc), wg_max_gauss = max(wg_max_gauss, tg1 - tg0);
         }
         __syncthreads();
         for (int w = threadIdx.x; w < words; w += blockDim.x) {
@@ -1265,6 +1314,10 @@ __global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles,
             }
         }
         __syncthreads();
+    }
+    if (threadIdx.x == 0 && wg_max_rows > 0) {
+        atomicMax(&tc->max_rows, wg_max_rows);
+        atomicMax(&tc->max_gauss, wg_max_gauss);
     }
 }
 void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, const int32_t* memb_g, int rows, TileDesc* tiles,

@@ -150,6 +150,8 @@ typedef struct dmsa_iter_trace {
 #define DMSA_FLAG_POSE_TABLE_HOST 0x1u /* build dense pose tables in host double math (bit-reproducible
                                           against the CPU oracle); default is the device kernel      */
 #define DMSA_FLAG_FIXED_ITERS     0x2u /* benchmarking: ignore the no-improvement / epsilon exits    */
+#define DMSA_FLAG_STAGE_TIMERS    0x8u /* also time voxelisation / fit / pose tables / normal equations with HIP events (each
+                                          event pair costs ~10 us of GPU idle; the correspondence kernel is always timed)  */
 #define DMSA_FLAG_MIRROR_SUMS     0x4u /* parity path: per-Gaussian sums run serially in member order, exactly like the
                                           reference's loops (DmsaOptimizer.h:247-264), instead of as wave reductions.
                                           Bit-reproducible against the CPU oracle; slower.  The default (wave-parallel)
