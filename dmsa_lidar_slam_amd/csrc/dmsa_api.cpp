@@ -14,6 +14,7 @@
 #include <functional>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dmsa_hip.h"
@@ -82,7 +83,7 @@ struct dmsa_ctx {
     std::vector<float> h_tables;
     // voxelisation
     DevBuf d_aabb, d_lattice, d_code[2], d_idx[2], d_code_s[2], d_idx_s[2], d_head, d_leaf_incl[2], d_leaf_start[2], d_slot_acc, d_slot_cnt,
-        d_gauss_of_slot, d_memb_of_slot, d_pos_slot_rank, d_sort_tmp, d_scan_tmp, d_counts;
+        d_gauss_of_slot, d_memb_of_slot, d_pos_slot_rank, d_nsorted, d_pair_d, d_pair_c, d_sort_tmp, d_scan_tmp, d_counts;
     LatticeTable h_lattice[2];
     bool key32[2] = {false, false};  // leaf codes of this level are 32-bit (tree depth <= 10)
     int depth_guess[2] = {-1, -1};   // tree depths of the previous voxelisation (speculation: saves one host sync)
@@ -356,7 +357,12 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     GaussCounts* counts = ctx->d_counts.as<GaussCounts>();
     const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS);
     const bool split = s.gauss_split != 0 && ctx->model == MODEL_KEYFRAMES;
-    if (split) HIPCHK(ctx->d_pos_slot_rank.ensure((size_t)n * 4));
+    if (split) {
+        HIPCHK(ctx->d_pos_slot_rank.ensure((size_t)n * 4));
+        HIPCHK(ctx->d_nsorted.ensure((size_t)n * 16));
+        HIPCHK(ctx->d_pair_d.ensure((size_t)n * 4));
+        HIPCHK(ctx->d_pair_c.ensure((size_t)n * 4));
+    }
     for (int l = 0; l < 2; ++l) {
         if (!lvl_on[l]) continue;
         const LatticeTable* tab = ctx->d_lattice.as<LatticeTable>() + l;
@@ -380,8 +386,9 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             launch_leaf_accept(ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(), &counts->level[l],
                                s.min_num_points_per_set, n, ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(), ctx->stream);
             if (split)
-                launch_leaf_split(ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(), ctx->d_nglobal.as<float4>(),
-                                  &counts->level[l], s.min_num_points_per_set, ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(),
+                launch_leaf_split(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(),
+                                  ctx->d_nglobal.as<float4>(), &counts->level[l], s.min_num_points_per_set, n, ctx->d_nsorted.as<float4>(),
+                                  ctx->d_pair_d.as<float>(), ctx->d_pair_c.as<int32_t>(), ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(),
                                   ctx->d_pos_slot_rank.as<int32_t>(), ctx->stream);
             launch_leaf_scan(ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(), ctx->d_memb_of_slot.as<int32_t>(),
                              &counts->level[l], ctx->stream);
@@ -530,11 +537,45 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             globs.clear(), extra.clear();
             host_eval(ctx, globs, extra);
             chain(ctx).get_params(origin.data());  // :204 (after updateImuError's global2relative round trip)
-            for (int k = 0; k < P; ++k) {
+            if (ctx->model == MODEL_KEYFRAMES && P >= 48) {
+                // The keyframe model carries no state from one evaluation to the next (setPoseParameters rewrites every
+                // relative pose and re-chains, MapManagement.h:197-202), so the P perturbed chains (O(F) exp/log each) are
+                // built by a few host threads; results are identical to the serial order.
+                const int a = num_extra_rows(ctx);
+                const size_t gsz = (size_t)chain(ctx).n * 6;
+                globs.resize((size_t)(1 + P) * gsz);
+                extra.resize((size_t)(1 + P) * a);
+                const KeyframeHost base = ctx->key;
+                const int nthr = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
+                std::vector<std::thread> pool;
+                for (int t = 0; t < nthr; ++t)
+                    pool.emplace_back([&, t]() {
+                        KeyframeHost kh = base;
+                        std::vector<double> lp(origin), g;
+                        for (int k = t; k < P; k += nthr) {
+                            lp = origin;
+                            lp[(size_t)k] += increment;
+                            kh.frames.set_params(lp.data());
+                            kh.frames.relative_to_global();
+                            g.clear();
+                            append_glob(kh.frames, g);
+                            std::copy(g.begin(), g.end(), globs.begin() + (size_t)(1 + k) * gsz);
+                            if (a > 0) kh.additional_rows(&extra[(size_t)(1 + k) * a]);
+                        }
+                    });
+                for (auto& th : pool) th.join();
+                ctx->evaluations += P;
+                // leave the chain where the serial loop would: last perturbation evaluated, then parameters restored
                 loop = origin;
-                loop[(size_t)k] += increment;
+                loop[(size_t)(P - 1)] += increment;
                 host_set_params(ctx, loop.data());
-                host_eval(ctx, globs, extra);
+            } else {
+                for (int k = 0; k < P; ++k) {
+                    loop = origin;
+                    loop[(size_t)k] += increment;
+                    host_set_params(ctx, loop.data());
+                    host_eval(ctx, globs, extra);
+                }
             }
             chain(ctx).set_params(origin.data());  // :231
             return build_tables(ctx, 1 + P, globs);
@@ -575,7 +616,10 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
         for (int i = 0; i < P; ++i) g[(size_t)i] = Hp[(size_t)P * n1 + i];
         error0 = Hp[(size_t)P * n1 + P];  // :101
         for (int i = 0; i < P; ++i) H[(size_t)i * P + i] += (double)s.lambda_diag;  // :110
-        lm_solve(H.data(), g.data(), P, s.step_length_optim, step.data());             // :113
+        if (ctx->flags & DMSA_FLAG_MIRROR_SUMS)
+            lm_solve(H.data(), g.data(), P, s.step_length_optim, step.data());  // :113, explicit inverse like the reference
+        else
+            lm_solve_lu(H.data(), g.data(), P, s.step_length_optim, step.data());
         bool anyNan = false;
         for (double v : step) anyNan = anyNan || std::isnan(v);
         if (anyNan) {  // :116-122 setPoseParameters(paramVec); break
@@ -691,7 +735,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
                       &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
                       &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_head, &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
                       &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_slot_acc, &ctx->d_slot_cnt, &ctx->d_gauss_of_slot, &ctx->d_memb_of_slot,
-                      &ctx->d_pos_slot_rank, &ctx->d_sort_tmp, &ctx->d_scan_tmp, &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_memb_g, &ctx->d_seg_off,
+                      &ctx->d_pos_slot_rank, &ctx->d_nsorted, &ctx->d_pair_d, &ctx->d_pair_c, &ctx->d_sort_tmp, &ctx->d_scan_tmp, &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_memb_g, &ctx->d_seg_off,
                       &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_counts, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(ctx->stream);

@@ -662,11 +662,50 @@ void launch_leaf_accept(const int32_t* leaf_start, const uint32_t* idx_sorted, c
                        slot_acc, slot_cnt);
 }
 
+// The quadratic part of splitSet (Gaussians.h:36-51), position-parallel: every sorted position a of an accepted leaf scans
+// all members c of its leaf (normals pre-gathered in sorted order, so a wave inside one big leaf reads the same address)
+// and keeps its first best partner.  Work per leaf is n^2 / 64 wave-iterations spread over n / 64 waves instead of one.
+__global__ __launch_bounds__(256) void k_split_gather_normals(const uint32_t* __restrict__ idx_sorted, const float4* __restrict__ nglobal, int64_t n,
+                                                              float4* __restrict__ nsorted) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) nsorted[i] = nglobal[idx_sorted[i]];
+}
+__global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__ leaf_incl, const int32_t* __restrict__ leaf_start,
+                                                     const int32_t* __restrict__ slot_acc, const float4* __restrict__ nsorted, int64_t n_valid_cap,
+                                                     const LevelCounts* __restrict__ counts, float* __restrict__ pair_best_d,
+                                                     int32_t* __restrict__ pair_best_c) {
+    const int nl = counts->num_leaves;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_valid_cap; i += stride) {
+        const int l = leaf_incl[i] - 1;
+        if (l < 0 || l >= nl || i >= leaf_start[nl]) continue;  // past the last valid position
+        if (!slot_acc[2 * l]) continue;
+        const int b = leaf_start[l], e = leaf_start[l + 1];
+        const float4 na = nsorted[i];
+        // The reference compares norms (sqrt) with a strict '<'.  sqrt is monotone, so a candidate whose SQUARED norm is not
+        // below the best squared norm can never win; the (correctly rounded, expensive) sqrt is only taken for the rest.
+        float best = FLT_MAX, best_sq = FLT_MAX;
+        int best_c = 0;
+        for (int j = b; j < e; ++j) {
+            if (j == (int)i) continue;
+            const float4 nc = nsorted[j];
+            const float sx = na.x + nc.x, sy = na.y + nc.y, sz = na.z + nc.z;
+            const float sq = sum3f(sx * sx, sy * sy, sz * sz);
+            if (sq < best_sq) {
+                const float d = sqrtf(sq);
+                if (d < best) best = d, best_sq = sq, best_c = j - b;
+            }
+        }
+        pair_best_d[i] = best, pair_best_c[i] = best_c;
+    }
+}
+
 // Gaussians.h:27-85 splitSet + the split branch of createGaussianSets (DmsaOptimizer.h:310-337), one wave per
 // accepted leaf.  pos_slot_rank[i] = rank within its set, sign bit set for the second set.
 __global__ __launch_bounds__(256) void k_leaf_split(const int32_t* __restrict__ leaf_start, const uint32_t* __restrict__ idx_sorted,
                                                     const int32_t* __restrict__ ring, const float4* __restrict__ nglobal,
-                                                    const LevelCounts* __restrict__ counts, int min_pts, int32_t* __restrict__ slot_acc,
+                                                    const LevelCounts* __restrict__ counts, int min_pts, const float* __restrict__ pair_best_d,
+                                                    const int32_t* __restrict__ pair_best_c, int32_t* __restrict__ slot_acc,
                                                     int32_t* __restrict__ slot_cnt, int32_t* __restrict__ pos_slot_rank) {
     const int nl = counts->num_leaves;
     const int lane = threadIdx.x & 63;
@@ -675,17 +714,13 @@ __global__ __launch_bounds__(256) void k_leaf_split(const int32_t* __restrict__ 
     for (int l = wave_global; l < nl; l += nwaves) {
         if (!slot_acc[2 * l]) continue;  // wave-uniform
         const int b = leaf_start[l], e = leaf_start[l + 1], cnt = e - b;
-        // most anti-parallel normal pair: min over ordered pairs (a outer, c inner, a != c) of |n_a + n_c|, first minimum wins
+        // most anti-parallel normal pair: min over ordered pairs (a outer, c inner, a != c) of |n_a + n_c|, first minimum wins.
+        // k_split_pairs already found, for every member a, its first best partner c; reduce over a (ties -> smallest a).
         float best = FLT_MAX;
         long long best_pair = LLONG_MAX;
-        const long long npairs = (long long)cnt * cnt;
-        for (long long q = lane; q < npairs; q += 64) {
-            const int a = (int)(q / cnt), c = (int)(q % cnt);
-            if (a == c) continue;
-            const float4 na = nglobal[idx_sorted[b + a]], nc = nglobal[idx_sorted[b + c]];
-            const float sx = na.x + nc.x, sy = na.y + nc.y, sz = na.z + nc.z;
-            const float d = sqrtf(sum3f(sx * sx, sy * sy, sz * sz));
-            if (d < best) best = d, best_pair = q;  // q ascends per lane, strict '<' keeps the first
+        for (int j = b + lane; j < e; j += 64) {
+            const float d = pair_best_d[j];
+            if (d < best) best = d, best_pair = (long long)(j - b) * cnt + pair_best_c[j];  // j ascends per lane
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -744,10 +779,14 @@ __global__ __launch_bounds__(256) void k_leaf_split(const int32_t* __restrict__ 
         }
     }
 }
-void launch_leaf_split(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const float4* nglobal, const LevelCounts* counts,
-                       int min_pts, int32_t* slot_acc, int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s) {
-    hipLaunchKernelGGL(k_leaf_split, dim3(1024), dim3(256), 0, s, leaf_start, idx_sorted, ring, nglobal, counts, min_pts, slot_acc, slot_cnt,
-                       pos_slot_rank);
+void launch_leaf_split(const int32_t* leaf_incl, const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const float4* nglobal,
+                       const LevelCounts* counts, int min_pts, int64_t n, float4* nsorted, float* pair_best_d, int32_t* pair_best_c, int32_t* slot_acc,
+                       int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s) {
+    hipLaunchKernelGGL(k_split_gather_normals, dim3(grid_for(n, 256)), dim3(256), 0, s, idx_sorted, nglobal, n, nsorted);
+    hipLaunchKernelGGL(k_split_pairs, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, s, leaf_incl, leaf_start, slot_acc, nsorted, n, counts, pair_best_d,
+                       pair_best_c);
+    hipLaunchKernelGGL(k_leaf_split, dim3(1024), dim3(256), 0, s, leaf_start, idx_sorted, ring, nglobal, counts, min_pts, pair_best_d, pair_best_c,
+                       slot_acc, slot_cnt, pos_slot_rank);
 }
 
 // Exclusive prefix sums of (accepted, accepted member count) over the two slots of every leaf.  The leaf count lives on the
