@@ -1,0 +1,218 @@
+"""GPU parity on BASELINE.json's configurations and the edge cases of the path.
+
+config 1 (one 16 384-point scan vs 50 k static, 5 iterations), config 3 (10 x 131 072 window, full size: structure and
+residual parity against the oracle plus size-independent properties), config 4 (keyframe set with gravity AND odometry
+rows, ragged frames), config 5 (rosette pattern, ids = k % 1000), and the degenerate inputs (no static map, non-finite
+points through the whole optimizeSet, fewer frames than Gaussians need).
+"""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation as Rot
+
+from dmsa_lidar_slam_amd import synth
+from dmsa_lidar_slam_amd.problems import DmsaOptimSettings
+
+pytestmark = pytest.mark.gpu
+
+H_INCR = float(np.sqrt(np.finfo(np.float32).eps))
+
+
+def _pose_diff(orc, a, b):
+    ga_o, ga_t = orc.relative2global(a.relOrientations, a.relTranslations)
+    gb_o, gb_t = orc.relative2global(b.relOrientations, b.relTranslations)
+    return np.abs(ga_t - gb_t).max(), np.abs(ga_o - gb_o).max()
+
+
+def _parity_run(hip, orc, prob, s, window=True):
+    """Whole optimizeSet on the parity path against the oracle: same control flow, poses within 1e-4 m / 1e-4 rad."""
+    p_ref, p_gpu = prob.copy(), prob.copy()
+    fn = orc.optimize_window if window else orc.optimize_keyframes
+    rep_ref, _, trace = fn(p_ref, s)
+    opt = hip.DmsaOptimizer(pose_table_host=True, mirror_sums=True)
+    rep = opt.optimizeSet(p_gpu, s)
+    assert (rep.iterations, rep.stop_reason, rep.evaluations) == (rep_ref.iterations, rep_ref.stop_reason, rep_ref.evaluations)
+    for a, b in zip(trace, opt.trace()):
+        assert (a["M"], a["M1"], a["Mm"], a["best_k"]) == (b["M"], b["M1"], b["Mm"], b["best_k"])
+        assert abs(a["error0"] - b["error0"]) <= 1e-9 * max(a["error0"], 1e-300)
+    dt, dr = _pose_diff(orc, p_ref, p_gpu)
+    assert dt < 1e-4 and dr < 1e-4, (dt, dr)
+    return rep, p_gpu
+
+
+# ---- config 1 ------------------------------------------------------------------------------------------------------
+def test_config1_single_scan_vs_static_map(hip, orc):
+    prob = synth.window_problem(seed=1, scans=1, rings=128, az_steps=128, num_static=50_000)
+    assert prob.localPoints.shape[0] <= 16_384 and prob.staticPoints.shape[0] == 50_000
+    rep, p_gpu = _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=5))
+    assert rep.iterations >= 1
+    moved_t, moved_r = _pose_diff(orc, prob, p_gpu)
+    assert moved_t > 1e-4 or moved_r > 1e-4
+
+
+# ---- config 5 ------------------------------------------------------------------------------------------------------
+def test_config5_rosette_no_imu(hip, orc):
+    prob = synth.rosette_window_problem(seed=2, scans=5, pts_per_scan=24_000, num_static=20_000)
+    assert prob.ringIds.max() == 999  # ids = k % 1000: the ring-diversity test sees "rings" that are just indices
+    _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=4))
+
+
+# ---- config 4: additional rows, ragged frames ------------------------------------------------------------------------
+def _with_odometry(prob, seed=0):
+    rng = np.random.default_rng(seed)
+    f = prob.numFrames
+    ro, rt = prob.truth_relative
+    prob.useOdometryErrorTerms = True
+    prob.odomRelTransl = rt + rng.normal(0, 0.005, rt.shape)
+    prob.odomRelOrientMat = (Rot.from_rotvec(ro) * Rot.from_rotvec(rng.normal(0, 1e-3, (f, 3)))).as_matrix()
+    prob.__post_init__()
+    return prob
+
+
+def test_keyframes_gravity_and_odometry_rows(hip, orc):
+    prob = _with_odometry(synth.keyframe_problem(seed=5, frames=6, rings=24, az_steps=160, arc=0.4))
+    prob.gravityPlausible[2] = 0  # implausible frame: its row stays exactly zero (MapManagement.h:216-231)
+    s = DmsaOptimSettings.keyframe_map(num_iter=3)
+    _parity_run(hip, orc, prob, s, window=False)
+    # the additional rows are really in the problem: switching them off changes the result
+    plain = prob.copy()
+    plain.useOdometryErrorTerms = False
+    plain.useGravityErrorTerms = False
+    a, b = prob.copy(), plain
+    hip.DmsaOptimizer(pose_table_host=True, mirror_sums=True).optimizeSet(a, s)
+    hip.DmsaOptimizer(pose_table_host=True, mirror_sums=True).optimizeSet(b, s)
+    assert _pose_diff(orc, a, b)[0] > 1e-7
+
+
+def test_keyframes_ragged_frames(hip, orc):
+    """Frames of very different sizes (one of them nearly empty)."""
+    prob = synth.keyframe_problem(seed=6, frames=6, rings=24, az_steps=160, arc=0.4)
+    off = prob.frameOffsets
+    keep = np.ones(prob.localPoints.shape[0], bool)
+    keep[off[1] + 5:off[2]] = False            # frame 1 keeps 5 points
+    keep[off[3]:off[4]][::2] = False           # frame 3 keeps every second point
+    sizes = np.array([keep[off[k]:off[k + 1]].sum() for k in range(prob.numFrames)])
+    prob.localPoints, prob.localNormals, prob.ringIds = prob.localPoints[keep], prob.localNormals[keep], prob.ringIds[keep]
+    prob.frameOffsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    prob.__post_init__()
+    _parity_run(hip, orc, prob, DmsaOptimSettings.keyframe_map(num_iter=2), window=False)
+
+
+def test_keyframes_fast_path_equivalent(hip, orc):
+    prob = synth.keyframe_problem(seed=3, frames=8, rings=24, az_steps=160, arc=0.5)
+    s = DmsaOptimSettings.keyframe_map(num_iter=3)
+    p_ref, p_gpu = prob.copy(), prob.copy()
+    rep_ref, _, trace = orc.optimize_keyframes(p_ref, s)
+    opt = hip.DmsaOptimizer()
+    rep = opt.optimizeSet(p_gpu, s)
+    assert rep.iterations == rep_ref.iterations and rep.stop_reason == rep_ref.stop_reason
+    tr = opt.trace()
+    assert (trace[0]["M"], trace[0]["Mm"]) == (tr[0]["M"], tr[0]["Mm"])
+    for a, b in zip(trace, tr):
+        assert abs(a["error0"] - b["error0"]) <= 5e-3 * a["error0"]
+    dt, dr = _pose_diff(orc, p_ref, p_gpu)
+    assert dt < 1e-2 and dr < 5e-3, (dt, dr)  # max_step = 0.01 bounds the drift of the keyframe pass
+
+
+# ---- degenerate inputs ----------------------------------------------------------------------------------------------
+def test_window_without_static_map(hip, orc):
+    prob = synth.window_problem(seed=4, scans=3, rings=32, az_steps=256, num_static=0)
+    assert prob.staticPoints.shape[0] == 0
+    _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=3))
+
+
+def test_window_with_nonfinite_points_end_to_end(hip, orc):
+    prob = synth.window_problem(seed=12, scans=3, rings=32, az_steps=192, num_static=4000)
+    prob.localPoints[0, 0] = np.nan
+    prob.localPoints[777, 2] = np.inf
+    prob.localPoints[5000:5016, 1] = np.nan
+    prob.staticPoints[10, 0] = -np.inf
+    rep, p_gpu = _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=3))
+    assert np.isfinite(p_gpu.relTranslations).all() and np.isfinite(p_gpu.relOrientations).all()
+
+
+def test_two_frame_keyframe_set_aborts_like_reference(hip, orc):
+    prob = synth.keyframe_problem(seed=9, frames=2, rings=4, az_steps=24, arc=0.05)
+    s = DmsaOptimSettings.keyframe_map(num_iter=3)
+    p_ref, p_gpu = prob.copy(), prob.copy()
+    rep_ref, _, _ = orc.optimize_keyframes(p_ref, s)
+    rep = hip.DmsaOptimizer(pose_table_host=True, mirror_sums=True).optimizeSet(p_gpu, s)
+    assert (rep.stop_reason, rep.iterations) == (rep_ref.stop_reason, rep_ref.iterations)
+    assert _pose_diff(orc, p_ref, p_gpu)[0] < 1e-12
+
+
+# ---- config 3 at full size ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_window():
+    return synth.window_problem(seed=1)  # 10 x 131 072 + 200 000 static, the bench workload
+
+
+def test_config3_full_size_structure_and_residuals(hip, orc, full_window):
+    """The bench workload itself: bit-exact voxel structure, Gaussian sets, information matrices and residuals on the
+    parity path; fast path within 1e-6 relative; size-independent invariants of both."""
+    prob = full_window
+    s = DmsaOptimSettings.sliding_window()
+    n, ns = prob.localPoints.shape[0], prob.staticPoints.shape[0]
+    table, _ = orc.window_pose_table(prob)
+    g = orc.transform_points(table, prob.localPoints, prob.tformIdPerPoint)
+    glob = np.concatenate([g, prob.staticPoints]).astype(np.float32)
+    ids = np.concatenate([prob.ringIds, prob.staticRingIds])
+    ref = orc.Gaussians(glob, ids, prob.minGridSize, s)
+
+    results = {}
+    for mirror in (True, False):
+        opt = hip.DmsaOptimizer(pose_table_host=True, mirror_sums=mirror)
+        opt.upload(prob)
+        opt.poseTables(prob.getPoseParameters())
+        got = opt.updateGlobalPoints(0)
+        assert np.array_equal(got[:n, :3], glob[:n, :3])
+        M, Mm = opt.buildGaussians(s)
+        assert (M, Mm) == (ref.M, ref.Mm)
+        for level, f in ((0, s.grid_size_1_factor), (1, s.grid_size_2_factor)):
+            info, code, key, order = opt.voxelLevel(level)
+            res = float(np.float32(f) * np.float32(prob.minGridSize))
+            info_r, code_r, key_r, order_r = orc.voxelize(glob, res)
+            assert info.depth == info_r.depth and info.num_leaves == info_r.num_leaves
+            assert np.array_equal(code, code_r) and np.array_equal(order, order_r)
+            # invariants: DFS order = non-decreasing codes, `order` is a permutation of the finite points, ascending in a leaf
+            sc = code[order]  # leaf codes are per point; `order` is the leaf-DFS permutation
+            assert np.all(sc[1:] >= sc[:-1])
+            assert np.array_equal(np.sort(order), np.arange(n + ns))
+            same = sc[1:] == sc[:-1]
+            assert np.all(order[1:][same] > order[:-1][same])
+        seg, memb, info12, w = opt.gaussians()
+        assert np.array_equal(seg, ref.seg_offset) and np.array_equal(memb, ref.members)
+        assert seg[-1] == Mm and np.all(np.diff(seg) >= s.min_num_points_per_set)
+        base = prob.getPoseParameters()
+        params = np.stack([base, base + H_INCR * np.eye(len(base))[4]])
+        tables = opt.poseTables(params)
+        e = opt.evalResiduals(2)
+        results[mirror] = (info12, w, e)
+        if not mirror:  # fast path: <= 1e-6 relative against the oracle evaluated with the SAME information matrices
+            ref.set_info(info12, w)
+            for b in range(2):
+                gb = orc.transform_points(tables[b], prob.localPoints, prob.tformIdPerPoint)
+                e_ref = ref.residuals(np.concatenate([gb, prob.staticPoints]).astype(np.float32))
+                rel = np.abs(e[b] - e_ref) / np.maximum(np.abs(e_ref), 1e-12)
+                assert rel.max() < 1e-6, (b, rel.max())
+        if mirror:
+            assert np.array_equal(info12, ref.info) and np.array_equal(w, ref.weights)
+            for b in range(2):
+                gb = orc.transform_points(tables[b], prob.localPoints, prob.tformIdPerPoint)
+                e_ref = ref.residuals(np.concatenate([gb, prob.staticPoints]).astype(np.float32))
+                assert np.array_equal(e[b], e_ref)
+        # idempotence: building again from the same points gives the same sets
+        assert opt.buildGaussians(s) == (M, Mm)
+        seg2, memb2, _, _ = opt.gaussians()
+        assert np.array_equal(seg2, seg) and np.array_equal(memb2, memb)
+        opt.close()
+    (i_m, w_m, e_m), (i_f, w_f, e_f) = results[True], results[False]
+    scale = np.abs(i_m).max(axis=1, keepdims=True)
+    assert (np.abs(i_f - i_m) / scale).max() < 1e-5
+    # independently fitted information matrices (double sums in a different order): the median still holds 1e-6
+    rel = np.abs(e_f - e_m) / np.maximum(np.abs(e_m), 1e-12)
+    assert np.median(rel) < 1e-6 and rel.max() < 5e-4
+
+
+def test_config3_full_size_two_iterations_match_oracle(hip, orc, full_window):
+    rep, _ = _parity_run(hip, orc, full_window, DmsaOptimSettings.sliding_window(num_iter=2))
+    assert rep.num_gaussians > 10_000
