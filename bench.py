@@ -13,6 +13,10 @@ N > 1: windows are sequentially dependent in a SLAM run, so the window pass shar
 ("weak" scaling: every rank optimises its own window); the one exchange step of the sharded path — an all-gather of
 the optimised poses (RCCL) — is inside the timed region.  value = total iterations of all ranks / max-over-ranks time.
 
+`--workload keyframes` is config 4, the pass that really shards: ONE ring-buffer map of (frames-1)*N+1 keyframes is cut
+into N neighbourhoods sharing a boundary frame (sharding.py), rank i keeps only its submap resident, and the timed region
+ends with the all-gather of relative poses + updatePosesFromSubmap on every rank.
+
 Rank 0 prints ONE JSON line with `roofline` (correspondence kernel, HIP-event timed on the library stream) and
 `cpu_baseline` (the CPU oracle on a bounded sample of the same workload; oracle/ is used here only as the baseline).
 """
@@ -75,7 +79,14 @@ def main():
         wl = f"window{args.scans}x{args.rings * args.az}+static{args.static}"
         n_points = prob.localPoints.shape[0] + prob.staticPoints.shape[0]
     else:
-        prob = synth.keyframe_problem(seed=1 + rank, frames=args.frames, arc=2 * np.pi * args.frames / 256.0)
+        # config 4: one ring-buffer map cut into `world` neighbourhoods of --frames keyframes sharing one boundary frame;
+        # every rank builds the same map (same seed) and keeps only its own submap resident
+        from dmsa_lidar_slam_amd.sharding import gather_neighbourhood_poses, neighbourhood_ranges
+
+        total_frames = (args.frames - 1) * world + 1
+        full_map = synth.keyframe_problem(seed=1, frames=total_frames, arc=2 * np.pi * total_frames / 256.0)
+        ranges = neighbourhood_ranges(total_frames, world)
+        prob = full_map.getSubmap(*ranges[rank])
         settings = DmsaOptimSettings.keyframe_map(num_iter=1)
         wl = f"keyframes{args.frames}x~{prob.localPoints.shape[0] // args.frames}"
         n_points = prob.localPoints.shape[0]
@@ -96,7 +107,10 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     rep = opt.optimizeResident(settings)
-    if world > 1:  # the sharded path's one exchange step: all-gather of the optimised poses over RCCL/xGMI
+    if args.workload == "keyframes":  # sharded keyframe pass: all-gather + updatePosesFromSubmap on every rank
+        prob.relOrientations[:], prob.relTranslations[:] = opt.poses()
+        gather_neighbourhood_poses(full_map, prob, ranges, rank, world, dist, f"cuda:{local_rank}")
+    elif world > 1:  # independent windows: the exchange step is an all-gather of the optimised poses over RCCL/xGMI
         ro, rt = opt.poses()
         mine = torch.from_numpy(np.concatenate([ro.ravel(), rt.ravel()])).cuda()
         gathered = [torch.empty_like(mine) for _ in range(world)]
@@ -147,7 +161,8 @@ def main():
         flops = 48.0 * rep.num_memberships * evals
         valu_tflops = flops / (tm.residual_kernel_ms * 1e-3) / 1e12 if tm.residual_kernel_ms > 0 else 0.0
         out = {
-            "metric": "DMSA iterations/sec (10-scan window, 131072 pts/scan)",
+            "metric": "DMSA iterations/sec (10-scan window, 131072 pts/scan)" if args.workload == "window"
+                      else "DMSA iterations/sec (sharded keyframe pass, iterations of all neighbourhoods)",
             "value": round(value, 3),
             "unit": "iterations/s",
             "n_gpus": world,
@@ -168,7 +183,8 @@ def main():
                 "gaussians": int(rep.num_gaussians),
                 "memberships": int(rep.num_memberships),
                 "path": "mirror(serial-order sums)" if args.mirror else "fast(wave-parallel sums)",
-                "sharding": "independent windows per rank + pose all-gather" if world > 1 else "single GPU",
+                "sharding": ("single GPU" if world == 1 else "independent windows per rank + pose all-gather" if args.workload == "window"
+                             else f"{world} keyframe neighbourhoods of one {total_frames}-frame map, one per GPU + pose all-gather"),
             },
             "roofline": {
                 "kernel": "correspondence kernel (k_residuals_tiles + k_residuals_big), B evaluations per launch",

@@ -60,7 +60,9 @@ struct EventPair {
 struct dmsa_ctx {
     int device = 0;
     uint32_t flags = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;  // stream2 carries the second voxel level only
+    hipEvent_t ev_fork = nullptr, ev_scan0 = nullptr, ev_join = nullptr;
+    bool dual_stream = true;  // DMSA_DUAL_STREAM=0: both levels on `stream`
     std::string err;
 
     Model model = MODEL_NONE;
@@ -82,8 +84,9 @@ struct dmsa_ctx {
     int h_pin_next = 0;
     std::vector<float> h_tables;
     // voxelisation
-    DevBuf d_aabb, d_lattice, d_code[2], d_idx[2], d_code_s[2], d_idx_s[2], d_head, d_leaf_incl[2], d_leaf_start[2], d_slot_acc, d_slot_cnt,
-        d_gauss_of_slot, d_memb_of_slot, d_pos_slot_rank, d_nsorted, d_pair_d, d_pair_c, d_sort_tmp, d_scan_tmp, d_counts;
+    // per-resolution scratch: the two voxelisations of an iteration run concurrently on `stream` and `stream2`
+    DevBuf d_aabb, d_lattice, d_code[2], d_idx[2], d_code_s[2], d_idx_s[2], d_head[2], d_leaf_incl[2], d_leaf_start[2], d_slot_acc[2], d_slot_cnt[2],
+        d_gauss_of_slot[2], d_memb_of_slot[2], d_pos_slot_rank[2], d_nsorted[2], d_pair_d[2], d_pair_c[2], d_sort_tmp[2], d_scan_tmp[2], d_counts;
     LatticeTable h_lattice[2];
     bool key32[2] = {false, false};  // leaf codes of this level are 32-bit (tree depth <= 10)
     int depth_guess[2] = {-1, -1};   // tree depths of the previous voxelisation (speculation: saves one host sync)
@@ -201,13 +204,15 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
         HIPCHK(ctx->d_leaf_incl[l].ensure(n * 4));
         HIPCHK(ctx->d_leaf_start[l].ensure((n + 1) * 4));
     }
-    HIPCHK(ctx->d_head.ensure(n * 4));
-    HIPCHK(ctx->d_slot_acc.ensure(2 * n * 4));
-    HIPCHK(ctx->d_slot_cnt.ensure(2 * n * 4));
-    HIPCHK(ctx->d_gauss_of_slot.ensure(2 * n * 4));
-    HIPCHK(ctx->d_memb_of_slot.ensure(2 * n * 4));
-    HIPCHK(ctx->d_sort_tmp.ensure(sort_pairs_temp_bytes(n)));
-    HIPCHK(ctx->d_scan_tmp.ensure(scan_temp_bytes(2 * n)));
+    for (int l = 0; l < 2; ++l) {
+        HIPCHK(ctx->d_head[l].ensure(n * 4));
+        HIPCHK(ctx->d_slot_acc[l].ensure(2 * n * 4));
+        HIPCHK(ctx->d_slot_cnt[l].ensure(2 * n * 4));
+        HIPCHK(ctx->d_gauss_of_slot[l].ensure(2 * n * 4));
+        HIPCHK(ctx->d_memb_of_slot[l].ensure(2 * n * 4));
+        HIPCHK(ctx->d_sort_tmp[l].ensure(sort_pairs_temp_bytes(n)));
+        HIPCHK(ctx->d_scan_tmp[l].ensure(scan_temp_bytes(2 * n)));
+    }
     HIPCHK(ctx->d_counts.ensure(sizeof(GaussCounts) + sizeof(TileCounts)));  // read back together
     // memberships: every point belongs to at most one set per resolution
     HIPCHK(ctx->d_memb_local.ensure(2 * n * 16));
@@ -357,52 +362,84 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     GaussCounts* counts = ctx->d_counts.as<GaussCounts>();
     const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS);
     const bool split = s.gauss_split != 0 && ctx->model == MODEL_KEYFRAMES;
-    if (split) {
-        HIPCHK(ctx->d_pos_slot_rank.ensure((size_t)n * 4));
-        HIPCHK(ctx->d_nsorted.ensure((size_t)n * 16));
-        HIPCHK(ctx->d_pair_d.ensure((size_t)n * 4));
-        HIPCHK(ctx->d_pair_c.ensure((size_t)n * 4));
-    }
-    for (int l = 0; l < 2; ++l) {
-        if (!lvl_on[l]) continue;
+    if (split)
+        for (int l = 0; l < 2; ++l) {
+            HIPCHK(ctx->d_pos_slot_rank[l].ensure((size_t)n * 4));
+            HIPCHK(ctx->d_nsorted[l].ensure((size_t)n * 16));
+            HIPCHK(ctx->d_pair_d[l].ensure((size_t)n * 8));
+        }
+    // The two resolutions are independent until their member lists are appended (level 1 starts at level 0's totals):
+    // level 0 runs on `stream`, level 1 on `stream2`; their launches are enqueued stage by stage so that both streams fill.
+    const bool two = ctx->dual_stream && lvl_on[0] && lvl_on[1];
+    hipStream_t st[2] = {ctx->stream, two ? ctx->stream2 : ctx->stream};
+    bool k32v[2] = {false, false};
+    auto stage_sort = [&](int l) -> int {
+        const unsigned end_bit = (unsigned)(sort_bits[l] + 1);
+        const bool k32 = end_bit <= 32;
+        k32v[l] = ctx->key32[l] = k32;
+        launch_voxel_keys(ctx->d_global.as<float4>(), n, ctx->d_lattice.as<LatticeTable>() + l, ctx->level_res[l], ctx->d_code[l].p, k32,
+                          ctx->d_idx[l].as<uint32_t>(), st[l]);
+        if (k32)
+            HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, ctx->d_code[l].as<uint32_t>(), ctx->d_code_s[l].as<uint32_t>(),
+                                      ctx->d_idx[l].as<uint32_t>(), ctx->d_idx_s[l].as<uint32_t>(), (size_t)n, end_bit, st[l]));
+        else
+            HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, ctx->d_code[l].as<uint64_t>(), ctx->d_code_s[l].as<uint64_t>(),
+                                      ctx->d_idx[l].as<uint32_t>(), ctx->d_idx_s[l].as<uint32_t>(), (size_t)n, end_bit, st[l]));
+        return DMSA_OK;
+    };
+    auto stage_leaves = [&](int l) -> int {
         const LatticeTable* tab = ctx->d_lattice.as<LatticeTable>() + l;
-        {
-            ScopedTimer tm(ctx, T_VOXEL);
-            const unsigned end_bit = (unsigned)(sort_bits[l] + 1);
-            const bool k32 = end_bit <= 32;
-            ctx->key32[l] = k32;
-            launch_voxel_keys(ctx->d_global.as<float4>(), n, ctx->d_lattice.as<LatticeTable>() + l, ctx->level_res[l], ctx->d_code[l].p, k32,
-                              ctx->d_idx[l].as<uint32_t>(), ctx->stream);
-            if (k32)
-                HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp.p, ctx->d_sort_tmp.cap, ctx->d_code[l].as<uint32_t>(), ctx->d_code_s[l].as<uint32_t>(),
-                                          ctx->d_idx[l].as<uint32_t>(), ctx->d_idx_s[l].as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
-            else
-                HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp.p, ctx->d_sort_tmp.cap, ctx->d_code[l].as<uint64_t>(), ctx->d_code_s[l].as<uint64_t>(),
-                                          ctx->d_idx[l].as<uint32_t>(), ctx->d_idx_s[l].as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
-            launch_head_flags(ctx->d_code_s[l].p, k32, n, tab, ctx->d_head.as<int32_t>(), ctx->stream);
-            HIPCHK(inclusive_scan_i32(ctx->d_scan_tmp.p, ctx->d_scan_tmp.cap, ctx->d_head.as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), (size_t)n, ctx->stream));
-            launch_leaf_starts(ctx->d_head.as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_code_s[l].p, k32, tab, n,
-                               ctx->d_leaf_start[l].as<int32_t>(), &counts->level[l], ctx->stream);
-            launch_leaf_accept(ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(), &counts->level[l],
-                               s.min_num_points_per_set, n, ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(), ctx->stream);
-            if (split)
-                launch_leaf_split(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(),
-                                  ctx->d_nglobal.as<float4>(), &counts->level[l], s.min_num_points_per_set, n, ctx->d_nsorted.as<float4>(),
-                                  ctx->d_pair_d.as<float>(), ctx->d_pair_c.as<int32_t>(), ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(),
-                                  ctx->d_pos_slot_rank.as<int32_t>(), ctx->stream);
-            launch_leaf_scan(ctx->d_slot_acc.as<int32_t>(), ctx->d_slot_cnt.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(), ctx->d_memb_of_slot.as<int32_t>(),
-                             &counts->level[l], ctx->stream);
-            launch_gather_members(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(),
-                                  ctx->d_code_s[l].p, k32, tab, ctx->d_slot_acc.as<int32_t>(), ctx->d_gauss_of_slot.as<int32_t>(),
-                                  ctx->d_memb_of_slot.as<int32_t>(), split ? ctx->d_pos_slot_rank.as<int32_t>() : nullptr, ctx->d_local.as<float4>(),
-                                  ctx->d_slot_cnt.as<int32_t>(), counts, l, n, ctx->d_memb_local.as<float4>(), ctx->d_memb_idx.as<int32_t>(),
-                                  ctx->d_memb_g.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), ctx->stream);
+        const bool k32 = k32v[l];
+        launch_head_flags(ctx->d_code_s[l].p, k32, n, tab, ctx->d_head[l].as<int32_t>(), st[l]);
+        HIPCHK(inclusive_scan_i32(ctx->d_scan_tmp[l].p, ctx->d_scan_tmp[l].cap, ctx->d_head[l].as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), (size_t)n, st[l]));
+        launch_leaf_starts(ctx->d_head[l].as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_code_s[l].p, k32, tab, n,
+                           ctx->d_leaf_start[l].as<int32_t>(), &counts->level[l], st[l]);
+        launch_leaf_accept(ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(), &counts->level[l],
+                           s.min_num_points_per_set, n, ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(), st[l]);
+        if (split)
+            launch_leaf_split(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(),
+                              ctx->d_nglobal.as<float4>(), &counts->level[l], s.min_num_points_per_set, n, ctx->d_nsorted[l].as<float4>(),
+                              ctx->d_pair_d[l].as<unsigned long long>(), ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(),
+                              ctx->d_pos_slot_rank[l].as<int32_t>(), st[l]);
+        launch_leaf_scan(ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(), ctx->d_gauss_of_slot[l].as<int32_t>(), ctx->d_memb_of_slot[l].as<int32_t>(),
+                         &counts->level[l], st[l]);
+        return DMSA_OK;
+    };
+    auto stage_gather = [&](int l) {
+        const LatticeTable* tab = ctx->d_lattice.as<LatticeTable>() + l;
+        launch_gather_members(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(),
+                              ctx->d_code_s[l].p, k32v[l], tab, ctx->d_slot_acc[l].as<int32_t>(), ctx->d_gauss_of_slot[l].as<int32_t>(),
+                              ctx->d_memb_of_slot[l].as<int32_t>(), split ? ctx->d_pos_slot_rank[l].as<int32_t>() : nullptr, ctx->d_local.as<float4>(),
+                              ctx->d_slot_cnt[l].as<int32_t>(), counts, l, n, ctx->d_memb_local.as<float4>(), ctx->d_memb_idx.as<int32_t>(),
+                              ctx->d_memb_g.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), st[l]);
+    };
+    {
+        ScopedTimer tm(ctx, T_VOXEL);
+        if (two) {
+            HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         }
-        if (!tiles_on) {
-            ScopedTimer tm(ctx, T_FIT);
-            launch_gauss_fit(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(), counts, l, ctx->d_info12.as<float>(),
-                             (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
+        for (int l = 0; l < 2; ++l)
+            if (lvl_on[l]) CHK(stage_sort(l));
+        for (int l = 0; l < 2; ++l) {
+            if (!lvl_on[l]) continue;
+            CHK(stage_leaves(l));
+            if (l == 0 && two) HIPCHK(hipEventRecord(ctx->ev_scan0, ctx->stream));  // level-0 totals are final
         }
+        if (two) HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_scan0, 0));
+        for (int l = 0; l < 2; ++l)
+            if (lvl_on[l]) stage_gather(l);
+        if (two) {
+            HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
+    }
+    if (!tiles_on) {
+        ScopedTimer tm(ctx, T_FIT);
+        for (int l = 0; l < 2; ++l)
+            if (lvl_on[l])
+                launch_gauss_fit(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(), counts, l, ctx->d_info12.as<float>(),
+                                 (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
     }
     // Tiles of whole Gaussians for the fit and the correspondence kernel; their counts travel with M / Mm.
     TileCounts htc{};
@@ -716,7 +753,10 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     if (const char* e = std::getenv("DMSA_K4_BIG")) ctx->cfg_big_n = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("DMSA_K4_TILES")) ctx->use_tiles = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_KEY_COMPRESS")) ctx->compress_keys = std::atoi(e) != 0;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (const char* e = std::getenv("DMSA_DUAL_STREAM")) ctx->dual_stream = std::atoi(e) != 0;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_scan0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return DMSA_ERR_HIP;
     }
@@ -733,11 +773,17 @@ void dmsa_destroy(dmsa_ctx* ctx) {
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     DevBuf* bufs[] = {&ctx->d_local, &ctx->d_nlocal, &ctx->d_ring, &ctx->d_global, &ctx->d_nglobal, &ctx->d_tables, &ctx->d_ctrl, &ctx->d_stamps,
                       &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
-                      &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_head, &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
-                      &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_slot_acc, &ctx->d_slot_cnt, &ctx->d_gauss_of_slot, &ctx->d_memb_of_slot,
-                      &ctx->d_pos_slot_rank, &ctx->d_nsorted, &ctx->d_pair_d, &ctx->d_pair_c, &ctx->d_sort_tmp, &ctx->d_scan_tmp, &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_memb_g, &ctx->d_seg_off,
+                      &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
+                      &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_memb_g, &ctx->d_seg_off,
                       &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_counts, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
     for (DevBuf* b : bufs) b->release();
+    for (int l = 0; l < 2; ++l)
+        for (DevBuf* b : {&ctx->d_head[l], &ctx->d_slot_acc[l], &ctx->d_slot_cnt[l], &ctx->d_gauss_of_slot[l], &ctx->d_memb_of_slot[l], &ctx->d_pos_slot_rank[l],
+                          &ctx->d_nsorted[l], &ctx->d_pair_d[l], &ctx->d_pair_c[l], &ctx->d_sort_tmp[l], &ctx->d_scan_tmp[l]})
+            b->release();
+    (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipEventDestroy(ctx->ev_fork), (void)hipEventDestroy(ctx->ev_scan0), (void)hipEventDestroy(ctx->ev_join);
+    (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -670,42 +670,69 @@ __global__ __launch_bounds__(256) void k_split_gather_normals(const uint32_t* __
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) nsorted[i] = nglobal[idx_sorted[i]];
 }
+// One workgroup = 256 consecutive sorted positions x one slice of the partner range.  The union of the leaves touched by
+// the 256 positions is contiguous; it is walked in LDS-staged chunks of kSplitChunk normals (inside a big leaf every lane
+// reads the same LDS address: a broadcast), slice y taking chunks y, y + kSplitSlices, ...  The slices of a position are
+// merged with a 64-bit atomicMin on (float bits of the distance, partner rank): distances are >= 0, so the unsigned order
+// of the bits is the float order, and the smaller rank wins a tie -- exactly the reference's first strict minimum.
+constexpr int kSplitChunk = 1024;
+constexpr int kSplitSlices = 8;
 __global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__ leaf_incl, const int32_t* __restrict__ leaf_start,
                                                      const int32_t* __restrict__ slot_acc, const float4* __restrict__ nsorted, int64_t n_valid_cap,
-                                                     const LevelCounts* __restrict__ counts, float* __restrict__ pair_best_d,
-                                                     int32_t* __restrict__ pair_best_c) {
+                                                     const LevelCounts* __restrict__ counts, unsigned long long* __restrict__ pair_best) {
+    __shared__ float4 s_n[kSplitChunk];
+    __shared__ int s_lo, s_hi;
     const int nl = counts->num_leaves;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_valid_cap; i += stride) {
+    const int64_t nvalid = min((int64_t)leaf_start[nl], n_valid_cap);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if ((int64_t)blockIdx.x * 256 >= nvalid) return;
+    if (threadIdx.x == 0) s_lo = INT_MAX, s_hi = 0;
+    __syncthreads();
+    bool active = i < nvalid;
+    int b = 0, e = 0;
+    if (active) {
         const int l = leaf_incl[i] - 1;
-        if (l < 0 || l >= nl || i >= leaf_start[nl]) continue;  // past the last valid position
-        if (!slot_acc[2 * l]) continue;
-        const int b = leaf_start[l], e = leaf_start[l + 1];
-        const float4 na = nsorted[i];
-        // The reference compares norms (sqrt) with a strict '<'.  sqrt is monotone, so a candidate whose SQUARED norm is not
-        // below the best squared norm can never win; the (correctly rounded, expensive) sqrt is only taken for the rest.
-        float best = FLT_MAX, best_sq = FLT_MAX;
-        int best_c = 0;
-        for (int j = b; j < e; ++j) {
-            if (j == (int)i) continue;
-            const float4 nc = nsorted[j];
+        active = l >= 0 && l < nl && slot_acc[2 * l] != 0;
+        if (active) {
+            b = leaf_start[l], e = leaf_start[l + 1];
+            atomicMin(&s_lo, b), atomicMax(&s_hi, e);
+        }
+    }
+    __syncthreads();
+    const int lo = s_lo, hi = s_hi;
+    if (hi <= lo) return;
+    const float4 na = active ? nsorted[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // The reference compares norms (sqrt) with a strict '<'.  sqrt is monotone, so a candidate whose SQUARED norm is not
+    // below the best squared norm can never win; the (correctly rounded, expensive) sqrt is only taken for the rest.
+    float best = FLT_MAX, best_sq = FLT_MAX;
+    int best_c = 0;
+    for (int c0 = lo + (int)blockIdx.y * kSplitChunk; c0 < hi; c0 += kSplitSlices * kSplitChunk) {
+        const int cn = min(kSplitChunk, hi - c0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cn; t += 256) s_n[t] = nsorted[c0 + t];
+        __syncthreads();
+        if (!active) continue;
+        const int j0 = max(b, c0) - c0, j1 = min(e, c0 + cn) - c0, self = (int)(i - c0);
+        for (int j = j0; j < j1; ++j) {
+            const float4 nc = s_n[j];
             const float sx = na.x + nc.x, sy = na.y + nc.y, sz = na.z + nc.z;
             const float sq = sum3f(sx * sx, sy * sy, sz * sz);
-            if (sq < best_sq) {
+            if (sq < best_sq && j != self) {
                 const float d = sqrtf(sq);
-                if (d < best) best = d, best_sq = sq, best_c = j - b;
+                if (d < best) best = d, best_sq = sq, best_c = c0 + j - b;
             }
         }
-        pair_best_d[i] = best, pair_best_c[i] = best_c;
     }
+    if (active && best < FLT_MAX)
+        atomicMin(&pair_best[i], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(uint32_t)best_c);
 }
 
 // Gaussians.h:27-85 splitSet + the split branch of createGaussianSets (DmsaOptimizer.h:310-337), one wave per
 // accepted leaf.  pos_slot_rank[i] = rank within its set, sign bit set for the second set.
 __global__ __launch_bounds__(256) void k_leaf_split(const int32_t* __restrict__ leaf_start, const uint32_t* __restrict__ idx_sorted,
                                                     const int32_t* __restrict__ ring, const float4* __restrict__ nglobal,
-                                                    const LevelCounts* __restrict__ counts, int min_pts, const float* __restrict__ pair_best_d,
-                                                    const int32_t* __restrict__ pair_best_c, int32_t* __restrict__ slot_acc,
+                                                    const LevelCounts* __restrict__ counts, int min_pts,
+                                                    const unsigned long long* __restrict__ pair_best, int32_t* __restrict__ slot_acc,
                                                     int32_t* __restrict__ slot_cnt, int32_t* __restrict__ pos_slot_rank) {
     const int nl = counts->num_leaves;
     const int lane = threadIdx.x & 63;
@@ -719,8 +746,9 @@ __global__ __launch_bounds__(256) void k_leaf_split(const int32_t* __restrict__ 
         float best = FLT_MAX;
         long long best_pair = LLONG_MAX;
         for (int j = b + lane; j < e; j += 64) {
-            const float d = pair_best_d[j];
-            if (d < best) best = d, best_pair = (long long)(j - b) * cnt + pair_best_c[j];  // j ascends per lane
+            const unsigned long long v = pair_best[j];  // ~0 = no partner at all
+            const float d = v == ~0ull ? FLT_MAX : __uint_as_float((uint32_t)(v >> 32));
+            if (d < best) best = d, best_pair = (long long)(j - b) * cnt + (long long)(uint32_t)v;  // j ascends per lane
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -780,13 +808,14 @@ __global__ __launch_bounds__(256) void k_leaf_split(const int32_t* __restrict__ 
     }
 }
 void launch_leaf_split(const int32_t* leaf_incl, const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const float4* nglobal,
-                       const LevelCounts* counts, int min_pts, int64_t n, float4* nsorted, float* pair_best_d, int32_t* pair_best_c, int32_t* slot_acc,
+                       const LevelCounts* counts, int min_pts, int64_t n, float4* nsorted, unsigned long long* pair_best, int32_t* slot_acc,
                        int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s) {
     hipLaunchKernelGGL(k_split_gather_normals, dim3(grid_for(n, 256)), dim3(256), 0, s, idx_sorted, nglobal, n, nsorted);
-    hipLaunchKernelGGL(k_split_pairs, dim3(grid_for(n, 256, 256 * 32)), dim3(256), 0, s, leaf_incl, leaf_start, slot_acc, nsorted, n, counts, pair_best_d,
-                       pair_best_c);
-    hipLaunchKernelGGL(k_leaf_split, dim3(1024), dim3(256), 0, s, leaf_start, idx_sorted, ring, nglobal, counts, min_pts, pair_best_d, pair_best_c,
-                       slot_acc, slot_cnt, pos_slot_rank);
+    (void)hipMemsetAsync(pair_best, 0xFF, (size_t)n * 8, s);
+    hipLaunchKernelGGL(k_split_pairs, dim3((unsigned)((n + 255) / 256), kSplitSlices), dim3(256), 0, s, leaf_incl, leaf_start, slot_acc, nsorted, n, counts,
+                       pair_best);
+    hipLaunchKernelGGL(k_leaf_split, dim3(1024), dim3(256), 0, s, leaf_start, idx_sorted, ring, nglobal, counts, min_pts, pair_best, slot_acc, slot_cnt,
+                       pos_slot_rank);
 }
 
 // Exclusive prefix sums of (accepted, accepted member count) over the two slots of every leaf.  The leaf count lives on the

@@ -23,16 +23,10 @@ def neighbourhood_ranges(num_frames: int, world: int):
     return [(int(edges[i]), int(edges[i + 1])) for i in range(world)]
 
 
-def optimize_neighbourhoods(full_map: MapManagement, settings: DmsaOptimSettings, optimize_fn, rank: int = 0, world: int = 1,
-                            dist=None, device=None):
-    """Shard `full_map` over `world` ranks and optimise this rank's neighbourhood with `optimize_fn(submap, settings)`
-    (which updates the submap's relative poses in place).  With world > 1, `dist` is an initialised torch.distributed
-    module (backend nccl == RCCL on the GPU box, gloo in the CPU tests).  Every rank returns with the SAME updated
-    relative poses in full_map."""
-    ranges = neighbourhood_ranges(full_map.numFrames, world)
+def gather_neighbourhood_poses(full_map: MapManagement, sub: MapManagement, ranges, rank: int, world: int, dist=None, device=None):
+    """The one exchange step of the sharded pass: all-gather every rank's optimised relative poses ((to - from) x 6
+    doubles) and apply updatePosesFromSubmap (MapManagement.h:278-288) for every neighbourhood on every rank."""
     f0, f1 = ranges[rank]
-    sub = full_map.getSubmap(f0, f1)
-    report = optimize_fn(sub, settings)
     width = max(t - f for f, t in ranges)
     mine = np.zeros((width, 6))
     mine[: f1 - f0, :3] = sub.relOrientations[1:]
@@ -44,12 +38,24 @@ def optimize_neighbourhoods(full_map: MapManagement, settings: DmsaOptimSettings
         if device is not None:
             t = t.to(device)
         gathered = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)  # the one exchange step of the sharded pass
+        dist.all_gather(gathered, t)
         parts = [g.cpu().numpy() for g in gathered]
     else:
         parts = [mine]
-    for (f, t_), part in zip(ranges, parts):  # == updatePosesFromSubmap for every neighbourhood (disjoint columns)
+    for (f, t_), part in zip(ranges, parts):  # disjoint columns: the order of application does not matter
         k = t_ - f
         full_map.relOrientations[f + 1:t_ + 1] = part[:k, :3]
         full_map.relTranslations[f + 1:t_ + 1] = part[:k, 3:]
+
+
+def optimize_neighbourhoods(full_map: MapManagement, settings: DmsaOptimSettings, optimize_fn, rank: int = 0, world: int = 1,
+                            dist=None, device=None):
+    """Shard `full_map` over `world` ranks and optimise this rank's neighbourhood with `optimize_fn(submap, settings)`
+    (which updates the submap's relative poses in place).  With world > 1, `dist` is an initialised torch.distributed
+    module (backend nccl == RCCL on the GPU box, gloo in the CPU tests).  Every rank returns with the SAME updated
+    relative poses in full_map."""
+    ranges = neighbourhood_ranges(full_map.numFrames, world)
+    sub = full_map.getSubmap(*ranges[rank])
+    report = optimize_fn(sub, settings)
+    gather_neighbourhood_poses(full_map, sub, ranges, rank, world, dist, device)
     return report
