@@ -366,7 +366,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         for (int l = 0; l < 2; ++l) {
             HIPCHK(ctx->d_pos_slot_rank[l].ensure((size_t)n * 4));
             HIPCHK(ctx->d_nsorted[l].ensure((size_t)n * 16));
-            HIPCHK(ctx->d_pair_d[l].ensure((size_t)n * 8));
+            HIPCHK(ctx->d_pair_d[l].ensure(split_scratch_bytes(n)));
         }
     // The two resolutions are independent until their member lists are appended (level 1 starts at level 0's totals):
     // level 0 runs on `stream`, level 1 on `stream2`; their launches are enqueued stage by stage so that both streams fill.

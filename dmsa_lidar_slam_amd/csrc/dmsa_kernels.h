@@ -91,8 +91,9 @@ void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const v
 void launch_leaf_accept(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const LevelCounts* counts, int min_pts,
                         int64_t capacity /* leaves */, int32_t* slot_acc /* 2 per leaf */, int32_t* slot_cnt, hipStream_t s);
 // keyframe pass: splitSet on accepted leaves; rewrites slot_acc/slot_cnt and fills per-position (set, rank)
+size_t split_scratch_bytes(int64_t n);  // pair_best[n] + task list + counter
 void launch_leaf_split(const int32_t* leaf_incl, const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const float4* nglobal,
-                       const LevelCounts* counts, int min_pts, int64_t n, float4* nsorted /* n */, unsigned long long* pair_best /* n */,
+                       const LevelCounts* counts, int min_pts, int64_t n, float4* nsorted /* n */, unsigned long long* pair_best /* split_scratch_bytes(n) */,
                        int32_t* slot_acc, int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s);
 void launch_leaf_scan(const int32_t* slot_acc, const int32_t* slot_cnt, int32_t* gauss_of_slot, int32_t* memb_of_slot, LevelCounts* counts,
                       hipStream_t s);

@@ -665,90 +665,168 @@ void launch_leaf_accept(const int32_t* leaf_start, const uint32_t* idx_sorted, c
 // The quadratic part of splitSet (Gaussians.h:36-51), position-parallel: every sorted position a of an accepted leaf scans
 // all members c of its leaf (normals pre-gathered in sorted order, so a wave inside one big leaf reads the same address)
 // and keeps its first best partner.  Work per leaf is n^2 / 64 wave-iterations spread over n / 64 waves instead of one.
-__global__ __launch_bounds__(256) void k_split_gather_normals(const uint32_t* __restrict__ idx_sorted, const float4* __restrict__ nglobal, int64_t n,
-                                                              float4* __restrict__ nsorted) {
+__global__ __launch_bounds__(256) void k_split_gather_normals(const uint32_t* __restrict__ idx_sorted, const float4* __restrict__ nglobal,
+                                                              const int32_t* __restrict__ ring, int64_t n, float4* __restrict__ nsorted) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) nsorted[i] = nglobal[idx_sorted[i]];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t pi = idx_sorted[i];
+        float4 v = nglobal[pi];
+        v.w = __int_as_float(ring[pi]);  // the normal's w is unused: carry the ring id in sorted order
+        nsorted[i] = v;
+    }
 }
-// One workgroup = 256 consecutive sorted positions x one slice of the partner range.  The union of the leaves touched by
-// the 256 positions is contiguous; it is walked in LDS-staged chunks of kSplitChunk normals (inside a big leaf every lane
-// reads the same LDS address: a broadcast), slice y taking chunks y, y + kSplitSlices, ...  The slices of a position are
-// merged with a 64-bit atomicMin on (float bits of the distance, partner rank): distances are >= 0, so the unsigned order
-// of the bits is the float order, and the smaller rank wins a tie -- exactly the reference's first strict minimum.
-constexpr int kSplitChunk = 1024;
-constexpr int kSplitSlices = 8;
-__global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__ leaf_incl, const int32_t* __restrict__ leaf_start,
-                                                     const int32_t* __restrict__ slot_acc, const float4* __restrict__ nsorted, int64_t n_valid_cap,
-                                                     const LevelCounts* __restrict__ counts, unsigned long long* __restrict__ pair_best) {
-    __shared__ float4 s_n[kSplitChunk];
-    __shared__ int s_lo, s_hi;
-    const int nl = counts->num_leaves;
-    const int64_t nvalid = min((int64_t)leaf_start[nl], n_valid_cap);
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if ((int64_t)blockIdx.x * 256 >= nvalid) return;
-    if (threadIdx.x == 0) s_lo = INT_MAX, s_hi = 0;
-    __syncthreads();
-    bool active = i < nvalid;
-    int b = 0, e = 0;
+// Work decomposition: a TASK is (wave block of 64 consecutive sorted positions) x (one chunk of the partner range).  The
+// union of the leaves touched by the 64 positions is contiguous; it is cut into at most kSplitMaxChunks chunks of >=
+// kSplitChunk partners, so a 17 000-point leaf becomes ~275 x 64 tasks that fill the chip, while the task list stays <= n
+// entries.  k_split_tasks writes the list (slots reserved with one atomicAdd per wave block; the order is irrelevant),
+// k_split_pairs walks it with persistent waves.
+constexpr int kSplitChunk = 256;
+constexpr int kSplitMaxChunks = 64;
+struct SplitTask {
+    int32_t wave_block;  // positions 64*wave_block .. +63
+    int32_t c0, c1;      // partner positions [c0, c1)
+    int32_t pad;
+};
+__device__ __forceinline__ void split_position_range(int64_t i, int64_t nvalid, int nl, const int32_t* __restrict__ leaf_incl,
+                                                     const int32_t* __restrict__ leaf_start, const int32_t* __restrict__ slot_acc, bool& active,
+                                                     int& b, int& e) {
+    active = i < nvalid;
+    b = INT_MAX, e = 0;
     if (active) {
         const int l = leaf_incl[i] - 1;
         active = l >= 0 && l < nl && slot_acc[2 * l] != 0;
-        if (active) {
-            b = leaf_start[l], e = leaf_start[l + 1];
-            atomicMin(&s_lo, b), atomicMax(&s_hi, e);
+        if (active) b = leaf_start[l], e = leaf_start[l + 1];
+    }
+}
+__global__ __launch_bounds__(1024) void k_split_tasks(const int32_t* __restrict__ leaf_incl, const int32_t* __restrict__ leaf_start,
+                                                      const int32_t* __restrict__ slot_acc, int64_t n_valid_cap,
+                                                      const LevelCounts* __restrict__ counts, SplitTask* __restrict__ tasks,
+                                                      int32_t* __restrict__ num_tasks) {
+    __shared__ int s_cnt[16], s_base;
+    const int nl = counts->num_leaves;
+    const int64_t nvalid = min((int64_t)leaf_start[nl], n_valid_cap);
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if ((int64_t)blockIdx.x * 1024 >= nvalid) return;
+    bool active;
+    int b, e;
+    split_position_range(i, nvalid, nl, leaf_incl, leaf_start, slot_acc, active, b, e);
+    int lo = b, hi = e;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) lo = min(lo, __shfl_xor(lo, m)), hi = max(hi, __shfl_xor(hi, m));
+    const int len = max(0, hi - lo);
+    int chunk = max(kSplitChunk, (len + kSplitMaxChunks - 1) / kSplitMaxChunks);
+    chunk = (chunk + 63) & ~63;
+    const int nchunks = (len + chunk - 1) / chunk;  // 0 for a wave block without accepted leaves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = nchunks;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one atomic per 1024 positions: the counter is a single contended address
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int c = s_cnt[w];
+            s_cnt[w] = tot, tot += c;
         }
+        s_base = tot ? atomicAdd(num_tasks, tot) : 0;
     }
     __syncthreads();
-    const int lo = s_lo, hi = s_hi;
-    if (hi <= lo) return;
-    const float4 na = active ? nsorted[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    // The reference compares norms (sqrt) with a strict '<'.  sqrt is monotone, so a candidate whose SQUARED norm is not
-    // below the best squared norm can never win; the (correctly rounded, expensive) sqrt is only taken for the rest.
-    float best = FLT_MAX, best_sq = FLT_MAX;
-    int best_c = 0;
-    for (int c0 = lo + (int)blockIdx.y * kSplitChunk; c0 < hi; c0 += kSplitSlices * kSplitChunk) {
-        const int cn = min(kSplitChunk, hi - c0);
-        __syncthreads();
-        for (int t = threadIdx.x; t < cn; t += 256) s_n[t] = nsorted[c0 + t];
-        __syncthreads();
-        if (!active) continue;
-        const int j0 = max(b, c0) - c0, j1 = min(e, c0 + cn) - c0, self = (int)(i - c0);
-        for (int j = j0; j < j1; ++j) {
-            const float4 nc = s_n[j];
-            const float sx = na.x + nc.x, sy = na.y + nc.y, sz = na.z + nc.z;
-            const float sq = sum3f(sx * sx, sy * sy, sz * sz);
+    if (lane < nchunks) {  // nchunks <= kSplitMaxChunks = 64
+        SplitTask t;
+        t.wave_block = (int32_t)(i >> 6), t.c0 = lo + lane * chunk, t.c1 = min(hi, lo + (lane + 1) * chunk), t.pad = 0;
+        tasks[s_base + s_cnt[wave] + lane] = t;
+    }
+}
+// A task's 64 positions meet its partners 64 at a time: one coalesced vector load puts partner c0 + lane into every lane
+// (the next 64 are prefetched meanwhile), then the partners are broadcast lane by lane with v_readlane.  No LDS and no scalar
+// cache in the loop (an LDS-staged loop was bound by LDS read bandwidth, a scalar-load loop by scalar-cache misses).  The
+// chunks of a position are merged with a 64-bit atomicMin on (float bits of the distance, partner rank): distances are >= 0,
+// so the unsigned order of the bits is the float order, and the smaller rank wins a tie -- the reference's first strict minimum.
+__device__ __forceinline__ float bcast_lane(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+__global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__ leaf_incl, const int32_t* __restrict__ leaf_start,
+                                                     const int32_t* __restrict__ slot_acc, const float4* __restrict__ nsorted, int64_t n_valid_cap,
+                                                     const LevelCounts* __restrict__ counts, const SplitTask* __restrict__ tasks,
+                                                     const int32_t* __restrict__ num_tasks, unsigned long long* __restrict__ pair_best) {
+    const int nl = counts->num_leaves;
+    const int64_t nvalid = min((int64_t)leaf_start[nl], n_valid_cap);
+    const int ntasks = *num_tasks;
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    const float kFar = 3.0e19f;  // (n_a + kFar)^2 overflows to +inf: padding partners can never win
+    for (int t = wave_global; t < ntasks; t += nwaves) {
+        const SplitTask task = tasks[t];
+        const int64_t i = (int64_t)task.wave_block * 64 + lane;
+        const int c0 = __builtin_amdgcn_readfirstlane(task.c0), c1 = __builtin_amdgcn_readfirstlane(task.c1);
+        bool active;
+        int b, e;
+        split_position_range(i, nvalid, nl, leaf_incl, leaf_start, slot_acc, active, b, e);
+        const bool uniform = __ballot(active && b <= c0 && e >= c1) == ~0ull;  // every position may pair with the whole chunk
+        const float4 na = active ? nsorted[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // The reference compares norms (sqrt) with a strict '<'.  sqrt is monotone, so a candidate whose SQUARED norm is not
+        // below the best squared norm can never win; the (correctly rounded, expensive) sqrt is only taken for the rest.
+        float best = FLT_MAX, best_sq = active ? FLT_MAX : -1.0f;
+        int best_c = 0;
+        const int self = (int)i;
+        auto exact = [&](float sq, int j) {  // the reference's update, in partner order
             if (sq < best_sq && j != self) {
                 const float d = sqrtf(sq);
-                if (d < best) best = d, best_sq = sq, best_c = c0 + j - b;
+                if (d < best) best = d, best_sq = sq, best_c = j - b;
             }
+        };
+        auto load64 = [&](int j) {
+            const int jj = j + lane;
+            return jj < c1 ? nsorted[jj] : make_float4(kFar, kFar, kFar, 0.f);
+        };
+        float4 cur = load64(c0);
+        for (int j = c0; j < c1; j += 64) {
+            const float4 nxt = j + 64 < c1 ? load64(j + 64) : make_float4(kFar, kFar, kFar, 0.f);
+#pragma unroll
+            for (int k = 0; k < 64; k += 4) {  // four independent candidates per step; the ordered exact update only if one can win
+                float q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float sx = na.x + bcast_lane(cur.x, k + u), sy = na.y + bcast_lane(cur.y, k + u), sz = na.z + bcast_lane(cur.z, k + u);
+                    q[u] = sum3f(sx * sx, sy * sy, sz * sz);
+                    if (!uniform) q[u] = (j + k + u >= b && j + k + u < e) ? q[u] : INFINITY;  // partner of another leaf
+                }
+                if (fminf(fminf(q[0], q[1]), fminf(q[2], q[3])) < best_sq) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) exact(q[u], j + k + u);
+                }
+            }
+            cur = nxt;
         }
+        if (active && best < FLT_MAX)
+            atomicMin(&pair_best[i], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(uint32_t)best_c);
     }
-    if (active && best < FLT_MAX)
-        atomicMin(&pair_best[i], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(uint32_t)best_c);
 }
 
-// Gaussians.h:27-85 splitSet + the split branch of createGaussianSets (DmsaOptimizer.h:310-337), one wave per
-// accepted leaf.  pos_slot_rank[i] = rank within its set, sign bit set for the second set.
-__global__ __launch_bounds__(256) void k_leaf_split(const int32_t* __restrict__ leaf_start, const uint32_t* __restrict__ idx_sorted,
-                                                    const int32_t* __restrict__ ring, const float4* __restrict__ nglobal,
-                                                    const LevelCounts* __restrict__ counts, int min_pts,
-                                                    const unsigned long long* __restrict__ pair_best, int32_t* __restrict__ slot_acc,
-                                                    int32_t* __restrict__ slot_cnt, int32_t* __restrict__ pos_slot_rank) {
+// Gaussians.h:27-85 splitSet + the split branch of createGaussianSets (DmsaOptimizer.h:310-337).  One GROUP of kThreads
+// threads per accepted leaf: a wave (kThreads = 64) for leaves of <= kSplitBigLeaf members, a 1024-thread workgroup for
+// the few larger ones (a 17 000-point leaf would otherwise be walked by one wave).  pos_slot_rank[i] = rank within its
+// set, sign bit set for the second set.
+constexpr int kSplitBigLeaf = 1024;
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void k_leaf_split(const int32_t* __restrict__ leaf_start, const float4* __restrict__ nsorted,
+                                                         const LevelCounts* __restrict__ counts, int min_pts,
+                                                         const unsigned long long* __restrict__ pair_best, int32_t* __restrict__ slot_acc,
+                                                         int32_t* __restrict__ slot_cnt, int32_t* __restrict__ pos_slot_rank) {
+    constexpr int kWaves = kThreads / 64;
+    __shared__ float s_best[kWaves];
+    __shared__ long long s_pair[kWaves];
+    __shared__ int s_c1[kWaves], s_c2[kWaves], s_mn[kWaves], s_mx[kWaves];
     const int nl = counts->num_leaves;
-    const int lane = threadIdx.x & 63;
-    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int l = wave_global; l < nl; l += nwaves) {
-        if (!slot_acc[2 * l]) continue;  // wave-uniform
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int l = blockIdx.x; l < nl; l += gridDim.x) {
+        if (!slot_acc[2 * l]) continue;  // group-uniform
         const int b = leaf_start[l], e = leaf_start[l + 1], cnt = e - b;
+        if ((cnt > kSplitBigLeaf) != (kWaves > 1)) continue;  // the other launch owns this leaf
         // most anti-parallel normal pair: min over ordered pairs (a outer, c inner, a != c) of |n_a + n_c|, first minimum wins.
         // k_split_pairs already found, for every member a, its first best partner c; reduce over a (ties -> smallest a).
         float best = FLT_MAX;
         long long best_pair = LLONG_MAX;
-        for (int j = b + lane; j < e; j += 64) {
+        for (int j = b + tid; j < e; j += kThreads) {
             const unsigned long long v = pair_best[j];  // ~0 = no partner at all
             const float d = v == ~0ull ? FLT_MAX : __uint_as_float((uint32_t)(v >> 32));
-            if (d < best) best = d, best_pair = (long long)(j - b) * cnt + (long long)(uint32_t)v;  // j ascends per lane
+            if (d < best) best = d, best_pair = (long long)(j - b) * cnt + (long long)(uint32_t)v;  // j ascends per thread
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -756,50 +834,71 @@ __global__ __launch_bounds__(256) void k_leaf_split(const int32_t* __restrict__ 
             const long long op = __shfl_xor(best_pair, m);
             if (ob < best || (ob == best && op < best_pair)) best = ob, best_pair = op;
         }
-        int rank_base1 = 0, rank_base2 = 0;
+        if (kWaves > 1) {
+            __syncthreads();  // previous leaf's readers are done
+            if (lane == 0) s_best[wave] = best, s_pair[wave] = best_pair;
+            __syncthreads();
+            best = s_best[0], best_pair = s_pair[0];
+            for (int w = 1; w < kWaves; ++w)
+                if (s_best[w] < best || (s_best[w] == best && s_pair[w] < best_pair)) best = s_best[w], best_pair = s_pair[w];
+        }
         if (!(best <= 0.5f)) {  // `minDiffFromZero > 0.5f` -> no split (also when there was no pair at all)
-            for (int j = b + lane; j < e; j += 64) pos_slot_rank[j] = j - b;
+            for (int j = b + tid; j < e; j += kThreads) pos_slot_rank[j] = j - b;
             continue;  // slot 2l stays as accepted by k_leaf_accept
         }
         const int ia = (int)(best_pair / cnt), ic = (int)(best_pair % cnt);
-        const float4 r1 = nglobal[idx_sorted[b + ia]], r2 = nglobal[idx_sorted[b + ic]];
-        bool any1 = false;
+        const float4 r1 = nsorted[b + ia], r2 = nsorted[b + ic];
         int mn1 = INT_MAX, mx1 = INT_MIN;
-        for (int j0 = b; j0 < e; j0 += 64) {
-            const int j = j0 + lane;
+        int rank_base1 = 0, rank_base2 = 0;
+        for (int j0 = b; j0 < e; j0 += kThreads) {
+            const int j = j0 + tid;
             bool in = j < e, first = false;
             int id = 0;
             if (in) {
-                const uint32_t pi = idx_sorted[j];
-                const float4 v = nglobal[pi];
+                const float4 v = nsorted[j];
                 const float d1 = sqrtf(sum3f((r1.x - v.x) * (r1.x - v.x), (r1.y - v.y) * (r1.y - v.y), (r1.z - v.z) * (r1.z - v.z)));
                 const float d2 = sqrtf(sum3f((r2.x - v.x) * (r2.x - v.x), (r2.y - v.y) * (r2.y - v.y), (r2.z - v.z) * (r2.z - v.z)));
                 first = d1 < d2;
-                id = ring[pi];
+                id = __float_as_int(v.w);
             }
             const unsigned long long m1 = __ballot(in && first), m2 = __ballot(in && !first);
             const unsigned long long below = (1ull << lane) - 1ull;
-            if (in) {
-                if (first) {
-                    pos_slot_rank[j] = rank_base1 + __popcll(m1 & below);
-                    mn1 = min(mn1, id), mx1 = max(mx1, id);
-                    any1 = true;
-                } else {
-                    pos_slot_rank[j] = (int32_t)(0x80000000u | (uint32_t)(rank_base2 + __popcll(m2 & below)));
+            int off1 = 0, off2 = 0, tot1 = __popcll(m1), tot2 = __popcll(m2);
+            if (kWaves > 1) {  // ranks continue across the waves of the group in position order
+                __syncthreads();
+                if (lane == 0) s_c1[wave] = tot1, s_c2[wave] = tot2;
+                __syncthreads();
+                tot1 = 0, tot2 = 0;
+                for (int w = 0; w < kWaves; ++w) {
+                    if (w == wave) off1 = tot1, off2 = tot2;
+                    tot1 += s_c1[w], tot2 += s_c2[w];
                 }
             }
-            rank_base1 += __popcll(m1);
-            rank_base2 += __popcll(m2);
+            if (in) {
+                if (first) {
+                    pos_slot_rank[j] = rank_base1 + off1 + __popcll(m1 & below);
+                    mn1 = min(mn1, id), mx1 = max(mx1, id);
+                } else {
+                    pos_slot_rank[j] = (int32_t)(0x80000000u | (uint32_t)(rank_base2 + off2 + __popcll(m2 & below)));
+                }
+            }
+            rank_base1 += tot1;
+            rank_base2 += tot2;
         }
-        (void)any1;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             mn1 = min(mn1, __shfl_xor(mn1, m));
             mx1 = max(mx1, __shfl_xor(mx1, m));
         }
+        if (kWaves > 1) {
+            __syncthreads();
+            if (lane == 0) s_mn[wave] = mn1, s_mx[wave] = mx1;
+            __syncthreads();
+            for (int w = 0; w < kWaves; ++w) mn1 = min(mn1, s_mn[w]), mx1 = max(mx1, s_mx[w]);
+        }
         // quirks kept: strict '>' on both sizes and BOTH diversity tests read the first set's ids
         const bool div1 = rank_base1 > 0 && mx1 != mn1;
-        if (lane == 0) {
+        if (tid == 0) {
             const int a1 = (rank_base1 > min_pts && div1) ? 1 : 0;
             const int a2 = (rank_base2 > min_pts && div1) ? 1 : 0;
             slot_acc[2 * l] = a1, slot_cnt[2 * l] = a1 ? rank_base1 : 0;
@@ -807,15 +906,20 @@ __global__ __launch_bounds__(256) void k_leaf_split(const int32_t* __restrict__ 
         }
     }
 }
+size_t split_scratch_bytes(int64_t n) { return (size_t)n * 8 + (size_t)n * sizeof(SplitTask) + 64; }
 void launch_leaf_split(const int32_t* leaf_incl, const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const float4* nglobal,
                        const LevelCounts* counts, int min_pts, int64_t n, float4* nsorted, unsigned long long* pair_best, int32_t* slot_acc,
                        int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s) {
-    hipLaunchKernelGGL(k_split_gather_normals, dim3(grid_for(n, 256)), dim3(256), 0, s, idx_sorted, nglobal, n, nsorted);
+    hipLaunchKernelGGL(k_split_gather_normals, dim3(grid_for(n, 256)), dim3(256), 0, s, idx_sorted, nglobal, ring, n, nsorted);
     (void)hipMemsetAsync(pair_best, 0xFF, (size_t)n * 8, s);
-    hipLaunchKernelGGL(k_split_pairs, dim3((unsigned)((n + 255) / 256), kSplitSlices), dim3(256), 0, s, leaf_incl, leaf_start, slot_acc, nsorted, n, counts,
-                       pair_best);
-    hipLaunchKernelGGL(k_leaf_split, dim3(1024), dim3(256), 0, s, leaf_start, idx_sorted, ring, nglobal, counts, min_pts, pair_best, slot_acc, slot_cnt,
-                       pos_slot_rank);
+    // task list (<= one entry per position) and its counter live behind the n pair_best entries
+    SplitTask* tasks = reinterpret_cast<SplitTask*>(pair_best + n);
+    int32_t* num_tasks = reinterpret_cast<int32_t*>(tasks + n);
+    (void)hipMemsetAsync(num_tasks, 0, sizeof(int32_t), s);
+    hipLaunchKernelGGL(k_split_tasks, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, leaf_incl, leaf_start, slot_acc, n, counts, tasks, num_tasks);
+    hipLaunchKernelGGL(k_split_pairs, dim3(4096), dim3(256), 0, s, leaf_incl, leaf_start, slot_acc, nsorted, n, counts, tasks, num_tasks, pair_best);
+    hipLaunchKernelGGL(k_leaf_split<64>, dim3(4096), dim3(64), 0, s, leaf_start, nsorted, counts, min_pts, pair_best, slot_acc, slot_cnt, pos_slot_rank);
+    hipLaunchKernelGGL(k_leaf_split<1024>, dim3(256), dim3(1024), 0, s, leaf_start, nsorted, counts, min_pts, pair_best, slot_acc, slot_cnt, pos_slot_rank);
 }
 
 // Exclusive prefix sums of (accepted, accepted member count) over the two slots of every leaf.  The leaf count lives on the
