@@ -609,11 +609,13 @@ struct PointSet {
     virtual void setPoseParameters(const std::vector<double>& p) = 0;
     virtual void centralize() = 0;
     virtual void decentralize() = 0;
+    virtual PointSet* clone() const = 0;  // independent copy (parallel evaluation variant of the CPU baseline)
     int64_t numPoints() const { return (int64_t)ids.size(); }
 };
 
 // ContinuousTrajectory.h:24-669 (hot methods only)
 struct WindowModel : PointSet {
+    PointSet* clone() const override { return new WindowModel(*this); }
     ConsecutivePoses controlPoses;
     std::vector<double> stamps, trajTime;
     int n_total = 0;
@@ -777,6 +779,7 @@ struct WindowModel : PointSet {
 
 // MapManagement.h:20-390 (hot methods only)
 struct KeyframeModel : PointSet {
+    PointSet* clone() const override { return new KeyframeModel(*this); }
     ConsecutivePoses keyframePoses;
     int F = 0;
     std::vector<int64_t> frameOffset;
@@ -959,10 +962,29 @@ static void lm_step(const double* e0, const double* J /* col-major rows x P */, 
 // ------------------------------------------------------------------------------------------------
 // DmsaOptimizer (DmsaOptimizer.h:41-364)
 // ------------------------------------------------------------------------------------------------
+// Number of threads for the evaluation-parallel variant of the CPU baseline (orc_set_threads).  1 = the reference's own
+// execution order (it runs every evaluation on one thread, DmsaOptimizer.h:56-57 only caps Eigen's GEMM threads).  With T > 1
+// the P forward differences and the 9 line-search trials run on independent copies of the point set; the LAST evaluation of
+// each batch still runs on the caller's set, so the state the reference leaves behind (quirks q2, q9) is unchanged.  Results are
+// bit-identical to T = 1 unless IMU rows are on: updateImuError carries state from one evaluation to the next, which copies
+// cannot reproduce (differences ~1e-12).  Parity tests always run with T = 1.
+static int g_threads = 1;
+
 struct Optimizer {
     Gaussians currentGauss;
     std::vector<double> Jacobian;  // col-major rows x P
     int evaluations = 0;
+
+    // updateErrorTerms on an arbitrary copy of the set, without touching the optimizer's own state
+    void evalOn(PointSet& set, std::vector<double>& errorVec) const {
+        const int numAdd = set.updateAdditionalErrors();
+        errorVec.resize((size_t)currentGauss.numPointSets + numAdd);
+        eval_residuals(currentGauss, set.globalPoints.data(), errorVec.data());
+        if (numAdd > 0) {
+            const std::vector<double>& add = set.getAdditionalErrorTerms();
+            std::copy(add.begin(), add.begin() + numAdd, errorVec.begin() + currentGauss.numPointSets);
+        }
+    }
 
     // :234-273
     void updateErrorTerms(PointSet& set, std::vector<double>& errorVec) {
@@ -988,7 +1010,28 @@ struct Optimizer {
         Jacobian.assign(rows * P, 0.0);
         const double increment = 1.0 * std::sqrt((double)std::numeric_limits<float>::epsilon());
         const double one_div_incr = 1.0 / increment;
-        for (size_t k = 0; k < P; ++k) {
+        size_t k_serial = 0;
+#ifdef _OPENMP
+        if (g_threads > 1 && P > 1) {
+#pragma omp parallel num_threads(g_threads)
+            {
+                std::unique_ptr<PointSet> mine(set.clone());
+                std::vector<double> lp, ev;
+#pragma omp for schedule(dynamic, 1)
+                for (long k = 0; k < (long)P - 1; ++k) {
+                    lp = origin;
+                    lp[(size_t)k] += increment;
+                    mine->setPoseParameters(lp);
+                    mine->updateGlobalPoints();
+                    evalOn(*mine, ev);
+                    for (size_t r = 0; r < rows; ++r) Jacobian[(size_t)k * rows + r] = one_div_incr * (ev[r] - error0[r]);
+                }
+            }
+            evaluations += (int)P - 1;
+            k_serial = P - 1;
+        }
+#endif
+        for (size_t k = k_serial; k < P; ++k) {
             loop = origin;
             loop[k] += increment;
             set.setPoseParameters(loop);
@@ -1004,12 +1047,38 @@ struct Optimizer {
         int best = 0;
         const std::vector<double> raw = params;
         std::vector<double> errorVec, test(raw.size());
+        double trialError[10] = {0};
+        int k_serial = 1;
+#ifdef _OPENMP
+        if (g_threads > 1) {
+#pragma omp parallel num_threads(g_threads)
+            {
+                std::unique_ptr<PointSet> mine(set.clone());
+                std::vector<double> tp(raw.size()), ev;
+#pragma omp for schedule(dynamic, 1)
+                for (int k = 1; k < 9; ++k) {
+                    for (size_t i = 0; i < raw.size(); ++i) tp[i] = raw[i] + 0.1 * (double)k * step[i];
+                    mine->setPoseParameters(tp);
+                    mine->updateGlobalPoints();
+                    evalOn(*mine, ev);
+                    trialError[k] = dot(ev);
+                }
+            }
+            evaluations += 8;
+            k_serial = 9;
+        }
+#endif
         for (int k = 1; k < 10; ++k) {
             for (size_t i = 0; i < raw.size(); ++i) test[i] = raw[i] + 0.1 * (double)k * step[i];
-            set.setPoseParameters(test);
-            set.updateGlobalPoints();
-            updateErrorTerms(set, errorVec);
-            const double errorTest = dot(errorVec);
+            double errorTest;
+            if (k >= k_serial) {
+                set.setPoseParameters(test);
+                set.updateGlobalPoints();
+                updateErrorTerms(set, errorVec);
+                errorTest = dot(errorVec);
+            } else {
+                errorTest = trialError[k];
+            }
             if (errorTest < minError) params = test, minError = errorTest, best = k;
         }
         return best;
@@ -1105,6 +1174,9 @@ struct orc_gaussians {
 };
 
 extern "C" {
+
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_get_threads(void) { return g_threads; }
 
 void orc_axang2rotm(const double* w, double* R9) {
     const M3 R = axang2rotm(w);

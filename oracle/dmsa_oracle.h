@@ -68,6 +68,10 @@ typedef struct orc_iter_trace {
 } orc_iter_trace;
 /* global_out (optional): (N+S) x 4 floats after the final updateGlobalPoints; trace (optional): capacity entries.
  * fixed_iters != 0 disables the no-improvement / epsilon exits (benchmarking, mirrors DMSA_FLAG_FIXED_ITERS). */
+/* evaluation-parallel variant of the CPU baseline (OpenMP over the P forward differences / 9 line-search trials; without IMU rows
+ * results are bit-identical to 1 thread).  Default 1 = the reference's execution order. */
+void orc_set_threads(int n);
+int orc_get_threads(void);
 int orc_optimize_window(dmsa_window_problem* p, const dmsa_settings* s, dmsa_report* rep, float* global_out,
                         orc_iter_trace* trace, int32_t trace_capacity, int32_t fixed_iters);
 int orc_optimize_keyframes(dmsa_keyframe_problem* p, const dmsa_settings* s, dmsa_report* rep, float* global_out,

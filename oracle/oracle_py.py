@@ -205,6 +205,14 @@ def _run(fn, prob, settings, fixed_iters, want_global, npts):
     return rep, gl, tr
 
 
+def set_threads(n: int) -> None:
+    """Evaluation-parallel variant of the CPU baseline (OpenMP over the forward differences / line-search trials; without IMU rows
+    results are bit-identical to one thread).  1 = the reference's own execution order."""
+    L = lib()
+    L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_set_threads(int(n))
+
+
 def optimize_window(prob: ContinuousTrajectory, settings: DmsaOptimSettings, fixed_iters=False, want_global=False):
     """Runs optimizeSet on `prob` IN PLACE (relOrientations / relTranslations are updated)."""
     n = prob.localPoints.shape[0] + prob.staticPoints.shape[0]

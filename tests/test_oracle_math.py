@@ -167,3 +167,33 @@ def test_lm_step_vs_numpy(orc):
     assert np.abs(g - J.T @ e0).max() / np.abs(g).max() < 1e-13
     ref = -0.2 * np.linalg.solve(Href, J.T @ e0)
     assert np.abs(step - ref).max() / np.abs(ref).max() < 1e-8
+
+
+def test_parallel_baseline_variant(orc):
+    """orc_set_threads(T): the evaluation-parallel CPU baseline.  Without IMU rows every evaluation is a pure function of its
+    parameters, so poses, trace and evaluation count equal the single-threaded (reference-order) run bit for bit.  With IMU rows
+    the reference carries state from one evaluation to the next (updateImuError's global2relative round trip,
+    ContinuousTrajectory.h:603-663), which copies of the set cannot reproduce: equal to ~1e-12 only."""
+    from dmsa_lidar_slam_amd import synth
+    from dmsa_lidar_slam_amd.problems import DmsaOptimSettings
+
+    cases = [(synth.window_problem(seed=5, scans=2, rings=24, az_steps=128, num_static=3000), DmsaOptimSettings.sliding_window(num_iter=3), orc.optimize_window, True),
+             (synth.keyframe_problem(seed=5, frames=5, rings=16, az_steps=96, arc=0.3), DmsaOptimSettings.keyframe_map(num_iter=2), orc.optimize_keyframes, True),
+             (synth.window_problem(seed=5, scans=2, rings=24, az_steps=128, num_static=3000, use_imu=True), DmsaOptimSettings.sliding_window(use_imu=True, num_iter=3), orc.optimize_window, False)]
+    for prob, s, fn, exact in cases:
+        a, b = prob.copy(), prob.copy()
+        try:
+            orc.set_threads(1)
+            rep_a, gl_a, tr_a = fn(a, s, want_global=True)
+            orc.set_threads(4)
+            rep_b, gl_b, tr_b = fn(b, s, want_global=True)
+        finally:
+            orc.set_threads(1)
+        assert (rep_a.iterations, rep_a.stop_reason, rep_a.evaluations) == (rep_b.iterations, rep_b.stop_reason, rep_b.evaluations)
+        if exact:
+            assert tr_a == tr_b
+            assert np.array_equal(a.relOrientations, b.relOrientations) and np.array_equal(a.relTranslations, b.relTranslations)
+            assert np.array_equal(gl_a, gl_b)
+        else:
+            assert [(t["M"], t["Mm"], t["best_k"]) for t in tr_a] == [(t["M"], t["Mm"], t["best_k"]) for t in tr_b]
+            assert np.abs(a.relOrientations - b.relOrientations).max() < 1e-9 and np.abs(a.relTranslations - b.relTranslations).max() < 1e-9
