@@ -105,6 +105,31 @@ class KeyframeProblem(C.Structure):
     ]
 
 
+class StaticSelectProblem(C.Structure):  # dmsa_static_points.h
+    _fields_ = [
+        ("num_window", C.c_int64),
+        ("window_xyz", c_float_p),
+        ("num_keyframes", C.c_int32),
+        ("keyframe_ids", c_int32_p),
+        ("frame_offset", c_int64_p),
+        ("key_xyz", c_float_p),
+        ("key_normal", c_float_p),
+        ("key_ring", c_int32_p),
+        ("cur_pos", C.c_float * 3),
+        ("min_grid_size", C.c_float),
+    ]
+
+
+class StaticSelectResult(C.Structure):
+    _fields_ = [
+        ("num_static", C.c_int64),
+        ("keyframe_id", C.c_int32),
+        ("min_related_key_id", C.c_int32),
+        ("max_overlap", C.c_int32),
+        ("pad", C.c_int32),
+    ]
+
+
 class Report(C.Structure):
     _fields_ = [
         ("iterations", C.c_int32),
@@ -209,6 +234,11 @@ def load_library() -> C.CDLL:
         "dmsa_get_timing": (C.c_int, [vp, C.POINTER(Timing), C.c_int32]),
         "dmsa_synchronize": (C.c_int, [vp]),
         "dmsa_get_trace": (C.c_int, [vp, C.POINTER(IterTrace), C.c_int32]),
+        # include/dmsa_static_points.h
+        "dmsa_select_static_points": (C.c_int, [vp, C.POINTER(StaticSelectProblem), c_float_p, c_int32_p, C.c_int64, c_int32_p, C.POINTER(StaticSelectResult)]),
+        "dmsa_get_overlap": (C.c_int, [vp, c_float_p, C.c_int64, c_float_p, C.c_int64, C.c_float, c_float_p, c_int64_p]),
+        "dmsa_random_grid_downsampling": (C.c_int, [vp, c_float_p, C.c_int64, C.c_float, C.c_uint32, c_int32_p, C.c_int64, c_int64_p]),
+        "dmsa_radius_exists": (C.c_int, [vp, c_float_p, C.c_int64, c_float_p, C.c_int64, C.c_float, C.POINTER(C.c_uint8)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -222,5 +252,6 @@ EXPORTED_SYMBOLS = (
     "dmsa_create dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
     "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
     "dmsa_set_params dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
-    "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_optimize_resident dmsa_get_poses"
+    "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_optimize_resident dmsa_get_poses "
+    "dmsa_select_static_points dmsa_get_overlap dmsa_random_grid_downsampling dmsa_radius_exists"
 ).split()

@@ -18,9 +18,11 @@
 #include <vector>
 
 #include "../../include/dmsa_hip.h"
+#include "../../include/dmsa_static_points.h"
 #include "device_prims.h"
 #include "dmsa_kernels.h"
 #include "host_math.h"
+#include "static_kernels.h"
 
 using namespace dmsa;
 
@@ -53,6 +55,19 @@ enum TimerSlot { T_RESIDUAL = 0, T_VOXEL, T_FIT, T_TABLE, T_NORMAL, T_TOTAL, T_C
 struct EventPair {
     hipEvent_t a, b;
     int slot;
+};
+
+// scratch of the static-point functions (include/dmsa_static_points.h); allocated on first use, independent of the resident problem
+struct StaticState {
+    DevBuf cloud, query, normal, ring, code, idx, code_s, idx_s, pts_sorted, table, flags, sel, scan, sort_tmp, scan_tmp, out_xyz, out_id, offsets, small,
+        aabb, lattice, head, incl, leaf_start, counts, rnd, pick;
+    DevBuf* all[27] = {&cloud, &query, &normal, &ring, &code, &idx, &code_s, &idx_s, &pts_sorted, &table, &flags, &sel, &scan, &sort_tmp, &scan_tmp, &out_xyz,
+                       &out_id, &offsets, &small, &aabb, &lattice, &head, &incl, &leaf_start, &counts, &rnd, &pick};
+    // the cell grid currently built over `cloud`
+    CellGrid grid{};
+    int64_t n_cloud = 0;
+    bool key32 = false;
+    uint32_t table_mask = 0;
 };
 
 }  // namespace
@@ -115,6 +130,7 @@ struct dmsa_ctx {
     double residual_bytes = 0.0, residual_unit_bytes = 0.0;
     int evaluations = 0;
     std::vector<dmsa_iter_trace> trace;
+    StaticState* sp = nullptr;
 };
 
 namespace {
@@ -777,6 +793,10 @@ void dmsa_destroy(dmsa_ctx* ctx) {
                       &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_memb_g, &ctx->d_seg_off,
                       &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_counts, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
     for (DevBuf* b : bufs) b->release();
+    if (ctx->sp) {
+        for (DevBuf* b : ctx->sp->all) b->release();
+        delete ctx->sp;
+    }
     for (int l = 0; l < 2; ++l)
         for (DevBuf* b : {&ctx->d_head[l], &ctx->d_slot_acc[l], &ctx->d_slot_cnt[l], &ctx->d_gauss_of_slot[l], &ctx->d_memb_of_slot[l], &ctx->d_pos_slot_rank[l],
                           &ctx->d_nsorted[l], &ctx->d_pair_d[l], &ctx->d_pair_c[l], &ctx->d_sort_tmp[l], &ctx->d_scan_tmp[l]})
@@ -1186,6 +1206,254 @@ int dmsa_optimize_keyframes(dmsa_ctx* ctx, dmsa_keyframe_problem* p, const dmsa_
     CHK(dmsa_keyframes_upload(ctx, p));
     CHK(optimize(ctx, *s, rep));
     write_back_poses(ctx->key.frames, p->rel_orient, p->rel_transl);
+    return DMSA_OK;
+}
+
+}  // extern "C"
+
+// ---- include/dmsa_static_points.h ---------------------------------------------------------------------------------------
+namespace {
+
+StaticState* sp_state(dmsa_ctx* ctx) {
+    if (!ctx->sp) ctx->sp = new (std::nothrow) StaticState();
+    return ctx->sp;
+}
+
+// Uniform cell grid over `n` host points (cells of 1.001 * radius): bounds -> [sync] -> codes -> radix sort -> sorted copies + hash of
+// the occupied cells.  Leaves the grid in sp->grid / table / pts_sorted / code_s.
+int sp_build_grid(dmsa_ctx* ctx, const float* cloud_xyz, int64_t n, float radius) {
+    StaticState* sp = sp_state(ctx);
+    if (!sp) return DMSA_ERR_NOMEM;
+    if (!(radius > 0.0f) || n < 0 || n > (int64_t)0x7FFFFFF0 || (n > 0 && !cloud_xyz)) return DMSA_ERR_INVALID;
+    sp->n_cloud = n;
+    if (n == 0) return DMSA_OK;
+    HIPCHK(sp->cloud.ensure((size_t)n * 16));
+    HIPCHK(sp->small.ensure(256));
+    HIPCHK(hipMemcpyAsync(sp->cloud.p, cloud_xyz, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    CloudBounds* d_b = sp->small.as<CloudBounds>();
+    launch_cloud_bounds_init(d_b, ctx->stream);
+    launch_cloud_bounds(sp->cloud.as<float4>(), n, d_b, ctx->stream);
+    CloudBounds hb{};
+    HIPCHK(hipMemcpyAsync(&hb, d_b, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(sync_spin(ctx->stream));
+    CellGrid g{};
+    g.inv = 1.0 / (1.001 * (double)radius);
+    g.nx = g.ny = g.nz = 1;
+    if (hb.num_finite > 0) {
+        int64_t* dims[3] = {&g.nx, &g.ny, &g.nz};
+        for (int a = 0; a < 3; ++a) {
+            g.lo[a] = (double)ordered_to_float(hb.lo[a]);
+            const double ext = ((double)ordered_to_float(hb.hi[a]) - g.lo[a]) * g.inv;
+            if (!(ext < 2097150.0)) return DMSA_ERR_DEPTH;  // more than 2^21 cells along an axis
+            *dims[a] = (int64_t)std::floor(ext) + 1;
+        }
+    }
+    sp->grid = g;
+    const double cells = (double)g.nx * (double)g.ny * (double)g.nz;
+    unsigned bits = 1;
+    while (bits < 63 && std::ldexp(1.0, (int)bits) < cells) ++bits;
+    sp->key32 = bits < 32;  // the invalid marker ~0 needs one more value than the largest code
+    const unsigned end_bit = sp->key32 ? 32u : 64u;
+    HIPCHK(sp->code.ensure((size_t)n * 8));
+    HIPCHK(sp->idx.ensure((size_t)n * 4));
+    HIPCHK(sp->code_s.ensure((size_t)n * 8));
+    HIPCHK(sp->idx_s.ensure((size_t)n * 4));
+    HIPCHK(sp->pts_sorted.ensure((size_t)n * 16));
+    HIPCHK(sp->sort_tmp.ensure(sort_pairs_temp_bytes((size_t)n)));
+    size_t cap = 1024;
+    while (cap < 2 * (size_t)n) cap <<= 1;
+    sp->table_mask = (uint32_t)(cap - 1);
+    HIPCHK(sp->table.ensure(cap * sizeof(CellHashEntry)));
+    HIPCHK(hipMemsetAsync(sp->table.p, 0xFF, cap * sizeof(CellHashEntry), ctx->stream));
+    if (sp->key32) {
+        launch_cell_codes32(sp->cloud.as<float4>(), n, g, sp->code.as<uint32_t>(), sp->idx.as<uint32_t>(), ctx->stream);
+        // sort on the bits that can differ; the all-ones marker of non-finite points has every bit set, so it still sorts last
+        HIPCHK(sort_pairs_u32_u32(sp->sort_tmp.p, sp->sort_tmp.cap, sp->code.as<uint32_t>(), sp->code_s.as<uint32_t>(), sp->idx.as<uint32_t>(),
+                                  sp->idx_s.as<uint32_t>(), (size_t)n, std::min(end_bit, bits + 1), ctx->stream));
+    } else {
+        launch_cell_codes(sp->cloud.as<float4>(), n, g, sp->code.as<uint64_t>(), sp->idx.as<uint32_t>(), ctx->stream);
+        HIPCHK(sort_pairs_u64_u32(sp->sort_tmp.p, sp->sort_tmp.cap, sp->code.as<uint64_t>(), sp->code_s.as<uint64_t>(), sp->idx.as<uint32_t>(),
+                                  sp->idx_s.as<uint32_t>(), (size_t)n, std::min(end_bit, bits + 1), ctx->stream));
+    }
+    launch_cell_table(sp->cloud.as<float4>(), sp->idx_s.as<uint32_t>(), sp->code_s.p, sp->key32, n, sp->pts_sorted.as<float4>(), sp->table.as<CellHashEntry>(),
+                      sp->table_mask, ctx->stream);
+    HIPCHK(hipGetLastError());
+    return DMSA_OK;
+}
+
+// flags (device, sp->flags) of `nq` host queries against the grid built last
+int sp_query(dmsa_ctx* ctx, const float* query_xyz, int64_t nq, float r2) {
+    StaticState* sp = ctx->sp;
+    if (nq <= 0) return DMSA_OK;
+    HIPCHK(sp->query.ensure((size_t)nq * 16));
+    HIPCHK(sp->flags.ensure((size_t)nq));
+    HIPCHK(hipMemcpyAsync(sp->query.p, query_xyz, (size_t)nq * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (sp->n_cloud == 0) {
+        HIPCHK(hipMemsetAsync(sp->flags.p, 0, (size_t)nq, ctx->stream));
+        return DMSA_OK;
+    }
+    launch_radius_exists(sp->query.as<float4>(), nq, sp->grid, sp->pts_sorted.as<float4>(), sp->code_s.p, sp->key32, sp->n_cloud, sp->table.as<CellHashEntry>(),
+                         sp->table_mask, r2, sp->flags.as<uint8_t>(), ctx->stream);
+    HIPCHK(hipGetLastError());
+    return DMSA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmsa_radius_exists(dmsa_ctx* ctx, const float* cloud_xyz, int64_t n_cloud, const float* query_xyz, int64_t n_query, float radius, uint8_t* flag_out) {
+    if (!ctx || n_query < 0 || (n_query > 0 && (!query_xyz || !flag_out))) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    CHK(sp_build_grid(ctx, cloud_xyz, n_cloud, radius));
+    CHK(sp_query(ctx, query_xyz, n_query, radius * radius));
+    if (n_query > 0) HIPCHK(hipMemcpyAsync(flag_out, ctx->sp->flags.p, (size_t)n_query, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return DMSA_OK;
+}
+
+int dmsa_select_static_points(dmsa_ctx* ctx, const dmsa_static_select_problem* p, float* static_xyz_out, int32_t* static_id_out, int64_t capacity,
+                              int32_t* overlap_per_keyframe, dmsa_static_select_result* res) {
+    if (!ctx || !p || !res || p->num_keyframes < 0 || p->num_window < 0 || (p->num_keyframes > 0 && (!p->frame_offset || !p->keyframe_ids))) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    const int K = p->num_keyframes;
+    const int64_t n = K > 0 ? p->frame_offset[K] : 0;
+    *res = dmsa_static_select_result{};
+    res->min_related_key_id = -1;
+    if (n > 0 && (!p->key_xyz || !p->key_normal || !p->key_ring)) return DMSA_ERR_INVALID;
+    if (n > (int64_t)0x7FFFFFF0) return DMSA_ERR_INVALID;
+    std::vector<int32_t> at((size_t)K + 1, 0);
+    if (n > 0) {
+        // std::pow(1.0f * minGridSize, 2): float argument, integer exponent -> double -> back to float (DmsaSlam.h:295)
+        const float sqrdMaxDist = (float)std::pow((double)(1.0f * p->min_grid_size), 2);
+        CHK(sp_build_grid(ctx, p->window_xyz, p->num_window, p->min_grid_size));
+        CHK(sp_query(ctx, p->key_xyz, n, sqrdMaxDist));
+        StaticState* sp = ctx->sp;
+        HIPCHK(sp->normal.ensure((size_t)n * 16));
+        HIPCHK(sp->ring.ensure((size_t)n * 4));
+        HIPCHK(sp->sel.ensure((size_t)n * 4));
+        HIPCHK(sp->scan.ensure((size_t)n * 4));
+        HIPCHK(sp->scan_tmp.ensure(scan_temp_bytes((size_t)n)));
+        HIPCHK(sp->out_xyz.ensure((size_t)n * 16));
+        HIPCHK(sp->out_id.ensure((size_t)n * 4));
+        HIPCHK(sp->offsets.ensure(((size_t)K + 1) * 8 + ((size_t)K + 1) * 4));
+        HIPCHK(hipMemcpyAsync(sp->normal.p, p->key_normal, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(sp->ring.p, p->key_ring, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(sp->offsets.p, p->frame_offset, ((size_t)K + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        launch_static_flags(sp->query.as<float4>(), sp->normal.as<float4>(), sp->flags.as<uint8_t>(), n, p->cur_pos[0], p->cur_pos[1], p->cur_pos[2],
+                            sp->sel.as<int32_t>(), ctx->stream);
+        HIPCHK(exclusive_scan_i32(sp->scan_tmp.p, sp->scan_tmp.cap, sp->sel.as<int32_t>(), sp->scan.as<int32_t>(), (size_t)n, ctx->stream));
+        launch_static_scatter(sp->query.as<float4>(), sp->ring.as<int32_t>(), sp->sel.as<int32_t>(), sp->scan.as<int32_t>(), n, sp->out_xyz.as<float4>(),
+                              sp->out_id.as<int32_t>(), ctx->stream);
+        int32_t* d_at = reinterpret_cast<int32_t*>(sp->offsets.as<int64_t>() + (K + 1));
+        launch_pick_offsets(sp->scan.as<int32_t>(), sp->sel.as<int32_t>(), sp->offsets.as<int64_t>(), K, n, d_at, ctx->stream);
+        HIPCHK(hipMemcpyAsync(at.data(), d_at, ((size_t)K + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    // per-keyframe bookkeeping of the loop (:270-274, :333-342): the running maximum is tested after every point, so a later
+    // keyframe only takes over when its count EXCEEDS the best so far
+    int keyframeId = 0, maxOverlapKey = 0, minRelatedKeyId = -1;
+    for (int kk = 0; kk < K; ++kk) {
+        const int k = p->keyframe_ids[kk], currOverlap = at[(size_t)kk + 1] - at[(size_t)kk];
+        if (overlap_per_keyframe) overlap_per_keyframe[kk] = currOverlap;
+        if (currOverlap > 0 && (minRelatedKeyId < 0 || k < minRelatedKeyId)) minRelatedKeyId = k;
+        if (currOverlap > maxOverlapKey) maxOverlapKey = currOverlap, keyframeId = k;
+    }
+    const int64_t total = at[(size_t)K];
+    res->num_static = total, res->keyframe_id = keyframeId, res->min_related_key_id = minRelatedKeyId, res->max_overlap = maxOverlapKey;
+    if (total > capacity) return DMSA_ERR_INVALID;
+    if (total > 0) {
+        if (static_xyz_out) HIPCHK(hipMemcpy(static_xyz_out, ctx->sp->out_xyz.p, (size_t)total * 16, hipMemcpyDeviceToHost));
+        if (static_id_out) HIPCHK(hipMemcpy(static_id_out, ctx->sp->out_id.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    }
+    return DMSA_OK;
+}
+
+int dmsa_get_overlap(dmsa_ctx* ctx, const float* pc1_xyz, int64_t n1, const float* pc2_xyz, int64_t n2, float max_dist_overlap, float* overlap_out,
+                     int64_t* num_corresp_out) {
+    if (!ctx || n1 < 0 || n2 < 0) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    unsigned long long nCorresp = 0;
+    float overlap = 0.0f;
+    if (n1 > 0 && n2 > 0) {  // :380-381
+        CHK(sp_build_grid(ctx, pc1_xyz, n1, max_dist_overlap));
+        CHK(sp_query(ctx, pc2_xyz, n2, max_dist_overlap * max_dist_overlap));
+        StaticState* sp = ctx->sp;
+        unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(sp->small.as<char>() + 128);
+        launch_count_flags(sp->flags.as<uint8_t>(), n2, d_cnt, ctx->stream);
+        HIPCHK(hipMemcpyAsync(&nCorresp, d_cnt, sizeof(nCorresp), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        overlap = static_cast<float>((int)nCorresp) / static_cast<float>(n2);  // :412
+    }
+    if (overlap_out) *overlap_out = overlap;
+    if (num_corresp_out) *num_corresp_out = (int64_t)nCorresp;
+    return DMSA_OK;
+}
+
+int dmsa_random_grid_downsampling(dmsa_ctx* ctx, const float* xyz, int64_t n, float grid_size, uint32_t seed, int32_t* picked_index_out, int64_t capacity,
+                                  int64_t* num_out) {
+    if (!ctx || n < 0 || (n > 0 && !xyz) || !(grid_size > 0.0f) || n > (int64_t)0x7FFFFFF0) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    if (num_out) *num_out = 0;
+    if (n == 0) return DMSA_OK;
+    StaticState* sp = sp_state(ctx);
+    if (!sp) return DMSA_ERR_NOMEM;
+    const double res = (double)grid_size;  // OctreePointCloud(gridSize): float -> double resolution
+    const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
+    HIPCHK(sp->cloud.ensure((size_t)n * 16));
+    HIPCHK(sp->aabb.ensure((size_t)nb * 8 * sizeof(float)));
+    HIPCHK(sp->lattice.ensure(2 * sizeof(LatticeTable)));
+    HIPCHK(sp->code.ensure((size_t)n * 8));
+    HIPCHK(sp->idx.ensure((size_t)n * 4));
+    HIPCHK(sp->code_s.ensure((size_t)n * 8));
+    HIPCHK(sp->idx_s.ensure((size_t)n * 4));
+    HIPCHK(sp->head.ensure((size_t)n * 4));
+    HIPCHK(sp->incl.ensure((size_t)n * 4));
+    HIPCHK(sp->leaf_start.ensure(((size_t)n + 1) * 4));
+    HIPCHK(sp->sort_tmp.ensure(sort_pairs_temp_bytes((size_t)n)));
+    HIPCHK(sp->scan_tmp.ensure(scan_temp_bytes((size_t)n)));
+    HIPCHK(sp->counts.ensure(sizeof(GaussCounts)));
+    HIPCHK(hipMemcpyAsync(sp->cloud.p, xyz, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(sp->counts.p, 0, sizeof(GaussCounts), ctx->stream));
+    // the same PCL-exact lattice / key / leaf machinery as createGaussianSets (DmsaOptimizer.h:282-298)
+    launch_block_aabb(sp->cloud.as<float4>(), n, sp->aabb.as<float>(), ctx->stream);
+    launch_lattice(sp->cloud.as<float4>(), n, sp->aabb.as<float>(), nb, res, res, false, sp->lattice.as<LatticeTable>(), ctx->stream);
+    LatticeTable lat[2];
+    HIPCHK(hipMemcpyAsync(lat, sp->lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(sync_spin(ctx->stream));
+    if (lat[0].status != 0) return lat[0].status;
+    if (!lat[0].defined) return DMSA_OK;  // no finite point: empty octree
+    const unsigned end_bit = (unsigned)(3 * lat[0].final_depth + 1);
+    const bool k32 = end_bit <= 32;
+    LatticeTable* tab = sp->lattice.as<LatticeTable>();
+    GaussCounts* counts = sp->counts.as<GaussCounts>();
+    launch_voxel_keys(sp->cloud.as<float4>(), n, tab, res, sp->code.p, k32, sp->idx.as<uint32_t>(), ctx->stream);
+    if (k32)
+        HIPCHK(sort_pairs_u32_u32(sp->sort_tmp.p, sp->sort_tmp.cap, sp->code.as<uint32_t>(), sp->code_s.as<uint32_t>(), sp->idx.as<uint32_t>(),
+                                  sp->idx_s.as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
+    else
+        HIPCHK(sort_pairs_u64_u32(sp->sort_tmp.p, sp->sort_tmp.cap, sp->code.as<uint64_t>(), sp->code_s.as<uint64_t>(), sp->idx.as<uint32_t>(),
+                                  sp->idx_s.as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
+    launch_head_flags(sp->code_s.p, k32, n, tab, sp->head.as<int32_t>(), ctx->stream);
+    HIPCHK(inclusive_scan_i32(sp->scan_tmp.p, sp->scan_tmp.cap, sp->head.as<int32_t>(), sp->incl.as<int32_t>(), (size_t)n, ctx->stream));
+    launch_leaf_starts(sp->head.as<int32_t>(), sp->incl.as<int32_t>(), sp->code_s.p, k32, tab, n, sp->leaf_start.as<int32_t>(), &counts->level[0], ctx->stream);
+    GaussCounts hc{};
+    HIPCHK(hipMemcpyAsync(&hc, counts, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(sync_spin(ctx->stream));
+    const int64_t leaves = hc.level[0].num_leaves;  // octree.getLeafCount()
+    if (num_out) *num_out = leaves;
+    if (leaves > capacity) return DMSA_ERR_INVALID;
+    if (leaves == 0 || !picked_index_out) return DMSA_OK;
+    // srand(seed); one rand() per leaf in depth-first order (helpers.h:86-94) -- the generator is sequential, so the draws are made
+    // on the host (O(leaves)) and only the pick runs on the device
+    std::vector<int32_t> rnd((size_t)leaves);
+    glibc_rand_fill(seed, rnd.data(), (size_t)leaves);
+    HIPCHK(sp->rnd.ensure((size_t)leaves * 4));
+    HIPCHK(sp->pick.ensure((size_t)leaves * 4));
+    HIPCHK(hipMemcpyAsync(sp->rnd.p, rnd.data(), (size_t)leaves * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_leaf_pick(sp->leaf_start.as<int32_t>(), sp->idx_s.as<uint32_t>(), sp->rnd.as<int32_t>(), (int)leaves, sp->pick.as<int32_t>(), ctx->stream);
+    HIPCHK(hipMemcpyAsync(picked_index_out, sp->pick.p, (size_t)leaves * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return DMSA_OK;
 }
 

@@ -414,4 +414,25 @@ void lm_solve_lu(const double* Hin, const double* g, int P, double alpha, double
     for (int i = 0; i < P; ++i) step[i] = -alpha * step[i];
 }
 
+void glibc_rand_fill(uint32_t seed, int32_t* out, size_t count) {
+    int32_t r[31];
+    if (seed == 0) seed = 1;
+    r[0] = (int32_t)seed;
+    for (int i = 1; i < 31; ++i) {
+        const long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+        long word = 16807 * lo - 2836 * hi;
+        if (word < 0) word += 2147483647;
+        r[i] = (int32_t)word;
+    }
+    int f = 3, b = 0;
+    auto next = [&]() {
+        const uint32_t v = (uint32_t)r[f] + (uint32_t)r[b];
+        r[f] = (int32_t)v;
+        f = (f + 1) % 31, b = (b + 1) % 31;
+        return (int32_t)(v >> 1);
+    };
+    for (int i = 0; i < 310; ++i) (void)next();
+    for (size_t i = 0; i < count; ++i) out[i] = next();
+}
+
 }  // namespace dmsa

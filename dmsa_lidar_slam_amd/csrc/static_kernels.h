@@ -1,0 +1,62 @@
+// static_kernels.h — launchers of the kernels behind include/dmsa_static_points.h:
+// "is there a cloud point within a radius" on a uniform cell grid in HBM, the selection / compaction of
+// DmsaSlam::addStaticPoints (DmsaSlam.h:300-344) and the leaf pick of randomGridDownsampling (helpers.h:67-182).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace dmsa {
+
+// bounds of the finite points of a cloud, as order-preserving unsigned images of the floats (atomicMin / atomicMax)
+struct CloudBounds {
+    uint32_t lo[3], hi[3];
+    uint32_t num_finite;
+    uint32_t pad;
+};
+__host__ __device__ inline uint32_t float_to_ordered(float f) {
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    return (v.u & 0x80000000u) ? ~v.u : (v.u | 0x80000000u);
+}
+__host__ __device__ inline float ordered_to_float(uint32_t o) {
+    union { float f; uint32_t u; } v;
+    v.u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return v.f;
+}
+
+// cell grid: cell (ix,iy,iz) = floor((p - lo) * inv) per axis in double, linear code ix + nx*(iy + ny*iz)
+struct CellGrid {
+    double lo[3];
+    double inv;          // 1 / (1.001 * radius): every point within the radius lies in the 27 cells around the query's cell
+    int64_t nx, ny, nz;  // cells per axis
+};
+struct CellHashEntry {
+    uint64_t key;        // linear cell code, ~0 = empty
+    uint32_t start;      // first sorted position of the cell
+    uint32_t pad;
+};
+
+void launch_cloud_bounds_init(CloudBounds* b, hipStream_t s);
+void launch_cloud_bounds(const float4* pts, int64_t n, CloudBounds* b, hipStream_t s);
+// codes (invalid marker = ~0 for non-finite points) + identity index
+void launch_cell_codes(const float4* pts, int64_t n, CellGrid g, uint64_t* code, uint32_t* idx, hipStream_t s);
+void launch_cell_codes32(const float4* pts, int64_t n, CellGrid g, uint32_t* code, uint32_t* idx, hipStream_t s);
+// sorted point copies + hash of the cell heads; `code_sorted` is u32 or u64 (key32)
+void launch_cell_table(const float4* pts, const uint32_t* idx_sorted, const void* code_sorted, bool key32, int64_t n, float4* pts_sorted,
+                       CellHashEntry* table, uint32_t table_mask, hipStream_t s);
+// flag[i] = 1 iff some cloud point has ((dx*dx + dy*dy) + dz*dz) <= r2 (float) to query i
+void launch_radius_exists(const float4* query, int64_t nq, CellGrid g, const float4* pts_sorted, const void* code_sorted, bool key32, int64_t n,
+                          const CellHashEntry* table, uint32_t table_mask, float r2, uint8_t* flag, hipStream_t s);
+// DmsaSlam.h:318-336: selected = within && isVisible(currPos, point) -> int flags for the scan
+void launch_static_flags(const float4* key_xyz, const float4* key_normal, const uint8_t* within, int64_t n, float px, float py, float pz, int32_t* sel,
+                         hipStream_t s);
+// stable compaction: out[scan[i]] = point i (w = 1) / ring id
+void launch_static_scatter(const float4* key_xyz, const int32_t* key_ring, const int32_t* sel, const int32_t* scan_excl, int64_t n, float4* out_xyz,
+                           int32_t* out_id, hipStream_t s);
+// out[k] = scan_excl[offset[k]] for k <= K (offset[K] == n reads the total = scan_excl[n-1] + sel[n-1])
+void launch_pick_offsets(const int32_t* scan_excl, const int32_t* sel, const int64_t* offsets, int K, int64_t n, int32_t* out, hipStream_t s);
+void launch_count_flags(const uint8_t* flag, int64_t n, unsigned long long* count, hipStream_t s);
+// helpers.h:93-101: out[l] = idx_sorted[start_l + int((double)rnd[l] / RAND_MAX * (double)(cnt_l - 1))]
+void launch_leaf_pick(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* rnd, int num_leaves, int32_t* out, hipStream_t s);
+
+}  // namespace dmsa

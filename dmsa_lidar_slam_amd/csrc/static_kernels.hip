@@ -1,0 +1,253 @@
+// static_kernels.hip — see static_kernels.h.  Compiled with -ffp-contract=off: the float distance
+// ((dx*dx + dy*dy) + dz*dz) and the visibility residual must round like the reference's scalar code.
+#include "static_kernels.h"
+
+#include <cfloat>
+#include <climits>
+
+namespace dmsa {
+namespace {
+constexpr int kBlock = 256;
+inline unsigned grid_for(int64_t n, int block = kBlock, int64_t cap = 1 << 20) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+__device__ __forceinline__ bool finite3(const float4 p) { return isfinite(p.x) && isfinite(p.y) && isfinite(p.z); }
+__device__ __forceinline__ uint64_t hash_cell(uint64_t key) {
+    key *= 0x9E3779B97F4A7C15ull;
+    return key ^ (key >> 29);
+}
+__device__ __forceinline__ bool cell_of(const float4 p, const CellGrid& g, int64_t& ix, int64_t& iy, int64_t& iz) {
+    if (!finite3(p)) return false;
+    const double vx = ((double)p.x - g.lo[0]) * g.inv, vy = ((double)p.y - g.lo[1]) * g.inv, vz = ((double)p.z - g.lo[2]) * g.inv;
+    // more than one cell outside the grid: no cell of the cloud can be a neighbour (also keeps the casts in range)
+    if (!(vx > -2.0 && vy > -2.0 && vz > -2.0 && vx < (double)g.nx + 2.0 && vy < (double)g.ny + 2.0 && vz < (double)g.nz + 2.0)) return false;
+    ix = (int64_t)floor(vx), iy = (int64_t)floor(vy), iz = (int64_t)floor(vz);
+    return true;
+}
+}  // namespace
+
+__global__ void k_cloud_bounds_init(CloudBounds* b) {
+    if (threadIdx.x < 3) b->lo[threadIdx.x] = 0xFFFFFFFFu, b->hi[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) b->num_finite = 0u, b->pad = 0u;
+}
+__global__ __launch_bounds__(kBlock) void k_cloud_bounds(const float4* __restrict__ pts, int64_t n, CloudBounds* __restrict__ b) {
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u}, cnt = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 p = pts[i];
+        if (!finite3(p)) continue;
+        const uint32_t o[3] = {float_to_ordered(p.x), float_to_ordered(p.y), float_to_ordered(p.z)};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) lo[a] = min(lo[a], o[a]), hi[a] = max(hi[a], o[a]);
+        ++cnt;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], m)), hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], m));
+        cnt += (uint32_t)__shfl_xor((int)cnt, m);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt > 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) atomicMin(&b->lo[a], lo[a]), atomicMax(&b->hi[a], hi[a]);
+        atomicAdd(&b->num_finite, cnt);
+    }
+}
+void launch_cloud_bounds_init(CloudBounds* b, hipStream_t s) { hipLaunchKernelGGL(k_cloud_bounds_init, dim3(1), dim3(64), 0, s, b); }
+void launch_cloud_bounds(const float4* pts, int64_t n, CloudBounds* b, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_cloud_bounds, dim3(grid_for(n, kBlock, 2048)), dim3(kBlock), 0, s, pts, n, b);
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_cell_codes(const float4* __restrict__ pts, int64_t n, CellGrid g, KeyT* __restrict__ code,
+                                                       uint32_t* __restrict__ idx) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int64_t ix, iy, iz;
+        KeyT c = (KeyT)~(KeyT)0;
+        if (cell_of(pts[i], g, ix, iy, iz)) {
+            // the grid was sized from the bounds of the same points: clamp only guards the last ulp of the division
+            ix = min(max(ix, (int64_t)0), g.nx - 1), iy = min(max(iy, (int64_t)0), g.ny - 1), iz = min(max(iz, (int64_t)0), g.nz - 1);
+            c = (KeyT)((uint64_t)ix + (uint64_t)g.nx * ((uint64_t)iy + (uint64_t)g.ny * (uint64_t)iz));
+        }
+        code[i] = c, idx[i] = (uint32_t)i;
+    }
+}
+void launch_cell_codes(const float4* pts, int64_t n, CellGrid g, uint64_t* code, uint32_t* idx, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_cell_codes<uint64_t>, dim3(grid_for(n)), dim3(kBlock), 0, s, pts, n, g, code, idx);
+}
+void launch_cell_codes32(const float4* pts, int64_t n, CellGrid g, uint32_t* code, uint32_t* idx, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_cell_codes<uint32_t>, dim3(grid_for(n)), dim3(kBlock), 0, s, pts, n, g, code, idx);
+}
+
+// Sorted copies of the points and the hash of the cell heads (one insert per occupied cell, linear probing).
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_cell_table(const float4* __restrict__ pts, const uint32_t* __restrict__ idx_sorted,
+                                                       const KeyT* __restrict__ code_sorted, int64_t n, float4* __restrict__ pts_sorted,
+                                                       CellHashEntry* __restrict__ table, uint32_t mask) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        pts_sorted[i] = pts[idx_sorted[i]];
+        const KeyT c = code_sorted[i];
+        if (c == (KeyT)~(KeyT)0) continue;  // non-finite points sort last and are never looked up
+        if (i > 0 && code_sorted[i - 1] == c) continue;
+        const uint64_t key = (uint64_t)c;
+        uint32_t slot = (uint32_t)hash_cell(key) & mask;
+        while (true) {
+            const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&table[slot].key), ~0ull, (unsigned long long)key);
+            if (prev == ~0ull) {
+                table[slot].start = (uint32_t)i;
+                break;
+            }
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+void launch_cell_table(const float4* pts, const uint32_t* idx_sorted, const void* code_sorted, bool key32, int64_t n, float4* pts_sorted,
+                       CellHashEntry* table, uint32_t table_mask, hipStream_t s) {
+    if (n <= 0) return;
+    if (key32)
+        hipLaunchKernelGGL(k_cell_table<uint32_t>, dim3(grid_for(n)), dim3(kBlock), 0, s, pts, idx_sorted, (const uint32_t*)code_sorted, n, pts_sorted, table,
+                           table_mask);
+    else
+        hipLaunchKernelGGL(k_cell_table<uint64_t>, dim3(grid_for(n)), dim3(kBlock), 0, s, pts, idx_sorted, (const uint64_t*)code_sorted, n, pts_sorted, table,
+                           table_mask);
+}
+
+// One thread per query: 27 cell lookups, then the exact float distance of flann::L2_Simple, ((0 + dx*dx) + dy*dy) + dz*dz,
+// against the points of each cell (contiguous in the sorted copy); stops at the first hit.
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_radius_exists(const float4* __restrict__ query, int64_t nq, CellGrid g, const float4* __restrict__ pts_sorted,
+                                                          const KeyT* __restrict__ code_sorted, int64_t n, const CellHashEntry* __restrict__ table,
+                                                          uint32_t mask, float r2, uint8_t* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const float4 q = query[i];
+    int64_t cx, cy, cz;
+    bool hit = false;
+    if (n > 0 && cell_of(q, g, cx, cy, cz)) {
+        for (int dz = -1; dz <= 1 && !hit; ++dz) {
+            const int64_t z = cz + dz;
+            if (z < 0 || z >= g.nz) continue;
+            for (int dy = -1; dy <= 1 && !hit; ++dy) {
+                const int64_t y = cy + dy;
+                if (y < 0 || y >= g.ny) continue;
+                for (int dx = -1; dx <= 1 && !hit; ++dx) {
+                    const int64_t x = cx + dx;
+                    if (x < 0 || x >= g.nx) continue;
+                    const uint64_t key = (uint64_t)x + (uint64_t)g.nx * ((uint64_t)y + (uint64_t)g.ny * (uint64_t)z);
+                    uint32_t slot = (uint32_t)hash_cell(key) & mask;
+                    int64_t start = -1;
+                    while (true) {
+                        const uint64_t k = table[slot].key;
+                        if (k == key) {
+                            start = table[slot].start;
+                            break;
+                        }
+                        if (k == ~0ull) break;
+                        slot = (slot + 1) & mask;
+                    }
+                    if (start < 0) continue;
+                    for (int64_t j = start; j < n && (uint64_t)code_sorted[j] == key; ++j) {
+                        const float4 p = pts_sorted[j];
+                        const float ddx = q.x - p.x, ddy = q.y - p.y, ddz = q.z - p.z;
+                        float d = 0.0f;
+                        d += ddx * ddx;
+                        d += ddy * ddy;
+                        d += ddz * ddz;
+                        if (d <= r2) {
+                            hit = true;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    flag[i] = hit ? 1 : 0;
+}
+void launch_radius_exists(const float4* query, int64_t nq, CellGrid g, const float4* pts_sorted, const void* code_sorted, bool key32, int64_t n,
+                          const CellHashEntry* table, uint32_t table_mask, float r2, uint8_t* flag, hipStream_t s) {
+    if (nq <= 0) return;
+    const unsigned grid = (unsigned)((nq + kBlock - 1) / kBlock);
+    if (key32)
+        hipLaunchKernelGGL(k_radius_exists<uint32_t>, dim3(grid), dim3(kBlock), 0, s, query, nq, g, pts_sorted, (const uint32_t*)code_sorted, n, table, table_mask,
+                           r2, flag);
+    else
+        hipLaunchKernelGGL(k_radius_exists<uint64_t>, dim3(grid), dim3(kBlock), 0, s, query, nq, g, pts_sorted, (const uint64_t*)code_sorted, n, table, table_mask,
+                           r2, flag);
+}
+
+// isVisible (DmsaSlam.h:360-375): d = p.n ; res = pos.n - d ; visible iff res >= -0.00001 (double compare); 3-term inner
+// products as x0 + (x1 + x2) like every fixed-size Eigen product on the path.
+__global__ __launch_bounds__(kBlock) void k_static_flags(const float4* __restrict__ key_xyz, const float4* __restrict__ key_normal,
+                                                         const uint8_t* __restrict__ within, int64_t n, float px, float py, float pz,
+                                                         int32_t* __restrict__ sel) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int s = 0;
+    if (within[i]) {
+        const float4 p = key_xyz[i], nn = key_normal[i];
+        const float d = p.x * nn.x + (p.y * nn.y + p.z * nn.z);
+        const float res = (px * nn.x + (py * nn.y + pz * nn.z)) - d;
+        s = ((double)res >= -0.00001) ? 1 : 0;
+    }
+    sel[i] = s;
+}
+void launch_static_flags(const float4* key_xyz, const float4* key_normal, const uint8_t* within, int64_t n, float px, float py, float pz, int32_t* sel,
+                         hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_static_flags, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, key_xyz, key_normal, within, n, px, py, pz, sel);
+}
+__global__ __launch_bounds__(kBlock) void k_static_scatter(const float4* __restrict__ key_xyz, const int32_t* __restrict__ key_ring,
+                                                           const int32_t* __restrict__ sel, const int32_t* __restrict__ scan_excl, int64_t n,
+                                                           float4* __restrict__ out_xyz, int32_t* __restrict__ out_id) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !sel[i]) return;
+    const float4 p = key_xyz[i];
+    const int o = scan_excl[i];
+    out_xyz[o] = make_float4(p.x, p.y, p.z, 1.0f);
+    out_id[o] = key_ring[i];
+}
+void launch_static_scatter(const float4* key_xyz, const int32_t* key_ring, const int32_t* sel, const int32_t* scan_excl, int64_t n, float4* out_xyz,
+                           int32_t* out_id, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_static_scatter, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, key_xyz, key_ring, sel, scan_excl, n, out_xyz, out_id);
+}
+__global__ void k_pick_offsets(const int32_t* __restrict__ scan_excl, const int32_t* __restrict__ sel, const int64_t* __restrict__ offsets, int K,
+                               int64_t n, int32_t* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > K) return;
+    const int64_t o = offsets[k];
+    out[k] = n == 0 ? 0 : (o < n ? scan_excl[o] : scan_excl[n - 1] + sel[n - 1]);
+}
+void launch_pick_offsets(const int32_t* scan_excl, const int32_t* sel, const int64_t* offsets, int K, int64_t n, int32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_pick_offsets, dim3((unsigned)((K + 1 + 63) / 64)), dim3(64), 0, s, scan_excl, sel, offsets, K, n, out);
+}
+__global__ __launch_bounds__(kBlock) void k_count_flags(const uint8_t* __restrict__ flag, int64_t n, unsigned long long* __restrict__ count) {
+    unsigned c = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) c += flag[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += (unsigned)__shfl_xor((int)c, m);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+}
+void launch_count_flags(const uint8_t* flag, int64_t n, unsigned long long* count, hipStream_t s) {
+    (void)hipMemsetAsync(count, 0, sizeof(unsigned long long), s);
+    if (n > 0) hipLaunchKernelGGL(k_count_flags, dim3(grid_for(n, kBlock, 1024)), dim3(kBlock), 0, s, flag, n, count);
+}
+__global__ __launch_bounds__(kBlock) void k_leaf_pick(const int32_t* __restrict__ leaf_start, const uint32_t* __restrict__ idx_sorted,
+                                                      const int32_t* __restrict__ rnd, int num_leaves, int32_t* __restrict__ out) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= num_leaves) return;
+    const int b = leaf_start[l], cnt = leaf_start[l + 1] - b;
+    const double r = (double)rnd[l] / 2147483647.0;         // (double)rand() / RAND_MAX
+    const int id = (int)(r * (double)(cnt - 1));            // static_cast<int>(r * (double)(indices.size() - 1))
+    out[l] = (int32_t)idx_sorted[b + id];
+}
+void launch_leaf_pick(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* rnd, int num_leaves, int32_t* out, hipStream_t s) {
+    if (num_leaves > 0) hipLaunchKernelGGL(k_leaf_pick, dim3((unsigned)((num_leaves + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, leaf_start, idx_sorted, rnd, num_leaves, out);
+}
+
+}  // namespace dmsa

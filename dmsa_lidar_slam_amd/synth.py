@@ -311,3 +311,49 @@ def keyframe_problem(seed: int = 1, frames: int = 256, rings: int = 32, az_steps
                          gravityPlausible=np.ones(frames, np.int32), gravity=g)
     prob.truth_relative = (ro, rt)
     return prob
+
+
+def static_select_problem(seed: int = 1, scans: int = 10, rings: int = 128, az_steps: int = 1024, frames: int = 3, key_rings: int = 32,
+                          key_az: int = 320, grid_size: float = 0.15, sigma: float = 0.01):
+    """Inputs of DmsaSlam::addStaticPoints (DmsaSlam.h:264-358): the window cloud in the world frame (scans along the
+    trajectory) and `frames` keyframe clouds with normals and ring ids recorded earlier in the same room, already transformed
+    to the world frame (getGlobalKeyframeCloud).  slam_settings.yaml uses the 3 closest keyframes."""
+    from .static_points import StaticSelectProblem
+
+    rng = np.random.default_rng(seed)
+    scene = Scene.room_with_stairs()
+    traj = SmoothTrajectory(p0=np.array([4.0, 3.0, 1.5]))
+    win = []
+    for s in range(scans):
+        d_local, _, frac = spinning_lidar_dirs(rings, az_steps)
+        t_rel = s * 0.1 + frac * 0.1
+        R, p = traj.pose(t_rel)
+        dw = R.apply(d_local)
+        r, _ = scene.raycast(p, dw)
+        r = r + rng.normal(0.0, sigma, r.shape)
+        keep = r >= 0.1
+        win.append((p[keep] + dw[keep] * r[keep, None]).astype(np.float32))
+    window = np.concatenate(win)
+    d_local, ring, _ = spinning_lidar_dirs(key_rings, key_az)
+    pts, nrm, ids, off, kf_ids = [], [], [], [0], []
+    for k in range(frames):
+        Rk, pk = traj.pose(np.array([-0.8 * (frames - k)]))  # keyframes recorded before the window, oldest first
+        dw = Rk.apply(d_local)
+        r, n_w = scene.raycast(np.broadcast_to(pk[0], dw.shape).copy(), dw)
+        r = r + rng.normal(0.0, sigma, r.shape)
+        keep = r >= 0.1
+        pw = pk[0] + dw[keep] * r[keep, None]
+        nw = n_w[keep].copy()
+        flip = np.sum(nw * (pw - pk[0]), axis=1) > 0  # normals point towards the sensor that saw them
+        nw[flip] *= -1.0
+        pts.append(pw.astype(np.float32)), nrm.append(nw.astype(np.float32)), ids.append(ring[keep])
+        off.append(off[-1] + int(keep.sum()))
+        kf_ids.append(5 + k)
+    order = np.arange(frames)[::-1]  # closestKeyIds: nearest (= newest) keyframe first
+    o2 = [0]
+    for k in order:
+        o2.append(o2[-1] + (off[k + 1] - off[k]))
+    _, cur = traj.pose(np.array([0.0]))
+    return StaticSelectProblem(windowPoints=window, keyframeIds=np.array([kf_ids[k] for k in order], np.int32), frameOffsets=np.array(o2, np.int64),
+                               keyPoints=np.concatenate([pts[k] for k in order]), keyNormals=np.concatenate([nrm[k] for k in order]),
+                               keyRingIds=np.concatenate([ids[k] for k in order]), currPos=cur[0].astype(np.float32), minGridSize=grid_size)

@@ -1,0 +1,74 @@
+/*
+ * dmsa_static_points.h — C ABI of the step immediately BEFORE the DMSA hot path in every window:
+ * static-point selection, random grid thinning and overlap ratio of DmsaSlam::addStaticPoints.
+ *
+ *   DmsaSlam::addStaticPoints      include/DMSA/DmsaSlam.h:264-358
+ *   DmsaSlam::isVisible            include/DMSA/DmsaSlam.h:360-375
+ *   DmsaSlam::getOverlap           include/DMSA/DmsaSlam.h:377-414
+ *   randomGridDownsampling         include/DMSA/helpers.h:67-182
+ *
+ * Same conventions as dmsa_hip.h (contexts, status codes, float[n][4] points, no CPU fallback).  The reference answers its
+ * "nearest neighbour within minGridSize" questions with a FLANN kd-tree (pcl::KdTreeFLANN, flann::L2_Simple); only the
+ * comparison `squared distance of the nearest neighbour <= radius^2` is ever used, which is the order-independent predicate
+ * "some point lies within the radius" -- evaluated here on a uniform cell grid in HBM with the same float distance
+ * ((dx*dx + dy*dy) + dz*dz, the accumulation order of L2_Simple).
+ */
+#ifndef DMSA_STATIC_POINTS_H
+#define DMSA_STATIC_POINTS_H
+
+#include "dmsa_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Inputs of the selection loop of addStaticPoints (DmsaSlam.h:300-344). */
+typedef struct dmsa_static_select_problem {
+    int64_t        num_window;      /* trajIn.globalPoints.size()                                                      */
+    const float*   window_xyz;      /* N x 4, the window cloud the kd-tree is built on (:288)                          */
+    int32_t        num_keyframes;   /* closest keyframes that passed the distance gate (:298-304), in closestKeyIds order */
+    const int32_t* keyframe_ids;    /* K, the ring-buffer ids k (reported back as keyframeId / minRelatedKeyId)        */
+    const int64_t* frame_offset;    /* K+1 prefix of points per keyframe cloud                                         */
+    const float*   key_xyz;         /* n x 4, GLOBAL keyframe clouds (getGlobalKeyframeCloud, MapManagement.h:290-299) */
+    const float*   key_normal;      /* n x 4, global normals                                                           */
+    const int32_t* key_ring;        /* n, keyframeDataBuffer.at(k).ringIds(j)                                          */
+    float          cur_pos[3];      /* currPosf = controlPoses.globalPoses.Translations.col(0).cast<float>() (:267-268) */
+    float          min_grid_size;   /* trajIn.minGridSize; gate = (1.0f * minGridSize)^2 (:295)                        */
+} dmsa_static_select_problem;
+
+typedef struct dmsa_static_select_result {
+    int64_t num_static;             /* staticPoints->size() before thinning                                            */
+    int32_t keyframe_id;            /* keyframeId: keyframe with the largest overlap, first one wins, 0 if none (:270, :338-342) */
+    int32_t min_related_key_id;     /* minRelatedKeyId: smallest id that contributed a point, -1 if none (:274, :333-334) */
+    int32_t max_overlap;            /* maxOverlapKey                                                                   */
+    int32_t pad;
+} dmsa_static_select_result;
+
+/* == the keyframe loop of addStaticPoints (DmsaSlam.h:300-344).  static_xyz_out (capacity x 4 floats, w = 1) / static_id_out
+ * (capacity) receive the selected points in the reference's push_back order (keyframes in the given order, points ascending);
+ * overlap_per_keyframe (K, optional) receives currOverlap of every keyframe.  Returns DMSA_ERR_INVALID if capacity is too
+ * small (num_static is still reported). */
+int dmsa_select_static_points(dmsa_ctx* ctx, const dmsa_static_select_problem* p, float* static_xyz_out, int32_t* static_id_out,
+                              int64_t capacity, int32_t* overlap_per_keyframe, dmsa_static_select_result* res);
+
+/* == getOverlap(pc1, pc2, maxDistOverlap) (DmsaSlam.h:377-414): fraction of the pc2 points that have a pc1 point within
+ * maxDistOverlap; 0 when either cloud is empty.  num_corresp_out is optional. */
+int dmsa_get_overlap(dmsa_ctx* ctx, const float* pc1_xyz, int64_t n1, const float* pc2_xyz, int64_t n2, float max_dist_overlap,
+                     float* overlap_out, int64_t* num_corresp_out);
+
+/* == randomGridDownsampling(rawPc, filteredPc, gridSize) (helpers.h:67-182) with srand(seed) in place of srand(time(0)):
+ * one point per occupied PCL-octree leaf, leaves in depth-first order, the point chosen by glibc rand() exactly like
+ * `id = int((double)rand() / RAND_MAX * (double)(indices.size() - 1))`.  picked_index_out (capacity) receives the index INTO
+ * rawPc of every filtered point; num_out = octree.getLeafCount(). */
+int dmsa_random_grid_downsampling(dmsa_ctx* ctx, const float* xyz, int64_t n, float grid_size, uint32_t seed,
+                                  int32_t* picked_index_out, int64_t capacity, int64_t* num_out);
+
+/* Predicate behind both kd-tree uses: flag_out[i] = 1 iff some cloud point lies within `radius` of query i
+ * (squared L2_Simple distance <= radius*radius in float).  Non-finite cloud points never match, non-finite queries get 0. */
+int dmsa_radius_exists(dmsa_ctx* ctx, const float* cloud_xyz, int64_t n_cloud, const float* query_xyz, int64_t n_query, float radius,
+                       uint8_t* flag_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMSA_STATIC_POINTS_H */

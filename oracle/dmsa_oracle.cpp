@@ -1166,6 +1166,122 @@ struct Optimizer {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// DmsaSlam::addStaticPoints, isVisible, getOverlap (DmsaSlam.h:264-414) and
+// randomGridDownsampling (helpers.h:67-182).  Third-party pieces restated from their published behaviour:
+//   * pcl::KdTreeFLANN<..>::nearestKSearch(q, 1, ..) with flann::L2_Simple<float>: the exact nearest neighbour under
+//     dist(a, b) = ((0 + d0*d0) + d1*d1) + d2*d2 in float.  The reference only tests `dist(nearest) <= radius^2`, which is the
+//     predicate "some point lies within the radius" -- independent of how the tree is walked.
+//   * glibc srand()/rand(): the TYPE_3 additive feedback generator of random_r.c (degree 31, separation 3, 310 warm-up
+//     draws), checked against the C library of this machine in tests/test_oracle_static.py.
+// ------------------------------------------------------------------------------------------------
+// fixed-size 3-vector inner product, Eigen's unrolled redux: x0 + (x1 + x2) (the order used for the quadratic form, see above)
+static inline float dot3f(const float* a, const float* b) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); }
+static inline float l2_simple(const float* a, const float* b) {
+    float result = 0.0f;
+    for (int i = 0; i < 3; ++i) {
+        const float diff = a[i] - b[i];
+        result += diff * diff;
+    }
+    return result;
+}
+
+// "is there a cloud point within `radius` of q": sorted-cell grid (cells of 1.001 * radius, so every point within the radius
+// sits in the 27 cells around the query's cell) + the exact float distance.  `brute` = plain loop over the cloud (the
+// definition; used by the tests to check the grid).
+struct RadiusGrid {
+    const float* pts = nullptr;
+    int64_t n = 0;
+    double lo[3] = {0, 0, 0}, inv = 1.0;
+    std::vector<std::pair<uint64_t, int32_t>> cells;  // (cell code, point index), sorted
+    float r2 = 0.0f;
+
+    static uint64_t code(int64_t ix, int64_t iy, int64_t iz) { return (uint64_t)ix | ((uint64_t)iy << 21) | ((uint64_t)iz << 42); }
+    bool cell_of(const float* p, int64_t c[3]) const {
+        for (int a = 0; a < 3; ++a) {
+            if (!std::isfinite(p[a])) return false;
+            c[a] = (int64_t)std::floor(((double)p[a] - lo[a]) * inv);
+        }
+        return true;
+    }
+    int build(const float* xyz4, int64_t count, float radius) {
+        pts = xyz4, n = count, r2 = radius * radius;
+        inv = 1.0 / (1.001 * (double)radius);
+        bool any = false;
+        double hi[3] = {0, 0, 0};
+        for (int64_t i = 0; i < n; ++i) {
+            const float* p = pts + 4 * i;
+            if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
+            for (int a = 0; a < 3; ++a) {
+                if (!any || p[a] < lo[a]) lo[a] = p[a];
+                if (!any || p[a] > hi[a]) hi[a] = p[a];
+            }
+            any = true;
+        }
+        cells.clear();
+        if (!any) return DMSA_OK;
+        for (int a = 0; a < 3; ++a)
+            if ((hi[a] - lo[a]) * inv >= 2097150.0) return DMSA_ERR_DEPTH;
+        cells.reserve((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t c[3];
+            if (cell_of(pts + 4 * i, c)) cells.emplace_back(code(c[0], c[1], c[2]), (int32_t)i);
+        }
+        std::sort(cells.begin(), cells.end());
+        return DMSA_OK;
+    }
+    bool within(const float* q) const {
+        int64_t c[3];
+        if (cells.empty() || !cell_of(q, c)) return false;
+        for (int64_t dz = -1; dz <= 1; ++dz)
+            for (int64_t dy = -1; dy <= 1; ++dy)
+                for (int64_t dx = -1; dx <= 1; ++dx) {
+                    const int64_t x = c[0] + dx, y = c[1] + dy, z = c[2] + dz;
+                    if (x < 0 || y < 0 || z < 0 || x > 2097151 || y > 2097151 || z > 2097151) continue;
+                    const uint64_t key = code(x, y, z);
+                    auto it = std::lower_bound(cells.begin(), cells.end(), std::make_pair(key, (int32_t)INT32_MIN));
+                    for (; it != cells.end() && it->first == key; ++it)
+                        if (l2_simple(q, pts + 4 * (int64_t)it->second) <= r2) return true;
+                }
+        return false;
+    }
+    bool within_brute(const float* q) const {
+        for (int64_t i = 0; i < n; ++i)
+            if (l2_simple(q, pts + 4 * i) <= r2) return true;  // NaN distances compare false
+        return false;
+    }
+};
+
+// DmsaSlam.h:360-375
+static inline bool is_visible(const float* pos, const float* point, const float* normal) {
+    const float d = dot3f(point, normal);
+    const float res = dot3f(pos, normal) - d;
+    return (double)res >= -0.00001;
+}
+
+// glibc random_r.c, TYPE_3
+struct GlibcRand {
+    int32_t r[31];
+    int f = 3, b = 0;
+    explicit GlibcRand(uint32_t seed) {
+        if (seed == 0) seed = 1;
+        r[0] = (int32_t)seed;
+        for (int i = 1; i < 31; ++i) {
+            const long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+            long word = 16807 * lo - 2836 * hi;
+            if (word < 0) word += 2147483647;
+            r[i] = (int32_t)word;
+        }
+        for (int i = 0; i < 310; ++i) (void)next();
+    }
+    int32_t next() {
+        const uint32_t v = (uint32_t)r[f] + (uint32_t)r[b];
+        r[f] = (int32_t)v;
+        f = (f + 1) % 31, b = (b + 1) % 31;
+        return (int32_t)(v >> 1);
+    }
+};
+
 // ====================================================================================================
 // C API
 // ====================================================================================================
@@ -1354,6 +1470,96 @@ int orc_lm_step(const double* e0, const double* e_batch, int32_t rows, int32_t P
     if (g_out) std::copy(g.begin(), g.end(), g_out);
     if (step_out) std::copy(step.begin(), step.end(), step_out);
     return DMSA_OK;
+}
+
+// ---- SURVEY 8(f) f1/f2 ---------------------------------------------------------------------------------------------
+int orc_radius_exists(const float* cloud, int64_t n_cloud, const float* query, int64_t n_query, float radius, uint8_t* flag_out, int brute) {
+    RadiusGrid g;
+    if (brute) {
+        g.pts = cloud, g.n = n_cloud, g.r2 = radius * radius;
+    } else {
+        const int rc = g.build(cloud, n_cloud, radius);
+        if (rc != DMSA_OK) return rc;
+    }
+    for (int64_t i = 0; i < n_query; ++i) flag_out[i] = (brute ? g.within_brute(query + 4 * i) : g.within(query + 4 * i)) ? 1 : 0;
+    return DMSA_OK;
+}
+
+// DmsaSlam.h:264-344, the loop over the closest keyframes (the distance gate of :304 is applied by the caller)
+int orc_select_static_points(const dmsa_static_select_problem* p, float* static_xyz_out, int32_t* static_id_out, int64_t capacity,
+                             int32_t* overlap_per_keyframe, dmsa_static_select_result* res) {
+    RadiusGrid kdtree;
+    const float sqrdMaxDist = (float)std::pow((double)(1.0f * p->min_grid_size), 2);  // std::pow(float, int) -> double -> float
+    const int rc = kdtree.build(p->window_xyz, p->num_window, p->min_grid_size);
+    if (rc != DMSA_OK) return rc;
+    kdtree.r2 = sqrdMaxDist;
+    int keyframeId = 0, maxOverlapKey = 0, minRelatedKeyId = -1;
+    int64_t count = 0;
+    for (int kk = 0; kk < p->num_keyframes; ++kk) {
+        const int k = p->keyframe_ids[kk];
+        int currOverlap = 0;
+        for (int64_t j = p->frame_offset[kk]; j < p->frame_offset[kk + 1]; ++j) {
+            const float* point = p->key_xyz + 4 * j;
+            if (kdtree.within(point) && is_visible(p->cur_pos, point, p->key_normal + 4 * j)) {
+                if (count < capacity) {
+                    if (static_xyz_out) static_xyz_out[4 * count] = point[0], static_xyz_out[4 * count + 1] = point[1], static_xyz_out[4 * count + 2] = point[2], static_xyz_out[4 * count + 3] = 1.0f;
+                    if (static_id_out) static_id_out[count] = p->key_ring[j];
+                }
+                ++count;
+                ++currOverlap;
+                if (minRelatedKeyId < 0 || k < minRelatedKeyId) minRelatedKeyId = k;
+            }
+            if (currOverlap > maxOverlapKey) maxOverlapKey = currOverlap, keyframeId = k;
+        }
+        if (overlap_per_keyframe) overlap_per_keyframe[kk] = currOverlap;
+    }
+    if (res) res->num_static = count, res->keyframe_id = keyframeId, res->min_related_key_id = minRelatedKeyId, res->max_overlap = maxOverlapKey, res->pad = 0;
+    return count <= capacity ? DMSA_OK : DMSA_ERR_INVALID;
+}
+
+// DmsaSlam.h:377-414
+int orc_get_overlap(const float* pc1, int64_t n1, const float* pc2, int64_t n2, float maxDistOverlap, float* overlap_out, int64_t* num_corresp_out) {
+    int64_t nCorresp = 0;
+    float overlap = 0.0f;
+    if (n1 > 0 && n2 > 0) {
+        RadiusGrid kdtree;
+        const int rc = kdtree.build(pc1, n1, maxDistOverlap);
+        if (rc != DMSA_OK) return rc;
+        kdtree.r2 = maxDistOverlap * maxDistOverlap;
+        for (int64_t i = 0; i < n2; ++i)
+            if (kdtree.within(pc2 + 4 * i)) ++nCorresp;
+        overlap = static_cast<float>(nCorresp) / static_cast<float>(n2);
+    }
+    if (overlap_out) *overlap_out = overlap;
+    if (num_corresp_out) *num_corresp_out = nCorresp;
+    return DMSA_OK;
+}
+
+void orc_glibc_rand(uint32_t seed, int32_t count, int32_t* out) {
+    GlibcRand g(seed);
+    for (int32_t i = 0; i < count; ++i) out[i] = g.next();
+}
+
+// helpers.h:67-182 with srand(seed)
+int orc_random_grid_downsampling(const float* xyz, int64_t n, float grid_size, uint32_t seed, int32_t* picked_index_out, int64_t capacity,
+                                 int64_t* num_out) {
+    VoxelResult v;
+    const int rc = voxelize(xyz, n, (double)grid_size, v);  // OctreePointCloud(gridSize): float -> double resolution
+    if (rc != DMSA_OK) return rc;
+    GlibcRand gen(seed);
+    int64_t filId = 0;
+    const int64_t nv = (int64_t)v.order.size();
+    for (int64_t b = 0; b < nv;) {  // leaves in depth-first order; indices of a leaf ascend
+        int64_t e = b + 1;
+        while (e < nv && v.code[(size_t)v.order[(size_t)e]] == v.code[(size_t)v.order[(size_t)b]]) ++e;
+        const double r = (double)gen.next() / 2147483647.0;
+        const int id = static_cast<int>(r * (double)((e - b) - 1));
+        if (filId < capacity && picked_index_out) picked_index_out[filId] = v.order[(size_t)(b + id)];
+        ++filId;
+        b = e;
+    }
+    if (num_out) *num_out = filId;
+    return filId <= capacity ? DMSA_OK : DMSA_ERR_INVALID;
 }
 
 }  // extern "C"

@@ -16,6 +16,7 @@
 
 #include <stdint.h>
 #include "../include/dmsa_hip.h" /* POD problem/settings/report structs only */
+#include "../include/dmsa_static_points.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -84,6 +85,15 @@ int orc_keyframe_additional_errors(const dmsa_keyframe_problem* p, double* rows_
 /* one numeric-Jacobian + LM step on given residual batches (DmsaOptimizer.h:107-113); for stage parity */
 int orc_lm_step(const double* e0, const double* e_batch /* P x rows */, int32_t rows, int32_t P, double h, double lambda,
                 double alpha, double* H_out /* PxP col-major */, double* g_out, double* step_out);
+
+/* ---- addStaticPoints selection / getOverlap (DmsaSlam.h:264-414), randomGridDownsampling (helpers.h:67-182) */
+int orc_radius_exists(const float* cloud, int64_t n_cloud, const float* query, int64_t n_query, float radius, uint8_t* flag_out, int brute);
+int orc_select_static_points(const dmsa_static_select_problem* p, float* static_xyz_out, int32_t* static_id_out, int64_t capacity,
+                             int32_t* overlap_per_keyframe, dmsa_static_select_result* res);
+int orc_get_overlap(const float* pc1, int64_t n1, const float* pc2, int64_t n2, float maxDistOverlap, float* overlap_out, int64_t* num_corresp_out);
+void orc_glibc_rand(uint32_t seed, int32_t count, int32_t* out); /* the first `count` values of rand() after srand(seed) */
+int orc_random_grid_downsampling(const float* xyz, int64_t n, float grid_size, uint32_t seed, int32_t* picked_index_out, int64_t capacity,
+                                 int64_t* num_out);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ def lib():
 
 
 def test_exports_every_declared_symbol(lib):
-    header = open(os.path.join(ROOT, "include", "dmsa_hip.h")).read()
+    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("dmsa_hip.h", "dmsa_static_points.h"))
     declared = set(re.findall(r"\b(dmsa_[a-z_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     assert declared == set(capi.EXPORTED_SYMBOLS)
@@ -37,6 +37,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(capi.Timing) == 80
     assert C.sizeof(capi.WindowProblem) == 192
     assert C.sizeof(capi.KeyframeProblem) == 360
+    assert C.sizeof(capi.StaticSelectProblem) == 80 and C.sizeof(capi.StaticSelectResult) == 24  # dmsa_static_points.h
 
 
 def test_default_settings_match_reference_defaults(lib):

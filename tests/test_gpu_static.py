@@ -1,0 +1,135 @@
+"""GPU parity of SURVEY.md 8(f) rows f1/f2 through include/dmsa_static_points.h: DmsaSlam::addStaticPoints selection +
+isVisible, getOverlap, randomGridDownsampling (seeded).  Everything here is index/flag work: the bar is bit-exact."""
+import numpy as np
+import pytest
+
+from dmsa_lidar_slam_amd import synth
+from dmsa_lidar_slam_amd.static_points import StaticPointSelector, StaticSelectProblem
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    s = StaticPointSelector(device=0)
+    yield s
+    s.close()
+
+
+def _pts(rng, n, lo, hi):
+    return np.concatenate([rng.uniform(lo, hi, (n, 3)), np.ones((n, 1))], axis=1).astype(f32)
+
+
+def _same_selection(a, b):
+    assert np.array_equal(a.staticPoints, b.staticPoints) and np.array_equal(a.staticIds, b.staticIds)
+    assert np.array_equal(a.overlapPerKeyframe, b.overlapPerKeyframe)
+    assert (a.keyframeId, a.minRelatedKeyId, a.maxOverlap) == (b.keyframeId, b.minRelatedKeyId, b.maxOverlap)
+
+
+def test_radius_exists_matches_oracle_and_brute_force(gpu, orc):
+    rng = np.random.default_rng(3)
+    cloud, query = _pts(rng, 20000, -4, 4), _pts(rng, 9000, -5, 5)
+    cloud[7, 0], cloud[8, 1], query[3, 2] = np.nan, np.inf, np.nan
+    query[4] = [1e30, 0, 0, 1]
+    query[5] = [-1e30, 3e38, 0, 1]
+    for r in (0.02, 0.3, 1.7):
+        got = gpu.radiusExists(cloud, query, r)
+        assert np.array_equal(got, orc.radius_exists(cloud, query, r))
+    got = gpu.radiusExists(cloud[:3000], query[:2000], 0.3)
+    assert np.array_equal(got, orc.radius_exists(cloud[:3000], query[:2000], 0.3, brute=True))
+    assert not gpu.radiusExists(np.zeros((0, 4), f32), query, 0.3).any()
+    assert gpu.radiusExists(cloud, np.zeros((0, 4), f32), 0.3).shape == (0,)
+    # every cloud point is within any radius of itself; all-NaN cloud matches nothing
+    assert gpu.radiusExists(cloud[100:200], cloud[100:200], 1e-3).all()
+    assert not gpu.radiusExists(np.full((10, 4), np.nan, f32), query[:50], 0.3).any()
+
+
+def test_radius_boundary_inclusive(gpu):
+    r = f32(0.3)
+    r2 = r * r
+    x_in = f32(np.sqrt(np.float64(r2)))
+    while f32(x_in * x_in) > r2:
+        x_in = np.nextafter(x_in, f32(0))
+    x_out = x_in
+    while f32(x_out * x_out) <= r2:
+        x_out = np.nextafter(x_out, f32(1))
+    q = np.array([[x_in, 0, 0, 1], [x_out, 0, 0, 1], [0, -x_in, 0, 1], [0, 0, x_out, 1]], f32)
+    assert gpu.radiusExists(np.array([[0, 0, 0, 1]], f32), q, r).tolist() == [True, False, True, False]
+
+
+def test_select_static_points_small(gpu, orc):
+    p = synth.static_select_problem(seed=2, scans=2, rings=32, az_steps=256, frames=3, key_rings=16, key_az=128)
+    p.keyNormals[5:400] *= -1.0
+    ref = orc.select_static_points(p)
+    assert 0 < ref.staticPoints.shape[0] < p.keyPoints.shape[0]
+    _same_selection(gpu.selectStaticPoints(p), ref)
+
+
+def test_select_static_points_edge_cases(gpu, orc):
+    p = synth.static_select_problem(seed=4, scans=1, rings=16, az_steps=128, frames=2, key_rings=8, key_az=64)
+    n0 = p.frameOffsets[1]
+    dup = StaticSelectProblem(windowPoints=p.windowPoints, keyframeIds=np.array([9, 4], np.int32), frameOffsets=np.array([0, n0, 2 * n0]),
+                              keyPoints=np.concatenate([p.keyPoints[:n0]] * 2), keyNormals=np.concatenate([p.keyNormals[:n0]] * 2),
+                              keyRingIds=np.concatenate([p.keyRingIds[:n0]] * 2), currPos=p.currPos, minGridSize=p.minGridSize)
+    got = gpu.selectStaticPoints(dup)
+    _same_selection(got, orc.select_static_points(dup))
+    assert got.keyframeId == 9 and got.minRelatedKeyId == 4  # first of equal overlaps; smallest contributing id
+    far = StaticSelectProblem(windowPoints=p.windowPoints + f32(1000.0), keyframeIds=p.keyframeIds, frameOffsets=p.frameOffsets, keyPoints=p.keyPoints,
+                              keyNormals=p.keyNormals, keyRingIds=p.keyRingIds, currPos=p.currPos, minGridSize=p.minGridSize)
+    got = gpu.selectStaticPoints(far)
+    assert got.staticPoints.shape[0] == 0 and (got.keyframeId, got.minRelatedKeyId, got.maxOverlap) == (0, -1, 0)
+    empty_frame = StaticSelectProblem(windowPoints=p.windowPoints, keyframeIds=np.array([3, 8, 1], np.int32), frameOffsets=np.array([0, n0, n0, p.keyPoints.shape[0]]),
+                                      keyPoints=p.keyPoints, keyNormals=p.keyNormals, keyRingIds=p.keyRingIds, currPos=p.currPos, minGridSize=p.minGridSize)
+    _same_selection(gpu.selectStaticPoints(empty_frame), orc.select_static_points(empty_frame))
+    no_window = StaticSelectProblem(windowPoints=np.zeros((0, 4), f32), keyframeIds=p.keyframeIds, frameOffsets=p.frameOffsets, keyPoints=p.keyPoints,
+                                    keyNormals=p.keyNormals, keyRingIds=p.keyRingIds, currPos=p.currPos, minGridSize=p.minGridSize)
+    _same_selection(gpu.selectStaticPoints(no_window), orc.select_static_points(no_window))
+    nan_prob = synth.static_select_problem(seed=4, scans=1, rings=16, az_steps=128, frames=2, key_rings=8, key_az=64)
+    nan_prob.windowPoints[::7, 1] = np.nan
+    nan_prob.keyPoints[::11, 0] = np.nan
+    _same_selection(gpu.selectStaticPoints(nan_prob), orc.select_static_points(nan_prob))
+
+
+def test_get_overlap(gpu, orc):
+    rng = np.random.default_rng(5)
+    a, b = _pts(rng, 15000, -3, 3), _pts(rng, 22000, -3.5, 3.5)
+    assert gpu.getOverlap(a, b, 0.25) == orc.get_overlap(a, b, 0.25)
+    assert gpu.getOverlap(np.zeros((0, 4), f32), b, 0.25) == (0.0, 0) and gpu.getOverlap(a, np.zeros((0, 4), f32), 0.25) == (0.0, 0)
+
+
+@pytest.mark.parametrize("seed", [1, 77, 0])
+def test_random_grid_downsampling(gpu, orc, seed):
+    rng = np.random.default_rng(11)
+    pts = _pts(rng, 30000, -6, 6)
+    pts[17, 0] = np.nan
+    pts[0, 2] = np.inf  # first point non-finite: the lattice anchors at the next one
+    for grid in (f32(0.4), f32(0.15), f32(0.075)):
+        got = gpu.randomGridDownsampling(pts, grid, seed)
+        assert np.array_equal(got, orc.random_grid_downsampling(pts, grid, seed))
+    assert gpu.randomGridDownsampling(np.zeros((0, 4), f32), 0.4, seed).shape == (0,)
+    assert gpu.randomGridDownsampling(np.full((5, 4), np.nan, f32), 0.4, seed).shape == (0,)
+    one = gpu.randomGridDownsampling(pts[5:6], 0.4, seed)
+    assert one.tolist() == [0]
+
+
+def test_add_static_points_full_size(gpu, orc):
+    """The whole step at the bench size: 10 x 131 072-point window cloud, 3 keyframes (slam_settings.yaml), thinning at
+    minGridSize / 2 with srand(7), overlap ratio of the 1.3 M window points against the thinned map."""
+    p = synth.static_select_problem(seed=1)
+    sel, active, active_ids, overlap = gpu.addStaticPoints(p, seed=7)
+    ref = orc.select_static_points(p)
+    _same_selection(sel, ref)
+    pick = orc.random_grid_downsampling(ref.staticPoints, f32(p.minGridSize) / f32(2.0), 7)
+    assert np.array_equal(active, ref.staticPoints[pick]) and np.array_equal(active_ids, ref.staticIds[pick])
+    assert overlap == orc.get_overlap(ref.staticPoints[pick], p.windowPoints, p.minGridSize)[0]
+    assert 0.5 < overlap < 1.0 and active.shape[0] > 10_000
+    # size-independent properties: idempotent; one DISTINCT point per occupied leaf, in leaf order whatever the seed (thinning again
+    # can only merge leaves: the lattice re-anchors at the new first point); every selected point has a window point within minGridSize
+    again, *_ = gpu.addStaticPoints(p, seed=7)
+    _same_selection(again, sel)
+    half = f32(p.minGridSize) / f32(2.0)
+    pick_a, pick_b = gpu.randomGridDownsampling(sel.staticPoints, half, 7), gpu.randomGridDownsampling(sel.staticPoints, half, 8)
+    assert pick_a.shape == pick_b.shape and np.unique(pick_a).shape == pick_a.shape and not np.array_equal(pick_a, pick_b)
+    assert gpu.randomGridDownsampling(active, half, 3).shape[0] <= active.shape[0]
+    assert gpu.radiusExists(p.windowPoints, sel.staticPoints, p.minGridSize).all()
