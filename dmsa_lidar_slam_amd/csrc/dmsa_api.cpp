@@ -110,6 +110,8 @@ struct dmsa_ctx {
     double level_res[2] = {0, 0};
     // Gaussians
     DevBuf d_memb_local, d_memb_idx, d_memb_g, d_seg_off, d_info12, d_wg_seg;
+    DevBuf d_order_key, d_order_key_s, d_order_val, d_order;  // parity path: Gaussians by descending size
+    bool order_valid = false;
     DevBuf d_memb_tile, d_tiles, d_tile_counts, d_tile_rows, d_fallback;
     int num_tiles = 0, num_fallback = 0, tile_max_rows = 0, tile_max_gauss = 0;
     bool use_tiles = true;  // DMSA_K4_TILES=0 selects the streaming kernel
@@ -237,6 +239,8 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
     HIPCHK(ctx->d_seg_off.ensure((2 * n + 2) * 4));
     HIPCHK(ctx->d_info12.ensure((2 * n / 2 + 16) * 48));  // sets have >= 2 members (two distinct ids)
     HIPCHK(ctx->d_wg_seg.ensure(4096 * 4));
+    if (ctx->flags & DMSA_FLAG_MIRROR_SUMS)
+        for (DevBuf* b : {&ctx->d_order_key, &ctx->d_order_key_s, &ctx->d_order_val, &ctx->d_order}) HIPCHK(b->ensure((n + 16) * 4));
     // tiled correspondence kernels: windows of 3T/4 members plus own-tile Gaussians (> T/4 members each) and their
     // neighbours: tiles <= (4/3 + 8)*Mm/T + 1 with Mm <= 2n; one row list of `rows` entries per tile
     const size_t max_tiles = 20 * n / (size_t)tile_points() + 64;
@@ -257,22 +261,33 @@ int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs) {
     const int np = ctx->model == MODEL_WINDOW ? ctx->win.ctrl.n : ctx->key.frames.n;
     if (ctx->flags & DMSA_FLAG_POSE_TABLE_HOST) {
         ctx->h_tables.resize((size_t)B * rows * 12);
-        PoseChain tmp;
-        tmp.resize(np);
-        for (int b = 0; b < B; ++b) {
-            for (int k = 0; k < np; ++k)
-                for (int c = 0; c < 3; ++c) {
-                    tmp.glob_o[3 * k + c] = globs[((size_t)b * np + k) * 6 + c];
-                    tmp.glob_t[3 * k + c] = globs[((size_t)b * np + k) * 6 + 3 + c];
-                }
-            float* T = &ctx->h_tables[(size_t)b * rows * 12];
-            if (ctx->model == MODEL_WINDOW)
-                window_dense_table(tmp, ctx->win.stamps, ctx->win.fh, ctx->win.traj_time, T);
-            else
-                keyframe_table(tmp, T);
-            float* id = T + (size_t)(rows - 1) * 12;  // identity row used by static points
-            const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-            std::memcpy(id, I, sizeof(I));
+        auto build_range = [&](int b0, int b1) {
+            PoseChain tmp;
+            tmp.resize(np);
+            for (int b = b0; b < b1; ++b) {
+                for (int k = 0; k < np; ++k)
+                    for (int c = 0; c < 3; ++c) {
+                        tmp.glob_o[3 * k + c] = globs[((size_t)b * np + k) * 6 + c];
+                        tmp.glob_t[3 * k + c] = globs[((size_t)b * np + k) * 6 + 3 + c];
+                    }
+                float* T = &ctx->h_tables[(size_t)b * rows * 12];
+                if (ctx->model == MODEL_WINDOW)
+                    window_dense_table(tmp, ctx->win.stamps, ctx->win.fh, ctx->win.traj_time, T);
+                else
+                    keyframe_table(tmp, T);
+                float* id = T + (size_t)(rows - 1) * 12;  // identity row used by static points
+                const float I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+                std::memcpy(id, I, sizeof(I));
+            }
+        };
+        // every table is a pure function of its control poses: build the tables of a batch on several host threads
+        const int nthreads = (int)std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), (size_t)B * rows / 2048 + 1);
+        if (nthreads <= 1) {
+            build_range(0, B);
+        } else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthreads; ++t) pool.emplace_back(build_range, (int)((int64_t)B * t / nthreads), (int)((int64_t)B * (t + 1) / nthreads));
+            for (auto& th : pool) th.join();
         }
         HIPCHK(hipMemcpyAsync(ctx->d_tables.p, ctx->h_tables.data(), ctx->h_tables.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));  // h_tables is reused by the next batch
@@ -345,6 +360,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                     bool allow_compression = true) {
     const int64_t n = ctx->n;
     ctx->gaussians_valid = false;
+    ctx->order_valid = false;
     ctx->M = 0, ctx->M1 = 0, ctx->Mm = 0;
     const bool lvl_on[2] = {s.grid_size_1_factor > std::numeric_limits<float>::min(), s.grid_size_2_factor > std::numeric_limits<float>::min()};
     // createGaussianSets(set, factor * minGridSize, ...): float product, widened to double by the octree constructor
@@ -496,6 +512,16 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             launch_fit_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_tables.as<float>(), ctx->tile_max_rows,
                              ctx->d_tiles.as<TileDesc>(), reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
                              ctx->d_info12.as<float>(), ctx->stream);
+        const int M_all = h.level[0].num_gauss + h.level[1].num_gauss;
+        if (!tiles_on && (ctx->flags & DMSA_FLAG_MIRROR_SUMS) && mirror_uses_rows() && M_all > 0) {
+            // parity path: order the Gaussians by size once (radix sort of M keys), then one row-cooperative fit for both levels
+            launch_gauss_size_keys(ctx->d_seg_off.as<int32_t>(), M_all, ctx->d_order_key.as<uint32_t>(), ctx->d_order_val.as<uint32_t>(), ctx->stream);
+            HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_order_key.as<uint32_t>(), ctx->d_order_key_s.as<uint32_t>(),
+                                      ctx->d_order_val.as<uint32_t>(), ctx->d_order.as<uint32_t>(), (size_t)M_all, 32, ctx->stream));
+            launch_gauss_fit_mirror_rows(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(), ctx->d_order.as<uint32_t>(), M_all,
+                                         ctx->d_info12.as<float>(), ctx->stream);
+            ctx->order_valid = true;
+        }
         launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
     }
     HIPCHK(hipGetLastError());
@@ -534,7 +560,8 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
     } else {
         ScopedTimer tm(ctx, T_RESIDUAL);
         launch_residuals(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tables.as<float>(), ctx->rows, ctx->M,
-                         B, ctx->d_wg_seg.as<int32_t>(), ctx->num_wg, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE, (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
+                         B, ctx->d_wg_seg.as<int32_t>(), ctx->num_wg, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE, (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream,
+                         false, ctx->order_valid ? ctx->d_order.as<uint32_t>() : nullptr);
     }
     ctx->residual_launches += 1;
     ctx->residual_evals += B;
@@ -791,7 +818,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
                       &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
                       &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
                       &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_memb_g, &ctx->d_seg_off,
-                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_counts, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
+                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_order_key, &ctx->d_order_key_s, &ctx->d_order_val, &ctx->d_order, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_counts, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
     for (DevBuf* b : bufs) b->release();
     if (ctx->sp) {
         for (DevBuf* b : ctx->sp->all) b->release();

@@ -1181,8 +1181,10 @@ __global__ __launch_bounds__(256) void k_gauss_fit_mirror(const int32_t* __restr
 }
 void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const GaussCounts* counts, int level, float* info12,
                       bool mirror, hipStream_t s) {
-    if (mirror)
+    if (mirror && !mirror_uses_rows())
         hipLaunchKernelGGL(k_gauss_fit_mirror, dim3(1024), dim3(256), 0, s, seg_off, memb_idx, global, counts, level, info12);
+    else if (mirror)
+        return;  // the row-cooperative parity fit runs once for both levels, after M is known (launch_gauss_fit_mirror_rows)
     else
         hipLaunchKernelGGL(k_gauss_fit, dim3(2048), dim3(256), 0, s, seg_off, memb_idx, global, counts, level, info12);
 }
@@ -1208,21 +1210,31 @@ __global__ __launch_bounds__(1024) void k_rebalancing_weights(const int32_t* __r
     if (threadIdx.x == 0) counts->weight_mean = mean;
     for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = info12[(size_t)g * 12 + 9] / mean;
 }
+// parity path: VectorXf::mean() as one serial double chain in index order (the oracle's statement of Gaussians.h:170-179).
+// Wave 0 loads 64 weights at a time (the next 64 are in flight meanwhile) and walks them with v_readlane; the sum is wave-uniform.
 __global__ __launch_bounds__(1024) void k_rebalancing_weights_mirror(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts,
                                                                      float* __restrict__ info12) {
     __shared__ float s_mean;
     const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
-    for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = (1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f;
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        auto weight = [&](int g) { return g < M ? (1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f : 0.0f; };  // +0.0 leaves the sum unchanged
         double s = 0.0;
-        for (int g = 0; g < M; ++g) s += (double)info12[(size_t)g * 12 + 9];
-        s_mean = (float)(s / (double)M);
-        counts->weight_mean = s_mean;
+        float wn = weight(lane);
+        for (int g0 = 0; g0 < M; g0 += 64) {
+            const float w = wn;
+            wn = weight(g0 + 64 + lane);
+#pragma unroll
+            for (int k = 0; k < 64; ++k) s += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), k));
+        }
+        if (lane == 0) {
+            s_mean = (float)(s / (double)M);
+            counts->weight_mean = s_mean;
+        }
     }
     __syncthreads();
     const float mean = s_mean;
-    for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = info12[(size_t)g * 12 + 9] / mean;
+    for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = ((1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f) / mean;
 }
 void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, bool mirror, hipStream_t s) {
     if (mirror)
@@ -2071,25 +2083,330 @@ __global__ __launch_bounds__(256) void k_residuals_mirror(const float4* __restri
     E[(size_t)b * ldE + g] = sqrt(fabs(acc));
 }
 
+// ---- parity path, row-cooperative --------------------------------------------------------------------------------------
+// The reference's per-Gaussian sums are SERIAL chains (float mean, DmsaOptimizer.h:247-254; double accumulation of the float
+// terms, :259-264): rounding makes them order dependent, so a bit-identical result needs the same chain.  What is parallel is
+// everything AROUND the chain.  A 16-lane DPP row owns one Gaussian: its lanes load and transform 16 members at once, then the
+// row's lane 0 runs the chain, fetching member j's value with `row_ror` folded into the add (v_add_f32_dpp) -- one VALU
+// instruction per member and chain, no LDS, no per-lane memory streams.  A wave runs four such rows; lanes past a row's last
+// member contribute +0.0, which leaves every partial sum unchanged (a sum that starts at +0.0 never becomes -0.0).
+template <int J>
+__device__ __forceinline__ float row_lane(float v) {  // in lane 0 of every 16-lane row: the value of the row's lane J
+    if constexpr (J == 0)
+        return v;
+    else
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (16 - J), 0xf, 0xf, false));  // row_ror:(16-J)
+}
+template <int J>
+__device__ __forceinline__ double row_lane(double v) {
+    if constexpr (J == 0) {
+        return v;
+    } else {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + (16 - J), 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + (16 - J), 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
+}
+template <int J>
+struct RowChain {
+    static __device__ __forceinline__ void add3f(float& sx, float& sy, float& sz, float x, float y, float z) {
+        sx = sx + row_lane<J>(x), sy = sy + row_lane<J>(y), sz = sz + row_lane<J>(z);
+        RowChain<J + 1>::add3f(sx, sy, sz, x, y, z);
+    }
+    static __device__ __forceinline__ void add_f_to_d(double& acc, float t) {
+        acc += (double)row_lane<J>(t);
+        RowChain<J + 1>::add_f_to_d(acc, t);
+    }
+    static __device__ __forceinline__ void add3d_from_f(double& sx, double& sy, double& sz, float& x, float& y, float& z) {
+        sx += (double)row_lane<J>(x), sy += (double)row_lane<J>(y), sz += (double)row_lane<J>(z);
+        asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz), "+v"(x), "+v"(y), "+v"(z));
+        RowChain<J + 1>::add3d_from_f(sx, sy, sz, x, y, z);
+    }
+    static __device__ __forceinline__ void add1d_from_f(double& sx, float& x) {
+        sx += (double)row_lane<J>(x);
+        asm volatile("" : "+v"(sx), "+v"(x));
+        RowChain<J + 1>::add1d_from_f(sx, x);
+    }
+    static __device__ __forceinline__ void add2d(double& a, double& b, double& va, double& vb) {
+        a += row_lane<J>(va), b += row_lane<J>(vb);
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(va), "+v"(vb));
+        RowChain<J + 1>::add2d(a, b, va, vb);
+    }
+    static __device__ __forceinline__ void add6d(double* a, double* v) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            a[c] += row_lane<J>(v[c]);
+            // ties the next lane move of this chain to this add: without it all 16 x 12 moves are hoisted (512 VGPRs + scratch)
+            asm volatile("" : "+v"(a[c]), "+v"(v[c]));
+        }
+        RowChain<J + 1>::add6d(a, v);
+    }
+};
+template <>
+struct RowChain<16> {
+    static __device__ __forceinline__ void add3f(float&, float&, float&, float, float, float) {}
+    static __device__ __forceinline__ void add_f_to_d(double&, float) {}
+    static __device__ __forceinline__ void add3d_from_f(double&, double&, double&, float&, float&, float&) {}
+    static __device__ __forceinline__ void add6d(double*, double*) {}
+    static __device__ __forceinline__ void add1d_from_f(double&, float&) {}
+    static __device__ __forceinline__ void add2d(double&, double&, double&, double&) {}
+};
+// value of the row's lane 0 in every lane of the row
+__device__ __forceinline__ float row_first(float v) { return __shfl(v, (int)(threadIdx.x & 63u & ~15u), 64); }
+__device__ __forceinline__ int wave_max4(int v) {  // max over the four rows' lane-0 values
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// updateErrorTerms (DmsaOptimizer.h:234-273), bit-identical to the serial loops: one row per (Gaussian, evaluation).
+template <bool kTableInLds>
+__global__ __launch_bounds__(256) void k_residuals_mirror_rows(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off,
+                                                               const float4* __restrict__ info12, const float4* __restrict__ tables, int rows, int M,
+                                                               const uint32_t* __restrict__ order, int eval_major, double* __restrict__ E,
+                                                               int64_t ldE) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_tab[];
+    // eval_major: blockIdx.x runs over the evaluations, so the workgroups holding the LONGEST chains of every evaluation are
+    // dispatched first (longest-processing-time-first); otherwise the last evaluation's long chains start last and form the tail
+    const int b = eval_major ? blockIdx.x : blockIdx.y, tblock = eval_major ? blockIdx.y : blockIdx.x;
+    const float4* gtab = tables + (size_t)b * rows * 3;
+    if (kTableInLds) {
+        for (int i = threadIdx.x; i < rows * 3; i += blockDim.x) s_tab[i] = gtab[i];
+        __syncthreads();
+    }
+    const float4* T = kTableInLds ? s_tab : gtab;
+    const int l16 = threadIdx.x & 15;
+    // `order` lists the Gaussians by descending size: the four rows of a wave get chains of (almost) equal length and the long
+    // chains -- the critical path -- start first
+    const int task = tblock * 16 + (threadIdx.x >> 4);
+    const bool on = task < M;
+    const int g = on ? (int)order[task] : 0;
+    const int off0 = on ? seg_off[g] : 0, n = on ? seg_off[g + 1] - off0 : 0;
+    const int nmax = wave_max4(n);
+    if (nmax == 0) return;
+    // kRowBatch chunks of 16 members per step: all loads of a step are issued before its chains run, so the memory latency of
+    // the long Gaussians (the critical path: their chains cannot be split) hides behind 4 x 16 chain steps
+    constexpr int kRowBatch = 4;
+    const int last = max(n - 1, 0);
+    auto load_step = [&](int j0, float4* dst) {  // the step after the one being chained is already in flight
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) dst[u] = memb[off0 + min(j0 + 16 * u + l16, last)];
+    };
+    float mx = 0.0f, my = 0.0f, mz = 0.0f;
+    float4 p[kRowBatch], pn[kRowBatch];
+    load_step(0, pn);
+    for (int j0 = 0; j0 < nmax; j0 += 16 * kRowBatch) {
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) p[u] = pn[u];
+        if (j0 + 16 * kRowBatch < nmax) load_step(j0 + 16 * kRowBatch, pn);
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) {
+            const int j = j0 + 16 * u + l16;
+            const int row = __float_as_int(p[u].w);
+            const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p[u].x, p[u].y, p[u].z);
+            const bool in = j < n;
+            RowChain<0>::add3f(mx, my, mz, in ? q.x : 0.0f, in ? q.y : 0.0f, in ? q.z : 0.0f);
+        }
+    }
+    const float nf = (float)n;
+    mx = row_first(mx) / nf, my = row_first(my) / nf, mz = row_first(mz) / nf;
+    const int gi = on ? g : 0;
+    const float4 i0 = info12[3 * gi], i1 = info12[3 * gi + 1], i2 = info12[3 * gi + 2];
+    const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
+    double acc = 0.0;
+    load_step(0, pn);
+    for (int j0 = 0; j0 < nmax; j0 += 16 * kRowBatch) {
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) p[u] = pn[u];
+        if (j0 + 16 * kRowBatch < nmax) load_step(j0 + 16 * kRowBatch, pn);
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) {
+            const int j = j0 + 16 * u + l16;
+            const int row = __float_as_int(p[u].w);
+            const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p[u].x, p[u].y, p[u].z);
+            const float d0 = q.x - mx, d1 = q.y - my, d2 = q.z - mz;
+            const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
+            const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
+            const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
+            const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
+            const float term = sum3f(v0 * d0, v1 * d1, v2 * d2);
+            RowChain<0>::add_f_to_d(acc, j < n ? term : 0.0f);
+        }
+    }
+    if (on && l16 == 0) E[(size_t)b * ldE + g] = sqrt(fabs(acc));
+}
+
+constexpr int kFitWaveThreshold = 1024;
+// Gaussians::addPointSet (Gaussians.h:130-168) with the oracle's serial double sums, one row per Gaussian (both levels, by
+// descending size like k_residuals_mirror_rows).
+__global__ __launch_bounds__(256) void k_gauss_fit_mirror_rows(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
+                                                               const float4* __restrict__ global, const uint32_t* __restrict__ order, int M,
+                                                               float* __restrict__ info12) {
+    const int l16 = threadIdx.x & 15;
+    {
+        const int task = blockIdx.x * 16 + (threadIdx.x >> 4);
+        const bool on = task < M;
+        const int g = on ? (int)order[task] : 0;
+        const int b = on ? seg_off[g] : 0;
+        int n = on ? seg_off[g + 1] - b : 0;
+        if (n > kFitWaveThreshold) n = 0;  // fitted by k_gauss_fit_mirror_wave (its chains split over the rows of a whole wave)
+        const int nmax = wave_max4(n);
+        if (nmax == 0) return;
+        constexpr int kRowBatch = 4;  // loads of 4 x 16 members in flight before the chains of a step (see k_residuals_mirror_rows)
+        const int last = max(n - 1, 0);
+        auto load_step = [&](int j0, float4* dst) {  // index + gather of the NEXT step overlap the chains of the current one
+#pragma unroll
+            for (int u = 0; u < kRowBatch; ++u) dst[u] = global[memb_idx[b + min(j0 + 16 * u + l16, last)]];
+        };
+        double sx = 0.0, sy = 0.0, sz = 0.0;
+        float4 p[kRowBatch], pn[kRowBatch];
+        load_step(0, pn);
+        for (int j0 = 0; j0 < nmax; j0 += 16 * kRowBatch) {
+#pragma unroll
+            for (int u = 0; u < kRowBatch; ++u) p[u] = pn[u];
+            if (j0 + 16 * kRowBatch < nmax) load_step(j0 + 16 * kRowBatch, pn);
+#pragma unroll
+            for (int u = 0; u < kRowBatch; ++u) {
+                const bool in = j0 + 16 * u + l16 < n;
+                float x = in ? p[u].x : 0.0f, y = in ? p[u].y : 0.0f, z = in ? p[u].z : 0.0f;
+                RowChain<0>::add3d_from_f(sx, sy, sz, x, y, z);
+            }
+        }
+        float mx = (float)(sx / (double)n), my = (float)(sy / (double)n), mz = (float)(sz / (double)n);
+        mx = row_first(mx), my = row_first(my), mz = row_first(mz);
+        double a[6] = {0, 0, 0, 0, 0, 0};
+        load_step(0, pn);
+        for (int j0 = 0; j0 < nmax; j0 += 16 * kRowBatch) {
+#pragma unroll
+            for (int u = 0; u < kRowBatch; ++u) p[u] = pn[u];
+            if (j0 + 16 * kRowBatch < nmax) load_step(j0 + 16 * kRowBatch, pn);
+#pragma unroll
+            for (int u = 0; u < kRowBatch; ++u) {
+                double v[6] = {0, 0, 0, 0, 0, 0};
+                if (j0 + 16 * u + l16 < n) {
+                    const float cx = p[u].x - mx, cy = p[u].y - my, cz = p[u].z - mz;
+                    v[0] = (double)cx * (double)cx, v[1] = (double)cx * (double)cy, v[2] = (double)cx * (double)cz;
+                    v[3] = (double)cy * (double)cy, v[4] = (double)cy * (double)cz, v[5] = (double)cz * (double)cz;
+                }
+                RowChain<0>::add6d(a, v);
+            }
+        }
+        if (on && n > 0 && l16 == 0) finish_gaussian(a[0], a[1], a[2], a[3], a[4], a[5], n, info12 + (size_t)g * 12);
+    }
+}
+
+// The long Gaussians are the critical path of the parity fit: nine serial double chains over up to 10^4 members.  The chains are
+// independent of each other, so a whole wave takes one Gaussian and spreads them over its four rows: three mean chains on rows
+// 0-2, then the six centred products as (row0: xx, yz) (row1: xy, zz) (row2: xz) (row3: yy).  Every chain is still the oracle's
+// serial sum in member order -> bit-identical.  All rows load the same members (L1 broadcast).
+__global__ __launch_bounds__(256) void k_gauss_fit_mirror_wave(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
+                                                               const float4* __restrict__ global, const uint32_t* __restrict__ order, int M,
+                                                               float* __restrict__ info12) {
+    const int task = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (task >= M) return;
+    const int g = (int)order[task];
+    const int b = seg_off[g], n = seg_off[g + 1] - b;
+    if (n <= kFitWaveThreshold) return;  // order is descending: everything after the first short Gaussian is short too
+    const int lane = threadIdx.x & 63, l16 = lane & 15, r = lane >> 4;
+    constexpr int kRowBatch = 4;
+    const int last = n - 1;
+    auto load_step = [&](int j0, float4* dst) {
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) dst[u] = global[memb_idx[b + min(j0 + 16 * u + l16, last)]];
+    };
+    float4 p[kRowBatch], pn[kRowBatch];
+    double s = 0.0;
+    load_step(0, pn);
+    for (int j0 = 0; j0 < n; j0 += 16 * kRowBatch) {
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) p[u] = pn[u];
+        if (j0 + 16 * kRowBatch < n) load_step(j0 + 16 * kRowBatch, pn);
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) {
+            const bool in = j0 + 16 * u + l16 < n;
+            float v = r == 0 ? p[u].x : (r == 1 ? p[u].y : (r == 2 ? p[u].z : 0.0f));
+            v = in ? v : 0.0f;
+            RowChain<0>::add1d_from_f(s, v);
+        }
+    }
+    const float mine = (float)(s / (double)n);  // valid in lane 0 of rows 0..2
+    const float mx = __shfl(mine, 0, 64), my = __shfl(mine, 16, 64), mz = __shfl(mine, 32, 64);
+    double a = 0.0, a2 = 0.0;
+    load_step(0, pn);
+    for (int j0 = 0; j0 < n; j0 += 16 * kRowBatch) {
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) p[u] = pn[u];
+        if (j0 + 16 * kRowBatch < n) load_step(j0 + 16 * kRowBatch, pn);
+#pragma unroll
+        for (int u = 0; u < kRowBatch; ++u) {
+            double va = 0.0, vb = 0.0;
+            if (j0 + 16 * u + l16 < n) {
+                const float cx = p[u].x - mx, cy = p[u].y - my, cz = p[u].z - mz;
+                const float fa0 = r == 3 ? cy : cx, fa1 = r == 0 ? cx : (r == 1 ? cy : (r == 2 ? cz : cy));  // xx, xy, xz, yy
+                const float fb0 = r == 0 ? cy : cz, fb1 = cz;                                                    // yz, zz
+                va = (double)fa0 * (double)fa1;
+                vb = r < 2 ? (double)fb0 * (double)fb1 : 0.0;
+            }
+            RowChain<0>::add2d(a, a2, va, vb);
+        }
+    }
+    // a: rows 0..3 = xx, xy, xz, yy ; a2: rows 0, 1 = yz, zz
+    const double axx = __shfl(a, 0, 64), axy = __shfl(a, 16, 64), axz = __shfl(a, 32, 64), ayy = __shfl(a, 48, 64), ayz = __shfl(a2, 0, 64), azz = __shfl(a2, 16, 64);
+    if (lane == 0) finish_gaussian(axx, axy, axz, ayy, ayz, azz, n, info12 + (size_t)g * 12);
+}
+
+__global__ __launch_bounds__(256) void k_gauss_size_keys(const int32_t* __restrict__ seg_off, int M, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < M) key[g] = 0xFFFFFFFFu - (uint32_t)(seg_off[g + 1] - seg_off[g]), val[g] = (uint32_t)g;  // ascending key = descending size
+}
+void launch_gauss_size_keys(const int32_t* seg_off, int M, uint32_t* key, uint32_t* val, hipStream_t s) {
+    if (M > 0) hipLaunchKernelGGL(k_gauss_size_keys, dim3((M + 255) / 256), dim3(256), 0, s, seg_off, M, key, val);
+}
+bool mirror_uses_rows() {
+    static const bool serial_threads = std::getenv("DMSA_MIRROR_THREADS") != nullptr;
+    return !serial_threads;
+}
+void launch_gauss_fit_mirror_rows(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const uint32_t* order, int M, float* info12,
+                                  hipStream_t s) {
+    if (M <= 0) return;
+    // long Gaussians first (they are the critical path), one wave each: waves whose Gaussian is at or below the threshold exit at
+    // once; the rows kernel fits exactly the complement
+    const int wave_tasks = M;
+    hipLaunchKernelGGL(k_gauss_fit_mirror_wave, dim3((wave_tasks + 3) / 4), dim3(256), 0, s, seg_off, memb_idx, global, order, M, info12);
+    hipLaunchKernelGGL(k_gauss_fit_mirror_rows, dim3((M + 15) / 16), dim3(256), 0, s, seg_off, memb_idx, global, order, M, info12);
+}
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
-                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s, bool pairs) {
+                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s, bool pairs, const uint32_t* order) {
     if (M <= 0 || B <= 0) return;
     const int seg_stride = pairs ? 2 : 1;
     const size_t lds = (size_t)rows * 48;
     static bool attr_set = false;
     if (mirror) {
         static bool attr_set_m = false;
-        const dim3 grid((M + 255) / 256, B);
-        if (lds <= 160 * 1024 - 1024) {
-            if (!attr_set_m) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals_mirror<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-                attr_set_m = true;
+        if (!mirror_uses_rows() || order == nullptr) {  // first-generation kernel: a thread per Gaussian (DMSA_MIRROR_THREADS=1)
+            const dim3 grid((M + 255) / 256, B);
+            if (lds <= 160 * 1024 - 1024) {
+                if (!attr_set_m) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals_mirror<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+                    attr_set_m = true;
+                }
+                hipLaunchKernelGGL(k_residuals_mirror<true>, grid, dim3(256), lds, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
+                                   reinterpret_cast<const float4*>(tables), rows, M, E, ldE);
+            } else {
+                hipLaunchKernelGGL(k_residuals_mirror<false>, grid, dim3(256), 0, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
+                                   reinterpret_cast<const float4*>(tables), rows, M, E, ldE);
             }
-            hipLaunchKernelGGL(k_residuals_mirror<true>, grid, dim3(256), lds, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
-                               reinterpret_cast<const float4*>(tables), rows, M, E, ldE);
+            return;
+        }
+        const int tblocks = (M + 15) / 16;  // 16 rows (Gaussians) per 256-thread workgroup
+        const int eval_major = tblocks <= 65535 ? 1 : 0;
+        const dim3 grid = eval_major ? dim3(B, tblocks) : dim3(tblocks, B);
+        static const bool table_global = std::getenv("DMSA_MIRROR_TABLE_GLOBAL") != nullptr;
+        if (lds <= 48 * 1024 && !table_global) {  // the table of one evaluation in LDS: three workgroups per CU
+            hipLaunchKernelGGL(k_residuals_mirror_rows<true>, grid, dim3(256), lds, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
+                               reinterpret_cast<const float4*>(tables), rows, M, order, eval_major, E, ldE);
         } else {
-            hipLaunchKernelGGL(k_residuals_mirror<false>, grid, dim3(256), 0, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
-                               reinterpret_cast<const float4*>(tables), rows, M, E, ldE);
+            hipLaunchKernelGGL(k_residuals_mirror_rows<false>, grid, dim3(256), 0, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
+                               reinterpret_cast<const float4*>(tables), rows, M, order, eval_major, E, ldE);
         }
         return;
     }
