@@ -133,6 +133,21 @@ def main():
                  "gaussian_fit_and_tiles": round(t2.gaussian_fit_ms / k, 4), "pose_tables": round(t2.pose_table_ms / k, 4),
                  "normal_eq": round(t2.normal_eq_ms / k, 4)}
         opt2.close()
+    # the bit-reproducible parity path (serial-order sums, host pose tables) on the same resident workload, outside the timed region
+    parity = None
+    if rank == 0 and not args.mirror:
+        opt3 = DmsaOptimizer(device=local_rank, fixed_iters=True, mirror_sums=True, pose_table_host=True)
+        opt3.upload(prob)
+        s3 = type(settings)(**{**settings.__dict__, "num_iter": 2})
+        opt3.optimizeResident(s3)
+        s3.num_iter = max(4, min(args.steps, 20))
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        r3 = opt3.optimizeResident(s3)
+        dt3 = time.perf_counter() - t3
+        parity = {"value": round(r3.iterations / dt3, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * dt3 / r3.iterations, 4),
+                  "note": "DMSA_FLAG_MIRROR_SUMS | DMSA_FLAG_POSE_TABLE_HOST: residual vectors bit-identical to the CPU oracle (tests/test_gpu_configs.py)"}
+        opt3.close()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -208,6 +223,7 @@ def main():
                          "frac": round(valu_tflops / 78.6, 4)},
             },
             "stage_ms_per_step": stage,
+            "parity_path": parity,
         }
         if world == 1 and args.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(prob, settings, args.cpu_iters, args.workload)
