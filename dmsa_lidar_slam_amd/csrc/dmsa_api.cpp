@@ -101,7 +101,7 @@ struct dmsa_ctx {
     // voxelisation
     // per-resolution scratch: the two voxelisations of an iteration run concurrently on `stream` and `stream2`
     DevBuf d_aabb, d_lattice, d_code[2], d_idx[2], d_code_s[2], d_idx_s[2], d_head[2], d_leaf_incl[2], d_leaf_start[2], d_slot_acc[2], d_slot_cnt[2],
-        d_gauss_of_slot[2], d_memb_of_slot[2], d_pos_slot_rank[2], d_nsorted[2], d_pair_d[2], d_pair_c[2], d_sort_tmp[2], d_scan_tmp[2], d_counts;
+        d_gauss_of_slot[2], d_memb_of_slot[2], d_pslot_of_slot[2], d_pos_slot_rank[2], d_nsorted[2], d_pair_d[2], d_pair_c[2], d_sort_tmp[2], d_scan_tmp[2], d_counts;
     LatticeTable h_lattice[2];
     bool key32[2] = {false, false};  // leaf codes of this level are 32-bit (tree depth <= 10)
     int depth_guess[2] = {-1, -1};   // tree depths of the previous voxelisation (speculation: saves one host sync)
@@ -112,7 +112,7 @@ struct dmsa_ctx {
     DevBuf d_memb_local, d_memb_idx, d_memb_g, d_seg_off, d_info12, d_wg_seg;
     DevBuf d_order_key, d_order_key_s, d_order_val, d_order;  // parity path: Gaussians by descending size
     bool order_valid = false;
-    DevBuf d_memb_tile, d_tiles, d_tile_counts, d_tile_rows, d_fallback;
+    DevBuf d_memb_tile, d_tiles, d_tile_counts, d_tile_rows, d_fallback, d_pad_off;
     int num_tiles = 0, num_fallback = 0, tile_max_rows = 0, tile_max_gauss = 0;
     bool use_tiles = true;  // DMSA_K4_TILES=0 selects the streaming kernel
     int M = 0, M1 = 0;
@@ -228,6 +228,7 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
         HIPCHK(ctx->d_slot_cnt[l].ensure(2 * n * 4));
         HIPCHK(ctx->d_gauss_of_slot[l].ensure(2 * n * 4));
         HIPCHK(ctx->d_memb_of_slot[l].ensure(2 * n * 4));
+        HIPCHK(ctx->d_pslot_of_slot[l].ensure(2 * n * 4));
         HIPCHK(ctx->d_sort_tmp[l].ensure(sort_pairs_temp_bytes(n)));
         HIPCHK(ctx->d_scan_tmp[l].ensure(scan_temp_bytes(2 * n)));
     }
@@ -243,8 +244,9 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
         for (DevBuf* b : {&ctx->d_order_key, &ctx->d_order_key_s, &ctx->d_order_val, &ctx->d_order}) HIPCHK(b->ensure((n + 16) * 4));
     // tiled correspondence kernels: windows of 3T/4 members plus own-tile Gaussians (> T/4 members each) and their
     // neighbours: tiles <= (4/3 + 8)*Mm/T + 1 with Mm <= 2n; one row list of `rows` entries per tile
-    const size_t max_tiles = 20 * n / (size_t)tile_points() + 64;
-    HIPCHK(ctx->d_memb_tile.ensure(2 * n * 16));
+    const size_t max_tiles = 41 * n / (size_t)tile_points() + 64;  // windows + own tiles + one head per kTileGauss Gaussians (M <= n)
+    HIPCHK(ctx->d_memb_tile.ensure(tile_slot_capacity(n) * 16));
+    HIPCHK(ctx->d_pad_off.ensure((2 * n + 2) * 4));
     HIPCHK(ctx->d_tiles.ensure(max_tiles * sizeof(TileDesc)));
     HIPCHK(ctx->d_tile_counts.ensure(sizeof(TileCounts)));
     HIPCHK(ctx->d_tile_rows.ensure(max_tiles * (size_t)ctx->rows * 4));
@@ -434,7 +436,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                               ctx->d_pair_d[l].as<unsigned long long>(), ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(),
                               ctx->d_pos_slot_rank[l].as<int32_t>(), st[l]);
         launch_leaf_scan(ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(), ctx->d_gauss_of_slot[l].as<int32_t>(), ctx->d_memb_of_slot[l].as<int32_t>(),
-                         &counts->level[l], st[l]);
+                         ctx->d_pslot_of_slot[l].as<int32_t>(), &counts->level[l], st[l]);
         return DMSA_OK;
     };
     auto stage_gather = [&](int l) {
@@ -443,7 +445,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                               ctx->d_code_s[l].p, k32v[l], tab, ctx->d_slot_acc[l].as<int32_t>(), ctx->d_gauss_of_slot[l].as<int32_t>(),
                               ctx->d_memb_of_slot[l].as<int32_t>(), split ? ctx->d_pos_slot_rank[l].as<int32_t>() : nullptr, ctx->d_local.as<float4>(),
                               ctx->d_slot_cnt[l].as<int32_t>(), counts, l, n, ctx->d_memb_local.as<float4>(), ctx->d_memb_idx.as<int32_t>(),
-                              ctx->d_memb_g.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), st[l]);
+                              ctx->d_memb_g.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), ctx->d_pslot_of_slot[l].as<int32_t>(), ctx->d_pad_off.as<int32_t>(), st[l]);
     };
     {
         ScopedTimer tm(ctx, T_VOXEL);
@@ -479,7 +481,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         ScopedTimer tm(ctx, T_FIT);
         launch_build_tiles(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_memb_local.as<float4>(), ctx->d_memb_g.as<int32_t>(), ctx->rows, ctx->d_tiles.as<TileDesc>(),
                            reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_memb_tile.as<float4>(), ctx->d_tile_rows.as<int32_t>(),
-                           ctx->stream);
+                           ctx->d_pad_off.as<int32_t>(), ctx->stream);
     }
     struct {
         GaussCounts g;
@@ -818,14 +820,14 @@ void dmsa_destroy(dmsa_ctx* ctx) {
                       &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
                       &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
                       &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_memb_g, &ctx->d_seg_off,
-                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_order_key, &ctx->d_order_key_s, &ctx->d_order_val, &ctx->d_order, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_counts, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
+                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_order_key, &ctx->d_order_key_s, &ctx->d_order_val, &ctx->d_order, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_counts, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_pad_off, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
     for (DevBuf* b : bufs) b->release();
     if (ctx->sp) {
         for (DevBuf* b : ctx->sp->all) b->release();
         delete ctx->sp;
     }
     for (int l = 0; l < 2; ++l)
-        for (DevBuf* b : {&ctx->d_head[l], &ctx->d_slot_acc[l], &ctx->d_slot_cnt[l], &ctx->d_gauss_of_slot[l], &ctx->d_memb_of_slot[l], &ctx->d_pos_slot_rank[l],
+        for (DevBuf* b : {&ctx->d_head[l], &ctx->d_slot_acc[l], &ctx->d_slot_cnt[l], &ctx->d_gauss_of_slot[l], &ctx->d_memb_of_slot[l], &ctx->d_pslot_of_slot[l], &ctx->d_pos_slot_rank[l],
                           &ctx->d_nsorted[l], &ctx->d_pair_d[l], &ctx->d_pair_c[l], &ctx->d_sort_tmp[l], &ctx->d_scan_tmp[l]})
             b->release();
     (void)hipStreamSynchronize(ctx->stream2);

@@ -95,14 +95,15 @@ size_t split_scratch_bytes(int64_t n);  // pair_best[n] + task list + counter
 void launch_leaf_split(const int32_t* leaf_incl, const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const float4* nglobal,
                        const LevelCounts* counts, int min_pts, int64_t n, float4* nsorted /* n */, unsigned long long* pair_best /* split_scratch_bytes(n) */,
                        int32_t* slot_acc, int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s);
-void launch_leaf_scan(const int32_t* slot_acc, const int32_t* slot_cnt, int32_t* gauss_of_slot, int32_t* memb_of_slot, LevelCounts* counts,
-                      hipStream_t s);
+void launch_leaf_scan(const int32_t* slot_acc, const int32_t* slot_cnt, int32_t* gauss_of_slot, int32_t* memb_of_slot,
+                      int32_t* pslot_of_slot /* prefix of the member counts rounded up to 8: tile slots */, LevelCounts* counts, hipStream_t s);
 void launch_level_totals(const int32_t* slot_acc, const int32_t* slot_cnt, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
                          LevelCounts* counts /* this level */, int64_t nslots, hipStream_t s);
 void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start, const uint32_t* idx_sorted, const void* code_sorted, bool key32,
                            const LatticeTable* table, const int32_t* slot_acc, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
                            const int32_t* pos_slot_rank /* or null */, const float4* local, const int32_t* slot_cnt, const GaussCounts* counts, int level,
-                           int64_t n, float4* memb_local, int32_t* memb_idx, int32_t* memb_g, int32_t* seg_off, hipStream_t s);
+                           int64_t n, float4* memb_local, int32_t* memb_idx, int32_t* memb_g, int32_t* seg_off, const int32_t* pslot_of_slot,
+                           int32_t* pad_off /* M+1 tile-slot offsets */, hipStream_t s);
 // ---- K3: Gaussian fit -------------------------------------------------------------------------------------
 // mirror == true: sums run serially in member order (bit-reproducible against the CPU restatement)
 void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const GaussCounts* counts, int level,
@@ -119,8 +120,11 @@ void launch_residuals(const float4* memb_local, const int32_t* seg_off, const fl
                       const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s, bool pairs = false,
                       const uint32_t* order = nullptr /* parity path: Gaussians by descending size */);
 // tiled variant (default fast path): tiles + per-tile row lists are rebuilt once per iteration
+// slots of the tile copy of the membership array: every Gaussian is padded to a multiple of 8 slots (Mm + 7 M <= 9 n)
+inline size_t tile_slot_capacity(size_t n_points) { return 9 * n_points + 64; }
 void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, const int32_t* memb_g, int rows, TileDesc* tiles,
-                        TileCounts* tc, int2* fallback, float4* memb_tile, int32_t* tile_rows, hipStream_t s);
+                        TileCounts* tc, int2* fallback, float4* memb_tile /* tile_slot_capacity(n) entries */, int32_t* tile_rows,
+                        int32_t* pad_off /* M+1 slot offsets */, hipStream_t s);
 int tile_points();
 void set_phase_clock_buffer(long long* p);  // debug instrumentation (-DDMSA_PHASE_CLOCKS builds only)
 // Gaussian fit on the tiles (fast path): info12[g] = information matrix of every accepted set, base pose table = table0

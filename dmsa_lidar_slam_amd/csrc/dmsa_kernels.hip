@@ -79,6 +79,8 @@ __device__ __forceinline__ float3 apply_row3(const float4 r0, const float4 r1, c
     return g;
 }
 __device__ __forceinline__ float sum3f(float a, float b, float c) { return a + (b + c); }
+// tile slots of a Gaussian with n members: rounded up to the 8 slots a thread of the tiled kernels owns (see k_tile_rows)
+__host__ __device__ __forceinline__ int pad_slots(int n) { return (n + 7) & ~7; }
 
 // ------------------------------------------------------------------------------------------------------------
 // K0 — transforms
@@ -926,16 +928,16 @@ void launch_leaf_split(const int32_t* leaf_incl, const int32_t* leaf_start, cons
 // device, and there are only ~10^4..10^5 leaves, so one 1024-thread workgroup walks them 4096 slots at a time.
 __global__ __launch_bounds__(1024) void k_leaf_scan(const int32_t* __restrict__ slot_acc, const int32_t* __restrict__ slot_cnt,
                                                     int32_t* __restrict__ gauss_of_slot, int32_t* __restrict__ memb_of_slot,
-                                                    LevelCounts* __restrict__ counts) {
+                                                    int32_t* __restrict__ pslot_of_slot, LevelCounts* __restrict__ counts) {
     constexpr int kPer = 16;  // slots per thread and round
-    __shared__ int s_w[16][2];
-    __shared__ int s_carry[2];
+    __shared__ int s_w[16][3];  // accepted sets, members, members rounded up to 8 (tile slots, see k_tile_rows)
+    __shared__ int s_carry[3];
     const int nslots = 2 * counts->num_leaves;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry[0] = 0, s_carry[1] = 0;
+    if (tid == 0) s_carry[0] = 0, s_carry[1] = 0, s_carry[2] = 0;
     __syncthreads();
     for (int base = 0; base < nslots; base += 1024 * kPer) {
-        int a[kPer], c[kPer], ta = 0, tc2 = 0;
+        int a[kPer], c[kPer], ta = 0, tc2 = 0, tp = 0;
         const int first = base + kPer * tid;
         if (first + kPer <= nslots) {  // vectorised: 4 x int4 per array
             const int4* pa = reinterpret_cast<const int4*>(slot_acc + first);
@@ -955,45 +957,47 @@ __global__ __launch_bounds__(1024) void k_leaf_scan(const int32_t* __restrict__ 
             }
         }
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) ta += a[k], tc2 += c[k];
-        int ia = ta, ic = tc2;
+        for (int k = 0; k < kPer; ++k) ta += a[k], tc2 += c[k], tp += pad_slots(c[k]);
+        int ia = ta, ic = tc2, ip = tp;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const int oa = __shfl_up(ia, d), oc = __shfl_up(ic, d);
-            if (lane >= d) ia += oa, ic += oc;
+            const int oa = __shfl_up(ia, d), oc = __shfl_up(ic, d), op = __shfl_up(ip, d);
+            if (lane >= d) ia += oa, ic += oc, ip += op;
         }
-        if (lane == 63) s_w[wave][0] = ia, s_w[wave][1] = ic;
+        if (lane == 63) s_w[wave][0] = ia, s_w[wave][1] = ic, s_w[wave][2] = ip;
         __syncthreads();
-        int ra = s_carry[0] + ia - ta, rc = s_carry[1] + ic - tc2;
-        for (int w = 0; w < wave; ++w) ra += s_w[w][0], rc += s_w[w][1];
-        int oa[kPer], oc[kPer];
+        int ra = s_carry[0] + ia - ta, rc = s_carry[1] + ic - tc2, rp = s_carry[2] + ip - tp;
+        for (int w = 0; w < wave; ++w) ra += s_w[w][0], rc += s_w[w][1], rp += s_w[w][2];
+        int oa[kPer], oc[kPer], op[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
-            oa[k] = ra, oc[k] = rc;
-            ra += a[k], rc += c[k];
+            oa[k] = ra, oc[k] = rc, op[k] = rp;
+            ra += a[k], rc += c[k], rp += pad_slots(c[k]);
         }
         if (first + kPer <= nslots) {  // 16-byte stores: 4x fewer (lane-strided) store instructions
             int4* qa = reinterpret_cast<int4*>(gauss_of_slot + first);
             int4* qc = reinterpret_cast<int4*>(memb_of_slot + first);
+            int4* qp = reinterpret_cast<int4*>(pslot_of_slot + first);
 #pragma unroll
             for (int k = 0; k < kPer / 4; ++k) {
                 qa[k] = make_int4(oa[4 * k], oa[4 * k + 1], oa[4 * k + 2], oa[4 * k + 3]);
                 qc[k] = make_int4(oc[4 * k], oc[4 * k + 1], oc[4 * k + 2], oc[4 * k + 3]);
+                qp[k] = make_int4(op[4 * k], op[4 * k + 1], op[4 * k + 2], op[4 * k + 3]);
             }
         } else {
 #pragma unroll
             for (int k = 0; k < kPer; ++k)
-                if (first + k < nslots) gauss_of_slot[first + k] = oa[k], memb_of_slot[first + k] = oc[k];
+                if (first + k < nslots) gauss_of_slot[first + k] = oa[k], memb_of_slot[first + k] = oc[k], pslot_of_slot[first + k] = op[k];
         }
         __syncthreads();
-        if (tid == 1023) s_carry[0] = ra, s_carry[1] = rc;
+        if (tid == 1023) s_carry[0] = ra, s_carry[1] = rc, s_carry[2] = rp;
         __syncthreads();
     }
-    if (tid == 0) counts->num_gauss = s_carry[0], counts->num_memb = s_carry[1];
+    if (tid == 0) counts->num_gauss = s_carry[0], counts->num_memb = s_carry[1], counts->pad = s_carry[2];  // pad: tile slots of the level
 }
-void launch_leaf_scan(const int32_t* slot_acc, const int32_t* slot_cnt, int32_t* gauss_of_slot, int32_t* memb_of_slot, LevelCounts* counts,
+void launch_leaf_scan(const int32_t* slot_acc, const int32_t* slot_cnt, int32_t* gauss_of_slot, int32_t* memb_of_slot, int32_t* pslot_of_slot, LevelCounts* counts,
                       hipStream_t s) {
-    hipLaunchKernelGGL(k_leaf_scan, dim3(1), dim3(1024), 0, s, slot_acc, slot_cnt, gauss_of_slot, memb_of_slot, counts);
+    hipLaunchKernelGGL(k_leaf_scan, dim3(1), dim3(1024), 0, s, slot_acc, slot_cnt, gauss_of_slot, memb_of_slot, pslot_of_slot, counts);
 }
 
 __global__ void k_level_totals(const int32_t* __restrict__ slot_acc, const int32_t* __restrict__ slot_cnt, const int32_t* __restrict__ gauss_of_slot,
@@ -1016,13 +1020,18 @@ __global__ __launch_bounds__(256) void k_gather_members(const int32_t* __restric
                                                         const int32_t* __restrict__ pos_slot_rank, const float4* __restrict__ local,
                                                         const int32_t* __restrict__ slot_cnt, const GaussCounts* __restrict__ counts, int level,
                                                         int64_t n, float4* __restrict__ memb_local, int32_t* __restrict__ memb_idx,
-                                                        int32_t* __restrict__ memb_g, int32_t* __restrict__ seg_off) {
+                                                        int32_t* __restrict__ memb_g, int32_t* __restrict__ seg_off,
+                                                        const int32_t* __restrict__ pslot_of_slot, int32_t* __restrict__ pad_off) {
     const KeyT invalid = (KeyT)lattice_invalid_code(*table);
     const int gbase = level == 0 ? 0 : counts->level[0].num_gauss;
     const int mbase = level == 0 ? 0 : counts->level[0].num_memb;
+    const int pbase = level == 0 ? 0 : counts->level[0].pad;  // tile-slot offsets continue behind level 0 like the member offsets
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid0 == 0) seg_off[gbase + counts->level[level].num_gauss] = mbase + counts->level[level].num_memb;
+    if (tid0 == 0) {
+        seg_off[gbase + counts->level[level].num_gauss] = mbase + counts->level[level].num_memb;
+        pad_off[gbase + counts->level[level].num_gauss] = pbase + counts->level[level].pad;
+    }
     for (int64_t i = tid0; i < n; i += stride) {
         if (code[i] == invalid) continue;
         const int l = leaf_incl[i] - 1;
@@ -1041,22 +1050,23 @@ __global__ __launch_bounds__(256) void k_gather_members(const int32_t* __restric
         memb_local[dst] = local[pi];
         memb_idx[dst] = (int32_t)pi;
         memb_g[dst] = (int32_t)((uint32_t)g | (rank == slot_cnt[slot] - 1 ? 0x80000000u : 0u));  // Gaussian id, bit 31: last member
-        if (rank == 0) seg_off[g] = dst;
+        if (rank == 0) seg_off[g] = dst, pad_off[g] = pbase + pslot_of_slot[slot];
     }
 }
 void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start, const uint32_t* idx_sorted, const void* code_sorted, bool key32,
                            const LatticeTable* table, const int32_t* slot_acc, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
                            const int32_t* pos_slot_rank, const float4* local, const int32_t* slot_cnt, const GaussCounts* counts, int level, int64_t n,
-                           float4* memb_local, int32_t* memb_idx, int32_t* memb_g, int32_t* seg_off, hipStream_t s) {
+                           float4* memb_local, int32_t* memb_idx, int32_t* memb_g, int32_t* seg_off, const int32_t* pslot_of_slot, int32_t* pad_off,
+                           hipStream_t s) {
     if (n <= 0) return;
     if (key32)
         hipLaunchKernelGGL(k_gather_members<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, leaf_of_pos, leaf_start, idx_sorted,
                            (const uint32_t*)code_sorted, table, slot_acc, gauss_of_slot, memb_of_slot, pos_slot_rank, local, slot_cnt, counts, level, n,
-                           memb_local, memb_idx, memb_g, seg_off);
+                           memb_local, memb_idx, memb_g, seg_off, pslot_of_slot, pad_off);
     else
         hipLaunchKernelGGL(k_gather_members<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, leaf_of_pos, leaf_start, idx_sorted,
                            (const uint64_t*)code_sorted, table, slot_acc, gauss_of_slot, memb_of_slot, pos_slot_rank, local, slot_cnt, counts, level, n,
-                           memb_local, memb_idx, memb_g, seg_off);
+                           memb_local, memb_idx, memb_g, seg_off, pslot_of_slot, pad_off);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1368,36 +1378,46 @@ constexpr int kTilePoints = 4096;
 constexpr int kTileThreads = 512;
 constexpr int kTilePpt = kTilePoints / kTileThreads;   // 8 members per thread
 constexpr int kTileGauss = 128;                         // Gaussians per tile (keeps the per-Gaussian LDS arrays small)
-// packed .w of a tile member: bits 0-11 rank of its pose-table row in the tile's row list, bits 12-21 Gaussian index
-// inside the tile, bit 31 set on the last member of a Gaussian
+// Tile slots: every Gaussian starts at a multiple of kTilePpt slots of the tile copy of the membership array (pad_off) and
+// its tail is filled with NULL slots, so the 8 slots of a thread always belong to ONE Gaussian: no partial sums inside a thread,
+// the information matrix / mean are read once per thread, the per-Gaussian prefix samples are the thread's inclusive prefix.
+// packed .w of a slot: bits 0-11 rank of its pose-table row in the tile's row list (null slots: the all-zero row appended after
+// the list, which transforms any point to exactly 0), bits 12-21 Gaussian index inside the tile, bit 30 null slot, bit 31 set on
+// the LAST SLOT of a Gaussian.
 __device__ __forceinline__ int tw_row(int w) { return w & 0xfff; }
 __device__ __forceinline__ int tw_gauss(int w) { return (w >> 12) & 0x3ff; }
 __device__ __forceinline__ bool tw_end(int w) { return w < 0; }
+__device__ __forceinline__ bool tw_null(int w) { return (w & 0x40000000) != 0; }
 
 constexpr int kBuildTilesLdsInts = 36 * 1024;  // 144 KB
 __global__ __launch_bounds__(1024) void k_build_tiles(const int32_t* __restrict__ seg_off_g, const GaussCounts* __restrict__ counts,
-                                                      TileDesc* __restrict__ tiles, TileCounts* __restrict__ tc, int2* __restrict__ fallback) {
+                                                      TileDesc* __restrict__ tiles, TileCounts* __restrict__ tc, int2* __restrict__ fallback,
+                                                      const int32_t* __restrict__ pad_off_g) {
     __shared__ int s_wave[16];
     __shared__ int s_nbig;
-    extern __shared__ int s_seg[];             // seg_off staged in LDS when it fits (coalesced read, random access after)
+    extern __shared__ int s_lds[];             // seg_off and pad_off staged in LDS when they fit (coalesced read, random access after)
     const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
-    const int half = 3 * kTilePoints / 4;      // window of member positions that starts a new tile
-    const int own_n = kTilePoints / 4;         // Gaussians above this size get a tile of their own (tile <= window + own_n)
+    const int half = 3 * kTilePoints / 4;      // window of SLOT positions that starts a new tile
+    const int own_n = kTilePoints / 4;         // Gaussians above this size get a tile of their own (tile <= window + own_n slots)
     if (threadIdx.x == 0) s_nbig = 0;
-    const bool in_lds = M + 1 <= kBuildTilesLdsInts;
+    const bool in_lds = 2 * (M + 1) <= kBuildTilesLdsInts;
+    int* s_seg = s_lds;
+    int* s_pad = s_lds + (M + 1);
     if (in_lds)
-        for (int i = threadIdx.x; i <= M; i += 1024) s_seg[i] = seg_off_g[i];
+        for (int i = threadIdx.x; i <= M; i += 1024) s_seg[i] = seg_off_g[i], s_pad[i] = pad_off_g[i];
     __syncthreads();
     const int32_t* seg_off = in_lds ? s_seg : seg_off_g;
-    auto own = [&](int g) { return seg_off[g + 1] - seg_off[g] > own_n; };
-    // a tile ends at own-tile Gaussians, at window boundaries of the member positions and every kTileGauss Gaussians
-    auto head = [&](int g) { return g == 0 || own(g) || own(g - 1) || (seg_off[g] / half) != (seg_off[g - 1] / half) || (g % kTileGauss) == 0; };
-    // every thread owns a contiguous run of Gaussians: count its tile heads, scan the counts once, then number the tiles
+    const int32_t* pad_off = in_lds ? s_pad : pad_off_g;  // slot offsets (members rounded up to 8 per Gaussian), written by k_gather_members
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // every thread owns a contiguous run of Gaussians
     const int per = (M + 1023) / 1024;
     const int g_lo = min(M, per * (int)threadIdx.x), g_hi = min(M, g_lo + per);
+    auto own = [&](int g) { return seg_off[g + 1] - seg_off[g] > own_n; };
+    // a tile ends at own-tile Gaussians, at window boundaries of the slot positions and every kTileGauss Gaussians
+    auto head = [&](int g) { return g == 0 || own(g) || own(g - 1) || (pad_off[g] / half) != (pad_off[g - 1] / half) || (g % kTileGauss) == 0; };
+    // count the tile heads of the run, scan the counts once, then number the tiles
     int cnt = 0;
     for (int g = g_lo; g < g_hi; ++g) cnt += head(g) ? 1 : 0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int v = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1415,31 +1435,40 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const int32_t* __restrict_
     for (int g = g_lo; g < g_hi; ++g) {
         if (head(g)) {
             const int n = seg_off[g + 1] - seg_off[g];
-            tiles[t].g0 = g, tiles[t].p0 = seg_off[g];
+            tiles[t].g0 = g, tiles[t].p0 = pad_off[g];
             const int kind = n > kTilePoints ? 1 : 0;  // 1: streamed by k_residuals_big, any size
             tiles[t].kind = kind;
             tiles[t].row_off = 0, tiles[t].nrows = 0, tiles[t].pad = 0;
             if (kind == 1) fallback[atomicAdd(&s_nbig, 1)] = make_int2(t, g);
             ++t;
         }
-        if (g == M - 1 || head(g + 1)) tiles[t - 1].g1 = g + 1, tiles[t - 1].p1 = seg_off[g + 1];
+        if (g == M - 1 || head(g + 1)) {
+            // slots [p0, p1): padded for staged tiles; a single streamed Gaussian ends at its last real member
+            const int n = seg_off[g + 1] - seg_off[g];
+            const bool big = n > kTilePoints;  // such a Gaussian is the head and the only member of its tile
+            tiles[t - 1].g1 = g + 1, tiles[t - 1].p1 = big ? pad_off[g] + n : pad_off[g + 1];
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) tc->num_tiles = total, tc->num_fallback = s_nbig, tc->max_rows = 0, tc->max_gauss = 0;
 }
 
-// Per tile: which pose-table rows do its members reference?  Writes the ascending row list, a copy of the members
-// whose .w is the rank of their row in that list, and the maximum list length (sizes the LDS table of the kernels).
+// Per tile: which pose-table rows do its members reference?  Writes the ascending row list, the SLOT copy of the members
+// (every Gaussian at its padded offset, .w = rank of the row in that list + Gaussian-in-tile + flags, null slots behind the last
+// member) and the maximum list length + 1 (sizes the LDS table of the kernels; the extra row is the all-zero row of null slots).
 __global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles, TileCounts* __restrict__ tc, const float4* __restrict__ memb,
-                                                   const int32_t* __restrict__ memb_g, int rows, float4* __restrict__ memb_tile,
+                                                   const int32_t* __restrict__ memb_g, const int32_t* __restrict__ seg_off,
+                                                   const int32_t* __restrict__ pad_off, int rows, float4* __restrict__ memb_tile,
                                                    int32_t* __restrict__ tile_rows) {
     extern __shared__ uint32_t s_bm[];  // words bitmap, then words prefix
+    __shared__ int s_nrows;
     const int words = (rows + 31) / 32;
     uint32_t* s_pre = s_bm + words;
     const int nt = tc->num_tiles;
     int wg_max_rows = 0, wg_max_gauss = 0;  // thread 0 only; published once per workgroup
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
-        const int p0 = tiles[t].p0, p1 = tiles[t].p1, tg0 = tiles[t].g0, tg1 = tiles[t].g1;
+        const int tg0 = tiles[t].g0, tg1 = tiles[t].g1;
+        const int p0 = seg_off[tg0], p1 = seg_off[tg1];  // member positions of the tile in the (unpadded) membership array
         for (int w = threadIdx.x; w < words; w += blockDim.x) s_bm[w] = 0u;
         __syncthreads();
         for (int i0 = p0 + threadIdx.x; i0 < p1; i0 += 4 * blockDim.x) {  // four independent loads in flight per lane
@@ -1464,9 +1493,11 @@ __global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles,
             }
             tiles[t].row_off = t * rows;
             tiles[t].nrows = (int)acc;
-            wg_max_rows = max(wg_max_rows, (int)acc), wg_max_gauss = max(wg_max_gauss, tg1 - tg0);
+            s_nrows = (int)acc;
+            wg_max_rows = max(wg_max_rows, (int)acc + 1), wg_max_gauss = max(wg_max_gauss, tg1 - tg0);
         }
         __syncthreads();
+        const uint32_t zero_row = (uint32_t)s_nrows;  // rank of the all-zero row the kernels append to the tile's rows
         for (int w = threadIdx.x; w < words; w += blockDim.x) {
             uint32_t bits = s_bm[w];
             int k = (int)s_pre[w];
@@ -1491,9 +1522,15 @@ __global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles,
                 if (i < p1) {
                     const int row = __float_as_int(pv[u].w);
                     const int lrow = (int)s_pre[row >> 5] + __popc(s_bm[row >> 5] & ((1u << (row & 31)) - 1u));
-                    const uint32_t packed = (uint32_t)lrow | (((gm[u] & 0x7fffffffu) - (uint32_t)tg0) << 12) | (gm[u] & 0x80000000u);
-                    pv[u].w = __int_as_float((int)packed);
-                    memb_tile[i] = pv[u];
+                    const int g = (int)(gm[u] & 0x7fffffffu);
+                    const bool last = (gm[u] & 0x80000000u) != 0;
+                    const int gb = seg_off[g], slot = pad_off[g] + (i - gb);
+                    const uint32_t gbits = (uint32_t)(g - tg0) << 12;
+                    const int nulls = last ? pad_off[g] + pad_slots(i + 1 - gb) - (slot + 1) : 0;  // slots behind the last member
+                    pv[u].w = __int_as_float((int)((uint32_t)lrow | gbits | ((last && nulls == 0) ? 0x80000000u : 0u)));
+                    memb_tile[slot] = pv[u];
+                    for (int z = 1; z <= nulls; ++z)
+                        memb_tile[slot + z] = make_float4(0.f, 0.f, 0.f, __int_as_float((int)(zero_row | gbits | 0x40000000u | (z == nulls ? 0x80000000u : 0u))));
                 }
             }
         }
@@ -1505,15 +1542,15 @@ __global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles,
     }
 }
 void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, const int32_t* memb_g, int rows, TileDesc* tiles,
-                        TileCounts* tc, int2* fallback, float4* memb_tile, int32_t* tile_rows, hipStream_t s) {
+                        TileCounts* tc, int2* fallback, float4* memb_tile, int32_t* tile_rows, int32_t* pad_off, hipStream_t s) {
     static bool bt_attr = false;
     if (!bt_attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, kBuildTilesLdsInts * 4);
         bt_attr = true;
     }
-    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(1024), kBuildTilesLdsInts * 4, s, seg_off, counts, tiles, tc, fallback);
+    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(1024), kBuildTilesLdsInts * 4, s, seg_off, counts, tiles, tc, fallback, pad_off);
     const size_t lds = (size_t)((rows + 31) / 32) * 8;
-    hipLaunchKernelGGL(k_tile_rows, dim3(1024), dim3(256), lds, s, tiles, tc, memb, memb_g, rows, memb_tile, tile_rows);
+    hipLaunchKernelGGL(k_tile_rows, dim3(1024), dim3(256), lds, s, tiles, tc, memb, memb_g, seg_off, pad_off, rows, memb_tile, tile_rows);
 }
 int tile_points() { return kTilePoints; }
 
@@ -1561,10 +1598,13 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
         const float4 v = memb_tile[td.p0 + min(i, np - 1)];  // unconditional load + select keeps pt[] in registers
         pt[k] = i < np ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const bool wave_on = kTilePpt * 64 * wave < np;  // wave-uniform: does this wave own any member?
-    bool any_end = false;                               // does this THREAD own the last member of some Gaussian?
+    const bool wave_on = kTilePpt * 64 * wave < np;  // wave-uniform: does this wave own any slot?
+    // the 8 slots of a thread belong to ONE Gaussian (slot layout of k_tile_rows); its last slot carries the end flag
+    const int my_g = tw_gauss(__float_as_int(pt[0].w));
+    const bool is_end = tw_end(__float_as_int(pt[kTilePpt - 1].w)) && kTilePpt * tid < np;
+    unsigned null_mask = 0;  // null slots transform to exactly 0 (zero row) and their Mahalanobis terms are dropped
 #pragma unroll
-    for (int k = 0; k < kTilePpt; ++k) any_end = any_end || tw_end(__float_as_int(pt[k].w));
+    for (int k = 0; k < kTilePpt; ++k) null_mask |= (tw_null(__float_as_int(pt[k].w)) ? 1u : 0u) << k;
     for (int q = tid; q < 3 * ng; q += kTileThreads) s_info[q] = info12[3 * td.g0 + q];
     for (int g = tid; g < ng; g += kTileThreads) s_nf[g] = (float)(seg_off[td.g0 + g + 1] - seg_off[td.g0 + g]);
     if (tid < 8) s_end[tid * kEndStride] = 0.0;  // prefix "before the first Gaussian", both parities x 4 components
@@ -1578,6 +1618,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
     if (tid + kTileThreads < nq) src1 = 3 * my_rows[(tid + kTileThreads) / 3] + ((tid + kTileThreads) % 3);
     if (tid + 2 * kTileThreads < nq) src2 = 3 * my_rows[(tid + 2 * kTileThreads) / 3] + ((tid + 2 * kTileThreads) % 3);
     const bool direct = nq > 3 * kTileThreads;  // tiles referencing > 512 rows: plain staging (two extra barriers)
+    if (tid < 6) s_tab[(size_t)(tid / 3) * max_rows * 3 + nq + (tid % 3)] = make_float4(0.f, 0.f, 0.f, 0.f);  // the zero row, both parities
     float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0, nx2 = nx0;
     if (b_begin < b_end && !direct) {
         const float4* gtab = tables + (size_t)b_begin * rows * 3;
@@ -1634,19 +1675,10 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
             const double tx = (double)fx, ty = (double)fy, tz = (double)fz;
             const double ix = wave_incl_scan_dpp(tx), iy = wave_incl_scan_dpp(ty), iz = wave_incl_scan_dpp(tz);
             if (lane == 63) wavep[4 * wave] = ix, wavep[4 * wave + 1] = iy, wavep[4 * wave + 2] = iz;
-            if (wave_on && any_end) {
-                const double rx = ix - tx, ry = iy - ty, rz = iz - tz;
-                fx = 0.0f, fy = 0.0f, fz = 0.0f;
-#pragma unroll
-                for (int k = 0; k < kTilePpt; ++k) {
-                    fx += gx[k], fy += gy[k], fz += gz[k];
-                    const int wv = __float_as_int(pt[k].w);
-                    if (tw_end(wv)) {
-                        const int lg = tw_gauss(wv) + 1;
-                        endp[lg] = rx + (double)fx, endp[kEndStride + lg] = ry + (double)fy, endp[2 * kEndStride + lg] = rz + (double)fz;
-                        endw[lg] = wave;
-                    }
-                }
+            if (is_end) {  // inclusive prefix at the last slot of my Gaussian
+                const int lg = my_g + 1;
+                endp[lg] = ix, endp[kEndStride + lg] = iy, endp[2 * kEndStride + lg] = iz;
+                endw[lg] = wave;
             }
         }
         PHASE(2)
@@ -1679,24 +1711,22 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
         PHASE(5)
         __syncthreads();  // B2
         PHASE(4)
-        // ---- pass 2: Mahalanobis terms (float, reference operation order); gx[k] is overwritten by the member's term ----
+        // ---- pass 2: Mahalanobis terms (float, reference operation order) ----
         float fq = 0.0f;
         if (wave_on) {
+            // information matrix / weight / mean of my Gaussian: one LDS read per thread and evaluation
+            const float4 i0 = s_info[3 * my_g], i1 = s_info[3 * my_g + 1], i2 = s_info[3 * my_g + 2];
+            const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
+            const float mx = s_mean[my_g], my = s_mean[kTileGauss + my_g], mz = s_mean[2 * kTileGauss + my_g];
 #pragma unroll
             for (int k = 0; k < kTilePpt; ++k) {
-                // information matrix / weight / mean of this member's Gaussian straight from LDS (broadcast reads)
-                const int lg = tw_gauss(__float_as_int(pt[k].w));
-                const float4 i0 = s_info[3 * lg], i1 = s_info[3 * lg + 1], i2 = s_info[3 * lg + 2];
-                const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
-                const float mx = s_mean[lg], my = s_mean[kTileGauss + lg], mz = s_mean[2 * kTileGauss + lg];
                 const float d0 = gx[k] - mx, d1 = gy[k] - my, d2 = gz[k] - mz;
                 const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
                 const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
                 const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
                 const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
-                gx[k] = sum3f(v0 * d0, v1 * d1, v2 * d2);
-                fq += gx[k];
-                asm volatile("" ::: "memory");
+                const float e = sum3f(v0 * d0, v1 * d1, v2 * d2);
+                fq += (null_mask >> k) & 1u ? 0.0f : e;
             }
         }
         PHASE(6)
@@ -1704,16 +1734,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
             const double tq = (double)fq;
             const double iq = wave_incl_scan_dpp(tq);
             if (lane == 63) wavep[4 * wave + 3] = iq;
-            if (wave_on && any_end) {
-                const double rq = iq - tq;
-                fq = 0.0f;
-#pragma unroll
-                for (int k = 0; k < kTilePpt; ++k) {
-                    fq += gx[k];
-                    const int wv = __float_as_int(pt[k].w);
-                    if (tw_end(wv)) endp[3 * kEndStride + tw_gauss(wv) + 1] = rq + (double)fq;
-                }
-            }
+            if (is_end) endp[3 * kEndStride + my_g + 1] = iq;
         }
         PHASE(7)
         __syncthreads();  // B3
@@ -1853,39 +1874,43 @@ __global__ __launch_bounds__(kTileThreads, 2) void k_fit_tiles(const float4* __r
         const int np = td.p1 - td.p0, ng = td.g1 - td.g0;
         __syncthreads();
         for (int q = tid; q < td.nrows * 3; q += kTileThreads) s_tab[q] = table0[3 * tile_rows[td.row_off + q / 3] + (q % 3)];
+        if (tid < 3) s_tab[td.nrows * 3 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // the zero row of the null slots
         if (tid < 9) s_end[tid * (kTileGauss + 1)] = 0.0;
         __syncthreads();
+        // the 8 slots of a thread belong to one Gaussian (slot layout of k_tile_rows)
         float gx[kTilePpt], gy[kTilePpt], gz[kTilePpt];
-        int wv[kTilePpt];
+        unsigned null_mask = 0;
+        int w0 = 0, w7 = 0;
         double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < kTilePpt; ++k) {
             const int i = kTilePpt * tid + k;
             const float4 v = memb_tile[td.p0 + min(i, np - 1)];
             const float4 p = i < np ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            wv[k] = __float_as_int(p.w);
-            const int row = tw_row(wv[k]);
+            const int wv = __float_as_int(p.w);
+            if (k == 0) w0 = wv;
+            if (k == kTilePpt - 1) w7 = wv;
+            null_mask |= (tw_null(wv) ? 1u : 0u) << k;
+            const int row = tw_row(wv);
             const float3 q = apply_row3(s_tab[3 * row], s_tab[3 * row + 1], s_tab[3 * row + 2], p.x, p.y, p.z);
             gx[k] = q.x, gy[k] = q.y, gz[k] = q.z;
             acc[0] += (double)q.x, acc[1] += (double)q.y, acc[2] += (double)q.z;
             asm volatile("" ::: "memory");
         }
-        double run[3];
+        const int my_g = tw_gauss(w0);
+        const bool is_end = tw_end(w7) && kTilePpt * tid < np;
+        double inc3[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const double inc = wave_incl_scan_dpp(acc[c]);
-            if (lane == 63) s_wave[9 * wave + c] = inc;
-            run[c] = inc - acc[c];
+            inc3[c] = wave_incl_scan_dpp(acc[c]);
+            if (lane == 63) s_wave[9 * wave + c] = inc3[c];
         }
         __syncthreads();
-        for (int w2 = 0; w2 < wave; ++w2)
-            for (int c = 0; c < 3; ++c) run[c] += s_wave[9 * w2 + c];
-#pragma unroll
-        for (int k = 0; k < kTilePpt; ++k) {
-            run[0] += (double)gx[k], run[1] += (double)gy[k], run[2] += (double)gz[k];
-            if (tw_end(wv[k])) {
-                const int lg = tw_gauss(wv[k]) + 1;
-                for (int c = 0; c < 3; ++c) s_end[c * (kTileGauss + 1) + lg] = run[c];
+        if (is_end) {
+            for (int c = 0; c < 3; ++c) {
+                double r = inc3[c];
+                for (int w2 = 0; w2 < wave; ++w2) r += s_wave[9 * w2 + c];
+                s_end[c * (kTileGauss + 1) + my_g + 1] = r;
             }
         }
         __syncthreads();
@@ -1895,32 +1920,28 @@ __global__ __launch_bounds__(kTileThreads, 2) void k_fit_tiles(const float4* __r
         }
         __syncthreads();
         double a6[6] = {0, 0, 0, 0, 0, 0};
+        {
+            const float mx = s_mean[my_g], my = s_mean[kTileGauss + my_g], mz = s_mean[2 * kTileGauss + my_g];
 #pragma unroll
-        for (int k = 0; k < kTilePpt; ++k) {
-            const int lg = tw_gauss(wv[k]);
-            const float cx = gx[k] - s_mean[lg], cy = gy[k] - s_mean[kTileGauss + lg], cz = gz[k] - s_mean[2 * kTileGauss + lg];
-            gx[k] = cx, gy[k] = cy, gz[k] = cz;
-            a6[0] += (double)cx * (double)cx, a6[1] += (double)cx * (double)cy, a6[2] += (double)cx * (double)cz;
-            a6[3] += (double)cy * (double)cy, a6[4] += (double)cy * (double)cz, a6[5] += (double)cz * (double)cz;
+            for (int k = 0; k < kTilePpt; ++k) {
+                const bool nul = (null_mask >> k) & 1u;
+                const float cx = nul ? 0.0f : gx[k] - mx, cy = nul ? 0.0f : gy[k] - my, cz = nul ? 0.0f : gz[k] - mz;
+                a6[0] += (double)cx * (double)cx, a6[1] += (double)cx * (double)cy, a6[2] += (double)cx * (double)cz;
+                a6[3] += (double)cy * (double)cy, a6[4] += (double)cy * (double)cz, a6[5] += (double)cz * (double)cz;
+            }
         }
-        double run6[6];
+        double inc6[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const double inc = wave_incl_scan_dpp(a6[c]);
-            if (lane == 63) s_wave[9 * wave + 3 + c] = inc;
-            run6[c] = inc - a6[c];
+            inc6[c] = wave_incl_scan_dpp(a6[c]);
+            if (lane == 63) s_wave[9 * wave + 3 + c] = inc6[c];
         }
         __syncthreads();
-        for (int w2 = 0; w2 < wave; ++w2)
-            for (int c = 0; c < 6; ++c) run6[c] += s_wave[9 * w2 + 3 + c];
-#pragma unroll
-        for (int k = 0; k < kTilePpt; ++k) {
-            const float cx = gx[k], cy = gy[k], cz = gz[k];
-            run6[0] += (double)cx * (double)cx, run6[1] += (double)cx * (double)cy, run6[2] += (double)cx * (double)cz;
-            run6[3] += (double)cy * (double)cy, run6[4] += (double)cy * (double)cz, run6[5] += (double)cz * (double)cz;
-            if (tw_end(wv[k])) {
-                const int lg = tw_gauss(wv[k]) + 1;
-                for (int c = 0; c < 6; ++c) s_end[(3 + c) * (kTileGauss + 1) + lg] = run6[c];
+        if (is_end) {
+            for (int c = 0; c < 6; ++c) {
+                double r = inc6[c];
+                for (int w2 = 0; w2 < wave; ++w2) r += s_wave[9 * w2 + 3 + c];
+                s_end[(3 + c) * (kTileGauss + 1) + my_g + 1] = r;
             }
         }
         __syncthreads();
