@@ -76,7 +76,7 @@ struct dmsa_ctx {
     int device = 0;
     uint32_t flags = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;  // stream2 carries the second voxel level only
-    hipEvent_t ev_fork = nullptr, ev_scan0 = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_scan0 = nullptr, ev_join = nullptr, ev_counts = nullptr;
     bool dual_stream = true;  // DMSA_DUAL_STREAM=0: both levels on `stream`
     std::string err;
 
@@ -489,8 +489,25 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     } both{};
     HIPCHK(hipMemcpyAsync(&both, ctx->d_counts.p, sizeof(both), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));  // incl. out_of_range
+    // The fit does not need the counts on the host (fixed grids, device-side tile counts): with the LDS table sized for ALL pose rows
+    // it is enqueued right behind the read-back, so the GPU keeps working while the host waits for M (sync #2 waits on an event
+    // recorded BEFORE the fit, not on the stream).
+    const bool early_fit = tiles_on && (size_t)(ctx->rows + 1) * 48 <= 56 * 1024;
+    HIPCHK(hipEventRecord(ctx->ev_counts, ctx->stream));
+    if (early_fit) {
+        ScopedTimer tm(ctx, T_FIT);
+        launch_fit_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_tables.as<float>(), ctx->rows + 1, ctx->d_tiles.as<TileDesc>(),
+                         reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
+                         ctx->d_info12.as<float>(), ctx->stream);
+        launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), false, ctx->stream);
+    }
     if (overlap) CHK(overlap());
-    HIPCHK(sync_spin(ctx->stream));  // sync #2: M sizes every later launch
+    {  // sync #2: M sizes every later launch
+        hipError_t e;
+        while ((e = hipEventQuery(ctx->ev_counts)) == hipErrorNotReady) {
+        }
+        HIPCHK(e);
+    }
     const GaussCounts h = both.g;
     htc = both.t;
     for (int l = 0; l < 2; ++l) {
@@ -510,7 +527,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     ctx->num_tiles = htc.num_tiles, ctx->num_fallback = htc.num_fallback, ctx->tile_max_rows = htc.max_rows, ctx->tile_max_gauss = htc.max_gauss;
     {
         ScopedTimer tm(ctx, T_FIT);
-        if (tiles_on && ctx->num_tiles > 0)
+        if (tiles_on && !early_fit && ctx->num_tiles > 0)
             launch_fit_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_tables.as<float>(), ctx->tile_max_rows,
                              ctx->d_tiles.as<TileDesc>(), reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
                              ctx->d_info12.as<float>(), ctx->stream);
@@ -524,7 +541,8 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                                          ctx->d_info12.as<float>(), ctx->stream);
             ctx->order_valid = true;
         }
-        launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
+        if (!early_fit)
+            launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
     }
     HIPCHK(hipGetLastError());
     ctx->M1 = h.level[0].num_gauss;
@@ -535,7 +553,8 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         int wg = ctx->cfg_num_wg;
         if (wg > ctx->M) wg = ctx->M;
         ctx->num_wg = wg;
-        launch_segment_partition(ctx->d_seg_off.as<int32_t>(), ctx->M, wg, ctx->d_wg_seg.as<int32_t>(), ctx->stream);
+        // the workgroup partition only feeds the streaming / parity correspondence kernels
+        if (!tiles_on || ctx->num_tiles == 0) launch_segment_partition(ctx->d_seg_off.as<int32_t>(), ctx->M, wg, ctx->d_wg_seg.as<int32_t>(), ctx->stream);
     }
     ctx->gaussians_valid = true;
     return DMSA_OK;
@@ -801,7 +820,8 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     if (const char* e = std::getenv("DMSA_DUAL_STREAM")) ctx->dual_stream = std::atoi(e) != 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_scan0, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_counts, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return DMSA_ERR_HIP;
     }
@@ -831,7 +851,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
                           &ctx->d_nsorted[l], &ctx->d_pair_d[l], &ctx->d_pair_c[l], &ctx->d_sort_tmp[l], &ctx->d_scan_tmp[l]})
             b->release();
     (void)hipStreamSynchronize(ctx->stream2);
-    (void)hipEventDestroy(ctx->ev_fork), (void)hipEventDestroy(ctx->ev_scan0), (void)hipEventDestroy(ctx->ev_join);
+    (void)hipEventDestroy(ctx->ev_fork), (void)hipEventDestroy(ctx->ev_scan0), (void)hipEventDestroy(ctx->ev_join), (void)hipEventDestroy(ctx->ev_counts);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
