@@ -1641,6 +1641,9 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
 #else
 #define PHASE(k)
 #endif
+    // information matrix / weight of my Gaussian: constant over the evaluations of the chunk
+    const float4 i0 = s_info[3 * my_g], i1 = s_info[3 * my_g + 1], i2 = s_info[3 * my_g + 2];
+    const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
     PHASE(0)
     for (int b = b_begin; b < b_end; ++b) {
         const int pb = b & 1;
@@ -1714,9 +1717,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
         // ---- pass 2: Mahalanobis terms (float, reference operation order) ----
         float fq = 0.0f;
         if (wave_on) {
-            // information matrix / weight / mean of my Gaussian: one LDS read per thread and evaluation
-            const float4 i0 = s_info[3 * my_g], i1 = s_info[3 * my_g + 1], i2 = s_info[3 * my_g + 2];
-            const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
+            // mean of my Gaussian: one LDS read per thread and evaluation (the information matrix stays in registers)
             const float mx = s_mean[my_g], my = s_mean[kTileGauss + my_g], mz = s_mean[2 * kTileGauss + my_g];
 #pragma unroll
             for (int k = 0; k < kTilePpt; ++k) {
