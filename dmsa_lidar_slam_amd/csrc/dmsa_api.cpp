@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -98,6 +100,9 @@ struct dmsa_ctx {
     size_t h_pin_slot = 0;  // doubles per slot
     int h_pin_next = 0;
     std::vector<float> h_tables;
+    // pinned staging of the point upload (packed on several host threads, then one DMA per array)
+    char* h_stage = nullptr;
+    size_t h_stage_cap = 0;
     // voxelisation
     // per-resolution scratch: the two voxelisations of an iteration run concurrently on `stream` and `stream2`
     DevBuf d_aabb, d_lattice, d_code[2], d_idx[2], d_code_s[2], d_idx_s[2], d_head[2], d_leaf_incl[2], d_leaf_start[2], d_slot_acc[2], d_slot_cnt[2],
@@ -836,6 +841,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
     drain_timers(ctx);
     for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     DevBuf* bufs[] = {&ctx->d_local, &ctx->d_nlocal, &ctx->d_ring, &ctx->d_global, &ctx->d_nglobal, &ctx->d_tables, &ctx->d_ctrl, &ctx->d_stamps,
                       &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
                       &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
@@ -881,30 +887,56 @@ int dmsa_window_upload(dmsa_ctx* ctx, const dmsa_window_problem* p) {
     ctx->N = p->num_points, ctx->S = p->num_static, ctx->n = ctx->N + ctx->S;
     ctx->rows = p->n_total + 1;
     const size_t n = (size_t)ctx->n;
-    // local points: (x, y, z, row index); static points ride along with the identity row
-    std::vector<float> loc(n * 4);
-    std::vector<int32_t> ring(n);
-    for (int64_t i = 0; i < ctx->N; ++i) {
-        loc[4 * i] = p->xyz_local[4 * i], loc[4 * i + 1] = p->xyz_local[4 * i + 1], loc[4 * i + 2] = p->xyz_local[4 * i + 2];
-        const int32_t row = p->tform_idx[i];
-        if (row < 0 || row >= p->n_total) {
-            ctx->err = "tform_idx out of range";
-            return DMSA_ERR_INVALID;
-        }
-        std::memcpy(&loc[4 * i + 3], &row, 4);
-        ring[(size_t)i] = p->ring_id[i];
+    // local points: (x, y, z, row index); static points ride along with the identity row.  Packed into pinned memory by a few
+    // host threads (the user's arrays are pageable), then one DMA per array.
+    const size_t stage_bytes = n * 20 + 64;
+    if (stage_bytes > ctx->h_stage_cap) {
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr, ctx->h_stage_cap = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), stage_bytes + stage_bytes / 8, hipHostMallocDefault));
+        ctx->h_stage_cap = stage_bytes + stage_bytes / 8;
     }
+    float* loc = reinterpret_cast<float*>(ctx->h_stage);
+    int32_t* ring = reinterpret_cast<int32_t*>(ctx->h_stage + n * 16);
     const int32_t id_row = p->n_total;
-    for (int64_t k = 0; k < ctx->S; ++k) {
-        const size_t i = (size_t)(ctx->N + k);
-        loc[4 * i] = p->xyz_static[4 * k], loc[4 * i + 1] = p->xyz_static[4 * k + 1], loc[4 * i + 2] = p->xyz_static[4 * k + 2];
-        std::memcpy(&loc[4 * i + 3], &id_row, 4);
-        ring[i] = p->ring_id_static[k];
+    const int64_t N = ctx->N, S = ctx->S;
+    std::atomic<bool> bad_row{false};
+    auto pack = [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+            if (i < N) {
+                const int32_t row = p->tform_idx[i];
+                if (row < 0 || row >= p->n_total) {
+                    bad_row = true;
+                    return;
+                }
+                loc[4 * i] = p->xyz_local[4 * i], loc[4 * i + 1] = p->xyz_local[4 * i + 1], loc[4 * i + 2] = p->xyz_local[4 * i + 2];
+                std::memcpy(&loc[4 * i + 3], &row, 4);
+                ring[i] = p->ring_id[i];
+            } else {
+                const int64_t k = i - N;
+                loc[4 * i] = p->xyz_static[4 * k], loc[4 * i + 1] = p->xyz_static[4 * k + 1], loc[4 * i + 2] = p->xyz_static[4 * k + 2];
+                std::memcpy(&loc[4 * i + 3], &id_row, 4);
+                ring[i] = p->ring_id_static[k];
+            }
+        }
+    };
+    const int nthreads = (int)std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), n / 65536 + 1);
+    if (nthreads <= 1) {
+        pack(0, N + S);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) pool.emplace_back(pack, (N + S) * t / nthreads, (N + S) * (t + 1) / nthreads);
+        for (auto& th : pool) th.join();
+    }
+    if (bad_row) {
+        ctx->err = "tform_idx out of range";
+        return DMSA_ERR_INVALID;
     }
     HIPCHK(ctx->d_local.ensure(n * 16 + 16));
     HIPCHK(ctx->d_ring.ensure(n * 4 + 16));
-    HIPCHK(hipMemcpy(ctx->d_local.p, loc.data(), n * 16, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->d_ring.p, ring.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(ctx->d_local.p, loc, n * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ring.p, ring, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next upload
     const int C = ctx->win.ctrl.n;
     HIPCHK(ctx->d_stamps.ensure((size_t)C * 8));
     HIPCHK(ctx->d_fhw.ensure((size_t)C * 8));
@@ -1215,9 +1247,16 @@ int dmsa_synchronize(dmsa_ctx* ctx) {
 
 int dmsa_optimize_window(dmsa_ctx* ctx, dmsa_window_problem* p, const dmsa_settings* s, dmsa_report* rep) {
     if (!ctx || !p || !s) return DMSA_ERR_INVALID;
+    static const bool trace = std::getenv("DMSA_TRACE_TIME") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     CHK(dmsa_window_upload(ctx, p));
+    const auto t1 = std::chrono::steady_clock::now();
     CHK(optimize(ctx, *s, rep));
+    const auto t2 = std::chrono::steady_clock::now();
     write_back_poses(ctx->win.ctrl, p->rel_orient, p->rel_transl);
+    if (trace)
+        std::fprintf(stderr, "[dmsa] optimize_window: upload %.2f ms, optimize %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                     std::chrono::duration<double, std::milli>(t2 - t1).count());
     return DMSA_OK;
 }
 
