@@ -107,7 +107,17 @@ struct dmsa_ctx {
     // per-resolution scratch: the two voxelisations of an iteration run concurrently on `stream` and `stream2`
     DevBuf d_aabb, d_lattice, d_code[2], d_idx[2], d_code_s[2], d_idx_s[2], d_head[2], d_leaf_incl[2], d_leaf_start[2], d_slot_acc[2], d_slot_cnt[2],
         d_gauss_of_slot[2], d_memb_of_slot[2], d_pslot_of_slot[2], d_pos_slot_rank[2], d_nsorted[2], d_pair_d[2], d_pair_c[2], d_sort_tmp[2], d_scan_tmp[2], d_counts;
-    LatticeTable h_lattice[2];
+    // Small device->host read-backs land in PINNED memory: an async copy into pageable memory blocks the host for 20-30 us.
+    struct Readback {
+        LatticeTable lattice[2];
+        GaussCounts g;
+        TileCounts t;
+        double errs[16];
+    };
+    Readback* h_rb = nullptr;  // hipHostMalloc
+    double* h_Hp = nullptr;     // pinned (P+1)^2 read-back of the normal equations
+    size_t h_Hp_cap = 0;
+    LatticeTable* h_lattice = nullptr;  // = h_rb->lattice
     bool key32[2] = {false, false};  // leaf codes of this level are 32-bit (tree depth <= 10)
     int depth_guess[2] = {-1, -1};   // tree depths of the previous voxelisation (speculation: saves one host sync)
     int bits_guess[2] = {-1, -1};    // leaf-code widths of the previous voxelisation
@@ -488,11 +498,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                            reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_memb_tile.as<float4>(), ctx->d_tile_rows.as<int32_t>(),
                            ctx->d_pad_off.as<int32_t>(), ctx->stream);
     }
-    struct {
-        GaussCounts g;
-        TileCounts t;
-    } both{};
-    HIPCHK(hipMemcpyAsync(&both, ctx->d_counts.p, sizeof(both), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&ctx->h_rb->g, ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));  // incl. out_of_range
     // The fit does not need the counts on the host (fixed grids, device-side tile counts): with the LDS table sized for ALL pose rows
     // it is enqueued right behind the read-back, so the GPU keeps working while the host waits for M (sync #2 waits on an event
@@ -513,8 +519,8 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         }
         HIPCHK(e);
     }
-    const GaussCounts h = both.g;
-    htc = both.t;
+    const GaussCounts h = ctx->h_rb->g;
+    htc = ctx->h_rb->t;
     for (int l = 0; l < 2; ++l) {
         if (lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
         const int true_bits = compress ? ctx->h_lattice[l].total_bits : 3 * ctx->h_lattice[l].final_depth;
@@ -714,8 +720,15 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             HIPCHK(ctx->d_Hp.ensure(Hp.size() * 8));
             launch_normal_equations(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, one_div_incr, ctx->d_ne_partial.as<double>(), ctx->d_Hp.as<double>(), ctx->stream);
         }
-        HIPCHK(hipMemcpyAsync(Hp.data(), ctx->d_Hp.p, Hp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (Hp.size() > ctx->h_Hp_cap) {
+            if (ctx->h_Hp) (void)hipHostFree(ctx->h_Hp);
+            ctx->h_Hp = nullptr, ctx->h_Hp_cap = 0;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_Hp), Hp.size() * 8, hipHostMallocDefault));
+            ctx->h_Hp_cap = Hp.size();
+        }
+        HIPCHK(hipMemcpyAsync(ctx->h_Hp, ctx->d_Hp.p, Hp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(sync_spin(ctx->stream));  // sync #3
+        std::memcpy(Hp.data(), ctx->h_Hp, Hp.size() * 8);
         const int n1 = P + 1;
         for (int j = 0; j < P; ++j)
             for (int i = 0; i < P; ++i) H[(size_t)j * P + i] = Hp[(size_t)j * n1 + i];
@@ -748,7 +761,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
         }
         CHK(build_tables(ctx, 9, globs));
         CHK(run_residuals(ctx, 9, &extra));
-        double errs[9];
+        double* errs = ctx->h_rb->errs;  // pinned
         {
             ScopedTimer tm(ctx, T_NORMAL);
             HIPCHK(ctx->d_sq_partial.ensure((size_t)squared_sums_partial_doubles(rowsE, 9) * 8));
@@ -830,6 +843,12 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
         delete ctx;
         return DMSA_ERR_HIP;
     }
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_rb), sizeof(dmsa_ctx::Readback), hipHostMallocDefault) != hipSuccess) {
+        delete ctx;
+        return DMSA_ERR_NOMEM;
+    }
+    std::memset(ctx->h_rb, 0, sizeof(dmsa_ctx::Readback));
+    ctx->h_lattice = ctx->h_rb->lattice;
     *out = ctx;
     return DMSA_OK;
 }
@@ -842,6 +861,8 @@ void dmsa_destroy(dmsa_ctx* ctx) {
     for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_rb) (void)hipHostFree(ctx->h_rb);
+    if (ctx->h_Hp) (void)hipHostFree(ctx->h_Hp);
     DevBuf* bufs[] = {&ctx->d_local, &ctx->d_nlocal, &ctx->d_ring, &ctx->d_global, &ctx->d_nglobal, &ctx->d_tables, &ctx->d_ctrl, &ctx->d_stamps,
                       &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
                       &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
