@@ -33,6 +33,10 @@ namespace {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }  // every buffer of a context is released with it, whether or not dmsa_destroy lists it
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p) (void)hipFree(p);
