@@ -94,22 +94,24 @@ def test_coincident_control_stamps_are_rejected(hip):
 
 
 def test_create_destroy_cycles_release_device_memory(hip):
-    """30 contexts created, used and destroyed in a row: device memory returns to where it was after the first one (the HIP
-    runtime keeps ~200 MB of code objects / pools once anything has run)."""
+    """45 contexts created, used and destroyed in a row: after the first few (the HIP runtime keeps ~200 MB of code objects /
+    pools once every kernel has run) the free device memory no longer moves."""
     import torch
 
     p = synth.window_problem(seed=45, scans=2, rings=16, az_steps=128, num_static=2000)
     s = DmsaOptimSettings.sliding_window(num_iter=1)
-    for _ in range(2):
-        o = hip.DmsaOptimizer()
-        o.optimizeSet(p.copy(), s)
-        o.close()
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info()
-    for _ in range(30):
-        o = hip.DmsaOptimizer()
-        o.optimizeSet(p.copy(), s)
-        o.close()
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info()
-    assert free0 - free1 < 16 * 1024 * 1024, (free0, free1)
+
+    def cycles(k):
+        for _ in range(k):
+            o = hip.DmsaOptimizer()
+            o.optimizeSet(p.copy(), s)
+            o.close()
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    import gc
+
+    gc.collect()
+    free_a = cycles(15)
+    free_b = cycles(30)
+    assert free_a - free_b < 16 * 1024 * 1024, (free_a, free_b)  # one-sided: contexts of earlier tests may be collected meanwhile
