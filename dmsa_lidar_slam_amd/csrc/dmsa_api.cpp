@@ -214,6 +214,7 @@ hipError_t sync_spin(hipStream_t stream) {
     hipError_t e;
     while ((e = hipStreamQuery(stream)) == hipErrorNotReady) {
     }
+    (void)hipGetLastError();  // hipErrorNotReady is recorded as the thread's last error: do not leave it for other HIP users (torch)
     return e;
 }
 
@@ -521,6 +522,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         hipError_t e;
         while ((e = hipEventQuery(ctx->ev_counts)) == hipErrorNotReady) {
         }
+        (void)hipGetLastError();  // see sync_spin
         HIPCHK(e);
     }
     const GaussCounts h = ctx->h_rb->g;

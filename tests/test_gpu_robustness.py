@@ -96,8 +96,7 @@ def test_coincident_control_stamps_are_rejected(hip):
 def test_create_destroy_cycles_release_device_memory(hip):
     """45 contexts created, used and destroyed in a row: after the first few (the HIP runtime keeps ~200 MB of code objects /
     pools once every kernel has run) the free device memory no longer moves."""
-    import torch
-
+    rt = C.CDLL("libamdhip64.so")  # the runtime the library itself is linked against
     p = synth.window_problem(seed=45, scans=2, rings=16, az_steps=128, num_static=2000)
     s = DmsaOptimSettings.sliding_window(num_iter=1)
 
@@ -106,8 +105,9 @@ def test_create_destroy_cycles_release_device_memory(hip):
             o = hip.DmsaOptimizer()
             o.optimizeSet(p.copy(), s)
             o.close()
-        torch.cuda.synchronize()
-        return torch.cuda.mem_get_info()[0]
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        assert rt.hipDeviceSynchronize() == 0 and rt.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
 
     import gc
 
