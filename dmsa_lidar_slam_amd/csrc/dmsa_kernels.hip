@@ -1767,7 +1767,7 @@ __global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(con
 // every evaluation of the chunk, so HBM/L2 sees them once per chunk; both passes transform on the fly.  Members beyond
 // that capacity are streamed per evaluation.
 constexpr int kBigThreads = 1024;
-constexpr int kBigKeep = 16;  // members kept in registers per thread
+constexpr int kBigKeep = 12;  // members kept in registers per thread (local coordinates + this evaluation's transformed coordinates)
 __device__ __forceinline__ float3 big_point(const float4* __restrict__ s_tab, const float4 p) {
     const int row = tw_row(__float_as_int(p.w));
     return apply_row3(s_tab[3 * row], s_tab[3 * row + 1], s_tab[3 * row + 2], p.x, p.y, p.z);
@@ -1803,12 +1803,12 @@ __global__ __launch_bounds__(kBigThreads) void k_residuals_big(const float4* __r
         for (int q = tid; q < nq; q += kBigThreads) tab[q] = gtab[3 * my_rows[q / 3] + (q % 3)];
         __syncthreads();
         float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        float qx[kBigKeep], qy[kBigKeep], qz[kBigKeep];  // transformed once per evaluation, reused by the second pass
 #pragma unroll
         for (int k = 0; k < kBigKeep; ++k) {
-            if (tid + kBigThreads * k < np) {
-                const float3 q = big_point(tab, pt[k]);
-                sx += q.x, sy += q.y, sz += q.z;
-            }
+            const float3 q = big_point(tab, pt[k]);
+            qx[k] = q.x, qy[k] = q.y, qz[k] = q.z;
+            if (tid + kBigThreads * k < np) sx += q.x, sy += q.y, sz += q.z;
             if ((k & 3) == 3) asm volatile("" ::: "memory");
         }
         for (int j = tid + kBigThreads * kBigKeep; j < np; j += kBigThreads) {
@@ -1832,8 +1832,7 @@ __global__ __launch_bounds__(kBigThreads) void k_residuals_big(const float4* __r
         };
 #pragma unroll
         for (int k = 0; k < kBigKeep; ++k) {
-            if (tid + kBigThreads * k < np) acc += term(big_point(tab, pt[k]));
-            if ((k & 3) == 3) asm volatile("" ::: "memory");
+            if (tid + kBigThreads * k < np) acc += term(make_float3(qx[k], qy[k], qz[k]));
         }
         for (int j = tid + kBigThreads * kBigKeep; j < np; j += kBigThreads) acc += term(big_point(tab, mp[j]));
         acc = wave_allsum(acc);
