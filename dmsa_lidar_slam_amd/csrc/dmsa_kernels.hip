@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const int32_t* __restrict_
 // Per tile: which pose-table rows do its members reference?  Writes the ascending row list, the SLOT copy of the members
 // (every Gaussian at its padded offset, .w = rank of the row in that list + Gaussian-in-tile + flags, null slots behind the last
 // member) and the maximum list length + 1 (sizes the LDS table of the kernels; the extra row is the all-zero row of null slots).
-__global__ __launch_bounds__(256) void k_tile_rows(TileDesc* __restrict__ tiles, TileCounts* __restrict__ tc, const float4* __restrict__ memb,
+__global__ __launch_bounds__(1024) void k_tile_rows(TileDesc* __restrict__ tiles, TileCounts* __restrict__ tc, const float4* __restrict__ memb,
                                                    const int32_t* __restrict__ memb_g, const int32_t* __restrict__ seg_off,
                                                    const int32_t* __restrict__ pad_off, int rows, float4* __restrict__ memb_tile,
                                                    int32_t* __restrict__ tile_rows) {
@@ -1550,7 +1550,7 @@ void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const
     }
     hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(1024), kBuildTilesLdsInts * 4, s, seg_off, counts, tiles, tc, fallback, pad_off);
     const size_t lds = (size_t)((rows + 31) / 32) * 8;
-    hipLaunchKernelGGL(k_tile_rows, dim3(1024), dim3(256), lds, s, tiles, tc, memb, memb_g, seg_off, pad_off, rows, memb_tile, tile_rows);
+    hipLaunchKernelGGL(k_tile_rows, dim3(1024), dim3(1024), lds, s, tiles, tc, memb, memb_g, seg_off, pad_off, rows, memb_tile, tile_rows);
 }
 int tile_points() { return kTilePoints; }
 
