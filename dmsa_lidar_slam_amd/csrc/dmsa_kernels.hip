@@ -1403,8 +1403,17 @@ __global__ __launch_bounds__(1024) void k_build_tiles(const int32_t* __restrict_
     const bool in_lds = 2 * (M + 1) <= kBuildTilesLdsInts;
     int* s_seg = s_lds;
     int* s_pad = s_lds + (M + 1);
-    if (in_lds)
-        for (int i = threadIdx.x; i <= M; i += 1024) s_seg[i] = seg_off_g[i], s_pad[i] = pad_off_g[i];
+    if (in_lds) {  // 16-byte loads: the staging is the latency of this single-workgroup kernel
+        const int n4 = (M + 1) / 4;
+        const int4* seg4 = reinterpret_cast<const int4*>(seg_off_g);
+        const int4* pad4 = reinterpret_cast<const int4*>(pad_off_g);
+        for (int i = threadIdx.x; i < n4; i += 1024) {
+            const int4 a = seg4[i], b = pad4[i];
+            s_seg[4 * i] = a.x, s_seg[4 * i + 1] = a.y, s_seg[4 * i + 2] = a.z, s_seg[4 * i + 3] = a.w;
+            s_pad[4 * i] = b.x, s_pad[4 * i + 1] = b.y, s_pad[4 * i + 2] = b.z, s_pad[4 * i + 3] = b.w;
+        }
+        for (int i = 4 * n4 + threadIdx.x; i <= M; i += 1024) s_seg[i] = seg_off_g[i], s_pad[i] = pad_off_g[i];
+    }
     __syncthreads();
     const int32_t* seg_off = in_lds ? s_seg : seg_off_g;
     const int32_t* pad_off = in_lds ? s_pad : pad_off_g;  // slot offsets (members rounded up to 8 per Gaussian), written by k_gather_members
