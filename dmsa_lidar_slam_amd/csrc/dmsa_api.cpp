@@ -122,10 +122,16 @@ struct dmsa_ctx {
     double* h_Hp = nullptr;     // pinned (P+1)^2 read-back of the normal equations
     size_t h_Hp_cap = 0;
     LatticeTable* h_lattice = nullptr;  // = h_rb->lattice
-    bool key32[2] = {false, false};  // leaf codes of this level are 32-bit (tree depth <= 10)
+    bool key32[2] = {false, false};  // leaf codes are 32-bit (both levels share the width: they are sorted together)
+    // level views into the shared code / index arrays (level 1 starts n entries behind level 0)
+    void* code_v[2] = {nullptr, nullptr};
+    void* code_s_v[2] = {nullptr, nullptr};
+    uint32_t* idx_v[2] = {nullptr, nullptr};
+    uint32_t* idx_s_v[2] = {nullptr, nullptr};
     int depth_guess[2] = {-1, -1};   // tree depths of the previous voxelisation (speculation: saves one host sync)
     int bits_guess[2] = {-1, -1};    // leaf-code widths of the previous voxelisation
     bool compress_keys = true;       // drop the constant high key bits before sorting (DMSA_KEY_COMPRESS=0 disables)
+    int merge_sort = -1;             // -1: by size; DMSA_MERGE_SORT=0/1 forces two sorts / one sort of both levels
     double level_res[2] = {0, 0};
     // Gaussians
     DevBuf d_memb_local, d_memb_idx, d_memb_g, d_seg_off, d_info12, d_wg_seg;
@@ -235,10 +241,12 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
     HIPCHK(ctx->d_aabb.ensure(nb * 8 * sizeof(float)));
     HIPCHK(ctx->d_lattice.ensure(2 * sizeof(LatticeTable)));
     for (int l = 0; l < 2; ++l) {
-        HIPCHK(ctx->d_code[l].ensure(n * 8));
-        HIPCHK(ctx->d_idx[l].ensure(n * 4));
-        HIPCHK(ctx->d_code_s[l].ensure(n * 8));
-        HIPCHK(ctx->d_idx_s[l].ensure(n * 4));
+        if (l == 0) {  // both levels live in ONE array of 2n entries (level 1 behind level 0): they are sorted together
+            HIPCHK(ctx->d_code[0].ensure(2 * n * 8));
+            HIPCHK(ctx->d_idx[0].ensure(2 * n * 4));
+            HIPCHK(ctx->d_code_s[0].ensure(2 * n * 8));
+            HIPCHK(ctx->d_idx_s[0].ensure(2 * n * 4));
+        }
         HIPCHK(ctx->d_leaf_incl[l].ensure(n * 4));
         HIPCHK(ctx->d_leaf_start[l].ensure((n + 1) * 4));
     }
@@ -249,7 +257,7 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
         HIPCHK(ctx->d_gauss_of_slot[l].ensure(2 * n * 4));
         HIPCHK(ctx->d_memb_of_slot[l].ensure(2 * n * 4));
         HIPCHK(ctx->d_pslot_of_slot[l].ensure(2 * n * 4));
-        HIPCHK(ctx->d_sort_tmp[l].ensure(sort_pairs_temp_bytes(n)));
+        HIPCHK(ctx->d_sort_tmp[l].ensure(sort_pairs_temp_bytes(2 * n)));
         HIPCHK(ctx->d_scan_tmp[l].ensure(scan_temp_bytes(2 * n)));
     }
     HIPCHK(ctx->d_counts.ensure(sizeof(GaussCounts) + sizeof(TileCounts)));  // read back together
@@ -427,31 +435,59 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     const bool two = ctx->dual_stream && lvl_on[0] && lvl_on[1];
     hipStream_t st[2] = {ctx->stream, two ? ctx->stream2 : ctx->stream};
     bool k32v[2] = {false, false};
-    auto stage_sort = [&](int l) -> int {
-        const unsigned end_bit = (unsigned)(sort_bits[l] + 1);
-        const bool k32 = end_bit <= 32;
-        k32v[l] = ctx->key32[l] = k32;
-        launch_voxel_keys(ctx->d_global.as<float4>(), n, ctx->d_lattice.as<LatticeTable>() + l, ctx->level_res[l], ctx->d_code[l].p, k32,
-                          ctx->d_idx[l].as<uint32_t>(), st[l]);
+    // Both resolutions are keyed into one array of 2n (code, point) pairs -- level 1 carries a tag bit above the widest code --
+    // and sorted by ONE radix sort: half the launches, twice the parallelism per pass, and the sorted halves are the two levels.
+    const int tag_bit = std::max(sort_bits[0], sort_bits[1]) + 1;  // bit `sort_bits` is the marker of non-finite points
+    const unsigned end_bit = (unsigned)(tag_bit + 1);
+    const bool k32 = end_bit <= 32;
+    {
+        const size_t ksz = k32 ? 4 : 8;
+        for (int l = 0; l < 2; ++l) {
+            k32v[l] = ctx->key32[l] = k32;
+            ctx->code_v[l] = ctx->d_code[0].as<char>() + (size_t)l * n * ksz, ctx->code_s_v[l] = ctx->d_code_s[0].as<char>() + (size_t)l * n * ksz;
+            ctx->idx_v[l] = ctx->d_idx[0].as<uint32_t>() + (size_t)l * n, ctx->idx_s_v[l] = ctx->d_idx_s[0].as<uint32_t>() + (size_t)l * n;
+        }
+    }
+    // Small clouds (keyframe sets: 3 x 10^5 points) are launch-bound: one sort of 2n pairs on one stream.  Large clouds (the window:
+    // 1.5 x 10^6) keep the two levels on two streams with one sort each (a sort only looks at the bits below its end bit, so the
+    // tag is inert there).
+    const bool merged = ctx->merge_sort < 0 ? n <= (int64_t)(1 << 20) : ctx->merge_sort != 0;
+    auto stage_keys = [&](int l, hipStream_t stream) {  // a disabled level is keyed with the other level's lattice (level_res is aliased) and ignored later
+        launch_voxel_keys(ctx->d_global.as<float4>(), n, ctx->d_lattice.as<LatticeTable>() + l, ctx->level_res[l], ctx->code_v[l], k32, ctx->idx_v[l],
+                          l == 0 ? 0ull : (1ull << tag_bit), stream);
+    };
+    auto stage_sort_both = [&]() -> int {
+        stage_keys(0, ctx->stream), stage_keys(1, ctx->stream);
         if (k32)
-            HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, ctx->d_code[l].as<uint32_t>(), ctx->d_code_s[l].as<uint32_t>(),
-                                      ctx->d_idx[l].as<uint32_t>(), ctx->d_idx_s[l].as<uint32_t>(), (size_t)n, end_bit, st[l]));
+            HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_code[0].as<uint32_t>(), ctx->d_code_s[0].as<uint32_t>(),
+                                      ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream));
         else
-            HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, ctx->d_code[l].as<uint64_t>(), ctx->d_code_s[l].as<uint64_t>(),
-                                      ctx->d_idx[l].as<uint32_t>(), ctx->d_idx_s[l].as<uint32_t>(), (size_t)n, end_bit, st[l]));
+            HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_code[0].as<uint64_t>(), ctx->d_code_s[0].as<uint64_t>(),
+                                      ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream));
+        return DMSA_OK;
+    };
+    auto stage_sort = [&](int l) -> int {
+        stage_keys(l, st[l]);
+        const unsigned eb = (unsigned)(sort_bits[l] + 1);
+        if (k32)
+            HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, (const uint32_t*)ctx->code_v[l], (uint32_t*)ctx->code_s_v[l], ctx->idx_v[l],
+                                      ctx->idx_s_v[l], (size_t)n, eb, st[l]));
+        else
+            HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, (const uint64_t*)ctx->code_v[l], (uint64_t*)ctx->code_s_v[l], ctx->idx_v[l],
+                                      ctx->idx_s_v[l], (size_t)n, eb, st[l]));
         return DMSA_OK;
     };
     auto stage_leaves = [&](int l) -> int {
         const LatticeTable* tab = ctx->d_lattice.as<LatticeTable>() + l;
         const bool k32 = k32v[l];
-        launch_head_flags(ctx->d_code_s[l].p, k32, n, tab, ctx->d_head[l].as<int32_t>(), st[l]);
+        launch_head_flags(ctx->code_s_v[l], k32, n, tab, ctx->d_head[l].as<int32_t>(), st[l]);
         HIPCHK(inclusive_scan_i32(ctx->d_scan_tmp[l].p, ctx->d_scan_tmp[l].cap, ctx->d_head[l].as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), (size_t)n, st[l]));
-        launch_leaf_starts(ctx->d_head[l].as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_code_s[l].p, k32, tab, n,
+        launch_leaf_starts(ctx->d_head[l].as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), ctx->code_s_v[l], k32, tab, n,
                            ctx->d_leaf_start[l].as<int32_t>(), &counts->level[l], st[l]);
-        launch_leaf_accept(ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(), &counts->level[l],
+        launch_leaf_accept(ctx->d_leaf_start[l].as<int32_t>(), ctx->idx_s_v[l], ctx->d_ring.as<int32_t>(), &counts->level[l],
                            s.min_num_points_per_set, n, ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(), st[l]);
         if (split)
-            launch_leaf_split(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(), ctx->d_ring.as<int32_t>(),
+            launch_leaf_split(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->idx_s_v[l], ctx->d_ring.as<int32_t>(),
                               ctx->d_nglobal.as<float4>(), &counts->level[l], s.min_num_points_per_set, n, ctx->d_nsorted[l].as<float4>(),
                               ctx->d_pair_d[l].as<unsigned long long>(), ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(),
                               ctx->d_pos_slot_rank[l].as<int32_t>(), st[l]);
@@ -461,20 +497,22 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     };
     auto stage_gather = [&](int l) {
         const LatticeTable* tab = ctx->d_lattice.as<LatticeTable>() + l;
-        launch_gather_members(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->d_idx_s[l].as<uint32_t>(),
-                              ctx->d_code_s[l].p, k32v[l], tab, ctx->d_slot_acc[l].as<int32_t>(), ctx->d_gauss_of_slot[l].as<int32_t>(),
+        launch_gather_members(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->idx_s_v[l],
+                              ctx->code_s_v[l], k32v[l], tab, ctx->d_slot_acc[l].as<int32_t>(), ctx->d_gauss_of_slot[l].as<int32_t>(),
                               ctx->d_memb_of_slot[l].as<int32_t>(), split ? ctx->d_pos_slot_rank[l].as<int32_t>() : nullptr, ctx->d_local.as<float4>(),
                               ctx->d_slot_cnt[l].as<int32_t>(), counts, l, n, ctx->d_memb_local.as<float4>(), ctx->d_memb_idx.as<int32_t>(),
                               ctx->d_memb_g.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), ctx->d_pslot_of_slot[l].as<int32_t>(), ctx->d_pad_off.as<int32_t>(), st[l]);
     };
     {
         ScopedTimer tm(ctx, T_VOXEL);
+        if (merged) CHK(stage_sort_both());
         if (two) {
             HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         }
-        for (int l = 0; l < 2; ++l)
-            if (lvl_on[l]) CHK(stage_sort(l));
+        if (!merged)
+            for (int l = 0; l < 2; ++l)
+                if (lvl_on[l]) CHK(stage_sort(l));
         for (int l = 0; l < 2; ++l) {
             if (!lvl_on[l]) continue;
             CHK(stage_leaves(l));
@@ -842,6 +880,7 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     if (const char* e = std::getenv("DMSA_K4_TILES")) ctx->use_tiles = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_KEY_COMPRESS")) ctx->compress_keys = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_DUAL_STREAM")) ctx->dual_stream = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DMSA_MERGE_SORT")) ctx->merge_sort = std::atoi(e) != 0 ? 1 : 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_scan0, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
@@ -1161,10 +1200,10 @@ int dmsa_get_voxel_level(dmsa_ctx* ctx, int32_t level, dmsa_voxel_level_info* in
     std::vector<uint64_t> code(n);
     if (ctx->key32[level]) {
         std::vector<uint32_t> c32(n);
-        HIPCHK(hipMemcpy(c32.data(), ctx->d_code[level].p, n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c32.data(), ctx->code_v[level], n * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; ++i) code[i] = c32[i];
     } else {
-        HIPCHK(hipMemcpy(code.data(), ctx->d_code[level].p, n * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(code.data(), ctx->code_v[level], n * 8, hipMemcpyDeviceToHost));
     }
     int64_t valid = 0;
     const int nb3[3] = {t.nbits[0], t.nbits[1], t.nbits[2]};
@@ -1175,6 +1214,7 @@ int dmsa_get_voxel_level(dmsa_ctx* ctx, int32_t level, dmsa_voxel_level_info* in
         uint32_t k[3] = {0, 0, 0};
         uint64_t full = UINT64_MAX;
         if (ok) {
+            code[i] &= ~t.code_or;  // level tag of the merged sort
             if (t.compressed) {  // undo the compression: peel the bits off in reverse order of their insertion
                 uint64_t c = code[i];
                 uint32_t low[3] = {0, 0, 0};
@@ -1198,7 +1238,7 @@ int dmsa_get_voxel_level(dmsa_ctx* ctx, int32_t level, dmsa_voxel_level_info* in
         if (key_xyz) key_xyz[3 * i] = k[0], key_xyz[3 * i + 1] = k[1], key_xyz[3 * i + 2] = k[2];
         if (leaf_code) leaf_code[i] = full;
     }
-    if (sorted_point_idx) HIPCHK(hipMemcpy(sorted_point_idx, ctx->d_idx_s[level].p, (size_t)valid * 4, hipMemcpyDeviceToHost));
+    if (sorted_point_idx) HIPCHK(hipMemcpy(sorted_point_idx, ctx->idx_s_v[level], (size_t)valid * 4, hipMemcpyDeviceToHost));
     if (info) {
         GaussCounts h{};
         HIPCHK(hipMemcpy(&h, ctx->d_counts.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -1542,7 +1582,7 @@ int dmsa_random_grid_downsampling(dmsa_ctx* ctx, const float* xyz, int64_t n, fl
     const bool k32 = end_bit <= 32;
     LatticeTable* tab = sp->lattice.as<LatticeTable>();
     GaussCounts* counts = sp->counts.as<GaussCounts>();
-    launch_voxel_keys(sp->cloud.as<float4>(), n, tab, res, sp->code.p, k32, sp->idx.as<uint32_t>(), ctx->stream);
+    launch_voxel_keys(sp->cloud.as<float4>(), n, tab, res, sp->code.p, k32, sp->idx.as<uint32_t>(), 0ull, ctx->stream);
     if (k32)
         HIPCHK(sort_pairs_u32_u32(sp->sort_tmp.p, sp->sort_tmp.cap, sp->code.as<uint32_t>(), sp->code_s.as<uint32_t>(), sp->idx.as<uint32_t>(),
                                   sp->idx_s.as<uint32_t>(), (size_t)n, end_bit, ctx->stream));

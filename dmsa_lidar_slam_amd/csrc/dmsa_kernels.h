@@ -33,8 +33,13 @@ struct LatticeTable {
     int32_t compressed;    // 1: codes are the compressed form, invalid marker = 1 << total_bits; 0: full 3*depth-bit codes
     int32_t out_of_range;  // set by k_voxel_keys if a key left [key_base << nbits, ...] (compression must be redone off)
     int32_t pad3;
+    // Level tag OR'ed into every code of this resolution (written by k_voxel_keys): both resolutions are sorted in ONE radix
+    // sort of 2n pairs, the tag bit sits above the widest code, so the first n sorted entries are level 0 and the rest level 1.
+    uint64_t code_or;
 };
-__host__ __device__ inline uint64_t lattice_invalid_code(const LatticeTable& t) { return 1ull << (t.compressed ? t.total_bits : 3 * t.final_depth); }
+__host__ __device__ inline uint64_t lattice_invalid_code(const LatticeTable& t) {
+    return (1ull << (t.compressed ? t.total_bits : 3 * t.final_depth)) | t.code_or;
+}
 
 // per-level device scalars produced by the segmentation stage
 struct LevelCounts {
@@ -83,7 +88,8 @@ void launch_block_aabb(const float4* global, int64_t n, float* aabb /* nb x 8 */
 void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, bool compress, LatticeTable* tables /* [2] */,
                     hipStream_t s);
 // leaf codes are 32-bit (key32) when 3*depth + 1 <= 32, else 64-bit; the buffers are sized for 64-bit keys either way
-void launch_voxel_keys(const float4* global, int64_t n, LatticeTable* table, double res, void* code, bool key32, uint32_t* idx, hipStream_t s);
+void launch_voxel_keys(const float4* global, int64_t n, LatticeTable* table, double res, void* code, bool key32, uint32_t* idx, uint64_t code_or,
+                       hipStream_t s);
 // ---- segmentation of the sorted (code, idx) arrays -------------------------------------------------------
 void launch_head_flags(const void* code_sorted, bool key32, int64_t n, const LatticeTable* table, int32_t* head, hipStream_t s);
 void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const void* code_sorted, bool key32, const LatticeTable* table, int64_t n,

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void k_lattice(const float4* __restrict__ glob
             tab->nbits[a] = bits, tab->key_base[a] = base;
             total += bits;
         }
-        tab->compressed = compress, tab->out_of_range = 0;
+        tab->compressed = compress, tab->out_of_range = 0, tab->code_or = 0;
         tab->total_bits = total;
         uint32_t acc[3] = {0, 0, 0};
         for (int a = 0; a < 3; ++a) tab->suffix_shift[st.nev][a] = 0;
@@ -530,7 +530,7 @@ __device__ __forceinline__ uint64_t spread3(uint32_t v) {  // 21 bits -> every t
 
 template <typename KeyT>  // uint32_t when the leaf code + invalid bit fit 32 bits (tree depth <= 10), else uint64_t
 __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ global, int64_t n, LatticeTable* __restrict__ table, double res,
-                                                    KeyT* __restrict__ code, uint32_t* __restrict__ idx) {
+                                                    KeyT* __restrict__ code, uint32_t* __restrict__ idx, uint64_t code_or) {
     __shared__ LatticeTable t;
     {
         const int words = sizeof(LatticeTable) / 4;
@@ -538,6 +538,9 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ g
         uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
         for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
     }
+    __syncthreads();
+    if (threadIdx.x == 0) t.code_or = code_or;                         // the tag of this launch, whatever an earlier launch left
+    if (blockIdx.x == 0 && threadIdx.x == 0) table->code_or = code_or;  // later kernels compare against lattice_invalid_code(*table)
     __syncthreads();
     const int nev = t.num_events;
     const uint64_t invalid = lattice_invalid_code(t);
@@ -568,21 +571,22 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ g
                     if (l < ny) cc = (cc << 1) | ((ky >> l) & 1u);
                     if (l < nz) cc = (cc << 1) | ((kz >> l) & 1u);
                 }
-                c = cc;
+                c = cc | code_or;
             } else {
-                c = (spread3(kx) << 2) | (spread3(ky) << 1) | spread3(kz);
+                c = (spread3(kx) << 2) | (spread3(ky) << 1) | spread3(kz) | code_or;
             }
         }
         code[i] = (KeyT)c;
         idx[i] = (uint32_t)i;
     }
 }
-void launch_voxel_keys(const float4* global, int64_t n, LatticeTable* table, double res, void* code, bool key32, uint32_t* idx, hipStream_t s) {
+void launch_voxel_keys(const float4* global, int64_t n, LatticeTable* table, double res, void* code, bool key32, uint32_t* idx, uint64_t code_or,
+                       hipStream_t s) {
     if (n <= 0) return;
     if (key32)
-        hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint32_t*)code, idx);
+        hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint32_t*)code, idx, code_or);
     else
-        hipLaunchKernelGGL(k_voxel_keys<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint64_t*)code, idx);
+        hipLaunchKernelGGL(k_voxel_keys<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint64_t*)code, idx, code_or);
 }
 
 // ------------------------------------------------------------------------------------------------------------
