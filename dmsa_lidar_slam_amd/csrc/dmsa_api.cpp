@@ -140,6 +140,7 @@ struct dmsa_ctx {
     DevBuf d_memb_tile, d_tiles, d_tile_counts, d_tile_rows, d_fallback, d_pad_off;
     int num_tiles = 0, num_fallback = 0, tile_max_rows = 0, tile_max_gauss = 0;
     bool use_tiles = true;  // DMSA_K4_TILES=0 selects the streaming kernel
+    bool tiles_usable = true;  // false when a tile references more pose rows than the tiled kernels' LDS holds (very long windows)
     int M = 0, M1 = 0;
     int64_t Mm = 0;
     int num_wg = 0;
@@ -580,9 +581,16 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         ctx->bits_guess[l] = ctx->h_lattice[l].total_bits;
     }
     ctx->num_tiles = htc.num_tiles, ctx->num_fallback = htc.num_fallback, ctx->tile_max_rows = htc.max_rows, ctx->tile_max_gauss = htc.max_gauss;
+    ctx->tiles_usable = !tiles_on || tiled_kernels_fit(htc.max_rows, htc.max_gauss);
     {
         ScopedTimer tm(ctx, T_FIT);
-        if (tiles_on && !early_fit && ctx->num_tiles > 0)
+        if (tiles_on && !early_fit && ctx->num_tiles > 0 && !ctx->tiles_usable) {
+            // tiles that reference more pose rows than fit in LDS: wave-per-set fit on the gathered members instead
+            for (int l = 0; l < 2; ++l)
+                if (lvl_on[l])
+                    launch_gauss_fit(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(), counts, l, ctx->d_info12.as<float>(), false,
+                                     ctx->stream);
+        } else if (tiles_on && !early_fit && ctx->num_tiles > 0)
             launch_fit_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_tables.as<float>(), ctx->tile_max_rows,
                              ctx->d_tiles.as<TileDesc>(), reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
                              ctx->d_info12.as<float>(), ctx->stream);
@@ -609,7 +617,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         if (wg > ctx->M) wg = ctx->M;
         ctx->num_wg = wg;
         // the workgroup partition only feeds the streaming / parity correspondence kernels
-        if (!tiles_on || ctx->num_tiles == 0) launch_segment_partition(ctx->d_seg_off.as<int32_t>(), ctx->M, wg, ctx->d_wg_seg.as<int32_t>(), ctx->stream);
+        if (!tiles_on || ctx->num_tiles == 0 || !ctx->tiles_usable) launch_segment_partition(ctx->d_seg_off.as<int32_t>(), ctx->M, wg, ctx->d_wg_seg.as<int32_t>(), ctx->stream);
     }
     ctx->gaussians_valid = true;
     return DMSA_OK;
@@ -626,7 +634,7 @@ int ensure_E(dmsa_ctx* ctx, int B) {
 }
 int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
     CHK(ensure_E(ctx, B));
-    const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS) && ctx->num_tiles > 0;
+    const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS) && ctx->num_tiles > 0 && ctx->tiles_usable;
     if (tiles_on) {
         ScopedTimer tm(ctx, T_RESIDUAL);
         launch_residuals_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(),

@@ -128,6 +128,9 @@ void launch_residuals(const float4* memb_local, const int32_t* seg_off, const fl
 // tiled variant (default fast path): tiles + per-tile row lists are rebuilt once per iteration
 // slots of the tile copy of the membership array: every Gaussian is padded to a multiple of 8 slots (Mm + 7 M <= 9 n)
 inline size_t tile_slot_capacity(size_t n_points) { return 9 * n_points + 64; }
+// true if the LDS carve of the tiled correspondence / fit kernels fits for tiles that reference up to `max_rows` pose rows
+// (zero row included) -- very long windows fall back to the streaming kernels
+bool tiled_kernels_fit(int max_rows, int max_gauss);
 void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, const int32_t* memb_g, int rows, TileDesc* tiles,
                         TileCounts* tc, int2* fallback, float4* memb_tile /* tile_slot_capacity(n) entries */, int32_t* tile_rows,
                         int32_t* pad_off /* M+1 slot offsets */, hipStream_t s);

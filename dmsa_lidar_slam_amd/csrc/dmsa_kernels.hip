@@ -2035,6 +2035,13 @@ void launch_fit_tiled(const float4* memb_tile, const int32_t* seg_off, const flo
 long long* g_phase_clk = nullptr;  // debug: per (tile, wave, phase) cycle counts when built with -DDMSA_PHASE_CLOCKS
 void set_phase_clock_buffer(long long* p) { g_phase_clk = p; }
 
+bool tiled_kernels_fit(int max_rows, int max_gauss) {
+    const size_t limit = 160 * 1024 - 512;
+    const size_t lds_tiles = (size_t)kRtOffTab + (size_t)2 * max_rows * 48 + (size_t)8 * (max_gauss > 0 ? max_gauss : 1);  // at least one evaluation of output
+    const size_t lds_big = 384 + (size_t)2 * max_rows * 48;
+    const size_t lds_fit = (size_t)kFitOffTab + (size_t)max_rows * 48;
+    return max_rows <= 4095 && lds_tiles <= limit && lds_big <= limit && lds_fit <= limit;  // 12-bit row ranks
+}
 void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables,
                             int rows, int M, int B, const TileDesc* tiles, const int32_t* tile_rows, int num_tiles, int max_rows, int max_gauss,
                             const int2* fallback, int num_fallback, int big_n, double* E, int64_t ldE, hipStream_t s) {
@@ -2054,6 +2061,11 @@ void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, c
     int b_chunk = (B + chunks - 1) / chunks;
     const int out_cap = (16 * 1024) / (8 * (max_gauss > 0 ? max_gauss : 1));  // s_out <= 16 KB of LDS
     if (b_chunk > out_cap) b_chunk = out_cap > 0 ? out_cap : 1;
+    {  // the residuals of a chunk leave through LDS: shrink the chunk if the tile's pose rows leave less room
+        const size_t base = (size_t)kRtOffTab + (size_t)2 * max_rows * 48, limit = 160 * 1024 - 512;
+        const size_t room = limit > base ? (limit - base) / ((size_t)8 * (max_gauss > 0 ? max_gauss : 1)) : 1;
+        if ((size_t)b_chunk > room) b_chunk = room > 0 ? (int)room : 1;
+    }
     chunks = (B + b_chunk - 1) / b_chunk;
     const size_t lds_tiles = (size_t)kRtOffTab + (size_t)2 * max_rows * 48 + (size_t)b_chunk * max_gauss * 8;
     const size_t lds_big = 384 + (size_t)2 * max_rows * 48;

@@ -216,3 +216,34 @@ def test_config3_full_size_structure_and_residuals(hip, orc, full_window):
 def test_config3_full_size_two_iterations_match_oracle(hip, orc, full_window):
     rep, _ = _parity_run(hip, orc, full_window, DmsaOptimSettings.sliding_window(num_iter=2))
     assert rep.num_gaussians > 10_000
+
+
+@pytest.mark.parametrize("dt_res", [2e-4, 2e-5])
+def test_long_pose_tables(hip, orc, dt_res):
+    """Dense pose tables of 10^3 .. 10^4 rows (fine dt_res): tiles may reference more rows than the tiled kernels hold in LDS, in
+    which case the library falls back to the streaming kernels -- same structure, residuals within 1e-6, parity path exact."""
+    prob = synth.window_problem(seed=14, scans=2, rings=32, az_steps=256, num_static=3000, dt_res=dt_res)
+    assert prob.trajTime.shape[0] > 900
+    s = DmsaOptimSettings.sliding_window(num_iter=2)
+    _parity_run(hip, orc, prob, s)
+    opt = hip.DmsaOptimizer(pose_table_host=True)
+    opt.upload(prob)
+    opt.poseTables(prob.getPoseParameters())
+    opt.updateGlobalPoints(0, download=False)
+    M, Mm = opt.buildGaussians(s)
+    table, _ = orc.window_pose_table(prob)
+    g = orc.transform_points(table, prob.localPoints, prob.tformIdPerPoint)
+    glob = np.concatenate([g, prob.staticPoints]).astype(np.float32)
+    ref = orc.Gaussians(glob, np.concatenate([prob.ringIds, prob.staticRingIds]), prob.minGridSize, s)
+    assert (M, Mm) == (ref.M, ref.Mm)
+    _, _, info, w = opt.gaussians()
+    ref.set_info(info, w)
+    base = prob.getPoseParameters()
+    params = np.stack([base, base + H_INCR * np.eye(len(base))[2]])
+    tables = opt.poseTables(params)
+    e = opt.evalResiduals(2)
+    for b in range(2):
+        gb = orc.transform_points(tables[b], prob.localPoints, prob.tformIdPerPoint)
+        e_ref = ref.residuals(np.concatenate([gb, prob.staticPoints]).astype(np.float32))
+        rel = np.abs(e[b] - e_ref) / np.maximum(np.abs(e_ref), 1e-12)
+        assert rel.max() < 1e-6, (b, rel.max())
