@@ -17,6 +17,9 @@ the optimised poses (RCCL) — is inside the timed region.  value = total iterat
 into N neighbourhoods sharing a boundary frame (sharding.py), rank i keeps only its submap resident, and the timed region
 ends with the all-gather of relative poses + updatePosesFromSubmap on every rank.
 
+`DMSA_BENCH_BACKEND=gloo` rehearses the N > 1 control flow (barriers, gathers, max-over-ranks timing) with more ranks than
+GPUs: ranks share devices and the collectives run on CPU tensors (used to test the 2-rank paths on a 1-GPU box).
+
 Rank 0 prints ONE JSON line with `roofline` (correspondence kernel, HIP-event timed on the library stream) and
 `cpu_baseline` (the CPU oracle on a bounded sample of the same workload; oracle/ is used here only as the baseline).
 """
@@ -65,9 +68,16 @@ def main():
             print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DMSA path has no CPU fallback")
+    # DMSA_BENCH_BACKEND=gloo: rehearse the N > 1 control flow on fewer GPUs than ranks (ranks share devices, collectives on CPU tensors)
+    backend = os.environ.get("DMSA_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
+    coll_dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from dmsa_lidar_slam_amd import synth
     from dmsa_lidar_slam_amd.api import DmsaOptimizer
@@ -109,10 +119,10 @@ def main():
     rep = opt.optimizeResident(settings)
     if args.workload == "keyframes":  # sharded keyframe pass: all-gather + updatePosesFromSubmap on every rank
         prob.relOrientations[:], prob.relTranslations[:] = opt.poses()
-        gather_neighbourhood_poses(full_map, prob, ranges, rank, world, dist, f"cuda:{local_rank}")
+        gather_neighbourhood_poses(full_map, prob, ranges, rank, world, dist, coll_dev)
     elif world > 1:  # independent windows: the exchange step is an all-gather of the optimised poses over RCCL/xGMI
         ro, rt = opt.poses()
-        mine = torch.from_numpy(np.concatenate([ro.ravel(), rt.ravel()])).cuda()
+        mine = torch.from_numpy(np.concatenate([ro.ravel(), rt.ravel()])).to(coll_dev)
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
     sync_all()
@@ -149,7 +159,7 @@ def main():
                   "note": "DMSA_FLAG_MIRROR_SUMS | DMSA_FLAG_POSE_TABLE_HOST: residual vectors bit-identical to the CPU oracle (tests/test_gpu_configs.py)"}
         opt3.close()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
