@@ -110,7 +110,7 @@ struct dmsa_ctx {
     // voxelisation
     // per-resolution scratch: the two voxelisations of an iteration run concurrently on `stream` and `stream2`
     DevBuf d_aabb, d_lattice, d_code[2], d_idx[2], d_code_s[2], d_idx_s[2], d_head[2], d_leaf_incl[2], d_leaf_start[2], d_slot_acc[2], d_slot_cnt[2],
-        d_gauss_of_slot[2], d_memb_of_slot[2], d_pslot_of_slot[2], d_pos_slot_rank[2], d_nsorted[2], d_pair_d[2], d_pair_c[2], d_sort_tmp[2], d_scan_tmp[2], d_counts;
+        d_gauss_of_slot[2], d_memb_of_slot[2], d_pslot_of_slot[2], d_pos_slot_rank[2], d_nsorted[2], d_pair_d[2], d_sort_tmp[2], d_scan_tmp[2], d_counts;
     // Small device->host read-backs land in PINNED memory: an async copy into pageable memory blocks the host for 20-30 us.
     struct Readback {
         LatticeTable lattice[2];
@@ -137,7 +137,7 @@ struct dmsa_ctx {
     DevBuf d_memb_local, d_memb_idx, d_memb_g, d_seg_off, d_info12, d_wg_seg;
     DevBuf d_order_key, d_order_key_s, d_order_val, d_order;  // parity path: Gaussians by descending size
     bool order_valid = false;
-    DevBuf d_memb_tile, d_tiles, d_tile_counts, d_tile_rows, d_fallback, d_pad_off;
+    DevBuf d_memb_tile, d_tiles, d_tile_rows, d_fallback, d_pad_off;
     int num_tiles = 0, num_fallback = 0, tile_max_rows = 0, tile_max_gauss = 0;
     bool use_tiles = true;  // DMSA_K4_TILES=0 selects the streaming kernel
     bool tiles_usable = true;  // false when a tile references more pose rows than the tiled kernels' LDS holds (very long windows)
@@ -277,7 +277,6 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
     HIPCHK(ctx->d_memb_tile.ensure(tile_slot_capacity(n) * 16));
     HIPCHK(ctx->d_pad_off.ensure((2 * n + 2) * 4));
     HIPCHK(ctx->d_tiles.ensure(max_tiles * sizeof(TileDesc)));
-    HIPCHK(ctx->d_tile_counts.ensure(sizeof(TileCounts)));
     HIPCHK(ctx->d_tile_rows.ensure(max_tiles * (size_t)ctx->rows * 4));
     HIPCHK(ctx->d_fallback.ensure((2 * n / (size_t)tile_points() + 16) * 8));  // single-Gaussian tiles: > T members each
     return DMSA_OK;
@@ -920,7 +919,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
                       &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
                       &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
                       &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_memb_g, &ctx->d_seg_off,
-                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_order_key, &ctx->d_order_key_s, &ctx->d_order_val, &ctx->d_order, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_counts, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_pad_off, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
+                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_order_key, &ctx->d_order_key_s, &ctx->d_order_val, &ctx->d_order, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_pad_off, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
     for (DevBuf* b : bufs) b->release();
     if (ctx->sp) {
         for (DevBuf* b : ctx->sp->all) b->release();
@@ -928,7 +927,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
     }
     for (int l = 0; l < 2; ++l)
         for (DevBuf* b : {&ctx->d_head[l], &ctx->d_slot_acc[l], &ctx->d_slot_cnt[l], &ctx->d_gauss_of_slot[l], &ctx->d_memb_of_slot[l], &ctx->d_pslot_of_slot[l], &ctx->d_pos_slot_rank[l],
-                          &ctx->d_nsorted[l], &ctx->d_pair_d[l], &ctx->d_pair_c[l], &ctx->d_sort_tmp[l], &ctx->d_scan_tmp[l]})
+                          &ctx->d_nsorted[l], &ctx->d_pair_d[l], &ctx->d_sort_tmp[l], &ctx->d_scan_tmp[l]})
             b->release();
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipEventDestroy(ctx->ev_fork), (void)hipEventDestroy(ctx->ev_scan0), (void)hipEventDestroy(ctx->ev_join), (void)hipEventDestroy(ctx->ev_counts);

@@ -1004,15 +1004,6 @@ void launch_leaf_scan(const int32_t* slot_acc, const int32_t* slot_cnt, int32_t*
     hipLaunchKernelGGL(k_leaf_scan, dim3(1), dim3(1024), 0, s, slot_acc, slot_cnt, gauss_of_slot, memb_of_slot, pslot_of_slot, counts);
 }
 
-__global__ void k_level_totals(const int32_t* __restrict__ slot_acc, const int32_t* __restrict__ slot_cnt, const int32_t* __restrict__ gauss_of_slot,
-                               const int32_t* __restrict__ memb_of_slot, LevelCounts* __restrict__ counts, int64_t nslots) {
-    counts->num_gauss = gauss_of_slot[nslots - 1] + slot_acc[nslots - 1];
-    counts->num_memb = memb_of_slot[nslots - 1] + slot_cnt[nslots - 1];
-}
-void launch_level_totals(const int32_t* slot_acc, const int32_t* slot_cnt, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
-                         LevelCounts* counts, int64_t nslots, hipStream_t s) {
-    hipLaunchKernelGGL(k_level_totals, dim3(1), dim3(1), 0, s, slot_acc, slot_cnt, gauss_of_slot, memb_of_slot, counts, nslots);
-}
 
 // members of accepted sets, physically regrouped in Gaussian order (leaf DFS order, ascending point index inside a
 // set): the correspondence kernel then streams contiguous float4s instead of gathering through index lists.
