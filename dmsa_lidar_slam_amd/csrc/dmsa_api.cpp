@@ -10,11 +10,13 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -74,6 +76,62 @@ struct StaticState {
     int64_t n_cloud = 0;
     bool key32 = false;
     uint32_t table_mask = 0;
+};
+
+// A few persistent host threads for the O(#poses x #evaluations) host math (perturbed pose chains of the keyframe pass, host pose
+// tables of the parity path, packing of an upload).  Spawning threads per batch cost ~0.5 ms per iteration; the workers sleep on a
+// condition variable between batches.
+class WorkerPool {
+public:
+    explicit WorkerPool(int n) {
+        for (int t = 0; t < n; ++t) threads_.emplace_back([this, t]() { run(t); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& th : threads_) th.join();
+    }
+    int size() const { return (int)threads_.size(); }
+    // fn(worker_index, num_workers) on every worker; returns when all are done
+    void run_all(const std::function<void(int, int)>& fn) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn, pending_ = (int)threads_.size(), ++generation_;
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this]() { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void run(int t) {
+        long seen = 0;
+        while (true) {
+            const std::function<void(int, int)>* fn = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&]() { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_, fn = fn_;
+            }
+            (*fn)(t, (int)threads_.size());
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int, int)>* fn_ = nullptr;
+    int pending_ = 0;
+    long generation_ = 0;
+    bool stop_ = false;
 };
 
 }  // namespace
@@ -159,6 +217,7 @@ struct dmsa_ctx {
     int evaluations = 0;
     std::vector<dmsa_iter_trace> trace;
     StaticState* sp = nullptr;
+    WorkerPool* pool = nullptr;  // created on first use
 };
 
 namespace {
@@ -178,6 +237,10 @@ namespace {
         if (_rc != DMSA_OK) return _rc; \
     } while (0)
 
+WorkerPool& workers(dmsa_ctx* ctx) {
+    if (!ctx->pool) ctx->pool = new WorkerPool((int)std::min(16u, std::max(2u, std::thread::hardware_concurrency())));
+    return *ctx->pool;
+}
 hipEvent_t get_event(dmsa_ctx* ctx) {
     if (!ctx->free_events.empty()) {
         hipEvent_t e = ctx->free_events.back();
@@ -311,13 +374,10 @@ int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs) {
             }
         };
         // every table is a pure function of its control poses: build the tables of a batch on several host threads
-        const int nthreads = (int)std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), (size_t)B * rows / 2048 + 1);
-        if (nthreads <= 1) {
+        if ((size_t)B * rows < 4096) {
             build_range(0, B);
         } else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthreads; ++t) pool.emplace_back(build_range, (int)((int64_t)B * t / nthreads), (int)((int64_t)B * (t + 1) / nthreads));
-            for (auto& th : pool) th.join();
+            workers(ctx).run_all([&](int t, int nt) { build_range((int)((int64_t)B * t / nt), (int)((int64_t)B * (t + 1) / nt)); });
         }
         HIPCHK(hipMemcpyAsync(ctx->d_tables.p, ctx->h_tables.data(), ctx->h_tables.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));  // h_tables is reused by the next batch
@@ -709,24 +769,20 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
                 globs.resize((size_t)(1 + P) * gsz);
                 extra.resize((size_t)(1 + P) * a);
                 const KeyframeHost base = ctx->key;
-                const int nthr = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
-                std::vector<std::thread> pool;
-                for (int t = 0; t < nthr; ++t)
-                    pool.emplace_back([&, t]() {
-                        KeyframeHost kh = base;
-                        std::vector<double> lp(origin), g;
-                        for (int k = t; k < P; k += nthr) {
-                            lp = origin;
-                            lp[(size_t)k] += increment;
-                            kh.frames.set_params(lp.data());
-                            kh.frames.relative_to_global();
-                            g.clear();
-                            append_glob(kh.frames, g);
-                            std::copy(g.begin(), g.end(), globs.begin() + (size_t)(1 + k) * gsz);
-                            if (a > 0) kh.additional_rows(&extra[(size_t)(1 + k) * a]);
-                        }
-                    });
-                for (auto& th : pool) th.join();
+                workers(ctx).run_all([&](int t, int nthr) {
+                    KeyframeHost kh = base;
+                    std::vector<double> lp(origin), g;
+                    for (int k = t; k < P; k += nthr) {
+                        lp = origin;
+                        lp[(size_t)k] += increment;
+                        kh.frames.set_params(lp.data());
+                        kh.frames.relative_to_global();
+                        g.clear();
+                        append_glob(kh.frames, g);
+                        std::copy(g.begin(), g.end(), globs.begin() + (size_t)(1 + k) * gsz);
+                        if (a > 0) kh.additional_rows(&extra[(size_t)(1 + k) * a]);
+                    }
+                });
                 ctx->evaluations += P;
                 // leave the chain where the serial loop would: last perturbation evaluated, then parameters restored
                 loop = origin;
@@ -925,6 +981,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
         for (DevBuf* b : ctx->sp->all) b->release();
         delete ctx->sp;
     }
+    delete ctx->pool;
     for (int l = 0; l < 2; ++l)
         for (DevBuf* b : {&ctx->d_head[l], &ctx->d_slot_acc[l], &ctx->d_slot_cnt[l], &ctx->d_gauss_of_slot[l], &ctx->d_memb_of_slot[l], &ctx->d_pslot_of_slot[l], &ctx->d_pos_slot_rank[l],
                           &ctx->d_nsorted[l], &ctx->d_pair_d[l], &ctx->d_sort_tmp[l], &ctx->d_scan_tmp[l]})
@@ -993,13 +1050,10 @@ int dmsa_window_upload(dmsa_ctx* ctx, const dmsa_window_problem* p) {
             }
         }
     };
-    const int nthreads = (int)std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), n / 65536 + 1);
-    if (nthreads <= 1) {
+    if (n < 131072) {
         pack(0, N + S);
     } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; ++t) pool.emplace_back(pack, (N + S) * t / nthreads, (N + S) * (t + 1) / nthreads);
-        for (auto& th : pool) th.join();
+        workers(ctx).run_all([&](int t, int nt) { pack((N + S) * t / nt, (N + S) * (t + 1) / nt); });
     }
     if (bad_row) {
         ctx->err = "tform_idx out of range";
