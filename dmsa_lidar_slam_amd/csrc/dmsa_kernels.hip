@@ -2213,7 +2213,8 @@ __global__ __launch_bounds__(256) void k_residuals_mirror_rows(const float4* __r
     const float4* T = kTableInLds ? s_tab : gtab;
     const int l16 = threadIdx.x & 15;
     // `order` lists the Gaussians by descending size: the four rows of a wave get chains of (almost) equal length and the long
-    // chains -- the critical path -- start first
+    // chains -- the critical path -- start first.  (A whole-wave variant for the longest Gaussians, rows chained through
+    // v_readlane, measured 5 % SLOWER end to end: the readlane hand-over costs more than the 1/16 -> 1/64 parallel work saves.)
     const int task = tblock * 16 + (threadIdx.x >> 4);
     const bool on = task < M;
     const int g = on ? (int)order[task] : 0;
@@ -2275,17 +2276,17 @@ __global__ __launch_bounds__(256) void k_residuals_mirror_rows(const float4* __r
 constexpr int kFitWaveThreshold = 1024;
 // Gaussians::addPointSet (Gaussians.h:130-168) with the oracle's serial double sums, one row per Gaussian (both levels, by
 // descending size like k_residuals_mirror_rows).
-__global__ __launch_bounds__(256) void k_gauss_fit_mirror_rows(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
-                                                               const float4* __restrict__ global, const uint32_t* __restrict__ order, int M,
-                                                               float* __restrict__ info12) {
+__device__ __forceinline__ void gauss_fit_mirror_rows(int block, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
+                                                      const float4* __restrict__ global, const uint32_t* __restrict__ order, int M, int wave_tasks,
+                                                      float* __restrict__ info12) {
     const int l16 = threadIdx.x & 15;
     {
-        const int task = blockIdx.x * 16 + (threadIdx.x >> 4);
+        const int task = block * 16 + (threadIdx.x >> 4);
         const bool on = task < M;
         const int g = on ? (int)order[task] : 0;
         const int b = on ? seg_off[g] : 0;
         int n = on ? seg_off[g + 1] - b : 0;
-        if (n > kFitWaveThreshold) n = 0;  // fitted by k_gauss_fit_mirror_wave (its chains split over the rows of a whole wave)
+        if (n > kFitWaveThreshold && task < wave_tasks) n = 0;  // fitted by gauss_fit_mirror_wave (its chains split over the rows of a whole wave)
         const int nmax = wave_max4(n);
         if (nmax == 0) return;
         constexpr int kRowBatch = 4;  // loads of 4 x 16 members in flight before the chains of a step (see k_residuals_mirror_rows)
@@ -2335,11 +2336,11 @@ __global__ __launch_bounds__(256) void k_gauss_fit_mirror_rows(const int32_t* __
 // independent of each other, so a whole wave takes one Gaussian and spreads them over its four rows: three mean chains on rows
 // 0-2, then the six centred products as (row0: xx, yz) (row1: xy, zz) (row2: xz) (row3: yy).  Every chain is still the oracle's
 // serial sum in member order -> bit-identical.  All rows load the same members (L1 broadcast).
-__global__ __launch_bounds__(256) void k_gauss_fit_mirror_wave(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
-                                                               const float4* __restrict__ global, const uint32_t* __restrict__ order, int M,
-                                                               float* __restrict__ info12) {
-    const int task = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (task >= M) return;
+__device__ __forceinline__ void gauss_fit_mirror_wave(int block, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
+                                                      const float4* __restrict__ global, const uint32_t* __restrict__ order, int M,
+                                                      float* __restrict__ info12) {
+    const int task = (int)((block * blockDim.x + threadIdx.x) >> 6);
+    if (task >= M) return;  // (task < 4 * wave_blocks by construction)
     const int g = (int)order[task];
     const int b = seg_off[g], n = seg_off[g + 1] - b;
     if (n <= kFitWaveThreshold) return;  // order is descending: everything after the first short Gaussian is short too
@@ -2402,14 +2403,23 @@ bool mirror_uses_rows() {
     static const bool serial_threads = std::getenv("DMSA_MIRROR_THREADS") != nullptr;
     return !serial_threads;
 }
+// One launch: the first `wave_blocks` workgroups give every Gaussian of the descending order a whole wave (only those above the
+// threshold do any work -- the long chains, the critical path, start first), the remaining workgroups fit the complement row by
+// row and fill the chip meanwhile.
+__global__ __launch_bounds__(256) void k_gauss_fit_mirror(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
+                                                          const float4* __restrict__ global, const uint32_t* __restrict__ order, int M, int wave_blocks,
+                                                          float* __restrict__ info12) {
+    if ((int)blockIdx.x < wave_blocks)
+        gauss_fit_mirror_wave((int)blockIdx.x, seg_off, memb_idx, global, order, M, info12);
+    else
+        gauss_fit_mirror_rows((int)blockIdx.x - wave_blocks, seg_off, memb_idx, global, order, M, 4 * wave_blocks, info12);
+}
 void launch_gauss_fit_mirror_rows(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const uint32_t* order, int M, float* info12,
                                   hipStream_t s) {
     if (M <= 0) return;
-    // long Gaussians first (they are the critical path), one wave each: waves whose Gaussian is at or below the threshold exit at
-    // once; the rows kernel fits exactly the complement
-    const int wave_tasks = M;
-    hipLaunchKernelGGL(k_gauss_fit_mirror_wave, dim3((wave_tasks + 3) / 4), dim3(256), 0, s, seg_off, memb_idx, global, order, M, info12);
-    hipLaunchKernelGGL(k_gauss_fit_mirror_rows, dim3((M + 15) / 16), dim3(256), 0, s, seg_off, memb_idx, global, order, M, info12);
+    const int wave_blocks = (std::min(M, 16384) + 3) / 4;  // Gaussians above the threshold sit at the front of the order; 16384 x 1024 members bound them
+    const int rows_blocks = (M + 15) / 16;
+    hipLaunchKernelGGL(k_gauss_fit_mirror, dim3(wave_blocks + rows_blocks), dim3(256), 0, s, seg_off, memb_idx, global, order, M, wave_blocks, info12);
 }
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
                       const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s, bool pairs, const uint32_t* order) {
