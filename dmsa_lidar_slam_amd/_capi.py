@@ -120,6 +120,11 @@ class StaticSelectProblem(C.Structure):  # dmsa_static_points.h
     ]
 
 
+class PreprocessConfig(C.Structure):  # dmsa_preprocess_config
+    _fields_ = [("max_num_points_per_scan", C.c_int32), ("min_dist_ds", C.c_float), ("min_dist", C.c_float), ("seed", C.c_uint32),
+                ("lidar_to_imu", C.c_float * 16)]
+
+
 class StaticSelectResult(C.Structure):
     _fields_ = [
         ("num_static", C.c_int64),
@@ -239,6 +244,7 @@ def load_library() -> C.CDLL:
         "dmsa_get_overlap": (C.c_int, [vp, c_float_p, C.c_int64, c_float_p, C.c_int64, C.c_float, c_float_p, c_int64_p]),
         "dmsa_random_grid_downsampling": (C.c_int, [vp, c_float_p, C.c_int64, C.c_float, C.c_uint32, c_int32_p, C.c_int64, c_int64_p]),
         "dmsa_radius_exists": (C.c_int, [vp, c_float_p, C.c_int64, c_float_p, C.c_int64, C.c_float, C.POINTER(C.c_uint8)]),
+        "dmsa_preprocess_scan": (C.c_int, [vp, c_float_p, C.c_int64, C.POINTER(PreprocessConfig), c_float_p, c_int32_p, C.c_int64, c_int64_p, c_float_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -253,5 +259,5 @@ EXPORTED_SYMBOLS = (
     "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
     "dmsa_set_params dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
     "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_optimize_resident dmsa_get_poses "
-    "dmsa_select_static_points dmsa_get_overlap dmsa_random_grid_downsampling dmsa_radius_exists"
+    "dmsa_select_static_points dmsa_get_overlap dmsa_random_grid_downsampling dmsa_radius_exists dmsa_preprocess_scan"
 ).split()

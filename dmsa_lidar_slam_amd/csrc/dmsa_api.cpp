@@ -1514,6 +1514,74 @@ int sp_query(dmsa_ctx* ctx, const float* query_xyz, int64_t nq, float r2) {
     return DMSA_OK;
 }
 
+// randomGridDownsampling (helpers.h:67-182) in three stages on the device-resident cloud sp->cloud.
+int sp_grid_upload(dmsa_ctx* ctx, const float* xyz, int64_t n) {
+    StaticState* sp = ctx->sp;
+    HIPCHK(sp->cloud.ensure((size_t)n * 16));
+    HIPCHK(sp->code.ensure((size_t)n * 8));
+    HIPCHK(sp->idx.ensure((size_t)n * 4));
+    HIPCHK(sp->code_s.ensure((size_t)n * 8));
+    HIPCHK(sp->idx_s.ensure((size_t)n * 4));
+    HIPCHK(sp->head.ensure((size_t)n * 4));
+    HIPCHK(sp->incl.ensure((size_t)n * 4));
+    HIPCHK(sp->leaf_start.ensure(((size_t)n + 1) * 4));
+    HIPCHK(sp->sort_tmp.ensure(sort_pairs_temp_bytes((size_t)n)));
+    HIPCHK(sp->scan_tmp.ensure(scan_temp_bytes((size_t)n)));
+    HIPCHK(sp->counts.ensure(sizeof(GaussCounts)));
+    HIPCHK(sp->lattice.ensure(2 * sizeof(LatticeTable)));
+    HIPCHK(sp->aabb.ensure((size_t)((n + kAabbBlock - 1) / kAabbBlock) * 8 * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(sp->cloud.p, xyz, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    launch_block_aabb(sp->cloud.as<float4>(), n, sp->aabb.as<float>(), ctx->stream);  // independent of the resolution
+    return DMSA_OK;
+}
+// the same PCL-exact lattice / key / leaf machinery as createGaussianSets (DmsaOptimizer.h:282-298): leaves sp->leaf_start (leaf
+// boundaries in depth-first order) and sp->idx_s (point indices, ascending inside a leaf); *leaves = octree.getLeafCount()
+int sp_grid_leaves(dmsa_ctx* ctx, int64_t n, float grid_size, int64_t* leaves) {
+    StaticState* sp = ctx->sp;
+    *leaves = 0;
+    const double res = (double)grid_size;  // OctreePointCloud(gridSize): float -> double resolution
+    const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
+    HIPCHK(hipMemsetAsync(sp->counts.p, 0, sizeof(GaussCounts), ctx->stream));
+    launch_lattice(sp->cloud.as<float4>(), n, sp->aabb.as<float>(), nb, res, res, false, sp->lattice.as<LatticeTable>(), ctx->stream);
+    LatticeTable lat[2];
+    HIPCHK(hipMemcpyAsync(lat, sp->lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(sync_spin(ctx->stream));
+    if (lat[0].status != 0) return lat[0].status;
+    if (!lat[0].defined) return DMSA_OK;  // no finite point: empty octree
+    const unsigned end_bit = (unsigned)(3 * lat[0].final_depth + 1);
+    const bool k32 = end_bit <= 32;
+    LatticeTable* tab = sp->lattice.as<LatticeTable>();
+    GaussCounts* counts = sp->counts.as<GaussCounts>();
+    launch_voxel_keys(sp->cloud.as<float4>(), n, tab, res, sp->code.p, k32, sp->idx.as<uint32_t>(), 0ull, ctx->stream);
+    if (k32)
+        HIPCHK(sort_pairs_u32_u32(sp->sort_tmp.p, sp->sort_tmp.cap, sp->code.as<uint32_t>(), sp->code_s.as<uint32_t>(), sp->idx.as<uint32_t>(),
+                                  sp->idx_s.as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
+    else
+        HIPCHK(sort_pairs_u64_u32(sp->sort_tmp.p, sp->sort_tmp.cap, sp->code.as<uint64_t>(), sp->code_s.as<uint64_t>(), sp->idx.as<uint32_t>(),
+                                  sp->idx_s.as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
+    launch_head_flags(sp->code_s.p, k32, n, tab, sp->head.as<int32_t>(), ctx->stream);
+    HIPCHK(inclusive_scan_i32(sp->scan_tmp.p, sp->scan_tmp.cap, sp->head.as<int32_t>(), sp->incl.as<int32_t>(), (size_t)n, ctx->stream));
+    launch_leaf_starts(sp->head.as<int32_t>(), sp->incl.as<int32_t>(), sp->code_s.p, k32, tab, n, sp->leaf_start.as<int32_t>(), &counts->level[0], ctx->stream);
+    GaussCounts hc{};
+    HIPCHK(hipMemcpyAsync(&hc, counts, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(sync_spin(ctx->stream));
+    *leaves = hc.level[0].num_leaves;
+    return DMSA_OK;
+}
+// srand(seed); one rand() per leaf in depth-first order (helpers.h:86-94) -- the generator is a sequential recurrence, so the draws
+// are made on the host (O(leaves)) and only the pick runs on the device; leaves sp->pick (index into the raw cloud per leaf)
+int sp_grid_pick(dmsa_ctx* ctx, int64_t leaves, uint32_t seed) {
+    StaticState* sp = ctx->sp;
+    std::vector<int32_t> rnd((size_t)leaves);
+    glibc_rand_fill(seed, rnd.data(), (size_t)leaves);
+    HIPCHK(sp->rnd.ensure((size_t)leaves * 4));
+    HIPCHK(sp->pick.ensure((size_t)leaves * 4));
+    HIPCHK(hipMemcpy(sp->rnd.p, rnd.data(), (size_t)leaves * 4, hipMemcpyHostToDevice));  // rnd is a local: synchronous copy
+    launch_leaf_pick(sp->leaf_start.as<int32_t>(), sp->idx_s.as<uint32_t>(), sp->rnd.as<int32_t>(), (int)leaves, sp->pick.as<int32_t>(), ctx->stream);
+    HIPCHK(hipGetLastError());
+    return DMSA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1614,62 +1682,68 @@ int dmsa_random_grid_downsampling(dmsa_ctx* ctx, const float* xyz, int64_t n, fl
     if (n == 0) return DMSA_OK;
     StaticState* sp = sp_state(ctx);
     if (!sp) return DMSA_ERR_NOMEM;
-    const double res = (double)grid_size;  // OctreePointCloud(gridSize): float -> double resolution
-    const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
-    HIPCHK(sp->cloud.ensure((size_t)n * 16));
-    HIPCHK(sp->aabb.ensure((size_t)nb * 8 * sizeof(float)));
-    HIPCHK(sp->lattice.ensure(2 * sizeof(LatticeTable)));
-    HIPCHK(sp->code.ensure((size_t)n * 8));
-    HIPCHK(sp->idx.ensure((size_t)n * 4));
-    HIPCHK(sp->code_s.ensure((size_t)n * 8));
-    HIPCHK(sp->idx_s.ensure((size_t)n * 4));
-    HIPCHK(sp->head.ensure((size_t)n * 4));
-    HIPCHK(sp->incl.ensure((size_t)n * 4));
-    HIPCHK(sp->leaf_start.ensure(((size_t)n + 1) * 4));
-    HIPCHK(sp->sort_tmp.ensure(sort_pairs_temp_bytes((size_t)n)));
-    HIPCHK(sp->scan_tmp.ensure(scan_temp_bytes((size_t)n)));
-    HIPCHK(sp->counts.ensure(sizeof(GaussCounts)));
-    HIPCHK(hipMemcpyAsync(sp->cloud.p, xyz, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(sp->counts.p, 0, sizeof(GaussCounts), ctx->stream));
-    // the same PCL-exact lattice / key / leaf machinery as createGaussianSets (DmsaOptimizer.h:282-298)
-    launch_block_aabb(sp->cloud.as<float4>(), n, sp->aabb.as<float>(), ctx->stream);
-    launch_lattice(sp->cloud.as<float4>(), n, sp->aabb.as<float>(), nb, res, res, false, sp->lattice.as<LatticeTable>(), ctx->stream);
-    LatticeTable lat[2];
-    HIPCHK(hipMemcpyAsync(lat, sp->lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(sync_spin(ctx->stream));
-    if (lat[0].status != 0) return lat[0].status;
-    if (!lat[0].defined) return DMSA_OK;  // no finite point: empty octree
-    const unsigned end_bit = (unsigned)(3 * lat[0].final_depth + 1);
-    const bool k32 = end_bit <= 32;
-    LatticeTable* tab = sp->lattice.as<LatticeTable>();
-    GaussCounts* counts = sp->counts.as<GaussCounts>();
-    launch_voxel_keys(sp->cloud.as<float4>(), n, tab, res, sp->code.p, k32, sp->idx.as<uint32_t>(), 0ull, ctx->stream);
-    if (k32)
-        HIPCHK(sort_pairs_u32_u32(sp->sort_tmp.p, sp->sort_tmp.cap, sp->code.as<uint32_t>(), sp->code_s.as<uint32_t>(), sp->idx.as<uint32_t>(),
-                                  sp->idx_s.as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
-    else
-        HIPCHK(sort_pairs_u64_u32(sp->sort_tmp.p, sp->sort_tmp.cap, sp->code.as<uint64_t>(), sp->code_s.as<uint64_t>(), sp->idx.as<uint32_t>(),
-                                  sp->idx_s.as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
-    launch_head_flags(sp->code_s.p, k32, n, tab, sp->head.as<int32_t>(), ctx->stream);
-    HIPCHK(inclusive_scan_i32(sp->scan_tmp.p, sp->scan_tmp.cap, sp->head.as<int32_t>(), sp->incl.as<int32_t>(), (size_t)n, ctx->stream));
-    launch_leaf_starts(sp->head.as<int32_t>(), sp->incl.as<int32_t>(), sp->code_s.p, k32, tab, n, sp->leaf_start.as<int32_t>(), &counts->level[0], ctx->stream);
-    GaussCounts hc{};
-    HIPCHK(hipMemcpyAsync(&hc, counts, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(sync_spin(ctx->stream));
-    const int64_t leaves = hc.level[0].num_leaves;  // octree.getLeafCount()
+    CHK(sp_grid_upload(ctx, xyz, n));
+    int64_t leaves = 0;
+    CHK(sp_grid_leaves(ctx, n, grid_size, &leaves));  // octree.getLeafCount()
     if (num_out) *num_out = leaves;
     if (leaves > capacity) return DMSA_ERR_INVALID;
     if (leaves == 0 || !picked_index_out) return DMSA_OK;
-    // srand(seed); one rand() per leaf in depth-first order (helpers.h:86-94) -- the generator is sequential, so the draws are made
-    // on the host (O(leaves)) and only the pick runs on the device
-    std::vector<int32_t> rnd((size_t)leaves);
-    glibc_rand_fill(seed, rnd.data(), (size_t)leaves);
-    HIPCHK(sp->rnd.ensure((size_t)leaves * 4));
-    HIPCHK(sp->pick.ensure((size_t)leaves * 4));
-    HIPCHK(hipMemcpyAsync(sp->rnd.p, rnd.data(), (size_t)leaves * 4, hipMemcpyHostToDevice, ctx->stream));
-    launch_leaf_pick(sp->leaf_start.as<int32_t>(), sp->idx_s.as<uint32_t>(), sp->rnd.as<int32_t>(), (int)leaves, sp->pick.as<int32_t>(), ctx->stream);
+    CHK(sp_grid_pick(ctx, leaves, seed));
     HIPCHK(hipMemcpyAsync(picked_index_out, sp->pick.p, (size_t)leaves * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return DMSA_OK;
+}
+
+int dmsa_preprocess_scan(dmsa_ctx* ctx, const float* raw_xyz, int64_t n, const dmsa_preprocess_config* cfg, float* xyz_out, int32_t* src_index_out,
+                         int64_t capacity, int64_t* num_out, float* grid_size_out) {
+    if (num_out) *num_out = 0;
+    if (!ctx || !cfg || n < 0 || (n > 0 && !raw_xyz) || cfg->max_num_points_per_scan < 0 || capacity < 0 || n > (int64_t)0x7FFFFFF0) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    static const float kGrids[4] = {0.4f, 0.3f, 0.2f, 0.15f};  // DmsaSlam.h:572-592
+    if (grid_size_out) *grid_size_out = kGrids[0];
+    if (n == 0) return DMSA_OK;
+    StaticState* sp = sp_state(ctx);
+    if (!sp) return DMSA_ERR_NOMEM;
+    CHK(sp_grid_upload(ctx, raw_xyz, n));
+    int64_t m = 0;
+    float grid = kGrids[0];
+    for (int pass = 0; pass < 4; ++pass) {  // every pass filters the RAW scan again; the last one run is the one kept
+        if (pass > 0 && !(m < (int64_t)cfg->max_num_points_per_scan)) break;
+        grid = kGrids[pass];
+        CHK(sp_grid_leaves(ctx, n, grid, &m));
+    }
+    if (grid_size_out) *grid_size_out = grid;
+    if (m == 0) return DMSA_OK;
+    CHK(sp_grid_pick(ctx, m, cfg->seed));
+    const int mi = (int)m;
+    // the leaf machinery is done with code / idx / code_s / idx_s / head / incl: reuse them for the range sort and the compaction
+    uint32_t* range_bits = sp->code.as<uint32_t>();
+    uint32_t* iota = sp->idx.as<uint32_t>();
+    uint32_t* sorted_bits = sp->code_s.as<uint32_t>();
+    int32_t* sel = sp->head.as<int32_t>();
+    int32_t* scan = sp->incl.as<int32_t>();
+    HIPCHK(sp->out_xyz.ensure((size_t)m * 16));
+    HIPCHK(sp->out_id.ensure((size_t)m * 4));
+    HIPCHK(sp->small.ensure(256));
+    int32_t* d_total = sp->small.as<int32_t>() + 48;
+    launch_scan_ranges(sp->cloud.as<float4>(), sp->pick.as<int32_t>(), mi, range_bits, iota, ctx->stream);
+    HIPCHK(sort_pairs_u32_u32(sp->sort_tmp.p, sp->sort_tmp.cap, range_bits, sorted_bits, iota, sp->idx_s.as<uint32_t>(), (size_t)m, 32u, ctx->stream));
+    const int thres_pos = std::min((int)cfg->max_num_points_per_scan, mi - 1);  // :609
+    launch_scan_range_gate(range_bits, sorted_bits, mi, thres_pos, cfg->min_dist_ds, cfg->min_dist, sel, ctx->stream);
+    HIPCHK(exclusive_scan_i32(sp->scan_tmp.p, sp->scan_tmp.cap, sel, scan, (size_t)m, ctx->stream));
+    launch_scan_emit(sp->cloud.as<float4>(), sp->pick.as<int32_t>(), sel, scan, mi, cfg->lidar_to_imu, sp->out_xyz.as<float4>(), sp->out_id.as<int32_t>(), d_total,
+                     ctx->stream);
+    HIPCHK(hipGetLastError());
+    int32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(sync_spin(ctx->stream));
+    if (num_out) *num_out = total;
+    if (total > capacity) return DMSA_ERR_INVALID;
+    if (total > 0) {
+        if (xyz_out) HIPCHK(hipMemcpyAsync(xyz_out, sp->out_xyz.p, (size_t)total * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (src_index_out) HIPCHK(hipMemcpyAsync(src_index_out, sp->out_id.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     return DMSA_OK;
 }
 

@@ -58,5 +58,12 @@ void launch_pick_offsets(const int32_t* scan_excl, const int32_t* sel, const int
 void launch_count_flags(const uint8_t* flag, int64_t n, unsigned long long* count, hipStream_t s);
 // helpers.h:93-101: out[l] = idx_sorted[start_l + int((double)rnd[l] / RAND_MAX * (double)(cnt_l - 1))]
 void launch_leaf_pick(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* rnd, int num_leaves, int32_t* out, hipStream_t s);
+// DmsaSlam::preProcess after the grid filter (DmsaSlam.h:594-630): ranges of the picked points (as sortable bits) + identity index,
+// the range gate against the threshold at sorted position `thres_pos`, and the stable compaction + lidar->IMU transform (w = 1)
+void launch_scan_ranges(const float4* raw, const int32_t* pick, int m, uint32_t* range_bits, uint32_t* iota, hipStream_t s);
+void launch_scan_range_gate(const uint32_t* range_bits, const uint32_t* sorted_bits, int m, int thres_pos, float min_dist_ds, float min_dist, int32_t* sel,
+                            hipStream_t s);
+void launch_scan_emit(const float4* raw, const int32_t* pick, const int32_t* sel, const int32_t* scan_excl, int m, const float* tform_colmajor, float4* out_xyz,
+                      int32_t* out_src, int32_t* total, hipStream_t s);
 
 }  // namespace dmsa

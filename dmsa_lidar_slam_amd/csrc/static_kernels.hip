@@ -250,4 +250,69 @@ void launch_leaf_pick(const int32_t* leaf_start, const uint32_t* idx_sorted, con
     if (num_leaves > 0) hipLaunchKernelGGL(k_leaf_pick, dim3((unsigned)((num_leaves + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, leaf_start, idx_sorted, rnd, num_leaves, out);
 }
 
+// ---- DmsaSlam::preProcess (DmsaSlam.h:594-630) after the grid filter ----------------------------------------------------------
+// ranges[k] = Vector3f(x, y, z).norm() of filtered point k (:601): sqrt(x0^2 + (x1^2 + x2^2)), correctly rounded float sqrt.
+// Ranges are non-negative (or +inf), so their bit patterns sort like the floats.
+__global__ __launch_bounds__(kBlock) void k_scan_ranges(const float4* __restrict__ raw, const int32_t* __restrict__ pick, int m,
+                                                        uint32_t* __restrict__ range_bits, uint32_t* __restrict__ iota) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const float4 p = raw[pick[k]];
+    const float xx = p.x * p.x, yy = p.y * p.y, zz = p.z * p.z;
+    const float t = yy + zz;
+    range_bits[k] = __float_as_uint(sqrtf(xx + t));
+    iota[k] = (uint32_t)k;
+}
+// :609 thresRange = std::max(rangesSorted[min(max_num_points_per_scan, size - 1)], minDistDS); :616 keep iff range < thresRange &&
+// range > min_dist.  The threshold is read from the sorted ranges on the device: no host round trip between sort and gate.
+__global__ __launch_bounds__(kBlock) void k_scan_range_gate(const uint32_t* __restrict__ range_bits, const uint32_t* __restrict__ sorted_bits, int m,
+                                                            int thres_pos, float min_dist_ds, float min_dist, int32_t* __restrict__ sel) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const float a = __uint_as_float(sorted_bits[thres_pos]);
+    const float thres = a < min_dist_ds ? min_dist_ds : a;  // std::max(a, b) = (a < b) ? b : a
+    const float r = __uint_as_float(range_bits[k]);
+    sel[k] = (r < thres && r > min_dist) ? 1 : 0;
+}
+// stable compaction (pcl::ExtractIndices keeps the order) + pcl::transformPointCloud(lidarToImuTform) + data[3] = 1 (:620-630).
+// Per component x*c0 + (y*c1 + (z*c2 + c3)): pcl::detail::Transformer<float>::se3 of PCL >= 1.10 (SSE2 build), no FMA.
+struct Mat4ColMajor { float m[16]; };
+__global__ __launch_bounds__(kBlock) void k_scan_emit(const float4* __restrict__ raw, const int32_t* __restrict__ pick, const int32_t* __restrict__ sel,
+                                                      const int32_t* __restrict__ scan_excl, int m, Mat4ColMajor T, float4* __restrict__ out_xyz,
+                                                      int32_t* __restrict__ out_src, int32_t* __restrict__ total) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    if (k == m - 1) *total = scan_excl[k] + sel[k];
+    if (!sel[k]) return;
+    const int src = pick[k];
+    const float4 p = raw[src];
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a = p.x * T.m[c], b = p.y * T.m[4 + c], d = p.z * T.m[8 + c];
+        const float t2 = d + T.m[12 + c];
+        const float t1 = b + t2;
+        o[c] = a + t1;
+    }
+    const int at = scan_excl[k];
+    out_xyz[at] = make_float4(o[0], o[1], o[2], 1.0f);
+    out_src[at] = src;
+}
+void launch_scan_ranges(const float4* raw, const int32_t* pick, int m, uint32_t* range_bits, uint32_t* iota, hipStream_t s) {
+    if (m > 0) hipLaunchKernelGGL(k_scan_ranges, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, raw, pick, m, range_bits, iota);
+}
+void launch_scan_range_gate(const uint32_t* range_bits, const uint32_t* sorted_bits, int m, int thres_pos, float min_dist_ds, float min_dist, int32_t* sel,
+                            hipStream_t s) {
+    if (m > 0)
+        hipLaunchKernelGGL(k_scan_range_gate, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, range_bits, sorted_bits, m, thres_pos, min_dist_ds,
+                           min_dist, sel);
+}
+void launch_scan_emit(const float4* raw, const int32_t* pick, const int32_t* sel, const int32_t* scan_excl, int m, const float* tform_colmajor, float4* out_xyz,
+                      int32_t* out_src, int32_t* total, hipStream_t s) {
+    Mat4ColMajor T;
+    for (int i = 0; i < 16; ++i) T.m[i] = tform_colmajor[i];
+    if (m > 0)
+        hipLaunchKernelGGL(k_scan_emit, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, raw, pick, sel, scan_excl, m, T, out_xyz, out_src, total);
+}
+
 }  // namespace dmsa

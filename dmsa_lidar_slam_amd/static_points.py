@@ -126,6 +126,21 @@ class StaticPointSelector:
                                                  flags.ctypes.data_as(C.POINTER(C.c_uint8))), "dmsa_radius_exists")
         return flags[: q.shape[0]].astype(bool)
 
+    def preProcess(self, rawPc, seed: int, max_num_points_per_scan: int = 3000, minDistDS: float = 30.0, min_dist: float = 0.0, lidarToImuTform=None):
+        """DmsaSlam::preProcess (DmsaSlam.h:569-634) on the coordinates of one scan; Config.h defaults.  Returns (filtered points
+        n x 4 with w = 1 in the IMU frame, index into rawPc of each of them, gridSize of the filter pass that was kept)."""
+        a = _xyz4(rawPc)
+        cfg = capi.PreprocessConfig()
+        cfg.max_num_points_per_scan, cfg.min_dist_ds, cfg.min_dist, cfg.seed = int(max_num_points_per_scan), float(minDistDS), float(min_dist), int(seed) & 0xFFFFFFFF
+        T = np.eye(4, dtype=np.float32) if lidarToImuTform is None else np.asarray(lidarToImuTform, np.float32).reshape(4, 4)
+        cfg.lidar_to_imu[:] = [float(v) for v in T.T.reshape(-1)]  # Eigen storage: column-major
+        cap = a.shape[0]
+        xyz, src = np.zeros((max(cap, 1), 4), np.float32), np.zeros(max(cap, 1), np.int32)
+        n, grid = C.c_int64(0), C.c_float(0.0)
+        self._check(self._lib.dmsa_preprocess_scan(self._ctx, capi.ptr(a, C.c_float), a.shape[0], C.byref(cfg), capi.ptr(xyz, C.c_float), capi.ptr(src, C.c_int32),
+                                                   cap, C.byref(n), C.byref(grid)), "dmsa_preprocess_scan")
+        return xyz[: n.value].copy(), src[: n.value].copy(), float(grid.value)
+
     def addStaticPoints(self, prob: StaticSelectProblem, seed: int):
         """The whole of DmsaSlam::addStaticPoints after the keyframe distance gate: selection, thinning at minGridSize/2
         (srand(seed)), overlap ratio against the window cloud.  Returns (selection, activePoints, activeIds, overlapToStatic)."""

@@ -6,6 +6,7 @@
  *   DmsaSlam::isVisible            include/DMSA/DmsaSlam.h:360-375
  *   DmsaSlam::getOverlap           include/DMSA/DmsaSlam.h:377-414
  *   randomGridDownsampling         include/DMSA/helpers.h:67-182
+ *   DmsaSlam::preProcess           include/DMSA/DmsaSlam.h:569-634   (the per-scan filter in front of the window, row f2)
  *
  * Same conventions as dmsa_hip.h (contexts, status codes, float[n][4] points, no CPU fallback).  The reference answers its
  * "nearest neighbour within minGridSize" questions with a FLANN kd-tree (pcl::KdTreeFLANN, flann::L2_Simple); only the
@@ -67,6 +68,27 @@ int dmsa_random_grid_downsampling(dmsa_ctx* ctx, const float* xyz, int64_t n, fl
  * (squared L2_Simple distance <= radius*radius in float).  Non-finite cloud points never match, non-finite queries get 0. */
 int dmsa_radius_exists(dmsa_ctx* ctx, const float* cloud_xyz, int64_t n_cloud, const float* query_xyz, int64_t n_query, float radius,
                        uint8_t* flag_out);
+
+/* Knobs of DmsaSlam::preProcess that live in Config (Config.h:24-25, :38, :58). */
+typedef struct dmsa_preprocess_config {
+    int32_t  max_num_points_per_scan; /* Config.h:24 (3000; 1000 for livox, dmsa_slam_ros.cpp:204)                      */
+    float    min_dist_ds;             /* Config.h:25 minDistDS: lower bound of the range threshold                      */
+    float    min_dist;                /* Config.h:38: points at or below this range are dropped                         */
+    uint32_t seed;                    /* srand(time(0)) of every filter pass -> srand(seed)                             */
+    float    lidar_to_imu[16];        /* Config.h:58 lidarToImuTform in Eigen's storage order (column-major)            */
+} dmsa_preprocess_config;
+
+/* == DmsaSlam::preProcess(rawPc, filteredPc) (DmsaSlam.h:569-634) on the coordinates of one scan:
+ *   1. adaptive random grid filter: randomGridDownsampling at 0.4 m, then 0.3 / 0.2 / 0.15 m while the result has fewer than
+ *      max_num_points_per_scan points (:572-592); *grid_size_out = filteredPc->gridSize of the pass that was kept;
+ *   2. ranges = Vector3f(x, y, z).norm(), thresRange = max(sorted ranges[min(max_num_points_per_scan, size - 1)], minDistDS) (:595-609);
+ *   3. keep the points with min_dist < range < thresRange in their order (:611-623);
+ *   4. pcl::transformPointCloud with lidarToImuTform, then data[3] = 1 (:626-630).
+ * xyz_out (capacity x 4 floats) receives the filtered points, src_index_out (capacity) the index INTO the raw scan each of them came
+ * from (stamp / id / isStatic of PointStampId travel with the point, PointStampId.h:33-45).  A scan without finite points gives
+ * num_out = 0 (the reference would read rangesSorted[-1]).  Returns DMSA_ERR_INVALID if capacity is too small (num_out still set). */
+int dmsa_preprocess_scan(dmsa_ctx* ctx, const float* raw_xyz, int64_t n, const dmsa_preprocess_config* cfg, float* xyz_out, int32_t* src_index_out,
+                         int64_t capacity, int64_t* num_out, float* grid_size_out);
 
 #ifdef __cplusplus
 }

@@ -1562,4 +1562,58 @@ int orc_random_grid_downsampling(const float* xyz, int64_t n, float grid_size, u
     return filId <= capacity ? DMSA_OK : DMSA_ERR_INVALID;
 }
 
+// DmsaSlam::preProcess (DmsaSlam.h:569-634) on the xyz part of a scan: adaptive random grid filter (0.4 / 0.3 / 0.2 / 0.15 m until
+// max_num_points_per_scan leaves are reached), range sort + threshold, strict range gates, lidar->IMU transform, w = 1.
+// srand(time(0)) of every filter pass becomes srand(seed) (the passes of one scan fall into the same second).  src_index_out[i] =
+// index into the raw scan of output point i (stamp / id / isStatic travel with it).  pcl::transformPointCloud(Matrix4f) of
+// PCL >= 1.10 (pcl::detail::Transformer<float>, SSE2 build): x*c0 + (y*c1 + (z*c2 + c3)) per component, no FMA -- recalled, the
+// PCL source is not in this container.  `tform` is the Eigen (column-major) storage of lidarToImuTform.
+int orc_preprocess_scan(const float* raw_xyz, int64_t n, int32_t max_num_points_per_scan, float min_dist_ds, float min_dist, uint32_t seed,
+                        const float* tform, float* xyz_out, int32_t* src_index_out, int64_t capacity, int64_t* num_out, float* grid_size_out) {
+    if (num_out) *num_out = 0;
+    if (n < 0 || max_num_points_per_scan < 0 || !tform) return DMSA_ERR_INVALID;
+    const float grids[4] = {0.4f, 0.3f, 0.2f, 0.15f};
+    std::vector<int32_t> pick((size_t)std::max<int64_t>(n, 1));
+    int64_t m = 0;
+    float grid = grids[0];
+    for (int pass = 0; pass < 4; ++pass) {  // :572-592
+        if (pass > 0 && !(m < (int64_t)max_num_points_per_scan)) break;
+        grid = grids[pass];
+        const int rc = orc_random_grid_downsampling(raw_xyz, n, grid, seed, pick.data(), n, &m);
+        if (rc != DMSA_OK) return rc;
+    }
+    if (grid_size_out) *grid_size_out = grid;
+    if (m == 0) return DMSA_OK;  // (the reference would index rangesSorted[-1] here)
+    std::vector<float> ranges((size_t)m), sorted((size_t)m);
+    for (int64_t k = 0; k < m; ++k) {  // :601 Vector3f::norm(): sqrt(x0^2 + (x1^2 + x2^2)), Eigen's unrolled 3-term redux
+        const float* p = raw_xyz + 4 * (size_t)pick[(size_t)k];
+        const float xx = p[0] * p[0], yy = p[1] * p[1], zz = p[2] * p[2];
+        const float t = yy + zz;
+        ranges[(size_t)k] = std::sqrt(xx + t);
+        sorted[(size_t)k] = ranges[(size_t)k];
+    }
+    std::sort(sorted.begin(), sorted.end());
+    const float thresRange = std::max(sorted[(size_t)std::min((int)max_num_points_per_scan, (int)(m - 1))], min_dist_ds);  // :609
+    int64_t out = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        if (!(ranges[(size_t)i] < thresRange && ranges[(size_t)i] > min_dist)) continue;  // :616
+        if (out < capacity) {
+            const float* p = raw_xyz + 4 * (size_t)pick[(size_t)i];
+            if (xyz_out) {
+                for (int c = 0; c < 3; ++c) {
+                    const float a = p[0] * tform[0 + c], b = p[1] * tform[4 + c], d = p[2] * tform[8 + c];
+                    const float t2 = d + tform[12 + c];
+                    const float t1 = b + t2;
+                    xyz_out[4 * (size_t)out + c] = a + t1;
+                }
+                xyz_out[4 * (size_t)out + 3] = 1.0f;  // :629-630
+            }
+            if (src_index_out) src_index_out[(size_t)out] = pick[(size_t)i];
+        }
+        ++out;
+    }
+    if (num_out) *num_out = out;
+    return out <= capacity ? DMSA_OK : DMSA_ERR_INVALID;
+}
+
 }  // extern "C"

@@ -94,6 +94,9 @@ int orc_get_overlap(const float* pc1, int64_t n1, const float* pc2, int64_t n2, 
 void orc_glibc_rand(uint32_t seed, int32_t count, int32_t* out); /* the first `count` values of rand() after srand(seed) */
 int orc_random_grid_downsampling(const float* xyz, int64_t n, float grid_size, uint32_t seed, int32_t* picked_index_out, int64_t capacity,
                                  int64_t* num_out);
+/* DmsaSlam::preProcess (DmsaSlam.h:569-634); tform = Eigen storage (column-major) of lidarToImuTform */
+int orc_preprocess_scan(const float* raw_xyz, int64_t n, int32_t max_num_points_per_scan, float min_dist_ds, float min_dist, uint32_t seed,
+                        const float* tform, float* xyz_out, int32_t* src_index_out, int64_t capacity, int64_t* num_out, float* grid_size_out);
 
 #ifdef __cplusplus
 }

@@ -214,6 +214,7 @@ def _static_sigs(L):
     L.orc_glibc_rand.argtypes = [C.c_uint32, C.c_int32, ip]
     L.orc_glibc_rand.restype = None
     L.orc_random_grid_downsampling.argtypes = [fp, C.c_int64, C.c_float, C.c_uint32, ip, C.c_int64, lp]
+    L.orc_preprocess_scan.argtypes = [fp, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_uint32, fp, fp, ip, C.c_int64, lp, fp]
     return L
 
 
@@ -274,6 +275,22 @@ def random_grid_downsampling(xyz, grid_size, seed):
     if rc != 0:
         raise RuntimeError(f"orc_random_grid_downsampling rc={rc}")
     return out[: n.value].copy()
+
+
+def preprocess_scan(raw, seed, max_num_points_per_scan=3000, min_dist_ds=30.0, min_dist=0.0, lidar_to_imu=None):
+    """DmsaSlam::preProcess (DmsaSlam.h:569-634): (filtered xyz1 in the IMU frame, index into raw, gridSize)."""
+    L = _static_sigs(lib())
+    a = np.ascontiguousarray(raw, np.float32)
+    T = np.eye(4, dtype=np.float32) if lidar_to_imu is None else np.asarray(lidar_to_imu, np.float32).reshape(4, 4)
+    tf = np.ascontiguousarray(T.T.reshape(-1))  # Eigen storage: column-major
+    cap = a.shape[0]
+    xyz, src = np.zeros((max(cap, 1), 4), np.float32), np.zeros(max(cap, 1), np.int32)
+    n, grid = C.c_int64(0), C.c_float(0.0)
+    rc = L.orc_preprocess_scan(capi.ptr(a, C.c_float), a.shape[0], int(max_num_points_per_scan), float(np.float32(min_dist_ds)), float(np.float32(min_dist)),
+                               int(seed) & 0xFFFFFFFF, capi.ptr(tf, C.c_float), capi.ptr(xyz, C.c_float), capi.ptr(src, C.c_int32), cap, C.byref(n), C.byref(grid))
+    if rc != 0:
+        raise RuntimeError(f"orc_preprocess_scan rc={rc}")
+    return xyz[: n.value].copy(), src[: n.value].copy(), float(grid.value)
 
 
 def set_threads(n: int) -> None:

@@ -31,6 +31,14 @@ t_ov, ov = timeit(lambda: g.getOverlap(active, p.windowPoints, p.minGridSize))
 t_all, _ = timeit(lambda: g.addStaticPoints(p, 7))
 out = {"window_points": int(p.windowPoints.shape[0]), "keyframe_points": int(p.keyPoints.shape[0]), "selected": int(sel.staticPoints.shape[0]),
        "active": int(active.shape[0]), "overlap": ov[0], "gpu_ms": {"select": round(t_sel, 3), "thin": round(t_ds, 3), "overlap": round(t_ov, 3), "addStaticPoints": round(t_all, 3)}}
+# DmsaSlam::preProcess of one raw 128 x 1024 scan (rays onto a 50 x 36 x 6 m box), Config.h defaults
+rng = np.random.default_rng(5)
+d = rng.normal(size=(131072, 3))
+d[:, 2] *= 0.3
+d /= np.linalg.norm(d, axis=1, keepdims=True)
+raw = np.concatenate([d * np.min(np.array([25.0, 18.0, 3.0])[None, :] / np.maximum(np.abs(d), 1e-9), axis=1)[:, None], np.ones((131072, 1))], axis=1).astype(f32)
+t_pre, pre = timeit(lambda: g.preProcess(raw, 7))
+out["preProcess"] = {"raw_points": int(raw.shape[0]), "filtered": int(pre[0].shape[0]), "grid": pre[2], "gpu_ms": round(t_pre, 3)}
 if "--cpu" in sys.argv:
     from oracle import oracle_py as orc
 
@@ -38,4 +46,7 @@ if "--cpu" in sys.argv:
     c_ds, rp = timeit(lambda: orc.random_grid_downsampling(rs.staticPoints, half, 7), 3)
     c_ov, _ = timeit(lambda: orc.get_overlap(rs.staticPoints[rp], p.windowPoints, p.minGridSize), 3)
     out["cpu_oracle_ms"] = {"select": round(c_sel, 2), "thin": round(c_ds, 2), "overlap": round(c_ov, 2)}
+    c_pre, rpre = timeit(lambda: orc.preprocess_scan(raw, 7), 3)
+    assert np.array_equal(rpre[0], pre[0]) and np.array_equal(rpre[1], pre[1])
+    out["preProcess"]["cpu_oracle_ms"] = round(c_pre, 2)
 print(json.dumps(out))

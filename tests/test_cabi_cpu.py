@@ -38,6 +38,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(capi.WindowProblem) == 192
     assert C.sizeof(capi.KeyframeProblem) == 360
     assert C.sizeof(capi.StaticSelectProblem) == 80 and C.sizeof(capi.StaticSelectResult) == 24  # dmsa_static_points.h
+    assert C.sizeof(capi.PreprocessConfig) == 80
 
 
 def test_default_settings_match_reference_defaults(lib):

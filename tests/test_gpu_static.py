@@ -133,3 +133,54 @@ def test_add_static_points_full_size(gpu, orc):
     assert pick_a.shape == pick_b.shape and np.unique(pick_a).shape == pick_a.shape and not np.array_equal(pick_a, pick_b)
     assert gpu.randomGridDownsampling(active, half, 3).shape[0] <= active.shape[0]
     assert gpu.radiusExists(p.windowPoints, sel.staticPoints, p.minGridSize).all()
+
+
+def _room_scan(rng, n, half=(25.0, 18.0, 3.0)):
+    d = rng.normal(size=(n, 3))
+    d[:, 2] *= 0.3
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t = np.min(np.asarray(half)[None, :] / np.maximum(np.abs(d), 1e-9), axis=1)
+    p = d * t[:, None] + rng.normal(scale=0.01, size=(n, 3))
+    return np.concatenate([p, rng.uniform(0, 1, (n, 1))], axis=1).astype(f32)
+
+
+def _same_scan(a, b):
+    assert a[2] == b[2], "gridSize of the kept filter pass"
+    assert np.array_equal(a[1], b[1]), "indices into the raw scan"
+    assert np.array_equal(a[0], b[0]), "filtered points, bit-exact"
+
+
+@pytest.mark.parametrize("n,max_pts,min_dist_ds,min_dist", [(131072, 3000, 30.0, 0.0), (60000, 1000, 10.0, 4.0), (1500, 3000, 30.0, 0.0), (20000, 100000, 5.0, 1.0)])
+def test_preprocess_scan(gpu, orc, n, max_pts, min_dist_ds, min_dist):
+    """DmsaSlam::preProcess (DmsaSlam.h:569-634): adaptive grid filter, range threshold, gates, lidar->IMU transform, w = 1."""
+    from scipy.spatial.transform import Rotation
+
+    rng = np.random.default_rng(n + max_pts)
+    raw = _room_scan(rng, n)
+    raw[5, 1] = np.nan
+    T = np.eye(4, dtype=f32)
+    T[:3, :3] = Rotation.from_euler("xyz", [0.02, -0.01, 1.3]).as_matrix().astype(f32)
+    T[:3, 3] = [0.05, -0.12, 0.3]
+    for seed in (9, 10):
+        got = gpu.preProcess(raw, seed, max_pts, min_dist_ds, min_dist, T)
+        _same_scan(got, orc.preprocess_scan(raw, seed, max_pts, min_dist_ds, min_dist, T))
+        assert np.all(got[0][:, 3] == 1.0)
+    _same_scan(gpu.preProcess(raw, 9), orc.preprocess_scan(raw, 9))  # Config.h defaults, identity transform
+
+
+def test_preprocess_scan_edge_cases(gpu, orc):
+    rng = np.random.default_rng(2)
+    assert gpu.preProcess(np.zeros((0, 4), f32), 1)[0].shape == (0, 4)
+    assert gpu.preProcess(np.full((7, 4), np.nan, f32), 1)[0].shape == (0, 4)
+    one = np.array([[3.0, 4.0, 0.0, 0.5]], f32)
+    _same_scan(gpu.preProcess(one, 1), orc.preprocess_scan(one, 1))  # thresRange = max(5, 30): kept
+    _same_scan(gpu.preProcess(one, 1, 3000, 4.0, 0.0), orc.preprocess_scan(one, 1, 3000, 4.0, 0.0))  # range == thresRange: dropped (strict <)
+    assert gpu.preProcess(one, 1, 3000, 4.0, 0.0)[0].shape[0] == 0
+    _same_scan(gpu.preProcess(one, 1, 3000, 30.0, 5.0), orc.preprocess_scan(one, 1, 3000, 30.0, 5.0))  # range == min_dist: dropped (strict >)
+    # the scratch is shared with the other static-point functions: interleave them
+    raw = _room_scan(rng, 40000)
+    a = gpu.preProcess(raw, 3)
+    gpu.radiusExists(raw[:5000], raw[5000:9000], 0.3)
+    gpu.randomGridDownsampling(raw, 0.2, 3)
+    _same_scan(gpu.preProcess(raw, 3), a)
+    _same_scan(a, orc.preprocess_scan(raw, 3))

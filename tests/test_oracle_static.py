@@ -148,3 +148,77 @@ def test_random_grid_downsampling_matches_octree_model(orc):
     got = orc.random_grid_downsampling(pts, grid, seed)
     assert got.tolist() == ref
     assert len(set(got.tolist())) == len(got) and 17 not in got
+
+
+def _room_scan(rng, n, half=(25.0, 18.0, 3.0)):
+    """Rays from the origin onto the walls of a box: ranges from ~3 m to ~30 m, like an indoor/outdoor lidar scan."""
+    d = rng.normal(size=(n, 3))
+    d[:, 2] *= 0.3
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t = np.min(np.asarray(half)[None, :] / np.maximum(np.abs(d), 1e-9), axis=1)
+    p = d * t[:, None] + rng.normal(scale=0.01, size=(n, 3))
+    return np.concatenate([p, rng.uniform(0, 1, (n, 1))], axis=1).astype(f32)  # w = garbage: preProcess must overwrite it with 1
+
+
+def _preprocess_literal(orc, raw, seed, max_pts, min_dist_ds, min_dist, T):
+    """DmsaSlam.h:569-634 line by line in numpy float32 (grid passes through the oracle's own, separately checked, grid filter)."""
+    grid = f32(0.4)
+    pick = orc.random_grid_downsampling(raw, grid, seed)
+    for g in (f32(0.3), f32(0.2), f32(0.15)):
+        if pick.shape[0] < max_pts:
+            grid = g
+            pick = orc.random_grid_downsampling(raw, g, seed)
+    fil = raw[pick]
+    if fil.shape[0] == 0:
+        return fil, pick, float(grid)
+    x, y, z = fil[:, 0], fil[:, 1], fil[:, 2]
+    ranges = np.sqrt((x * x + (y * y + z * z).astype(f32)).astype(f32)).astype(f32)
+    srt = np.sort(ranges)
+    thres = max(srt[min(max_pts, srt.shape[0] - 1)], f32(min_dist_ds))
+    keep = (ranges < thres) & (ranges > f32(min_dist))
+    fil, pick = fil[keep], pick[keep]
+    T = np.asarray(T, f32)
+    out = np.ones((fil.shape[0], 4), f32)
+    for c in range(3):
+        t2 = (fil[:, 2] * T[c, 2]).astype(f32) + T[c, 3]
+        t1 = (fil[:, 1] * T[c, 1]).astype(f32) + t2.astype(f32)
+        out[:, c] = (fil[:, 0] * T[c, 0]).astype(f32) + t1.astype(f32)
+    return out, pick, float(grid)
+
+
+def _lidar_to_imu():
+    from scipy.spatial.transform import Rotation
+
+    T = np.eye(4, dtype=f32)
+    T[:3, :3] = Rotation.from_euler("xyz", [0.02, -0.01, 1.3]).as_matrix().astype(f32)
+    T[:3, 3] = [0.05, -0.12, 0.3]
+    return T
+
+
+@pytest.mark.parametrize("n,max_pts,min_dist_ds,min_dist", [(60000, 3000, 30.0, 0.0), (60000, 1000, 10.0, 4.0), (1500, 3000, 30.0, 0.0), (20000, 100000, 5.0, 1.0)])
+def test_preprocess_matches_literal_transcription(orc, n, max_pts, min_dist_ds, min_dist):
+    rng = np.random.default_rng(n + max_pts)
+    raw = _room_scan(rng, n)
+    raw[5, 1] = np.nan
+    T = _lidar_to_imu()
+    xyz, src, grid = orc.preprocess_scan(raw, 9, max_pts, min_dist_ds, min_dist, T)
+    ref_xyz, ref_src, ref_grid = _preprocess_literal(orc, raw, 9, max_pts, min_dist_ds, min_dist, T)
+    assert grid == ref_grid and np.array_equal(src, ref_src) and np.array_equal(xyz, ref_xyz)
+    assert np.all(xyz[:, 3] == 1.0) and 5 not in src and np.unique(src).shape == src.shape
+    # the transform is a rigid motion of the picked raw points (independent float64 check)
+    assert np.allclose(xyz[:, :3], raw[src, :3].astype(np.float64) @ T[:3, :3].T.astype(np.float64) + T[:3, 3], atol=1e-4)
+
+
+def test_preprocess_adaptive_grid_and_threshold(orc):
+    """Sparse scan -> the filter falls through to 0.15 m; dense scan -> stays at 0.4 m and the range threshold caps the count at
+    max_num_points_per_scan (ranges strictly below the (max+1)-th smallest) unless minDistDS is larger."""
+    rng = np.random.default_rng(2)
+    sparse, dense = _room_scan(rng, 800), _room_scan(rng, 150000)
+    _, src, grid = orc.preprocess_scan(sparse, 1)
+    assert grid == float(f32(0.15)) and 0 < src.shape[0] <= 800
+    xyz, src, grid = orc.preprocess_scan(dense, 1, 3000, 0.5, 0.0)
+    assert grid == float(f32(0.4)) and src.shape[0] <= 3000 and src.shape[0] > 2900
+    xyz30, src30, _ = orc.preprocess_scan(dense, 1, 3000, 30.0, 0.0)  # minDistDS = 30 m: everything closer than 30 m survives
+    assert src30.shape[0] > src.shape[0] and np.all(np.linalg.norm(xyz30[:, :3], axis=1) < 30.0 + 1e-3)
+    assert orc.preprocess_scan(np.zeros((0, 4), f32), 1)[0].shape == (0, 4)
+    assert orc.preprocess_scan(np.full((7, 4), np.nan, f32), 1)[0].shape == (0, 4)
