@@ -16,7 +16,8 @@ from dmsa_lidar_slam_amd import _capi as capi
 from dmsa_lidar_slam_amd.problems import ContinuousTrajectory, DmsaOptimSettings, MapManagement
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "libdmsa_oracle.so")
+# DMSA_ORACLE_LIB: time another build of the same source (scripts/cpu_variants.py: -O1 like the reference, -O3 -march=native)
+LIB = os.environ.get("DMSA_ORACLE_LIB") or os.path.join(_HERE, "libdmsa_oracle.so")
 _lib = None
 
 
