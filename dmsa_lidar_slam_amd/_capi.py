@@ -125,6 +125,12 @@ class PreprocessConfig(C.Structure):  # dmsa_preprocess_config
                 ("lidar_to_imu", C.c_float * 16)]
 
 
+class TrajState(C.Structure):  # dmsa_traj_state (dmsa_window_setup.h)
+    _fields_ = [("t0", C.c_double), ("horizon", C.c_double), ("dt_res", C.c_double), ("n_total", C.c_int32), ("num_control_poses", C.c_int32),
+                ("stamps", c_double_p), ("traj_time", c_double_p), ("acc_meas", c_double_p), ("ang_vel_meas", c_double_p), ("gravity", C.c_double * 3),
+                ("rel_orient", c_double_p), ("rel_transl", c_double_p), ("glob_orient", c_double_p), ("glob_transl", c_double_p)]
+
+
 class StaticSelectResult(C.Structure):
     _fields_ = [
         ("num_static", C.c_int64),
@@ -245,6 +251,19 @@ def load_library() -> C.CDLL:
         "dmsa_random_grid_downsampling": (C.c_int, [vp, c_float_p, C.c_int64, C.c_float, C.c_uint32, c_int32_p, C.c_int64, c_int64_p]),
         "dmsa_radius_exists": (C.c_int, [vp, c_float_p, C.c_int64, c_float_p, C.c_int64, C.c_float, C.POINTER(C.c_uint8)]),
         "dmsa_preprocess_scan": (C.c_int, [vp, c_float_p, C.c_int64, C.POINTER(PreprocessConfig), c_float_p, c_int32_p, C.c_int64, c_int64_p, c_float_p]),
+        # include/dmsa_window_setup.h
+        "dmsa_imu_buffer_create": (C.c_int, [C.c_int32, C.POINTER(vp)]),
+        "dmsa_imu_buffer_destroy": (None, [vp]),
+        "dmsa_imu_buffer_add": (C.c_int, [vp, c_double_p, c_double_p, C.c_double]),
+        "dmsa_imu_buffer_closest": (C.c_int, [vp, C.c_double, c_double_p, c_double_p, c_double_p]),
+        "dmsa_imu_buffer_state": (C.c_int, [vp, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]),
+        "dmsa_traj_dims": (C.c_int, [C.c_double, C.c_double, C.c_double, c_double_p, c_int32_p]),
+        "dmsa_traj_grids": (C.c_int, [C.c_double, C.c_double, C.c_int32, C.c_int32, c_double_p, c_double_p, c_int32_p]),
+        "dmsa_traj_tform_indices": (C.c_int, [vp, c_double_p, C.c_int64, C.c_double, c_double_p, C.c_int32, c_int32_p]),
+        "dmsa_traj_transfer_imu": (C.c_int, [vp, C.c_double, c_double_p, C.c_int32, c_double_p, c_double_p, c_double_p]),
+        "dmsa_traj_preint_factors": (C.c_int, [C.c_int32, C.c_int32, c_int32_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                               c_double_p, c_double_p, c_double_p]),
+        "dmsa_traj_update_initial_guess": (C.c_int, [c_int32_p, C.POINTER(TrajState), C.POINTER(TrajState), C.c_int32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -259,5 +278,7 @@ EXPORTED_SYMBOLS = (
     "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
     "dmsa_set_params dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
     "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_optimize_resident dmsa_get_poses "
-    "dmsa_select_static_points dmsa_get_overlap dmsa_random_grid_downsampling dmsa_radius_exists dmsa_preprocess_scan"
+    "dmsa_select_static_points dmsa_get_overlap dmsa_random_grid_downsampling dmsa_radius_exists dmsa_preprocess_scan "
+    "dmsa_imu_buffer_create dmsa_imu_buffer_destroy dmsa_imu_buffer_add dmsa_imu_buffer_closest dmsa_imu_buffer_state dmsa_traj_dims dmsa_traj_grids "
+    "dmsa_traj_tform_indices dmsa_traj_transfer_imu dmsa_traj_preint_factors dmsa_traj_update_initial_guess"
 ).split()

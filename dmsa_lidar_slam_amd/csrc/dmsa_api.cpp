@@ -23,6 +23,7 @@
 
 #include "../../include/dmsa_hip.h"
 #include "../../include/dmsa_static_points.h"
+#include "../../include/dmsa_window_setup.h"
 #include "device_prims.h"
 #include "dmsa_kernels.h"
 #include "host_math.h"
@@ -1744,6 +1745,25 @@ int dmsa_preprocess_scan(dmsa_ctx* ctx, const float* raw_xyz, int64_t n, const d
         if (src_index_out) HIPCHK(hipMemcpyAsync(src_index_out, sp->out_id.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
+    return DMSA_OK;
+}
+
+// include/dmsa_window_setup.h: the one per-point step of the window setup (the rest is host arithmetic in window_setup.cpp)
+int dmsa_traj_tform_indices(dmsa_ctx* ctx, const double* point_stamps, int64_t n, double t0, const double* traj_time, int32_t n_total, int32_t* tform_idx_out) {
+    if (!ctx || n < 0 || n_total < 1 || !traj_time || (n > 0 && (!point_stamps || !tform_idx_out)) || n > (int64_t)0x7FFFFFF0) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    if (n == 0) return DMSA_OK;
+    StaticState* sp = sp_state(ctx);
+    if (!sp) return DMSA_ERR_NOMEM;
+    HIPCHK(sp->cloud.ensure((size_t)n * 8));
+    HIPCHK(sp->query.ensure((size_t)n_total * 8));
+    HIPCHK(sp->out_id.ensure((size_t)n * 4));
+    HIPCHK(hipMemcpyAsync(sp->cloud.p, point_stamps, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(sp->query.p, traj_time, (size_t)n_total * 8, hipMemcpyHostToDevice, ctx->stream));
+    launch_tform_indices(sp->cloud.as<double>(), n, t0, sp->query.as<double>(), n_total, sp->out_id.as<int32_t>(), ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(tform_idx_out, sp->out_id.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return DMSA_OK;
 }
 

@@ -65,5 +65,7 @@ void launch_scan_range_gate(const uint32_t* range_bits, const uint32_t* sorted_b
                             hipStream_t s);
 void launch_scan_emit(const float4* raw, const int32_t* pick, const int32_t* sel, const int32_t* scan_excl, int m, const float* tform_colmajor, float4* out_xyz,
                       int32_t* out_src, int32_t* total, hipStream_t s);
+// ContinuousTrajectory::registerPcBuffer (:240-260): out[k] = min(lower_bound(traj_time, stamps[k] - t0), n_total - 1)
+void launch_tform_indices(const double* stamps, int64_t n, double t0, const double* traj_time, int n_total, int32_t* out, hipStream_t s);
 
 }  // namespace dmsa

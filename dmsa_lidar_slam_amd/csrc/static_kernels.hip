@@ -315,4 +315,39 @@ void launch_scan_emit(const float4* raw, const int32_t* pick, const int32_t* sel
         hipLaunchKernelGGL(k_scan_emit, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, raw, pick, sel, scan_excl, m, T, out_xyz, out_src, total);
 }
 
+// ---- ContinuousTrajectory::registerPcBuffer (ContinuousTrajectory.h:240-260) ------------------------------------------------------
+// tformIdPerPoint[k] = min(lower_bound(trajTime, stamp_k - t0), n_total - 1): std::lower_bound's own bisection, one per point, on
+// the dense time grid staged in LDS (8 KB at n_total = 1002).  A NaN stamp compares false everywhere and lands on index 0, like the
+// reference.
+constexpr int kTimeGridLds = 8192;  // doubles: 64 KB
+__global__ __launch_bounds__(kBlock) void k_tform_indices(const double* __restrict__ stamps, int64_t n, double t0, const double* __restrict__ traj_time,
+                                                          int n_total, int use_lds, int32_t* __restrict__ out) {
+    extern __shared__ double s_time[];
+    const double* grid = traj_time;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < n_total; i += blockDim.x) s_time[i] = traj_time[i];
+        __syncthreads();
+        grid = s_time;
+    }
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double v = stamps[i] - t0;
+        int first = 0, len = n_total;
+        while (len > 0) {
+            const int half = len >> 1, mid = first + half;
+            if (grid[mid] < v)
+                first = mid + 1, len = len - half - 1;
+            else
+                len = half;
+        }
+        out[i] = first < n_total - 1 ? first : n_total - 1;
+    }
+}
+void launch_tform_indices(const double* stamps, int64_t n, double t0, const double* traj_time, int n_total, int32_t* out, hipStream_t s) {
+    if (n <= 0) return;
+    const int use_lds = n_total <= kTimeGridLds ? 1 : 0;
+    hipLaunchKernelGGL(k_tform_indices, dim3(grid_for(n, kBlock, 2048)), dim3(kBlock), use_lds ? (size_t)n_total * sizeof(double) : 0, s, stamps, n, t0, traj_time,
+                       n_total, use_lds, out);
+}
+
 }  // namespace dmsa

@@ -208,6 +208,42 @@ def window_problem(seed: int = 1, scans: int = 10, rings: int = 128, az_steps: i
     return prob
 
 
+def scan_sequence(seed: int = 1, scans: int = 12, rings: int = 32, az_steps: int = 256, scan_period: float = 0.1, sigma: float = 0.01,
+                  grid_size: float = 0.15, epoch: float = 1.6e9, scene: Scene | None = None):
+    """A stream of scans as the node buffers them (PointCloudBuffer): list of (xyz_local (n,3) f32, absolute stamps (n,) f64,
+    ring ids (n,) i32, gridSize) plus the generating trajectory — input of window_setup.prepareTrajectoryForOptimization."""
+    rng = np.random.default_rng(seed)
+    scene = scene or Scene.room_with_stairs()
+    traj = SmoothTrajectory(p0=np.array([4.0, 3.0, 1.5]))
+    clouds = []
+    for s in range(scans):
+        p, r, t = _scan(scene, traj, s * scan_period, scan_period, rings, az_steps, rng, sigma)
+        clouds.append((p, epoch + t, r.astype(np.int32), np.float32(grid_size)))
+    return clouds, traj
+
+
+def imu_stream(traj: SmoothTrajectory, t_begin: float, t_end: float, rate: float = 400.0, epoch: float = 1.6e9, rng=None, sigma_acc: float = 0.0,
+               sigma_gyr: float = 0.0):
+    """Body-frame specific force and angular velocity along `traj` (what an IMU rigidly mounted at the sensor origin reports,
+    gravity (0, 0, -9.805) as in ContinuousTrajectory.h:345): stamps (absolute), acc (n,3), ang_vel (n,3)."""
+    g = np.array([0.0, 0.0, -9.805])
+    t = np.arange(t_begin, t_end, 1.0 / rate)
+    h = 1e-4
+    R, _ = traj.pose(t)
+    _, pp = traj.pose(t + h)
+    _, p0 = traj.pose(t)
+    _, pm = traj.pose(t - h)
+    a_world = (pp - 2.0 * p0 + pm) / (h * h)
+    acc = R.inv().apply(a_world - g)
+    Rp, _ = traj.pose(t + h)
+    Rm, _ = traj.pose(t - h)
+    ang = (Rm.inv() * Rp).as_rotvec() / (2.0 * h)  # body-frame rate
+    if rng is not None:
+        acc = acc + rng.normal(0.0, sigma_acc, acc.shape)
+        ang = ang + rng.normal(0.0, sigma_gyr, ang.shape)
+    return epoch + t, acc, ang
+
+
 def _imu_factors(traj: SmoothTrajectory, t_off: float, ctrl_stamps: np.ndarray, dt_res: float, rng):
     """Preintegrated factors consistent with the truth (stand-in for ImuPreintegration, which is outside the hot path)."""
     c = len(ctrl_stamps)

@@ -204,6 +204,26 @@ struct BarycentricRational {
         }
         return numerator / denominator;
     }
+    // barycentric_rational_imp<Real>::prime (Boost 1.71 detail/barycentric_rational_detail.hpp), used by updateInitialGuess :418
+    double prime(double t) const {
+        const double rx = (*this)(t);
+        double numerator = 0.0, denominator = 0.0;
+        for (size_t i = 0; i < x.size(); ++i) {
+            if (t == x[i]) {
+                double sum = 0.0;
+                for (size_t j = 0; j < x.size(); ++j) {
+                    if (j == i) continue;
+                    sum += w[j] * (y[i] - y[j]) / (x[i] - x[j]);
+                }
+                return -sum / w[i];
+            }
+            const double q = w[i] / (t - x[i]);
+            const double diff = (rx - y[i]) / (t - x[i]);
+            numerator += q * diff;
+            denominator += q;
+        }
+        return numerator / denominator;
+    }
 };
 
 // Poses.h:16-76: 3xn column-major axis-angle + translations.
@@ -1617,3 +1637,415 @@ int orc_preprocess_scan(const float* raw_xyz, int64_t n, int32_t max_num_points_
 }
 
 }  // extern "C"
+
+// ================================================================================================================================
+// the producers of the hot path's inputs (DmsaSlam::prepareTrajectoryForOptimization, DmsaSlam.h:416-461)
+// ================================================================================================================================
+namespace {
+
+static inline M3 skewm(const double* v) { return M3{{{0.0, -v[2], v[1]}, {v[2], 0.0, -v[0]}, {-v[1], v[0], 0.0}}}; }  // helpers.h:39-49
+static inline M3 smul(double s, const M3& a) {
+    M3 c;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c.m[i][j] = s * a.m[i][j];
+    return c;
+}
+static inline M3 muls(const M3& a, double s) {
+    M3 c;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c.m[i][j] = a.m[i][j] * s;
+    return c;
+}
+static inline M3 addm(const M3& a, const M3& b) {
+    M3 c;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c.m[i][j] = a.m[i][j] + b.m[i][j];
+    return c;
+}
+static inline M3 subm(const M3& a, const M3& b) {
+    M3 c;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c.m[i][j] = a.m[i][j] - b.m[i][j];
+    return c;
+}
+
+// VectorXd::LinSpaced(n, 0, high): Eigen 3.4 linspaced_op_impl<double> (not flipped since |high| >= |low| = 0)
+static void linSpaced(int n, double high, std::vector<double>& out) {
+    out.resize((size_t)n);
+    const double step = n == 1 ? 0.0 : (high - 0.0) / (double)(n - 1);
+    for (int i = 0; i < n; ++i) out[(size_t)i] = (i == n - 1 && n > 1) ? high : 0.0 + (double)i * step;
+}
+
+// ImuBuffer.h:14-175
+struct ImuBufferO {
+    std::vector<double> AccMeas, AngVelMeas, Stamps;
+    double bias_gyr[3] = {0, 0, 0};
+    int oldestIndex = 0, maxNumMeas = 10000, numUpdates = 0;
+    explicit ImuBufferO(int maxNumMeasIn) : maxNumMeas(maxNumMeasIn) {
+        AccMeas.assign(3 * (size_t)maxNumMeas, 0.0), AngVelMeas.assign(3 * (size_t)maxNumMeas, 0.0), Stamps.assign((size_t)maxNumMeas, 0.0);
+    }
+    void addMeasurement(const double* AccVec, const double* AngVelVec, double stamp) {  // :46-66
+        for (int c = 0; c < 3; ++c) AccMeas[3 * (size_t)oldestIndex + c] = AccVec[c], AngVelMeas[3 * (size_t)oldestIndex + c] = AngVelVec[c] - bias_gyr[c];
+        Stamps[(size_t)oldestIndex] = stamp;
+        ++oldestIndex;
+        if (oldestIndex == maxNumMeas) oldestIndex = 0;
+        ++numUpdates;
+        if (numUpdates == 50) {
+            const int n = std::min(numUpdates, maxNumMeas);
+            for (int c = 0; c < 3; ++c) {
+                double sum = 0.0;
+                for (int k = 0; k < n; ++k) sum += AngVelMeas[3 * (size_t)k + c];
+                bias_gyr[c] = sum / (double)n;
+            }
+        }
+    }
+    double getClosestMeasurement(double t, double* AccVec, double* AngVelVec) const {  // :68-125
+        const double* S = Stamps.data();
+        double measurementDiff = 0.0;
+        long index;
+        if (numUpdates <= maxNumMeas || oldestIndex == 0) {
+            const double* pointerToVal = std::lower_bound(S, S + std::min(maxNumMeas - 1, numUpdates - 1), t);
+            index = pointerToVal - S;
+            measurementDiff = std::abs(t - *pointerToVal);
+        } else {
+            const double* pointerToValRight = std::lower_bound(S + oldestIndex, S + maxNumMeas - 1, t);
+            const double* pointerToValLeft = std::lower_bound(S, S + oldestIndex - 1, t);
+            if (std::abs(t - *pointerToValRight) < std::abs(t - *pointerToValLeft)) {
+                index = pointerToValRight - S;
+                measurementDiff = t - *pointerToValRight;
+            } else {
+                index = pointerToValLeft - S;
+                measurementDiff = t - *pointerToValLeft;
+            }
+        }
+        for (int c = 0; c < 3; ++c) AccVec[c] = AccMeas[3 * (size_t)index + c], AngVelVec[c] = AngVelMeas[3 * (size_t)index + c];
+        return measurementDiff;
+    }
+};
+
+// ImuPreintegration.h:23-139 (matrices row-major here; 9 x 9 order rot, vel, pos)
+struct ImuPreintegrationO {
+    double deltaPos[3], deltaVel[3];
+    M3 deltaRot;
+    double cov[9][9];
+    ImuPreintegrationO() { reset(); }
+    void reset() {
+        for (int c = 0; c < 3; ++c) deltaPos[c] = deltaVel[c] = 0.0;
+        deltaRot = eye3();
+        for (auto& r : cov)
+            for (double& v : r) v = 0.0;
+    }
+    static M3 getJacobianR(const double* rot) {  // :35-47
+        const double rotNorm = norm3(rot);
+        const M3 skewRot = skewm(rot);
+        if (rotNorm < 0.00001) return eye3();
+        return addm(subm(eye3(), smul((1.0 - std::cos(rotNorm)) / std::pow(rotNorm, 2), skewRot)),
+                    mul(smul((rotNorm - std::sin(rotNorm)) / std::pow(rotNorm, 3), skewRot), skewRot));
+    }
+    void addMeasurement(const double* omega, const double* acc, double dt, const double* gyr_cov, const double* acc_cov) {  // :55-107
+        const double dt2 = dt * dt;
+        const double w[3] = {dt * omega[0], dt * omega[1], dt * omega[2]};
+        const M3 rotIncr = axang2rotm(w);
+        double A[9][9] = {}, B[9][6] = {}, Noise[6][6] = {};
+        for (int i = 0; i < 9; ++i) A[i][i] = 1.0;
+        auto blockA = [&](int r0, int c0, const M3& M) {
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) A[r0 + r][c0 + c] = M.m[r][c];
+        };
+        auto blockB = [&](int r0, int c0, const M3& M) {
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) B[r0 + r][c0 + c] = M.m[r][c];
+        };
+        blockA(0, 0, transpose(rotIncr));
+        blockA(3, 0, muls(mul(smul(-1.0, deltaRot), skewm(acc)), dt));
+        blockA(6, 0, muls(mul(smul(-0.5, deltaRot), skewm(acc)), dt2));
+        blockA(6, 3, smul(dt, eye3()));
+        double aa[3];
+        rotm2axang(deltaRot, aa);
+        blockB(0, 0, muls(getJacobianR(aa), dt));
+        blockB(3, 3, muls(deltaRot, dt));
+        blockB(6, 3, muls(smul(0.5, deltaRot), dt2));
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) Noise[r][c] = gyr_cov[3 * c + r], Noise[3 + r][3 + c] = acc_cov[3 * c + r];
+        double AC[9][9], BN[9][6], next[9][9];
+        for (int r = 0; r < 9; ++r)
+            for (int c = 0; c < 9; ++c) {
+                double sum = 0.0;
+                for (int k = 0; k < 9; ++k) sum += A[r][k] * cov[k][c];
+                AC[r][c] = sum;
+            }
+        for (int r = 0; r < 9; ++r)
+            for (int c = 0; c < 6; ++c) {
+                double sum = 0.0;
+                for (int k = 0; k < 6; ++k) sum += B[r][k] * Noise[k][c];
+                BN[r][c] = sum;
+            }
+        for (int r = 0; r < 9; ++r)
+            for (int c = 0; c < 9; ++c) {
+                double s1 = 0.0, s2 = 0.0;
+                for (int k = 0; k < 9; ++k) s1 += AC[r][k] * A[c][k];
+                for (int k = 0; k < 6; ++k) s2 += BN[r][k] * B[c][k];
+                next[r][c] = s1 + s2;
+            }
+        std::memcpy(cov, next, sizeof(next));
+        double ra[3], hra[3];
+        matvec(smul(0.5, deltaRot), acc, hra);
+        matvec(deltaRot, acc, ra);
+        for (int c = 0; c < 3; ++c) {
+            deltaPos[c] = deltaPos[c] + (deltaVel[c] * dt + hra[c] * dt2);
+            deltaVel[c] = deltaVel[c] + ra[c] * dt;
+        }
+        deltaRot = mul(deltaRot, rotIncr);
+    }
+};
+
+// Eigen::AngleAxisd(Matrix3d): via Quaterniond(mat) and AngleAxis(q); returns angle() * axis()
+static void angleAxisFromMatrix(const M3& mat, double* out) {
+    double q[4];  // x y z w
+    double t = mat.m[0][0] + mat.m[1][1] + mat.m[2][2];
+    if (t > 0.0) {
+        t = std::sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (mat.m[2][1] - mat.m[1][2]) * t;
+        q[1] = (mat.m[0][2] - mat.m[2][0]) * t;
+        q[2] = (mat.m[1][0] - mat.m[0][1]) * t;
+    } else {
+        int i = 0;
+        if (mat.m[1][1] > mat.m[0][0]) i = 1;
+        if (mat.m[2][2] > mat.m[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(mat.m[i][i] - mat.m[j][j] - mat.m[k][k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (mat.m[k][j] - mat.m[j][k]) * t;
+        q[j] = (mat.m[j][i] + mat.m[i][j]) * t;
+        q[k] = (mat.m[k][i] + mat.m[i][k]) * t;
+    }
+    double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    if (n != 0.0) {
+        const double angle = 2.0 * std::atan2(n, std::fabs(q[3]));
+        if (q[3] < 0.0) n = -n;
+        for (int c = 0; c < 3; ++c) out[c] = angle * (q[c] / n);
+    } else {
+        out[0] = out[1] = out[2] = 0.0;
+    }
+}
+
+// The setup half of ContinuousTrajectory (ContinuousTrajectory.h:228-568), on the caller's arrays
+struct TrajSetupO {
+    dmsa_traj_state* s;
+    ConsecutivePoses controlPoses;
+    explicit TrajSetupO(dmsa_traj_state* st) : s(st) {
+        const int C = s->num_control_poses;
+        controlPoses.resize(C);
+        std::copy(s->rel_orient, s->rel_orient + 3 * C, controlPoses.rel.O.begin()), std::copy(s->rel_transl, s->rel_transl + 3 * C, controlPoses.rel.T.begin());
+        std::copy(s->glob_orient, s->glob_orient + 3 * C, controlPoses.glob.O.begin()), std::copy(s->glob_transl, s->glob_transl + 3 * C, controlPoses.glob.T.begin());
+    }
+    void store() {
+        std::copy(controlPoses.rel.O.begin(), controlPoses.rel.O.end(), s->rel_orient), std::copy(controlPoses.rel.T.begin(), controlPoses.rel.T.end(), s->rel_transl);
+        std::copy(controlPoses.glob.O.begin(), controlPoses.glob.O.end(), s->glob_orient), std::copy(controlPoses.glob.T.begin(), controlPoses.glob.T.end(), s->glob_transl);
+    }
+    void initGravityDir() {  // :263-299
+        const double* measuredGravity = s->acc_meas;  // accMeas.col(0)
+        const double v1[3] = {s->gravity[0], s->gravity[1], s->gravity[2]};
+        const double v2[3] = {-1.0 * measuredGravity[0], -1.0 * measuredGravity[1], -1.0 * measuredGravity[2]};
+        double axis[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+        const double z = axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2];
+        if (z > 0.0) {
+            const double nn = std::sqrt(z);
+            for (double& a : axis) a = a / nn;
+        }
+        const double angle = std::acos((v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2]) / (norm3(v1) * norm3(v2)));
+        const M3 K = skewm(axis);
+        const M3 R_to_grav = addm(addm(eye3(), smul(std::sin(angle), K)), mul(smul(1 - std::cos(angle), K), K));
+        angleAxisFromMatrix(transpose(R_to_grav), &controlPoses.rel.O[0]);
+        controlPoses.relative2global();
+    }
+    static void getInterpRotation(const Poses& posesGlobal, const double* stamps, int n, double t, double* axangNew) {  // :570-591
+        const long rightIndex = std::lower_bound(stamps, stamps + n - 1, t) - stamps;
+        if (rightIndex > 0) {
+            const double t_rel = (t - stamps[rightIndex - 1]) / (stamps[rightIndex] - stamps[rightIndex - 1]);
+            slerp(&posesGlobal.O[3 * (size_t)(rightIndex - 1)], &posesGlobal.O[3 * (size_t)rightIndex], t_rel, axangNew);
+        } else {
+            for (int c = 0; c < 3; ++c) axangNew[c] = posesGlobal.O[(size_t)c];
+        }
+    }
+    void getImuIntegratedParams(double t0, const double* axang0, const double* pos0, const double* v0, double tend, double* axang_end, double* pos_end,
+                                double* v_end) const {  // :470-516
+        const double* tt = s->traj_time;
+        long index = std::lower_bound(tt, tt + s->n_total - 1, t0) - tt;
+        // *(pointerToVal - 1) is read even at index 0 in the reference; t0 <= trajTime[0] there, so `next` always wins
+        const double prev = index > 0 ? tt[index - 1] : -std::numeric_limits<double>::infinity();
+        const double next = tt[index];
+        if (std::abs(t0 - prev) < std::abs(t0 - next)) index = index - 1;
+        M3 R_imu2w = axang2rotm(axang0);
+        double pos_w[3] = {pos0[0], pos0[1], pos0[2]}, vel_w[3] = {v0[0], v0[1], v0[2]};
+        const double dt_res = s->dt_res, dt_res2 = dt_res * dt_res;
+        double currTime = t0;
+        while (std::abs(currTime + dt_res - tend) < std::abs(currTime - tend) && index < s->n_total) {
+            const double* acc = s->acc_meas + 3 * (size_t)index;
+            double hra[3], ra[3];
+            matvec(smul(0.5, R_imu2w), acc, hra);
+            matvec(R_imu2w, acc, ra);
+            for (int c = 0; c < 3; ++c) {
+                pos_w[c] = ((pos_w[c] + vel_w[c] * dt_res) + (0.5 * s->gravity[c]) * dt_res2) + hra[c] * dt_res2;
+                vel_w[c] = (vel_w[c] + s->gravity[c] * dt_res) + ra[c] * dt_res;
+            }
+            const double* av = s->ang_vel_meas + 3 * (size_t)index;
+            const double w[3] = {dt_res * av[0], dt_res * av[1], dt_res * av[2]};
+            R_imu2w = mul(R_imu2w, axang2rotm(w));
+            index += 1;
+            currTime += dt_res;
+        }
+        rotm2axang(R_imu2w, axang_end);
+        for (int c = 0; c < 3; ++c) pos_end[c] = pos_w[c], v_end[c] = vel_w[c];
+    }
+    void updateInitialGuess(int32_t& isInitialized, TrajSetupO& oldTraj, bool useImu) {  // :366-468
+        int lastKnownParamId = 0;
+        if (!isInitialized) {
+            if (useImu) initGravityDir();
+            isInitialized = 1;
+            return;
+        }
+        oldTraj.controlPoses.relative2global();
+        const int C = s->num_control_poses, Co = oldTraj.s->num_control_poses;
+        for (int k = 0; k < C; ++k)
+            if (s->t0 + s->stamps[k] < oldTraj.s->t0 + oldTraj.s->horizon) lastKnownParamId = k;
+        for (int k = 0; k <= lastKnownParamId; ++k)
+            getInterpRotation(oldTraj.controlPoses.glob, oldTraj.s->stamps, Co, s->stamps[k] + s->t0 - oldTraj.s->t0, &controlPoses.glob.O[3 * (size_t)k]);
+        double v0[3];
+        for (int k = 0; k < 3; ++k) {
+            std::vector<double> vec_translations((size_t)Co);
+            for (int j = 0; j < Co; ++j) vec_translations[(size_t)j] = oldTraj.controlPoses.glob.T[3 * (size_t)j + k];
+            BarycentricRational spline(oldTraj.s->stamps, vec_translations.data(), Co, 2);
+            for (int j = 0; j <= lastKnownParamId; ++j) controlPoses.glob.T[3 * (size_t)j + k] = spline(s->stamps[j] + s->t0 - oldTraj.s->t0);
+            v0[k] = spline.prime(s->stamps[lastKnownParamId] + s->t0 - oldTraj.s->t0);
+        }
+        controlPoses.global2relative();
+        if (useImu) {
+            double pos0[3], axang0[3];
+            for (int c = 0; c < 3; ++c) pos0[c] = controlPoses.glob.T[3 * (size_t)lastKnownParamId + c], axang0[c] = controlPoses.glob.O[3 * (size_t)lastKnownParamId + c];
+            for (int k = lastKnownParamId; k < C - 1; ++k) {
+                double axang_end[3], pos_end[3], v_end[3];
+                getImuIntegratedParams(s->stamps[k], axang0, pos0, v0, s->stamps[k + 1], axang_end, pos_end, v_end);
+                for (int c = 0; c < 3; ++c) {
+                    controlPoses.glob.O[3 * (size_t)(k + 1) + c] = axang_end[c], controlPoses.glob.T[3 * (size_t)(k + 1) + c] = pos_end[c];
+                    axang0[c] = axang_end[c], pos0[c] = pos_end[c], v0[c] = v_end[c];
+                }
+            }
+            controlPoses.global2relative();
+        } else {
+            for (int k = lastKnownParamId; k < C - 1; ++k)
+                for (int c = 0; c < 3; ++c) {
+                    controlPoses.rel.O[3 * (size_t)(k + 1) + c] = controlPoses.rel.O[3 * (size_t)lastKnownParamId + c];
+                    controlPoses.rel.T[3 * (size_t)(k + 1) + c] = controlPoses.rel.T[3 * (size_t)lastKnownParamId + c];
+                }
+            controlPoses.relative2global();
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+void* orc_imu_buffer_create(int32_t max_num_meas) { return max_num_meas >= 2 ? new ImuBufferO(max_num_meas) : nullptr; }
+void orc_imu_buffer_destroy(void* b) { delete static_cast<ImuBufferO*>(b); }
+void orc_imu_buffer_add(void* b, const double* acc, const double* ang_vel, double stamp) { static_cast<ImuBufferO*>(b)->addMeasurement(acc, ang_vel, stamp); }
+int orc_imu_buffer_closest(const void* b, double t, double* acc_out, double* ang_vel_out, double* timediff_out) {
+    const ImuBufferO* B = static_cast<const ImuBufferO*>(b);
+    if (B->numUpdates <= 0) return DMSA_ERR_INVALID;
+    *timediff_out = B->getClosestMeasurement(t, acc_out, ang_vel_out);
+    return DMSA_OK;
+}
+void orc_imu_buffer_state(const void* b, int32_t* num_updates, int32_t* oldest_index, double* bias_gyr) {
+    const ImuBufferO* B = static_cast<const ImuBufferO*>(b);
+    *num_updates = B->numUpdates, *oldest_index = B->oldestIndex;
+    for (int c = 0; c < 3; ++c) bias_gyr[c] = B->bias_gyr[c];
+}
+
+// initTraj :301-346
+int orc_traj_dims(double t_min, double t_max, double dt_res, double* horizon_out, int32_t* n_total_out) {
+    const double horizon = t_max - t_min + dt_res;
+    *horizon_out = horizon;
+    *n_total_out = (int32_t)(std::round(horizon / dt_res) + 1);
+    return DMSA_OK;
+}
+int orc_traj_grids(double horizon, double dt_res, int32_t n_total, int32_t C, double* traj_time_out, double* stamps_out, int32_t* param_indices_out) {
+    std::vector<double> v;
+    linSpaced(n_total, horizon, v);
+    std::copy(v.begin(), v.end(), traj_time_out);
+    linSpaced(C, horizon, v);
+    std::copy(v.begin(), v.end(), stamps_out);
+    for (int k = 0; k < C; ++k) param_indices_out[k] = (int32_t)std::round(stamps_out[k] / dt_res);
+    return DMSA_OK;
+}
+// registerPcBuffer :240-260
+int orc_traj_tform_indices(const double* point_stamps, int64_t n, double t0, const double* traj_time, int32_t n_total, int32_t* out) {
+    for (int64_t k = 0; k < n; ++k) {
+        const double* pointerToVal = std::lower_bound(traj_time, traj_time + n_total, point_stamps[k] - t0);
+        out[k] = std::min((int)(pointerToVal - traj_time), (int)(n_total - 1));
+    }
+    return DMSA_OK;
+}
+// transferImuMeasurements :348-364
+int orc_traj_transfer_imu(const void* b, double t0, const double* traj_time, int32_t n_total, double* acc_meas_out, double* ang_vel_meas_out, double* worst) {
+    const ImuBufferO* B = static_cast<const ImuBufferO*>(b);
+    if (B->numUpdates <= 0) return DMSA_ERR_INVALID;
+    double w = 0.0;
+    for (int k = 0; k < n_total; ++k) {
+        const double currGlobalTime = t0 + traj_time[k];
+        const double timediff = B->getClosestMeasurement(currGlobalTime, acc_meas_out + 3 * (size_t)k, ang_vel_meas_out + 3 * (size_t)k);
+        w = std::max(w, std::abs(timediff));
+    }
+    if (worst) *worst = w;
+    return DMSA_OK;
+}
+// updatePreintFactors :518-568
+int orc_traj_preint_factors(int32_t n_total, int32_t C, const int32_t* paramIndices, double dt_res, const double* accMeas, const double* angVelMeas,
+                            const double* gyr_cov, const double* acc_cov, double* preintImuRots, double* preintRelPositions, double* preintRelVelocity,
+                            double* CovPVRot_inv, double* preintPosComplHor) {
+    ImuPreintegrationO imuPreintegration;
+    for (int i = 0; i < 9; ++i) preintImuRots[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int c = 0; c < 3; ++c) preintRelPositions[c] = preintRelVelocity[c] = 0.0;
+    std::fill(CovPVRot_inv, CovPVRot_inv + 81, 0.0);
+    for (int k = 1; k < C; ++k) {
+        const int fromId = paramIndices[k - 1], toId = paramIndices[k];
+        imuPreintegration.reset();
+        for (int t = fromId; t < toId; ++t) imuPreintegration.addMeasurement(angVelMeas + 3 * (size_t)t, accMeas + 3 * (size_t)t, dt_res, gyr_cov, acc_cov);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) preintImuRots[9 * (size_t)k + 3 * c + r] = imuPreintegration.deltaRot.m[r][c];
+        for (int c = 0; c < 3; ++c) preintRelPositions[3 * (size_t)k + c] = imuPreintegration.deltaPos[c], preintRelVelocity[3 * (size_t)k + c] = imuPreintegration.deltaVel[c];
+        std::vector<double> covMat(81), inv;
+        for (int r = 0; r < 9; ++r)
+            for (int c = 0; c < 9; ++c) covMat[(size_t)c * 9 + r] = imuPreintegration.cov[r][c];
+        invert_dense(covMat, 9, inv);  // Matrix<double,9,9>::inverse(): partial-pivot LU
+        std::copy(inv.begin(), inv.end(), CovPVRot_inv + 81 * (size_t)k);
+    }
+    imuPreintegration.reset();
+    for (int t = 0; t < n_total; ++t) imuPreintegration.addMeasurement(angVelMeas + 3 * (size_t)t, accMeas + 3 * (size_t)t, dt_res, gyr_cov, acc_cov);
+    for (int c = 0; c < 3; ++c) preintPosComplHor[c] = imuPreintegration.deltaPos[c];
+    return DMSA_OK;
+}
+// updateInitialGuess :366-468
+int orc_traj_update_initial_guess(int32_t* is_initialized, dmsa_traj_state* cur, dmsa_traj_state* old_traj, int32_t use_imu) {
+    TrajSetupO c(cur);
+    if (!*is_initialized) {
+        TrajSetupO none(cur);
+        c.updateInitialGuess(*is_initialized, none, use_imu != 0);
+        c.store();
+        return DMSA_OK;
+    }
+    TrajSetupO o(old_traj);
+    try {
+        c.updateInitialGuess(*is_initialized, o, use_imu != 0);
+    } catch (const std::logic_error&) {
+        return DMSA_ERR_INVALID;
+    }
+    c.store(), o.store();
+    return DMSA_OK;
+}
+
+}  // extern "C"
+

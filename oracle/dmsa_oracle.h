@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include "../include/dmsa_hip.h" /* POD problem/settings/report structs only */
 #include "../include/dmsa_static_points.h"
+#include "../include/dmsa_window_setup.h" /* dmsa_traj_state POD only */
 
 #ifdef __cplusplus
 extern "C" {
@@ -97,6 +98,22 @@ int orc_random_grid_downsampling(const float* xyz, int64_t n, float grid_size, u
 /* DmsaSlam::preProcess (DmsaSlam.h:569-634); tform = Eigen storage (column-major) of lidarToImuTform */
 int orc_preprocess_scan(const float* raw_xyz, int64_t n, int32_t max_num_points_per_scan, float min_dist_ds, float min_dist, uint32_t seed,
                         const float* tform, float* xyz_out, int32_t* src_index_out, int64_t capacity, int64_t* num_out, float* grid_size_out);
+
+/* ---- ImuBuffer (ImuBuffer.h:14-175), ImuPreintegration (ImuPreintegration.h:23-139) and the setup half of
+ * ContinuousTrajectory (ContinuousTrajectory.h:228-568); same array conventions as include/dmsa_window_setup.h */
+void* orc_imu_buffer_create(int32_t max_num_meas);
+void orc_imu_buffer_destroy(void* b);
+void orc_imu_buffer_add(void* b, const double* acc, const double* ang_vel, double stamp);
+int orc_imu_buffer_closest(const void* b, double t, double* acc_out, double* ang_vel_out, double* timediff_out);
+void orc_imu_buffer_state(const void* b, int32_t* num_updates, int32_t* oldest_index, double* bias_gyr);
+int orc_traj_dims(double t_min, double t_max, double dt_res, double* horizon_out, int32_t* n_total_out);
+int orc_traj_grids(double horizon, double dt_res, int32_t n_total, int32_t C, double* traj_time_out, double* stamps_out, int32_t* param_indices_out);
+int orc_traj_tform_indices(const double* point_stamps, int64_t n, double t0, const double* traj_time, int32_t n_total, int32_t* out);
+int orc_traj_transfer_imu(const void* b, double t0, const double* traj_time, int32_t n_total, double* acc_meas_out, double* ang_vel_meas_out, double* worst);
+int orc_traj_preint_factors(int32_t n_total, int32_t C, const int32_t* paramIndices, double dt_res, const double* accMeas, const double* angVelMeas,
+                            const double* gyr_cov, const double* acc_cov, double* preintImuRots, double* preintRelPositions, double* preintRelVelocity,
+                            double* CovPVRot_inv, double* preintPosComplHor);
+int orc_traj_update_initial_guess(int32_t* is_initialized, dmsa_traj_state* cur, dmsa_traj_state* old_traj, int32_t use_imu);
 
 #ifdef __cplusplus
 }

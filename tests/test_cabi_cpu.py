@@ -21,7 +21,7 @@ def lib():
 
 
 def test_exports_every_declared_symbol(lib):
-    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("dmsa_hip.h", "dmsa_static_points.h"))
+    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("dmsa_hip.h", "dmsa_static_points.h", "dmsa_window_setup.h"))
     declared = set(re.findall(r"\b(dmsa_[a-z_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     assert declared == set(capi.EXPORTED_SYMBOLS)
@@ -39,6 +39,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(capi.KeyframeProblem) == 360
     assert C.sizeof(capi.StaticSelectProblem) == 80 and C.sizeof(capi.StaticSelectResult) == 24  # dmsa_static_points.h
     assert C.sizeof(capi.PreprocessConfig) == 80
+    assert C.sizeof(capi.TrajState) == 120  # dmsa_window_setup.h
 
 
 def test_default_settings_match_reference_defaults(lib):

@@ -1,0 +1,300 @@
+"""SURVEY.md 8(f) row f3 on the CPU: the oracle's restatement of ImuBuffer / ImuPreintegration / the setup half of
+ContinuousTrajectory against independent numpy/scipy implementations, and the product's host functions
+(include/dmsa_window_setup.h, window_setup.cpp) against the oracle — bit for bit: both are plain double arithmetic in the
+reference's evaluation order.  The per-point search (dmsa_traj_tform_indices) needs the GPU: tests/test_gpu_window_setup.py."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation as Rot
+from scipy.spatial.transform import Slerp
+
+from dmsa_lidar_slam_amd import posemath, synth
+from dmsa_lidar_slam_amd import window_setup as ws
+
+GYR_COV = np.diag([1e-4, 2e-4, 1.5e-4]) + 1e-6
+ACC_COV = np.diag([1e-2, 2e-2, 1.5e-2]) + 1e-4
+
+
+@pytest.fixture(scope="module")
+def prod():
+    return ws.WindowSetup(device=0)
+
+
+@pytest.fixture(scope="module")
+def orcw(orc):
+    return orc.WindowSetup()
+
+
+def _same_state(a, b):
+    for f in ("t0", "horizon", "dt_res", "n_total"):
+        assert getattr(a, f) == getattr(b, f), f
+    for f in ("stamps", "trajTime", "paramIndices", "relOrientations", "relTranslations", "globOrientations", "globTranslations", "accMeas", "angVelMeas",
+              "preintImuRots", "preintRelPositions", "preintRelVelocity", "CovPVRot_inv", "preintPosComplHor"):
+        x, y = getattr(a, f), getattr(b, f)
+        assert (x is None) == (y is None), f
+        if x is not None:
+            assert np.array_equal(x, y), f
+
+
+def _fill(buf, stamps, acc, ang, rng=None):
+    """The reference takes the mean of the first 50 angular velocities as gyro bias (ImuBuffer.h:60-64), i.e. it assumes the sensor
+    rests while they arrive: start every stream with 50 samples at rest."""
+    t_rest = stamps[0] - (50 - np.arange(50)) * (stamps[1] - stamps[0])
+    for t in t_rest:
+        buf.addMeasurement([0.0, 0.0, 9.805], rng.normal(0.0, 1e-4, 3) if rng is not None else np.zeros(3), t)
+    for t, a, w in zip(stamps, acc, ang):
+        buf.addMeasurement(a, w, t)
+
+
+# ---- initTraj ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("t_min,t_max,C,dt", [(1.6e9, 1.6e9 + 0.99993, 6, 1e-3), (12.5, 13.0004, 4, 1e-3), (0.0, 0.4999, 6, 2e-3), (1.7e9 + 0.123456, 1.7e9 + 1.3, 8, 1e-3)])
+def test_init_traj(prod, orcw, t_min, t_max, C, dt):
+    a, b = prod.initTraj(t_min, t_max, C, False, dt), orcw.initTraj(t_min, t_max, C, False, dt)
+    _same_state(a, b)
+    horizon = t_max - t_min + dt
+    assert b.horizon == horizon and b.n_total == int(round(horizon / dt)) + 1
+    # LinSpaced: i * step with the exact end point; numpy's linspace is the same statement
+    assert np.array_equal(b.trajTime, np.linspace(0.0, horizon, b.n_total)) and b.trajTime[-1] == horizon and b.trajTime[0] == 0.0
+    assert np.array_equal(b.stamps, np.linspace(0.0, horizon, C))
+    assert np.array_equal(b.paramIndices, np.round(b.stamps / dt).astype(np.int32))
+    assert not b.relOrientations.any() and not b.globTranslations.any()
+
+
+# ---- ImuBuffer -----------------------------------------------------------------------------------------------------------------------
+class _ImuBufferLiteral:
+    """ImuBuffer.h:46-125 transcribed with numpy searchsorted on the same sub-ranges."""
+
+    def __init__(self, n):
+        self.A, self.W, self.S = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros(n)
+        self.bias, self.oldest, self.max, self.num = np.zeros(3), 0, n, 0
+
+    def add(self, a, w, t):
+        self.A[self.oldest], self.W[self.oldest], self.S[self.oldest] = a, np.asarray(w) - self.bias, t
+        self.oldest = (self.oldest + 1) % self.max
+        self.num += 1
+        if self.num == 50:
+            acc = np.zeros(3)
+            for k in range(50):
+                acc = acc + self.W[k]
+            self.bias = acc / 50.0
+
+    def closest(self, t):
+        if self.num <= self.max or self.oldest == 0:
+            i = int(np.searchsorted(self.S[: min(self.max - 1, self.num - 1)], t, side="left"))
+            return self.A[i], self.W[i], abs(t - self.S[i])
+        r = self.oldest + int(np.searchsorted(self.S[self.oldest: self.max - 1], t, side="left"))
+        le = int(np.searchsorted(self.S[: self.oldest - 1], t, side="left"))
+        i = r if abs(t - self.S[r]) < abs(t - self.S[le]) else le
+        return self.A[i], self.W[i], t - self.S[i]
+
+
+@pytest.mark.parametrize("cap,count", [(400, 120), (64, 64), (64, 200), (64, 257), (10000, 49)])
+def test_imu_buffer(orc, cap, count):
+    rng = np.random.default_rng(cap + count)
+    stamps = 1.6e9 + np.cumsum(rng.uniform(0.002, 0.003, count))
+    acc, ang = rng.normal(size=(count, 3)), rng.normal(0.01, 0.002, size=(count, 3))
+    lit, ob, pb = _ImuBufferLiteral(cap), orc.ImuBuffer(cap), ws.ImuBuffer(cap)
+    for t, a, w in zip(stamps, acc, ang):
+        lit.add(a, w, t), ob.addMeasurement(a, w, t), pb.addMeasurement(a, w, t)
+    n, oldest, bias = ob.state()
+    pn, poldest, pbias, latest, oldest_stamp = pb.state()
+    assert (n, oldest) == (lit.num, lit.oldest) == (pn, poldest) and np.array_equal(bias, lit.bias) and np.array_equal(pbias, bias)
+    assert latest == stamps[-1] and oldest_stamp == (stamps[0] if count < cap else stamps[count - cap])
+    if count >= 50:
+        assert np.allclose(bias, ang[:50].mean(axis=0), atol=1e-15)
+    for t in np.concatenate([rng.uniform(stamps[0] - 0.01, stamps[-1] + 0.01, 200), stamps[::7]]):
+        la, lw, ld = lit.closest(t)
+        oa, ow, od = ob.getClosestMeasurement(t)
+        pa, pw, pd = pb.getClosestMeasurement(t)
+        assert np.array_equal(oa, la) and np.array_equal(ow, lw) and od == ld
+        assert np.array_equal(pa, la) and np.array_equal(pw, lw) and pd == ld
+    with pytest.raises(Exception):
+        ws.ImuBuffer(cap).getClosestMeasurement(1.0)  # empty buffer: the reference would search an inverted range
+
+
+# ---- preintegration ----------------------------------------------------------------------------------------------------------------------
+def _skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def _preintegrate_numpy(omega, acc, dt, gyr_cov, acc_cov):
+    """Forster et al. (RSS 2015) as ImuPreintegration.h:55-107 states it, in plain numpy (independent of the C++ restatements)."""
+    dR, dv, dp, cov = np.eye(3), np.zeros(3), np.zeros(3), np.zeros((9, 9))
+    N = np.zeros((6, 6))
+    N[:3, :3], N[3:, 3:] = gyr_cov, acc_cov
+    for w, a in zip(omega, acc):
+        inc = Rot.from_rotvec(dt * w).as_matrix()
+        A, B = np.eye(9), np.zeros((9, 6))
+        A[0:3, 0:3] = inc.T
+        A[3:6, 0:3] = -dR @ _skew(a) * dt
+        A[6:9, 0:3] = -0.5 * dR @ _skew(a) * dt * dt
+        A[6:9, 3:6] = dt * np.eye(3)
+        phi = Rot.from_matrix(dR).as_rotvec()
+        n = np.linalg.norm(phi)
+        Jr = np.eye(3) if n < 1e-5 else np.eye(3) - (1 - np.cos(n)) / n**2 * _skew(phi) + (n - np.sin(n)) / n**3 * _skew(phi) @ _skew(phi)
+        B[0:3, 0:3], B[3:6, 3:6], B[6:9, 3:6] = Jr * dt, dR * dt, 0.5 * dR * dt * dt
+        cov = A @ cov @ A.T + B @ N @ B.T
+        dp = dp + dv * dt + 0.5 * dR @ a * dt * dt
+        dv = dv + dR @ a * dt
+        dR = dR @ inc
+    return dR, dv, dp, cov
+
+
+def _imu_window(prod_or_orc, buf_cls, seed=3):
+    """A trajectory state with IMU samples transferred, shared by the tests below."""
+    clouds, traj = synth.scan_sequence(seed=seed, scans=5, rings=8, az_steps=64)
+    t_min, t_max = min(c[1].min() for c in clouds), max(c[1].max() for c in clouds)
+    st, acc, ang = synth.imu_stream(traj, -0.3, 0.7, rate=400.0, rng=np.random.default_rng(seed), sigma_acc=0.02, sigma_gyr=0.002)
+    buf = buf_cls(10000)
+    _fill(buf, st, acc, ang, np.random.default_rng(seed + 100))
+    state = prod_or_orc.initTraj(t_min, t_max, 6, True, 1e-3)
+    worst = prod_or_orc.transferImuMeasurements(state, buf)
+    return state, worst, clouds, traj, buf
+
+
+def test_transfer_and_preint_factors(prod, orcw, orc):
+    a, worst_a, *_ = _imu_window(prod, ws.ImuBuffer)
+    b, worst_b, *_ = _imu_window(orcw, orc.ImuBuffer)
+    assert worst_a == worst_b and worst_b < 0.0026  # 400 Hz stream: the next sample is at most one period away
+    prod.updatePreintFactors(a, GYR_COV, ACC_COV), orcw.updatePreintFactors(b, GYR_COV, ACC_COV)
+    _same_state(a, b)
+    # independent numpy preintegration between the control poses and over the horizon
+    for k in range(1, 6):
+        lo, hi = b.paramIndices[k - 1], b.paramIndices[k]
+        dR, dv, dp, cov = _preintegrate_numpy(b.angVelMeas[lo:hi], b.accMeas[lo:hi], b.dt_res, GYR_COV, ACC_COV)
+        assert np.allclose(b.preintImuRots[k], dR, atol=1e-12) and np.allclose(b.preintRelVelocity[k], dv, atol=1e-12)
+        assert np.allclose(b.preintRelPositions[k], dp, atol=1e-12)
+        assert np.allclose(b.CovPVRot_inv[k] @ cov, np.eye(9), atol=1e-6)
+    assert np.array_equal(b.preintImuRots[0], np.eye(3)) and not b.preintRelPositions[0].any() and not b.CovPVRot_inv[0].any()
+    *_, dp_all, _ = _preintegrate_numpy(b.angVelMeas, b.accMeas, b.dt_res, GYR_COV, ACC_COV)
+    assert np.allclose(b.preintPosComplHor, dp_all, atol=1e-12)
+
+
+def test_preintegrated_deltas_describe_the_true_motion(orcw, orc):
+    """Physics check: with a noise-free IMU stream the deltas match the generating trajectory (Forster eq. 33)."""
+    clouds, traj = synth.scan_sequence(seed=1, scans=5, rings=8, az_steps=64)
+    st, acc, ang = synth.imu_stream(traj, -0.3, 0.7, rate=1000.0)
+    buf = orc.ImuBuffer(10000)
+    _fill(buf, st, acc, ang)
+    s = orcw.initTraj(min(c[1].min() for c in clouds), max(c[1].max() for c in clouds), 6, True, 1e-3)
+    orcw.transferImuMeasurements(s, buf)
+    orcw.updatePreintFactors(s, GYR_COV, ACC_COV)
+    g, epoch = np.array([0.0, 0.0, -9.805]), 1.6e9
+    for k in range(1, 6):
+        t0, t1 = s.t0 - epoch + s.stamps[k - 1], s.t0 - epoch + s.stamps[k]
+        (R0, p0), (R1, p1) = traj.pose(t0), traj.pose(t1)
+        v0 = (traj.pose(t0 + 1e-5)[1] - traj.pose(t0 - 1e-5)[1]) / 2e-5
+        dt = t1 - t0
+        assert np.allclose(s.preintImuRots[k], (R0.inv() * R1).as_matrix(), atol=2e-3)
+        assert np.allclose(s.preintRelPositions[k], R0.inv().apply(p1 - p0 - v0 * dt - 0.5 * g * dt * dt), atol=2e-3)
+
+
+# ---- updateInitialGuess ------------------------------------------------------------------------------------------------------------------
+def _old_state(setup, seed=5, C=6, t0=1.6e9, horizon=0.501, use_imu=False):
+    rng = np.random.default_rng(seed)
+    s = setup.initTraj(t0, t0 + horizon - 1e-3, C, use_imu, 1e-3)
+    traj = synth.SmoothTrajectory(p0=np.array([4.0, 3.0, 1.5]))
+    R, p = traj.pose(s.stamps)
+    go, gt = R.as_rotvec() + rng.normal(0, 1e-3, (C, 3)), p + rng.normal(0, 1e-3, (C, 3))
+    ro, rt = posemath.global2relative(go, gt)
+    s.relOrientations[...], s.relTranslations[...] = ro, rt
+    return s
+
+
+@pytest.mark.parametrize("shift,C_new", [(0.1, 6), (0.25, 6), (0.45, 4), (0.0, 6), (0.6, 6)])
+def test_update_initial_guess_constant_velocity(prod, orcw, shift, C_new):
+    """Known part = interpolation of the old window (slerp / Floater-Hormann d = 2), rest = constant relative motion (:453-466)."""
+    olds = [_old_state(prod), _old_state(orcw)]
+    curs = [w.initTraj(1.6e9 + shift, 1.6e9 + shift + 0.5, C_new, False, 1e-3) for w in (prod, orcw)]
+    flags = [w.updateInitialGuess(True, c, o, False) for w, c, o in zip((prod, orcw), curs, olds)]
+    assert flags == [True, True]
+    _same_state(curs[0], curs[1]), _same_state(olds[0], olds[1])
+    cur, old = curs[1], olds[1]
+    q = cur.stamps + cur.t0 - old.t0
+    last = int(np.max(np.nonzero(cur.t0 + cur.stamps < old.t0 + old.horizon)[0])) if np.any(cur.t0 + cur.stamps < old.t0 + old.horizon) else 0
+    # old's global poses were refreshed from its relative ones (:382)
+    go, gt = posemath.relative2global(old.relOrientations, old.relTranslations)
+    assert np.allclose(old.globOrientations, go, atol=1e-12) and np.allclose(old.globTranslations, gt, atol=1e-12)
+    if last > 0 or shift == 0.0:
+        from scipy.interpolate import FloaterHormannInterpolator
+
+        inside = [k for k in range(last + 1) if q[k] <= old.stamps[-1]]
+        for a in range(3):
+            fh = FloaterHormannInterpolator(old.stamps, old.globTranslations[:, a], d=2)
+            assert np.allclose(cur.globTranslations[inside, a], fh(q[inside]), atol=1e-9)
+        sl = Slerp(old.stamps, Rot.from_rotvec(old.globOrientations))
+        for k in inside:
+            if q[k] > old.stamps[0]:
+                assert np.allclose(Rot.from_rotvec(cur.globOrientations[k]).as_matrix(), sl([q[k]]).as_matrix()[0], atol=1e-9)
+    # prediction: every relative pose after lastKnown repeats relative pose lastKnown
+    for k in range(last, C_new - 1):
+        assert np.array_equal(cur.relOrientations[k + 1], cur.relOrientations[last]) and np.array_equal(cur.relTranslations[k + 1], cur.relTranslations[last])
+    go, gt = posemath.relative2global(cur.relOrientations, cur.relTranslations)
+    assert np.allclose(cur.globOrientations, go, atol=1e-12) and np.allclose(cur.globTranslations, gt, atol=1e-12)
+
+
+def test_barycentric_prime_is_the_derivative(orcw):
+    """s.prime() (:418) seeds the IMU prediction with the velocity at the last known control pose.  Read it back through a coasting
+    window (zero specific force, zero gravity: p(t) = p0 + v0 t) and compare with a central difference of scipy's Floater-Hormann
+    interpolant — between nodes and exactly at a node (the branch that sums over the other nodes)."""
+    from scipy.interpolate import FloaterHormannInterpolator
+
+    old = _old_state(orcw)
+    _, gt = posemath.relative2global(old.relOrientations, old.relTranslations)
+    for q in (0.4321, old.stamps[4]):
+        cur = orcw.initTraj(old.t0 + q, old.t0 + q + 0.299, 3, True, 1e-3)  # stamps 0 / 0.15 / 0.3: only pose 0 lies inside the old window
+        cur.accMeas, cur.angVelMeas = np.zeros((cur.n_total, 3)), np.zeros((cur.n_total, 3))
+        cur.gravity = np.zeros(3)
+        assert orcw.updateInitialGuess(True, cur, old, True)
+        qq = cur.stamps[0] + cur.t0 - old.t0
+        h = 1e-6
+        v_fd = np.array([(FloaterHormannInterpolator(old.stamps, gt[:, a], d=2)(qq + h) - FloaterHormannInterpolator(old.stamps, gt[:, a], d=2)(qq - h)) / (2 * h)
+                         for a in range(3)])
+        v0 = (cur.globTranslations[1] - cur.globTranslations[0]) / 0.15  # 150 integration steps of 1 ms
+        assert np.allclose(v0, v_fd, rtol=1e-6, atol=1e-7)
+        assert np.allclose(cur.globTranslations[2] - cur.globTranslations[1], cur.globTranslations[1] - cur.globTranslations[0], atol=1e-12)
+
+
+def test_update_initial_guess_imu_prediction(prod, orcw, orc):
+    """IMU branch (:424-452): both implementations agree bit for bit and the predicted poses follow the true motion."""
+    outs = []
+    for w, buf_cls in ((prod, ws.ImuBuffer), (orcw, orc.ImuBuffer)):
+        cur, _, clouds, traj, buf = _imu_window(w, buf_cls, seed=4)
+        old = w.initTraj(cur.t0 - 0.25, cur.t0 + 0.2, 6, True, 1e-3)
+        R, p = traj.pose(old.t0 - 1.6e9 + old.stamps)
+        ro, rt = posemath.global2relative(R.as_rotvec(), p)
+        old.relOrientations[...], old.relTranslations[...] = ro, rt
+        assert w.updateInitialGuess(True, cur, old, True)
+        outs.append((cur, old, traj))
+    _same_state(outs[0][0], outs[1][0]), _same_state(outs[0][1], outs[1][1])
+    cur, old, traj = outs[1]
+    R, p = traj.pose(cur.t0 - 1.6e9 + cur.stamps)
+    assert np.allclose(cur.globTranslations, p, atol=0.02)  # 0.3 s of dead reckoning on a noisy 400 Hz stream
+    assert np.allclose(Rot.from_rotvec(cur.globOrientations).as_matrix(), R.as_matrix(), atol=0.01)
+
+
+def test_first_window_gravity_alignment(prod, orcw, orc):
+    """initGravityDir (:263-299): pose 0 rotates the measured specific force onto -gravity; flag flips; without IMU nothing moves."""
+    outs = []
+    for w, buf_cls in ((prod, ws.ImuBuffer), (orcw, orc.ImuBuffer)):
+        cur, *_ = _imu_window(w, buf_cls, seed=6)
+        assert w.updateInitialGuess(False, cur, None, True) is True
+        outs.append(cur)
+    _same_state(outs[0], outs[1])
+    cur = outs[1]
+    R0 = Rot.from_rotvec(cur.relOrientations[0])
+    up = R0.apply(cur.accMeas[0] / np.linalg.norm(cur.accMeas[0]))
+    assert np.allclose(up, [0.0, 0.0, 1.0], atol=1e-9)
+    assert np.array_equal(cur.globOrientations[0], cur.relOrientations[0]) and not cur.relOrientations[1:].any()
+    plain = orcw.initTraj(0.0, 0.5, 6, False, 1e-3)
+    assert orcw.updateInitialGuess(False, plain, None, False) is True and not plain.relOrientations.any() and not plain.globTranslations.any()
+
+
+def test_tform_indices_oracle_is_searchsorted(orcw):
+    rng = np.random.default_rng(0)
+    s = orcw.initTraj(1.6e9, 1.6e9 + 1.0, 6, False, 1e-3)
+    st = np.concatenate([1.6e9 + rng.uniform(-0.01, 1.02, 5000), s.t0 + s.trajTime[::13], [np.nan, np.inf, -np.inf]])
+    got = orcw.tformIdPerPoint(s, st)
+    with np.errstate(invalid="ignore"):
+        ref = np.minimum(np.searchsorted(s.trajTime, st - s.t0, side="left"), s.n_total - 1)
+    ref[np.isnan(st)] = 0  # every comparison with NaN is false: lower_bound stays at the first element
+    assert np.array_equal(got, ref)
