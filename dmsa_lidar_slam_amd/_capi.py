@@ -131,6 +131,14 @@ class TrajState(C.Structure):  # dmsa_traj_state (dmsa_window_setup.h)
                 ("rel_orient", c_double_p), ("rel_transl", c_double_p), ("glob_orient", c_double_p), ("glob_transl", c_double_p)]
 
 
+class PointCloud2(C.Structure):  # dmsa_pointcloud2 (dmsa_wire_formats.h)
+    _fields_ = [("height", C.c_uint32), ("width", C.c_uint32), ("point_step", C.c_uint32), ("num_fields", C.c_uint32), ("field_offsets", c_uint32_p),
+                ("data", C.POINTER(C.c_uint8)), ("data_bytes", C.c_uint64), ("stamp_msg", C.c_double), ("delta_t_pcs", C.c_double)]
+
+
+SENSORS = {"hesai": 0, "ouster": 1, "robosense": 2, "velodyne": 3, "livoxXYZRTLT_s": 4, "livoxXYZRTLT_ns": 5, "sick": 6, "unknown": 7}
+
+
 class StaticSelectResult(C.Structure):
     _fields_ = [
         ("num_static", C.c_int64),
@@ -264,6 +272,10 @@ def load_library() -> C.CDLL:
         "dmsa_traj_preint_factors": (C.c_int, [C.c_int32, C.c_int32, c_int32_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                                c_double_p, c_double_p, c_double_p]),
         "dmsa_traj_update_initial_guess": (C.c_int, [c_int32_p, C.POINTER(TrajState), C.POINTER(TrajState), C.c_int32]),
+        # include/dmsa_wire_formats.h
+        "dmsa_decode_pointcloud2": (C.c_int, [vp, C.POINTER(PointCloud2), C.c_int32, c_float_p, c_double_p, c_int32_p]),
+        "dmsa_format_tum_pose": (C.c_int, [C.c_double, c_double_p, c_double_p, C.c_char_p, C.c_int32]),
+        "dmsa_compose_nonkeyframe_pose": (C.c_int, [c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -280,5 +292,6 @@ EXPORTED_SYMBOLS = (
     "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_optimize_resident dmsa_get_poses "
     "dmsa_select_static_points dmsa_get_overlap dmsa_random_grid_downsampling dmsa_radius_exists dmsa_preprocess_scan "
     "dmsa_imu_buffer_create dmsa_imu_buffer_destroy dmsa_imu_buffer_add dmsa_imu_buffer_closest dmsa_imu_buffer_state dmsa_traj_dims dmsa_traj_grids "
-    "dmsa_traj_tform_indices dmsa_traj_transfer_imu dmsa_traj_preint_factors dmsa_traj_update_initial_guess"
+    "dmsa_traj_tform_indices dmsa_traj_transfer_imu dmsa_traj_preint_factors dmsa_traj_update_initial_guess "
+    "dmsa_decode_pointcloud2 dmsa_format_tum_pose dmsa_compose_nonkeyframe_pose"
 ).split()

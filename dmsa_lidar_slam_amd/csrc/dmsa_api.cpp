@@ -24,6 +24,7 @@
 #include "../../include/dmsa_hip.h"
 #include "../../include/dmsa_static_points.h"
 #include "../../include/dmsa_window_setup.h"
+#include "../../include/dmsa_wire_formats.h"
 #include "device_prims.h"
 #include "dmsa_kernels.h"
 #include "host_math.h"
@@ -1763,6 +1764,46 @@ int dmsa_traj_tform_indices(dmsa_ctx* ctx, const double* point_stamps, int64_t n
     launch_tform_indices(sp->cloud.as<double>(), n, t0, sp->query.as<double>(), n_total, sp->out_id.as<int32_t>(), ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(tform_idx_out, sp->out_id.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return DMSA_OK;
+}
+
+// include/dmsa_wire_formats.h: the PointCloud2 decoder (the text side lives in wire_formats.cpp)
+int dmsa_decode_pointcloud2(dmsa_ctx* ctx, const dmsa_pointcloud2* msg, int32_t sensor, float* xyz_out, double* stamp_out, int32_t* id_out) {
+    if (!ctx || !msg || sensor < DMSA_SENSOR_HESAI || sensor > DMSA_SENSOR_UNKNOWN) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    const uint64_t n64 = (uint64_t)msg->height * msg->width;
+    if (n64 == 0) return DMSA_OK;
+    if (n64 > 0x7FFFFFF0ull || !msg->data || !msg->field_offsets || msg->num_fields < 3 || !xyz_out || !stamp_out || !id_out) return DMSA_ERR_INVALID;
+    if (n64 * msg->point_step > msg->data_bytes || n64 * msg->point_step > 0xFFFFFFFFull) return DMSA_ERR_INVALID;
+    // which fields the sensor type reads (dmsa_slam_ros.cpp:411-481): {stamp field, its size, ring field, its size}, -1 = none
+    static const int kFields[8][4] = {{4, 8, 5, 2}, {4, 4, 6, 1}, {5, 8, 4, 2}, {5, 4, 4, 2}, {6, 8, -1, 0}, {6, 8, -1, 0}, {8, 4, 11, 1}, {-1, 0, -1, 0}};
+    const int* fs = kFields[sensor];
+    PointCloud2Fields f{msg->field_offsets[0], msg->field_offsets[1], msg->field_offsets[2], 0, 0};
+    auto inside = [&](uint32_t off, uint32_t size) { return (uint64_t)off + size <= msg->point_step; };
+    if (!inside(f.x, 4) || !inside(f.y, 4) || !inside(f.z, 4)) return DMSA_ERR_INVALID;
+    if (fs[0] >= 0) {
+        if ((uint32_t)fs[0] >= msg->num_fields || !inside(msg->field_offsets[fs[0]], (uint32_t)fs[1])) return DMSA_ERR_INVALID;
+        f.stamp = msg->field_offsets[fs[0]];
+    }
+    if (fs[2] >= 0) {
+        if ((uint32_t)fs[2] >= msg->num_fields || !inside(msg->field_offsets[fs[2]], (uint32_t)fs[3])) return DMSA_ERR_INVALID;
+        f.ring = msg->field_offsets[fs[2]];
+    }
+    StaticState* sp = sp_state(ctx);
+    if (!sp) return DMSA_ERR_NOMEM;
+    const size_t n = (size_t)n64, bytes = n * msg->point_step;
+    HIPCHK(sp->query.ensure(bytes));
+    HIPCHK(sp->cloud.ensure(n * 16));
+    HIPCHK(sp->code.ensure(n * 8));
+    HIPCHK(sp->out_id.ensure(n * 4));
+    HIPCHK(hipMemcpyAsync(sp->query.p, msg->data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    launch_decode_pointcloud2(sp->query.as<uint8_t>(), (uint32_t)n, msg->point_step, f, sensor, msg->stamp_msg, msg->delta_t_pcs, sp->cloud.as<float4>(),
+                              sp->code.as<double>(), sp->out_id.as<int32_t>(), ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(xyz_out, sp->cloud.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(stamp_out, sp->code.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(id_out, sp->out_id.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return DMSA_OK;
 }

@@ -67,5 +67,11 @@ void launch_scan_emit(const float4* raw, const int32_t* pick, const int32_t* sel
                       int32_t* out_src, int32_t* total, hipStream_t s);
 // ContinuousTrajectory::registerPcBuffer (:240-260): out[k] = min(lower_bound(traj_time, stamps[k] - t0), n_total - 1)
 void launch_tform_indices(const double* stamps, int64_t n, double t0, const double* traj_time, int n_total, int32_t* out, hipStream_t s);
+// dmsa_slam_ros::callbackPointCloud (:399-486): byte offsets inside a point of the fields the sensor type reads
+struct PointCloud2Fields {
+    uint32_t x, y, z, stamp, ring;
+};
+void launch_decode_pointcloud2(const uint8_t* data, uint32_t n, uint32_t point_step, PointCloud2Fields f, int sensor, double stamp_msg, double delta_t, float4* xyz,
+                               double* stamp, int32_t* id, hipStream_t s);
 
 }  // namespace dmsa

@@ -350,4 +350,43 @@ void launch_tform_indices(const double* stamps, int64_t n, double t0, const doub
                        n_total, use_lds, out);
 }
 
+// ---- dmsa_slam_ros::callbackPointCloud (src/dmsa_slam_ros.cpp:399-486) -------------------------------------------------------------
+// One point per thread: memcpy-style reads from the message blob at the field offsets the sensor type names.  The blob is read
+// byte-wise (fields are not aligned in general); a 131 072-point scan is 4-6 MB, the L2 absorbs the overlap between neighbours.
+template <typename T>
+__device__ __forceinline__ T load_unaligned(const uint8_t* p) {
+    T v;
+    uint8_t* d = reinterpret_cast<uint8_t*>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T); ++i) d[i] = p[i];
+    return v;
+}
+__global__ __launch_bounds__(kBlock) void k_decode_pointcloud2(const uint8_t* __restrict__ data, uint32_t n, uint32_t point_step, PointCloud2Fields f, int sensor,
+                                                               double stamp_msg, double delta_t, float4* __restrict__ xyz, double* __restrict__ stamp,
+                                                               int32_t* __restrict__ id) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint8_t* p = data + (size_t)(k * point_step);  // uint32 product like the reference's `k * msg->point_step`
+    xyz[k] = make_float4(load_unaligned<float>(p + f.x), load_unaligned<float>(p + f.y), load_unaligned<float>(p + f.z), 0.0f);
+    double st;
+    int32_t ring;
+    switch (sensor) {
+        case 0: st = load_unaligned<double>(p + f.stamp), ring = (int32_t)load_unaligned<uint16_t>(p + f.ring); break;                                   // hesai
+        case 1: st = stamp_msg + 1e-9 * (double)load_unaligned<uint32_t>(p + f.stamp), ring = (int32_t)load_unaligned<uint8_t>(p + f.ring); break;      // ouster
+        case 2: st = load_unaligned<double>(p + f.stamp), ring = (int32_t)load_unaligned<uint16_t>(p + f.ring); break;                                   // robosense
+        case 3: st = stamp_msg + (double)load_unaligned<float>(p + f.stamp), ring = (int32_t)load_unaligned<uint16_t>(p + f.ring); break;                // velodyne
+        case 4: st = load_unaligned<double>(p + f.stamp), ring = (int32_t)(k % 1000u); break;                                                            // livox, seconds
+        case 5: st = 1e-9 * load_unaligned<double>(p + f.stamp), ring = (int32_t)(k % 1000u); break;                                                     // livox, nanoseconds
+        case 6: st = stamp_msg + (double)load_unaligned<float>(p + f.stamp), ring = (int32_t)load_unaligned<int8_t>(p + f.ring); break;                  // sick
+        default: st = stamp_msg + delta_t * (double)k / (double)n, ring = (int32_t)(k % 1000u); break;                                                   // unknown
+    }
+    stamp[k] = st;
+    id[k] = ring;
+}
+void launch_decode_pointcloud2(const uint8_t* data, uint32_t n, uint32_t point_step, PointCloud2Fields f, int sensor, double stamp_msg, double delta_t, float4* xyz,
+                               double* stamp, int32_t* id, hipStream_t s) {
+    if (n > 0)
+        hipLaunchKernelGGL(k_decode_pointcloud2, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, data, n, point_step, f, sensor, stamp_msg, delta_t, xyz, stamp, id);
+}
+
 }  // namespace dmsa

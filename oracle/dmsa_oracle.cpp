@@ -2049,3 +2049,120 @@ int orc_traj_update_initial_guess(int32_t* is_initialized, dmsa_traj_state* cur,
 
 }  // extern "C"
 
+// ================================================================================================================================
+// wire formats (src/dmsa_slam_ros.cpp:374-486, OutputManagement.h:80-182)
+// ================================================================================================================================
+#include <iomanip>
+#include <sstream>
+
+extern "C" {
+
+// callbackPointCloud :399-486, literally: memcpy from msg->data at arrayPosition + fields[i].offset
+int orc_decode_pointcloud2(const dmsa_pointcloud2* msg, int32_t sensor, float* xyz_out, double* stamp_out, int32_t* id_out) {
+    const uint32_t n = msg->height * msg->width;
+    const uint8_t* data = msg->data;
+    const uint32_t* off = msg->field_offsets;
+    const double stampMsg = msg->stamp_msg, deltaTPcs = msg->delta_t_pcs;
+    uint8_t ring_tmp8;
+    int8_t ring_int8;
+    uint16_t ring_tmp;
+    uint32_t relStampNano;
+    float tmpStampFloat;
+    double tmpStampDouble;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t arrayPosition = k * msg->point_step;
+        float* xyz = xyz_out + 4 * (size_t)k;
+        xyz[3] = 0.0f;  // value-initialised PointStampId
+        std::memcpy(&xyz[0], &data[arrayPosition + off[0]], sizeof(float));
+        std::memcpy(&xyz[1], &data[arrayPosition + off[1]], sizeof(float));
+        std::memcpy(&xyz[2], &data[arrayPosition + off[2]], sizeof(float));
+        switch (sensor) {
+            case DMSA_SENSOR_HESAI:
+                std::memcpy(&tmpStampDouble, &data[arrayPosition + off[4]], sizeof(double));
+                std::memcpy(&ring_tmp, &data[arrayPosition + off[5]], sizeof(uint16_t));
+                stamp_out[k] = tmpStampDouble, id_out[k] = (int)ring_tmp;
+                break;
+            case DMSA_SENSOR_OUSTER:
+                std::memcpy(&relStampNano, &data[arrayPosition + off[4]], sizeof(uint32_t));
+                std::memcpy(&ring_tmp8, &data[arrayPosition + off[6]], sizeof(uint8_t));
+                tmpStampDouble = stampMsg + 1e-9 * (double)relStampNano;
+                stamp_out[k] = tmpStampDouble, id_out[k] = (int)ring_tmp8;
+                break;
+            case DMSA_SENSOR_ROBOSENSE:
+                std::memcpy(&tmpStampDouble, &data[arrayPosition + off[5]], sizeof(double));
+                std::memcpy(&ring_tmp, &data[arrayPosition + off[4]], sizeof(uint16_t));
+                stamp_out[k] = tmpStampDouble, id_out[k] = (int)ring_tmp;
+                break;
+            case DMSA_SENSOR_VELODYNE:
+                std::memcpy(&tmpStampFloat, &data[arrayPosition + off[5]], sizeof(float));
+                std::memcpy(&ring_tmp, &data[arrayPosition + off[4]], sizeof(uint16_t));
+                stamp_out[k] = stampMsg + static_cast<double>(tmpStampFloat), id_out[k] = (int)ring_tmp;
+                break;
+            case DMSA_SENSOR_LIVOX_S:
+                std::memcpy(&tmpStampDouble, &data[arrayPosition + off[6]], sizeof(double));
+                stamp_out[k] = tmpStampDouble, id_out[k] = (int)(k % 1000);
+                break;
+            case DMSA_SENSOR_LIVOX_NS:
+                std::memcpy(&tmpStampDouble, &data[arrayPosition + off[6]], sizeof(double));
+                stamp_out[k] = 1e-9 * tmpStampDouble, id_out[k] = (int)(k % 1000);
+                break;
+            case DMSA_SENSOR_SICK:
+                std::memcpy(&tmpStampFloat, &data[arrayPosition + off[8]], sizeof(float));
+                std::memcpy(&ring_int8, &data[arrayPosition + off[11]], sizeof(int8_t));
+                stamp_out[k] = stampMsg + static_cast<double>(tmpStampFloat), id_out[k] = static_cast<int>(ring_int8);
+                break;
+            default:
+                stamp_out[k] = stampMsg + deltaTPcs * (double)k / (double)(msg->height * msg->width), id_out[k] = (int)(k % 1000);
+                break;
+        }
+    }
+    return DMSA_OK;
+}
+
+// addPoseToFile (OutputManagement.h:80-96) through the same iostream manipulators
+int orc_format_tum_pose(double stamp, const double* pos, const double* orient, char* out, int32_t cap) {
+    std::ostringstream file;
+    file << std::setprecision(6) << std::fixed << stamp << " ";
+    file << std::setprecision(5) << std::fixed << pos[0] << " " << pos[1] << " " << pos[2] << " ";
+    const M3 R = axang2rotm(orient);
+    // Quaterniond q(R)
+    double q[4];
+    double t = R.m[0][0] + R.m[1][1] + R.m[2][2];
+    if (t > 0.0) {
+        t = std::sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R.m[2][1] - R.m[1][2]) * t, q[1] = (R.m[0][2] - R.m[2][0]) * t, q[2] = (R.m[1][0] - R.m[0][1]) * t;
+    } else {
+        int i = 0;
+        if (R.m[1][1] > R.m[0][0]) i = 1;
+        if (R.m[2][2] > R.m[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R.m[i][i] - R.m[j][j] - R.m[k][k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R.m[k][j] - R.m[j][k]) * t;
+        q[j] = (R.m[j][i] + R.m[i][j]) * t;
+        q[k] = (R.m[k][i] + R.m[i][k]) * t;
+    }
+    file << std::setprecision(6) << std::fixed << q[0] << " " << q[1] << " " << q[2] << " " << q[3];
+    file << "\n";
+    const std::string line = file.str();
+    if ((int)line.size() >= cap) return DMSA_ERR_INVALID;
+    std::memcpy(out, line.c_str(), line.size() + 1);
+    return (int)line.size();
+}
+
+// saveDensePoses :148-153 / makeNonKeyframePoseGlobal :176-182
+int orc_compose_nonkeyframe_pose(const double* keyframePos, const double* keyframeOrient, const double* Translation, const double* Orientation, double* globalPos,
+                                 double* globalOrient) {
+    const M3 keyRot = axang2rotm(keyframeOrient);
+    double rt[3];
+    matvec(keyRot, Translation, rt);
+    for (int c = 0; c < 3; ++c) globalPos[c] = rt[c] + keyframePos[c];
+    rotm2axang(mul(keyRot, axang2rotm(Orientation)), globalOrient);
+    return DMSA_OK;
+}
+
+}  // extern "C"
+

@@ -18,6 +18,7 @@
 #include "../include/dmsa_hip.h" /* POD problem/settings/report structs only */
 #include "../include/dmsa_static_points.h"
 #include "../include/dmsa_window_setup.h" /* dmsa_traj_state POD only */
+#include "../include/dmsa_wire_formats.h" /* dmsa_pointcloud2 POD + sensor enum only */
 
 #ifdef __cplusplus
 extern "C" {
@@ -114,6 +115,12 @@ int orc_traj_preint_factors(int32_t n_total, int32_t C, const int32_t* paramIndi
                             const double* gyr_cov, const double* acc_cov, double* preintImuRots, double* preintRelPositions, double* preintRelVelocity,
                             double* CovPVRot_inv, double* preintPosComplHor);
 int orc_traj_update_initial_guess(int32_t* is_initialized, dmsa_traj_state* cur, dmsa_traj_state* old_traj, int32_t use_imu);
+
+/* ---- wire formats (src/dmsa_slam_ros.cpp:374-486, OutputManagement.h:80-182) */
+int orc_decode_pointcloud2(const dmsa_pointcloud2* msg, int32_t sensor, float* xyz_out, double* stamp_out, int32_t* id_out);
+int orc_format_tum_pose(double stamp, const double* pos, const double* orient, char* out, int32_t cap);
+int orc_compose_nonkeyframe_pose(const double* keyframePos, const double* keyframeOrient, const double* Translation, const double* Orientation, double* globalPos,
+                                 double* globalOrient);
 
 #ifdef __cplusplus
 }

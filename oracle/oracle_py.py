@@ -434,3 +434,35 @@ class WindowSetup:
         self._L.orc_traj_tform_indices(capi.ptr(st, C.c_double), st.shape[0], traj.t0, capi.ptr(traj.trajTime, C.c_double), traj.n_total, capi.ptr(out, C.c_int32))
         return out[: st.shape[0]]
 
+
+# ---- wire formats -------------------------------------------------------------------------------------------------
+def decode_pointcloud2(msg, sensor: str, delta_t_pcs: float = 0.0):
+    """callbackPointCloud (dmsa_slam_ros.cpp:399-486) on a wire_formats.PointCloud2Msg."""
+    L = lib()
+    L.orc_decode_pointcloud2.argtypes = [C.POINTER(capi.PointCloud2), C.c_int32, capi.c_float_p, capi.c_double_p, capi.c_int32_p]
+    n = int(msg.height) * int(msg.width)
+    xyz, st, ids = np.zeros((max(n, 1), 4), np.float32), np.zeros(max(n, 1)), np.zeros(max(n, 1), np.int32)
+    cm = msg.to_c(delta_t_pcs)
+    L.orc_decode_pointcloud2(C.byref(cm), capi.SENSORS[sensor], capi.ptr(xyz, C.c_float), capi.ptr(st, C.c_double), capi.ptr(ids, C.c_int32))
+    return xyz[:n], st[:n], ids[:n]
+
+
+def format_tum_pose(stamp, pos, orient) -> str:
+    L = lib()
+    L.orc_format_tum_pose.argtypes = [C.c_double, capi.c_double_p, capi.c_double_p, C.c_char_p, C.c_int32]
+    p, o = np.ascontiguousarray(pos, np.float64), np.ascontiguousarray(orient, np.float64)
+    buf = C.create_string_buffer(512)
+    n = L.orc_format_tum_pose(float(stamp), capi.ptr(p, C.c_double), capi.ptr(o, C.c_double), buf, 512)
+    if n < 0:
+        raise RuntimeError(f"orc_format_tum_pose rc={n}")
+    return buf.raw[:n].decode()
+
+
+def compose_nonkeyframe_pose(key_pos, key_orient, transl, orient):
+    L = lib()
+    L.orc_compose_nonkeyframe_pose.argtypes = [capi.c_double_p] * 6
+    a = [np.ascontiguousarray(v, np.float64) for v in (key_pos, key_orient, transl, orient)]
+    gp, go = np.zeros(3), np.zeros(3)
+    L.orc_compose_nonkeyframe_pose(*[capi.ptr(v, C.c_double) for v in a], capi.ptr(gp, C.c_double), capi.ptr(go, C.c_double))
+    return gp, go
+

@@ -21,8 +21,8 @@ def lib():
 
 
 def test_exports_every_declared_symbol(lib):
-    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("dmsa_hip.h", "dmsa_static_points.h", "dmsa_window_setup.h"))
-    declared = set(re.findall(r"\b(dmsa_[a-z_]+)\s*\(", header))
+    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("dmsa_hip.h", "dmsa_static_points.h", "dmsa_window_setup.h", "dmsa_wire_formats.h"))
+    declared = set(re.findall(r"\b(dmsa_[a-z_0-9]+)\s*\(", header))
     assert declared, "no declarations parsed"
     assert declared == set(capi.EXPORTED_SYMBOLS)
     for name in declared:
@@ -40,6 +40,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(capi.StaticSelectProblem) == 80 and C.sizeof(capi.StaticSelectResult) == 24  # dmsa_static_points.h
     assert C.sizeof(capi.PreprocessConfig) == 80
     assert C.sizeof(capi.TrajState) == 120  # dmsa_window_setup.h
+    assert C.sizeof(capi.PointCloud2) == 56  # dmsa_wire_formats.h
 
 
 def test_default_settings_match_reference_defaults(lib):
