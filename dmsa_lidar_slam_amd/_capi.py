@@ -276,6 +276,10 @@ def load_library() -> C.CDLL:
         "dmsa_decode_pointcloud2": (C.c_int, [vp, C.POINTER(PointCloud2), C.c_int32, c_float_p, c_double_p, c_int32_p]),
         "dmsa_format_tum_pose": (C.c_int, [C.c_double, c_double_p, c_double_p, C.c_char_p, C.c_int32]),
         "dmsa_compose_nonkeyframe_pose": (C.c_int, [c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+        # include/dmsa_keyframe_cloud.h
+        "dmsa_update_normals": (C.c_int, [vp, c_float_p, C.c_int64, C.c_int32, C.c_float, c_float_p, c_float_p, c_int32_p]),
+        "dmsa_make_keyframe_cloud": (C.c_int, [vp, c_float_p, c_int32_p, C.c_int64, C.c_float, C.c_uint32, c_double_p, c_double_p, c_float_p, c_float_p, c_int32_p,
+                                               c_int32_p, C.c_int64, c_int64_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
@@ -293,5 +297,5 @@ EXPORTED_SYMBOLS = (
     "dmsa_select_static_points dmsa_get_overlap dmsa_random_grid_downsampling dmsa_radius_exists dmsa_preprocess_scan "
     "dmsa_imu_buffer_create dmsa_imu_buffer_destroy dmsa_imu_buffer_add dmsa_imu_buffer_closest dmsa_imu_buffer_state dmsa_traj_dims dmsa_traj_grids "
     "dmsa_traj_tform_indices dmsa_traj_transfer_imu dmsa_traj_preint_factors dmsa_traj_update_initial_guess "
-    "dmsa_decode_pointcloud2 dmsa_format_tum_pose dmsa_compose_nonkeyframe_pose"
+    "dmsa_decode_pointcloud2 dmsa_format_tum_pose dmsa_compose_nonkeyframe_pose dmsa_update_normals dmsa_make_keyframe_cloud"
 ).split()

@@ -25,6 +25,7 @@
 #include "../../include/dmsa_static_points.h"
 #include "../../include/dmsa_window_setup.h"
 #include "../../include/dmsa_wire_formats.h"
+#include "../../include/dmsa_keyframe_cloud.h"
 #include "device_prims.h"
 #include "dmsa_kernels.h"
 #include "host_math.h"
@@ -76,6 +77,7 @@ struct StaticState {
     // the cell grid currently built over `cloud`
     CellGrid grid{};
     int64_t n_cloud = 0;
+    uint32_t num_finite = 0;
     bool key32 = false;
     uint32_t table_mask = 0;
 };
@@ -1439,6 +1441,7 @@ StaticState* sp_state(dmsa_ctx* ctx) {
 
 // Uniform cell grid over `n` host points (cells of 1.001 * radius): bounds -> [sync] -> codes -> radix sort -> sorted copies + hash of
 // the occupied cells.  Leaves the grid in sp->grid / table / pts_sorted / code_s.
+int sp_build_grid_device(dmsa_ctx* ctx, int64_t n, float radius);
 int sp_build_grid(dmsa_ctx* ctx, const float* cloud_xyz, int64_t n, float radius) {
     StaticState* sp = sp_state(ctx);
     if (!sp) return DMSA_ERR_NOMEM;
@@ -1446,14 +1449,23 @@ int sp_build_grid(dmsa_ctx* ctx, const float* cloud_xyz, int64_t n, float radius
     sp->n_cloud = n;
     if (n == 0) return DMSA_OK;
     HIPCHK(sp->cloud.ensure((size_t)n * 16));
-    HIPCHK(sp->small.ensure(256));
     HIPCHK(hipMemcpyAsync(sp->cloud.p, cloud_xyz, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    return sp_build_grid_device(ctx, n, radius);
+}
+// the same on a cloud that already sits in sp->cloud
+int sp_build_grid_device(dmsa_ctx* ctx, int64_t n, float radius) {
+    StaticState* sp = ctx->sp;
+    if (!(radius > 0.0f) || n < 0 || n > (int64_t)0x7FFFFFF0) return DMSA_ERR_INVALID;
+    sp->n_cloud = n;
+    if (n == 0) return DMSA_OK;
+    HIPCHK(sp->small.ensure(256));
     CloudBounds* d_b = sp->small.as<CloudBounds>();
     launch_cloud_bounds_init(d_b, ctx->stream);
     launch_cloud_bounds(sp->cloud.as<float4>(), n, d_b, ctx->stream);
     CloudBounds hb{};
     HIPCHK(hipMemcpyAsync(&hb, d_b, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(sync_spin(ctx->stream));
+    sp->num_finite = hb.num_finite;
     CellGrid g{};
     g.inv = 1.0 / (1.001 * (double)radius);
     g.nx = g.ny = g.nz = 1;
@@ -1804,6 +1816,78 @@ int dmsa_decode_pointcloud2(dmsa_ctx* ctx, const dmsa_pointcloud2* msg, int32_t 
     HIPCHK(hipMemcpyAsync(xyz_out, sp->cloud.p, n * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(stamp_out, sp->code.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(id_out, sp->out_id.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return DMSA_OK;
+}
+
+// include/dmsa_keyframe_cloud.h
+namespace {
+// normals of the n points in sp->cloud (device) into sp->normal; neighbour lists into sp->sel when wanted
+int sp_normals(dmsa_ctx* ctx, int64_t n, int k, float cell_hint, const float* viewpoint, bool want_nn) {
+    StaticState* sp = ctx->sp;
+    HIPCHK(sp->normal.ensure((size_t)n * 16));
+    if (want_nn) HIPCHK(sp->sel.ensure((size_t)n * (size_t)k * 4));
+    CHK(sp_build_grid_device(ctx, n, cell_hint));
+    launch_knn_normals(sp->cloud.as<float4>(), n, k, sp->grid, 1.001 * (double)cell_hint, sp->pts_sorted.as<float4>(), sp->idx_s.as<uint32_t>(), sp->code_s.p,
+                       sp->key32, sp->table.as<CellHashEntry>(), sp->table_mask, sp->num_finite, viewpoint[0], viewpoint[1], viewpoint[2], sp->normal.as<float4>(),
+                       want_nn ? sp->sel.as<int32_t>() : nullptr, ctx->stream);
+    HIPCHK(hipGetLastError());
+    return DMSA_OK;
+}
+}  // namespace
+
+int dmsa_update_normals(dmsa_ctx* ctx, const float* xyz, int64_t n, int32_t k, float cell_hint, const float viewpoint[3], float* normal_out, int32_t* nn_index_out) {
+    if (!ctx || n < 0 || (n > 0 && (!xyz || !normal_out)) || k < 1 || k > 8 || !(cell_hint > 0.0f) || !viewpoint || n > (int64_t)0x7FFFFFF0 / 8) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    if (n == 0) return DMSA_OK;
+    StaticState* sp = sp_state(ctx);
+    if (!sp) return DMSA_ERR_NOMEM;
+    HIPCHK(sp->cloud.ensure((size_t)n * 16));
+    HIPCHK(hipMemcpyAsync(sp->cloud.p, xyz, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    CHK(sp_normals(ctx, n, k, cell_hint, viewpoint, nn_index_out != nullptr));
+    HIPCHK(hipMemcpyAsync(normal_out, sp->normal.p, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (nn_index_out) HIPCHK(hipMemcpyAsync(nn_index_out, sp->sel.p, (size_t)n * (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return DMSA_OK;
+}
+
+int dmsa_make_keyframe_cloud(dmsa_ctx* ctx, const float* global_xyz, const int32_t* ids, int64_t n, float min_grid_size, uint32_t seed, const double pos0[3],
+                             const double orient0[3], float* xyz_local_out, float* normal_out, int32_t* ring_out, int32_t* src_index_out, int64_t capacity,
+                             int64_t* num_out) {
+    if (num_out) *num_out = 0;
+    if (!ctx || n < 0 || (n > 0 && (!global_xyz || !ids)) || !(min_grid_size > 0.0f) || !pos0 || !orient0 || capacity < 0 || n > (int64_t)0x7FFFFFF0 / 8) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    if (n == 0) return DMSA_OK;
+    StaticState* sp = sp_state(ctx);
+    if (!sp) return DMSA_ERR_NOMEM;
+    // randomGridDownsampling(trajIn.globalPoints, keyframeCloudFiltered, trajIn.minGridSize) (:505)
+    CHK(sp_grid_upload(ctx, global_xyz, n));
+    int64_t m = 0;
+    CHK(sp_grid_leaves(ctx, n, min_grid_size, &m));
+    if (num_out) *num_out = m;
+    if (m > capacity) return DMSA_ERR_INVALID;
+    if (m == 0) return DMSA_OK;
+    CHK(sp_grid_pick(ctx, m, seed));
+    // currWorldPose = Translations.col(0).cast<float>(), currRotInv = axang2rotm(Orientations.col(0)).transpose().cast<float>() (:511-512)
+    const dmsa::Mat3 R = dmsa::so3_exp({orient0[0], orient0[1], orient0[2]});
+    float rinv[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) rinv[3 * r + c] = (float)R(c, r);
+    HIPCHK(sp->ring.ensure((size_t)n * 4));
+    HIPCHK(sp->out_xyz.ensure((size_t)m * 16));
+    HIPCHK(sp->out_id.ensure((size_t)m * 4));
+    HIPCHK(hipMemcpyAsync(sp->ring.p, ids, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_to_keyframe_frame(sp->cloud.as<float4>(), sp->ring.as<int32_t>(), sp->pick.as<int32_t>(), (int)m, rinv, (float)pos0[0], (float)pos0[1], (float)pos0[2],
+                             sp->out_xyz.as<float4>(), sp->out_id.as<int32_t>(), ctx->stream);
+    if (src_index_out) HIPCHK(hipMemcpyAsync(src_index_out, sp->pick.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ring_out) HIPCHK(hipMemcpyAsync(ring_out, sp->out_id.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (xyz_local_out) HIPCHK(hipMemcpyAsync(xyz_local_out, sp->out_xyz.p, (size_t)m * 16, hipMemcpyDeviceToHost, ctx->stream));
+    // updateNormals(keyframeCloud_imu) (:526): k = 6, viewpoint = origin; the local cloud becomes the grid's cloud
+    HIPCHK(sp->cloud.ensure((size_t)m * 16));
+    HIPCHK(hipMemcpyAsync(sp->cloud.p, sp->out_xyz.p, (size_t)m * 16, hipMemcpyDeviceToDevice, ctx->stream));
+    const float origin[3] = {0.0f, 0.0f, 0.0f};
+    CHK(sp_normals(ctx, m, 6, 2.0f * min_grid_size, origin, false));
+    if (normal_out) HIPCHK(hipMemcpyAsync(normal_out, sp->normal.p, (size_t)m * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return DMSA_OK;
 }

@@ -73,5 +73,14 @@ struct PointCloud2Fields {
 };
 void launch_decode_pointcloud2(const uint8_t* data, uint32_t n, uint32_t point_step, PointCloud2Fields f, int sensor, double stamp_msg, double delta_t, float4* xyz,
                                double* stamp, int32_t* id, hipStream_t s);
+// DmsaSlam::updateNormals (DmsaSlam.h:553-567): exact k-NN (k <= 8) on the cell grid built over the same cloud + PCL's normal
+// estimation (single-pass float covariance, eigen33, viewpoint flip).  normal = (nx, ny, nz, curvature); nn_index (n x k, optional)
+// = neighbour indices in search order, -1 padded.
+void launch_knn_normals(const float4* cloud, int64_t n, int k, CellGrid g, double cell_size, const float4* pts_sorted, const uint32_t* idx_sorted,
+                        const void* code_sorted, bool key32, const CellHashEntry* table, uint32_t table_mask, uint32_t num_finite, float vpx, float vpy, float vpz,
+                        float4* normal, int32_t* nn_index, hipStream_t s);
+// addNewKeyframeToMap (:518-523): local[k] = Rinv * (global[pick[k]] - t), ring[k] = ids[pick[k]]
+void launch_to_keyframe_frame(const float4* global, const int32_t* ids, const int32_t* pick, int m, const float* rinv_rowmajor, float tx, float ty, float tz,
+                              float4* local, int32_t* ring, hipStream_t s);
 
 }  // namespace dmsa

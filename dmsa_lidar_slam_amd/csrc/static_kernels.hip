@@ -389,4 +389,263 @@ void launch_decode_pointcloud2(const uint8_t* data, uint32_t n, uint32_t point_s
         hipLaunchKernelGGL(k_decode_pointcloud2, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, data, n, point_step, f, sensor, stamp_msg, delta_t, xyz, stamp, id);
 }
 
+// ---- DmsaSlam::updateNormals (DmsaSlam.h:553-567): pcl::NormalEstimationOMP, k nearest neighbours, viewpoint flip ---------------------
+// Exact k-NN on the sorted cell grid: rings of cells around the query's cell are scanned until the k-th best distance lies strictly
+// inside the radius the scanned block guarantees (ring * cell size), or the block covers the whole grid.  Candidates are ordered by
+// (flann::L2_Simple float distance, point index) -- the order of a sorted FLANN result with ties broken by index.
+constexpr int kMaxNeighbours = 8;
+constexpr int kMaxRings = 6;  // (2 * 6 + 1)^3 = 2197 cells before an isolated query falls back to an exhaustive pass
+struct NeighbourList {
+    float d[kMaxNeighbours];
+    uint32_t pos[kMaxNeighbours];  // position in the sorted copy
+    int count;
+};
+template <int K>
+__device__ __forceinline__ void knn_insert(NeighbourList& nl, int k, float d, uint32_t pos, const uint32_t* __restrict__ idx_sorted) {
+    // every index below is a compile-time constant after unrolling: the lists stay in registers, no indirect register addressing
+    if (nl.count == k) {
+        float last_d = 0.0f;
+        uint32_t last_pos = 0;
+#pragma unroll
+        for (int m = 0; m < K; ++m)
+            if (m == k - 1) last_d = nl.d[m], last_pos = nl.pos[m];
+        if (d > last_d) return;
+        if (d == last_d && idx_sorted[pos] > idx_sorted[last_pos]) return;
+    }
+    float cd = d;
+    uint32_t cp = pos;
+    bool placed = false;
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        if (m < k && !placed) {
+            if (m >= nl.count) {
+                nl.d[m] = cd, nl.pos[m] = cp, placed = true;
+            } else {
+                const bool before = cd < nl.d[m] || (cd == nl.d[m] && idx_sorted[cp] < idx_sorted[nl.pos[m]]);
+                if (before) {
+                    const float td = nl.d[m];
+                    const uint32_t tp = nl.pos[m];
+                    nl.d[m] = cd, nl.pos[m] = cp;
+                    cd = td, cp = tp;
+                }
+            }
+        }
+    }
+    if (nl.count < k) nl.count += 1;
+}
+template <typename KeyT>
+__device__ __forceinline__ void knn_scan_cell(NeighbourList& nl, int k, const float4 q, int64_t x, int64_t y, int64_t z, const CellGrid& g,
+                                              const float4* __restrict__ pts_sorted, const uint32_t* __restrict__ idx_sorted, const KeyT* __restrict__ code_sorted,
+                                              int64_t n, const CellHashEntry* __restrict__ table, uint32_t mask) {
+    const uint64_t key = (uint64_t)x + (uint64_t)g.nx * ((uint64_t)y + (uint64_t)g.ny * (uint64_t)z);
+    uint32_t slot = (uint32_t)hash_cell(key) & mask;
+    int64_t start = -1;
+    while (true) {
+        const uint64_t kk = table[slot].key;
+        if (kk == key) {
+            start = table[slot].start;
+            break;
+        }
+        if (kk == ~0ull) break;
+        slot = (slot + 1) & mask;
+    }
+    if (start < 0) return;
+    for (int64_t j = start; j < n && (uint64_t)code_sorted[j] == key; ++j) {
+        const float4 p = pts_sorted[j];
+        const float ddx = q.x - p.x, ddy = q.y - p.y, ddz = q.z - p.z;
+        float d = 0.0f;
+        d += ddx * ddx;
+        d += ddy * ddy;
+        d += ddz * ddz;
+        knn_insert<kMaxNeighbours>(nl, k, d, (uint32_t)j, idx_sorted);
+    }
+}
+// pcl::computeRoots2 / computeRoots / eigen33 (pcl/common/impl/eigen.hpp, PCL 1.10), smallest eigenvalue and its vector, float
+__device__ __forceinline__ void pcl_roots2(float b, float c, float* roots) {
+    roots[0] = 0.0f;
+    float d = (float)((double)(b * b) - 4.0 * (double)c);  // Scalar (b * b - 4.0 * c): the subtraction runs in double
+    if (d < 0.0f) d = 0.0f;
+    const float sd = sqrtf(d);
+    roots[2] = 0.5f * (b + sd);
+    roots[1] = 0.5f * (b - sd);
+}
+__device__ __forceinline__ void pcl_roots(const float* m /* row-major 3x3 */, float* roots) {
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m11 = m[4], m12 = m[5], m22 = m[8];
+    const float c0 = m00 * m11 * m22 + 2.0f * m01 * m02 * m12 - m00 * m12 * m12 - m11 * m02 * m02 - m22 * m01 * m01;
+    const float c1 = m00 * m11 - m01 * m01 + m00 * m22 - m02 * m02 + m11 * m22 - m12 * m12;
+    const float c2 = m00 + m11 + m22;
+    if (fabsf(c0) < FLT_EPSILON) {
+        pcl_roots2(c2, c1, roots);
+        return;
+    }
+    const float s_inv3 = (float)(1.0 / 3.0), s_sqrt3 = sqrtf(3.0f);
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.0f) q = 0.0f;
+    const float rho = sqrtf(-a_over_3);
+    const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
+    const float cos_theta = cosf(theta), sin_theta = sinf(theta);
+    roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
+    roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    float t;
+    if (roots[0] >= roots[1]) t = roots[0], roots[0] = roots[1], roots[1] = t;
+    if (roots[1] >= roots[2]) {
+        t = roots[1], roots[1] = roots[2], roots[2] = t;
+        if (roots[0] >= roots[1]) t = roots[0], roots[0] = roots[1], roots[1] = t;
+    }
+    if (roots[0] <= 0.0f) pcl_roots2(c2, c1, roots);
+}
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void k_knn_normals(const float4* __restrict__ cloud, int64_t n, int k, CellGrid g, double cell_size,
+                                                        const float4* __restrict__ pts_sorted, const uint32_t* __restrict__ idx_sorted,
+                                                        const KeyT* __restrict__ code_sorted, const CellHashEntry* __restrict__ table, uint32_t mask,
+                                                        uint32_t num_finite, float vpx, float vpy, float vpz, float4* __restrict__ normal,
+                                                        int32_t* __restrict__ nn_index) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q = cloud[i];
+    const float nanv = __int_as_float(0x7fc00000);
+    NeighbourList nl;
+    nl.count = 0;
+    int64_t cx, cy, cz;
+    const int want = (int)min((uint32_t)k, num_finite);
+    if (want > 0 && cell_of(q, g, cx, cy, cz)) {
+        cx = min(max(cx, (int64_t)0), g.nx - 1), cy = min(max(cy, (int64_t)0), g.ny - 1), cz = min(max(cz, (int64_t)0), g.nz - 1);
+        const int64_t reach = max(max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy)), max(cz, g.nz - 1 - cz));  // ring that covers the whole grid
+        for (int64_t ring = 0; ring <= reach; ++ring) {
+            if (ring > kMaxRings) {
+                // an isolated query (its neighbours are dozens of cells away): the shells grow as ring^2 hash probes, an exhaustive pass
+                // over the cloud is cheaper.  Start over so that nothing is inserted twice.
+                nl.count = 0;
+                for (int64_t j = 0; j < n; ++j) {
+                    if (code_sorted[j] == (KeyT)~(KeyT)0) break;  // non-finite points sort last
+                    const float4 p = pts_sorted[j];
+                    const float ddx = q.x - p.x, ddy = q.y - p.y, ddz = q.z - p.z;
+                    float d = 0.0f;
+                    d += ddx * ddx;
+                    d += ddy * ddy;
+                    d += ddz * ddz;
+                    knn_insert<kMaxNeighbours>(nl, want, d, (uint32_t)j, idx_sorted);
+                }
+                break;
+            }
+            for (int64_t dz = -ring; dz <= ring; ++dz) {
+                const int64_t z = cz + dz;
+                if (z < 0 || z >= g.nz) continue;
+                for (int64_t dy = -ring; dy <= ring; ++dy) {
+                    const int64_t y = cy + dy;
+                    if (y < 0 || y >= g.ny) continue;
+                    const bool face = dz == -ring || dz == ring || dy == -ring || dy == ring;
+                    for (int64_t dx = -ring; dx <= ring; dx += (face || ring == 0) ? 1 : 2 * ring) {  // only the shell of the block
+                        const int64_t x = cx + dx;
+                        if (x < 0 || x >= g.nx) continue;
+                        knn_scan_cell<KeyT>(nl, want, q, x, y, z, g, pts_sorted, idx_sorted, code_sorted, n, table, mask);
+                    }
+                }
+            }
+            // every point outside the scanned block is at least ring * cell away (the clamp above only moves queries that sit on the
+            // upper faces of the grid, where nothing lies beyond); 0.999 absorbs the rounding of the cell assignment
+            const double safe = 0.999 * (double)ring * cell_size;
+            float worst = 0.0f;
+#pragma unroll
+            for (int m = 0; m < kMaxNeighbours; ++m)
+                if (m == want - 1) worst = nl.d[m];
+            if (nl.count == want && (double)worst < safe * safe) break;
+        }
+    }
+    if (nn_index) {
+#pragma unroll
+        for (int m = 0; m < kMaxNeighbours; ++m)
+            if (m < k) nn_index[i * k + m] = m < nl.count ? (int32_t)idx_sorted[nl.pos[m]] : -1;
+    }
+    if (nl.count < 3) {  // NormalEstimation: non-finite query, or pcl::computePointNormal with fewer than 3 indices
+        normal[i] = make_float4(nanv, nanv, nanv, nanv);
+        return;
+    }
+    // pcl::computeMeanAndCovarianceMatrix (single pass, float accumulators, neighbours in search order)
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+#pragma unroll
+    for (int m = 0; m < kMaxNeighbours; ++m) {
+        if (m >= nl.count) continue;
+        const float4 p = pts_sorted[nl.pos[m]];
+        a0 += p.x * p.x, a1 += p.x * p.y, a2 += p.x * p.z, a3 += p.y * p.y, a4 += p.y * p.z, a5 += p.z * p.z, a6 += p.x, a7 += p.y, a8 += p.z;
+    }
+    const float cnt = (float)nl.count;
+    a0 /= cnt, a1 /= cnt, a2 /= cnt, a3 /= cnt, a4 /= cnt, a5 /= cnt, a6 /= cnt, a7 /= cnt, a8 /= cnt;
+    float cov[9];
+    cov[0] = a0 - a6 * a6, cov[1] = a1 - a6 * a7, cov[2] = a2 - a6 * a8, cov[4] = a3 - a7 * a7, cov[5] = a4 - a7 * a8, cov[8] = a5 - a8 * a8;
+    cov[3] = cov[1], cov[6] = cov[2], cov[7] = cov[5];
+    // pcl::solvePlaneParameters -> pcl::eigen33 (smallest eigenvalue)
+    float scale = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) scale = fmaxf(scale, fabsf(cov[e]));
+    if (scale <= FLT_MIN) scale = 1.0f;
+    float sm[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) sm[e] = cov[e] / scale;
+    float roots[3];
+    pcl_roots(sm, roots);
+    const float eigenvalue = roots[0] * scale;
+    sm[0] -= roots[0], sm[4] -= roots[0], sm[8] -= roots[0];
+    const float r0x = sm[0], r0y = sm[1], r0z = sm[2], r1x = sm[3], r1y = sm[4], r1z = sm[5], r2x = sm[6], r2y = sm[7], r2z = sm[8];
+    const float v1x = r0y * r1z - r0z * r1y, v1y = r0z * r1x - r0x * r1z, v1z = r0x * r1y - r0y * r1x;
+    const float v2x = r0y * r2z - r0z * r2y, v2y = r0z * r2x - r0x * r2z, v2z = r0x * r2y - r0y * r2x;
+    const float v3x = r1y * r2z - r1z * r2y, v3y = r1z * r2x - r1x * r2z, v3z = r1x * r2y - r1y * r2x;
+    const float len1 = v1x * v1x + (v1y * v1y + v1z * v1z), len2 = v2x * v2x + (v2y * v2y + v2z * v2z), len3 = v3x * v3x + (v3y * v3y + v3z * v3z);
+    float nx, ny, nz;
+    if (len1 >= len2 && len1 >= len3) {
+        const float s = sqrtf(len1);
+        nx = v1x / s, ny = v1y / s, nz = v1z / s;
+    } else if (len2 >= len1 && len2 >= len3) {
+        const float s = sqrtf(len2);
+        nx = v2x / s, ny = v2y / s, nz = v2z / s;
+    } else {
+        const float s = sqrtf(len3);
+        nx = v3x / s, ny = v3y / s, nz = v3z / s;
+    }
+    const float eig_sum = cov[0] + cov[4] + cov[8];
+    const float curvature = eig_sum != 0.0f ? fabsf(eigenvalue / eig_sum) : 0.0f;
+    // pcl::flipNormalTowardsViewpoint
+    const float wx = vpx - q.x, wy = vpy - q.y, wz = vpz - q.z;
+    const float cos_theta = wx * nx + wy * ny + wz * nz;
+    if (cos_theta < 0.0f) nx *= -1.0f, ny *= -1.0f, nz *= -1.0f;
+    normal[i] = make_float4(nx, ny, nz, curvature);
+}
+void launch_knn_normals(const float4* cloud, int64_t n, int k, CellGrid g, double cell_size, const float4* pts_sorted, const uint32_t* idx_sorted,
+                        const void* code_sorted, bool key32, const CellHashEntry* table, uint32_t table_mask, uint32_t num_finite, float vpx, float vpy, float vpz,
+                        float4* normal, int32_t* nn_index, hipStream_t s) {
+    if (n <= 0) return;
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    if (key32)
+        hipLaunchKernelGGL(k_knn_normals<uint32_t>, dim3(grid), dim3(kBlock), 0, s, cloud, n, k, g, cell_size, pts_sorted, idx_sorted, (const uint32_t*)code_sorted,
+                           table, table_mask, num_finite, vpx, vpy, vpz, normal, nn_index);
+    else
+        hipLaunchKernelGGL(k_knn_normals<uint64_t>, dim3(grid), dim3(kBlock), 0, s, cloud, n, k, g, cell_size, pts_sorted, idx_sorted, (const uint64_t*)code_sorted,
+                           table, table_mask, num_finite, vpx, vpy, vpz, normal, nn_index);
+}
+
+// addNewKeyframeToMap (DmsaSlam.h:518-523): p_local = currRotInv * (p_global - currWorldPose), float, 3-term products as x0 + (x1 + x2)
+struct Mat3f { float m[9]; };  // row-major
+__global__ __launch_bounds__(kBlock) void k_to_keyframe_frame(const float4* __restrict__ global, const int32_t* __restrict__ ids, const int32_t* __restrict__ pick,
+                                                              int m, Mat3f Rinv, float tx, float ty, float tz, float4* __restrict__ local, int32_t* __restrict__ ring) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const int src = pick[k];
+    const float4 p = global[src];
+    const float dx = p.x - tx, dy = p.y - ty, dz = p.z - tz;
+    local[k] = make_float4(Rinv.m[0] * dx + (Rinv.m[1] * dy + Rinv.m[2] * dz), Rinv.m[3] * dx + (Rinv.m[4] * dy + Rinv.m[5] * dz),
+                           Rinv.m[6] * dx + (Rinv.m[7] * dy + Rinv.m[8] * dz), 1.0f);
+    ring[k] = ids[src];
+}
+void launch_to_keyframe_frame(const float4* global, const int32_t* ids, const int32_t* pick, int m, const float* rinv_rowmajor, float tx, float ty, float tz,
+                              float4* local, int32_t* ring, hipStream_t s) {
+    Mat3f R;
+    for (int i = 0; i < 9; ++i) R.m[i] = rinv_rowmajor[i];
+    if (m > 0) hipLaunchKernelGGL(k_to_keyframe_frame, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, global, ids, pick, m, R, tx, ty, tz, local, ring);
+}
+
 }  // namespace dmsa

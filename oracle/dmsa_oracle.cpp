@@ -2166,3 +2166,168 @@ int orc_compose_nonkeyframe_pose(const double* keyframePos, const double* keyfra
 
 }  // extern "C"
 
+// ================================================================================================================================
+// keyframe creation (DmsaSlam.h:469-567) -- pcl::NormalEstimationOMP restated, brute-force neighbours
+// ================================================================================================================================
+namespace {
+
+// pcl/common/impl/eigen.hpp (PCL 1.10): computeRoots2, computeRoots, eigen33 (smallest eigenvalue / eigenvector), float
+static void pclComputeRoots2(float b, float c, float* roots) {
+    roots[0] = 0.0f;
+    float d = float(b * b - 4.0 * c);
+    if (d < 0.0) d = 0.0;
+    const float sd = std::sqrt(d);
+    roots[2] = 0.5f * (b + sd);
+    roots[1] = 0.5f * (b - sd);
+}
+static void pclComputeRoots(const float m[3][3], float* roots) {
+    const float c0 = m[0][0] * m[1][1] * m[2][2] + 2.0f * m[0][1] * m[0][2] * m[1][2] - m[0][0] * m[1][2] * m[1][2] - m[1][1] * m[0][2] * m[0][2] -
+                     m[2][2] * m[0][1] * m[0][1];
+    const float c1 = m[0][0] * m[1][1] - m[0][1] * m[0][1] + m[0][0] * m[2][2] - m[0][2] * m[0][2] + m[1][1] * m[2][2] - m[1][2] * m[1][2];
+    const float c2 = m[0][0] + m[1][1] + m[2][2];
+    if (std::abs(c0) < std::numeric_limits<float>::epsilon()) {
+        pclComputeRoots2(c2, c1, roots);
+        return;
+    }
+    const float s_inv3 = float(1.0 / 3.0);
+    const float s_sqrt3 = std::sqrt(float(3.0));
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+    if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+    if (q > 0.0f) q = 0.0f;
+    const float rho = std::sqrt(-a_over_3);
+    const float theta = std::atan2(std::sqrt(-q), half_b) * s_inv3;
+    const float cos_theta = std::cos(theta);
+    const float sin_theta = std::sin(theta);
+    roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
+    roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    if (roots[0] >= roots[1]) std::swap(roots[0], roots[1]);
+    if (roots[1] >= roots[2]) {
+        std::swap(roots[1], roots[2]);
+        if (roots[0] >= roots[1]) std::swap(roots[0], roots[1]);
+    }
+    if (roots[0] <= 0) pclComputeRoots2(c2, c1, roots);
+}
+
+// NormalEstimation::computeFeature for one point given its neighbour list (pcl/features/normal_3d.h)
+static void pclPointNormal(const float* cloud, const int* nn, int count, const float* point, const float* vp, float* out) {
+    const float nanv = std::numeric_limits<float>::quiet_NaN();
+    if (count < 3) {
+        out[0] = out[1] = out[2] = out[3] = nanv;
+        return;
+    }
+    float accu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // computeMeanAndCovarianceMatrix
+    for (int m = 0; m < count; ++m) {
+        const float* p = cloud + 4 * (size_t)nn[m];
+        accu[0] += p[0] * p[0], accu[1] += p[0] * p[1], accu[2] += p[0] * p[2], accu[3] += p[1] * p[1], accu[4] += p[1] * p[2], accu[5] += p[2] * p[2];
+        accu[6] += p[0], accu[7] += p[1], accu[8] += p[2];
+    }
+    for (float& a : accu) a /= static_cast<float>(count);
+    float cov[3][3];
+    cov[0][0] = accu[0] - accu[6] * accu[6], cov[0][1] = accu[1] - accu[6] * accu[7], cov[0][2] = accu[2] - accu[6] * accu[8];
+    cov[1][1] = accu[3] - accu[7] * accu[7], cov[1][2] = accu[4] - accu[7] * accu[8], cov[2][2] = accu[5] - accu[8] * accu[8];
+    cov[1][0] = cov[0][1], cov[2][0] = cov[0][2], cov[2][1] = cov[1][2];
+    // solvePlaneParameters -> eigen33
+    float scale = 0.0f;
+    for (auto& r : cov)
+        for (float v : r) scale = std::max(scale, std::abs(v));
+    if (scale <= std::numeric_limits<float>::min()) scale = 1.0f;
+    float sm[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) sm[r][c] = cov[r][c] / scale;
+    float roots[3];
+    pclComputeRoots(sm, roots);
+    const float eigenvalue = roots[0] * scale;
+    for (int d = 0; d < 3; ++d) sm[d][d] -= roots[0];
+    auto cross = [](const float* a, const float* b, float* o) { o[0] = a[1] * b[2] - a[2] * b[1], o[1] = a[2] * b[0] - a[0] * b[2], o[2] = a[0] * b[1] - a[1] * b[0]; };
+    float vec1[3], vec2[3], vec3[3];
+    cross(sm[0], sm[1], vec1), cross(sm[0], sm[2], vec2), cross(sm[1], sm[2], vec3);
+    auto sq = [](const float* v) { const float t = v[1] * v[1] + v[2] * v[2]; return v[0] * v[0] + t; };  // Eigen's 3-term redux
+    const float len1 = sq(vec1), len2 = sq(vec2), len3 = sq(vec3);
+    const float* best = vec3;
+    float len = len3;
+    if (len1 >= len2 && len1 >= len3)
+        best = vec1, len = len1;
+    else if (len2 >= len1 && len2 >= len3)
+        best = vec2, len = len2;
+    const float s = std::sqrt(len);
+    float nx = best[0] / s, ny = best[1] / s, nz = best[2] / s;
+    const float eig_sum = cov[0][0] + cov[1][1] + cov[2][2];
+    const float curvature = eig_sum != 0 ? std::abs(eigenvalue / eig_sum) : 0.0f;
+    // flipNormalTowardsViewpoint
+    const float vx = vp[0] - point[0], vy = vp[1] - point[1], vz = vp[2] - point[2];
+    const float cos_theta = (vx * nx + vy * ny + vz * nz);
+    if (cos_theta < 0) nx *= -1, ny *= -1, nz *= -1;
+    out[0] = nx, out[1] = ny, out[2] = nz, out[3] = curvature;
+}
+
+}  // namespace
+
+extern "C" {
+
+// DmsaSlam::updateNormals (DmsaSlam.h:553-567).  Neighbours: exhaustive search, ascending (L2_Simple float distance, index).
+int orc_update_normals(const float* xyz, int64_t n, int32_t k, const float* viewpoint, float* normal_out, int32_t* nn_index_out) {
+    if (k < 1 || k > 8) return DMSA_ERR_INVALID;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < n; ++i) {
+        const float* q = xyz + 4 * (size_t)i;
+        int nn[8];
+        float nd[8];
+        int count = 0;
+        if (std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2])) {
+            for (int64_t j = 0; j < n; ++j) {
+                const float* p = xyz + 4 * (size_t)j;
+                if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
+                const float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+                float d = 0.0f;
+                d += dx * dx;
+                d += dy * dy;
+                d += dz * dz;
+                if (count == k && !(d < nd[k - 1])) continue;  // ascending j: a later equal distance never displaces an earlier one
+                int at = count < k ? count : k - 1;
+                while (at > 0 && d < nd[at - 1]) nd[at] = nd[at - 1], nn[at] = nn[at - 1], --at;
+                nd[at] = d, nn[at] = (int)j;
+                if (count < k) ++count;
+            }
+        }
+        if (nn_index_out)
+            for (int m = 0; m < k; ++m) nn_index_out[(size_t)i * k + m] = m < count ? nn[m] : -1;
+        pclPointNormal(xyz, nn, count, q, viewpoint, normal_out + 4 * (size_t)i);
+    }
+    return DMSA_OK;
+}
+
+// the cloud part of DmsaSlam::addNewKeyframeToMap (DmsaSlam.h:497-531)
+int orc_make_keyframe_cloud(const float* global_xyz, const int32_t* ids, int64_t n, float min_grid_size, uint32_t seed, const double* pos0, const double* orient0,
+                            float* xyz_local_out, float* normal_out, int32_t* ring_out, int32_t* src_index_out, int64_t capacity, int64_t* num_out) {
+    std::vector<int32_t> pick((size_t)std::max<int64_t>(n, 1));
+    int64_t m = 0;
+    const int rc = orc_random_grid_downsampling(global_xyz, n, min_grid_size, seed, pick.data(), n, &m);
+    if (rc != DMSA_OK) return rc;
+    if (num_out) *num_out = m;
+    if (m > capacity) return DMSA_ERR_INVALID;
+    const M3 R = axang2rotm(orient0);
+    float currRotInv[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) currRotInv[r][c] = (float)R.m[c][r];
+    const float currWorldPose[3] = {(float)pos0[0], (float)pos0[1], (float)pos0[2]};
+    for (int64_t k = 0; k < m; ++k) {
+        const float* p = global_xyz + 4 * (size_t)pick[(size_t)k];
+        const float d[3] = {p[0] - currWorldPose[0], p[1] - currWorldPose[1], p[2] - currWorldPose[2]};
+        for (int r = 0; r < 3; ++r) {
+            const float t = currRotInv[r][1] * d[1] + currRotInv[r][2] * d[2];
+            xyz_local_out[4 * (size_t)k + r] = currRotInv[r][0] * d[0] + t;
+        }
+        xyz_local_out[4 * (size_t)k + 3] = 1.0f;
+        ring_out[(size_t)k] = ids[(size_t)pick[(size_t)k]];
+        if (src_index_out) src_index_out[(size_t)k] = pick[(size_t)k];
+    }
+    const float origin[3] = {0.0f, 0.0f, 0.0f};
+    return orc_update_normals(xyz_local_out, m, 6, origin, normal_out, nullptr);
+}
+
+}  // extern "C"
+

@@ -122,6 +122,11 @@ int orc_format_tum_pose(double stamp, const double* pos, const double* orient, c
 int orc_compose_nonkeyframe_pose(const double* keyframePos, const double* keyframeOrient, const double* Translation, const double* Orientation, double* globalPos,
                                  double* globalOrient);
 
+/* ---- keyframe creation (DmsaSlam.h:469-567); exhaustive neighbour search + pcl::NormalEstimation restated */
+int orc_update_normals(const float* xyz, int64_t n, int32_t k, const float* viewpoint, float* normal_out, int32_t* nn_index_out);
+int orc_make_keyframe_cloud(const float* global_xyz, const int32_t* ids, int64_t n, float min_grid_size, uint32_t seed, const double* pos0, const double* orient0,
+                            float* xyz_local_out, float* normal_out, int32_t* ring_out, int32_t* src_index_out, int64_t capacity, int64_t* num_out);
+
 #ifdef __cplusplus
 }
 #endif

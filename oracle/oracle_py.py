@@ -466,3 +466,37 @@ def compose_nonkeyframe_pose(key_pos, key_orient, transl, orient):
     L.orc_compose_nonkeyframe_pose(*[capi.ptr(v, C.c_double) for v in a], capi.ptr(gp, C.c_double), capi.ptr(go, C.c_double))
     return gp, go
 
+
+# ---- keyframe creation --------------------------------------------------------------------------------------------
+def update_normals(cloud, k=6, origin=(0.0, 0.0, 0.0), neighbours=False):
+    """DmsaSlam::updateNormals (DmsaSlam.h:553-567): exhaustive neighbour search + pcl::NormalEstimation restated."""
+    L = lib()
+    L.orc_update_normals.argtypes = [capi.c_float_p, C.c_int64, C.c_int32, capi.c_float_p, capi.c_float_p, capi.c_int32_p]
+    a = np.ascontiguousarray(cloud, np.float32)
+    n = a.shape[0]
+    vp = np.ascontiguousarray(origin, np.float32)
+    out = np.zeros((max(n, 1), 4), np.float32)
+    nn = np.zeros((max(n, 1), k), np.int32) if neighbours else None
+    rc = L.orc_update_normals(capi.ptr(a, C.c_float), n, int(k), capi.ptr(vp, C.c_float), capi.ptr(out, C.c_float), capi.ptr(nn, C.c_int32))
+    if rc != 0:
+        raise RuntimeError(f"orc_update_normals rc={rc}")
+    return (out[:n], nn[:n]) if neighbours else out[:n]
+
+
+def make_keyframe_cloud(global_points, ids, min_grid_size, seed, pos0, orient0):
+    L = lib()
+    L.orc_make_keyframe_cloud.argtypes = [capi.c_float_p, capi.c_int32_p, C.c_int64, C.c_float, C.c_uint32, capi.c_double_p, capi.c_double_p, capi.c_float_p,
+                                          capi.c_float_p, capi.c_int32_p, capi.c_int32_p, C.c_int64, capi.c_int64_p]
+    a, ids = np.ascontiguousarray(global_points, np.float32), np.ascontiguousarray(ids, np.int32)
+    n = a.shape[0]
+    p, o = np.ascontiguousarray(pos0, np.float64), np.ascontiguousarray(orient0, np.float64)
+    xyz, nrm = np.zeros((max(n, 1), 4), np.float32), np.zeros((max(n, 1), 4), np.float32)
+    ring, src, m = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32), C.c_int64(0)
+    rc = L.orc_make_keyframe_cloud(capi.ptr(a, C.c_float), capi.ptr(ids, C.c_int32), n, float(np.float32(min_grid_size)), int(seed) & 0xFFFFFFFF,
+                                   capi.ptr(p, C.c_double), capi.ptr(o, C.c_double), capi.ptr(xyz, C.c_float), capi.ptr(nrm, C.c_float), capi.ptr(ring, C.c_int32),
+                                   capi.ptr(src, C.c_int32), n, C.byref(m))
+    if rc != 0:
+        raise RuntimeError(f"orc_make_keyframe_cloud rc={rc}")
+    k = m.value
+    return xyz[:k].copy(), nrm[:k].copy(), ring[:k].copy(), src[:k].copy()
+

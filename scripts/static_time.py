@@ -39,6 +39,15 @@ d /= np.linalg.norm(d, axis=1, keepdims=True)
 raw = np.concatenate([d * np.min(np.array([25.0, 18.0, 3.0])[None, :] / np.maximum(np.abs(d), 1e-9), axis=1)[:, None], np.ones((131072, 1))], axis=1).astype(f32)
 t_pre, pre = timeit(lambda: g.preProcess(raw, 7))
 out["preProcess"] = {"raw_points": int(raw.shape[0]), "filtered": int(pre[0].shape[0]), "grid": pre[2], "gpu_ms": round(t_pre, 3)}
+# keyframe creation (addNewKeyframeToMap :497-531): thinning + local frame + normals (k = 6) of one window's cloud
+from dmsa_lidar_slam_amd.keyframe_cloud import KeyframeCloudBuilder  # noqa: E402
+
+kb = KeyframeCloudBuilder(0)
+ids = np.zeros(p.windowPoints.shape[0], np.int32)
+pos0, orient0 = np.array([0.1, -0.2, 0.05]), np.array([0.01, -0.02, 0.3])
+t_kf, kf = timeit(lambda: kb.addNewKeyframeCloud(p.windowPoints, ids, p.minGridSize, 7, pos0, orient0), 5)
+t_nrm, _ = timeit(lambda: kb.updateNormals(kf[0], 2 * p.minGridSize), 5)
+out["keyframeCloud"] = {"global_points": int(p.windowPoints.shape[0]), "keyframe_points": int(kf[0].shape[0]), "gpu_ms": round(t_kf, 3), "normals_only_gpu_ms": round(t_nrm, 3)}
 if "--cpu" in sys.argv:
     from oracle import oracle_py as orc
 
@@ -49,4 +58,8 @@ if "--cpu" in sys.argv:
     c_pre, rpre = timeit(lambda: orc.preprocess_scan(raw, 7), 3)
     assert np.array_equal(rpre[0], pre[0]) and np.array_equal(rpre[1], pre[1])
     out["preProcess"]["cpu_oracle_ms"] = round(c_pre, 2)
+    orc.set_threads(1)
+    sub = kf[0][:20000]  # the oracle's neighbour search is exhaustive (O(n^2)): time a 20 000-point subset, one thread
+    c_nrm, _ = timeit(lambda: orc.update_normals(sub), 1)
+    out["keyframeCloud"]["cpu_oracle_normals_20000_points_ms"] = round(c_nrm, 1)
 print(json.dumps(out))
