@@ -1,0 +1,146 @@
+"""A miniature of DmsaSlam::processPointCloud (DmsaSlam.h:115-202) on synthetic scans, composed only of this library's calls:
+
+    PointCloud2 bytes --decode--> scan --preProcess--> ring buffer --prepareTrajectoryForOptimization--> window problem
+      --addStaticPoints (keyframe map)--> optimizeSet --> keyframe decision --addNewKeyframeCloud--> map ... --> TUM lines
+
+The orchestration itself (ring buffers, when to add a keyframe) is deliberately tiny and lives here, not in the library:
+SURVEY.md 8 puts it outside the hot path.  Run:  python examples/sequence_demo.py [--scans 14]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from dmsa_lidar_slam_amd import posemath, synth  # noqa: E402
+from dmsa_lidar_slam_amd import window_setup as ws  # noqa: E402
+from dmsa_lidar_slam_amd import wire_formats as wf  # noqa: E402
+from dmsa_lidar_slam_amd.api import DmsaOptimizer  # noqa: E402
+from dmsa_lidar_slam_amd.keyframe_cloud import KeyframeCloudBuilder  # noqa: E402
+from dmsa_lidar_slam_amd.problems import DmsaOptimSettings  # noqa: E402
+from dmsa_lidar_slam_amd.static_points import StaticPointSelector, StaticSelectProblem  # noqa: E402
+
+f32 = np.float32
+OUSTER = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad0", "<f4"), ("intensity", "<f4"), ("t", "<u4"), ("reflectivity", "<u2"), ("ring", "u1"),
+                   ("pad1", "u1"), ("ambient", "<u2"), ("pad2", "<u2"), ("range", "<u4")])
+OUSTER_FIELDS = ["x", "y", "z", "intensity", "t", "reflectivity", "ring", "ambient", "range"]
+
+
+def scan_to_pointcloud2(xyz, stamps, rings):
+    """What an Ouster driver would publish for this scan (header stamp = first point, t = nanoseconds since then)."""
+    rec = np.zeros(xyz.shape[0], OUSTER)
+    rec["x"], rec["y"], rec["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    head = float(stamps.min())
+    rec["t"] = np.round((stamps - head) * 1e9).astype(np.uint32)
+    rec["ring"] = rings
+    offs = np.array([OUSTER.fields[n][1] for n in OUSTER_FIELDS], np.uint32)
+    return wf.PointCloud2Msg(height=1, width=xyz.shape[0], point_step=OUSTER.itemsize, field_offsets=offs, data=np.frombuffer(rec.tobytes(), np.uint8).copy(),
+                             stamp=head)
+
+
+class MiniSlam:
+    def __init__(self, n_clouds=5, num_control_poses=6, dt_res=1e-3, max_points_per_scan=3000, min_overlap_new_keyframe=0.7, dist_new_keyframe=1.0, seed=7):
+        self.decoder = wf.PointCloud2Decoder("ouster")
+        self.static = StaticPointSelector(0)
+        self.setup = ws.WindowSetup(0)
+        self.kf_builder = KeyframeCloudBuilder(0)
+        self.optimizer = DmsaOptimizer(device=0)
+        self.n_clouds, self.C, self.dt_res, self.max_pts, self.seed = n_clouds, num_control_poses, dt_res, max_points_per_scan, seed
+        self.min_overlap, self.dist_kf = min_overlap_new_keyframe, dist_new_keyframe
+        self.buffer, self.old_traj, self.initialized = [], None, False
+        self.keyframes = []   # dicts: pos, orient, xyz (local), normal (local), ring
+        self.lines, self.log = [], []
+
+    def close(self):
+        for o in (self.decoder, self.static, self.setup, self.kf_builder, self.optimizer):
+            o.close()
+
+    def _keyframe_global(self, kf):
+        from scipy.spatial.transform import Rotation as Rot
+
+        R = Rot.from_rotvec(kf["orient"])
+        xyz = kf["xyz"].copy()
+        xyz[:, :3] = (R.apply(kf["xyz"][:, :3].astype(np.float64)) + kf["pos"]).astype(f32)
+        nrm = kf["normal"].copy()
+        nrm[:, :3] = R.apply(np.nan_to_num(kf["normal"][:, :3].astype(np.float64))).astype(f32)
+        return xyz, nrm
+
+    def process(self, msg, first_pose=None):
+        # callbackPointCloud + preProcess
+        xyz, stamps, ids = self.decoder.decode(msg)
+        fxyz, src, grid = self.static.preProcess(xyz, self.seed, self.max_pts)
+        self.buffer.append((fxyz[:, :3].copy(), stamps[src], ids[src], f32(grid)))
+        if len(self.buffer) > self.n_clouds:
+            self.buffer.pop(0)
+        if len(self.buffer) < self.n_clouds:
+            return
+        # prepareTrajectoryForOptimization
+        traj, prob, self.initialized = self.setup.prepareTrajectoryForOptimization(self.buffer, self.old_traj, self.initialized, self.C, self.dt_res)
+        if self.old_traj is None and first_pose is not None:  # the demo starts in motion: seed the first window with its true poses
+            prob.relOrientations[...], prob.relTranslations[...] = first_pose(traj)
+        settings = DmsaOptimSettings.sliding_window(use_imu=False, num_iter=5)
+        overlap = 0.0
+        if self.keyframes:
+            # addStaticPoints against the (here: all) keyframes
+            self.optimizer.upload(prob)
+            self.optimizer.poseTables(self.optimizer.getPoseParameters(), download=False)
+            window_global = self.optimizer.updateGlobalPoints(0)
+            kx, kn, kr, off = [], [], [], [0]
+            for kf in self.keyframes:
+                gx, gn = self._keyframe_global(kf)
+                kx.append(gx), kn.append(gn), kr.append(kf["ring"]), off.append(off[-1] + gx.shape[0])
+            go, gt = posemath.relative2global(prob.relOrientations, prob.relTranslations)
+            sp = StaticSelectProblem(windowPoints=window_global, keyframeIds=np.arange(len(self.keyframes), dtype=np.int32), frameOffsets=np.array(off, np.int64),
+                                     keyPoints=np.concatenate(kx), keyNormals=np.concatenate(kn), keyRingIds=np.concatenate(kr), currPos=gt[0].astype(f32),
+                                     minGridSize=prob.minGridSize)
+            sel, active, active_ids, overlap = self.static.addStaticPoints(sp, self.seed)
+            prob.staticPoints, prob.staticRingIds = active, active_ids
+        rep = self.optimizer.optimizeSet(prob, settings)
+        traj.relOrientations[...], traj.relTranslations[...] = prob.relOrientations, prob.relTranslations
+        self.old_traj = traj
+        go, gt = posemath.relative2global(prob.relOrientations, prob.relTranslations)
+        self.lines.append(wf.addPoseToFile(traj.t0, gt[0], go[0]))
+        # keyframe decision (DmsaSlam.h:170-186)
+        need = not self.keyframes or overlap < self.min_overlap or np.linalg.norm(gt[0] - self.keyframes[-1]["pos"]) > self.dist_kf
+        if need:
+            self.optimizer.upload(prob)
+            self.optimizer.poseTables(self.optimizer.getPoseParameters(), download=False)
+            window_global = self.optimizer.updateGlobalPoints(0)[: prob.localPoints.shape[0]]
+            kxyz, knrm, kring, _ = self.kf_builder.addNewKeyframeCloud(window_global, prob.ringIds, prob.minGridSize, self.seed, gt[0], go[0])
+            self.keyframes.append({"pos": gt[0].copy(), "orient": go[0].copy(), "xyz": kxyz, "normal": knrm, "ring": kring})
+        self.log.append({"t0": traj.t0, "pos": gt[0].copy(), "orient": go[0].copy(), "iterations": rep.iterations, "gaussians": rep.num_gaussians,
+                         "static": int(prob.staticPoints.shape[0]), "overlap": float(overlap), "keyframes": len(self.keyframes)})
+
+
+def run(scans=14, rings=64, az_steps=512, seed=1):
+    clouds, truth = synth.scan_sequence(seed=seed, scans=scans, rings=rings, az_steps=az_steps)
+    slam = MiniSlam()
+
+    def first_pose(traj):
+        R, p = truth.pose(traj.t0 - 1.6e9 + traj.stamps)
+        return posemath.global2relative(R.as_rotvec(), p)
+
+    for xyz, stamps, ring, _ in clouds:
+        slam.process(scan_to_pointcloud2(xyz, stamps, ring), first_pose)
+    errs = []
+    for e in slam.log:
+        _, p = truth.pose(np.array([e["t0"] - 1.6e9]))
+        errs.append(float(np.linalg.norm(e["pos"] - p[0])))
+    out = {"windows": len(slam.log), "keyframes": len(slam.keyframes), "max_position_error_m": max(errs) if errs else None, "log": slam.log, "tum": slam.lines}
+    slam.close()
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scans", type=int, default=14)
+    a = ap.parse_args()
+    r = run(a.scans)
+    for e in r["log"]:
+        print(f"t0={e['t0']:.3f} pos=({e['pos'][0]:.3f} {e['pos'][1]:.3f} {e['pos'][2]:.3f}) iters={e['iterations']} M={e['gaussians']} static={e['static']} "
+              f"overlap={e['overlap']:.2f} keyframes={e['keyframes']}")
+    print("".join(r["tum"]), end="")
+    print(f"windows={r['windows']} keyframes={r['keyframes']} max |position error| = {r['max_position_error_m']:.3f} m")
