@@ -2055,69 +2055,69 @@ int orc_traj_update_initial_guess(int32_t* is_initialized, dmsa_traj_state* cur,
 #include <iomanip>
 #include <sstream>
 
-extern "C" {
+// callbackPointCloud :399-486 restated as a table: which message field carries the stamp / the ring for each config.sensor, how it
+// is encoded, and how the point stamp follows from it.  Every value is fetched with memcpy at k * point_step + fields[i].offset,
+// like the node does.
+namespace {
+enum class StampKind { AbsF64, RelU32Nanos, RelF32, AbsF64Nanos, Heuristic };
+enum class RingKind { U16, U8, I8, IndexMod1000 };
+struct SensorLayout {
+    int stamp_field;
+    StampKind stamp;
+    int ring_field;
+    RingKind ring;
+};
+const SensorLayout kSensorLayouts[8] = {
+    {4, StampKind::AbsF64, 5, RingKind::U16},              // hesai      :411-419
+    {4, StampKind::RelU32Nanos, 6, RingKind::U8},          // ouster     :420-430
+    {5, StampKind::AbsF64, 4, RingKind::U16},              // robosense  :431-439
+    {5, StampKind::RelF32, 4, RingKind::U16},              // velodyne   :440-448
+    {6, StampKind::AbsF64, -1, RingKind::IndexMod1000},    // livox s    :449-458
+    {6, StampKind::AbsF64Nanos, -1, RingKind::IndexMod1000},  // livox ns :459-469
+    {8, StampKind::RelF32, 11, RingKind::I8},              // sick       :470-478
+    {-1, StampKind::Heuristic, -1, RingKind::IndexMod1000},   // unknown :479-486
+};
+template <typename T>
+T fetch(const uint8_t* at) {
+    T v;
+    std::memcpy(&v, at, sizeof(T));
+    return v;
+}
+}  // namespace
 
-// callbackPointCloud :399-486, literally: memcpy from msg->data at arrayPosition + fields[i].offset
-int orc_decode_pointcloud2(const dmsa_pointcloud2* msg, int32_t sensor, float* xyz_out, double* stamp_out, int32_t* id_out) {
-    const uint32_t n = msg->height * msg->width;
-    const uint8_t* data = msg->data;
+extern "C" int orc_decode_pointcloud2(const dmsa_pointcloud2* msg, int32_t sensor, float* xyz_out, double* stamp_out, int32_t* id_out) {
+    if (sensor < 0 || sensor > 7) return DMSA_ERR_INVALID;
+    const SensorLayout& L = kSensorLayouts[sensor];
+    const uint32_t count = msg->height * msg->width;
     const uint32_t* off = msg->field_offsets;
-    const double stampMsg = msg->stamp_msg, deltaTPcs = msg->delta_t_pcs;
-    uint8_t ring_tmp8;
-    int8_t ring_int8;
-    uint16_t ring_tmp;
-    uint32_t relStampNano;
-    float tmpStampFloat;
-    double tmpStampDouble;
-    for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t arrayPosition = k * msg->point_step;
-        float* xyz = xyz_out + 4 * (size_t)k;
-        xyz[3] = 0.0f;  // value-initialised PointStampId
-        std::memcpy(&xyz[0], &data[arrayPosition + off[0]], sizeof(float));
-        std::memcpy(&xyz[1], &data[arrayPosition + off[1]], sizeof(float));
-        std::memcpy(&xyz[2], &data[arrayPosition + off[2]], sizeof(float));
-        switch (sensor) {
-            case DMSA_SENSOR_HESAI:
-                std::memcpy(&tmpStampDouble, &data[arrayPosition + off[4]], sizeof(double));
-                std::memcpy(&ring_tmp, &data[arrayPosition + off[5]], sizeof(uint16_t));
-                stamp_out[k] = tmpStampDouble, id_out[k] = (int)ring_tmp;
-                break;
-            case DMSA_SENSOR_OUSTER:
-                std::memcpy(&relStampNano, &data[arrayPosition + off[4]], sizeof(uint32_t));
-                std::memcpy(&ring_tmp8, &data[arrayPosition + off[6]], sizeof(uint8_t));
-                tmpStampDouble = stampMsg + 1e-9 * (double)relStampNano;
-                stamp_out[k] = tmpStampDouble, id_out[k] = (int)ring_tmp8;
-                break;
-            case DMSA_SENSOR_ROBOSENSE:
-                std::memcpy(&tmpStampDouble, &data[arrayPosition + off[5]], sizeof(double));
-                std::memcpy(&ring_tmp, &data[arrayPosition + off[4]], sizeof(uint16_t));
-                stamp_out[k] = tmpStampDouble, id_out[k] = (int)ring_tmp;
-                break;
-            case DMSA_SENSOR_VELODYNE:
-                std::memcpy(&tmpStampFloat, &data[arrayPosition + off[5]], sizeof(float));
-                std::memcpy(&ring_tmp, &data[arrayPosition + off[4]], sizeof(uint16_t));
-                stamp_out[k] = stampMsg + static_cast<double>(tmpStampFloat), id_out[k] = (int)ring_tmp;
-                break;
-            case DMSA_SENSOR_LIVOX_S:
-                std::memcpy(&tmpStampDouble, &data[arrayPosition + off[6]], sizeof(double));
-                stamp_out[k] = tmpStampDouble, id_out[k] = (int)(k % 1000);
-                break;
-            case DMSA_SENSOR_LIVOX_NS:
-                std::memcpy(&tmpStampDouble, &data[arrayPosition + off[6]], sizeof(double));
-                stamp_out[k] = 1e-9 * tmpStampDouble, id_out[k] = (int)(k % 1000);
-                break;
-            case DMSA_SENSOR_SICK:
-                std::memcpy(&tmpStampFloat, &data[arrayPosition + off[8]], sizeof(float));
-                std::memcpy(&ring_int8, &data[arrayPosition + off[11]], sizeof(int8_t));
-                stamp_out[k] = stampMsg + static_cast<double>(tmpStampFloat), id_out[k] = static_cast<int>(ring_int8);
-                break;
-            default:
-                stamp_out[k] = stampMsg + deltaTPcs * (double)k / (double)(msg->height * msg->width), id_out[k] = (int)(k % 1000);
-                break;
+    for (uint32_t k = 0; k < count; ++k) {
+        const uint8_t* pt = msg->data + (uint32_t)(k * msg->point_step);
+        float* o = xyz_out + 4 * (size_t)k;
+        o[0] = fetch<float>(pt + off[0]), o[1] = fetch<float>(pt + off[1]), o[2] = fetch<float>(pt + off[2]);
+        o[3] = 0.0f;  // PointStampId is value-initialised by PointCloud::resize
+        const uint8_t* sp = L.stamp_field >= 0 ? pt + off[L.stamp_field] : nullptr;
+        double st = 0.0;
+        switch (L.stamp) {
+            case StampKind::AbsF64: st = fetch<double>(sp); break;
+            case StampKind::RelU32Nanos: st = msg->stamp_msg + 1e-9 * (double)fetch<uint32_t>(sp); break;
+            case StampKind::RelF32: st = msg->stamp_msg + static_cast<double>(fetch<float>(sp)); break;
+            case StampKind::AbsF64Nanos: st = 1e-9 * fetch<double>(sp); break;
+            case StampKind::Heuristic: st = msg->stamp_msg + msg->delta_t_pcs * (double)k / (double)count; break;
         }
+        const uint8_t* rp = L.ring_field >= 0 ? pt + off[L.ring_field] : nullptr;
+        int ring = 0;
+        switch (L.ring) {
+            case RingKind::U16: ring = (int)fetch<uint16_t>(rp); break;
+            case RingKind::U8: ring = (int)fetch<uint8_t>(rp); break;
+            case RingKind::I8: ring = static_cast<int>(fetch<int8_t>(rp)); break;
+            case RingKind::IndexMod1000: ring = (int)(k % 1000); break;
+        }
+        stamp_out[k] = st, id_out[k] = ring;
     }
     return DMSA_OK;
 }
+
+extern "C" {
 
 // addPoseToFile (OutputManagement.h:80-96) through the same iostream manipulators
 int orc_format_tum_pose(double stamp, const double* pos, const double* orient, char* out, int32_t cap) {
