@@ -112,6 +112,11 @@ def main():
     settings.num_iter = max(1, args.warmup)
     if args.warmup > 0:
         opt.optimizeResident(settings)
+    if world > 1:
+        # warm the collective the timed region ends with: the first all-gather on a fresh communicator sets up its xGMI peer
+        # connections (tens of ms), which is start-up cost, not part of a step
+        w = torch.zeros(64, dtype=torch.float64, device=coll_dev)
+        dist.all_gather([torch.empty_like(w) for _ in range(world)], w)
     opt.timing(reset=True)
     settings.num_iter = args.steps
     sync_all()
