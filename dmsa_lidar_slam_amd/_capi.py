@@ -241,6 +241,7 @@ def load_library() -> C.CDLL:
         "dmsa_decentralize": (C.c_int, [vp]),
         "dmsa_get_params": (C.c_int, [vp, c_double_p, c_int32_p]),
         "dmsa_set_params": (C.c_int, [vp, c_double_p]),
+        "dmsa_additional_errors": (C.c_int, [vp, c_double_p, C.c_int32, c_int32_p]),
         "dmsa_pose_tables": (C.c_int, [vp, C.c_int32, c_double_p, c_float_p]),
         "dmsa_set_pose_tables": (C.c_int, [vp, C.c_int32, c_float_p]),
         "dmsa_num_table_rows": (C.c_int, [vp, c_int32_p]),
@@ -292,7 +293,7 @@ def load_library() -> C.CDLL:
 EXPORTED_SYMBOLS = (
     "dmsa_create dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
     "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
-    "dmsa_set_params dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
+    "dmsa_set_params dmsa_additional_errors dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
     "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_optimize_resident dmsa_get_poses "
     "dmsa_select_static_points dmsa_get_overlap dmsa_random_grid_downsampling dmsa_radius_exists dmsa_preprocess_scan "
     "dmsa_imu_buffer_create dmsa_imu_buffer_destroy dmsa_imu_buffer_add dmsa_imu_buffer_closest dmsa_imu_buffer_state dmsa_traj_dims dmsa_traj_grids "

@@ -124,6 +124,12 @@ class DmsaOptimizer:
         params = np.ascontiguousarray(params, np.float64)
         self._check(self._lib.dmsa_set_params(self._ctx, capi.ptr(params, C.c_double)), "set_params")
 
+    def getAdditionalErrorTerms(self) -> np.ndarray:
+        """updateAdditionalErrors() + getAdditionalErrorTerms() for the current pose parameters of the resident problem."""
+        out, n = np.zeros(4096), C.c_int32(0)
+        self._check(self._lib.dmsa_additional_errors(self._ctx, capi.ptr(out, C.c_double), out.shape[0], C.byref(n)), "additional_errors")
+        return out[: n.value].copy()
+
     def numTableRows(self) -> int:
         r = C.c_int32()
         self._check(self._lib.dmsa_num_table_rows(self._ctx, C.byref(r)), "num_table_rows")

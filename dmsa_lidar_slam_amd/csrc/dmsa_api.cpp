@@ -1147,6 +1147,20 @@ int dmsa_set_params(dmsa_ctx* ctx, const double* params) {
     return DMSA_OK;
 }
 
+int dmsa_additional_errors(dmsa_ctx* ctx, double* rows_out, int32_t capacity, int32_t* num_out) {
+    if (!ctx || ctx->model == MODEL_NONE || !num_out) return DMSA_ERR_INVALID;
+    const int a = num_extra_rows(ctx);
+    *num_out = a;
+    if (a == 0) return DMSA_OK;
+    if (!rows_out || capacity < a) return DMSA_ERR_INVALID;
+    chain(ctx).relative_to_global();
+    if (ctx->model == MODEL_WINDOW)
+        ctx->win.imu_rows(rows_out);
+    else
+        ctx->key.additional_rows(rows_out);
+    return DMSA_OK;
+}
+
 int dmsa_num_table_rows(dmsa_ctx* ctx, int32_t* n_rows) {
     if (!ctx || ctx->model == MODEL_NONE || !n_rows) return DMSA_ERR_INVALID;
     *n_rows = ctx->rows - 1;

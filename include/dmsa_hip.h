@@ -184,6 +184,10 @@ int dmsa_decentralize(dmsa_ctx* ctx);
 /* current parameter vector (getPoseParameters) of the uploaded problem, P doubles */
 int dmsa_get_params(dmsa_ctx* ctx, double* params, int32_t* P);
 int dmsa_set_params(dmsa_ctx* ctx, const double* params);
+/* == updateAdditionalErrors() + getAdditionalErrorTerms() (OptimizablePointSet.h:27-31; ContinuousTrajectory.h:102-117 IMU rows,
+ * MapManagement.h:162-252 gravity then odometry rows) for the CURRENT pose parameters of the uploaded problem (the chain is
+ * re-linked first, like updateGlobalPoints does).  rows_out: capacity doubles; num_out = number of rows (0 when the model has none). */
+int dmsa_additional_errors(dmsa_ctx* ctx, double* rows_out, int32_t capacity, int32_t* num_out);
 /* Build B dense pose tables from B parameter vectors (B x P row-major doubles).
  * tables_out (optional, host): B x n_rows x 12 floats, each row = 3x4 [R|t] row-major.
  * == setPoseParameters + updateTrajDenseTforms (window) / per-keyframe transforms (keyframes). */

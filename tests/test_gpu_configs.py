@@ -247,3 +247,27 @@ def test_long_pose_tables(hip, orc, dt_res):
         e_ref = ref.residuals(np.concatenate([gb, prob.staticPoints]).astype(np.float32))
         rel = np.abs(e[b] - e_ref) / np.maximum(np.abs(e_ref), 1e-12)
         assert rel.max() < 1e-6, (b, rel.max())
+
+
+def test_additional_error_rows_bit_exact(orc):
+    """getAdditionalErrorTerms through the C ABI: IMU rows of the window model (ContinuousTrajectory.h:603-663) and gravity rows of
+    the keyframe model (MapManagement.h:210-232) are host double arithmetic in the reference's order: identical to the oracle."""
+    from dmsa_lidar_slam_amd.api import DmsaOptimizer
+
+    g = DmsaOptimizer(device=0)
+    w = synth.window_problem(seed=3, scans=3, rings=16, az_steps=128, num_static=500, use_imu=True)
+    g.upload(w)
+    a, b = g.getAdditionalErrorTerms(), orc.window_additional_errors(w)
+    assert a.shape == (5,) and np.array_equal(a, b) and np.all(a > 0)
+    params = g.getPoseParameters()
+    params[3] += 1e-3
+    g.setPoseParameters(params)
+    assert not np.array_equal(g.getAdditionalErrorTerms(), a)  # the rows follow the pose parameters
+    k = synth.keyframe_problem(seed=5, frames=6, rings=16, az_steps=128, arc=0.4)
+    g.upload(k)
+    a, b = g.getAdditionalErrorTerms(), orc.keyframe_additional_errors(k)
+    assert a.shape == b.shape and np.array_equal(a, b) and a[0] == 0.0  # row 0 stays exactly 0 (q13)
+    w0 = synth.window_problem(seed=3, scans=3, rings=16, az_steps=128, num_static=500)
+    g.upload(w0)
+    assert g.getAdditionalErrorTerms().shape == (0,)
+    g.close()
