@@ -1456,14 +1456,25 @@ StaticState* sp_state(dmsa_ctx* ctx) {
 // Uniform cell grid over `n` host points (cells of 1.001 * radius): bounds -> [sync] -> codes -> radix sort -> sorted copies + hash of
 // the occupied cells.  Leaves the grid in sp->grid / table / pts_sorted / code_s.
 int sp_build_grid_device(dmsa_ctx* ctx, int64_t n, float radius);
+// n points into a device buffer: from the host, or (host pointer NULL) the first n global points of the uploaded problem as the
+// last dmsa_transform_points / optimizeSet left them -- the window cloud never leaves HBM between the hot path and the steps around it
+int sp_stage_points(dmsa_ctx* ctx, void* dst, const float* host_xyz, int64_t n) {
+    if (host_xyz) {
+        HIPCHK(hipMemcpyAsync(dst, host_xyz, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+        return DMSA_OK;
+    }
+    if (ctx->model == MODEL_NONE || n > ctx->n || !ctx->d_global.p) return DMSA_ERR_INVALID;
+    HIPCHK(hipMemcpyAsync(dst, ctx->d_global.p, (size_t)n * 16, hipMemcpyDeviceToDevice, ctx->stream));
+    return DMSA_OK;
+}
 int sp_build_grid(dmsa_ctx* ctx, const float* cloud_xyz, int64_t n, float radius) {
     StaticState* sp = sp_state(ctx);
     if (!sp) return DMSA_ERR_NOMEM;
-    if (!(radius > 0.0f) || n < 0 || n > (int64_t)0x7FFFFFF0 || (n > 0 && !cloud_xyz)) return DMSA_ERR_INVALID;
+    if (!(radius > 0.0f) || n < 0 || n > (int64_t)0x7FFFFFF0) return DMSA_ERR_INVALID;
     sp->n_cloud = n;
     if (n == 0) return DMSA_OK;
     HIPCHK(sp->cloud.ensure((size_t)n * 16));
-    HIPCHK(hipMemcpyAsync(sp->cloud.p, cloud_xyz, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    CHK(sp_stage_points(ctx, sp->cloud.p, cloud_xyz, n));
     return sp_build_grid_device(ctx, n, radius);
 }
 // the same on a cloud that already sits in sp->cloud
@@ -1531,7 +1542,7 @@ int sp_query(dmsa_ctx* ctx, const float* query_xyz, int64_t nq, float r2) {
     if (nq <= 0) return DMSA_OK;
     HIPCHK(sp->query.ensure((size_t)nq * 16));
     HIPCHK(sp->flags.ensure((size_t)nq));
-    HIPCHK(hipMemcpyAsync(sp->query.p, query_xyz, (size_t)nq * 16, hipMemcpyHostToDevice, ctx->stream));
+    CHK(sp_stage_points(ctx, sp->query.p, query_xyz, nq));
     if (sp->n_cloud == 0) {
         HIPCHK(hipMemsetAsync(sp->flags.p, 0, (size_t)nq, ctx->stream));
         return DMSA_OK;
@@ -1558,7 +1569,7 @@ int sp_grid_upload(dmsa_ctx* ctx, const float* xyz, int64_t n) {
     HIPCHK(sp->counts.ensure(sizeof(GaussCounts)));
     HIPCHK(sp->lattice.ensure(2 * sizeof(LatticeTable)));
     HIPCHK(sp->aabb.ensure((size_t)((n + kAabbBlock - 1) / kAabbBlock) * 8 * sizeof(float)));
-    HIPCHK(hipMemcpyAsync(sp->cloud.p, xyz, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    CHK(sp_stage_points(ctx, sp->cloud.p, xyz, n));
     launch_block_aabb(sp->cloud.as<float4>(), n, sp->aabb.as<float>(), ctx->stream);  // independent of the resolution
     return DMSA_OK;
 }
@@ -1704,7 +1715,7 @@ int dmsa_get_overlap(dmsa_ctx* ctx, const float* pc1_xyz, int64_t n1, const floa
 
 int dmsa_random_grid_downsampling(dmsa_ctx* ctx, const float* xyz, int64_t n, float grid_size, uint32_t seed, int32_t* picked_index_out, int64_t capacity,
                                   int64_t* num_out) {
-    if (!ctx || n < 0 || (n > 0 && !xyz) || !(grid_size > 0.0f) || n > (int64_t)0x7FFFFFF0) return DMSA_ERR_INVALID;
+    if (!ctx || n < 0 || !(grid_size > 0.0f) || n > (int64_t)0x7FFFFFF0) return DMSA_ERR_INVALID;
     CHK(set_device(ctx));
     if (num_out) *num_out = 0;
     if (n == 0) return DMSA_OK;
@@ -1869,7 +1880,8 @@ int dmsa_make_keyframe_cloud(dmsa_ctx* ctx, const float* global_xyz, const int32
                              const double orient0[3], float* xyz_local_out, float* normal_out, int32_t* ring_out, int32_t* src_index_out, int64_t capacity,
                              int64_t* num_out) {
     if (num_out) *num_out = 0;
-    if (!ctx || n < 0 || (n > 0 && (!global_xyz || !ids)) || !(min_grid_size > 0.0f) || !pos0 || !orient0 || capacity < 0 || n > (int64_t)0x7FFFFFF0 / 8) return DMSA_ERR_INVALID;
+    if (!ctx || n < 0 || !(min_grid_size > 0.0f) || !pos0 || !orient0 || capacity < 0 || n > (int64_t)0x7FFFFFF0 / 8) return DMSA_ERR_INVALID;
+    if ((global_xyz == nullptr) != (ids == nullptr)) return DMSA_ERR_INVALID;  // both from the host or both resident
     CHK(set_device(ctx));
     if (n == 0) return DMSA_OK;
     StaticState* sp = sp_state(ctx);
@@ -1890,7 +1902,10 @@ int dmsa_make_keyframe_cloud(dmsa_ctx* ctx, const float* global_xyz, const int32
     HIPCHK(sp->ring.ensure((size_t)n * 4));
     HIPCHK(sp->out_xyz.ensure((size_t)m * 16));
     HIPCHK(sp->out_id.ensure((size_t)m * 4));
-    HIPCHK(hipMemcpyAsync(sp->ring.p, ids, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (ids)
+        HIPCHK(hipMemcpyAsync(sp->ring.p, ids, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    else
+        HIPCHK(hipMemcpyAsync(sp->ring.p, ctx->d_ring.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     launch_to_keyframe_frame(sp->cloud.as<float4>(), sp->ring.as<int32_t>(), sp->pick.as<int32_t>(), (int)m, rinv, (float)pos0[0], (float)pos0[1], (float)pos0[2],
                              sp->out_xyz.as<float4>(), sp->out_id.as<int32_t>(), ctx->stream);
     if (src_index_out) HIPCHK(hipMemcpyAsync(src_index_out, sp->pick.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));

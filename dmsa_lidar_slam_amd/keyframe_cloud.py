@@ -12,8 +12,13 @@ from .static_points import _xyz4
 
 
 class KeyframeCloudBuilder:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, optimizer=None):
+        """optimizer: a DmsaOptimizer whose context (and resident window cloud) this builder shares; None = own context."""
         self._lib = capi.load_library()
+        self._owner = optimizer is None
+        if optimizer is not None:
+            self._ctx = optimizer._ctx
+            return
         ctx = C.c_void_p()
         rc = self._lib.dmsa_create(device, 0, C.byref(ctx))
         if rc != capi.DMSA_OK:
@@ -21,9 +26,9 @@ class KeyframeCloudBuilder:
         self._ctx = ctx
 
     def close(self):
-        if getattr(self, "_ctx", None):
+        if getattr(self, "_ctx", None) and self._owner:
             self._lib.dmsa_destroy(self._ctx)
-            self._ctx = None
+        self._ctx = None
 
     __del__ = close
 
@@ -42,12 +47,12 @@ class KeyframeCloudBuilder:
                                                   capi.ptr(out, C.c_float), capi.ptr(nn, C.c_int32)), "dmsa_update_normals")
         return (out[:n], nn[:n]) if neighbours else out[:n]
 
-    def addNewKeyframeCloud(self, globalPoints, ids, minGridSize: float, seed: int, pos0, orient0):
+    def addNewKeyframeCloud(self, globalPoints, ids, minGridSize: float, seed: int, pos0, orient0, numResident: int = 0):
         """addNewKeyframeToMap (:497-531) without the bookkeeping: (pointCloudLocal xyz (m,4), normals (m,4), ringIds (m,), index into
-        globalPoints (m,))."""
-        a = _xyz4(globalPoints)
-        ids = np.ascontiguousarray(ids, np.int32)
-        n = a.shape[0]
+        globalPoints (m,)).  globalPoints None: the first numResident global points / ring ids resident in the shared optimizer context."""
+        a = _xyz4(globalPoints) if globalPoints is not None else None
+        ids = np.ascontiguousarray(ids, np.int32) if globalPoints is not None else None
+        n = a.shape[0] if a is not None else int(numResident)
         p, o = np.ascontiguousarray(pos0, np.float64), np.ascontiguousarray(orient0, np.float64)
         xyz, nrm = np.zeros((max(n, 1), 4), np.float32), np.zeros((max(n, 1), 4), np.float32)
         ring, src, m = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32), C.c_int64(0)

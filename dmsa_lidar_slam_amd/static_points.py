@@ -24,7 +24,7 @@ def _xyz4(a) -> np.ndarray:
 @dataclass
 class StaticSelectProblem:
     """Inputs of the keyframe loop of addStaticPoints (names as in DmsaSlam.h:264-344)."""
-    windowPoints: np.ndarray        # trajIn.globalPoints, (N,4) float32
+    windowPoints: np.ndarray | None  # trajIn.globalPoints, (N,4) float32; None = the resident window of the shared optimizer context
     keyframeIds: np.ndarray         # closest keyframe ids that passed the distance gate, in closestKeyIds order
     frameOffsets: np.ndarray        # (K+1,) prefix of points per keyframe cloud
     keyPoints: np.ndarray           # (n,4) GLOBAL keyframe clouds, concatenated
@@ -32,9 +32,11 @@ class StaticSelectProblem:
     keyRingIds: np.ndarray          # (n,)
     currPos: np.ndarray             # (3,) float32
     minGridSize: float
+    numWindowResident: int = 0      # number of resident window points to use when windowPoints is None
 
     def __post_init__(self):
-        self.windowPoints, self.keyPoints, self.keyNormals = _xyz4(self.windowPoints), _xyz4(self.keyPoints), _xyz4(self.keyNormals)
+        self.windowPoints = _xyz4(self.windowPoints) if self.windowPoints is not None else None
+        self.keyPoints, self.keyNormals = _xyz4(self.keyPoints), _xyz4(self.keyNormals)
         self.keyframeIds = np.ascontiguousarray(self.keyframeIds, dtype=np.int32)
         self.frameOffsets = np.ascontiguousarray(self.frameOffsets, dtype=np.int64)
         self.keyRingIds = np.ascontiguousarray(self.keyRingIds, dtype=np.int32)
@@ -44,7 +46,7 @@ class StaticSelectProblem:
 
     def to_c(self) -> capi.StaticSelectProblem:
         p = capi.StaticSelectProblem()
-        p.num_window = self.windowPoints.shape[0]
+        p.num_window = self.windowPoints.shape[0] if self.windowPoints is not None else int(self.numWindowResident)
         p.window_xyz = capi.ptr(self.windowPoints, C.c_float)
         p.num_keyframes = self.keyframeIds.shape[0]
         p.keyframe_ids = capi.ptr(self.keyframeIds, C.c_int32)
@@ -69,8 +71,13 @@ class StaticSelection:
 class StaticPointSelector:
     """GPU implementation of the pieces of DmsaSlam::addStaticPoints (one context on one device)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, optimizer=None):
+        """optimizer: a DmsaOptimizer whose context (and resident window cloud) this selector shares; None = own context."""
         self._lib = capi.load_library()
+        self._owner = optimizer is None
+        if optimizer is not None:
+            self._ctx = optimizer._ctx
+            return
         ctx = C.c_void_p()
         rc = self._lib.dmsa_create(device, 0, C.byref(ctx))
         if rc != capi.DMSA_OK:
@@ -78,9 +85,9 @@ class StaticPointSelector:
         self._ctx = ctx
 
     def close(self):
-        if getattr(self, "_ctx", None):
+        if getattr(self, "_ctx", None) and self._owner:
             self._lib.dmsa_destroy(self._ctx)
-            self._ctx = None
+        self._ctx = None
 
     def __del__(self):
         try:
@@ -103,10 +110,12 @@ class StaticPointSelector:
         m = res.num_static
         return StaticSelection(xyz[:m].copy(), ids[:m].copy(), ov[: prob.keyframeIds.shape[0]].copy(), res.keyframe_id, res.min_related_key_id, res.max_overlap)
 
-    def getOverlap(self, pc1, pc2, maxDistOverlap: float):
-        a, b = _xyz4(pc1), _xyz4(pc2)
+    def getOverlap(self, pc1, pc2, maxDistOverlap: float, numResident: int = 0):
+        """pc2 None: the first numResident resident window points of the shared optimizer context."""
+        a = _xyz4(pc1)
+        b = _xyz4(pc2) if pc2 is not None else None
         ov, nc = C.c_float(0.0), C.c_int64(0)
-        self._check(self._lib.dmsa_get_overlap(self._ctx, capi.ptr(a, C.c_float), a.shape[0], capi.ptr(b, C.c_float), b.shape[0],
+        self._check(self._lib.dmsa_get_overlap(self._ctx, capi.ptr(a, C.c_float), a.shape[0], capi.ptr(b, C.c_float), b.shape[0] if b is not None else int(numResident),
                                                float(np.float32(maxDistOverlap)), C.byref(ov), C.byref(nc)), "dmsa_get_overlap")
         return float(ov.value), int(nc.value)
 
@@ -150,5 +159,5 @@ class StaticPointSelector:
             active, active_ids = sel.staticPoints[pick], sel.staticIds[pick]
         else:
             active, active_ids = np.zeros((0, 4), np.float32), np.zeros(0, np.int32)
-        overlap, _ = self.getOverlap(active, prob.windowPoints, prob.minGridSize)
+        overlap, _ = self.getOverlap(active, prob.windowPoints, prob.minGridSize, prob.numWindowResident)
         return sel, active, active_ids, overlap

@@ -43,11 +43,12 @@ def scan_to_pointcloud2(xyz, stamps, rings):
 
 class MiniSlam:
     def __init__(self, n_clouds=5, num_control_poses=6, dt_res=1e-3, max_points_per_scan=3000, min_overlap_new_keyframe=0.7, dist_new_keyframe=1.0, seed=7):
-        self.decoder = wf.PointCloud2Decoder("ouster")
-        self.static = StaticPointSelector(0)
-        self.setup = ws.WindowSetup(0)
-        self.kf_builder = KeyframeCloudBuilder(0)
         self.optimizer = DmsaOptimizer(device=0)
+        self.decoder = wf.PointCloud2Decoder("ouster")
+        self.scan_filter = StaticPointSelector(0)                      # preProcess works on raw scans: its own context
+        self.static = StaticPointSelector(optimizer=self.optimizer)     # these two share the optimizer's context: the window cloud
+        self.kf_builder = KeyframeCloudBuilder(optimizer=self.optimizer)  # stays resident in HBM between the steps
+        self.setup = ws.WindowSetup(0)
         self.n_clouds, self.C, self.dt_res, self.max_pts, self.seed = n_clouds, num_control_poses, dt_res, max_points_per_scan, seed
         self.min_overlap, self.dist_kf = min_overlap_new_keyframe, dist_new_keyframe
         self.buffer, self.old_traj, self.initialized = [], None, False
@@ -55,7 +56,7 @@ class MiniSlam:
         self.lines, self.log = [], []
 
     def close(self):
-        for o in (self.decoder, self.static, self.setup, self.kf_builder, self.optimizer):
+        for o in (self.decoder, self.scan_filter, self.static, self.setup, self.kf_builder, self.optimizer):
             o.close()
 
     def _keyframe_global(self, kf):
@@ -71,7 +72,7 @@ class MiniSlam:
     def process(self, msg, first_pose=None):
         # callbackPointCloud + preProcess
         xyz, stamps, ids = self.decoder.decode(msg)
-        fxyz, src, grid = self.static.preProcess(xyz, self.seed, self.max_pts)
+        fxyz, src, grid = self.scan_filter.preProcess(xyz, self.seed, self.max_pts)
         self.buffer.append((fxyz[:, :3].copy(), stamps[src], ids[src], f32(grid)))
         if len(self.buffer) > self.n_clouds:
             self.buffer.pop(0)
@@ -87,13 +88,13 @@ class MiniSlam:
             # addStaticPoints against the (here: all) keyframes
             self.optimizer.upload(prob)
             self.optimizer.poseTables(self.optimizer.getPoseParameters(), download=False)
-            window_global = self.optimizer.updateGlobalPoints(0)
+            self.optimizer.updateGlobalPoints(0, download=False)  # trajIn.globalPoints: resident, never downloaded
             kx, kn, kr, off = [], [], [], [0]
             for kf in self.keyframes:
                 gx, gn = self._keyframe_global(kf)
                 kx.append(gx), kn.append(gn), kr.append(kf["ring"]), off.append(off[-1] + gx.shape[0])
             go, gt = posemath.relative2global(prob.relOrientations, prob.relTranslations)
-            sp = StaticSelectProblem(windowPoints=window_global, keyframeIds=np.arange(len(self.keyframes), dtype=np.int32), frameOffsets=np.array(off, np.int64),
+            sp = StaticSelectProblem(windowPoints=None, numWindowResident=prob.localPoints.shape[0], keyframeIds=np.arange(len(self.keyframes), dtype=np.int32), frameOffsets=np.array(off, np.int64),
                                      keyPoints=np.concatenate(kx), keyNormals=np.concatenate(kn), keyRingIds=np.concatenate(kr), currPos=gt[0].astype(f32),
                                      minGridSize=prob.minGridSize)
             sel, active, active_ids, overlap = self.static.addStaticPoints(sp, self.seed)
@@ -106,10 +107,8 @@ class MiniSlam:
         # keyframe decision (DmsaSlam.h:170-186)
         need = not self.keyframes or overlap < self.min_overlap or np.linalg.norm(gt[0] - self.keyframes[-1]["pos"]) > self.dist_kf
         if need:
-            self.optimizer.upload(prob)
-            self.optimizer.poseTables(self.optimizer.getPoseParameters(), download=False)
-            window_global = self.optimizer.updateGlobalPoints(0)[: prob.localPoints.shape[0]]
-            kxyz, knrm, kring, _ = self.kf_builder.addNewKeyframeCloud(window_global, prob.ringIds, prob.minGridSize, self.seed, gt[0], go[0])
+            # the optimised window is still resident (final updateGlobalPoints of optimizeSet, DmsaOptimizer.h:149)
+            kxyz, knrm, kring, _ = self.kf_builder.addNewKeyframeCloud(None, None, prob.minGridSize, self.seed, gt[0], go[0], numResident=prob.localPoints.shape[0])
             self.keyframes.append({"pos": gt[0].copy(), "orient": go[0].copy(), "xyz": kxyz, "normal": knrm, "ring": kring})
         self.log.append({"t0": traj.t0, "pos": gt[0].copy(), "orient": go[0].copy(), "iterations": rep.iterations, "gaussians": rep.num_gaussians,
                          "static": int(prob.staticPoints.shape[0]), "overlap": float(overlap), "keyframes": len(self.keyframes)})

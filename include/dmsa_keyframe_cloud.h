@@ -30,7 +30,8 @@ int dmsa_update_normals(dmsa_ctx* ctx, const float* xyz, int64_t n, int32_t k, f
 /* == the cloud part of addNewKeyframeToMap (DmsaSlam.h:497-531): randomGridDownsampling(globalPoints, minGridSize) with srand(seed),
  * p_local = currRotInv * (p - currWorldPose) in float for control pose 0 (pos0, orient0: axis-angle), ring ids of the kept points,
  * normals (k = 6, viewpoint = sensor origin).  Outputs sized by capacity (points); src_index_out = index into global_xyz of every
- * keyframe point.  DMSA_ERR_INVALID if capacity is too small (num_out still set). */
+ * keyframe point.  DMSA_ERR_INVALID if capacity is too small (num_out still set).  global_xyz == NULL && ids == NULL: use the first n
+ * global points and ring ids of the problem uploaded to this context (the window optimizeSet just finished) instead of host arrays. */
 int dmsa_make_keyframe_cloud(dmsa_ctx* ctx, const float* global_xyz, const int32_t* ids, int64_t n, float min_grid_size, uint32_t seed, const double pos0[3],
                              const double orient0[3], float* xyz_local_out, float* normal_out, int32_t* ring_out, int32_t* src_index_out, int64_t capacity,
                              int64_t* num_out);

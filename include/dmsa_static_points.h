@@ -8,7 +8,12 @@
  *   randomGridDownsampling         include/DMSA/helpers.h:67-182
  *   DmsaSlam::preProcess           include/DMSA/DmsaSlam.h:569-634   (the per-scan filter in front of the window, row f2)
  *
- * Same conventions as dmsa_hip.h (contexts, status codes, float[n][4] points, no CPU fallback).  The reference answers its
+ * Same conventions as dmsa_hip.h (contexts, status codes, float[n][4] points, no CPU fallback).
+ *
+ * RESIDENT WINDOW CLOUD: wherever a function takes the window cloud (window_xyz of the selection, pc1 / pc2 of getOverlap, the
+ * input of randomGridDownsampling), a NULL pointer means "the first n global points of the problem uploaded to this context, as
+ * the last dmsa_transform_points / dmsa_optimize_* left them" -- the 1.3 M-point cloud then never crosses PCIe between the hot
+ * path and the steps around it.  DMSA_ERR_INVALID when nothing is uploaded or n exceeds the resident point count.  The reference answers its
  * "nearest neighbour within minGridSize" questions with a FLANN kd-tree (pcl::KdTreeFLANN, flann::L2_Simple); only the
  * comparison `squared distance of the nearest neighbour <= radius^2` is ever used, which is the order-independent predicate
  * "some point lies within the radius" -- evaluated here on a uniform cell grid in HBM with the same float distance

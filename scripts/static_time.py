@@ -31,6 +31,27 @@ t_ov, ov = timeit(lambda: g.getOverlap(active, p.windowPoints, p.minGridSize))
 t_all, _ = timeit(lambda: g.addStaticPoints(p, 7))
 out = {"window_points": int(p.windowPoints.shape[0]), "keyframe_points": int(p.keyPoints.shape[0]), "selected": int(sel.staticPoints.shape[0]),
        "active": int(active.shape[0]), "overlap": ov[0], "gpu_ms": {"select": round(t_sel, 3), "thin": round(t_ds, 3), "overlap": round(t_ov, 3), "addStaticPoints": round(t_all, 3)}}
+# the same with the window cloud RESIDENT in the optimizer's context (NULL window pointers): identity poses make global == local
+from dmsa_lidar_slam_amd.api import DmsaOptimizer  # noqa: E402
+from dmsa_lidar_slam_amd.keyframe_cloud import KeyframeCloudBuilder  # noqa: E402
+from dmsa_lidar_slam_amd.problems import ContinuousTrajectory  # noqa: E402
+from dmsa_lidar_slam_amd.static_points import StaticSelectProblem  # noqa: E402
+
+nw = p.windowPoints.shape[0]
+ident = ContinuousTrajectory(relOrientations=np.zeros((2, 3)), relTranslations=np.zeros((2, 3)), stamps=np.array([0.0, 1.0]), trajTime=np.linspace(0.0, 1.0, 11),
+                             localPoints=p.windowPoints, tformIdPerPoint=np.zeros(nw, np.int32), ringIds=np.zeros(nw, np.int32), minGridSize=p.minGridSize)
+opt = DmsaOptimizer(device=0)
+opt.upload(ident)
+opt.poseTables(opt.getPoseParameters(), download=False)
+opt.updateGlobalPoints(0, download=False)
+gr = StaticPointSelector(optimizer=opt)
+pr = StaticSelectProblem(windowPoints=None, numWindowResident=nw, keyframeIds=p.keyframeIds, frameOffsets=p.frameOffsets, keyPoints=p.keyPoints, keyNormals=p.keyNormals,
+                         keyRingIds=p.keyRingIds, currPos=p.currPos, minGridSize=p.minGridSize)
+t_res, res_out = timeit(lambda: gr.addStaticPoints(pr, 7))
+assert np.array_equal(res_out[1], active)
+kr = KeyframeCloudBuilder(optimizer=opt)
+t_kfr, _ = timeit(lambda: kr.addNewKeyframeCloud(None, None, p.minGridSize, 7, np.zeros(3), np.zeros(3), numResident=nw), 5)
+out["resident_window_gpu_ms"] = {"addStaticPoints": round(t_res, 3), "keyframeCloud": round(t_kfr, 3)}
 # DmsaSlam::preProcess of one raw 128 x 1024 scan (rays onto a 50 x 36 x 6 m box), Config.h defaults
 rng = np.random.default_rng(5)
 d = rng.normal(size=(131072, 3))

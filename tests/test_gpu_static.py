@@ -184,3 +184,43 @@ def test_preprocess_scan_edge_cases(gpu, orc):
     gpu.randomGridDownsampling(raw, 0.2, 3)
     _same_scan(gpu.preProcess(raw, 3), a)
     _same_scan(a, orc.preprocess_scan(raw, 3))
+
+
+def test_resident_window_cloud(orc):
+    """NULL window pointers = the global points of the problem uploaded to the shared context: same results as with host arrays, and
+    the keyframe cloud is built from the resident points and ring ids."""
+    from dmsa_lidar_slam_amd import posemath
+    from dmsa_lidar_slam_amd.api import DmsaOptimizer
+    from dmsa_lidar_slam_amd.keyframe_cloud import KeyframeCloudBuilder
+
+    w = synth.window_problem(seed=3, scans=4, rings=32, az_steps=256, num_static=0)
+    opt = DmsaOptimizer(device=0)
+    opt.upload(w)
+    opt.poseTables(opt.getPoseParameters(), download=False)
+    window_global = opt.updateGlobalPoints(0)
+    n = window_global.shape[0]
+    p = synth.static_select_problem(seed=2, scans=1, rings=16, az_steps=64, frames=3, key_rings=32, key_az=160)
+    host = StaticSelectProblem(windowPoints=window_global, keyframeIds=p.keyframeIds, frameOffsets=p.frameOffsets, keyPoints=p.keyPoints, keyNormals=p.keyNormals,
+                               keyRingIds=p.keyRingIds, currPos=p.currPos, minGridSize=p.minGridSize)
+    res = StaticSelectProblem(windowPoints=None, numWindowResident=n, keyframeIds=p.keyframeIds, frameOffsets=p.frameOffsets, keyPoints=p.keyPoints,
+                              keyNormals=p.keyNormals, keyRingIds=p.keyRingIds, currPos=p.currPos, minGridSize=p.minGridSize)
+    shared = StaticPointSelector(optimizer=opt)
+    a = shared.addStaticPoints(res, seed=7)
+    own = StaticPointSelector(device=0)
+    b = own.addStaticPoints(host, seed=7)
+    _same_selection(a[0], b[0])
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3] and a[0].staticPoints.shape[0] > 100
+    _same_selection(a[0], orc.select_static_points(host))
+    go, gt = posemath.relative2global(w.relOrientations, w.relTranslations)
+    kb = KeyframeCloudBuilder(optimizer=opt)
+    r = kb.addNewKeyframeCloud(None, None, w.minGridSize, 5, gt[0], go[0], numResident=n)
+    h = orc.make_keyframe_cloud(window_global, w.ringIds, w.minGridSize, 5, gt[0], go[0])
+    assert np.array_equal(r[0], h[0]) and np.array_equal(r[2], h[2]) and np.array_equal(r[3], h[3]) and r[0].shape[0] > 1000
+    # the resident problem is untouched: optimizeSet still runs on it
+    from dmsa_lidar_slam_amd.problems import DmsaOptimSettings
+
+    rep = opt.optimizeResident(DmsaOptimSettings.sliding_window(num_iter=1))
+    assert rep.iterations == 1
+    with pytest.raises(Exception):
+        own.addStaticPoints(res, seed=7)  # nothing uploaded to that context
+    kb.close(), shared.close(), own.close(), opt.close()
