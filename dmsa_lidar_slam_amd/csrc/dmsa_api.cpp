@@ -242,7 +242,11 @@ namespace {
     } while (0)
 
 WorkerPool& workers(dmsa_ctx* ctx) {
-    if (!ctx->pool) ctx->pool = new WorkerPool((int)std::min(16u, std::max(2u, std::thread::hardware_concurrency())));
+    if (!ctx->pool) {
+        unsigned want = 16;  // DMSA_HOST_THREADS overrides (host pose tables of the parity path, perturbed keyframe chains, upload packing)
+        if (const char* e = std::getenv("DMSA_HOST_THREADS")) want = (unsigned)std::max(1, std::atoi(e));
+        ctx->pool = new WorkerPool((int)std::min(want, std::max(2u, std::thread::hardware_concurrency())));
+    }
     return *ctx->pool;
 }
 hipEvent_t get_event(dmsa_ctx* ctx) {
