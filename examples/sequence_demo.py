@@ -41,82 +41,119 @@ def scan_to_pointcloud2(xyz, stamps, rings):
                              stamp=head)
 
 
-class MiniSlam:
-    def __init__(self, n_clouds=5, num_control_poses=6, dt_res=1e-3, max_points_per_scan=3000, min_overlap_new_keyframe=0.7, dist_new_keyframe=1.0, seed=7):
-        self.optimizer = DmsaOptimizer(device=0)
+class GpuBackend:
+    """The library calls MiniSlam strings together.  (tests/test_gpu_sequence.py runs the same MiniSlam on a backend made of the CPU
+    oracle's functions and compares the two trajectories.)"""
+
+    def __init__(self, parity: bool = False):
+        self.optimizer = DmsaOptimizer(device=0, pose_table_host=parity, mirror_sums=parity)
         self.decoder = wf.PointCloud2Decoder("ouster")
         self.scan_filter = StaticPointSelector(0)                      # preProcess works on raw scans: its own context
         self.static = StaticPointSelector(optimizer=self.optimizer)     # these two share the optimizer's context: the window cloud
         self.kf_builder = KeyframeCloudBuilder(optimizer=self.optimizer)  # stays resident in HBM between the steps
         self.setup = ws.WindowSetup(0)
-        self.n_clouds, self.C, self.dt_res, self.max_pts, self.seed = n_clouds, num_control_poses, dt_res, max_points_per_scan, seed
+
+    def close(self):
+        for o in (self.decoder, self.scan_filter, self.static, self.setup, self.kf_builder, self.optimizer):
+            o.close()
+
+    def decode(self, msg):
+        return self.decoder.decode(msg)
+
+    def preProcess(self, xyz, seed, max_pts):
+        return self.scan_filter.preProcess(xyz, seed, max_pts)
+
+    def prepare(self, buffer, old_traj, initialized, C, dt_res):
+        return self.setup.prepareTrajectoryForOptimization(buffer, old_traj, initialized, C, dt_res)
+
+    def addStaticPoints(self, prob, key_xyz, key_nrm, key_ring, offsets, curr_pos, seed):
+        self.optimizer.upload(prob)
+        self.optimizer.poseTables(self.optimizer.getPoseParameters(), download=False)
+        self.optimizer.updateGlobalPoints(0, download=False)  # trajIn.globalPoints: resident, never downloaded
+        sp = StaticSelectProblem(windowPoints=None, numWindowResident=prob.localPoints.shape[0], keyframeIds=np.arange(len(offsets) - 1, dtype=np.int32),
+                                 frameOffsets=offsets, keyPoints=key_xyz, keyNormals=key_nrm, keyRingIds=key_ring, currPos=curr_pos, minGridSize=prob.minGridSize)
+        _, active, active_ids, overlap = self.static.addStaticPoints(sp, seed)
+        return active, active_ids, overlap
+
+    def optimizeSet(self, prob, settings):
+        return self.optimizer.optimizeSet(prob, settings)
+
+    def keyframeCloud(self, prob, pos0, orient0, seed):
+        # the optimised window is still resident (final updateGlobalPoints of optimizeSet, DmsaOptimizer.h:149)
+        xyz, nrm, ring, _ = self.kf_builder.addNewKeyframeCloud(None, None, prob.minGridSize, seed, pos0, orient0, numResident=prob.localPoints.shape[0])
+        return xyz, nrm, ring
+
+    def tumLine(self, stamp, pos, orient):
+        return wf.addPoseToFile(stamp, pos, orient)
+
+
+class MiniSlam:
+    def __init__(self, backend=None, n_clouds=5, num_control_poses=6, dt_res=1e-3, max_points_per_scan=3000, min_overlap_new_keyframe=0.7, dist_new_keyframe=1.0,
+                 seed=7, num_iter=5):
+        self.be = backend or GpuBackend()
+        self.n_clouds, self.C, self.dt_res, self.max_pts, self.seed, self.num_iter = n_clouds, num_control_poses, dt_res, max_points_per_scan, seed, num_iter
         self.min_overlap, self.dist_kf = min_overlap_new_keyframe, dist_new_keyframe
         self.buffer, self.old_traj, self.initialized = [], None, False
         self.keyframes = []   # dicts: pos, orient, xyz (local), normal (local), ring
         self.lines, self.log = [], []
 
     def close(self):
-        for o in (self.decoder, self.scan_filter, self.static, self.setup, self.kf_builder, self.optimizer):
-            o.close()
+        self.be.close()
 
-    def _keyframe_global(self, kf):
+    @staticmethod
+    def _keyframe_global(kf):
+        """getGlobalKeyframeCloud (MapManagement.h:290-299): float transform of points and normals of one keyframe."""
         from scipy.spatial.transform import Rotation as Rot
 
-        R = Rot.from_rotvec(kf["orient"])
+        R = Rot.from_rotvec(kf["orient"]).as_matrix().astype(f32)
         xyz = kf["xyz"].copy()
-        xyz[:, :3] = (R.apply(kf["xyz"][:, :3].astype(np.float64)) + kf["pos"]).astype(f32)
+        xyz[:, :3] = (kf["xyz"][:, :3] @ R.T + kf["pos"].astype(f32)).astype(f32)
         nrm = kf["normal"].copy()
-        nrm[:, :3] = R.apply(np.nan_to_num(kf["normal"][:, :3].astype(np.float64))).astype(f32)
+        nrm[:, :3] = (np.nan_to_num(kf["normal"][:, :3]) @ R.T).astype(f32)
         return xyz, nrm
 
     def process(self, msg, first_pose=None):
         # callbackPointCloud + preProcess
-        xyz, stamps, ids = self.decoder.decode(msg)
-        fxyz, src, grid = self.scan_filter.preProcess(xyz, self.seed, self.max_pts)
+        xyz, stamps, ids = self.be.decode(msg)
+        fxyz, src, grid = self.be.preProcess(xyz, self.seed, self.max_pts)
         self.buffer.append((fxyz[:, :3].copy(), stamps[src], ids[src], f32(grid)))
         if len(self.buffer) > self.n_clouds:
             self.buffer.pop(0)
         if len(self.buffer) < self.n_clouds:
             return
         # prepareTrajectoryForOptimization
-        traj, prob, self.initialized = self.setup.prepareTrajectoryForOptimization(self.buffer, self.old_traj, self.initialized, self.C, self.dt_res)
+        traj, prob, self.initialized = self.be.prepare(self.buffer, self.old_traj, self.initialized, self.C, self.dt_res)
         if self.old_traj is None and first_pose is not None:  # the demo starts in motion: seed the first window with its true poses
             prob.relOrientations[...], prob.relTranslations[...] = first_pose(traj)
-        settings = DmsaOptimSettings.sliding_window(use_imu=False, num_iter=5)
+        settings = DmsaOptimSettings.sliding_window(use_imu=False, num_iter=self.num_iter)
         overlap = 0.0
-        if self.keyframes:
-            # addStaticPoints against the (here: all) keyframes
-            self.optimizer.upload(prob)
-            self.optimizer.poseTables(self.optimizer.getPoseParameters(), download=False)
-            self.optimizer.updateGlobalPoints(0, download=False)  # trajIn.globalPoints: resident, never downloaded
+        if self.keyframes:  # addStaticPoints against the (here: all) keyframes
             kx, kn, kr, off = [], [], [], [0]
             for kf in self.keyframes:
                 gx, gn = self._keyframe_global(kf)
                 kx.append(gx), kn.append(gn), kr.append(kf["ring"]), off.append(off[-1] + gx.shape[0])
             go, gt = posemath.relative2global(prob.relOrientations, prob.relTranslations)
-            sp = StaticSelectProblem(windowPoints=None, numWindowResident=prob.localPoints.shape[0], keyframeIds=np.arange(len(self.keyframes), dtype=np.int32), frameOffsets=np.array(off, np.int64),
-                                     keyPoints=np.concatenate(kx), keyNormals=np.concatenate(kn), keyRingIds=np.concatenate(kr), currPos=gt[0].astype(f32),
-                                     minGridSize=prob.minGridSize)
-            sel, active, active_ids, overlap = self.static.addStaticPoints(sp, self.seed)
+            active, active_ids, overlap = self.be.addStaticPoints(prob, np.concatenate(kx), np.concatenate(kn), np.concatenate(kr), np.array(off, np.int64),
+                                                                  gt[0].astype(f32), self.seed)
             prob.staticPoints, prob.staticRingIds = active, active_ids
-        rep = self.optimizer.optimizeSet(prob, settings)
+        rep = self.be.optimizeSet(prob, settings)
         traj.relOrientations[...], traj.relTranslations[...] = prob.relOrientations, prob.relTranslations
         self.old_traj = traj
         go, gt = posemath.relative2global(prob.relOrientations, prob.relTranslations)
-        self.lines.append(wf.addPoseToFile(traj.t0, gt[0], go[0]))
+        self.lines.append(self.be.tumLine(traj.t0, gt[0], go[0]))
         # keyframe decision (DmsaSlam.h:170-186)
         need = not self.keyframes or overlap < self.min_overlap or np.linalg.norm(gt[0] - self.keyframes[-1]["pos"]) > self.dist_kf
         if need:
-            # the optimised window is still resident (final updateGlobalPoints of optimizeSet, DmsaOptimizer.h:149)
-            kxyz, knrm, kring, _ = self.kf_builder.addNewKeyframeCloud(None, None, prob.minGridSize, self.seed, gt[0], go[0], numResident=prob.localPoints.shape[0])
+            kxyz, knrm, kring = self.be.keyframeCloud(prob, gt[0], go[0], self.seed)
             self.keyframes.append({"pos": gt[0].copy(), "orient": go[0].copy(), "xyz": kxyz, "normal": knrm, "ring": kring})
         self.log.append({"t0": traj.t0, "pos": gt[0].copy(), "orient": go[0].copy(), "iterations": rep.iterations, "gaussians": rep.num_gaussians,
-                         "static": int(prob.staticPoints.shape[0]), "overlap": float(overlap), "keyframes": len(self.keyframes)})
+                         "static": int(prob.staticPoints.shape[0]), "overlap": float(overlap), "keyframes": len(self.keyframes),
+                         "rel": (prob.relOrientations.copy(), prob.relTranslations.copy())})
 
 
-def run(scans=14, rings=64, az_steps=512, seed=1):
+def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, **slam_args):
     clouds, truth = synth.scan_sequence(seed=seed, scans=scans, rings=rings, az_steps=az_steps)
-    slam = MiniSlam()
+    slam = MiniSlam(backend, **slam_args)
 
     def first_pose(traj):
         R, p = truth.pose(traj.t0 - 1.6e9 + traj.stamps)

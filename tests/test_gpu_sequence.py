@@ -1,10 +1,13 @@
 """The f-rows composed: PointCloud2 bytes -> preProcess -> window setup -> addStaticPoints -> optimizeSet -> keyframe creation -> TUM
-lines on a synthetic drive (examples/sequence_demo.py, a miniature of DmsaSlam::processPointCloud)."""
+lines on a synthetic drive (examples/sequence_demo.py, a miniature of DmsaSlam::processPointCloud) — and the same sequence run on a
+backend made of the CPU oracle's functions: the full-sequence trajectory difference, BASELINE.json's parity criterion."""
 import os
 import sys
 
 import numpy as np
 import pytest
+
+from dmsa_lidar_slam_amd import window_setup as ws
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
@@ -23,3 +26,75 @@ def test_sequence_demo_tracks_the_motion():
     assert len(r["tum"]) == 8 and all(len(line.split()) == 8 for line in r["tum"])
     stamps = [float(line.split()[0]) for line in r["tum"]]
     assert np.all(np.diff(stamps) > 0.09)
+
+
+class OracleBackend:
+    """Every step of MiniSlam on the CPU oracle (test infrastructure)."""
+
+    def __init__(self, orc):
+        self.orc = orc
+        self.setup = orc.WindowSetup()
+
+    def close(self):
+        pass
+
+    def decode(self, msg):
+        return self.orc.decode_pointcloud2(msg, "ouster")
+
+    def preProcess(self, xyz, seed, max_pts):
+        return self.orc.preprocess_scan(xyz, seed, max_pts)
+
+    def prepare(self, buffer, old_traj, initialized, C, dt_res):
+        t_min, t_max = min(float(np.min(c[1])) for c in buffer), max(float(np.max(c[1])) for c in buffer)
+        traj = self.setup.initTraj(t_min, t_max, C, False, dt_res)
+        initialized = self.setup.updateInitialGuess(initialized, traj, old_traj, False)
+        prob = ws.assemble_problem(traj, buffer, self.setup.tformIdPerPoint(traj, np.concatenate([c[1] for c in buffer])))
+        return traj, prob, initialized
+
+    def _window_global(self, prob):
+        table, _ = self.orc.window_pose_table(prob)
+        return self.orc.transform_points(table, prob.localPoints, prob.tformIdPerPoint)
+
+    def addStaticPoints(self, prob, key_xyz, key_nrm, key_ring, offsets, curr_pos, seed):
+        from dmsa_lidar_slam_amd.static_points import StaticSelectProblem
+
+        win = self._window_global(prob)
+        sp = StaticSelectProblem(windowPoints=win, keyframeIds=np.arange(len(offsets) - 1, dtype=np.int32), frameOffsets=offsets, keyPoints=key_xyz,
+                                 keyNormals=key_nrm, keyRingIds=key_ring, currPos=curr_pos, minGridSize=prob.minGridSize)
+        sel = self.orc.select_static_points(sp)
+        if sel.staticPoints.shape[0] == 0:
+            return np.zeros((0, 4), np.float32), np.zeros(0, np.int32), 0.0
+        pick = self.orc.random_grid_downsampling(sel.staticPoints, np.float32(prob.minGridSize) / np.float32(2.0), seed)
+        active, ids = sel.staticPoints[pick], sel.staticIds[pick]
+        return active, ids, self.orc.get_overlap(active, win, prob.minGridSize)[0]
+
+    def optimizeSet(self, prob, settings):
+        rep, _, _ = self.orc.optimize_window(prob, settings)
+        return rep
+
+    def keyframeCloud(self, prob, pos0, orient0, seed):
+        xyz, nrm, ring, _ = self.orc.make_keyframe_cloud(self._window_global(prob), prob.ringIds, prob.minGridSize, seed, pos0, orient0)
+        return xyz, nrm, ring
+
+    def tumLine(self, stamp, pos, orient):
+        return self.orc.format_tum_pose(stamp, pos, orient)
+
+
+def test_full_sequence_trajectory_matches_the_oracle(orc):
+    """Same PointCloud2 stream through the HIP library (parity path) and through the oracle: every decision (points kept by
+    preProcess, static points, keyframes) identical, every window's control poses within 1e-4 m / 1e-4 rad, identical TUM lines."""
+    import sequence_demo
+
+    args = dict(scans=10, rings=32, az_steps=256, num_iter=3)
+    g = sequence_demo.run(backend=sequence_demo.GpuBackend(parity=True), **args)
+    o = sequence_demo.run(backend=OracleBackend(orc), **args)
+    assert g["windows"] == o["windows"] == 6 and g["keyframes"] == o["keyframes"]
+    worst_t = worst_r = 0.0
+    for a, b in zip(g["log"], o["log"]):
+        assert (a["iterations"], a["gaussians"], a["static"], a["keyframes"]) == (b["iterations"], b["gaussians"], b["static"], b["keyframes"])
+        assert a["overlap"] == b["overlap"]
+        worst_r = max(worst_r, float(np.abs(a["rel"][0] - b["rel"][0]).max()))
+        worst_t = max(worst_t, float(np.abs(a["rel"][1] - b["rel"][1]).max()))
+    assert worst_t < 1e-4 and worst_r < 1e-4, (worst_t, worst_r)
+    assert g["tum"] == o["tum"]
+    print(f"full-sequence difference: {worst_t:.2e} m, {worst_r:.2e} rad over {g['windows']} windows")
