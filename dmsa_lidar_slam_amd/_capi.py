@@ -273,6 +273,7 @@ def load_library() -> C.CDLL:
         "dmsa_traj_preint_factors": (C.c_int, [C.c_int32, C.c_int32, c_int32_p, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                                c_double_p, c_double_p, c_double_p]),
         "dmsa_traj_update_initial_guess": (C.c_int, [c_int32_p, C.POINTER(TrajState), C.POINTER(TrajState), C.c_int32]),
+        "dmsa_traj_submap_gravity_estimate": (C.c_int, [C.POINTER(TrajState), c_double_p, c_double_p]),
         # include/dmsa_wire_formats.h
         "dmsa_decode_pointcloud2": (C.c_int, [vp, C.POINTER(PointCloud2), C.c_int32, c_float_p, c_double_p, c_int32_p]),
         "dmsa_format_tum_pose": (C.c_int, [C.c_double, c_double_p, c_double_p, C.c_char_p, C.c_int32]),
@@ -297,6 +298,6 @@ EXPORTED_SYMBOLS = (
     "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_optimize_resident dmsa_get_poses "
     "dmsa_select_static_points dmsa_get_overlap dmsa_random_grid_downsampling dmsa_radius_exists dmsa_preprocess_scan "
     "dmsa_imu_buffer_create dmsa_imu_buffer_destroy dmsa_imu_buffer_add dmsa_imu_buffer_closest dmsa_imu_buffer_state dmsa_traj_dims dmsa_traj_grids "
-    "dmsa_traj_tform_indices dmsa_traj_transfer_imu dmsa_traj_preint_factors dmsa_traj_update_initial_guess "
+    "dmsa_traj_tform_indices dmsa_traj_transfer_imu dmsa_traj_preint_factors dmsa_traj_update_initial_guess dmsa_traj_submap_gravity_estimate "
     "dmsa_decode_pointcloud2 dmsa_format_tum_pose dmsa_compose_nonkeyframe_pose dmsa_update_normals dmsa_make_keyframe_cloud"
 ).split()

@@ -451,4 +451,29 @@ int dmsa_traj_update_initial_guess(int32_t* is_initialized, dmsa_traj_state* cur
     return DMSA_OK;
 }
 
+// ---- getSubmapGravityEstimate -------------------------------------------------------------------------------------------------------------
+int dmsa_traj_submap_gravity_estimate(const dmsa_traj_state* s, const double preint_pos_horizon[3], double gravity_imu_out[3]) {
+    if (!s || !preint_pos_horizon || !gravity_imu_out || s->num_control_poses < 3 || s->n_total < 2 || !s->stamps || !s->traj_time || !s->glob_orient || !s->glob_transl)
+        return DMSA_ERR_INVALID;
+    const int C = s->num_control_poses;
+    FloaterHormann2 fh;
+    if (!fh.build(s->stamps, C)) return DMSA_ERR_INVALID;
+    std::vector<double> y((size_t)C);
+    double d0[3], d1[3];
+    for (int a = 0; a < 3; ++a) {  // denseGlobalPoses.Translations.col(0 / 1): the interpolant of updateTrajDenseTforms at trajTime 0 / 1
+        for (int j = 0; j < C; ++j) y[(size_t)j] = s->glob_transl[3 * j + a];
+        d0[a] = fh.eval(y.data(), s->traj_time[0]), d1[a] = fh.eval(y.data(), s->traj_time[1]);
+    }
+    const double one_div_t_res = 1.0 / s->dt_res;
+    const Vec3 v_start_w = one_div_t_res * Vec3{d1[0] - d0[0], d1[1] - d0[1], d1[2] - d0[2]};
+    const Mat3 Rt = transposed(so3_exp(col3(s->glob_orient, 0)));
+    const Vec3 first = col3(s->glob_transl, 0), last = col3(s->glob_transl, C - 1);
+    const Vec3 inner = (last - first) - (s->horizon * v_start_w);
+    const Vec3 r = Rt * inner;
+    const double denom = 0.5 * std::pow(s->horizon, 2);
+    gravity_imu_out[0] = (r.x - preint_pos_horizon[0]) / denom, gravity_imu_out[1] = (r.y - preint_pos_horizon[1]) / denom,
+    gravity_imu_out[2] = (r.z - preint_pos_horizon[2]) / denom;
+    return DMSA_OK;
+}
+
 }  // extern "C"

@@ -189,6 +189,15 @@ class WindowSetup:
                "dmsa_traj_update_initial_guess")
         return bool(flag.value)
 
+    # :593-601
+    def getSubmapGravityEstimate(self, traj: TrajectoryState) -> np.ndarray:
+        """measuredGravity of a keyframe made from this window (needs updatePreintFactors and current GLOBAL control poses)."""
+        out = np.zeros(3)
+        cs = traj.to_c()
+        _check(self._lib.dmsa_traj_submap_gravity_estimate(C.byref(cs), capi.ptr(traj.preintPosComplHor, C.c_double), capi.ptr(out, C.c_double)),
+               "dmsa_traj_submap_gravity_estimate")
+        return out
+
     # :228-261 (the per-point search; runs on the device)
     def tformIdPerPoint(self, traj: TrajectoryState, pointStamps) -> np.ndarray:
         st = _f64(pointStamps)

@@ -10,6 +10,7 @@
  *   ContinuousTrajectory::updateInitialGuess      include/DMSA/ContinuousTrajectory.h:366-468
  *   ContinuousTrajectory::initGravityDir          include/DMSA/ContinuousTrajectory.h:263-299
  *   ContinuousTrajectory::getImuIntegratedParams  include/DMSA/ContinuousTrajectory.h:470-516
+ *   ContinuousTrajectory::getSubmapGravityEstimate include/DMSA/ContinuousTrajectory.h:593-601   (measuredGravity of a new keyframe)
  *   ImuPreintegration                             include/DMSA/ImuPreintegration.h:23-139
  *   ImuBuffer                                     include/DMSA/ImuBuffer.h:14-175
  *
@@ -93,6 +94,12 @@ typedef struct dmsa_traj_state {
  * (:370-379).  Later calls: interpolate the known part from `old` (slerp / barycentric rational of order 2), then predict the rest
  * by IMU integration (use_imu) or constant relative motion.  old's global poses are refreshed by relative2global (:382). */
 int dmsa_traj_update_initial_guess(int32_t* is_initialized, dmsa_traj_state* cur, dmsa_traj_state* old_traj, int32_t use_imu);
+
+/* ---- getSubmapGravityEstimate (:593-601), called by initializeMap / addNewKeyframeToMap (DmsaSlam.h:488-489, :533-534) -------------
+ * gravity_imu = (R(first orientation)^T * (last translation - first translation - v_start_w * horizon) - preintPosComplHor)
+ *               / (0.5 * horizon^2),   v_start_w = (denseTranslation(1) - denseTranslation(0)) / dt_res.
+ * Reads the GLOBAL control poses of `s` (glob_orient / glob_transl), stamps, traj_time, horizon, dt_res. */
+int dmsa_traj_submap_gravity_estimate(const dmsa_traj_state* s, const double preint_pos_horizon[3], double gravity_imu_out[3]);
 
 #ifdef __cplusplus
 }

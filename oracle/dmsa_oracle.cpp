@@ -2028,6 +2028,25 @@ int orc_traj_preint_factors(int32_t n_total, int32_t C, const int32_t* paramIndi
     for (int c = 0; c < 3; ++c) preintPosComplHor[c] = imuPreintegration.deltaPos[c];
     return DMSA_OK;
 }
+// getSubmapGravityEstimate :593-601
+int orc_traj_submap_gravity_estimate(const dmsa_traj_state* s, const double* preintPosComplHor, double* gravity_imu) {
+    const int C = s->num_control_poses;
+    double dense0[3], dense1[3];
+    for (int k = 0; k < 3; ++k) {
+        std::vector<double> tr((size_t)C);
+        for (int j = 0; j < C; ++j) tr[(size_t)j] = s->glob_transl[3 * (size_t)j + k];
+        BarycentricRational spline(s->stamps, tr.data(), C, 2);
+        dense0[k] = spline(s->traj_time[0]), dense1[k] = spline(s->traj_time[1]);
+    }
+    const double one_div_t_res = 1.0 / s->dt_res;
+    double v_start_w[3], inner[3], rot[3];
+    for (int c = 0; c < 3; ++c) v_start_w[c] = one_div_t_res * (dense1[c] - dense0[c]);
+    const M3 R_imu2w_start = axang2rotm(s->glob_orient);
+    for (int c = 0; c < 3; ++c) inner[c] = s->glob_transl[3 * (size_t)(C - 1) + c] - s->glob_transl[c] - v_start_w[c] * s->horizon;
+    matvec(transpose(R_imu2w_start), inner, rot);
+    for (int c = 0; c < 3; ++c) gravity_imu[c] = (rot[c] - preintPosComplHor[c]) / (0.5 * std::pow(s->horizon, 2));
+    return DMSA_OK;
+}
 // updateInitialGuess :366-468
 int orc_traj_update_initial_guess(int32_t* is_initialized, dmsa_traj_state* cur, dmsa_traj_state* old_traj, int32_t use_imu) {
     TrajSetupO c(cur);

@@ -115,6 +115,7 @@ int orc_traj_preint_factors(int32_t n_total, int32_t C, const int32_t* paramIndi
                             const double* gyr_cov, const double* acc_cov, double* preintImuRots, double* preintRelPositions, double* preintRelVelocity,
                             double* CovPVRot_inv, double* preintPosComplHor);
 int orc_traj_update_initial_guess(int32_t* is_initialized, dmsa_traj_state* cur, dmsa_traj_state* old_traj, int32_t use_imu);
+int orc_traj_submap_gravity_estimate(const dmsa_traj_state* s, const double* preintPosComplHor, double* gravity_imu);
 
 /* ---- wire formats (src/dmsa_slam_ros.cpp:374-486, OutputManagement.h:80-182) */
 int orc_decode_pointcloud2(const dmsa_pointcloud2* msg, int32_t sensor, float* xyz_out, double* stamp_out, int32_t* id_out);

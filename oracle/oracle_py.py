@@ -428,6 +428,13 @@ class WindowSetup:
             raise RuntimeError(f"orc_traj_update_initial_guess rc={rc}")
         return bool(flag.value)
 
+    def getSubmapGravityEstimate(self, traj):
+        self._L.orc_traj_submap_gravity_estimate.argtypes = [C.POINTER(capi.TrajState), capi.c_double_p, capi.c_double_p]
+        out = np.zeros(3)
+        cs = traj.to_c()
+        self._L.orc_traj_submap_gravity_estimate(C.byref(cs), capi.ptr(traj.preintPosComplHor, C.c_double), capi.ptr(out, C.c_double))
+        return out
+
     def tformIdPerPoint(self, traj, pointStamps):
         st = np.ascontiguousarray(pointStamps, np.float64)
         out = np.zeros(max(1, st.shape[0]), np.int32)

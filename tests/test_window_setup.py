@@ -298,3 +298,24 @@ def test_tform_indices_oracle_is_searchsorted(orcw):
         ref = np.minimum(np.searchsorted(s.trajTime, st - s.t0, side="left"), s.n_total - 1)
     ref[np.isnan(st)] = 0  # every comparison with NaN is false: lower_bound stays at the first element
     assert np.array_equal(got, ref)
+
+
+def test_submap_gravity_estimate(prod, orcw, orc):
+    """getSubmapGravityEstimate (:593-601): with the true poses and a clean IMU stream the estimate is gravity seen from the first
+    control pose, R0^T (0, 0, -9.805); product and oracle agree bit for bit."""
+    outs = []
+    for w, buf_cls in ((prod, ws.ImuBuffer), (orcw, orc.ImuBuffer)):
+        clouds, traj = synth.scan_sequence(seed=1, scans=5, rings=8, az_steps=64)
+        st, acc, ang = synth.imu_stream(traj, -0.3, 0.7, rate=1000.0)
+        buf = buf_cls(10000)
+        _fill(buf, st, acc, ang)
+        s = w.initTraj(min(c[1].min() for c in clouds), max(c[1].max() for c in clouds), 6, True, 1e-3)
+        w.transferImuMeasurements(s, buf)
+        w.updatePreintFactors(s, GYR_COV, ACC_COV)
+        R, p = traj.pose(s.t0 - 1.6e9 + s.stamps)
+        s.globOrientations[...], s.globTranslations[...] = R.as_rotvec(), p
+        outs.append((w.getSubmapGravityEstimate(s), R))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    g_est, R = outs[1]
+    assert np.allclose(g_est, R[0].inv().apply([0.0, 0.0, -9.805]), atol=0.15)
+    assert abs(np.linalg.norm(g_est) - 9.805) < 0.15  # the plausibility gate of addNewKeyframeToMap (DmsaSlam.h:536-539) would pass
