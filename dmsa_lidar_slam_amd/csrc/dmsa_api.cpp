@@ -879,9 +879,13 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
         double* errs = ctx->h_rb->errs;  // pinned
         {
             ScopedTimer tm(ctx, T_NORMAL);
-            HIPCHK(ctx->d_sq_partial.ensure((size_t)squared_sums_partial_doubles(rowsE, 9) * 8));
+            const bool blocked = (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0;
+            HIPCHK(ctx->d_sq_partial.ensure((size_t)std::max(squared_sums_partial_doubles(rowsE, 9), squared_sums_blocked_partial_doubles(rowsE, P, 9)) * 8));
             HIPCHK(ctx->d_sq_out.ensure(16 * 8));
-            launch_squared_sums(ctx->d_E.as<double>(), ctx->ldE, rowsE, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
+            if (blocked)
+                launch_squared_sums_blocked(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
+            else
+                launch_squared_sums(ctx->d_E.as<double>(), ctx->ldE, rowsE, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
         }
         HIPCHK(hipMemcpyAsync(errs, ctx->d_sq_out.p, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(sync_spin(ctx->stream));  // sync #4

@@ -146,5 +146,8 @@ void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, doub
 int normal_equations_partial_doubles(int rows, int P);
 void launch_squared_sums(const double* E, int64_t ldE, int rows, int B, double* partial, double* out, hipStream_t s);
 int squared_sums_partial_doubles(int rows, int B);
+// parity path: the same sums in the blocked row order of the normal equations (bit-identical to the oracle)
+void launch_squared_sums_blocked(const double* E, int64_t ldE, int rows, int P, int B, double* partial, double* out, hipStream_t s);
+int squared_sums_blocked_partial_doubles(int rows, int P, int B);
 
 }  // namespace dmsa

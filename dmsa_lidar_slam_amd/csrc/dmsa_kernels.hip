@@ -2574,6 +2574,31 @@ __global__ void k_squared_sums_reduce(const double* __restrict__ partial, int ns
     for (int sp = 0; sp < nsplit; ++sp) s += partial[(size_t)b * nsplit + sp];
     out[b] = s;
 }
+// Parity path: e^T e of every evaluation in the blocked order of the normal equations (blocks of ne_rows_per_split(rows, P)
+// consecutive rows summed row by row, block sums added in order) -- the order the oracle states, so that the line search compares
+// bit-identical numbers.
+__global__ __launch_bounds__(64) void k_squared_sums_blocked(const double* __restrict__ E, int64_t ldE, int rows, int rs, int nsplit,
+                                                             double* __restrict__ partial) {
+    const int sp = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (sp >= nsplit) return;
+    const int r_end = min(rows, (sp + 1) * rs);
+    double s = 0.0;
+    for (int r = sp * rs; r < r_end; ++r) {
+        const double v = E[(size_t)b * ldE + r];
+        s += v * v;
+    }
+    partial[(size_t)b * nsplit + sp] = s;
+}
+int squared_sums_blocked_partial_doubles(int rows, int P, int B) {
+    const int rs = ne_rows_per_split(rows, P);
+    return ((rows + rs - 1) / rs) * B;
+}
+void launch_squared_sums_blocked(const double* E, int64_t ldE, int rows, int P, int B, double* partial, double* out, hipStream_t s) {
+    const int rs = ne_rows_per_split(rows, P);
+    const int nsplit = (rows + rs - 1) / rs;
+    hipLaunchKernelGGL(k_squared_sums_blocked, dim3((nsplit + 63) / 64, B), dim3(64), 0, s, E, ldE, rows, rs, nsplit, partial);
+    hipLaunchKernelGGL(k_squared_sums_reduce, dim3((B + 63) / 64), dim3(64), 0, s, partial, nsplit, B, out);
+}
 void launch_squared_sums(const double* E, int64_t ldE, int rows, int B, double* partial, double* out, hipStream_t s) {
     const int nsplit = (rows + kSqRows - 1) / kSqRows;
     hipLaunchKernelGGL(k_squared_sums_partial, dim3(nsplit, B), dim3(256), 0, s, E, ldE, rows, partial);

@@ -501,8 +501,10 @@ __device__ __forceinline__ void pcl_roots(const float* m /* row-major 3x3 */, fl
     float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
     if (q > 0.0f) q = 0.0f;
     const float rho = sqrtf(-a_over_3);
-    const float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
-    const float cos_theta = cosf(theta), sin_theta = sinf(theta);
+    // float atan2 / cos / sin as a correctly rounded libm returns them: evaluated in double, rounded once (glibc's sinf / cosf work
+    // the same way; device and host double functions agree after the rounding, so normals are reproducible across the two)
+    const float theta = (float)atan2((double)sqrtf(-q), (double)half_b) * s_inv3;
+    const float cos_theta = (float)cos((double)theta), sin_theta = (float)sin((double)theta);
     roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
     roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);

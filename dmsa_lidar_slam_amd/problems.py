@@ -291,3 +291,54 @@ class MapManagement:
         n = toId - fromId + 1
         self.relTranslations[fromId + 1:fromId + n] = submap.relTranslations[1:n]
         self.relOrientations[fromId + 1:fromId + n] = submap.relOrientations[1:n]
+
+    @staticmethod
+    def addKeyframe(keyframeMap: "MapManagement | None", position_w, orient_w, localPoints, localNormals, ringIds, gridSize: float,
+                    measuredGravity=None, gravityPlausible: bool = True, maxNumKeyframes: int = 256, **settings) -> "MapManagement":
+        """MapManagement::addKeyframe (MapManagement.h:311-390) as a pure function: the map with one more keyframe at the GLOBAL pose
+        (position_w, orient_w).  Relative poses are re-derived from the global ones (global2relative, :337), the new frame's odometry
+        measurement is its own relative pose (:339-355), a full ring buffer drops its oldest frame (:323-335), minGridSize follows the
+        smallest keyframe gridSize.  `settings` (useOdometryErrorTerms, balancingFactorOdom, ...) apply when the map is created."""
+        from .posemath import global2relative, relative2global
+
+        pts, nrm = _xyz4(localPoints), np.asarray(localNormals, np.float32)
+        pts[:, 3] = 1.0  # :357-358
+        ids = np.ascontiguousarray(ringIds, np.int32)
+        pos, ori = _f64(position_w, (3,)), _f64(orient_w, (3,))
+        grav = np.zeros(3) if measuredGravity is None else _f64(measuredGravity, (3,))
+        if keyframeMap is None:
+            go, gt = ori[None, :], pos[None, :]
+            offsets = np.array([0, pts.shape[0]], np.int64)
+            cloud, normals, rings = pts, nrm, ids
+            mg, gp = grav[None, :], np.array([int(gravityPlausible)], np.int32)
+            odom_t, odom_R, grid = np.zeros((0, 3)), np.zeros((0, 3, 3)), float(gridSize)
+            base = dict(settings)
+        else:
+            m = keyframeMap
+            go, gt = relative2global(m.relOrientations, m.relTranslations)  # :313
+            first = 1 if m.numFrames >= maxNumKeyframes else 0               # full ring buffer: the oldest keyframe leaves
+            a = int(m.frameOffsets[first])
+            go, gt = np.vstack([go[first:], ori]), np.vstack([gt[first:], pos])
+            offsets = np.concatenate([m.frameOffsets[first:] - a, [m.frameOffsets[-1] - a + pts.shape[0]]]).astype(np.int64)
+            cloud, normals, rings = np.vstack([m.localPoints[a:], pts]), np.vstack([m.localNormals[a:], _pad4(nrm)]), np.concatenate([m.ringIds[a:], ids])
+            z3, z33 = np.zeros((m.numFrames, 3)), np.tile(np.eye(3), (m.numFrames, 1, 1))
+            mg = np.vstack([(m.measuredGravity if m.measuredGravity is not None else z3)[first:], grav])
+            gp = np.concatenate([(m.gravityPlausible if m.gravityPlausible is not None else np.ones(m.numFrames, np.int32))[first:], [int(gravityPlausible)]]).astype(np.int32)
+            odom_t, odom_R = (m.odomRelTransl if m.odomRelTransl is not None else z3)[first:], (m.odomRelOrientMat if m.odomRelOrientMat is not None else z33)[first:]
+            grid = min(float(m.minGridSize), float(gridSize))
+            base = dict(useGravityErrorTerms=m.useGravityErrorTerms, useOdometryErrorTerms=m.useOdometryErrorTerms, gravity=m.gravity, Cov_grav_inv=m.Cov_grav_inv,
+                        balancingFactorGrav=m.balancingFactorGrav, balancingFactorOdom=m.balancingFactorOdom, odometryTranslCovInv=m.odometryTranslCovInv,
+                        odometryOrientCovInv=m.odometryOrientCovInv)
+        ro, rt = global2relative(go, gt)  # :337
+        from scipy.spatial.transform import Rotation as Rot
+
+        odom_t = np.vstack([odom_t, rt[-1]])                                              # relativeTransl (:344 / :351)
+        odom_R = np.concatenate([odom_R, Rot.from_rotvec(ro[-1]).as_matrix()[None]])      # relativeOrientMat = axang2rotm(relativeOrient) (:347)
+        return MapManagement(relOrientations=ro, relTranslations=rt, frameOffsets=offsets, localPoints=cloud, localNormals=_pad4(normals), ringIds=rings,
+                             minGridSize=grid, measuredGravity=mg, gravityPlausible=gp, odomRelTransl=odom_t, odomRelOrientMat=odom_R, **base)
+
+
+def _pad4(a):
+    a = np.asarray(a, np.float32)
+    return a if a.shape[1] == 4 else np.concatenate([a, np.zeros((a.shape[0], 1), np.float32)], axis=1)
+

@@ -20,7 +20,7 @@ from dmsa_lidar_slam_amd import window_setup as ws  # noqa: E402
 from dmsa_lidar_slam_amd import wire_formats as wf  # noqa: E402
 from dmsa_lidar_slam_amd.api import DmsaOptimizer  # noqa: E402
 from dmsa_lidar_slam_amd.keyframe_cloud import KeyframeCloudBuilder  # noqa: E402
-from dmsa_lidar_slam_amd.problems import DmsaOptimSettings  # noqa: E402
+from dmsa_lidar_slam_amd.problems import DmsaOptimSettings, MapManagement  # noqa: E402
 from dmsa_lidar_slam_amd.static_points import StaticPointSelector, StaticSelectProblem  # noqa: E402
 
 f32 = np.float32
@@ -47,6 +47,7 @@ class GpuBackend:
 
     def __init__(self, parity: bool = False):
         self.optimizer = DmsaOptimizer(device=0, pose_table_host=parity, mirror_sums=parity)
+        self.kf_optimizer = DmsaOptimizer(device=0, pose_table_host=parity, mirror_sums=parity)  # keyframeMapOptimizer (DmsaSlam.h:53)
         self.decoder = wf.PointCloud2Decoder("ouster")
         self.scan_filter = StaticPointSelector(0)                      # preProcess works on raw scans: its own context
         self.static = StaticPointSelector(optimizer=self.optimizer)     # these two share the optimizer's context: the window cloud
@@ -54,7 +55,7 @@ class GpuBackend:
         self.setup = ws.WindowSetup(0)
 
     def close(self):
-        for o in (self.decoder, self.scan_filter, self.static, self.setup, self.kf_builder, self.optimizer):
+        for o in (self.decoder, self.scan_filter, self.static, self.setup, self.kf_builder, self.optimizer, self.kf_optimizer):
             o.close()
 
     def decode(self, msg):
@@ -78,6 +79,9 @@ class GpuBackend:
     def optimizeSet(self, prob, settings):
         return self.optimizer.optimizeSet(prob, settings)
 
+    def optimizeKeyframes(self, submap, settings):
+        return self.kf_optimizer.optimizeSet(submap, settings)
+
     def keyframeCloud(self, prob, pos0, orient0, seed):
         # the optimised window is still resident (final updateGlobalPoints of optimizeSet, DmsaOptimizer.h:149)
         xyz, nrm, ring, _ = self.kf_builder.addNewKeyframeCloud(None, None, prob.minGridSize, seed, pos0, orient0, numResident=prob.localPoints.shape[0])
@@ -89,27 +93,36 @@ class GpuBackend:
 
 class MiniSlam:
     def __init__(self, backend=None, n_clouds=5, num_control_poses=6, dt_res=1e-3, max_points_per_scan=3000, min_overlap_new_keyframe=0.7, dist_new_keyframe=1.0,
-                 seed=7, num_iter=5):
+                 seed=7, num_iter=5, num_iter_keyframe_optim=0):
         self.be = backend or GpuBackend()
+        self.kf_iters = num_iter_keyframe_optim  # > 0: keyframeOptimization after every new keyframe (DmsaSlam.h:181-184, :212-238)
         self.n_clouds, self.C, self.dt_res, self.max_pts, self.seed, self.num_iter = n_clouds, num_control_poses, dt_res, max_points_per_scan, seed, num_iter
         self.min_overlap, self.dist_kf = min_overlap_new_keyframe, dist_new_keyframe
         self.buffer, self.old_traj, self.initialized = [], None, False
-        self.keyframes = []   # dicts: pos, orient, xyz (local), normal (local), ring
+        self.map = None       # MapManagement: the keyframe map
         self.lines, self.log = [], []
 
     def close(self):
         self.be.close()
 
-    @staticmethod
-    def _keyframe_global(kf):
-        """getGlobalKeyframeCloud (MapManagement.h:290-299): float transform of points and normals of one keyframe."""
+    @property
+    def keyframes(self):
+        return 0 if self.map is None else self.map.numFrames
+
+    def _keyframe_poses(self):
+        return posemath.relative2global(self.map.relOrientations, self.map.relTranslations)
+
+    def _map_global(self):
+        """getGlobalKeyframeCloud (MapManagement.h:290-299) for every keyframe: float transform of points and normals."""
         from scipy.spatial.transform import Rotation as Rot
 
-        R = Rot.from_rotvec(kf["orient"]).as_matrix().astype(f32)
-        xyz = kf["xyz"].copy()
-        xyz[:, :3] = (kf["xyz"][:, :3] @ R.T + kf["pos"].astype(f32)).astype(f32)
-        nrm = kf["normal"].copy()
-        nrm[:, :3] = (np.nan_to_num(kf["normal"][:, :3]) @ R.T).astype(f32)
+        go, gt = self._keyframe_poses()
+        xyz, nrm = self.map.localPoints.copy(), self.map.localNormals.copy()
+        for k in range(self.map.numFrames):
+            a, b = int(self.map.frameOffsets[k]), int(self.map.frameOffsets[k + 1])
+            R = Rot.from_rotvec(go[k]).as_matrix().astype(f32)
+            xyz[a:b, :3] = (self.map.localPoints[a:b, :3] @ R.T + gt[k].astype(f32)).astype(f32)
+            nrm[a:b, :3] = (np.nan_to_num(self.map.localNormals[a:b, :3]) @ R.T).astype(f32)
         return xyz, nrm
 
     def process(self, msg, first_pose=None):
@@ -128,13 +141,9 @@ class MiniSlam:
         settings = DmsaOptimSettings.sliding_window(use_imu=False, num_iter=self.num_iter)
         overlap = 0.0
         if self.keyframes:  # addStaticPoints against the (here: all) keyframes
-            kx, kn, kr, off = [], [], [], [0]
-            for kf in self.keyframes:
-                gx, gn = self._keyframe_global(kf)
-                kx.append(gx), kn.append(gn), kr.append(kf["ring"]), off.append(off[-1] + gx.shape[0])
+            kx, kn = self._map_global()
             go, gt = posemath.relative2global(prob.relOrientations, prob.relTranslations)
-            active, active_ids, overlap = self.be.addStaticPoints(prob, np.concatenate(kx), np.concatenate(kn), np.concatenate(kr), np.array(off, np.int64),
-                                                                  gt[0].astype(f32), self.seed)
+            active, active_ids, overlap = self.be.addStaticPoints(prob, kx, kn, self.map.ringIds, self.map.frameOffsets, gt[0].astype(f32), self.seed)
             prob.staticPoints, prob.staticRingIds = active, active_ids
         rep = self.be.optimizeSet(prob, settings)
         traj.relOrientations[...], traj.relTranslations[...] = prob.relOrientations, prob.relTranslations
@@ -142,13 +151,23 @@ class MiniSlam:
         go, gt = posemath.relative2global(prob.relOrientations, prob.relTranslations)
         self.lines.append(self.be.tumLine(traj.t0, gt[0], go[0]))
         # keyframe decision (DmsaSlam.h:170-186)
-        need = not self.keyframes or overlap < self.min_overlap or np.linalg.norm(gt[0] - self.keyframes[-1]["pos"]) > self.dist_kf
+        need = not self.keyframes or overlap < self.min_overlap or np.linalg.norm(gt[0] - self._keyframe_poses()[1][-1]) > self.dist_kf
+        kf_rep = None
         if need:
             kxyz, knrm, kring = self.be.keyframeCloud(prob, gt[0], go[0], self.seed)
-            self.keyframes.append({"pos": gt[0].copy(), "orient": go[0].copy(), "xyz": kxyz, "normal": knrm, "ring": kring})
+            self.map = MapManagement.addKeyframe(self.map, gt[0], go[0], kxyz, knrm, kring, prob.minGridSize, useOdometryErrorTerms=True)
+            if self.kf_iters > 0 and self.map.numFrames >= 3:  # keyframeOptimization(fromId = 0, KeyframeMap)
+                last = self.map.numFrames - 1
+                sub = self.map.getSubmap(0, last)
+                kf_rep = self.be.optimizeKeyframes(sub, DmsaOptimSettings.keyframe_map(num_iter=self.kf_iters))
+                self.map.updatePosesFromSubmap(0, last, sub)
+                kgo, kgt = self._keyframe_poses()
+                traj.relOrientations[0], traj.relTranslations[0] = kgo[-1], kgt[-1]  # "update curr trajectory" (:233-237)
         self.log.append({"t0": traj.t0, "pos": gt[0].copy(), "orient": go[0].copy(), "iterations": rep.iterations, "gaussians": rep.num_gaussians,
-                         "static": int(prob.staticPoints.shape[0]), "overlap": float(overlap), "keyframes": len(self.keyframes),
-                         "rel": (prob.relOrientations.copy(), prob.relTranslations.copy())})
+                         "static": int(prob.staticPoints.shape[0]), "overlap": float(overlap), "keyframes": self.keyframes,
+                         "rel": (prob.relOrientations.copy(), prob.relTranslations.copy()),
+                         "keyframe_opt": None if kf_rep is None else (kf_rep.iterations, kf_rep.num_gaussians),
+                         "map_rel": (self.map.relOrientations.copy(), self.map.relTranslations.copy())})
 
 
 def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, **slam_args):
@@ -165,7 +184,7 @@ def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, **slam_args):
     for e in slam.log:
         _, p = truth.pose(np.array([e["t0"] - 1.6e9]))
         errs.append(float(np.linalg.norm(e["pos"] - p[0])))
-    out = {"windows": len(slam.log), "keyframes": len(slam.keyframes), "max_position_error_m": max(errs) if errs else None, "log": slam.log, "tum": slam.lines}
+    out = {"windows": len(slam.log), "keyframes": slam.keyframes, "max_position_error_m": max(errs) if errs else None, "log": slam.log, "tum": slam.lines}
     slam.close()
     return out
 
@@ -173,10 +192,12 @@ def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, **slam_args):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=14)
+    ap.add_argument("--keyframe-dist", type=float, default=0.25, help="dist_new_keyframe [m]")
+    ap.add_argument("--keyframe-iters", type=int, default=3, help="num_iter_keyframe_optim (0 = no keyframe optimisation)")
     a = ap.parse_args()
-    r = run(a.scans)
+    r = run(a.scans, dist_new_keyframe=a.keyframe_dist, num_iter_keyframe_optim=a.keyframe_iters)
     for e in r["log"]:
         print(f"t0={e['t0']:.3f} pos=({e['pos'][0]:.3f} {e['pos'][1]:.3f} {e['pos'][2]:.3f}) iters={e['iterations']} M={e['gaussians']} static={e['static']} "
-              f"overlap={e['overlap']:.2f} keyframes={e['keyframes']}")
+              f"overlap={e['overlap']:.2f} keyframes={e['keyframes']} keyframe_opt={e['keyframe_opt']}")
     print("".join(r["tum"]), end="")
     print(f"windows={r['windows']} keyframes={r['keyframes']} max |position error| = {r['max_position_error_m']:.3f} m")

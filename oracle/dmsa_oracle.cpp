@@ -951,6 +951,31 @@ static bool invert_dense(std::vector<double> A /* col-major PxP */, int P, std::
     return true;
 }
 
+// Summation order of H = J^T J, g = J^T e and e^T e (DmsaOptimizer.h:101-113).  The reference computes them with Eigen's blocked,
+// vectorised (and up to 4-thread) GEMM / GEMV / dot, whose order cannot be known; this restatement fixes one that is easy to state
+// and easy to parallelise: rows are cut into consecutive blocks of reduction_block_rows(rows, P), every block is summed row by
+// row, the block sums are added in order.  (The HIP kernels use the same rule, so the two agree to the last bit.)
+static int reduction_block_rows(int rows, int P) {
+    int rs = 256;
+    if (P > 64) {
+        const int want = (rows + 31) / 32;
+        rs = ((want + 31) / 32) * 32;
+        if (rs < 256) rs = 256;
+    }
+    return rs;
+}
+template <typename Term>
+static double blocked_sum(int rows, int P, Term term) {
+    const int rs = reduction_block_rows(rows, P);
+    double total = 0.0;
+    for (int r0 = 0; r0 < rows; r0 += rs) {
+        double s = 0.0;
+        for (int r = r0; r < std::min(rows, r0 + rs); ++r) s += term(r);
+        total += s;
+    }
+    return total;
+}
+
 static void lm_step(const double* e0, const double* J /* col-major rows x P */, int rows, int P, double lambda, double alpha,
                     std::vector<double>& H, std::vector<double>& g, std::vector<double>& step) {
     H.assign((size_t)P * P, 0.0);
@@ -959,13 +984,10 @@ static void lm_step(const double* e0, const double* J /* col-major rows x P */, 
         const double* Ji = J + (size_t)i * rows;
         for (int j = i; j < P; ++j) {
             const double* Jj = J + (size_t)j * rows;
-            double s = 0.0;
-            for (int r = 0; r < rows; ++r) s += Ji[r] * Jj[r];
+            const double s = blocked_sum(rows, P, [&](int r) { return Ji[r] * Jj[r]; });
             H[(size_t)j * P + i] = s, H[(size_t)i * P + j] = s;
         }
-        double s = 0.0;
-        for (int r = 0; r < rows; ++r) s += Ji[r] * e0[r];
-        g[(size_t)i] = s;
+        g[(size_t)i] = blocked_sum(rows, P, [&](int r) { return Ji[r] * e0[r]; });
     }
     for (int i = 0; i < P; ++i) H[(size_t)i * P + i] += lambda;  // :110
     std::vector<double> Hinv;
@@ -1021,6 +1043,10 @@ struct Optimizer {
         double s = 0.0;
         for (double v : a) s += v * v;
         return s;
+    }
+    // e^T e in the blocked order of the normal equations (see reduction_block_rows)
+    static double dotRows(const std::vector<double>& a, int P) {
+        return blocked_sum((int)a.size(), P, [&](int r) { return a[(size_t)r] * a[(size_t)r]; });
     }
     // :199-232
     void calcNumericJacobian(std::vector<double>& error0, PointSet& set) {
@@ -1081,7 +1107,7 @@ struct Optimizer {
                     mine->setPoseParameters(tp);
                     mine->updateGlobalPoints();
                     evalOn(*mine, ev);
-                    trialError[k] = dot(ev);
+                    trialError[k] = dotRows(ev, (int)raw.size());
                 }
             }
             evaluations += 8;
@@ -1095,7 +1121,7 @@ struct Optimizer {
                 set.setPoseParameters(test);
                 set.updateGlobalPoints();
                 updateErrorTerms(set, errorVec);
-                errorTest = dot(errorVec);
+                errorTest = dotRows(errorVec, (int)raw.size());
             } else {
                 errorTest = trialError[k];
             }
@@ -1138,7 +1164,7 @@ struct Optimizer {
             }
             currentGauss.updateRebalancingWeights();
             updateErrorTerms(set, errorVec);
-            error0 = dot(errorVec);
+            error0 = dotRows(errorVec, (int)paramVec.size());
             calcNumericJacobian(errorVec, set);
             const int P = (int)paramVec.size(), rows = (int)errorVec.size();
             std::vector<double> H, g;
@@ -2217,9 +2243,10 @@ static void pclComputeRoots(const float m[3][3], float* roots) {
     float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
     if (q > 0.0f) q = 0.0f;
     const float rho = std::sqrt(-a_over_3);
-    const float theta = std::atan2(std::sqrt(-q), half_b) * s_inv3;
-    const float cos_theta = std::cos(theta);
-    const float sin_theta = std::sin(theta);
+    // std::atan2 / cos / sin on floats, stated as their correctly rounded values (double evaluation, one rounding)
+    const float theta = (float)std::atan2((double)std::sqrt(-q), (double)half_b) * s_inv3;
+    const float cos_theta = (float)std::cos((double)theta);
+    const float sin_theta = (float)std::sin((double)theta);
     roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
     roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);

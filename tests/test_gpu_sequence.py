@@ -72,6 +72,10 @@ class OracleBackend:
         rep, _, _ = self.orc.optimize_window(prob, settings)
         return rep
 
+    def optimizeKeyframes(self, submap, settings):
+        rep, _, _ = self.orc.optimize_keyframes(submap, settings)
+        return rep
+
     def keyframeCloud(self, prob, pos0, orient0, seed):
         xyz, nrm, ring, _ = self.orc.make_keyframe_cloud(self._window_global(prob), prob.ringIds, prob.minGridSize, seed, pos0, orient0)
         return xyz, nrm, ring
@@ -95,6 +99,29 @@ def test_full_sequence_trajectory_matches_the_oracle(orc):
         assert a["overlap"] == b["overlap"]
         worst_r = max(worst_r, float(np.abs(a["rel"][0] - b["rel"][0]).max()))
         worst_t = max(worst_t, float(np.abs(a["rel"][1] - b["rel"][1]).max()))
-    assert worst_t < 1e-4 and worst_r < 1e-4, (worst_t, worst_r)
+    assert worst_t < 1e-4 and worst_r < 1e-4, (worst_t, worst_r)  # BASELINE.json's bar
+    assert worst_t < 1e-12 and worst_r < 1e-12, (worst_t, worst_r)  # what the shared reduction order actually gives: 0
     assert g["tum"] == o["tum"]
     print(f"full-sequence difference: {worst_t:.2e} m, {worst_r:.2e} rad over {g['windows']} windows")
+
+
+def test_full_sequence_with_keyframe_optimisation(orc):
+    """The same with a keyframe every 0.25 m and keyframeOptimization (gauss_split, odometry rows) after every new keyframe: the
+    keyframe pass runs on clouds and normals produced by the library itself.  Same decisions, bit-identical poses."""
+    import sequence_demo
+
+    args = dict(scans=14, rings=32, az_steps=256, num_iter=3, dist_new_keyframe=0.25, num_iter_keyframe_optim=2)
+    g = sequence_demo.run(backend=sequence_demo.GpuBackend(parity=True), **args)
+    o = sequence_demo.run(backend=OracleBackend(orc), **args)
+    assert g["windows"] == o["windows"] == 10 and g["keyframes"] == o["keyframes"] >= 3
+    assert any(e["keyframe_opt"] is not None for e in g["log"])
+    worst = 0.0
+    for a, b in zip(g["log"], o["log"]):
+        assert (a["iterations"], a["gaussians"], a["static"], a["keyframes"], a["keyframe_opt"]) == (b["iterations"], b["gaussians"], b["static"], b["keyframes"], b["keyframe_opt"])
+        worst = max(worst, float(np.abs(a["rel"][0] - b["rel"][0]).max()), float(np.abs(a["rel"][1] - b["rel"][1]).max()))
+        worst = max(worst, float(np.abs(a["map_rel"][0] - b["map_rel"][0]).max()), float(np.abs(a["map_rel"][1] - b["map_rel"][1]).max()))
+    assert worst < 1e-4, worst  # BASELINE.json's bar
+    assert worst < 1e-12, worst  # actual: 0
+    assert g["max_position_error_m"] < 0.25
+    print(f"full-sequence difference with keyframe optimisation: {worst:.2e} over {g['windows']} windows, {g['keyframes']} keyframes")
+
