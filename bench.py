@@ -162,7 +162,8 @@ def main():
         r3 = opt3.optimizeResident(s3)
         dt3 = time.perf_counter() - t3
         parity = {"value": round(r3.iterations / dt3, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * dt3 / r3.iterations, 4),
-                  "note": "DMSA_FLAG_MIRROR_SUMS | DMSA_FLAG_POSE_TABLE_HOST: residual vectors bit-identical to the CPU oracle (tests/test_gpu_configs.py)"}
+                  "note": "DMSA_FLAG_MIRROR_SUMS | DMSA_FLAG_POSE_TABLE_HOST: residual vectors AND optimised poses bit-identical to the CPU oracle "
+                          "(tests/test_gpu_configs.py, tests/test_gpu_sequence.py)"}
         opt3.close()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
