@@ -271,3 +271,30 @@ def test_additional_error_rows_bit_exact(orc):
     g.upload(w0)
     assert g.getAdditionalErrorTerms().shape == (0,)
     g.close()
+
+
+@pytest.mark.parametrize("case", ["window_static", "window_imu", "rosette", "keyframes_split", "keyframes_p72"])
+def test_parity_path_trajectories_bit_identical(orc, case):
+    """Serial-order sums, host pose tables and the shared reduction order of the normal equations: the parity path returns the
+    oracle's poses bit for bit (not just within 1e-4), iteration counts, Gaussian counts and line-search decisions included."""
+    from dmsa_lidar_slam_amd.api import DmsaOptimizer
+
+    if case == "window_static":
+        p, s, run = synth.window_problem(seed=6, scans=4, rings=32, az_steps=256, num_static=4000), DmsaOptimSettings.sliding_window(num_iter=4), orc.optimize_window
+    elif case == "window_imu":
+        p, s, run = synth.window_problem(seed=7, scans=5, rings=16, az_steps=256, num_static=1500, use_imu=True), DmsaOptimSettings.sliding_window(use_imu=True, num_iter=4), orc.optimize_window
+    elif case == "rosette":
+        p, s, run = synth.rosette_window_problem(seed=2, scans=4, pts_per_scan=6000, num_static=3000), DmsaOptimSettings.sliding_window(num_iter=4), orc.optimize_window
+    elif case == "keyframes_split":
+        p, s, run = synth.keyframe_problem(seed=3, frames=6, rings=16, az_steps=160, arc=0.4), DmsaOptimSettings.keyframe_map(num_iter=4), orc.optimize_keyframes
+    else:  # 13 frames: P = 72 > 64 takes the other branch of the block-size rule
+        p, s, run = synth.keyframe_problem(seed=4, frames=13, rings=16, az_steps=96, arc=0.8), DmsaOptimSettings.keyframe_map(num_iter=3), orc.optimize_keyframes
+    a, b = p.copy(), p.copy()
+    g = DmsaOptimizer(device=0, pose_table_host=True, mirror_sums=True)
+    ra, tr_a = g.optimizeSet(a, s), g.trace()
+    g.close()
+    rb, _, tr_b = run(b, s)
+    assert (ra.iterations, ra.stop_reason, ra.num_gaussians, ra.num_memberships, ra.evaluations) == (rb.iterations, rb.stop_reason, rb.num_gaussians, rb.num_memberships, rb.evaluations)
+    assert [(t["M"], t["Mm"], t["best_k"], t["error0"], t["step_norm"]) for t in tr_a[: ra.iterations]] == [(t["M"], t["Mm"], t["best_k"], t["error0"], t["step_norm"]) for t in tr_b[: rb.iterations]]
+    assert np.array_equal(a.relOrientations, b.relOrientations) and np.array_equal(a.relTranslations, b.relTranslations)
+    assert ra.iterations >= 2
