@@ -193,6 +193,7 @@ struct dmsa_ctx {
     int depth_guess[2] = {-1, -1};   // tree depths of the previous voxelisation (speculation: saves one host sync)
     int bits_guess[2] = {-1, -1};    // leaf-code widths of the previous voxelisation
     bool compress_keys = true;       // drop the constant high key bits before sorting (DMSA_KEY_COMPRESS=0 disables)
+    bool overlap_batch = true;       // host math of the Jacobian batch while the GPU voxelises (DMSA_OVERLAP_BATCH=0 disables)
     int merge_sort = -1;             // -1: by size; DMSA_MERGE_SORT=0/1 forces two sorts / one sort of both levels
     double level_res[2] = {0, 0};
     // Gaussians
@@ -662,14 +663,18 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                              ctx->d_tiles.as<TileDesc>(), reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
                              ctx->d_info12.as<float>(), ctx->stream);
         const int M_all = h.level[0].num_gauss + h.level[1].num_gauss;
-        if (!tiles_on && (ctx->flags & DMSA_FLAG_MIRROR_SUMS) && mirror_uses_rows() && M_all > 0) {
-            // parity path: order the Gaussians by size once (radix sort of M keys), then one row-cooperative fit for both levels
-            launch_gauss_size_keys(ctx->d_seg_off.as<int32_t>(), M_all, ctx->d_order_key.as<uint32_t>(), ctx->d_order_val.as<uint32_t>(), ctx->stream);
-            HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_order_key.as<uint32_t>(), ctx->d_order_key_s.as<uint32_t>(),
-                                      ctx->d_order_val.as<uint32_t>(), ctx->d_order.as<uint32_t>(), (size_t)M_all, 32, ctx->stream));
-            launch_gauss_fit_mirror_rows(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(), ctx->d_order.as<uint32_t>(), M_all,
-                                         ctx->d_info12.as<float>(), ctx->stream);
-            ctx->order_valid = true;
+        if (!tiles_on && (ctx->flags & DMSA_FLAG_MIRROR_SUMS) && M_all > 0) {
+            // parity path: order the Gaussians by size once (radix sort of M keys; the row-cooperative residual kernel wants the long
+            // chains first), then one fit for both levels in the oracle's blocked summation order
+            const bool ordered = mirror_uses_rows();
+            if (ordered) {
+                launch_gauss_size_keys(ctx->d_seg_off.as<int32_t>(), M_all, ctx->d_order_key.as<uint32_t>(), ctx->d_order_val.as<uint32_t>(), ctx->stream);
+                HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_order_key.as<uint32_t>(), ctx->d_order_key_s.as<uint32_t>(),
+                                          ctx->d_order_val.as<uint32_t>(), ctx->d_order.as<uint32_t>(), (size_t)M_all, 32, ctx->stream));
+            }
+            launch_gauss_fit_blocked(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(),
+                                     ordered ? ctx->d_order.as<uint32_t>() : nullptr, M_all, ctx->d_info12.as<float>(), ctx->stream);
+            ctx->order_valid = ordered;
         }
         if (!early_fit)
             launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
@@ -807,11 +812,12 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             chain(ctx).set_params(origin.data());  // :231
             return build_tables(ctx, 1 + P, globs);
         };
-        // Fast path: the batch does not depend on the Gaussians, so its host math and pose-table kernel are issued while
-        // the GPU is still voxelising (table 0 of the batch equals the base table the fit reads).  The parity path keeps
-        // the reference's order of operations.
-        const bool overlap = !(ctx->flags & DMSA_FLAG_MIRROR_SUMS);
+        // The batch does not depend on the Gaussians, so its host math (on the parity path: 1 + P libm pose tables) and the
+        // pose-table upload / kernel are issued while the GPU is still voxelising (table 0 of the batch equals the base table the
+        // fit reads).  The host-side order of evaluations is the reference's either way; only the early exit below has to undo it.
+        const bool overlap = ctx->overlap_batch;
         const int evals_before = ctx->evaluations;
+        const PoseChain chain_before = chain(ctx);  // exact undo, incl. the pose-0 round trip updateImuError leaves behind
         if (overlap)
             CHK(build_gaussians(ctx, s, jacobian_batch));  // :78-86, :96
         else
@@ -821,8 +827,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             stop = DMSA_STOP_FEW_GAUSSIANS;
             if (overlap) {  // undo the speculative batch: the reference had not evaluated anything in this iteration
                 ctx->evaluations = evals_before;
-                chain(ctx).set_params(paramVec.data());
-                chain(ctx).relative_to_global();
+                chain(ctx) = chain_before;
             }
             break;
         }
@@ -954,6 +959,7 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     if (const char* e = std::getenv("DMSA_K4_BIG")) ctx->cfg_big_n = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("DMSA_K4_TILES")) ctx->use_tiles = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_KEY_COMPRESS")) ctx->compress_keys = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DMSA_OVERLAP_BATCH")) ctx->overlap_batch = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_DUAL_STREAM")) ctx->dual_stream = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_MERGE_SORT")) ctx->merge_sort = std::atoi(e) != 0 ? 1 : 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||

@@ -118,8 +118,8 @@ void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t
 // parity path (DMSA_FLAG_MIRROR_SUMS), row-cooperative kernels: Gaussians sorted by size, one fit launch for both levels
 bool mirror_uses_rows();  // false with DMSA_MIRROR_THREADS=1 (first-generation thread-per-Gaussian kernels)
 void launch_gauss_size_keys(const int32_t* seg_off, int M, uint32_t* key, uint32_t* val, hipStream_t s);
-void launch_gauss_fit_mirror_rows(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const uint32_t* order, int M, float* info12,
-                                  hipStream_t s);
+// parity path: fit of all M Gaussians in the oracle's blocked summation order (order = Gaussians by descending size, or nullptr)
+void launch_gauss_fit_blocked(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const uint32_t* order, int M, float* info12, hipStream_t s);
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
                       const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s, bool pairs = false,
                       const uint32_t* order = nullptr /* parity path: Gaussians by descending size */);

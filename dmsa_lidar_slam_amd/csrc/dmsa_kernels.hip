@@ -1159,37 +1159,92 @@ __global__ __launch_bounds__(256) void k_gauss_fit(const int32_t* __restrict__ s
     }
 }
 
-// Mirror variant: one thread per Gaussian, sums in member order exactly like the CPU restatement (bit-reproducible).
-__global__ __launch_bounds__(256) void k_gauss_fit_mirror(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
-                                                          const float4* __restrict__ global, const GaussCounts* __restrict__ counts, int level,
-                                                          float* __restrict__ info12) {
-    const int gbase = level == 0 ? 0 : counts->level[0].num_gauss;
-    const int gend = gbase + counts->level[level].num_gauss;
-    const int stride = gridDim.x * blockDim.x;
-    for (int g = gbase + blockIdx.x * blockDim.x + threadIdx.x; g < gend; g += stride) {
-        const int b = seg_off[g], e = seg_off[g + 1], n = e - b;
-        double sx = 0.0, sy = 0.0, sz = 0.0;
-        for (int j = b; j < e; ++j) {
-            const float4 p = global[memb_idx[j]];
-            sx += (double)p.x, sy += (double)p.y, sz += (double)p.z;
-        }
-        const float mx = (float)(sx / (double)n), my = (float)(sy / (double)n), mz = (float)(sz / (double)n);
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
-        for (int j = b; j < e; ++j) {
-            const float4 p = global[memb_idx[j]];
-            const float cx = p.x - mx, cy = p.y - my, cz = p.z - mz;
-            a0 += (double)cx * (double)cx, a1 += (double)cx * (double)cy, a2 += (double)cx * (double)cz;
-            a3 += (double)cy * (double)cy, a4 += (double)cy * (double)cz, a5 += (double)cz * (double)cz;
-        }
-        finish_gaussian(a0, a1, a2, a3, a4, a5, n, info12 + (size_t)g * 12);
+// Parity path: the fit's nine double sums in the order the oracle states (Gaussians::addPointSet there): consecutive blocks of
+// kSumBlock members, every block summed member by member, the block sums added in order.  One 64-thread workgroup per Gaussian,
+// one thread per block (the longest Gaussians of the bench window have 56 blocks), thread 0 adds the block sums in order; the six
+// covariance sums need the rounded means of the first pass.  Loads run eight members ahead of the sums.
+constexpr int kSumBlock = 256;
+template <int kTerms, typename Load>
+__device__ __forceinline__ void block_sums(int j0, int j1, Load load, double* acc) {
+    constexpr int kAhead = 8;
+    for (int j = j0; j < j1; j += kAhead) {
+        double t[kAhead][kTerms];
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) load(min(j + u, j1 - 1), t[u]);
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u)
+            if (j + u < j1) {
+#pragma unroll
+                for (int c = 0; c < kTerms; ++c) acc[c] += t[u][c];
+            }
     }
 }
+__global__ __launch_bounds__(64) void k_gauss_fit_blocked(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
+                                                         const float4* __restrict__ global, const uint32_t* __restrict__ order, int M,
+                                                         float* __restrict__ info12) {
+    __shared__ double s_part[64][6];
+    __shared__ double s_tot[6];
+    __shared__ float s_mean[3];
+    const int task = blockIdx.x, tid = threadIdx.x;
+    if (task >= M) return;
+    const int g = order ? (int)order[task] : task;  // descending size when ordered: the long fits start first
+    const int b = seg_off[g], n = seg_off[g + 1] - b, nblk = (n + kSumBlock - 1) / kSumBlock;
+    if (tid < 6) s_tot[tid] = 0.0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 64) {  // pass 1: sums of x, y, z
+        const int blk = base + tid;
+        double acc[3] = {0.0, 0.0, 0.0};
+        if (blk < nblk)
+            block_sums<3>(blk * kSumBlock, min(n, (blk + 1) * kSumBlock), [&](int j, double* t) {
+                const float4 p = global[memb_idx[b + j]];
+                t[0] = (double)p.x, t[1] = (double)p.y, t[2] = (double)p.z;
+            }, acc);
+        s_part[tid][0] = acc[0], s_part[tid][1] = acc[1], s_part[tid][2] = acc[2];
+        __syncthreads();
+        if (tid < 3) {
+            double tot = s_tot[tid];
+            const int cnt = min(64, nblk - base);
+            for (int t = 0; t < cnt; ++t) tot += s_part[t][tid];
+            s_tot[tid] = tot;
+        }
+        __syncthreads();
+    }
+    if (tid < 3) s_mean[tid] = (float)(s_tot[tid] / (double)n);
+    __syncthreads();
+    const float mx = s_mean[0], my = s_mean[1], mz = s_mean[2];
+    if (tid < 6) s_tot[tid] = 0.0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 64) {  // pass 2: xx xy xz yy yz zz of the centred members
+        const int blk = base + tid;
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (blk < nblk)
+            block_sums<6>(blk * kSumBlock, min(n, (blk + 1) * kSumBlock), [&](int j, double* t) {
+                const float4 p = global[memb_idx[b + j]];
+                const float cx = p.x - mx, cy = p.y - my, cz = p.z - mz;
+                t[0] = (double)cx * (double)cx, t[1] = (double)cx * (double)cy, t[2] = (double)cx * (double)cz;
+                t[3] = (double)cy * (double)cy, t[4] = (double)cy * (double)cz, t[5] = (double)cz * (double)cz;
+            }, acc);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s_part[tid][c] = acc[c];
+        __syncthreads();
+        if (tid < 6) {
+            double tot = s_tot[tid];
+            const int cnt = min(64, nblk - base);
+            for (int t = 0; t < cnt; ++t) tot += s_part[t][tid];
+            s_tot[tid] = tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) finish_gaussian(s_tot[0], s_tot[1], s_tot[2], s_tot[3], s_tot[4], s_tot[5], n, info12 + (size_t)g * 12);
+}
+void launch_gauss_fit_blocked(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const uint32_t* order, int M, float* info12, hipStream_t s) {
+    if (M > 0) hipLaunchKernelGGL(k_gauss_fit_blocked, dim3(M), dim3(64), 0, s, seg_off, memb_idx, global, order, M, info12);
+}
+
 void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const GaussCounts* counts, int level, float* info12,
                       bool mirror, hipStream_t s) {
-    if (mirror && !mirror_uses_rows())
-        hipLaunchKernelGGL(k_gauss_fit_mirror, dim3(1024), dim3(256), 0, s, seg_off, memb_idx, global, counts, level, info12);
-    else if (mirror)
-        return;  // the row-cooperative parity fit runs once for both levels, after M is known (launch_gauss_fit_mirror_rows)
+    if (mirror)
+        return;  // the parity fit runs once for both levels, after M is known (launch_gauss_fit_blocked)
     else
         hipLaunchKernelGGL(k_gauss_fit, dim3(2048), dim3(256), 0, s, seg_off, memb_idx, global, counts, level, info12);
 }
@@ -1215,27 +1270,37 @@ __global__ __launch_bounds__(1024) void k_rebalancing_weights(const int32_t* __r
     if (threadIdx.x == 0) counts->weight_mean = mean;
     for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = info12[(size_t)g * 12 + 9] / mean;
 }
-// parity path: VectorXf::mean() as one serial double chain in index order (the oracle's statement of Gaussians.h:170-179).
-// Wave 0 loads 64 weights at a time (the next 64 are in flight meanwhile) and walks them with v_readlane; the sum is wave-uniform.
+// parity path: VectorXf::mean() in the oracle's blocked order (blocks of kSumBlock weights summed in index order, block sums added
+// in order): one thread per block, thread 0 adds the block sums.
 __global__ __launch_bounds__(1024) void k_rebalancing_weights_mirror(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts,
                                                                      float* __restrict__ info12) {
+    __shared__ double s_part[1024];
+    __shared__ double s_tot;
     __shared__ float s_mean;
     const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        auto weight = [&](int g) { return g < M ? (1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f : 0.0f; };  // +0.0 leaves the sum unchanged
+    const int nblk = (M + kSumBlock - 1) / kSumBlock;
+    if (threadIdx.x == 0) s_tot = 0.0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int blk = base + (int)threadIdx.x;
         double s = 0.0;
-        float wn = weight(lane);
-        for (int g0 = 0; g0 < M; g0 += 64) {
-            const float w = wn;
-            wn = weight(g0 + 64 + lane);
-#pragma unroll
-            for (int k = 0; k < 64; ++k) s += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), k));
+        if (blk < nblk) {
+            const int g1 = min(M, (blk + 1) * kSumBlock);
+            for (int g = blk * kSumBlock; g < g1; ++g) s += (double)((1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f);
         }
-        if (lane == 0) {
-            s_mean = (float)(s / (double)M);
-            counts->weight_mean = s_mean;
+        s_part[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = s_tot;
+            const int cnt = min(1024, nblk - base);
+            for (int t = 0; t < cnt; ++t) tot += s_part[t];
+            s_tot = tot;
         }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        s_mean = (float)(s_tot / (double)M);
+        counts->weight_mean = s_mean;
     }
     __syncthreads();
     const float mean = s_mean;
@@ -2159,16 +2224,6 @@ struct RowChain {
         asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz), "+v"(x), "+v"(y), "+v"(z));
         RowChain<J + 1>::add3d_from_f(sx, sy, sz, x, y, z);
     }
-    static __device__ __forceinline__ void add1d_from_f(double& sx, float& x) {
-        sx += (double)row_lane<J>(x);
-        asm volatile("" : "+v"(sx), "+v"(x));
-        RowChain<J + 1>::add1d_from_f(sx, x);
-    }
-    static __device__ __forceinline__ void add2d(double& a, double& b, double& va, double& vb) {
-        a += row_lane<J>(va), b += row_lane<J>(vb);
-        asm volatile("" : "+v"(a), "+v"(b), "+v"(va), "+v"(vb));
-        RowChain<J + 1>::add2d(a, b, va, vb);
-    }
     static __device__ __forceinline__ void add6d(double* a, double* v) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -2185,8 +2240,6 @@ struct RowChain<16> {
     static __device__ __forceinline__ void add_f_to_d(double&, float) {}
     static __device__ __forceinline__ void add3d_from_f(double&, double&, double&, float&, float&, float&) {}
     static __device__ __forceinline__ void add6d(double*, double*) {}
-    static __device__ __forceinline__ void add1d_from_f(double&, float&) {}
-    static __device__ __forceinline__ void add2d(double&, double&, double&, double&) {}
 };
 // value of the row's lane 0 in every lane of the row
 __device__ __forceinline__ float row_first(float v) { return __shfl(v, (int)(threadIdx.x & 63u & ~15u), 64); }
@@ -2273,153 +2326,17 @@ __global__ __launch_bounds__(256) void k_residuals_mirror_rows(const float4* __r
     if (on && l16 == 0) E[(size_t)b * ldE + g] = sqrt(fabs(acc));
 }
 
-constexpr int kFitWaveThreshold = 1024;
-// Gaussians::addPointSet (Gaussians.h:130-168) with the oracle's serial double sums, one row per Gaussian (both levels, by
-// descending size like k_residuals_mirror_rows).
-__device__ __forceinline__ void gauss_fit_mirror_rows(int block, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
-                                                      const float4* __restrict__ global, const uint32_t* __restrict__ order, int M, int wave_tasks,
-                                                      float* __restrict__ info12) {
-    const int l16 = threadIdx.x & 15;
-    {
-        const int task = block * 16 + (threadIdx.x >> 4);
-        const bool on = task < M;
-        const int g = on ? (int)order[task] : 0;
-        const int b = on ? seg_off[g] : 0;
-        int n = on ? seg_off[g + 1] - b : 0;
-        if (n > kFitWaveThreshold && task < wave_tasks) n = 0;  // fitted by gauss_fit_mirror_wave (its chains split over the rows of a whole wave)
-        const int nmax = wave_max4(n);
-        if (nmax == 0) return;
-        constexpr int kRowBatch = 4;  // loads of 4 x 16 members in flight before the chains of a step (see k_residuals_mirror_rows)
-        const int last = max(n - 1, 0);
-        auto load_step = [&](int j0, float4* dst) {  // index + gather of the NEXT step overlap the chains of the current one
-#pragma unroll
-            for (int u = 0; u < kRowBatch; ++u) dst[u] = global[memb_idx[b + min(j0 + 16 * u + l16, last)]];
-        };
-        double sx = 0.0, sy = 0.0, sz = 0.0;
-        float4 p[kRowBatch], pn[kRowBatch];
-        load_step(0, pn);
-        for (int j0 = 0; j0 < nmax; j0 += 16 * kRowBatch) {
-#pragma unroll
-            for (int u = 0; u < kRowBatch; ++u) p[u] = pn[u];
-            if (j0 + 16 * kRowBatch < nmax) load_step(j0 + 16 * kRowBatch, pn);
-#pragma unroll
-            for (int u = 0; u < kRowBatch; ++u) {
-                const bool in = j0 + 16 * u + l16 < n;
-                float x = in ? p[u].x : 0.0f, y = in ? p[u].y : 0.0f, z = in ? p[u].z : 0.0f;
-                RowChain<0>::add3d_from_f(sx, sy, sz, x, y, z);
-            }
-        }
-        float mx = (float)(sx / (double)n), my = (float)(sy / (double)n), mz = (float)(sz / (double)n);
-        mx = row_first(mx), my = row_first(my), mz = row_first(mz);
-        double a[6] = {0, 0, 0, 0, 0, 0};
-        load_step(0, pn);
-        for (int j0 = 0; j0 < nmax; j0 += 16 * kRowBatch) {
-#pragma unroll
-            for (int u = 0; u < kRowBatch; ++u) p[u] = pn[u];
-            if (j0 + 16 * kRowBatch < nmax) load_step(j0 + 16 * kRowBatch, pn);
-#pragma unroll
-            for (int u = 0; u < kRowBatch; ++u) {
-                double v[6] = {0, 0, 0, 0, 0, 0};
-                if (j0 + 16 * u + l16 < n) {
-                    const float cx = p[u].x - mx, cy = p[u].y - my, cz = p[u].z - mz;
-                    v[0] = (double)cx * (double)cx, v[1] = (double)cx * (double)cy, v[2] = (double)cx * (double)cz;
-                    v[3] = (double)cy * (double)cy, v[4] = (double)cy * (double)cz, v[5] = (double)cz * (double)cz;
-                }
-                RowChain<0>::add6d(a, v);
-            }
-        }
-        if (on && n > 0 && l16 == 0) finish_gaussian(a[0], a[1], a[2], a[3], a[4], a[5], n, info12 + (size_t)g * 12);
-    }
-}
-
-// The long Gaussians are the critical path of the parity fit: nine serial double chains over up to 10^4 members.  The chains are
-// independent of each other, so a whole wave takes one Gaussian and spreads them over its four rows: three mean chains on rows
-// 0-2, then the six centred products as (row0: xx, yz) (row1: xy, zz) (row2: xz) (row3: yy).  Every chain is still the oracle's
-// serial sum in member order -> bit-identical.  All rows load the same members (L1 broadcast).
-__device__ __forceinline__ void gauss_fit_mirror_wave(int block, const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
-                                                      const float4* __restrict__ global, const uint32_t* __restrict__ order, int M,
-                                                      float* __restrict__ info12) {
-    const int task = (int)((block * blockDim.x + threadIdx.x) >> 6);
-    if (task >= M) return;  // (task < 4 * wave_blocks by construction)
-    const int g = (int)order[task];
-    const int b = seg_off[g], n = seg_off[g + 1] - b;
-    if (n <= kFitWaveThreshold) return;  // order is descending: everything after the first short Gaussian is short too
-    const int lane = threadIdx.x & 63, l16 = lane & 15, r = lane >> 4;
-    constexpr int kRowBatch = 4;
-    const int last = n - 1;
-    auto load_step = [&](int j0, float4* dst) {
-#pragma unroll
-        for (int u = 0; u < kRowBatch; ++u) dst[u] = global[memb_idx[b + min(j0 + 16 * u + l16, last)]];
-    };
-    float4 p[kRowBatch], pn[kRowBatch];
-    double s = 0.0;
-    load_step(0, pn);
-    for (int j0 = 0; j0 < n; j0 += 16 * kRowBatch) {
-#pragma unroll
-        for (int u = 0; u < kRowBatch; ++u) p[u] = pn[u];
-        if (j0 + 16 * kRowBatch < n) load_step(j0 + 16 * kRowBatch, pn);
-#pragma unroll
-        for (int u = 0; u < kRowBatch; ++u) {
-            const bool in = j0 + 16 * u + l16 < n;
-            float v = r == 0 ? p[u].x : (r == 1 ? p[u].y : (r == 2 ? p[u].z : 0.0f));
-            v = in ? v : 0.0f;
-            RowChain<0>::add1d_from_f(s, v);
-        }
-    }
-    const float mine = (float)(s / (double)n);  // valid in lane 0 of rows 0..2
-    const float mx = __shfl(mine, 0, 64), my = __shfl(mine, 16, 64), mz = __shfl(mine, 32, 64);
-    double a = 0.0, a2 = 0.0;
-    load_step(0, pn);
-    for (int j0 = 0; j0 < n; j0 += 16 * kRowBatch) {
-#pragma unroll
-        for (int u = 0; u < kRowBatch; ++u) p[u] = pn[u];
-        if (j0 + 16 * kRowBatch < n) load_step(j0 + 16 * kRowBatch, pn);
-#pragma unroll
-        for (int u = 0; u < kRowBatch; ++u) {
-            double va = 0.0, vb = 0.0;
-            if (j0 + 16 * u + l16 < n) {
-                const float cx = p[u].x - mx, cy = p[u].y - my, cz = p[u].z - mz;
-                const float fa0 = r == 3 ? cy : cx, fa1 = r == 0 ? cx : (r == 1 ? cy : (r == 2 ? cz : cy));  // xx, xy, xz, yy
-                const float fb0 = r == 0 ? cy : cz, fb1 = cz;                                                    // yz, zz
-                va = (double)fa0 * (double)fa1;
-                vb = r < 2 ? (double)fb0 * (double)fb1 : 0.0;
-            }
-            RowChain<0>::add2d(a, a2, va, vb);
-        }
-    }
-    // a: rows 0..3 = xx, xy, xz, yy ; a2: rows 0, 1 = yz, zz
-    const double axx = __shfl(a, 0, 64), axy = __shfl(a, 16, 64), axz = __shfl(a, 32, 64), ayy = __shfl(a, 48, 64), ayz = __shfl(a2, 0, 64), azz = __shfl(a2, 16, 64);
-    if (lane == 0) finish_gaussian(axx, axy, axz, ayy, ayz, azz, n, info12 + (size_t)g * 12);
-}
-
+// order of the Gaussians by descending size for the row-cooperative parity kernels: ascending key = descending size
 __global__ __launch_bounds__(256) void k_gauss_size_keys(const int32_t* __restrict__ seg_off, int M, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < M) key[g] = 0xFFFFFFFFu - (uint32_t)(seg_off[g + 1] - seg_off[g]), val[g] = (uint32_t)g;  // ascending key = descending size
+    if (g < M) key[g] = 0xFFFFFFFFu - (uint32_t)(seg_off[g + 1] - seg_off[g]), val[g] = (uint32_t)g;
 }
 void launch_gauss_size_keys(const int32_t* seg_off, int M, uint32_t* key, uint32_t* val, hipStream_t s) {
     if (M > 0) hipLaunchKernelGGL(k_gauss_size_keys, dim3((M + 255) / 256), dim3(256), 0, s, seg_off, M, key, val);
 }
-bool mirror_uses_rows() {
+bool mirror_uses_rows() {  // DMSA_MIRROR_THREADS: first-generation thread-per-Gaussian residual chains instead of the DPP rows
     static const bool serial_threads = std::getenv("DMSA_MIRROR_THREADS") != nullptr;
     return !serial_threads;
-}
-// One launch: the first `wave_blocks` workgroups give every Gaussian of the descending order a whole wave (only those above the
-// threshold do any work -- the long chains, the critical path, start first), the remaining workgroups fit the complement row by
-// row and fill the chip meanwhile.
-__global__ __launch_bounds__(256) void k_gauss_fit_mirror(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
-                                                          const float4* __restrict__ global, const uint32_t* __restrict__ order, int M, int wave_blocks,
-                                                          float* __restrict__ info12) {
-    if ((int)blockIdx.x < wave_blocks)
-        gauss_fit_mirror_wave((int)blockIdx.x, seg_off, memb_idx, global, order, M, info12);
-    else
-        gauss_fit_mirror_rows((int)blockIdx.x - wave_blocks, seg_off, memb_idx, global, order, M, 4 * wave_blocks, info12);
-}
-void launch_gauss_fit_mirror_rows(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const uint32_t* order, int M, float* info12,
-                                  hipStream_t s) {
-    if (M <= 0) return;
-    const int wave_blocks = (std::min(M, 16384) + 3) / 4;  // Gaussians above the threshold sit at the front of the order; 16384 x 1024 members bound them
-    const int rows_blocks = (M + 15) / 16;
-    hipLaunchKernelGGL(k_gauss_fit_mirror, dim3(wave_blocks + rows_blocks), dim3(256), 0, s, seg_off, memb_idx, global, order, M, wave_blocks, info12);
 }
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
                       const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s, bool pairs, const uint32_t* order) {

@@ -474,20 +474,33 @@ struct Gaussians {
         numPointSets = 0;
     }
     // Gaussians.h:130-168
+    // Order of the fit's reductions.  The reference computes colwise().mean() and centered^T * centered with Eigen's vectorised
+    // dynamic-size float paths (Gaussians.h:146-154), whose summation order cannot be known; this restatement accumulates in double
+    // and fixes an order that is easy to state and to parallelise: consecutive blocks of kSumBlock members, every block summed
+    // member by member, the block sums added in order.  (The parity kernels of the HIP library use the same rule.)
+    static constexpr size_t kSumBlock = 256;
+    template <typename Term>
+    static double blockedSum(size_t n, Term term) {
+        double total = 0.0;
+        for (size_t j0 = 0; j0 < n; j0 += kSumBlock) {
+            double s = 0.0;
+            for (size_t j = j0; j < std::min(n, j0 + kSumBlock); ++j) s += term(j);
+            total += s;
+        }
+        return total;
+    }
     void addPointSet(const std::vector<int>& ids, const float* xyz4, float observationWeight) {
         const size_t n = ids.size();
         float mean[3];
-        for (int c = 0; c < 3; ++c) {
-            double s = 0.0;
-            for (size_t j = 0; j < n; ++j) s += (double)xyz4[4 * (size_t)ids[j] + c];
-            mean[c] = (float)(s / (double)n);
-        }
-        double acc[6] = {0, 0, 0, 0, 0, 0};  // xx xy xz yy yz zz
-        for (size_t j = 0; j < n; ++j) {
-            const float* p = xyz4 + 4 * (size_t)ids[j];
-            const float cx = p[0] - mean[0], cy = p[1] - mean[1], cz = p[2] - mean[2];
-            acc[0] += (double)cx * (double)cx, acc[1] += (double)cx * (double)cy, acc[2] += (double)cx * (double)cz;
-            acc[3] += (double)cy * (double)cy, acc[4] += (double)cy * (double)cz, acc[5] += (double)cz * (double)cz;
+        for (int c = 0; c < 3; ++c) mean[c] = (float)(blockedSum(n, [&](size_t j) { return (double)xyz4[4 * (size_t)ids[j] + c]; }) / (double)n);
+        double acc[6];  // xx xy xz yy yz zz
+        for (int q = 0; q < 6; ++q) {
+            static const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+            acc[q] = blockedSum(n, [&](size_t j) {
+                const float* p = xyz4 + 4 * (size_t)ids[j];
+                const float ca = p[ia[q]] - mean[ia[q]], cb = p[ib[q]] - mean[ib[q]];
+                return (double)ca * (double)cb;
+            });
         }
         const double denom = (double)((long)n - 1);
         float cov[3][3];
@@ -507,12 +520,12 @@ struct Gaussians {
     // Gaussians.h:170-179
     void updateRebalancingWeights() {
         weights.resize((size_t)numPointSets);
-        double s = 0.0;
         for (int k = 0; k < numPointSets; ++k) {
             const float nk = (float)(segOffset[k + 1] - segOffset[k]);
             weights[k] = (1.0f / nk) * obsWeights[k];
-            s += (double)weights[k];
         }
+        // VectorXf::mean() (Gaussians.h:176): Eigen's vectorised reduction, order unknowable -> same blocked double sum as the fit
+        const double s = blockedSum((size_t)numPointSets, [&](size_t k) { return (double)weights[k]; });
         const float mean = (float)(s / (double)numPointSets);
         for (int k = 0; k < numPointSets; ++k) weights[k] = weights[k] / mean;
     }
