@@ -64,8 +64,14 @@ class GpuBackend:
     def preProcess(self, xyz, seed, max_pts):
         return self.scan_filter.preProcess(xyz, seed, max_pts)
 
-    def prepare(self, buffer, old_traj, initialized, C, dt_res):
-        return self.setup.prepareTrajectoryForOptimization(buffer, old_traj, initialized, C, dt_res)
+    def newImuBuffer(self):
+        return ws.ImuBuffer(10000)
+
+    def prepare(self, buffer, old_traj, initialized, C, dt_res, imu=None, cov_gyr=None, cov_acc=None):
+        return self.setup.prepareTrajectoryForOptimization(buffer, old_traj, initialized, C, dt_res, imu, cov_gyr, cov_acc)
+
+    def gravityEstimate(self, traj):
+        return self.setup.getSubmapGravityEstimate(traj)
 
     def addStaticPoints(self, prob, key_xyz, key_nrm, key_ring, offsets, curr_pos, seed):
         self.optimizer.upload(prob)
@@ -93,8 +99,10 @@ class GpuBackend:
 
 class MiniSlam:
     def __init__(self, backend=None, n_clouds=5, num_control_poses=6, dt_res=1e-3, max_points_per_scan=3000, min_overlap_new_keyframe=0.7, dist_new_keyframe=1.0,
-                 seed=7, num_iter=5, num_iter_keyframe_optim=0):
+                 seed=7, num_iter=5, num_iter_keyframe_optim=0, use_imu=False, gravity_outlier_thresh=1.0):
         self.be = backend or GpuBackend()
+        self.imu = self.be.newImuBuffer() if use_imu else None  # processImuMeasurements (DmsaSlam.h:100-113) feeds it
+        self.cov_gyr, self.cov_acc, self.gravity_thresh = np.diag([1e-4] * 3), np.diag([1e-2] * 3), gravity_outlier_thresh
         self.kf_iters = num_iter_keyframe_optim  # > 0: keyframeOptimization after every new keyframe (DmsaSlam.h:181-184, :212-238)
         self.n_clouds, self.C, self.dt_res, self.max_pts, self.seed, self.num_iter = n_clouds, num_control_poses, dt_res, max_points_per_scan, seed, num_iter
         self.min_overlap, self.dist_kf = min_overlap_new_keyframe, dist_new_keyframe
@@ -135,10 +143,10 @@ class MiniSlam:
         if len(self.buffer) < self.n_clouds:
             return
         # prepareTrajectoryForOptimization
-        traj, prob, self.initialized = self.be.prepare(self.buffer, self.old_traj, self.initialized, self.C, self.dt_res)
+        traj, prob, self.initialized = self.be.prepare(self.buffer, self.old_traj, self.initialized, self.C, self.dt_res, self.imu, self.cov_gyr, self.cov_acc)
         if self.old_traj is None and first_pose is not None:  # the demo starts in motion: seed the first window with its true poses
             prob.relOrientations[...], prob.relTranslations[...] = first_pose(traj)
-        settings = DmsaOptimSettings.sliding_window(use_imu=False, num_iter=self.num_iter)
+        settings = DmsaOptimSettings.sliding_window(use_imu=self.imu is not None, num_iter=self.num_iter)
         overlap = 0.0
         if self.keyframes:  # addStaticPoints against the (here: all) keyframes
             kx, kn = self._map_global()
@@ -155,7 +163,13 @@ class MiniSlam:
         kf_rep = None
         if need:
             kxyz, knrm, kring = self.be.keyframeCloud(prob, gt[0], go[0], self.seed)
-            self.map = MapManagement.addKeyframe(self.map, gt[0], go[0], kxyz, knrm, kring, prob.minGridSize, useOdometryErrorTerms=True)
+            grav, plausible = None, True
+            if self.imu is not None:  # measuredGravity + plausibility gate (DmsaSlam.h:533-539)
+                traj.globOrientations[...], traj.globTranslations[...] = go, gt
+                grav = self.be.gravityEstimate(traj)
+                plausible = bool(abs(np.linalg.norm(grav) - 9.805) < self.gravity_thresh)
+            self.map = MapManagement.addKeyframe(self.map, gt[0], go[0], kxyz, knrm, kring, prob.minGridSize, measuredGravity=grav, gravityPlausible=plausible,
+                                                 useOdometryErrorTerms=True, useGravityErrorTerms=self.imu is not None)
             if self.kf_iters > 0 and self.map.numFrames >= 3:  # keyframeOptimization(fromId = 0, KeyframeMap)
                 last = self.map.numFrames - 1
                 sub = self.map.getSubmap(0, last)
@@ -173,6 +187,12 @@ class MiniSlam:
 def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, **slam_args):
     clouds, truth = synth.scan_sequence(seed=seed, scans=scans, rings=rings, az_steps=az_steps)
     slam = MiniSlam(backend, **slam_args)
+    if slam.imu is not None:  # the whole IMU stream up front (the node interleaves the two callbacks): 50 samples at rest for the gyro bias, then the drive
+        st, acc, ang = synth.imu_stream(truth, -0.3, scans * 0.1 + 0.3, rate=400.0, rng=np.random.default_rng(seed + 50), sigma_acc=0.02, sigma_gyr=0.002)
+        for t in st[0] - (50 - np.arange(50)) * 0.0025:
+            slam.imu.addMeasurement([0.0, 0.0, 9.805], np.zeros(3), t)
+        for t, a, w in zip(st, acc, ang):
+            slam.imu.addMeasurement(a, w, t)
 
     def first_pose(traj):
         R, p = truth.pose(traj.t0 - 1.6e9 + traj.stamps)
@@ -194,8 +214,9 @@ if __name__ == "__main__":
     ap.add_argument("--scans", type=int, default=14)
     ap.add_argument("--keyframe-dist", type=float, default=0.25, help="dist_new_keyframe [m]")
     ap.add_argument("--keyframe-iters", type=int, default=3, help="num_iter_keyframe_optim (0 = no keyframe optimisation)")
+    ap.add_argument("--imu", action="store_true", help="IMU rows in the window, gravity rows in the keyframe pass")
     a = ap.parse_args()
-    r = run(a.scans, dist_new_keyframe=a.keyframe_dist, num_iter_keyframe_optim=a.keyframe_iters)
+    r = run(a.scans, dist_new_keyframe=a.keyframe_dist, num_iter_keyframe_optim=a.keyframe_iters, use_imu=a.imu)
     for e in r["log"]:
         print(f"t0={e['t0']:.3f} pos=({e['pos'][0]:.3f} {e['pos'][1]:.3f} {e['pos'][2]:.3f}) iters={e['iterations']} M={e['gaussians']} static={e['static']} "
               f"overlap={e['overlap']:.2f} keyframes={e['keyframes']} keyframe_opt={e['keyframe_opt']}")

@@ -44,12 +44,22 @@ class OracleBackend:
     def preProcess(self, xyz, seed, max_pts):
         return self.orc.preprocess_scan(xyz, seed, max_pts)
 
-    def prepare(self, buffer, old_traj, initialized, C, dt_res):
+    def newImuBuffer(self):
+        return self.orc.ImuBuffer(10000)
+
+    def prepare(self, buffer, old_traj, initialized, C, dt_res, imu=None, cov_gyr=None, cov_acc=None):
         t_min, t_max = min(float(np.min(c[1])) for c in buffer), max(float(np.max(c[1])) for c in buffer)
-        traj = self.setup.initTraj(t_min, t_max, C, False, dt_res)
-        initialized = self.setup.updateInitialGuess(initialized, traj, old_traj, False)
+        use_imu = imu is not None
+        traj = self.setup.initTraj(t_min, t_max, C, use_imu, dt_res)
+        if use_imu:
+            self.setup.transferImuMeasurements(traj, imu)
+            self.setup.updatePreintFactors(traj, cov_gyr, cov_acc)
+        initialized = self.setup.updateInitialGuess(initialized, traj, old_traj, use_imu)
         prob = ws.assemble_problem(traj, buffer, self.setup.tformIdPerPoint(traj, np.concatenate([c[1] for c in buffer])))
         return traj, prob, initialized
+
+    def gravityEstimate(self, traj):
+        return self.setup.getSubmapGravityEstimate(traj)
 
     def _window_global(self, prob):
         table, _ = self.orc.window_pose_table(prob)
@@ -124,4 +134,21 @@ def test_full_sequence_with_keyframe_optimisation(orc):
     assert worst < 1e-12, worst  # actual: 0
     assert g["max_position_error_m"] < 0.25
     print(f"full-sequence difference with keyframe optimisation: {worst:.2e} over {g['windows']} windows, {g['keyframes']} keyframes")
+
+
+def test_full_sequence_with_imu(orc):
+    """BASELINE.json config 2's shape (sliding window with IMU rows, keyframes with gravity rows): IMU ring buffer -> nearest
+    samples -> preintegration -> IMU-predicted initial guess -> optimizeSet with IMU rows -> measuredGravity of new keyframes ->
+    keyframe optimisation with gravity + odometry rows.  HIP library (parity path) and oracle: bit-identical poses."""
+    import sequence_demo
+
+    args = dict(scans=12, rings=32, az_steps=256, num_iter=3, dist_new_keyframe=0.25, num_iter_keyframe_optim=2, use_imu=True)
+    g = sequence_demo.run(backend=sequence_demo.GpuBackend(parity=True), **args)
+    o = sequence_demo.run(backend=OracleBackend(orc), **args)
+    assert g["windows"] == o["windows"] == 8 and g["keyframes"] == o["keyframes"] >= 3
+    for a, b in zip(g["log"], o["log"]):
+        assert (a["iterations"], a["gaussians"], a["static"], a["keyframes"], a["keyframe_opt"]) == (b["iterations"], b["gaussians"], b["static"], b["keyframes"], b["keyframe_opt"])
+        for x, y in zip(a["rel"] + a["map_rel"], b["rel"] + b["map_rel"]):
+            assert np.array_equal(x, y)
+    assert g["tum"] == o["tum"] and g["max_position_error_m"] < 0.25
 
