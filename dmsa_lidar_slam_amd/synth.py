@@ -208,6 +208,28 @@ def window_problem(seed: int = 1, scans: int = 10, rings: int = 128, az_steps: i
     return prob
 
 
+def rosette_scan_sequence(seed: int = 1, scans: int = 12, pts_per_scan: int = 12_000, scan_period: float = 0.1, sigma: float = 0.01,
+                          grid_size: float = 0.15, epoch: float = 1.6e9):
+    """Config 5's scan stream: non-repetitive scan pattern (Livox Mid-360-like), no rings -- the node assigns id = k % 1000 while
+    decoding (dmsa_slam_ros.cpp:449-469).  Same tuple layout as scan_sequence; the third entry is the point index inside its scan."""
+    rng = np.random.default_rng(seed)
+    scene = Scene.room_with_stairs()
+    traj = SmoothTrajectory(p0=np.array([4.0, 3.0, 1.5]))
+    clouds = []
+    for s in range(scans):
+        frac = np.arange(pts_per_scan) / pts_per_scan
+        tt = s * scan_period + frac * scan_period
+        a = 2 * np.pi * (17.0 * frac + 0.37 * s)  # Mid-360-like: full azimuth, elevation -7 .. 52 degrees, never the same line twice
+        el = np.deg2rad(-7.0 + 59.0 * np.abs(np.cos(2 * np.pi * 3.4 * frac + 0.11 * s)))
+        d = np.stack([np.cos(el) * np.cos(a), np.cos(el) * np.sin(a), np.sin(el)], axis=-1)
+        R, p = traj.pose(tt)
+        r, _ = scene.raycast(p, R.apply(d))
+        r = r + rng.normal(0, sigma, r.shape)
+        keep = r >= 0.1
+        clouds.append(((d[keep] * r[keep, None]).astype(np.float32), epoch + tt[keep], np.arange(int(keep.sum()), dtype=np.int32), np.float32(grid_size)))
+    return clouds, traj
+
+
 def scan_sequence(seed: int = 1, scans: int = 12, rings: int = 32, az_steps: int = 256, scan_period: float = 0.1, sigma: float = 0.01,
                   grid_size: float = 0.15, epoch: float = 1.6e9, scene: Scene | None = None):
     """A stream of scans as the node buffers them (PointCloudBuffer): list of (xyz_local (n,3) f32, absolute stamps (n,) f64,

@@ -29,6 +29,21 @@ OUSTER = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad0", "<f4"), ("
 OUSTER_FIELDS = ["x", "y", "z", "intensity", "t", "reflectivity", "ring", "ambient", "range"]
 
 
+LIVOX = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("reflectivity", "<f4"), ("tag", "u1"), ("line", "u1"), ("timestamp", "<f8")])  # XYZRTLT, packed
+LIVOX_FIELDS = ["x", "y", "z", "reflectivity", "tag", "line", "timestamp"]
+
+
+def scan_to_livox_pointcloud2(xyz, stamps):
+    """What livox_ros_driver2 publishes (XYZRTLT, per-point timestamp in NANOSECONDS as a double: the driver bug the node's
+    livoxXYZRTLT_ns branch works around, dmsa_slam_ros.cpp:459-469).  No ring field: the node assigns id = k % 1000."""
+    rec = np.zeros(xyz.shape[0], LIVOX)
+    rec["x"], rec["y"], rec["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    rec["timestamp"] = np.round(stamps * 1e9)
+    offs = np.array([LIVOX.fields[n][1] for n in LIVOX_FIELDS], np.uint32)
+    return wf.PointCloud2Msg(height=1, width=xyz.shape[0], point_step=LIVOX.itemsize, field_offsets=offs, data=np.frombuffer(rec.tobytes(), np.uint8).copy(),
+                             stamp=float(stamps.min()))
+
+
 def scan_to_pointcloud2(xyz, stamps, rings):
     """What an Ouster driver would publish for this scan (header stamp = first point, t = nanoseconds since then)."""
     rec = np.zeros(xyz.shape[0], OUSTER)
@@ -45,10 +60,11 @@ class GpuBackend:
     """The library calls MiniSlam strings together.  (tests/test_gpu_sequence.py runs the same MiniSlam on a backend made of the CPU
     oracle's functions and compares the two trajectories.)"""
 
-    def __init__(self, parity: bool = False):
+    def __init__(self, parity: bool = False, sensor: str = "ouster"):
+        self.sensor = sensor
         self.optimizer = DmsaOptimizer(device=0, pose_table_host=parity, mirror_sums=parity)
         self.kf_optimizer = DmsaOptimizer(device=0, pose_table_host=parity, mirror_sums=parity)  # keyframeMapOptimizer (DmsaSlam.h:53)
-        self.decoder = wf.PointCloud2Decoder("ouster")
+        self.decoder = wf.PointCloud2Decoder(sensor)
         self.scan_filter = StaticPointSelector(0)                      # preProcess works on raw scans: its own context
         self.static = StaticPointSelector(optimizer=self.optimizer)     # these two share the optimizer's context: the window cloud
         self.kf_builder = KeyframeCloudBuilder(optimizer=self.optimizer)  # stays resident in HBM between the steps
@@ -184,8 +200,12 @@ class MiniSlam:
                          "map_rel": (self.map.relOrientations.copy(), self.map.relTranslations.copy())})
 
 
-def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, **slam_args):
-    clouds, truth = synth.scan_sequence(seed=seed, scans=scans, rings=rings, az_steps=az_steps)
+def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, livox=False, **slam_args):
+    if livox:  # BASELINE.json config 5: Livox-like rosette scans, livoxXYZRTLT_ns messages, no IMU
+        clouds, truth = synth.rosette_scan_sequence(seed=seed, scans=scans)
+        backend = backend or GpuBackend(sensor="livoxXYZRTLT_ns")
+    else:
+        clouds, truth = synth.scan_sequence(seed=seed, scans=scans, rings=rings, az_steps=az_steps)
     slam = MiniSlam(backend, **slam_args)
     if slam.imu is not None:  # the whole IMU stream up front (the node interleaves the two callbacks): 50 samples at rest for the gyro bias, then the drive
         st, acc, ang = synth.imu_stream(truth, -0.3, scans * 0.1 + 0.3, rate=400.0, rng=np.random.default_rng(seed + 50), sigma_acc=0.02, sigma_gyr=0.002)
@@ -199,7 +219,7 @@ def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, **slam_args):
         return posemath.global2relative(R.as_rotvec(), p)
 
     for xyz, stamps, ring, _ in clouds:
-        slam.process(scan_to_pointcloud2(xyz, stamps, ring), first_pose)
+        slam.process(scan_to_livox_pointcloud2(xyz, stamps) if livox else scan_to_pointcloud2(xyz, stamps, ring), first_pose)
     errs = []
     for e in slam.log:
         _, p = truth.pose(np.array([e["t0"] - 1.6e9]))
@@ -215,8 +235,10 @@ if __name__ == "__main__":
     ap.add_argument("--keyframe-dist", type=float, default=0.25, help="dist_new_keyframe [m]")
     ap.add_argument("--keyframe-iters", type=int, default=3, help="num_iter_keyframe_optim (0 = no keyframe optimisation)")
     ap.add_argument("--imu", action="store_true", help="IMU rows in the window, gravity rows in the keyframe pass")
+    ap.add_argument("--livox", action="store_true", help="rosette scans as livoxXYZRTLT_ns messages (ids = k % 1000)")
     a = ap.parse_args()
-    r = run(a.scans, dist_new_keyframe=a.keyframe_dist, num_iter_keyframe_optim=a.keyframe_iters, use_imu=a.imu)
+    r = run(a.scans, dist_new_keyframe=a.keyframe_dist, num_iter_keyframe_optim=a.keyframe_iters, use_imu=a.imu, livox=a.livox,
+            **(dict(max_points_per_scan=1000) if a.livox else {}))
     for e in r["log"]:
         print(f"t0={e['t0']:.3f} pos=({e['pos'][0]:.3f} {e['pos'][1]:.3f} {e['pos'][2]:.3f}) iters={e['iterations']} M={e['gaussians']} static={e['static']} "
               f"overlap={e['overlap']:.2f} keyframes={e['keyframes']} keyframe_opt={e['keyframe_opt']}")

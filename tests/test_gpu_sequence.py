@@ -31,15 +31,15 @@ def test_sequence_demo_tracks_the_motion():
 class OracleBackend:
     """Every step of MiniSlam on the CPU oracle (test infrastructure)."""
 
-    def __init__(self, orc):
-        self.orc = orc
+    def __init__(self, orc, sensor="ouster"):
+        self.orc, self.sensor = orc, sensor
         self.setup = orc.WindowSetup()
 
     def close(self):
         pass
 
     def decode(self, msg):
-        return self.orc.decode_pointcloud2(msg, "ouster")
+        return self.orc.decode_pointcloud2(msg, self.sensor)
 
     def preProcess(self, xyz, seed, max_pts):
         return self.orc.preprocess_scan(xyz, seed, max_pts)
@@ -151,4 +151,20 @@ def test_full_sequence_with_imu(orc):
         for x, y in zip(a["rel"] + a["map_rel"], b["rel"] + b["map_rel"]):
             assert np.array_equal(x, y)
     assert g["tum"] == o["tum"] and g["max_position_error_m"] < 0.25
+
+
+def test_full_sequence_livox(orc):
+    """BASELINE.json config 5's shape: rosette (non-repetitive) scans published as livoxXYZRTLT_ns messages (nanosecond stamps as
+    doubles, no ring field -> id = k % 1000), max_num_points_per_scan = 1000 (dmsa_slam_ros.cpp:204), no IMU.  Bit-identical poses."""
+    import sequence_demo
+
+    args = dict(scans=10, livox=True, num_iter=3, max_points_per_scan=1000, dist_new_keyframe=0.3, num_iter_keyframe_optim=2)
+    g = sequence_demo.run(backend=sequence_demo.GpuBackend(parity=True, sensor="livoxXYZRTLT_ns"), **args)
+    o = sequence_demo.run(backend=OracleBackend(orc, sensor="livoxXYZRTLT_ns"), **args)
+    assert g["windows"] == o["windows"] == 6 and g["keyframes"] == o["keyframes"] >= 1
+    for a, b in zip(g["log"], o["log"]):
+        assert (a["iterations"], a["gaussians"], a["static"], a["keyframes"], a["keyframe_opt"]) == (b["iterations"], b["gaussians"], b["static"], b["keyframes"], b["keyframe_opt"])
+        for x, y in zip(a["rel"] + a["map_rel"], b["rel"] + b["map_rel"]):
+            assert np.array_equal(x, y)
+    assert g["tum"] == o["tum"] and g["max_position_error_m"] < 0.2
 
