@@ -29,6 +29,19 @@ OUSTER = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad0", "<f4"), ("
 OUSTER_FIELDS = ["x", "y", "z", "intensity", "t", "reflectivity", "ring", "ambient", "range"]
 
 
+HESAI = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4"), ("timestamp", "<f8"), ("ring", "<u2")])  # PandarXT: absolute f64 stamps
+HESAI_FIELDS = ["x", "y", "z", "intensity", "timestamp", "ring"]
+
+
+def scan_to_hesai_pointcloud2(xyz, stamps, rings):
+    """What the Hesai driver publishes (dmsa_slam_ros.cpp:411-419: stamp = double @fields[4], ring = uint16 @fields[5])."""
+    rec = np.zeros(xyz.shape[0], HESAI)
+    rec["x"], rec["y"], rec["z"], rec["timestamp"], rec["ring"] = xyz[:, 0], xyz[:, 1], xyz[:, 2], stamps, rings
+    offs = np.array([HESAI.fields[n][1] for n in HESAI_FIELDS], np.uint32)
+    return wf.PointCloud2Msg(height=1, width=xyz.shape[0], point_step=HESAI.itemsize, field_offsets=offs, data=np.frombuffer(rec.tobytes(), np.uint8).copy(),
+                             stamp=float(stamps.min()))
+
+
 LIVOX = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("reflectivity", "<f4"), ("tag", "u1"), ("line", "u1"), ("timestamp", "<f8")])  # XYZRTLT, packed
 LIVOX_FIELDS = ["x", "y", "z", "reflectivity", "tag", "line", "timestamp"]
 
@@ -200,12 +213,14 @@ class MiniSlam:
                          "map_rel": (self.map.relOrientations.copy(), self.map.relTranslations.copy())})
 
 
-def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, livox=False, **slam_args):
+def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, livox=False, hesai=False, **slam_args):
     if livox:  # BASELINE.json config 5: Livox-like rosette scans, livoxXYZRTLT_ns messages, no IMU
         clouds, truth = synth.rosette_scan_sequence(seed=seed, scans=scans)
         backend = backend or GpuBackend(sensor="livoxXYZRTLT_ns")
     else:
         clouds, truth = synth.scan_sequence(seed=seed, scans=scans, rings=rings, az_steps=az_steps)
+        if hesai:  # BASELINE.json config 2: PandarXT-32 messages (+ IMU through use_imu=True)
+            backend = backend or GpuBackend(sensor="hesai")
     slam = MiniSlam(backend, **slam_args)
     if slam.imu is not None:  # the whole IMU stream up front (the node interleaves the two callbacks): 50 samples at rest for the gyro bias, then the drive
         st, acc, ang = synth.imu_stream(truth, -0.3, scans * 0.1 + 0.3, rate=400.0, rng=np.random.default_rng(seed + 50), sigma_acc=0.02, sigma_gyr=0.002)
@@ -219,7 +234,8 @@ def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, livox=False, **s
         return posemath.global2relative(R.as_rotvec(), p)
 
     for xyz, stamps, ring, _ in clouds:
-        slam.process(scan_to_livox_pointcloud2(xyz, stamps) if livox else scan_to_pointcloud2(xyz, stamps, ring), first_pose)
+        msg = scan_to_livox_pointcloud2(xyz, stamps) if livox else scan_to_hesai_pointcloud2(xyz, stamps, ring) if hesai else scan_to_pointcloud2(xyz, stamps, ring)
+        slam.process(msg, first_pose)
     errs = []
     for e in slam.log:
         _, p = truth.pose(np.array([e["t0"] - 1.6e9]))
@@ -235,9 +251,10 @@ if __name__ == "__main__":
     ap.add_argument("--keyframe-dist", type=float, default=0.25, help="dist_new_keyframe [m]")
     ap.add_argument("--keyframe-iters", type=int, default=3, help="num_iter_keyframe_optim (0 = no keyframe optimisation)")
     ap.add_argument("--imu", action="store_true", help="IMU rows in the window, gravity rows in the keyframe pass")
+    ap.add_argument("--hesai", action="store_true", help="32-ring scans as Hesai PandarXT messages (absolute double stamps, uint16 ring)")
     ap.add_argument("--livox", action="store_true", help="rosette scans as livoxXYZRTLT_ns messages (ids = k % 1000)")
     a = ap.parse_args()
-    r = run(a.scans, dist_new_keyframe=a.keyframe_dist, num_iter_keyframe_optim=a.keyframe_iters, use_imu=a.imu, livox=a.livox,
+    r = run(a.scans, dist_new_keyframe=a.keyframe_dist, num_iter_keyframe_optim=a.keyframe_iters, use_imu=a.imu, livox=a.livox, hesai=a.hesai, **(dict(rings=32, az_steps=512) if a.hesai else {}),
             **(dict(max_points_per_scan=1000) if a.livox else {}))
     for e in r["log"]:
         print(f"t0={e['t0']:.3f} pos=({e['pos'][0]:.3f} {e['pos'][1]:.3f} {e['pos'][2]:.3f}) iters={e['iterations']} M={e['gaussians']} static={e['static']} "

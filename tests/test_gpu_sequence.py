@@ -137,14 +137,15 @@ def test_full_sequence_with_keyframe_optimisation(orc):
 
 
 def test_full_sequence_with_imu(orc):
-    """BASELINE.json config 2's shape (sliding window with IMU rows, keyframes with gravity rows): IMU ring buffer -> nearest
+    """BASELINE.json config 2's shape (32-ring scans as Hesai PandarXT messages, sliding window with IMU rows, keyframes with
+    gravity rows): IMU ring buffer -> nearest
     samples -> preintegration -> IMU-predicted initial guess -> optimizeSet with IMU rows -> measuredGravity of new keyframes ->
     keyframe optimisation with gravity + odometry rows.  HIP library (parity path) and oracle: bit-identical poses."""
     import sequence_demo
 
-    args = dict(scans=12, rings=32, az_steps=256, num_iter=3, dist_new_keyframe=0.25, num_iter_keyframe_optim=2, use_imu=True)
-    g = sequence_demo.run(backend=sequence_demo.GpuBackend(parity=True), **args)
-    o = sequence_demo.run(backend=OracleBackend(orc), **args)
+    args = dict(scans=12, rings=32, az_steps=256, num_iter=3, dist_new_keyframe=0.25, num_iter_keyframe_optim=2, use_imu=True, hesai=True)
+    g = sequence_demo.run(backend=sequence_demo.GpuBackend(parity=True, sensor="hesai"), **args)
+    o = sequence_demo.run(backend=OracleBackend(orc, sensor="hesai"), **args)
     assert g["windows"] == o["windows"] == 8 and g["keyframes"] == o["keyframes"] >= 3
     for a, b in zip(g["log"], o["log"]):
         assert (a["iterations"], a["gaussians"], a["static"], a["keyframes"], a["keyframe_opt"]) == (b["iterations"], b["gaussians"], b["static"], b["keyframes"], b["keyframe_opt"])
