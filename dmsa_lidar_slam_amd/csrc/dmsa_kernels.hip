@@ -2219,27 +2219,11 @@ struct RowChain {
         acc += (double)row_lane<J>(t);
         RowChain<J + 1>::add_f_to_d(acc, t);
     }
-    static __device__ __forceinline__ void add3d_from_f(double& sx, double& sy, double& sz, float& x, float& y, float& z) {
-        sx += (double)row_lane<J>(x), sy += (double)row_lane<J>(y), sz += (double)row_lane<J>(z);
-        asm volatile("" : "+v"(sx), "+v"(sy), "+v"(sz), "+v"(x), "+v"(y), "+v"(z));
-        RowChain<J + 1>::add3d_from_f(sx, sy, sz, x, y, z);
-    }
-    static __device__ __forceinline__ void add6d(double* a, double* v) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            a[c] += row_lane<J>(v[c]);
-            // ties the next lane move of this chain to this add: without it all 16 x 12 moves are hoisted (512 VGPRs + scratch)
-            asm volatile("" : "+v"(a[c]), "+v"(v[c]));
-        }
-        RowChain<J + 1>::add6d(a, v);
-    }
 };
 template <>
 struct RowChain<16> {
     static __device__ __forceinline__ void add3f(float&, float&, float&, float, float, float) {}
     static __device__ __forceinline__ void add_f_to_d(double&, float) {}
-    static __device__ __forceinline__ void add3d_from_f(double&, double&, double&, float&, float&, float&) {}
-    static __device__ __forceinline__ void add6d(double*, double*) {}
 };
 // value of the row's lane 0 in every lane of the row
 __device__ __forceinline__ float row_first(float v) { return __shfl(v, (int)(threadIdx.x & 63u & ~15u), 64); }
@@ -2266,8 +2250,9 @@ __global__ __launch_bounds__(256) void k_residuals_mirror_rows(const float4* __r
     const float4* T = kTableInLds ? s_tab : gtab;
     const int l16 = threadIdx.x & 15;
     // `order` lists the Gaussians by descending size: the four rows of a wave get chains of (almost) equal length and the long
-    // chains -- the critical path -- start first.  (A whole-wave variant for the longest Gaussians, rows chained through
-    // v_readlane, measured 5 % SLOWER end to end: the readlane hand-over costs more than the 1/16 -> 1/64 parallel work saves.)
+    // chains -- the critical path -- start first.  (A whole-wave variant for the longest Gaussians -- 64 members transformed per
+    // step, the four rows chained in order through v_readlane, loads four steps ahead -- has 26 % fewer instructions per member and is
+    // still 15-40 % SLOWER per launch: the chain is bound by the latency of its dependent adds, and the hand-overs add to it.)
     const int task = tblock * 16 + (threadIdx.x >> 4);
     const bool on = task < M;
     const int g = on ? (int)order[task] : 0;
