@@ -218,12 +218,13 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("DMSA_LIB_PATH", LIB_PATH)  # kernel A/B experiments load an alternative BUILD of the same HIP library
+    if not os.path.exists(path):
         raise DmsaLibraryMissing(
-            f"{LIB_PATH} not found — run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found — run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950) first; there is no CPU fallback"
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp = C.c_void_p
     sig = {
         "dmsa_create": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(vp)]),

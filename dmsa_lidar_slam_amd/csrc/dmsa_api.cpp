@@ -29,6 +29,7 @@
 #include "device_prims.h"
 #include "dmsa_kernels.h"
 #include "host_math.h"
+#include "serial_kernels.h"
 #include "static_kernels.h"
 
 using namespace dmsa;
@@ -178,6 +179,7 @@ struct dmsa_ctx {
         LatticeTable lattice[2];
         GaussCounts g;
         TileCounts t;
+        SerialCounts sc;  // d_counts holds the three structs back to back
         double errs[16];
     };
     Readback* h_rb = nullptr;  // hipHostMalloc
@@ -198,8 +200,12 @@ struct dmsa_ctx {
     double level_res[2] = {0, 0};
     // Gaussians
     DevBuf d_memb_local, d_memb_idx, d_memb_g, d_seg_off, d_info12, d_wg_seg;
-    DevBuf d_order_key, d_order_key_s, d_order_val, d_order;  // parity path: Gaussians by descending size
+    DevBuf d_order_key, d_order_key_s, d_order_val, d_order;  // reference-order path: Gaussians by descending size class
+    DevBuf d_tablesT;                                          // pose tables of the current batch, transposed ([row][evaluation][12])
     bool order_valid = false;
+    bool serial_classes = true;  // DMSA_MIRROR_ROWS=1: previous generation (size sort + DPP-row kernel) for A/B timing
+    SerialCounts serial_counts{0, 0, 0, 0};
+    bool serial_two_streams = true;  // DMSA_SERIAL_STREAMS=1: all tiers of the reference-order correspondence kernels on one stream
     DevBuf d_memb_tile, d_tiles, d_tile_rows, d_fallback, d_pad_off;
     int num_tiles = 0, num_fallback = 0, tile_max_rows = 0, tile_max_gauss = 0;
     bool use_tiles = true;  // DMSA_K4_TILES=0 selects the streaming kernel
@@ -333,7 +339,7 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
         HIPCHK(ctx->d_sort_tmp[l].ensure(sort_pairs_temp_bytes(2 * n)));
         HIPCHK(ctx->d_scan_tmp[l].ensure(scan_temp_bytes(2 * n)));
     }
-    HIPCHK(ctx->d_counts.ensure(sizeof(GaussCounts) + sizeof(TileCounts)));  // read back together
+    HIPCHK(ctx->d_counts.ensure(sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts)));  // read back together
     // memberships: every point belongs to at most one set per resolution
     HIPCHK(ctx->d_memb_local.ensure(2 * n * 16));
     HIPCHK(ctx->d_memb_idx.ensure(2 * n * 4));
@@ -467,7 +473,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     ctx->level_res[1] = (double)(s.grid_size_2_factor * ctx->min_grid_size);
     if (!lvl_on[0]) ctx->level_res[0] = ctx->level_res[1];
     if (!lvl_on[1]) ctx->level_res[1] = ctx->level_res[0];
-    HIPCHK(hipMemsetAsync(ctx->d_counts.p, 0, sizeof(GaussCounts) + sizeof(TileCounts), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counts.p, 0, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts), ctx->stream));
     const bool compress = ctx->compress_keys && allow_compression;
     const bool speculate = allow_speculation && ctx->depth_guess[0] >= 0 && ctx->depth_guess[1] >= 0 && ctx->depth_guess[0] < 20 && ctx->depth_guess[1] < 20 &&
                            (!compress || (ctx->bits_guess[0] >= 0 && ctx->bits_guess[1] >= 0));
@@ -610,7 +616,11 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                            reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_memb_tile.as<float4>(), ctx->d_tile_rows.as<int32_t>(),
                            ctx->d_pad_off.as<int32_t>(), ctx->stream);
     }
-    HIPCHK(hipMemcpyAsync(&ctx->h_rb->g, ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts), hipMemcpyDeviceToHost, ctx->stream));
+    const bool classes_on = !tiles_on && (ctx->flags & DMSA_FLAG_MIRROR_SUMS) && ctx->serial_classes;
+    if (classes_on)  // size classes of the reference-order correspondence kernels: needs only seg_off, so it runs before the read-back
+        launch_size_classes(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_order.as<uint32_t>(),
+                            reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts) + sizeof(TileCounts)), ctx->stream);
+    HIPCHK(hipMemcpyAsync(&ctx->h_rb->g, ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));  // incl. out_of_range
     // The fit does not need the counts on the host (fixed grids, device-side tile counts): with the LDS table sized for ALL pose rows
     // it is enqueued right behind the read-back, so the GPU keeps working while the host waits for M (sync #2 waits on an event
@@ -667,7 +677,8 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             // parity path: order the Gaussians by size once (radix sort of M keys; the row-cooperative residual kernel wants the long
             // chains first), then one fit for both levels in the oracle's blocked summation order
             const bool ordered = mirror_uses_rows();
-            if (ordered) {
+            ctx->serial_counts = classes_on ? ctx->h_rb->sc : SerialCounts{0, 0, 0, 0};
+            if (ordered && !classes_on) {
                 launch_gauss_size_keys(ctx->d_seg_off.as<int32_t>(), M_all, ctx->d_order_key.as<uint32_t>(), ctx->d_order_val.as<uint32_t>(), ctx->stream);
                 HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_order_key.as<uint32_t>(), ctx->d_order_key_s.as<uint32_t>(),
                                           ctx->d_order_val.as<uint32_t>(), ctx->d_order.as<uint32_t>(), (size_t)M_all, 32, ctx->stream));
@@ -713,6 +724,22 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
                                ctx->d_tables.as<float>(), ctx->rows, ctx->M, B, ctx->d_tiles.as<TileDesc>(), ctx->d_tile_rows.as<int32_t>(), ctx->num_tiles,
                                ctx->tile_max_rows, ctx->tile_max_gauss, ctx->d_fallback.as<int2>(), ctx->num_fallback, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE,
                                ctx->stream);
+    } else if ((ctx->flags & DMSA_FLAG_MIRROR_SUMS) && ctx->serial_classes && ctx->order_valid) {
+        // reference-order sums (default path): lane = evaluation on transposed pose tables
+        HIPCHK(ctx->d_tablesT.ensure((size_t)B * ctx->rows * 48));
+        ScopedTimer tm(ctx, T_RESIDUAL);
+        launch_transpose_tables(ctx->d_tables.as<float>(), ctx->rows, B, ctx->d_tablesT.as<float>(), ctx->stream);
+        const bool two = ctx->serial_two_streams && ctx->serial_counts.n_long > 0;
+        if (two) {  // the latency tier keeps `stream`; the throughput tiers run beside it on stream2
+            HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        }
+        launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
+                                ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, ctx->stream, two ? ctx->stream2 : ctx->stream);
+        if (two) {
+            HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
     } else {
         ScopedTimer tm(ctx, T_RESIDUAL);
         launch_residuals(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tables.as<float>(), ctx->rows, ctx->M,
@@ -962,6 +989,8 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     if (const char* e = std::getenv("DMSA_OVERLAP_BATCH")) ctx->overlap_batch = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_DUAL_STREAM")) ctx->dual_stream = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_MERGE_SORT")) ctx->merge_sort = std::atoi(e) != 0 ? 1 : 0;
+    if (const char* e = std::getenv("DMSA_MIRROR_ROWS")) ctx->serial_classes = std::atoi(e) == 0;
+    if (const char* e = std::getenv("DMSA_SERIAL_STREAMS")) ctx->serial_two_streams = std::atoi(e) != 1;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_scan0, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||

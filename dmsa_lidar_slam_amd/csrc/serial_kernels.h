@@ -1,0 +1,40 @@
+// serial_kernels.h — correspondence kernels of the DEFAULT (reference-order) path.
+//
+// DmsaOptimizer::updateErrorTerms (DmsaOptimizer.h:234-273) sums every Gaussian with two explicit serial loops: a float mean in
+// member order (:247-254) and float Mahalanobis terms added to a double in member order (:259-264).  Rounding makes both order
+// dependent, and the numeric Jacobian amplifies 1e-7 differences into millimetres, so the library's default path
+// keeps the reference's order bit for bit.  What is parallel: the B evaluations of a batch (lane = evaluation: every lane runs the
+// same chain on its own pose table), the Gaussians, and everything AROUND a chain (transform + quadratic form of each member).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "dmsa_kernels.h"
+
+namespace dmsa {
+
+// Gaussians ordered for the serial-order kernels: [0, n_chain) long ones by descending size class (pipelined kernel),
+// [n_chain, n_chain + n_small) the short ones by descending size (lane-per-evaluation kernel).
+struct SerialCounts {
+    int32_t n_chain, n_small, max_members;
+    int32_t n_long;  // the first n_long entries of the order: Gaussians of the latency tier (>= 2^12 members)
+};
+int serial_small_threshold();  // members; Gaussians up to this size go to the lane-per-evaluation kernel (DMSA_SERIAL_SMALL)
+// one workgroup: counting sort of the M = counts->level[0..1].num_gauss Gaussians by size class
+void launch_size_classes(const int32_t* seg_off, const GaussCounts* counts, uint32_t* order /* M */, SerialCounts* out, hipStream_t s);
+// tables [B][rows][12] -> tablesT [rows][B][12]: the B evaluations of one pose row are contiguous (lane = evaluation reads coalesce)
+void launch_transpose_tables(const float* tables, int rows, int B, float* tablesT, hipStream_t s);
+// updateErrorTerms for B pose tables, bit-identical to the reference's serial loops.  E[b * ldE + g] = sqrt(|sum|).
+// The latency tier runs on s_long, the other two tiers on s_rest (pass the same stream twice to serialise them); the caller joins
+// the streams.
+void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tablesT, int B, const uint32_t* order,
+                             const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest);
+// LDS / shape parameters chosen for a batch of B evaluations (exposed for the bench's roofline notes and the tests)
+struct SerialShape {
+    int nsub_long, Bs_long;  // latency tier: evaluation sub-batches per Gaussian, evaluations per sub-batch
+    int nsub, Bs;            // throughput tier
+    int lanes, nsub_small;   // lane-per-evaluation kernel: lanes per (Gaussian, sub-batch), sub-batches
+};
+SerialShape serial_shape(int B);
+
+}  // namespace dmsa

@@ -1,0 +1,591 @@
+// serial_kernels.hip — reference-order correspondence kernels for gfx950 (the library's default path).
+//
+// updateErrorTerms (DmsaOptimizer.h:234-273) per Gaussian k and evaluation b:
+//     mean = 0; for j in members: mean += p_j            (float, member order, :247-254);  mean /= n
+//     e    = 0; for j in members: e += double( float( (w d^T) A d ) ),  d = p_j - mean       (:259-264)
+//     E[b][k] = sqrt(|e|)                                                                     (:267)
+// with p_j = T_b[row_j] * local_j (the fused updateGlobalPoints, ContinuousTrajectory.h:151 / MapManagement.h:143).
+// Both loops are serial chains whose rounding depends on the order, so the order is kept.  Mapping:
+//   * lane = evaluation.  The members of a Gaussian are the same for every evaluation of a batch, so the lanes of a group walk
+//     the member list together, each with its own pose table; a chain step is ONE vector add that serves every lane — no
+//     cross-lane traffic, no reduction tree, full lane utilisation of the chain instructions.
+//   * pose tables are stored transposed ([row][evaluation][12]) so that "row r of every evaluation" is one coalesced read, and
+//     a lane keeps the 12 floats of its current row in registers: consecutive members of a Gaussian mostly share a row
+//     (same scan, neighbouring firing times), so table traffic is a few percent of the member traffic.
+//   * short Gaussians (k_residuals_small): a group of 16 / 32 / 64 lanes owns one Gaussian and does everything in registers.
+//   * long Gaussians (k_residuals_chain): a dependent add has ~8 cycles latency and a single wave issues one instruction per
+//     ~5 cycles, so 14 000 members x (transform + quadratic form + chain) in ONE wave would take milliseconds.  A workgroup
+//     splits the roles instead: producer waves compute the per-member values of a 64-member chunk for all evaluations of the
+//     sub-batch (lane = (member, evaluation)) into an LDS ring, and one chainer wave (lane = (coordinate, evaluation)) adds
+//     them in member order, fed by ds_read_b128 (four members per read).  The critical path of a Gaussian is then its chain
+//     alone: ~8 cycles per member for the float mean, ~12 for the double sum.
+// Everything is compiled with -ffp-contract=off: separate multiplies and adds like the reference's -O1 build without FMA.
+#include "serial_kernels.h"
+
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+namespace dmsa {
+
+namespace {
+
+constexpr int kChunk = 64;        // members per pipeline phase of the chain kernel
+constexpr int kSmallMax = 256;    // upper limit of the small-Gaussian threshold (histogram size of k_size_classes)
+
+__device__ __forceinline__ float3 apply_row3s(const float4 r0, const float4 r1, const float4 r2, const float x, const float y, const float z) {
+    float3 g;  // Matrix4f * Vector4f, column-wise like Eigen's packet product: ((c0*x + c1*y) + c2*z) + c3
+    g.x = ((r0.x * x + r0.y * y) + r0.z * z) + r0.w;
+    g.y = ((r1.x * x + r1.y * y) + r1.z * z) + r1.w;
+    g.z = ((r2.x * x + r2.y * y) + r2.z * z) + r2.w;
+    return g;
+}
+__device__ __forceinline__ float sum3s(float a, float b, float c) { return a + (b + c); }  // Eigen's 3-term redux
+// the float Mahalanobis term of DmsaOptimizer.h:263: ((w d^T) A) d, every product and sum rounded separately
+struct Info {
+    float A00, A10, A20, A01, A11, A21, A02, A12, A22, w;
+};
+__device__ __forceinline__ Info load_info(const float4* __restrict__ info12, int g) {
+    const float4 i0 = info12[3 * g], i1 = info12[3 * g + 1], i2 = info12[3 * g + 2];
+    return Info{i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y};
+}
+__device__ __forceinline__ float mahalanobis_term(const Info& I, const float3 q, const float mx, const float my, const float mz) {
+    const float d0 = q.x - mx, d1 = q.y - my, d2 = q.z - mz;
+    const float wd0 = I.w * d0, wd1 = I.w * d1, wd2 = I.w * d2;
+    const float v0 = sum3s(wd0 * I.A00, wd1 * I.A10, wd2 * I.A20);
+    const float v1 = sum3s(wd0 * I.A01, wd1 * I.A11, wd2 * I.A21);
+    const float v2 = sum3s(wd0 * I.A02, wd1 * I.A12, wd2 * I.A22);
+    return sum3s(v0 * d0, v1 * d1, v2 * d2);
+}
+// LDS barrier that leaves global loads in flight (a __syncthreads() also waits for vmcnt(0), which would serialise the member
+// prefetch of the producers with every phase)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Per-lane cache of one pose-table row (transposed tables: [row][B][12]).  The reload is written in assembly with its own
+// s_waitcnt INSIDE the branch: left to the compiler, the wait for the three row loads lands behind the join of the branch as
+// vmcnt(0), i.e. every step would also wait for the member prefetch that was issued just before it -- the full memory latency
+// per step, taken or not.  This way only a step that really changes rows (a few percent) drains the queue.
+// The x and y rows are kept as register PAIRS: a wave of these kernels is bound by instruction issue (one instruction per ~5
+// cycles), not by VALU time, so the x/y halves of the transform and of the quadratic form go through v_pk_mul_f32 / v_pk_add_f32
+// (two IEEE operations per instruction, each rounded separately -- same results, two thirds of the instructions).
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct RowCache {
+    int row = -1;
+    f2 cx, cy, cz, cw;  // (row0[k], row1[k]) for k = x, y, z, w
+    float4 r2;
+    __device__ __forceinline__ void fetch(const float4* __restrict__ tabT, int B, int b, int want) {
+        if (want != row) {
+            const float4* t = tabT + ((size_t)want * B + b) * 3;
+            float4 r0, r1;
+            asm volatile(
+                "global_load_dwordx4 %0, %3, off\n\t"
+                "global_load_dwordx4 %1, %3, off offset:16\n\t"
+                "global_load_dwordx4 %2, %3, off offset:32\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+                : "v"(t)
+                : "memory");
+            cx = f2{r0.x, r1.x}, cy = f2{r0.y, r1.y}, cz = f2{r0.z, r1.z}, cw = f2{r0.w, r1.w};
+            row = want;
+        }
+    }
+    // Matrix4f * Vector4f, column-wise like Eigen's packet product: ((c0*x + c1*y) + c2*z) + c3
+    __device__ __forceinline__ void apply(const float4 p, f2& gxy, float& gz) const {
+#ifdef DMSA_NO_PK
+        gxy.x = ((cx.x * p.x + cy.x * p.y) + cz.x * p.z) + cw.x;
+        gxy.y = ((cx.y * p.x + cy.y * p.y) + cz.y * p.z) + cw.y;
+#else
+        gxy = ((cx * p.x + cy * p.y) + cz * p.z) + cw;
+#endif
+        gz = ((r2.x * p.x + r2.y * p.y) + r2.z * p.z) + r2.w;
+    }
+};
+// information matrix in the packed form of the quadratic form: columns 0/1 as pairs, column 2 and the weight as scalars
+struct InfoPk {
+    f2 a0, a1, a2;         // (A00, A01), (A10, A11), (A20, A21)
+    float A02, A12, A22, w;
+};
+__device__ __forceinline__ InfoPk load_info_pk(const float4* __restrict__ info12, int g) {
+    const float4 i0 = info12[3 * g], i1 = info12[3 * g + 1], i2 = info12[3 * g + 2];
+    // info12 = A00 A10 A20 | A01 A11 A21 | A02 A12 A22 | w  (column-major 3x3 + weight)
+    return InfoPk{f2{i0.x, i0.w}, f2{i0.y, i1.x}, f2{i0.z, i1.y}, i1.z, i1.w, i2.x, i2.y};
+}
+// the float Mahalanobis term of DmsaOptimizer.h:263, ((w d^T) A) d with 3-term sums as a + (b + c); identical operation order to
+// mahalanobis_term(), the x/y columns packed
+__device__ __forceinline__ float mahalanobis_term_pk(const InfoPk& I, const f2 gxy, const float gz, const f2 mxy, const float mz) {
+    const f2 d = gxy - mxy;
+    const float d2 = gz - mz;
+    const f2 wd = I.w * d;
+    const float wd2 = I.w * d2;
+    const f2 v01 = wd.x * I.a0 + (wd.y * I.a1 + wd2 * I.a2);
+    const float v2 = wd.x * I.A02 + (wd.y * I.A12 + wd2 * I.A22);
+    const f2 t = v01 * d;
+    return t.x + (t.y + v2 * d2);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// size classes: one workgroup sorts the Gaussians by descending size class (counting sort in LDS)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_size_classes(const int32_t* __restrict__ seg_off, const GaussCounts* __restrict__ counts, int ns, int long_log2,
+                                                       uint32_t* __restrict__ order, SerialCounts* __restrict__ out) {
+    __shared__ int h_c[64], h_s[kSmallMax], s_max;
+    const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) h_c[i] = 0;
+    for (int i = threadIdx.x; i < kSmallMax; i += blockDim.x) h_s[i] = 0;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    // chain bin: descending (floor(log2 n), next bit) -> at most 2x spread of sizes inside a bin, longest first
+    auto chain_bin = [](int n) { const int k = 31 - __clz(n); const int sub = k > 0 ? (n >> (k - 1)) & 1 : 0; return 63 - (2 * k + sub); };
+    int mx = 0;
+    for (int g = threadIdx.x; g < M; g += blockDim.x) {
+        const int n = max(seg_off[g + 1] - seg_off[g], 1);
+        mx = max(mx, n);
+        if (n <= ns)
+            atomicAdd(&h_s[ns - n], 1);
+        else
+            atomicAdd(&h_c[chain_bin(n)], 1);
+    }
+    atomicMax(&s_max, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int pos = 0, n_long = 0;
+        for (int b = 0; b < 64; ++b) {
+            const int c = h_c[b];
+            h_c[b] = pos, pos += c;
+            if (b == 63 - 2 * long_log2) n_long = pos;  // bins 0 .. 63 - 2 * long_log2 hold n >= 2^long_log2
+        }
+        const int n_chain = pos;
+        for (int b = 0; b < ns; ++b) {
+            const int c = h_s[b];
+            h_s[b] = pos, pos += c;
+        }
+        out->n_chain = n_chain, out->n_small = pos - n_chain, out->max_members = s_max, out->n_long = n_long;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < M; g += blockDim.x) {
+        const int n = max(seg_off[g + 1] - seg_off[g], 1);
+        const int pos = n <= ns ? atomicAdd(&h_s[ns - n], 1) : atomicAdd(&h_c[chain_bin(n)], 1);
+        order[pos] = (uint32_t)g;  // the order inside a bin is arbitrary: every (Gaussian, evaluation) result is independent of it
+    }
+}
+
+__global__ __launch_bounds__(256) void k_transpose_tables(const float4* __restrict__ tables, int rows, int B, float4* __restrict__ tablesT) {
+    const int total = rows * B * 3;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
+        const int k = o % 3, rb = o / 3, b = rb % B, row = rb / B;
+        tablesT[o] = tables[((size_t)b * rows + row) * 3 + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// short Gaussians: a group of L lanes = the evaluations of one (Gaussian, sub-batch); members are walked serially
+// ------------------------------------------------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ void small_wave(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12,
+                                           const float4* __restrict__ tabT, int B, const uint32_t* __restrict__ order, int n_items_g, int nsub,
+                                           double* __restrict__ E, int64_t ldE, int wave_index) {
+    constexpr int G = 64 / L;  // Gaussians per wave
+    const int lane = threadIdx.x & 63, grp = lane / L, bl = lane % L;
+    const int item = wave_index * G + grp;
+    const int gi = item / nsub, sub = item - gi * nsub;
+    const int b = sub * L + bl;
+    const bool on = gi < n_items_g && b < B;
+    const int g = gi < n_items_g ? (int)order[gi] : 0;
+    const int off0 = gi < n_items_g ? seg_off[g] : 0;
+    const int n = on ? seg_off[g + 1] - off0 : 0;
+    int nmax = n;  // longest member list of the wave's groups (sorted by size: nearly equal)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m));
+    if (nmax == 0) return;
+    const int last = max(n - 1, 0);
+    const int bc = on ? b : 0;
+    RowCache rc;
+    constexpr int U = 4;  // members in flight: the loads of the next four steps are issued before the current four are used
+    float4 cur[U], nxt[U];
+    auto load4 = [&](int j0, float4* dst) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) dst[u] = memb[off0 + min(j0 + u, last)];
+    };
+    // ---- float mean in member order (:247-254) ----
+    float mx = 0.0f, my = 0.0f, mz = 0.0f;
+    load4(0, nxt);
+    for (int j0 = 0; j0 < nmax; j0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        if (j0 + U < nmax) load4(j0 + U, nxt);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (j0 + u < n) {
+                rc.fetch(tabT, B, bc, __float_as_int(cur[u].w));
+                f2 gxy;
+                float gz;
+                rc.apply(cur[u], gxy, gz);
+                mx = mx + gxy.x, my = my + gxy.y, mz = mz + gz;
+            }
+        }
+    }
+    const float nf = (float)n;
+    mx = mx / nf, my = my / nf, mz = mz / nf;
+    // ---- float terms added to a double in member order (:259-264) ----
+    const InfoPk I = load_info_pk(info12, g);
+    const f2 mxy = f2{mx, my};
+    double acc = 0.0;
+    load4(0, nxt);
+    for (int j0 = 0; j0 < nmax; j0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        if (j0 + U < nmax) load4(j0 + U, nxt);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (j0 + u < n) {
+                rc.fetch(tabT, B, bc, __float_as_int(cur[u].w));
+                f2 gxy;
+                float gz;
+                rc.apply(cur[u], gxy, gz);
+                acc += (double)mahalanobis_term_pk(I, gxy, gz, mxy, mz);
+            }
+        }
+    }
+    if (on) E[(size_t)b * ldE + g] = sqrt(fabs(acc));
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void k_residuals_small(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off,
+                                                         const float4* __restrict__ info12, const float4* __restrict__ tabT, int B,
+                                                         const uint32_t* __restrict__ order, int n_items_g, int nsub, double* __restrict__ E,
+                                                         int64_t ldE) {
+    small_wave<L>(memb, seg_off, info12, tabT, B, order, n_items_g, nsub, E, ldE, (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// long Gaussians: producers -> LDS ring -> chainer.  One workgroup = one (Gaussian, sub-batch of Bs evaluations).
+//
+// Phase p (one s_barrier per phase, kSlots = 3 ring slots): the producers fill slot p % 3 with chunk p while the chainer
+// consumes chunk p - 2.  The lag of two phases is what lets the chainer run a rolling prefetch: chunk p - 1 is complete since
+// the previous barrier, so the ds_reads for the next 16 members are always in flight while the current ones are added, across
+// chunk boundaries too -- the chain never waits for LDS latency, only for its own dependent adds.
+// ------------------------------------------------------------------------------------------------------------
+#ifdef DMSA_SERIAL_TIMELINE
+__device__ long long g_tl[2][16][64][2];
+#define TL_BARRIER(pass, ph)                                                             \
+    do {                                                                                 \
+        const int _ph = (ph);                                                            \
+        if (kSepLoader && blockIdx.x == 0 && _ph >= 32 && _ph < 96) {                                  \
+            const long long _a = clock64();                                              \
+            lds_barrier();                                                               \
+            const long long _b = clock64();                                              \
+            if ((threadIdx.x & 63) == 0) g_tl[pass][threadIdx.x >> 6][_ph - 32][0] = _a, g_tl[pass][threadIdx.x >> 6][_ph - 32][1] = _b; \
+        } else                                                                           \
+            lds_barrier();                                                               \
+    } while (0)
+#else
+#define TL_BARRIER(pass, ph) lds_barrier()
+#endif
+constexpr int kSlots = 3;
+
+constexpr int kBL = 16;  // evaluation stride of the LDS ring layout (compile time: every ds_read of the chainer gets an immediate offset)
+
+// kProd producer waves; kSepLoader: one more wave that only feeds the member ring (otherwise the last producer does that too).
+//   <8, true>  latency tier (the longest Gaussians): with Bs <= 8 every producer has ONE step per phase, so a phase lasts as
+//              long as its chain segment even for the producer wave that loses the issue arbitration on the chainer's SIMD
+//   <3, false> throughput tier: 4 waves per workgroup, phases are producer-bound, but 8 workgroups share a CU and the resident
+//              waves spend most of their time issuing instead of waiting at a barrier
+template <int kProd, bool kSepLoader>
+__global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_residuals_chain(
+    const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12, const float4* __restrict__ tabT, int B,
+    const uint32_t* __restrict__ order, int Bs, int nsub, int prio, double* __restrict__ E, int64_t ldE) {
+    constexpr int kProducers = kProd;
+    constexpr int kMaxSteps = (kBL + kProd - 1) / kProd;  // steps per chunk <= kBL (Bs = kBL: 4 members per step)
+    // pass 1 ring: float  q[kSlots][kChunk / 4][3][kBL][4]   (member-in-group fastest: the chainer reads four members per ds_read_b128)
+    // pass 2 ring: double t[kSlots][kChunk / 2][kBL][2]       (aliases the pass-1 ring)
+    constexpr int kSlotFloats = kChunk * 3 * kBL, kSlotDoubles = kChunk * kBL;
+    __shared__ __attribute__((aligned(16))) float s_q[kSlots * kSlotFloats];
+    __shared__ float s_mean[3 * kBL];
+    __shared__ __attribute__((aligned(16))) float4 s_m[4][kChunk];  // member ring (filled by LDS-DMA)
+    double* s_t = reinterpret_cast<double*>(s_q);
+
+    const int item = blockIdx.x, gi = item / nsub, sub = item - gi * nsub;
+    const int g = (int)order[gi];
+    const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
+    const int b0 = sub * Bs, nb = min(Bs, B - b0);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nchunks = (n + kChunk - 1) / kChunk;
+    const int nphases = nchunks + 2;
+
+    if (wave == 0) {
+        // ================= chainer: lane = (coordinate, evaluation) =================
+        // A single wave issues one instruction per ~5 cycles, so the chain loop carries nothing but the adds and one ds_read per
+        // four (two) members: no exec masking (lanes outside the (coordinate, evaluation) grid add garbage that is never
+        // stored), immediate LDS offsets, fully unrolled chunks.
+        __builtin_amdgcn_s_setprio(3);  // the chain is the critical path of the workgroup (and of the launch for the longest Gaussians)
+        const int cc = lane >> 4, cb = lane & 15;
+        const bool on1 = cc < 3 && cb < nb;
+        float acc = 0.0f;
+        {
+            const float4* q4 = reinterpret_cast<const float4*>(s_q) + (cc < 3 ? cc * kBL + cb : 0);
+            constexpr int gstride = 3 * kBL;       // float4 entries per group of four members
+            constexpr int slot4 = kSlotFloats / 4;
+            constexpr int D = 8, S = kChunk / 4;   // prefetch depth and steps per chunk (one step = one float4 = four members)
+            float4 r[D];
+            lds_barrier();  // the member ring holds chunk 0
+            lds_barrier();  // phase 0: the producers fill chunk 0
+            for (int p = 1; p < nphases; ++p) {
+                const int c = p - 2;
+                if (p == 1) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) r[k] = q4[k * gstride];  // chunk 0 is complete since the first barrier
+                } else {
+                    const float4* cs = q4 + (c % kSlots) * slot4;
+                    const float4* ns = q4 + ((c + 1) % kSlots) * slot4;  // complete since the previous barrier (or unused)
+                    const int cnt = min(kChunk, n - c * kChunk);
+                    if (cnt == kChunk) {
+#pragma unroll
+                        for (int k = 0; k < S; ++k) {
+                            const float4 v = r[k % D];
+                            r[k % D] = k + D < S ? cs[(k + D) * gstride] : ns[(k + D - S) * gstride];
+                            acc = acc + v.x, acc = acc + v.y, acc = acc + v.z, acc = acc + v.w;
+                        }
+                    } else {  // last chunk of the Gaussian
+#pragma unroll
+                        for (int k = 0; k < S; ++k) {
+                            const float4 v = r[k % D];
+                            if (k + D < S) r[k % D] = cs[(k + D) * gstride];
+                            if (4 * k + 0 < cnt) acc = acc + v.x;
+                            if (4 * k + 1 < cnt) acc = acc + v.y;
+                            if (4 * k + 2 < cnt) acc = acc + v.z;
+                            if (4 * k + 3 < cnt) acc = acc + v.w;
+                        }
+                    }
+                }
+                TL_BARRIER(0, p);
+            }
+        }
+        if (on1) s_mean[cc * kBL + cb] = acc / (float)n;
+        lds_barrier();
+        const bool on2 = lane < nb;  // coordinate slot 0
+        double dacc = 0.0;
+        {
+            const double2* t2 = reinterpret_cast<const double2*>(s_t) + cb;
+            constexpr int slot2 = kSlotDoubles / 2;
+            constexpr int D = 8, S = kChunk / 2;  // one step = one double2 = two members
+            double2 r[D];
+            lds_barrier();  // phase 0
+            for (int p = 1; p < nphases; ++p) {
+                const int c = p - 2;
+                if (p == 1) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) r[k] = t2[k * kBL];
+                } else {
+                    const double2* cs = t2 + (c % kSlots) * slot2;
+                    const double2* ns = t2 + ((c + 1) % kSlots) * slot2;
+                    const int cnt = min(kChunk, n - c * kChunk);
+                    if (cnt == kChunk) {
+#pragma unroll
+                        for (int k = 0; k < S; ++k) {
+                            const double2 v = r[k % D];
+                            r[k % D] = k + D < S ? cs[(k + D) * kBL] : ns[(k + D - S) * kBL];
+                            dacc += v.x, dacc += v.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < S; ++k) {
+                            const double2 v = r[k % D];
+                            if (k + D < S) r[k % D] = cs[(k + D) * kBL];
+                            if (2 * k + 0 < cnt) dacc += v.x;
+                            if (2 * k + 1 < cnt) dacc += v.y;
+                        }
+                    }
+                }
+                TL_BARRIER(1, p);
+            }
+        }
+        if (on2) E[(size_t)(b0 + lane) * ldE + g] = sqrt(fabs(dacc));
+        return;
+    }
+
+    // ================= producers: lane = (member of the step, evaluation) =================
+    // the workgroups of the longest Gaussians bound the launch: their producers win the VALU arbitration on their CU
+    if (prio >= 2)
+        __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1)
+        __builtin_amdgcn_s_setprio(1);
+    const int pw = wave - 1;
+    const bool loader = pw == (kSepLoader ? kProducers : kProducers - 1);  // the wave that feeds the member ring
+    const bool works = !kSepLoader || pw < kProducers;
+    const int mps = 64 / Bs;                         // members per step
+    const int steps = (kChunk + mps - 1) / mps;      // steps per chunk
+    const int ms = lane / Bs, pb = lane - ms * Bs;
+    const bool lane_on = ms < mps && pb < nb;
+    const int bcol = b0 + (pb < nb ? pb : 0);
+    const int last = n - 1;
+    RowCache rc;
+    int jl_u[kMaxSteps];  // member slot inside the chunk of this lane's step u (kChunk: none)
+#pragma unroll
+    for (int u = 0; u < kMaxSteps; ++u) {
+        const int t = pw + u * kProducers, jl = t * mps + ms;
+        jl_u[u] = (works && t < steps && lane_on && jl < kChunk) ? jl : kChunk;
+    }
+    // Members reach the producers through LDS: ONE wave issues ONE global_load_lds_dwordx4 per chunk (64 lanes x 16 B = the 64
+    // members of a chunk, written lane-linear into a 4-slot ring) two phases ahead of its use.  No member ever sits in a
+    // register across a barrier, so there is nothing for the compiler to copy or to wait for inside the phase loop; the only
+    // vector-memory wait of a phase is the loader's "all but the newest DMA have landed" in front of the barrier.
+    const unsigned lds_m = (unsigned)(uintptr_t)&s_m[0][0];
+    auto dma = [&](int P) {  // members of the chunk consumed in global phase P (pass 1: P = p, pass 2: P = nphases + p)
+        if (loader) {
+            const int c = P < nphases ? P : P - nphases;
+            const float4* src = memb + off0 + min(c * kChunk + lane, last);  // past the last chunk: a harmless re-read of the last member
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_m + (unsigned)(P & 3) * (kChunk * 16));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src), "s"(dst)
+                         : "memory");
+        }
+    };
+    auto landed = [&]() {  // every DMA but the newest has landed (one DMA is issued per phase, always)
+        if (loader) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    };
+    // ---- pass 1: transformed coordinates of every member ----
+    dma(0), dma(1);
+    landed();
+    lds_barrier();  // chunk 0 of the member ring is visible
+    for (int p = 0; p < nphases; ++p) {
+        dma(p + 2);
+        if (p < nchunks) {
+            float* slot = s_q + (p % kSlots) * kSlotFloats + pb * 4;
+            const int left = n - p * kChunk;  // members from this chunk on
+#pragma unroll
+            for (int u = 0; u < kMaxSteps; ++u) {
+                if (jl_u[u] < left && jl_u[u] < kChunk) {
+                    const int jl = jl_u[u];
+                    const float4 pt = s_m[p & 3][jl];
+                    rc.fetch(tabT, B, bcol, __float_as_int(pt.w));
+                    f2 gxy;
+                    float gz;
+                    rc.apply(pt, gxy, gz);
+                    float* dst = slot + (jl >> 2) * (3 * kBL * 4) + (jl & 3);
+                    dst[0] = gxy.x, dst[4 * kBL] = gxy.y, dst[8 * kBL] = gz;
+                }
+            }
+        }
+        landed();
+        TL_BARRIER(0, p);
+    }
+    // ---- pass 2: Mahalanobis terms (needs the mean of pass 1) ----
+    const InfoPk I = load_info_pk(info12, g);
+    lds_barrier();  // s_mean is complete
+    const f2 mxy = f2{s_mean[pb & 15], s_mean[kBL + (pb & 15)]};
+    const float mz = s_mean[2 * kBL + (pb & 15)];
+    for (int p = 0; p < nphases; ++p) {
+        const int P = nphases + p;
+        dma(P + 2);
+        if (p < nchunks) {
+            double* slot = s_t + (p % kSlots) * kSlotDoubles + pb * 2;
+            const int left = n - p * kChunk;
+#pragma unroll
+            for (int u = 0; u < kMaxSteps; ++u) {
+                if (jl_u[u] < left && jl_u[u] < kChunk) {
+                    const int jl = jl_u[u];
+                    const float4 pt = s_m[P & 3][jl];
+                    rc.fetch(tabT, B, bcol, __float_as_int(pt.w));
+                    f2 gxy;
+                    float gz;
+                    rc.apply(pt, gxy, gz);
+                    slot[(jl >> 1) * (kBL * 2) + (jl & 1)] = (double)mahalanobis_term_pk(I, gxy, gz, mxy, mz);
+                }
+            }
+        }
+        landed();
+        TL_BARRIER(1, p);
+    }
+    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in LDS after the workgroup has released it
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+int serial_small_threshold() {
+    static const int v = [] {
+        int t = 128;
+        if (const char* e = std::getenv("DMSA_SERIAL_SMALL")) t = std::atoi(e);
+        return t < 1 ? 1 : (t > kSmallMax ? kSmallMax : t);
+    }();
+    return v;
+}
+static int serial_long_log2() {  // Gaussians with >= 2^k members go to the latency tier (DMSA_SERIAL_LONG_LOG2)
+    static const int v = [] {
+        int t = 12;
+        if (const char* e = std::getenv("DMSA_SERIAL_LONG_LOG2")) t = std::atoi(e);
+        return t < 8 ? 8 : (t > 30 ? 30 : t);
+    }();
+    return v;
+}
+static int env_int(const char* name, int dflt, int lo, int hi) {
+    const char* e = std::getenv(name);
+    const int t = e ? std::atoi(e) : dflt;
+    return t < lo ? lo : (t > hi ? hi : t);
+}
+SerialShape serial_shape(int B) {
+    static const int bs_long = env_int("DMSA_SERIAL_BS_LONG", 8, 1, kBL), bs_mid = env_int("DMSA_SERIAL_BS", kBL, 1, kBL);
+    SerialShape s;
+    s.nsub_long = (B + bs_long - 1) / bs_long, s.Bs_long = (B + s.nsub_long - 1) / s.nsub_long;
+    s.nsub = (B + bs_mid - 1) / bs_mid, s.Bs = (B + s.nsub - 1) / s.nsub;
+    s.lanes = B <= 16 ? 16 : (B <= 32 ? 32 : 64);
+    s.nsub_small = (B + s.lanes - 1) / s.lanes;
+    return s;
+}
+void launch_size_classes(const int32_t* seg_off, const GaussCounts* counts, uint32_t* order, SerialCounts* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_size_classes, dim3(1), dim3(1024), 0, s, seg_off, counts, serial_small_threshold(), serial_long_log2(), order, out);
+}
+void launch_transpose_tables(const float* tables, int rows, int B, float* tablesT, hipStream_t s) {
+    const int total = rows * B * 3;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(k_transpose_tables, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, s, reinterpret_cast<const float4*>(tables), rows, B,
+                       reinterpret_cast<float4*>(tablesT));
+}
+void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tablesT, int B, const uint32_t* order,
+                             const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest) {
+    if (B <= 0) return;
+    const SerialShape sh = serial_shape(B);
+    const float4* info = reinterpret_cast<const float4*>(info12);
+    const float4* tabT = reinterpret_cast<const float4*>(tablesT);
+    const int n_long = sc.n_long, n_mid = sc.n_chain - sc.n_long;
+    // latency tier first (its longest chain bounds the batch), blocks in descending size; the other tiers fill the chip around it
+    if (n_long > 0)
+        hipLaunchKernelGGL((k_residuals_chain<8, true>), dim3((unsigned)n_long * sh.nsub_long), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
+                           sh.Bs_long, sh.nsub_long, 2, E, ldE);
+    if (n_mid > 0)
+        hipLaunchKernelGGL((k_residuals_chain<3, false>), dim3((unsigned)n_mid * sh.nsub), dim3(64 * 4), 0, s_rest, memb_local, seg_off, info, tabT, B,
+                           order + n_long, sh.Bs, sh.nsub, 0, E, ldE);
+    if (sc.n_small > 0) {
+        const int items = sc.n_small * sh.nsub_small;
+        const int per_block = 4 * (64 / sh.lanes);
+        const dim3 grid((items + per_block - 1) / per_block);
+        const uint32_t* ord = order + sc.n_chain;
+        if (sh.lanes == 16)
+            hipLaunchKernelGGL(k_residuals_small<16>, grid, dim3(256), 0, s_rest, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
+        else if (sh.lanes == 32)
+            hipLaunchKernelGGL(k_residuals_small<32>, grid, dim3(256), 0, s_rest, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
+        else
+            hipLaunchKernelGGL(k_residuals_small<64>, grid, dim3(256), 0, s_rest, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
+    }
+#ifdef DMSA_SERIAL_TIMELINE
+    if (std::getenv("DMSA_SERIAL_DEBUG") && n_long > 0) {
+        static long long h[2][16][64][2];
+        (void)hipStreamSynchronize(s_long);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tl), sizeof(h));
+        for (int pass = 0; pass < 2; ++pass)
+            for (int ph = 8; ph < 14; ++ph) {
+                fprintf(stderr, "[timeline] B=%d pass=%d phase=%d:", B, pass + 1, ph + 32);
+                const long long base = h[pass][0][ph][0];
+                for (int w = 0; w < 10; ++w) fprintf(stderr, " w%d[%lld,%lld]", w, h[pass][w][ph][0] - base, h[pass][w][ph][1] - base);
+                fprintf(stderr, "\n");
+            }
+    }
+#endif
+}
+
+}  // namespace dmsa

@@ -27,11 +27,19 @@ def stats(db_path):
         if "rocprim" in short:
             short = "rocprim::" + short.split("::")[-1][:48] + "<...>"
         print(f"{short[:72]:72s} {n:6d} {total / 1e3:10.1f} {avg / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * total / tot:6.2f}")
-    # per grid shape for the correspondence kernel
-    print("\n# k_residuals by launch shape (grid_y = evaluations per launch)")
-    for gy, n, avg in cur.execute(
-            "select grid_y, count(*), avg(end-start) from kernels where name like '%k_residuals%' group by grid_y order by grid_y"):
-        print(f"  evaluations/launch={gy:4d} launches={n:4d} avg_us={avg / 1e3:9.2f} us_per_evaluation={avg / 1e3 / max(1, gy):8.2f}")
+    # per launch shape for the correspondence kernels (grid_x/grid_y are in THREADS in rocprofv3's tables)
+    print("\n# correspondence kernels by launch shape (workgroups = grid / workgroup size)")
+    q = ("select name, grid_x, grid_y, workgroup_x, count(*), avg(end-start), min(end-start), max(end-start) from kernels "
+         "where name like '%k_residuals%' group by name, grid_x, grid_y order by name, grid_x, grid_y")
+    try:
+        rows = cur.execute(q).fetchall()
+    except sqlite3.OperationalError:
+        rows = [(n, gx, gy, 0, c, a, a, a) for n, gx, gy, c, a in cur.execute(
+            "select name, grid_x, grid_y, count(*), avg(end-start) from kernels where name like '%k_residuals%' group by name, grid_x, grid_y")]
+    for name, gx, gy, wx, n, avg, mn, mx in rows:
+        short = name.split("(")[0].replace("void ", "")
+        wg = f"{gx // wx}x{gy}" if wx else f"{gx}x{gy} threads"
+        print(f"  {short[:44]:44s} workgroups={wg:>12s} wg_size={wx:4d} launches={n:4d} avg_us={avg / 1e3:9.2f} min_us={mn / 1e3:9.2f} max_us={mx / 1e3:9.2f}")
 
 
 def pmc(root):
