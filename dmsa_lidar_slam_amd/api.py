@@ -23,12 +23,17 @@ class DmsaError(RuntimeError):
 class DmsaOptimizer:
     """One context == one GPU == one host thread (the reference's optimizer is not re-entrant either)."""
 
-    def __init__(self, device: int = 0, pose_table_host: bool = False, fixed_iters: bool = False, mirror_sums: bool = False,
-                 stage_timers: bool = False):
+    def __init__(self, device: int = 0, pose_table_host: bool = False, fixed_iters: bool = False, mirror_sums: bool | None = None,
+                 stage_timers: bool = False, fast_sums: bool = False):
+        """Default = the reference's summation order (bit-identical to the CPU restatement) with pose tables built on the device.
+        fast_sums=True selects the wave-parallel sums (DMSA_FLAG_FAST_SUMS: faster, but outside the 1e-4 pose tolerance after a few
+        iterations); mirror_sums is the round-1 spelling (mirror_sums=False == fast_sums=True)."""
         self._lib = capi.load_library()
         self._ctx = C.c_void_p()
+        if mirror_sums is not None:
+            fast_sums = not mirror_sums
         flags = (capi.FLAG_POSE_TABLE_HOST if pose_table_host else 0) | (capi.FLAG_FIXED_ITERS if fixed_iters else 0)
-        flags |= capi.FLAG_MIRROR_SUMS if mirror_sums else 0
+        flags |= capi.FLAG_FAST_SUMS if fast_sums else 0
         flags |= capi.FLAG_STAGE_TIMERS if stage_timers else 0
         rc = self._lib.dmsa_create(int(device), flags, C.byref(self._ctx))
         if rc != capi.DMSA_OK:
@@ -196,6 +201,15 @@ class DmsaOptimizer:
         self._check(self._lib.dmsa_normal_equations(self._ctx, P, a, capi.ptr(er, C.c_double), float(h), float(lam), capi.ptr(H, C.c_double),
                                                     capi.ptr(g, C.c_double)), "normal_equations")
         return H, g  # H is symmetric, so col-major == row-major
+
+    def detmathEval(self, fn: int, x, y=None) -> np.ndarray:
+        """include/dmsa_detmath.h evaluated on the device (fn 0 sin, 1 cos, 2 acos, 3 atan2(y, x)) -- parity tests."""
+        x = np.ascontiguousarray(x, np.float64)
+        yy = None if y is None else np.ascontiguousarray(y, np.float64)
+        out = np.zeros_like(x)
+        self._check(self._lib.dmsa_detmath_eval(self._ctx, int(fn), capi.ptr(x, C.c_double), capi.ptr(yy, C.c_double) if yy is not None else None, x.size,
+                                                capi.ptr(out, C.c_double)), "dmsa_detmath_eval")
+        return out
 
     def timing(self, reset: bool = False) -> capi.Timing:
         t = capi.Timing()

@@ -981,6 +981,8 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return DMSA_ERR_NO_DEVICE;
     dmsa_ctx* ctx = new (std::nothrow) dmsa_ctx();
     if (!ctx) return DMSA_ERR_NOMEM;
+    // the reference's summation order is the default; DMSA_FLAG_FAST_SUMS opts out (internally the default is the MIRROR_SUMS bit)
+    flags = (flags & DMSA_FLAG_FAST_SUMS) ? (flags & ~DMSA_FLAG_MIRROR_SUMS) : (flags | DMSA_FLAG_MIRROR_SUMS);
     ctx->device = device, ctx->flags = flags;
     if (const char* e = std::getenv("DMSA_K4_WGS")) ctx->cfg_num_wg = std::max(1, std::min(4000, std::atoi(e)));
     if (const char* e = std::getenv("DMSA_K4_BIG")) ctx->cfg_big_n = std::max(1, std::atoi(e));
@@ -1420,6 +1422,21 @@ int dmsa_get_timing(dmsa_ctx* ctx, dmsa_timing* t, int32_t reset) {
     return DMSA_OK;
 }
 
+int dmsa_detmath_eval(dmsa_ctx* ctx, int32_t fn, const double* x, const double* y, int64_t n, double* out) {
+    if (!ctx || !x || !out || n < 0 || fn < 0 || fn > 3 || (fn == 3 && !y)) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    DevBuf dx, dy, dout;
+    HIPCHK(dx.ensure((size_t)n * 8 + 8));
+    HIPCHK(dy.ensure((size_t)n * 8 + 8));
+    HIPCHK(dout.ensure((size_t)n * 8 + 8));
+    HIPCHK(hipMemcpyAsync(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (y) HIPCHK(hipMemcpyAsync(dy.p, y, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    launch_detmath_eval(fn, dx.as<double>(), dy.as<double>(), n, dout.as<double>(), ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return DMSA_OK;
+}
 int dmsa_get_trace(dmsa_ctx* ctx, dmsa_iter_trace* out, int32_t capacity) {
     if (!ctx || !out || capacity < 0) return DMSA_ERR_INVALID;
     const int n = std::min<int>(capacity, (int)ctx->trace.size());

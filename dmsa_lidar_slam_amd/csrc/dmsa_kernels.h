@@ -83,6 +83,9 @@ void launch_window_pose_tables(const double* ctrl, const double* stamps, const d
 // frames: B x F x 6 doubles global poses -> B x (F+1) x 12
 void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tables, hipStream_t s);
 
+// include/dmsa_detmath.h evaluated on the device (parity tests): fn 0 sin, 1 cos, 2 acos, 3 atan2(y, x)
+void launch_detmath_eval(int fn, const double* x, const double* y, int64_t n, double* out, hipStream_t s);
+
 // ---- K2: PCL-exact voxel lattice + keys -----------------------------------------------------------------
 void launch_block_aabb(const float4* global, int64_t n, float* aabb /* nb x 8 */, hipStream_t s);
 void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, bool compress, LatticeTable* tables /* [2] */,

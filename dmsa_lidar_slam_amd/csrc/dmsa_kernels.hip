@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 
+#include "../../include/dmsa_detmath.h"
 #include "../../include/dmsa_hip.h"
 
 namespace dmsa {
@@ -145,7 +146,8 @@ void launch_shift_points(float4* pts, int64_t n, float ox, float oy, float oz, f
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1 — dense pose tables (double math, one thread per dense pose)
+// K1 — dense pose tables (double math, one thread per dense pose).  sin / cos / acos / atan2 come from include/dmsa_detmath.h:
+// fixed sequences of correctly rounded IEEE operations, so the tables are bit-identical to the host's and the oracle's.
 // ------------------------------------------------------------------------------------------------------------
 struct D3 {
     double x, y, z;
@@ -156,8 +158,8 @@ __device__ __forceinline__ void d_so3_exp(const D3 w, double R[9]) {
         R[0] = 1, R[1] = 0, R[2] = 0, R[3] = 0, R[4] = 1, R[5] = 0, R[6] = 0, R[7] = 0, R[8] = 1;
         return;
     }
-    const double s = sin(theta) / theta;
-    const double sh = sin(0.5 * theta);
+    const double s = dmsa_det::det_sin(theta) / theta;
+    const double sh = dmsa_det::det_sin(0.5 * theta);
     const double c = 2.0 * sh * sh / (theta * theta);
     const double t2 = theta * theta;
     R[0] = 1.0 + c * (w.x * w.x - t2);
@@ -175,8 +177,8 @@ __device__ __forceinline__ void d_quat_from_axang(const D3 a, double q[4]) {
     const double ang = sqrt(sq);
     D3 ax = a;
     if (sq > 0.0) ax = D3{a.x / ang, a.y / ang, a.z / ang};
-    const double sh = sin(0.5 * ang);
-    q[0] = cos(0.5 * ang), q[1] = sh * ax.x, q[2] = sh * ax.y, q[3] = sh * ax.z;
+    const double sh = dmsa_det::det_sin(0.5 * ang);
+    q[0] = dmsa_det::det_cos(0.5 * ang), q[1] = sh * ax.x, q[2] = sh * ax.y, q[3] = sh * ax.z;
 }
 __device__ __forceinline__ D3 d_slerp_axang(const D3 a, const D3 b, const double t) {
     double q1[4], q2[4];
@@ -189,15 +191,15 @@ __device__ __forceinline__ D3 d_slerp_axang(const D3 a, const D3 b, const double
     if (ad >= one) {
         s0 = 1.0 - t, s1 = t;
     } else {
-        const double th = acos(ad), sn = sin(th);
-        s0 = sin((1.0 - t) * th) / sn;
-        s1 = sin(t * th) / sn;
+        const double th = dmsa_det::det_acos(ad), sn = dmsa_det::det_sin(th);
+        s0 = dmsa_det::det_sin((1.0 - t) * th) / sn;
+        s1 = dmsa_det::det_sin(t * th) / sn;
     }
     if (d < 0.0) s1 = -s1;
     const double qw = s0 * q1[0] + s1 * q2[0], qx = s0 * q1[1] + s1 * q2[1], qy = s0 * q1[2] + s1 * q2[2], qz = s0 * q1[3] + s1 * q2[3];
     double n = sqrt(qx * qx + qy * qy + qz * qz);
     if (n == 0.0) return D3{0.0, 0.0, 0.0};
-    const double angle = 2.0 * atan2(n, fabs(qw));
+    const double angle = 2.0 * dmsa_det::det_atan2(n, fabs(qw));
     if (qw < 0.0) n = -n;
     return D3{(qx / n) * angle, (qy / n) * angle, (qz / n) * angle};
 }
@@ -275,6 +277,16 @@ __global__ __launch_bounds__(256) void k_keyframe_pose_tables(const double* __re
     out[0] = (float)R[0], out[1] = (float)R[1], out[2] = (float)R[2], out[3] = (float)p[3];
     out[4] = (float)R[3], out[5] = (float)R[4], out[6] = (float)R[5], out[7] = (float)p[4];
     out[8] = (float)R[6], out[9] = (float)R[7], out[10] = (float)R[8], out[11] = (float)p[5];
+}
+
+__global__ __launch_bounds__(256) void k_detmath_eval(int fn, const double* __restrict__ x, const double* __restrict__ y, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = x[i];
+    out[i] = fn == 0 ? dmsa_det::det_sin(a) : fn == 1 ? dmsa_det::det_cos(a) : fn == 2 ? dmsa_det::det_acos(a) : dmsa_det::det_atan2(y[i], a);
+}
+void launch_detmath_eval(int fn, const double* x, const double* y, int64_t n, double* out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_detmath_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fn, x, y, n, out);
 }
 
 void launch_window_pose_tables(const double* ctrl, const double* stamps, const double* fh_w, const double* traj_time, int B, int C, int n_t,

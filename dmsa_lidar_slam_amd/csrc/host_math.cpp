@@ -2,6 +2,8 @@
 // reproducible across compilers (the pose table built here feeds float casts and voxel keys downstream).
 #include "host_math.h"
 
+#include "../../include/dmsa_detmath.h"
+
 #include <algorithm>
 #include <cstring>
 #include <limits>
@@ -29,8 +31,8 @@ Mat3 transposed(const Mat3& A) {
 Mat3 so3_exp(Vec3 w) {
     const double theta = length(w);
     if (theta < 0.00001) return Mat3::identity();
-    const double s = std::sin(theta) / theta;
-    const double sh = std::sin(0.5 * theta);
+    const double s = dmsa_det::det_sin(theta) / theta;  // the trigonometry of the pose-table path is include/dmsa_detmath.h on host AND device
+    const double sh = dmsa_det::det_sin(0.5 * theta);
     const double c = 2.0 * sh * sh / (theta * theta);
     const double t2 = theta * theta;
     Mat3 R;
@@ -91,8 +93,8 @@ inline Quat quat_from_axang(Vec3 a) {
     const double ang = std::sqrt(sq);
     Vec3 ax = a;
     if (sq > 0.0) ax = {a.x / ang, a.y / ang, a.z / ang};
-    const double sh = std::sin(0.5 * ang);
-    return {std::cos(0.5 * ang), sh * ax.x, sh * ax.y, sh * ax.z};
+    const double sh = dmsa_det::det_sin(0.5 * ang);
+    return {dmsa_det::det_cos(0.5 * ang), sh * ax.x, sh * ax.y, sh * ax.z};
 }
 }  // namespace
 
@@ -105,15 +107,15 @@ Vec3 slerp_axang(Vec3 a, Vec3 b, double t) {
     if (ad >= one) {
         s0 = 1.0 - t, s1 = t;
     } else {
-        const double th = std::acos(ad), sn = std::sin(th);
-        s0 = std::sin((1.0 - t) * th) / sn;
-        s1 = std::sin(t * th) / sn;
+        const double th = dmsa_det::det_acos(ad), sn = dmsa_det::det_sin(th);
+        s0 = dmsa_det::det_sin((1.0 - t) * th) / sn;
+        s1 = dmsa_det::det_sin(t * th) / sn;
     }
     if (d < 0.0) s1 = -s1;
     const Quat q{s0 * q1.w + s1 * q2.w, s0 * q1.x + s1 * q2.x, s0 * q1.y + s1 * q2.y, s0 * q1.z + s1 * q2.z};
     double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
     if (n == 0.0) return {0.0, 0.0, 0.0};
-    const double angle = 2.0 * std::atan2(n, std::fabs(q.w));
+    const double angle = 2.0 * dmsa_det::det_atan2(n, std::fabs(q.w));
     if (q.w < 0.0) n = -n;
     return {(q.x / n) * angle, (q.y / n) * angle, (q.z / n) * angle};
 }

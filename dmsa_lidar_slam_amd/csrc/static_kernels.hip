@@ -2,6 +2,8 @@
 // ((dx*dx + dy*dy) + dz*dz) and the visibility residual must round like the reference's scalar code.
 #include "static_kernels.h"
 
+#include "../../include/dmsa_detmath.h"
+
 #include <cfloat>
 #include <climits>
 
@@ -503,8 +505,8 @@ __device__ __forceinline__ void pcl_roots(const float* m /* row-major 3x3 */, fl
     const float rho = sqrtf(-a_over_3);
     // float atan2 / cos / sin as a correctly rounded libm returns them: evaluated in double, rounded once (glibc's sinf / cosf work
     // the same way; device and host double functions agree after the rounding, so normals are reproducible across the two)
-    const float theta = (float)atan2((double)sqrtf(-q), (double)half_b) * s_inv3;
-    const float cos_theta = (float)cos((double)theta), sin_theta = (float)sin((double)theta);
+    const float theta = (float)dmsa_det::det_atan2((double)sqrtf(-q), (double)half_b) * s_inv3;
+    const float cos_theta = (float)dmsa_det::det_cos((double)theta), sin_theta = (float)dmsa_det::det_sin((double)theta);
     roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
     roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);

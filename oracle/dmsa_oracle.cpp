@@ -19,8 +19,16 @@
 // centered^T*centered, VectorXf::mean(), MatrixXd products) this file accumulates in double and rounds
 // once — the correctly rounded value every float order approximates.  EigenSolver<Matrix3f> (general
 // QR) is replaced by a fixed-sweep symmetric Jacobi iteration in float.  Build with -ffp-contract=off.
+//
+// sin / cos / acos / atan2 of the pose-table path (axang2rotm, slerp; the float trigonometry of the normals) are NOT glibc's:
+// they are include/dmsa_detmath.h, fixed sequences of correctly rounded IEEE operations (fdlibm's algorithms) shared with the
+// product's host code and device kernels, so that a pose table built on the GPU can be compared with this file bit for bit.
+// Against glibc they differ by at most 1 ulp (atan2: 2 ulp outside the first quadrant) in ~3 % of the arguments
+// (tests/test_detmath.py) -- a deviation from the reference, which calls glibc through Eigen.
 
 #include "dmsa_oracle.h"
+
+#include "../include/dmsa_detmath.h"
 
 #include <algorithm>
 #include <cmath>
@@ -65,8 +73,8 @@ static inline double norm3(const double* a) { return std::sqrt(a[0] * a[0] + a[1
 static M3 axang2rotm(const double* w) {
     const double theta = norm3(w);
     if (theta < 0.00001) return eye3();
-    const double s = std::sin(theta) / theta;
-    const double sh = std::sin(0.5 * theta);
+    const double s = dmsa_det::det_sin(theta) / theta;  // sin / cos / acos / atan2 of the pose-table path: include/dmsa_detmath.h
+    const double sh = dmsa_det::det_sin(0.5 * theta);
     const double c = 2.0 * sh * sh / (theta * theta);
     const double x = w[0], y = w[1], z = w[2];
     M3 R;
@@ -138,8 +146,8 @@ static void slerp(const double* aa1, const double* aa2, double t, double* out) {
         if (sq > 0.0) {  // Eigen normalized(): zero vector stays zero
             ax[0] = a[0] / ang, ax[1] = a[1] / ang, ax[2] = a[2] / ang;
         }
-        const double sh = std::sin(0.5 * ang);
-        qs[i][0] = std::cos(0.5 * ang);
+        const double sh = dmsa_det::det_sin(0.5 * ang);
+        qs[i][0] = dmsa_det::det_cos(0.5 * ang);
         qs[i][1] = sh * ax[0], qs[i][2] = sh * ax[1], qs[i][3] = sh * ax[2];
     }
     const double one = 1.0 - std::numeric_limits<double>::epsilon();
@@ -150,10 +158,10 @@ static void slerp(const double* aa1, const double* aa2, double t, double* out) {
         scale0 = 1.0 - t;
         scale1 = t;
     } else {
-        const double theta = std::acos(absD);
-        const double sinTheta = std::sin(theta);
-        scale0 = std::sin((1.0 - t) * theta) / sinTheta;
-        scale1 = std::sin(t * theta) / sinTheta;
+        const double theta = dmsa_det::det_acos(absD);
+        const double sinTheta = dmsa_det::det_sin(theta);
+        scale0 = dmsa_det::det_sin((1.0 - t) * theta) / sinTheta;
+        scale1 = dmsa_det::det_sin(t * theta) / sinTheta;
     }
     if (d < 0.0) scale1 = -scale1;
     double q[4];
@@ -161,7 +169,7 @@ static void slerp(const double* aa1, const double* aa2, double t, double* out) {
     // AngleAxisd(q)
     double n = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     if (n != 0.0) {
-        const double angle = 2.0 * std::atan2(n, std::fabs(q[0]));
+        const double angle = 2.0 * dmsa_det::det_atan2(n, std::fabs(q[0]));
         if (q[0] < 0.0) n = -n;
         out[0] = (q[1] / n) * angle, out[1] = (q[2] / n) * angle, out[2] = (q[3] / n) * angle;
     } else {
@@ -1389,6 +1397,11 @@ int orc_barycentric_rational(const double* x, const double* y, int n, int d, con
     return DMSA_OK;
 }
 
+int orc_detmath_eval(int fn, const double* x, const double* y, long n, double* out) {
+    for (long i = 0; i < n; ++i)
+        out[i] = fn == 0 ? dmsa_det::det_sin(x[i]) : fn == 1 ? dmsa_det::det_cos(x[i]) : fn == 2 ? dmsa_det::det_acos(x[i]) : dmsa_det::det_atan2(y[i], x[i]);
+    return 0;
+}
 int orc_window_pose_table(const dmsa_window_problem* p, float* table, double* dense_transl) {
     dmsa_window_problem q = *p;
     q.num_points = 0, q.num_static = 0, q.use_imu = 0;
@@ -2257,9 +2270,9 @@ static void pclComputeRoots(const float m[3][3], float* roots) {
     if (q > 0.0f) q = 0.0f;
     const float rho = std::sqrt(-a_over_3);
     // std::atan2 / cos / sin on floats, stated as their correctly rounded values (double evaluation, one rounding)
-    const float theta = (float)std::atan2((double)std::sqrt(-q), (double)half_b) * s_inv3;
-    const float cos_theta = (float)std::cos((double)theta);
-    const float sin_theta = (float)std::sin((double)theta);
+    const float theta = (float)dmsa_det::det_atan2((double)std::sqrt(-q), (double)half_b) * s_inv3;
+    const float cos_theta = (float)dmsa_det::det_cos((double)theta);
+    const float sin_theta = (float)dmsa_det::det_sin((double)theta);
     roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
     roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);

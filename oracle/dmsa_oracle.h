@@ -37,6 +37,8 @@ int  orc_barycentric_rational(const double* x, const double* y, int n, int d, co
 /* updateTrajDenseTforms (ContinuousTrajectory.h:189-226) for the relative poses in p.
  * table: n_total x 12 floats ([R|t] row-major 3x4); dense_transl (optional): 3 x n_total col-major doubles */
 int orc_window_pose_table(const dmsa_window_problem* p, float* table, double* dense_transl);
+/* include/dmsa_detmath.h on the host: fn 0 sin, 1 cos, 2 acos, 3 atan2(y, x) */
+int orc_detmath_eval(int fn, const double* x, const double* y, long n, double* out);
 /* per-keyframe transforms of MapManagement::updateGlobalPoints (MapManagement.h:128-138): F x 12 floats */
 int orc_keyframe_pose_table(const dmsa_keyframe_problem* p, float* table);
 /* p_g = T[row] * (x,y,z,1) exactly as Matrix4f*Vector4f evaluates (ContinuousTrajectory.h:151) */

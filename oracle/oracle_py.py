@@ -118,6 +118,16 @@ def barycentric_rational(x, y, t, d=2):
     return out
 
 
+def detmath_eval(fn: int, x, y=None):
+    """include/dmsa_detmath.h compiled for the host: fn 0 sin, 1 cos, 2 acos, 3 atan2(y, x)."""
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.zeros_like(x) if y is None else np.ascontiguousarray(y, np.float64)
+    out = np.zeros_like(x)
+    lib().orc_detmath_eval.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_long, C.POINTER(C.c_double)]
+    lib().orc_detmath_eval(int(fn), capi.ptr(x, C.c_double), capi.ptr(y, C.c_double), x.size, capi.ptr(out, C.c_double))
+    return out
+
+
 def window_pose_table(prob: ContinuousTrajectory):
     n_t = prob.trajTime.shape[0]
     table = np.zeros((n_t, 12), np.float32)

@@ -73,7 +73,7 @@ def test_cpp_wrapper_matches_python_mirror_and_oracle(demo, tmp_path, hip, orc):
     rt = np.fromfile(tmp_path / "out_rt.f64").reshape(-1, 3)
     gl = np.fromfile(tmp_path / "out_global.f32", dtype=np.float32).reshape(-1, 4)
     p_py, p_ref = prob.copy(), prob.copy()
-    opt = hip.DmsaOptimizer(pose_table_host=True, mirror_sums=True)
+    opt = hip.DmsaOptimizer()
     rep = opt.optimizeSet(p_py, s)
     assert f"iterations {rep.iterations} stop_reason {rep.stop_reason}" in r.stdout
     assert np.array_equal(ro, p_py.relOrientations) and np.array_equal(rt, p_py.relTranslations)

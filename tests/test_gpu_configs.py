@@ -28,7 +28,7 @@ def _parity_run(hip, orc, prob, s, window=True):
     p_ref, p_gpu = prob.copy(), prob.copy()
     fn = orc.optimize_window if window else orc.optimize_keyframes
     rep_ref, _, trace = fn(p_ref, s)
-    opt = hip.DmsaOptimizer(pose_table_host=True, mirror_sums=True)
+    opt = hip.DmsaOptimizer()
     rep = opt.optimizeSet(p_gpu, s)
     assert (rep.iterations, rep.stop_reason, rep.evaluations) == (rep_ref.iterations, rep_ref.stop_reason, rep_ref.evaluations)
     for a, b in zip(trace, opt.trace()):
@@ -78,8 +78,8 @@ def test_keyframes_gravity_and_odometry_rows(hip, orc):
     plain.useOdometryErrorTerms = False
     plain.useGravityErrorTerms = False
     a, b = prob.copy(), plain
-    hip.DmsaOptimizer(pose_table_host=True, mirror_sums=True).optimizeSet(a, s)
-    hip.DmsaOptimizer(pose_table_host=True, mirror_sums=True).optimizeSet(b, s)
+    hip.DmsaOptimizer().optimizeSet(a, s)
+    hip.DmsaOptimizer().optimizeSet(b, s)
     assert _pose_diff(orc, a, b)[0] > 1e-7
 
 
@@ -102,7 +102,7 @@ def test_keyframes_fast_path_equivalent(hip, orc):
     s = DmsaOptimSettings.keyframe_map(num_iter=3)
     p_ref, p_gpu = prob.copy(), prob.copy()
     rep_ref, _, trace = orc.optimize_keyframes(p_ref, s)
-    opt = hip.DmsaOptimizer()
+    opt = hip.DmsaOptimizer(fast_sums=True)
     rep = opt.optimizeSet(p_gpu, s)
     assert rep.iterations == rep_ref.iterations and rep.stop_reason == rep_ref.stop_reason
     tr = opt.trace()
@@ -135,7 +135,7 @@ def test_two_frame_keyframe_set_aborts_like_reference(hip, orc):
     s = DmsaOptimSettings.keyframe_map(num_iter=3)
     p_ref, p_gpu = prob.copy(), prob.copy()
     rep_ref, _, _ = orc.optimize_keyframes(p_ref, s)
-    rep = hip.DmsaOptimizer(pose_table_host=True, mirror_sums=True).optimizeSet(p_gpu, s)
+    rep = hip.DmsaOptimizer().optimizeSet(p_gpu, s)
     assert (rep.stop_reason, rep.iterations) == (rep_ref.stop_reason, rep_ref.iterations)
     assert _pose_diff(orc, p_ref, p_gpu)[0] < 1e-12
 
@@ -160,7 +160,7 @@ def test_config3_full_size_structure_and_residuals(hip, orc, full_window):
 
     results = {}
     for mirror in (True, False):
-        opt = hip.DmsaOptimizer(pose_table_host=True, mirror_sums=mirror)
+        opt = hip.DmsaOptimizer(fast_sums=not mirror)
         opt.upload(prob)
         opt.poseTables(prob.getPoseParameters())
         got = opt.updateGlobalPoints(0)
@@ -226,7 +226,7 @@ def test_long_pose_tables(hip, orc, dt_res):
     assert prob.trajTime.shape[0] > 900
     s = DmsaOptimSettings.sliding_window(num_iter=2)
     _parity_run(hip, orc, prob, s)
-    opt = hip.DmsaOptimizer(pose_table_host=True)
+    opt = hip.DmsaOptimizer(fast_sums=True)
     opt.upload(prob)
     opt.poseTables(prob.getPoseParameters())
     opt.updateGlobalPoints(0, download=False)
@@ -290,7 +290,7 @@ def test_parity_path_trajectories_bit_identical(orc, case):
     else:  # 13 frames: P = 72 > 64 takes the other branch of the block-size rule
         p, s, run = synth.keyframe_problem(seed=4, frames=13, rings=16, az_steps=96, arc=0.8), DmsaOptimSettings.keyframe_map(num_iter=3), orc.optimize_keyframes
     a, b = p.copy(), p.copy()
-    g = DmsaOptimizer(device=0, pose_table_host=True, mirror_sums=True)
+    g = DmsaOptimizer(device=0)
     ra, tr_a = g.optimizeSet(a, s), g.trace()
     g.close()
     rb, _, tr_b = run(b, s)

@@ -24,14 +24,14 @@ def test_context_reuse_across_sizes_and_models(hip, orc):
              (synth.window_problem(seed=32, scans=4, rings=32, az_steps=256, num_static=9000), s_w),
              (synth.keyframe_problem(seed=33, frames=5, rings=16, az_steps=128, arc=0.3), s_k),
              (synth.window_problem(seed=31, scans=2, rings=16, az_steps=128, num_static=2000), s_w)]
-    shared = hip.DmsaOptimizer(pose_table_host=True, mirror_sums=True)
+    shared = hip.DmsaOptimizer()
     got = []
     for p, s in probs:
         q = p.copy()
         shared.optimizeSet(q, s)
         got.append(_poses(q))
         fresh = p.copy()
-        hip.DmsaOptimizer(pose_table_host=True, mirror_sums=True).optimizeSet(fresh, s)
+        hip.DmsaOptimizer().optimizeSet(fresh, s)
         assert np.array_equal(got[-1], _poses(fresh))
     assert np.array_equal(got[0], got[3])
 

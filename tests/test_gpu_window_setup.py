@@ -55,7 +55,7 @@ def test_sequence_of_windows_matches_oracle_chain(setup, orc, use_imu):
     setup and optimiser: the problems handed to optimizeSet must be bit-identical, the optimised poses within 1e-4 m / 1e-4 rad."""
     clouds, traj = synth.scan_sequence(seed=2, scans=7, rings=32, az_steps=256)
     settings = DmsaOptimSettings.sliding_window(use_imu=use_imu, num_iter=3)
-    gpu = DmsaOptimizer(device=0, pose_table_host=True, mirror_sums=True)
+    gpu = DmsaOptimizer(device=0)
     ow = orc.WindowSetup()
     buf_p, buf_o = (_imu_buffer(ws.ImuBuffer, traj, 9), _imu_buffer(orc.ImuBuffer, traj, 9)) if use_imu else (None, None)
     old_p = old_o = None
