@@ -200,11 +200,13 @@ struct dmsa_ctx {
     double level_res[2] = {0, 0};
     // Gaussians
     DevBuf d_memb_local, d_memb_idx, d_memb_g, d_seg_off, d_info12, d_wg_seg;
-    DevBuf d_order_key, d_order_key_s, d_order_val, d_order;  // reference-order path: Gaussians by descending size class
+    DevBuf d_order;  // reference-order path: Gaussians by descending size class
     DevBuf d_tablesT;                                          // pose tables of the current batch, transposed ([row][evaluation][12])
     bool order_valid = false;
-    bool serial_classes = true;  // DMSA_MIRROR_ROWS=1: previous generation (size sort + DPP-row kernel) for A/B timing
+    DevBuf d_fit_sums;           // six centred product sums per Gaussian (fit kernels -> finish kernel)
+    bool fit_guess_valid = false;  // serial_counts of the previous voxelisation may size this one's speculative fit launches
     SerialCounts serial_counts{0, 0, 0, 0};
+    int global_table = 0;  // index (in the current batch) of the pose table d_global was computed with
     bool serial_two_streams = true;  // DMSA_SERIAL_STREAMS=1: all tiers of the reference-order correspondence kernels on one stream
     DevBuf d_memb_tile, d_tiles, d_tile_rows, d_fallback, d_pad_off;
     int num_tiles = 0, num_fallback = 0, tile_max_rows = 0, tile_max_gauss = 0;
@@ -347,8 +349,10 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
     HIPCHK(ctx->d_seg_off.ensure((2 * n + 2) * 4));
     HIPCHK(ctx->d_info12.ensure((2 * n / 2 + 16) * 48));  // sets have >= 2 members (two distinct ids)
     HIPCHK(ctx->d_wg_seg.ensure(4096 * 4));
-    if (ctx->flags & DMSA_FLAG_MIRROR_SUMS)
-        for (DevBuf* b : {&ctx->d_order_key, &ctx->d_order_key_s, &ctx->d_order_val, &ctx->d_order}) HIPCHK(b->ensure((n + 16) * 4));
+    if (ctx->flags & DMSA_FLAG_MIRROR_SUMS) {
+        HIPCHK(ctx->d_order.ensure((n + 16) * 4));
+        HIPCHK(ctx->d_fit_sums.ensure((n + 16) * 6 * 8));
+    }
     // tiled correspondence kernels: windows of 3T/4 members plus own-tile Gaussians (> T/4 members each) and their
     // neighbours: tiles <= (4/3 + 8)*Mm/T + 1 with Mm <= 2n; one row list of `rows` entries per tile
     const size_t max_tiles = 41 * n / (size_t)tile_points() + 64;  // windows + own tiles + one head per kTileGauss Gaussians (M <= n)
@@ -448,6 +452,7 @@ void host_set_params(dmsa_ctx* ctx, const double* p) {
 }
 
 int transform_points(dmsa_ctx* ctx, int b) {
+    ctx->global_table = b;  // the fit re-derives the global coordinates of the members from this table
     const float4* table = ctx->d_tables.as<float4>() + (size_t)b * ctx->rows * 3;
     if (ctx->model == MODEL_KEYFRAMES)
         launch_transform_normals(ctx->d_local.as<float4>(), ctx->d_nlocal.as<float4>(), table, ctx->d_global.as<float4>(), ctx->d_nglobal.as<float4>(),
@@ -457,6 +462,24 @@ int transform_points(dmsa_ctx* ctx, int b) {
     HIPCHK(hipGetLastError());
     return DMSA_OK;
 }
+
+// DMSA_HOST_TIMELINE=1: host-side time stamps of the last iteration's phases (where the host enqueues, where it waits)
+struct HostTimeline {
+    bool on = std::getenv("DMSA_HOST_TIMELINE") != nullptr;
+    std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> marks;
+    void reset() { marks.clear(); }
+    void mark(const char* what) {
+        if (on) marks.emplace_back(what, std::chrono::steady_clock::now());
+    }
+    void print() const {
+        if (!on || marks.size() < 2) return;
+        std::fprintf(stderr, "[host timeline]");
+        for (size_t i = 1; i < marks.size(); ++i)
+            std::fprintf(stderr, " %s %.0f |", marks[i].first, std::chrono::duration<double, std::micro>(marks[i].second - marks[i - 1].second).count());
+        std::fprintf(stderr, " total %.0f us\n", std::chrono::duration<double, std::micro>(marks.back().second - marks.front().second).count());
+    }
+};
+HostTimeline g_tl;
 
 // ---- Gaussians (DmsaOptimizer.h:78-96) ---------------------------------------------------------------------
 // `overlap` (optional) runs on the host after every voxelisation kernel has been enqueued and before the counts are read
@@ -616,7 +639,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                            reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_memb_tile.as<float4>(), ctx->d_tile_rows.as<int32_t>(),
                            ctx->d_pad_off.as<int32_t>(), ctx->stream);
     }
-    const bool classes_on = !tiles_on && (ctx->flags & DMSA_FLAG_MIRROR_SUMS) && ctx->serial_classes;
+    const bool classes_on = !tiles_on && (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0;
     if (classes_on)  // size classes of the reference-order correspondence kernels: needs only seg_off, so it runs before the read-back
         launch_size_classes(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_order.as<uint32_t>(),
                             reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts) + sizeof(TileCounts)), ctx->stream);
@@ -627,6 +650,43 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     // recorded BEFORE the fit, not on the stream).
     const bool early_fit = tiles_on && (size_t)(ctx->rows + 1) * 48 <= 56 * 1024;
     HIPCHK(hipEventRecord(ctx->ev_counts, ctx->stream));
+    // Default path: the fit (oracle's tree order) is enqueued BEHIND the read-back as well, with the previous iteration's class
+    // counts (+ margin) as grids -- the kernels take the true ranges from device memory, surplus workgroups exit, and whatever the
+    // guess missed is launched after sync #2.  The three classes run side by side on two streams (each is latency-bound on its own).
+    const int32_t* d_sc = reinterpret_cast<const int32_t*>(ctx->d_counts.as<char>() + sizeof(GaussCounts) + sizeof(TileCounts));
+    const float* fit_table = ctx->d_tables.as<float>() + (size_t)ctx->global_table * ctx->rows * 12;
+    int fit_launched[3] = {0, 0, 0}, finish_launched = 0;
+    auto launch_fit = [&](const int first[3], const int tasks[3], int finish_gauss) -> int {
+        ScopedTimer tm(ctx, T_FIT);
+        const bool two = ctx->dual_stream && (tasks[1] > 0 || tasks[2] > 0);
+        if (two) {
+            HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        }
+        hipStream_t s2 = two ? ctx->stream2 : ctx->stream;
+        launch_gauss_fit_tree(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, 0, first[0], tasks[0],
+                              ctx->d_fit_sums.as<double>(), ctx->stream);
+        launch_gauss_fit_tree(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, 1, first[1], tasks[1],
+                              ctx->d_fit_sums.as<double>(), s2);
+        launch_gauss_fit_tree(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, 2, first[2], tasks[2],
+                              ctx->d_fit_sums.as<double>(), s2);
+        launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), true, ctx->stream);
+        if (two) {
+            HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
+        launch_gauss_fit_finish(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_fit_sums.as<double>(), finish_gauss, ctx->d_info12.as<float>(), ctx->stream);
+        HIPCHK(hipGetLastError());
+        return DMSA_OK;
+    };
+    if (classes_on && ctx->fit_guess_valid) {
+        const SerialCounts& pg = ctx->serial_counts;  // previous iteration
+        const int first[3] = {0, 0, 0};
+        auto grow = [](int v) { return v + v / 8 + 16; };
+        fit_launched[0] = grow(pg.n_long), fit_launched[1] = grow(pg.n_chain - pg.n_long), fit_launched[2] = grow(pg.n_small);
+        finish_launched = grow(pg.n_chain + pg.n_small);
+        CHK(launch_fit(first, fit_launched, finish_launched));
+    }
     if (early_fit) {
         ScopedTimer tm(ctx, T_FIT);
         launch_fit_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_tables.as<float>(), ctx->rows + 1, ctx->d_tiles.as<TileDesc>(),
@@ -634,7 +694,9 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                          ctx->d_info12.as<float>(), ctx->stream);
         launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), false, ctx->stream);
     }
+    g_tl.mark("voxel enq");
     if (overlap) CHK(overlap());
+    g_tl.mark("jacobian batch host+enq");
     {  // sync #2: M sizes every later launch
         hipError_t e;
         while ((e = hipEventQuery(ctx->ev_counts)) == hipErrorNotReady) {
@@ -642,6 +704,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         (void)hipGetLastError();  // see sync_spin
         HIPCHK(e);
     }
+    g_tl.mark("sync#2 wait");
     const GaussCounts h = ctx->h_rb->g;
     htc = ctx->h_rb->t;
     for (int l = 0; l < 2; ++l) {
@@ -673,21 +736,18 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                              ctx->d_tiles.as<TileDesc>(), reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
                              ctx->d_info12.as<float>(), ctx->stream);
         const int M_all = h.level[0].num_gauss + h.level[1].num_gauss;
-        if (!tiles_on && (ctx->flags & DMSA_FLAG_MIRROR_SUMS) && M_all > 0) {
-            // parity path: order the Gaussians by size once (radix sort of M keys; the row-cooperative residual kernel wants the long
-            // chains first), then one fit for both levels in the oracle's blocked summation order
-            const bool ordered = mirror_uses_rows();
-            ctx->serial_counts = classes_on ? ctx->h_rb->sc : SerialCounts{0, 0, 0, 0};
-            if (ordered && !classes_on) {
-                launch_gauss_size_keys(ctx->d_seg_off.as<int32_t>(), M_all, ctx->d_order_key.as<uint32_t>(), ctx->d_order_val.as<uint32_t>(), ctx->stream);
-                HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_order_key.as<uint32_t>(), ctx->d_order_key_s.as<uint32_t>(),
-                                          ctx->d_order_val.as<uint32_t>(), ctx->d_order.as<uint32_t>(), (size_t)M_all, 32, ctx->stream));
-            }
-            launch_gauss_fit_blocked(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(),
-                                     ordered ? ctx->d_order.as<uint32_t>() : nullptr, M_all, ctx->d_info12.as<float>(), ctx->stream);
-            ctx->order_valid = ordered;
+        if (classes_on) {
+            // whatever the pre-sync launches did not cover (first iteration, or a class that grew by more than the margin)
+            ctx->serial_counts = ctx->h_rb->sc;
+            const SerialCounts& sc = ctx->serial_counts;
+            const int want[3] = {sc.n_long, sc.n_chain - sc.n_long, sc.n_small};
+            int rest[3], any = 0;
+            for (int c = 0; c < 3; ++c) rest[c] = std::max(0, want[c] - fit_launched[c]), any += rest[c];
+            if (M_all > 0 && (any > 0 || finish_launched < M_all)) CHK(launch_fit(fit_launched, rest, M_all));
+            ctx->fit_guess_valid = M_all > 0;
+            ctx->order_valid = true;
         }
-        if (!early_fit)
+        if (!early_fit && !classes_on)
             launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
     }
     HIPCHK(hipGetLastError());
@@ -724,7 +784,7 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
                                ctx->d_tables.as<float>(), ctx->rows, ctx->M, B, ctx->d_tiles.as<TileDesc>(), ctx->d_tile_rows.as<int32_t>(), ctx->num_tiles,
                                ctx->tile_max_rows, ctx->tile_max_gauss, ctx->d_fallback.as<int2>(), ctx->num_fallback, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE,
                                ctx->stream);
-    } else if ((ctx->flags & DMSA_FLAG_MIRROR_SUMS) && ctx->serial_classes && ctx->order_valid) {
+    } else if ((ctx->flags & DMSA_FLAG_MIRROR_SUMS) && ctx->order_valid) {
         // reference-order sums (default path): lane = evaluation on transposed pose tables
         HIPCHK(ctx->d_tablesT.ensure((size_t)B * ctx->rows * 48));
         ScopedTimer tm(ctx, T_RESIDUAL);
@@ -743,8 +803,7 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
     } else {
         ScopedTimer tm(ctx, T_RESIDUAL);
         launch_residuals(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tables.as<float>(), ctx->rows, ctx->M,
-                         B, ctx->d_wg_seg.as<int32_t>(), ctx->num_wg, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE, (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream,
-                         false, ctx->order_valid ? ctx->d_order.as<uint32_t>() : nullptr);
+                         B, ctx->d_wg_seg.as<int32_t>(), ctx->num_wg, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE, ctx->stream, false);
     }
     ctx->residual_launches += 1;
     ctx->residual_evals += B;
@@ -766,6 +825,7 @@ int upload_common(dmsa_ctx* ctx) {
     ctx->centralized = false;
     ctx->batch = 0;
     ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
+    ctx->fit_guess_valid = false;
     return DMSA_OK;
 }
 
@@ -787,6 +847,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
     HIPCHK(ctx->d_tables.ensure((size_t)(P + 1) * ctx->rows * 48));  // never reallocated while kernels read it
     for (int iter = 0; iter < s.num_iter; ++iter) {
         ++iters;
+        g_tl.reset(), g_tl.mark("start");
         chain(ctx).get_params(paramVec.data());  // :72
         // :75 updateGlobalPoints (the window model re-chains here, the keyframe model did in setPoseParameters)
         if (ctx->model == MODEL_WINDOW) chain(ctx).relative_to_global();
@@ -794,6 +855,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
         append_glob(chain(ctx), globs);
         CHK(build_tables(ctx, 1, globs));
         CHK(transform_points(ctx, 0));
+        g_tl.mark("table0+transform enq");
         // Host part of evaluation 0 (:99) and of the P forward-difference evaluations of calcNumericJacobian (:199-232):
         // one batch of 1+P pose tables.
         auto jacobian_batch = [&]() -> int {
@@ -849,6 +911,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             CHK(build_gaussians(ctx, s, jacobian_batch));  // :78-86, :96
         else
             CHK(build_gaussians(ctx, s));
+        g_tl.mark("build_gaussians (incl. sync#2)");
         ctx->trace.push_back(dmsa_iter_trace{ctx->M, ctx->M1, ctx->Mm, 0.0, 0.0, 0, 0});
         if (ctx->M < s.min_num_gaussians) {  // :89-93
             stop = DMSA_STOP_FEW_GAUSSIANS;
@@ -874,7 +937,9 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             ctx->h_Hp_cap = Hp.size();
         }
         HIPCHK(hipMemcpyAsync(ctx->h_Hp, ctx->d_Hp.p, Hp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        g_tl.mark("residuals+NE enq");
         HIPCHK(sync_spin(ctx->stream));  // sync #3
+        g_tl.mark("sync#3 wait");
         std::memcpy(Hp.data(), ctx->h_Hp, Hp.size() * 8);
         const int n1 = P + 1;
         for (int j = 0; j < P; ++j)
@@ -906,6 +971,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             host_set_params(ctx, test.data());
             host_eval(ctx, globs, extra);
         }
+        g_tl.mark("solve+trial chains");
         CHK(build_tables(ctx, 9, globs));
         CHK(run_residuals(ctx, 9, &extra));
         double* errs = ctx->h_rb->errs;  // pinned
@@ -920,7 +986,9 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
                 launch_squared_sums(ctx->d_E.as<double>(), ctx->ldE, rowsE, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
         }
         HIPCHK(hipMemcpyAsync(errs, ctx->d_sq_out.p, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        g_tl.mark("line search enq");
         HIPCHK(sync_spin(ctx->stream));  // sync #4
+        g_tl.mark("sync#4 wait");
         drain_timers(ctx);
         double minError = error0;
         bestK = 0;
@@ -946,6 +1014,7 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             break;
         }
     }
+    g_tl.print();
     if (s.use_centralization) CHK(dmsa_decentralize(ctx));
     // :149 final updateGlobalPoints
     if (ctx->model == MODEL_WINDOW) chain(ctx).relative_to_global();
@@ -991,7 +1060,6 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     if (const char* e = std::getenv("DMSA_OVERLAP_BATCH")) ctx->overlap_batch = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_DUAL_STREAM")) ctx->dual_stream = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_MERGE_SORT")) ctx->merge_sort = std::atoi(e) != 0 ? 1 : 0;
-    if (const char* e = std::getenv("DMSA_MIRROR_ROWS")) ctx->serial_classes = std::atoi(e) == 0;
     if (const char* e = std::getenv("DMSA_SERIAL_STREAMS")) ctx->serial_two_streams = std::atoi(e) != 1;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_scan0, hipEventDisableTiming) != hipSuccess ||
@@ -1024,7 +1092,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
                       &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
                       &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
                       &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_memb_g, &ctx->d_seg_off,
-                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_order_key, &ctx->d_order_key_s, &ctx->d_order_val, &ctx->d_order, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_pad_off, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
+                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_order, &ctx->d_fit_sums, &ctx->d_tablesT, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_pad_off, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
     for (DevBuf* b : bufs) b->release();
     if (ctx->sp) {
         for (DevBuf* b : ctx->sp->all) b->release();

@@ -118,14 +118,16 @@ void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const flo
 void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, bool mirror, hipStream_t s);
 // ---- K4: correspondence kernel ------------------------------------------------------------------------------
 void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t* wg_seg, hipStream_t s);
-// parity path (DMSA_FLAG_MIRROR_SUMS), row-cooperative kernels: Gaussians sorted by size, one fit launch for both levels
-bool mirror_uses_rows();  // false with DMSA_MIRROR_THREADS=1 (first-generation thread-per-Gaussian kernels)
-void launch_gauss_size_keys(const int32_t* seg_off, int M, uint32_t* key, uint32_t* val, hipStream_t s);
-// parity path: fit of all M Gaussians in the oracle's blocked summation order (order = Gaussians by descending size, or nullptr)
-void launch_gauss_fit_blocked(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const uint32_t* order, int M, float* info12, hipStream_t s);
+// default path: fit in the oracle's summation order (blocks of 64 members, pairwise tree inside a block, block sums in order).
+// `order` = Gaussians by descending size class, `sc` = the DEVICE copy of SerialCounts (class ranges); cls 0 / 1 / 2 = long / middle /
+// short class with 16 / 4 / 1 waves per Gaussian; workgroups [task0, task0 + tasks) of the class.  Writes the six centred product
+// sums per Gaussian; launch_gauss_fit_finish turns them into information matrices (max_gauss >= M threads).
+void launch_gauss_fit_tree(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, int cls,
+                           int task0, int tasks, double* sums, hipStream_t s);
+void launch_gauss_fit_finish(const int32_t* seg_off, const GaussCounts* counts, const double* sums, int max_gauss, float* info12, hipStream_t s);
+// streaming correspondence kernel of the opt-in fast sums (fallback of the tiled kernels)
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
-                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s, bool pairs = false,
-                      const uint32_t* order = nullptr /* parity path: Gaussians by descending size */);
+                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, hipStream_t s, bool pairs = false);
 // tiled variant (default fast path): tiles + per-tile row lists are rebuilt once per iteration
 // slots of the tile copy of the membership array: every Gaussian is padded to a multiple of 8 slots (Mm + 7 M <= 9 n)
 inline size_t tile_slot_capacity(size_t n_points) { return 9 * n_points + 64; }

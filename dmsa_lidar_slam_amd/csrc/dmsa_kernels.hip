@@ -1171,86 +1171,126 @@ __global__ __launch_bounds__(256) void k_gauss_fit(const int32_t* __restrict__ s
     }
 }
 
-// Parity path: the fit's nine double sums in the order the oracle states (Gaussians::addPointSet there): consecutive blocks of
-// kSumBlock members, every block summed member by member, the block sums added in order.  One 64-thread workgroup per Gaussian,
-// one thread per block (the longest Gaussians of the bench window have 56 blocks), thread 0 adds the block sums in order; the six
-// covariance sums need the rounded means of the first pass.  Loads run eight members ahead of the sums.
-constexpr int kSumBlock = 256;
-template <int kTerms, typename Load>
-__device__ __forceinline__ void block_sums(int j0, int j1, Load load, double* acc) {
-    constexpr int kAhead = 8;
-    for (int j = j0; j < j1; j += kAhead) {
-        double t[kAhead][kTerms];
-#pragma unroll
-        for (int u = 0; u < kAhead; ++u) load(min(j + u, j1 - 1), t[u]);
-#pragma unroll
-        for (int u = 0; u < kAhead; ++u)
-            if (j + u < j1) {
-#pragma unroll
-                for (int c = 0; c < kTerms; ++c) acc[c] += t[u][c];
-            }
-    }
+// Default path: the fit's nine double sums in the order the oracle states (Gaussians::addPointSet there).  The reference sums with
+// Eigen's vectorised dynamic-size reductions (Gaussians.h:146-154), whose order cannot be known, so the oracle states one that a
+// wave computes in a handful of instructions: consecutive blocks of 64 members, each block reduced by the balanced pairwise tree
+// (exactly what wave_allsum's DPP steps do: v[i] += v[i - w] for w = 1, 2, .. 32), the block sums added in block order.  One
+// workgroup per Gaussian; its waves take blocks round by round, thread c adds the round's block sums of component c in order.
+// Members are read from the Gaussian-ordered copy of the LOCAL points and transformed with the base pose table (the same
+// operation sequence as k_transform, so the coordinates are the ones the voxelisation saw).
+constexpr int kSumBlock = 64;
+// The classes of the size-ordered Gaussian list (serial_kernels.h): 0 = long (16 waves per Gaussian), 1 = middle (4), 2 = short (1).
+// The kernels read the class ranges from DEVICE memory, so they can be launched before the host knows the counts (with the
+// previous iteration's counts as the grid): a workgroup beyond the true count exits.
+__device__ __forceinline__ bool fit_task(const int32_t* __restrict__ sc /* n_chain, n_small, max, n_long */, int cls, int task, int& index) {
+    const int n_chain = sc[0], n_small = sc[1], n_long = sc[3];
+    const int first = cls == 0 ? 0 : (cls == 1 ? n_long : n_chain);
+    const int count = cls == 0 ? n_long : (cls == 1 ? n_chain - n_long : n_small);
+    index = first + task;
+    return task < count;
 }
-__global__ __launch_bounds__(64) void k_gauss_fit_blocked(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
-                                                         const float4* __restrict__ global, const uint32_t* __restrict__ order, int M,
-                                                         float* __restrict__ info12) {
-    __shared__ double s_part[64][6];
+template <int kFitWaves, int kMaxBlk>
+__global__ __launch_bounds__(64 * kFitWaves) void k_gauss_fit_tree(const float4* __restrict__ memb_local, const int32_t* __restrict__ seg_off,
+                                                                   const float4* __restrict__ table0, const uint32_t* __restrict__ order,
+                                                                   const int32_t* __restrict__ sc, int cls, int task0, double* __restrict__ sums) {
+    __shared__ double s_blk[kMaxBlk][6];
     __shared__ double s_tot[6];
     __shared__ float s_mean[3];
-    const int task = blockIdx.x, tid = threadIdx.x;
-    if (task >= M) return;
-    const int g = order ? (int)order[task] : task;  // descending size when ordered: the long fits start first
+    int index;
+    if (!fit_task(sc, cls, task0 + (int)blockIdx.x, index)) return;
+    const int g = (int)order[index];
     const int b = seg_off[g], n = seg_off[g + 1] - b, nblk = (n + kSumBlock - 1) / kSumBlock;
-    if (tid < 6) s_tot[tid] = 0.0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    auto global_point = [&](int j) {
+        const float4 p = memb_local[b + j];
+        const int row = __float_as_int(p.w);
+        return apply_row3(table0[3 * row], table0[3 * row + 1], table0[3 * row + 2], p.x, p.y, p.z);
+    };
+    if (threadIdx.x < 6) s_tot[threadIdx.x] = 0.0;
     __syncthreads();
-    for (int base = 0; base < nblk; base += 64) {  // pass 1: sums of x, y, z
-        const int blk = base + tid;
-        double acc[3] = {0.0, 0.0, 0.0};
-        if (blk < nblk)
-            block_sums<3>(blk * kSumBlock, min(n, (blk + 1) * kSumBlock), [&](int j, double* t) {
-                const float4 p = global[memb_idx[b + j]];
-                t[0] = (double)p.x, t[1] = (double)p.y, t[2] = (double)p.z;
-            }, acc);
-        s_part[tid][0] = acc[0], s_part[tid][1] = acc[1], s_part[tid][2] = acc[2];
+    // a super-round = kMaxBlk blocks: the waves reduce their blocks without meeting, then thread c adds the block sums of component c
+    // in block order
+    for (int sb = 0; sb < nblk; sb += kMaxBlk) {  // pass 1: sums of x, y, z
+        const int end = min(nblk, sb + kMaxBlk);
+        for (int blk = sb + wave; blk < end; blk += kFitWaves) {
+            const int j = blk * kSumBlock + lane;
+            double x = 0.0, y = 0.0, z = 0.0;
+            if (j < n) {
+                const float3 q = global_point(j);
+                x = (double)q.x, y = (double)q.y, z = (double)q.z;
+            }
+            x = wave_allsum(x), y = wave_allsum(y), z = wave_allsum(z);
+            if (lane == 0) s_blk[blk - sb][0] = x, s_blk[blk - sb][1] = y, s_blk[blk - sb][2] = z;
+        }
         __syncthreads();
-        if (tid < 3) {
-            double tot = s_tot[tid];
-            const int cnt = min(64, nblk - base);
-            for (int t = 0; t < cnt; ++t) tot += s_part[t][tid];
-            s_tot[tid] = tot;
+        if (threadIdx.x < 3) {
+            double tot = s_tot[threadIdx.x];
+            for (int t = 0; t < end - sb; ++t) tot += s_blk[t][threadIdx.x];
+            s_tot[threadIdx.x] = tot;
         }
         __syncthreads();
     }
-    if (tid < 3) s_mean[tid] = (float)(s_tot[tid] / (double)n);
+    if (threadIdx.x < 3) s_mean[threadIdx.x] = (float)(s_tot[threadIdx.x] / (double)n);
     __syncthreads();
     const float mx = s_mean[0], my = s_mean[1], mz = s_mean[2];
-    if (tid < 6) s_tot[tid] = 0.0;
+    if (threadIdx.x < 6) s_tot[threadIdx.x] = 0.0;
     __syncthreads();
-    for (int base = 0; base < nblk; base += 64) {  // pass 2: xx xy xz yy yz zz of the centred members
-        const int blk = base + tid;
-        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (blk < nblk)
-            block_sums<6>(blk * kSumBlock, min(n, (blk + 1) * kSumBlock), [&](int j, double* t) {
-                const float4 p = global[memb_idx[b + j]];
-                const float cx = p.x - mx, cy = p.y - my, cz = p.z - mz;
+    for (int sb = 0; sb < nblk; sb += kMaxBlk) {  // pass 2: xx xy xz yy yz zz of the centred members
+        const int end = min(nblk, sb + kMaxBlk);
+        for (int blk = sb + wave; blk < end; blk += kFitWaves) {
+            const int j = blk * kSumBlock + lane;
+            double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (j < n) {
+                const float3 q = global_point(j);
+                const float cx = q.x - mx, cy = q.y - my, cz = q.z - mz;
                 t[0] = (double)cx * (double)cx, t[1] = (double)cx * (double)cy, t[2] = (double)cx * (double)cz;
                 t[3] = (double)cy * (double)cy, t[4] = (double)cy * (double)cz, t[5] = (double)cz * (double)cz;
-            }, acc);
+            }
 #pragma unroll
-        for (int c = 0; c < 6; ++c) s_part[tid][c] = acc[c];
+            for (int c = 0; c < 6; ++c) {
+                const double v = wave_allsum(t[c]);
+                if (lane == 0) s_blk[blk - sb][c] = v;
+            }
+        }
         __syncthreads();
-        if (tid < 6) {
-            double tot = s_tot[tid];
-            const int cnt = min(64, nblk - base);
-            for (int t = 0; t < cnt; ++t) tot += s_part[t][tid];
-            s_tot[tid] = tot;
+        if (threadIdx.x < 6) {
+            double tot = s_tot[threadIdx.x];
+            for (int t = 0; t < end - sb; ++t) tot += s_blk[t][threadIdx.x];
+            s_tot[threadIdx.x] = tot;
         }
         __syncthreads();
     }
-    if (tid == 0) finish_gaussian(s_tot[0], s_tot[1], s_tot[2], s_tot[3], s_tot[4], s_tot[5], n, info12 + (size_t)g * 12);
+    if (threadIdx.x < 6) sums[(size_t)g * 6 + threadIdx.x] = s_tot[threadIdx.x];
 }
-void launch_gauss_fit_blocked(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const uint32_t* order, int M, float* info12, hipStream_t s) {
-    if (M > 0) hipLaunchKernelGGL(k_gauss_fit_blocked, dim3(M), dim3(64), 0, s, seg_off, memb_idx, global, order, M, info12);
+// covariance -> limitCovariance -> inverse (Gaussians.h:146-168, :181-201), one thread per Gaussian: the serial 3x3 work of all
+// Gaussians fills whole waves instead of trailing every fit workgroup on a single lane
+__global__ __launch_bounds__(256) void k_gauss_fit_finish(const int32_t* __restrict__ seg_off, const GaussCounts* __restrict__ counts,
+                                                          const double* __restrict__ sums, float* __restrict__ info12) {
+    const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= M) return;
+    const double* a = sums + (size_t)g * 6;
+    float o[12];
+    finish_gaussian(a[0], a[1], a[2], a[3], a[4], a[5], seg_off[g + 1] - seg_off[g], o);
+    float* dst = info12 + (size_t)g * 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+        if (i != 9) dst[i] = o[i];  // slot 9 is the rebalancing weight (k_size_classes / k_rebalancing_weights write it)
+}
+int fit_small_max_blocks() { return 4; }  // short class: Gaussians up to serial_small_threshold() <= 256 members
+void launch_gauss_fit_tree(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, int cls,
+                           int task0, int tasks, double* sums, hipStream_t s) {
+    if (tasks <= 0) return;
+    const float4* t0 = reinterpret_cast<const float4*>(table0);
+    if (cls == 0)
+        hipLaunchKernelGGL((k_gauss_fit_tree<16, 256>), dim3(tasks), dim3(1024), 0, s, memb_local, seg_off, t0, order, sc, cls, task0, sums);
+    else if (cls == 1)
+        hipLaunchKernelGGL((k_gauss_fit_tree<4, 64>), dim3(tasks), dim3(256), 0, s, memb_local, seg_off, t0, order, sc, cls, task0, sums);
+    else
+        hipLaunchKernelGGL((k_gauss_fit_tree<1, 4>), dim3(tasks), dim3(64), 0, s, memb_local, seg_off, t0, order, sc, cls, task0, sums);
+}
+void launch_gauss_fit_finish(const int32_t* seg_off, const GaussCounts* counts, const double* sums, int max_gauss, float* info12, hipStream_t s) {
+    if (max_gauss > 0) hipLaunchKernelGGL(k_gauss_fit_finish, dim3((max_gauss + 255) / 256), dim3(256), 0, s, seg_off, counts, sums, info12);
 }
 
 void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const GaussCounts* counts, int level, float* info12,
@@ -1282,30 +1322,31 @@ __global__ __launch_bounds__(1024) void k_rebalancing_weights(const int32_t* __r
     if (threadIdx.x == 0) counts->weight_mean = mean;
     for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = info12[(size_t)g * 12 + 9] / mean;
 }
-// parity path: VectorXf::mean() in the oracle's blocked order (blocks of kSumBlock weights summed in index order, block sums added
-// in order): one thread per block, thread 0 adds the block sums.
+// default path: VectorXf::mean() (Gaussians.h:176) in the oracle's order -- blocks of 64 weights reduced by the pairwise tree, block
+// sums added in order: the 16 waves take 16 blocks per round, thread 0 adds the round's sums
 __global__ __launch_bounds__(1024) void k_rebalancing_weights_mirror(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts,
                                                                      float* __restrict__ info12) {
-    __shared__ double s_part[1024];
+    __shared__ double s_slot[16];
     __shared__ double s_tot;
     __shared__ float s_mean;
     const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
     const int nblk = (M + kSumBlock - 1) / kSumBlock;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) s_tot = 0.0;
     __syncthreads();
-    for (int base = 0; base < nblk; base += 1024) {
-        const int blk = base + (int)threadIdx.x;
-        double s = 0.0;
+    for (int base = 0; base < nblk; base += 16) {
+        const int blk = base + wave;
         if (blk < nblk) {
-            const int g1 = min(M, (blk + 1) * kSumBlock);
-            for (int g = blk * kSumBlock; g < g1; ++g) s += (double)((1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f);
+            const int g = blk * kSumBlock + lane;
+            const double w = g < M ? (double)((1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f) : 0.0;
+            const double v = wave_allsum(w);
+            if (lane == 0) s_slot[wave] = v;
         }
-        s_part[threadIdx.x] = s;
         __syncthreads();
         if (threadIdx.x == 0) {
             double tot = s_tot;
-            const int cnt = min(1024, nblk - base);
-            for (int t = 0; t < cnt; ++t) tot += s_part[t];
+            const int cnt = min(16, nblk - base);
+            for (int t = 0; t < cnt; ++t) tot += s_slot[t];
             s_tot = tot;
         }
         __syncthreads();
@@ -2154,223 +2195,12 @@ void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, c
     }
 }
 
-// Mirror variant: one thread per Gaussian; the float mean and the double sum run in member order exactly like
-// DmsaOptimizer.h:247-264 (bit-reproducible against the CPU restatement; used by the parity path).
-template <bool kTableInLds>
-__global__ __launch_bounds__(256) void k_residuals_mirror(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off,
-                                                          const float4* __restrict__ info12, const float4* __restrict__ tables, int rows, int M,
-                                                          double* __restrict__ E, int64_t ldE) {
-    extern __shared__ __attribute__((aligned(16))) float4 s_tab[];
-    const int b = blockIdx.y;
-    const float4* gtab = tables + (size_t)b * rows * 3;
-    if (kTableInLds) {
-        for (int i = threadIdx.x; i < rows * 3; i += blockDim.x) s_tab[i] = gtab[i];
-        __syncthreads();
-    }
-    const float4* T = kTableInLds ? s_tab : gtab;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= M) return;
-    const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
-    float mx = 0.0f, my = 0.0f, mz = 0.0f;
-    for (int j = 0; j < n; ++j) {
-        const float4 p = memb[off0 + j];
-        const int row = __float_as_int(p.w);
-        const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p.x, p.y, p.z);
-        mx = mx + q.x, my = my + q.y, mz = mz + q.z;
-    }
-    const float nf = (float)n;
-    mx = mx / nf, my = my / nf, mz = mz / nf;
-    const float4 i0 = info12[3 * g], i1 = info12[3 * g + 1], i2 = info12[3 * g + 2];
-    const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
-    double acc = 0.0;
-    for (int j = 0; j < n; ++j) {
-        const float4 p = memb[off0 + j];
-        const int row = __float_as_int(p.w);
-        const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p.x, p.y, p.z);
-        const float d0 = q.x - mx, d1 = q.y - my, d2 = q.z - mz;
-        const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
-        const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
-        const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
-        const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
-        acc += (double)sum3f(v0 * d0, v1 * d1, v2 * d2);
-    }
-    E[(size_t)b * ldE + g] = sqrt(fabs(acc));
-}
-
-// ---- parity path, row-cooperative --------------------------------------------------------------------------------------
-// The reference's per-Gaussian sums are SERIAL chains (float mean, DmsaOptimizer.h:247-254; double accumulation of the float
-// terms, :259-264): rounding makes them order dependent, so a bit-identical result needs the same chain.  What is parallel is
-// everything AROUND the chain.  A 16-lane DPP row owns one Gaussian: its lanes load and transform 16 members at once, then the
-// row's lane 0 runs the chain, fetching member j's value with `row_ror` folded into the add (v_add_f32_dpp) -- one VALU
-// instruction per member and chain, no LDS, no per-lane memory streams.  A wave runs four such rows; lanes past a row's last
-// member contribute +0.0, which leaves every partial sum unchanged (a sum that starts at +0.0 never becomes -0.0).
-template <int J>
-__device__ __forceinline__ float row_lane(float v) {  // in lane 0 of every 16-lane row: the value of the row's lane J
-    if constexpr (J == 0)
-        return v;
-    else
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (16 - J), 0xf, 0xf, false));  // row_ror:(16-J)
-}
-template <int J>
-__device__ __forceinline__ double row_lane(double v) {
-    if constexpr (J == 0) {
-        return v;
-    } else {
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + (16 - J), 0xf, 0xf, false);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + (16 - J), 0xf, 0xf, false);
-        return __hiloint2double(hi, lo);
-    }
-}
-template <int J>
-struct RowChain {
-    static __device__ __forceinline__ void add3f(float& sx, float& sy, float& sz, float x, float y, float z) {
-        sx = sx + row_lane<J>(x), sy = sy + row_lane<J>(y), sz = sz + row_lane<J>(z);
-        RowChain<J + 1>::add3f(sx, sy, sz, x, y, z);
-    }
-    static __device__ __forceinline__ void add_f_to_d(double& acc, float t) {
-        acc += (double)row_lane<J>(t);
-        RowChain<J + 1>::add_f_to_d(acc, t);
-    }
-};
-template <>
-struct RowChain<16> {
-    static __device__ __forceinline__ void add3f(float&, float&, float&, float, float, float) {}
-    static __device__ __forceinline__ void add_f_to_d(double&, float) {}
-};
-// value of the row's lane 0 in every lane of the row
-__device__ __forceinline__ float row_first(float v) { return __shfl(v, (int)(threadIdx.x & 63u & ~15u), 64); }
-__device__ __forceinline__ int wave_max4(int v) {  // max over the four rows' lane-0 values
-    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    return max(max(a, b), max(c, d));
-}
-
-// updateErrorTerms (DmsaOptimizer.h:234-273), bit-identical to the serial loops: one row per (Gaussian, evaluation).
-template <bool kTableInLds>
-__global__ __launch_bounds__(256) void k_residuals_mirror_rows(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off,
-                                                               const float4* __restrict__ info12, const float4* __restrict__ tables, int rows, int M,
-                                                               const uint32_t* __restrict__ order, int eval_major, double* __restrict__ E,
-                                                               int64_t ldE) {
-    extern __shared__ __attribute__((aligned(16))) float4 s_tab[];
-    // eval_major: blockIdx.x runs over the evaluations, so the workgroups holding the LONGEST chains of every evaluation are
-    // dispatched first (longest-processing-time-first); otherwise the last evaluation's long chains start last and form the tail
-    const int b = eval_major ? blockIdx.x : blockIdx.y, tblock = eval_major ? blockIdx.y : blockIdx.x;
-    const float4* gtab = tables + (size_t)b * rows * 3;
-    if (kTableInLds) {
-        for (int i = threadIdx.x; i < rows * 3; i += blockDim.x) s_tab[i] = gtab[i];
-        __syncthreads();
-    }
-    const float4* T = kTableInLds ? s_tab : gtab;
-    const int l16 = threadIdx.x & 15;
-    // `order` lists the Gaussians by descending size: the four rows of a wave get chains of (almost) equal length and the long
-    // chains -- the critical path -- start first.  (A whole-wave variant for the longest Gaussians -- 64 members transformed per
-    // step, the four rows chained in order through v_readlane, loads four steps ahead -- has 26 % fewer instructions per member and is
-    // still 15-40 % SLOWER per launch: the chain is bound by the latency of its dependent adds, and the hand-overs add to it.)
-    const int task = tblock * 16 + (threadIdx.x >> 4);
-    const bool on = task < M;
-    const int g = on ? (int)order[task] : 0;
-    const int off0 = on ? seg_off[g] : 0, n = on ? seg_off[g + 1] - off0 : 0;
-    const int nmax = wave_max4(n);
-    if (nmax == 0) return;
-    // kRowBatch chunks of 16 members per step: all loads of a step are issued before its chains run, so the memory latency of
-    // the long Gaussians (the critical path: their chains cannot be split) hides behind 4 x 16 chain steps
-    constexpr int kRowBatch = 4;
-    const int last = max(n - 1, 0);
-    auto load_step = [&](int j0, float4* dst) {  // the step after the one being chained is already in flight
-#pragma unroll
-        for (int u = 0; u < kRowBatch; ++u) dst[u] = memb[off0 + min(j0 + 16 * u + l16, last)];
-    };
-    float mx = 0.0f, my = 0.0f, mz = 0.0f;
-    float4 p[kRowBatch], pn[kRowBatch];
-    load_step(0, pn);
-    for (int j0 = 0; j0 < nmax; j0 += 16 * kRowBatch) {
-#pragma unroll
-        for (int u = 0; u < kRowBatch; ++u) p[u] = pn[u];
-        if (j0 + 16 * kRowBatch < nmax) load_step(j0 + 16 * kRowBatch, pn);
-#pragma unroll
-        for (int u = 0; u < kRowBatch; ++u) {
-            const int j = j0 + 16 * u + l16;
-            const int row = __float_as_int(p[u].w);
-            const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p[u].x, p[u].y, p[u].z);
-            const bool in = j < n;
-            RowChain<0>::add3f(mx, my, mz, in ? q.x : 0.0f, in ? q.y : 0.0f, in ? q.z : 0.0f);
-        }
-    }
-    const float nf = (float)n;
-    mx = row_first(mx) / nf, my = row_first(my) / nf, mz = row_first(mz) / nf;
-    const int gi = on ? g : 0;
-    const float4 i0 = info12[3 * gi], i1 = info12[3 * gi + 1], i2 = info12[3 * gi + 2];
-    const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
-    double acc = 0.0;
-    load_step(0, pn);
-    for (int j0 = 0; j0 < nmax; j0 += 16 * kRowBatch) {
-#pragma unroll
-        for (int u = 0; u < kRowBatch; ++u) p[u] = pn[u];
-        if (j0 + 16 * kRowBatch < nmax) load_step(j0 + 16 * kRowBatch, pn);
-#pragma unroll
-        for (int u = 0; u < kRowBatch; ++u) {
-            const int j = j0 + 16 * u + l16;
-            const int row = __float_as_int(p[u].w);
-            const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p[u].x, p[u].y, p[u].z);
-            const float d0 = q.x - mx, d1 = q.y - my, d2 = q.z - mz;
-            const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
-            const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
-            const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
-            const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
-            const float term = sum3f(v0 * d0, v1 * d1, v2 * d2);
-            RowChain<0>::add_f_to_d(acc, j < n ? term : 0.0f);
-        }
-    }
-    if (on && l16 == 0) E[(size_t)b * ldE + g] = sqrt(fabs(acc));
-}
-
-// order of the Gaussians by descending size for the row-cooperative parity kernels: ascending key = descending size
-__global__ __launch_bounds__(256) void k_gauss_size_keys(const int32_t* __restrict__ seg_off, int M, uint32_t* __restrict__ key, uint32_t* __restrict__ val) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < M) key[g] = 0xFFFFFFFFu - (uint32_t)(seg_off[g + 1] - seg_off[g]), val[g] = (uint32_t)g;
-}
-void launch_gauss_size_keys(const int32_t* seg_off, int M, uint32_t* key, uint32_t* val, hipStream_t s) {
-    if (M > 0) hipLaunchKernelGGL(k_gauss_size_keys, dim3((M + 255) / 256), dim3(256), 0, s, seg_off, M, key, val);
-}
-bool mirror_uses_rows() {  // DMSA_MIRROR_THREADS: first-generation thread-per-Gaussian residual chains instead of the DPP rows
-    static const bool serial_threads = std::getenv("DMSA_MIRROR_THREADS") != nullptr;
-    return !serial_threads;
-}
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
-                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, bool mirror, hipStream_t s, bool pairs, const uint32_t* order) {
+                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, hipStream_t s, bool pairs) {
     if (M <= 0 || B <= 0) return;
     const int seg_stride = pairs ? 2 : 1;
     const size_t lds = (size_t)rows * 48;
     static bool attr_set = false;
-    if (mirror) {
-        static bool attr_set_m = false;
-        if (!mirror_uses_rows() || order == nullptr) {  // first-generation kernel: a thread per Gaussian (DMSA_MIRROR_THREADS=1)
-            const dim3 grid((M + 255) / 256, B);
-            if (lds <= 160 * 1024 - 1024) {
-                if (!attr_set_m) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals_mirror<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-                    attr_set_m = true;
-                }
-                hipLaunchKernelGGL(k_residuals_mirror<true>, grid, dim3(256), lds, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
-                                   reinterpret_cast<const float4*>(tables), rows, M, E, ldE);
-            } else {
-                hipLaunchKernelGGL(k_residuals_mirror<false>, grid, dim3(256), 0, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
-                                   reinterpret_cast<const float4*>(tables), rows, M, E, ldE);
-            }
-            return;
-        }
-        const int tblocks = (M + 15) / 16;  // 16 rows (Gaussians) per 256-thread workgroup
-        const int eval_major = tblocks <= 65535 ? 1 : 0;
-        const dim3 grid = eval_major ? dim3(B, tblocks) : dim3(tblocks, B);
-        static const bool table_global = std::getenv("DMSA_MIRROR_TABLE_GLOBAL") != nullptr;
-        if (lds <= 48 * 1024 && !table_global) {  // the table of one evaluation in LDS: three workgroups per CU
-            hipLaunchKernelGGL(k_residuals_mirror_rows<true>, grid, dim3(256), lds, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
-                               reinterpret_cast<const float4*>(tables), rows, M, order, eval_major, E, ldE);
-        } else {
-            hipLaunchKernelGGL(k_residuals_mirror_rows<false>, grid, dim3(256), 0, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
-                               reinterpret_cast<const float4*>(tables), rows, M, order, eval_major, E, ldE);
-        }
-        return;
-    }
     if (lds <= 160 * 1024 - 1280) {
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
@@ -2493,15 +2323,23 @@ __global__ void k_squared_sums_reduce(const double* __restrict__ partial, int ns
 // bit-identical numbers.
 __global__ __launch_bounds__(64) void k_squared_sums_blocked(const double* __restrict__ E, int64_t ldE, int rows, int rs, int nsplit,
                                                              double* __restrict__ partial) {
-    const int sp = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (sp >= nsplit) return;
-    const int r_end = min(rows, (sp + 1) * rs);
+    // one wave per (row block, evaluation): the block's values arrive by coalesced loads, lane 0 adds their squares row by row
+    __shared__ double s_v[1024];
+    const int sp = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int r0 = sp * rs, r_end = min(rows, r0 + rs);
     double s = 0.0;
-    for (int r = sp * rs; r < r_end; ++r) {
-        const double v = E[(size_t)b * ldE + r];
-        s += v * v;
+    for (int c0 = r0; c0 < r_end; c0 += 1024) {
+        const int cnt = min(1024, r_end - c0);
+        for (int i = lane; i < cnt; i += 64) s_v[i] = E[(size_t)b * ldE + c0 + i];
+        __syncthreads();
+        if (lane == 0)
+            for (int i = 0; i < cnt; ++i) {
+                const double v = s_v[i];
+                s += v * v;
+            }
+        __syncthreads();
     }
-    partial[(size_t)b * nsplit + sp] = s;
+    if (lane == 0) partial[(size_t)b * nsplit + sp] = s;
 }
 int squared_sums_blocked_partial_doubles(int rows, int P, int B) {
     const int rs = ne_rows_per_split(rows, P);
@@ -2510,7 +2348,7 @@ int squared_sums_blocked_partial_doubles(int rows, int P, int B) {
 void launch_squared_sums_blocked(const double* E, int64_t ldE, int rows, int P, int B, double* partial, double* out, hipStream_t s) {
     const int rs = ne_rows_per_split(rows, P);
     const int nsplit = (rows + rs - 1) / rs;
-    hipLaunchKernelGGL(k_squared_sums_blocked, dim3((nsplit + 63) / 64, B), dim3(64), 0, s, E, ldE, rows, rs, nsplit, partial);
+    hipLaunchKernelGGL(k_squared_sums_blocked, dim3(nsplit, B), dim3(64), 0, s, E, ldE, rows, rs, nsplit, partial);
     hipLaunchKernelGGL(k_squared_sums_reduce, dim3((B + 63) / 64), dim3(64), 0, s, partial, nsplit, B, out);
 }
 void launch_squared_sums(const double* E, int64_t ldE, int rows, int B, double* partial, double* out, hipStream_t s) {

@@ -484,16 +484,19 @@ struct Gaussians {
     // Gaussians.h:130-168
     // Order of the fit's reductions.  The reference computes colwise().mean() and centered^T * centered with Eigen's vectorised
     // dynamic-size float paths (Gaussians.h:146-154), whose summation order cannot be known; this restatement accumulates in double
-    // and fixes an order that is easy to state and to parallelise: consecutive blocks of kSumBlock members, every block summed
-    // member by member, the block sums added in order.  (The parity kernels of the HIP library use the same rule.)
-    static constexpr size_t kSumBlock = 256;
+    // and fixes an order that is easy to state and to parallelise: consecutive blocks of kSumBlock = 64 members, every block reduced
+    // by the balanced pairwise tree (v[i] += v[i - w] for w = 1, 2, 4 .. 32; missing members count as +0.0), the block sums added
+    // in block order.  (The kernels of the HIP library use the same rule: it is what a 64-lane wave reduction computes.)
+    static constexpr size_t kSumBlock = 64;
     template <typename Term>
     static double blockedSum(size_t n, Term term) {
         double total = 0.0;
         for (size_t j0 = 0; j0 < n; j0 += kSumBlock) {
-            double s = 0.0;
-            for (size_t j = j0; j < std::min(n, j0 + kSumBlock); ++j) s += term(j);
-            total += s;
+            double v[kSumBlock];
+            for (size_t i = 0; i < kSumBlock; ++i) v[i] = j0 + i < n ? term(j0 + i) : 0.0;
+            for (size_t w = 1; w < kSumBlock; w <<= 1)
+                for (size_t i = 2 * w - 1; i < kSumBlock; i += 2 * w) v[i] = v[i] + v[i - w];
+            total += v[kSumBlock - 1];
         }
         return total;
     }
