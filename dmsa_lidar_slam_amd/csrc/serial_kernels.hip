@@ -31,7 +31,6 @@ namespace dmsa {
 
 namespace {
 
-constexpr int kChunk = 64;        // members per pipeline phase of the chain kernel
 constexpr int kSmallMax = 256;    // upper limit of the small-Gaussian threshold (histogram size of k_size_classes)
 
 __device__ __forceinline__ float3 apply_row3s(const float4 r0, const float4 r1, const float4 r2, const float x, const float y, const float z) {
@@ -122,6 +121,46 @@ __device__ __forceinline__ float mahalanobis_term_pk(const InfoPk& I, const f2 g
     const float v2 = wd.x * I.A02 + (wd.y * I.A12 + wd2 * I.A22);
     const f2 t = v01 * d;
     return t.x + (t.y + v2 * d2);
+}
+
+// ---- member-pair form (producers of the chain kernel) -----------------------------------------------------------------
+// A producer lane takes TWO consecutive members at a time and carries them through the transform and the quadratic form as the
+// two halves of packed registers (v_pk_mul_f32 / v_pk_add_f32: two separately rounded IEEE operations per instruction).  The
+// pose-table row is a per-lane scalar that the packed instructions broadcast (op_sel), so the same code serves both members when
+// they share a row -- the common case: consecutive members of a Gaussian come from neighbouring firing times.
+typedef float f4 __attribute__((ext_vector_type(4)));
+struct Rows {  // one pose-table row: three native 4-float vectors (inline-asm outputs stay in registers; a HIP float4 struct would not)
+    f4 r0, r1, r2;
+};
+__device__ __forceinline__ Rows load_rows(const float4* __restrict__ tabT, int B, int b, int row) {
+    const float4* t = tabT + ((size_t)row * B + b) * 3;
+    Rows r;
+    asm volatile(
+        "global_load_dwordx4 %0, %3, off\n\t"
+        "global_load_dwordx4 %1, %3, off offset:16\n\t"
+        "global_load_dwordx4 %2, %3, off offset:32\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r.r0), "=&v"(r.r1), "=&v"(r.r2)
+        : "v"(t)
+        : "memory");
+    return r;
+}
+// Matrix4f * Vector4f, column-wise like Eigen's packet product: ((c0*x + c1*y) + c2*z) + c3; V = float or f2 (two members)
+template <class V>
+__device__ __forceinline__ void transform_v(const Rows rc, const V x, const V y, const V z, V& gx, V& gy, V& gz) {
+    gx = ((rc.r0.x * x + rc.r0.y * y) + rc.r0.z * z) + rc.r0.w;
+    gy = ((rc.r1.x * x + rc.r1.y * y) + rc.r1.z * z) + rc.r1.w;
+    gz = ((rc.r2.x * x + rc.r2.y * y) + rc.r2.z * z) + rc.r2.w;
+}
+// ((w d^T) A) d of DmsaOptimizer.h:263 with 3-term sums as a + (b + c) -- the operation order of mahalanobis_term()
+template <class V>
+__device__ __forceinline__ V mahalanobis_v(const Info& I, const V gx, const V gy, const V gz, const float mx, const float my, const float mz) {
+    const V d0 = gx - mx, d1 = gy - my, d2 = gz - mz;
+    const V wd0 = I.w * d0, wd1 = I.w * d1, wd2 = I.w * d2;
+    const V v0 = wd0 * I.A00 + (wd1 * I.A10 + wd2 * I.A20);
+    const V v1 = wd0 * I.A01 + (wd1 * I.A11 + wd2 * I.A21);
+    const V v2 = wd0 * I.A02 + (wd1 * I.A12 + wd2 * I.A22);
+    return v0 * d0 + (v1 * d1 + v2 * d2);
 }
 
 }  // namespace
@@ -289,16 +328,16 @@ constexpr int kSlots = 3;
 constexpr int kBL = 16;  // evaluation stride of the LDS ring layout (compile time: every ds_read of the chainer gets an immediate offset)
 
 // kProd producer waves; kSepLoader: one more wave that only feeds the member ring (otherwise the last producer does that too).
-//   <8, true>  latency tier (the longest Gaussians): with Bs <= 8 every producer has ONE step per phase, so a phase lasts as
+//   <8, true, 64>  latency tier (the longest Gaussians): with Bs <= 8 every producer has ONE step per phase, so a phase lasts as
 //              long as its chain segment even for the producer wave that loses the issue arbitration on the chainer's SIMD
-//   <3, false> throughput tier: 4 waves per workgroup, phases are producer-bound, but 8 workgroups share a CU and the resident
-//              waves spend most of their time issuing instead of waiting at a barrier
-template <int kProd, bool kSepLoader>
+//   <4, false, 32> throughput tier: 5 waves and 20 KB of LDS per workgroup (32-member chunks), six workgroups per CU; phases are
+//              producer-bound, but the resident waves spend most of their time issuing instead of waiting at a barrier
+template <int kProd, bool kSepLoader, int kChunk>
 __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_residuals_chain(
     const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12, const float4* __restrict__ tabT, int B,
     const uint32_t* __restrict__ order, int Bs, int nsub, int prio, double* __restrict__ E, int64_t ldE) {
     constexpr int kProducers = kProd;
-    constexpr int kMaxSteps = (kBL + kProd - 1) / kProd;  // steps per chunk <= kBL (Bs = kBL: 4 members per step)
+    constexpr int kMaxSteps = (kChunk / 8 + kProd - 1) / kProd;  // steps per chunk <= kChunk / 8 (Bs = kBL: 4 member pairs per step)
     // pass 1 ring: float  q[kSlots][kChunk / 4][3][kBL][4]   (member-in-group fastest: the chainer reads four members per ds_read_b128)
     // pass 2 ring: double t[kSlots][kChunk / 2][kBL][2]       (aliases the pass-1 ring)
     constexpr int kSlotFloats = kChunk * 3 * kBL, kSlotDoubles = kChunk * kBL;
@@ -347,6 +386,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
                             const float4 v = r[k % D];
                             r[k % D] = k + D < S ? cs[(k + D) * gstride] : ns[(k + D - S) * gstride];
                             acc = acc + v.x, acc = acc + v.y, acc = acc + v.z, acc = acc + v.w;
+                            __builtin_amdgcn_sched_barrier(0);  // keep ONE read per four adds, D steps ahead (the scheduler would cluster the reads and wait)
                         }
                     } else {  // last chunk of the Gaussian
 #pragma unroll
@@ -388,6 +428,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
                             const double2 v = r[k % D];
                             r[k % D] = k + D < S ? cs[(k + D) * kBL] : ns[(k + D - S) * kBL];
                             dacc += v.x, dacc += v.y;
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     } else {
 #pragma unroll
@@ -414,29 +455,45 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
         __builtin_amdgcn_s_setprio(1);
     const int pw = wave - 1;
     const bool loader = pw == (kSepLoader ? kProducers : kProducers - 1);  // the wave that feeds the member ring
+#ifdef DMSA_ISOLATE_CHAINER
+    const bool works = (!kSepLoader || pw < kProducers) && (!kSepLoader || (wave & 3) != 0);  // waves 4, 8 share the chainer's SIMD: no work
+#else
     const bool works = !kSepLoader || pw < kProducers;
-    const int mps = 64 / Bs;                         // members per step
-    const int steps = (kChunk + mps - 1) / mps;      // steps per chunk
+#endif
+    const int mps = 64 / Bs;                              // member PAIRS per step
+    const int steps = (kChunk / 2 + mps - 1) / mps;       // steps per chunk
     const int ms = lane / Bs, pb = lane - ms * Bs;
     const bool lane_on = ms < mps && pb < nb;
     const int bcol = b0 + (pb < nb ? pb : 0);
     const int last = n - 1;
-    RowCache rc;
-    int jl_u[kMaxSteps];  // member slot inside the chunk of this lane's step u (kChunk: none)
+    Rows rc;  // the pose-table row of this lane's evaluation that the last member used, and its index
+    int rc_row = -1;
+    rc.r0 = rc.r1 = rc.r2 = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    int jl_u[kMaxSteps];  // first member (even) of this lane's pair in step u (kChunk: none)
 #pragma unroll
     for (int u = 0; u < kMaxSteps; ++u) {
-        const int t = pw + u * kProducers, jl = t * mps + ms;
+#ifdef DMSA_ISOLATE_CHAINER
+        const int rank = kSepLoader ? pw - (pw >> 2) : pw, nwork = kSepLoader ? kProducers - kProducers / 4 : kProducers;  // w1..w3 -> 0..2, w5..w7 -> 3..5
+        const int t = rank + u * nwork, jl = 2 * (t * mps + ms);
+#else
+        const int t = pw + u * kProducers, jl = 2 * (t * mps + ms);
+#endif
+#ifdef DMSA_NO_PRODUCE  // timing experiment: producers only keep the barriers (results are garbage)
+        jl_u[u] = kChunk;
+#else
         jl_u[u] = (works && t < steps && lane_on && jl < kChunk) ? jl : kChunk;
+#endif
     }
     // Members reach the producers through LDS: ONE wave issues ONE global_load_lds_dwordx4 per chunk (64 lanes x 16 B = the 64
     // members of a chunk, written lane-linear into a 4-slot ring) two phases ahead of its use.  No member ever sits in a
     // register across a barrier, so there is nothing for the compiler to copy or to wait for inside the phase loop; the only
-    // vector-memory wait of a phase is the loader's "all but the newest DMA have landed" in front of the barrier.
+    // vector-memory wait of a phase is the loader's "all but the newest DMA have landed" in front of the barrier.  Slots past the
+    // end of the Gaussian hold copies of its last member (clamped addresses): whatever a lane computes from them is never read.
     const unsigned lds_m = (unsigned)(uintptr_t)&s_m[0][0];
     auto dma = [&](int P) {  // members of the chunk consumed in global phase P (pass 1: P = p, pass 2: P = nphases + p)
-        if (loader) {
+        if (loader && lane < kChunk) {
             const int c = P < nphases ? P : P - nphases;
-            const float4* src = memb + off0 + min(c * kChunk + lane, last);  // past the last chunk: a harmless re-read of the last member
+            const float4* src = memb + off0 + min(c * kChunk + lane, last);
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_m + (unsigned)(P & 3) * (kChunk * 16));
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -447,6 +504,15 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
     };
     auto landed = [&]() {  // every DMA but the newest has landed (one DMA is issued per phase, always)
         if (loader) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    };
+    // the pair (jl, jl + 1) of ring slot `slot`, coordinates as member pairs: ds_read2_b32 with dword offsets (k, k + 4)
+    struct Pair {
+        f2 x, y, z;
+        int row0, row1;
+    };
+    auto read_pair = [&](int slot, int jl) {
+        const float* m = reinterpret_cast<const float*>(&s_m[slot][jl]);
+        return Pair{f2{m[0], m[4]}, f2{m[1], m[5]}, f2{m[2], m[6]}, __float_as_int(m[3]), __float_as_int(m[7])};
     };
     // ---- pass 1: transformed coordinates of every member ----
     dma(0), dma(1);
@@ -461,13 +527,18 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
             for (int u = 0; u < kMaxSteps; ++u) {
                 if (jl_u[u] < left && jl_u[u] < kChunk) {
                     const int jl = jl_u[u];
-                    const float4 pt = s_m[p & 3][jl];
-                    rc.fetch(tabT, B, bcol, __float_as_int(pt.w));
-                    f2 gxy;
-                    float gz;
-                    rc.apply(pt, gxy, gz);
-                    float* dst = slot + (jl >> 2) * (3 * kBL * 4) + (jl & 3);
-                    dst[0] = gxy.x, dst[4 * kBL] = gxy.y, dst[8 * kBL] = gz;
+                    const Pair m = read_pair(p & 3, jl);
+                    float* dst = slot + (jl >> 2) * (3 * kBL * 4) + (jl & 3);  // jl even: the pair is two adjacent floats
+                    if (m.row0 != rc_row) rc = load_rows(tabT, B, bcol, m.row0), rc_row = m.row0;
+                    f2 gx, gy, gz;
+                    transform_v(rc, m.x, m.y, m.z, gx, gy, gz);
+                    if (m.row1 != m.row0) {  // a row boundary between the two members: the second one again, with its own row
+                        const Rows r1 = load_rows(tabT, B, bcol, m.row1);
+                        float hx, hy, hz;
+                        transform_v(r1, m.x.y, m.y.y, m.z.y, hx, hy, hz);
+                        gx.y = hx, gy.y = hy, gz.y = hz;
+                    }
+                    *reinterpret_cast<f2*>(dst) = gx, *reinterpret_cast<f2*>(dst + 4 * kBL) = gy, *reinterpret_cast<f2*>(dst + 8 * kBL) = gz;
                 }
             }
         }
@@ -475,10 +546,9 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
         TL_BARRIER(0, p);
     }
     // ---- pass 2: Mahalanobis terms (needs the mean of pass 1) ----
-    const InfoPk I = load_info_pk(info12, g);
+    const Info I = load_info(info12, g);
     lds_barrier();  // s_mean is complete
-    const f2 mxy = f2{s_mean[pb & 15], s_mean[kBL + (pb & 15)]};
-    const float mz = s_mean[2 * kBL + (pb & 15)];
+    const float mx = s_mean[pb & 15], my = s_mean[kBL + (pb & 15)], mz = s_mean[2 * kBL + (pb & 15)];
     for (int p = 0; p < nphases; ++p) {
         const int P = nphases + p;
         dma(P + 2);
@@ -489,12 +559,19 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
             for (int u = 0; u < kMaxSteps; ++u) {
                 if (jl_u[u] < left && jl_u[u] < kChunk) {
                     const int jl = jl_u[u];
-                    const float4 pt = s_m[P & 3][jl];
-                    rc.fetch(tabT, B, bcol, __float_as_int(pt.w));
-                    f2 gxy;
-                    float gz;
-                    rc.apply(pt, gxy, gz);
-                    slot[(jl >> 1) * (kBL * 2) + (jl & 1)] = (double)mahalanobis_term_pk(I, gxy, gz, mxy, mz);
+                    const Pair m = read_pair(P & 3, jl);
+                    double* dst = slot + (jl >> 1) * (kBL * 2);  // jl even: the pair is one double2
+                    if (m.row0 != rc_row) rc = load_rows(tabT, B, bcol, m.row0), rc_row = m.row0;
+                    f2 gx, gy, gz;
+                    transform_v(rc, m.x, m.y, m.z, gx, gy, gz);
+                    if (m.row1 != m.row0) {
+                        const Rows r1 = load_rows(tabT, B, bcol, m.row1);
+                        float hx, hy, hz;
+                        transform_v(r1, m.x.y, m.y.y, m.z.y, hx, hy, hz);
+                        gx.y = hx, gy.y = hy, gz.y = hz;
+                    }
+                    const f2 t = mahalanobis_v(I, gx, gy, gz, mx, my, mz);
+                    *reinterpret_cast<double2*>(dst) = double2{(double)t.x, (double)t.y};
                 }
             }
         }
@@ -555,10 +632,10 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
     const int n_long = sc.n_long, n_mid = sc.n_chain - sc.n_long;
     // latency tier first (its longest chain bounds the batch), blocks in descending size; the other tiers fill the chip around it
     if (n_long > 0)
-        hipLaunchKernelGGL((k_residuals_chain<8, true>), dim3((unsigned)n_long * sh.nsub_long), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
+        hipLaunchKernelGGL((k_residuals_chain<8, true, 64>), dim3((unsigned)n_long * sh.nsub_long), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
                            sh.Bs_long, sh.nsub_long, 2, E, ldE);
     if (n_mid > 0)
-        hipLaunchKernelGGL((k_residuals_chain<3, false>), dim3((unsigned)n_mid * sh.nsub), dim3(64 * 4), 0, s_rest, memb_local, seg_off, info, tabT, B,
+        hipLaunchKernelGGL((k_residuals_chain<4, false, 32>), dim3((unsigned)n_mid * sh.nsub), dim3(64 * 5), 0, s_rest, memb_local, seg_off, info, tabT, B,
                            order + n_long, sh.Bs, sh.nsub, 0, E, ldE);
     if (sc.n_small > 0) {
         const int items = sc.n_small * sh.nsub_small;
@@ -577,13 +654,13 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
         static long long h[2][16][64][2];
         (void)hipStreamSynchronize(s_long);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tl), sizeof(h));
-        for (int pass = 0; pass < 2; ++pass)
-            for (int ph = 8; ph < 14; ++ph) {
-                fprintf(stderr, "[timeline] B=%d pass=%d phase=%d:", B, pass + 1, ph + 32);
-                const long long base = h[pass][0][ph][0];
-                for (int w = 0; w < 10; ++w) fprintf(stderr, " w%d[%lld,%lld]", w, h[pass][w][ph][0] - base, h[pass][w][ph][1] - base);
-                fprintf(stderr, "\n");
-            }
+        for (int pass = 0; pass < 2; ++pass) {
+            fprintf(stderr, "[timeline] B=%d pass=%d chainer work per phase (release -> next arrival), phases 40..55:", B, pass + 1);
+            for (int ph = 8; ph < 24; ++ph) fprintf(stderr, " %lld", h[pass][0][ph + 1][0] - h[pass][0][ph][1]);
+            fprintf(stderr, "  | phase length (arrival -> arrival):");
+            for (int ph = 8; ph < 24; ++ph) fprintf(stderr, " %lld", h[pass][0][ph + 1][0] - h[pass][0][ph][0]);
+            fprintf(stderr, "\n");
+        }
     }
 #endif
 }

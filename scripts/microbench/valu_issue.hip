@@ -150,6 +150,40 @@ __global__ void k_lds_chain_f64(double* out, long long* cyc) {
     if (threadIdx.x == 0) cyc[0] = t1 - t0;  // 16 * 256 chain steps
 }
 
+// replica of the chainer's pass-1 loop: rolling ring of D float4 reads, ONE read per four dependent adds, pinned by sched_barrier;
+// MODE bit 0: s_setprio 3; bit 1: an s_barrier with nine idle waves after every 64 adds
+template <int MODE>
+__global__ void k_ring_chain(float* out, long long* cyc) {
+    __shared__ float4 s_q[4096];  // 64 KB
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_q[i] = float4{1.0f / (1 + (i & 1023)), 0.5f, 0.25f, 0.125f};
+    __syncthreads();
+    const bool chain = threadIdx.x < 64;
+    if (chain && (MODE & 1)) __builtin_amdgcn_s_setprio(3);
+    float acc = 0.f;
+    constexpr int D = 8, S = 16;
+    float4 r[D];
+    const float4* q4 = s_q + (threadIdx.x & 63);
+    if (chain)
+        for (int k = 0; k < D; ++k) r[k] = q4[k * 64];
+    long long t0 = clock64();
+    for (int rep = 0; rep < 64; ++rep) {
+        if (chain) {
+            const float4* cs = q4 + (rep & 3) * 1024;
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const float4 v = r[k % D];
+                r[k % D] = cs[((k + D) % S) * 64];
+                acc = acc + v.x, acc = acc + v.y, acc = acc + v.z, acc = acc + v.w;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (MODE & 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    long long t1 = clock64();
+    if (chain) out[threadIdx.x] = acc;
+    if (threadIdx.x == 0) cyc[0] = t1 - t0;  // 64 * 64 chain steps
+}
+
 template <class F>
 static void run(const char* name, F launch, double steps, long long* d_cyc) {
     hipEvent_t e0, e1;
@@ -193,6 +227,20 @@ int main() {
     run("lds b128 + 4 f32 adds chain", [&] { hipLaunchKernelGGL(k_lds_chain<4>, 1, 256, 0, 0, d_out, d_cyc); }, 16.0 * 256, d_cyc);
     run("lds b128(4 f32) + cvt + f64 add chain", [&] { hipLaunchKernelGGL(k_lds_chain_f64<0>, 1, 256, 0, 0, d_outd, d_cyc); }, 16.0 * 256, d_cyc);
     run("lds b128(2 f64) + f64 add chain", [&] { hipLaunchKernelGGL(k_lds_chain_f64<1>, 1, 256, 0, 0, d_outd, d_cyc); }, 16.0 * 256, d_cyc);
+    puts("-- replica of the chainer loop (rolling ring, 1 read per 4 adds): plain / setprio 3 / + barrier per 64 adds with 9 idle waves --");
+    run("ring chain, 1 wave", [&] { hipLaunchKernelGGL(k_ring_chain<0>, 1, 64, 0, 0, d_out, d_cyc); }, 4096.0, d_cyc);
+    run("ring chain, 1 wave, setprio 3", [&] { hipLaunchKernelGGL(k_ring_chain<1>, 1, 64, 0, 0, d_out, d_cyc); }, 4096.0, d_cyc);
+    run("ring chain, 10 waves, barrier per 64 adds", [&] { hipLaunchKernelGGL(k_ring_chain<2>, 1, 640, 0, 0, d_out, d_cyc); }, 4096.0, d_cyc);
+    run("ring chain, 10 waves, barrier, setprio 3", [&] { hipLaunchKernelGGL(k_ring_chain<3>, 1, 640, 0, 0, d_out, d_cyc); }, 4096.0, d_cyc);
+    run("ring chain, 10 waves, barrier, 220 workgroups", [&] { hipLaunchKernelGGL(k_ring_chain<3>, 220, 640, 0, 0, d_out, d_cyc); }, 4096.0, d_cyc);
+    puts("-- LDS-fed f32 chain (b128 + 4 adds), one chain wave per workgroup, many workgroups: does the per-step time hold chip-wide? --");
+    for (int wgs : {1, 64, 256, 512}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "lds b128 + 4 f32 adds chain, %3d workgroups x 256 threads", wgs);
+        run(nm, [&] { hipLaunchKernelGGL(k_lds_chain<4>, wgs, 256, 0, 0, d_out, d_cyc); }, 16.0 * 256, d_cyc);
+        snprintf(nm, sizeof nm, "lds b128(2 f64) + f64 add chain, %3d workgroups", wgs);
+        run(nm, [&] { hipLaunchKernelGGL(k_lds_chain_f64<1>, wgs, 256, 0, 0, d_outd, d_cyc); }, 16.0 * 256, d_cyc);
+    }
     puts("-- one workgroup (one CU): waves per SIMD sharing the VALU (ticks per instruction of ONE wave) --");
     for (int waves : {4, 8, 16}) {
         char nm[96];
