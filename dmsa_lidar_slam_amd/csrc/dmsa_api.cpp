@@ -347,7 +347,9 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
     HIPCHK(ctx->d_memb_idx.ensure(2 * n * 4));
     HIPCHK(ctx->d_memb_g.ensure(2 * n * 4));
     HIPCHK(ctx->d_seg_off.ensure((2 * n + 2) * 4));
-    HIPCHK(ctx->d_info12.ensure((2 * n / 2 + 16) * 48));  // sets have >= 2 members (two distinct ids)
+    // sets have >= 2 members (two distinct ids) -- except the second half of a splitSet, which may keep a single member when
+    // min_num_points_per_set <= 1: size for one set per membership
+    HIPCHK(ctx->d_info12.ensure((2 * n + 16) * 48));
     HIPCHK(ctx->d_wg_seg.ensure(4096 * 4));
     if (ctx->flags & DMSA_FLAG_MIRROR_SUMS) {
         HIPCHK(ctx->d_order.ensure((n + 16) * 4));
@@ -830,7 +832,19 @@ int upload_common(dmsa_ctx* ctx) {
 }
 
 // ---- the optimizeSet loop (DmsaOptimizer.h:54-150) -------------------------------------------------------------
+int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep);
+// A failure inside the loop (HIP error, lattice deeper than 21 levels, allocation) must not leave the resident problem in the centred
+// frame: the static points were shifted in place and the window origin lives only in the context.
 int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
+    const int rc = optimize_impl(ctx, s, rep);
+    if (rc != DMSA_OK && ctx->centralized) {
+        const std::string err = ctx->err;
+        (void)dmsa_decentralize(ctx);
+        ctx->err = err;
+    }
+    return rc;
+}
+int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
     ScopedTimer total(ctx, T_TOTAL);
     const bool fixed = (ctx->flags & DMSA_FLAG_FIXED_ITERS) != 0;
     const int P = num_params(ctx);
@@ -1122,8 +1136,13 @@ void dmsa_default_settings(dmsa_settings* s) {
 int dmsa_window_upload(dmsa_ctx* ctx, const dmsa_window_problem* p) {
     if (!ctx || !p || p->num_points < 0 || p->num_static < 0) return DMSA_ERR_INVALID;
     CHK(set_device(ctx));
+    if ((p->num_points > 0 && (!p->xyz_local || !p->tform_idx || !p->ring_id)) || (p->num_static > 0 && (!p->xyz_static || !p->ring_id_static)) ||
+        !(p->min_grid_size > 0.0f)) {
+        ctx->err = "invalid window problem (null point arrays or min_grid_size <= 0)";
+        return DMSA_ERR_INVALID;
+    }
     if (!ctx->win.init(*p)) {
-        ctx->err = "invalid window problem (control poses / stamps)";
+        ctx->err = "invalid window problem (fewer than 3 control poses, coincident stamps, null pose arrays or IMU parameter indices outside the time grid)";
         return DMSA_ERR_INVALID;
     }
     if (ctx->win.ctrl.n > 64) {
@@ -1195,6 +1214,19 @@ int dmsa_window_upload(dmsa_ctx* ctx, const dmsa_window_problem* p) {
 
 int dmsa_keyframes_upload(dmsa_ctx* ctx, const dmsa_keyframe_problem* p) {
     if (!ctx || !p || p->num_frames < 2) return DMSA_ERR_INVALID;
+    if (!p->frame_offset || !p->xyz_local || !p->normal_local || !p->ring_id || !p->rel_orient || !p->rel_transl || !(p->min_grid_size > 0.0f)) {
+        ctx->err = "invalid keyframe problem (null arrays or min_grid_size <= 0)";
+        return DMSA_ERR_INVALID;
+    }
+    if (p->frame_offset[0] != 0) {
+        ctx->err = "invalid keyframe problem (frame_offset[0] != 0)";
+        return DMSA_ERR_INVALID;
+    }
+    for (int k = 0; k < p->num_frames; ++k)
+        if (p->frame_offset[k + 1] < p->frame_offset[k]) {
+            ctx->err = "invalid keyframe problem (frame_offset not non-decreasing)";
+            return DMSA_ERR_INVALID;
+        }
     CHK(set_device(ctx));
     if (!ctx->key.init(*p)) return DMSA_ERR_INVALID;
     ctx->model = MODEL_KEYFRAMES;
@@ -1223,6 +1255,7 @@ int dmsa_keyframes_upload(dmsa_ctx* ctx, const dmsa_keyframe_problem* p) {
 int dmsa_centralize(dmsa_ctx* ctx) {
     if (!ctx || ctx->model == MODEL_NONE) return DMSA_ERR_INVALID;
     if (ctx->model == MODEL_KEYFRAMES) return DMSA_OK;  // MapManagement::centralize returns immediately (MapManagement.h:73-79)
+    if (ctx->centralized) return DMSA_OK;  // already in the centred frame: a second shift would lose the origin
     CHK(set_device(ctx));
     WindowHost& w = ctx->win;  // ContinuousTrajectory.h:75-88
     w.origin = {w.ctrl.rel_t[0], w.ctrl.rel_t[1], w.ctrl.rel_t[2]};
@@ -1237,6 +1270,7 @@ int dmsa_centralize(dmsa_ctx* ctx) {
 int dmsa_decentralize(dmsa_ctx* ctx) {
     if (!ctx || ctx->model == MODEL_NONE) return DMSA_ERR_INVALID;
     if (ctx->model == MODEL_KEYFRAMES) return DMSA_OK;
+    if (!ctx->centralized) return DMSA_OK;  // nothing to undo
     CHK(set_device(ctx));
     WindowHost& w = ctx->win;  // ContinuousTrajectory.h:89-100
     w.ctrl.global_to_relative();

@@ -924,15 +924,18 @@ __global__ __launch_bounds__(kThreads) void k_leaf_split(const int32_t* __restri
         }
     }
 }
-size_t split_scratch_bytes(int64_t n) { return (size_t)n * 8 + (size_t)n * sizeof(SplitTask) + 64; }
+// pair_best[n] | counter (own 64-byte slot) | task list.  k_split_tasks emits up to 64 tasks per 64-position wave block, i.e. up to
+// 64 * ceil(n / 64) entries when n is not a multiple of 64: the list is sized for that, and the counter no longer sits behind it.
+static inline size_t split_task_capacity(int64_t n) { return (size_t)((n + 63) / 64) * 64 + 64; }
+size_t split_scratch_bytes(int64_t n) { return (size_t)n * 8 + 64 + split_task_capacity(n) * sizeof(SplitTask) + 64; }
 void launch_leaf_split(const int32_t* leaf_incl, const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const float4* nglobal,
                        const LevelCounts* counts, int min_pts, int64_t n, float4* nsorted, unsigned long long* pair_best, int32_t* slot_acc,
                        int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s) {
     hipLaunchKernelGGL(k_split_gather_normals, dim3(grid_for(n, 256)), dim3(256), 0, s, idx_sorted, nglobal, ring, n, nsorted);
     (void)hipMemsetAsync(pair_best, 0xFF, (size_t)n * 8, s);
-    // task list (<= one entry per position) and its counter live behind the n pair_best entries
-    SplitTask* tasks = reinterpret_cast<SplitTask*>(pair_best + n);
-    int32_t* num_tasks = reinterpret_cast<int32_t*>(tasks + n);
+    // the task counter (own slot) and the task list live behind the n pair_best entries
+    int32_t* num_tasks = reinterpret_cast<int32_t*>(pair_best + n);
+    SplitTask* tasks = reinterpret_cast<SplitTask*>(reinterpret_cast<char*>(pair_best + n) + 64);
     (void)hipMemsetAsync(num_tasks, 0, sizeof(int32_t), s);
     hipLaunchKernelGGL(k_split_tasks, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, leaf_incl, leaf_start, slot_acc, n, counts, tasks, num_tasks);
     hipLaunchKernelGGL(k_split_pairs, dim3(4096), dim3(256), 0, s, leaf_incl, leaf_start, slot_acc, nsorted, n, counts, tasks, num_tasks, pair_best);

@@ -230,7 +230,10 @@ void keyframe_table(const PoseChain& frames, float* table) {
 // ---- WindowHost ---------------------------------------------------------------------------------------
 bool WindowHost::init(const dmsa_window_problem& p) {
     const int C = p.num_control_poses;
-    if (C < 2 || p.n_total < 2) return false;
+    // Floater-Hormann with d = 2 needs at least three nodes (boost's barycentric_rational throws for n <= order; with two nodes every
+    // weight would be zero and the tables NaN)
+    if (C < 3 || p.n_total < 2) return false;
+    if (!p.rel_orient || !p.rel_transl || !p.stamps || !p.traj_time) return false;
     ctrl.resize(C);
     std::copy(p.rel_orient, p.rel_orient + 3 * C, ctrl.rel_o.begin());
     std::copy(p.rel_transl, p.rel_transl + 3 * C, ctrl.rel_t.begin());
@@ -239,6 +242,12 @@ bool WindowHost::init(const dmsa_window_problem& p) {
     if (!fh.build(stamps.data(), C)) return false;
     use_imu = p.use_imu != 0;
     if (use_imu) {
+        if (!p.param_indices || !p.preint_rot || !p.preint_pos || !p.preint_vel || !p.cov_pvrot_inv || !(p.dt_res > 0.0)) return false;
+        // updateImuError reads trajTime[i0 + 1] and trajTime[i1 - 1] (ContinuousTrajectory.h:634-637): the indices must stay inside the grid
+        for (int k = 1; k < C; ++k) {
+            const int i0 = p.param_indices[k - 1], i1 = p.param_indices[k];
+            if (i0 < 0 || i0 + 1 >= p.n_total || i1 < 1 || i1 >= p.n_total) return false;
+        }
         dt_res = p.dt_res, balancing_imu = p.balancing_imu;
         gravity = {p.gravity[0], p.gravity[1], p.gravity[2]};
         param_indices.assign(p.param_indices, p.param_indices + C);

@@ -195,11 +195,15 @@ class MapManagement:
     odomRelOrientMat: np.ndarray | None = None    # (F,3,3)
     odometryTranslCovInv: np.ndarray = field(default_factory=lambda: np.eye(3) / 0.01 ** 2)
     odometryOrientCovInv: np.ndarray = field(default_factory=lambda: np.eye(3) / 0.01 ** 2)
+    gridSizes: np.ndarray | None = None           # (F,) KeyframeData::gridSize of every frame (minGridSize = their minimum, MapManagement.h:123-130)
 
     def __post_init__(self):
         self.relOrientations = _f64(self.relOrientations)
         self.relTranslations = _f64(self.relTranslations)
         f = self.relOrientations.shape[0]
+        if self.gridSizes is not None:
+            self.gridSizes = np.ascontiguousarray(self.gridSizes, dtype=np.float32)
+            assert self.gridSizes.shape == (f,)
         assert self.relOrientations.shape == (f, 3) and self.relTranslations.shape == (f, 3)
         self.frameOffsets = np.ascontiguousarray(self.frameOffsets, dtype=np.int64)
         assert self.frameOffsets.shape == (f + 1,)
@@ -272,17 +276,27 @@ class MapManagement:
         ro, rt = global2relative(go[fromId:toId + 1], gt[fromId:toId + 1])
         a, b = int(self.frameOffsets[fromId]), int(self.frameOffsets[toId + 1])
         sl = slice(fromId, toId + 1)
+        # The reference rebuilds the submap through addKeyframe (:266), which stores as each frame's odometry measurement the relative
+        # pose derived from the CURRENT global poses (:337-355): at extraction the odometry residuals are exactly zero, i.e. a prior on
+        # the current estimate, not on the odometry of the time the keyframe was created.
+        odom_t = odom_R = None
+        if self.odomRelTransl is not None or self.useOdometryErrorTerms:
+            from scipy.spatial.transform import Rotation as Rot
+
+            odom_t, odom_R = rt.copy(), Rot.from_rotvec(ro).as_matrix()
+        # minGridSize of the submap = smallest gridSize of ITS frames (:260-272)
+        grid = float(self.minGridSize) if self.gridSizes is None else float(self.gridSizes[sl].min())
         return MapManagement(
             relOrientations=ro, relTranslations=rt, frameOffsets=self.frameOffsets[fromId:toId + 2] - a,
             localPoints=self.localPoints[a:b], localNormals=self.localNormals[a:b], ringIds=self.ringIds[a:b],
-            minGridSize=self.minGridSize, useGravityErrorTerms=self.useGravityErrorTerms,
+            minGridSize=grid, useGravityErrorTerms=self.useGravityErrorTerms,
             useOdometryErrorTerms=self.useOdometryErrorTerms, gravity=self.gravity, Cov_grav_inv=self.Cov_grav_inv,
             balancingFactorGrav=self.balancingFactorGrav, balancingFactorOdom=self.balancingFactorOdom,
             measuredGravity=None if self.measuredGravity is None else self.measuredGravity[sl],
             gravityPlausible=None if self.gravityPlausible is None else self.gravityPlausible[sl],
-            odomRelTransl=None if self.odomRelTransl is None else self.odomRelTransl[sl],
-            odomRelOrientMat=None if self.odomRelOrientMat is None else self.odomRelOrientMat[sl],
+            odomRelTransl=odom_t, odomRelOrientMat=odom_R,
             odometryTranslCovInv=self.odometryTranslCovInv, odometryOrientCovInv=self.odometryOrientCovInv,
+            gridSizes=None if self.gridSizes is None else self.gridSizes[sl],
         )
 
     def updatePosesFromSubmap(self, fromId: int, toId: int, submap: "MapManagement") -> None:
@@ -311,7 +325,7 @@ class MapManagement:
             offsets = np.array([0, pts.shape[0]], np.int64)
             cloud, normals, rings = pts, nrm, ids
             mg, gp = grav[None, :], np.array([int(gravityPlausible)], np.int32)
-            odom_t, odom_R, grid = np.zeros((0, 3)), np.zeros((0, 3, 3)), float(gridSize)
+            odom_t, odom_R, grids = np.zeros((0, 3)), np.zeros((0, 3, 3)), np.array([gridSize], np.float32)
             base = dict(settings)
         else:
             m = keyframeMap
@@ -325,7 +339,8 @@ class MapManagement:
             mg = np.vstack([(m.measuredGravity if m.measuredGravity is not None else z3)[first:], grav])
             gp = np.concatenate([(m.gravityPlausible if m.gravityPlausible is not None else np.ones(m.numFrames, np.int32))[first:], [int(gravityPlausible)]]).astype(np.int32)
             odom_t, odom_R = (m.odomRelTransl if m.odomRelTransl is not None else z3)[first:], (m.odomRelOrientMat if m.odomRelOrientMat is not None else z33)[first:]
-            grid = min(float(m.minGridSize), float(gridSize))
+            old = m.gridSizes if m.gridSizes is not None else np.full(m.numFrames, m.minGridSize, np.float32)
+            grids = np.concatenate([old[first:], [gridSize]]).astype(np.float32)  # an evicted frame no longer bounds minGridSize (:123-130)
             base = dict(useGravityErrorTerms=m.useGravityErrorTerms, useOdometryErrorTerms=m.useOdometryErrorTerms, gravity=m.gravity, Cov_grav_inv=m.Cov_grav_inv,
                         balancingFactorGrav=m.balancingFactorGrav, balancingFactorOdom=m.balancingFactorOdom, odometryTranslCovInv=m.odometryTranslCovInv,
                         odometryOrientCovInv=m.odometryOrientCovInv)
@@ -335,7 +350,8 @@ class MapManagement:
         odom_t = np.vstack([odom_t, rt[-1]])                                              # relativeTransl (:344 / :351)
         odom_R = np.concatenate([odom_R, Rot.from_rotvec(ro[-1]).as_matrix()[None]])      # relativeOrientMat = axang2rotm(relativeOrient) (:347)
         return MapManagement(relOrientations=ro, relTranslations=rt, frameOffsets=offsets, localPoints=cloud, localNormals=_pad4(normals), ringIds=rings,
-                             minGridSize=grid, measuredGravity=mg, gravityPlausible=gp, odomRelTransl=odom_t, odomRelOrientMat=odom_R, **base)
+                             minGridSize=float(grids.min()), measuredGravity=mg, gravityPlausible=gp, odomRelTransl=odom_t, odomRelOrientMat=odom_R,
+                             gridSizes=grids, **base)
 
 
 def _pad4(a):

@@ -97,6 +97,23 @@ def test_keyframes_ragged_frames(hip, orc):
     _parity_run(hip, orc, prob, DmsaOptimSettings.keyframe_map(num_iter=2), window=False)
 
 
+def test_config4_at_the_shard_size_bench_times(hip, orc):
+    """One neighbourhood exactly as `bench.py --workload keyframes` / the keyframe_pass key shards it: 32 keyframes x ~10^4 points
+    (P = 186 parameters, 197 evaluations per iteration), gauss_split, gravity rows -- the default path against the oracle for two
+    iterations: same Gaussian counts, same line-search decisions, poses within 1e-4 m / 1e-4 rad (the oracle needs ~1.5 s per
+    iteration here)."""
+    frames = 32
+    full = synth.keyframe_problem(seed=1, frames=frames, arc=2 * np.pi * frames / 256.0)
+    prob = full.getSubmap(0, frames - 1)
+    assert prob.numParams == 186 and prob.localPoints.shape[0] > 300_000 and prob.useGravityErrorTerms
+    s = DmsaOptimSettings.keyframe_map(num_iter=2)
+    assert s.gauss_split
+    rep, p_gpu = _parity_run(hip, orc, prob, s, window=False)
+    assert rep.iterations == 2 and rep.evaluations == 2 * (186 + 10)
+    moved_t, moved_r = _pose_diff(orc, prob, p_gpu)
+    assert moved_t > 1e-5 or moved_r > 1e-5
+
+
 def test_keyframes_fast_path_equivalent(hip, orc):
     prob = synth.keyframe_problem(seed=3, frames=8, rings=24, az_steps=160, arc=0.5)
     s = DmsaOptimSettings.keyframe_map(num_iter=3)

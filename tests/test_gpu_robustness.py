@@ -51,12 +51,13 @@ def test_two_contexts_interleaved(hip):
     assert (ra1.num_gaussians, rb1.num_gaussians) != (0, 0)
 
 
-def test_fast_path_is_deterministic(hip):
+@pytest.mark.parametrize("fast", [False, True])
+def test_both_paths_are_deterministic(hip, fast):
     p = synth.window_problem(seed=43, scans=3, rings=32, az_steps=192, num_static=4000)
     s = DmsaOptimSettings.sliding_window(num_iter=3)
     a, b = p.copy(), p.copy()
-    hip.DmsaOptimizer().optimizeSet(a, s)
-    hip.DmsaOptimizer().optimizeSet(b, s)
+    hip.DmsaOptimizer(fast_sums=fast).optimizeSet(a, s)
+    hip.DmsaOptimizer(fast_sums=fast).optimizeSet(b, s)
     assert np.array_equal(_poses(a), _poses(b))
 
 
@@ -91,6 +92,42 @@ def test_coincident_control_stamps_are_rejected(hip):
     p.stamps[2] = p.stamps[1]
     with pytest.raises(hip.DmsaError):
         hip.DmsaOptimizer().optimizeSet(p, DmsaOptimSettings.sliding_window(num_iter=1))
+
+
+def test_malformed_problems_are_rejected(hip):
+    """What the reference would turn into NaN tables or out-of-bounds reads comes back as DMSA_ERR_INVALID: two control poses
+    (Floater-Hormann d = 2 needs three), IMU parameter indices outside the time grid, non-positive minGridSize, frame offsets
+    that decrease, a null normal array."""
+    s = DmsaOptimSettings.sliding_window(num_iter=1)
+    two = synth.window_problem(seed=38, scans=2, rings=8, az_steps=64, num_static=100, num_control_poses=2)
+    with pytest.raises(hip.DmsaError):
+        hip.DmsaOptimizer().optimizeSet(two, s)
+    imu = synth.window_problem(seed=39, scans=2, rings=8, az_steps=64, num_static=100, use_imu=True)
+    imu.paramIndices = imu.paramIndices.copy()
+    imu.paramIndices[-1] = imu.trajTime.shape[0] + 5
+    with pytest.raises(hip.DmsaError):
+        hip.DmsaOptimizer().optimizeSet(imu, DmsaOptimSettings.sliding_window(use_imu=True, num_iter=1))
+    grid = synth.window_problem(seed=40, scans=2, rings=8, az_steps=64, num_static=100)
+    grid.minGridSize = 0.0
+    with pytest.raises(hip.DmsaError):
+        hip.DmsaOptimizer().optimizeSet(grid, s)
+    kf = synth.keyframe_problem(seed=41, frames=3, rings=8, az_steps=64, arc=0.1)
+    kf.frameOffsets = kf.frameOffsets.copy()
+    kf.frameOffsets[1], kf.frameOffsets[2] = kf.frameOffsets[2], kf.frameOffsets[1]
+    with pytest.raises(hip.DmsaError):
+        hip.DmsaOptimizer().optimizeSet(kf, DmsaOptimSettings.keyframe_map(num_iter=1))
+
+
+def test_repeated_centralize_keeps_the_origin(hip):
+    """dmsa_centralize twice in a row must not lose the window origin (the second call is a no-op), and decentralize restores it."""
+    p = synth.window_problem(seed=42, scans=2, rings=8, az_steps=64, num_static=500)
+    opt = hip.DmsaOptimizer()
+    opt.upload(p)
+    before = opt.poses()
+    opt.centralize(), opt.centralize()
+    opt.decentralize(), opt.decentralize()
+    after = opt.poses()
+    assert np.abs(before[1] - after[1]).max() < 1e-12 and np.abs(before[0] - after[0]).max() < 1e-12
 
 
 def test_create_destroy_cycles_release_device_memory(hip):
