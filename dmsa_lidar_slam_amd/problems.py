@@ -270,20 +270,25 @@ class MapManagement:
     def getSubmap(self, fromId: int, toId: int) -> "MapManagement":
         """MapManagement::getSubmap (MapManagement.h:254-276): independent problem over keyframes
         fromId..toId whose first frame carries its GLOBAL pose (and therefore stays fixed)."""
-        from .posemath import global2relative, relative2global
-
-        go, gt = relative2global(self.relOrientations, self.relTranslations)
-        ro, rt = global2relative(go[fromId:toId + 1], gt[fromId:toId + 1])
+        # pose part through the C ABI (include/dmsa_keyframe_map.h: the same code a C++ host links)
+        n = toId - fromId + 1
+        ro, rt = np.zeros((n, 3)), np.zeros((n, 3))
+        odom_t, odom_R_cm = np.zeros((n, 3)), np.zeros((n, 9))
+        full_o, full_t = _f64(self.relOrientations), _f64(self.relTranslations)
+        rc = capi.load_library().dmsa_submap_poses(self.numFrames, capi.ptr(full_o, C.c_double), capi.ptr(full_t, C.c_double), int(fromId), int(toId),
+                                                   capi.ptr(ro, C.c_double), capi.ptr(rt, C.c_double), capi.ptr(odom_t, C.c_double), capi.ptr(odom_R_cm, C.c_double))
+        if rc != 0:
+            raise ValueError(f"getSubmap({fromId}, {toId}) on {self.numFrames} frames")
         a, b = int(self.frameOffsets[fromId]), int(self.frameOffsets[toId + 1])
         sl = slice(fromId, toId + 1)
         # The reference rebuilds the submap through addKeyframe (:266), which stores as each frame's odometry measurement the relative
         # pose derived from the CURRENT global poses (:337-355): at extraction the odometry residuals are exactly zero, i.e. a prior on
         # the current estimate, not on the odometry of the time the keyframe was created.
-        odom_t = odom_R = None
+        odom_R = None
         if self.odomRelTransl is not None or self.useOdometryErrorTerms:
-            from scipy.spatial.transform import Rotation as Rot
-
-            odom_t, odom_R = rt.copy(), Rot.from_rotvec(ro).as_matrix()
+            odom_R = np.ascontiguousarray(np.transpose(odom_R_cm.reshape(n, 3, 3), (0, 2, 1)))  # col-major 3x3 -> [k][row][col]
+        else:
+            odom_t = None
         # minGridSize of the submap = smallest gridSize of ITS frames (:260-272)
         grid = float(self.minGridSize) if self.gridSizes is None else float(self.gridSizes[sl].min())
         return MapManagement(
@@ -302,9 +307,11 @@ class MapManagement:
     def updatePosesFromSubmap(self, fromId: int, toId: int, submap: "MapManagement") -> None:
         """MapManagement::updatePosesFromSubmap (MapManagement.h:278-288): relative poses of
         columns fromId+1..toId are overwritten by the submap's."""
-        n = toId - fromId + 1
-        self.relTranslations[fromId + 1:fromId + n] = submap.relTranslations[1:n]
-        self.relOrientations[fromId + 1:fromId + n] = submap.relOrientations[1:n]
+        sub_o, sub_t = _f64(submap.relOrientations), _f64(submap.relTranslations)
+        rc = capi.load_library().dmsa_update_poses_from_submap(self.numFrames, capi.ptr(self.relOrientations, C.c_double), capi.ptr(self.relTranslations, C.c_double),
+                                                               int(fromId), int(toId), capi.ptr(sub_o, C.c_double), capi.ptr(sub_t, C.c_double))
+        if rc != 0:
+            raise ValueError(f"updatePosesFromSubmap({fromId}, {toId}) on {self.numFrames} frames")
 
     @staticmethod
     def addKeyframe(keyframeMap: "MapManagement | None", position_w, orient_w, localPoints, localNormals, ringIds, gridSize: float,

@@ -17,10 +17,16 @@ from .problems import DmsaOptimSettings, MapManagement
 
 def neighbourhood_ranges(num_frames: int, world: int):
     """Contiguous [from, to] frame ranges (inclusive) sharing one boundary frame; every rank gets >= 2 frames."""
+    import ctypes as C
+
+    from . import _capi as capi
+
     if world < 1 or num_frames < world + 1:
         raise ValueError("need at least world + 1 keyframes")
-    edges = np.linspace(0, num_frames - 1, world + 1).round().astype(int)
-    return [(int(edges[i]), int(edges[i + 1])) for i in range(world)]
+    f, t = (C.c_int32 * world)(), (C.c_int32 * world)()
+    if capi.load_library().dmsa_neighbourhood_ranges(int(num_frames), int(world), f, t) != 0:  # include/dmsa_keyframe_map.h
+        raise ValueError("dmsa_neighbourhood_ranges")
+    return [(int(f[i]), int(t[i])) for i in range(world)]
 
 
 def gather_neighbourhood_poses(full_map: MapManagement, sub: MapManagement, ranges, rank: int, world: int, dist=None, device=None):
@@ -28,9 +34,11 @@ def gather_neighbourhood_poses(full_map: MapManagement, sub: MapManagement, rang
     doubles) and apply updatePosesFromSubmap (MapManagement.h:278-288) for every neighbourhood on every rank."""
     f0, f1 = ranges[rank]
     width = max(t - f for f, t in ranges)
+    # updatePosesFromSubmap on the owner (its global2relative round trip needs the submap's first pose), then the owner's columns travel
+    full_map.updatePosesFromSubmap(f0, f1, sub)
     mine = np.zeros((width, 6))
-    mine[: f1 - f0, :3] = sub.relOrientations[1:]
-    mine[: f1 - f0, 3:] = sub.relTranslations[1:]
+    mine[: f1 - f0, :3] = full_map.relOrientations[f0 + 1:f1 + 1]
+    mine[: f1 - f0, 3:] = full_map.relTranslations[f0 + 1:f1 + 1]
     if world > 1:
         import torch
 

@@ -73,3 +73,32 @@ def test_two_rank_gloo_sharded_pass_matches_sequential(tmp_path):
         ref.updatePosesFromSubmap(f, t, sub)
     assert np.array_equal(a["ro"], ref.relOrientations) and np.array_equal(a["rt"], ref.relTranslations)
     assert np.abs(a["rt"] - m.relTranslations).max() > 1e-5  # the pass changed something
+
+
+def test_keyframe_map_seam_of_the_c_abi():
+    """include/dmsa_keyframe_map.h (host-only entry points of libdmsa_hip.so, what a C++ host links): getSubmap's poses against an
+    independent scipy statement, the odometry measurements it stores, and updatePosesFromSubmap as the inverse cut."""
+    sys.path.insert(0, ROOT)
+    from scipy.spatial.transform import Rotation as Rot
+
+    from dmsa_lidar_slam_amd import posemath
+
+    m = _make_map()
+    m.useOdometryErrorTerms = True
+    sub = m.getSubmap(2, 5)
+    go, gt = posemath.relative2global(m.relOrientations, m.relTranslations)   # scipy rotations, independent of the library's math
+    ro, rt = posemath.global2relative(go[2:6], gt[2:6])
+    assert np.abs(sub.relOrientations - ro).max() < 1e-12 and np.abs(sub.relTranslations - rt).max() < 1e-12
+    assert np.array_equal(sub.odomRelTransl, sub.relTranslations)
+    assert np.abs(sub.odomRelOrientMat - Rot.from_rotvec(sub.relOrientations).as_matrix()).max() < 1e-12
+    assert sub.localPoints.shape[0] == m.frameOffsets[6] - m.frameOffsets[2]
+    # writing an unchanged submap back leaves the map where it was (to rounding), a changed one lands in columns 3..5 only
+    back = m.copy()
+    back.updatePosesFromSubmap(2, 5, sub)
+    assert np.abs(back.relTranslations - m.relTranslations).max() < 1e-12 and np.abs(back.relOrientations - m.relOrientations).max() < 1e-12
+    sub.relTranslations[1:] += 0.01
+    back.updatePosesFromSubmap(2, 5, sub)
+    changed = np.abs(back.relTranslations - m.relTranslations).max(axis=1) > 1e-6
+    assert list(np.nonzero(changed)[0]) == [3, 4, 5]
+    with pytest.raises(ValueError):
+        m.getSubmap(3, 99)
