@@ -1,0 +1,172 @@
+// ref_main.cpp — harness that runs the UNMODIFIED reference (davidskdds/DMSA_LiDAR_SLAM, include/DMSA/*.h) on the flat dumps of
+// dmsa_lidar_slam_amd/dump.py and writes the poses its DmsaOptimizer::optimizeSet produces.  TEST INFRASTRUCTURE (oracle pinning).
+//
+// It cannot be built in the graft image: the reference's headers need Eigen 3.4 (unsupported/MatrixFunctions, reshaped), PCL >= 1.10
+// (octree, kdtree, features), Boost.Math and the ROS headers pcl_conversions / pcl_ros (PointStampId.h:21-24).  On a machine that has
+// them (Ubuntu 20.04 + ROS Noetic, README.md:77-79 of the reference) scripts/build_ref_oracle.sh compiles this file against the
+// reference tree where it lies, runs it on tests/golden/ref_inputs/*.bin and writes tests/golden/ref_*.poses.bin;
+// tests/test_ref_fixtures.py then checks the CPU oracle and the HIP library against those files.  No stand-in headers, no copied
+// reference source: only #include of the reference's own files.
+//
+//   ref_main window    <window.bin> <poses_out.bin> <num_iter>     DmsaOptimizer<PointStampId>::optimizeSet(ContinuousTrajectory&)
+//   ref_main keyframes <map.bin>    <poses_out.bin> <num_iter>     DmsaOptimizer<PointNormal>::optimizeSet(MapManagement&)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+
+#include "DMSA/PointStampId.h"
+#include "DMSA/PointCloudPlus.h"
+#include "DMSA/PointCloudBuffer.h"
+#include "DMSA/helpers.h"
+#include "DMSA/ContinuousTrajectory.h"
+#include "DMSA/KeyframeData.h"
+#include "DMSA/MapManagement.h"
+#include "DMSA/DmsaOptimizer.h"
+
+template <class T>
+static bool rd(FILE* f, T* p, size_t count) { return std::fread(p, sizeof(T), count, f) == count; }
+
+static void write_poses(const char* path, const Eigen::Matrix3Xd& o, const Eigen::Matrix3Xd& t) {
+    FILE* f = std::fopen(path, "wb");
+    const int32_t hdr[2] = {(int32_t)o.cols(), 0};
+    std::fwrite("DMSAPO01", 1, 8, f), std::fwrite(hdr, 4, 2, f);
+    std::fwrite(o.data(), 8, (size_t)o.size(), f), std::fwrite(t.data(), 8, (size_t)t.size(), f);  // 3 x n column-major == F x 3 row-major
+    std::fclose(f);
+}
+
+// window dump: dump.py write_window_problem ('DMSAWN01')
+static int run_window(const char* in, const char* out, int num_iter) {
+    FILE* f = std::fopen(in, "rb");
+    if (!f) return 2;
+    char magic[8];
+    int32_t C, n_total, use_imu, pad;
+    int64_t N, S;
+    float min_grid, padf;
+    double dt_res;
+    if (!(rd(f, magic, 8) && !std::memcmp(magic, "DMSAWN01", 8) && rd(f, &C, 1) && rd(f, &n_total, 1) && rd(f, &N, 1) && rd(f, &S, 1) && rd(f, &min_grid, 1) &&
+          rd(f, &padf, 1) && rd(f, &use_imu, 1) && rd(f, &pad, 1) && rd(f, &dt_res, 1)))
+        return 2;
+    std::vector<double> ro(3 * C), rt(3 * C), stamps(C), traj(n_total);
+    std::vector<float> xyz(4 * N), sxyz(4 * S);
+    std::vector<int32_t> tf(N), ring(N), sring(S);
+    if (!(rd(f, ro.data(), ro.size()) && rd(f, rt.data(), rt.size()) && rd(f, stamps.data(), stamps.size()) && rd(f, traj.data(), traj.size()) &&
+          rd(f, xyz.data(), xyz.size()) && rd(f, tf.data(), tf.size()) && rd(f, ring.data(), ring.size()) && rd(f, sxyz.data(), sxyz.size()) &&
+          rd(f, sring.data(), sring.size())))
+        return 2;
+    std::fclose(f);
+    if (use_imu) {
+        std::fprintf(stderr, "ref_main: IMU windows are not part of this harness (no IMU rows in the dump)\n");
+        return 2;
+    }
+    ContinuousTrajectory traj_obj;
+    // initTraj (ContinuousTrajectory.h:301-346) derives the time grid from (t_min, t_max, dt_res); the dump carries the grid it produced,
+    // so the same call reproduces it: horizon = trajTime.back()
+    traj_obj.initTraj(0.0, traj.back() - dt_res, C, false, dt_res);
+    if (traj_obj.n_total != n_total) {
+        std::fprintf(stderr, "ref_main: initTraj gives n_total %d, dump has %d\n", traj_obj.n_total, n_total);
+        return 3;
+    }
+    for (int k = 0; k < C; ++k) {
+        traj_obj.controlPoses.stamps(k) = stamps[k];
+        for (int c = 0; c < 3; ++c) traj_obj.controlPoses.relativePoses.Orientations(c, k) = ro[3 * k + c], traj_obj.controlPoses.relativePoses.Translations(c, k) = rt[3 * k + c];
+    }
+    for (int k = 0; k < n_total; ++k) traj_obj.trajTime(k) = traj[k];
+    // one PointCloudPlus holding every window point; stamp = trajTime[tformIdx] makes registerPcBuffer's lower_bound (:253-254) return
+    // exactly the dumped index
+    auto buffer = std::make_shared<PointCloudBuffer>();
+    buffer->init(1);
+    PointCloudPlus cloud;
+    cloud.gridSize = min_grid;
+    cloud.points.resize(N);
+    for (int64_t i = 0; i < N; ++i) {
+        PointStampId& p = cloud.points[i];
+        p.x = xyz[4 * i], p.y = xyz[4 * i + 1], p.z = xyz[4 * i + 2], p.data[3] = 1.0f;
+        p.stamp = traj[tf[i]], p.id = ring[i], p.isStatic = 0;
+    }
+    cloud.width = (uint32_t)N, cloud.height = 1;
+    buffer->addElem(cloud);
+    traj_obj.registerPcBuffer(buffer);
+    pcl::PointCloud<PointStampId> stat;
+    stat.points.resize(S);
+    for (int64_t i = 0; i < S; ++i) stat.points[i].x = sxyz[4 * i], stat.points[i].y = sxyz[4 * i + 1], stat.points[i].z = sxyz[4 * i + 2], stat.points[i].id = sring[i];
+    traj_obj.addStaticPoints(stat);  // :158-172
+    DmsaOptimSettings s;             // optimSettingsSlidingWindow (DmsaSlam.h:84-90)
+    s.num_iter = num_iter, s.step_length_optim = 0.05, s.max_step = 0.01, s.gauss_split = false, s.min_num_points_per_set = 6;
+    DmsaOptimizer<PointStampId> opt;
+    opt.optimizeSet(traj_obj, s);    // DmsaSlam.h:166
+    write_poses(out, traj_obj.controlPoses.relativePoses.Orientations, traj_obj.controlPoses.relativePoses.Translations);
+    return 0;
+}
+
+// keyframe dump: dump.py write_keyframe_map ('DMSAKF01')
+static int run_keyframes(const char* in, const char* out, int num_iter) {
+    FILE* f = std::fopen(in, "rb");
+    if (!f) return 2;
+    char magic[8];
+    int32_t F, use_gravity;
+    int64_t n;
+    float min_grid, padf;
+    double gravity[3], cov[9], bal;
+    if (!(rd(f, magic, 8) && !std::memcmp(magic, "DMSAKF01", 8) && rd(f, &F, 1) && rd(f, &use_gravity, 1) && rd(f, &n, 1) && rd(f, &min_grid, 1) && rd(f, &padf, 1) &&
+          rd(f, gravity, 3) && rd(f, cov, 9) && rd(f, &bal, 1)))
+        return 2;
+    std::vector<double> ro(3 * F), rt(3 * F), grav(3 * F);
+    std::vector<int64_t> off(F + 1);
+    std::vector<float> xyz(4 * n), nrm(4 * n);
+    std::vector<int32_t> ring(n), plaus(F);
+    if (!(rd(f, ro.data(), ro.size()) && rd(f, rt.data(), rt.size()) && rd(f, off.data(), off.size()) && rd(f, xyz.data(), xyz.size()) && rd(f, nrm.data(), nrm.size()) &&
+          rd(f, ring.data(), ring.size()) && rd(f, grav.data(), grav.size()) && rd(f, plaus.data(), plaus.size())))
+        return 2;
+    std::fclose(f);
+    // global poses of the dumped relative chain (ConsecutivePoses::relative2global), then the map is built the way DmsaSlam builds it:
+    // one addKeyframe per frame (MapManagement.h:311-390)
+    StampedConsecutivePoses chain(F);
+    for (int k = 0; k < F; ++k)
+        for (int c = 0; c < 3; ++c) chain.relativePoses.Orientations(c, k) = ro[3 * k + c], chain.relativePoses.Translations(c, k) = rt[3 * k + c];
+    chain.relative2global();
+    MapManagement map(F);
+    map.useGravityErrorTerms = use_gravity != 0, map.useOdometryErrorTerms = false;
+    map.gravity << gravity[0], gravity[1], gravity[2];
+    map.Cov_grav_inv = Eigen::Map<Eigen::Matrix3d>(cov);
+    map.balancingFactorGrav = bal;
+    for (int k = 0; k < F; ++k) {
+        KeyframeData kd;
+        kd.pointCloudLocal = pcl::PointCloud<pcl::PointNormal>::Ptr(new pcl::PointCloud<pcl::PointNormal>());
+        const int64_t a = off[k], b = off[k + 1];
+        kd.pointCloudLocal->points.resize(b - a);
+        kd.ringIds.resize(b - a);
+        for (int64_t i = a; i < b; ++i) {
+            pcl::PointNormal& p = kd.pointCloudLocal->points[i - a];
+            p.x = xyz[4 * i], p.y = xyz[4 * i + 1], p.z = xyz[4 * i + 2];
+            p.normal_x = nrm[4 * i], p.normal_y = nrm[4 * i + 1], p.normal_z = nrm[4 * i + 2];
+            kd.ringIds(i - a) = ring[i];
+        }
+        kd.pointCloudLocal->width = (uint32_t)(b - a), kd.pointCloudLocal->height = 1;
+        kd.gridSize = min_grid;
+        kd.measuredGravity << grav[3 * k], grav[3 * k + 1], grav[3 * k + 2];
+        kd.gravityPlausible = plaus[k] != 0;
+        Eigen::Vector3d pos = chain.globalPoses.Translations.col(k), ori = chain.globalPoses.Orientations.col(k);
+        map.addKeyframe(pos, ori, (double)k, kd);
+    }
+    DmsaOptimSettings s;  // optimSettingsMap (DmsaSlam.h:91-99)
+    s.num_iter = num_iter, s.epsilon = 1e-4, s.step_length_optim = 0.2, s.max_step = 0.01, s.gauss_split = true, s.min_num_points_per_set = 10;
+    DmsaOptimizer<pcl::PointNormal> opt;
+    opt.optimizeSet(map, s);  // DmsaSlam.h:228
+    map.keyframePoses.global2relative();
+    write_poses(out, map.keyframePoses.relativePoses.Orientations.leftCols(F), map.keyframePoses.relativePoses.Translations.leftCols(F));
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc != 5) {
+        std::fprintf(stderr, "usage: %s window|keyframes <in.bin> <poses_out.bin> <num_iter>\n", argv[0]);
+        return 2;
+    }
+    const int it = std::atoi(argv[4]);
+    return !std::strcmp(argv[1], "window") ? run_window(argv[2], argv[3], it) : run_keyframes(argv[2], argv[3], it);
+}
