@@ -206,6 +206,7 @@ struct dmsa_ctx {
     DevBuf d_fit_sums;           // six centred product sums per Gaussian (fit kernels -> finish kernel)
     bool fit_guess_valid = false;  // serial_counts of the previous voxelisation may size this one's speculative fit launches
     SerialCounts serial_counts{0, 0, 0, 0};
+    bool E_is_jacobian = false;  // the matrix-core normal equations (P > 64) rewrote the residual batch as the columns of [J | e0]
     int global_table = 0;  // index (in the current batch) of the pose table d_global was computed with
     bool serial_two_streams = true;  // DMSA_SERIAL_STREAMS=1: all tiers of the reference-order correspondence kernels on one stream
     DevBuf d_memb_tile, d_tiles, d_tile_rows, d_fallback, d_pad_off;
@@ -807,6 +808,7 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
         launch_residuals(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tables.as<float>(), ctx->rows, ctx->M,
                          B, ctx->d_wg_seg.as<int32_t>(), ctx->num_wg, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE, ctx->stream, false);
     }
+    ctx->E_is_jacobian = false;
     ctx->residual_launches += 1;
     ctx->residual_evals += B;
     ctx->residual_bytes += 16.0 * (double)ctx->Mm + 48.0 * ctx->M + (double)B * (48.0 * ctx->rows + 8.0 * ctx->M);
@@ -1390,7 +1392,12 @@ int dmsa_eval_residuals(dmsa_ctx* ctx, double* e_out) {
 
 int dmsa_normal_equations(dmsa_ctx* ctx, int32_t P, int32_t a, const double* extra_rows, double h, double lambda, double* H_out, double* g_out) {
     if (!ctx || !ctx->gaussians_valid || ctx->batch != P + 1 || (a != ctx->extra_rows && a != 0)) return DMSA_ERR_INVALID;
+    if (ctx->E_is_jacobian) {  // P > 64 turns the residual batch into [J | e0] in place: evaluate the residuals again first
+        ctx->err = "dmsa_normal_equations: the residual batch was already consumed (call dmsa_eval_residuals again)";
+        return DMSA_ERR_INVALID;
+    }
     CHK(set_device(ctx));
+    ctx->E_is_jacobian = P > 64;
     int rowsE = ctx->M;
     if (a > 0 && extra_rows) {
         if (a != ctx->extra_rows) return DMSA_ERR_INVALID;

@@ -2289,11 +2289,88 @@ __global__ __launch_bounds__(256) void k_normal_eq_reduce(const double* __restri
     for (int sp = 0; sp < nsplit; ++sp) s += partial[(((size_t)sp * nt * nt) + (size_t)tj * nt + ti) * kNeTile * kNeTile + lj * kNeTile + li];
     Hp[(size_t)j * n1 + i] = s;
 }
+// P > 64 (keyframe pass: 2 * rows * P^2 is hundreds of MFLOP): the same 32 x 32 tiles on the matrix cores.  A workgroup = 2 x 2
+// waves, each wave one 16 x 16 tile of D = A_i^T A_j through chained v_mfma_f64_16x16x4_f64: k = four consecutive ROWS, so the
+// accumulator runs d = fma(a_r, b_r, d) row by row over the whole row block -- the order the oracle states for P > 64
+// (its blocked_dot; the instruction's rounding was pinned with scripts/microbench/mfma_f64_semantics.hip:
+// a fused chain, k ascending).  Operand panels (32 columns x 64 rows each) are staged through LDS with row-contiguous loads.
+typedef double d4v __attribute__((ext_vector_type(4)));
+constexpr int kMfmaRows = 64;
+// columns of A' = [J | e0] in place: E[k + 1][r] <- inv_h * (E[k + 1][r] - E[0][r]) (DmsaOptimizer.h:226), E[0] stays e0.  The residual
+// batch is consumed by the normal equations only, and every panel element is then ONE load for the 2 * nt tiles that need it.
+__global__ __launch_bounds__(256) void k_jacobian_columns(double* __restrict__ E, int64_t ldE, int rows, int P, double inv_h) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (r < rows) E[(size_t)(k + 1) * ldE + r] = inv_h * (E[(size_t)(k + 1) * ldE + r] - E[r]);
+}
+// element (column c of A', row r): c < P -> E[c + 1][r], c == P -> E[0][r], beyond -> 0
+__device__ __forceinline__ double ne_col_scaled(const double* __restrict__ E, int64_t ldE, int P, int c, int r) {
+    return c > P ? 0.0 : E[(size_t)(c == P ? 0 : c + 1) * ldE + r];
+}
+// Only tiles with ti <= tj are computed (H is symmetric, and a fused chain of a_r * b_r does not care which factor is which); an
+// off-diagonal workgroup writes its tile and the mirrored one.  The panels of the next 64 rows are loaded into registers before
+// the MFMAs of the current ones.
+__global__ __launch_bounds__(256) void k_normal_eq_mfma(const double* __restrict__ E, int64_t ldE, int rows, int P, int rs, int nt,
+                                                        double* __restrict__ partial) {
+    __shared__ double s_a[kNeTile][kMfmaRows + 4];
+    __shared__ double s_b[kNeTile][kMfmaRows + 4];
+    int ti = 0, tj = 0;  // blockIdx.x enumerates the pairs ti <= tj row by row
+    for (int rest = blockIdx.x, row = 0; row < nt; ++row) {
+        if (rest < nt - row) {
+            ti = row, tj = row + rest;
+            break;
+        }
+        rest -= nt - row;
+    }
+    const int split = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wi = wave & 1, wj = wave >> 1;  // the wave's 16 x 16 quarter of the 32 x 32 tile
+    d4v acc = {0.0, 0.0, 0.0, 0.0};
+    const int r_begin = split * rs, r_end = min(rows, r_begin + rs);
+    constexpr int kPer = kNeTile * kMfmaRows / 256;  // panel elements per thread
+    double ra[kPer], rb[kPer];
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int q = threadIdx.x + u * 256, kk = q / kMfmaRows, r = r0 + q % kMfmaRows;
+            const bool in = r < r_end;  // rows past the block: zeros, fma(0, 0, d) == d
+            ra[u] = in ? ne_col_scaled(E, ldE, P, ti * kNeTile + kk, r) : 0.0;
+            rb[u] = in ? ne_col_scaled(E, ldE, P, tj * kNeTile + kk, r) : 0.0;
+        }
+    };
+    fetch(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += kMfmaRows) {
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int q = threadIdx.x + u * 256;
+            s_a[q / kMfmaRows][q % kMfmaRows] = ra[u], s_b[q / kMfmaRows][q % kMfmaRows] = rb[u];
+        }
+        __syncthreads();
+        if (r0 + kMfmaRows < r_end) fetch(r0 + kMfmaRows);
+        const double* pa = &s_a[wi * 16 + (lane & 15)][lane >> 4];
+        const double* pb = &s_b[wj * 16 + (lane & 15)][lane >> 4];
+#pragma unroll
+        for (int k4 = 0; k4 < kMfmaRows / 4; ++k4)  // A[i][k] = column i at row r0 + 4 k4 + k, B[k][j] likewise
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * k4], pb[4 * k4], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    double* out = partial + ((size_t)split * nt * nt + (size_t)tj * nt + ti) * kNeTile * kNeTile;
+    double* mirror = partial + ((size_t)split * nt * nt + (size_t)ti * nt + tj) * kNeTile * kNeTile;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // register r of lane l: D[i = l / 16 + 4 r][j = l % 16]
+        const int li = wi * 16 + (lane >> 4) + 4 * r, lj = wj * 16 + (lane & 15);
+        out[lj * kNeTile + li] = acc[r];
+        if (ti != tj) mirror[li * kNeTile + lj] = acc[r];
+    }
+}
 void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s) {
     const int nt = (P + 1 + kNeTile - 1) / kNeTile;
     const int rs = ne_rows_per_split(rows, P);
     const int nsplit = (rows + rs - 1) / rs;
-    hipLaunchKernelGGL(k_normal_eq_partial, dim3(nt * nt, nsplit), dim3(256), 0, s, E, ldE, rows, P, inv_h, rs, nt, partial);
+    if (P > 64) {  // NOTE: turns the residual batch E into the columns of [J | e0] in place
+        hipLaunchKernelGGL(k_jacobian_columns, dim3((rows + 255) / 256, P), dim3(256), 0, s, const_cast<double*>(E), ldE, rows, P, inv_h);
+        hipLaunchKernelGGL(k_normal_eq_mfma, dim3(nt * (nt + 1) / 2, nsplit), dim3(256), 0, s, E, ldE, rows, P, rs, nt, partial);
+    } else
+        hipLaunchKernelGGL(k_normal_eq_partial, dim3(nt * nt, nsplit), dim3(256), 0, s, E, ldE, rows, P, inv_h, rs, nt, partial);
     const int n1 = P + 1;
     hipLaunchKernelGGL(k_normal_eq_reduce, dim3((n1 * n1 + 255) / 256), dim3(256), 0, s, partial, nsplit, nt, P, Hp);
 }
@@ -2324,7 +2401,7 @@ __global__ void k_squared_sums_reduce(const double* __restrict__ partial, int ns
 // Parity path: e^T e of every evaluation in the blocked order of the normal equations (blocks of ne_rows_per_split(rows, P)
 // consecutive rows summed row by row, block sums added in order) -- the order the oracle states, so that the line search compares
 // bit-identical numbers.
-__global__ __launch_bounds__(64) void k_squared_sums_blocked(const double* __restrict__ E, int64_t ldE, int rows, int rs, int nsplit,
+__global__ __launch_bounds__(64) void k_squared_sums_blocked(const double* __restrict__ E, int64_t ldE, int rows, int rs, int nsplit, int fused,
                                                              double* __restrict__ partial) {
     // one wave per (row block, evaluation): the block's values arrive by coalesced loads, lane 0 adds their squares row by row
     __shared__ double s_v[1024];
@@ -2335,11 +2412,15 @@ __global__ __launch_bounds__(64) void k_squared_sums_blocked(const double* __res
         const int cnt = min(1024, r_end - c0);
         for (int i = lane; i < cnt; i += 64) s_v[i] = E[(size_t)b * ldE + c0 + i];
         __syncthreads();
-        if (lane == 0)
-            for (int i = 0; i < cnt; ++i) {
-                const double v = s_v[i];
-                s += v * v;
-            }
+        if (lane == 0) {
+            if (fused)  // P > 64: the rule of the matrix-core normal equations, one fused multiply-add per row
+                for (int i = 0; i < cnt; ++i) s = fma(s_v[i], s_v[i], s);
+            else
+                for (int i = 0; i < cnt; ++i) {
+                    const double v = s_v[i];
+                    s += v * v;
+                }
+        }
         __syncthreads();
     }
     if (lane == 0) partial[(size_t)b * nsplit + sp] = s;
@@ -2351,7 +2432,7 @@ int squared_sums_blocked_partial_doubles(int rows, int P, int B) {
 void launch_squared_sums_blocked(const double* E, int64_t ldE, int rows, int P, int B, double* partial, double* out, hipStream_t s) {
     const int rs = ne_rows_per_split(rows, P);
     const int nsplit = (rows + rs - 1) / rs;
-    hipLaunchKernelGGL(k_squared_sums_blocked, dim3(nsplit, B), dim3(64), 0, s, E, ldE, rows, rs, nsplit, partial);
+    hipLaunchKernelGGL(k_squared_sums_blocked, dim3(nsplit, B), dim3(64), 0, s, E, ldE, rows, rs, nsplit, P > 64 ? 1 : 0, partial);
     hipLaunchKernelGGL(k_squared_sums_reduce, dim3((B + 63) / 64), dim3(64), 0, s, partial, nsplit, B, out);
 }
 void launch_squared_sums(const double* E, int64_t ldE, int rows, int B, double* partial, double* out, hipStream_t s) {

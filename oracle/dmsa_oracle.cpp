@@ -988,13 +988,18 @@ static int reduction_block_rows(int rows, int P) {
     }
     return rs;
 }
-template <typename Term>
-static double blocked_sum(int rows, int P, Term term) {
+// x^T y in that order.  For P <= 64 every step is a separately rounded multiply and add (the reference is built without FMA,
+// CMakeLists.txt:13-17).  For P > 64 -- the keyframe pass, where J^T J is a real contraction and runs on the matrix cores -- every
+// step is ONE fused multiply-add, s = fma(x[r], y[r], s), row by row: exactly what chained v_mfma_f64_16x16x4_f64 instructions
+// compute (verified bit for bit: scripts/microbench/mfma_f64_semantics.hip).  Eigen's GEMM order and rounding are unknowable either
+// way; what matters is that H, g, e0^T e0 and the line search's e^T e all follow ONE rule.
+static double blocked_dot(int rows, int P, const double* x, const double* y) {
     const int rs = reduction_block_rows(rows, P);
+    const bool fused = P > 64;
     double total = 0.0;
     for (int r0 = 0; r0 < rows; r0 += rs) {
         double s = 0.0;
-        for (int r = r0; r < std::min(rows, r0 + rs); ++r) s += term(r);
+        for (int r = r0; r < std::min(rows, r0 + rs); ++r) s = fused ? std::fma(x[r], y[r], s) : s + x[r] * y[r];
         total += s;
     }
     return total;
@@ -1008,10 +1013,10 @@ static void lm_step(const double* e0, const double* J /* col-major rows x P */, 
         const double* Ji = J + (size_t)i * rows;
         for (int j = i; j < P; ++j) {
             const double* Jj = J + (size_t)j * rows;
-            const double s = blocked_sum(rows, P, [&](int r) { return Ji[r] * Jj[r]; });
+            const double s = blocked_dot(rows, P, Ji, Jj);
             H[(size_t)j * P + i] = s, H[(size_t)i * P + j] = s;
         }
-        g[(size_t)i] = blocked_sum(rows, P, [&](int r) { return Ji[r] * e0[r]; });
+        g[(size_t)i] = blocked_dot(rows, P, Ji, e0);
     }
     for (int i = 0; i < P; ++i) H[(size_t)i * P + i] += lambda;  // :110
     std::vector<double> Hinv;
@@ -1070,7 +1075,7 @@ struct Optimizer {
     }
     // e^T e in the blocked order of the normal equations (see reduction_block_rows)
     static double dotRows(const std::vector<double>& a, int P) {
-        return blocked_sum((int)a.size(), P, [&](int r) { return a[(size_t)r] * a[(size_t)r]; });
+        return blocked_dot((int)a.size(), P, a.data(), a.data());
     }
     // :199-232
     void calcNumericJacobian(std::vector<double>& error0, PointSet& set) {
