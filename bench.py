@@ -234,7 +234,7 @@ def main():
             },
             "roofline": {
                 "kernel": ("correspondence kernels k_residuals_tiles + k_residuals_big" if args.fast_sums else
-                           "reference-order correspondence kernels (k_residuals_chain<8,true> + k_residuals_chain<3,false> + k_residuals_small, "
+                           "reference-order correspondence kernels (k_residuals_chain<8,true,64> + k_residuals_chain<4,false,32> + k_residuals_small, "
                            "two streams, one HIP-event pair around the batch)") + ", B evaluations per launch",
                 "bound": "hbm",
                 # the brief's figure: per-unit algorithmic bytes x units per launch / launch time

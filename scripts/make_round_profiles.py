@@ -21,46 +21,62 @@ os.makedirs(dst, exist_ok=True)
 out = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "summarize_profile.py"), "stats", os.path.join(src, "stats", "stats_results.db")])
 open(os.path.join(dst, f"{tag}_kernel_stats.txt"), "wb").write(out)
 
-# 2. PMC summary + HBM traffic per launch pair
+# 2. PMC summary + HBM traffic per evaluation batch
+def short(name):
+    n = name.replace("void ", "").split("(")[0]
+    return n[n.index("k_"):] if "k_" in n else n
+
+
 per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
 for f in sorted(glob.glob(os.path.join(src, "p*", "*_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
-        kn = "k_residuals_tiles" if "k_residuals_tiles" in r["Kernel_Name"] else "k_residuals_big"
-        # the Jacobian batch (31 evaluations) uses the larger grid of each kernel
-        per[kn][int(r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # the Jacobian batch (P + 1 evaluations) and the line-search batch (9 evaluations) differ in workgroup count
+        per[short(r["Kernel_Name"])][(int(r["Grid_Size"]), int(r["Workgroup_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 lines = [f"# rocprofv3 --pmc passes (one pass per counter group, --kernel-trace only) of `python bench.py --steps 3 --warmup 1 --cpu-iters 0`",
-         "# workload window10x131072+static200000; means over the dispatches of each launch shape",
+         f"# workload {bench['config']['workload']}; means over the dispatches of each launch shape",
          "# FETCH_SIZE / WRITE_SIZE are KiB.  On gfx950 FETCH_SIZE reports half the bytes of a wide coalesced 16 B/lane stream",
          "# (MI355X_MICROARCH.md, HBM): both the raw value and the x2-corrected value are listed; Infinity-Cache hits are included."]
 traffic = {}
 for kn in sorted(per):
-    for shape, ctrs in sorted(per[kn].items(), reverse=True):
+    for (grid, wg), ctrs in sorted(per[kn].items(), reverse=True):
         c = {k: sum(v) / len(v) for k, v in ctrs.items()}
-        lines.append(f"\n## {kn}: grid_size={shape} threads, dispatches={len(next(iter(ctrs.values())))}")
+        lines.append(f"\n## {kn}: workgroups={grid // wg} x {wg} threads, dispatches={len(next(iter(ctrs.values())))}")
         for k in sorted(c):
             lines.append(f"  {k:24s} {c[k]:14.5g}")
         if "FETCH_SIZE" in c:
             raw = c["FETCH_SIZE"] * 1024
             wr = c.get("WRITE_SIZE", 0.0) * 1024
             lines.append(f"  -> memory-side read {raw / 1e6:.1f} MB raw / {2 * raw / 1e6:.1f} MB with the gfx950 x2 correction; write {wr / 1e6:.2f} MB per launch")
-            traffic.setdefault(kn, []).append((shape, 2 * raw + wr))
+            traffic.setdefault(kn, []).append(2 * raw + wr)
         if "TCC_HIT_sum" in c:
             lines.append(f"  -> L2 hit rate {c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']):.3f}")
         if "SQ_WAVE_CYCLES" in c:
             for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
-                lines.append(f"  -> {k}/SQ_WAVE_CYCLES = {c[k] / c['SQ_WAVE_CYCLES']:.3f}")
+                if k in c:
+                    lines.append(f"  -> {k}/SQ_WAVE_CYCLES = {c[k] / c['SQ_WAVE_CYCLES']:.3f}")
+        if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
+            lines.append(f"  -> VALU instructions per wave {c['SQ_INSTS_VALU'] / c['SQ_WAVES']:.0f}, LDS {c.get('SQ_INSTS_LDS', 0) / c['SQ_WAVES']:.0f}")
 open(os.path.join(dst, f"{tag}_pmc_correspondence.txt"), "w").write("\n".join(lines) + "\n")
 
-# one evaluation batch = one k_residuals_tiles launch + one k_residuals_big launch; average the two batch shapes (31 and 9
-# evaluations, one of each per iteration) like bench.py averages its launches
-def avg(kn):
-    v = [t for _, t in traffic.get(kn, [])]
-    return sum(v) / len(v) if v else 0.0
-
-bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-tj = {"workload": bench["config"]["workload"], "hbm_bytes_per_launch": round(avg("k_residuals_tiles") + avg("k_residuals_big")),
-      "source": f"profiles/{tag}_pmc_correspondence.txt (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, per evaluation-batch launch pair)"}
+# one evaluation batch = one launch of every correspondence kernel; each kernel's two launch shapes (P + 1 and 9 evaluations,
+# one of each per iteration) are averaged like bench.py averages its batches
+total = sum(sum(v) / len(v) for v in traffic.values())
+path = "fast_sums" if "fast" in bench["config"]["path"] else "default"
+tj = {"workload": bench["config"]["workload"], "path": path, "hbm_bytes_per_launch": round(total),
+      "kernels": {k: round(sum(v) / len(v)) for k, v in traffic.items()},
+      "source": f"profiles/{tag}_pmc_correspondence.txt (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, summed over the kernels of one evaluation batch)"}
 open(os.path.join(dst, f"{tag}_traffic.json"), "w").write(json.dumps(tj, indent=1) + "\n")
 open(os.path.join(dst, f"{tag}_bench.json"), "w").write(json.dumps(bench) + "\n")
+# 3. keyframe-set kernel stats and the repeated bench lines, when the round script collected them
+kf = os.path.join(src, "kfstats", "stats_results.db")
+if os.path.exists(kf):
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "summarize_profile.py"), "stats", kf])
+    open(os.path.join(dst, f"{tag}_keyframes_kernel_stats.txt"), "wb").write(out)
+runs = os.path.join(src, "bench_runs.jsonl")
+if os.path.exists(runs):
+    rr = [json.loads(l) for l in open(runs) if l.strip().startswith("{")]
+    keep = [{k: r[k] for k in ("value", "ms_per_step", "steps", "stage_ms_per_step") if k in r} | {"roofline_avg_launch_ms": r["roofline"]["avg_launch_ms"]} for r in rr]
+    open(os.path.join(dst, f"{tag}_bench_runs.json"), "w").write(json.dumps(keep, indent=1) + "\n")
 print(open(os.path.join(dst, f"{tag}_kernel_stats.txt")).read()[:2500])
 print(tj)
