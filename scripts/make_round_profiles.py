@@ -28,10 +28,23 @@ def short(name):
 
 
 per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
+rows = []
 for f in sorted(glob.glob(os.path.join(src, "p*", "*_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         # the Jacobian batch (P + 1 evaluations) and the line-search batch (9 evaluations) differ in workgroup count
-        per[short(r["Kernel_Name"])][(int(r["Grid_Size"]), int(r["Workgroup_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        rows.append((short(r["Kernel_Name"]), int(r["Grid_Size"]), int(r["Workgroup_Size"]), r["Counter_Name"], float(r["Counter_Value"])))
+# the workgroup count follows the Gaussian count of the iteration; bucket every kernel's launches into its two batch kinds
+lohi = {}
+for kn, grid, wg, _, _ in rows:
+    lo, hi = lohi.get(kn, (grid, grid))
+    lohi[kn] = (min(lo, grid), max(hi, grid))
+wgs = {}
+for kn, grid, wg, cn, v in rows:
+    lo, hi = lohi[kn]
+    kind = "Jacobian batch (P + 1 evaluations)" if (hi > 1.5 * lo and grid > (lo + hi) / 2) else "line-search batch (9 evaluations)" if hi > 1.5 * lo else "all launches"
+    per[kn][kind][cn].append(v)
+    wgs.setdefault((kn, kind), []).append(grid // wg)
+    wgs[(kn, kind, "wg")] = wg
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 lines = [f"# rocprofv3 --pmc passes (one pass per counter group, --kernel-trace only) of `python bench.py --steps 3 --warmup 1 --cpu-iters 0`",
          f"# workload {bench['config']['workload']}; means over the dispatches of each launch shape",
@@ -39,16 +52,17 @@ lines = [f"# rocprofv3 --pmc passes (one pass per counter group, --kernel-trace 
          "# (MI355X_MICROARCH.md, HBM): both the raw value and the x2-corrected value are listed; Infinity-Cache hits are included."]
 traffic = {}
 for kn in sorted(per):
-    for (grid, wg), ctrs in sorted(per[kn].items(), reverse=True):
+    for kind, ctrs in sorted(per[kn].items()):
         c = {k: sum(v) / len(v) for k, v in ctrs.items()}
-        lines.append(f"\n## {kn}: workgroups={grid // wg} x {wg} threads, dispatches={len(next(iter(ctrs.values())))}")
+        w = wgs[(kn, kind)]
+        lines.append(f"\n## {kn}, {kind}: workgroups={min(w)}..{max(w)} x {wgs[(kn, kind, 'wg')]} threads, dispatches={len(next(iter(ctrs.values())))}")
         for k in sorted(c):
             lines.append(f"  {k:24s} {c[k]:14.5g}")
         if "FETCH_SIZE" in c:
             raw = c["FETCH_SIZE"] * 1024
             wr = c.get("WRITE_SIZE", 0.0) * 1024
             lines.append(f"  -> memory-side read {raw / 1e6:.1f} MB raw / {2 * raw / 1e6:.1f} MB with the gfx950 x2 correction; write {wr / 1e6:.2f} MB per launch")
-            traffic.setdefault(kn, []).append(2 * raw + wr)
+            traffic[f"{kn} / {kind}"] = 2 * raw + wr
         if "TCC_HIT_sum" in c:
             lines.append(f"  -> L2 hit rate {c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']):.3f}")
         if "SQ_WAVE_CYCLES" in c:
@@ -59,13 +73,13 @@ for kn in sorted(per):
             lines.append(f"  -> VALU instructions per wave {c['SQ_INSTS_VALU'] / c['SQ_WAVES']:.0f}, LDS {c.get('SQ_INSTS_LDS', 0) / c['SQ_WAVES']:.0f}")
 open(os.path.join(dst, f"{tag}_pmc_correspondence.txt"), "w").write("\n".join(lines) + "\n")
 
-# one evaluation batch = one launch of every correspondence kernel; each kernel's two launch shapes (P + 1 and 9 evaluations,
-# one of each per iteration) are averaged like bench.py averages its batches
-total = sum(sum(v) / len(v) for v in traffic.values())
+# an iteration runs two evaluation batches (P + 1 evaluations, then 9), each one launch of every kernel family (the lane-per-
+# evaluation kernel is instantiated per batch width); bench.py averages its event pairs over both, so: all launches / 2
+total = sum(traffic.values()) / 2
 path = "fast_sums" if "fast" in bench["config"]["path"] else "default"
 tj = {"workload": bench["config"]["workload"], "path": path, "hbm_bytes_per_launch": round(total),
-      "kernels": {k: round(sum(v) / len(v)) for k, v in traffic.items()},
-      "source": f"profiles/{tag}_pmc_correspondence.txt (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, summed over the kernels of one evaluation batch)"}
+      "kernel_launches": {k: round(v) for k, v in traffic.items()},
+      "source": f"profiles/{tag}_pmc_correspondence.txt (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, all kernels of the two evaluation batches of an iteration / 2)"}
 open(os.path.join(dst, f"{tag}_traffic.json"), "w").write(json.dumps(tj, indent=1) + "\n")
 open(os.path.join(dst, f"{tag}_bench.json"), "w").write(json.dumps(bench) + "\n")
 # 3. keyframe-set kernel stats and the repeated bench lines, when the round script collected them

@@ -27,19 +27,23 @@ def stats(db_path):
         if "rocprim" in short:
             short = "rocprim::" + short.split("::")[-1][:48] + "<...>"
         print(f"{short[:72]:72s} {n:6d} {total / 1e3:10.1f} {avg / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * total / tot:6.2f}")
-    # per launch shape for the correspondence kernels (grid_x/grid_y are in THREADS in rocprofv3's tables)
-    print("\n# correspondence kernels by launch shape (workgroups = grid / workgroup size)")
-    q = ("select name, grid_x, grid_y, workgroup_x, count(*), avg(end-start), min(end-start), max(end-start) from kernels "
-         "where name like '%k_residuals%' group by name, grid_x, grid_y order by name, grid_x, grid_y")
-    try:
-        rows = cur.execute(q).fetchall()
-    except sqlite3.OperationalError:
-        rows = [(n, gx, gy, 0, c, a, a, a) for n, gx, gy, c, a in cur.execute(
-            "select name, grid_x, grid_y, count(*), avg(end-start) from kernels where name like '%k_residuals%' group by name, grid_x, grid_y")]
-    for name, gx, gy, wx, n, avg, mn, mx in rows:
-        short = name.split("(")[0].replace("void ", "")
-        wg = f"{gx // wx}x{gy}" if wx else f"{gx}x{gy} threads"
-        print(f"  {short[:44]:44s} workgroups={wg:>12s} wg_size={wx:4d} launches={n:4d} avg_us={avg / 1e3:9.2f} min_us={mn / 1e3:9.2f} max_us={mx / 1e3:9.2f}")
+    # the correspondence kernels by batch kind: an iteration launches every kernel family twice (P + 1 evaluations for the
+    # Jacobian, 9 for the line search); the workgroup count follows the iteration's Gaussian count, so launches are bucketed
+    # at the midpoint of each kernel's workgroup range (grid_x is in THREADS in rocprofv3's tables)
+    print("\n# correspondence kernels by batch kind (workgroups = grid_x / workgroup size, x grid_y)")
+    rows = cur.execute("select name, grid_x, grid_y, workgroup_x, end-start from kernels where name like '%k_residuals%'").fetchall()
+    by = collections.defaultdict(list)
+    for name, gx, gy, wx, d in rows:
+        by[name.split("(")[0].replace("void ", "")].append(((gx // max(1, wx)) * gy, wx, d))
+    for short in sorted(by):
+        lo, hi = min(w for w, _, _ in by[short]), max(w for w, _, _ in by[short])
+        two = hi > 1.5 * lo
+        for kind in (("P+1 evaluations", "9 evaluations") if two else ("all launches",)):
+            sel = [(w, wx, d) for w, wx, d in by[short] if not two or (w > (lo + hi) / 2) == (kind == "P+1 evaluations")]
+            ds = [d for _, _, d in sel]
+            ws = [w for w, _, _ in sel]
+            print(f"  {short[:44]:44s} {kind:16s} workgroups={min(ws):6d}..{max(ws):<6d} wg_size={sel[0][1]:4d} launches={len(sel):4d} "
+                  f"avg_us={sum(ds) / len(ds) / 1e3:9.2f} min_us={min(ds) / 1e3:9.2f} max_us={max(ds) / 1e3:9.2f}")
 
 
 def pmc(root):
