@@ -166,6 +166,9 @@ struct dmsa_ctx {
     double* h_pin = nullptr;
     size_t h_pin_slot = 0;  // doubles per slot
     int h_pin_next = 0;
+    double* h_xpin = nullptr;  // the same for the additional rows of a batch
+    size_t h_xpin_slot = 0;
+    int h_xpin_next = 0;
     std::vector<float> h_tables;
     // pinned staging of the point upload (packed on several host threads, then one DMA per array)
     char* h_stage = nullptr;
@@ -780,6 +783,25 @@ int ensure_E(dmsa_ctx* ctx, int B) {
 }
 int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
     CHK(ensure_E(ctx, B));
+    const int a = ctx->extra_rows;
+    if (a > 0 && extra != nullptr) {
+        // additional rows (IMU / gravity / odometry) go below the Gaussian rows of every evaluation, through a pinned ring like the
+        // control poses: no host synchronisation, and the copy runs ahead of the correspondence kernels
+        constexpr int kPinSlots = 4;  // at least one stream synchronisation separates reuse of a slot
+        const size_t need = (size_t)a * B;
+        if (need > ctx->h_xpin_slot) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (ctx->h_xpin) (void)hipHostFree(ctx->h_xpin);
+            ctx->h_xpin = nullptr;
+            ctx->h_xpin_slot = need + need / 2 + 64;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_xpin), ctx->h_xpin_slot * kPinSlots * sizeof(double), hipHostMallocDefault));
+        }
+        double* slot = ctx->h_xpin + (size_t)ctx->h_xpin_next * ctx->h_xpin_slot;
+        ctx->h_xpin_next = (ctx->h_xpin_next + 1) % kPinSlots;
+        std::memcpy(slot, extra->data(), need * sizeof(double));
+        HIPCHK(hipMemcpy2DAsync(ctx->d_E.as<double>() + ctx->M, (size_t)ctx->ldE * 8, slot, (size_t)a * 8, (size_t)a * 8, (size_t)B, hipMemcpyHostToDevice,
+                                ctx->stream));
+    }
     const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS) && ctx->num_tiles > 0 && ctx->tiles_usable;
     if (tiles_on) {
         ScopedTimer tm(ctx, T_RESIDUAL);
@@ -814,12 +836,6 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
     ctx->residual_bytes += 16.0 * (double)ctx->Mm + 48.0 * ctx->M + (double)B * (48.0 * ctx->rows + 8.0 * ctx->M);
     ctx->residual_unit_bytes += (double)B * (16.0 * (double)ctx->Mm + 56.0 * ctx->M + 48.0 * ctx->rows);
     HIPCHK(hipGetLastError());
-    const int a = ctx->extra_rows;
-    if (a > 0 && extra != nullptr) {
-        HIPCHK(hipMemcpy2DAsync(ctx->d_E.as<double>() + ctx->M, (size_t)ctx->ldE * 8, extra->data(), (size_t)a * 8, (size_t)a * 8, (size_t)B,
-                                hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
     return DMSA_OK;
 }
 
@@ -964,7 +980,10 @@ int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
         error0 = Hp[(size_t)P * n1 + P];  // :101
         for (int i = 0; i < P; ++i) H[(size_t)i * P + i] += (double)s.lambda_diag;  // :110
         if (ctx->flags & DMSA_FLAG_MIRROR_SUMS)
-            lm_solve(H.data(), g.data(), P, s.step_length_optim, step.data());  // :113, explicit inverse like the reference
+        {   // :113, explicit inverse like the reference
+            const ParallelRun par = [&](const std::function<void(int, int)>& fn) { workers(ctx).run_all(fn); };
+            lm_solve(H.data(), g.data(), P, s.step_length_optim, step.data(), P >= 64 ? &par : nullptr);
+        }
         else
             lm_solve_lu(H.data(), g.data(), P, s.step_length_optim, step.data());
         bool anyNan = false;
@@ -1101,6 +1120,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
     drain_timers(ctx);
     for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->h_xpin) (void)hipHostFree(ctx->h_xpin);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_rb) (void)hipHostFree(ctx->h_rb);
     if (ctx->h_Hp) (void)hipHostFree(ctx->h_Hp);
@@ -1528,6 +1548,21 @@ int dmsa_get_timing(dmsa_ctx* ctx, dmsa_timing* t, int32_t reset) {
         for (double& v : ctx->t_ms) v = 0.0;
         ctx->residual_launches = 0, ctx->residual_evals = 0, ctx->residual_bytes = 0.0, ctx->residual_unit_bytes = 0.0;
     }
+    return DMSA_OK;
+}
+
+int dmsa_lm_solve(const double* H_damped, const double* g, int32_t P, double alpha, int32_t threads, double* step) {
+    if (!H_damped || !g || !step || P < 1) return DMSA_ERR_INVALID;
+    if (threads <= 1) {
+        lm_solve(H_damped, g, P, alpha, step, nullptr);
+        return DMSA_OK;
+    }
+    const ParallelRun par = [&](const std::function<void(int, int)>& fn) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; ++t) th.emplace_back([&fn, t, threads]() { fn(t, threads); });
+        for (auto& x : th) x.join();
+    };
+    lm_solve(H_damped, g, P, alpha, step, &par);
     return DMSA_OK;
 }
 

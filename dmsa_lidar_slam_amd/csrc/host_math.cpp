@@ -2,6 +2,11 @@
 // reproducible across compilers (the pose table built here feeds float casts and voxel keys downstream).
 #include "host_math.h"
 
+#include <atomic>
+#include <cstdlib>
+#include <memory>
+#include <thread>
+
 #include "../../include/dmsa_detmath.h"
 
 #include <algorithm>
@@ -366,43 +371,159 @@ void KeyframeHost::additional_rows(double* rows) const {
 }
 
 // ---- LM solve -----------------------------------------------------------------------------------------
-void lm_solve(const double* Hin, const double* g, int P, double alpha, double* step) {
-    // Gauss-Jordan with partial pivoting on [A | I]; the same operation on every element as the column-major statement of the
-    // oracle (invert_dense), but stored row-major so that the row updates are contiguous (7x faster at P = 186, bit-identical).
+namespace {
+// One cache line per worker: a worker announces "I finished phase k" by storing k, and waits until everybody did.  No shared
+// read-modify-write, so a barrier costs about one cache-to-cache transfer (a shared counter cost 5-8 us per barrier on the 2-socket
+// EPYC host).  The workers of a solve meet once per pivot step, 1-2 us apart, so they spin (and yield if the machine is oversubscribed).
+struct alignas(64) PhaseFlag {
+    std::atomic<int> phase{0};
+};
+struct alignas(64) PivotCandidate {
+    double best;
+    int row;  // logical row, -1: this worker owns no candidate row
+};
+constexpr int kMaxSolveThreads = 12;
+int solve_thread_cap() {  // DMSA_SOLVE_THREADS overrides (1..16)
+    static const int cap = []() {
+        const char* e = std::getenv("DMSA_SOLVE_THREADS");
+        return e ? std::max(1, std::min(kMaxSolveThreads, std::atoi(e))) : kMaxSolveThreads;
+    }();
+    return cap;
+}
+}  // namespace
+
+void lm_solve(const double* Hin, const double* g, int P, double alpha, double* step, const ParallelRun* par) {
+    // Gauss-Jordan with partial pivoting on [A | I]; the same operation on every element that reaches the result as the column-major
+    // statement of the oracle (invert_dense), but stored row-major so that the row updates are contiguous.  Columns of A left of the
+    // pivot hold exact zeros after their own elimination step (x - x*1) and are never read again, so they are not updated.
     const size_t n = (size_t)P;
     std::vector<double> A(n * n), inv(n * n, 0.0);
+    bool finite = true;
     for (size_t r = 0; r < n; ++r)
-        for (size_t c = 0; c < n; ++c) A[r * n + c] = Hin[c * n + r];  // element (r, c) of the column-major input
+        for (size_t c = 0; c < n; ++c) {
+            A[r * n + c] = Hin[c * n + r];  // element (r, c) of the column-major input
+            finite = finite && std::isfinite(Hin[c * n + r]);
+        }
     for (size_t i = 0; i < n; ++i) inv[i * n + i] = 1.0;
-    for (size_t c0 = 0; c0 < n; ++c0) {
-        size_t piv = c0;
-        double best = std::fabs(A[c0 * n + c0]);
-        for (size_t r = c0 + 1; r < n; ++r)
-            if (std::fabs(A[r * n + c0]) > best) best = std::fabs(A[r * n + c0]), piv = r;
-        if (piv != c0) {
-            std::swap_ranges(&A[c0 * n], &A[c0 * n] + n, &A[piv * n]);
-            std::swap_ranges(&inv[c0 * n], &inv[c0 * n] + n, &inv[piv * n]);
+    if (par == nullptr || P < 64 || !finite) {
+        for (size_t c0 = 0; c0 < n; ++c0) {
+            size_t piv = c0;
+            double best = std::fabs(A[c0 * n + c0]);
+            for (size_t r = c0 + 1; r < n; ++r)
+                if (std::fabs(A[r * n + c0]) > best) best = std::fabs(A[r * n + c0]), piv = r;
+            if (piv != c0) {
+                std::swap_ranges(&A[c0 * n + c0], &A[c0 * n] + n, &A[piv * n + c0]);
+                std::swap_ranges(&inv[c0 * n], &inv[c0 * n] + n, &inv[piv * n]);
+            }
+            double* a0 = &A[c0 * n];
+            double* i0 = &inv[c0 * n];
+            const double d = a0[c0];
+            for (size_t c = c0; c < n; ++c) a0[c] /= d;
+            for (size_t c = 0; c < n; ++c) i0[c] /= d;
+            for (size_t r = 0; r < n; ++r) {
+                if (r == c0) continue;
+                double* ar = &A[r * n];
+                double* ir = &inv[r * n];
+                const double f = ar[c0];
+                if (f == 0.0) continue;
+                for (size_t c = c0; c < n; ++c) ar[c] -= f * a0[c];
+                for (size_t c = 0; c < n; ++c) ir[c] -= f * i0[c];
+            }
         }
-        double* a0 = &A[c0 * n];
-        double* i0 = &inv[c0 * n];
-        const double d = a0[c0];
-        for (size_t c = 0; c < n; ++c) a0[c] /= d, i0[c] /= d;
-        for (size_t r = 0; r < n; ++r) {
-            if (r == c0) continue;
-            double* ar = &A[r * n];
-            double* ir = &inv[r * n];
-            const double f = ar[c0];
-            if (f == 0.0) continue;
-            for (size_t c = 0; c < n; ++c) ar[c] -= f * a0[c];
-            for (size_t c = 0; c < n; ++c) ir[c] -= f * i0[c];
+        for (size_t i = 0; i < n; ++i) {
+            double s = 0.0;
+            const double* ii = &inv[i * n];
+            for (size_t j = 0; j < n; ++j) s += (-alpha * ii[j]) * g[j];  // element (i, j) of the inverse
+            step[i] = s;
         }
+        return;
     }
-    for (size_t i = 0; i < n; ++i) {
-        double s = 0.0;
-        const double* ii = &inv[i * n];
-        for (size_t j = 0; j < n; ++j) s += (-alpha * ii[j]) * g[j];  // element (i, j) of the inverse
-        step[i] = s;
-    }
+    // P >= 64 (the keyframe pass, P = 186 per 32-frame neighbourhood: the solve was 60 % of an iteration): the rows of a pivot step
+    // are independent, so every worker owns a block of PHYSICAL rows for the whole solve.  Row swaps become a permutation every worker
+    // tracks privately; the pivot search is a per-worker maximum over its own rows (published with the row's logical index, ties to
+    // the lower index = the serial loop's first strict maximum); every worker scales its own copy of the pivot row, and the owner
+    // stores the scaled row one step later, when nobody reads the unscaled one any more.  One barrier per pivot step; element by
+    // element the same operations as above, so the result does not depend on the number of workers.
+    PhaseFlag flags[kMaxSolveThreads];
+    PivotCandidate cand[2][kMaxSolveThreads];
+    (*par)([&](int t, int nthr) {
+        const int use = std::min({nthr, solve_thread_cap(), std::max(1, P / 16)});
+        if (t >= use) return;
+        int phase = 0;
+        auto barrier = [&]() {
+            ++phase;
+            flags[t].phase.store(phase, std::memory_order_release);
+            for (int u = 0; u < use; ++u)
+                for (int spins = 0; flags[u].phase.load(std::memory_order_acquire) < phase; ++spins) {
+                    if (spins > 4096)
+                        std::this_thread::yield();
+                    else
+                        __builtin_ia32_pause();
+                }
+        };
+        const size_t lo = n * (size_t)t / (size_t)use, hi = n * (size_t)(t + 1) / (size_t)use;
+        std::vector<int> perm(n), iperm(n);  // logical row -> physical row and back
+        for (size_t i = 0; i < n; ++i) perm[i] = iperm[i] = (int)i;
+        std::vector<double> rowbuf[2] = {std::vector<double>(2 * n), std::vector<double>(2 * n)};
+        auto publish = [&](size_t col, int after /* candidates: logical index > after */) {
+            PivotCandidate c{0.0, -1};
+            for (size_t p = lo; p < hi; ++p) {
+                const int l = iperm[p];
+                if (l <= after) continue;
+                const double v = std::fabs(A[p * n + col]);
+                if (c.row < 0 || v > c.best || (v == c.best && l < c.row)) c.best = v, c.row = l;
+            }
+            cand[col & 1][t] = c;
+        };
+        publish(0, -1);
+        barrier();
+        int pending = -1;  // physical row whose scaled copy (rowbuf of the previous step) this worker still has to store
+        for (size_t c0 = 0; c0 < n; ++c0) {
+            int pl = -1;
+            double best = 0.0;
+            for (int u = 0; u < use; ++u) {
+                const PivotCandidate& c = cand[c0 & 1][u];
+                if (c.row >= 0 && (pl < 0 || c.best > best || (c.best == best && c.row < pl))) best = c.best, pl = c.row;
+            }
+            const int pp = perm[(size_t)pl];
+            if (pending >= 0) {  // last step's pivot row becomes an ordinary row of this step
+                const double* b = rowbuf[(c0 - 1) & 1].data();
+                std::copy(b + (c0 - 1), b + n, &A[(size_t)pending * n + (c0 - 1)]);
+                std::copy(b + n, b + 2 * n, &inv[(size_t)pending * n]);
+                pending = -1;
+            }
+            double* a0 = rowbuf[c0 & 1].data();
+            double* i0 = a0 + n;
+            {
+                const double* ap = &A[(size_t)pp * n];
+                const double* ip = &inv[(size_t)pp * n];
+                const double d = ap[c0];
+                for (size_t c = c0; c < n; ++c) a0[c] = ap[c] / d;
+                for (size_t c = 0; c < n; ++c) i0[c] = ip[c] / d;
+            }
+            const int p0 = perm[c0];
+            perm[c0] = pp, perm[(size_t)pl] = p0, iperm[(size_t)pp] = (int)c0, iperm[(size_t)p0] = pl;
+            if ((size_t)pp >= lo && (size_t)pp < hi) pending = pp;
+            for (size_t p = lo; p < hi; ++p) {
+                if ((int)p == pp) continue;
+                double* ar = &A[p * n];
+                double* ir = &inv[p * n];
+                const double f = ar[c0];
+                if (f == 0.0) continue;
+                for (size_t c = c0; c < n; ++c) ar[c] -= f * a0[c];
+                for (size_t c = 0; c < n; ++c) ir[c] -= f * i0[c];
+            }
+            if (c0 + 1 < n) publish(c0 + 1, (int)c0);
+            barrier();
+        }
+        if (pending >= 0) std::copy(rowbuf[(n - 1) & 1].data() + n, rowbuf[(n - 1) & 1].data() + 2 * n, &inv[(size_t)pending * n]);
+        for (size_t p = lo; p < hi; ++p) {
+            double s = 0.0;
+            const double* ii = &inv[p * n];
+            for (size_t j = 0; j < n; ++j) s += (-alpha * ii[j]) * g[j];  // element (i, j) of the inverse
+            step[(size_t)iperm[p]] = s;
+        }
+    });
 }
 
 void lm_solve_lu(const double* Hin, const double* g, int P, double alpha, double* step) {

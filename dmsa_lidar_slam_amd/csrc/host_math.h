@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "../../include/dmsa_hip.h"
@@ -102,7 +103,10 @@ struct KeyframeHost {
 
 // Dense symmetric solve for the LM step: step = -alpha * H^-1 * g with H^-1 from partial-pivot elimination
 // (DmsaOptimizer.h:113, MatrixXd::inverse()).
-void lm_solve(const double* H /* PxP col-major */, const double* g, int P, double alpha, double* step);
+// `par` (optional) runs a function on every thread of the caller's worker pool: fn(worker, num_workers); the row updates of a pivot
+// step are spread over them for P >= 64 (same operations, same result).
+using ParallelRun = std::function<void(const std::function<void(int, int)>&)>;
+void lm_solve(const double* H /* PxP col-major */, const double* g, int P, double alpha, double* step, const ParallelRun* par = nullptr);
 // Same step through a partial-pivot LU solve instead of the explicit inverse (P^3/3 instead of 2 P^3 flops; differs from
 // lm_solve by rounding only).  Used by the fast path, where P reaches several hundred in the keyframe pass.
 void lm_solve_lu(const double* H /* PxP symmetric */, const double* g, int P, double alpha, double* step);

@@ -226,6 +226,12 @@ int dmsa_get_voxel_level(dmsa_ctx* ctx, int32_t level, dmsa_voxel_level_info* in
 int dmsa_get_gaussians(dmsa_ctx* ctx, int32_t* seg_offset /* M+1 */, int32_t* member_idx /* Mm */,
                        float* info_mats /* M x 9 col-major */, float* weights /* M */);
 
+/* Host-only: the Levenberg-Marquardt step of DmsaOptimizer.h:110-113, step = (-alpha * (H + lambda I)^-1) * g, with the explicit
+ * inverse the reference forms (`H_damped` = H + lambda I, P x P column-major, symmetric or not).  `threads` > 1 spreads the row
+ * updates of every pivot step over that many host threads for P >= 64 -- the result does not depend on it (tested bit for bit);
+ * inside optimizeSet the context's worker pool plays that part.  No device needed. */
+int dmsa_lm_solve(const double* H_damped, const double* g, int32_t P, double alpha, int32_t threads, double* step);
+
 /* Evaluates include/dmsa_detmath.h ON THE DEVICE: fn 0 sin(x), 1 cos(x), 2 acos(x), 3 atan2(y, x); n doubles each (y may be NULL for
  * fn < 3).  The pose-table kernels (ContinuousTrajectory.h:189-226, MapManagement.h:140-147) take their trigonometry from that
  * header; the tests compare these device results bit for bit with the same header compiled for the host. */

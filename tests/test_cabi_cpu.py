@@ -1,6 +1,8 @@
 """CPU-side checks of the product boundary: the C-ABI library builds/loads, exports every symbol declared in
 include/dmsa_hip.h, and refuses to run without a GPU (no compute calls here)."""
 import ctypes as C
+
+import numpy as np
 import os
 import re
 
@@ -73,3 +75,25 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle_py" not in txt and "dmsa_oracle" not in txt and "libdmsa_oracle" not in txt, f
+
+
+@pytest.mark.parametrize("P", [12, 30, 96, 186])
+def test_host_lm_solve_equals_the_oracle_step_for_any_thread_count(lib, orc, P):
+    """DmsaOptimizer.h:110-113 on the host side of the product: the explicit inverse by Gauss-Jordan, rows of a pivot step spread
+    over worker threads for P >= 64 (the keyframe pass: 60 % of an iteration before).  Bit-identical to the oracle's lm_step and
+    independent of the thread count."""
+
+
+    rng = np.random.default_rng(100 + P)
+    rows = 4 * P + 50
+    e0 = rng.uniform(0.5, 2.0, rows)
+    eb = e0[None, :] + rng.normal(size=(P, rows)) * 1e-4
+    # a few exactly dependent columns exercise the pivot swaps under the weak damping of the reference (lambda = 1e-5)
+    eb[P // 3] = eb[P // 3 + 1]
+    h = float(np.sqrt(np.finfo(np.float32).eps))
+    H, g, step_ref = orc.lm_step(e0, eb, h, float(np.float32(1e-5)), 0.2)   # H comes back damped
+    for threads in (1, 3, 8):
+        step = np.zeros(P)
+        assert lib.dmsa_lm_solve(capi.ptr(H, C.c_double), capi.ptr(g, C.c_double), P, 0.2, threads, capi.ptr(step, C.c_double)) == capi.DMSA_OK
+        assert np.array_equal(step, step_ref), (P, threads, np.abs(step - step_ref).max())
+    assert lib.dmsa_lm_solve(None, capi.ptr(g, C.c_double), P, 0.2, 1, capi.ptr(step_ref, C.c_double)) == capi.DMSA_ERR_INVALID
