@@ -211,6 +211,12 @@ class DmsaOptimizer:
                                                 capi.ptr(out, C.c_double)), "dmsa_detmath_eval")
         return out
 
+    def serialFallbackSums(self, reset: bool = False) -> int:
+        """(Gaussian, sub-batch) double sums that were chained member by member because the exactness test of the parallel sum failed."""
+        v = C.c_uint64(0)
+        self._check(self._lib.dmsa_serial_fallback_sums(self._ctx, int(reset), C.byref(v)), "dmsa_serial_fallback_sums")
+        return int(v.value)
+
     def timing(self, reset: bool = False) -> capi.Timing:
         t = capi.Timing()
         self._check(self._lib.dmsa_get_timing(self._ctx, C.byref(t), int(reset)), "get_timing")

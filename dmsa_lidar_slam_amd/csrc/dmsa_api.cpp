@@ -1551,6 +1551,14 @@ int dmsa_get_timing(dmsa_ctx* ctx, dmsa_timing* t, int32_t reset) {
     return DMSA_OK;
 }
 
+int dmsa_serial_fallback_sums(dmsa_ctx* ctx, int32_t reset, uint64_t* count) {
+    if (!ctx || !count) return DMSA_ERR_INVALID;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *count = serial_fallback_sums(reset != 0);
+    return DMSA_OK;
+}
+
 int dmsa_lm_solve(const double* H_damped, const double* g, int32_t P, double alpha, int32_t threads, double* step) {
     if (!H_damped || !g || !step || P < 1) return DMSA_ERR_INVALID;
     if (threads <= 1) {

@@ -36,5 +36,8 @@ struct SerialShape {
     int lanes, nsub_small;   // lane-per-evaluation kernel: lanes per (Gaussian, sub-batch), sub-batches
 };
 SerialShape serial_shape(int B);
+// Introspection: how many (Gaussian, evaluation sub-batch) workgroups of the chain tiers failed the exactness test of the parallel second
+// pass and were summed again member by member since the last reset (synchronises the device).
+unsigned long long serial_fallback_sums(bool reset);
 
 }  // namespace dmsa

@@ -325,6 +325,18 @@ __device__ long long g_tl[2][16][64][2];
 #endif
 constexpr int kSlots = 3;
 
+// ---- second pass without a chain ---------------------------------------------------------------------------------------------
+// The reference adds the float terms of a Gaussian to a double one by one (DmsaOptimizer.h:259-264): acc = RN(acc + t_j), acc_0 = 0.
+// Let all terms be > 0 and q = min_j (exponent(t_j) - 23): every term -- a float, 24 significant bits -- is a multiple of 2^q, and
+// so is every partial sum, in member order or in ANY other order; none exceeds U = sum_j t_j.  If U < 2^(q+53) all those partial
+// sums are representable doubles, no addition rounds, and the chain, a tree and the exact sum are the same number.  That is the
+// case for practically every Gaussian (rebalanced sums stay below 2^7, the smallest terms are ~2^-18: 49 of 53 bits), so the
+// second pass is computed as a plain parallel reduction that also tracks the smallest term, and the condition is CHECKED with
+// integer arithmetic on conservative bounds (U <= computed sum x (1 + 2^-30)).  A (Gaussian, sub-batch) that fails -- a zero or
+// negative term, a tiny term beside a large sum -- is summed again one member after the other by the pipelined code below.
+__device__ unsigned long long g_fallback_sums;  // (Gaussian, sub-batch) workgroups that failed the test (tree_mode 1) since the last reset
+__device__ __forceinline__ uint32_t hi_word(double x) { return (uint32_t)(__double_as_longlong(x) >> 32); }
+
 constexpr int kBL = 16;  // evaluation stride of the LDS ring layout (compile time: every ds_read of the chainer gets an immediate offset)
 
 // kProd producer waves; kSepLoader: one more wave that only feeds the member ring (otherwise the last producer does that too).
@@ -335,8 +347,11 @@ constexpr int kBL = 16;  // evaluation stride of the LDS ring layout (compile ti
 template <int kProd, bool kSepLoader, int kChunk>
 __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_residuals_chain(
     const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12, const float4* __restrict__ tabT, int B,
-    const uint32_t* __restrict__ order, int Bs, int nsub, int prio, double* __restrict__ E, int64_t ldE) {
+    const uint32_t* __restrict__ order, int Bs, int nsub, int prio, int tree_mode, double* __restrict__ E, int64_t ldE) {
+    // tree_mode 0: second pass as a chain (the reference's loop, pipelined); 1: parallel second pass, chain only if the exactness test
+    // fails; 2: parallel pass computed, then the chain anyway (test hook)
     constexpr int kProducers = kProd;
+    constexpr int kWaves = kProd + 1 + (kSepLoader ? 1 : 0);
     constexpr int kMaxSteps = (kChunk / 8 + kProd - 1) / kProd;  // steps per chunk <= kChunk / 8 (Bs = kBL: 4 member pairs per step)
     // pass 1 ring: float  q[kSlots][kChunk / 4][3][kBL][4]   (member-in-group fastest: the chainer reads four members per ds_read_b128)
     // pass 2 ring: double t[kSlots][kChunk / 2][kBL][2]       (aliases the pass-1 ring)
@@ -344,6 +359,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
     __shared__ __attribute__((aligned(16))) float s_q[kSlots * kSlotFloats];
     __shared__ float s_mean[3 * kBL];
     __shared__ __attribute__((aligned(16))) float4 s_m[4][kChunk];  // member ring (filled by LDS-DMA)
+    __shared__ int s_chain;  // the parallel second pass failed its test for some evaluation
     double* s_t = reinterpret_cast<double*>(s_q);
 
     const int item = blockIdx.x, gi = item / nsub, sub = item - gi * nsub;
@@ -353,6 +369,65 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nchunks = (n + kChunk - 1) / kChunk;
     const int nphases = nchunks + 2;
+
+    // ---- second pass as a parallel reduction (all waves; see "second pass without a chain" above) ----
+    // lane = (member of the step, evaluation) like the producers; every wave strides through the member list on its own, partial sums
+    // and the smallest term stay in registers, one LDS reduction per workgroup at the end.  Returns true when E is written.
+    auto parallel_second_pass = [&]() -> bool {
+        if (tree_mode == 0) return false;
+        const int mpl = 64 / Bs, ms2 = lane / Bs, pb2 = lane - ms2 * Bs;  // members per wave step
+        const bool lane_on2 = ms2 < mpl && pb2 < nb;
+        const int bcol2 = b0 + (pb2 < nb ? pb2 : 0);
+        const float mx2 = s_mean[pb2 & 15], my2 = s_mean[kBL + (pb2 & 15)], mz2 = s_mean[2 * kBL + (pb2 & 15)];
+        const Info I2 = load_info(info12, g);
+        if (threadIdx.x == 0) s_chain = 0;
+        double part = 0.0;
+        uint32_t key = 0xffffffffu;  // high word of the smallest term as a double (monotone for positive values); 0: a term <= 0 or NaN
+        Rows r2;
+        r2.r0 = r2.r1 = r2.r2 = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        int r2_row = -1;
+        const int stride = kWaves * mpl;
+        int j = wave * mpl + ms2;
+        float4 m_next = memb[off0 + min(j, n - 1)];
+        for (int j0 = wave * mpl; j0 < n; j0 += stride) {
+            const float4 m = m_next;
+            const int jn = j + stride;
+            m_next = memb[off0 + min(jn, n - 1)];  // one step ahead
+            if (lane_on2 && j < n) {
+                const int row = __float_as_int(m.w);
+                if (row != r2_row) r2 = load_rows(tabT, B, bcol2, row), r2_row = row;
+                float gx, gy, gz;
+                transform_v(r2, m.x, m.y, m.z, gx, gy, gz);
+                const float t = mahalanobis_v(I2, gx, gy, gz, mx2, my2, mz2);
+                const double td = (double)t;
+                part += td;
+                key = min(key, t > 0.0f ? hi_word(td) : 0u);
+            }
+            j = jn;
+        }
+        double* red = s_t;  // the rings are idle between the passes
+        uint32_t* redk = reinterpret_cast<uint32_t*>(s_t + kWaves * 64);
+        red[wave * 64 + lane] = part, redk[wave * 64 + lane] = key;
+        lds_barrier();
+        if (wave == 0 && lane < nb) {
+            double U = 0.0;
+            uint32_t k = 0xffffffffu;
+            for (int w = 0; w < kWaves; ++w)
+                for (int s2 = 0; s2 < mpl; ++s2) U += red[w * 64 + s2 * Bs + lane], k = min(k, redk[w * 64 + s2 * Bs + lane]);
+            const int q = (int)(k >> 20) - 1023 - 23;           // every term is a multiple of 2^q
+            const int pe = min(max(q + 53 + 1023, 0), 2046);
+            const double limit = __hiloint2double(pe << 20, 0);  // 2^(q+53); 0 when that is below the normal range: the test fails
+            const bool exact = U * (1.0 + 0x1p-30) < limit && tree_mode == 1;  // NaN fails; U itself may be rounded: < n 2^-53 relative
+            if (exact)
+                E[(size_t)(b0 + lane) * ldE + g] = sqrt(fabs(U));
+            else
+                s_chain = 1;
+        }
+        lds_barrier();
+        const bool chain = s_chain != 0;
+        if (chain && threadIdx.x == 0 && tree_mode == 1) atomicAdd(&g_fallback_sums, 1ull);
+        return !chain;
+    };
 
     if (wave == 0) {
         // ================= chainer: lane = (coordinate, evaluation) =================
@@ -405,6 +480,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
         }
         if (on1) s_mean[cc * kBL + cb] = acc / (float)n;
         lds_barrier();
+        if (parallel_second_pass()) return;
         const bool on2 = lane < nb;  // coordinate slot 0
         double dacc = 0.0;
         {
@@ -548,6 +624,10 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
     // ---- pass 2: Mahalanobis terms (needs the mean of pass 1) ----
     const Info I = load_info(info12, g);
     lds_barrier();  // s_mean is complete
+    if (parallel_second_pass()) {
+        if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the member DMAs issued ahead for a chained second pass
+        return;
+    }
     const float mx = s_mean[pb & 15], my = s_mean[kBL + (pb & 15)], mz = s_mean[2 * kBL + (pb & 15)];
     for (int p = 0; p < nphases; ++p) {
         const int P = nphases + p;
@@ -605,6 +685,18 @@ static int env_int(const char* name, int dflt, int lo, int hi) {
     const int t = e ? std::atoi(e) : dflt;
     return t < lo ? lo : (t > hi ? hi : t);
 }
+static int serial_tree_mode() {  // DMSA_SERIAL_TREE: 0 chained second pass, 1 parallel second pass with exactness test (default), 2 both (test hook)
+    return env_int("DMSA_SERIAL_TREE", 1, 0, 2);  // read per launch: the tests switch it inside one process
+}
+unsigned long long serial_fallback_sums(bool reset) {
+    unsigned long long v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_fallback_sums), sizeof(v));
+    if (reset) {
+        const unsigned long long z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fallback_sums), &z, sizeof(z));
+    }
+    return v;
+}
 SerialShape serial_shape(int B) {
     static const int bs_long = env_int("DMSA_SERIAL_BS_LONG", 8, 1, kBL), bs_mid = env_int("DMSA_SERIAL_BS", kBL, 1, kBL);
     SerialShape s;
@@ -630,13 +722,14 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
     const float4* info = reinterpret_cast<const float4*>(info12);
     const float4* tabT = reinterpret_cast<const float4*>(tablesT);
     const int n_long = sc.n_long, n_mid = sc.n_chain - sc.n_long;
+    const int tree_mode = serial_tree_mode();
     // latency tier first (its longest chain bounds the batch), blocks in descending size; the other tiers fill the chip around it
     if (n_long > 0)
         hipLaunchKernelGGL((k_residuals_chain<8, true, 64>), dim3((unsigned)n_long * sh.nsub_long), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
-                           sh.Bs_long, sh.nsub_long, 2, E, ldE);
+                           sh.Bs_long, sh.nsub_long, 2, tree_mode, E, ldE);
     if (n_mid > 0)
         hipLaunchKernelGGL((k_residuals_chain<4, false, 32>), dim3((unsigned)n_mid * sh.nsub), dim3(64 * 5), 0, s_rest, memb_local, seg_off, info, tabT, B,
-                           order + n_long, sh.Bs, sh.nsub, 0, E, ldE);
+                           order + n_long, sh.Bs, sh.nsub, 0, tree_mode, E, ldE);
     if (sc.n_small > 0) {
         const int items = sc.n_small * sh.nsub_small;
         const int per_block = 4 * (64 / sh.lanes);

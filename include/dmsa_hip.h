@@ -226,6 +226,12 @@ int dmsa_get_voxel_level(dmsa_ctx* ctx, int32_t level, dmsa_voxel_level_info* in
 int dmsa_get_gaussians(dmsa_ctx* ctx, int32_t* seg_offset /* M+1 */, int32_t* member_idx /* Mm */,
                        float* info_mats /* M x 9 col-major */, float* weights /* M */);
 
+/* Introspection of the default path's correspondence kernels: the double sum of a long Gaussian (DmsaOptimizer.h:259-264) is computed
+ * as a parallel reduction whenever integer bounds prove that the reference's member-by-member chain cannot round;
+ * this is the number of (Gaussian, evaluation sub-batch) sums for which the proof failed and the chain was run instead, since the
+ * last reset.  Results are the same either way; the counter only says how often the slow way was taken.  Synchronises the device. */
+int dmsa_serial_fallback_sums(dmsa_ctx* ctx, int32_t reset, uint64_t* count);
+
 /* Host-only: the Levenberg-Marquardt step of DmsaOptimizer.h:110-113, step = (-alpha * (H + lambda I)^-1) * g, with the explicit
  * inverse the reference forms (`H_damped` = H + lambda I, P x P column-major, symmetric or not).  `threads` > 1 spreads the row
  * updates of every pivot step over that many host threads for P >= 64 -- the result does not depend on it (tested bit for bit);

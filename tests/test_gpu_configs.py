@@ -315,3 +315,64 @@ def test_parity_path_trajectories_bit_identical(orc, case):
     assert [(t["M"], t["Mm"], t["best_k"], t["error0"], t["step_norm"]) for t in tr_a[: ra.iterations]] == [(t["M"], t["Mm"], t["best_k"], t["error0"], t["step_norm"]) for t in tr_b[: rb.iterations]]
     assert np.array_equal(a.relOrientations, b.relOrientations) and np.array_equal(a.relTranslations, b.relTranslations)
     assert ra.iterations >= 2
+
+
+def test_parallel_second_pass_of_the_chain_tiers(hip, orc, full_window, monkeypatch):
+    """The double sum of every Gaussian above 128 members is computed as a parallel reduction when integer bounds prove that the
+    reference's member-by-member chain cannot round (DESIGN.md 6.1), otherwise by the chain.  Residuals must equal the oracle's
+    sequential sums bit for bit in all three modes (parallel with test, parallel then chain anyway, chain only) -- also on a window
+    with adversarial members: static points placed exactly on the float means of the largest Gaussians give terms that are zero or
+    ~2^-40 beside sums ~2^6, for which the proof must fail and the chain run (counted by dmsa_serial_fallback_sums)."""
+    s = DmsaOptimSettings.sliding_window()
+    base = full_window
+    table, _ = orc.window_pose_table(base)
+    g = orc.transform_points(table, base.localPoints, base.tformIdPerPoint)
+    glob = np.concatenate([g, base.staticPoints]).astype(np.float32)
+    ids = np.concatenate([base.ringIds, base.staticRingIds])
+    G = orc.Gaussians(glob, ids, base.minGridSize, s)
+    sizes = np.diff(G.seg_offset)
+    big = np.argsort(-sizes)[:6]
+    assert sizes[big[0]] >= 4096
+    extra = []
+    for gi in big:
+        P = glob[G.members[G.seg_offset[gi]:G.seg_offset[gi + 1]], :3]
+        m = np.zeros(3, np.float32)
+        for p in P:  # the reference's float chain
+            m = (m + p).astype(np.float32)
+        extra.append((m / np.float32(len(P))).astype(np.float32))
+    adv = base.copy()
+    pts = np.zeros((len(extra), adv.staticPoints.shape[1]), np.float32)
+    pts[:, :3] = np.array(extra)
+    adv.staticPoints = np.concatenate([adv.staticPoints, pts]).astype(np.float32)
+    adv.staticRingIds = np.concatenate([adv.staticRingIds, np.full(len(extra), 7, adv.staticRingIds.dtype)])
+
+    for prob, expect_fallbacks in ((base, False), (adv, True)):
+        glob_p = np.concatenate([g, prob.staticPoints]).astype(np.float32)
+        ref = orc.Gaussians(glob_p, np.concatenate([prob.ringIds, prob.staticRingIds]), prob.minGridSize, s)
+        pbase = prob.getPoseParameters()
+        params = np.stack([pbase] + [pbase + H_INCR * np.eye(len(pbase))[k] for k in range(8)])  # 9 evaluations: two sub-batches
+        e_ref = None
+        for mode in ("1", "2", "0"):
+            monkeypatch.setenv("DMSA_SERIAL_TREE", mode)
+            opt = hip.DmsaOptimizer()
+            opt.upload(prob)
+            opt.poseTables(pbase[None, :], download=False)
+            opt.updateGlobalPoints(0, download=False)
+            assert opt.buildGaussians(s) == (ref.M, ref.Mm)
+            tables = opt.poseTables(params)
+            opt.serialFallbackSums(reset=True)
+            e = opt.evalResiduals(len(params))
+            fallbacks = opt.serialFallbackSums()
+            if e_ref is None:
+                e_ref = []
+                for b in range(len(params)):
+                    gb = orc.transform_points(tables[b], prob.localPoints, prob.tformIdPerPoint)
+                    e_ref.append(ref.residuals(np.concatenate([gb, prob.staticPoints]).astype(np.float32)))
+                e_ref = np.array(e_ref)
+            assert np.array_equal(e, e_ref), (mode, np.abs(e - e_ref).max())
+            if mode == "1":
+                chained = int((np.diff(ref.seg_offset) > 128).sum())  # Gaussians of the chain tiers, one or two sub-batches each
+                assert (fallbacks > 0) == expect_fallbacks and fallbacks < 0.02 * chained, (fallbacks, chained)
+            else:
+                assert fallbacks == 0  # only the live test counts
+            opt.close()
