@@ -386,14 +386,17 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
         Rows r2;
         r2.r0 = r2.r1 = r2.r2 = f4{0.0f, 0.0f, 0.0f, 0.0f};
         int r2_row = -1;
-        const int stride = kWaves * mpl;
-        int j = wave * mpl + ms2;
-        float4 m_next = memb[off0 + min(j, n - 1)];
-        for (int j0 = wave * mpl; j0 < n; j0 += stride) {
-            const float4 m = m_next;
-            const int jn = j + stride;
-            m_next = memb[off0 + min(jn, n - 1)];  // one step ahead
-            if (lane_on2 && j < n) {
+        // every wave takes one contiguous block of the member list (consecutive members mostly share a pose-table row, so a lane
+        // changes rows about once per row of its block instead of once per step); members are fetched two steps ahead
+        const int blk = ((n + kWaves - 1) / kWaves + mpl - 1) / mpl * mpl;
+        const int jend = min(n, (wave + 1) * blk);
+        int j = wave * blk + ms2;
+        float4 m_a = memb[off0 + min(j, n - 1)], m_b = memb[off0 + min(j + mpl, n - 1)];
+        for (int j0 = wave * blk; j0 < jend; j0 += mpl) {
+            const float4 m = m_a;
+            m_a = m_b;
+            m_b = memb[off0 + min(j + 2 * mpl, n - 1)];
+            if (lane_on2 && j < jend) {
                 const int row = __float_as_int(m.w);
                 if (row != r2_row) r2 = load_rows(tabT, B, bcol2, row), r2_row = row;
                 float gx, gy, gz;
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_res
                 part += td;
                 key = min(key, t > 0.0f ? hi_word(td) : 0u);
             }
-            j = jn;
+            j += mpl;
         }
         double* red = s_t;  // the rings are idle between the passes
         uint32_t* redk = reinterpret_cast<uint32_t*>(s_t + kWaves * 64);
@@ -698,7 +701,7 @@ unsigned long long serial_fallback_sums(bool reset) {
     return v;
 }
 SerialShape serial_shape(int B) {
-    static const int bs_long = env_int("DMSA_SERIAL_BS_LONG", 8, 1, kBL), bs_mid = env_int("DMSA_SERIAL_BS", kBL, 1, kBL);
+    static const int bs_long = env_int("DMSA_SERIAL_BS_LONG", kBL, 1, kBL), bs_mid = env_int("DMSA_SERIAL_BS", kBL, 1, kBL);
     SerialShape s;
     s.nsub_long = (B + bs_long - 1) / bs_long, s.Bs_long = (B + s.nsub_long - 1) / s.nsub_long;
     s.nsub = (B + bs_mid - 1) / bs_mid, s.Bs = (B + s.nsub - 1) / s.nsub;
