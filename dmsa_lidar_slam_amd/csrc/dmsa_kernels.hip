@@ -399,13 +399,17 @@ __device__ void lattice_adopt(LatticeRun& st, const float4 p, const double res, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_lattice(const float4* __restrict__ global, int64_t n, const float* __restrict__ aabb, int nb, double res0,
-                                                 double res1, int compress, LatticeTable* __restrict__ tables) {
-    __shared__ float s_glob[4][6];
+constexpr int kLatticeThreads = 1024;            // = kAabbBlock: one point of the replayed block per thread
+constexpr int kLatticeLdsBlocks = 2048;           // block bounds kept in LDS (48 KB); larger clouds read the rest from global memory
+__global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __restrict__ global, int64_t n, const float* __restrict__ aabb, int nb, double res0,
+                                                            double res1, int compress, LatticeTable* __restrict__ tables) {
+    static_assert(kLatticeThreads == kAabbBlock, "one thread per point of a block");
+    constexpr int kWaves = kLatticeThreads / 64;
+    __shared__ float s_glob[kWaves][6];
     __shared__ LatticeRun st;
     __shared__ uint32_t s_shift[kMaxLatticeEvents][3];
-    __shared__ int s_red[4];
-    __shared__ int s_pick;
+    __shared__ int s_red[kWaves];
+    __shared__ float s_bb[kLatticeLdsBlocks][6];
     LatticeTable* tab = tables + blockIdx.x;
     const double res = blockIdx.x == 0 ? res0 : res1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -414,10 +418,13 @@ __global__ __launch_bounds__(256) void k_lattice(const float4* __restrict__ glob
         for (int a = 0; a < 3; ++a) st.mn[a] = 0.0, st.mx[a] = 0.0;
         tab->first_idx = -1;
     }
-    {  // bounds of all finite points (for the key-range compression)
+    {  // stage the block bounds; bounds of all finite points (for the key-range compression)
         float g6[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        for (int b2 = tid; b2 < nb; b2 += 256) {
-            const float* bb = aabb + (size_t)b2 * 8;
+        for (int b2 = tid; b2 < nb; b2 += kLatticeThreads) {
+            const float4 lo = *reinterpret_cast<const float4*>(aabb + (size_t)b2 * 8), hi = *reinterpret_cast<const float4*>(aabb + (size_t)b2 * 8 + 4);
+            const float bb[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+            if (b2 < kLatticeLdsBlocks)
+                for (int a = 0; a < 6; ++a) s_bb[b2][a] = bb[a];
             if (bb[0] <= bb[3])
                 for (int a = 0; a < 3; ++a) g6[a] = fminf(g6[a], bb[a]), g6[3 + a] = fmaxf(g6[3 + a], bb[3 + a]);
         }
@@ -426,62 +433,69 @@ __global__ __launch_bounds__(256) void k_lattice(const float4* __restrict__ glob
             for (int a = 0; a < 6; ++a) s_glob[wave][a] = g6[a];
     }
     __syncthreads();
+    // minimum of an int over the workgroup (every thread gets it)
+    auto block_min = [&](int v) {
+        v = wave_allmin(v);
+        if (lane == 0) s_red[wave] = v;
+        __syncthreads();
+        int m = s_red[0];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) m = min(m, s_red[w]);
+        __syncthreads();
+        return m;
+    };
     int cursor = 0;
     while (cursor < nb) {
         // first block >= cursor whose bounds do not fit the current box
         int found = INT_MAX;
-        for (int base = cursor; base < nb; base += 256) {
+        for (int base = cursor; base < nb; base += kLatticeThreads) {
             const int blk = base + tid;
             int cand = INT_MAX;
             if (blk < nb) {
-                const float* bb = aabb + (size_t)blk * 8;
-                const bool any_finite = bb[0] <= bb[3];
-                if (any_finite) {
+                float bb[6];
+                if (blk < kLatticeLdsBlocks) {
+                    for (int a = 0; a < 6; ++a) bb[a] = s_bb[blk][a];
+                } else {
+                    for (int a = 0; a < 6; ++a) bb[a] = aabb[(size_t)blk * 8 + a];
+                }
+                if (bb[0] <= bb[3]) {  // the block holds a finite point
                     bool viol = !st.defined;
                     for (int a = 0; a < 3; ++a) viol = viol || (double)bb[a] < st.mn[a] || (double)bb[3 + a] >= st.mx[a];
                     if (viol) cand = blk;
                 }
             }
-            cand = wave_allmin(cand);
-            if (lane == 0) s_red[wave] = cand;
-            __syncthreads();
-            const int m = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-            __syncthreads();
+            const int m = block_min(cand);
             if (m != INT_MAX) {
                 found = m;
                 break;
             }
         }
         if (found == INT_MAX) break;
-        // replay the block until none of its points violates the box
-        const int64_t pbase = (int64_t)found * kAabbBlock;
+        // replay the block until none of its points violates the box; its points stay in registers, one per thread, and a point that
+        // fitted once fits for good (the box only grows), so the search resumes behind the last pick
+        const int64_t pi = (int64_t)found * kAabbBlock + tid;
+        float4 p = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        bool live = false;
+        if (pi < n) {
+            p = global[pi];
+            live = isfinite(p.x) && isfinite(p.y) && isfinite(p.z);
+        }
+        int from = 0;
         while (true) {
             int cand = INT_MAX;
-#pragma unroll
-            for (int k = 0; k < kAabbBlock / 256; ++k) {
-                const int off = tid + 256 * k;
-                const int64_t i = pbase + off;
-                if (i < n) {
-                    const float4 p = global[i];
-                    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-                        bool viol = !st.defined;
-                        viol = viol || (double)p.x < st.mn[0] || (double)p.x >= st.mx[0];
-                        viol = viol || (double)p.y < st.mn[1] || (double)p.y >= st.mx[1];
-                        viol = viol || (double)p.z < st.mn[2] || (double)p.z >= st.mx[2];
-                        if (viol) cand = min(cand, off);
-                    }
-                }
+            if (live && tid >= from) {
+                bool viol = !st.defined;
+                viol = viol || (double)p.x < st.mn[0] || (double)p.x >= st.mx[0];
+                viol = viol || (double)p.y < st.mn[1] || (double)p.y >= st.mx[1];
+                viol = viol || (double)p.z < st.mn[2] || (double)p.z >= st.mx[2];
+                if (viol) cand = tid;
             }
-            cand = wave_allmin(cand);
-            if (lane == 0) s_red[wave] = cand;
+            const int m = block_min(cand);
+            if (m == INT_MAX) break;
+            if (tid == m) lattice_adopt(st, p, res, pi, tab, s_shift);  // the violating thread applies PCL's growth loop itself
             __syncthreads();
-            const int m = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-            if (tid == 0) {
-                s_pick = m;
-                if (m != INT_MAX) lattice_adopt(st, global[pbase + m], res, pbase + m, tab, s_shift);
-            }
-            __syncthreads();
-            if (s_pick == INT_MAX || st.status != 0) break;
+            if (st.status != 0) break;
+            from = m + 1;
         }
         if (st.status != 0) break;
         cursor = found + 1;
@@ -497,8 +511,8 @@ __global__ __launch_bounds__(256) void k_lattice(const float4* __restrict__ glob
         // rounded against a different origin), common prefix -> number of varying low bits
         int total = 0;
         for (int a = 0; a < 3; ++a) {
-            const float lo = fminf(fminf(s_glob[0][a], s_glob[1][a]), fminf(s_glob[2][a], s_glob[3][a]));
-            const float hi = fmaxf(fmaxf(s_glob[0][3 + a], s_glob[1][3 + a]), fmaxf(s_glob[2][3 + a], s_glob[3][3 + a]));
+            float lo = s_glob[0][a], hi = s_glob[0][3 + a];
+            for (int w = 1; w < kWaves; ++w) lo = fminf(lo, s_glob[w][a]), hi = fmaxf(hi, s_glob[w][3 + a]);
             int bits = st.depth;
             uint32_t base = 0;
             if (st.defined && lo <= hi) {
@@ -525,7 +539,7 @@ __global__ __launch_bounds__(256) void k_lattice(const float4* __restrict__ glob
 }
 void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, bool compress, LatticeTable* tables,
                     hipStream_t s) {
-    hipLaunchKernelGGL(k_lattice, dim3(2), dim3(256), 0, s, global, n, aabb, nb, res0, res1, compress ? 1 : 0, tables);
+    hipLaunchKernelGGL(k_lattice, dim3(2), dim3(kLatticeThreads), 0, s, global, n, aabb, nb, res0, res1, compress ? 1 : 0, tables);
 }
 
 // (c) genOctreeKeyforPoint with the bounding box in force when the point was inserted, plus the integer shifts of

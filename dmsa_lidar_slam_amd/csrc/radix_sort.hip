@@ -6,7 +6,7 @@
 //
 //   k_sort_hist   one read of the keys: the 256-bin histograms of ALL digits (LDS atomics, one global atomic per bin and
 //                 workgroup); its workgroups also clear the look-back state of the passes
-//   k_sort_pass   x ceil(bits / 8): "onesweep" -- a tile of 4096 pairs per workgroup, ranks by wave-level digit matching (eight
+//   k_sort_pass   x ceil(bits / 8): "onesweep" -- a tile of 8192 pairs per workgroup, ranks by wave-level digit matching (eight
 //                 ballots per key, one LDS counter per (wave, digit)), tile prefix by decoupled look-back (thread d follows digit d
 //                 through the earlier tiles' published counts), pairs reordered in LDS so that every digit leaves the tile as one
 //                 contiguous run.  Tiles are handed out by an atomic ticket, so a tile only ever waits for tiles that started earlier.
@@ -22,7 +22,15 @@ namespace dmsa {
 namespace {
 
 constexpr int kBins = 256;
-constexpr int kSortThreads = 256, kSortWaves = kSortThreads / 64, kItems = 16, kTile = kSortThreads * kItems;  // 4096 pairs per tile
+#ifndef DMSA_SORT_THREADS
+#define DMSA_SORT_THREADS 512
+#endif
+#ifndef DMSA_SORT_LOOKBACK
+#define DMSA_SORT_LOOKBACK 16
+#endif
+constexpr int kSortThreads = DMSA_SORT_THREADS, kSortWaves = kSortThreads / 64, kItems = 16, kTile = kSortThreads * kItems;  // pairs per tile
+constexpr int kLook = DMSA_SORT_LOOKBACK;  // predecessors inspected per round trip of the look-back
+static_assert(kSortThreads >= kBins && kSortThreads % 64 == 0, "one thread per digit");
 constexpr int kHistItems = 32;                                                                                   // 8192 keys per histogram workgroup
 constexpr int kMaxPasses = 4;
 constexpr uint32_t kFlagPartial = 1u << 30, kFlagPrefix = 2u << 30, kValMask = (1u << 30) - 1;
@@ -45,14 +53,41 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
     for (int p = 0; p < kMaxPasses; ++p) s_h[p][tid] = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + tid; i < state_words; i += (size_t)gridDim.x * 256) tile_state[i] = 0;
     __syncthreads();
-    const size_t base = (size_t)blockIdx.x * (256 * kHistItems);
-#pragma unroll 4
-    for (int k = 0; k < kHistItems; ++k) {
-        const size_t i = base + (size_t)k * 256 + tid;
-        if (i < n) {
-            const uint32_t key = keys[i];
-            for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(key >> (8 * p)) & 255u], 1u);
+    // Leaf codes of neighbouring points share their upper digits: counting key by key would send all 64 lanes of a wave to the same LDS
+    // counter.  Every thread walks its own 32 consecutive keys and counts RUNS of equal digits in registers; one LDS atomic per run.
+    const size_t base = (size_t)blockIdx.x * (256 * kHistItems) + (size_t)tid * kHistItems;
+    uint32_t prev[kMaxPasses] = {0, 0, 0, 0}, run[kMaxPasses] = {0, 0, 0, 0};
+    if (base < n) {
+        const size_t m = n - base < (size_t)kHistItems ? n - base : (size_t)kHistItems;
+        for (size_t k4 = 0; k4 < m; k4 += 4) {
+            uint32_t kk[4];
+            if (k4 + 4 <= m) {
+                const uint4 v = *reinterpret_cast<const uint4*>(keys + base + k4);  // base is a multiple of 32 keys: 16-byte aligned
+                kk[0] = v.x, kk[1] = v.y, kk[2] = v.z, kk[3] = v.w;
+            } else {
+                for (int u = 0; u < 4; ++u) kk[u] = k4 + u < m ? keys[base + k4 + u] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k4 + u < m) {
+#pragma unroll
+                    for (int p = 0; p < kMaxPasses; ++p) {
+                        if (p < passes) {
+                            const uint32_t d = (kk[u] >> (8 * p)) & 255u;
+                            if (d == prev[p]) {
+                                ++run[p];
+                            } else {
+                                if (run[p]) atomicAdd(&s_h[p][prev[p]], run[p]);
+                                prev[p] = d, run[p] = 1;
+                            }
+                        }
+                    }
+                }
+            }
         }
+#pragma unroll
+        for (int p = 0; p < kMaxPasses; ++p)
+            if (p < passes && run[p]) atomicAdd(&s_h[p][prev[p]], run[p]);
     }
     __syncthreads();
     for (int p = 0; p < passes; ++p) {
@@ -95,8 +130,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint32_t* __re
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) s_tile = atomicAdd(&h->ticket[pass], 1u);
-#pragma unroll
-    for (int w = 0; w < kSortWaves; ++w) s_cnt[w][tid] = 0;
+    for (int i = tid; i < kSortWaves * kBins; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
     const size_t base = (size_t)tile * kTile;
@@ -133,36 +167,54 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint32_t* __re
     }
     __syncthreads();
     // ---- digit d = tid: offsets of the waves inside the digit, tile count, position of the digit inside the tile ----
+    const bool digit_thread = tid < kBins;
     uint32_t count = 0;
+    if (digit_thread) {
 #pragma unroll
-    for (int w = 0; w < kSortWaves; ++w) {
-        const uint32_t c = s_cnt[w][tid];
-        s_cnt[w][tid] = count;
-        count += c;
+        for (int w = 0; w < kSortWaves; ++w) {
+            const uint32_t c = s_cnt[w][tid];
+            s_cnt[w][tid] = count;
+            count += c;
+        }
     }
     uint32_t tile_total, bins_total;
     const uint32_t local_excl = block_exclusive_scan(count, s_wave, tile_total);
-    const uint32_t bin_base = block_exclusive_scan(h->hist[pass][tid], s_wave, bins_total);
+    const uint32_t bin_base = block_exclusive_scan(digit_thread ? h->hist[pass][tid] : 0u, s_wave, bins_total);
     // ---- decoupled look-back over the tiles with a smaller ticket ----
-    uint32_t* st = tile_state + (size_t)tile * kBins + tid;
     uint32_t excl = 0;
-    if (tile == 0) {
-        __hip_atomic_store(st, kFlagPrefix | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        __hip_atomic_store(st, kFlagPartial | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int64_t t = (int64_t)tile - 1;; --t) {
-            const uint32_t* prev = tile_state + (size_t)t * kBins + tid;
-            uint32_t v;
-            do {
-                v = __hip_atomic_load(prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while ((v >> 30) == 0u);
-            excl += v & kValMask;
-            if ((v >> 30) == 2u) break;
+    if (digit_thread) {
+        uint32_t* st = tile_state + (size_t)tile * kBins + tid;
+        if (tile == 0) {
+            __hip_atomic_store(st, kFlagPrefix | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(st, kFlagPartial | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // kLook predecessors per round trip: the loads are independent, their results are consumed in order
+            int64_t t = (int64_t)tile - 1;
+            bool done = false;
+            while (!done) {
+                uint32_t v[kLook];
+#pragma unroll
+                for (int u = 0; u < kLook; ++u)
+                    v[u] = t - u >= 0 ? __hip_atomic_load(tile_state + (size_t)(t - u) * kBins + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (kFlagPrefix | 0u);
+                int used = 0;
+#pragma unroll
+                for (int u = 0; u < kLook; ++u) {
+                    if (!done && used == u) {
+                        const uint32_t f = v[u] >> 30;
+                        if (f != 0u) {
+                            excl += v[u] & kValMask;
+                            ++used;
+                            done = f == 2u;
+                        }
+                    }
+                }
+                t -= used;
+            }
+            __hip_atomic_store(st, kFlagPrefix | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __hip_atomic_store(st, kFlagPrefix | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_base[tid] = bin_base + excl;
+        s_excl[tid] = local_excl;
     }
-    s_base[tid] = bin_base + excl;
-    s_excl[tid] = local_excl;
     __syncthreads();
     // ---- reorder inside the tile: every digit becomes one contiguous run ----
 #pragma unroll
