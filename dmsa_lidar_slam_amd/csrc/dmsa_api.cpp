@@ -189,6 +189,9 @@ struct dmsa_ctx {
     double* h_Hp = nullptr;     // pinned (P+1)^2 read-back of the normal equations
     size_t h_Hp_cap = 0;
     LatticeTable* h_lattice = nullptr;  // = h_rb->lattice
+    DevBuf d_seg_state[2];           // look-back state of k_leaf_segments (ticket counter + one word per tile), zeroed when allocated
+    uint32_t seg_epoch[2] = {0, 0}, seg_ticket[2] = {0, 0};
+    bool fused_segments = true;      // DMSA_FUSED_SEGMENTS=0: head flags / library scan / leaf starts as three kernels
     bool key32[2] = {false, false};  // leaf codes are 32-bit (both levels share the width: they are sorted together)
     // level views into the shared code / index arrays (level 1 starts n entries behind level 0)
     void* code_v[2] = {nullptr, nullptr};
@@ -584,10 +587,25 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     auto stage_leaves = [&](int l) -> int {
         const LatticeTable* tab = ctx->d_lattice.as<LatticeTable>() + l;
         const bool k32 = k32v[l];
-        launch_head_flags(ctx->code_s_v[l], k32, n, tab, ctx->d_head[l].as<int32_t>(), st[l]);
-        HIPCHK(inclusive_scan_i32(ctx->d_scan_tmp[l].p, ctx->d_scan_tmp[l].cap, ctx->d_head[l].as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), (size_t)n, st[l]));
-        launch_leaf_starts(ctx->d_head[l].as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), ctx->code_s_v[l], k32, tab, n,
-                           ctx->d_leaf_start[l].as<int32_t>(), &counts->level[l], st[l]);
+        if (ctx->fused_segments) {
+            // one single-pass kernel; its look-back state is never cleared (epoch-tagged words, running ticket counter)
+            const size_t need = 8 * (size_t)(1 + leaf_segment_tiles(n));
+            if (need > ctx->d_seg_state[l].cap) {
+                HIPCHK(ctx->d_seg_state[l].ensure(need));
+                HIPCHK(hipMemsetAsync(ctx->d_seg_state[l].p, 0, ctx->d_seg_state[l].cap, st[l]));
+                ctx->seg_epoch[l] = 0, ctx->seg_ticket[l] = 0;
+            }
+            ctx->seg_epoch[l] += 1;
+            if (ctx->seg_epoch[l] == 0) ctx->seg_epoch[l] = 1;
+            launch_leaf_segments(ctx->code_s_v[l], k32, n, tab, ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), &counts->level[l],
+                                 ctx->d_seg_state[l].as<unsigned long long>(), ctx->seg_epoch[l], ctx->seg_ticket[l], st[l]);
+            ctx->seg_ticket[l] += (uint32_t)leaf_segment_tiles(n);
+        } else {
+            launch_head_flags(ctx->code_s_v[l], k32, n, tab, ctx->d_head[l].as<int32_t>(), st[l]);
+            HIPCHK(inclusive_scan_i32(ctx->d_scan_tmp[l].p, ctx->d_scan_tmp[l].cap, ctx->d_head[l].as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), (size_t)n, st[l]));
+            launch_leaf_starts(ctx->d_head[l].as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), ctx->code_s_v[l], k32, tab, n,
+                               ctx->d_leaf_start[l].as<int32_t>(), &counts->level[l], st[l]);
+        }
         launch_leaf_accept(ctx->d_leaf_start[l].as<int32_t>(), ctx->idx_s_v[l], ctx->d_ring.as<int32_t>(), &counts->level[l],
                            s.min_num_points_per_set, n, ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(), st[l]);
         if (split)
@@ -1093,6 +1111,7 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     if (const char* e = std::getenv("DMSA_K4_TILES")) ctx->use_tiles = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_KEY_COMPRESS")) ctx->compress_keys = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_OVERLAP_BATCH")) ctx->overlap_batch = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DMSA_FUSED_SEGMENTS")) ctx->fused_segments = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_DUAL_STREAM")) ctx->dual_stream = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_MERGE_SORT")) ctx->merge_sort = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("DMSA_SERIAL_STREAMS")) ctx->serial_two_streams = std::atoi(e) != 1;

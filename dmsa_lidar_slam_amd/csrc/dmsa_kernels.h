@@ -95,6 +95,11 @@ void launch_voxel_keys(const float4* global, int64_t n, LatticeTable* table, dou
                        hipStream_t s);
 // ---- segmentation of the sorted (code, idx) arrays -------------------------------------------------------
 void launch_head_flags(const void* code_sorted, bool key32, int64_t n, const LatticeTable* table, int32_t* head, hipStream_t s);
+// the three steps head flags / inclusive scan / leaf starts in one single-pass kernel; `state` = 8 * (1 + leaf_segment_tiles(n)) bytes,
+// zeroed once when allocated; epoch > 0 differs from call to call, ticket_base = sum of the tile counts of all earlier calls on this state
+int leaf_segment_tiles(int64_t n);
+void launch_leaf_segments(const void* code_sorted, bool key32, int64_t n, const LatticeTable* table, int32_t* leaf_incl, int32_t* leaf_start, LevelCounts* counts,
+                          unsigned long long* state, uint32_t epoch, uint32_t ticket_base, hipStream_t s);
 void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const void* code_sorted, bool key32, const LatticeTable* table, int64_t n,
                         int32_t* leaf_start, LevelCounts* counts, hipStream_t s);
 void launch_leaf_accept(const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const LevelCounts* counts, int min_pts,

@@ -32,6 +32,10 @@ __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, kRowMask, 0xf, true));
 }
 template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, kCtrl, kRowMask, 0xf, true);
+}
+template <int kCtrl, int kRowMask>
 __device__ __forceinline__ double dpp_mov(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xf, true);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xf, true);
@@ -660,6 +664,111 @@ void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const v
         hipLaunchKernelGGL(k_leaf_starts<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, head, leaf_of_pos, (const uint64_t*)code_sorted, table, n,
                            leaf_start, counts);
 }
+
+// head flags + inclusive scan + leaf starts in ONE pass over the sorted codes (the three-kernel form above remains for the static
+// map).  Single-pass chained scan: tiles of 8192 positions are handed out by an atomic ticket, a tile publishes its number of leaf
+// heads and looks back over the earlier tiles.  Nothing is cleared between calls: every published word carries the call's epoch
+// (other epochs read as "not there yet") and the ticket counter runs on, the host passing the value it had when the call started.
+constexpr int kSegThreads = 512, kSegItems = 16, kSegTile = kSegThreads * kSegItems;
+template <typename KeyT>
+__global__ __launch_bounds__(kSegThreads) void k_leaf_segments(const KeyT* __restrict__ code, int64_t n, const LatticeTable* __restrict__ table,
+                                                                int32_t* __restrict__ leaf_incl, int32_t* __restrict__ leaf_start,
+                                                                LevelCounts* __restrict__ counts, unsigned long long* __restrict__ state /* [0]: ticket, [1 + tile] */,
+                                                                uint32_t epoch, uint32_t ticket_base) {
+    __shared__ uint32_t s_tile;
+    __shared__ int s_wave_total[kSegThreads / 64];
+    __shared__ int s_excl;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) s_tile = atomicAdd(reinterpret_cast<unsigned int*>(state), 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const KeyT invalid = (KeyT)lattice_invalid_code(*table);
+    const int64_t base = (int64_t)tile * kSegTile;
+    int flag[kSegItems], incl[kSegItems];
+    bool last_valid[kSegItems];
+    int run = 0;  // heads in the earlier rows of this wave
+#pragma unroll
+    for (int k = 0; k < kSegItems; ++k) {
+        const int64_t i = base + (int64_t)(wave * kSegItems + k) * 64 + lane;
+        flag[k] = 0, last_valid[k] = false;
+        if (i < n) {
+            const KeyT c = code[i];
+            flag[k] = (c != invalid && (i == 0 || code[i - 1] != c)) ? 1 : 0;
+            last_valid[k] = c != invalid && (i == n - 1 || code[i + 1] == invalid);
+        }
+        const int sc = wave_incl_scan_dpp(flag[k]);
+        incl[k] = run + sc;
+        run += __builtin_amdgcn_readlane(sc, 63);
+    }
+    if (lane == 0) s_wave_total[wave] = run;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kSegThreads / 64; ++w) {
+        const int t = s_wave_total[w];
+        if (w < wave) before += t;
+        total += t;
+    }
+    if (wave == 0) {
+        // look-back by one wave: lane u inspects predecessor t - u, 64 tiles per round trip (a round trip to the device-coherent level
+        // of the cache hierarchy costs about a microsecond on this multi-die GPU, so the chain is walked as wide as possible)
+        constexpr unsigned long long kPartial = 1ull << 30, kPrefix = 2ull << 30;
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        unsigned long long* st = state + 1;
+        int excl = 0;
+        if (tile == 0) {
+            if (lane == 0) __hip_atomic_store(st, tag | kPrefix | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(st + tile, tag | kPartial | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t t = (int64_t)tile - 1;
+            while (true) {
+                const int64_t mine = t - lane;
+                const unsigned long long v = mine >= 0 ? __hip_atomic_load(st + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag | kPrefix);
+                const uint32_t f = (uint32_t)(v >> 32) == epoch ? ((uint32_t)v) >> 30 : 0u;
+                const unsigned long long ready = __ballot(f != 0u), prefix = __ballot(f == 2u);
+                // lanes 0 .. stop-1 are consumed: up to and including the first prefix, or up to the first entry that is not there yet
+                const int first_missing = ready == ~0ull ? 64 : __builtin_ctzll(~ready);
+                const int first_prefix = prefix == 0ull ? 64 : __builtin_ctzll(prefix);
+                const bool done = first_prefix < first_missing;
+                const int stop = done ? first_prefix + 1 : first_missing;
+                int part = lane < stop ? (int)((uint32_t)v & ((1u << 30) - 1u)) : 0;
+                part = wave_incl_scan_dpp(part);
+                excl += __builtin_amdgcn_readlane(part, 63);
+                if (done) break;
+                t -= stop;
+            }
+            if (lane == 0) __hip_atomic_store(st + tile, tag | kPrefix | (unsigned)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_excl = excl;
+    }
+    __syncthreads();
+    const int off = s_excl + before;
+#pragma unroll
+    for (int k = 0; k < kSegItems; ++k) {
+        const int64_t i = base + (int64_t)(wave * kSegItems + k) * 64 + lane;
+        if (i < n) {
+            const int li = off + incl[k];
+            leaf_incl[i] = li;
+            if (flag[k]) leaf_start[li - 1] = (int32_t)i;
+            if (last_valid[k]) {
+                counts->num_leaves = li;
+                leaf_start[li] = (int32_t)(i + 1);
+            }
+        }
+    }
+}
+void launch_leaf_segments(const void* code_sorted, bool key32, int64_t n, const LatticeTable* table, int32_t* leaf_incl, int32_t* leaf_start, LevelCounts* counts,
+                          unsigned long long* state, uint32_t epoch, uint32_t ticket_base, hipStream_t s) {
+    if (n <= 0) return;
+    const unsigned tiles = (unsigned)((n + kSegTile - 1) / kSegTile);
+    if (key32)
+        hipLaunchKernelGGL(k_leaf_segments<uint32_t>, dim3(tiles), dim3(kSegThreads), 0, s, (const uint32_t*)code_sorted, n, table, leaf_incl, leaf_start, counts, state,
+                           epoch, ticket_base);
+    else
+        hipLaunchKernelGGL(k_leaf_segments<uint64_t>, dim3(tiles), dim3(kSegThreads), 0, s, (const uint64_t*)code_sorted, n, table, leaf_incl, leaf_start, counts, state,
+                           epoch, ticket_base);
+}
+int leaf_segment_tiles(int64_t n) { return (int)((n + kSegTile - 1) / kSegTile); }
 
 // DmsaOptimizer.h:302-307: a leaf becomes a point set iff size >= minNumberPts and max(id) != min(id)
 __global__ __launch_bounds__(256) void k_leaf_accept(const int32_t* __restrict__ leaf_start, const uint32_t* __restrict__ idx_sorted,
