@@ -23,7 +23,7 @@ def stats(db_path):
     print(f"# total kernel time {tot / 1e3:.1f} us over {sum(r[1] for r in rows)} dispatches")
     print(f"{'kernel':72s} {'calls':>6s} {'total_us':>10s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
     for name, n, total, avg, mn, mx in rows:
-        short = name.split("(")[0].replace("void ", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         if "rocprim" in short:
             short = "rocprim::" + short.split("::")[-1][:48] + "<...>"
         print(f"{short[:72]:72s} {n:6d} {total / 1e3:10.1f} {avg / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * total / tot:6.2f}")
@@ -34,7 +34,7 @@ def stats(db_path):
     rows = cur.execute("select name, grid_x, grid_y, workgroup_x, end-start from kernels where name like '%k_residuals%'").fetchall()
     by = collections.defaultdict(list)
     for name, gx, gy, wx, d in rows:
-        by[name.split("(")[0].replace("void ", "")].append(((gx // max(1, wx)) * gy, wx, d))
+        by[name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")].append(((gx // max(1, wx)) * gy, wx, d))
     for short in sorted(by):
         lo, hi = min(w for w, _, _ in by[short]), max(w for w, _, _ in by[short])
         two = hi > 1.5 * lo
