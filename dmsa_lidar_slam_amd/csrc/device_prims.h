@@ -17,7 +17,8 @@ hipError_t sort_pairs_u32_u32(void* temp, size_t temp_bytes, const uint32_t* key
 // radix_sort.hip: the hand-written onesweep sort behind sort_pairs_u32_u32 (DMSA_SORT=rocprim selects the library sort instead)
 size_t sort_pairs_u32_workspace_bytes(size_t n);
 hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                                   size_t n, unsigned end_bit, hipStream_t stream);
+                                   size_t n, unsigned end_bit, hipStream_t stream, bool prepared = false);
+bool sort_is_onesweep();  // false when DMSA_SORT=rocprim selects the library sort
 hipError_t inclusive_scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t stream);
 hipError_t exclusive_scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t stream);
 }  // namespace dmsa

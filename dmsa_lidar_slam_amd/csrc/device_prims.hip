@@ -30,6 +30,7 @@ size_t scan_temp_bytes(size_t n) {
     (void)rocprim::exclusive_scan(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, int32_t(0), n, rocprim::plus<int32_t>());
     return a > b ? a : b;
 }
+bool sort_is_onesweep() { return !use_library_sort(); }
 hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
                               uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream) {
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, stream);

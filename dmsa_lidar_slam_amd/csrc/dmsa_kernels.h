@@ -87,12 +87,17 @@ void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tabl
 void launch_detmath_eval(int fn, const double* x, const double* y, int64_t n, double* out, hipStream_t s);
 
 // ---- K2: PCL-exact voxel lattice + keys -----------------------------------------------------------------
-void launch_block_aabb(const float4* global, int64_t n, float* aabb /* nb x 8 */, hipStream_t s);
+// also clears `zero_bytes` (a multiple of 4) at `zero`: the counters of the iteration
+void launch_block_aabb(const float4* global, int64_t n, float* aabb /* nb x 8 */, void* zero, size_t zero_bytes, hipStream_t s);
+// sort_header0/1 (may be null): sort headers (radix_sort_dev.h) cleared on the side, for key kernels that count the sort digits
 void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, bool compress, LatticeTable* tables /* [2] */,
-                    hipStream_t s);
+                    void* sort_header0, void* sort_header1, hipStream_t s);
 // leaf codes are 32-bit (key32) when 3*depth + 1 <= 32, else 64-bit; the buffers are sized for 64-bit keys either way
+// `sort` (may be null; 32-bit keys only): the plan of the sort that follows -- the kernel then clears its look-back words and adds the
+// digit histograms of the keys it writes to its (cleared) header, and the sort is started with prepared = true
+struct SortPlan;
 void launch_voxel_keys(const float4* global, int64_t n, LatticeTable* table, double res, void* code, bool key32, uint32_t* idx, uint64_t code_or,
-                       hipStream_t s);
+                       const SortPlan* sort, hipStream_t s);
 // ---- segmentation of the sorted (code, idx) arrays -------------------------------------------------------
 void launch_head_flags(const void* code_sorted, bool key32, int64_t n, const LatticeTable* table, int32_t* head, hipStream_t s);
 // the three steps head flags / inclusive scan / leaf starts in one single-pass kernel; `state` = 8 * (1 + leaf_segment_tiles(n)) bytes,

@@ -11,6 +11,7 @@
 // P = 30.  Built with -ffp-contract=off (no FMA fusion: the transform and the voxel keys
 // must round exactly like the reference's separate multiply/add).
 #include "dmsa_kernels.h"
+#include "radix_sort_dev.h"
 
 #include <cfloat>
 #include <climits>
@@ -305,8 +306,11 @@ void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tabl
 // K2 — PCL-exact voxel lattice
 // ------------------------------------------------------------------------------------------------------------
 // (a) axis-aligned bounds of every block of 1024 points: lets the sequential bounding-box logic skip whole blocks.
-__global__ __launch_bounds__(256) void k_block_aabb(const float4* __restrict__ global, int64_t n, float* __restrict__ aabb) {
+__global__ __launch_bounds__(256) void k_block_aabb(const float4* __restrict__ global, int64_t n, float* __restrict__ aabb, uint32_t* __restrict__ zero,
+                                                    int zero_words) {
     __shared__ float s_red[4][6];
+    if (blockIdx.x == 0)  // the per-iteration counters of the voxelisation (a separate memset would be one more dispatch in the chain)
+        for (int i = threadIdx.x; i < zero_words; i += 256) zero[i] = 0u;
     const int64_t base = (int64_t)blockIdx.x * kAabbBlock;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -334,10 +338,13 @@ __global__ __launch_bounds__(256) void k_block_aabb(const float4* __restrict__ g
         aabb[(size_t)blockIdx.x * 8 + threadIdx.x] = v;
     }
 }
-void launch_block_aabb(const float4* global, int64_t n, float* aabb, hipStream_t s) {
-    if (n <= 0) return;
+void launch_block_aabb(const float4* global, int64_t n, float* aabb, void* zero, size_t zero_bytes, hipStream_t s) {
+    if (n <= 0) {
+        if (zero_bytes) (void)hipMemsetAsync(zero, 0, zero_bytes, s);
+        return;
+    }
     const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
-    hipLaunchKernelGGL(k_block_aabb, dim3(nb), dim3(256), 0, s, global, n, aabb);
+    hipLaunchKernelGGL(k_block_aabb, dim3(nb), dim3(256), 0, s, global, n, aabb, static_cast<uint32_t*>(zero), (int)(zero_bytes / 4));
 }
 
 // (b) the incremental bounding box of OctreePointCloud::adoptBoundingBoxToPoint, replayed by one workgroup per
@@ -406,8 +413,14 @@ __device__ void lattice_adopt(LatticeRun& st, const float4 p, const double res, 
 constexpr int kLatticeThreads = 1024;            // = kAabbBlock: one point of the replayed block per thread
 constexpr int kLatticeLdsBlocks = 2048;           // block bounds kept in LDS (48 KB); larger clouds read the rest from global memory
 __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __restrict__ global, int64_t n, const float* __restrict__ aabb, int nb, double res0,
-                                                            double res1, int compress, LatticeTable* __restrict__ tables) {
+                                                            double res1, int compress, LatticeTable* __restrict__ tables, uint32_t* __restrict__ sort_header0,
+                                                            uint32_t* __restrict__ sort_header1) {
     static_assert(kLatticeThreads == kAabbBlock, "one thread per point of a block");
+    {  // the key kernels that follow count the sort digits into these headers
+        uint32_t* h = blockIdx.x == 0 ? sort_header0 : sort_header1;
+        if (h != nullptr)
+            for (unsigned i = threadIdx.x; i < sizeof(SortHeader) / 4; i += kLatticeThreads) h[i] = 0u;
+    }
     constexpr int kWaves = kLatticeThreads / 64;
     __shared__ float s_glob[kWaves][6];
     __shared__ LatticeRun st;
@@ -542,8 +555,9 @@ __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __res
     }
 }
 void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, bool compress, LatticeTable* tables,
-                    hipStream_t s) {
-    hipLaunchKernelGGL(k_lattice, dim3(2), dim3(kLatticeThreads), 0, s, global, n, aabb, nb, res0, res1, compress ? 1 : 0, tables);
+                    void* sort_header0, void* sort_header1, hipStream_t s) {
+    hipLaunchKernelGGL(k_lattice, dim3(2), dim3(kLatticeThreads), 0, s, global, n, aabb, nb, res0, res1, compress ? 1 : 0, tables,
+                       static_cast<uint32_t*>(sort_header0), static_cast<uint32_t*>(sort_header1));
 }
 
 // (c) genOctreeKeyforPoint with the bounding box in force when the point was inserted, plus the integer shifts of
@@ -560,8 +574,15 @@ __device__ __forceinline__ uint64_t spread3(uint32_t v) {  // 21 bits -> every t
 
 template <typename KeyT>  // uint32_t when the leaf code + invalid bit fit 32 bits (tree depth <= 10), else uint64_t
 __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ global, int64_t n, LatticeTable* __restrict__ table, double res,
-                                                    KeyT* __restrict__ code, uint32_t* __restrict__ idx, uint64_t code_or) {
+                                                    KeyT* __restrict__ code, uint32_t* __restrict__ idx, uint64_t code_or, SortHeader* __restrict__ sort_header,
+                                                    uint32_t* __restrict__ sort_state, size_t sort_state_words, int sort_passes) {
     __shared__ LatticeTable t;
+    __shared__ uint32_t s_h[kSortMaxPasses][kSortBins];
+    const bool counting = sort_header != nullptr && sizeof(KeyT) == 4;  // the sort that follows takes its digit histograms from here
+    if (counting) {
+        for (int p = 0; p < kSortMaxPasses; ++p) s_h[p][threadIdx.x] = 0u;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < sort_state_words; i += (size_t)gridDim.x * blockDim.x) sort_state[i] = 0u;
+    }
     {
         const int words = sizeof(LatticeTable) / 4;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(table);
@@ -608,15 +629,26 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ g
         }
         code[i] = (KeyT)c;
         idx[i] = (uint32_t)i;
+        if (counting) sort_hist_add(s_h, sort_passes, (uint32_t)c, true);
+    }
+    if (counting) {
+        __syncthreads();
+        for (int p = 0; p < sort_passes; ++p) {
+            const uint32_t v = s_h[p][threadIdx.x];
+            if (v) atomicAdd(&sort_header->hist[p][threadIdx.x], v);
+        }
     }
 }
 void launch_voxel_keys(const float4* global, int64_t n, LatticeTable* table, double res, void* code, bool key32, uint32_t* idx, uint64_t code_or,
-                       hipStream_t s) {
+                       const SortPlan* sort, hipStream_t s) {
     if (n <= 0) return;
+    SortHeader* h = sort && key32 ? sort->header : nullptr;
     if (key32)
-        hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint32_t*)code, idx, code_or);
+        hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint32_t*)code, idx, code_or, h,
+                           h ? sort->tile_state : nullptr, h ? sort->state_words : (size_t)0, h ? sort->passes : 0);
     else
-        hipLaunchKernelGGL(k_voxel_keys<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint64_t*)code, idx, code_or);
+        hipLaunchKernelGGL(k_voxel_keys<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint64_t*)code, idx, code_or,
+                           (SortHeader*)nullptr, (uint32_t*)nullptr, (size_t)0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------

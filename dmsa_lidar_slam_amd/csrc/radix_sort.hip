@@ -14,6 +14,7 @@
 // Stable (elements of a tile are ranked in memory order, tiles in ticket order), deterministic, bit-identical to any other stable
 // sort -- the parity tests compare the resulting leaf order with the oracle's.
 #include "device_prims.h"
+#include "radix_sort_dev.h"
 
 #include <cstdint>
 
@@ -21,7 +22,7 @@ namespace dmsa {
 
 namespace {
 
-constexpr int kBins = 256;
+constexpr int kBins = kSortBins;
 #ifndef DMSA_SORT_THREADS
 #define DMSA_SORT_THREADS 512
 #endif
@@ -32,14 +33,8 @@ constexpr int kSortThreads = DMSA_SORT_THREADS, kSortWaves = kSortThreads / 64, 
 constexpr int kLook = DMSA_SORT_LOOKBACK;  // predecessors inspected per round trip of the look-back
 static_assert(kSortThreads >= kBins && kSortThreads % 64 == 0, "one thread per digit");
 constexpr int kHistItems = 32;                                                                                   // 8192 keys per histogram workgroup
-constexpr int kMaxPasses = 4;
+constexpr int kMaxPasses = kSortMaxPasses;
 constexpr uint32_t kFlagPartial = 1u << 30, kFlagPrefix = 2u << 30, kValMask = (1u << 30) - 1;
-
-struct SortHeader {
-    uint32_t hist[kMaxPasses][kBins];
-    uint32_t ticket[kMaxPasses];
-    uint32_t pad[60];
-};
 
 __global__ __launch_bounds__(256) void k_sort_zero(SortHeader* h) {
     uint32_t* w = reinterpret_cast<uint32_t*>(h);
@@ -246,25 +241,37 @@ size_t sort_pairs_u32_workspace_bytes(size_t n) {
     return align_up(sizeof(SortHeader), 256) + align_up(tiles * kBins * kMaxPasses * 4, 256) + 2 * align_up(n * 4, 256);
 }
 
+SortPlan sort_pairs_u32_plan(void* temp, size_t n, unsigned end_bit) {
+    const size_t tiles = (n + kTile - 1) / kTile;
+    const int passes = end_bit == 0 ? 1 : (int)((end_bit + 7) / 8);
+    char* w = static_cast<char*>(temp);
+    SortPlan p;
+    p.header = reinterpret_cast<SortHeader*>(w);
+    p.tile_state = reinterpret_cast<uint32_t*>(w + align_up(sizeof(SortHeader), 256));
+    p.passes = passes;
+    p.state_words = tiles * kBins * (size_t)(passes < kMaxPasses ? passes : kMaxPasses);
+    return p;
+}
+
 hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                                   size_t n, unsigned end_bit, hipStream_t stream) {
+                                   size_t n, unsigned end_bit, hipStream_t stream, bool prepared) {
     if (n == 0) return hipSuccess;
     if (n >= (size_t)kValMask || temp_bytes < sort_pairs_u32_workspace_bytes(n)) return hipErrorInvalidValue;
-    const int passes = end_bit == 0 ? 1 : (int)((end_bit + 7) / 8);
+    const SortPlan plan = sort_pairs_u32_plan(temp, n, end_bit);
+    const int passes = plan.passes;
     if (passes > kMaxPasses) return hipErrorInvalidValue;
     const size_t tiles = (n + kTile - 1) / kTile;
-    char* w = static_cast<char*>(temp);
-    SortHeader* h = reinterpret_cast<SortHeader*>(w);
-    w += align_up(sizeof(SortHeader), 256);
-    uint32_t* state = reinterpret_cast<uint32_t*>(w);
-    const size_t state_words = tiles * kBins * (size_t)passes;
-    w += align_up(tiles * kBins * kMaxPasses * 4, 256);
+    char* w = static_cast<char*>(temp) + align_up(sizeof(SortHeader), 256) + align_up(tiles * kBins * kMaxPasses * 4, 256);
     uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(w);
     w += align_up(n * 4, 256);
     uint32_t* vals_tmp = reinterpret_cast<uint32_t*>(w);
-    hipLaunchKernelGGL(k_sort_zero, dim3(1), dim3(256), 0, stream, h);
-    const unsigned hist_blocks = (unsigned)((n + 256 * kHistItems - 1) / (256 * kHistItems));
-    hipLaunchKernelGGL(k_sort_hist, dim3(hist_blocks), dim3(256), 0, stream, keys_in, n, passes, h, state, state_words);
+    SortHeader* h = plan.header;
+    uint32_t* state = plan.tile_state;
+    if (!prepared) {  // otherwise the producer of the keys cleared the header and the look-back words and counted the digits
+        hipLaunchKernelGGL(k_sort_zero, dim3(1), dim3(256), 0, stream, h);
+        const unsigned hist_blocks = (unsigned)((n + 256 * kHistItems - 1) / (256 * kHistItems));
+        hipLaunchKernelGGL(k_sort_hist, dim3(hist_blocks), dim3(256), 0, stream, keys_in, n, passes, h, state, plan.state_words);
+    }
     // ping-pong so that the last pass writes the caller's output arrays
     const uint32_t* kin = keys_in;
     const uint32_t* vin = vals_in;
