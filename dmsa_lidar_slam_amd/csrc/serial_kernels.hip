@@ -291,8 +291,11 @@ __device__ __forceinline__ void small_wave(const float4* __restrict__ memb, cons
     if (on) E[(size_t)b * ldE + g] = sqrt(fabs(acc));
 }
 
+#ifndef DMSA_SMALL_WAVES
+#define DMSA_SMALL_WAVES 1
+#endif
 template <int L>
-__global__ __launch_bounds__(256) void k_residuals_small(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off,
+__global__ __launch_bounds__(256, DMSA_SMALL_WAVES) void k_residuals_small(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off,
                                                          const float4* __restrict__ info12, const float4* __restrict__ tabT, int B,
                                                          const uint32_t* __restrict__ order, int n_items_g, int nsub, double* __restrict__ E,
                                                          int64_t ldE) {
@@ -345,7 +348,14 @@ constexpr int kBL = 16;  // evaluation stride of the LDS ring layout (compile ti
 //   <4, false, 32> throughput tier: 5 waves and 20 KB of LDS per workgroup (32-member chunks), six workgroups per CU; phases are
 //              producer-bound, but the resident waves spend most of their time issuing instead of waiting at a barrier
 template <int kProd, bool kSepLoader, int kChunk>
-__global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0))) void k_residuals_chain(
+// the throughput tier runs at 8 waves per SIMD (64 VGPRs, a few spilled dwords): +3 % per iteration over the 6 waves the compiler picks on its own
+#ifndef DMSA_MID_WAVES
+#define DMSA_MID_WAVES 8
+#endif
+#ifndef DMSA_LONG_WAVES
+#define DMSA_LONG_WAVES 1
+#endif
+__global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader ? DMSA_LONG_WAVES : DMSA_MID_WAVES) void k_residuals_chain(
     const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12, const float4* __restrict__ tabT, int B,
     const uint32_t* __restrict__ order, int Bs, int nsub, int prio, int tree_mode, double* __restrict__ E, int64_t ldE) {
     // tree_mode 0: second pass as a chain (the reference's loop, pipelined); 1: parallel second pass, chain only if the exactness test
