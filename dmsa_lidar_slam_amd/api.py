@@ -211,6 +211,23 @@ class DmsaOptimizer:
                                                 capi.ptr(out, C.c_double)), "dmsa_detmath_eval")
         return out
 
+    def sortPairs(self, keys, values, end_bit: int = 32):
+        """The library's stable radix sort of (u32 key, u32 value) pairs on key bits [0, end_bit) -- test hook."""
+        k = np.ascontiguousarray(keys, np.uint32)
+        v = np.ascontiguousarray(values, np.uint32)
+        ko, vo = np.zeros_like(k), np.zeros_like(v)
+        self._check(self._lib.dmsa_sort_pairs(self._ctx, capi.ptr(k, C.c_uint32), capi.ptr(v, C.c_uint32), k.size, int(end_bit), capi.ptr(ko, C.c_uint32),
+                                              capi.ptr(vo, C.c_uint32)), "dmsa_sort_pairs")
+        return ko, vo
+
+    def leafSegments(self, codes_sorted, code_bits: int):
+        """Segmentation of sorted leaf codes by the single-pass kernel -- test hook.  Returns (leaf_of_pos, leaf_start[:num_leaves + 1])."""
+        c = np.ascontiguousarray(codes_sorted, np.uint32)
+        of_pos, start, nl = np.zeros(c.size, np.int32), np.zeros(c.size + 1, np.int32), C.c_int32(0)
+        self._check(self._lib.dmsa_leaf_segments(self._ctx, capi.ptr(c, C.c_uint32), c.size, int(code_bits), capi.ptr(of_pos, C.c_int32), capi.ptr(start, C.c_int32),
+                                                 C.byref(nl)), "dmsa_leaf_segments")
+        return of_pos, start[:nl.value + 1]
+
     def serialFallbackSums(self, reset: bool = False) -> int:
         """(Gaussian, sub-batch) double sums that were chained member by member because the exactness test of the parallel sum failed."""
         v = C.c_uint64(0)

@@ -1590,6 +1590,56 @@ int dmsa_get_timing(dmsa_ctx* ctx, dmsa_timing* t, int32_t reset) {
     return DMSA_OK;
 }
 
+int dmsa_sort_pairs(dmsa_ctx* ctx, const uint32_t* keys, const uint32_t* values, int64_t n, uint32_t end_bit, uint32_t* keys_sorted, uint32_t* values_sorted) {
+    if (!ctx || n < 0 || end_bit > 32 || (n > 0 && (!keys || !values || !keys_sorted || !values_sorted))) return DMSA_ERR_INVALID;
+    if (n == 0) return DMSA_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf kin, vin, kout, vout, tmp;
+    const size_t bytes = (size_t)n * 4;
+    for (DevBuf* b : {&kin, &vin, &kout, &vout}) HIPCHK(b->ensure(bytes));
+    HIPCHK(tmp.ensure(sort_pairs_u32_workspace_bytes((size_t)n)));
+    HIPCHK(hipMemcpyAsync(kin.p, keys, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(vin.p, values, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(sort_pairs_u32_onesweep(tmp.p, tmp.cap, kin.as<uint32_t>(), kout.as<uint32_t>(), vin.as<uint32_t>(), vout.as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
+    HIPCHK(hipMemcpyAsync(keys_sorted, kout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(values_sorted, vout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return DMSA_OK;
+}
+
+int dmsa_leaf_segments(dmsa_ctx* ctx, const uint32_t* codes_sorted, int64_t n, uint32_t code_bits, int32_t* leaf_of_pos, int32_t* leaf_start, int32_t* num_leaves) {
+    if (!ctx || n < 0 || code_bits > 31 || !num_leaves || (n > 0 && (!codes_sorted || !leaf_of_pos || !leaf_start))) return DMSA_ERR_INVALID;
+    *num_leaves = 0;
+    if (n == 0) return DMSA_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf code, incl, start, tab, cnt, state;
+    HIPCHK(code.ensure((size_t)n * 4));
+    HIPCHK(incl.ensure((size_t)n * 4));
+    HIPCHK(start.ensure((size_t)(n + 1) * 4));
+    HIPCHK(tab.ensure(sizeof(LatticeTable)));
+    HIPCHK(cnt.ensure(sizeof(LevelCounts)));
+    HIPCHK(state.ensure(8 * (size_t)(1 + leaf_segment_tiles(n))));
+    LatticeTable t{};
+    t.compressed = 1, t.total_bits = (int)code_bits, t.code_or = 0;
+    HIPCHK(hipMemcpyAsync(tab.p, &t, sizeof(t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(code.p, codes_sorted, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(cnt.p, 0, sizeof(LevelCounts), ctx->stream));
+    HIPCHK(hipMemsetAsync(state.p, 0, state.cap, ctx->stream));
+    HIPCHK(hipMemsetAsync(incl.p, 0, (size_t)n * 4, ctx->stream));
+    // two calls on the same state: the second must ignore what the first left behind (epochs, running ticket)
+    const uint32_t tiles = (uint32_t)leaf_segment_tiles(n);
+    for (uint32_t call = 0; call < 2; ++call)
+        launch_leaf_segments(code.p, true, n, tab.as<LatticeTable>(), incl.as<int32_t>(), start.as<int32_t>(), cnt.as<LevelCounts>(), state.as<unsigned long long>(),
+                             call + 1, call * tiles, ctx->stream);
+    LevelCounts hc{};
+    HIPCHK(hipMemcpyAsync(&hc, cnt.p, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(leaf_of_pos, incl.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *num_leaves = hc.num_leaves;
+    if (hc.num_leaves > 0) HIPCHK(hipMemcpy(leaf_start, start.p, (size_t)(hc.num_leaves + 1) * 4, hipMemcpyDeviceToHost));
+    return DMSA_OK;
+}
+
 int dmsa_serial_fallback_sums(dmsa_ctx* ctx, int32_t reset, uint64_t* count) {
     if (!ctx || !count) return DMSA_ERR_INVALID;
     HIPCHK(hipSetDevice(ctx->device));

@@ -226,6 +226,18 @@ int dmsa_get_voxel_level(dmsa_ctx* ctx, int32_t level, dmsa_voxel_level_info* in
 int dmsa_get_gaussians(dmsa_ctx* ctx, int32_t* seg_offset /* M+1 */, int32_t* member_idx /* Mm */,
                        float* info_mats /* M x 9 col-major */, float* weights /* M */);
 
+/* The voxelisation's device primitives on caller data, for tests (host arrays in, host arrays out, synchronous):
+ * dmsa_sort_pairs   stable sort of (u32 key, u32 value) pairs on key bits [0, end_bit) with the library's own radix sort
+ *                   (csrc/radix_sort.hip) -- the order of pcl::octree's depth-first leaf iteration with ascending point index in a leaf
+ *                   is exactly a stable sort by leaf code (octree_pointcloud.hpp, DmsaOptimizer.h:284-316);
+ * dmsa_leaf_segments  the segmentation of sorted codes into leaves by the single-pass kernel: leaf_of_pos[i] = 1-based index of the
+ *                   leaf position i belongs to, leaf_start[0 .. num_leaves] and the number of leaves; the code 1 << code_bits marks
+ *                   non-finite points (sorted to the end) and belongs to no leaf. */
+int dmsa_sort_pairs(dmsa_ctx* ctx, const uint32_t* keys, const uint32_t* values, int64_t n, uint32_t end_bit, uint32_t* keys_sorted,
+                    uint32_t* values_sorted);
+int dmsa_leaf_segments(dmsa_ctx* ctx, const uint32_t* codes_sorted, int64_t n, uint32_t code_bits, int32_t* leaf_of_pos /* n */,
+                       int32_t* leaf_start /* n + 1 */, int32_t* num_leaves);
+
 /* Introspection of the default path's correspondence kernels: the double sum of a long Gaussian (DmsaOptimizer.h:259-264) is computed
  * as a parallel reduction whenever integer bounds prove that the reference's member-by-member chain cannot round;
  * this is the number of (Gaussian, evaluation sub-batch) sums for which the proof failed and the chain was run instead, since the
