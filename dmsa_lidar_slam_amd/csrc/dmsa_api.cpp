@@ -1038,10 +1038,36 @@ int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             for (double& v : step) v = (s.max_step / maxElem) * v;
         // adaptiveStepSize (:152-182): nine trial evaluations in one batch
         globs.clear(), extra.clear();
-        for (int k = 1; k < 10; ++k) {
-            for (int i = 0; i < P; ++i) test[(size_t)i] = paramVec[(size_t)i] + 0.1 * (double)k * step[(size_t)i];
+        if (ctx->model == MODEL_KEYFRAMES && P >= 48) {
+            // like the Jacobian batch: the keyframe model carries nothing from one evaluation to the next, so the nine trial chains are
+            // built side by side; the chain is left where the serial loop leaves it (last trial evaluated)
+            const int a = num_extra_rows(ctx);
+            const size_t gsz = (size_t)chain(ctx).n * 6;
+            globs.resize(9 * gsz);
+            extra.resize((size_t)9 * a);
+            const KeyframeHost base = ctx->key;
+            workers(ctx).run_all([&](int t, int nthr) {
+                KeyframeHost kh = base;
+                std::vector<double> tp((size_t)P), g;
+                for (int k = 1 + t; k < 10; k += nthr) {
+                    for (int i = 0; i < P; ++i) tp[(size_t)i] = paramVec[(size_t)i] + 0.1 * (double)k * step[(size_t)i];
+                    kh.frames.set_params(tp.data());
+                    kh.frames.relative_to_global();
+                    g.clear();
+                    append_glob(kh.frames, g);
+                    std::copy(g.begin(), g.end(), globs.begin() + (size_t)(k - 1) * gsz);
+                    if (a > 0) kh.additional_rows(&extra[(size_t)(k - 1) * a]);
+                }
+            });
+            ctx->evaluations += 9;
+            for (int i = 0; i < P; ++i) test[(size_t)i] = paramVec[(size_t)i] + 0.1 * 9.0 * step[(size_t)i];
             host_set_params(ctx, test.data());
-            host_eval(ctx, globs, extra);
+        } else {
+            for (int k = 1; k < 10; ++k) {
+                for (int i = 0; i < P; ++i) test[(size_t)i] = paramVec[(size_t)i] + 0.1 * (double)k * step[(size_t)i];
+                host_set_params(ctx, test.data());
+                host_eval(ctx, globs, extra);
+            }
         }
         g_tl.mark("solve+trial chains");
         CHK(build_tables(ctx, 9, globs));

@@ -3,6 +3,8 @@
 #include "host_math.h"
 
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <memory>
 #include <thread>
@@ -378,10 +380,6 @@ namespace {
 struct alignas(64) PhaseFlag {
     std::atomic<int> phase{0};
 };
-struct alignas(64) PivotCandidate {
-    double best;
-    int row;  // logical row, -1: this worker owns no candidate row
-};
 constexpr int kMaxSolveThreads = 12;
 int solve_thread_cap() {  // DMSA_SOLVE_THREADS overrides (1..16)
     static const int cap = []() {
@@ -390,6 +388,25 @@ int solve_thread_cap() {  // DMSA_SOLVE_THREADS overrides (1..16)
     }();
     return cap;
 }
+}  // namespace
+
+namespace {
+// x[i] -= f * s[i] and x[i] /= d: separate IEEE operations per element (this file is compiled with -ffp-contract=off), so the vector
+// width does not change a bit; the AVX2 copies are only taken on CPUs that have them.
+__attribute__((target("avx2"))) void row_sub_scaled_avx2(double* __restrict__ x, const double* __restrict__ s, double f, size_t n) {
+    for (size_t i = 0; i < n; ++i) x[i] -= f * s[i];
+}
+void row_sub_scaled_base(double* __restrict__ x, const double* __restrict__ s, double f, size_t n) {
+    for (size_t i = 0; i < n; ++i) x[i] -= f * s[i];
+}
+__attribute__((target("avx2"))) void row_div_avx2(double* __restrict__ x, double d, size_t n) {
+    for (size_t i = 0; i < n; ++i) x[i] /= d;
+}
+void row_div_base(double* __restrict__ x, double d, size_t n) {
+    for (size_t i = 0; i < n; ++i) x[i] /= d;
+}
+inline void row_sub_scaled(double* x, const double* s, double f, size_t n, bool avx2) { avx2 ? row_sub_scaled_avx2(x, s, f, n) : row_sub_scaled_base(x, s, f, n); }
+inline void row_div(double* x, double d, size_t n, bool avx2) { avx2 ? row_div_avx2(x, d, n) : row_div_base(x, d, n); }
 }  // namespace
 
 void lm_solve(const double* Hin, const double* g, int P, double alpha, double* step, const ParallelRun* par) {
@@ -438,14 +455,26 @@ void lm_solve(const double* Hin, const double* g, int P, double alpha, double* s
         }
         return;
     }
-    // P >= 64 (the keyframe pass, P = 186 per 32-frame neighbourhood: the solve was 60 % of an iteration): the rows of a pivot step
-    // are independent, so every worker owns a block of PHYSICAL rows for the whole solve.  Row swaps become a permutation every worker
-    // tracks privately; the pivot search is a per-worker maximum over its own rows (published with the row's logical index, ties to
-    // the lower index = the serial loop's first strict maximum); every worker scales its own copy of the pivot row, and the owner
-    // stores the scaled row one step later, when nobody reads the unscaled one any more.  One barrier per pivot step; element by
-    // element the same operations as above, so the result does not depend on the number of workers.
+    // P >= 64 (the keyframe pass, P = 186 per 32-frame neighbourhood, where the solve was 60 % of an iteration): blocked, on the
+    // caller's worker threads, with the SAME operations on every element.  A pivot step k turns element x of a row into x - f_rk s_kc
+    // (f_rk: the row's entry in column k before the step, s_kc: the scaled pivot row) or, in the pivot row, into x / d_k.  K = 8
+    // consecutive steps are applied to an element in one go, in step order, so its sequence of roundings is unchanged; what the steps
+    // need -- pivots, d_k, f_rk -- depends only on the K panel columns, which every worker factors privately (n x K numbers), as it
+    // does the K scaled pivot rows.  Then every worker updates its own block of rows from the previous buffer into the next one
+    // (two buffers: nobody overwrites what a slower worker still reads), one barrier per panel: 24 barriers instead of 186, and the
+    // row updates stay in L1.  Row swaps are a permutation every worker tracks privately.
+    constexpr int K = 8;
+    const size_t ld = 2 * n;
+    std::vector<double> buf[2] = {std::vector<double>(n * ld), std::vector<double>(n * ld)};
+    for (size_t r = 0; r < n; ++r) {
+        std::copy(&A[r * n], &A[r * n] + n, &buf[0][r * ld]);
+        std::copy(&inv[r * n], &inv[r * n] + n, &buf[0][r * ld + n]);
+    }
+    const bool avx2 = __builtin_cpu_supports("avx2");
     PhaseFlag flags[kMaxSolveThreads];
-    PivotCandidate cand[2][kMaxSolveThreads];
+    static const bool trace = std::getenv("DMSA_SOLVE_TRACE") != nullptr;
+    const auto t_enter = std::chrono::steady_clock::now();
+    double tr_us[4] = {0, 0, 0, 0};
     (*par)([&](int t, int nthr) {
         const int use = std::min({nthr, solve_thread_cap(), std::max(1, P / 16)});
         if (t >= use) return;
@@ -463,67 +492,91 @@ void lm_solve(const double* Hin, const double* g, int P, double alpha, double* s
         };
         const size_t lo = n * (size_t)t / (size_t)use, hi = n * (size_t)(t + 1) / (size_t)use;
         std::vector<int> perm(n), iperm(n);  // logical row -> physical row and back
+        std::vector<char> pivoted(n, 0);
         for (size_t i = 0; i < n; ++i) perm[i] = iperm[i] = (int)i;
-        std::vector<double> rowbuf[2] = {std::vector<double>(2 * n), std::vector<double>(2 * n)};
-        auto publish = [&](size_t col, int after /* candidates: logical index > after */) {
-            PivotCandidate c{0.0, -1};
-            for (size_t p = lo; p < hi; ++p) {
-                const int l = iperm[p];
-                if (l <= after) continue;
-                const double v = std::fabs(A[p * n + col]);
-                if (c.row < 0 || v > c.best || (v == c.best && l < c.row)) c.best = v, c.row = l;
+        std::vector<double> Pn(n * K), F(n * K), S((size_t)K * ld);
+        int piv[K];
+        double dd[K];
+        int panel = 0;
+        for (size_t k0 = 0; k0 < n; k0 += K, ++panel) {
+            const size_t kp = std::min((size_t)K, n - k0), k1 = k0 + kp;
+            const double* src = buf[panel & 1].data();
+            double* dst = buf[(panel + 1) & 1].data();
+            barrier();  // the previous panel's output is complete
+            if (trace && t == 0 && panel == 0) tr_us[0] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count();
+            // ---- the panel columns of all rows, factored privately (every worker gets the same pivots and multipliers) ----
+            for (size_t r = 0; r < n; ++r)
+                for (size_t j = 0; j < (size_t)K; ++j) Pn[r * K + j] = j < kp ? src[r * ld + k0 + j] : 0.0;
+            for (size_t j = 0; j < kp; ++j) {
+                const size_t k = k0 + j;
+                int pl = -1;
+                double best = 0.0;
+                for (size_t r = 0; r < n; ++r) {  // first strict maximum in logical row order = the serial search from row k down
+                    if (pivoted[r]) continue;
+                    const double v = std::fabs(Pn[r * K + j]);
+                    const int l = iperm[r];
+                    if (pl < 0 || v > best || (v == best && l < pl)) best = v, pl = l;
+                }
+                const int pp = perm[(size_t)pl];
+                const int p0 = perm[k];
+                perm[k] = pp, perm[(size_t)pl] = p0, iperm[(size_t)pp] = (int)k, iperm[(size_t)p0] = pl;
+                pivoted[(size_t)pp] = 1;
+                piv[j] = pp;
+                const double d = Pn[(size_t)pp * K + j];
+                dd[j] = d;
+                // whole panel rows (fixed length K: vectorised): the columns left of j hold finished entries nobody reads again
+                double prow[K];
+                for (int c = 0; c < K; ++c) prow[c] = Pn[(size_t)pp * K + c] / d;
+                for (int c = 0; c < K; ++c) Pn[(size_t)pp * K + c] = prow[c];
+                for (size_t r = 0; r < n; ++r) {
+                    if ((int)r == pp) continue;
+                    double* pr = &Pn[r * K];
+                    const double f = pr[j];
+                    F[r * K + j] = f;
+                    if (f == 0.0) continue;
+                    for (int c = 0; c < K; ++c) pr[c] -= f * prow[c];
+                }
             }
-            cand[col & 1][t] = c;
-        };
-        publish(0, -1);
-        barrier();
-        int pending = -1;  // physical row whose scaled copy (rowbuf of the previous step) this worker still has to store
-        for (size_t c0 = 0; c0 < n; ++c0) {
-            int pl = -1;
-            double best = 0.0;
-            for (int u = 0; u < use; ++u) {
-                const PivotCandidate& c = cand[c0 & 1][u];
-                if (c.row >= 0 && (pl < 0 || c.best > best || (c.best == best && c.row < pl))) best = c.best, pl = c.row;
+            // columns that still matter: A right of the panel, and the whole inverse half
+            const size_t c_lo = k1;
+            const size_t len = ld - c_lo;
+            // ---- the K scaled pivot rows (as they are at their own step), privately ----
+            for (size_t j = 0; j < kp; ++j) {
+                double* sj = &S[j * ld];
+                const size_t pp = (size_t)piv[j];
+                std::copy(src + pp * ld + c_lo, src + pp * ld + ld, sj + c_lo);
+                for (size_t i2 = 0; i2 < j; ++i2) {
+                    const double f = F[pp * K + i2];
+                    if (f != 0.0) row_sub_scaled(sj + c_lo, &S[i2 * ld] + c_lo, f, len, avx2);
+                }
+                row_div(sj + c_lo, dd[j], len, avx2);
             }
-            const int pp = perm[(size_t)pl];
-            if (pending >= 0) {  // last step's pivot row becomes an ordinary row of this step
-                const double* b = rowbuf[(c0 - 1) & 1].data();
-                std::copy(b + (c0 - 1), b + n, &A[(size_t)pending * n + (c0 - 1)]);
-                std::copy(b + n, b + 2 * n, &inv[(size_t)pending * n]);
-                pending = -1;
+            // ---- own rows: all steps of the panel on every element, in step order ----
+            for (size_t r = lo; r < hi; ++r) {
+                double* x = dst + r * ld;
+                std::copy(src + r * ld + c_lo, src + r * ld + ld, x + c_lo);
+                for (size_t j = 0; j < kp; ++j) {
+                    if ((int)r == piv[j]) {
+                        row_div(x + c_lo, dd[j], len, avx2);
+                    } else {
+                        const double f = F[r * K + j];
+                        if (f != 0.0) row_sub_scaled(x + c_lo, &S[j * ld] + c_lo, f, len, avx2);
+                    }
+                }
             }
-            double* a0 = rowbuf[c0 & 1].data();
-            double* i0 = a0 + n;
-            {
-                const double* ap = &A[(size_t)pp * n];
-                const double* ip = &inv[(size_t)pp * n];
-                const double d = ap[c0];
-                for (size_t c = c0; c < n; ++c) a0[c] = ap[c] / d;
-                for (size_t c = 0; c < n; ++c) i0[c] = ip[c] / d;
-            }
-            const int p0 = perm[c0];
-            perm[c0] = pp, perm[(size_t)pl] = p0, iperm[(size_t)pp] = (int)c0, iperm[(size_t)p0] = pl;
-            if ((size_t)pp >= lo && (size_t)pp < hi) pending = pp;
-            for (size_t p = lo; p < hi; ++p) {
-                if ((int)p == pp) continue;
-                double* ar = &A[p * n];
-                double* ir = &inv[p * n];
-                const double f = ar[c0];
-                if (f == 0.0) continue;
-                for (size_t c = c0; c < n; ++c) ar[c] -= f * a0[c];
-                for (size_t c = 0; c < n; ++c) ir[c] -= f * i0[c];
-            }
-            if (c0 + 1 < n) publish(c0 + 1, (int)c0);
-            barrier();
         }
-        if (pending >= 0) std::copy(rowbuf[(n - 1) & 1].data() + n, rowbuf[(n - 1) & 1].data() + 2 * n, &inv[(size_t)pending * n]);
+        if (trace && t == 0) tr_us[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count();
+        const double* fin = buf[panel & 1].data();
         for (size_t p = lo; p < hi; ++p) {
             double s = 0.0;
-            const double* ii = &inv[p * n];
+            const double* ii = fin + p * ld + n;
             for (size_t j = 0; j < n; ++j) s += (-alpha * ii[j]) * g[j];  // element (i, j) of the inverse
             step[(size_t)iperm[p]] = s;
         }
     });
+    if (trace)
+        std::fprintf(stderr, "[solve] P=%d workers awake after %.0f us, panels done after %.0f us, returned after %.0f us\n", P, tr_us[0], tr_us[1],
+                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count());
 }
 
 void lm_solve_lu(const double* Hin, const double* g, int P, double alpha, double* step) {
