@@ -401,12 +401,8 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         const int blk = ((n + kWaves - 1) / kWaves + mpl - 1) / mpl * mpl;
         const int jend = min(n, (wave + 1) * blk);
         int j = wave * blk + ms2;
-        float4 m_a = memb[off0 + min(j, n - 1)], m_b = memb[off0 + min(j + mpl, n - 1)];
-        for (int j0 = wave * blk; j0 < jend; j0 += mpl) {
-            const float4 m = m_a;
-            m_a = m_b;
-            m_b = memb[off0 + min(j + 2 * mpl, n - 1)];
-            if (lane_on2 && j < jend) {
+        auto term = [&](const float4 m, int jj) {
+            if (lane_on2 && jj < jend) {
                 const int row = __float_as_int(m.w);
                 if (row != r2_row) r2 = load_rows(tabT, B, bcol2, row), r2_row = row;
                 float gx, gy, gz;
@@ -416,7 +412,17 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
                 part += td;
                 key = min(key, t > 0.0f ? hi_word(td) : 0u);
             }
-            j += mpl;
+        };
+        // four member registers used in turn, each refilled (for four steps ahead) right AFTER its use: the load can land in the
+        // register it replaces, so there is no rotation copy -- a copy of a freshly loaded register makes the step wait for its own load
+        auto fetch = [&](int jj) { return memb[off0 + min(jj, n - 1)]; };
+        float4 m_a = fetch(j), m_b = fetch(j + mpl), m_c = fetch(j + 2 * mpl), m_d = fetch(j + 3 * mpl);
+        for (int j0 = wave * blk; j0 < jend; j0 += 4 * mpl) {
+            term(m_a, j), m_a = fetch(j + 4 * mpl);
+            term(m_b, j + mpl), m_b = fetch(j + 5 * mpl);
+            term(m_c, j + 2 * mpl), m_c = fetch(j + 6 * mpl);
+            term(m_d, j + 3 * mpl), m_d = fetch(j + 7 * mpl);
+            j += 4 * mpl;
         }
         double* red = s_t;  // the rings are idle between the passes
         uint32_t* redk = reinterpret_cast<uint32_t*>(s_t + kWaves * 64);
