@@ -242,28 +242,25 @@ __device__ __forceinline__ void small_wave(const float4* __restrict__ memb, cons
     const int last = max(n - 1, 0);
     const int bc = on ? b : 0;
     RowCache rc;
-    constexpr int U = 4;  // members in flight: the loads of the next four steps are issued before the current four are used
-    float4 cur[U], nxt[U];
-    auto load4 = [&](int j0, float4* dst) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) dst[u] = memb[off0 + min(j0 + u, last)];
-    };
+    constexpr int U = 4;  // members in flight: every member register is refilled (for U steps ahead) right after its use, in place --
+                          // rotating registers (cur = nxt) makes the compiler copy freshly loaded values, i.e. wait for them at once
+    float4 m[U];
+    auto member = [&](int jj) { return memb[off0 + min(jj, last)]; };
     // ---- float mean in member order (:247-254) ----
     float mx = 0.0f, my = 0.0f, mz = 0.0f;
-    load4(0, nxt);
-    for (int j0 = 0; j0 < nmax; j0 += U) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-        if (j0 + U < nmax) load4(j0 + U, nxt);
+    for (int u = 0; u < U; ++u) m[u] = member(u);
+    for (int j0 = 0; j0 < nmax; j0 += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (j0 + u < n) {
-                rc.fetch(tabT, B, bc, __float_as_int(cur[u].w));
+                rc.fetch(tabT, B, bc, __float_as_int(m[u].w));
                 f2 gxy;
                 float gz;
-                rc.apply(cur[u], gxy, gz);
+                rc.apply(m[u], gxy, gz);
                 mx = mx + gxy.x, my = my + gxy.y, mz = mz + gz;
             }
+            m[u] = member(j0 + U + u);
         }
     }
     const float nf = (float)n;
@@ -272,20 +269,19 @@ __device__ __forceinline__ void small_wave(const float4* __restrict__ memb, cons
     const InfoPk I = load_info_pk(info12, g);
     const f2 mxy = f2{mx, my};
     double acc = 0.0;
-    load4(0, nxt);
-    for (int j0 = 0; j0 < nmax; j0 += U) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-        if (j0 + U < nmax) load4(j0 + U, nxt);
+    for (int u = 0; u < U; ++u) m[u] = member(u);
+    for (int j0 = 0; j0 < nmax; j0 += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (j0 + u < n) {
-                rc.fetch(tabT, B, bc, __float_as_int(cur[u].w));
+                rc.fetch(tabT, B, bc, __float_as_int(m[u].w));
                 f2 gxy;
                 float gz;
-                rc.apply(cur[u], gxy, gz);
+                rc.apply(m[u], gxy, gz);
                 acc += (double)mahalanobis_term_pk(I, gxy, gz, mxy, mz);
             }
+            m[u] = member(j0 + U + u);
         }
     }
     if (on) E[(size_t)b * ldE + g] = sqrt(fabs(acc));
