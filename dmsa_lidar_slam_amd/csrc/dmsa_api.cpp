@@ -146,6 +146,9 @@ struct dmsa_ctx {
     int device = 0;
     uint32_t flags = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;  // stream2 carries the second voxel level only
+    hipStream_t stream3 = nullptr;                    // the short tier of the correspondence kernels (DMSA_SERIAL_STREAMS=2: with the throughput tier on stream2, =1: everything on `stream`)
+    hipEvent_t ev_join3 = nullptr;
+    bool serial_three_streams = true;
     hipEvent_t ev_fork = nullptr, ev_scan0 = nullptr, ev_join = nullptr, ev_counts = nullptr;
     bool dual_stream = true;  // DMSA_DUAL_STREAM=0: both levels on `stream`
     std::string err;
@@ -856,11 +859,18 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
             HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         }
+        const bool three = two && ctx->serial_three_streams;
+        if (three) HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
         launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
-                                ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, ctx->stream, two ? ctx->stream2 : ctx->stream);
+                                ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, ctx->stream, two ? ctx->stream2 : ctx->stream,
+                                three ? ctx->stream3 : (two ? ctx->stream2 : ctx->stream));
         if (two) {
             HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
+        if (three) {
+            HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
         }
     } else {
         ScopedTimer tm(ctx, T_RESIDUAL);
@@ -1160,11 +1170,12 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     if (const char* e = std::getenv("DMSA_SORT_PREHIST")) ctx->prehist = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_DUAL_STREAM")) ctx->dual_stream = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_MERGE_SORT")) ctx->merge_sort = std::atoi(e) != 0 ? 1 : 0;
-    if (const char* e = std::getenv("DMSA_SERIAL_STREAMS")) ctx->serial_two_streams = std::atoi(e) != 1;
+    if (const char* e = std::getenv("DMSA_SERIAL_STREAMS")) ctx->serial_two_streams = std::atoi(e) != 1, ctx->serial_three_streams = std::atoi(e) >= 3;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_scan0, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_counts, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_counts, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return DMSA_ERR_HIP;
     }
@@ -1206,6 +1217,9 @@ void dmsa_destroy(dmsa_ctx* ctx) {
             b->release();
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipEventDestroy(ctx->ev_fork), (void)hipEventDestroy(ctx->ev_scan0), (void)hipEventDestroy(ctx->ev_join), (void)hipEventDestroy(ctx->ev_counts);
+    (void)hipStreamSynchronize(ctx->stream3);
+    (void)hipEventDestroy(ctx->ev_join3);
+    (void)hipStreamDestroy(ctx->stream3);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

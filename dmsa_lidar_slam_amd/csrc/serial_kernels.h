@@ -25,10 +25,10 @@ void launch_size_classes(const int32_t* seg_off, const GaussCounts* counts, uint
 // tables [B][rows][12] -> tablesT [rows][B][12]: the B evaluations of one pose row are contiguous (lane = evaluation reads coalesce)
 void launch_transpose_tables(const float* tables, int rows, int B, float* tablesT, hipStream_t s);
 // updateErrorTerms for B pose tables, bit-identical to the reference's serial loops.  E[b * ldE + g] = sqrt(|sum|).
-// The latency tier runs on s_long, the other two tiers on s_rest (pass the same stream twice to serialise them); the caller joins
+// The latency tier runs on s_long, the throughput tier on s_rest, the short tier on s_small (pass a stream twice to serialise tiers); the caller joins
 // the streams.
 void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tablesT, int B, const uint32_t* order,
-                             const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest);
+                             const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small);
 // LDS / shape parameters chosen for a batch of B evaluations (exposed for the bench's roofline notes and the tests)
 struct SerialShape {
     int nsub_long, Bs_long;  // latency tier: evaluation sub-batches per Gaussian, evaluations per sub-batch

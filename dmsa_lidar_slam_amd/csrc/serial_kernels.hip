@@ -731,7 +731,7 @@ void launch_transpose_tables(const float* tables, int rows, int B, float* tables
                        reinterpret_cast<float4*>(tablesT));
 }
 void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tablesT, int B, const uint32_t* order,
-                             const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest) {
+                             const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small) {
     if (B <= 0) return;
     const SerialShape sh = serial_shape(B);
     const float4* info = reinterpret_cast<const float4*>(info12);
@@ -751,11 +751,11 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
         const dim3 grid((items + per_block - 1) / per_block);
         const uint32_t* ord = order + sc.n_chain;
         if (sh.lanes == 16)
-            hipLaunchKernelGGL(k_residuals_small<16>, grid, dim3(256), 0, s_rest, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
+            hipLaunchKernelGGL(k_residuals_small<16>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
         else if (sh.lanes == 32)
-            hipLaunchKernelGGL(k_residuals_small<32>, grid, dim3(256), 0, s_rest, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
+            hipLaunchKernelGGL(k_residuals_small<32>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
         else
-            hipLaunchKernelGGL(k_residuals_small<64>, grid, dim3(256), 0, s_rest, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
+            hipLaunchKernelGGL(k_residuals_small<64>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
     }
 #ifdef DMSA_SERIAL_TIMELINE
     if (std::getenv("DMSA_SERIAL_DEBUG") && n_long > 0) {
