@@ -147,7 +147,9 @@ struct dmsa_ctx {
     uint32_t flags = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;  // stream2 carries the second voxel level only
     hipStream_t stream3 = nullptr;                    // the short tier of the correspondence kernels (DMSA_SERIAL_STREAMS=2: with the throughput tier on stream2, =1: everything on `stream`)
-    hipEvent_t ev_join3 = nullptr;
+    hipEvent_t ev_join3 = nullptr, ev_tables = nullptr;
+    bool tables_pending = false;  // the current batch's pose tables were enqueued on stream2 (ev_tables marks their end)
+    int tablesT_batch = 0;        // d_tablesT holds the transposed tables of a batch of this size (0: stale)
     bool serial_three_streams = true;
     hipEvent_t ev_fork = nullptr, ev_scan0 = nullptr, ev_join = nullptr, ev_counts = nullptr;
     bool dual_stream = true;  // DMSA_DUAL_STREAM=0: both levels on `stream`
@@ -380,7 +382,12 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
 
 // ---- pose tables ------------------------------------------------------------------------------------------
 // `globs`: B x (C or F) x 6 doubles (axis-angle | translation) of the GLOBAL poses of every evaluation in the batch.
-int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs) {
+int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs, hipStream_t stream = nullptr) {
+    if (stream == nullptr) stream = ctx->stream;
+    if (ctx->tables_pending && stream == ctx->stream) {  // an earlier batch's tables may still be in flight on the second stream
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
+        ctx->tables_pending = false;
+    }
     ScopedTimer tm(ctx, T_TABLE);
     const int rows = ctx->rows;
     HIPCHK(ctx->d_tables.ensure((size_t)B * rows * 48));
@@ -412,8 +419,8 @@ int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs) {
         } else {
             workers(ctx).run_all([&](int t, int nt) { build_range((int)((int64_t)B * t / nt), (int)((int64_t)B * (t + 1) / nt)); });
         }
-        HIPCHK(hipMemcpyAsync(ctx->d_tables.p, ctx->h_tables.data(), ctx->h_tables.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));  // h_tables is reused by the next batch
+        HIPCHK(hipMemcpyAsync(ctx->d_tables.p, ctx->h_tables.data(), ctx->h_tables.size() * 4, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));  // h_tables is reused by the next batch
     } else {
         HIPCHK(ctx->d_ctrl.ensure(globs.size() * 8));
         constexpr int kPinSlots = 4;  // at least one stream synchronisation separates reuse of a slot (4 syncs per iteration)
@@ -427,14 +434,15 @@ int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs) {
         double* slot = ctx->h_pin + (size_t)ctx->h_pin_next * ctx->h_pin_slot;
         ctx->h_pin_next = (ctx->h_pin_next + 1) % kPinSlots;
         std::memcpy(slot, globs.data(), globs.size() * 8);
-        HIPCHK(hipMemcpyAsync(ctx->d_ctrl.p, slot, globs.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->d_ctrl.p, slot, globs.size() * 8, hipMemcpyHostToDevice, stream));
         if (ctx->model == MODEL_WINDOW)
             launch_window_pose_tables(ctx->d_ctrl.as<double>(), ctx->d_stamps.as<double>(), ctx->d_fhw.as<double>(), ctx->d_trajtime.as<double>(), B,
-                                      np, rows - 1, ctx->d_tables.as<float>(), ctx->stream);
+                                      np, rows - 1, ctx->d_tables.as<float>(), stream);
         else
-            launch_keyframe_pose_tables(ctx->d_ctrl.as<double>(), B, np, ctx->d_tables.as<float>(), ctx->stream);
+            launch_keyframe_pose_tables(ctx->d_ctrl.as<double>(), B, np, ctx->d_tables.as<float>(), stream);
     }
     ctx->batch = B;
+    ctx->tablesT_batch = 0;  // the transposed copy (default path) no longer matches
     return DMSA_OK;
 }
 
@@ -704,7 +712,8 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     int fit_launched[3] = {0, 0, 0}, finish_launched = 0;
     auto launch_fit = [&](const int first[3], const int tasks[3], int finish_gauss) -> int {
         ScopedTimer tm(ctx, T_FIT);
-        const bool two = ctx->dual_stream && (tasks[1] > 0 || tasks[2] > 0);
+        static const bool fit2 = std::getenv("DMSA_FIT_STREAMS") == nullptr || std::atoi(std::getenv("DMSA_FIT_STREAMS")) != 1;
+        const bool two = fit2 && ctx->dual_stream && (tasks[1] > 0 || tasks[2] > 0);
         if (two) {
             HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
@@ -717,7 +726,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         launch_gauss_fit_tree(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, 2, first[2], tasks[2],
                               ctx->d_fit_sums.as<double>(), s2);
         launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), true, ctx->stream);
-        if (two) {
+        if (two) {  // (the weights on a third stream: measured 2 % slower per iteration -- a cross-stream wait costs more than the 19 us kernel)
             HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         }
@@ -806,7 +815,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         if (wg > ctx->M) wg = ctx->M;
         ctx->num_wg = wg;
         // the workgroup partition only feeds the streaming / parity correspondence kernels
-        if (!tiles_on || ctx->num_tiles == 0 || !ctx->tiles_usable) launch_segment_partition(ctx->d_seg_off.as<int32_t>(), ctx->M, wg, ctx->d_wg_seg.as<int32_t>(), ctx->stream);
+        if (!classes_on && (!tiles_on || ctx->num_tiles == 0 || !ctx->tiles_usable)) launch_segment_partition(ctx->d_seg_off.as<int32_t>(), ctx->M, wg, ctx->d_wg_seg.as<int32_t>(), ctx->stream);
     }
     ctx->gaussians_valid = true;
     return DMSA_OK;
@@ -823,6 +832,10 @@ int ensure_E(dmsa_ctx* ctx, int B) {
 }
 int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
     CHK(ensure_E(ctx, B));
+    if (ctx->tables_pending) {  // the pose tables of this batch were built on the second stream
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
+        ctx->tables_pending = false;
+    }
     const int a = ctx->extra_rows;
     if (a > 0 && extra != nullptr) {
         // additional rows (IMU / gravity / odometry) go below the Gaussian rows of every evaluation, through a pinned ring like the
@@ -853,7 +866,7 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
         // reference-order sums (default path): lane = evaluation on transposed pose tables
         HIPCHK(ctx->d_tablesT.ensure((size_t)B * ctx->rows * 48));
         ScopedTimer tm(ctx, T_RESIDUAL);
-        launch_transpose_tables(ctx->d_tables.as<float>(), ctx->rows, B, ctx->d_tablesT.as<float>(), ctx->stream);
+        if (ctx->tablesT_batch != B) launch_transpose_tables(ctx->d_tables.as<float>(), ctx->rows, B, ctx->d_tablesT.as<float>(), ctx->stream);
         const bool two = ctx->serial_two_streams && ctx->serial_counts.n_long > 0;
         if (two) {  // the latency tier keeps `stream`; the throughput tiers run beside it on stream2
             HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -978,7 +991,18 @@ int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
                 }
             }
             chain(ctx).set_params(origin.data());  // :231
-            return build_tables(ctx, 1 + P, globs);
+            // The tables of the batch (and, on the default path, their transposed copy) depend on nothing the GPU is busy with: they go
+            // to the second stream, behind the level-1 voxelisation, instead of between the fit and the correspondence kernels.
+            hipStream_t ts = ctx->dual_stream ? ctx->stream2 : ctx->stream;
+            CHK(build_tables(ctx, 1 + P, globs, ts));
+            if (ctx->flags & DMSA_FLAG_MIRROR_SUMS) {
+                HIPCHK(ctx->d_tablesT.ensure((size_t)(1 + P) * ctx->rows * 48));
+                launch_transpose_tables(ctx->d_tables.as<float>(), ctx->rows, 1 + P, ctx->d_tablesT.as<float>(), ts);
+                ctx->tablesT_batch = 1 + P;
+            }
+            HIPCHK(hipEventRecord(ctx->ev_tables, ts));
+            ctx->tables_pending = ts != ctx->stream;
+            return DMSA_OK;
         };
         // The batch does not depend on the Gaussians, so its host math (on the parity path: 1 + P libm pose tables) and the
         // pose-table upload / kernel are issued while the GPU is still voxelising (table 0 of the batch equals the base table the
@@ -1175,7 +1199,8 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_scan0, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_counts, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess) {
+        hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_tables, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return DMSA_ERR_HIP;
     }
@@ -1218,7 +1243,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipEventDestroy(ctx->ev_fork), (void)hipEventDestroy(ctx->ev_scan0), (void)hipEventDestroy(ctx->ev_join), (void)hipEventDestroy(ctx->ev_counts);
     (void)hipStreamSynchronize(ctx->stream3);
-    (void)hipEventDestroy(ctx->ev_join3);
+    (void)hipEventDestroy(ctx->ev_join3), (void)hipEventDestroy(ctx->ev_tables);
     (void)hipStreamDestroy(ctx->stream3);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
