@@ -647,13 +647,13 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                          ctx->d_pslot_of_slot[l].as<int32_t>(), &counts->level[l], st[l]);
         return DMSA_OK;
     };
-    auto stage_gather = [&](int l) {
+    auto stage_gather = [&](int l, hipStream_t gs) {
         const LatticeTable* tab = ctx->d_lattice.as<LatticeTable>() + l;
         launch_gather_members(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->idx_s_v[l],
                               ctx->code_s_v[l], k32v[l], tab, ctx->d_slot_acc[l].as<int32_t>(), ctx->d_gauss_of_slot[l].as<int32_t>(),
                               ctx->d_memb_of_slot[l].as<int32_t>(), split ? ctx->d_pos_slot_rank[l].as<int32_t>() : nullptr, ctx->d_local.as<float4>(),
                               ctx->d_slot_cnt[l].as<int32_t>(), counts, l, n, ctx->d_memb_local.as<float4>(), ctx->d_memb_idx.as<int32_t>(),
-                              ctx->d_memb_g.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), ctx->d_pslot_of_slot[l].as<int32_t>(), ctx->d_pad_off.as<int32_t>(), st[l]);
+                              ctx->d_memb_g.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), ctx->d_pslot_of_slot[l].as<int32_t>(), ctx->d_pad_off.as<int32_t>(), gs);
     };
     {
         ScopedTimer tm(ctx, T_VOXEL);
@@ -670,13 +670,13 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             CHK(stage_leaves(l));
             if (l == 0 && two) HIPCHK(hipEventRecord(ctx->ev_scan0, ctx->stream));  // level-0 totals are final
         }
-        if (two) HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_scan0, 0));
-        for (int l = 0; l < 2; ++l)
-            if (lvl_on[l]) stage_gather(l);
-        if (two) {
-            HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-        }
+        // Both gathers on the first stream (level 1 appends behind level 0's totals anyway): the level-1 chain ends with its leaf scan,
+        // long before level 0's gather is through, so the wait below finds its event signalled -- a join at the END of a stream costs
+        // ~20 us of cross-queue signalling in front of everything that follows.
+        if (two) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+        if (lvl_on[0]) stage_gather(0, ctx->stream);
+        if (two) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        if (lvl_on[1]) stage_gather(1, ctx->stream);
     }
     if (!tiles_on) {
         ScopedTimer tm(ctx, T_FIT);
