@@ -697,13 +697,20 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     if (classes_on)  // size classes of the reference-order correspondence kernels: needs only seg_off, so it runs before the read-back
         launch_size_classes(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_order.as<uint32_t>(),
                             reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts) + sizeof(TileCounts)), ctx->stream);
-    HIPCHK(hipMemcpyAsync(&ctx->h_rb->g, ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));  // incl. out_of_range
+    // The read-back of the counts runs on the third stream: a device-to-host copy ends with a system-scope release that holds up the
+    // stream it is on for ~20 us, and the fit behind it does not need to wait for that.
+    hipStream_t rb = ctx->dual_stream ? ctx->stream3 : ctx->stream;
+    if (rb != ctx->stream) {
+        HIPCHK(hipEventRecord(ctx->ev_scan0, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(rb, ctx->ev_scan0, 0));
+    }
+    HIPCHK(hipMemcpyAsync(&ctx->h_rb->g, ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts), hipMemcpyDeviceToHost, rb));
+    HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, rb));  // incl. out_of_range
     // The fit does not need the counts on the host (fixed grids, device-side tile counts): with the LDS table sized for ALL pose rows
     // it is enqueued right behind the read-back, so the GPU keeps working while the host waits for M (sync #2 waits on an event
     // recorded BEFORE the fit, not on the stream).
     const bool early_fit = tiles_on && (size_t)(ctx->rows + 1) * 48 <= 56 * 1024;
-    HIPCHK(hipEventRecord(ctx->ev_counts, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev_counts, rb));
     // Default path: the fit (oracle's tree order) is enqueued BEHIND the read-back as well, with the previous iteration's class
     // counts (+ margin) as grids -- the kernels take the true ranges from device memory, surplus workgroups exit, and whatever the
     // guess missed is launched after sync #2.  The three classes run side by side on two streams (each is latency-bound on its own).
@@ -992,8 +999,8 @@ int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             }
             chain(ctx).set_params(origin.data());  // :231
             // The tables of the batch (and, on the default path, their transposed copy) depend on nothing the GPU is busy with: they go
-            // to the second stream, behind the level-1 voxelisation, instead of between the fit and the correspondence kernels.
-            hipStream_t ts = ctx->dual_stream ? ctx->stream2 : ctx->stream;
+            // to another stream, beside the voxelisation, instead of between the fit and the correspondence kernels.
+            hipStream_t ts = ctx->dual_stream ? ctx->stream3 : ctx->stream;  // the third stream is idle during the voxelisation (the second also carries the fit)
             CHK(build_tables(ctx, 1 + P, globs, ts));
             if (ctx->flags & DMSA_FLAG_MIRROR_SUMS) {
                 HIPCHK(ctx->d_tablesT.ensure((size_t)(1 + P) * ctx->rows * 48));
