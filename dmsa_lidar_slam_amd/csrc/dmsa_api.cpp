@@ -435,11 +435,20 @@ int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs, hipStre
         ctx->h_pin_next = (ctx->h_pin_next + 1) % kPinSlots;
         std::memcpy(slot, globs.data(), globs.size() * 8);
         HIPCHK(hipMemcpyAsync(ctx->d_ctrl.p, slot, globs.size() * 8, hipMemcpyHostToDevice, stream));
+        // default path: the correspondence kernels read the tables transposed ([row][evaluation][12]); batches are written both ways at once
+        float* tT = nullptr;
+        if ((ctx->flags & DMSA_FLAG_MIRROR_SUMS) && B > 1) {
+            HIPCHK(ctx->d_tablesT.ensure((size_t)B * rows * 48));
+            tT = ctx->d_tablesT.as<float>();
+        }
         if (ctx->model == MODEL_WINDOW)
             launch_window_pose_tables(ctx->d_ctrl.as<double>(), ctx->d_stamps.as<double>(), ctx->d_fhw.as<double>(), ctx->d_trajtime.as<double>(), B,
-                                      np, rows - 1, ctx->d_tables.as<float>(), stream);
+                                      np, rows - 1, ctx->d_tables.as<float>(), tT, stream);
         else
-            launch_keyframe_pose_tables(ctx->d_ctrl.as<double>(), B, np, ctx->d_tables.as<float>(), stream);
+            launch_keyframe_pose_tables(ctx->d_ctrl.as<double>(), B, np, ctx->d_tables.as<float>(), tT, stream);
+        ctx->batch = B;
+        ctx->tablesT_batch = tT ? B : 0;
+        return DMSA_OK;
     }
     ctx->batch = B;
     ctx->tablesT_batch = 0;  // the transposed copy (default path) no longer matches
@@ -1002,11 +1011,6 @@ int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             // to another stream, beside the voxelisation, instead of between the fit and the correspondence kernels.
             hipStream_t ts = ctx->dual_stream ? ctx->stream3 : ctx->stream;  // the third stream is idle during the voxelisation (the second also carries the fit)
             CHK(build_tables(ctx, 1 + P, globs, ts));
-            if (ctx->flags & DMSA_FLAG_MIRROR_SUMS) {
-                HIPCHK(ctx->d_tablesT.ensure((size_t)(1 + P) * ctx->rows * 48));
-                launch_transpose_tables(ctx->d_tables.as<float>(), ctx->rows, 1 + P, ctx->d_tablesT.as<float>(), ts);
-                ctx->tablesT_batch = 1 + P;
-            }
             HIPCHK(hipEventRecord(ctx->ev_tables, ts));
             ctx->tables_pending = ts != ctx->stream;
             return DMSA_OK;
@@ -1485,6 +1489,7 @@ int dmsa_set_pose_tables(dmsa_ctx* ctx, int32_t B, const float* tables) {
     HIPCHK(hipMemcpyAsync(ctx->d_tables.p, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->batch = B;
+    ctx->tablesT_batch = 0;
     return DMSA_OK;
 }
 

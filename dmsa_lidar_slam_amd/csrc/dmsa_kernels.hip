@@ -213,7 +213,7 @@ constexpr int kMaxCtrl = 64;  // control poses per window the table kernel keeps
 
 __global__ __launch_bounds__(256) void k_window_pose_tables(const double* __restrict__ ctrl, const double* __restrict__ stamps,
                                                             const double* __restrict__ fh_w, const double* __restrict__ traj_time, int C, int n_t,
-                                                            float* __restrict__ tables) {
+                                                            float* __restrict__ tables, float* __restrict__ tablesT) {
     __shared__ double s_ctrl[kMaxCtrl * 6];
     __shared__ double s_stamp[kMaxCtrl];
     __shared__ double s_w[kMaxCtrl];
@@ -222,12 +222,16 @@ __global__ __launch_bounds__(256) void k_window_pose_tables(const double* __rest
     for (int i = threadIdx.x; i < C; i += blockDim.x) s_stamp[i] = stamps[i], s_w[i] = fh_w[i];
     __syncthreads();
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n_t) return;
     float* out = tables + ((size_t)b * (n_t + 1) + j) * 12;
+    // the reference-order correspondence kernels read the tables as [row][evaluation][12]: written here as well, when asked for
+    float* outT = tablesT ? tablesT + ((size_t)j * gridDim.y + b) * 12 : nullptr;
     if (j == n_t) {  // identity row for static points
         out[0] = 1, out[1] = 0, out[2] = 0, out[3] = 0, out[4] = 0, out[5] = 1, out[6] = 0, out[7] = 0, out[8] = 0, out[9] = 0, out[10] = 1, out[11] = 0;
+        if (outT)
+            for (int q = 0; q < 12; ++q) outT[q] = out[q];
         return;
     }
-    if (j > n_t) return;
     const double t = traj_time[j];
     // getInterpRotation: lower_bound over stamps[0 .. C-2]
     int right = 0;
@@ -265,15 +269,22 @@ __global__ __launch_bounds__(256) void k_window_pose_tables(const double* __rest
     out[0] = (float)R[0], out[1] = (float)R[1], out[2] = (float)R[2], out[3] = (float)tr[0];
     out[4] = (float)R[3], out[5] = (float)R[4], out[6] = (float)R[5], out[7] = (float)tr[1];
     out[8] = (float)R[6], out[9] = (float)R[7], out[10] = (float)R[8], out[11] = (float)tr[2];
+    if (outT) {
+        float4* o4 = reinterpret_cast<float4*>(outT);
+        o4[0] = make_float4(out[0], out[1], out[2], out[3]), o4[1] = make_float4(out[4], out[5], out[6], out[7]), o4[2] = make_float4(out[8], out[9], out[10], out[11]);
+    }
 }
 
-__global__ __launch_bounds__(256) void k_keyframe_pose_tables(const double* __restrict__ frames, int F, float* __restrict__ tables) {
+__global__ __launch_bounds__(256) void k_keyframe_pose_tables(const double* __restrict__ frames, int F, float* __restrict__ tables, float* __restrict__ tablesT) {
     const int b = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > F) return;
     float* out = tables + ((size_t)b * (F + 1) + k) * 12;
+    float* outT = tablesT ? tablesT + ((size_t)k * gridDim.y + b) * 12 : nullptr;
     if (k == F) {
         out[0] = 1, out[1] = 0, out[2] = 0, out[3] = 0, out[4] = 0, out[5] = 1, out[6] = 0, out[7] = 0, out[8] = 0, out[9] = 0, out[10] = 1, out[11] = 0;
+        if (outT)
+            for (int q = 0; q < 12; ++q) outT[q] = out[q];
         return;
     }
     const double* p = frames + ((size_t)b * F + k) * 6;
@@ -282,6 +293,8 @@ __global__ __launch_bounds__(256) void k_keyframe_pose_tables(const double* __re
     out[0] = (float)R[0], out[1] = (float)R[1], out[2] = (float)R[2], out[3] = (float)p[3];
     out[4] = (float)R[3], out[5] = (float)R[4], out[6] = (float)R[5], out[7] = (float)p[4];
     out[8] = (float)R[6], out[9] = (float)R[7], out[10] = (float)R[8], out[11] = (float)p[5];
+    if (outT)
+        for (int q = 0; q < 12; ++q) outT[q] = out[q];
 }
 
 __global__ __launch_bounds__(256) void k_detmath_eval(int fn, const double* __restrict__ x, const double* __restrict__ y, int64_t n, double* __restrict__ out) {
@@ -295,11 +308,11 @@ void launch_detmath_eval(int fn, const double* x, const double* y, int64_t n, do
 }
 
 void launch_window_pose_tables(const double* ctrl, const double* stamps, const double* fh_w, const double* traj_time, int B, int C, int n_t,
-                               float* tables, hipStream_t s) {
-    hipLaunchKernelGGL(k_window_pose_tables, dim3((n_t + 1 + 255) / 256, B), dim3(256), 0, s, ctrl, stamps, fh_w, traj_time, C, n_t, tables);
+                               float* tables, float* tablesT, hipStream_t s) {
+    hipLaunchKernelGGL(k_window_pose_tables, dim3((n_t + 1 + 255) / 256, B), dim3(256), 0, s, ctrl, stamps, fh_w, traj_time, C, n_t, tables, tablesT);
 }
-void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tables, hipStream_t s) {
-    hipLaunchKernelGGL(k_keyframe_pose_tables, dim3((F + 1 + 255) / 256, B), dim3(256), 0, s, frames, F, tables);
+void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tables, float* tablesT, hipStream_t s) {
+    hipLaunchKernelGGL(k_keyframe_pose_tables, dim3((F + 1 + 255) / 256, B), dim3(256), 0, s, frames, F, tables, tablesT);
 }
 
 // ------------------------------------------------------------------------------------------------------------
