@@ -235,7 +235,7 @@ def main():
             "roofline": {
                 "kernel": ("correspondence kernels k_residuals_tiles + k_residuals_big" if args.fast_sums else
                            "reference-order correspondence kernels (k_residuals_chain<8,true,64> + k_residuals_chain<4,false,32> + k_residuals_small, "
-                           "two streams, one HIP-event pair around the batch)") + ", B evaluations per launch",
+                           "three streams, one HIP-event pair around the batch)") + ", B evaluations per launch",
                 "bound": "hbm",
                 # the brief's figure: per-unit algorithmic bytes x units per launch / launch time
                 "achieved": round(achieved, 2),
