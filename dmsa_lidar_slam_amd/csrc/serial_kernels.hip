@@ -546,11 +546,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         __builtin_amdgcn_s_setprio(1);
     const int pw = wave - 1;
     const bool loader = pw == (kSepLoader ? kProducers : kProducers - 1);  // the wave that feeds the member ring
-#ifdef DMSA_ISOLATE_CHAINER
-    const bool works = (!kSepLoader || pw < kProducers) && (!kSepLoader || (wave & 3) != 0);  // waves 4, 8 share the chainer's SIMD: no work
-#else
     const bool works = !kSepLoader || pw < kProducers;
-#endif
     const int mps = 64 / Bs;                              // member PAIRS per step
     const int steps = (kChunk / 2 + mps - 1) / mps;       // steps per chunk
     const int ms = lane / Bs, pb = lane - ms * Bs;
@@ -563,17 +559,8 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     int jl_u[kMaxSteps];  // first member (even) of this lane's pair in step u (kChunk: none)
 #pragma unroll
     for (int u = 0; u < kMaxSteps; ++u) {
-#ifdef DMSA_ISOLATE_CHAINER
-        const int rank = kSepLoader ? pw - (pw >> 2) : pw, nwork = kSepLoader ? kProducers - kProducers / 4 : kProducers;  // w1..w3 -> 0..2, w5..w7 -> 3..5
-        const int t = rank + u * nwork, jl = 2 * (t * mps + ms);
-#else
         const int t = pw + u * kProducers, jl = 2 * (t * mps + ms);
-#endif
-#ifdef DMSA_NO_PRODUCE  // timing experiment: producers only keep the barriers (results are garbage)
-        jl_u[u] = kChunk;
-#else
         jl_u[u] = (works && t < steps && lane_on && jl < kChunk) ? jl : kChunk;
-#endif
     }
     // Members reach the producers through LDS: ONE wave issues ONE global_load_lds_dwordx4 per chunk (64 lanes x 16 B = the 64
     // members of a chunk, written lane-linear into a 4-slot ring) two phases ahead of its use.  No member ever sits in a
