@@ -1068,6 +1068,7 @@ int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
         }
         else
             lm_solve_lu(H.data(), g.data(), P, s.step_length_optim, step.data());
+        g_tl.mark("assemble+solve");
         bool anyNan = false;
         for (double v : step) anyNan = anyNan || std::isnan(v);
         if (anyNan) {  // :116-122 setPoseParameters(paramVec); break
@@ -1114,7 +1115,7 @@ int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
                 host_eval(ctx, globs, extra);
             }
         }
-        g_tl.mark("solve+trial chains");
+        g_tl.mark("trial chains");
         CHK(build_tables(ctx, 9, globs));
         CHK(run_residuals(ctx, 9, &extra));
         double* errs = ctx->h_rb->errs;  // pinned
