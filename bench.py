@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--az", type=int, default=1024)
     ap.add_argument("--static", type=int, default=200_000)
     ap.add_argument("--frames", type=int, default=32, help="keyframes per rank for --workload keyframes")
-    ap.add_argument("--cpu-iters", type=int, default=6, help="oracle iterations timed for cpu_baseline (0 disables)")
+    ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations timed for cpu_baseline (0 disables)")
     ap.add_argument("--keyframe-steps", type=int, default=10, help="iterations of the secondary sharded-keyframe-pass measurement (0 disables)")
     ap.add_argument("--fast-sums", action="store_true", help="time the opt-in wave-parallel sums (DMSA_FLAG_FAST_SUMS) instead of the default path")
     ap.add_argument("--mirror", action="store_true", help="accepted and ignored: the reference-order sums are the default path")
