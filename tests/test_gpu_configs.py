@@ -376,3 +376,30 @@ def test_parallel_second_pass_of_the_chain_tiers(hip, orc, full_window, monkeypa
             else:
                 assert fallbacks == 0  # only the live test counts
             opt.close()
+
+
+def test_window_beyond_two_million_points(hip, orc):
+    """2.7 M points: more 1024-point blocks than the lattice kernel keeps in LDS (2048; the rest of the block bounds are read from
+    global memory), 330 sort tiles per level.  Voxel structure and Gaussian sets bit-exact against the oracle."""
+    prob = synth.window_problem(seed=5, scans=10, rings=128, az_steps=2048, num_static=100_000)
+    s = DmsaOptimSettings.sliding_window()
+    n = prob.localPoints.shape[0] + prob.staticPoints.shape[0]
+    assert n > 2048 * 1024
+    table, _ = orc.window_pose_table(prob)
+    g = orc.transform_points(table, prob.localPoints, prob.tformIdPerPoint)
+    glob = np.concatenate([g, prob.staticPoints]).astype(np.float32)
+    ref = orc.Gaussians(glob, np.concatenate([prob.ringIds, prob.staticRingIds]), prob.minGridSize, s)
+    opt = hip.DmsaOptimizer()
+    opt.upload(prob)
+    opt.poseTables(prob.getPoseParameters(), download=False)
+    opt.updateGlobalPoints(0, download=False)
+    assert opt.buildGaussians(s) == (ref.M, ref.Mm)
+    for level, f in ((0, s.grid_size_1_factor), (1, s.grid_size_2_factor)):
+        info, code, key, order = opt.voxelLevel(level)
+        info_r, code_r, key_r, order_r = orc.voxelize(glob, float(np.float32(f) * np.float32(prob.minGridSize)))
+        assert (info.depth, info.num_events, info.num_leaves) == (info_r.depth, info_r.num_events, info_r.num_leaves)
+        assert np.array_equal(code, code_r) and np.array_equal(order, order_r)
+    seg, memb, info12, w = opt.gaussians()
+    assert np.array_equal(seg, ref.seg_offset) and np.array_equal(memb, ref.members)
+    assert np.array_equal(info12, ref.info) and np.array_equal(w, ref.weights)
+    opt.close()
