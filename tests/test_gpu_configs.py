@@ -403,3 +403,34 @@ def test_window_beyond_two_million_points(hip, orc):
     assert np.array_equal(seg, ref.seg_offset) and np.array_equal(memb, ref.members)
     assert np.array_equal(info12, ref.info) and np.array_equal(w, ref.weights)
     opt.close()
+
+
+@pytest.mark.parametrize("compress", ["1", "0"])
+def test_fine_grid_and_full_width_codes(hip, orc, compress, monkeypatch):
+    """minGridSize = 0.012 m: trees of depth >= 11.  With DMSA_KEY_COMPRESS=0 the leaf codes keep all 3 x depth bits and no longer fit 32
+    bits -- the 64-bit code path (library sort, 64-bit leaf segmentation), which is also what a mis-predicted code range falls back to.
+    Same structure, bit for bit, either way."""
+    monkeypatch.setenv("DMSA_KEY_COMPRESS", compress)
+    prob = synth.window_problem(seed=21, scans=3, rings=64, az_steps=512, num_static=20_000)
+    prob.minGridSize = 0.012
+    s = DmsaOptimSettings.sliding_window(num_iter=2)
+    table, _ = orc.window_pose_table(prob)
+    g = orc.transform_points(table, prob.localPoints, prob.tformIdPerPoint)
+    glob = np.concatenate([g, prob.staticPoints]).astype(np.float32)
+    ref = orc.Gaussians(glob, np.concatenate([prob.ringIds, prob.staticRingIds]), prob.minGridSize, s)
+    opt = hip.DmsaOptimizer()
+    opt.upload(prob)
+    opt.poseTables(prob.getPoseParameters(), download=False)
+    opt.updateGlobalPoints(0, download=False)
+    assert opt.buildGaussians(s) == (ref.M, ref.Mm)
+    info0 = opt.voxelLevel(0)[0]
+    assert info0.depth >= 11  # 3 x 11 bits + the marker of non-finite points + the level tag: beyond 32 bits when uncompressed
+    for level, f in ((0, s.grid_size_1_factor), (1, s.grid_size_2_factor)):
+        info, code, key, order = opt.voxelLevel(level)
+        info_r, code_r, key_r, order_r = orc.voxelize(glob, float(np.float32(f) * np.float32(prob.minGridSize)))
+        assert info.depth == info_r.depth and info.num_leaves == info_r.num_leaves
+        assert np.array_equal(order, order_r)
+    seg, memb, info12, w = opt.gaussians()
+    assert np.array_equal(seg, ref.seg_offset) and np.array_equal(memb, ref.members) and np.array_equal(info12, ref.info)
+    opt.close()
+    _parity_run(hip, orc, prob, s)
