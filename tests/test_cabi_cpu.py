@@ -77,7 +77,7 @@ def test_product_never_imports_oracle():
                 assert "oracle_py" not in txt and "dmsa_oracle" not in txt and "libdmsa_oracle" not in txt, f
 
 
-@pytest.mark.parametrize("P", [12, 30, 96, 186])
+@pytest.mark.parametrize("P", [12, 30, 63, 64, 65, 96, 186])
 def test_host_lm_solve_equals_the_oracle_step_for_any_thread_count(lib, orc, P):
     """DmsaOptimizer.h:110-113 on the host side of the product: the explicit inverse by Gauss-Jordan, rows of a pivot step spread
     over worker threads for P >= 64 (the keyframe pass: 60 % of an iteration before).  Bit-identical to the oracle's lm_step and
