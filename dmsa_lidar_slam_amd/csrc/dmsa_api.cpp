@@ -728,23 +728,30 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     int fit_launched[3] = {0, 0, 0}, finish_launched = 0;
     auto launch_fit = [&](const int first[3], const int tasks[3], int finish_gauss) -> int {
         ScopedTimer tm(ctx, T_FIT);
-        static const bool fit2 = std::getenv("DMSA_FIT_STREAMS") == nullptr || std::atoi(std::getenv("DMSA_FIT_STREAMS")) != 1;
-        const bool two = fit2 && ctx->dual_stream && (tasks[1] > 0 || tasks[2] > 0);
-        if (two) {
-            HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
-            HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        }
-        hipStream_t s2 = two ? ctx->stream2 : ctx->stream;
-        launch_gauss_fit_tree(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, 0, first[0], tasks[0],
-                              ctx->d_fit_sums.as<double>(), ctx->stream);
-        launch_gauss_fit_tree(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, 1, first[1], tasks[1],
-                              ctx->d_fit_sums.as<double>(), s2);
-        launch_gauss_fit_tree(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, 2, first[2], tasks[2],
-                              ctx->d_fit_sums.as<double>(), s2);
-        launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), true, ctx->stream);
-        if (two) {  // (the weights on a third stream: measured 2 % slower per iteration -- a cross-stream wait costs more than the 19 us kernel)
-            HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        static const bool merged_fit = std::getenv("DMSA_FIT_MERGED") == nullptr || std::atoi(std::getenv("DMSA_FIT_MERGED")) != 0;
+        if (merged_fit) {
+            // one launch for the three size classes and the rebalancing weights: no fork to a second stream, no join (DMSA_FIT_MERGED=0: the
+            // classes as three kernels on two streams, the weights behind the long class)
+            launch_gauss_fit_all(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, first, tasks,
+                                 ctx->d_fit_sums.as<double>(), counts, ctx->d_info12.as<float>(), true, ctx->stream);
+        } else {
+            const bool two = ctx->dual_stream && (tasks[1] > 0 || tasks[2] > 0);
+            if (two) {
+                HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+                HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            }
+            hipStream_t s2 = two ? ctx->stream2 : ctx->stream;
+            launch_gauss_fit_tree(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, 0, first[0], tasks[0],
+                                  ctx->d_fit_sums.as<double>(), ctx->stream);
+            launch_gauss_fit_tree(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, 1, first[1], tasks[1],
+                                  ctx->d_fit_sums.as<double>(), s2);
+            launch_gauss_fit_tree(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, 2, first[2], tasks[2],
+                                  ctx->d_fit_sums.as<double>(), s2);
+            launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), true, ctx->stream);
+            if (two) {
+                HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+                HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            }
         }
         launch_gauss_fit_finish(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_fit_sums.as<double>(), finish_gauss, ctx->d_info12.as<float>(), ctx->stream);
         HIPCHK(hipGetLastError());

@@ -134,6 +134,9 @@ void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t
 // sums per Gaussian; launch_gauss_fit_finish turns them into information matrices (max_gauss >= M threads).
 void launch_gauss_fit_tree(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, int cls,
                            int task0, int tasks, double* sums, hipStream_t s);
+// the three classes and (with_weights) the rebalancing weights in one launch; tasks[c] Gaussians of class c starting at first[c] within the class
+void launch_gauss_fit_all(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, const int first[3],
+                          const int tasks[3], double* sums, GaussCounts* counts, float* info12, bool with_weights, hipStream_t s);
 void launch_gauss_fit_finish(const int32_t* seg_off, const GaussCounts* counts, const double* sums, int max_gauss, float* info12, hipStream_t s);
 // streaming correspondence kernel of the opt-in fast sums (fallback of the tiled kernels)
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,

@@ -1449,6 +1449,117 @@ __global__ __launch_bounds__(256) void k_gauss_fit_finish(const int32_t* __restr
         if (i != 9) dst[i] = o[i];  // slot 9 is the rebalancing weight (k_size_classes / k_rebalancing_weights write it)
 }
 int fit_small_max_blocks() { return 4; }  // short class: Gaussians up to serial_small_threshold() <= 256 members
+// All three classes -- and the rebalancing weights -- in ONE launch of 1024-thread workgroups: a workgroup is one long Gaussian (16 waves),
+// four middle ones (4 waves each) or sixteen short ones (1 wave each); the last workgroup computes the weights.  Same block sums in the
+// same order as k_gauss_fit_tree; what changes is that nothing has to be forked to a second stream and joined again (a cross-stream
+// dependency costs ~15 us each way on this GPU, scripts/microbench/graph_edge.hip), and the weights no longer sit behind the long fit.
+template <int kFitWaves, int kMaxBlk>
+__device__ __forceinline__ void fit_tree_group(const float4* __restrict__ memb_local, const int32_t* __restrict__ seg_off, const float4* __restrict__ table0,
+                                               int g /* -1: no Gaussian for this group */, int gtid, double (*s_blk)[6] /* [kMaxBlk] */, double* s_tot /* [6] */,
+                                               float* s_mean /* [3] */, int* s_rounds, double* __restrict__ sums) {
+    const int b = g >= 0 ? seg_off[g] : 0, n = g >= 0 ? seg_off[g + 1] - b : 0, nblk = (n + kSumBlock - 1) / kSumBlock;
+    const int wave = gtid >> 6, lane = gtid & 63;
+    auto global_point = [&](int j) {
+        const float4 p = memb_local[b + j];
+        const int row = __float_as_int(p.w);
+        return apply_row3(table0[3 * row], table0[3 * row + 1], table0[3 * row + 2], p.x, p.y, p.z);
+    };
+    // the groups of a workgroup meet at the same barriers: everybody runs as many super-rounds as the group with the most blocks
+    if (gtid == 0) atomicMax(s_rounds, (nblk + kMaxBlk - 1) / kMaxBlk);
+    if (gtid < 6) s_tot[gtid] = 0.0;
+    __syncthreads();
+    const int rounds = *s_rounds;
+    for (int r = 0; r < rounds; ++r) {  // pass 1: sums of x, y, z
+        const int sb = r * kMaxBlk, end = min(nblk, sb + kMaxBlk);
+        for (int blk = sb + wave; blk < end; blk += kFitWaves) {
+            const int j = blk * kSumBlock + lane;
+            double x = 0.0, y = 0.0, z = 0.0;
+            if (j < n) {
+                const float3 q = global_point(j);
+                x = (double)q.x, y = (double)q.y, z = (double)q.z;
+            }
+            x = wave_allsum(x), y = wave_allsum(y), z = wave_allsum(z);
+            if (lane == 0) s_blk[blk - sb][0] = x, s_blk[blk - sb][1] = y, s_blk[blk - sb][2] = z;
+        }
+        __syncthreads();
+        if (gtid < 3) {
+            double tot = s_tot[gtid];
+            for (int t = 0; t < end - sb; ++t) tot += s_blk[t][gtid];
+            s_tot[gtid] = tot;
+        }
+        __syncthreads();
+    }
+    if (gtid < 3) s_mean[gtid] = (float)(s_tot[gtid] / (double)n);
+    __syncthreads();
+    const float mx = s_mean[0], my = s_mean[1], mz = s_mean[2];
+    if (gtid < 6) s_tot[gtid] = 0.0;
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {  // pass 2: xx xy xz yy yz zz of the centred members
+        const int sb = r * kMaxBlk, end = min(nblk, sb + kMaxBlk);
+        for (int blk = sb + wave; blk < end; blk += kFitWaves) {
+            const int j = blk * kSumBlock + lane;
+            double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (j < n) {
+                const float3 q = global_point(j);
+                const float cx = q.x - mx, cy = q.y - my, cz = q.z - mz;
+                t[0] = (double)cx * (double)cx, t[1] = (double)cx * (double)cy, t[2] = (double)cx * (double)cz;
+                t[3] = (double)cy * (double)cy, t[4] = (double)cy * (double)cz, t[5] = (double)cz * (double)cz;
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double v = wave_allsum(t[c]);
+                if (lane == 0) s_blk[blk - sb][c] = v;
+            }
+        }
+        __syncthreads();
+        if (gtid < 6) {
+            double tot = s_tot[gtid];
+            for (int t = 0; t < end - sb; ++t) tot += s_blk[t][gtid];
+            s_tot[gtid] = tot;
+        }
+        __syncthreads();
+    }
+    if (g >= 0 && gtid < 6) sums[(size_t)g * 6 + gtid] = s_tot[gtid];
+}
+__device__ void rebalancing_weights_mirror_body(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts, float* __restrict__ info12, double* s_slot,
+                                                double* s_tot, float* s_mean);
+struct FitLaunch {
+    int first[3], tasks[3];  // per class: index of the first Gaussian of the class covered by this launch, number covered
+    int wg[3];               // workgroups per class
+};
+__global__ __launch_bounds__(1024) void k_gauss_fit_all(const float4* __restrict__ memb_local, const int32_t* __restrict__ seg_off, const float4* __restrict__ table0,
+                                                        const uint32_t* __restrict__ order, const int32_t* __restrict__ sc, FitLaunch fl, double* __restrict__ sums,
+                                                        GaussCounts* __restrict__ counts, float* __restrict__ info12) {
+    __shared__ double s_blk[256][6];  // class 0: [256][6]; class 1: 4 x [64][6]; class 2: 16 x [4][6]
+    __shared__ double s_tot[16][6];
+    __shared__ float s_mean[16][3];
+    __shared__ int s_rounds;
+    if (threadIdx.x == 0) s_rounds = 0;
+    __syncthreads();
+    const int tid = threadIdx.x;
+    int bx = blockIdx.x;
+    auto pick = [&](int cls, int task) {
+        int index;
+        return task < fl.tasks[cls] && fit_task(sc, cls, fl.first[cls] + task, index) ? (int)order[index] : -1;
+    };
+    if (bx < fl.wg[0]) {
+        fit_tree_group<16, 256>(memb_local, seg_off, table0, pick(0, bx), tid, s_blk, s_tot[0], s_mean[0], &s_rounds, sums);
+        return;
+    }
+    bx -= fl.wg[0];
+    if (bx < fl.wg[1]) {
+        const int grp = tid >> 8;
+        fit_tree_group<4, 64>(memb_local, seg_off, table0, pick(1, bx * 4 + grp), tid & 255, s_blk + grp * 64, s_tot[grp], s_mean[grp], &s_rounds, sums);
+        return;
+    }
+    bx -= fl.wg[1];
+    if (bx < fl.wg[2]) {
+        const int grp = tid >> 6;
+        fit_tree_group<1, 4>(memb_local, seg_off, table0, pick(2, bx * 16 + grp), tid & 63, s_blk + grp * 4, s_tot[grp], s_mean[grp], &s_rounds, sums);
+        return;
+    }
+    rebalancing_weights_mirror_body(seg_off, counts, info12, &s_blk[0][0], &s_tot[0][0], &s_mean[0][0]);
+}
 void launch_gauss_fit_tree(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, int cls,
                            int task0, int tasks, double* sums, hipStream_t s) {
     if (tasks <= 0) return;
@@ -1459,6 +1570,15 @@ void launch_gauss_fit_tree(const float4* memb_local, const int32_t* seg_off, con
         hipLaunchKernelGGL((k_gauss_fit_tree<4, 64>), dim3(tasks), dim3(256), 0, s, memb_local, seg_off, t0, order, sc, cls, task0, sums);
     else
         hipLaunchKernelGGL((k_gauss_fit_tree<1, 4>), dim3(tasks), dim3(64), 0, s, memb_local, seg_off, t0, order, sc, cls, task0, sums);
+}
+void launch_gauss_fit_all(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, const int first[3],
+                          const int tasks[3], double* sums, GaussCounts* counts, float* info12, bool with_weights, hipStream_t s) {
+    FitLaunch fl;
+    for (int c = 0; c < 3; ++c) fl.first[c] = first[c], fl.tasks[c] = tasks[c] > 0 ? tasks[c] : 0;
+    fl.wg[0] = fl.tasks[0], fl.wg[1] = (fl.tasks[1] + 3) / 4, fl.wg[2] = (fl.tasks[2] + 15) / 16;
+    const int grid = fl.wg[0] + fl.wg[1] + fl.wg[2] + (with_weights ? 1 : 0);
+    if (grid <= 0) return;
+    hipLaunchKernelGGL(k_gauss_fit_all, dim3(grid), dim3(1024), 0, s, memb_local, seg_off, reinterpret_cast<const float4*>(table0), order, sc, fl, sums, counts, info12);
 }
 void launch_gauss_fit_finish(const int32_t* seg_off, const GaussCounts* counts, const double* sums, int max_gauss, float* info12, hipStream_t s) {
     if (max_gauss > 0) hipLaunchKernelGGL(k_gauss_fit_finish, dim3((max_gauss + 255) / 256), dim3(256), 0, s, seg_off, counts, sums, info12);
@@ -1495,15 +1615,12 @@ __global__ __launch_bounds__(1024) void k_rebalancing_weights(const int32_t* __r
 }
 // default path: VectorXf::mean() (Gaussians.h:176) in the oracle's order -- blocks of 64 weights reduced by the pairwise tree, block
 // sums added in order: the 16 waves take 16 blocks per round, thread 0 adds the round's sums
-__global__ __launch_bounds__(1024) void k_rebalancing_weights_mirror(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts,
-                                                                     float* __restrict__ info12) {
-    __shared__ double s_slot[16];
-    __shared__ double s_tot;
-    __shared__ float s_mean;
+__device__ void rebalancing_weights_mirror_body(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts, float* __restrict__ info12, double* s_slot /* [16] */,
+                                                double* s_tot /* [1] */, float* s_mean /* [1] */) {
     const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
     const int nblk = (M + kSumBlock - 1) / kSumBlock;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) s_tot = 0.0;
+    if (threadIdx.x == 0) *s_tot = 0.0;
     __syncthreads();
     for (int base = 0; base < nblk; base += 16) {
         const int blk = base + wave;
@@ -1515,20 +1632,27 @@ __global__ __launch_bounds__(1024) void k_rebalancing_weights_mirror(const int32
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            double tot = s_tot;
+            double tot = *s_tot;
             const int cnt = min(16, nblk - base);
             for (int t = 0; t < cnt; ++t) tot += s_slot[t];
-            s_tot = tot;
+            *s_tot = tot;
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        s_mean = (float)(s_tot / (double)M);
-        counts->weight_mean = s_mean;
+        *s_mean = (float)(*s_tot / (double)M);
+        counts->weight_mean = *s_mean;
     }
     __syncthreads();
-    const float mean = s_mean;
+    const float mean = *s_mean;
     for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = ((1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f) / mean;
+}
+__global__ __launch_bounds__(1024) void k_rebalancing_weights_mirror(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts,
+                                                                     float* __restrict__ info12) {
+    __shared__ double s_slot[16];
+    __shared__ double s_tot;
+    __shared__ float s_mean;
+    rebalancing_weights_mirror_body(seg_off, counts, info12, s_slot, &s_tot, &s_mean);
 }
 void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, bool mirror, hipStream_t s) {
     if (mirror)
