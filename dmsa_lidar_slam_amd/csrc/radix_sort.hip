@@ -52,12 +52,13 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
     // counter.  Every thread walks its own 32 consecutive keys and counts RUNS of equal digits in registers; one LDS atomic per run.
     const size_t base = (size_t)blockIdx.x * (256 * kHistItems) + (size_t)tid * kHistItems;
     uint32_t prev[kMaxPasses] = {0, 0, 0, 0}, run[kMaxPasses] = {0, 0, 0, 0};
+    const bool aligned16 = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;  // a view into a larger array (level 1 behind level 0) may not be
     if (base < n) {
         const size_t m = n - base < (size_t)kHistItems ? n - base : (size_t)kHistItems;
         for (size_t k4 = 0; k4 < m; k4 += 4) {
             uint32_t kk[4];
-            if (k4 + 4 <= m) {
-                const uint4 v = *reinterpret_cast<const uint4*>(keys + base + k4);  // base is a multiple of 32 keys: 16-byte aligned
+            if (k4 + 4 <= m && aligned16) {
+                const uint4 v = *reinterpret_cast<const uint4*>(keys + base + k4);  // base is a multiple of 32 keys
                 kk[0] = v.x, kk[1] = v.y, kk[2] = v.z, kk[3] = v.w;
             } else {
                 for (int u = 0; u < 4; ++u) kk[u] = k4 + u < m ? keys[base + k4 + u] : 0u;

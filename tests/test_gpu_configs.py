@@ -434,3 +434,12 @@ def test_fine_grid_and_full_width_codes(hip, orc, compress, monkeypatch):
     assert np.array_equal(seg, ref.seg_offset) and np.array_equal(memb, ref.members) and np.array_equal(info12, ref.info)
     opt.close()
     _parity_run(hip, orc, prob, s)
+
+
+def test_separate_level_sorts_on_an_odd_point_count(hip, orc, monkeypatch):
+    """DMSA_MERGE_SORT=0 sorts the two resolutions separately, as large windows do; with an odd point count the level-1 arrays start at an
+    address that is only 4-byte aligned (views into the shared key / index arrays)."""
+    monkeypatch.setenv("DMSA_MERGE_SORT", "0")
+    prob = synth.window_problem(seed=23, scans=3, rings=32, az_steps=256, num_static=5001)
+    assert (prob.localPoints.shape[0] + prob.staticPoints.shape[0]) % 2 == 1
+    _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=3))
