@@ -151,7 +151,7 @@ struct dmsa_ctx {
     bool tables_pending = false;  // the current batch's pose tables were enqueued on stream2 (ev_tables marks their end)
     int tablesT_batch = 0;        // d_tablesT holds the transposed tables of a batch of this size (0: stale)
     bool serial_three_streams = true;
-    hipEvent_t ev_fork = nullptr, ev_scan0 = nullptr, ev_join = nullptr, ev_counts = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_scan0 = nullptr /* end of the size classes: the read-back stream waits for it */, ev_join = nullptr, ev_counts = nullptr;
     bool dual_stream = true;  // DMSA_DUAL_STREAM=0: both levels on `stream`
     std::string err;
 
@@ -677,7 +677,6 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         for (int l = 0; l < 2; ++l) {
             if (!lvl_on[l]) continue;
             CHK(stage_leaves(l));
-            if (l == 0 && two) HIPCHK(hipEventRecord(ctx->ev_scan0, ctx->stream));  // level-0 totals are final
         }
         // Both gathers on the first stream (level 1 appends behind level 0's totals anyway): the level-1 chain ends with its leaf scan,
         // long before level 0's gather is through, so the wait below finds its event signalled -- a join at the END of a stream costs
