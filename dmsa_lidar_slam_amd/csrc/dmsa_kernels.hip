@@ -588,7 +588,7 @@ __device__ __forceinline__ uint64_t spread3(uint32_t v) {  // 21 bits -> every t
 template <typename KeyT>  // uint32_t when the leaf code + invalid bit fit 32 bits (tree depth <= 10), else uint64_t
 __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ global, int64_t n, LatticeTable* __restrict__ table, double res,
                                                     KeyT* __restrict__ code, uint32_t* __restrict__ idx, uint64_t code_or, SortHeader* __restrict__ sort_header,
-                                                    uint32_t* __restrict__ sort_state, size_t sort_state_words, int sort_passes) {
+                                                    uint32_t* __restrict__ sort_state, size_t sort_state_words, int sort_passes, uint32_t sort_last_mask) {
     __shared__ LatticeTable t;
     __shared__ uint32_t s_h[kSortMaxPasses][kSortBins];
     const bool counting = sort_header != nullptr && sizeof(KeyT) == 4;  // the sort that follows takes its digit histograms from here
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void k_voxel_keys(const float4* __restrict__ g
         }
         code[i] = (KeyT)c;
         idx[i] = (uint32_t)i;
-        if (counting) sort_hist_add(s_h, sort_passes, (uint32_t)c, true);
+        if (counting) sort_hist_add(s_h, sort_passes, sort_last_mask, (uint32_t)c, true);
     }
     if (counting) {
         __syncthreads();
@@ -658,10 +658,10 @@ void launch_voxel_keys(const float4* global, int64_t n, LatticeTable* table, dou
     SortHeader* h = sort && key32 ? sort->header : nullptr;
     if (key32)
         hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint32_t*)code, idx, code_or, h,
-                           h ? sort->tile_state : nullptr, h ? sort->state_words : (size_t)0, h ? sort->passes : 0);
+                           h ? sort->tile_state : nullptr, h ? sort->state_words : (size_t)0, h ? sort->passes : 0, h ? sort->last_mask : 255u);
     else
         hipLaunchKernelGGL(k_voxel_keys<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, global, n, table, res, (uint64_t*)code, idx, code_or,
-                           (SortHeader*)nullptr, (uint32_t*)nullptr, (size_t)0, 0);
+                           (SortHeader*)nullptr, (uint32_t*)nullptr, (size_t)0, 0, 255u);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_sort_zero(SortHeader* h) {
     for (unsigned i = threadIdx.x; i < sizeof(SortHeader) / 4; i += 256) w[i] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ keys, size_t n, int passes, SortHeader* __restrict__ h,
+__global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ keys, size_t n, int passes, uint32_t last_mask, SortHeader* __restrict__ h,
                                                    uint32_t* __restrict__ tile_state, size_t state_words) {
     __shared__ uint32_t s_h[kMaxPasses][kBins];
     const int tid = threadIdx.x;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
 #pragma unroll
                     for (int p = 0; p < kMaxPasses; ++p) {
                         if (p < passes) {
-                            const uint32_t d = (kk[u] >> (8 * p)) & 255u;
+                            const uint32_t d = sort_digit(kk[u], p, passes, last_mask);
                             if (d == prev[p]) {
                                 ++run[p];
                             } else {
@@ -116,7 +116,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
 }
 
 __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int pass, int shift,
+                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int pass, int shift, uint32_t digit_mask,
                                                             SortHeader* __restrict__ h, uint32_t* __restrict__ tile_state /* [tiles][256] of this pass */) {
     __shared__ uint32_t s_cnt[kSortWaves][kBins];  // per wave and digit: running count while ranking, then the wave's offset inside the digit
     __shared__ uint32_t s_base[kBins];              // where the digit's run of this tile starts in the output
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint32_t* __re
     for (int k = 0; k < kItems; ++k) {
         const size_t i = base + (size_t)(wave * kItems + k) * 64 + lane;
         const bool valid = i < n;
-        const uint32_t d = (key[k] >> shift) & 255u;
+        const uint32_t d = (key[k] >> shift) & digit_mask;
         uint64_t peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint32_t* __re
     for (int k = 0; k < kItems; ++k) {
         const size_t i = base + (size_t)(wave * kItems + k) * 64 + lane;
         if (i < n) {
-            const uint32_t d = (key[k] >> shift) & 255u;
+            const uint32_t d = (key[k] >> shift) & digit_mask;
             const uint32_t lpos = s_excl[d] + s_cnt[wave][d] + rank[k];
             s_keys[lpos] = key[k], s_vals[lpos] = val[k];
         }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint32_t* __re
 #pragma unroll 4
     for (uint32_t i = tid; i < in_tile; i += kSortThreads) {
         const uint32_t kk = s_keys[i];
-        const uint32_t d = (kk >> shift) & 255u;
+        const uint32_t d = (kk >> shift) & digit_mask;
         const size_t pos = (size_t)s_base[d] + (i - s_excl[d]);
         keys_out[pos] = kk, vals_out[pos] = s_vals[i];
     }
@@ -250,6 +250,9 @@ SortPlan sort_pairs_u32_plan(void* temp, size_t n, unsigned end_bit) {
     p.header = reinterpret_cast<SortHeader*>(w);
     p.tile_state = reinterpret_cast<uint32_t*>(w + align_up(sizeof(SortHeader), 256));
     p.passes = passes;
+    // stable on the key bits [0, end_bit): whatever lies above takes no part (rocPRIM's begin_bit / end_bit semantics)
+    const unsigned top = end_bit == 0 ? 0u : end_bit - 8u * (unsigned)(passes - 1);
+    p.last_mask = top >= 8u ? 255u : ((1u << top) - 1u);
     p.state_words = tiles * kBins * (size_t)(passes < kMaxPasses ? passes : kMaxPasses);
     return p;
 }
@@ -271,7 +274,7 @@ hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t
     if (!prepared) {  // otherwise the producer of the keys cleared the header and the look-back words and counted the digits
         hipLaunchKernelGGL(k_sort_zero, dim3(1), dim3(256), 0, stream, h);
         const unsigned hist_blocks = (unsigned)((n + 256 * kHistItems - 1) / (256 * kHistItems));
-        hipLaunchKernelGGL(k_sort_hist, dim3(hist_blocks), dim3(256), 0, stream, keys_in, n, passes, h, state, plan.state_words);
+        hipLaunchKernelGGL(k_sort_hist, dim3(hist_blocks), dim3(256), 0, stream, keys_in, n, passes, plan.last_mask, h, state, plan.state_words);
     }
     // ping-pong so that the last pass writes the caller's output arrays
     const uint32_t* kin = keys_in;
@@ -280,7 +283,8 @@ hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t
         const bool to_out = ((passes - 1 - p) & 1) == 0;
         uint32_t* kout = to_out ? keys_out : keys_tmp;
         uint32_t* vout = to_out ? vals_out : vals_tmp;
-        hipLaunchKernelGGL(k_sort_pass, dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, p, 8 * p, h, state + (size_t)p * tiles * kBins);
+        hipLaunchKernelGGL(k_sort_pass, dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, p, 8 * p, p == passes - 1 ? plan.last_mask : 255u, h,
+                           state + (size_t)p * tiles * kBins);
         kin = kout, vin = vout;
     }
     return hipGetLastError();

@@ -23,13 +23,18 @@ struct SortPlan {
     uint32_t* tile_state;  // look-back words of all passes
     size_t state_words;
     int passes;
+    uint32_t last_mask;  // digit mask of the LAST pass: key bits at or above end_bit take no part in the sort (255 when end_bit is a multiple of 8)
 };
 SortPlan sort_pairs_u32_plan(void* temp, size_t n, unsigned end_bit);
 
 #ifdef __HIPCC__
+// digit of pass p: the last pass only looks at the key bits below the sort's end bit
+__device__ __forceinline__ uint32_t sort_digit(uint32_t key, int p, int passes, uint32_t last_mask) {
+    return (key >> (8 * p)) & (p == passes - 1 ? last_mask : 255u);
+}
 // One key of the calling lane into the workgroup's LDS histograms.  Leaf codes of neighbouring points share their upper digits: when
 // all active lanes of the wave hold the same digit, one lane adds the whole count.
-__device__ __forceinline__ void sort_hist_add(uint32_t (*s_h)[kSortBins], int passes, uint32_t key, bool valid) {
+__device__ __forceinline__ void sort_hist_add(uint32_t (*s_h)[kSortBins], int passes, uint32_t last_mask, uint32_t key, bool valid) {
     const unsigned long long vm = __ballot(valid);
     if (vm == 0ull) return;
     const int leader = __ffsll((long long)vm) - 1;
@@ -37,7 +42,7 @@ __device__ __forceinline__ void sort_hist_add(uint32_t (*s_h)[kSortBins], int pa
 #pragma unroll
     for (int p = 0; p < kSortMaxPasses; ++p) {
         if (p < passes) {
-            const uint32_t d = (key >> (8 * p)) & 255u;
+            const uint32_t d = sort_digit(key, p, passes, last_mask);
             const uint32_t d0 = (uint32_t)__shfl((int)d, leader);
             if (__ballot(valid && d != d0) == 0ull) {
                 if (lane == leader) atomicAdd(&s_h[p][d0], (uint32_t)__popcll(vm));

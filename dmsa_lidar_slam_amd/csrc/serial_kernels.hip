@@ -432,7 +432,9 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
             const int q = (int)(k >> 20) - 1023 - 23;           // every term is a multiple of 2^q
             const int pe = min(max(q + 53 + 1023, 0), 2046);
             const double limit = __hiloint2double(pe << 20, 0);  // 2^(q+53); 0 when that is below the normal range: the test fails
-            const bool exact = U * (1.0 + 0x1p-30) < limit && tree_mode == 1;  // NaN fails; U itself may be rounded: < n 2^-53 relative
+            // k == 0: some term was zero, negative or NaN -- the proof needs positive terms, so the chain runs (a non-positive U would
+            // otherwise slip under the 2^-993 the clamped exponent gives).  NaN fails; U itself may be rounded: < n 2^-53 relative
+            const bool exact = k != 0u && U * (1.0 + 0x1p-30) < limit && tree_mode == 1;
             if (exact)
                 E[(size_t)(b0 + lane) * ldE + g] = sqrt(fabs(U));
             else

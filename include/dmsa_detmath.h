@@ -25,7 +25,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define DMSA_DET_HD __host__ __device__ inline
 #else
 #define DMSA_DET_HD inline

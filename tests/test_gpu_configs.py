@@ -114,6 +114,36 @@ def test_config4_at_the_shard_size_bench_times(hip, orc):
     assert moved_t > 1e-5 or moved_r > 1e-5
 
 
+def test_more_gaussians_than_points(hip, orc):
+    """min_num_points_per_set = 0 with gauss_split: a leaf of three points (two ids on one face, a third point on the opposite face)
+    splits into a set of two and a set of one, at both resolutions -- M = 4n/3 > n.  Buffers indexed by Gaussian (size-class order, fit
+    sums) must hold that (they were sized n + 16); structure and one optimizeSet against the oracle."""
+    from dmsa_lidar_slam_amd.problems import MapManagement
+
+    rng = np.random.default_rng(3)
+    cells, g = 400, 0.05
+    centre = (rng.integers(-12, 12, (cells, 3)) * 40 * g + rng.uniform(-0.3 * g, 0.3 * g, (cells, 3))).astype(np.float32)
+    centre = np.unique(centre.round(3), axis=0)
+    cells = centre.shape[0]
+    pts = np.repeat(centre, 3, axis=0) + rng.uniform(-0.05 * g, 0.05 * g, (3 * cells, 3)).astype(np.float32)
+    nrm = np.tile(np.array([[0, 0, 1], [0, 0, 1], [0, 0, -1]], np.float32), (cells, 1))
+    ids = np.tile(np.array([1, 2, 3], np.int32), cells)
+    n = pts.shape[0]
+    frames = 3
+    off = np.array([0, n // 3, 2 * n // 3, n], np.int64)
+    rel_o = np.zeros((frames, 3))
+    rel_t = np.zeros((frames, 3))
+    rel_t[1:] = rng.normal(0, 1e-3, (frames - 1, 3))
+    prob = MapManagement(relOrientations=rel_o, relTranslations=rel_t, frameOffsets=off, localPoints=pts, localNormals=nrm, ringIds=ids, minGridSize=g)
+    s = DmsaOptimSettings.keyframe_map(num_iter=2)
+    s.min_num_points_per_set = 0
+    p_ref = prob.copy()
+    rep_ref, _, trace = orc.optimize_keyframes(p_ref, s)
+    assert trace[0]["M"] > n + 16, (trace[0]["M"], n)
+    rep, p_gpu = _parity_run(hip, orc, prob, s, window=False)
+    assert rep.num_gaussians > n + 16
+
+
 def test_keyframes_fast_path_equivalent(hip, orc):
     prob = synth.keyframe_problem(seed=3, frames=8, rings=24, az_steps=160, arc=0.5)
     s = DmsaOptimSettings.keyframe_map(num_iter=3)

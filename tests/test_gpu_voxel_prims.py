@@ -45,6 +45,13 @@ def test_radix_sort_is_the_stable_sort(hip, n):
     ks, vs = opt.sortPairs(keys, vals, 8)
     order = np.argsort(keys & 0xFF, kind="stable")
     assert np.array_equal(ks, keys[order]) and np.array_equal(vs, order.astype(np.uint32))
+    # ... also when end_bit is not a multiple of 8: the last pass must mask its digit (random bits above end_bit)
+    for bits in (1, 5, 11, 17, 21, 27, 31):
+        keys = _keys(rng, n, 32, "random")
+        ks, vs = opt.sortPairs(keys, vals, bits)
+        order = np.argsort(keys & np.uint32((1 << bits) - 1), kind="stable")
+        assert np.array_equal(ks, keys[order]), (n, bits)
+        assert np.array_equal(vs, order.astype(np.uint32)), (n, bits)
     opt.close()
 
 
