@@ -36,12 +36,33 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json")  # newest first
+
+
+def spawn_ranks(n, backend, visible):
+    """`python bench.py --gpus N` without a launcher: re-run this command as N ranks under torch.distributed.run (127.0.0.1 rendezvous
+    on a free port, one process per GPU) and pass its exit code on."""
+    import socket
+    import subprocess
+
+    if backend == "nccl" and visible < n:
+        print(f"bench.py: --gpus {n} over RCCL needs {n} visible GPUs, found {visible}", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without WORLD_SIZE: launching {' '.join(cmd)}", file=sys.stderr)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200, help="timed iterations (default: a timed region of >= 0.2 s)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="window", choices=["window", "keyframes"])
     ap.add_argument("--scans", type=int, default=10)
@@ -62,16 +83,22 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DMSA path has no CPU fallback")
     # DMSA_BENCH_BACKEND=gloo: rehearse the N > 1 control flow on fewer GPUs than ranks (ranks share devices, collectives on CPU tensors)
     backend = os.environ.get("DMSA_BENCH_BACKEND", "nccl")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU under torch.distributed.run) instead of
+        # quietly measuring one GPU
+        raise SystemExit(spawn_ranks(args.gpus, backend, torch.cuda.device_count()))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} visible GPUs, found {torch.cuda.device_count()} "
+                         "(DMSA_BENCH_BACKEND=gloo rehearses the control flow on fewer)")
     local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     coll_dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
@@ -80,6 +107,19 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+
+    # who runs where: every rank's (rank, device) pair and the world size the communicator really has
+    placement = [[rank, local_rank]]
+    coll_world = 1
+    if world > 1:
+        coll_world = dist.get_world_size()
+        me = torch.tensor([rank, local_rank], dtype=torch.int64, device=coll_dev)
+        got = [torch.empty_like(me) for _ in range(world)]
+        dist.all_gather(got, me)
+        placement = [[int(g[0]), int(g[1])] for g in got]
+        if rank == 0:
+            print(f"[bench] n_gpus={world} backend={backend} ({'RCCL' if backend == 'nccl' else backend}) collective world size={coll_world} "
+                  f"rank->device {placement}", file=sys.stderr)
 
     from dmsa_lidar_slam_amd import synth
     from dmsa_lidar_slam_amd.api import DmsaOptimizer
@@ -194,14 +234,18 @@ def main():
         bytes_per_launch = tm.residual_unit_bytes / launches            # per-unit figure x units per launch
         compulsory_per_launch = tm.residual_algorithmic_bytes / launches  # bytes(B): members read once per launch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
-                tj = json.load(f)
-            if tj.get("workload") == wl and tj.get("path") == ("fast_sums" if args.fast_sums else "default"):
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+        # HBM bytes per launch: PMC counters cannot be read from inside this process, so the figure comes from the committed rocprofv3
+        # --pmc passes of this same command (scripts/profile_round.sh -> profiles/rNN_traffic.json) and is labelled as such
+        traffic, traffic_source = None, None
+        for name in TRAFFIC_FILES:
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    tj = json.load(f)
+                if tj.get("workload") == wl and tj.get("path") == ("fast_sums" if args.fast_sums else "default"):
+                    traffic, traffic_source = tj.get("hbm_bytes_per_launch"), f"from_profiles: profiles/{name}"
+                    break
+            except Exception:
+                continue
         # fp32 vector-ALU view of the same launches: 48 flop per member and evaluation, none fusable into FMA
         flops = 48.0 * rep.num_memberships * evals
         valu_tflops = flops / (tm.residual_kernel_ms * 1e-3) / 1e12 if tm.residual_kernel_ms > 0 else 0.0
@@ -229,6 +273,8 @@ def main():
                 "memberships": int(rep.num_memberships),
                 "path": "opt-in fast sums (DMSA_FLAG_FAST_SUMS)" if args.fast_sums
                         else "default: reference-order sums, device pose tables (poses bit-identical to the CPU restatement)",
+                "rank_device": placement,
+                "collective": {"backend": "rccl" if backend == "nccl" else backend, "world_size": coll_world},
                 "sharding": ("single GPU" if world == 1 else "independent windows per rank + pose all-gather" if args.workload == "window"
                              else f"{world} keyframe neighbourhoods of one {total_frames}-frame map, one per GPU + pose all-gather"),
             },
@@ -247,6 +293,7 @@ def main():
                 # HBM bytes the PMC passes counted (profiles/r02_traffic.json), same launch time
                 "frac_counters": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and avg_ms > 0) else None,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "avg_launch_ms": round(avg_ms, 5),
                 "launches": int(tm.residual_launches),
                 "evaluations": int(tm.residual_evaluations),

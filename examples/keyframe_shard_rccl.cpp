@@ -92,6 +92,9 @@ int run_rank(int rank, int world, Rendezvous* rv, const KeyframeMap& full, int i
     CHECK(hipSetDevice(dev) == hipSuccess, "hipSetDevice");
     ncclComm_t comm;
     CHECK(ncclCommInitRank(&comm, world, id, rank) == ncclSuccess, "ncclCommInitRank");
+    int comm_ranks = 0;
+    CHECK(ncclCommCount(comm, &comm_ranks) == ncclSuccess && comm_ranks == world, "ncclCommCount");
+    if (rank == 0) std::printf("[rccl] ranks=%d visible_gpus=%d\n", comm_ranks, ndev);  // the world size the communicator really has
     hipStream_t stream;
     CHECK(hipStreamCreate(&stream) == hipSuccess, "hipStreamCreate");
 
