@@ -17,80 +17,6 @@
 
 namespace dmsa {
 
-Mat3 operator*(const Mat3& A, const Mat3& B) {
-    Mat3 C;
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) C(r, c) = A(r, 0) * B(0, c) + A(r, 1) * B(1, c) + A(r, 2) * B(2, c);
-    return C;
-}
-Vec3 operator*(const Mat3& A, Vec3 v) {
-    return {A(0, 0) * v.x + A(0, 1) * v.y + A(0, 2) * v.z, A(1, 0) * v.x + A(1, 1) * v.y + A(1, 2) * v.z,
-            A(2, 0) * v.x + A(2, 1) * v.y + A(2, 2) * v.z};
-}
-Mat3 transposed(const Mat3& A) {
-    Mat3 T;
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) T(r, c) = A(c, r);
-    return T;
-}
-
-// exp of a skew matrix in closed form (Rodrigues).  Identity below EPSILON_ROT = 1e-5 (helpers.h:18,53).
-Mat3 so3_exp(Vec3 w) {
-    const double theta = length(w);
-    if (theta < 0.00001) return Mat3::identity();
-    const double s = dmsa_det::det_sin(theta) / theta;  // the trigonometry of the pose-table path is include/dmsa_detmath.h on host AND device
-    const double sh = dmsa_det::det_sin(0.5 * theta);
-    const double c = 2.0 * sh * sh / (theta * theta);
-    const double t2 = theta * theta;
-    Mat3 R;
-    R(0, 0) = 1.0 + c * (w.x * w.x - t2);
-    R(1, 1) = 1.0 + c * (w.y * w.y - t2);
-    R(2, 2) = 1.0 + c * (w.z * w.z - t2);
-    R(0, 1) = c * w.x * w.y - s * w.z;
-    R(1, 0) = c * w.x * w.y + s * w.z;
-    R(0, 2) = c * w.x * w.z + s * w.y;
-    R(2, 0) = c * w.x * w.z - s * w.y;
-    R(1, 2) = c * w.y * w.z - s * w.x;
-    R(2, 1) = c * w.y * w.z + s * w.x;
-    return R;
-}
-
-// principal log of a rotation through its unit quaternion (largest-pivot extraction), angle in [0, pi].
-Vec3 so3_log(const Mat3& R) {
-    const double tr = R(0, 0) + R(1, 1) + R(2, 2);
-    double qw, qx, qy, qz;
-    if (tr > 0.0) {
-        const double s = std::sqrt(tr + 1.0) * 2.0;
-        qw = 0.25 * s;
-        qx = (R(2, 1) - R(1, 2)) / s;
-        qy = (R(0, 2) - R(2, 0)) / s;
-        qz = (R(1, 0) - R(0, 1)) / s;
-    } else if (R(0, 0) > R(1, 1) && R(0, 0) > R(2, 2)) {
-        const double s = std::sqrt(1.0 + R(0, 0) - R(1, 1) - R(2, 2)) * 2.0;
-        qw = (R(2, 1) - R(1, 2)) / s;
-        qx = 0.25 * s;
-        qy = (R(0, 1) + R(1, 0)) / s;
-        qz = (R(0, 2) + R(2, 0)) / s;
-    } else if (R(1, 1) > R(2, 2)) {
-        const double s = std::sqrt(1.0 + R(1, 1) - R(0, 0) - R(2, 2)) * 2.0;
-        qw = (R(0, 2) - R(2, 0)) / s;
-        qx = (R(0, 1) + R(1, 0)) / s;
-        qy = 0.25 * s;
-        qz = (R(1, 2) + R(2, 1)) / s;
-    } else {
-        const double s = std::sqrt(1.0 + R(2, 2) - R(0, 0) - R(1, 1)) * 2.0;
-        qw = (R(1, 0) - R(0, 1)) / s;
-        qx = (R(0, 2) + R(2, 0)) / s;
-        qy = (R(1, 2) + R(2, 1)) / s;
-        qz = 0.25 * s;
-    }
-    const double n = std::sqrt(qx * qx + qy * qy + qz * qz);
-    if (n == 0.0) return {0.0, 0.0, 0.0};
-    const double angle = 2.0 * std::atan2(n, std::fabs(qw));
-    const double k = angle / (qw < 0.0 ? -n : n);
-    return {qx * k, qy * k, qz * k};
-}
-
 namespace {
 struct Quat {
     double w, x, y, z;
@@ -134,28 +60,9 @@ void PoseChain::resize(int count) {
     glob_o.assign(3 * (size_t)n, 0.0), glob_t.assign(3 * (size_t)n, 0.0);
 }
 static inline Vec3 col(const std::vector<double>& m, int k) { return {m[3 * k], m[3 * k + 1], m[3 * k + 2]}; }
-static inline void set_col(std::vector<double>& m, int k, Vec3 v) { m[3 * k] = v.x, m[3 * k + 1] = v.y, m[3 * k + 2] = v.z; }
 
-void PoseChain::relative_to_global() {
-    Mat3 R = Mat3::identity();
-    Vec3 T{0, 0, 0};
-    for (int k = 0; k < n; ++k) {
-        T = T + R * col(rel_t, k);
-        set_col(glob_t, k, T);
-        R = R * so3_exp(col(rel_o, k));
-        set_col(glob_o, k, so3_log(R));
-    }
-}
-void PoseChain::global_to_relative() {
-    set_col(rel_o, 0, col(glob_o, 0));
-    set_col(rel_t, 0, col(glob_t, 0));
-    for (int k = n - 1; k > 0; --k) {
-        const Mat3 R1t = transposed(so3_exp(col(glob_o, k - 1)));
-        const Mat3 R2 = so3_exp(col(glob_o, k));
-        set_col(rel_o, k, so3_log(R1t * R2));
-        set_col(rel_t, k, R1t * (col(glob_t, k) - col(glob_t, k - 1)));
-    }
-}
+void PoseChain::relative_to_global() { chain_relative_to_global(n, rel_o.data(), rel_t.data(), glob_o.data(), glob_t.data()); }
+void PoseChain::global_to_relative() { chain_global_to_relative(n, glob_o.data(), glob_t.data(), rel_o.data(), rel_t.data()); }
 void PoseChain::get_params(double* p) const {
     std::copy(rel_o.begin() + 3, rel_o.end(), p);
     std::copy(rel_t.begin() + 3, rel_t.end(), p + 3 * (n - 1));
@@ -266,44 +173,19 @@ bool WindowHost::init(const dmsa_window_problem& p) {
     return true;
 }
 
+ImuConsts WindowHost::imu_consts() const {
+    ImuConsts c{};
+    c.use_imu = use_imu ? 1 : 0, c.dt_res = dt_res, c.balancing_imu = balancing_imu;
+    c.gravity[0] = gravity.x, c.gravity[1] = gravity.y, c.gravity[2] = gravity.z;
+    c.param_indices = param_indices.data(), c.preint_rot = preint_rot.data(), c.preint_pos = preint_pos.data(), c.preint_vel = preint_vel.data();
+    c.cov_inv = cov_inv.data();
+    return c;
+}
 void WindowHost::imu_rows(double* rows) {
     ctrl.global_to_relative();  // ContinuousTrajectory.h:606
-    const int C = ctrl.n;
-    std::vector<double> ax((size_t)C), ay((size_t)C), az((size_t)C);
-    for (int k = 0; k < C; ++k) ax[k] = ctrl.glob_t[3 * k], ay[k] = ctrl.glob_t[3 * k + 1], az[k] = ctrl.glob_t[3 * k + 2];
-    auto dense_t = [&](int j) { const double t = traj_time[(size_t)j]; return Vec3{fh.eval(ax.data(), t), fh.eval(ay.data(), t), fh.eval(az.data(), t)}; };
-    const double inv_dt = 1.0 / dt_res;
-    for (int k = 1; k < C; ++k) {
-        const Mat3 Rst = transposed(so3_exp(col(ctrl.glob_o, k - 1)));
-        const double delta_t = stamps[k] - stamps[k - 1];
-        const int i0 = param_indices[k - 1], i1 = param_indices[k];
-        const Vec3 v_start = inv_dt * (dense_t(i0 + 1) - dense_t(i0));
-        const Vec3 v_end = inv_dt * (dense_t(i1) - dense_t(i1 - 1));
-        const double half_dt2 = 0.5 * std::pow(delta_t, 2);
-        const Vec3 pk = col(ctrl.glob_t, k), pk1 = col(ctrl.glob_t, k - 1);
-        const Vec3 tmp_p{pk.x - pk1.x - v_start.x * delta_t - half_dt2 * gravity.x, pk.y - pk1.y - v_start.y * delta_t - half_dt2 * gravity.y,
-                         pk.z - pk1.z - v_start.z * delta_t - half_dt2 * gravity.z};
-        const Vec3 dp = Rst * tmp_p;
-        Mat3 P;
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) P(r, c) = preint_rot[9 * (size_t)k + 3 * c + r];
-        const Vec3 rot_err = so3_log(transposed(P) * so3_exp(col(ctrl.rel_o, k)));
-        const Vec3 tmp_v{v_end.x - v_start.x - gravity.x * delta_t, v_end.y - v_start.y - gravity.y * delta_t, v_end.z - v_start.z - gravity.z * delta_t};
-        const Vec3 dv = Rst * tmp_v;
-        const double ce[9] = {rot_err.x, rot_err.y, rot_err.z,
-                              dv.x - preint_vel[3 * (size_t)k], dv.y - preint_vel[3 * (size_t)k + 1], dv.z - preint_vel[3 * (size_t)k + 2],
-                              dp.x - preint_pos[3 * (size_t)k], dp.y - preint_pos[3 * (size_t)k + 1], dp.z - preint_pos[3 * (size_t)k + 2]};
-        const double* Ci = &cov_inv[81 * (size_t)k];
-        double q = 0.0, left[9];
-        for (int j = 0; j < 9; ++j) {
-            double s = 0.0;
-            for (int i = 0; i < 9; ++i) s += ce[i] * Ci[9 * j + i];
-            left[j] = s;
-        }
-        for (int j = 0; j < 9; ++j) q += left[j] * ce[j];
-        q *= balancing_imu;
-        rows[k - 1] = std::sqrt(q);
-    }
+    const ImuConsts c = imu_consts();
+    for (int k = 1; k < ctrl.n; ++k)
+        rows[k - 1] = imu_row(k, ctrl.n, stamps.data(), fh.w.data(), traj_time.data(), c, ctrl.glob_o.data(), ctrl.glob_t.data(), col(ctrl.rel_o, k));
 }
 
 // ---- KeyframeHost -------------------------------------------------------------------------------------
@@ -332,44 +214,28 @@ bool KeyframeHost::init(const dmsa_keyframe_problem& p) {
 }
 int KeyframeHost::num_extra_rows() const { return (use_gravity ? frames.n : 0) + (use_odometry ? frames.n - 1 : 0); }
 
-static inline double quad_form3(Vec3 d, const double* Ci /* col-major */) {
-    const double l0 = d.x * Ci[0] + d.y * Ci[1] + d.z * Ci[2];
-    const double l1 = d.x * Ci[3] + d.y * Ci[4] + d.z * Ci[5];
-    const double l2 = d.x * Ci[6] + d.y * Ci[7] + d.z * Ci[8];
-    return l0 * d.x + l1 * d.y + l2 * d.z;
+KeyframeRowConsts KeyframeHost::row_consts() const {
+    KeyframeRowConsts c{};
+    c.use_gravity = use_gravity ? 1 : 0, c.use_odometry = use_odometry ? 1 : 0;
+    c.gravity[0] = gravity.x, c.gravity[1] = gravity.y, c.gravity[2] = gravity.z;
+    std::copy(cov_grav_inv, cov_grav_inv + 9, c.cov_grav_inv);
+    c.balancing_grav = balancing_grav, c.balancing_odom = balancing_odom;
+    std::copy(odom_transl_cov_inv, odom_transl_cov_inv + 9, c.odom_transl_cov_inv);
+    std::copy(odom_orient_cov_inv, odom_orient_cov_inv + 9, c.odom_orient_cov_inv);
+    c.measured_gravity = measured_gravity.data(), c.gravity_plausible = gravity_plausible.data();
+    c.odom_transl = odom_transl.data(), c.odom_orient_mat = odom_orient_mat.data();
+    return c;
 }
-
 void KeyframeHost::additional_rows(double* rows) const {
     const int F = frames.n;
+    const KeyframeRowConsts c = row_consts();
     int at = 0;
     if (use_gravity) {  // MapManagement.h:210-232 — row 0 and implausible frames stay exactly 0
-        for (int k = 0; k < F; ++k) rows[at + k] = 0.0;
-        for (int k = 1; k < F; ++k) {
-            if (!gravity_plausible[(size_t)k]) continue;
-            const Vec3 m{measured_gravity[3 * (size_t)k], measured_gravity[3 * (size_t)k + 1], measured_gravity[3 * (size_t)k + 2]};
-            Vec3 d = so3_exp(col(frames.glob_o, k)) * m;
-            d = {d.x - gravity.x, d.y - gravity.y, d.z - gravity.z};
-            double q = quad_form3(d, cov_grav_inv);
-            q *= balancing_grav;
-            rows[at + k] = std::sqrt(q);
-        }
+        for (int k = 0; k < F; ++k) rows[at + k] = gravity_row(k, c, col(frames.glob_o, k));
         at += F;
     }
-    if (use_odometry) {  // MapManagement.h:234-252
-        for (int k = 1; k < F; ++k) {
-            const Vec3 o{odom_transl[3 * (size_t)k], odom_transl[3 * (size_t)k + 1], odom_transl[3 * (size_t)k + 2]};
-            const Vec3 td = o - col(frames.rel_t, k);
-            Mat3 Rm;
-            for (int r = 0; r < 3; ++r)
-                for (int c = 0; c < 3; ++c) Rm(r, c) = odom_orient_mat[9 * (size_t)k + 3 * c + r];
-            const Vec3 od = so3_log(transposed(so3_exp(col(frames.rel_o, k))) * Rm);
-            double q = 0.0;
-            q += quad_form3(td, odom_transl_cov_inv);
-            q += quad_form3(od, odom_orient_cov_inv);
-            q *= balancing_odom;
-            rows[at + k - 1] = std::sqrt(q);
-        }
-    }
+    if (use_odometry)  // MapManagement.h:234-252
+        for (int k = 1; k < F; ++k) rows[at + k - 1] = odometry_row(k, c, col(frames.rel_o, k), col(frames.rel_t, k));
 }
 
 // ---- LM solve -----------------------------------------------------------------------------------------

@@ -17,29 +17,12 @@
 #include <vector>
 
 #include "../../include/dmsa_hip.h"
+#include "pose_math.h"
 
 namespace dmsa {
 
-struct Vec3 {
-    double x, y, z;
-};
-inline Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-inline Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-inline Vec3 operator*(double s, Vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
-inline double length(Vec3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
-
-struct Mat3 {
-    double a[9];  // row-major
-    double& operator()(int r, int c) { return a[3 * r + c]; }
-    double operator()(int r, int c) const { return a[3 * r + c]; }
-    static Mat3 identity() { return Mat3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
-};
-Mat3 operator*(const Mat3& A, const Mat3& B);
-Vec3 operator*(const Mat3& A, Vec3 v);
-Mat3 transposed(const Mat3& A);
-
-Mat3 so3_exp(Vec3 w);                         // axang2rotm, helpers.h:51-57
-Vec3 so3_log(const Mat3& R);                  // rotm2axang, helpers.h:59-65
+// Vec3 / Mat3, so3_exp (axang2rotm, helpers.h:51-57), so3_log (rotm2axang, helpers.h:59-65) and the per-pose chain steps live in
+// pose_math.h: one definition for the host and for the device kernels of the loop
 Vec3 slerp_axang(Vec3 a, Vec3 b, double t);   // helpers.h:24-37
 
 // Global <-> relative pose chains.  Columns are stored contiguously: pose k = o[3k..3k+2], t[3k..3k+2]
@@ -85,6 +68,7 @@ struct WindowHost {
     int num_extra_rows() const { return use_imu ? ctrl.n - 1 : 0; }
     // updateImuError on the CURRENT chain state (runs global_to_relative first, like the reference)
     void imu_rows(double* rows);
+    ImuConsts imu_consts() const;  // pointers into this object's vectors
 };
 
 struct KeyframeHost {
@@ -99,6 +83,7 @@ struct KeyframeHost {
     bool init(const dmsa_keyframe_problem& p);
     int num_extra_rows() const;
     void additional_rows(double* rows) const;  // MapManagement.h:162-252, gravity rows then odometry rows
+    KeyframeRowConsts row_consts() const;      // pointers into this object's vectors
 };
 
 // Dense symmetric solve for the LM step: step = -alpha * H^-1 * g with H^-1 from partial-pivot elimination

@@ -16,7 +16,6 @@ using namespace dmsa;
 
 namespace {
 
-inline Vec3 col3(const double* m, int k) { return {m[3 * k], m[3 * k + 1], m[3 * k + 2]}; }
 inline void put3(double* m, int k, Vec3 v) { m[3 * k] = v.x, m[3 * k + 1] = v.y, m[3 * k + 2] = v.z; }
 inline Mat3 skew(Vec3 v) { return Mat3{{0.0, -v.z, v.y, v.z, 0.0, -v.x, -v.y, v.x, 0.0}}; }  // helpers.h:39-49
 inline Mat3 scaled(double s, const Mat3& A) {

@@ -40,6 +40,29 @@
 #include <stdexcept>
 #include <vector>
 
+// ---- hypothesis switches ---------------------------------------------------------------------------------------------
+// Where this file states an evaluation order or an arithmetic the reference's sources do not spell out (Eigen internals recalled,
+// not read; orders chosen so that a GPU computes them naturally), a compile-time switch selects the plausible alternative.  The
+// shipped oracle defines none of them; scripts/oracle_sensitivity.py builds one library per switch (make -C oracle hypotheses) and
+// reports how far the optimised poses move -- which hypotheses the 1e-4 m / 1e-4 rad claim depends on.
+//   ORC_VAR_TRANSFORM_PAIRWISE  Matrix4f * Vector4f as (c0 x + c1 y) + (c2 z + c3) instead of ((c0 x + c1 y) + c2 z) + c3
+//   ORC_VAR_SUM3_LEFT           3-term fixed-size redux as (x0 + x1) + x2 instead of x0 + (x1 + x2)
+//   ORC_VAR_MAHA_ASSOC          w * ((d^T A) d) instead of ((w d^T) A) d                       (DmsaOptimizer.h:263)
+//   ORC_VAR_FIT_FLOAT           fit sums / weight mean as float chains in member order instead of 64-wide trees in double
+//   ORC_VAR_JTJ_NOFMA           J^T J, J^T e, e^T e for P > 64 with separately rounded multiply and add (the reference has no FMA)
+//   ORC_VAR_GLIBC_TRIG          sin / cos / acos / atan2 from glibc instead of include/dmsa_detmath.h
+#ifdef ORC_VAR_GLIBC_TRIG
+#define ORC_SIN(x) std::sin(x)
+#define ORC_COS(x) std::cos(x)
+#define ORC_ACOS(x) std::acos(x)
+#define ORC_ATAN2(y, x) std::atan2(y, x)
+#else
+#define ORC_SIN(x) dmsa_det::det_sin(x)
+#define ORC_COS(x) dmsa_det::det_cos(x)
+#define ORC_ACOS(x) dmsa_det::det_acos(x)
+#define ORC_ATAN2(y, x) dmsa_det::det_atan2(y, x)
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -73,8 +96,8 @@ static inline double norm3(const double* a) { return std::sqrt(a[0] * a[0] + a[1
 static M3 axang2rotm(const double* w) {
     const double theta = norm3(w);
     if (theta < 0.00001) return eye3();
-    const double s = dmsa_det::det_sin(theta) / theta;  // sin / cos / acos / atan2 of the pose-table path: include/dmsa_detmath.h
-    const double sh = dmsa_det::det_sin(0.5 * theta);
+    const double s = ORC_SIN(theta) / theta;  // sin / cos / acos / atan2 of the pose-table path: include/dmsa_detmath.h
+    const double sh = ORC_SIN(0.5 * theta);
     const double c = 2.0 * sh * sh / (theta * theta);
     const double x = w[0], y = w[1], z = w[2];
     M3 R;
@@ -127,7 +150,7 @@ static void rotm2axang(const M3& R, double* out) {
         out[0] = out[1] = out[2] = 0.0;
         return;
     }
-    const double angle = 2.0 * std::atan2(n, std::fabs(qw));
+    const double angle = 2.0 * ORC_ATAN2(n, std::fabs(qw));
     const double k = angle / (qw < 0.0 ? -n : n);
     out[0] = qx * k, out[1] = qy * k, out[2] = qz * k;
 }
@@ -146,8 +169,8 @@ static void slerp(const double* aa1, const double* aa2, double t, double* out) {
         if (sq > 0.0) {  // Eigen normalized(): zero vector stays zero
             ax[0] = a[0] / ang, ax[1] = a[1] / ang, ax[2] = a[2] / ang;
         }
-        const double sh = dmsa_det::det_sin(0.5 * ang);
-        qs[i][0] = dmsa_det::det_cos(0.5 * ang);
+        const double sh = ORC_SIN(0.5 * ang);
+        qs[i][0] = ORC_COS(0.5 * ang);
         qs[i][1] = sh * ax[0], qs[i][2] = sh * ax[1], qs[i][3] = sh * ax[2];
     }
     const double one = 1.0 - std::numeric_limits<double>::epsilon();
@@ -158,10 +181,10 @@ static void slerp(const double* aa1, const double* aa2, double t, double* out) {
         scale0 = 1.0 - t;
         scale1 = t;
     } else {
-        const double theta = dmsa_det::det_acos(absD);
-        const double sinTheta = dmsa_det::det_sin(theta);
-        scale0 = dmsa_det::det_sin((1.0 - t) * theta) / sinTheta;
-        scale1 = dmsa_det::det_sin(t * theta) / sinTheta;
+        const double theta = ORC_ACOS(absD);
+        const double sinTheta = ORC_SIN(theta);
+        scale0 = ORC_SIN((1.0 - t) * theta) / sinTheta;
+        scale1 = ORC_SIN(t * theta) / sinTheta;
     }
     if (d < 0.0) scale1 = -scale1;
     double q[4];
@@ -169,7 +192,7 @@ static void slerp(const double* aa1, const double* aa2, double t, double* out) {
     // AngleAxisd(q)
     double n = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     if (n != 0.0) {
-        const double angle = 2.0 * dmsa_det::det_atan2(n, std::fabs(q[0]));
+        const double angle = 2.0 * ORC_ATAN2(n, std::fabs(q[0]));
         if (q[0] < 0.0) n = -n;
         out[0] = (q[1] / n) * angle, out[1] = (q[2] / n) * angle, out[2] = (q[3] / n) * angle;
     } else {
@@ -297,10 +320,18 @@ struct ConsecutivePoses {
 // ------------------------------------------------------------------------------------------------
 // Matrix4f * Vector4f with w = 1 (ContinuousTrajectory.h:151, MapManagement.h:142): ((c0*x + c1*y) + c2*z) + c3*1
 static inline void tform_point(const float* T /* 12: row-major 3x4 */, const float* p, float* out) {
+#ifdef ORC_VAR_TRANSFORM_PAIRWISE
+    for (int r = 0; r < 3; ++r) out[r] = (T[4 * r + 0] * p[0] + T[4 * r + 1] * p[1]) + (T[4 * r + 2] * p[2] + T[4 * r + 3]);
+#else
     for (int r = 0; r < 3; ++r) out[r] = ((T[4 * r + 0] * p[0] + T[4 * r + 1] * p[1]) + T[4 * r + 2] * p[2]) + T[4 * r + 3];
+#endif
 }
 // 3-term fixed-size inner product: Eigen's unrolled redux splits in halves -> x0 + (x1 + x2)
+#ifdef ORC_VAR_SUM3_LEFT
+static inline float sum3(float a, float b, float c) { return (a + b) + c; }
+#else
 static inline float sum3(float a, float b, float c) { return a + (b + c); }
+#endif
 // Matrix3f * Vector3f (MapManagement.h:144)
 static inline void rot_vec(const float* T, const float* v, float* out) {
     for (int r = 0; r < 3; ++r) out[r] = sum3(T[4 * r + 0] * v[0], T[4 * r + 1] * v[1], T[4 * r + 2] * v[2]);
@@ -490,6 +521,11 @@ struct Gaussians {
     static constexpr size_t kSumBlock = 64;
     template <typename Term>
     static double blockedSum(size_t n, Term term) {
+#ifdef ORC_VAR_FIT_FLOAT
+        float chain = 0.0f;  // a scalar float loop in member order
+        for (size_t j = 0; j < n; ++j) chain = chain + (float)term(j);
+        return (double)chain;
+#endif
         double total = 0.0;
         for (size_t j0 = 0; j0 < n; j0 += kSumBlock) {
             double v[kSumBlock];
@@ -625,11 +661,18 @@ static void eval_residuals(const Gaussians& g, const float* xyz4, double* e) {
             const float* p = xyz4 + 4 * (size_t)g.members[j];
             const float d0 = p[0] - mean[0], d1 = p[1] - mean[1], d2 = p[2] - mean[2];
             // ((float(w) * d^T) * A) * d, 3-term sums as x0 + (x1 + x2); the float 1x1 result is added to a double
+#ifdef ORC_VAR_MAHA_ASSOC
+            const float u0 = sum3(d0 * A[0], d1 * A[1], d2 * A[2]);
+            const float u1 = sum3(d0 * A[3], d1 * A[4], d2 * A[5]);
+            const float u2 = sum3(d0 * A[6], d1 * A[7], d2 * A[8]);
+            const float q = w * sum3(u0 * d0, u1 * d1, u2 * d2);
+#else
             const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
             const float v0 = sum3(wd0 * A[0], wd1 * A[1], wd2 * A[2]);
             const float v1 = sum3(wd0 * A[3], wd1 * A[4], wd2 * A[5]);
             const float v2 = sum3(wd0 * A[6], wd1 * A[7], wd2 * A[8]);
             const float q = sum3(v0 * d0, v1 * d1, v2 * d2);
+#endif
             acc += (double)q;
         }
         e[k] = std::sqrt(std::fabs(acc));
@@ -995,7 +1038,11 @@ static int reduction_block_rows(int rows, int P) {
 // way; what matters is that H, g, e0^T e0 and the line search's e^T e all follow ONE rule.
 static double blocked_dot(int rows, int P, const double* x, const double* y) {
     const int rs = reduction_block_rows(rows, P);
+#ifdef ORC_VAR_JTJ_NOFMA
+    const bool fused = false;
+#else
     const bool fused = P > 64;
+#endif
     double total = 0.0;
     for (int r0 = 0; r0 < rows; r0 += rs) {
         double s = 0.0;
