@@ -30,6 +30,7 @@
 #include "radix_sort_dev.h"
 #include "dmsa_kernels.h"
 #include "host_math.h"
+#include "loop_kernels.h"
 #include "serial_kernels.h"
 #include "static_kernels.h"
 
@@ -209,6 +210,7 @@ struct dmsa_ctx {
     int bits_guess[2] = {-1, -1};    // leaf-code widths of the previous voxelisation
     bool compress_keys = true;       // drop the constant high key bits before sorting (DMSA_KEY_COMPRESS=0 disables)
     bool overlap_batch = true;       // host math of the Jacobian batch while the GPU voxelises (DMSA_OVERLAP_BATCH=0 disables)
+    bool device_loop = true;         // DMSA_DEVICE_LOOP=0: drive the default path's loop from the host as rounds 1-2 did
     int merge_sort = -1;             // -1: by size; DMSA_MERGE_SORT=0/1 forces two sorts / one sort of both levels
     double level_res[2] = {0, 0};
     // Gaussians
@@ -220,7 +222,23 @@ struct dmsa_ctx {
     bool fit_guess_valid = false;  // serial_counts of the previous voxelisation may size this one's speculative fit launches
     SerialCounts serial_counts{0, 0, 0, 0};
     bool E_is_jacobian = false;  // the matrix-core normal equations (P > 64) rewrote the residual batch as the columns of [J | e0]
-    int global_table = 0;  // index (in the current batch) of the pose table d_global was computed with
+    const float* base_table = nullptr;  // the pose table d_global was computed with (the fit re-derives the members' global coordinates from it)
+    // ---- device-resident optimizeSet loop (loop_kernels.h) ----
+    LoopModel loop_model{};      // built at upload: device pointers to the model's constants
+    DevBuf d_imu_idx, d_imu_rot, d_imu_pos, d_imu_vel, d_imu_cov;           // window model, IMU factor rows
+    DevBuf d_key_grav, d_key_plaus, d_key_odom_t, d_key_odom_R;             // keyframe model, gravity / odometry rows
+    DevBuf d_loop_state;   // three chain states: start of the iteration, after the Jacobian batch, after the line search
+    DevBuf d_loop_vec;     // paramVec[P] | step[P]
+    DevBuf d_ctrl0;        // global poses of the base table (n x 6)
+    DevBuf d_table0;       // the base pose table (own buffer: the Jacobian batch's tables are written beside the fit that still reads it)
+    DevBuf d_loop_extra;   // additional rows of the two batches: [1+P][a] | [9][a]
+    DevBuf d_loop_iter;    // LoopFlags | IterResult[num_iter]
+    IterResult* h_results = nullptr;  // pinned
+    int h_results_cap = 0;
+    // one extra device->host copy riding on the counts read-back of build_gaussians (the previous iteration's IterResult)
+    const void* rb_extra_src = nullptr;
+    void* rb_extra_dst = nullptr;
+    size_t rb_extra_bytes = 0;
     bool serial_two_streams = true;  // DMSA_SERIAL_STREAMS=1: all tiers of the reference-order correspondence kernels on one stream
     DevBuf d_memb_tile, d_tiles, d_tile_rows, d_fallback, d_pad_off;
     int num_tiles = 0, num_fallback = 0, tile_max_rows = 0, tile_max_gauss = 0;
@@ -301,12 +319,19 @@ struct ScopedTimer {
 };
 // fold finished event pairs into the accumulators (call after a stream synchronisation)
 void drain_timers(dmsa_ctx* ctx) {
+    // pairs whose closing event has not completed yet stay pending (the device-resident loop drains without a full synchronisation)
+    std::vector<EventPair> later;
     for (auto& ev : ctx->pending) {
+        if (hipEventQuery(ev.b) == hipErrorNotReady) {
+            later.push_back(ev);
+            continue;
+        }
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) ctx->t_ms[ev.slot] += (double)ms;
         ctx->free_events.push_back(ev.a), ctx->free_events.push_back(ev.b);
     }
-    ctx->pending.clear();
+    (void)hipGetLastError();  // hipErrorNotReady is recorded as the thread's last error
+    ctx->pending.swap(later);
 }
 
 // Host synchronisation on the critical path of an iteration: polling the stream avoids the ~20-30 us wake-up latency of a
@@ -428,6 +453,7 @@ int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs, hipStre
         if (globs.size() > ctx->h_pin_slot) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
             if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
             ctx->h_pin = nullptr;
             ctx->h_pin_slot = globs.size() + globs.size() / 2 + 64;
             HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), ctx->h_pin_slot * kPinSlots * sizeof(double), hipHostMallocDefault));
@@ -484,8 +510,8 @@ void host_set_params(dmsa_ctx* ctx, const double* p) {
 }
 
 int transform_points(dmsa_ctx* ctx, int b) {
-    ctx->global_table = b;  // the fit re-derives the global coordinates of the members from this table
     const float4* table = ctx->d_tables.as<float4>() + (size_t)b * ctx->rows * 3;
+    ctx->base_table = reinterpret_cast<const float*>(table);  // the fit re-derives the global coordinates of the members from this table
     if (ctx->model == MODEL_KEYFRAMES)
         launch_transform_normals(ctx->d_local.as<float4>(), ctx->d_nlocal.as<float4>(), table, ctx->d_global.as<float4>(), ctx->d_nglobal.as<float4>(),
                                  ctx->n, ctx->stream);
@@ -715,6 +741,8 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     }
     HIPCHK(hipMemcpyAsync(&ctx->h_rb->g, ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts), hipMemcpyDeviceToHost, rb));
     HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, rb));  // incl. out_of_range
+    if (ctx->rb_extra_bytes)  // device loop: the previous iteration's stop decision travels with the counts
+        HIPCHK(hipMemcpyAsync(ctx->rb_extra_dst, ctx->rb_extra_src, ctx->rb_extra_bytes, hipMemcpyDeviceToHost, rb));
     // The fit does not need the counts on the host (fixed grids, device-side tile counts): with the LDS table sized for ALL pose rows
     // it is enqueued right behind the read-back, so the GPU keeps working while the host waits for M (sync #2 waits on an event
     // recorded BEFORE the fit, not on the stream).
@@ -724,7 +752,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     // counts (+ margin) as grids -- the kernels take the true ranges from device memory, surplus workgroups exit, and whatever the
     // guess missed is launched after sync #2.  The three classes run side by side on two streams (each is latency-bound on its own).
     const int32_t* d_sc = reinterpret_cast<const int32_t*>(ctx->d_counts.as<char>() + sizeof(GaussCounts) + sizeof(TileCounts));
-    const float* fit_table = ctx->d_tables.as<float>() + (size_t)ctx->global_table * ctx->rows * 12;
+    const float* fit_table = ctx->base_table ? ctx->base_table : ctx->d_tables.as<float>();
     int fit_launched[3] = {0, 0, 0}, finish_launched = 0;
     auto launch_fit = [&](const int first[3], const int tasks[3], int finish_gauss) -> int {
         ScopedTimer tm(ctx, T_FIT);
@@ -853,13 +881,15 @@ int ensure_E(dmsa_ctx* ctx, int B) {
     HIPCHK(ctx->d_E.ensure((size_t)B * ld * 8));
     return DMSA_OK;
 }
-int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
+int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const double* d_extra = nullptr) {
     CHK(ensure_E(ctx, B));
     if (ctx->tables_pending) {  // the pose tables of this batch were built on the second stream
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
         ctx->tables_pending = false;
     }
     const int a = ctx->extra_rows;
+    if (a > 0 && d_extra != nullptr)  // device loop: the chain kernels left the additional rows of the batch in device memory
+        launch_loop_scatter_extra(d_extra, B, a, ctx->d_E.as<double>(), ctx->ldE, ctx->M, ctx->stream);
     if (a > 0 && extra != nullptr) {
         // additional rows (IMU / gravity / odometry) go below the Gaussian rows of every evaluation, through a pinned ring like the
         // control poses: no host synchronisation, and the copy runs ahead of the correspondence kernels
@@ -922,11 +952,56 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra) {
     return DMSA_OK;
 }
 
+// The constants of the problem model the device-resident loop reads (IMU factors / gravity and odometry measurements) and the kernel
+// argument that points at them.  Called by the upload entry points after the host model (ctx->win / ctx->key) is initialised.
+int upload_loop_model(dmsa_ctx* ctx) {
+    auto put = [&](DevBuf& buf, const void* src, size_t bytes) -> int {
+        HIPCHK(buf.ensure(bytes + 16));
+        if (bytes) HIPCHK(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice));
+        return DMSA_OK;
+    };
+    LoopModel m{};
+    if (ctx->model == MODEL_WINDOW) {
+        const WindowHost& w = ctx->win;
+        m.model = 1, m.n = w.ctrl.n, m.P = w.ctrl.num_params(), m.extra = w.num_extra_rows();
+        m.stamps = ctx->d_stamps.as<double>(), m.fhw = ctx->d_fhw.as<double>(), m.traj_time = ctx->d_trajtime.as<double>();
+        m.imu = w.imu_consts();
+        m.imu.param_indices = nullptr, m.imu.preint_rot = m.imu.preint_pos = m.imu.preint_vel = m.imu.cov_inv = nullptr;
+        if (w.use_imu) {
+            CHK(put(ctx->d_imu_idx, w.param_indices.data(), w.param_indices.size() * 4));
+            CHK(put(ctx->d_imu_rot, w.preint_rot.data(), w.preint_rot.size() * 8));
+            CHK(put(ctx->d_imu_pos, w.preint_pos.data(), w.preint_pos.size() * 8));
+            CHK(put(ctx->d_imu_vel, w.preint_vel.data(), w.preint_vel.size() * 8));
+            CHK(put(ctx->d_imu_cov, w.cov_inv.data(), w.cov_inv.size() * 8));
+            m.imu.param_indices = ctx->d_imu_idx.as<int>(), m.imu.preint_rot = ctx->d_imu_rot.as<double>(), m.imu.preint_pos = ctx->d_imu_pos.as<double>();
+            m.imu.preint_vel = ctx->d_imu_vel.as<double>(), m.imu.cov_inv = ctx->d_imu_cov.as<double>();
+        }
+    } else {
+        const KeyframeHost& k = ctx->key;
+        m.model = 2, m.n = k.frames.n, m.P = k.frames.num_params(), m.extra = k.num_extra_rows();
+        m.key = k.row_consts();
+        m.key.measured_gravity = nullptr, m.key.gravity_plausible = nullptr, m.key.odom_transl = nullptr, m.key.odom_orient_mat = nullptr;
+        if (k.use_gravity) {
+            CHK(put(ctx->d_key_grav, k.measured_gravity.data(), k.measured_gravity.size() * 8));
+            CHK(put(ctx->d_key_plaus, k.gravity_plausible.data(), k.gravity_plausible.size() * 4));
+            m.key.measured_gravity = ctx->d_key_grav.as<double>(), m.key.gravity_plausible = ctx->d_key_plaus.as<int>();
+        }
+        if (k.use_odometry) {
+            CHK(put(ctx->d_key_odom_t, k.odom_transl.data(), k.odom_transl.size() * 8));
+            CHK(put(ctx->d_key_odom_R, k.odom_orient_mat.data(), k.odom_orient_mat.size() * 8));
+            m.key.odom_transl = ctx->d_key_odom_t.as<double>(), m.key.odom_orient_mat = ctx->d_key_odom_R.as<double>();
+        }
+    }
+    ctx->loop_model = m;
+    return DMSA_OK;
+}
+
 int upload_common(dmsa_ctx* ctx) {
     CHK(alloc_point_buffers(ctx));
     ctx->gaussians_valid = false;
     ctx->centralized = false;
     ctx->batch = 0;
+    ctx->base_table = nullptr;
     ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
     ctx->fit_guess_valid = false;
     return DMSA_OK;
@@ -936,8 +1011,12 @@ int upload_common(dmsa_ctx* ctx) {
 int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep);
 // A failure inside the loop (HIP error, lattice deeper than 21 levels, allocation) must not leave the resident problem in the centred
 // frame: the static points were shifted in place and the window origin lives only in the context.
+int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep);
 int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
-    const int rc = optimize_impl(ctx, s, rep);
+    // default path: the loop state lives on the device (one host wait per iteration); the host-driven loop remains for the opt-in fast
+    // sums and for host-built pose tables
+    const bool device_loop = (ctx->flags & DMSA_FLAG_MIRROR_SUMS) && !(ctx->flags & DMSA_FLAG_POSE_TABLE_HOST) && ctx->device_loop;
+    const int rc = device_loop ? optimize_device_loop(ctx, s, rep) : optimize_impl(ctx, s, rep);
     if (rc != DMSA_OK && ctx->centralized) {
         const std::string err = ctx->err;
         (void)dmsa_decentralize(ctx);
@@ -1016,7 +1095,10 @@ int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
             chain(ctx).set_params(origin.data());  // :231
             // The tables of the batch (and, on the default path, their transposed copy) depend on nothing the GPU is busy with: they go
             // to another stream, beside the voxelisation, instead of between the fit and the correspondence kernels.
-            hipStream_t ts = ctx->dual_stream ? ctx->stream3 : ctx->stream;  // the third stream is idle during the voxelisation (the second also carries the fit)
+            // On the main stream: the fit launched before and after this point reads table 0 of d_tables, which this batch rewrites (with
+            // the same bits) -- in stream order that is no race.  (The device-resident loop keeps the base table in its own buffer and
+            // builds the batch beside the voxelisation.)
+            hipStream_t ts = ctx->stream;
             CHK(build_tables(ctx, 1 + P, globs, ts));
             HIPCHK(hipEventRecord(ctx->ev_tables, ts));
             ctx->tables_pending = ts != ctx->stream;
@@ -1183,6 +1265,252 @@ int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
     return DMSA_OK;
 }
 
+// ---- the same loop with its control state on the device (loop_kernels.h) ---------------------------------------------------------
+// Per iteration the host only enqueues; its one wait is for the Gaussian counts that size the correspondence launches (sync A).  The
+// stop decision of iteration i (no improvement / epsilon / NaN step) is taken on the device and reaches the host with the counts of
+// iteration i + 1: every loop kernel of a stopped loop is a no-op, so the extra voxelisation that was already enqueued changes nothing.
+// P > 64 (keyframe sets) still solves the normal equations on the host's worker pool: one more wait per iteration.
+int pinned_doubles(dmsa_ctx* ctx, size_t count, double** out) {
+    constexpr int kPinSlots = 4;
+    if (count > ctx->h_pin_slot) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+        ctx->h_pin = nullptr;
+        ctx->h_pin_slot = count + count / 2 + 64;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), ctx->h_pin_slot * kPinSlots * sizeof(double), hipHostMallocDefault));
+    }
+    *out = ctx->h_pin + (size_t)ctx->h_pin_next * ctx->h_pin_slot;
+    ctx->h_pin_next = (ctx->h_pin_next + 1) % kPinSlots;
+    return DMSA_OK;
+}
+int device_tables(dmsa_ctx* ctx, int B, const double* d_ctrl, float* tables, float* tablesT, hipStream_t stream) {
+    const int np = ctx->loop_model.n;
+    if (ctx->model == MODEL_WINDOW)
+        launch_window_pose_tables(d_ctrl, ctx->d_stamps.as<double>(), ctx->d_fhw.as<double>(), ctx->d_trajtime.as<double>(), B, np, ctx->rows - 1, tables, tablesT,
+                                  stream);
+    else
+        launch_keyframe_pose_tables(d_ctrl, B, np, tables, tablesT, stream);
+    HIPCHK(hipGetLastError());
+    return DMSA_OK;
+}
+
+int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
+    ScopedTimer total(ctx, T_TOTAL);
+    const bool fixed = (ctx->flags & DMSA_FLAG_FIXED_ITERS) != 0;
+    const LoopModel& m = ctx->loop_model;
+    const int P = m.P, n = m.n, a = m.extra > 0 ? m.extra : 0;
+    const int num_iter = std::max(0, s.num_iter);
+    int stop = DMSA_STOP_NUM_ITER, iters = 0, bestK = 0;
+    double error0 = 0.0, stepNorm = 0.0;
+    ctx->evaluations = 0;
+    ctx->trace.clear();
+    const double increment = 1.0 * std::sqrt((double)std::numeric_limits<float>::epsilon());
+    const double one_div_incr = 1.0 / increment;
+
+    if (s.use_centralization) CHK(dmsa_centralize(ctx));
+    // device buffers of the loop
+    const size_t st = loop_state_doubles(n);
+    HIPCHK(ctx->d_loop_state.ensure(3 * st * 8));
+    HIPCHK(ctx->d_loop_vec.ensure((size_t)2 * P * 8 + 64));
+    HIPCHK(ctx->d_ctrl0.ensure((size_t)n * 6 * 8));
+    HIPCHK(ctx->d_ctrl.ensure((size_t)(1 + P) * n * 6 * 8));
+    HIPCHK(ctx->d_table0.ensure((size_t)ctx->rows * 48));
+    HIPCHK(ctx->d_tables.ensure((size_t)(P + 1) * ctx->rows * 48));  // never reallocated while kernels read it
+    HIPCHK(ctx->d_tablesT.ensure((size_t)(P + 1) * ctx->rows * 48));
+    HIPCHK(ctx->d_loop_extra.ensure((size_t)(1 + P + 9) * std::max(a, 1) * 8));
+    HIPCHK(ctx->d_loop_iter.ensure(sizeof(LoopFlags) + (size_t)(num_iter + 1) * sizeof(IterResult)));
+    HIPCHK(ctx->d_Hp.ensure((size_t)(P + 1) * (P + 1) * 8));
+    HIPCHK(ctx->d_sq_out.ensure(16 * 8));
+    if (num_iter + 1 > ctx->h_results_cap) {
+        if (ctx->h_results) (void)hipHostFree(ctx->h_results);
+        ctx->h_results = nullptr, ctx->h_results_cap = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_results), (size_t)(num_iter + 17) * sizeof(IterResult), hipHostMallocDefault));
+        ctx->h_results_cap = num_iter + 17;
+    }
+    std::memset(ctx->h_results, 0, (size_t)ctx->h_results_cap * sizeof(IterResult));
+    double* S0 = ctx->d_loop_state.as<double>();
+    double* S1 = S0 + st;
+    double* S2 = S1 + st;
+    double* d_param = ctx->d_loop_vec.as<double>();
+    double* d_step = d_param + P;
+    double* d_extra_jac = ctx->d_loop_extra.as<double>();
+    double* d_extra_trial = d_extra_jac + (size_t)(1 + P) * a;
+    LoopFlags* d_flags = ctx->d_loop_iter.as<LoopFlags>();
+    IterResult* d_results = reinterpret_cast<IterResult*>(d_flags + 1);
+    // seed: the host chain as centralize() left it
+    {
+        PoseChain& c = chain(ctx);
+        double* pin = nullptr;
+        CHK(pinned_doubles(ctx, st, &pin));
+        std::copy(c.rel_o.begin(), c.rel_o.end(), pin);
+        std::copy(c.rel_t.begin(), c.rel_t.end(), pin + 3 * n);
+        std::copy(c.glob_o.begin(), c.glob_o.end(), pin + 6 * n);
+        std::copy(c.glob_t.begin(), c.glob_t.end(), pin + 9 * n);
+        HIPCHK(hipMemcpyAsync(S0, pin, st * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_loop_iter.p, 0, sizeof(LoopFlags) + (size_t)(num_iter + 1) * sizeof(IterResult), ctx->stream));
+    }
+    std::vector<double> Hp, H, g, step;
+    if (P > kLoopSolveMaxP) Hp.resize((size_t)(P + 1) * (P + 1)), H.resize((size_t)P * P), g.resize((size_t)P), step.resize((size_t)P);
+    // what the report says about the Gaussians belongs to the last iteration that really ran
+    int last_M = 0, last_M1 = 0;
+    int64_t last_Mm = 0;
+    int nan_evals = 0;
+    hipStream_t side = ctx->dual_stream ? ctx->stream3 : ctx->stream;
+    for (int iter = 0; iter < num_iter; ++iter) {
+        g_tl.reset(), g_tl.mark("start");
+        // :72-75 parameters, chain, base table, global points
+        if (iter == 0) launch_loop_begin(m, S0, d_param, ctx->d_ctrl0.as<double>(), d_flags, ctx->stream);  // later iterations: done by loop_finish
+        {
+            ScopedTimer tm(ctx, T_TABLE);
+            CHK(device_tables(ctx, 1, ctx->d_ctrl0.as<double>(), ctx->d_table0.as<float>(), nullptr, ctx->stream));
+        }
+        ctx->base_table = ctx->d_table0.as<float>();
+        if (ctx->model == MODEL_KEYFRAMES)
+            launch_transform_normals(ctx->d_local.as<float4>(), ctx->d_nlocal.as<float4>(), ctx->d_table0.as<float4>(), ctx->d_global.as<float4>(),
+                                     ctx->d_nglobal.as<float4>(), ctx->n, ctx->stream);
+        else
+            launch_transform(ctx->d_local.as<float4>(), ctx->d_table0.as<float4>(), ctx->d_global.as<float4>(), ctx->n, ctx->stream);
+        // :99, :199-232 the 1 + P chains, rows and pose tables of the Jacobian batch: beside the voxelisation, they need nothing from it
+        if (side != ctx->stream) {
+            HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(hipStreamWaitEvent(side, ctx->ev_fork, 0));
+        }
+        launch_loop_chain(m, 0, S0, S1, d_param, d_step, increment, ctx->d_ctrl.as<double>(), d_extra_jac, d_flags, side);
+        CHK(device_tables(ctx, 1 + P, ctx->d_ctrl.as<double>(), ctx->d_tables.as<float>(), ctx->d_tablesT.as<float>(), side));
+        ctx->batch = 1 + P, ctx->tablesT_batch = 1 + P;
+        HIPCHK(hipEventRecord(ctx->ev_tables, side));
+        ctx->tables_pending = side != ctx->stream;
+        g_tl.mark("begin+batch enq");
+        // :78-96; the previous iteration's result rides on the read-back of the counts
+        if (iter > 0) {
+            ctx->rb_extra_src = d_results + (iter - 1), ctx->rb_extra_dst = ctx->h_results + (iter - 1), ctx->rb_extra_bytes = sizeof(IterResult);
+        } else {
+            ctx->rb_extra_bytes = 0;
+        }
+        const int rc = build_gaussians(ctx, s);
+        ctx->rb_extra_bytes = 0;
+        CHK(rc);
+        drain_timers(ctx);  // everything the previous iteration timed has completed
+        g_tl.mark("build_gaussians (incl. sync A)");
+        if (iter > 0 && ctx->h_results[iter - 1].stop != 0) break;  // the loop ended in the previous iteration: this one never started
+        ++iters;
+        last_M = ctx->M, last_M1 = ctx->M1, last_Mm = ctx->Mm;
+        ctx->trace.push_back(dmsa_iter_trace{ctx->M, ctx->M1, ctx->Mm, 0.0, 0.0, 0, 0});
+        if (ctx->M < s.min_num_gaussians) {  // :89-93 -- nothing of this iteration has touched the state the next call starts from (S0)
+            stop = DMSA_STOP_FEW_GAUSSIANS;
+            break;
+        }
+        ctx->evaluations += 1 + P;
+        CHK(run_residuals(ctx, 1 + P, nullptr, d_extra_jac));
+        const int rowsE = ctx->M + ctx->extra_rows;
+        {
+            ScopedTimer tm(ctx, T_NORMAL);
+            HIPCHK(ctx->d_ne_partial.ensure((size_t)normal_equations_partial_doubles(rowsE, P) * 8));
+            launch_normal_equations(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, one_div_incr, ctx->d_ne_partial.as<double>(), ctx->d_Hp.as<double>(), ctx->stream);
+        }
+        bool host_nan = false;
+        if (P <= kLoopSolveMaxP) {
+            // :107-128 on the device
+            launch_loop_lm_step(ctx->d_Hp.as<double>(), P, (double)s.lambda_diag, s.step_length_optim, s.max_step, d_step, d_flags, ctx->stream);
+        } else {
+            if (Hp.size() > ctx->h_Hp_cap) {
+                if (ctx->h_Hp) (void)hipHostFree(ctx->h_Hp);
+                ctx->h_Hp = nullptr, ctx->h_Hp_cap = 0;
+                HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_Hp), Hp.size() * 8, hipHostMallocDefault));
+                ctx->h_Hp_cap = Hp.size();
+            }
+            HIPCHK(hipMemcpyAsync(ctx->h_Hp, ctx->d_Hp.p, Hp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            g_tl.mark("residuals+NE enq");
+            HIPCHK(sync_spin(ctx->stream));  // sync B (P > 64 only)
+            g_tl.mark("sync B wait");
+            std::memcpy(Hp.data(), ctx->h_Hp, Hp.size() * 8);
+            const int n1 = P + 1;
+            for (int j = 0; j < P; ++j)
+                for (int i = 0; i < P; ++i) H[(size_t)j * P + i] = Hp[(size_t)j * n1 + i];
+            for (int i = 0; i < P; ++i) g[(size_t)i] = Hp[(size_t)P * n1 + i];
+            for (int i = 0; i < P; ++i) H[(size_t)i * P + i] += (double)s.lambda_diag;  // :110
+            const ParallelRun par = [&](const std::function<void(int, int)>& fn) { workers(ctx).run_all(fn); };
+            lm_solve(H.data(), g.data(), P, s.step_length_optim, step.data(), &par);  // :113
+            for (double v : step) host_nan = host_nan || std::isnan(v);
+            double* pin = nullptr;
+            CHK(pinned_doubles(ctx, (size_t)P, &pin));
+            std::memcpy(pin, step.data(), (size_t)P * 8);
+            HIPCHK(hipMemcpyAsync(d_step, pin, (size_t)P * 8, hipMemcpyHostToDevice, ctx->stream));
+            launch_loop_step_finish(P, s.max_step, d_step, d_flags, ctx->stream);  // NaN test, clamp
+            g_tl.mark("solve");
+        }
+        // :152-182 nine trials, :130-143 decision
+        launch_loop_chain(m, 1, S1, S2, d_param, d_step, increment, ctx->d_ctrl.as<double>(), d_extra_trial, d_flags, ctx->stream);
+        {
+            ScopedTimer tm(ctx, T_TABLE);
+            CHK(device_tables(ctx, 9, ctx->d_ctrl.as<double>(), ctx->d_tables.as<float>(), ctx->d_tablesT.as<float>(), ctx->stream));
+            ctx->batch = 9, ctx->tablesT_batch = 9;
+        }
+        if (!host_nan) ctx->evaluations += 9;
+        nan_evals = host_nan ? 0 : 9;
+        CHK(run_residuals(ctx, 9, nullptr, d_extra_trial));
+        {
+            ScopedTimer tm(ctx, T_NORMAL);
+            HIPCHK(ctx->d_sq_partial.ensure((size_t)std::max(squared_sums_partial_doubles(rowsE, 9), squared_sums_blocked_partial_doubles(rowsE, P, 9)) * 8));
+            launch_squared_sums_blocked(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
+        }
+        launch_loop_finish(m, S1, S2, S0, d_param, d_step, ctx->d_Hp.as<double>(), ctx->d_sq_out.as<double>(), fixed ? 1 : 0, s.epsilon, d_results + iter, d_flags,
+                           ctx->d_ctrl0.as<double>(), iter + 1 < num_iter ? 1 : 0, ctx->stream);
+        HIPCHK(hipGetLastError());
+        g_tl.mark("iteration enq");
+        if (host_nan) break;  // the device takes the same decision; nothing more to enqueue
+    }
+    g_tl.print();
+    // final state and the results not yet seen
+    std::vector<double> fin(st);
+    {
+        double* pin = nullptr;
+        CHK(pinned_doubles(ctx, st, &pin));
+        HIPCHK(hipMemcpyAsync(pin, S0, st * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (iters > 0) HIPCHK(hipMemcpyAsync(ctx->h_results, d_results, (size_t)iters * sizeof(IterResult), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        std::copy(pin, pin + st, fin.begin());
+    }
+    drain_timers(ctx);
+    {
+        PoseChain& c = chain(ctx);
+        std::copy(fin.begin(), fin.begin() + 3 * n, c.rel_o.begin());
+        std::copy(fin.begin() + 3 * n, fin.begin() + 6 * n, c.rel_t.begin());
+        std::copy(fin.begin() + 6 * n, fin.begin() + 9 * n, c.glob_o.begin());
+        std::copy(fin.begin() + 9 * n, fin.begin() + 12 * n, c.glob_t.begin());
+    }
+    for (int i = 0; i < iters && i < (int)ctx->trace.size(); ++i) {
+        const IterResult& r = ctx->h_results[i];
+        const bool ran = !(stop == DMSA_STOP_FEW_GAUSSIANS && i == iters - 1);  // the aborted iteration has no step
+        if (!ran) break;
+        error0 = r.error0;
+        if (r.stop == DMSA_STOP_NAN) {  // :116-122: left before the line search, nothing else of this iteration is recorded
+            stop = r.stop;
+            ctx->evaluations -= nan_evals;
+            break;
+        }
+        ctx->trace[(size_t)i].error0 = r.error0, ctx->trace[(size_t)i].step_norm = r.step_norm, ctx->trace[(size_t)i].best_k = r.best_k;
+        stepNorm = r.step_norm, bestK = r.best_k;
+        if (r.stop != 0) stop = r.stop;
+    }
+    ctx->M = last_M, ctx->M1 = last_M1, ctx->Mm = last_Mm;
+    if (s.use_centralization) CHK(dmsa_decentralize(ctx));
+    // :149 final updateGlobalPoints
+    if (ctx->model == MODEL_WINDOW) chain(ctx).relative_to_global();
+    std::vector<double> globs;
+    append_glob(chain(ctx), globs);
+    CHK(build_tables(ctx, 1, globs));
+    CHK(transform_points(ctx, 0));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (rep) {
+        rep->iterations = iters, rep->stop_reason = stop;
+        rep->num_gaussians = ctx->M, rep->num_gaussians_l1 = ctx->M1, rep->num_memberships = ctx->Mm;
+        rep->error0 = error0, rep->last_step_norm = stepNorm, rep->last_line_search_k = bestK;
+        rep->evaluations = ctx->evaluations;
+    }
+    return DMSA_OK;
+}
+
 void write_back_poses(const PoseChain& c, double* rel_o, double* rel_t) {
     std::copy(c.rel_o.begin(), c.rel_o.end(), rel_o);
     std::copy(c.rel_t.begin(), c.rel_t.end(), rel_t);
@@ -1209,6 +1537,7 @@ int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) {
     if (const char* e = std::getenv("DMSA_K4_TILES")) ctx->use_tiles = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_KEY_COMPRESS")) ctx->compress_keys = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_OVERLAP_BATCH")) ctx->overlap_batch = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DMSA_DEVICE_LOOP")) ctx->device_loop = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_FUSED_SEGMENTS")) ctx->fused_segments = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_SORT_PREHIST")) ctx->prehist = std::atoi(e) != 0;
     if (const char* e = std::getenv("DMSA_DUAL_STREAM")) ctx->dual_stream = std::atoi(e) != 0;
@@ -1354,6 +1683,7 @@ int dmsa_window_upload(dmsa_ctx* ctx, const dmsa_window_problem* p) {
     HIPCHK(hipMemcpy(ctx->d_trajtime.p, ctx->win.traj_time.data(), (size_t)p->n_total * 8, hipMemcpyHostToDevice));
     ctx->win.ctrl.relative_to_global();
     ctx->min_grid_size = p->min_grid_size;
+    CHK(upload_loop_model(ctx));
     return upload_common(ctx);
 }
 
@@ -1394,6 +1724,7 @@ int dmsa_keyframes_upload(dmsa_ctx* ctx, const dmsa_keyframe_problem* p) {
     HIPCHK(hipMemcpy(ctx->d_nlocal.p, p->normal_local, n * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->d_ring.p, p->ring_id, n * 4, hipMemcpyHostToDevice));
     ctx->min_grid_size = p->min_grid_size;
+    CHK(upload_loop_model(ctx));
     return upload_common(ctx);
 }
 

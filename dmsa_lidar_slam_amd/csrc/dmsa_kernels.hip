@@ -2553,8 +2553,9 @@ __global__ __launch_bounds__(256) void k_normal_eq_partial(const double* __restr
             const int kk = q / kNeTile, rr = q % kNeTile;
             const int r = r0 + rr;
             const bool in = r < r_end;
-            s_a[kk][rr] = in ? ne_col(E, ldE, P, inv_h, ti * kNeTile + kk, r, rows) : 0.0;
-            s_b[kk][rr] = in ? ne_col(E, ldE, P, inv_h, tj * kNeTile + kk, r, rows) : 0.0;
+            const double va = in ? ne_col(E, ldE, P, inv_h, ti * kNeTile + kk, r, rows) : 0.0;
+            s_a[kk][rr] = va;
+            s_b[kk][rr] = ti == tj ? va : (in ? ne_col(E, ldE, P, inv_h, tj * kNeTile + kk, r, rows) : 0.0);  // diagonal tiles: one load serves both
         }
         __syncthreads();
 #pragma unroll 8
@@ -2577,8 +2578,19 @@ __global__ __launch_bounds__(256) void k_normal_eq_reduce(const double* __restri
     if (q >= n1 * n1) return;
     const int i = q % n1, j = q / n1;  // Hp col-major: element (i, j)
     const int ti = i / kNeTile, tj = j / kNeTile, li = i % kNeTile, lj = j % kNeTile;
+    // block sums in block order (the oracle's rule); the loads of a batch are issued together, only the adds are a chain
+    const double* src = partial + ((size_t)tj * nt + ti) * kNeTile * kNeTile + lj * kNeTile + li;
+    const size_t stride = (size_t)nt * nt * kNeTile * kNeTile;
     double s = 0.0;
-    for (int sp = 0; sp < nsplit; ++sp) s += partial[(((size_t)sp * nt * nt) + (size_t)tj * nt + ti) * kNeTile * kNeTile + lj * kNeTile + li];
+    int sp = 0;
+    for (; sp + 16 <= nsplit; sp += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(sp + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; sp < nsplit; ++sp) s += src[(size_t)sp * stride];
     Hp[(size_t)j * n1 + i] = s;
 }
 // P > 64 (keyframe pass: 2 * rows * P^2 is hundreds of MFLOP): the same 32 x 32 tiles on the matrix cores.  A workgroup = 2 x 2

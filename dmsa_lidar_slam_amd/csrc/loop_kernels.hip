@@ -1,0 +1,492 @@
+// loop_kernels.hip — see loop_kernels.h.  Small fp64 kernels (one wave per evaluation, lane = pose) that keep optimizeSet's control
+// state on the device.  Everything here is latency-, not throughput-bound: the point is that the host no longer has to wait for the
+// normal equations, solve, re-chain and upload between the two evaluation batches of an iteration.
+//
+// Operation order = host_math.cpp's (both sides compile pose_math.h): a chain is exp per pose (parallel over lanes), the running
+// product R_k = R_{k-1} exp(o_k), T_k = T_{k-1} + R_{k-1} t_k strictly left to right on one lane (rounding makes it order dependent),
+// then log per pose (parallel).
+#include "loop_kernels.h"
+
+#include <cfloat>
+
+namespace dmsa {
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ void store_mat(double* dst, const Mat3& M) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dst[i] = M.a[i];
+}
+__device__ __forceinline__ Mat3 load_mat(const double* src) {
+    Mat3 M;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M.a[i] = src[i];
+    return M;
+}
+
+// relative2global on LDS arrays, one wave: ConsecutivePoses.h:26-43
+__device__ void wave_relative_to_global(int n, const double* rel_o, const double* rel_t, double* glob_o, double* glob_t, double* sE, double* sR) {
+    const int lane = threadIdx.x;
+    for (int k = lane; k < n; k += kWave) store_mat(sE + 9 * k, so3_exp(col3(rel_o, k)));
+    __syncthreads();
+    if (lane == 0) {
+        Mat3 R = Mat3::identity();
+        Vec3 T{0, 0, 0};
+        for (int k = 0; k < n; ++k) {
+            T = T + R * col3(rel_t, k);
+            set_col3(glob_t, k, T);
+            R = R * load_mat(sE + 9 * k);
+            store_mat(sR + 9 * k, R);
+        }
+    }
+    __syncthreads();
+    for (int k = lane; k < n; k += kWave) set_col3(glob_o, k, so3_log(load_mat(sR + 9 * k)));
+    __syncthreads();
+}
+// global2relative: ConsecutivePoses.h:45-67 (every pose independent of the others)
+__device__ void wave_global_to_relative(int n, const double* glob_o, const double* glob_t, double* rel_o, double* rel_t) {
+    const int lane = threadIdx.x;
+    for (int k = lane; k < n; k += kWave) {
+        if (k == 0) {
+            set_col3(rel_o, 0, col3(glob_o, 0));
+            set_col3(rel_t, 0, col3(glob_t, 0));
+        } else {
+            Vec3 ro, rt;
+            unchain_step(col3(glob_o, k - 1), col3(glob_t, k - 1), col3(glob_o, k), col3(glob_t, k), ro, rt);
+            set_col3(rel_o, k, ro), set_col3(rel_t, k, rt);
+        }
+    }
+    __syncthreads();
+}
+
+// Pose 0 of the window model under updateImuError's global2relative (ContinuousTrajectory.h:606): every evaluation replaces the relative
+// pose 0 by the global pose 0 the chain just derived from it, p <- g(p) with g = (log(I exp(o)), 0 + I t).  Evaluation j of a batch
+// starts from g^j(p0).  g reaches a fixed point (or a short cycle) after one or two applications, so the orbit is followed until it
+// repeats instead of j times.
+struct Pose0 {
+    Vec3 o, t;
+};
+__device__ __forceinline__ Pose0 pose0_round_trip(const Pose0 p) {
+    Mat3 R = Mat3::identity();
+    Vec3 T{0, 0, 0};
+    Vec3 go, gt;
+    chain_step(R, T, p.o, p.t, go, gt);
+    return Pose0{go, gt};
+}
+__device__ __forceinline__ bool same_bits(const Pose0& a, const Pose0& b) {
+    return a.o.x == b.o.x && a.o.y == b.o.y && a.o.z == b.o.z && a.t.x == b.t.x && a.t.y == b.t.y && a.t.z == b.t.z;
+}
+__device__ Pose0 pose0_orbit(Pose0 p0, int j) {
+    constexpr int kHist = 6;
+    Pose0 hist[kHist];
+    hist[0] = p0;
+    Pose0 p = p0;
+    for (int i = 1; i <= j; ++i) {
+        p = pose0_round_trip(p);
+        if (i < kHist) {
+            for (int q = 0; q < i; ++q)
+                if (same_bits(hist[q], p)) {  // the orbit is periodic from q on with period i - q
+                    const int L = i - q;
+                    return hist[q + (j - q) % L];
+                }
+            hist[i] = p;
+        }
+    }
+    return p;
+}
+
+// additional rows of the CURRENT chain in LDS -> rows[0 .. extra); the window model's updateImuError runs global2relative first
+__device__ void wave_extra_rows(const LoopModel& m, double* rel_o, double* rel_t, const double* glob_o, const double* glob_t, double* rows) {
+    const int lane = threadIdx.x;
+    if (m.extra <= 0) return;
+    if (m.model == 1) {
+        wave_global_to_relative(m.n, glob_o, glob_t, rel_o, rel_t);
+        for (int k = 1 + lane; k < m.n; k += kWave) rows[k - 1] = imu_row(k, m.n, m.stamps, m.fhw, m.traj_time, m.imu, glob_o, glob_t, col3(rel_o, k));
+    } else {
+        int at = 0;
+        if (m.key.use_gravity) {
+            for (int k = lane; k < m.n; k += kWave) rows[k] = gravity_row(k, m.key, col3(glob_o, k));
+            at = m.n;
+        }
+        if (m.key.use_odometry)
+            for (int k = 1 + lane; k < m.n; k += kWave) rows[at + k - 1] = odometry_row(k, m.key, col3(rel_o, k), col3(rel_t, k));
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void load_state(const double* st, int n, double* rel_o, double* rel_t, double* glob_o, double* glob_t) {
+    for (int i = threadIdx.x; i < 3 * n; i += kWave) rel_o[i] = st[i], rel_t[i] = st[3 * n + i], glob_o[i] = st[6 * n + i], glob_t[i] = st[9 * n + i];
+    __syncthreads();
+}
+__device__ __forceinline__ void store_state(double* st, int n, const double* rel_o, const double* rel_t, const double* glob_o, const double* glob_t) {
+    for (int i = threadIdx.x; i < 3 * n; i += kWave) st[i] = rel_o[i], st[3 * n + i] = rel_t[i], st[6 * n + i] = glob_o[i], st[9 * n + i] = glob_t[i];
+}
+// Poses::setParamsFromVector (Poses.h:72-76): pose 0 is not a parameter
+__device__ __forceinline__ void set_params_lds(int n, const double* p, double* rel_o, double* rel_t) {
+    for (int i = threadIdx.x; i < 3 * (n - 1); i += kWave) rel_o[3 + i] = p[i], rel_t[3 + i] = p[3 * (n - 1) + i];
+    __syncthreads();
+}
+__device__ __forceinline__ void store_ctrl(double* ctrl, int n, const double* glob_o, const double* glob_t) {
+    for (int i = threadIdx.x; i < 3 * n; i += kWave) {
+        const int k = i / 3, c = i - 3 * k;
+        ctrl[6 * k + c] = glob_o[i], ctrl[6 * k + 3 + c] = glob_t[i];
+    }
+}
+
+struct ChainLds {
+    double *rel_o, *rel_t, *glob_o, *glob_t, *E, *R, *par, *org, *rows;
+};
+__device__ __forceinline__ ChainLds carve(double* sm, int n, int P) {
+    ChainLds c;
+    c.rel_o = sm, c.rel_t = sm + 3 * n, c.glob_o = sm + 6 * n, c.glob_t = sm + 9 * n, c.E = sm + 12 * n, c.R = sm + 21 * n;
+    c.par = sm + 30 * n, c.org = c.par + P, c.rows = c.org + P;
+    return c;
+}
+size_t chain_lds_bytes(const LoopModel& m) { return (30 * (size_t)m.n + 2 * (size_t)m.P + (size_t)(m.extra > 0 ? m.extra : 1)) * sizeof(double); }
+
+// iteration start (:72-75) on the chain held in LDS: paramVec = getPoseParameters(); updateGlobalPoints re-chains the window model (the
+// keyframe model did in setPoseParameters); ctrl0 = the global poses of the base table
+__device__ void begin_body(const LoopModel& m, const ChainLds& c, double* __restrict__ state0, double* __restrict__ paramVec, double* __restrict__ ctrl0) {
+    for (int i = threadIdx.x; i < 3 * (m.n - 1); i += kWave) paramVec[i] = c.rel_o[3 + i], paramVec[3 * (m.n - 1) + i] = c.rel_t[3 + i];
+    if (m.model == 1) {
+        wave_relative_to_global(m.n, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.E, c.R);
+        store_state(state0, m.n, c.rel_o, c.rel_t, c.glob_o, c.glob_t);
+    }
+    store_ctrl(ctrl0, m.n, c.glob_o, c.glob_t);
+}
+__global__ __launch_bounds__(kWave) void k_loop_begin(const LoopModel m, double* __restrict__ state0, double* __restrict__ paramVec, double* __restrict__ ctrl0,
+                                                      LoopFlags* __restrict__ flags) {
+    extern __shared__ double sm[];
+    if (flags->stop != 0) return;
+    if (threadIdx.x == 0) flags->nan = 0;
+    const ChainLds c = carve(sm, m.n, m.P);
+    load_state(state0, m.n, c.rel_o, c.rel_t, c.glob_o, c.glob_t);
+    begin_body(m, c, state0, paramVec, ctrl0);
+}
+
+// One workgroup (= one wave) per evaluation of the batch.  Evaluations of a batch depend on each other only through relative pose 0 of
+// the window model with IMU rows (pose0_orbit); everything else an evaluation reads is the incoming state and its own parameters.
+__global__ __launch_bounds__(kWave) void k_loop_chain(const LoopModel m, int mode, const double* __restrict__ state_in, double* __restrict__ state_out,
+                                                      const double* __restrict__ paramVec, const double* __restrict__ step, double increment,
+                                                      double* __restrict__ ctrl, double* __restrict__ extra, const LoopFlags* __restrict__ flags) {
+    extern __shared__ double sm[];
+    if (flags->stop != 0 || (mode == 1 && flags->nan != 0)) return;
+    const int n = m.n, P = m.P, a = m.extra > 0 ? m.extra : 0;
+    const int b = blockIdx.x, B = gridDim.x;
+    const ChainLds c = carve(sm, n, P);
+    load_state(state_in, n, c.rel_o, c.rel_t, c.glob_o, c.glob_t);
+    const bool carries = m.model == 1 && a > 0;  // updateImuError's global2relative rewrites relative pose 0 in every evaluation
+    const Pose0 p_in{col3(c.rel_o, 0), col3(c.rel_t, 0)};
+    double* my_ctrl = ctrl + (size_t)b * n * 6;
+    double* my_rows = extra + (size_t)b * a;
+    bool evaluate;
+    if (mode == 0) {
+        // evaluation 0 (:99) is the chain as loop_begin left it
+        if (b == 0) store_ctrl(my_ctrl, n, c.glob_o, c.glob_t);
+        // its additional rows; the window model's round trip also decides `origin` (:204 reads the parameters AFTER it), so every
+        // evaluation of that model repeats it
+        if (b == 0 || carries) {
+            wave_extra_rows(m, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.rows);
+            if (b == 0)
+                for (int i = threadIdx.x; i < a; i += kWave) my_rows[i] = c.rows[i];
+        }
+        // origin = getPoseParameters(); loop = origin, loop[k] += h for evaluation k + 1 (:209-212)
+        for (int i = threadIdx.x; i < 3 * (n - 1); i += kWave) {
+            const double o = c.rel_o[3 + i], t = c.rel_t[3 + i];
+            c.org[i] = o, c.org[3 * (n - 1) + i] = t;
+            c.par[i] = o, c.par[3 * (n - 1) + i] = t;
+        }
+        __syncthreads();
+        if (b > 0 && threadIdx.x == 0) c.par[b - 1] += increment;
+        __syncthreads();
+        evaluate = b > 0;
+    } else {
+        // trial k = b + 1: raw + 0.1 k step (:160)
+        for (int i = threadIdx.x; i < P; i += kWave) c.par[i] = paramVec[i] + 0.1 * (double)(b + 1) * step[i];
+        __syncthreads();
+        evaluate = true;
+    }
+    if (evaluate) {
+        if (carries) {  // relative pose 0 as the b evaluations of this batch that ran before this one left it
+            if (threadIdx.x == 0) {
+                const Pose0 p = pose0_orbit(p_in, b);
+                set_col3(c.rel_o, 0, p.o), set_col3(c.rel_t, 0, p.t);
+            }
+            __syncthreads();
+        }
+        set_params_lds(n, c.par, c.rel_o, c.rel_t);
+        wave_relative_to_global(n, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.E, c.R);
+        store_ctrl(my_ctrl, n, c.glob_o, c.glob_t);
+        wave_extra_rows(m, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.rows);
+        for (int i = threadIdx.x; i < a; i += kWave) my_rows[i] = c.rows[i];
+    }
+    if (b == B - 1) {
+        // the state the serial loop leaves behind: the last evaluation of the batch; the Jacobian batch then restores the parameters (:231)
+        if (mode == 0) set_params_lds(n, c.org, c.rel_o, c.rel_t);
+        store_state(state_out, n, c.rel_o, c.rel_t, c.glob_o, c.glob_t);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_loop_scatter_extra(const double* __restrict__ extra, int B, int a, double* __restrict__ E, int64_t ldE, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * a) return;
+    const int b = i / a, r = i - b * a;
+    E[(size_t)b * ldE + M + r] = extra[i];
+}
+
+// Gauss-Jordan with partial pivoting on [A | I] in LDS, the element operations of host_math.cpp's lm_solve (serial branch) one to one.
+// Lane = column of the augmented matrix (row-major in LDS: a row is a conflict-free access), wave w owns the rows r = w (mod kSolveWaves).
+// A pivot step is one round of LDS reads (pivot column for the search and as multipliers, the two rows that swap, the wave's own rows),
+// one barrier, arithmetic in registers, one round of writes, one barrier: the search and the pivot row are computed redundantly by
+// every wave, so nothing is exchanged between waves but the matrix itself.  Multipliers reach the lanes through v_readlane (the lane
+// that read M[r][c0] is lane r).  Columns of A left of the pivot hold finished entries nobody reads again; they are updated along.
+constexpr int kSolveWaves = 8, kSolveRows = kLoopSolveMaxP / kSolveWaves;  // rows per wave (upper bound)
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// max over the wave of values >= 0 (or the sentinel -1) without the LDS crossbar: DPP row shifts and row broadcasts (an inclusive
+// max-scan whose last lane holds the maximum); lanes a step does not reach see 0, which never exceeds a real maximum
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max_nonneg(double v) {
+    double o;
+    o = dpp_mov_f64<0x111, 0xf>(v), v = o > v ? o : v;  // row_shr:1
+    o = dpp_mov_f64<0x112, 0xf>(v), v = o > v ? o : v;  // row_shr:2
+    o = dpp_mov_f64<0x114, 0xf>(v), v = o > v ? o : v;  // row_shr:4
+    o = dpp_mov_f64<0x118, 0xf>(v), v = o > v ? o : v;  // row_shr:8
+    o = dpp_mov_f64<0x142, 0xa>(v), v = o > v ? o : v;  // row_bcast:15 -> rows 1 and 3
+    o = dpp_mov_f64<0x143, 0xc>(v), v = o > v ? o : v;  // row_bcast:31 -> rows 2 and 3
+    return readlane_f64(v, 63);
+}
+template <int kColsPerLane>
+__global__ __launch_bounds__(kSolveWaves* kWave) void k_loop_lm_step(const double* __restrict__ Hp, int P, double lambda, double alpha, double max_step,
+                                                                      double* __restrict__ step, LoopFlags* __restrict__ flags) {
+    extern __shared__ double sm[];
+    if (flags->stop != 0) return;
+    const int W = 2 * P, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, n1 = P + 1;
+    double* M = sm;                    // P x W row-major: [A | inv]
+    double* g = sm + (size_t)P * W;    // P
+    for (int r = wave; r < P; r += kSolveWaves)
+#pragma unroll
+        for (int q = 0; q < kColsPerLane; ++q) {
+            const int c = lane + q * kWave;
+            if (c < W) {
+                double v;
+                if (c < P) {  // H(r, c) = Hp[c * n1 + r] (column-major), damped on the diagonal (:110)
+                    v = Hp[(size_t)c * n1 + r];
+                    if (r == c) v += lambda;
+                } else {
+                    v = (c - P) == r ? 1.0 : 0.0;
+                }
+                M[(size_t)r * W + c] = v;
+            }
+        }
+    if (wave == 0 && lane < P) g[lane] = Hp[(size_t)P * n1 + lane];
+    __syncthreads();
+    for (int c0 = 0; c0 < P; ++c0) {
+        // ---- reads of the state before the step ----
+        const bool in = lane >= c0 && lane < P;
+        const double fcol = lane < P ? M[(size_t)lane * W + c0] : 0.0;  // lane = row: the pivot column
+        double x[kSolveRows][kColsPerLane];
+#pragma unroll
+        for (int j = 0; j < kSolveRows; ++j) {
+            const int r = wave + j * kSolveWaves;
+#pragma unroll
+            for (int q = 0; q < kColsPerLane; ++q) {
+                const int c = lane + q * kWave;
+                x[j][q] = (r < P && c < W) ? M[(size_t)r * W + c] : 0.0;
+            }
+        }
+        // first strict maximum of |A[r][c0]| over r >= c0 (a NaN never wins; a NaN on the diagonal keeps the diagonal)
+        double v = in ? fabs(fcol) : -1.0;
+        if (isnan(v)) v = -1.0;
+        const double mx = wave_max_nonneg(v);
+        const unsigned long long hit = __ballot(in && v == mx);
+        const double diag = readlane_f64(fcol, c0);
+        const int piv = isnan(diag) || hit == 0ull ? c0 : (int)(__ffsll((long long)hit) - 1);
+        const double d = readlane_f64(fcol, piv);    // the pivot
+        const double f_swapped = diag;               // multiplier of the row that moves from c0 to piv
+        double top[kColsPerLane], srow[kColsPerLane];
+#pragma unroll
+        for (int q = 0; q < kColsPerLane; ++q) {
+            const int c = lane + q * kWave;
+            top[q] = c < W ? M[(size_t)c0 * W + c] : 0.0;
+            const double pv = c < W ? M[(size_t)piv * W + c] : 0.0;
+            srow[q] = pv / d;  // the scaled pivot row, which becomes row c0
+        }
+        __syncthreads();  // every read of the old state is done
+        // ---- writes: row c0 <- scaled pivot row; row piv <- old row c0, updated; all other rows updated ----
+#pragma unroll
+        for (int j = 0; j < kSolveRows; ++j) {
+            const int r = wave + j * kSolveWaves;
+            if (r >= P) continue;
+            const bool is_top = r == c0, is_swapped = r == piv && piv != c0;
+            const double f = is_swapped ? f_swapped : readlane_f64(fcol, r);
+#pragma unroll
+            for (int q = 0; q < kColsPerLane; ++q) {
+                const int c = lane + q * kWave;
+                if (c >= W) continue;
+                const double old = is_swapped ? top[q] : x[j][q];
+                const double upd = f == 0.0 ? old : old - f * srow[q];
+                M[(size_t)r * W + c] = is_top ? srow[q] : upd;
+            }
+        }
+        __syncthreads();
+    }
+    // :113 step = (-alpha H^-1) g, row by row (lane = row; P <= 64), then the NaN test and the clamp of :116-128 in registers
+    if (wave != 0) return;
+    double s = 0.0;
+    if (lane < P)
+        for (int j = 0; j < P; ++j) s += (-alpha * M[(size_t)lane * W + P + j]) * g[j];
+    if (__ballot(lane < P && isnan(s)) != 0ull) {
+        if (lane == 0) flags->nan = 1;
+        return;
+    }
+    double mx = lane < P ? s : -INFINITY, mn = lane < P ? s : INFINITY;  // max / min do not depend on the order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
+        mx = mx < a ? a : mx;
+        mn = c < mn ? c : mn;
+    }
+    const double neg = -mn;
+    const double max_elem = mx < neg ? neg : mx;  // std::max(mx, -mn)
+    if (max_elem > max_step) s = (max_step / max_elem) * s;
+    if (lane < P) step[lane] = s;
+}
+
+// the same tail for a step the host solved (P > 64): one wave, NaN test and extrema as wave reductions (max / min are order independent)
+__global__ __launch_bounds__(kWave) void k_loop_step_finish(int P, double max_step, double* __restrict__ step, LoopFlags* __restrict__ flags) {
+    if (flags->stop != 0) return;
+    const int lane = threadIdx.x;
+    bool any_nan = false;
+    double mx = -INFINITY, mn = INFINITY;
+    for (int i = lane; i < P; i += kWave) {
+        const double v = step[i];
+        any_nan = any_nan || isnan(v);
+        mx = mx < v ? v : mx;
+        mn = v < mn ? v : mn;
+    }
+    if (__ballot(any_nan) != 0ull) {
+        if (lane == 0) flags->nan = 1;
+        return;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_xor(mx, o), b = __shfl_xor(mn, o);
+        mx = mx < a ? a : mx;
+        mn = b < mn ? b : mn;
+    }
+    const double neg = -mn;
+    const double max_elem = mx < neg ? neg : mx;  // std::max(mx, -mn)
+    if (max_elem > max_step)
+        for (int i = lane; i < P; i += kWave) step[i] = (max_step / max_elem) * step[i];
+}
+
+__global__ __launch_bounds__(kWave) void k_loop_finish(const LoopModel m, const double* __restrict__ state_jac, const double* __restrict__ state_trial,
+                                                       double* __restrict__ state0, double* __restrict__ paramVec, const double* __restrict__ step,
+                                                       const double* __restrict__ Hp, const double* __restrict__ errs, int fixed_iters, double epsilon,
+                                                       IterResult* __restrict__ result, LoopFlags* __restrict__ flags, double* __restrict__ ctrl0, int chain_next) {
+    extern __shared__ double sm[];
+    if (flags->stop != 0) return;
+    const int n = m.n, P = m.P;
+    const ChainLds c = carve(sm, n, P);
+    __shared__ int s_best, s_stop;
+    __shared__ double s_norm;
+    const double error0 = Hp[(size_t)P * (P + 1) + P];  // e0^T e0 (:101)
+    if (flags->nan != 0) {
+        // :116-122 setPoseParameters(paramVec); break -- on the state the Jacobian batch left
+        load_state(state_jac, n, c.rel_o, c.rel_t, c.glob_o, c.glob_t);
+        set_params_lds(n, paramVec, c.rel_o, c.rel_t);
+        if (m.model == 2) wave_relative_to_global(n, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.E, c.R);
+        store_state(state0, n, c.rel_o, c.rel_t, c.glob_o, c.glob_t);
+        if (threadIdx.x == 0) {
+            result->stop = 2 /* DMSA_STOP_NAN */, result->best_k = 0, result->error0 = error0, result->step_norm = 0.0;
+            flags->stop = 2;
+        }
+        return;
+    }
+    // the step and the nine trial errors through LDS (coalesced loads; the sums below are serial chains on one lane)
+    for (int i = threadIdx.x; i < P; i += kWave) c.org[i] = step[i];
+    if (threadIdx.x < 9) c.E[threadIdx.x] = errs[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double min_error = error0;
+        int best = 0;
+        for (int k = 1; k < 10; ++k)
+            if (c.E[k - 1] < min_error) min_error = c.E[k - 1], best = k;
+        double ss = 0.0;
+        for (int i = 0; i < P; ++i) ss += c.org[i] * c.org[i];
+        const double norm = sqrt(ss);
+        int stop = 0;
+        if (best == 0 && !fixed_iters)
+            stop = 3;  // DMSA_STOP_NO_IMPROVEMENT: the set stays at raw + 0.9 step, not restored (:130-134)
+        else if (norm < epsilon && !fixed_iters)
+            stop = 4;  // DMSA_STOP_EPSILON (:139-143), after setPoseParameters
+        s_best = best, s_stop = stop, s_norm = norm;
+        result->stop = stop, result->best_k = best, result->error0 = error0, result->step_norm = norm;
+        if (stop != 0) flags->stop = stop;
+    }
+    __syncthreads();
+    load_state(state_trial, n, c.rel_o, c.rel_t, c.glob_o, c.glob_t);
+    if (s_stop != 3) {
+        // :136 setPoseParameters(best parameters): raw + 0.1 k step for the winning k, raw when no trial won (fixed iterations only)
+        const int best = s_best;
+        for (int i = threadIdx.x; i < P; i += kWave) c.par[i] = best > 0 ? paramVec[i] + 0.1 * (double)best * c.org[i] : paramVec[i];
+        __syncthreads();
+        set_params_lds(n, c.par, c.rel_o, c.rel_t);
+        if (m.model == 2) wave_relative_to_global(n, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.E, c.R);
+    }
+    store_state(state0, n, c.rel_o, c.rel_t, c.glob_o, c.glob_t);
+    // the loop goes on: the start of the next iteration (what k_loop_begin does for the first) right here, one launch less on the
+    // critical path.  Not after the last iteration: decentralize() reads the global poses of the last evaluated trial.
+    if (s_stop == 0 && chain_next) {
+        __syncthreads();
+        begin_body(m, c, state0, paramVec, ctrl0);
+    }
+}
+
+}  // namespace
+
+void launch_loop_begin(const LoopModel& m, double* state0, double* paramVec, double* ctrl0, LoopFlags* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_loop_begin, dim3(1), dim3(kWave), chain_lds_bytes(m), s, m, state0, paramVec, ctrl0, flags);
+}
+void launch_loop_chain(const LoopModel& m, int mode, const double* state_in, double* state_out, const double* paramVec, const double* step, double increment,
+                       double* ctrl, double* extra, const LoopFlags* flags, hipStream_t s) {
+    const int B = mode == 0 ? 1 + m.P : 9;
+    hipLaunchKernelGGL(k_loop_chain, dim3(B), dim3(kWave), chain_lds_bytes(m), s, m, mode, state_in, state_out, paramVec, step, increment, ctrl, extra, flags);
+}
+void launch_loop_scatter_extra(const double* extra, int B, int a, double* E, int64_t ldE, int M, hipStream_t s) {
+    if (a <= 0 || B <= 0) return;
+    hipLaunchKernelGGL(k_loop_scatter_extra, dim3((B * a + 255) / 256), dim3(256), 0, s, extra, B, a, E, ldE, M);
+}
+void launch_loop_lm_step(const double* Hp, int P, double lambda, double alpha, double max_step, double* step, LoopFlags* flags, hipStream_t s) {
+    const size_t bytes = (2 * (size_t)P * P + (size_t)P) * sizeof(double);
+    static bool raised = false;
+    if (bytes > 48 * 1024 && !raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_loop_lm_step<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        raised = true;
+    }
+    if (2 * P <= kWave)
+        hipLaunchKernelGGL(k_loop_lm_step<1>, dim3(1), dim3(kSolveWaves * kWave), bytes, s, Hp, P, lambda, alpha, max_step, step, flags);
+    else
+        hipLaunchKernelGGL(k_loop_lm_step<2>, dim3(1), dim3(kSolveWaves * kWave), bytes, s, Hp, P, lambda, alpha, max_step, step, flags);
+}
+void launch_loop_step_finish(int P, double max_step, double* step, LoopFlags* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_loop_step_finish, dim3(1), dim3(64), 0, s, P, max_step, step, flags);
+}
+void launch_loop_finish(const LoopModel& m, const double* state_jac, const double* state_trial, double* state0, double* paramVec, const double* step,
+                        const double* Hp, const double* trial_errs, int fixed_iters, double epsilon, IterResult* result, LoopFlags* flags, double* ctrl0,
+                        int chain_next, hipStream_t s) {
+    hipLaunchKernelGGL(k_loop_finish, dim3(1), dim3(kWave), chain_lds_bytes(m), s, m, state_jac, state_trial, state0, paramVec, step, Hp, trial_errs, fixed_iters,
+                       epsilon, result, flags, ctrl0, chain_next);
+}
+
+}  // namespace dmsa
