@@ -261,6 +261,7 @@ def load_library() -> C.CDLL:
         "dmsa_leaf_segments": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_int64, C.c_uint32, c_int32_p, c_int32_p, c_int32_p]),
         "dmsa_serial_fallback_sums": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_uint64)]),
         "dmsa_lm_solve": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.c_double, C.c_int32, c_double_p]),
+        "dmsa_lm_solve_device": (C.c_int, [vp, c_double_p, c_double_p, C.c_int32, C.c_double, C.c_double, c_double_p, c_int32_p]),
         "dmsa_neighbourhood_ranges": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "dmsa_submap_poses": (C.c_int, [C.c_int32, c_double_p, c_double_p, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p]),
         "dmsa_update_poses_from_submap": (C.c_int, [C.c_int32, c_double_p, c_double_p, C.c_int32, C.c_int32, c_double_p, c_double_p]),
@@ -305,7 +306,7 @@ EXPORTED_SYMBOLS = (
     "dmsa_create dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
     "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
     "dmsa_set_params dmsa_additional_errors dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
-    "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_detmath_eval dmsa_lm_solve dmsa_serial_fallback_sums dmsa_sort_pairs dmsa_leaf_segments dmsa_neighbourhood_ranges dmsa_submap_poses dmsa_update_poses_from_submap dmsa_optimize_resident dmsa_get_poses "
+    "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_detmath_eval dmsa_lm_solve dmsa_lm_solve_device dmsa_serial_fallback_sums dmsa_sort_pairs dmsa_leaf_segments dmsa_neighbourhood_ranges dmsa_submap_poses dmsa_update_poses_from_submap dmsa_optimize_resident dmsa_get_poses "
     "dmsa_select_static_points dmsa_get_overlap dmsa_random_grid_downsampling dmsa_radius_exists dmsa_preprocess_scan "
     "dmsa_imu_buffer_create dmsa_imu_buffer_destroy dmsa_imu_buffer_add dmsa_imu_buffer_closest dmsa_imu_buffer_state dmsa_traj_dims dmsa_traj_grids "
     "dmsa_traj_tform_indices dmsa_traj_transfer_imu dmsa_traj_preint_factors dmsa_traj_update_initial_guess dmsa_traj_submap_gravity_estimate "

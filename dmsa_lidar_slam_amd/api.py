@@ -228,6 +228,18 @@ class DmsaOptimizer:
                                                  C.byref(nl)), "dmsa_leaf_segments")
         return of_pos, start[:nl.value + 1]
 
+    def lmSolveDevice(self, H_damped, g, alpha: float, max_step: float = float("inf")):
+        """The LM step of DmsaOptimizer.h:107-128 as the device-resident loop computes it -- test hook.  Returns (step, has_nan)."""
+        H = np.ascontiguousarray(H_damped, np.float64)
+        gv = np.ascontiguousarray(g, np.float64)
+        P = gv.size
+        assert H.shape == (P, P)
+        Hc = np.ascontiguousarray(H.T)  # column-major
+        step, nan = np.zeros(P), C.c_int32(0)
+        self._check(self._lib.dmsa_lm_solve_device(self._ctx, capi.ptr(Hc, C.c_double), capi.ptr(gv, C.c_double), P, float(alpha), float(max_step),
+                                                   capi.ptr(step, C.c_double), C.byref(nan)), "dmsa_lm_solve_device")
+        return step, bool(nan.value)
+
     def serialFallbackSums(self, reset: bool = False) -> int:
         """(Gaussian, sub-batch) double sums that were chained member by member because the exactness test of the parallel sum failed."""
         v = C.c_uint64(0)

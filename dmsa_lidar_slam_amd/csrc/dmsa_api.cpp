@@ -222,6 +222,7 @@ struct dmsa_ctx {
     bool fit_guess_valid = false;  // serial_counts of the previous voxelisation may size this one's speculative fit launches
     SerialCounts serial_counts{0, 0, 0, 0};
     bool E_is_jacobian = false;  // the matrix-core normal equations (P > 64) rewrote the residual batch as the columns of [J | e0]
+    bool aabb_fresh = false;  // d_aabb / the zeroed counters belong to the current d_global (launch_transform_aabb ran last)
     const float* base_table = nullptr;  // the pose table d_global was computed with (the fit re-derives the members' global coordinates from it)
     // ---- device-resident optimizeSet loop (loop_kernels.h) ----
     LoopModel loop_model{};      // built at upload: device pointers to the model's constants
@@ -233,6 +234,8 @@ struct dmsa_ctx {
     DevBuf d_table0;       // the base pose table (own buffer: the Jacobian batch's tables are written beside the fit that still reads it)
     DevBuf d_loop_extra;   // additional rows of the two batches: [1+P][a] | [9][a]
     DevBuf d_loop_iter;    // LoopFlags | IterResult[num_iter]
+    DevBuf d_panel_work;   // scratch of the blocked device solve for P > 64 (published panels, inverse, hand-over flags)
+    uint32_t panel_epoch = 0;
     IterResult* h_results = nullptr;  // pinned
     int h_results_cap = 0;
     // one extra device->host copy riding on the counts read-back of build_gaussians (the previous iteration's IterResult)
@@ -562,8 +565,10 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     {
         ScopedTimer tm(ctx, T_VOXEL);
         const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
-        launch_block_aabb(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts),
-                          ctx->stream);
+        if (!ctx->aabb_fresh)  // the device loop's fused transform already left the block bounds and cleared the counters
+            launch_block_aabb(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts),
+                              ctx->stream);
+        ctx->aabb_fresh = false;
         launch_lattice(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), nb, ctx->level_res[0], ctx->level_res[1], compress,
                        ctx->d_lattice.as<LatticeTable>(), prehist ? ctx->d_sort_tmp[0].p : nullptr, prehist ? ctx->d_sort_tmp[1].p : nullptr, ctx->stream);
         if (!speculate) {  // sync #1: tree depths select the radix-sort bit range (speculation reads them with the counts instead)
@@ -1294,6 +1299,25 @@ int device_tables(dmsa_ctx* ctx, int B, const double* d_ctrl, float* tables, flo
     return DMSA_OK;
 }
 
+// :107-128 on the device: one workgroup for P <= 64, column-block workgroups handing panels to each other beyond
+int device_lm_step(dmsa_ctx* ctx, const double* d_Hp, int P, double lambda, double alpha, double max_step, double* d_step, LoopFlags* d_flags) {
+    if (P <= kLoopSolveMaxP) {
+        launch_loop_lm_step(d_Hp, P, lambda, alpha, max_step, d_step, d_flags, ctx->stream);
+    } else {
+        const size_t bytes = loop_panel_solve_doubles(P) * 8;
+        if (bytes > ctx->d_panel_work.cap) {
+            HIPCHK(ctx->d_panel_work.ensure(bytes));
+            HIPCHK(hipMemsetAsync(ctx->d_panel_work.p, 0, ctx->d_panel_work.cap, ctx->stream));
+            ctx->panel_epoch = 0;
+        }
+        ctx->panel_epoch += 1;
+        if (ctx->panel_epoch == 0) ctx->panel_epoch = 1;
+        launch_loop_lm_panels(d_Hp, P, lambda, alpha, max_step, ctx->d_panel_work.as<double>(), ctx->panel_epoch, d_step, d_flags, ctx->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return DMSA_OK;
+}
+
 int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
     ScopedTimer total(ctx, T_TOTAL);
     const bool fixed = (ctx->flags & DMSA_FLAG_FIXED_ITERS) != 0;
@@ -1350,7 +1374,7 @@ int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep
         HIPCHK(hipMemsetAsync(ctx->d_loop_iter.p, 0, sizeof(LoopFlags) + (size_t)(num_iter + 1) * sizeof(IterResult), ctx->stream));
     }
     std::vector<double> Hp, H, g, step;
-    if (P > kLoopSolveMaxP) Hp.resize((size_t)(P + 1) * (P + 1)), H.resize((size_t)P * P), g.resize((size_t)P), step.resize((size_t)P);
+    if (P > kLoopPanelMaxP) Hp.resize((size_t)(P + 1) * (P + 1)), H.resize((size_t)P * P), g.resize((size_t)P), step.resize((size_t)P);
     // what the report says about the Gaussians belongs to the last iteration that really ran
     int last_M = 0, last_M1 = 0;
     int64_t last_Mm = 0;
@@ -1365,11 +1389,13 @@ int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep
             CHK(device_tables(ctx, 1, ctx->d_ctrl0.as<double>(), ctx->d_table0.as<float>(), nullptr, ctx->stream));
         }
         ctx->base_table = ctx->d_table0.as<float>();
-        if (ctx->model == MODEL_KEYFRAMES)
-            launch_transform_normals(ctx->d_local.as<float4>(), ctx->d_nlocal.as<float4>(), ctx->d_table0.as<float4>(), ctx->d_global.as<float4>(),
-                                     ctx->d_nglobal.as<float4>(), ctx->n, ctx->stream);
-        else
-            launch_transform(ctx->d_local.as<float4>(), ctx->d_table0.as<float4>(), ctx->d_global.as<float4>(), ctx->n, ctx->stream);
+        {
+            ScopedTimer tm(ctx, T_VOXEL);
+            launch_transform_aabb(ctx->d_local.as<float4>(), ctx->model == MODEL_KEYFRAMES ? ctx->d_nlocal.as<float4>() : nullptr, ctx->d_table0.as<float4>(),
+                                  ctx->d_global.as<float4>(), ctx->model == MODEL_KEYFRAMES ? ctx->d_nglobal.as<float4>() : nullptr, ctx->n,
+                                  ctx->d_aabb.as<float>(), ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts), ctx->stream);
+            ctx->aabb_fresh = true;
+        }
         // :99, :199-232 the 1 + P chains, rows and pose tables of the Jacobian batch: beside the voxelisation, they need nothing from it
         if (side != ctx->stream) {
             HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -1406,12 +1432,19 @@ int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep
         {
             ScopedTimer tm(ctx, T_NORMAL);
             HIPCHK(ctx->d_ne_partial.ensure((size_t)normal_equations_partial_doubles(rowsE, P) * 8));
-            launch_normal_equations(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, one_div_incr, ctx->d_ne_partial.as<double>(), ctx->d_Hp.as<double>(), ctx->stream);
+            // P <= 64: the block sums stay unreduced, the solve kernel adds them while it loads the matrix
+            launch_normal_equations(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, one_div_incr, ctx->d_ne_partial.as<double>(), ctx->d_Hp.as<double>(), ctx->stream,
+                                    P > kLoopSolveMaxP);
         }
         bool host_nan = false;
+        double* d_error0 = ctx->d_Hp.as<double>() + (size_t)P * (P + 1) + P;  // e0^T e0, element (P, P) of Hp
         if (P <= kLoopSolveMaxP) {
+            const NormalEqPartials q = normal_equations_partials(rowsE, P);
+            launch_loop_lm_step_partials(ctx->d_ne_partial.as<double>(), q.nsplit, q.nt, P, (double)s.lambda_diag, s.step_length_optim, s.max_step, d_step, d_flags,
+                                         d_error0, ctx->stream);
+        } else if (P <= kLoopPanelMaxP) {
             // :107-128 on the device
-            launch_loop_lm_step(ctx->d_Hp.as<double>(), P, (double)s.lambda_diag, s.step_length_optim, s.max_step, d_step, d_flags, ctx->stream);
+            CHK(device_lm_step(ctx, ctx->d_Hp.as<double>(), P, (double)s.lambda_diag, s.step_length_optim, s.max_step, d_step, d_flags));
         } else {
             if (Hp.size() > ctx->h_Hp_cap) {
                 if (ctx->h_Hp) (void)hipHostFree(ctx->h_Hp);
@@ -1452,10 +1485,10 @@ int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep
         {
             ScopedTimer tm(ctx, T_NORMAL);
             HIPCHK(ctx->d_sq_partial.ensure((size_t)std::max(squared_sums_partial_doubles(rowsE, 9), squared_sums_blocked_partial_doubles(rowsE, P, 9)) * 8));
-            launch_squared_sums_blocked(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
+            launch_squared_sums_blocked(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 9, ctx->d_sq_partial.as<double>(), nullptr, ctx->stream);  // block sums only
         }
-        launch_loop_finish(m, S1, S2, S0, d_param, d_step, ctx->d_Hp.as<double>(), ctx->d_sq_out.as<double>(), fixed ? 1 : 0, s.epsilon, d_results + iter, d_flags,
-                           ctx->d_ctrl0.as<double>(), iter + 1 < num_iter ? 1 : 0, ctx->stream);
+        launch_loop_finish(m, S1, S2, S0, d_param, d_step, d_error0, ctx->d_sq_partial.as<double>(), normal_equations_partials(rowsE, P).nsplit, fixed ? 1 : 0,
+                           s.epsilon, d_results + iter, d_flags, ctx->d_ctrl0.as<double>(), iter + 1 < num_iter ? 1 : 0, ctx->stream);
         HIPCHK(hipGetLastError());
         g_tl.mark("iteration enq");
         if (host_nan) break;  // the device takes the same decision; nothing more to enqueue
@@ -2076,6 +2109,30 @@ int dmsa_lm_solve(const double* H_damped, const double* g, int32_t P, double alp
         for (auto& x : th) x.join();
     };
     lm_solve(H_damped, g, P, alpha, step, &par);
+    return DMSA_OK;
+}
+
+int dmsa_lm_solve_device(dmsa_ctx* ctx, const double* H_damped, const double* g, int32_t P, double alpha, double max_step, double* step, int32_t* nan_out) {
+    if (!ctx || !H_damped || !g || !step || P < 1 || P > kLoopPanelMaxP) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    const int n1 = P + 1;
+    std::vector<double> Hp((size_t)n1 * n1, 0.0);  // the layout the normal-equation kernels leave: H | g in the last column (and row)
+    for (int j = 0; j < P; ++j)
+        for (int i = 0; i < P; ++i) Hp[(size_t)j * n1 + i] = H_damped[(size_t)j * P + i];
+    for (int i = 0; i < P; ++i) Hp[(size_t)P * n1 + i] = g[i], Hp[(size_t)i * n1 + P] = g[i];
+    DevBuf dHp, dstep, dflags;
+    HIPCHK(dHp.ensure(Hp.size() * 8));
+    HIPCHK(dstep.ensure((size_t)P * 8 + 8));
+    HIPCHK(dflags.ensure(sizeof(LoopFlags)));
+    HIPCHK(hipMemcpyAsync(dHp.p, Hp.data(), Hp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(dflags.p, 0, sizeof(LoopFlags), ctx->stream));
+    HIPCHK(hipMemsetAsync(dstep.p, 0, (size_t)P * 8, ctx->stream));
+    CHK(device_lm_step(ctx, dHp.as<double>(), P, 0.0, alpha, max_step, dstep.as<double>(), dflags.as<LoopFlags>()));
+    LoopFlags hf{};
+    HIPCHK(hipMemcpyAsync(step, dstep.p, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&hf, dflags.p, sizeof(hf), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (nan_out) *nan_out = hf.nan;
     return DMSA_OK;
 }
 

@@ -87,6 +87,9 @@ void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tabl
 void launch_detmath_eval(int fn, const double* x, const double* y, int64_t n, double* out, hipStream_t s);
 
 // ---- K2: PCL-exact voxel lattice + keys -----------------------------------------------------------------
+// updateGlobalPoints and the block bounds of the voxelisation that follows in one pass over the points (nlocal / nglobal null for the window model)
+void launch_transform_aabb(const float4* local, const float4* nlocal, const float4* table, float4* global, float4* nglobal, int64_t n, float* aabb, void* zero,
+                           size_t zero_bytes, hipStream_t s);
 // also clears `zero_bytes` (a multiple of 4) at `zero`: the counters of the iteration
 void launch_block_aabb(const float4* global, int64_t n, float* aabb /* nb x 8 */, void* zero, size_t zero_bytes, hipStream_t s);
 // sort_header0/1 (may be null): sort headers (radix_sort_dev.h) cleared on the side, for key kernels that count the sort digits
@@ -160,11 +163,18 @@ void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, c
                             const int2* fallback, int num_fallback, int big_n, double* E, int64_t ldE, hipStream_t s);
 // ---- K5: normal equations + squared-error sums -------------------------------------------------------------
 // Hp = [J | e0]^T [J | e0] of size (P+1)^2, col-major, J.col(k) = inv_h * (E[k+1] - E[0]) over `rows` rows
-void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s);
+// reduce = false leaves the block sums in `partial` for a consumer that adds them itself (loop_kernels.hip): element (i, j) of Hp is the sum
+// over sp < nsplit, in that order, of partial[((sp * nt + j / 32) * nt + i / 32) * 1024 + (j % 32) * 32 + i % 32]
+struct NormalEqPartials {
+    int nsplit, nt;
+};
+NormalEqPartials normal_equations_partials(int rows, int P);
+void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s, bool reduce = true);
 int normal_equations_partial_doubles(int rows, int P);
 void launch_squared_sums(const double* E, int64_t ldE, int rows, int B, double* partial, double* out, hipStream_t s);
 int squared_sums_partial_doubles(int rows, int B);
-// parity path: the same sums in the blocked row order of the normal equations (bit-identical to the oracle)
+// parity path: the same sums in the blocked row order of the normal equations (bit-identical to the oracle); out == nullptr leaves the block
+// sums of evaluation b at partial[b * nsplit + sp] (nsplit as normal_equations_partials) for a consumer that adds them in order
 void launch_squared_sums_blocked(const double* E, int64_t ldE, int rows, int P, int B, double* partial, double* out, hipStream_t s);
 int squared_sums_blocked_partial_doubles(int rows, int P, int B);
 

@@ -351,6 +351,65 @@ __global__ __launch_bounds__(256) void k_block_aabb(const float4* __restrict__ g
         aabb[(size_t)blockIdx.x * 8 + threadIdx.x] = v;
     }
 }
+// K0 + (a) in one pass: updateGlobalPoints writes the global points and leaves the bounds of every 1024-point block behind, so the
+// voxelisation does not read the 24 MB it was just handed again (same arithmetic as k_transform(_normals) and k_block_aabb).
+template <bool kNormals>
+__global__ __launch_bounds__(256) void k_transform_aabb(const float4* __restrict__ local, const float4* __restrict__ nlocal, const float4* __restrict__ table,
+                                                        float4* __restrict__ global, float4* __restrict__ nglobal, int64_t n, float* __restrict__ aabb,
+                                                        uint32_t* __restrict__ zero, int zero_words) {
+    __shared__ float s_red[4][6];
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < zero_words; i += 256) zero[i] = 0u;
+    const int64_t base = (int64_t)blockIdx.x * kAabbBlock;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int k = 0; k < kAabbBlock / 256; ++k) {
+        const int64_t i = base + threadIdx.x + 256 * k;
+        if (i < n) {
+            const float4 p = local[i];
+            const int row = __float_as_int(p.w);
+            const float4 r0 = table[3 * row], r1 = table[3 * row + 1], r2 = table[3 * row + 2];
+            const float3 g = apply_row3(r0, r1, r2, p.x, p.y, p.z);
+            global[i] = make_float4(g.x, g.y, g.z, 1.0f);
+            if (kNormals) {
+                const float4 v = nlocal[i];
+                nglobal[i] = make_float4(sum3f(r0.x * v.x, r0.y * v.y, r0.z * v.z), sum3f(r1.x * v.x, r1.y * v.y, r1.z * v.z),
+                                         sum3f(r2.x * v.x, r2.y * v.y, r2.z * v.z), 0.0f);
+            }
+            if (isfinite(g.x) && isfinite(g.y) && isfinite(g.z)) {
+                mn[0] = fminf(mn[0], g.x), mn[1] = fminf(mn[1], g.y), mn[2] = fminf(mn[2], g.z);
+                mx[0] = fmaxf(mx[0], g.x), mx[1] = fmaxf(mx[1], g.y), mx[2] = fmaxf(mx[2], g.z);
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = wave_allminf(mn[a]);
+        mx[a] = wave_allmaxf(mx[a]);
+    }
+    if (lane == 0)
+        for (int a = 0; a < 3; ++a) s_red[wave][a] = mn[a], s_red[wave][3 + a] = mx[a];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s_red[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, s_red[w][threadIdx.x]) : fmaxf(v, s_red[w][threadIdx.x]);
+        aabb[(size_t)blockIdx.x * 8 + threadIdx.x] = v;
+    }
+}
+void launch_transform_aabb(const float4* local, const float4* nlocal, const float4* table, float4* global, float4* nglobal, int64_t n, float* aabb, void* zero,
+                           size_t zero_bytes, hipStream_t s) {
+    if (n <= 0) {
+        if (zero_bytes) (void)hipMemsetAsync(zero, 0, zero_bytes, s);
+        return;
+    }
+    const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
+    if (nlocal)
+        hipLaunchKernelGGL(k_transform_aabb<true>, dim3(nb), dim3(256), 0, s, local, nlocal, table, global, nglobal, n, aabb, static_cast<uint32_t*>(zero),
+                           (int)(zero_bytes / 4));
+    else
+        hipLaunchKernelGGL(k_transform_aabb<false>, dim3(nb), dim3(256), 0, s, local, nlocal, table, global, nglobal, n, aabb, static_cast<uint32_t*>(zero),
+                           (int)(zero_bytes / 4));
+}
 void launch_block_aabb(const float4* global, int64_t n, float* aabb, void* zero, size_t zero_bytes, hipStream_t s) {
     if (n <= 0) {
         if (zero_bytes) (void)hipMemsetAsync(zero, 0, zero_bytes, s);
@@ -2538,39 +2597,42 @@ __device__ __forceinline__ double ne_col(const double* __restrict__ E, int64_t l
     return inv_h * (E[(size_t)(k + 1) * ldE + r] - e0);
 }
 
-__global__ __launch_bounds__(256) void k_normal_eq_partial(const double* __restrict__ E, int64_t ldE, int rows, int P, double inv_h, int rs, int nt,
-                                                           double* __restrict__ partial) {
+// 32 x 32 outputs per workgroup, one per thread (1024 threads); the 32 rows x 32 columns of both operands of a stage are one element per
+// thread, fetched into registers one stage ahead of the products that consume them.  Every output sums its row block row by row.
+__global__ __launch_bounds__(1024) void k_normal_eq_partial(const double* __restrict__ E, int64_t ldE, int rows, int P, double inv_h, int rs, int nt,
+                                                            double* __restrict__ partial) {
     __shared__ double s_a[kNeTile][kNeTile + 1];
     __shared__ double s_b[kNeTile][kNeTile + 1];
     const int tile = blockIdx.x, ti = tile % nt, tj = tile / nt;
     const int split = blockIdx.y;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 2 x 2 outputs each
-    double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // output (column ti*32 + tx of A', column tj*32 + ty)
+    const int kk = threadIdx.x >> 5, rr = threadIdx.x & 31;  // staging: column kk, row rr of the stage
+    double c = 0.0;
     const int r_begin = split * rs, r_end = min(rows, r_begin + rs);
-    for (int r0 = r_begin; r0 < r_end; r0 += kNeTile) {
-        // stage 32 columns x 32 rows of both operands (row index fastest in global memory -> coalesced)
-        for (int q = threadIdx.x; q < kNeTile * kNeTile; q += 256) {
-            const int kk = q / kNeTile, rr = q % kNeTile;
-            const int r = r0 + rr;
-            const bool in = r < r_end;
-            const double va = in ? ne_col(E, ldE, P, inv_h, ti * kNeTile + kk, r, rows) : 0.0;
-            s_a[kk][rr] = va;
-            s_b[kk][rr] = ti == tj ? va : (in ? ne_col(E, ldE, P, inv_h, tj * kNeTile + kk, r, rows) : 0.0);  // diagonal tiles: one load serves both
-        }
-        __syncthreads();
+    // the whole row block of this workgroup (rs = 256 rows = 8 stages for P <= 64) is fetched up front: one memory latency instead of one
+    // per stage
+    constexpr int kStages = 8;
+    double na[kStages], nb[kStages];
+    auto fetch = [&](int r0, double& a, double& b) {
+        const int r = r0 + rr;
+        const bool in = r < r_end;
+        a = in ? ne_col(E, ldE, P, inv_h, ti * kNeTile + kk, r, rows) : 0.0;
+        b = ti == tj ? a : (in ? ne_col(E, ldE, P, inv_h, tj * kNeTile + kk, r, rows) : 0.0);  // diagonal tiles: one load serves both
+    };
+    for (int g0 = r_begin; g0 < r_end; g0 += kStages * kNeTile) {
+#pragma unroll
+        for (int u = 0; u < kStages; ++u) fetch(g0 + u * kNeTile, na[u], nb[u]);
+#pragma unroll
+        for (int u = 0; u < kStages; ++u) {
+            if (g0 + u * kNeTile >= r_end) break;
+            s_a[kk][rr] = na[u], s_b[kk][rr] = nb[u];
+            __syncthreads();
 #pragma unroll 8
-        for (int rr = 0; rr < kNeTile; ++rr) {
-            const double a0 = s_a[2 * tx][rr], a1 = s_a[2 * tx + 1][rr];
-            const double b0 = s_b[2 * ty][rr], b1 = s_b[2 * ty + 1][rr];
-            c00 += a0 * b0, c01 += a0 * b1, c10 += a1 * b0, c11 += a1 * b1;
+            for (int q = 0; q < kNeTile; ++q) c += s_a[tx][q] * s_b[ty][q];
+            __syncthreads();
         }
-        __syncthreads();
     }
-    double* out = partial + ((size_t)split * nt * nt + tile) * kNeTile * kNeTile;
-    out[(2 * ty) * kNeTile + 2 * tx] = c00;
-    out[(2 * ty + 1) * kNeTile + 2 * tx] = c01;
-    out[(2 * ty) * kNeTile + 2 * tx + 1] = c10;
-    out[(2 * ty + 1) * kNeTile + 2 * tx + 1] = c11;
+    partial[((size_t)split * nt * nt + tile) * kNeTile * kNeTile + ty * kNeTile + tx] = c;
 }
 __global__ __launch_bounds__(256) void k_normal_eq_reduce(const double* __restrict__ partial, int nsplit, int nt, int P, double* __restrict__ Hp) {
     const int n1 = P + 1;
@@ -2666,7 +2728,14 @@ __global__ __launch_bounds__(256) void k_normal_eq_mfma(const double* __restrict
         if (ti != tj) mirror[li * kNeTile + lj] = acc[r];
     }
 }
-void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s) {
+NormalEqPartials normal_equations_partials(int rows, int P) {
+    NormalEqPartials q;
+    q.nt = (P + 1 + kNeTile - 1) / kNeTile;
+    const int rs = ne_rows_per_split(rows, P);
+    q.nsplit = (rows + rs - 1) / rs;
+    return q;
+}
+void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s, bool reduce) {
     const int nt = (P + 1 + kNeTile - 1) / kNeTile;
     const int rs = ne_rows_per_split(rows, P);
     const int nsplit = (rows + rs - 1) / rs;
@@ -2674,9 +2743,9 @@ void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, doub
         hipLaunchKernelGGL(k_jacobian_columns, dim3((rows + 255) / 256, P), dim3(256), 0, s, const_cast<double*>(E), ldE, rows, P, inv_h);
         hipLaunchKernelGGL(k_normal_eq_mfma, dim3(nt * (nt + 1) / 2, nsplit), dim3(256), 0, s, E, ldE, rows, P, rs, nt, partial);
     } else
-        hipLaunchKernelGGL(k_normal_eq_partial, dim3(nt * nt, nsplit), dim3(256), 0, s, E, ldE, rows, P, inv_h, rs, nt, partial);
+        hipLaunchKernelGGL(k_normal_eq_partial, dim3(nt * nt, nsplit), dim3(1024), 0, s, E, ldE, rows, P, inv_h, rs, nt, partial);
     const int n1 = P + 1;
-    hipLaunchKernelGGL(k_normal_eq_reduce, dim3((n1 * n1 + 255) / 256), dim3(256), 0, s, partial, nsplit, nt, P, Hp);
+    if (reduce) hipLaunchKernelGGL(k_normal_eq_reduce, dim3((n1 * n1 + 255) / 256), dim3(256), 0, s, partial, nsplit, nt, P, Hp);
 }
 
 constexpr int kSqRows = 4096;
@@ -2737,7 +2806,7 @@ void launch_squared_sums_blocked(const double* E, int64_t ldE, int rows, int P, 
     const int rs = ne_rows_per_split(rows, P);
     const int nsplit = (rows + rs - 1) / rs;
     hipLaunchKernelGGL(k_squared_sums_blocked, dim3(nsplit, B), dim3(64), 0, s, E, ldE, rows, rs, nsplit, P > 64 ? 1 : 0, partial);
-    hipLaunchKernelGGL(k_squared_sums_reduce, dim3((B + 63) / 64), dim3(64), 0, s, partial, nsplit, B, out);
+    if (out) hipLaunchKernelGGL(k_squared_sums_reduce, dim3((B + 63) / 64), dim3(64), 0, s, partial, nsplit, B, out);  // out null: the consumer adds the block sums
 }
 void launch_squared_sums(const double* E, int64_t ldE, int rows, int B, double* partial, double* out, hipStream_t s) {
     const int nsplit = (rows + kSqRows - 1) / kSqRows;

@@ -52,14 +52,26 @@ void launch_loop_scatter_extra(const double* extra, int B, int a, double* E, int
 // pivoting, step = (-alpha H^-1) g, NaN test, clamp to max_step
 constexpr int kLoopSolveMaxP = 64;
 void launch_loop_lm_step(const double* Hp, int P, double lambda, double alpha, double max_step, double* step, LoopFlags* flags, hipStream_t s);
+// the same from the block sums of the normal-equation kernel (launch_normal_equations(..., reduce = false)): the reduction rides along;
+// *error0_out receives e0^T e0 (element (P, P))
+void launch_loop_lm_step_partials(const double* partial, int nsplit, int nt, int P, double lambda, double alpha, double max_step, double* step, LoopFlags* flags,
+                                  double* error0_out, hipStream_t s);
+// The same step for 64 < P <= 1024 on ceil(2P / 8) workgroups (column blocks of [A | I], panels of 8 pivot columns handed from owner to
+// owner).  `work`: loop_panel_solve_doubles(P) doubles of device scratch, zeroed once when allocated; `epoch` > 0 differs from call to
+// call on the same scratch (published panels and counters carry it, nothing is cleared between calls).
+constexpr int kLoopPanelMaxP = 1024;
+size_t loop_panel_solve_doubles(int P);
+void launch_loop_lm_panels(const double* Hp, int P, double lambda, double alpha, double max_step, double* work, unsigned int epoch, double* step,
+                           LoopFlags* flags, hipStream_t s);
 // the same tail (NaN test, clamp) for a step the host solved (P > 64)
 void launch_loop_step_finish(int P, double max_step, double* step, LoopFlags* flags, hipStream_t s);
 // end of the iteration (:130-143): arg-min over the trial errors, setPoseParameters, stop decisions; state_jac / state_trial are the
 // states after the two batches, state0 receives the state the next iteration starts from
 // With chain_next != 0 and the loop going on it also does the next iteration's launch_loop_begin (paramVec, window re-chain, ctrl0), so
 // begin is launched for the first iteration only; chain_next = 0 after the last iteration (decentralize() reads the last trial's poses).
+// error0: e0^T e0 of the iteration; trial_errs: the nine e^T e, or (trial_nsplit > 0) their block sums [9][trial_nsplit], added here in order.
 void launch_loop_finish(const LoopModel& m, const double* state_jac, const double* state_trial, double* state0, double* paramVec, const double* step,
-                        const double* Hp, const double* trial_errs, int fixed_iters, double epsilon, IterResult* result, LoopFlags* flags, double* ctrl0,
-                        int chain_next, hipStream_t s);
+                        const double* error0, const double* trial_errs, int trial_nsplit, int fixed_iters, double epsilon, IterResult* result, LoopFlags* flags,
+                        double* ctrl0, int chain_next, hipStream_t s);
 
 }  // namespace dmsa

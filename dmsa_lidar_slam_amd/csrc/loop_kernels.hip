@@ -265,30 +265,64 @@ __device__ __forceinline__ double wave_max_nonneg(double v) {
     o = dpp_mov_f64<0x143, 0xc>(v), v = o > v ? o : v;  // row_bcast:31 -> rows 2 and 3
     return readlane_f64(v, 63);
 }
+// element (i, j) of Hp = [J | e0]^T [J | e0]: either reduced already, or the block sums of the normal-equation kernel added here in block
+// order (the loads of sixteen blocks in flight together, only the adds are a chain) -- one dispatch less between the batch and the step
+struct HpSource {
+    const double* Hp;       // (P+1)^2 column-major, or null
+    const double* partial;  // block sums (dmsa_kernels.h: NormalEqPartials)
+    int nsplit, nt;
+};
+__device__ __forceinline__ double hp_element(const HpSource& h, int n1, int i, int j) {
+    if (h.Hp) return h.Hp[(size_t)j * n1 + i];
+    const double* src = h.partial + ((size_t)(j >> 5) * h.nt + (i >> 5)) * 1024 + (j & 31) * 32 + (i & 31);
+    const size_t stride = (size_t)h.nt * h.nt * 1024;
+    double s = 0.0;
+    int sp = 0;
+    for (; sp + 32 <= h.nsplit; sp += 32) {
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = src[(size_t)(sp + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s += v[u];
+    }
+    if (sp < h.nsplit) {  // the tail in one batch as well
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = sp + u < h.nsplit ? src[(size_t)(sp + u) * stride] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+            if (sp + u < h.nsplit) s += v[u];
+    }
+    return s;
+}
 template <int kColsPerLane>
-__global__ __launch_bounds__(kSolveWaves* kWave) void k_loop_lm_step(const double* __restrict__ Hp, int P, double lambda, double alpha, double max_step,
-                                                                      double* __restrict__ step, LoopFlags* __restrict__ flags) {
+__global__ __launch_bounds__(kSolveWaves* kWave) void k_loop_lm_step(const HpSource hp, int P, double lambda, double alpha, double max_step,
+                                                                      double* __restrict__ step, LoopFlags* __restrict__ flags, double* __restrict__ error0_out) {
     extern __shared__ double sm[];
     if (flags->stop != 0) return;
     const int W = 2 * P, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, n1 = P + 1;
     double* M = sm;                    // P x W row-major: [A | inv]
     double* g = sm + (size_t)P * W;    // P
-    for (int r = wave; r < P; r += kSolveWaves)
-#pragma unroll
-        for (int q = 0; q < kColsPerLane; ++q) {
-            const int c = lane + q * kWave;
-            if (c < W) {
-                double v;
-                if (c < P) {  // H(r, c) = Hp[c * n1 + r] (column-major), damped on the diagonal (:110)
-                    v = Hp[(size_t)c * n1 + r];
-                    if (r == c) v += lambda;
-                } else {
-                    v = (c - P) == r ? 1.0 : 0.0;
-                }
-                M[(size_t)r * W + c] = v;
-            }
+    // [H + lambda I | g] and e0^T e0: the (P+1)^2 - 1 - P elements that matter spread evenly over the threads (every element may be a sum
+    // of block sums: as many of those loads in flight as possible)
+    for (int idx = threadIdx.x; idx < n1 * n1; idx += kSolveWaves * kWave) {
+        const int j = idx / n1, i = idx - j * n1;  // element (i, j), column-major like Hp
+        if (j < P && i < P) {
+            double v = hp_element(hp, n1, i, j);  // H(i, j), damped on the diagonal (:110)
+            if (i == j) v += lambda;
+            M[(size_t)i * W + j] = v;
+        } else if (j == P) {
+            const double v = hp_element(hp, n1, i, P);  // g = J^T e0 (last column), e0^T e0 for the end of the iteration
+            if (i < P)
+                g[i] = v;
+            else if (error0_out)
+                *error0_out = v;
         }
-    if (wave == 0 && lane < P) g[lane] = Hp[(size_t)P * n1 + lane];
+    }
+    for (int idx = threadIdx.x; idx < P * P; idx += kSolveWaves * kWave) {
+        const int r = idx / P, c = idx - r * P;
+        M[(size_t)r * W + P + c] = r == c ? 1.0 : 0.0;
+    }
     __syncthreads();
     for (int c0 = 0; c0 < P; ++c0) {
         // ---- reads of the state before the step ----
@@ -362,6 +396,262 @@ __global__ __launch_bounds__(kSolveWaves* kWave) void k_loop_lm_step(const doubl
     if (lane < P) step[lane] = s;
 }
 
+// ---- P > 64: the same Gauss-Jordan inverse, blocked over column blocks of the augmented matrix [A | I], one workgroup per block ------
+// Every element sees the operations of the serial algorithm in step order -- pivot row: x / d_k, other rows: x - f_rk * s_kc (skipped
+// for f_rk == 0) -- so the result is the serial one bit for bit (as host_math.cpp's blocked lm_solve argues).  What a step needs, the
+// pivot choice, d_k and the multipliers f_rk, depends only on column k; K = 8 consecutive pivot columns form a PANEL whose evolution
+// depends on nothing but itself.  Workgroup b owns columns [8b, 8b + 8) of all rows (thread = row, the 8 entries in registers) and, panel
+// by panel, factors a private copy of the panel in lockstep with its own block: per step one argmax over the rows, one division of
+// the pivot row's 16 entries by the thread that owns it, one multiply-subtract of 16 entries by everybody else.  The only traffic
+// between workgroups: the owner of the next panel publishes its block (n x 8 doubles) when it has applied the current panel, and the
+// others pick it up -- a chain of P / 8 hand-overs instead of P, no grid-wide barrier.  A-blocks retire once they have served as
+// panel; the last workgroup to finish multiplies the inverse with g and clamps the step (:113-128).
+#ifndef DMSA_PANEL
+#define DMSA_PANEL 8
+#endif
+constexpr int kPanel = DMSA_PANEL;  // pivot columns per panel = columns per workgroup
+constexpr int kPanelLdsHead = 2 * kPanel + 8 + 16 + 16;  // doubles in front of s_perm: pivot row (+ pivot), per-wave best value / row
+struct PanelSolveWork {   // device scratch of one solve (sized by loop_panel_solve_bytes)
+    unsigned int epoch_flags_offset;  // unused placeholder: layout is computed from P
+};
+__device__ __forceinline__ void agent_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double agent_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_old_f64(double old, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), kCtrl, kRowMask, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), kCtrl, kRowMask, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// (value, logical row) of the wave's best candidate: largest value, among equals the smallest logical row; value -1 = no candidate
+__device__ __forceinline__ void wave_best(double& v, int& l) {
+#define DMSA_BEST_STEP(CTRL, MASK)                                                                    \
+    {                                                                                                 \
+        const double ov = dpp_old_f64<CTRL, MASK>(-2.0, v);                                           \
+        const int ol = __builtin_amdgcn_update_dpp(0x7fffffff, l, CTRL, MASK, 0xf, false);            \
+        const bool take = ov > v || (ov == v && ol < l);                                              \
+        v = take ? ov : v, l = take ? ol : l;                                                         \
+    }
+    DMSA_BEST_STEP(0x111, 0xf)  // row_shr:1
+    DMSA_BEST_STEP(0x112, 0xf)  // row_shr:2
+    DMSA_BEST_STEP(0x114, 0xf)  // row_shr:4
+    DMSA_BEST_STEP(0x118, 0xf)  // row_shr:8
+    DMSA_BEST_STEP(0x142, 0xa)  // row_bcast:15
+    DMSA_BEST_STEP(0x143, 0xc)  // row_bcast:31
+#undef DMSA_BEST_STEP
+    v = readlane_f64(v, 63), l = __builtin_amdgcn_readlane(l, 63);
+}
+__global__ __launch_bounds__(1024) void k_loop_lm_panels(const double* __restrict__ Hp, int P, double lambda, double alpha, double max_step,
+                                                         double* __restrict__ work, unsigned int epoch, double* __restrict__ step, LoopFlags* __restrict__ flags) {
+    if (flags->stop != 0) return;
+    const int n = P, n1 = P + 1, r = threadIdx.x, b = blockIdx.x, nblocks = gridDim.x;
+    const int npanels = (n + kPanel - 1) / kPanel;
+    double* pub = work;                                            // [npanels][n][8]
+    double* inv_out = pub + (size_t)npanels * n * kPanel;          // [n][n] physical rows
+    unsigned long long* ready = reinterpret_cast<unsigned long long*>(inv_out + (size_t)n * n);  // [npanels]: epoch when published
+    unsigned long long* done = ready + npanels;                    // [0]: (epoch << 32) | finished workgroups
+    int* iperm_out = reinterpret_cast<int*>(done + 2);             // [n]: logical row of every physical row after the last step
+    extern __shared__ double sm[];
+    double* s_prow = sm;                        // 16 (+1): pivot row entries (panel | own block), raw then scaled; [16] = the pivot
+    double* s_bv = sm + 2 * kPanel + 8;         // per wave: best value (<= 16 waves)
+    int* s_bl = reinterpret_cast<int*>(sm + 2 * kPanel + 8 + 16);   // per wave: best logical row
+    int* s_perm = s_bl + 16;                    // logical -> physical
+    __shared__ int s_last;
+    const bool row = r < n;
+    const int lane = r & 63, wave = r >> 6, nwaves = (blockDim.x + 63) >> 6;
+    // own block: columns c0 .. c0 + 7 of [A | I]
+    const int c0 = b * kPanel;
+    double xo[kPanel];
+#pragma unroll
+    for (int c = 0; c < kPanel; ++c) {
+        const int col = c0 + c;
+        double v = 0.0;
+        if (row) {
+            if (col < n) {
+                v = Hp[(size_t)col * n1 + r];  // H(r, col), damped on the diagonal (:110)
+                if (col == r) v += lambda;
+            } else if (col < 2 * n) {
+                v = (col - n) == r ? 1.0 : 0.0;
+            }
+        }
+        xo[c] = v;
+    }
+    for (int i = r; i < n; i += blockDim.x) s_perm[i] = i;
+    int logical = r;      // iperm[r]
+    bool pivoted = false;
+    if (b == 0 && row) {  // block 0 is panel 0 as it stands
+#pragma unroll
+        for (int c = 0; c < kPanel; ++c) pub[(size_t)r * kPanel + c] = xo[c];
+    }
+    if (b == 0) __threadfence();
+    __syncthreads();
+    if (b == 0 && r == 0) __hip_atomic_store(ready, (unsigned long long)epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const int last_panel_of_block = c0 + kPanel <= n ? b : npanels - 1;  // an A block is dead once it has been the panel
+    for (int p = 0; p <= last_panel_of_block && p < npanels; ++p) {
+        const int k0 = p * kPanel, kp = min(kPanel, n - k0);
+        const bool is_panel = p == b;
+        // ---- the panel as its owner published it ----
+        // Hand-over: the owner's plain stores are released by its fence + flag; consumers poll the flag with a relaxed load (an acquire
+        // load would invalidate the L2 on every poll) and fence once after they have seen it.  Measured alternatives: acquire polling
+        // 459 us per solve at P = 186, data through agent-scope atomics instead of fences 443 us, this 405 us.
+        if (r == 0)
+            while (__hip_atomic_load(ready + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)epoch) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+        __threadfence();
+        double xp[kPanel];
+        {
+            const double2* src = reinterpret_cast<const double2*>(pub + ((size_t)p * n + (row ? r : 0)) * kPanel);
+#pragma unroll
+            for (int c = 0; c < kPanel / 2; ++c) {
+                const double2 v = src[c];
+                xp[2 * c] = row ? v.x : 0.0, xp[2 * c + 1] = row ? v.y : 0.0;
+            }
+        }
+        // ---- kp pivot steps on the panel copy and on the own block in lockstep ----
+#pragma unroll
+        for (int j = 0; j < kPanel; ++j) {
+            if (j >= kp) break;
+            const int k = k0 + j;
+            // pivot: largest |x| among the rows not yet pivoted, ties to the smallest logical row (= the serial search from row k down)
+            double v = row && !pivoted ? fabs(xp[j]) : -1.0;
+            if (isnan(v)) v = -1.0;
+            int l = row && !pivoted ? logical : 0x7fffffff;
+            wave_best(v, l);
+            if (lane == 0) s_bv[wave] = v, s_bl[wave] = l;
+            __syncthreads();
+            double bv = s_bv[0];
+            int bl = s_bl[0];
+            for (int w = 1; w < nwaves; ++w) {
+                const double ov = s_bv[w];
+                const int ol = s_bl[w];
+                if (ov > bv || (ov == bv && ol < bl)) bv = ov, bl = ol;
+            }
+            if (bv < 0.0) bl = k;  // nothing comparable (NaNs): keep the diagonal like the serial search
+            const int pp = s_perm[bl], p0 = s_perm[k];
+            const bool mine = row && r == pp;
+            // the pivot row's 16 entries are divided by 16 lanes (one fp64 division is ~40 dependent instructions; sixteen of them on
+            // the one lane that owns the row would dominate the step)
+            if (mine) {
+#pragma unroll
+                for (int c = 0; c < kPanel; ++c) s_prow[c] = xp[c], s_prow[kPanel + c] = xo[c];
+                s_prow[2 * kPanel] = xp[j];
+            }
+            __syncthreads();  // (also: everybody has read s_perm / s_bv / s_bl of this step)
+            if (r < 2 * kPanel) {
+                const double q = s_prow[r] / s_prow[2 * kPanel];
+                __builtin_amdgcn_wave_barrier();  // all sixteen lanes (one wave) have read the pivot before any overwrites
+                s_prow[r] = q;
+            }
+            if (row && r == pp) logical = k, pivoted = true;
+            else if (row && r == p0) logical = bl;
+            if (r == 0) s_perm[k] = pp, s_perm[bl] = p0;
+            __syncthreads();
+            if (row) {
+                if (mine) {
+#pragma unroll
+                    for (int c = 0; c < kPanel; ++c) xp[c] = s_prow[c], xo[c] = s_prow[kPanel + c];
+                } else {
+                    const double f = xp[j];
+                    if (f != 0.0) {
+                        const double2* pr = reinterpret_cast<const double2*>(s_prow);  // broadcast reads, two entries per instruction
+#pragma unroll
+                        for (int c = 0; c < kPanel / 2; ++c) {
+                            const double2 a2 = pr[c], b2 = pr[kPanel / 2 + c];
+                            xp[2 * c] -= f * a2.x, xp[2 * c + 1] -= f * a2.y;
+                            xo[2 * c] -= f * b2.x, xo[2 * c + 1] -= f * b2.y;
+                        }
+                    }
+                }
+            }
+            // no barrier here: the next step's first barrier separates these reads of s_prow from its next writer
+        }
+        if (is_panel) {
+            // the block was its own panel: what happened to the copy happened to the block
+#pragma unroll
+            for (int c = 0; c < kPanel; ++c) xo[c] = xp[c];
+        }
+        // ---- hand the next panel over as soon as it exists ----
+        if (b == p + 1 && p + 1 < npanels) {
+            if (row) {
+                double2* dst = reinterpret_cast<double2*>(pub + ((size_t)(p + 1) * n + r) * kPanel);
+#pragma unroll
+                for (int c = 0; c < kPanel / 2; ++c) dst[c] = double2{xo[2 * c], xo[2 * c + 1]};
+            }
+            __threadfence();
+            __syncthreads();
+            if (r == 0) __hip_atomic_store(ready + p + 1, (unsigned long long)epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- columns of the inverse ----
+    if (row)
+#pragma unroll
+        for (int c = 0; c < kPanel; ++c) {
+            const int col = c0 + c;
+            if (col >= n && col < 2 * n) inv_out[(size_t)r * n + (col - n)] = xo[c];
+        }
+    // the last block always lives to the last panel: its row permutation is the final one
+    if (b == nblocks - 1 && row) iperm_out[r] = logical;
+    __threadfence();
+    __syncthreads();
+    if (r == 0) {
+        // count finished workgroups of THIS solve (the word carries the epoch; a stale epoch restarts the count)
+        unsigned long long seen = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
+        do {
+            want = (seen >> 32) == (unsigned long long)epoch ? seen + 1ull : (((unsigned long long)epoch << 32) | 1ull);
+        } while (!__hip_atomic_compare_exchange_strong(done, &seen, want, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        s_last = (int)(want & 0xffffffffull) == nblocks;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // :113 step = (-alpha H^-1) g, row by row; the physical row r is logical row iperm[r] (a retired A block stopped tracking the
+    // permutation, so it is read back from the block that certainly saw every step)
+    double* s_step = sm + kPanelLdsHead + ((size_t)n + 1) / 2 + 1;   // behind s_perm (ints)
+    double sres = 0.0;
+    if (row) {
+        // the row of the inverse arrives eight entries at a time (independent loads in flight), the sum itself is a chain in column order
+        const double* irow = inv_out + (size_t)r * n;
+        const double* gv = Hp + (size_t)P * n1;
+        int j = 0;
+        for (; j + 8 <= n; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = irow[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sres += (-alpha * v[u]) * gv[j + u];
+        }
+        for (; j < n; ++j) sres += (-alpha * irow[j]) * gv[j];
+        s_step[iperm_out[r]] = sres;
+    }
+    __syncthreads();
+    // NaN test and clamp (:116-128): wave 0 walks the step (max / min do not depend on the order)
+    if (wave == 0) {
+        bool any_nan = false;
+        double mx = -INFINITY, mn = INFINITY;
+        for (int i = lane; i < n; i += 64) {
+            const double v = s_step[i];
+            any_nan = any_nan || isnan(v);
+            mx = mx < v ? v : mx;
+            mn = v < mn ? v : mn;
+        }
+        if (__ballot(any_nan) != 0ull) {
+            if (lane == 0) flags->nan = 1;
+        } else {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
+                mx = mx < a ? a : mx;
+                mn = c < mn ? c : mn;
+            }
+            const double neg = -mn;
+            const double max_elem = mx < neg ? neg : mx;
+            for (int i = lane; i < n; i += 64) {
+                const double v = s_step[i];
+                step[i] = max_elem > max_step ? (max_step / max_elem) * v : v;
+            }
+        }
+    }
+}
+
 // the same tail for a step the host solved (P > 64): one wave, NaN test and extrema as wave reductions (max / min are order independent)
 __global__ __launch_bounds__(kWave) void k_loop_step_finish(int P, double max_step, double* __restrict__ step, LoopFlags* __restrict__ flags) {
     if (flags->stop != 0) return;
@@ -392,15 +682,16 @@ __global__ __launch_bounds__(kWave) void k_loop_step_finish(int P, double max_st
 
 __global__ __launch_bounds__(kWave) void k_loop_finish(const LoopModel m, const double* __restrict__ state_jac, const double* __restrict__ state_trial,
                                                        double* __restrict__ state0, double* __restrict__ paramVec, const double* __restrict__ step,
-                                                       const double* __restrict__ Hp, const double* __restrict__ errs, int fixed_iters, double epsilon,
-                                                       IterResult* __restrict__ result, LoopFlags* __restrict__ flags, double* __restrict__ ctrl0, int chain_next) {
+                                                       const double* __restrict__ error0_ptr, const double* __restrict__ errs, int errs_nsplit,
+                                                       int fixed_iters, double epsilon, IterResult* __restrict__ result, LoopFlags* __restrict__ flags,
+                                                       double* __restrict__ ctrl0, int chain_next) {
     extern __shared__ double sm[];
     if (flags->stop != 0) return;
     const int n = m.n, P = m.P;
     const ChainLds c = carve(sm, n, P);
     __shared__ int s_best, s_stop;
     __shared__ double s_norm;
-    const double error0 = Hp[(size_t)P * (P + 1) + P];  // e0^T e0 (:101)
+    const double error0 = *error0_ptr;  // e0^T e0 (:101)
     if (flags->nan != 0) {
         // :116-122 setPoseParameters(paramVec); break -- on the state the Jacobian batch left
         load_state(state_jac, n, c.rel_o, c.rel_t, c.glob_o, c.glob_t);
@@ -415,7 +706,25 @@ __global__ __launch_bounds__(kWave) void k_loop_finish(const LoopModel m, const 
     }
     // the step and the nine trial errors through LDS (coalesced loads; the sums below are serial chains on one lane)
     for (int i = threadIdx.x; i < P; i += kWave) c.org[i] = step[i];
-    if (threadIdx.x < 9) c.E[threadIdx.x] = errs[threadIdx.x];
+    if (threadIdx.x < 9) {
+        // e^T e of trial threadIdx.x + 1: reduced already (errs_nsplit == 0), or its block sums added here in block order
+        double e = 0.0;
+        if (errs_nsplit <= 0) {
+            e = errs[threadIdx.x];
+        } else {
+            const double* src = errs + (size_t)threadIdx.x * errs_nsplit;
+            int sp = 0;
+            for (; sp + 16 <= errs_nsplit; sp += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = src[sp + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) e += v[u];
+            }
+            for (; sp < errs_nsplit; ++sp) e += src[sp];
+        }
+        c.E[threadIdx.x] = e;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         double min_error = error0;
@@ -467,7 +776,8 @@ void launch_loop_scatter_extra(const double* extra, int B, int a, double* E, int
     if (a <= 0 || B <= 0) return;
     hipLaunchKernelGGL(k_loop_scatter_extra, dim3((B * a + 255) / 256), dim3(256), 0, s, extra, B, a, E, ldE, M);
 }
-void launch_loop_lm_step(const double* Hp, int P, double lambda, double alpha, double max_step, double* step, LoopFlags* flags, hipStream_t s) {
+static void launch_lm_step(const HpSource& hp, int P, double lambda, double alpha, double max_step, double* step, LoopFlags* flags, double* error0_out,
+                           hipStream_t s) {
     const size_t bytes = (2 * (size_t)P * P + (size_t)P) * sizeof(double);
     static bool raised = false;
     if (bytes > 48 * 1024 && !raised) {
@@ -475,18 +785,37 @@ void launch_loop_lm_step(const double* Hp, int P, double lambda, double alpha, d
         raised = true;
     }
     if (2 * P <= kWave)
-        hipLaunchKernelGGL(k_loop_lm_step<1>, dim3(1), dim3(kSolveWaves * kWave), bytes, s, Hp, P, lambda, alpha, max_step, step, flags);
+        hipLaunchKernelGGL(k_loop_lm_step<1>, dim3(1), dim3(kSolveWaves * kWave), bytes, s, hp, P, lambda, alpha, max_step, step, flags, error0_out);
     else
-        hipLaunchKernelGGL(k_loop_lm_step<2>, dim3(1), dim3(kSolveWaves * kWave), bytes, s, Hp, P, lambda, alpha, max_step, step, flags);
+        hipLaunchKernelGGL(k_loop_lm_step<2>, dim3(1), dim3(kSolveWaves * kWave), bytes, s, hp, P, lambda, alpha, max_step, step, flags, error0_out);
+}
+void launch_loop_lm_step(const double* Hp, int P, double lambda, double alpha, double max_step, double* step, LoopFlags* flags, hipStream_t s) {
+    launch_lm_step(HpSource{Hp, nullptr, 0, 0}, P, lambda, alpha, max_step, step, flags, nullptr, s);
+}
+void launch_loop_lm_step_partials(const double* partial, int nsplit, int nt, int P, double lambda, double alpha, double max_step, double* step, LoopFlags* flags,
+                                  double* error0_out, hipStream_t s) {
+    launch_lm_step(HpSource{nullptr, partial, nsplit, nt}, P, lambda, alpha, max_step, step, flags, error0_out, s);
+}
+size_t loop_panel_solve_doubles(int P) {
+    const size_t panels = ((size_t)P + kPanel - 1) / kPanel;
+    return panels * (size_t)P * kPanel /* published panels */ + (size_t)P * P /* inverse */ + panels + 2 /* flags, done counter (as 8-byte words) */ +
+           (size_t)P / 2 + 2 /* final row permutation (ints) */;
+}
+void launch_loop_lm_panels(const double* Hp, int P, double lambda, double alpha, double max_step, double* work, unsigned int epoch, double* step,
+                           LoopFlags* flags, hipStream_t s) {
+    const int nblocks = (2 * P + kPanel - 1) / kPanel;
+    const int threads = ((P + 63) / 64) * 64;
+    const size_t lds = kPanelLdsHead * sizeof(double) + ((size_t)P + 2) / 2 * sizeof(double) + sizeof(double) + (size_t)P * sizeof(double) + 64;
+    hipLaunchKernelGGL(k_loop_lm_panels, dim3(nblocks), dim3(threads), lds, s, Hp, P, lambda, alpha, max_step, work, epoch, step, flags);
 }
 void launch_loop_step_finish(int P, double max_step, double* step, LoopFlags* flags, hipStream_t s) {
     hipLaunchKernelGGL(k_loop_step_finish, dim3(1), dim3(64), 0, s, P, max_step, step, flags);
 }
 void launch_loop_finish(const LoopModel& m, const double* state_jac, const double* state_trial, double* state0, double* paramVec, const double* step,
-                        const double* Hp, const double* trial_errs, int fixed_iters, double epsilon, IterResult* result, LoopFlags* flags, double* ctrl0,
-                        int chain_next, hipStream_t s) {
-    hipLaunchKernelGGL(k_loop_finish, dim3(1), dim3(kWave), chain_lds_bytes(m), s, m, state_jac, state_trial, state0, paramVec, step, Hp, trial_errs, fixed_iters,
-                       epsilon, result, flags, ctrl0, chain_next);
+                        const double* error0, const double* trial_errs, int trial_nsplit, int fixed_iters, double epsilon, IterResult* result, LoopFlags* flags,
+                        double* ctrl0, int chain_next, hipStream_t s) {
+    hipLaunchKernelGGL(k_loop_finish, dim3(1), dim3(kWave), chain_lds_bytes(m), s, m, state_jac, state_trial, state0, paramVec, step, error0, trial_errs,
+                       trial_nsplit, fixed_iters, epsilon, result, flags, ctrl0, chain_next);
 }
 
 }  // namespace dmsa

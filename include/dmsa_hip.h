@@ -250,6 +250,13 @@ int dmsa_serial_fallback_sums(dmsa_ctx* ctx, int32_t reset, uint64_t* count);
  * inside optimizeSet the context's worker pool plays that part.  No device needed. */
 int dmsa_lm_solve(const double* H_damped, const double* g, int32_t P, double alpha, int32_t threads, double* step);
 
+/* The same step computed ON THE DEVICE, as the device-resident loop of optimizeSet does (csrc/loop_kernels.hip): one workgroup for
+ * P <= 64, one workgroup per block of 8 columns of [H | I] beyond, panels of 8 pivot columns handed from owner to owner.  Followed by
+ * the NaN test and the clamp of DmsaOptimizer.h:116-128 (`max_step` = +inf disables the clamp; *nan_out = 1 and an undefined step when
+ * the step holds a NaN).  Bit-identical to dmsa_lm_solve (tests). */
+int dmsa_lm_solve_device(dmsa_ctx* ctx, const double* H_damped, const double* g, int32_t P, double alpha, double max_step, double* step,
+                         int32_t* nan_out);
+
 /* Evaluates include/dmsa_detmath.h ON THE DEVICE: fn 0 sin(x), 1 cos(x), 2 acos(x), 3 atan2(y, x); n doubles each (y may be NULL for
  * fn < 3).  The pose-table kernels (ContinuousTrajectory.h:189-226, MapManagement.h:140-147) take their trigonometry from that
  * header; the tests compare these device results bit for bit with the same header compiled for the host. */

@@ -1,0 +1,111 @@
+"""The device-resident optimizeSet loop (csrc/loop_kernels.hip): the LM step of DmsaOptimizer.h:107-128 computed on the device (one
+workgroup for P <= 64, panel hand-over between column-block workgroups beyond) against the oracle's step bit for bit; and whole
+optimizeSet calls that END EARLY (no improvement / epsilon / too few Gaussians) -- the stop decision is taken on the device and reaches
+the host one synchronisation late -- against the oracle and against the host-driven loop of rounds 1-2 (DMSA_DEVICE_LOOP=0)."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation as Rot
+
+from dmsa_lidar_slam_amd import synth
+from dmsa_lidar_slam_amd.problems import DmsaOptimSettings
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(orc, P, seed):
+    rng = np.random.default_rng(seed)
+    rows = 4 * P + 50
+    e0 = rng.uniform(0.5, 2.0, rows)
+    eb = e0[None, :] + rng.normal(size=(P, rows)) * 1e-4
+    eb[P // 3] = eb[P // 3 + 1]  # exactly dependent columns: pivot swaps under the weak damping of the reference (lambda = 1e-5)
+    h = float(np.sqrt(np.finfo(np.float32).eps))
+    return orc.lm_step(e0, eb, h, float(np.float32(1e-5)), 0.2)  # H (damped), g, step
+
+
+@pytest.mark.parametrize("P", [6, 12, 30, 31, 63, 64, 65, 72, 96, 184, 186, 187, 200, 594])
+def test_device_lm_step_equals_the_oracle_step(hip, orc, P):
+    H, g, step_ref = _system(orc, P, 300 + P)
+    opt = hip.DmsaOptimizer()
+    for rep in range(2):  # the panel solve reuses its scratch with a new epoch
+        step, nan = opt.lmSolveDevice(H.reshape(P, P), g, 0.2)
+        assert not nan
+        assert np.array_equal(step, step_ref), (P, rep, np.abs(step - step_ref).max())
+    # the clamp of :125-128
+    max_step = 0.37 * np.abs(step_ref).max()
+    mx, mn = step_ref.max(), step_ref.min()
+    max_elem = max(mx, -mn)
+    step, nan = opt.lmSolveDevice(H.reshape(P, P), g, 0.2, max_step)
+    assert not nan and np.array_equal(step, (max_step / max_elem) * step_ref)
+    # a NaN in the system is reported, not clamped
+    Hn = H.reshape(P, P).copy()
+    Hn[P // 2, P // 2] = np.nan
+    _, nan = opt.lmSolveDevice(Hn, g, 0.2)
+    assert nan
+    opt.close()
+
+
+def _run(hip, prob, s):
+    p = prob.copy()
+    opt = hip.DmsaOptimizer()
+    rep = opt.optimizeSet(p, s)
+    tr = opt.trace()
+    opt.close()
+    return p, rep, tr
+
+
+def _same(a, b):
+    (pa, ra, ta), (pb, rb, tb) = a, b
+    assert (ra.iterations, ra.stop_reason, ra.evaluations, ra.num_gaussians, ra.num_gaussians_l1, ra.num_memberships) == \
+           (rb.iterations, rb.stop_reason, rb.evaluations, rb.num_gaussians, rb.num_gaussians_l1, rb.num_memberships)
+    assert (ra.error0, ra.last_step_norm, ra.last_line_search_k) == (rb.error0, rb.last_step_norm, rb.last_line_search_k)
+    assert [(t["M"], t["M1"], t["Mm"], t["best_k"], t["error0"], t["step_norm"]) for t in ta[: ra.iterations]] == \
+           [(t["M"], t["M1"], t["Mm"], t["best_k"], t["error0"], t["step_norm"]) for t in tb[: rb.iterations]]
+    assert np.array_equal(pa.relOrientations, pb.relOrientations) and np.array_equal(pa.relTranslations, pb.relTranslations)
+
+
+def _cases():
+    kf = synth.keyframe_problem(seed=5, frames=6, rings=24, az_steps=160, arc=0.4)
+    rng = np.random.default_rng(0)
+    ro, rt = kf.truth_relative
+    kf.useOdometryErrorTerms = True
+    kf.odomRelTransl = rt + rng.normal(0, 0.005, rt.shape)
+    kf.odomRelOrientMat = (Rot.from_rotvec(ro) * Rot.from_rotvec(rng.normal(0, 1e-3, (kf.numFrames, 3)))).as_matrix()
+    kf.__post_init__()
+    return {
+        "window_runs_to_a_stop": (synth.window_problem(seed=31, scans=3, rings=32, az_steps=256, num_static=4000), DmsaOptimSettings.sliding_window(num_iter=15), True),
+        "window_imu": (synth.window_problem(seed=7, scans=5, rings=16, az_steps=256, num_static=1500, use_imu=True),
+                                      DmsaOptimSettings.sliding_window(use_imu=True, num_iter=15), True),
+        "rosette": (synth.rosette_window_problem(seed=2, scans=4, pts_per_scan=6000, num_static=3000), DmsaOptimSettings.sliding_window(num_iter=12), True),
+        "keyframes_gravity_odometry": (kf, DmsaOptimSettings.keyframe_map(num_iter=12), False),
+        "keyframes_P72": (synth.keyframe_problem(seed=4, frames=13, rings=16, az_steps=96, arc=0.8), DmsaOptimSettings.keyframe_map(num_iter=6), False),
+    }
+
+
+@pytest.mark.parametrize("case", list(_cases()))
+def test_early_exits_match_the_oracle_and_the_host_driven_loop(hip, orc, case, monkeypatch):
+    prob, s, window = _cases()[case]
+    dev = _run(hip, prob, s)
+    p_ref = prob.copy()
+    rep_ref, _, tr_ref = (orc.optimize_window if window else orc.optimize_keyframes)(p_ref, s)
+    _same(dev, (p_ref, rep_ref, tr_ref))
+    monkeypatch.setenv("DMSA_DEVICE_LOOP", "0")
+    host = _run(hip, prob, s)
+    _same(dev, host)
+    if case == "window_runs_to_a_stop":
+        assert dev[1].stop_reason != 0 and dev[1].iterations < s.num_iter  # the case really exercises a device-side stop
+
+
+def test_too_few_gaussians_leaves_the_state_of_the_iteration_start(hip, orc):
+    """numPointSets < min_num_gaussians (DmsaOptimizer.h:89-93) in the SECOND iteration: the Jacobian batch of that iteration was already
+    enqueued beside the voxelisation; nothing of it may reach the poses."""
+    prob = synth.window_problem(seed=11, scans=2, rings=16, az_steps=128, num_static=800)
+    s = DmsaOptimSettings.sliding_window(num_iter=4)
+    p0 = prob.copy()
+    rep0, _, tr0 = orc.optimize_window(p0, s)
+    s.min_num_gaussians = tr0[1]["M"] + 1 if rep0.iterations > 1 else tr0[0]["M"] + 1  # iteration 1 passes only if it has more sets than iteration 2
+    if rep0.iterations > 1 and tr0[0]["M"] <= tr0[1]["M"]:
+        s.min_num_gaussians = tr0[0]["M"] + 1  # falls back to stopping in the first iteration
+    p_ref = prob.copy()
+    rep_ref, _, tr_ref = orc.optimize_window(p_ref, s)
+    assert rep_ref.stop_reason == 1
+    _same(_run(hip, prob, s), (p_ref, rep_ref, tr_ref))
