@@ -150,6 +150,12 @@ class StaticSelectResult(C.Structure):
     ]
 
 
+class DebugOptions(C.Structure):
+    """include/dmsa_debug.h: dmsa_debug_options (fill with dmsa_default_debug_options first)."""
+    _fields_ = [(n, C.c_int32) for n in ("device_loop", "dual_stream", "serial_streams", "merge_sort", "key_compress", "fused_segments", "sort_prehist",
+                                           "library_sort", "overlap_batch", "serial_tree", "host_threads", "solve_threads", "host_timeline", "trace_time")]
+
+
 class Report(C.Structure):
     _fields_ = [
         ("iterations", C.c_int32),
@@ -260,6 +266,8 @@ def load_library() -> C.CDLL:
         "dmsa_sort_pairs": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "dmsa_leaf_segments": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_int64, C.c_uint32, c_int32_p, c_int32_p, c_int32_p]),
         "dmsa_serial_fallback_sums": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_uint64)]),
+        "dmsa_default_debug_options": (None, [C.POINTER(DebugOptions)]),
+        "dmsa_create_ex": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(DebugOptions), C.POINTER(vp)]),
         "dmsa_lm_solve": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.c_double, C.c_int32, c_double_p]),
         "dmsa_lm_solve_device": (C.c_int, [vp, c_double_p, c_double_p, C.c_int32, C.c_double, C.c_double, c_double_p, c_int32_p]),
         "dmsa_neighbourhood_ranges": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -303,7 +311,7 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "dmsa_create dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
+    "dmsa_create dmsa_create_ex dmsa_default_debug_options dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
     "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
     "dmsa_set_params dmsa_additional_errors dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
     "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_detmath_eval dmsa_lm_solve dmsa_lm_solve_device dmsa_serial_fallback_sums dmsa_sort_pairs dmsa_leaf_segments dmsa_neighbourhood_ranges dmsa_submap_poses dmsa_update_poses_from_submap dmsa_optimize_resident dmsa_get_poses "

@@ -24,10 +24,11 @@ class DmsaOptimizer:
     """One context == one GPU == one host thread (the reference's optimizer is not re-entrant either)."""
 
     def __init__(self, device: int = 0, pose_table_host: bool = False, fixed_iters: bool = False, mirror_sums: bool | None = None,
-                 stage_timers: bool = False, fast_sums: bool = False):
+                 stage_timers: bool = False, fast_sums: bool = False, debug: dict | None = None):
         """Default = the reference's summation order (bit-identical to the CPU restatement) with pose tables built on the device.
         fast_sums=True selects the wave-parallel sums (DMSA_FLAG_FAST_SUMS: faster, but outside the 1e-4 pose tolerance after a few
-        iterations); mirror_sums is the round-1 spelling (mirror_sums=False == fast_sums=True)."""
+        iterations); mirror_sums is the round-1 spelling (mirror_sums=False == fast_sums=True).  `debug`: switches of
+        include/dmsa_debug.h by name, e.g. {"device_loop": 0} -- alternative implementations with the same results (tests, A/B timing)."""
         self._lib = capi.load_library()
         self._ctx = C.c_void_p()
         if mirror_sums is not None:
@@ -35,7 +36,16 @@ class DmsaOptimizer:
         flags = (capi.FLAG_POSE_TABLE_HOST if pose_table_host else 0) | (capi.FLAG_FIXED_ITERS if fixed_iters else 0)
         flags |= capi.FLAG_FAST_SUMS if fast_sums else 0
         flags |= capi.FLAG_STAGE_TIMERS if stage_timers else 0
-        rc = self._lib.dmsa_create(int(device), flags, C.byref(self._ctx))
+        if debug:
+            opts = capi.DebugOptions()
+            self._lib.dmsa_default_debug_options(C.byref(opts))
+            for k, v in debug.items():
+                if not hasattr(opts, k):
+                    raise KeyError(f"unknown debug switch {k!r} (include/dmsa_debug.h)")
+                setattr(opts, k, int(v))
+            rc = self._lib.dmsa_create_ex(int(device), flags, C.byref(opts), C.byref(self._ctx))
+        else:
+            rc = self._lib.dmsa_create(int(device), flags, C.byref(self._ctx))
         if rc != capi.DMSA_OK:
             self._ctx = None
             raise DmsaError(f"dmsa_create(device={device}) failed with {rc} (no usable HIP device; there is no CPU fallback)")

@@ -1,0 +1,420 @@
+// context.cpp — lifetime of a dmsa_ctx: creation (debug switches), destruction, device buffers, uploads of the two problem models, timers.
+#include "dmsa_ctx.h"
+
+HostTimeline g_tl;
+
+WorkerPool& workers(dmsa_ctx* ctx) {
+    if (!ctx->pool) {
+        const unsigned want = (unsigned)std::max(1, ctx->dbg.host_threads);  // host pose tables, perturbed keyframe chains, upload packing, host solve
+        ctx->pool = new WorkerPool((int)std::min(want, std::max(2u, std::thread::hardware_concurrency())));
+    }
+    return *ctx->pool;
+}
+hipEvent_t get_event(dmsa_ctx* ctx) {
+    if (!ctx->free_events.empty()) {
+        hipEvent_t e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+// fold finished event pairs into the accumulators (call after a stream synchronisation)
+void drain_timers(dmsa_ctx* ctx) {
+    // pairs whose closing event has not completed yet stay pending (the device-resident loop drains without a full synchronisation)
+    std::vector<EventPair> later;
+    for (auto& ev : ctx->pending) {
+        if (hipEventQuery(ev.b) == hipErrorNotReady) {
+            later.push_back(ev);
+            continue;
+        }
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) ctx->t_ms[ev.slot] += (double)ms;
+        ctx->free_events.push_back(ev.a), ctx->free_events.push_back(ev.b);
+    }
+    (void)hipGetLastError();  // hipErrorNotReady is recorded as the thread's last error
+    ctx->pending.swap(later);
+}
+
+// Host synchronisation on the critical path of an iteration: polling the stream avoids the ~20-30 us wake-up latency of a
+// blocking hipStreamSynchronize (there are four such points per iteration).
+hipError_t sync_spin(hipStream_t stream) {
+    hipError_t e;
+    while ((e = hipStreamQuery(stream)) == hipErrorNotReady) {
+    }
+    (void)hipGetLastError();  // hipErrorNotReady is recorded as the thread's last error: do not leave it for other HIP users (torch)
+    return e;
+}
+
+int set_device(dmsa_ctx* ctx) {
+    HIPCHK(hipSetDevice(ctx->device));
+    return DMSA_OK;
+}
+
+int num_params(const dmsa_ctx* ctx) { return ctx->model == MODEL_WINDOW ? ctx->win.ctrl.num_params() : ctx->key.frames.num_params(); }
+PoseChain& chain(dmsa_ctx* ctx) { return ctx->model == MODEL_WINDOW ? ctx->win.ctrl : ctx->key.frames; }
+int num_extra_rows(const dmsa_ctx* ctx) { return ctx->model == MODEL_WINDOW ? ctx->win.num_extra_rows() : ctx->key.num_extra_rows(); }
+
+
+// allocate everything whose size depends only on the point count
+int alloc_point_buffers(dmsa_ctx* ctx) {
+    const size_t n = (size_t)ctx->n;
+    HIPCHK(ctx->d_global.ensure(n * 16));
+    const size_t nb = (n + kAabbBlock - 1) / kAabbBlock;
+    HIPCHK(ctx->d_aabb.ensure(nb * 8 * sizeof(float)));
+    HIPCHK(ctx->d_lattice.ensure(2 * sizeof(LatticeTable)));
+    for (int l = 0; l < 2; ++l) {
+        if (l == 0) {  // both levels live in ONE array of 2n entries (level 1 behind level 0): they are sorted together
+            HIPCHK(ctx->d_code[0].ensure(2 * n * 8));
+            HIPCHK(ctx->d_idx[0].ensure(2 * n * 4));
+            HIPCHK(ctx->d_code_s[0].ensure(2 * n * 8));
+            HIPCHK(ctx->d_idx_s[0].ensure(2 * n * 4));
+        }
+        HIPCHK(ctx->d_leaf_incl[l].ensure(n * 4));
+        HIPCHK(ctx->d_leaf_start[l].ensure((n + 1) * 4));
+    }
+    for (int l = 0; l < 2; ++l) {
+        HIPCHK(ctx->d_head[l].ensure(n * 4));
+        HIPCHK(ctx->d_slot_acc[l].ensure(2 * n * 4));
+        HIPCHK(ctx->d_slot_cnt[l].ensure(2 * n * 4));
+        HIPCHK(ctx->d_gauss_of_slot[l].ensure(2 * n * 4));
+        HIPCHK(ctx->d_memb_of_slot[l].ensure(2 * n * 4));
+        HIPCHK(ctx->d_pslot_of_slot[l].ensure(2 * n * 4));
+        HIPCHK(ctx->d_sort_tmp[l].ensure(sort_pairs_temp_bytes(2 * n)));
+        HIPCHK(ctx->d_scan_tmp[l].ensure(scan_temp_bytes(2 * n)));
+    }
+    HIPCHK(ctx->d_counts.ensure(sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts)));  // read back together
+    // memberships: every point belongs to at most one set per resolution
+    HIPCHK(ctx->d_memb_local.ensure(2 * n * 16));
+    HIPCHK(ctx->d_memb_idx.ensure(2 * n * 4));
+    HIPCHK(ctx->d_memb_g.ensure(2 * n * 4));
+    HIPCHK(ctx->d_seg_off.ensure((2 * n + 2) * 4));
+    // sets have >= 2 members (two distinct ids) -- except the second half of a splitSet, which may keep a single member when
+    // min_num_points_per_set <= 1: size for one set per membership
+    HIPCHK(ctx->d_info12.ensure((2 * n + 16) * 48));
+    HIPCHK(ctx->d_wg_seg.ensure(4096 * 4));
+    if (ctx->flags & DMSA_FLAG_MIRROR_SUMS) {
+        // one entry per Gaussian, and M can approach 2n (see d_info12 above)
+        HIPCHK(ctx->d_order.ensure((2 * n + 16) * 4));
+        HIPCHK(ctx->d_fit_sums.ensure((2 * n + 16) * 6 * 8));
+    }
+    // tiled correspondence kernels: windows of 3T/4 members plus own-tile Gaussians (> T/4 members each) and their
+    // neighbours: tiles <= (4/3 + 8)*Mm/T + 1 with Mm <= 2n; one row list of `rows` entries per tile
+    const size_t max_tiles = 41 * n / (size_t)tile_points() + 64;  // windows + own tiles + one head per kTileGauss Gaussians (M <= n)
+    HIPCHK(ctx->d_memb_tile.ensure(tile_slot_capacity(n) * 16));
+    HIPCHK(ctx->d_pad_off.ensure((2 * n + 2) * 4));
+    HIPCHK(ctx->d_tiles.ensure(max_tiles * sizeof(TileDesc)));
+    HIPCHK(ctx->d_tile_rows.ensure(max_tiles * (size_t)ctx->rows * 4));
+    HIPCHK(ctx->d_fallback.ensure((2 * n / (size_t)tile_points() + 16) * 8));  // single-Gaussian tiles: > T members each
+    return DMSA_OK;
+}
+
+
+// The constants of the problem model the device-resident loop reads (IMU factors / gravity and odometry measurements) and the kernel
+// argument that points at them.  Called by the upload entry points after the host model (ctx->win / ctx->key) is initialised.
+int upload_loop_model(dmsa_ctx* ctx) {
+    auto put = [&](DevBuf& buf, const void* src, size_t bytes) -> int {
+        HIPCHK(buf.ensure(bytes + 16));
+        if (bytes) HIPCHK(hipMemcpy(buf.p, src, bytes, hipMemcpyHostToDevice));
+        return DMSA_OK;
+    };
+    LoopModel m{};
+    if (ctx->model == MODEL_WINDOW) {
+        const WindowHost& w = ctx->win;
+        m.model = 1, m.n = w.ctrl.n, m.P = w.ctrl.num_params(), m.extra = w.num_extra_rows();
+        m.stamps = ctx->d_stamps.as<double>(), m.fhw = ctx->d_fhw.as<double>(), m.traj_time = ctx->d_trajtime.as<double>();
+        m.imu = w.imu_consts();
+        m.imu.param_indices = nullptr, m.imu.preint_rot = m.imu.preint_pos = m.imu.preint_vel = m.imu.cov_inv = nullptr;
+        if (w.use_imu) {
+            CHK(put(ctx->d_imu_idx, w.param_indices.data(), w.param_indices.size() * 4));
+            CHK(put(ctx->d_imu_rot, w.preint_rot.data(), w.preint_rot.size() * 8));
+            CHK(put(ctx->d_imu_pos, w.preint_pos.data(), w.preint_pos.size() * 8));
+            CHK(put(ctx->d_imu_vel, w.preint_vel.data(), w.preint_vel.size() * 8));
+            CHK(put(ctx->d_imu_cov, w.cov_inv.data(), w.cov_inv.size() * 8));
+            m.imu.param_indices = ctx->d_imu_idx.as<int>(), m.imu.preint_rot = ctx->d_imu_rot.as<double>(), m.imu.preint_pos = ctx->d_imu_pos.as<double>();
+            m.imu.preint_vel = ctx->d_imu_vel.as<double>(), m.imu.cov_inv = ctx->d_imu_cov.as<double>();
+        }
+    } else {
+        const KeyframeHost& k = ctx->key;
+        m.model = 2, m.n = k.frames.n, m.P = k.frames.num_params(), m.extra = k.num_extra_rows();
+        m.key = k.row_consts();
+        m.key.measured_gravity = nullptr, m.key.gravity_plausible = nullptr, m.key.odom_transl = nullptr, m.key.odom_orient_mat = nullptr;
+        if (k.use_gravity) {
+            CHK(put(ctx->d_key_grav, k.measured_gravity.data(), k.measured_gravity.size() * 8));
+            CHK(put(ctx->d_key_plaus, k.gravity_plausible.data(), k.gravity_plausible.size() * 4));
+            m.key.measured_gravity = ctx->d_key_grav.as<double>(), m.key.gravity_plausible = ctx->d_key_plaus.as<int>();
+        }
+        if (k.use_odometry) {
+            CHK(put(ctx->d_key_odom_t, k.odom_transl.data(), k.odom_transl.size() * 8));
+            CHK(put(ctx->d_key_odom_R, k.odom_orient_mat.data(), k.odom_orient_mat.size() * 8));
+            m.key.odom_transl = ctx->d_key_odom_t.as<double>(), m.key.odom_orient_mat = ctx->d_key_odom_R.as<double>();
+        }
+    }
+    ctx->loop_model = m;
+    return DMSA_OK;
+}
+
+int upload_common(dmsa_ctx* ctx) {
+    CHK(alloc_point_buffers(ctx));
+    ctx->gaussians_valid = false;
+    ctx->centralized = false;
+    ctx->batch = 0;
+    ctx->base_table = nullptr;
+    ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
+    ctx->fit_guess_valid = false;
+    return DMSA_OK;
+}
+
+
+void write_back_poses(const PoseChain& c, double* rel_o, double* rel_t) {
+    std::copy(c.rel_o.begin(), c.rel_o.end(), rel_o);
+    std::copy(c.rel_t.begin(), c.rel_t.end(), rel_t);
+}
+
+
+extern "C" {
+
+void dmsa_default_debug_options(dmsa_debug_options* o) {
+    if (!o) return;
+    o->device_loop = 1, o->dual_stream = 1, o->serial_streams = 3, o->merge_sort = -1, o->key_compress = 1, o->fused_segments = 1, o->sort_prehist = 0;
+    o->library_sort = 0, o->overlap_batch = 1, o->serial_tree = 1, o->host_threads = 16, o->solve_threads = 12, o->host_timeline = 0, o->trace_time = 0;
+}
+// DMSA_DEBUG="name=value,name=value": the one environment variable of the library (include/dmsa_debug.h)
+static void apply_debug_env(dmsa_debug_options* o) {
+    const char* e = std::getenv("DMSA_DEBUG");
+    if (!e) return;
+    struct Field {
+        const char* name;
+        int32_t* v;
+    } fields[] = {{"device_loop", &o->device_loop},     {"dual_stream", &o->dual_stream},   {"serial_streams", &o->serial_streams}, {"merge_sort", &o->merge_sort},
+                  {"key_compress", &o->key_compress},   {"fused_segments", &o->fused_segments}, {"sort_prehist", &o->sort_prehist}, {"library_sort", &o->library_sort},
+                  {"overlap_batch", &o->overlap_batch}, {"serial_tree", &o->serial_tree},   {"host_threads", &o->host_threads},     {"solve_threads", &o->solve_threads},
+                  {"host_timeline", &o->host_timeline}, {"trace_time", &o->trace_time}};
+    std::string text(e);
+    size_t at = 0;
+    while (at < text.size()) {
+        size_t end = text.find(',', at);
+        if (end == std::string::npos) end = text.size();
+        const std::string item = text.substr(at, end - at);
+        const size_t eq = item.find('=');
+        if (eq != std::string::npos) {
+            const std::string name = item.substr(0, eq);
+            bool known = false;
+            for (auto& f : fields)
+                if (name == f.name) *f.v = std::atoi(item.c_str() + eq + 1), known = true;
+            if (!known) std::fprintf(stderr, "[dmsa] DMSA_DEBUG: unknown switch '%s' ignored\n", name.c_str());
+        }
+        at = end + 1;
+    }
+}
+int dmsa_create(int device, uint32_t flags, dmsa_ctx** out) { return dmsa_create_ex(device, flags, nullptr, out); }
+int dmsa_create_ex(int device, uint32_t flags, const dmsa_debug_options* options, dmsa_ctx** out) {
+    if (!out) return DMSA_ERR_INVALID;
+    dmsa_debug_options dbg;
+    dmsa_default_debug_options(&dbg);
+    if (options) dbg = *options;
+    apply_debug_env(&dbg);
+    dbg.serial_streams = std::max(1, std::min(3, dbg.serial_streams)), dbg.serial_tree = std::max(0, std::min(2, dbg.serial_tree));
+    dbg.host_threads = std::max(1, std::min(64, dbg.host_threads)), dbg.solve_threads = std::max(1, std::min(16, dbg.solve_threads));
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return DMSA_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return DMSA_ERR_NO_DEVICE;
+    dmsa_ctx* ctx = new (std::nothrow) dmsa_ctx();
+    if (!ctx) return DMSA_ERR_NOMEM;
+    // the reference's summation order is the default; DMSA_FLAG_FAST_SUMS opts out (internally the default is the MIRROR_SUMS bit)
+    flags = (flags & DMSA_FLAG_FAST_SUMS) ? (flags & ~DMSA_FLAG_MIRROR_SUMS) : (flags | DMSA_FLAG_MIRROR_SUMS);
+    ctx->device = device, ctx->flags = flags;
+    ctx->dbg = dbg;
+    ctx->compress_keys = dbg.key_compress != 0, ctx->overlap_batch = dbg.overlap_batch != 0, ctx->device_loop = dbg.device_loop != 0;
+    ctx->fused_segments = dbg.fused_segments != 0, ctx->prehist = dbg.sort_prehist != 0, ctx->dual_stream = dbg.dual_stream != 0;
+    ctx->merge_sort = dbg.merge_sort < 0 ? -1 : (dbg.merge_sort != 0 ? 1 : 0);
+    ctx->serial_two_streams = dbg.serial_streams != 1, ctx->serial_three_streams = dbg.serial_streams >= 3;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_scan0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_counts, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_tables, hipEventDisableTiming) != hipSuccess) {
+        delete ctx;
+        return DMSA_ERR_HIP;
+    }
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_rb), sizeof(dmsa_ctx::Readback), hipHostMallocDefault) != hipSuccess) {
+        delete ctx;
+        return DMSA_ERR_NOMEM;
+    }
+    std::memset(ctx->h_rb, 0, sizeof(dmsa_ctx::Readback));
+    ctx->h_lattice = ctx->h_rb->lattice;
+    *out = ctx;
+    return DMSA_OK;
+}
+
+void dmsa_destroy(dmsa_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    drain_timers(ctx);
+    for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->h_xpin) (void)hipHostFree(ctx->h_xpin);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_rb) (void)hipHostFree(ctx->h_rb);
+    if (ctx->h_Hp) (void)hipHostFree(ctx->h_Hp);
+    DevBuf* bufs[] = {&ctx->d_local, &ctx->d_nlocal, &ctx->d_ring, &ctx->d_global, &ctx->d_nglobal, &ctx->d_tables, &ctx->d_ctrl, &ctx->d_stamps,
+                      &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
+                      &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
+                      &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_memb_g, &ctx->d_seg_off,
+                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_order, &ctx->d_fit_sums, &ctx->d_tablesT, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_pad_off, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
+    for (DevBuf* b : bufs) b->release();
+    if (ctx->sp) {
+        for (DevBuf* b : ctx->sp->all) b->release();
+        delete ctx->sp;
+    }
+    delete ctx->pool;
+    for (int l = 0; l < 2; ++l)
+        for (DevBuf* b : {&ctx->d_head[l], &ctx->d_slot_acc[l], &ctx->d_slot_cnt[l], &ctx->d_gauss_of_slot[l], &ctx->d_memb_of_slot[l], &ctx->d_pslot_of_slot[l], &ctx->d_pos_slot_rank[l],
+                          &ctx->d_nsorted[l], &ctx->d_pair_d[l], &ctx->d_sort_tmp[l], &ctx->d_scan_tmp[l]})
+            b->release();
+    (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipEventDestroy(ctx->ev_fork), (void)hipEventDestroy(ctx->ev_scan0), (void)hipEventDestroy(ctx->ev_join), (void)hipEventDestroy(ctx->ev_counts);
+    (void)hipStreamSynchronize(ctx->stream3);
+    (void)hipEventDestroy(ctx->ev_join3), (void)hipEventDestroy(ctx->ev_tables);
+    (void)hipStreamDestroy(ctx->stream3);
+    (void)hipStreamDestroy(ctx->stream2);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* dmsa_last_error(const dmsa_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+void dmsa_default_settings(dmsa_settings* s) {
+    if (!s) return;
+    s->num_iter = 15, s->epsilon = 1e-5, s->use_analytic_jacobi = 0, s->step_length_optim = 0.05, s->max_step = 0.01, s->gauss_split = 0;
+    s->grid_size_1_factor = 2.0f, s->grid_size_2_factor = 5.0f, s->min_num_points_per_set = 6, s->min_num_gaussians = 30;
+    s->lambda_diag = 0.00001f, s->use_centralization = 1;
+}
+
+int dmsa_window_upload(dmsa_ctx* ctx, const dmsa_window_problem* p) {
+    if (!ctx || !p || p->num_points < 0 || p->num_static < 0) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    if ((p->num_points > 0 && (!p->xyz_local || !p->tform_idx || !p->ring_id)) || (p->num_static > 0 && (!p->xyz_static || !p->ring_id_static)) ||
+        !(p->min_grid_size > 0.0f)) {
+        ctx->err = "invalid window problem (null point arrays or min_grid_size <= 0)";
+        return DMSA_ERR_INVALID;
+    }
+    if (!ctx->win.init(*p)) {
+        ctx->err = "invalid window problem (fewer than 3 control poses, coincident stamps, null pose arrays or IMU parameter indices outside the time grid)";
+        return DMSA_ERR_INVALID;
+    }
+    if (ctx->win.ctrl.n > 64) {
+        ctx->err = "more than 64 control poses";
+        return DMSA_ERR_INVALID;
+    }
+    ctx->model = MODEL_WINDOW;
+    ctx->N = p->num_points, ctx->S = p->num_static, ctx->n = ctx->N + ctx->S;
+    ctx->rows = p->n_total + 1;
+    const size_t n = (size_t)ctx->n;
+    // local points: (x, y, z, row index); static points ride along with the identity row.  Packed into pinned memory by a few
+    // host threads (the user's arrays are pageable), then one DMA per array.
+    const size_t stage_bytes = n * 20 + 64;
+    if (stage_bytes > ctx->h_stage_cap) {
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr, ctx->h_stage_cap = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), stage_bytes + stage_bytes / 8, hipHostMallocDefault));
+        ctx->h_stage_cap = stage_bytes + stage_bytes / 8;
+    }
+    float* loc = reinterpret_cast<float*>(ctx->h_stage);
+    int32_t* ring = reinterpret_cast<int32_t*>(ctx->h_stage + n * 16);
+    const int32_t id_row = p->n_total;
+    const int64_t N = ctx->N, S = ctx->S;
+    std::atomic<bool> bad_row{false};
+    auto pack = [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+            if (i < N) {
+                const int32_t row = p->tform_idx[i];
+                if (row < 0 || row >= p->n_total) {
+                    bad_row = true;
+                    return;
+                }
+                loc[4 * i] = p->xyz_local[4 * i], loc[4 * i + 1] = p->xyz_local[4 * i + 1], loc[4 * i + 2] = p->xyz_local[4 * i + 2];
+                std::memcpy(&loc[4 * i + 3], &row, 4);
+                ring[i] = p->ring_id[i];
+            } else {
+                const int64_t k = i - N;
+                loc[4 * i] = p->xyz_static[4 * k], loc[4 * i + 1] = p->xyz_static[4 * k + 1], loc[4 * i + 2] = p->xyz_static[4 * k + 2];
+                std::memcpy(&loc[4 * i + 3], &id_row, 4);
+                ring[i] = p->ring_id_static[k];
+            }
+        }
+    };
+    if (n < 131072) {
+        pack(0, N + S);
+    } else {
+        workers(ctx).run_all([&](int t, int nt) { pack((N + S) * t / nt, (N + S) * (t + 1) / nt); });
+    }
+    if (bad_row) {
+        ctx->err = "tform_idx out of range";
+        return DMSA_ERR_INVALID;
+    }
+    HIPCHK(ctx->d_local.ensure(n * 16 + 16));
+    HIPCHK(ctx->d_ring.ensure(n * 4 + 16));
+    HIPCHK(hipMemcpyAsync(ctx->d_local.p, loc, n * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ring.p, ring, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next upload
+    const int C = ctx->win.ctrl.n;
+    HIPCHK(ctx->d_stamps.ensure((size_t)C * 8));
+    HIPCHK(ctx->d_fhw.ensure((size_t)C * 8));
+    HIPCHK(ctx->d_trajtime.ensure((size_t)p->n_total * 8));
+    HIPCHK(hipMemcpy(ctx->d_stamps.p, ctx->win.stamps.data(), (size_t)C * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_fhw.p, ctx->win.fh.w.data(), (size_t)C * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_trajtime.p, ctx->win.traj_time.data(), (size_t)p->n_total * 8, hipMemcpyHostToDevice));
+    ctx->win.ctrl.relative_to_global();
+    ctx->min_grid_size = p->min_grid_size;
+    CHK(upload_loop_model(ctx));
+    return upload_common(ctx);
+}
+
+int dmsa_keyframes_upload(dmsa_ctx* ctx, const dmsa_keyframe_problem* p) {
+    if (!ctx || !p || p->num_frames < 2) return DMSA_ERR_INVALID;
+    if (!p->frame_offset || !p->xyz_local || !p->normal_local || !p->ring_id || !p->rel_orient || !p->rel_transl || !(p->min_grid_size > 0.0f)) {
+        ctx->err = "invalid keyframe problem (null arrays or min_grid_size <= 0)";
+        return DMSA_ERR_INVALID;
+    }
+    if (p->frame_offset[0] != 0) {
+        ctx->err = "invalid keyframe problem (frame_offset[0] != 0)";
+        return DMSA_ERR_INVALID;
+    }
+    for (int k = 0; k < p->num_frames; ++k)
+        if (p->frame_offset[k + 1] < p->frame_offset[k]) {
+            ctx->err = "invalid keyframe problem (frame_offset not non-decreasing)";
+            return DMSA_ERR_INVALID;
+        }
+    CHK(set_device(ctx));
+    if (!ctx->key.init(*p)) return DMSA_ERR_INVALID;
+    ctx->model = MODEL_KEYFRAMES;
+    const int F = p->num_frames;
+    ctx->n = p->frame_offset[F], ctx->N = ctx->n, ctx->S = 0;
+    ctx->rows = F + 1;
+    const size_t n = (size_t)ctx->n;
+    std::vector<float> loc(n * 4);
+    for (int k = 0; k < F; ++k)
+        for (int64_t i = p->frame_offset[k]; i < p->frame_offset[k + 1]; ++i) {
+            loc[4 * i] = p->xyz_local[4 * i], loc[4 * i + 1] = p->xyz_local[4 * i + 1], loc[4 * i + 2] = p->xyz_local[4 * i + 2];
+            const int32_t row = k;
+            std::memcpy(&loc[4 * i + 3], &row, 4);
+        }
+    HIPCHK(ctx->d_local.ensure(n * 16 + 16));
+    HIPCHK(ctx->d_nlocal.ensure(n * 16 + 16));
+    HIPCHK(ctx->d_nglobal.ensure(n * 16 + 16));
+    HIPCHK(ctx->d_ring.ensure(n * 4 + 16));
+    HIPCHK(hipMemcpy(ctx->d_local.p, loc.data(), n * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_nlocal.p, p->normal_local, n * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_ring.p, p->ring_id, n * 4, hipMemcpyHostToDevice));
+    ctx->min_grid_size = p->min_grid_size;
+    CHK(upload_loop_model(ctx));
+    return upload_common(ctx);
+}
+
+
+}  // extern "C"

@@ -12,13 +12,13 @@ size_t scan_temp_bytes(size_t n);
 // stable LSD radix sort of (key u64, value u32) pairs on bits [0, end_bit)
 hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
                               uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream);
+// library_sort = false: the hand-written onesweep sort of radix_sort.hip; true: rocPRIM (dmsa_debug_options::library_sort)
 hipError_t sort_pairs_u32_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                              uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream);
-// radix_sort.hip: the hand-written onesweep sort behind sort_pairs_u32_u32 (DMSA_SORT=rocprim selects the library sort instead)
+                              uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream, bool library_sort = false);
+// radix_sort.hip: the hand-written onesweep sort behind sort_pairs_u32_u32
 size_t sort_pairs_u32_workspace_bytes(size_t n);
 hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                                    size_t n, unsigned end_bit, hipStream_t stream, bool prepared = false);
-bool sort_is_onesweep();  // false when DMSA_SORT=rocprim selects the library sort
 hipError_t inclusive_scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t stream);
 hipError_t exclusive_scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t stream);
 }  // namespace dmsa

@@ -17,27 +17,19 @@ size_t sort_pairs_temp_bytes(size_t n) {
     bytes = bytes > b32 ? bytes : b32;
     return bytes > own ? bytes : own;
 }
-static bool use_library_sort() {
-    static const bool v = [] {
-        const char* e = std::getenv("DMSA_SORT");
-        return e != nullptr && std::strcmp(e, "rocprim") == 0;
-    }();
-    return v;
-}
 size_t scan_temp_bytes(size_t n) {
     size_t a = 0, b = 0;
     (void)rocprim::inclusive_scan(nullptr, a, (const int32_t*)nullptr, (int32_t*)nullptr, n, rocprim::plus<int32_t>());
     (void)rocprim::exclusive_scan(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, int32_t(0), n, rocprim::plus<int32_t>());
     return a > b ? a : b;
 }
-bool sort_is_onesweep() { return !use_library_sort(); }
 hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
                               uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream) {
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, stream);
 }
 hipError_t sort_pairs_u32_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                              uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream) {
-    if (!use_library_sort() && end_bit <= 32) return sort_pairs_u32_onesweep(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, end_bit, stream);
+                              uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream, bool library_sort) {
+    if (!library_sort && end_bit <= 32) return sort_pairs_u32_onesweep(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, end_bit, stream);
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, stream);
 }
 hipError_t inclusive_scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t stream) {

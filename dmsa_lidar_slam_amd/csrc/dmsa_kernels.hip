@@ -2517,7 +2517,7 @@ void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, c
         attr_set = true;
     }
     // evaluations are chunked so that tiles x chunks fills the chip several times over
-    static const int target_wgs = std::getenv("DMSA_K4_TARGET_WGS") ? std::atoi(std::getenv("DMSA_K4_TARGET_WGS")) : 2048;
+    constexpr int target_wgs = 2048;
     int chunks = (target_wgs + num_tiles - 1) / num_tiles;
     if (chunks > B) chunks = B;
     if (chunks < 1) chunks = 1;

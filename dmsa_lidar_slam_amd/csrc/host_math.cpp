@@ -246,14 +246,7 @@ namespace {
 struct alignas(64) PhaseFlag {
     std::atomic<int> phase{0};
 };
-constexpr int kMaxSolveThreads = 12;
-int solve_thread_cap() {  // DMSA_SOLVE_THREADS overrides (1..16)
-    static const int cap = []() {
-        const char* e = std::getenv("DMSA_SOLVE_THREADS");
-        return e ? std::max(1, std::min(kMaxSolveThreads, std::atoi(e))) : kMaxSolveThreads;
-    }();
-    return cap;
-}
+constexpr int kMaxSolveThreads = 16;
 }  // namespace
 
 namespace {
@@ -275,7 +268,7 @@ inline void row_sub_scaled(double* x, const double* s, double f, size_t n, bool 
 inline void row_div(double* x, double d, size_t n, bool avx2) { avx2 ? row_div_avx2(x, d, n) : row_div_base(x, d, n); }
 }  // namespace
 
-void lm_solve(const double* Hin, const double* g, int P, double alpha, double* step, const ParallelRun* par) {
+void lm_solve(const double* Hin, const double* g, int P, double alpha, double* step, const ParallelRun* par, int max_threads) {
     // Gauss-Jordan with partial pivoting on [A | I]; the same operation on every element that reaches the result as the column-major
     // statement of the oracle (invert_dense), but stored row-major so that the row updates are contiguous.  Columns of A left of the
     // pivot hold exact zeros after their own elimination step (x - x*1) and are never read again, so they are not updated.
@@ -338,11 +331,11 @@ void lm_solve(const double* Hin, const double* g, int P, double alpha, double* s
     }
     const bool avx2 = __builtin_cpu_supports("avx2");
     PhaseFlag flags[kMaxSolveThreads];
-    static const bool trace = std::getenv("DMSA_SOLVE_TRACE") != nullptr;
+    constexpr bool trace = false;  // flip for a phase timing of the blocked solve on stderr
     const auto t_enter = std::chrono::steady_clock::now();
     double tr_us[4] = {0, 0, 0, 0};
     (*par)([&](int t, int nthr) {
-        const int use = std::min({nthr, solve_thread_cap(), std::max(1, P / 16)});
+        const int use = std::min({nthr, std::max(1, std::min(kMaxSolveThreads, max_threads)), std::max(1, P / 16)});
         if (t >= use) return;
         int phase = 0;
         auto barrier = [&]() {

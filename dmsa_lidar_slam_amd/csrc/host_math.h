@@ -91,7 +91,8 @@ struct KeyframeHost {
 // `par` (optional) runs a function on every thread of the caller's worker pool: fn(worker, num_workers); the row updates of a pivot
 // step are spread over them for P >= 64 (same operations, same result).
 using ParallelRun = std::function<void(const std::function<void(int, int)>&)>;
-void lm_solve(const double* H /* PxP col-major */, const double* g, int P, double alpha, double* step, const ParallelRun* par = nullptr);
+void lm_solve(const double* H /* PxP col-major */, const double* g, int P, double alpha, double* step, const ParallelRun* par = nullptr,
+              int max_threads = 12 /* of par's workers that take part */);
 // Same step through a partial-pivot LU solve instead of the explicit inverse (P^3/3 instead of 2 P^3 flops; differs from
 // lm_solve by rounding only).  Used by the fast path, where P reaches several hundred in the keyframe pass.
 void lm_solve_lu(const double* H /* PxP symmetric */, const double* g, int P, double alpha, double* step);

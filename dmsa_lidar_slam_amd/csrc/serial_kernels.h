@@ -19,7 +19,7 @@ struct SerialCounts {
     int32_t n_chain, n_small, max_members;
     int32_t n_long;  // the first n_long entries of the order: Gaussians of the latency tier (>= 2^12 members)
 };
-int serial_small_threshold();  // members; Gaussians up to this size go to the lane-per-evaluation kernel (DMSA_SERIAL_SMALL)
+int serial_small_threshold();  // members; Gaussians up to this size go to the lane-per-evaluation kernel
 // one workgroup: counting sort of the M = counts->level[0..1].num_gauss Gaussians by size class
 void launch_size_classes(const int32_t* seg_off, const GaussCounts* counts, uint32_t* order /* M */, SerialCounts* out, hipStream_t s);
 // tables [B][rows][12] -> tablesT [rows][B][12]: the B evaluations of one pose row are contiguous (lane = evaluation reads coalesce)
@@ -28,7 +28,8 @@ void launch_transpose_tables(const float* tables, int rows, int B, float* tables
 // The latency tier runs on s_long, the throughput tier on s_rest, the short tier on s_small (pass a stream twice to serialise tiers); the caller joins
 // the streams.
 void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tablesT, int B, const uint32_t* order,
-                             const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small);
+                             const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small,
+                             int tree_mode = 1 /* dmsa_debug_options::serial_tree */);
 // LDS / shape parameters chosen for a batch of B evaluations (exposed for the bench's roofline notes and the tests)
 struct SerialShape {
     int nsub_long, Bs_long;  // latency tier: evaluation sub-batches per Gaussian, evaluations per sub-batch

@@ -668,30 +668,8 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-int serial_small_threshold() {
-    static const int v = [] {
-        int t = 128;
-        if (const char* e = std::getenv("DMSA_SERIAL_SMALL")) t = std::atoi(e);
-        return t < 1 ? 1 : (t > kSmallMax ? kSmallMax : t);
-    }();
-    return v;
-}
-static int serial_long_log2() {  // Gaussians with >= 2^k members go to the latency tier (DMSA_SERIAL_LONG_LOG2)
-    static const int v = [] {
-        int t = 12;
-        if (const char* e = std::getenv("DMSA_SERIAL_LONG_LOG2")) t = std::atoi(e);
-        return t < 8 ? 8 : (t > 30 ? 30 : t);
-    }();
-    return v;
-}
-static int env_int(const char* name, int dflt, int lo, int hi) {
-    const char* e = std::getenv(name);
-    const int t = e ? std::atoi(e) : dflt;
-    return t < lo ? lo : (t > hi ? hi : t);
-}
-static int serial_tree_mode() {  // DMSA_SERIAL_TREE: 0 chained second pass, 1 parallel second pass with exactness test (default), 2 both (test hook)
-    return env_int("DMSA_SERIAL_TREE", 1, 0, 2);  // read per launch: the tests switch it inside one process
-}
+int serial_small_threshold() { return 128; }  // members; Gaussians up to this size go to the lane-per-evaluation kernel
+static int serial_long_log2() { return 12; }  // Gaussians with >= 2^12 members go to the latency tier
 unsigned long long serial_fallback_sums(bool reset) {
     unsigned long long v = 0;
     (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_fallback_sums), sizeof(v));
@@ -702,7 +680,7 @@ unsigned long long serial_fallback_sums(bool reset) {
     return v;
 }
 SerialShape serial_shape(int B) {
-    static const int bs_long = env_int("DMSA_SERIAL_BS_LONG", kBL, 1, kBL), bs_mid = env_int("DMSA_SERIAL_BS", kBL, 1, kBL);
+    constexpr int bs_long = kBL, bs_mid = kBL;  // evaluations per workgroup of the two chain tiers
     SerialShape s;
     s.nsub_long = (B + bs_long - 1) / bs_long, s.Bs_long = (B + s.nsub_long - 1) / s.nsub_long;
     s.nsub = (B + bs_mid - 1) / bs_mid, s.Bs = (B + s.nsub - 1) / s.nsub;
@@ -720,13 +698,12 @@ void launch_transpose_tables(const float* tables, int rows, int B, float* tables
                        reinterpret_cast<float4*>(tablesT));
 }
 void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tablesT, int B, const uint32_t* order,
-                             const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small) {
+                             const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small, int tree_mode) {
     if (B <= 0) return;
     const SerialShape sh = serial_shape(B);
     const float4* info = reinterpret_cast<const float4*>(info12);
     const float4* tabT = reinterpret_cast<const float4*>(tablesT);
     const int n_long = sc.n_long, n_mid = sc.n_chain - sc.n_long;
-    const int tree_mode = serial_tree_mode();
     // latency tier first (its longest chain bounds the batch), blocks in descending size; the other tiers fill the chip around it
     if (n_long > 0)
         hipLaunchKernelGGL((k_residuals_chain<8, true, 64>), dim3((unsigned)n_long * sh.nsub_long), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
@@ -747,7 +724,7 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
             hipLaunchKernelGGL(k_residuals_small<64>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
     }
 #ifdef DMSA_SERIAL_TIMELINE
-    if (std::getenv("DMSA_SERIAL_DEBUG") && n_long > 0) {
+    if (n_long > 0) {
         static long long h[2][16][64][2];
         (void)hipStreamSynchronize(s_long);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tl), sizeof(h));

@@ -1,0 +1,318 @@
+// voxelize_driver.cpp — currentGauss.reset() + createGaussianSets at both resolutions + Gaussian fit + updateRebalancingWeights
+// (DmsaOptimizer.h:78-96) as one launch sequence over three streams; kernels in dmsa_kernels.hip / radix_sort.hip / serial_kernels.hip.
+#include "dmsa_ctx.h"
+
+// ---- Gaussians (DmsaOptimizer.h:78-96) ---------------------------------------------------------------------
+// `overlap` (optional) runs on the host after every voxelisation kernel has been enqueued and before the counts are read
+// back: host work placed there hides behind the GPU.
+int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<int()>& overlap, bool allow_speculation, bool allow_compression) {
+    const int64_t n = ctx->n;
+    ctx->gaussians_valid = false;
+    ctx->order_valid = false;
+    ctx->M = 0, ctx->M1 = 0, ctx->Mm = 0;
+    const bool lvl_on[2] = {s.grid_size_1_factor > std::numeric_limits<float>::min(), s.grid_size_2_factor > std::numeric_limits<float>::min()};
+    // createGaussianSets(set, factor * minGridSize, ...): float product, widened to double by the octree constructor
+    ctx->level_res[0] = (double)(s.grid_size_1_factor * ctx->min_grid_size);
+    ctx->level_res[1] = (double)(s.grid_size_2_factor * ctx->min_grid_size);
+    if (!lvl_on[0]) ctx->level_res[0] = ctx->level_res[1];
+    if (!lvl_on[1]) ctx->level_res[1] = ctx->level_res[0];
+    const bool compress = ctx->compress_keys && allow_compression;
+    const bool speculate = allow_speculation && ctx->depth_guess[0] >= 0 && ctx->depth_guess[1] >= 0 && ctx->depth_guess[0] < 20 && ctx->depth_guess[1] < 20 &&
+                           (!compress || (ctx->bits_guess[0] >= 0 && ctx->bits_guess[1] >= 0));
+    // the key kernels count the digits of the sort that follows (own sort, 32-bit codes): no clearing kernel, no histogram pass
+    const bool prehist = !ctx->dbg.library_sort && ctx->prehist;
+    {
+        ScopedTimer tm(ctx, T_VOXEL);
+        const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
+        if (!ctx->aabb_fresh)  // the device loop's fused transform already left the block bounds and cleared the counters
+            launch_block_aabb(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts),
+                              ctx->stream);
+        ctx->aabb_fresh = false;
+        launch_lattice(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), nb, ctx->level_res[0], ctx->level_res[1], compress,
+                       ctx->d_lattice.as<LatticeTable>(), prehist ? ctx->d_sort_tmp[0].p : nullptr, prehist ? ctx->d_sort_tmp[1].p : nullptr, ctx->stream);
+        if (!speculate) {  // sync #1: tree depths select the radix-sort bit range (speculation reads them with the counts instead)
+            HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(sync_spin(ctx->stream));
+        }
+    }
+    // The sort only needs an UPPER bound of the tree depth.  From the second iteration on the previous depths are used
+    // without waiting for the lattice kernel; the true depths arrive with the counts (sync #2) and a too-small guess (the
+    // bounding box doubled between two iterations) re-runs the voxelisation synchronously.
+    int sort_depth[2], sort_bits[2];
+    for (int l = 0; l < 2; ++l) {
+        sort_depth[l] = speculate ? ctx->depth_guess[l] : ctx->h_lattice[l].final_depth;
+        // width of the leaf codes: all 3*depth bits, or (compressed) only the bits that vary over the points
+        sort_bits[l] = !compress ? 3 * sort_depth[l] : (speculate ? ctx->bits_guess[l] : ctx->h_lattice[l].total_bits);
+        if (!speculate && lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
+    }
+    GaussCounts* counts = ctx->d_counts.as<GaussCounts>();
+    const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS);
+    const bool split = s.gauss_split != 0 && ctx->model == MODEL_KEYFRAMES;
+    if (split)
+        for (int l = 0; l < 2; ++l) {
+            HIPCHK(ctx->d_pos_slot_rank[l].ensure((size_t)n * 4));
+            HIPCHK(ctx->d_nsorted[l].ensure((size_t)n * 16));
+            HIPCHK(ctx->d_pair_d[l].ensure(split_scratch_bytes(n)));
+        }
+    // The two resolutions are independent until their member lists are appended (level 1 starts at level 0's totals):
+    // level 0 runs on `stream`, level 1 on `stream2`; their launches are enqueued stage by stage so that both streams fill.
+    const bool two = ctx->dual_stream && lvl_on[0] && lvl_on[1];
+    hipStream_t st[2] = {ctx->stream, two ? ctx->stream2 : ctx->stream};
+    bool k32v[2] = {false, false};
+    // Both resolutions are keyed into one array of 2n (code, point) pairs -- level 1 carries a tag bit above the widest code --
+    // and sorted by ONE radix sort: half the launches, twice the parallelism per pass, and the sorted halves are the two levels.
+    const int tag_bit = std::max(sort_bits[0], sort_bits[1]) + 1;  // bit `sort_bits` is the marker of non-finite points
+    const unsigned end_bit = (unsigned)(tag_bit + 1);
+    const bool k32 = end_bit <= 32;
+    {
+        const size_t ksz = k32 ? 4 : 8;
+        for (int l = 0; l < 2; ++l) {
+            k32v[l] = ctx->key32[l] = k32;
+            ctx->code_v[l] = ctx->d_code[0].as<char>() + (size_t)l * n * ksz, ctx->code_s_v[l] = ctx->d_code_s[0].as<char>() + (size_t)l * n * ksz;
+            ctx->idx_v[l] = ctx->d_idx[0].as<uint32_t>() + (size_t)l * n, ctx->idx_s_v[l] = ctx->d_idx_s[0].as<uint32_t>() + (size_t)l * n;
+        }
+    }
+    // Small clouds (keyframe sets: 3 x 10^5 points) are launch-bound: one sort of 2n pairs on one stream.  Large clouds (the window:
+    // 1.5 x 10^6) keep the two levels on two streams with one sort each (a sort only looks at the bits below its end bit, so the
+    // tag is inert there).
+    const bool merged = ctx->merge_sort < 0 ? n <= (int64_t)(1 << 20) : ctx->merge_sort != 0;
+    const bool prepared = prehist && k32;
+    SortPlan plan[2];  // merged: one sort of 2n pairs in workspace 0, both key kernels count into its header
+    for (int l = 0; l < 2; ++l)
+        plan[l] = merged ? sort_pairs_u32_plan(ctx->d_sort_tmp[0].p, (size_t)(2 * n), end_bit)
+                         : sort_pairs_u32_plan(ctx->d_sort_tmp[l].p, (size_t)n, (unsigned)(sort_bits[l] + 1));
+    auto stage_keys = [&](int l, hipStream_t stream) {  // a disabled level is keyed with the other level's lattice (level_res is aliased) and ignored later
+        SortPlan pl = plan[l];
+        if (merged && l == 1) pl.state_words = 0;  // the look-back words of the common sort are cleared once
+        launch_voxel_keys(ctx->d_global.as<float4>(), n, ctx->d_lattice.as<LatticeTable>() + l, ctx->level_res[l], ctx->code_v[l], k32, ctx->idx_v[l],
+                          l == 0 ? 0ull : (1ull << tag_bit), prepared ? &pl : nullptr, stream);
+    };
+    auto stage_sort_both = [&]() -> int {
+        stage_keys(0, ctx->stream), stage_keys(1, ctx->stream);
+        if (k32 && prepared)
+            HIPCHK(sort_pairs_u32_onesweep(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_code[0].as<uint32_t>(), ctx->d_code_s[0].as<uint32_t>(),
+                                           ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream, true));
+        else if (k32)
+            HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_code[0].as<uint32_t>(), ctx->d_code_s[0].as<uint32_t>(),
+                                      ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream, ctx->dbg.library_sort != 0));
+        else
+            HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_code[0].as<uint64_t>(), ctx->d_code_s[0].as<uint64_t>(),
+                                      ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream));
+        return DMSA_OK;
+    };
+    auto stage_sort = [&](int l) -> int {
+        stage_keys(l, st[l]);
+        const unsigned eb = (unsigned)(sort_bits[l] + 1);
+        if (k32 && prepared)
+            HIPCHK(sort_pairs_u32_onesweep(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, (const uint32_t*)ctx->code_v[l], (uint32_t*)ctx->code_s_v[l], ctx->idx_v[l],
+                                           ctx->idx_s_v[l], (size_t)n, eb, st[l], true));
+        else if (k32)
+            HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, (const uint32_t*)ctx->code_v[l], (uint32_t*)ctx->code_s_v[l], ctx->idx_v[l],
+                                      ctx->idx_s_v[l], (size_t)n, eb, st[l], ctx->dbg.library_sort != 0));
+        else
+            HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, (const uint64_t*)ctx->code_v[l], (uint64_t*)ctx->code_s_v[l], ctx->idx_v[l],
+                                      ctx->idx_s_v[l], (size_t)n, eb, st[l]));
+        return DMSA_OK;
+    };
+    auto stage_leaves = [&](int l) -> int {
+        const LatticeTable* tab = ctx->d_lattice.as<LatticeTable>() + l;
+        const bool k32 = k32v[l];
+        if (ctx->fused_segments) {
+            // one single-pass kernel; its look-back state is never cleared (epoch-tagged words, running ticket counter)
+            const size_t need = 8 * (size_t)(1 + leaf_segment_tiles(n));
+            if (need > ctx->d_seg_state[l].cap) {
+                HIPCHK(ctx->d_seg_state[l].ensure(need));
+                HIPCHK(hipMemsetAsync(ctx->d_seg_state[l].p, 0, ctx->d_seg_state[l].cap, st[l]));
+                ctx->seg_epoch[l] = 0, ctx->seg_ticket[l] = 0;
+            }
+            ctx->seg_epoch[l] += 1;
+            if (ctx->seg_epoch[l] == 0) ctx->seg_epoch[l] = 1;
+            launch_leaf_segments(ctx->code_s_v[l], k32, n, tab, ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), &counts->level[l],
+                                 ctx->d_seg_state[l].as<unsigned long long>(), ctx->seg_epoch[l], ctx->seg_ticket[l], st[l]);
+            ctx->seg_ticket[l] += (uint32_t)leaf_segment_tiles(n);
+        } else {
+            launch_head_flags(ctx->code_s_v[l], k32, n, tab, ctx->d_head[l].as<int32_t>(), st[l]);
+            HIPCHK(inclusive_scan_i32(ctx->d_scan_tmp[l].p, ctx->d_scan_tmp[l].cap, ctx->d_head[l].as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), (size_t)n, st[l]));
+            launch_leaf_starts(ctx->d_head[l].as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), ctx->code_s_v[l], k32, tab, n,
+                               ctx->d_leaf_start[l].as<int32_t>(), &counts->level[l], st[l]);
+        }
+        launch_leaf_accept(ctx->d_leaf_start[l].as<int32_t>(), ctx->idx_s_v[l], ctx->d_ring.as<int32_t>(), &counts->level[l],
+                           s.min_num_points_per_set, n, ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(), st[l]);
+        if (split)
+            launch_leaf_split(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->idx_s_v[l], ctx->d_ring.as<int32_t>(),
+                              ctx->d_nglobal.as<float4>(), &counts->level[l], s.min_num_points_per_set, n, ctx->d_nsorted[l].as<float4>(),
+                              ctx->d_pair_d[l].as<unsigned long long>(), ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(),
+                              ctx->d_pos_slot_rank[l].as<int32_t>(), st[l]);
+        launch_leaf_scan(ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(), ctx->d_gauss_of_slot[l].as<int32_t>(), ctx->d_memb_of_slot[l].as<int32_t>(),
+                         ctx->d_pslot_of_slot[l].as<int32_t>(), &counts->level[l], st[l]);
+        return DMSA_OK;
+    };
+    auto stage_gather = [&](int l, hipStream_t gs) {
+        const LatticeTable* tab = ctx->d_lattice.as<LatticeTable>() + l;
+        launch_gather_members(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->idx_s_v[l],
+                              ctx->code_s_v[l], k32v[l], tab, ctx->d_slot_acc[l].as<int32_t>(), ctx->d_gauss_of_slot[l].as<int32_t>(),
+                              ctx->d_memb_of_slot[l].as<int32_t>(), split ? ctx->d_pos_slot_rank[l].as<int32_t>() : nullptr, ctx->d_local.as<float4>(),
+                              ctx->d_slot_cnt[l].as<int32_t>(), counts, l, n, ctx->d_memb_local.as<float4>(), ctx->d_memb_idx.as<int32_t>(),
+                              ctx->d_memb_g.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), ctx->d_pslot_of_slot[l].as<int32_t>(), ctx->d_pad_off.as<int32_t>(), gs);
+    };
+    {
+        ScopedTimer tm(ctx, T_VOXEL);
+        if (merged) CHK(stage_sort_both());
+        if (two) {
+            HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        }
+        if (!merged)
+            for (int l = 0; l < 2; ++l)
+                if (lvl_on[l]) CHK(stage_sort(l));
+        for (int l = 0; l < 2; ++l) {
+            if (!lvl_on[l]) continue;
+            CHK(stage_leaves(l));
+        }
+        // Both gathers on the first stream (level 1 appends behind level 0's totals anyway): the level-1 chain ends with its leaf scan,
+        // long before level 0's gather is through, so the wait below finds its event signalled -- a join at the END of a stream costs
+        // ~20 us of cross-queue signalling in front of everything that follows.
+        if (two) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+        if (lvl_on[0]) stage_gather(0, ctx->stream);
+        if (two) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        if (lvl_on[1]) stage_gather(1, ctx->stream);
+    }
+    if (!tiles_on) {
+        ScopedTimer tm(ctx, T_FIT);
+        for (int l = 0; l < 2; ++l)
+            if (lvl_on[l])
+                launch_gauss_fit(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(), counts, l, ctx->d_info12.as<float>(),
+                                 (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
+    }
+    // Tiles of whole Gaussians for the fit and the correspondence kernel; their counts travel with M / Mm.
+    TileCounts htc{};
+    if (tiles_on) {
+        ScopedTimer tm(ctx, T_FIT);
+        launch_build_tiles(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_memb_local.as<float4>(), ctx->d_memb_g.as<int32_t>(), ctx->rows, ctx->d_tiles.as<TileDesc>(),
+                           reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_memb_tile.as<float4>(), ctx->d_tile_rows.as<int32_t>(),
+                           ctx->d_pad_off.as<int32_t>(), ctx->stream);
+    }
+    const bool classes_on = !tiles_on && (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0;
+    if (classes_on)  // size classes of the reference-order correspondence kernels: needs only seg_off, so it runs before the read-back
+        launch_size_classes(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_order.as<uint32_t>(),
+                            reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts) + sizeof(TileCounts)), ctx->stream);
+    // The read-back of the counts runs on the third stream: a device-to-host copy ends with a system-scope release that holds up the
+    // stream it is on for ~20 us, and the fit behind it does not need to wait for that.
+    hipStream_t rb = ctx->dual_stream ? ctx->stream3 : ctx->stream;
+    if (rb != ctx->stream) {
+        HIPCHK(hipEventRecord(ctx->ev_scan0, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(rb, ctx->ev_scan0, 0));
+    }
+    HIPCHK(hipMemcpyAsync(&ctx->h_rb->g, ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts), hipMemcpyDeviceToHost, rb));
+    HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, rb));  // incl. out_of_range
+    if (ctx->rb_extra_bytes)  // device loop: the previous iteration's stop decision travels with the counts
+        HIPCHK(hipMemcpyAsync(ctx->rb_extra_dst, ctx->rb_extra_src, ctx->rb_extra_bytes, hipMemcpyDeviceToHost, rb));
+    // The fit does not need the counts on the host (fixed grids, device-side tile counts): with the LDS table sized for ALL pose rows
+    // it is enqueued right behind the read-back, so the GPU keeps working while the host waits for M (sync #2 waits on an event
+    // recorded BEFORE the fit, not on the stream).
+    const bool early_fit = tiles_on && (size_t)(ctx->rows + 1) * 48 <= 56 * 1024;
+    HIPCHK(hipEventRecord(ctx->ev_counts, rb));
+    // Default path: the fit (oracle's tree order) is enqueued BEHIND the read-back as well, with the previous iteration's class
+    // counts (+ margin) as grids -- the kernels take the true ranges from device memory, surplus workgroups exit, and whatever the
+    // guess missed is launched after sync #2.  The three classes run side by side on two streams (each is latency-bound on its own).
+    const int32_t* d_sc = reinterpret_cast<const int32_t*>(ctx->d_counts.as<char>() + sizeof(GaussCounts) + sizeof(TileCounts));
+    const float* fit_table = ctx->base_table ? ctx->base_table : ctx->d_tables.as<float>();
+    int fit_launched[3] = {0, 0, 0}, finish_launched = 0;
+    auto launch_fit = [&](const int first[3], const int tasks[3], int finish_gauss) -> int {
+        ScopedTimer tm(ctx, T_FIT);
+        {
+            // one launch for the three size classes and the rebalancing weights: no fork to a second stream, no join
+            launch_gauss_fit_all(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, first, tasks,
+                                 ctx->d_fit_sums.as<double>(), counts, ctx->d_info12.as<float>(), true, ctx->stream);
+        }
+        launch_gauss_fit_finish(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_fit_sums.as<double>(), finish_gauss, ctx->d_info12.as<float>(), ctx->stream);
+        HIPCHK(hipGetLastError());
+        return DMSA_OK;
+    };
+    if (classes_on && ctx->fit_guess_valid) {
+        const SerialCounts& pg = ctx->serial_counts;  // previous iteration
+        const int first[3] = {0, 0, 0};
+        auto grow = [](int v) { return v + v / 8 + 16; };
+        fit_launched[0] = grow(pg.n_long), fit_launched[1] = grow(pg.n_chain - pg.n_long), fit_launched[2] = grow(pg.n_small);
+        finish_launched = grow(pg.n_chain + pg.n_small);
+        CHK(launch_fit(first, fit_launched, finish_launched));
+    }
+    if (early_fit) {
+        ScopedTimer tm(ctx, T_FIT);
+        launch_fit_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_tables.as<float>(), ctx->rows + 1, ctx->d_tiles.as<TileDesc>(),
+                         reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
+                         ctx->d_info12.as<float>(), ctx->stream);
+        launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), false, ctx->stream);
+    }
+    g_tl.mark("voxel enq");
+    if (overlap) CHK(overlap());
+    g_tl.mark("jacobian batch host+enq");
+    {  // sync #2: M sizes every later launch
+        hipError_t e;
+        while ((e = hipEventQuery(ctx->ev_counts)) == hipErrorNotReady) {
+        }
+        (void)hipGetLastError();  // see sync_spin
+        HIPCHK(e);
+    }
+    g_tl.mark("sync#2 wait");
+    const GaussCounts h = ctx->h_rb->g;
+    htc = ctx->h_rb->t;
+    for (int l = 0; l < 2; ++l) {
+        if (lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
+        const int true_bits = compress ? ctx->h_lattice[l].total_bits : 3 * ctx->h_lattice[l].final_depth;
+        if (lvl_on[l] && compress && ctx->h_lattice[l].out_of_range) {
+            ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
+            return build_gaussians(ctx, s, nullptr, false, false);  // a key left the predicted range: redo with full-width codes
+        }
+        if (speculate && lvl_on[l] && (ctx->h_lattice[l].final_depth > sort_depth[l] || true_bits > sort_bits[l])) {
+            ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
+            return build_gaussians(ctx, s, nullptr, false, allow_compression);  // mis-speculated: redo (overlap work already ran)
+        }
+        ctx->depth_guess[l] = ctx->h_lattice[l].final_depth;
+        ctx->bits_guess[l] = ctx->h_lattice[l].total_bits;
+    }
+    ctx->num_tiles = htc.num_tiles, ctx->num_fallback = htc.num_fallback, ctx->tile_max_rows = htc.max_rows, ctx->tile_max_gauss = htc.max_gauss;
+    ctx->tiles_usable = !tiles_on || tiled_kernels_fit(htc.max_rows, htc.max_gauss);
+    {
+        ScopedTimer tm(ctx, T_FIT);
+        if (tiles_on && !early_fit && ctx->num_tiles > 0 && !ctx->tiles_usable) {
+            // tiles that reference more pose rows than fit in LDS: wave-per-set fit on the gathered members instead
+            for (int l = 0; l < 2; ++l)
+                if (lvl_on[l])
+                    launch_gauss_fit(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(), counts, l, ctx->d_info12.as<float>(), false,
+                                     ctx->stream);
+        } else if (tiles_on && !early_fit && ctx->num_tiles > 0)
+            launch_fit_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_tables.as<float>(), ctx->tile_max_rows,
+                             ctx->d_tiles.as<TileDesc>(), reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
+                             ctx->d_info12.as<float>(), ctx->stream);
+        const int M_all = h.level[0].num_gauss + h.level[1].num_gauss;
+        if (classes_on) {
+            // whatever the pre-sync launches did not cover (first iteration, or a class that grew by more than the margin)
+            ctx->serial_counts = ctx->h_rb->sc;
+            const SerialCounts& sc = ctx->serial_counts;
+            const int want[3] = {sc.n_long, sc.n_chain - sc.n_long, sc.n_small};
+            int rest[3], any = 0;
+            for (int c = 0; c < 3; ++c) rest[c] = std::max(0, want[c] - fit_launched[c]), any += rest[c];
+            if (M_all > 0 && (any > 0 || finish_launched < M_all)) CHK(launch_fit(fit_launched, rest, M_all));
+            ctx->fit_guess_valid = M_all > 0;
+            ctx->order_valid = true;
+        }
+        if (!early_fit && !classes_on)
+            launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
+    }
+    HIPCHK(hipGetLastError());
+    ctx->M1 = h.level[0].num_gauss;
+    ctx->M = h.level[0].num_gauss + h.level[1].num_gauss;
+    ctx->Mm = (int64_t)h.level[0].num_memb + h.level[1].num_memb;
+    if (ctx->M > 0) {
+        // enough workgroups to fill 256 CUs several times over, but never more workgroups than Gaussians
+        int wg = ctx->cfg_num_wg;
+        if (wg > ctx->M) wg = ctx->M;
+        ctx->num_wg = wg;
+        // the workgroup partition only feeds the streaming / parity correspondence kernels
+        if (!classes_on && (!tiles_on || ctx->num_tiles == 0 || !ctx->tiles_usable)) launch_segment_partition(ctx->d_seg_off.as<int32_t>(), ctx->M, wg, ctx->d_wg_seg.as<int32_t>(), ctx->stream);
+    }
+    ctx->gaussians_valid = true;
+    return DMSA_OK;
+}
+

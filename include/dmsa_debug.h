@@ -1,0 +1,48 @@
+/*
+ * dmsa_debug.h — debug / experiment switches of a dmsa_ctx.
+ *
+ * Production code never needs this header: dmsa_create() (dmsa_hip.h) uses the defaults listed here.  The switches select between
+ * implementations that produce THE SAME RESULTS (tests run both sides of each); they exist for A/B timing, for bisecting, and for the
+ * parity tests that exercise a fallback on purpose.  They are fixed when the context is created:
+ *
+ *   dmsa_create_ex(device, flags, &options, &ctx)     from code, or
+ *   DMSA_DEBUG="name=value,name=value" in the environment: read ONCE by dmsa_create / dmsa_create_ex, overrides fields by name
+ *                                                      (profiling scripts).  It is the only environment variable the library reads.
+ */
+#ifndef DMSA_DEBUG_H
+#define DMSA_DEBUG_H
+
+#include "dmsa_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dmsa_debug_options {
+    int32_t device_loop;     /* 1   optimizeSet's control state lives on the device (csrc/loop_kernels.hip); 0: the host drives the loop
+                                     (three waits per iteration, as in rounds 1-2)                                                        */
+    int32_t dual_stream;     /* 1   the two voxel resolutions and the count read-back on their own streams; 0: everything on one stream   */
+    int32_t serial_streams;  /* 3   streams the three tiers of the reference-order correspondence kernels run on (1, 2 or 3)              */
+    int32_t merge_sort;      /* -1  both voxel levels in ONE radix sort (1), one sort per level (0), or by point count (-1: <= 2^20 merged) */
+    int32_t key_compress;    /* 1   drop the key bits that are equal for all points before sorting; 0: full 3 x depth bit leaf codes
+                                     (64-bit codes and the library sort from depth 11 on -- also the fallback of a mis-predicted range)   */
+    int32_t fused_segments;  /* 1   head flags + scan + leaf starts in one single-pass kernel; 0: three kernels with a library scan      */
+    int32_t sort_prehist;    /* 0   the key kernels count the sort digits (measured 1.5 % slower than the sort's own histogram pass)     */
+    int32_t library_sort;    /* 0   rocPRIM's radix sort instead of csrc/radix_sort.hip                                                  */
+    int32_t overlap_batch;   /* 1   host-driven loop only: host math of the Jacobian batch while the GPU voxelises                        */
+    int32_t serial_tree;     /* 1   double sum of the chain tiers: 1 parallel reduction when the exactness test allows it,
+                                     0 always the member-order chain, 2 both and keep the chain's result (test hook)                      */
+    int32_t host_threads;    /* 16  worker threads of the context (upload packing, host-built pose tables, host solve)                   */
+    int32_t solve_threads;   /* 12  of which the blocked host LM solve uses at most this many                                            */
+    int32_t host_timeline;   /* 0   print host-side time stamps of the last iteration of every optimize call to stderr                   */
+    int32_t trace_time;      /* 0   print upload / optimize wall time of dmsa_optimize_window to stderr                                  */
+} dmsa_debug_options;
+
+void dmsa_default_debug_options(dmsa_debug_options* o);
+/* dmsa_create with explicit switches (`options` may be NULL = defaults); DMSA_DEBUG still overrides by name. */
+int dmsa_create_ex(int device, uint32_t flags, const dmsa_debug_options* options, dmsa_ctx** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMSA_DEBUG_H */

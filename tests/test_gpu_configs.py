@@ -23,12 +23,12 @@ def _pose_diff(orc, a, b):
     return np.abs(ga_t - gb_t).max(), np.abs(ga_o - gb_o).max()
 
 
-def _parity_run(hip, orc, prob, s, window=True):
+def _parity_run(hip, orc, prob, s, window=True, debug=None):
     """Whole optimizeSet on the parity path against the oracle: same control flow, poses within 1e-4 m / 1e-4 rad."""
     p_ref, p_gpu = prob.copy(), prob.copy()
     fn = orc.optimize_window if window else orc.optimize_keyframes
     rep_ref, _, trace = fn(p_ref, s)
-    opt = hip.DmsaOptimizer()
+    opt = hip.DmsaOptimizer(debug=debug)
     rep = opt.optimizeSet(p_gpu, s)
     assert (rep.iterations, rep.stop_reason, rep.evaluations) == (rep_ref.iterations, rep_ref.stop_reason, rep_ref.evaluations)
     for a, b in zip(trace, opt.trace()):
@@ -383,8 +383,7 @@ def test_parallel_second_pass_of_the_chain_tiers(hip, orc, full_window, monkeypa
         params = np.stack([pbase] + [pbase + H_INCR * np.eye(len(pbase))[k] for k in range(8)])  # 9 evaluations: two sub-batches
         e_ref = None
         for mode in ("1", "2", "0"):
-            monkeypatch.setenv("DMSA_SERIAL_TREE", mode)
-            opt = hip.DmsaOptimizer()
+            opt = hip.DmsaOptimizer(debug={"serial_tree": int(mode)})
             opt.upload(prob)
             opt.poseTables(pbase[None, :], download=False)
             opt.updateGlobalPoints(0, download=False)
@@ -436,11 +435,11 @@ def test_window_beyond_two_million_points(hip, orc):
 
 
 @pytest.mark.parametrize("compress", ["1", "0"])
-def test_fine_grid_and_full_width_codes(hip, orc, compress, monkeypatch):
-    """minGridSize = 0.012 m: trees of depth >= 11.  With DMSA_KEY_COMPRESS=0 the leaf codes keep all 3 x depth bits and no longer fit 32
+def test_fine_grid_and_full_width_codes(hip, orc, compress):
+    """minGridSize = 0.012 m: trees of depth >= 11.  With key_compress = 0 (include/dmsa_debug.h) the leaf codes keep all 3 x depth bits and no longer fit 32
     bits -- the 64-bit code path (library sort, 64-bit leaf segmentation), which is also what a mis-predicted code range falls back to.
     Same structure, bit for bit, either way."""
-    monkeypatch.setenv("DMSA_KEY_COMPRESS", compress)
+    debug = {"key_compress": int(compress)}
     prob = synth.window_problem(seed=21, scans=3, rings=64, az_steps=512, num_static=20_000)
     prob.minGridSize = 0.012
     s = DmsaOptimSettings.sliding_window(num_iter=2)
@@ -448,7 +447,7 @@ def test_fine_grid_and_full_width_codes(hip, orc, compress, monkeypatch):
     g = orc.transform_points(table, prob.localPoints, prob.tformIdPerPoint)
     glob = np.concatenate([g, prob.staticPoints]).astype(np.float32)
     ref = orc.Gaussians(glob, np.concatenate([prob.ringIds, prob.staticRingIds]), prob.minGridSize, s)
-    opt = hip.DmsaOptimizer()
+    opt = hip.DmsaOptimizer(debug=debug)
     opt.upload(prob)
     opt.poseTables(prob.getPoseParameters(), download=False)
     opt.updateGlobalPoints(0, download=False)
@@ -463,13 +462,13 @@ def test_fine_grid_and_full_width_codes(hip, orc, compress, monkeypatch):
     seg, memb, info12, w = opt.gaussians()
     assert np.array_equal(seg, ref.seg_offset) and np.array_equal(memb, ref.members) and np.array_equal(info12, ref.info)
     opt.close()
-    _parity_run(hip, orc, prob, s)
+    _parity_run(hip, orc, prob, s, debug=debug)
 
 
-def test_separate_level_sorts_on_an_odd_point_count(hip, orc, monkeypatch):
-    """DMSA_MERGE_SORT=0 sorts the two resolutions separately, as large windows do; with an odd point count the level-1 arrays start at an
+def test_separate_level_sorts_on_an_odd_point_count(hip, orc):
+    """merge_sort = 0 (include/dmsa_debug.h) sorts the two resolutions separately, as large windows do; with an odd point count the level-1 arrays start at an
     address that is only 4-byte aligned (views into the shared key / index arrays)."""
-    monkeypatch.setenv("DMSA_MERGE_SORT", "0")
     prob = synth.window_problem(seed=23, scans=3, rings=32, az_steps=256, num_static=5001)
     assert (prob.localPoints.shape[0] + prob.staticPoints.shape[0]) % 2 == 1
-    _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=3))
+    _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=3), debug={"merge_sort": 0})
+    _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=2), debug={"merge_sort": 0, "library_sort": 1, "fused_segments": 0, "dual_stream": 0})

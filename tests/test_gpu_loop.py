@@ -1,7 +1,7 @@
 """The device-resident optimizeSet loop (csrc/loop_kernels.hip): the LM step of DmsaOptimizer.h:107-128 computed on the device (one
 workgroup for P <= 64, panel hand-over between column-block workgroups beyond) against the oracle's step bit for bit; and whole
 optimizeSet calls that END EARLY (no improvement / epsilon / too few Gaussians) -- the stop decision is taken on the device and reaches
-the host one synchronisation late -- against the oracle and against the host-driven loop of rounds 1-2 (DMSA_DEVICE_LOOP=0)."""
+the host one synchronisation late -- against the oracle and against the host-driven loop of rounds 1-2 (debug switch device_loop = 0)."""
 import numpy as np
 import pytest
 from scipy.spatial.transform import Rotation as Rot
@@ -44,9 +44,9 @@ def test_device_lm_step_equals_the_oracle_step(hip, orc, P):
     opt.close()
 
 
-def _run(hip, prob, s):
+def _run(hip, prob, s, debug=None):
     p = prob.copy()
-    opt = hip.DmsaOptimizer()
+    opt = hip.DmsaOptimizer(debug=debug)
     rep = opt.optimizeSet(p, s)
     tr = opt.trace()
     opt.close()
@@ -82,14 +82,13 @@ def _cases():
 
 
 @pytest.mark.parametrize("case", list(_cases()))
-def test_early_exits_match_the_oracle_and_the_host_driven_loop(hip, orc, case, monkeypatch):
+def test_early_exits_match_the_oracle_and_the_host_driven_loop(hip, orc, case):
     prob, s, window = _cases()[case]
     dev = _run(hip, prob, s)
     p_ref = prob.copy()
     rep_ref, _, tr_ref = (orc.optimize_window if window else orc.optimize_keyframes)(p_ref, s)
     _same(dev, (p_ref, rep_ref, tr_ref))
-    monkeypatch.setenv("DMSA_DEVICE_LOOP", "0")
-    host = _run(hip, prob, s)
+    host = _run(hip, prob, s, debug={"device_loop": 0})
     _same(dev, host)
     if case == "window_runs_to_a_stop":
         assert dev[1].stop_reason != 0 and dev[1].iterations < s.num_iter  # the case really exercises a device-side stop
