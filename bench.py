@@ -213,6 +213,49 @@ def main():
                 "note": "DMSA_FLAG_FAST_SUMS (wave-parallel sums, LU solve): not the drop-in path -- its summation order differs from the "
                         "reference's and the numeric Jacobian amplifies that beyond the 1e-4 tolerance"}
         opt3.close(), oa.close(), ob.close()
+    # What a drop-in call costs with the PCIe traffic inside (never `value`): (a) dmsa_optimize_window with host arrays, the whole window
+    # uploaded per call; (b) the window resident in a ring (include/dmsa_window_ring.h): one new scan + the static points per call, as
+    # DmsaSlam::processPointCloud feeds its ring buffer (DmsaSlam.h:116-204).  Ten iterations per call (num_iter_sliding_window_optim).
+    pcie = None
+    if rank == 0 and args.workload == "window" and not args.fast_sums and hasattr(prob, "scanOffsets"):
+        s10 = type(settings)(**{**settings.__dict__, "num_iter": 10})
+        o_full = DmsaOptimizer(device=local_rank, fixed_iters=True)
+        o_full.optimizeSet(prob.copy(), s10)  # first call: allocations
+        t_full = []
+        for _ in range(3):
+            pc = prob.copy()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            o_full.optimizeSet(pc, s10)
+            t_full.append(time.perf_counter() - t)
+        o_full.close()
+        off = prob.scanOffsets
+        per_scan = int(np.diff(off).max())
+        o_ring = DmsaOptimizer(device=local_rank, fixed_iters=True)
+        o_ring.ringCreate(len(off) - 1, per_scan, prob.staticPoints.shape[0], prob.trajTime.size, prob.relOrientations.shape[0])
+        for k in range(len(off) - 1):
+            o_ring.ringPush(prob.localPoints[off[k]:off[k + 1]], prob.pointStamps[off[k]:off[k + 1]], prob.ringIds[off[k]:off[k + 1]])
+        o_ring.uploadFromRing(prob.copy(), prob.t0)
+        o_ring.optimizeResident(s10)
+        t_ring = []
+        for k in range(3):
+            pc = prob.copy()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            o_ring.ringPush(prob.localPoints[off[k]:off[k + 1]], prob.pointStamps[off[k]:off[k + 1]], prob.ringIds[off[k]:off[k + 1]])  # the window slides by one scan
+            o_ring.uploadFromRing(pc, prob.t0)
+            o_ring.optimizeResident(s10)
+            o_ring.poses()
+            t_ring.append(time.perf_counter() - t)
+        o_ring.close()
+        n_all = prob.localPoints.shape[0]
+        pcie = {"iterations_per_call": 10,
+                "full_upload_call_ms": round(1e3 * min(t_full), 3), "full_upload_it_per_s": round(10 / min(t_full), 1),
+                "full_upload_h2d_bytes": int(20 * (n_all + prob.staticPoints.shape[0])),
+                "resident_ring_call_ms": round(1e3 * min(t_ring), 3), "resident_ring_it_per_s": round(10 / min(t_ring), 1),
+                "resident_ring_h2d_bytes": int(28 * per_scan + 20 * prob.staticPoints.shape[0]),
+                "note": "wall time of whole calls through the Python ctypes layer, best of 3; (a) dmsa_optimize_window with host arrays, (b) one "
+                        "scan pushed into the resident ring + dmsa_window_upload_from_ring + dmsa_optimize_resident + dmsa_get_poses"}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -309,6 +352,7 @@ def main():
             "stage_ms_per_step": stage,
             "fast_sums_path": fast,
             "keyframe_pass": keyframe_pass,
+            "pcie_inclusive": pcie,
         }
         if world == 1 and args.cpu_iters > 0:
             out["cpu_baseline"] = cpu_baseline(prob, settings, args.cpu_iters, args.workload)

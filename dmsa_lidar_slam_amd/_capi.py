@@ -156,6 +156,12 @@ class DebugOptions(C.Structure):
                                            "library_sort", "overlap_batch", "serial_tree", "host_threads", "solve_threads", "host_timeline", "trace_time")]
 
 
+class WindowRingConfig(C.Structure):
+    """include/dmsa_window_ring.h: dmsa_window_ring_config."""
+    _fields_ = [("num_scans", C.c_int32), ("max_points_per_scan", C.c_int64), ("max_static_points", C.c_int64), ("max_n_total", C.c_int32),
+                ("max_control_poses", C.c_int32)]
+
+
 class Report(C.Structure):
     _fields_ = [
         ("iterations", C.c_int32),
@@ -268,6 +274,11 @@ def load_library() -> C.CDLL:
         "dmsa_serial_fallback_sums": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_uint64)]),
         "dmsa_default_debug_options": (None, [C.POINTER(DebugOptions)]),
         "dmsa_create_ex": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(DebugOptions), C.POINTER(vp)]),
+        # include/dmsa_window_ring.h
+        "dmsa_window_ring_create": (C.c_int, [vp, C.POINTER(WindowRingConfig)]),
+        "dmsa_window_ring_push": (C.c_int, [vp, c_float_p, c_double_p, c_int32_p, C.c_int64]),
+        "dmsa_window_ring_points": (C.c_int, [vp, c_int32_p, c_int64_p]),
+        "dmsa_window_upload_from_ring": (C.c_int, [vp, C.POINTER(WindowProblem), C.c_double]),
         "dmsa_lm_solve": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.c_double, C.c_int32, c_double_p]),
         "dmsa_lm_solve_device": (C.c_int, [vp, c_double_p, c_double_p, C.c_int32, C.c_double, C.c_double, c_double_p, c_int32_p]),
         "dmsa_neighbourhood_ranges": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -318,5 +329,6 @@ EXPORTED_SYMBOLS = (
     "dmsa_select_static_points dmsa_get_overlap dmsa_random_grid_downsampling dmsa_radius_exists dmsa_preprocess_scan "
     "dmsa_imu_buffer_create dmsa_imu_buffer_destroy dmsa_imu_buffer_add dmsa_imu_buffer_closest dmsa_imu_buffer_state dmsa_traj_dims dmsa_traj_grids "
     "dmsa_traj_tform_indices dmsa_traj_transfer_imu dmsa_traj_preint_factors dmsa_traj_update_initial_guess dmsa_traj_submap_gravity_estimate "
+    "dmsa_window_ring_create dmsa_window_ring_push dmsa_window_ring_points dmsa_window_upload_from_ring "
     "dmsa_decode_pointcloud2 dmsa_format_tum_pose dmsa_compose_nonkeyframe_pose dmsa_update_normals dmsa_make_keyframe_cloud"
 ).split()

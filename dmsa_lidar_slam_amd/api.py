@@ -116,6 +116,34 @@ class DmsaOptimizer:
         self._check(rc, "upload")
         self._problem, self._cprob = pointSet, cp
 
+    # -- include/dmsa_window_ring.h: the window's scans resident in HBM -------------------------------------------------
+    def ringCreate(self, num_scans: int, max_points_per_scan: int, max_static_points: int, max_n_total: int, max_control_poses: int = 6):
+        cfg = capi.WindowRingConfig(int(num_scans), int(max_points_per_scan), int(max_static_points), int(max_n_total), int(max_control_poses))
+        self._check(self._lib.dmsa_window_ring_create(self._ctx, C.byref(cfg)), "window_ring_create")
+
+    def ringPush(self, xyz_local, stamps, ring_ids):
+        """pcBuffer->addElem(scan) (RingBuffer.h:67-88): the newest scan replaces the oldest one in HBM."""
+        x = np.ascontiguousarray(xyz_local, np.float32)
+        if x.shape[1] == 3:
+            x = np.ascontiguousarray(np.concatenate([x, np.ones((x.shape[0], 1), np.float32)], axis=1))
+        t = np.ascontiguousarray(stamps, np.float64)
+        r = np.ascontiguousarray(ring_ids, np.int32)
+        assert x.shape[0] == t.size == r.size
+        self._check(self._lib.dmsa_window_ring_push(self._ctx, capi.ptr(x, C.c_float), capi.ptr(t, C.c_double), capi.ptr(r, C.c_int32), x.shape[0]), "window_ring_push")
+
+    def ringPoints(self):
+        s, n = C.c_int32(0), C.c_int64(0)
+        self._check(self._lib.dmsa_window_ring_points(self._ctx, C.byref(s), C.byref(n)), "window_ring_points")
+        return int(s.value), int(n.value)
+
+    def uploadFromRing(self, window: ContinuousTrajectory, t0: float):
+        """The resident scans + this window's control poses / time grid / static points become the problem (registerPcBuffer on the device).
+        `window.localPoints / tformIdPerPoint / ringIds` are not read."""
+        cp = window.to_c()
+        cp.num_points = 0
+        self._check(self._lib.dmsa_window_upload_from_ring(self._ctx, C.byref(cp), float(t0)), "window_upload_from_ring")
+        self._problem, self._cprob = window, cp
+
     def _num_points(self) -> int:
         p = self._problem
         if isinstance(p, ContinuousTrajectory):

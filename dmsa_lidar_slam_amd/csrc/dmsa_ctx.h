@@ -145,9 +145,19 @@ private:
 };
 
 
+// include/dmsa_window_ring.h: the window's scans resident in HBM (slot s holds up to `cap` points at offset s * cap)
+struct WindowRing {
+    int num_scans = 0;  // 0: no ring
+    int64_t cap = 0;
+    int head = 0, filled = 0;  // next slot to overwrite, slots in use
+    std::vector<int64_t> count;
+    DevBuf xyz, stamp, id;
+};
+
 struct dmsa_ctx {
     int device = 0;
     uint32_t flags = 0;
+    WindowRing ring;
     dmsa_debug_options dbg{};  // include/dmsa_debug.h: fixed at dmsa_create(_ex); the fields below that mirror it are set from it there
     hipStream_t stream = nullptr, stream2 = nullptr;  // stream2 carries the second voxel level only
     hipStream_t stream3 = nullptr;                    // the short tier of the correspondence kernels (debug switch serial_streams: 2 = with the throughput tier on stream2, 1 = everything on `stream`)

@@ -66,6 +66,9 @@ void launch_scan_range_gate(const uint32_t* range_bits, const uint32_t* sorted_b
 void launch_scan_emit(const float4* raw, const int32_t* pick, const int32_t* sel, const int32_t* scan_excl, int m, const float* tform_colmajor, float4* out_xyz,
                       int32_t* out_src, int32_t* total, hipStream_t s);
 // ContinuousTrajectory::registerPcBuffer (:240-260): out[k] = min(lower_bound(traj_time, stamps[k] - t0), n_total - 1)
+// include/dmsa_window_ring.h: one resident scan -> the window's local points (x, y, z, pose-table row) and ring ids
+void launch_ring_assemble(const float4* xyz, const double* stamps, const int32_t* ring, int64_t n, double t0, const double* traj_time, int n_total,
+                          float4* local_out, int32_t* ring_out, hipStream_t s);
 void launch_tform_indices(const double* stamps, int64_t n, double t0, const double* traj_time, int n_total, int32_t* out, hipStream_t s);
 // dmsa_slam_ros::callbackPointCloud (:399-486): byte offsets inside a point of the fields the sensor type reads
 struct PointCloud2Fields {

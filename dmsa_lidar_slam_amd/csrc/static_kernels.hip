@@ -360,6 +360,42 @@ __global__ __launch_bounds__(kBlock) void k_tform_indices(const double* __restri
         out[i] = first < n_total - 1 ? first : n_total - 1;
     }
 }
+// One scan of the resident window ring into the window's point arrays: row = min(lower_bound(trajTime, stamp - t0), n_total - 1) like
+// k_tform_indices, packed into the w of the local point; ring ids copied along.
+__global__ __launch_bounds__(kBlock) void k_ring_assemble(const float4* __restrict__ xyz, const double* __restrict__ stamps, const int32_t* __restrict__ ring,
+                                                          int64_t n, double t0, const double* __restrict__ traj_time, int n_total, int use_lds,
+                                                          float4* __restrict__ local_out, int32_t* __restrict__ ring_out) {
+    extern __shared__ double s_time[];
+    const double* grid = traj_time;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < n_total; i += blockDim.x) s_time[i] = traj_time[i];
+        __syncthreads();
+        grid = s_time;
+    }
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double v = stamps[i] - t0;
+        int first = 0, len = n_total;
+        while (len > 0) {
+            const int half = len >> 1, mid = first + half;
+            if (grid[mid] < v)
+                first = mid + 1, len = len - half - 1;
+            else
+                len = half;
+        }
+        const int row = first < n_total - 1 ? first : n_total - 1;
+        const float4 q = xyz[i];
+        local_out[i] = make_float4(q.x, q.y, q.z, __int_as_float(row));
+        ring_out[i] = ring[i];
+    }
+}
+void launch_ring_assemble(const float4* xyz, const double* stamps, const int32_t* ring, int64_t n, double t0, const double* traj_time, int n_total,
+                          float4* local_out, int32_t* ring_out, hipStream_t s) {
+    if (n <= 0) return;
+    const int use_lds = n_total <= kTimeGridLds ? 1 : 0;
+    hipLaunchKernelGGL(k_ring_assemble, dim3(grid_for(n, kBlock, 2048)), dim3(kBlock), use_lds ? (size_t)n_total * sizeof(double) : 0, s, xyz, stamps, ring, n, t0,
+                       traj_time, n_total, use_lds, local_out, ring_out);
+}
 void launch_tform_indices(const double* stamps, int64_t n, double t0, const double* traj_time, int n_total, int32_t* out, hipStream_t s) {
     if (n <= 0) return;
     const int use_lds = n_total <= kTimeGridLds ? 1 : 0;

@@ -205,6 +205,9 @@ def window_problem(seed: int = 1, scans: int = 10, rings: int = 128, az_steps: i
         tformIdPerPoint=tform_idx, ringIds=ids, staticPoints=static.astype(np.float32), staticRingIds=static_ids,
         minGridSize=grid_size, useImuErrorTerms=use_imu, dt_res=dt_res, **kw)
     prob.truth_global = (go, gt)  # for convergence checks
+    # what the ring buffer of scans holds (PointStampId::stamp per point, one cloud per scan) and the origin of the time grid
+    prob.pointStamps, prob.t0 = stamps_abs, float(t0)
+    prob.scanOffsets = np.concatenate([[0], np.cumsum([len(t) for t in stamps])]).astype(np.int64)
     return prob
 
 
