@@ -238,7 +238,8 @@ def main():
         o_ring.uploadFromRing(prob.copy(), prob.t0)
         o_ring.optimizeResident(s10)
         t_ring = []
-        for k in range(3):
+        for rep_i in range(3):
+            k = rep_i % (len(off) - 1)
             pc = prob.copy()
             torch.cuda.synchronize()
             t = time.perf_counter()

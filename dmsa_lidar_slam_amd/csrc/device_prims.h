@@ -14,11 +14,11 @@ hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* key
                               uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream);
 // library_sort = false: the hand-written onesweep sort of radix_sort.hip; true: rocPRIM (dmsa_debug_options::library_sort)
 hipError_t sort_pairs_u32_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                              uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream, bool library_sort = false);
+                              uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream, bool library_sort = false, bool header_zeroed = false);
 // radix_sort.hip: the hand-written onesweep sort behind sort_pairs_u32_u32
 size_t sort_pairs_u32_workspace_bytes(size_t n);
 hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                                   size_t n, unsigned end_bit, hipStream_t stream, bool prepared = false);
+                                   size_t n, unsigned end_bit, hipStream_t stream, int prepared = 0 /* 1: header already zeroed, 2: header + look-back state + histograms done */);
 hipError_t inclusive_scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t stream);
 hipError_t exclusive_scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t stream);
 }  // namespace dmsa

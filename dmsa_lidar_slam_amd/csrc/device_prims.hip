@@ -28,8 +28,8 @@ hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* key
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, stream);
 }
 hipError_t sort_pairs_u32_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                              uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream, bool library_sort) {
-    if (!library_sort && end_bit <= 32) return sort_pairs_u32_onesweep(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, end_bit, stream);
+                              uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream, bool library_sort, bool header_zeroed) {
+    if (!library_sort && end_bit <= 32) return sort_pairs_u32_onesweep(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, end_bit, stream, header_zeroed ? 1 : 0);
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, stream);
 }
 hipError_t inclusive_scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t stream) {

@@ -185,10 +185,8 @@ __device__ __forceinline__ void d_quat_from_axang(const D3 a, double q[4]) {
     const double sh = dmsa_det::det_sin(0.5 * ang);
     q[0] = dmsa_det::det_cos(0.5 * ang), q[1] = sh * ax.x, q[2] = sh * ax.y, q[3] = sh * ax.z;
 }
-__device__ __forceinline__ D3 d_slerp_axang(const D3 a, const D3 b, const double t) {
-    double q1[4], q2[4];
-    d_quat_from_axang(a, q1);
-    d_quat_from_axang(b, q2);
+// slerp of two rotations given as the unit quaternions d_quat_from_axang makes of them (helpers.h:24-37)
+__device__ __forceinline__ D3 d_slerp_quat(const double* q1, const double* q2, const double t) {
     const double one = 1.0 - DBL_EPSILON;
     const double d = q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3];
     const double ad = fabs(d);
@@ -217,9 +215,15 @@ __global__ __launch_bounds__(256) void k_window_pose_tables(const double* __rest
     __shared__ double s_ctrl[kMaxCtrl * 6];
     __shared__ double s_stamp[kMaxCtrl];
     __shared__ double s_w[kMaxCtrl];
+    __shared__ double s_quat[kMaxCtrl * 4];  // Quaterniond(AngleAxisd) of every control pose: the same value for every dense pose that uses it
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < C * 6; i += blockDim.x) s_ctrl[i] = ctrl[(size_t)b * C * 6 + i];
     for (int i = threadIdx.x; i < C; i += blockDim.x) s_stamp[i] = stamps[i], s_w[i] = fh_w[i];
+    __syncthreads();
+    if (threadIdx.x < C) {
+        const double* a = &s_ctrl[6 * threadIdx.x];
+        d_quat_from_axang(D3{a[0], a[1], a[2]}, &s_quat[4 * threadIdx.x]);
+    }
     __syncthreads();
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > n_t) return;
@@ -239,30 +243,29 @@ __global__ __launch_bounds__(256) void k_window_pose_tables(const double* __rest
     D3 o;
     if (right > 0) {
         const double t_rel = (t - s_stamp[right - 1]) / (s_stamp[right] - s_stamp[right - 1]);
-        const double* a = &s_ctrl[6 * (right - 1)];
-        const double* bq = &s_ctrl[6 * right];
-        o = d_slerp_axang(D3{a[0], a[1], a[2]}, D3{bq[0], bq[1], bq[2]}, t_rel);
+        o = d_slerp_quat(&s_quat[4 * (right - 1)], &s_quat[4 * right], t_rel);
     } else {
         o = D3{s_ctrl[0], s_ctrl[1], s_ctrl[2]};
     }
     // Floater–Hormann evaluation with the exact-node short-circuit, one interpolant per axis (shared weights)
+    // (the weight quotient w_i / (t - x_i) and the denominator are the same numbers for the three axes: computed once)
     double tr[3];
-    for (int a = 0; a < 3; ++a) {
-        double num = 0.0, den = 0.0, exact = 0.0;
+    {
+        double num[3] = {0.0, 0.0, 0.0}, den = 0.0, exact[3] = {0.0, 0.0, 0.0};
         bool hit = false;
         for (int i = 0; i < C; ++i) {
-            const double yi = s_ctrl[6 * i + 3 + a];
             if (t == s_stamp[i]) {
-                if (!hit) exact = yi;
+                if (!hit)
+                    for (int a = 0; a < 3; ++a) exact[a] = s_ctrl[6 * i + 3 + a];
                 hit = true;
             }
             if (!hit) {
                 const double q = s_w[i] / (t - s_stamp[i]);
-                num += q * yi;
+                for (int a = 0; a < 3; ++a) num[a] += q * s_ctrl[6 * i + 3 + a];
                 den += q;
             }
         }
-        tr[a] = hit ? exact : num / den;
+        for (int a = 0; a < 3; ++a) tr[a] = hit ? exact[a] : num[a] / den;
     }
     double R[9];
     d_so3_exp(o, R);
@@ -2597,42 +2600,45 @@ __device__ __forceinline__ double ne_col(const double* __restrict__ E, int64_t l
     return inv_h * (E[(size_t)(k + 1) * ldE + r] - e0);
 }
 
-// 32 x 32 outputs per workgroup, one per thread (1024 threads); the 32 rows x 32 columns of both operands of a stage are one element per
-// thread, fetched into registers one stage ahead of the products that consume them.  Every output sums its row block row by row.
-__global__ __launch_bounds__(1024) void k_normal_eq_partial(const double* __restrict__ E, int64_t ldE, int rows, int P, double inv_h, int rs, int nt,
-                                                            double* __restrict__ partial) {
+// A 32 x 32 output tile of a row block is shared by kNeQuarters workgroups (blockIdx.z = which 8 of the 32 second-operand columns): 256
+// threads, one output each, so the row block's LDS traffic (the bound of this kernel: two 8-byte reads per multiply-add) is spread over
+// four compute units.  The whole row block (rs = 256 rows = 8 stages for P <= 64) is fetched into registers up front: one memory
+// latency instead of one per stage.  Every output sums its row block row by row.
+constexpr int kNeQuarters = 4, kNeQCols = kNeTile / kNeQuarters;
+__global__ __launch_bounds__(256) void k_normal_eq_partial(const double* __restrict__ E, int64_t ldE, int rows, int P, double inv_h, int rs, int nt,
+                                                           double* __restrict__ partial) {
     __shared__ double s_a[kNeTile][kNeTile + 1];
-    __shared__ double s_b[kNeTile][kNeTile + 1];
+    __shared__ double s_b[kNeQCols][kNeTile + 1];
     const int tile = blockIdx.x, ti = tile % nt, tj = tile / nt;
-    const int split = blockIdx.y;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // output (column ti*32 + tx of A', column tj*32 + ty)
-    const int kk = threadIdx.x >> 5, rr = threadIdx.x & 31;  // staging: column kk, row rr of the stage
+    const int split = blockIdx.y, quarter = blockIdx.z;
+    const int tx = threadIdx.x & 31, tyl = threadIdx.x >> 5;  // output (column ti*32 + tx of A', column tj*32 + quarter*8 + tyl)
+    const int rr = threadIdx.x & 31, kq = threadIdx.x >> 5;   // staging: row rr of the stage; columns kq, kq + 8, kq + 16, kq + 24 of the first operand
     double c = 0.0;
     const int r_begin = split * rs, r_end = min(rows, r_begin + rs);
-    // the whole row block of this workgroup (rs = 256 rows = 8 stages for P <= 64) is fetched up front: one memory latency instead of one
-    // per stage
     constexpr int kStages = 8;
-    double na[kStages], nb[kStages];
-    auto fetch = [&](int r0, double& a, double& b) {
-        const int r = r0 + rr;
-        const bool in = r < r_end;
-        a = in ? ne_col(E, ldE, P, inv_h, ti * kNeTile + kk, r, rows) : 0.0;
-        b = ti == tj ? a : (in ? ne_col(E, ldE, P, inv_h, tj * kNeTile + kk, r, rows) : 0.0);  // diagonal tiles: one load serves both
-    };
+    double na[kStages][kNeQuarters], nb[kStages];
     for (int g0 = r_begin; g0 < r_end; g0 += kStages * kNeTile) {
 #pragma unroll
-        for (int u = 0; u < kStages; ++u) fetch(g0 + u * kNeTile, na[u], nb[u]);
+        for (int u = 0; u < kStages; ++u) {
+            const int r = g0 + u * kNeTile + rr;
+            const bool in = r < r_end;
+#pragma unroll
+            for (int q = 0; q < kNeQuarters; ++q) na[u][q] = in ? ne_col(E, ldE, P, inv_h, ti * kNeTile + kq + q * kNeQCols, r, rows) : 0.0;
+            nb[u] = in ? ne_col(E, ldE, P, inv_h, tj * kNeTile + quarter * kNeQCols + kq, r, rows) : 0.0;
+        }
 #pragma unroll
         for (int u = 0; u < kStages; ++u) {
             if (g0 + u * kNeTile >= r_end) break;
-            s_a[kk][rr] = na[u], s_b[kk][rr] = nb[u];
+#pragma unroll
+            for (int q = 0; q < kNeQuarters; ++q) s_a[kq + q * kNeQCols][rr] = na[u][q];
+            s_b[kq][rr] = nb[u];
             __syncthreads();
 #pragma unroll 8
-            for (int q = 0; q < kNeTile; ++q) c += s_a[tx][q] * s_b[ty][q];
+            for (int q = 0; q < kNeTile; ++q) c += s_a[tx][q] * s_b[tyl][q];
             __syncthreads();
         }
     }
-    partial[((size_t)split * nt * nt + tile) * kNeTile * kNeTile + ty * kNeTile + tx] = c;
+    partial[((size_t)split * nt * nt + tile) * kNeTile * kNeTile + (quarter * kNeQCols + tyl) * kNeTile + tx] = c;
 }
 __global__ __launch_bounds__(256) void k_normal_eq_reduce(const double* __restrict__ partial, int nsplit, int nt, int P, double* __restrict__ Hp) {
     const int n1 = P + 1;
@@ -2743,7 +2749,7 @@ void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, doub
         hipLaunchKernelGGL(k_jacobian_columns, dim3((rows + 255) / 256, P), dim3(256), 0, s, const_cast<double*>(E), ldE, rows, P, inv_h);
         hipLaunchKernelGGL(k_normal_eq_mfma, dim3(nt * (nt + 1) / 2, nsplit), dim3(256), 0, s, E, ldE, rows, P, rs, nt, partial);
     } else
-        hipLaunchKernelGGL(k_normal_eq_partial, dim3(nt * nt, nsplit), dim3(1024), 0, s, E, ldE, rows, P, inv_h, rs, nt, partial);
+        hipLaunchKernelGGL(k_normal_eq_partial, dim3(nt * nt, nsplit, kNeQuarters), dim3(256), 0, s, E, ldE, rows, P, inv_h, rs, nt, partial);
     const int n1 = P + 1;
     if (reduce) hipLaunchKernelGGL(k_normal_eq_reduce, dim3((n1 * n1 + 255) / 256), dim3(256), 0, s, partial, nsplit, nt, P, Hp);
 }

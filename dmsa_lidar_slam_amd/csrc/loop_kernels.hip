@@ -295,7 +295,7 @@ __device__ __forceinline__ double hp_element(const HpSource& h, int n1, int i, i
     }
     return s;
 }
-template <int kColsPerLane>
+template <int kColsPerLane, int kRows /* rows per wave: P <= kRows * kSolveWaves */>
 __global__ __launch_bounds__(kSolveWaves* kWave) void k_loop_lm_step(const HpSource hp, int P, double lambda, double alpha, double max_step,
                                                                       double* __restrict__ step, LoopFlags* __restrict__ flags, double* __restrict__ error0_out) {
     extern __shared__ double sm[];
@@ -328,9 +328,9 @@ __global__ __launch_bounds__(kSolveWaves* kWave) void k_loop_lm_step(const HpSou
         // ---- reads of the state before the step ----
         const bool in = lane >= c0 && lane < P;
         const double fcol = lane < P ? M[(size_t)lane * W + c0] : 0.0;  // lane = row: the pivot column
-        double x[kSolveRows][kColsPerLane];
+        double x[kRows][kColsPerLane];
 #pragma unroll
-        for (int j = 0; j < kSolveRows; ++j) {
+        for (int j = 0; j < kRows; ++j) {
             const int r = wave + j * kSolveWaves;
 #pragma unroll
             for (int q = 0; q < kColsPerLane; ++q) {
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kSolveWaves* kWave) void k_loop_lm_step(const HpSou
         __syncthreads();  // every read of the old state is done
         // ---- writes: row c0 <- scaled pivot row; row piv <- old row c0, updated; all other rows updated ----
 #pragma unroll
-        for (int j = 0; j < kSolveRows; ++j) {
+        for (int j = 0; j < kRows; ++j) {
             const int r = wave + j * kSolveWaves;
             if (r >= P) continue;
             const bool is_top = r == c0, is_swapped = r == piv && piv != c0;
@@ -781,13 +781,13 @@ static void launch_lm_step(const HpSource& hp, int P, double lambda, double alph
     const size_t bytes = (2 * (size_t)P * P + (size_t)P) * sizeof(double);
     static bool raised = false;
     if (bytes > 48 * 1024 && !raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_loop_lm_step<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_loop_lm_step<2, kSolveRows>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         raised = true;
     }
-    if (2 * P <= kWave)
-        hipLaunchKernelGGL(k_loop_lm_step<1>, dim3(1), dim3(kSolveWaves * kWave), bytes, s, hp, P, lambda, alpha, max_step, step, flags, error0_out);
+    if (P <= 4 * kSolveWaves)  // the default window (P = 30): one column per lane, four rows per wave
+        hipLaunchKernelGGL((k_loop_lm_step<1, 4>), dim3(1), dim3(kSolveWaves * kWave), bytes, s, hp, P, lambda, alpha, max_step, step, flags, error0_out);
     else
-        hipLaunchKernelGGL(k_loop_lm_step<2>, dim3(1), dim3(kSolveWaves * kWave), bytes, s, hp, P, lambda, alpha, max_step, step, flags, error0_out);
+        hipLaunchKernelGGL((k_loop_lm_step<2, kSolveRows>), dim3(1), dim3(kSolveWaves * kWave), bytes, s, hp, P, lambda, alpha, max_step, step, flags, error0_out);
 }
 void launch_loop_lm_step(const double* Hp, int P, double lambda, double alpha, double max_step, double* step, LoopFlags* flags, hipStream_t s) {
     launch_lm_step(HpSource{Hp, nullptr, 0, 0}, P, lambda, alpha, max_step, step, flags, nullptr, s);

@@ -258,7 +258,7 @@ SortPlan sort_pairs_u32_plan(void* temp, size_t n, unsigned end_bit) {
 }
 
 hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
-                                   size_t n, unsigned end_bit, hipStream_t stream, bool prepared) {
+                                   size_t n, unsigned end_bit, hipStream_t stream, int prepared) {
     if (n == 0) return hipSuccess;
     if (n >= (size_t)kValMask || temp_bytes < sort_pairs_u32_workspace_bytes(n)) return hipErrorInvalidValue;
     const SortPlan plan = sort_pairs_u32_plan(temp, n, end_bit);
@@ -271,8 +271,8 @@ hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t
     uint32_t* vals_tmp = reinterpret_cast<uint32_t*>(w);
     SortHeader* h = plan.header;
     uint32_t* state = plan.tile_state;
-    if (!prepared) {  // otherwise the producer of the keys cleared the header and the look-back words and counted the digits
-        hipLaunchKernelGGL(k_sort_zero, dim3(1), dim3(256), 0, stream, h);
+    if (prepared < 2) {  // 2: the producer of the keys cleared the header and the look-back words and counted the digits
+        if (prepared < 1) hipLaunchKernelGGL(k_sort_zero, dim3(1), dim3(256), 0, stream, h);  // 1: an earlier kernel of the stream cleared the header
         const unsigned hist_blocks = (unsigned)((n + 256 * kHistItems - 1) / (256 * kHistItems));
         hipLaunchKernelGGL(k_sort_hist, dim3(hist_blocks), dim3(256), 0, stream, keys_in, n, passes, plan.last_mask, h, state, plan.state_words);
     }

@@ -21,6 +21,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                            (!compress || (ctx->bits_guess[0] >= 0 && ctx->bits_guess[1] >= 0));
     // the key kernels count the digits of the sort that follows (own sort, 32-bit codes): no clearing kernel, no histogram pass
     const bool prehist = !ctx->dbg.library_sort && ctx->prehist;
+    const bool headers_zeroed = !ctx->dbg.library_sort;
     {
         ScopedTimer tm(ctx, T_VOXEL);
         const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
@@ -28,8 +29,9 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             launch_block_aabb(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts),
                               ctx->stream);
         ctx->aabb_fresh = false;
+        // the lattice kernel clears the headers of the own radix sorts on the side (one dispatch less per sort)
         launch_lattice(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), nb, ctx->level_res[0], ctx->level_res[1], compress,
-                       ctx->d_lattice.as<LatticeTable>(), prehist ? ctx->d_sort_tmp[0].p : nullptr, prehist ? ctx->d_sort_tmp[1].p : nullptr, ctx->stream);
+                       ctx->d_lattice.as<LatticeTable>(), headers_zeroed ? ctx->d_sort_tmp[0].p : nullptr, headers_zeroed ? ctx->d_sort_tmp[1].p : nullptr, ctx->stream);
         if (!speculate) {  // sync #1: tree depths select the radix-sort bit range (speculation reads them with the counts instead)
             HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(sync_spin(ctx->stream));
@@ -91,10 +93,10 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         stage_keys(0, ctx->stream), stage_keys(1, ctx->stream);
         if (k32 && prepared)
             HIPCHK(sort_pairs_u32_onesweep(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_code[0].as<uint32_t>(), ctx->d_code_s[0].as<uint32_t>(),
-                                           ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream, true));
+                                           ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream, 2));
         else if (k32)
             HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_code[0].as<uint32_t>(), ctx->d_code_s[0].as<uint32_t>(),
-                                      ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream, ctx->dbg.library_sort != 0));
+                                      ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream, ctx->dbg.library_sort != 0, headers_zeroed));
         else
             HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_code[0].as<uint64_t>(), ctx->d_code_s[0].as<uint64_t>(),
                                       ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream));
@@ -105,10 +107,10 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         const unsigned eb = (unsigned)(sort_bits[l] + 1);
         if (k32 && prepared)
             HIPCHK(sort_pairs_u32_onesweep(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, (const uint32_t*)ctx->code_v[l], (uint32_t*)ctx->code_s_v[l], ctx->idx_v[l],
-                                           ctx->idx_s_v[l], (size_t)n, eb, st[l], true));
+                                           ctx->idx_s_v[l], (size_t)n, eb, st[l], 2));
         else if (k32)
             HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, (const uint32_t*)ctx->code_v[l], (uint32_t*)ctx->code_s_v[l], ctx->idx_v[l],
-                                      ctx->idx_s_v[l], (size_t)n, eb, st[l], ctx->dbg.library_sort != 0));
+                                      ctx->idx_s_v[l], (size_t)n, eb, st[l], ctx->dbg.library_sort != 0, headers_zeroed));
         else
             HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, (const uint64_t*)ctx->code_v[l], (uint64_t*)ctx->code_s_v[l], ctx->idx_v[l],
                                       ctx->idx_s_v[l], (size_t)n, eb, st[l]));
