@@ -422,23 +422,30 @@ __device__ __forceinline__ double dpp_old_f64(double old, double v) {
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), kCtrl, kRowMask, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-// (value, logical row) of the wave's best candidate: largest value, among equals the smallest logical row; value -1 = no candidate
+// (value, logical row) of the wave's best candidate: largest value, among equals the smallest logical row; value -1 = no candidate.
+// The maximum runs through a DPP max-scan; its owner is found with one ballot -- ties (equal |x| in two rows) are rare and walked bit by bit.
 __device__ __forceinline__ void wave_best(double& v, int& l) {
-#define DMSA_BEST_STEP(CTRL, MASK)                                                                    \
-    {                                                                                                 \
-        const double ov = dpp_old_f64<CTRL, MASK>(-2.0, v);                                           \
-        const int ol = __builtin_amdgcn_update_dpp(0x7fffffff, l, CTRL, MASK, 0xf, false);            \
-        const bool take = ov > v || (ov == v && ol < l);                                              \
-        v = take ? ov : v, l = take ? ol : l;                                                         \
+    double m = v, o;
+    o = dpp_old_f64<0x111, 0xf>(-2.0, m), m = o > m ? o : m;  // row_shr:1
+    o = dpp_old_f64<0x112, 0xf>(-2.0, m), m = o > m ? o : m;  // row_shr:2
+    o = dpp_old_f64<0x114, 0xf>(-2.0, m), m = o > m ? o : m;  // row_shr:4
+    o = dpp_old_f64<0x118, 0xf>(-2.0, m), m = o > m ? o : m;  // row_shr:8
+    o = dpp_old_f64<0x142, 0xa>(-2.0, m), m = o > m ? o : m;  // row_bcast:15
+    o = dpp_old_f64<0x143, 0xc>(-2.0, m), m = o > m ? o : m;  // row_bcast:31
+    const double mx = readlane_f64(m, 63);
+    if (mx < 0.0) {  // no candidate in this wave
+        v = -1.0, l = 0x7fffffff;
+        return;
     }
-    DMSA_BEST_STEP(0x111, 0xf)  // row_shr:1
-    DMSA_BEST_STEP(0x112, 0xf)  // row_shr:2
-    DMSA_BEST_STEP(0x114, 0xf)  // row_shr:4
-    DMSA_BEST_STEP(0x118, 0xf)  // row_shr:8
-    DMSA_BEST_STEP(0x142, 0xa)  // row_bcast:15
-    DMSA_BEST_STEP(0x143, 0xc)  // row_bcast:31
-#undef DMSA_BEST_STEP
-    v = readlane_f64(v, 63), l = __builtin_amdgcn_readlane(l, 63);
+    unsigned long long hit = __ballot(v == mx);
+    int best = __builtin_amdgcn_readlane(l, __builtin_ctzll(hit));
+    hit &= hit - 1ull;
+    while (hit != 0ull) {  // another lane with the same value: the smaller logical row wins
+        const int other = __builtin_amdgcn_readlane(l, __builtin_ctzll(hit));
+        best = other < best ? other : best;
+        hit &= hit - 1ull;
+    }
+    v = mx, l = best;
 }
 __global__ __launch_bounds__(1024) void k_loop_lm_panels(const double* __restrict__ Hp, int P, double lambda, double alpha, double max_step,
                                                          double* __restrict__ work, unsigned int epoch, double* __restrict__ step, LoopFlags* __restrict__ flags) {
@@ -486,16 +493,26 @@ __global__ __launch_bounds__(1024) void k_loop_lm_panels(const double* __restric
     __syncthreads();
     if (b == 0 && r == 0) __hip_atomic_store(ready, (unsigned long long)epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const int last_panel_of_block = c0 + kPanel <= n ? b : npanels - 1;  // an A block is dead once it has been the panel
+#ifdef DMSA_PANEL_TIMING
+    long long t_wait = 0, t_load = 0, t_steps = 0, t_pub = 0, t_begin = wall_clock64();
+#endif
     for (int p = 0; p <= last_panel_of_block && p < npanels; ++p) {
+#ifdef DMSA_PANEL_TIMING
+        const long long ta = wall_clock64();
+#endif
         const int k0 = p * kPanel, kp = min(kPanel, n - k0);
         const bool is_panel = p == b;
         // ---- the panel as its owner published it ----
         // Hand-over: the owner's plain stores are released by its fence + flag; consumers poll the flag with a relaxed load (an acquire
-        // load would invalidate the L2 on every poll) and fence once after they have seen it.  Measured alternatives: acquire polling
-        // 459 us per solve at P = 186, data through agent-scope atomics instead of fences 443 us, this 405 us.
+        // load would invalidate the L2 on every poll) and fence once after they have seen it.  A hand-over costs ~3 us (-DDMSA_PANEL_TIMING
+        // prints where a block's time goes); write-through stores / agent-scope atomic loads instead of the fences were no faster.  What
+        // bounds the solve is the pivot step itself: ~1.2 us of dependent LDS round trips, wave reductions and one fp64 division.
         if (r == 0)
             while (__hip_atomic_load(ready + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)epoch) __builtin_amdgcn_s_sleep(1);
         __syncthreads();
+#ifdef DMSA_PANEL_TIMING
+        const long long tb = wall_clock64();
+#endif
         __threadfence();
         double xp[kPanel];
         {
@@ -506,6 +523,10 @@ __global__ __launch_bounds__(1024) void k_loop_lm_panels(const double* __restric
                 xp[2 * c] = row ? v.x : 0.0, xp[2 * c + 1] = row ? v.y : 0.0;
             }
         }
+#ifdef DMSA_PANEL_TIMING
+        __syncthreads();
+        const long long tc = wall_clock64();
+#endif
         // ---- kp pivot steps on the panel copy and on the own block in lockstep ----
 #pragma unroll
         for (int j = 0; j < kPanel; ++j) {
@@ -518,13 +539,10 @@ __global__ __launch_bounds__(1024) void k_loop_lm_panels(const double* __restric
             wave_best(v, l);
             if (lane == 0) s_bv[wave] = v, s_bl[wave] = l;
             __syncthreads();
-            double bv = s_bv[0];
-            int bl = s_bl[0];
-            for (int w = 1; w < nwaves; ++w) {
-                const double ov = s_bv[w];
-                const int ol = s_bl[w];
-                if (ov > bv || (ov == bv && ol < bl)) bv = ov, bl = ol;
-            }
+            // the waves' candidates meet in every wave: lane w takes wave w's, one more reduction (no chain of LDS reads)
+            double bv = lane < nwaves ? s_bv[lane] : -1.0;
+            int bl = lane < nwaves ? s_bl[lane] : 0x7fffffff;
+            wave_best(bv, bl);
             if (bv < 0.0) bl = k;  // nothing comparable (NaNs): keep the diagonal like the serial search
             const int pp = s_perm[bl], p0 = s_perm[k];
             const bool mine = row && r == pp;
@@ -552,18 +570,20 @@ __global__ __launch_bounds__(1024) void k_loop_lm_panels(const double* __restric
                 } else {
                     const double f = xp[j];
                     if (f != 0.0) {
-                        const double2* pr = reinterpret_cast<const double2*>(s_prow);  // broadcast reads, two entries per instruction
 #pragma unroll
-                        for (int c = 0; c < kPanel / 2; ++c) {
-                            const double2 a2 = pr[c], b2 = pr[kPanel / 2 + c];
-                            xp[2 * c] -= f * a2.x, xp[2 * c + 1] -= f * a2.y;
-                            xo[2 * c] -= f * b2.x, xo[2 * c + 1] -= f * b2.y;
+                        for (int c = 0; c < kPanel; ++c) {  // (16-byte reads of the pivot row measured slower: 443 vs 405 us per solve at P = 186)
+                            xp[c] -= f * s_prow[c];
+                            xo[c] -= f * s_prow[kPanel + c];
                         }
                     }
                 }
             }
             // no barrier here: the next step's first barrier separates these reads of s_prow from its next writer
         }
+#ifdef DMSA_PANEL_TIMING
+        __syncthreads();
+        const long long td = wall_clock64();
+#endif
         if (is_panel) {
             // the block was its own panel: what happened to the copy happened to the block
 #pragma unroll
@@ -580,7 +600,15 @@ __global__ __launch_bounds__(1024) void k_loop_lm_panels(const double* __restric
             __syncthreads();
             if (r == 0) __hip_atomic_store(ready + p + 1, (unsigned long long)epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
+#ifdef DMSA_PANEL_TIMING
+        t_wait += tb - ta, t_load += tc - tb, t_steps += td - tc, t_pub += wall_clock64() - td;
+#endif
     }
+#ifdef DMSA_PANEL_TIMING
+    if (r == 0 && (b == nblocks - 1 || b == 12 || b == 13))
+        printf("[panel timing] block %d: total %lld  wait %lld  fence+load %lld  steps %lld  publish %lld (x10 ns), %d panels\n", b, wall_clock64() - t_begin, t_wait,
+               t_load, t_steps, t_pub, min(last_panel_of_block + 1, npanels));
+#endif
     // ---- columns of the inverse ----
     if (row)
 #pragma unroll
