@@ -156,6 +156,11 @@ class DebugOptions(C.Structure):
                                            "library_sort", "overlap_batch", "serial_tree", "host_threads", "solve_threads", "host_timeline", "trace_time")]
 
 
+class RawImu(C.Structure):
+    """include/dmsa_raw_sequence.h: dmsa_raw_imu."""
+    _fields_ = [("stamp", C.c_double), ("ang_vel", C.c_double * 3), ("lin_acc", C.c_double * 3)]
+
+
 class WindowRingConfig(C.Structure):
     """include/dmsa_window_ring.h: dmsa_window_ring_config."""
     _fields_ = [("num_scans", C.c_int32), ("max_points_per_scan", C.c_int64), ("max_static_points", C.c_int64), ("max_n_total", C.c_int32),
@@ -308,6 +313,14 @@ def load_library() -> C.CDLL:
         "dmsa_decode_pointcloud2": (C.c_int, [vp, C.POINTER(PointCloud2), C.c_int32, c_float_p, c_double_p, c_int32_p]),
         "dmsa_format_tum_pose": (C.c_int, [C.c_double, c_double_p, c_double_p, C.c_char_p, C.c_int32]),
         "dmsa_compose_nonkeyframe_pose": (C.c_int, [c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+        # include/dmsa_raw_sequence.h
+        "dmsa_raw_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+        "dmsa_raw_close": (None, [vp]),
+        "dmsa_raw_next": (C.c_int, [vp, c_int32_p, C.POINTER(PointCloud2), C.POINTER(RawImu)]),
+        "dmsa_raw_create": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+        "dmsa_raw_write_pointcloud2": (C.c_int, [vp, C.POINTER(PointCloud2)]),
+        "dmsa_raw_write_imu": (C.c_int, [vp, C.POINTER(RawImu)]),
+        "dmsa_raw_finish": (C.c_int, [vp]),
         # include/dmsa_keyframe_cloud.h
         "dmsa_update_normals": (C.c_int, [vp, c_float_p, C.c_int64, C.c_int32, C.c_float, c_float_p, c_float_p, c_int32_p]),
         "dmsa_make_keyframe_cloud": (C.c_int, [vp, c_float_p, c_int32_p, C.c_int64, C.c_float, C.c_uint32, c_double_p, c_double_p, c_float_p, c_float_p, c_int32_p,
@@ -330,5 +343,6 @@ EXPORTED_SYMBOLS = (
     "dmsa_imu_buffer_create dmsa_imu_buffer_destroy dmsa_imu_buffer_add dmsa_imu_buffer_closest dmsa_imu_buffer_state dmsa_traj_dims dmsa_traj_grids "
     "dmsa_traj_tform_indices dmsa_traj_transfer_imu dmsa_traj_preint_factors dmsa_traj_update_initial_guess dmsa_traj_submap_gravity_estimate "
     "dmsa_window_ring_create dmsa_window_ring_push dmsa_window_ring_points dmsa_window_upload_from_ring "
+    "dmsa_raw_open dmsa_raw_close dmsa_raw_next dmsa_raw_create dmsa_raw_write_pointcloud2 dmsa_raw_write_imu dmsa_raw_finish "
     "dmsa_decode_pointcloud2 dmsa_format_tum_pose dmsa_compose_nonkeyframe_pose dmsa_update_normals dmsa_make_keyframe_cloud"
 ).split()

@@ -213,7 +213,12 @@ class MiniSlam:
                          "map_rel": (self.map.relOrientations.copy(), self.map.relTranslations.copy())})
 
 
-def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, livox=False, hesai=False, **slam_args):
+def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, livox=False, hesai=False, record=None, replay=None, **slam_args):
+    """record: write the message stream (PointCloud2 + Imu, bag order) to a flat dump (include/dmsa_raw_sequence.h) while running;
+    replay: run from such a dump instead of generating the messages -- what a recorded sequence converted by scripts/rosbag_to_raw.py
+    goes through (src/dmsa_slam_ros.cpp:240-307)."""
+    from dmsa_lidar_slam_amd import raw_sequence as rs
+
     if livox:  # BASELINE.json config 5: Livox-like rosette scans, livoxXYZRTLT_ns messages, no IMU
         clouds, truth = synth.rosette_scan_sequence(seed=seed, scans=scans)
         backend = backend or GpuBackend(sensor="livoxXYZRTLT_ns")
@@ -222,20 +227,37 @@ def run(scans=14, rings=64, az_steps=512, seed=1, backend=None, livox=False, hes
         if hesai:  # BASELINE.json config 2: PandarXT-32 messages (+ IMU through use_imu=True)
             backend = backend or GpuBackend(sensor="hesai")
     slam = MiniSlam(backend, **slam_args)
-    if slam.imu is not None:  # the whole IMU stream up front (the node interleaves the two callbacks): 50 samples at rest for the gyro bias, then the drive
-        st, acc, ang = synth.imu_stream(truth, -0.3, scans * 0.1 + 0.3, rate=400.0, rng=np.random.default_rng(seed + 50), sigma_acc=0.02, sigma_gyr=0.002)
-        for t in st[0] - (50 - np.arange(50)) * 0.0025:
-            slam.imu.addMeasurement([0.0, 0.0, 9.805], np.zeros(3), t)
-        for t, a, w in zip(st, acc, ang):
-            slam.imu.addMeasurement(a, w, t)
+    writer = rs.RawWriter(record) if record else None
 
     def first_pose(traj):
         R, p = truth.pose(traj.t0 - 1.6e9 + traj.stamps)
         return posemath.global2relative(R.as_rotvec(), p)
 
-    for xyz, stamps, ring, _ in clouds:
-        msg = scan_to_livox_pointcloud2(xyz, stamps) if livox else scan_to_hesai_pointcloud2(xyz, stamps, ring) if hesai else scan_to_pointcloud2(xyz, stamps, ring)
-        slam.process(msg, first_pose)
+    if replay:  # the bag loop (:270-281): messages in file order, Imu -> processImuMeasurements, PointCloud2 -> processPointCloud
+        for kind, m in rs.RawReader(replay):
+            if kind == "imu":
+                if slam.imu is not None:
+                    slam.imu.addMeasurement(m[2], m[1], m[0])
+            else:
+                slam.process(m, first_pose)
+    else:
+        if slam.imu is not None:  # the whole IMU stream up front (the node interleaves the two callbacks): 50 samples at rest for the gyro bias, then the drive
+            st, acc, ang = synth.imu_stream(truth, -0.3, scans * 0.1 + 0.3, rate=400.0, rng=np.random.default_rng(seed + 50), sigma_acc=0.02, sigma_gyr=0.002)
+            for t in st[0] - (50 - np.arange(50)) * 0.0025:
+                slam.imu.addMeasurement([0.0, 0.0, 9.805], np.zeros(3), t)
+                if writer:
+                    writer.writeImu(t, np.zeros(3), [0.0, 0.0, 9.805])
+            for t, a, w in zip(st, acc, ang):
+                slam.imu.addMeasurement(a, w, t)
+                if writer:
+                    writer.writeImu(t, w, a)
+        for xyz, stamps, ring, _ in clouds:
+            msg = scan_to_livox_pointcloud2(xyz, stamps) if livox else scan_to_hesai_pointcloud2(xyz, stamps, ring) if hesai else scan_to_pointcloud2(xyz, stamps, ring)
+            if writer:
+                writer.writePointCloud2(msg)
+            slam.process(msg, first_pose)
+    if writer:
+        writer.close()
     errs = []
     for e in slam.log:
         _, p = truth.pose(np.array([e["t0"] - 1.6e9]))
@@ -253,8 +275,10 @@ if __name__ == "__main__":
     ap.add_argument("--imu", action="store_true", help="IMU rows in the window, gravity rows in the keyframe pass")
     ap.add_argument("--hesai", action="store_true", help="32-ring scans as Hesai PandarXT messages (absolute double stamps, uint16 ring)")
     ap.add_argument("--livox", action="store_true", help="rosette scans as livoxXYZRTLT_ns messages (ids = k % 1000)")
+    ap.add_argument("--record", help="also write the message stream to this flat dump (include/dmsa_raw_sequence.h)")
+    ap.add_argument("--replay", help="take the messages from this flat dump instead of generating them (same sensor flags as when it was recorded)")
     a = ap.parse_args()
-    r = run(a.scans, dist_new_keyframe=a.keyframe_dist, num_iter_keyframe_optim=a.keyframe_iters, use_imu=a.imu, livox=a.livox, hesai=a.hesai, **(dict(rings=32, az_steps=512) if a.hesai else {}),
+    r = run(a.scans, record=a.record, replay=a.replay, dist_new_keyframe=a.keyframe_dist, num_iter_keyframe_optim=a.keyframe_iters, use_imu=a.imu, livox=a.livox, hesai=a.hesai, **(dict(rings=32, az_steps=512) if a.hesai else {}),
             **(dict(max_points_per_scan=1000) if a.livox else {}))
     for e in r["log"]:
         print(f"t0={e['t0']:.3f} pos=({e['pos'][0]:.3f} {e['pos'][1]:.3f} {e['pos'][2]:.3f}) iters={e['iterations']} M={e['gaussians']} static={e['static']} "

@@ -23,7 +23,7 @@ def lib():
 
 
 def test_exports_every_declared_symbol(lib):
-    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("dmsa_hip.h", "dmsa_debug.h", "dmsa_window_ring.h", "dmsa_static_points.h", "dmsa_window_setup.h", "dmsa_wire_formats.h", "dmsa_keyframe_cloud.h", "dmsa_keyframe_map.h"))
+    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("dmsa_hip.h", "dmsa_debug.h", "dmsa_window_ring.h", "dmsa_static_points.h", "dmsa_window_setup.h", "dmsa_wire_formats.h", "dmsa_raw_sequence.h", "dmsa_keyframe_cloud.h", "dmsa_keyframe_map.h"))
     declared = set(re.findall(r"\b(dmsa_[a-z_0-9]+)\s*\(", header))
     assert declared, "no declarations parsed"
     assert declared == set(capi.EXPORTED_SYMBOLS)

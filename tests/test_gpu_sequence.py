@@ -169,3 +169,19 @@ def test_full_sequence_livox(orc):
             assert np.array_equal(x, y)
     assert g["tum"] == o["tum"] and g["max_position_error_m"] < 0.2
 
+
+
+def test_recorded_sequence_replays_to_the_same_trajectory(tmp_path):
+    """include/dmsa_raw_sequence.h: the message stream of the config-2-shaped run (Hesai PointCloud2 + Imu) written to a flat dump and
+    replayed from it -- the stand-in for the rosbag loop (src/dmsa_slam_ros.cpp:240-307) -- gives the same trajectory, line for line."""
+    import sequence_demo
+
+    args = dict(scans=10, rings=32, az_steps=256, num_iter=3, dist_new_keyframe=0.25, num_iter_keyframe_optim=2, use_imu=True, hesai=True)
+    dump = str(tmp_path / "drive.raw")
+    a = sequence_demo.run(backend=sequence_demo.GpuBackend(parity=True, sensor="hesai"), record=dump, **args)
+    assert os.path.getsize(dump) > 10 * 32 * 256 * 20
+    b = sequence_demo.run(backend=sequence_demo.GpuBackend(parity=True, sensor="hesai"), replay=dump, **args)
+    assert a["windows"] == b["windows"] >= 5 and a["tum"] == b["tum"]
+    for x, y in zip(a["log"], b["log"]):
+        for u, v in zip(x["rel"] + x["map_rel"], y["rel"] + y["map_rel"]):
+            assert np.array_equal(u, v)
