@@ -461,7 +461,8 @@ static int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep
 // Per iteration the host only enqueues; its one wait is for the Gaussian counts that size the correspondence launches (sync A).  The
 // stop decision of iteration i (no improvement / epsilon / NaN step) is taken on the device and reaches the host with the counts of
 // iteration i + 1: every loop kernel of a stopped loop is a no-op, so the extra voxelisation that was already enqueued changes nothing.
-// P > 64 (keyframe sets) still solves the normal equations on the host's worker pool: one more wait per iteration.
+// The LM step is solved on the device as well (one workgroup up to P = 64, the panel kernel up to P = 1024); only beyond that the
+// normal equations go to the host's worker pool, which costs one more wait per iteration.
 int pinned_doubles(dmsa_ctx* ctx, size_t count, double** out) {
     constexpr int kPinSlots = 4;
     if (count > ctx->h_pin_slot) {

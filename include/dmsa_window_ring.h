@@ -1,7 +1,7 @@
 /*
  * dmsa_window_ring.h — the scans of the sliding window stay in HBM from one optimizeSet to the next.
  *
- * DmsaSlam::processPointCloud (DmsaSlam.h:116-204) keeps the last `num_clouds_submap` scans in a ring buffer (RingBuffer.h:31-88,
+ * DmsaSlam::processPointCloud (DmsaSlam.h:116-204) keeps the last `config.n_clouds` scans (Config.h:19, DmsaSlam.h:64, :140) in a ring buffer (RingBuffer.h:31-88,
  * PointCloudBuffer.h:24-49): every new scan replaces the oldest one, the other scans of the window are the ones the previous
  * optimizeSet already saw.  dmsa_optimize_window (dmsa_hip.h) takes the whole window as host arrays on every call -- 30 MB over PCIe
  * for a 10 x 131 072-point window.  With this header a caller uploads ONE scan per window:
@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 typedef struct dmsa_window_ring_config {
-    int32_t num_scans;            /* scans per window: config num_clouds_submap (RingBuffer capacity)            */
+    int32_t num_scans;            /* scans per window: config.n_clouds (RingBuffer capacity)                  */
     int64_t max_points_per_scan;  /* capacity of a ring slot                                                     */
     int64_t max_static_points;    /* capacity reserved for the static map points addStaticPoints appends        */
     int32_t max_n_total;          /* dense poses the pose tables are sized for (horizon / dt_res + 1)            */
