@@ -211,6 +211,8 @@ struct dmsa_ctx {
     LatticeTable* h_lattice = nullptr;  // = h_rb->lattice
     DevBuf d_seg_state[2];           // look-back state of k_leaf_segments (ticket counter + one word per tile), zeroed when allocated
     uint32_t seg_epoch[2] = {0, 0}, seg_ticket[2] = {0, 0};
+    DevBuf d_fin_state[2];           // the same for k_leaf_finalize (six words per tile)
+    uint32_t fin_epoch[2] = {0, 0}, fin_ticket[2] = {0, 0};
     bool prehist = false;            // debug switch sort_prehist: the key kernels count the sort digits (measured 1.5 % slower than the sort's own histogram pass)
     bool fused_segments = true;      // debug switch fused_segments = 0: head flags / library scan / leaf starts as three kernels
     bool key32[2] = {false, false};  // leaf codes are 32-bit (both levels share the width: they are sorted together)

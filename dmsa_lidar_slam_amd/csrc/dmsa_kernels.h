@@ -119,6 +119,12 @@ void launch_leaf_split(const int32_t* leaf_incl, const int32_t* leaf_start, cons
                        int32_t* slot_acc, int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s);
 void launch_leaf_scan(const int32_t* slot_acc, const int32_t* slot_cnt, int32_t* gauss_of_slot, int32_t* memb_of_slot,
                       int32_t* pslot_of_slot /* prefix of the member counts rounded up to 8: tile slots */, LevelCounts* counts, hipStream_t s);
+// launch_leaf_scan as a multi-workgroup single-pass kernel.  `state`: leaf_finalize_state_bytes(n) bytes zeroed once when allocated;
+// epoch / ticket_base as for launch_leaf_segments (tiles per call: leaf_finalize_tiles(n)).
+int leaf_finalize_tiles(int64_t n);
+size_t leaf_finalize_state_bytes(int64_t n);
+void launch_leaf_finalize(const int32_t* slot_acc, const int32_t* slot_cnt, int64_t n /* leaf capacity */, int32_t* gauss_of_slot, int32_t* memb_of_slot,
+                          int32_t* pslot_of_slot, LevelCounts* counts, unsigned long long* state, uint32_t epoch, uint32_t ticket_base, hipStream_t s);
 void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start, const uint32_t* idx_sorted, const void* code_sorted, bool key32,
                            const LatticeTable* table, const int32_t* slot_acc, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
                            const int32_t* pos_slot_rank /* or null */, const float4* local, const int32_t* slot_cnt, const GaussCounts* counts, int level,

@@ -1249,6 +1249,116 @@ void launch_leaf_scan(const int32_t* slot_acc, const int32_t* slot_cnt, int32_t*
     hipLaunchKernelGGL(k_leaf_scan, dim3(1), dim3(1024), 0, s, slot_acc, slot_cnt, gauss_of_slot, memb_of_slot, pslot_of_slot, counts);
 }
 
+// The same three slot scans as ONE multi-workgroup pass (the single-workgroup kernel above walks the 3 x 10^5 leaves of a window's fine
+// level in 24 us).  Tiles of 4096 leaves are handed out by an atomic ticket; a tile publishes its three totals (accepted sets, members,
+// members rounded up to 8) and looks back over the earlier tiles 64 at a time, exactly like k_leaf_segments: every published word
+// carries the call's epoch, partial totals and inclusive prefixes live in separate words (three values cannot change state atomically
+// together), nothing is cleared between calls.  (Computing the leaf test of k_leaf_accept in here as well was measured 15 us SLOWER:
+// eight leaves per thread walk their members one after the other, while k_leaf_accept spreads the walks over 131 072 threads.)
+constexpr int kFinThreads = 512, kFinItems = 8, kFinTile = kFinThreads * kFinItems;  // leaves per tile
+constexpr int kFinWords = 6;                                                          // per tile: partial a, c, p | prefix a, c, p
+__global__ __launch_bounds__(kFinThreads) void k_leaf_finalize(const int32_t* __restrict__ slot_acc, const int32_t* __restrict__ slot_cnt,
+                                                                int32_t* __restrict__ gauss_of_slot,
+                                                                int32_t* __restrict__ memb_of_slot, int32_t* __restrict__ pslot_of_slot,
+                                                                LevelCounts* __restrict__ counts, unsigned long long* __restrict__ state /* [0]: ticket */,
+                                                                uint32_t epoch, uint32_t ticket_base) {
+    __shared__ uint32_t s_tile;
+    __shared__ int s_wave_total[kFinThreads / 64][3];
+    __shared__ int s_excl[3];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) s_tile = atomicAdd(reinterpret_cast<unsigned int*>(state), 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const int nl = counts->num_leaves;
+    const int base = (int)tile * kFinTile;
+    if (base >= nl && !(tile == 0)) return;  // surplus tile (the grid is sized for one leaf per point); tile 0 always reports the totals
+    int a0[kFinItems], c0[kFinItems], a1[kFinItems], c1[kFinItems];
+#pragma unroll
+    for (int k = 0; k < kFinItems; ++k) {
+        const int l = base + (wave * kFinItems + k) * 64 + lane;
+        int2 va = make_int2(0, 0), vc = make_int2(0, 0);
+        if (l < nl) va = reinterpret_cast<const int2*>(slot_acc)[l], vc = reinterpret_cast<const int2*>(slot_cnt)[l];
+        a0[k] = va.x, a1[k] = va.y, c0[k] = vc.x, c1[k] = vc.y;
+    }
+    // inclusive scans over the leaves of the wave's rows (a leaf = its two slots)
+    int ia[kFinItems], ic[kFinItems], ip[kFinItems];
+    int ra = 0, rc = 0, rp = 0;
+#pragma unroll
+    for (int k = 0; k < kFinItems; ++k) {
+        const int sa = wave_incl_scan_dpp(a0[k] + a1[k]), sc = wave_incl_scan_dpp(c0[k] + c1[k]), sp = wave_incl_scan_dpp(pad_slots(c0[k]) + pad_slots(c1[k]));
+        ia[k] = ra + sa, ic[k] = rc + sc, ip[k] = rp + sp;
+        ra += __builtin_amdgcn_readlane(sa, 63), rc += __builtin_amdgcn_readlane(sc, 63), rp += __builtin_amdgcn_readlane(sp, 63);
+    }
+    if (lane == 0) s_wave_total[wave][0] = ra, s_wave_total[wave][1] = rc, s_wave_total[wave][2] = rp;
+    __syncthreads();
+    int before[3] = {0, 0, 0}, total[3] = {0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < kFinThreads / 64; ++w)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int t = s_wave_total[w][q];
+            if (w < wave) before[q] += t;
+            total[q] += t;
+        }
+    if (wave == 0) {
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        unsigned long long* st = state + 1;
+        int excl[3] = {0, 0, 0};
+        if (tile != 0) {
+            if (lane < 3) __hip_atomic_store(st + (size_t)tile * kFinWords + lane, tag | (unsigned)total[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t t = (int64_t)tile - 1;
+            while (true) {
+                const int64_t mine = t - lane;
+                unsigned long long v[kFinWords];
+#pragma unroll
+                for (int q = 0; q < kFinWords; ++q)
+                    v[q] = mine >= 0 ? __hip_atomic_load(st + (size_t)mine * kFinWords + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+                const bool has_part = (uint32_t)(v[0] >> 32) == epoch && (uint32_t)(v[1] >> 32) == epoch && (uint32_t)(v[2] >> 32) == epoch;
+                const bool has_pref = (uint32_t)(v[3] >> 32) == epoch && (uint32_t)(v[4] >> 32) == epoch && (uint32_t)(v[5] >> 32) == epoch;
+                const unsigned long long ready = __ballot(has_part || has_pref), prefix = __ballot(has_pref);
+                const int first_missing = ready == ~0ull ? 64 : __builtin_ctzll(~ready);
+                const int first_prefix = prefix == 0ull ? 64 : __builtin_ctzll(prefix);
+                const bool done = first_prefix < first_missing;
+                const int stop = done ? first_prefix + 1 : first_missing;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    int part = lane < stop ? (int)(uint32_t)(has_pref ? v[3 + q] : v[q]) : 0;
+                    part = wave_incl_scan_dpp(part);
+                    excl[q] += __builtin_amdgcn_readlane(part, 63);
+                }
+                if (done) break;
+                t -= stop;
+            }
+        }
+        if (lane < 3)
+            __hip_atomic_store(st + (size_t)tile * kFinWords + 3 + lane, tag | (unsigned)(excl[lane] + total[lane]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) s_excl[0] = excl[0], s_excl[1] = excl[1], s_excl[2] = excl[2];
+    }
+    __syncthreads();
+    const int oa = s_excl[0] + before[0], oc = s_excl[1] + before[1], op = s_excl[2] + before[2];
+#pragma unroll
+    for (int k = 0; k < kFinItems; ++k) {
+        const int l = base + (wave * kFinItems + k) * 64 + lane;
+        if (l < nl) {
+            // exclusive prefix of slot 2l = everything before the leaf; slot 2l + 1 additionally has slot 2l in front of it
+            const int ea = oa + ia[k] - (a0[k] + a1[k]), ec = oc + ic[k] - (c0[k] + c1[k]), ep = op + ip[k] - (pad_slots(c0[k]) + pad_slots(c1[k]));
+            reinterpret_cast<int2*>(gauss_of_slot)[l] = make_int2(ea, ea + a0[k]);
+            reinterpret_cast<int2*>(memb_of_slot)[l] = make_int2(ec, ec + c0[k]);
+            reinterpret_cast<int2*>(pslot_of_slot)[l] = make_int2(ep, ep + pad_slots(c0[k]));
+        }
+    }
+    // the tile that holds the last leaf reports the totals of the level (tile 0 when there is no leaf at all)
+    if (tid == 0 && (nl <= 0 ? tile == 0 : (base < nl && nl <= base + kFinTile)))
+        counts->num_gauss = s_excl[0] + total[0], counts->num_memb = s_excl[1] + total[1], counts->pad = s_excl[2] + total[2];
+}
+int leaf_finalize_tiles(int64_t n) { return (int)std::max<int64_t>(1, (n + kFinTile - 1) / kFinTile); }
+size_t leaf_finalize_state_bytes(int64_t n) { return 8 * (size_t)(1 + kFinWords * leaf_finalize_tiles(n)); }
+void launch_leaf_finalize(const int32_t* slot_acc, const int32_t* slot_cnt, int64_t n, int32_t* gauss_of_slot, int32_t* memb_of_slot, int32_t* pslot_of_slot,
+                          LevelCounts* counts, unsigned long long* state, uint32_t epoch, uint32_t ticket_base, hipStream_t s) {
+    hipLaunchKernelGGL(k_leaf_finalize, dim3((unsigned)leaf_finalize_tiles(n)), dim3(kFinThreads), 0, s, slot_acc, slot_cnt, gauss_of_slot, memb_of_slot, pslot_of_slot,
+                       counts, state, epoch, ticket_base);
+}
+
 
 // members of accepted sets, physically regrouped in Gaussian order (leaf DFS order, ascending point index inside a
 // set): the correspondence kernel then streams contiguous float4s instead of gathering through index lists.

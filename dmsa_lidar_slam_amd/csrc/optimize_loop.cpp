@@ -167,22 +167,28 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
         ScopedTimer tm(ctx, T_RESIDUAL);
         if (ctx->tablesT_batch != B) launch_transpose_tables(ctx->d_tables.as<float>(), ctx->rows, B, ctx->d_tablesT.as<float>(), ctx->stream);
         const bool two = ctx->serial_two_streams && ctx->serial_counts.n_long > 0;
-        if (two) {  // the latency tier keeps `stream`; the throughput tiers run beside it on stream2
+        const bool three = two && ctx->serial_three_streams;
+        // The latency tier keeps `stream` and is launched first: its workgroups must get their CUs before the thousands of workgroups of
+        // the other tiers fill the chip.  (Giving `stream` to the throughput tier in the Jacobian batch, which that tier bounds, so that it
+        // starts without the ~12 us fork delay: 1050 -> 990 it/s -- the latency tier then queues behind everybody else.)
+        hipStream_t s_long = ctx->stream;
+        hipStream_t s_mid = two ? ctx->stream2 : ctx->stream;
+        hipStream_t s_small = three ? ctx->stream3 : s_mid;
+        if (two) {
             HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         }
-        const bool three = two && ctx->serial_three_streams;
         if (three) HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
         launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
-                                ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, ctx->stream, two ? ctx->stream2 : ctx->stream,
-                                three ? ctx->stream3 : (two ? ctx->stream2 : ctx->stream), ctx->dbg.serial_tree);
-        if (two) {
-            HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-        }
+                                ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree);
+        // joins: the stream that finishes first is waited for first (its wait is through while `stream` still works)
         if (three) {
             HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
+        }
+        if (two) {
+            HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         }
     } else {
         ScopedTimer tm(ctx, T_RESIDUAL);

@@ -680,7 +680,11 @@ unsigned long long serial_fallback_sums(bool reset) {
     return v;
 }
 SerialShape serial_shape(int B) {
-    constexpr int bs_long = kBL, bs_mid = kBL;  // evaluations per workgroup of the two chain tiers
+    // evaluations per workgroup of the two chain tiers.  The 9 trials of the line search go through the latency tier as 5 + 4: its
+    // longest Gaussian bounds that batch, and half the evaluations per workgroup halve its (workgroup-local) second pass: +1.5 % it/s.
+    // (3 + 3 + 3 and 2 x 5 for the throughput tier, or 4 x 8 for the Jacobian batch, are slower: the first pass is repeated per sub-batch.)
+    constexpr int kTrialLong = 5;
+    const int bs_long = B <= kBL ? kTrialLong : kBL, bs_mid = kBL;
     SerialShape s;
     s.nsub_long = (B + bs_long - 1) / bs_long, s.Bs_long = (B + s.nsub_long - 1) / s.nsub_long;
     s.nsub = (B + bs_mid - 1) / bs_mid, s.Bs = (B + s.nsub - 1) / s.nsub;

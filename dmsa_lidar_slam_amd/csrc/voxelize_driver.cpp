@@ -138,6 +138,22 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             launch_leaf_starts(ctx->d_head[l].as<int32_t>(), ctx->d_leaf_incl[l].as<int32_t>(), ctx->code_s_v[l], k32, tab, n,
                                ctx->d_leaf_start[l].as<int32_t>(), &counts->level[l], st[l]);
         }
+        // slot scans: one multi-workgroup single-pass kernel (debug switch fused_leaf_scan = 0: the single-workgroup k_leaf_scan)
+        auto finalize = [&]() -> int {
+            const size_t need = leaf_finalize_state_bytes(n);
+            if (need > ctx->d_fin_state[l].cap) {
+                HIPCHK(ctx->d_fin_state[l].ensure(need));
+                HIPCHK(hipMemsetAsync(ctx->d_fin_state[l].p, 0, ctx->d_fin_state[l].cap, st[l]));
+                ctx->fin_epoch[l] = 0, ctx->fin_ticket[l] = 0;
+            }
+            ctx->fin_epoch[l] += 1;
+            if (ctx->fin_epoch[l] == 0) ctx->fin_epoch[l] = 1;
+            launch_leaf_finalize(ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(), n, ctx->d_gauss_of_slot[l].as<int32_t>(),
+                                 ctx->d_memb_of_slot[l].as<int32_t>(), ctx->d_pslot_of_slot[l].as<int32_t>(), &counts->level[l],
+                                 ctx->d_fin_state[l].as<unsigned long long>(), ctx->fin_epoch[l], ctx->fin_ticket[l], st[l]);
+            ctx->fin_ticket[l] += (uint32_t)leaf_finalize_tiles(n);
+            return DMSA_OK;
+        };
         launch_leaf_accept(ctx->d_leaf_start[l].as<int32_t>(), ctx->idx_s_v[l], ctx->d_ring.as<int32_t>(), &counts->level[l],
                            s.min_num_points_per_set, n, ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(), st[l]);
         if (split)
@@ -145,8 +161,11 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                               ctx->d_nglobal.as<float4>(), &counts->level[l], s.min_num_points_per_set, n, ctx->d_nsorted[l].as<float4>(),
                               ctx->d_pair_d[l].as<unsigned long long>(), ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(),
                               ctx->d_pos_slot_rank[l].as<int32_t>(), st[l]);
-        launch_leaf_scan(ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(), ctx->d_gauss_of_slot[l].as<int32_t>(), ctx->d_memb_of_slot[l].as<int32_t>(),
-                         ctx->d_pslot_of_slot[l].as<int32_t>(), &counts->level[l], st[l]);
+        if (ctx->dbg.fused_leaf_scan != 0)
+            CHK(finalize());
+        else
+            launch_leaf_scan(ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(), ctx->d_gauss_of_slot[l].as<int32_t>(), ctx->d_memb_of_slot[l].as<int32_t>(),
+                             ctx->d_pslot_of_slot[l].as<int32_t>(), &counts->level[l], st[l]);
         return DMSA_OK;
     };
     auto stage_gather = [&](int l, hipStream_t gs) {

@@ -36,6 +36,8 @@ typedef struct dmsa_debug_options {
     int32_t solve_threads;   /* 12  of which the blocked host LM solve uses at most this many                                            */
     int32_t host_timeline;   /* 0   print host-side time stamps of the last iteration of every optimize call to stderr                   */
     int32_t trace_time;      /* 0   print upload / optimize wall time of dmsa_optimize_window to stderr                                  */
+    int32_t fused_leaf_scan; /* 1   slot scans of the accepted leaves as a multi-workgroup single-pass kernel; 0: the                
+                                     single-workgroup k_leaf_scan                                                                         */
 } dmsa_debug_options;
 
 void dmsa_default_debug_options(dmsa_debug_options* o);

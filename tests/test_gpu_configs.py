@@ -471,4 +471,4 @@ def test_separate_level_sorts_on_an_odd_point_count(hip, orc):
     prob = synth.window_problem(seed=23, scans=3, rings=32, az_steps=256, num_static=5001)
     assert (prob.localPoints.shape[0] + prob.staticPoints.shape[0]) % 2 == 1
     _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=3), debug={"merge_sort": 0})
-    _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=2), debug={"merge_sort": 0, "library_sort": 1, "fused_segments": 0, "dual_stream": 0})
+    _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=2), debug={"merge_sort": 0, "library_sort": 1, "fused_segments": 0, "dual_stream": 0, "fused_leaf_scan": 0})
