@@ -251,6 +251,8 @@ struct dmsa_ctx {
     DevBuf d_loop_iter;    // LoopFlags | IterResult[num_iter]
     DevBuf d_panel_work;   // scratch of the blocked device solve for P > 64 (published panels, inverse, hand-over flags)
     uint32_t panel_epoch = 0;
+    DevBuf d_sync;         // counters of launch_sync_signal / launch_sync_wait: [0] forks, [1] joins, [2] a wait timed out
+    uint32_t sync_fork = 0, sync_join = 0;
     IterResult* h_results = nullptr;  // pinned
     int h_results_cap = 0;
     // one extra device->host copy riding on the counts read-back of build_gaussians (the previous iteration's IterResult)

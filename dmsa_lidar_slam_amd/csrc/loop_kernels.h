@@ -40,6 +40,12 @@ struct LoopFlags {
     int32_t pad[2];
 };
 
+// Cross-stream dependency through a counter in device memory instead of an event (8-10 us of barrier packets per record / wait):
+// launch_sync_signal adds one to *counter in stream order; launch_sync_wait holds its stream until *counter has reached `target`
+// (wrap-safe).  The signal MUST be enqueued before the wait.  *timed_out is set if the wait gave up (~2 s).
+void launch_sync_signal(uint32_t* counter, hipStream_t s);
+void launch_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, hipStream_t s);
+
 // iteration start (:72-75): paramVec = getPoseParameters(); window model: relative2global; ctrl0 = global poses (n x 6: axis-angle | translation)
 void launch_loop_begin(const LoopModel& m, double* state0, double* paramVec, double* ctrl0, LoopFlags* flags, hipStream_t s);
 // mode 0: the 1 + P evaluations of calcNumericJacobian (:199-232) from state_in (after loop_begin) -> ctrl[1+P][n][6], extra[1+P][a], state_out

@@ -836,6 +836,30 @@ void launch_loop_lm_panels(const double* Hp, int P, double lambda, double alpha,
     const size_t lds = kPanelLdsHead * sizeof(double) + ((size_t)P + 2) / 2 * sizeof(double) + sizeof(double) + (size_t)P * sizeof(double) + 64;
     hipLaunchKernelGGL(k_loop_lm_panels, dim3(nblocks), dim3(threads), lds, s, Hp, P, lambda, alpha, max_step, work, epoch, step, flags);
 }
+// ---- stream dependencies without barrier packets -----------------------------------------------------------------------------------
+// A hipEventRecord / hipStreamWaitEvent pair costs 8-10 us on each of the two streams (barrier packets serialise the queue around them).
+// These two one-wave kernels carry the same dependency through a counter in device memory: the signal runs in stream order behind the
+// producer (whose end-of-kernel release makes its results visible), the wait spins in front of the consumer, which starts with the usual
+// acquire.  Counters only grow; the host passes the value a wait has to see.  No deadlock as long as every signal is ENQUEUED before the
+// wait that needs it: hardware queues are FIFO, so a wait can only ever sit in front of packets that were enqueued after its signal.
+__global__ __launch_bounds__(64) void k_sync_signal(uint32_t* counter) {
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(64) void k_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out) {
+    if (threadIdx.x != 0) return;
+    // bounded: seconds of polling, then the consumer runs anyway and the host reports DMSA_ERR_HIP (never a hung GPU)
+    uint32_t v = 0;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t)(v - target) >= 0) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    timed_out[0] = 1, timed_out[1] = (int32_t)target, timed_out[2] = (int32_t)v;  // what was waited for, what was seen
+}
+void launch_sync_signal(uint32_t* counter, hipStream_t s) { hipLaunchKernelGGL(k_sync_signal, dim3(1), dim3(64), 0, s, counter); }
+void launch_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sync_wait, dim3(1), dim3(64), 0, s, counter, target, timed_out);
+}
 void launch_loop_step_finish(int P, double max_step, double* step, LoopFlags* flags, hipStream_t s) {
     hipLaunchKernelGGL(k_loop_step_finish, dim3(1), dim3(64), 0, s, P, max_step, step, flags);
 }

@@ -174,21 +174,48 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
         hipStream_t s_long = ctx->stream;
         hipStream_t s_mid = two ? ctx->stream2 : ctx->stream;
         hipStream_t s_small = three ? ctx->stream3 : s_mid;
-        if (two) {
+        // fork and join of the tier streams: counters in device memory (loop_kernels.h) instead of events, whose barrier packets cost
+        // 8-10 us per record / wait on `stream`; debug switch device_sync = 0 keeps the events
+        const bool dev_sync = two && ctx->dbg.device_sync != 0;
+        uint32_t* d_sync = nullptr;
+        if (dev_sync) {
+            d_sync = ctx->d_sync.as<uint32_t>();  // zeroed when the context was created
+            // the fork signal is given by the latency tier itself once all its workgroups are placed (serial_kernels.hip); its launch is
+            // enqueued before the waits (the order that rules out a deadlock on shared hardware queues)
+            ctx->sync_fork += 1;
+        } else if (two) {
             HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            if (three) HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
         }
-        if (three) HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
-        launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
-                                ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree);
-        // joins: the stream that finishes first is waited for first (its wait is through while `stream` still works)
-        if (three) {
-            HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
+        if (dev_sync) {
+            // latency tier first (with the signal), then the waits in front of the other tiers
+            launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
+                                    ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree, d_sync, 1);
+            int32_t* timed_out = reinterpret_cast<int32_t*>(d_sync + 2);
+            launch_sync_wait(d_sync, ctx->sync_fork, timed_out, ctx->stream2);
+            if (three) launch_sync_wait(d_sync, ctx->sync_fork, timed_out, ctx->stream3);
+            launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
+                                    ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree, nullptr, 6);
+        } else {
+            launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
+                                    ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree);
         }
-        if (two) {
-            HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
-            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        if (dev_sync) {
+            launch_sync_signal(d_sync + 1, ctx->stream2);
+            if (three) launch_sync_signal(d_sync + 1, ctx->stream3);
+            ctx->sync_join += three ? 2 : 1;
+            launch_sync_wait(d_sync + 1, ctx->sync_join, reinterpret_cast<int32_t*>(d_sync + 2), ctx->stream);
+        } else {
+            // joins: the stream that finishes first is waited for first (its wait is through while `stream` still works)
+            if (three) {
+                HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
+                HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
+            }
+            if (two) {
+                HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+                HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            }
         }
     } else {
         ScopedTimer tm(ctx, T_RESIDUAL);
@@ -214,7 +241,20 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
     // default path: the loop state lives on the device (one host wait per iteration); the host-driven loop remains for the opt-in fast
     // sums and for host-built pose tables
     const bool device_loop = (ctx->flags & DMSA_FLAG_MIRROR_SUMS) && !(ctx->flags & DMSA_FLAG_POSE_TABLE_HOST) && ctx->device_loop;
-    const int rc = device_loop ? optimize_device_loop(ctx, s, rep) : optimize_impl(ctx, s, rep);
+    int rc = device_loop ? optimize_device_loop(ctx, s, rep) : optimize_impl(ctx, s, rep);
+    if (rc == DMSA_OK && ctx->d_sync.p) {  // a device-side wait that gave up means a consumer ran before its producers: nothing of this call can be trusted
+        int32_t timed_out[3] = {0, 0, 0};
+        if (hipMemcpy(timed_out, ctx->d_sync.as<int32_t>() + 2, sizeof(timed_out), hipMemcpyDeviceToHost) != hipSuccess || timed_out[0] != 0) {
+            ctx->err = "a device-side stream dependency timed out (launch_sync_wait): waited for " + std::to_string(timed_out[1]) + ", counter at " +
+                       std::to_string(timed_out[2]) + "; host counts: forks " + std::to_string(ctx->sync_fork) + ", joins " + std::to_string(ctx->sync_join);
+            // start over: nothing is in flight after the failed call's final synchronisation
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(ctx->d_sync.p, 0, 64);
+            (void)hipDeviceSynchronize();
+            ctx->sync_fork = ctx->sync_join = 0;
+            rc = DMSA_ERR_HIP;
+        }
+    }
     if (rc != DMSA_OK && ctx->centralized) {
         const std::string err = ctx->err;
         (void)dmsa_decentralize(ctx);

@@ -353,7 +353,7 @@ template <int kProd, bool kSepLoader, int kChunk>
 #endif
 __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader ? DMSA_LONG_WAVES : DMSA_MID_WAVES) void k_residuals_chain(
     const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12, const float4* __restrict__ tabT, int B,
-    const uint32_t* __restrict__ order, int Bs, int nsub, int prio, int tree_mode, double* __restrict__ E, int64_t ldE) {
+    const uint32_t* __restrict__ order, int Bs, int nsub, int prio, int tree_mode, double* __restrict__ E, int64_t ldE, uint32_t* start_signal) {
     // tree_mode 0: second pass as a chain (the reference's loop, pipelined); 1: parallel second pass, chain only if the exactness test
     // fails; 2: parallel pass computed, then the chain anyway (test hook)
     constexpr int kProducers = kProd;
@@ -368,6 +368,11 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     __shared__ int s_chain;  // the parallel second pass failed its test for some evaluation
     double* s_t = reinterpret_cast<double*>(s_q);
 
+    // Fork of the tier streams (launch_sync_wait in front of the other tiers): the LAST workgroup of the latency tier releases them, i.e.
+    // they start once every workgroup of this launch has its CU -- released any earlier, thousands of their workgroups get in first and
+    // the longest Gaussians, which bound the batch, queue behind them (+60 us per line-search batch).
+    if (start_signal != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        __hip_atomic_fetch_add(start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int item = blockIdx.x, gi = item / nsub, sub = item - gi * nsub;
     const int g = (int)order[gi];
     const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
@@ -702,20 +707,21 @@ void launch_transpose_tables(const float* tables, int rows, int B, float* tables
                        reinterpret_cast<float4*>(tablesT));
 }
 void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tablesT, int B, const uint32_t* order,
-                             const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small, int tree_mode) {
+                             const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small, int tree_mode,
+                             uint32_t* start_signal, int tiers) {
     if (B <= 0) return;
     const SerialShape sh = serial_shape(B);
     const float4* info = reinterpret_cast<const float4*>(info12);
     const float4* tabT = reinterpret_cast<const float4*>(tablesT);
     const int n_long = sc.n_long, n_mid = sc.n_chain - sc.n_long;
     // latency tier first (its longest chain bounds the batch), blocks in descending size; the other tiers fill the chip around it
-    if (n_long > 0)
+    if (n_long > 0 && (tiers & 1))
         hipLaunchKernelGGL((k_residuals_chain<8, true, 64>), dim3((unsigned)n_long * sh.nsub_long), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
-                           sh.Bs_long, sh.nsub_long, 2, tree_mode, E, ldE);
-    if (n_mid > 0)
+                           sh.Bs_long, sh.nsub_long, 2, tree_mode, E, ldE, start_signal);
+    if (n_mid > 0 && (tiers & 2))
         hipLaunchKernelGGL((k_residuals_chain<4, false, 32>), dim3((unsigned)n_mid * sh.nsub), dim3(64 * 5), 0, s_rest, memb_local, seg_off, info, tabT, B,
-                           order + n_long, sh.Bs, sh.nsub, 0, tree_mode, E, ldE);
-    if (sc.n_small > 0) {
+                           order + n_long, sh.Bs, sh.nsub, 0, tree_mode, E, ldE, (uint32_t*)nullptr);
+    if (sc.n_small > 0 && (tiers & 4)) {
         const int items = sc.n_small * sh.nsub_small;
         const int per_block = 4 * (64 / sh.lanes);
         const dim3 grid((items + per_block - 1) / per_block);

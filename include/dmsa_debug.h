@@ -38,6 +38,8 @@ typedef struct dmsa_debug_options {
     int32_t trace_time;      /* 0   print upload / optimize wall time of dmsa_optimize_window to stderr                                  */
     int32_t fused_leaf_scan; /* 1   slot scans of the accepted leaves as a multi-workgroup single-pass kernel; 0: the                
                                      single-workgroup k_leaf_scan                                                                         */
+    int32_t device_sync;     /* 1   fork / join of the three tier streams through counters in device memory (one-wave signal / wait
+                                     kernels); 0: hipEventRecord / hipStreamWaitEvent                                                   */
 } dmsa_debug_options;
 
 void dmsa_default_debug_options(dmsa_debug_options* o);
