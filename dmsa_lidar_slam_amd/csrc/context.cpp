@@ -248,7 +248,7 @@ int dmsa_create_ex(int device, uint32_t flags, const dmsa_debug_options* options
     ctx->h_lattice = ctx->h_rb->lattice;
     // counters of the device-side stream dependencies (loop_kernels.h): zero BEFORE any stream of this context can look at them -- the
     // three streams are not ordered among themselves, and a recycled allocation still holds the counts of the context that freed it
-    if (ctx->d_sync.ensure(64) != hipSuccess || hipMemsetAsync(ctx->d_sync.p, 0, 64, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    if (ctx->d_sync.ensure(SYNC_SLOTS * 4) != hipSuccess || hipMemsetAsync(ctx->d_sync.p, 0, SYNC_SLOTS * 4, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
         dmsa_destroy(ctx);
         return DMSA_ERR_HIP;
     }

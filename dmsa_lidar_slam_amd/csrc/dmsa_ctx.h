@@ -251,8 +251,11 @@ struct dmsa_ctx {
     DevBuf d_loop_iter;    // LoopFlags | IterResult[num_iter]
     DevBuf d_panel_work;   // scratch of the blocked device solve for P > 64 (published panels, inverse, hand-over flags)
     uint32_t panel_epoch = 0;
-    DevBuf d_sync;         // counters of launch_sync_signal / launch_sync_wait: [0] forks, [1] joins, [2] a wait timed out
-    uint32_t sync_fork = 0, sync_join = 0;
+    DevBuf d_sync;         // counters of the device-side stream dependencies (dev_sync.h: SyncSlot), zeroed when the context is created
+    uint32_t sync_sig[SYNC_SLOTS] = {};  // signals enqueued so far per slot = the value a wait enqueued now has to see
+    bool tables_dev_sync = false;        // tables_pending is to be resolved through SYNC_TABLES, not ev_tables
+    uint32_t* sync_counter(int slot) const { return d_sync.as<uint32_t>() + slot; }
+    int32_t* sync_timed_out() const { return d_sync.as<int32_t>() + SYNC_TIMED_OUT; }
     IterResult* h_results = nullptr;  // pinned
     int h_results_cap = 0;
     // one extra device->host copy riding on the counts read-back of build_gaussians (the previous iteration's IterResult)

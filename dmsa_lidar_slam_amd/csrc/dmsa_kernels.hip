@@ -489,7 +489,7 @@ constexpr int kLatticeThreads = 1024;            // = kAabbBlock: one point of t
 constexpr int kLatticeLdsBlocks = 2048;           // block bounds kept in LDS (48 KB); larger clouds read the rest from global memory
 __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __restrict__ global, int64_t n, const float* __restrict__ aabb, int nb, double res0,
                                                             double res1, int compress, LatticeTable* __restrict__ tables, uint32_t* __restrict__ sort_header0,
-                                                            uint32_t* __restrict__ sort_header1) {
+                                                            uint32_t* __restrict__ sort_header1, uint32_t* done /* dev_sync.h: both workgroups add one */) {
     static_assert(kLatticeThreads == kAabbBlock, "one thread per point of a block");
     {  // the key kernels that follow count the sort digits into these headers
         uint32_t* h = blockIdx.x == 0 ? sort_header0 : sort_header1;
@@ -628,11 +628,15 @@ __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __res
                 tab->suffix_shift[e][a] = acc[a];
             }
     }
+    if (done != nullptr) {  // the key kernels of the other level run on another stream
+        __syncthreads();
+        if (threadIdx.x == 0) dev_sync_signal(done);
+    }
 }
 void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, bool compress, LatticeTable* tables,
-                    void* sort_header0, void* sort_header1, hipStream_t s) {
+                    void* sort_header0, void* sort_header1, hipStream_t s, uint32_t* done) {
     hipLaunchKernelGGL(k_lattice, dim3(2), dim3(kLatticeThreads), 0, s, global, n, aabb, nb, res0, res1, compress ? 1 : 0, tables,
-                       static_cast<uint32_t*>(sort_header0), static_cast<uint32_t*>(sort_header1));
+                       static_cast<uint32_t*>(sort_header0), static_cast<uint32_t*>(sort_header1), done);
 }
 
 // (c) genOctreeKeyforPoint with the bounding box in force when the point was inserted, plus the integer shifts of

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include "dev_sync.h"
 #include "pose_math.h"
 
 namespace dmsa {
@@ -40,14 +41,9 @@ struct LoopFlags {
     int32_t pad[2];
 };
 
-// Cross-stream dependency through a counter in device memory instead of an event (8-10 us of barrier packets per record / wait):
-// launch_sync_signal adds one to *counter in stream order; launch_sync_wait holds its stream until *counter has reached `target`
-// (wrap-safe).  The signal MUST be enqueued before the wait.  *timed_out is set if the wait gave up (~2 s).
-void launch_sync_signal(uint32_t* counter, hipStream_t s);
-void launch_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, hipStream_t s);
-
 // iteration start (:72-75): paramVec = getPoseParameters(); window model: relative2global; ctrl0 = global poses (n x 6: axis-angle | translation)
-void launch_loop_begin(const LoopModel& m, double* state0, double* paramVec, double* ctrl0, LoopFlags* flags, hipStream_t s);
+void launch_loop_begin(const LoopModel& m, double* state0, double* paramVec, double* ctrl0, LoopFlags* flags, hipStream_t s,
+                       uint32_t* state_ready = nullptr /* dev_sync.h: signalled when the state of the iteration start is in place */);
 // mode 0: the 1 + P evaluations of calcNumericJacobian (:199-232) from state_in (after loop_begin) -> ctrl[1+P][n][6], extra[1+P][a], state_out
 // mode 1: the 9 trials of adaptiveStepSize (:152-182), paramVec + 0.1 k step, from state_in (after the Jacobian batch) -> ctrl[9][n][6], extra[9][a], state_out
 void launch_loop_chain(const LoopModel& m, int mode, const double* state_in, double* state_out, const double* paramVec, const double* step, double increment,
@@ -78,6 +74,6 @@ void launch_loop_step_finish(int P, double max_step, double* step, LoopFlags* fl
 // error0: e0^T e0 of the iteration; trial_errs: the nine e^T e, or (trial_nsplit > 0) their block sums [9][trial_nsplit], added here in order.
 void launch_loop_finish(const LoopModel& m, const double* state_jac, const double* state_trial, double* state0, double* paramVec, const double* step,
                         const double* error0, const double* trial_errs, int trial_nsplit, int fixed_iters, double epsilon, IterResult* result, LoopFlags* flags,
-                        double* ctrl0, int chain_next, hipStream_t s);
+                        double* ctrl0, int chain_next, hipStream_t s, uint32_t* state_ready = nullptr /* as for launch_loop_begin */);
 
 }  // namespace dmsa

@@ -156,14 +156,20 @@ __device__ void begin_body(const LoopModel& m, const ChainLds& c, double* __rest
     }
     store_ctrl(ctrl0, m.n, c.glob_o, c.glob_t);
 }
+// `state_ready` (optional): counter the Jacobian chains on the side stream wait for (dev_sync.h) -- signalled on every path, a stopped
+// loop included
 __global__ __launch_bounds__(kWave) void k_loop_begin(const LoopModel m, double* __restrict__ state0, double* __restrict__ paramVec, double* __restrict__ ctrl0,
-                                                      LoopFlags* __restrict__ flags) {
+                                                      LoopFlags* __restrict__ flags, uint32_t* state_ready) {
     extern __shared__ double sm[];
-    if (flags->stop != 0) return;
-    if (threadIdx.x == 0) flags->nan = 0;
-    const ChainLds c = carve(sm, m.n, m.P);
-    load_state(state0, m.n, c.rel_o, c.rel_t, c.glob_o, c.glob_t);
-    begin_body(m, c, state0, paramVec, ctrl0);
+    DevSync sy;
+    sy.signal_counter = state_ready;
+    if (flags->stop == 0) {
+        if (threadIdx.x == 0) flags->nan = 0;
+        const ChainLds c = carve(sm, m.n, m.P);
+        load_state(state0, m.n, c.rel_o, c.rel_t, c.glob_o, c.glob_t);
+        begin_body(m, c, state0, paramVec, ctrl0);
+    }
+    dev_sync_leave(sy);
 }
 
 // One workgroup (= one wave) per evaluation of the batch.  Evaluations of a batch depend on each other only through relative pose 0 of
@@ -708,12 +714,11 @@ __global__ __launch_bounds__(kWave) void k_loop_step_finish(int P, double max_st
         for (int i = lane; i < P; i += kWave) step[i] = (max_step / max_elem) * step[i];
 }
 
-__global__ __launch_bounds__(kWave) void k_loop_finish(const LoopModel m, const double* __restrict__ state_jac, const double* __restrict__ state_trial,
-                                                       double* __restrict__ state0, double* __restrict__ paramVec, const double* __restrict__ step,
-                                                       const double* __restrict__ error0_ptr, const double* __restrict__ errs, int errs_nsplit,
-                                                       int fixed_iters, double epsilon, IterResult* __restrict__ result, LoopFlags* __restrict__ flags,
-                                                       double* __restrict__ ctrl0, int chain_next) {
-    extern __shared__ double sm[];
+__device__ __forceinline__ void loop_finish_body(double* sm, const LoopModel& m, const double* __restrict__ state_jac, const double* __restrict__ state_trial,
+                                                 double* __restrict__ state0, double* __restrict__ paramVec, const double* __restrict__ step,
+                                                 const double* __restrict__ error0_ptr, const double* __restrict__ errs, int errs_nsplit, int fixed_iters,
+                                                 double epsilon, IterResult* __restrict__ result, LoopFlags* __restrict__ flags, double* __restrict__ ctrl0,
+                                                 int chain_next) {
     if (flags->stop != 0) return;
     const int n = m.n, P = m.P;
     const ChainLds c = carve(sm, n, P);
@@ -789,11 +794,22 @@ __global__ __launch_bounds__(kWave) void k_loop_finish(const LoopModel m, const 
         begin_body(m, c, state0, paramVec, ctrl0);
     }
 }
+__global__ __launch_bounds__(kWave) void k_loop_finish(const LoopModel m, const double* __restrict__ state_jac, const double* __restrict__ state_trial,
+                                                       double* __restrict__ state0, double* __restrict__ paramVec, const double* __restrict__ step,
+                                                       const double* __restrict__ error0_ptr, const double* __restrict__ errs, int errs_nsplit,
+                                                       int fixed_iters, double epsilon, IterResult* __restrict__ result, LoopFlags* __restrict__ flags,
+                                                       double* __restrict__ ctrl0, int chain_next, uint32_t* state_ready) {
+    extern __shared__ double sm[];
+    loop_finish_body(sm, m, state_jac, state_trial, state0, paramVec, step, error0_ptr, errs, errs_nsplit, fixed_iters, epsilon, result, flags, ctrl0, chain_next);
+    DevSync sy;
+    sy.signal_counter = state_ready;  // the next iteration's Jacobian chains (side stream) may start: on every path, a stopped loop included
+    dev_sync_leave(sy);
+}
 
 }  // namespace
 
-void launch_loop_begin(const LoopModel& m, double* state0, double* paramVec, double* ctrl0, LoopFlags* flags, hipStream_t s) {
-    hipLaunchKernelGGL(k_loop_begin, dim3(1), dim3(kWave), chain_lds_bytes(m), s, m, state0, paramVec, ctrl0, flags);
+void launch_loop_begin(const LoopModel& m, double* state0, double* paramVec, double* ctrl0, LoopFlags* flags, hipStream_t s, uint32_t* state_ready) {
+    hipLaunchKernelGGL(k_loop_begin, dim3(1), dim3(kWave), chain_lds_bytes(m), s, m, state0, paramVec, ctrl0, flags, state_ready);
 }
 void launch_loop_chain(const LoopModel& m, int mode, const double* state_in, double* state_out, const double* paramVec, const double* step, double increment,
                        double* ctrl, double* extra, const LoopFlags* flags, hipStream_t s) {
@@ -836,25 +852,12 @@ void launch_loop_lm_panels(const double* Hp, int P, double lambda, double alpha,
     const size_t lds = kPanelLdsHead * sizeof(double) + ((size_t)P + 2) / 2 * sizeof(double) + sizeof(double) + (size_t)P * sizeof(double) + 64;
     hipLaunchKernelGGL(k_loop_lm_panels, dim3(nblocks), dim3(threads), lds, s, Hp, P, lambda, alpha, max_step, work, epoch, step, flags);
 }
-// ---- stream dependencies without barrier packets -----------------------------------------------------------------------------------
-// A hipEventRecord / hipStreamWaitEvent pair costs 8-10 us on each of the two streams (barrier packets serialise the queue around them).
-// These two one-wave kernels carry the same dependency through a counter in device memory: the signal runs in stream order behind the
-// producer (whose end-of-kernel release makes its results visible), the wait spins in front of the consumer, which starts with the usual
-// acquire.  Counters only grow; the host passes the value a wait has to see.  No deadlock as long as every signal is ENQUEUED before the
-// wait that needs it: hardware queues are FIFO, so a wait can only ever sit in front of packets that were enqueued after its signal.
+// ---- stream dependencies without barrier packets (dev_sync.h) ------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_sync_signal(uint32_t* counter) {
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) dev_sync_signal(counter);
 }
 __global__ __launch_bounds__(64) void k_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out) {
-    if (threadIdx.x != 0) return;
-    // bounded: seconds of polling, then the consumer runs anyway and the host reports DMSA_ERR_HIP (never a hung GPU)
-    uint32_t v = 0;
-    for (int spin = 0; spin < (1 << 22); ++spin) {
-        v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int32_t)(v - target) >= 0) return;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    timed_out[0] = 1, timed_out[1] = (int32_t)target, timed_out[2] = (int32_t)v;  // what was waited for, what was seen
+    if (threadIdx.x == 0) dev_sync_wait(counter, target, timed_out);
 }
 void launch_sync_signal(uint32_t* counter, hipStream_t s) { hipLaunchKernelGGL(k_sync_signal, dim3(1), dim3(64), 0, s, counter); }
 void launch_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, hipStream_t s) {
@@ -865,9 +868,9 @@ void launch_loop_step_finish(int P, double max_step, double* step, LoopFlags* fl
 }
 void launch_loop_finish(const LoopModel& m, const double* state_jac, const double* state_trial, double* state0, double* paramVec, const double* step,
                         const double* error0, const double* trial_errs, int trial_nsplit, int fixed_iters, double epsilon, IterResult* result, LoopFlags* flags,
-                        double* ctrl0, int chain_next, hipStream_t s) {
+                        double* ctrl0, int chain_next, hipStream_t s, uint32_t* state_ready) {
     hipLaunchKernelGGL(k_loop_finish, dim3(1), dim3(kWave), chain_lds_bytes(m), s, m, state_jac, state_trial, state0, paramVec, step, error0, trial_errs,
-                       trial_nsplit, fixed_iters, epsilon, result, flags, ctrl0, chain_next);
+                       trial_nsplit, fixed_iters, epsilon, result, flags, ctrl0, chain_next, state_ready);
 }
 
 }  // namespace dmsa

@@ -7,7 +7,10 @@
 int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs, hipStream_t stream) {
     if (stream == nullptr) stream = ctx->stream;
     if (ctx->tables_pending && stream == ctx->stream) {  // an earlier batch's tables may still be in flight on the second stream
-        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
+        if (ctx->tables_dev_sync)
+            launch_sync_wait(ctx->sync_counter(SYNC_TABLES), ctx->sync_sig[SYNC_TABLES], ctx->sync_timed_out(), ctx->stream);
+        else
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
         ctx->tables_pending = false;
     }
     ScopedTimer tm(ctx, T_TABLE);
@@ -129,8 +132,11 @@ int ensure_E(dmsa_ctx* ctx, int B) {
 }
 int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const double* d_extra) {
     CHK(ensure_E(ctx, B));
-    if (ctx->tables_pending) {  // the pose tables of this batch were built on the second stream
-        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
+    if (ctx->tables_pending) {  // the pose tables of this batch were built on another stream (and k_size_classes did not wait for them)
+        if (ctx->tables_dev_sync)
+            launch_sync_wait(ctx->sync_counter(SYNC_TABLES), ctx->sync_sig[SYNC_TABLES], ctx->sync_timed_out(), ctx->stream);
+        else
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
         ctx->tables_pending = false;
     }
     const int a = ctx->extra_rows;
@@ -182,7 +188,7 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
             d_sync = ctx->d_sync.as<uint32_t>();  // zeroed when the context was created
             // the fork signal is given by the latency tier itself once all its workgroups are placed (serial_kernels.hip); its launch is
             // enqueued before the waits (the order that rules out a deadlock on shared hardware queues)
-            ctx->sync_fork += 1;
+            ctx->sync_sig[SYNC_TIER_FORK] += 1;
         } else if (two) {
             HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
@@ -191,10 +197,10 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
         if (dev_sync) {
             // latency tier first (with the signal), then the waits in front of the other tiers
             launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
-                                    ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree, d_sync, 1);
-            int32_t* timed_out = reinterpret_cast<int32_t*>(d_sync + 2);
-            launch_sync_wait(d_sync, ctx->sync_fork, timed_out, ctx->stream2);
-            if (three) launch_sync_wait(d_sync, ctx->sync_fork, timed_out, ctx->stream3);
+                                    ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree,
+                                    d_sync + SYNC_TIER_FORK, 1);
+            launch_sync_wait(d_sync + SYNC_TIER_FORK, ctx->sync_sig[SYNC_TIER_FORK], ctx->sync_timed_out(), ctx->stream2);
+            if (three) launch_sync_wait(d_sync + SYNC_TIER_FORK, ctx->sync_sig[SYNC_TIER_FORK], ctx->sync_timed_out(), ctx->stream3);
             launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
                                     ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree, nullptr, 6);
         } else {
@@ -202,10 +208,10 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
                                     ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree);
         }
         if (dev_sync) {
-            launch_sync_signal(d_sync + 1, ctx->stream2);
-            if (three) launch_sync_signal(d_sync + 1, ctx->stream3);
-            ctx->sync_join += three ? 2 : 1;
-            launch_sync_wait(d_sync + 1, ctx->sync_join, reinterpret_cast<int32_t*>(d_sync + 2), ctx->stream);
+            launch_sync_signal(d_sync + SYNC_TIER_JOIN, ctx->stream2);
+            if (three) launch_sync_signal(d_sync + SYNC_TIER_JOIN, ctx->stream3);
+            ctx->sync_sig[SYNC_TIER_JOIN] += three ? 2 : 1;
+            launch_sync_wait(d_sync + SYNC_TIER_JOIN, ctx->sync_sig[SYNC_TIER_JOIN], ctx->sync_timed_out(), ctx->stream);
         } else {
             // joins: the stream that finishes first is waited for first (its wait is through while `stream` still works)
             if (three) {
@@ -244,14 +250,14 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
     int rc = device_loop ? optimize_device_loop(ctx, s, rep) : optimize_impl(ctx, s, rep);
     if (rc == DMSA_OK && ctx->d_sync.p) {  // a device-side wait that gave up means a consumer ran before its producers: nothing of this call can be trusted
         int32_t timed_out[3] = {0, 0, 0};
-        if (hipMemcpy(timed_out, ctx->d_sync.as<int32_t>() + 2, sizeof(timed_out), hipMemcpyDeviceToHost) != hipSuccess || timed_out[0] != 0) {
+        if (hipMemcpy(timed_out, ctx->sync_timed_out(), sizeof(timed_out), hipMemcpyDeviceToHost) != hipSuccess || timed_out[0] != 0) {
             ctx->err = "a device-side stream dependency timed out (launch_sync_wait): waited for " + std::to_string(timed_out[1]) + ", counter at " +
-                       std::to_string(timed_out[2]) + "; host counts: forks " + std::to_string(ctx->sync_fork) + ", joins " + std::to_string(ctx->sync_join);
+                       std::to_string(timed_out[2]);
             // start over: nothing is in flight after the failed call's final synchronisation
             (void)hipDeviceSynchronize();
-            (void)hipMemset(ctx->d_sync.p, 0, 64);
+            (void)hipMemset(ctx->d_sync.p, 0, SYNC_SLOTS * 4);
             (void)hipDeviceSynchronize();
-            ctx->sync_fork = ctx->sync_join = 0;
+            for (uint32_t& v : ctx->sync_sig) v = 0;
             rc = DMSA_ERR_HIP;
         }
     }
@@ -339,7 +345,7 @@ static int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep
             hipStream_t ts = ctx->stream;
             CHK(build_tables(ctx, 1 + P, globs, ts));
             HIPCHK(hipEventRecord(ctx->ev_tables, ts));
-            ctx->tables_pending = ts != ctx->stream;
+            ctx->tables_pending = ts != ctx->stream, ctx->tables_dev_sync = false;
             return DMSA_OK;
         };
         // The batch does not depend on the Gaussians, so its host math (on the parity path: 1 + P libm pose tables) and the
@@ -617,7 +623,13 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
     for (int iter = 0; iter < num_iter; ++iter) {
         g_tl.on = ctx->dbg.host_timeline != 0, g_tl.reset(), g_tl.mark("start");
         // :72-75 parameters, chain, base table, global points
-        if (iter == 0) launch_loop_begin(m, S0, d_param, ctx->d_ctrl0.as<double>(), d_flags, ctx->stream);  // later iterations: done by loop_finish
+        // the Jacobian chains on the side stream start when the state of the iteration start is in place: signalled by k_loop_begin /
+        // the previous k_loop_finish themselves (dev_sync.h) -- no event on the main stream
+        const bool dev_sync = ctx->dbg.device_sync != 0 && side != ctx->stream;
+        if (iter == 0) {  // later iterations: done by loop_finish
+            launch_loop_begin(m, S0, d_param, ctx->d_ctrl0.as<double>(), d_flags, ctx->stream, dev_sync ? ctx->sync_counter(SYNC_LOOP_STATE) : nullptr);
+            if (dev_sync) ctx->sync_sig[SYNC_LOOP_STATE] += 1;
+        }
         {
             ScopedTimer tm(ctx, T_TABLE);
             CHK(device_tables(ctx, 1, ctx->d_ctrl0.as<double>(), ctx->d_table0.as<float>(), nullptr, ctx->stream));
@@ -631,15 +643,22 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             ctx->aabb_fresh = true;
         }
         // :99, :199-232 the 1 + P chains, rows and pose tables of the Jacobian batch: beside the voxelisation, they need nothing from it
-        if (side != ctx->stream) {
+        if (dev_sync) {
+            launch_sync_wait(ctx->sync_counter(SYNC_LOOP_STATE), ctx->sync_sig[SYNC_LOOP_STATE], ctx->sync_timed_out(), side);
+        } else if (side != ctx->stream) {
             HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(hipStreamWaitEvent(side, ctx->ev_fork, 0));
         }
         launch_loop_chain(m, 0, S0, S1, d_param, d_step, increment, ctx->d_ctrl.as<double>(), d_extra_jac, d_flags, side);
         CHK(device_tables(ctx, 1 + P, ctx->d_ctrl.as<double>(), ctx->d_tables.as<float>(), ctx->d_tablesT.as<float>(), side));
         ctx->batch = 1 + P, ctx->tablesT_batch = 1 + P;
-        HIPCHK(hipEventRecord(ctx->ev_tables, side));
-        ctx->tables_pending = side != ctx->stream;
+        if (dev_sync) {  // the main stream picks the tables up in k_size_classes (or, if that kernel is not launched, in run_residuals)
+            launch_sync_signal(ctx->sync_counter(SYNC_TABLES), side);
+            ctx->sync_sig[SYNC_TABLES] += 1;
+        } else {
+            HIPCHK(hipEventRecord(ctx->ev_tables, side));
+        }
+        ctx->tables_pending = side != ctx->stream, ctx->tables_dev_sync = dev_sync;
         g_tl.mark("begin+batch enq");
         // :78-96; the previous iteration's result rides on the read-back of the counts
         if (iter > 0) {
@@ -721,8 +740,13 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             HIPCHK(ctx->d_sq_partial.ensure((size_t)std::max(squared_sums_partial_doubles(rowsE, 9), squared_sums_blocked_partial_doubles(rowsE, P, 9)) * 8));
             launch_squared_sums_blocked(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 9, ctx->d_sq_partial.as<double>(), nullptr, ctx->stream);  // block sums only
         }
-        launch_loop_finish(m, S1, S2, S0, d_param, d_step, d_error0, ctx->d_sq_partial.as<double>(), normal_equations_partials(rowsE, P).nsplit, fixed ? 1 : 0,
-                           s.epsilon, d_results + iter, d_flags, ctx->d_ctrl0.as<double>(), iter + 1 < num_iter ? 1 : 0, ctx->stream);
+        {
+            const bool sig = ctx->dbg.device_sync != 0 && side != ctx->stream;  // for the next iteration's chains, if there is one (a signal nobody waits for is harmless)
+            launch_loop_finish(m, S1, S2, S0, d_param, d_step, d_error0, ctx->d_sq_partial.as<double>(), normal_equations_partials(rowsE, P).nsplit, fixed ? 1 : 0,
+                               s.epsilon, d_results + iter, d_flags, ctx->d_ctrl0.as<double>(), iter + 1 < num_iter ? 1 : 0, ctx->stream,
+                               sig ? ctx->sync_counter(SYNC_LOOP_STATE) : nullptr);
+            if (sig) ctx->sync_sig[SYNC_LOOP_STATE] += 1;
+        }
         HIPCHK(hipGetLastError());
         g_tl.mark("iteration enq");
         if (host_nan) break;  // the device takes the same decision; nothing more to enqueue

@@ -169,8 +169,9 @@ __device__ __forceinline__ V mahalanobis_v(const Info& I, const V gx, const V gy
 // size classes: one workgroup sorts the Gaussians by descending size class (counting sort in LDS)
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_size_classes(const int32_t* __restrict__ seg_off, const GaussCounts* __restrict__ counts, int ns, int long_log2,
-                                                       uint32_t* __restrict__ order, SerialCounts* __restrict__ out) {
+                                                       uint32_t* __restrict__ order, SerialCounts* __restrict__ out, const DevSync sy) {
     __shared__ int h_c[64], h_s[kSmallMax], s_max;
+    dev_sync_enter(sy);  // e.g. the pose tables of the Jacobian batch, built beside the voxelisation: what follows this kernel on its stream needs them
     const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
     for (int i = threadIdx.x; i < 64; i += blockDim.x) h_c[i] = 0;
     for (int i = threadIdx.x; i < kSmallMax; i += blockDim.x) h_s[i] = 0;
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(1024) void k_size_classes(const int32_t* __restrict
         const int pos = n <= ns ? atomicAdd(&h_s[ns - n], 1) : atomicAdd(&h_c[chain_bin(n)], 1);
         order[pos] = (uint32_t)g;  // the order inside a bin is arbitrary: every (Gaussian, evaluation) result is independent of it
     }
+    dev_sync_leave(sy);  // the counts are final: their read-back (another stream) may start
 }
 
 __global__ __launch_bounds__(256) void k_transpose_tables(const float4* __restrict__ tables, int rows, int B, float4* __restrict__ tablesT) {
@@ -697,8 +699,8 @@ SerialShape serial_shape(int B) {
     s.nsub_small = (B + s.lanes - 1) / s.lanes;
     return s;
 }
-void launch_size_classes(const int32_t* seg_off, const GaussCounts* counts, uint32_t* order, SerialCounts* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_size_classes, dim3(1), dim3(1024), 0, s, seg_off, counts, serial_small_threshold(), serial_long_log2(), order, out);
+void launch_size_classes(const int32_t* seg_off, const GaussCounts* counts, uint32_t* order, SerialCounts* out, hipStream_t s, const DevSync& sy) {
+    hipLaunchKernelGGL(k_size_classes, dim3(1), dim3(1024), 0, s, seg_off, counts, serial_small_threshold(), serial_long_log2(), order, out, sy);
 }
 void launch_transpose_tables(const float* tables, int rows, int B, float* tablesT, hipStream_t s) {
     const int total = rows * B * 3;

@@ -30,8 +30,12 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                               ctx->stream);
         ctx->aabb_fresh = false;
         // the lattice kernel clears the headers of the own radix sorts on the side (one dispatch less per sort)
+        // device-side stream dependencies (dev_sync.h) instead of events where a kernel of this sequence can carry the signal
+        const bool dev_sync_lattice = ctx->dbg.device_sync != 0 && ctx->dual_stream && lvl_on[0] && lvl_on[1];
         launch_lattice(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), nb, ctx->level_res[0], ctx->level_res[1], compress,
-                       ctx->d_lattice.as<LatticeTable>(), headers_zeroed ? ctx->d_sort_tmp[0].p : nullptr, headers_zeroed ? ctx->d_sort_tmp[1].p : nullptr, ctx->stream);
+                       ctx->d_lattice.as<LatticeTable>(), headers_zeroed ? ctx->d_sort_tmp[0].p : nullptr, headers_zeroed ? ctx->d_sort_tmp[1].p : nullptr, ctx->stream,
+                       dev_sync_lattice ? ctx->sync_counter(SYNC_LATTICE) : nullptr);
+        if (dev_sync_lattice) ctx->sync_sig[SYNC_LATTICE] += 2;  // one per resolution
         if (!speculate) {  // sync #1: tree depths select the radix-sort bit range (speculation reads them with the counts instead)
             HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(sync_spin(ctx->stream));
@@ -178,8 +182,16 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     };
     {
         ScopedTimer tm(ctx, T_VOXEL);
+        const bool dev_sync = two && ctx->dbg.device_sync != 0;
         if (merged) CHK(stage_sort_both());
-        if (two) {
+        if (dev_sync) {
+            // level 1 on its own stream: it needs the lattice (k_lattice signals) and, merged, the common sort (a signal kernel behind it)
+            if (merged) {
+                launch_sync_signal(ctx->sync_counter(SYNC_LATTICE), ctx->stream);
+                ctx->sync_sig[SYNC_LATTICE] += 1;
+            }
+            launch_sync_wait(ctx->sync_counter(SYNC_LATTICE), ctx->sync_sig[SYNC_LATTICE], ctx->sync_timed_out(), ctx->stream2);
+        } else if (two) {
             HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         }
@@ -193,9 +205,17 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         // Both gathers on the first stream (level 1 appends behind level 0's totals anyway): the level-1 chain ends with its leaf scan,
         // long before level 0's gather is through, so the wait below finds its event signalled -- a join at the END of a stream costs
         // ~20 us of cross-queue signalling in front of everything that follows.
-        if (two) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+        if (dev_sync) {
+            launch_sync_signal(ctx->sync_counter(SYNC_LEVEL1), ctx->stream2);
+            ctx->sync_sig[SYNC_LEVEL1] += 1;
+        } else if (two) {
+            HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+        }
         if (lvl_on[0]) stage_gather(0, ctx->stream);
-        if (two) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        if (dev_sync)
+            launch_sync_wait(ctx->sync_counter(SYNC_LEVEL1), ctx->sync_sig[SYNC_LEVEL1], ctx->sync_timed_out(), ctx->stream);
+        else if (two)
+            HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         if (lvl_on[1]) stage_gather(1, ctx->stream);
     }
     if (!tiles_on) {
@@ -214,13 +234,28 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                            ctx->d_pad_off.as<int32_t>(), ctx->stream);
     }
     const bool classes_on = !tiles_on && (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0;
-    if (classes_on)  // size classes of the reference-order correspondence kernels: needs only seg_off, so it runs before the read-back
-        launch_size_classes(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_order.as<uint32_t>(),
-                            reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts) + sizeof(TileCounts)), ctx->stream);
     // The read-back of the counts runs on the third stream: a device-to-host copy ends with a system-scope release that holds up the
     // stream it is on for ~20 us, and the fit behind it does not need to wait for that.
     hipStream_t rb = ctx->dual_stream ? ctx->stream3 : ctx->stream;
-    if (rb != ctx->stream) {
+    bool rb_released = false;
+    if (classes_on) {  // size classes of the reference-order correspondence kernels: needs only seg_off, so it runs before the read-back
+        // k_size_classes is one workgroup on the main stream between the voxelisation and the fit: it also carries two stream dependencies
+        // (dev_sync.h) -- it waits for the pose tables of the Jacobian batch (built on the side stream long ago) and releases the read-back
+        DevSync sy;
+        if (ctx->dbg.device_sync != 0) {
+            sy.timed_out = ctx->sync_timed_out();
+            if (ctx->tables_pending && ctx->tables_dev_sync) {
+                sy.wait_counter = ctx->sync_counter(SYNC_TABLES), sy.wait_target = ctx->sync_sig[SYNC_TABLES];
+                ctx->tables_pending = false;
+            }
+            if (rb != ctx->stream) sy.signal_counter = ctx->sync_counter(SYNC_CLASSES), ctx->sync_sig[SYNC_CLASSES] += 1, rb_released = true;
+        }
+        launch_size_classes(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_order.as<uint32_t>(),
+                            reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts) + sizeof(TileCounts)), ctx->stream, sy);
+    }
+    if (rb_released) {
+        launch_sync_wait(ctx->sync_counter(SYNC_CLASSES), ctx->sync_sig[SYNC_CLASSES], ctx->sync_timed_out(), rb);
+    } else if (rb != ctx->stream) {
         HIPCHK(hipEventRecord(ctx->ev_scan0, ctx->stream));
         HIPCHK(hipStreamWaitEvent(rb, ctx->ev_scan0, 0));
     }
