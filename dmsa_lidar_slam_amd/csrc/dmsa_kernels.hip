@@ -1640,11 +1640,22 @@ __device__ __forceinline__ void fit_tree_group(const float4* __restrict__ memb_l
         const int row = __float_as_int(p.w);
         return apply_row3(table0[3 * row], table0[3 * row + 1], table0[3 * row + 2], p.x, p.y, p.z);
     };
-    // the groups of a workgroup meet at the same barriers: everybody runs as many super-rounds as the group with the most blocks
-    if (gtid == 0) atomicMax(s_rounds, (nblk + kMaxBlk - 1) / kMaxBlk);
+    // A group of ONE wave (the short class: sixteen Gaussians per workgroup) needs no workgroup barrier at all -- its LDS traffic is in
+    // order, its scratch is its own -- so the sixteen waves run and end independently instead of meeting ten times at the pace of the
+    // slowest.  Groups of several waves meet at the same barriers: everybody runs as many super-rounds as the group with the most blocks.
+    constexpr bool kSolo = kFitWaves == 1;
+    auto sync = [&]() {
+        if (kSolo) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+        }
+    };
+    if (!kSolo && gtid == 0) atomicMax(s_rounds, (nblk + kMaxBlk - 1) / kMaxBlk);
     if (gtid < 6) s_tot[gtid] = 0.0;
-    __syncthreads();
-    const int rounds = *s_rounds;
+    sync();
+    const int rounds = kSolo ? (nblk + kMaxBlk - 1) / kMaxBlk : *s_rounds;
     for (int r = 0; r < rounds; ++r) {  // pass 1: sums of x, y, z
         const int sb = r * kMaxBlk, end = min(nblk, sb + kMaxBlk);
         for (int blk = sb + wave; blk < end; blk += kFitWaves) {
@@ -1657,19 +1668,19 @@ __device__ __forceinline__ void fit_tree_group(const float4* __restrict__ memb_l
             x = wave_allsum(x), y = wave_allsum(y), z = wave_allsum(z);
             if (lane == 0) s_blk[blk - sb][0] = x, s_blk[blk - sb][1] = y, s_blk[blk - sb][2] = z;
         }
-        __syncthreads();
+        sync();
         if (gtid < 3) {
             double tot = s_tot[gtid];
             for (int t = 0; t < end - sb; ++t) tot += s_blk[t][gtid];
             s_tot[gtid] = tot;
         }
-        __syncthreads();
+        sync();
     }
     if (gtid < 3) s_mean[gtid] = (float)(s_tot[gtid] / (double)n);
-    __syncthreads();
+    sync();
     const float mx = s_mean[0], my = s_mean[1], mz = s_mean[2];
     if (gtid < 6) s_tot[gtid] = 0.0;
-    __syncthreads();
+    sync();
     for (int r = 0; r < rounds; ++r) {  // pass 2: xx xy xz yy yz zz of the centred members
         const int sb = r * kMaxBlk, end = min(nblk, sb + kMaxBlk);
         for (int blk = sb + wave; blk < end; blk += kFitWaves) {
@@ -1687,13 +1698,13 @@ __device__ __forceinline__ void fit_tree_group(const float4* __restrict__ memb_l
                 if (lane == 0) s_blk[blk - sb][c] = v;
             }
         }
-        __syncthreads();
+        sync();
         if (gtid < 6) {
             double tot = s_tot[gtid];
             for (int t = 0; t < end - sb; ++t) tot += s_blk[t][gtid];
             s_tot[gtid] = tot;
         }
-        __syncthreads();
+        sync();
     }
     if (g >= 0 && gtid < 6) sums[(size_t)g * 6 + gtid] = s_tot[gtid];
 }

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         const Info I2 = load_info(info12, g);
         if (threadIdx.x == 0) s_chain = 0;
         double part = 0.0;
-        uint32_t key = 0xffffffffu;  // high word of the smallest term as a double (monotone for positive values); 0: a term <= 0 or NaN
+        int key = 0x7fffffff;  // bits of the smallest term (positive floats order like their bit patterns); <= 0: a zero or negative term (or -NaN)
         Rows r2;
         r2.r0 = r2.r1 = r2.r2 = f4{0.0f, 0.0f, 0.0f, 0.0f};
         int r2_row = -1;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
                 const float t = mahalanobis_v(I2, gx, gy, gz, mx2, my2, mz2);
                 const double td = (double)t;
                 part += td;
-                key = min(key, t > 0.0f ? hi_word(td) : 0u);
+                key = min(key, __float_as_int(t));
             }
         };
         // four member registers used in turn, each refilled (for four steps ahead) right AFTER its use: the load can land in the
@@ -428,20 +428,21 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
             j += 4 * mpl;
         }
         double* red = s_t;  // the rings are idle between the passes
-        uint32_t* redk = reinterpret_cast<uint32_t*>(s_t + kWaves * 64);
+        int* redk = reinterpret_cast<int*>(s_t + kWaves * 64);
         red[wave * 64 + lane] = part, redk[wave * 64 + lane] = key;
         lds_barrier();
         if (wave == 0 && lane < nb) {
             double U = 0.0;
-            uint32_t k = 0xffffffffu;
+            int k = 0x7fffffff;
             for (int w = 0; w < kWaves; ++w)
                 for (int s2 = 0; s2 < mpl; ++s2) U += red[w * 64 + s2 * Bs + lane], k = min(k, redk[w * 64 + s2 * Bs + lane]);
-            const int q = (int)(k >> 20) - 1023 - 23;           // every term is a multiple of 2^q
+            const int q = ((k >> 23) & 0xff) - 127 - 23;        // every term is a multiple of 2^q (a denormal smallest term: of 2^-149, so also of 2^-150)
             const int pe = min(max(q + 53 + 1023, 0), 2046);
             const double limit = __hiloint2double(pe << 20, 0);  // 2^(q+53); 0 when that is below the normal range: the test fails
-            // k == 0: some term was zero, negative or NaN -- the proof needs positive terms, so the chain runs (a non-positive U would
-            // otherwise slip under the 2^-993 the clamped exponent gives).  NaN fails; U itself may be rounded: < n 2^-53 relative
-            const bool exact = k != 0u && U * (1.0 + 0x1p-30) < limit && tree_mode == 1;
+            // k <= 0: some term was zero or negative -- the proof needs positive terms, so the chain runs (a non-positive U would otherwise
+            // slip under the 2^-993 the clamped exponent gives).  A NaN term makes U a NaN, which fails the comparison; U itself may be
+            // rounded: < n 2^-53 relative
+            const bool exact = k > 0 && U * (1.0 + 0x1p-30) < limit && tree_mode == 1;
             if (exact)
                 E[(size_t)(b0 + lane) * ldE + g] = sqrt(fabs(U));
             else
