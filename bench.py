@@ -325,7 +325,7 @@ def main():
             "roofline": {
                 "kernel": ("correspondence kernels k_residuals_tiles + k_residuals_big" if args.fast_sums else
                            "reference-order correspondence kernels (k_residuals_chain<8,true,64> + k_residuals_chain<4,false,32> + k_residuals_small, "
-                           "three streams, one HIP-event pair around the batch)") + ", B evaluations per launch",
+                           "three streams, fork / join by device counters, one HIP-event pair around the batch)") + ", B evaluations per launch",
                 "bound": "hbm",
                 # the brief's figure: per-unit algorithmic bytes x units per launch / launch time
                 "achieved": round(achieved, 2),
@@ -345,8 +345,10 @@ def main():
                 "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
                 "compulsory_bytes_per_launch": round(compulsory_per_launch, 1),
                 "us_per_evaluation": round(1e3 * tm.residual_kernel_ms / evals, 3),
-                "bound_stated": "vector issue / dependent-add latency, not HBM: a launch evaluates B pose tables on members it reads "
-                                "once per pass, so `frac` is an effective rate; the HBM fractions are frac_compulsory and frac_counters",
+                "bound_stated": "not HBM: vector instruction issue for the Jacobian batch (its three kernels use 86 % of the issue slots, DESIGN.md "
+                                "6.2), dependent-add latency of the longest Gaussian for the line-search batch.  A launch evaluates B pose tables on "
+                                "members it reads once per pass, so `frac` is an effective rate; the HBM fractions are frac_compulsory and "
+                                "frac_counters",
                 "valu": {"achieved_tflops": round(valu_tflops, 2), "peak_tflops_no_fma": 78.6,
                          "frac": round(valu_tflops / 78.6, 4)},
             },

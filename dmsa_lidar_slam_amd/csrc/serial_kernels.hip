@@ -179,8 +179,28 @@ __global__ __launch_bounds__(1024) void k_size_classes(const int32_t* __restrict
     __syncthreads();
     // chain bin: descending (floor(log2 n), next bit) -> at most 2x spread of sizes inside a bin, longest first
     auto chain_bin = [](int n) { const int k = 31 - __clz(n); const int sub = k > 0 ? (n >> (k - 1)) & 1 : 0; return 63 - (2 * k + sub); };
+    // The sizes of the first kPer x 1024 Gaussians stay in registers for both passes, all their loads issued at once: the kernel is one
+    // workgroup on the critical path, and a loop of dependent (load, LDS atomic) pairs pays the memory latency M / 1024 times.
+    constexpr int kPer = 16;
+    int nn[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int g = threadIdx.x + u * 1024;
+        nn[u] = g < M ? max(seg_off[g + 1] - seg_off[g], 1) : 0;
+    }
     int mx = 0;
-    for (int g = threadIdx.x; g < M; g += blockDim.x) {
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int n = nn[u];
+        if (n > 0) {
+            mx = max(mx, n);
+            if (n <= ns)
+                atomicAdd(&h_s[ns - n], 1);
+            else
+                atomicAdd(&h_c[chain_bin(n)], 1);
+        }
+    }
+    for (int g = threadIdx.x + kPer * 1024; g < M; g += blockDim.x) {
         const int n = max(seg_off[g + 1] - seg_off[g], 1);
         mx = max(mx, n);
         if (n <= ns)
@@ -190,25 +210,49 @@ __global__ __launch_bounds__(1024) void k_size_classes(const int32_t* __restrict
     }
     atomicMax(&s_max, mx);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int pos = 0, n_long = 0;
-        for (int b = 0; b < 64; ++b) {
-            const int c = h_c[b];
-            h_c[b] = pos, pos += c;
-            if (b == 63 - 2 * long_log2) n_long = pos;  // bins 0 .. 63 - 2 * long_log2 hold n >= 2^long_log2
+    if (threadIdx.x < 64) {  // exclusive prefix over the 64 chain bins, then over the ns <= 256 short bins (four per lane): one wave, two scans
+        const int lane = threadIdx.x;
+        auto scan = [&](int v) {
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(v, o);
+                if (lane >= o) v += t;
+            }
+            return v;
+        };
+        const int c = h_c[lane];
+        const int incl = scan(c);
+        h_c[lane] = incl - c;
+        const int n_chain = __shfl(incl, 63);
+        const int n_long = __shfl(incl, 63 - 2 * long_log2);  // bins 0 .. 63 - 2 * long_log2 hold n >= 2^long_log2
+        int v[4], t = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = 4 * lane + u < ns ? h_s[4 * lane + u] : 0, t += v[u];
+        const int ti = scan(t);
+        int pos = n_chain + ti - t;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (4 * lane + u < ns) h_s[4 * lane + u] = pos;
+            pos += v[u];
         }
-        const int n_chain = pos;
-        for (int b = 0; b < ns; ++b) {
-            const int c = h_s[b];
-            h_s[b] = pos, pos += c;
-        }
-        out->n_chain = n_chain, out->n_small = pos - n_chain, out->max_members = s_max, out->n_long = n_long;
+        const int n_small = __shfl(ti, 63);
+        if (lane == 0) out->n_chain = n_chain, out->n_small = n_small, out->max_members = s_max, out->n_long = n_long;
     }
     __syncthreads();
-    for (int g = threadIdx.x; g < M; g += blockDim.x) {
+    // the order inside a bin is arbitrary: every (Gaussian, evaluation) result is independent of it
+    int pos_u[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int n = nn[u];
+        pos_u[u] = n <= 0 ? -1 : (n <= ns ? atomicAdd(&h_s[ns - n], 1) : atomicAdd(&h_c[chain_bin(n)], 1));
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u)
+        if (pos_u[u] >= 0) order[pos_u[u]] = (uint32_t)(threadIdx.x + u * 1024);
+    for (int g = threadIdx.x + kPer * 1024; g < M; g += blockDim.x) {
         const int n = max(seg_off[g + 1] - seg_off[g], 1);
         const int pos = n <= ns ? atomicAdd(&h_s[ns - n], 1) : atomicAdd(&h_c[chain_bin(n)], 1);
-        order[pos] = (uint32_t)g;  // the order inside a bin is arbitrary: every (Gaussian, evaluation) result is independent of it
+        order[pos] = (uint32_t)g;
     }
     dev_sync_leave(sy);  // the counts are final: their read-back (another stream) may start
 }
