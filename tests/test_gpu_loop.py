@@ -90,6 +90,9 @@ def test_early_exits_match_the_oracle_and_the_host_driven_loop(hip, orc, case):
     _same(dev, (p_ref, rep_ref, tr_ref))
     host = _run(hip, prob, s, debug={"device_loop": 0})
     _same(dev, host)
+    # the stream dependencies as HIP events instead of device counters (csrc/dev_sync.h), and the single-workgroup slot scan
+    _same(dev, _run(hip, prob, s, debug={"device_sync": 0, "fused_leaf_scan": 0}))
+    _same(dev, _run(hip, prob, s, debug={"device_loop": 0, "device_sync": 0}))
     if case == "window_runs_to_a_stop":
         assert dev[1].stop_reason != 0 and dev[1].iterations < s.num_iter  # the case really exercises a device-side stop
 
@@ -108,3 +111,28 @@ def test_too_few_gaussians_leaves_the_state_of_the_iteration_start(hip, orc):
     rep_ref, _, tr_ref = orc.optimize_window(p_ref, s)
     assert rep_ref.stop_reason == 1
     _same(_run(hip, prob, s), (p_ref, rep_ref, tr_ref))
+
+
+def test_many_contexts_in_one_process_share_hardware_queues(hip, orc):
+    """The device-side stream dependencies (csrc/dev_sync.h) must hold when HIP maps the streams of several contexts onto the same
+    hardware queues, and when a context reuses the allocation (and so the stale counters) of one that was closed: eight contexts are
+    created, used alternately and closed in a different order.  A wait that gave up would surface as DMSA_ERR_HIP."""
+    from dmsa_lidar_slam_amd.api import DmsaOptimizer
+
+    prob = synth.window_problem(seed=3, scans=3, rings=32, az_steps=256, num_static=3000)
+    s = DmsaOptimSettings.sliding_window(num_iter=4)
+    p_ref = prob.copy()
+    orc.optimize_window(p_ref, s)
+    opts = [DmsaOptimizer(device=0) for _ in range(8)]
+    results = []
+    for rounds in range(2):
+        for o in opts:
+            p = prob.copy()
+            o.optimizeSet(p, s)
+            results.append(p)
+        opts[rounds].close()
+        opts[rounds] = DmsaOptimizer(device=0)  # lands on the memory the closed context just freed
+    for o in opts:
+        o.close()
+    for p in results:
+        assert np.array_equal(p.relOrientations, p_ref.relOrientations) and np.array_equal(p.relTranslations, p_ref.relTranslations)
