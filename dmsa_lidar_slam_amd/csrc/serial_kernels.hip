@@ -65,9 +65,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // s_waitcnt INSIDE the branch: left to the compiler, the wait for the three row loads lands behind the join of the branch as
 // vmcnt(0), i.e. every step would also wait for the member prefetch that was issued just before it -- the full memory latency
 // per step, taken or not.  This way only a step that really changes rows (a few percent) drains the queue.
-// The x and y rows are kept as register PAIRS: a wave of these kernels is bound by instruction issue (one instruction per ~5
-// cycles), not by VALU time, so the x/y halves of the transform and of the quadratic form go through v_pk_mul_f32 / v_pk_add_f32
-// (two IEEE operations per instruction, each rounded separately -- same results, two thirds of the instructions).
+// Packed fp32 (v_pk_mul_f32 / v_pk_add_f32 round each half separately, so it is legal here) is used in ONE place only, the quadratic
+// form of the short tier.  Rounds 1-2 also packed the x / y halves of the transforms and the member pairs of the producers ("two
+// thirds of the instructions"); on gfx950 a wave64 packed instruction occupies the SIMD for two passes, these kernels are bound by
+// vector issue, and measured site by site in round 3 the transforms are faster written out as scalar operations
+// (+1.7 % it/s), the parallel second pass is slower packed (-2.7 %), and the short tier's quadratic form is slower unpacked (-1.5 %).
 typedef float f2 __attribute__((ext_vector_type(2)));
 struct RowCache {
     int row = -1;
@@ -91,16 +93,12 @@ struct RowCache {
     }
     // Matrix4f * Vector4f, column-wise like Eigen's packet product: ((c0*x + c1*y) + c2*z) + c3
     __device__ __forceinline__ void apply(const float4 p, f2& gxy, float& gz) const {
-#ifdef DMSA_NO_PK
         gxy.x = ((cx.x * p.x + cy.x * p.y) + cz.x * p.z) + cw.x;
         gxy.y = ((cx.y * p.x + cy.y * p.y) + cz.y * p.z) + cw.y;
-#else
-        gxy = ((cx * p.x + cy * p.y) + cz * p.z) + cw;
-#endif
         gz = ((r2.x * p.x + r2.y * p.y) + r2.z * p.z) + r2.w;
     }
 };
-// information matrix in the packed form of the quadratic form: columns 0/1 as pairs, column 2 and the weight as scalars
+// information matrix in the packed form of the short tier's quadratic form: columns 0 / 1 as pairs, column 2 and the weight as scalars
 struct InfoPk {
     f2 a0, a1, a2;         // (A00, A01), (A10, A11), (A20, A21)
     float A02, A12, A22, w;
@@ -111,7 +109,7 @@ __device__ __forceinline__ InfoPk load_info_pk(const float4* __restrict__ info12
     return InfoPk{f2{i0.x, i0.w}, f2{i0.y, i1.x}, f2{i0.z, i1.y}, i1.z, i1.w, i2.x, i2.y};
 }
 // the float Mahalanobis term of DmsaOptimizer.h:263, ((w d^T) A) d with 3-term sums as a + (b + c); identical operation order to
-// mahalanobis_term(), the x/y columns packed
+// mahalanobis_term(), the x / y columns packed
 __device__ __forceinline__ float mahalanobis_term_pk(const InfoPk& I, const f2 gxy, const float gz, const f2 mxy, const float mz) {
     const f2 d = gxy - mxy;
     const float d2 = gz - mz;
@@ -124,10 +122,9 @@ __device__ __forceinline__ float mahalanobis_term_pk(const InfoPk& I, const f2 g
 }
 
 // ---- member-pair form (producers of the chain kernel) -----------------------------------------------------------------
-// A producer lane takes TWO consecutive members at a time and carries them through the transform and the quadratic form as the
-// two halves of packed registers (v_pk_mul_f32 / v_pk_add_f32: two separately rounded IEEE operations per instruction).  The
-// pose-table row is a per-lane scalar that the packed instructions broadcast (op_sel), so the same code serves both members when
-// they share a row -- the common case: consecutive members of a Gaussian come from neighbouring firing times.
+// A producer lane takes TWO consecutive members at a time (one LDS read of the member ring, one LDS write of the coordinates for
+// both); when they share a pose-table row -- the common case: consecutive members of a Gaussian come from neighbouring firing times
+// -- the row is loaded once.  The arithmetic is scalar per member (see RowCache).
 typedef float f4 __attribute__((ext_vector_type(4)));
 struct Rows {  // one pose-table row: three native 4-float vectors (inline-asm outputs stay in registers; a HIP float4 struct would not)
     f4 r0, r1, r2;
@@ -152,6 +149,12 @@ __device__ __forceinline__ void transform_v(const Rows rc, const V x, const V y,
     gy = ((rc.r1.x * x + rc.r1.y * y) + rc.r1.z * z) + rc.r1.w;
     gz = ((rc.r2.x * x + rc.r2.y * y) + rc.r2.z * z) + rc.r2.w;
 }
+__device__ __forceinline__ void transform_v(const Rows rc, const f2 x, const f2 y, const f2 z, f2& gx, f2& gy, f2& gz) {  // a member pair
+    float a, b, c, d, e, f;
+    transform_v<float>(rc, x.x, y.x, z.x, a, b, c);
+    transform_v<float>(rc, x.y, y.y, z.y, d, e, f);
+    gx = f2{a, d}, gy = f2{b, e}, gz = f2{c, f};
+}
 // ((w d^T) A) d of DmsaOptimizer.h:263 with 3-term sums as a + (b + c) -- the operation order of mahalanobis_term()
 template <class V>
 __device__ __forceinline__ V mahalanobis_v(const Info& I, const V gx, const V gy, const V gz, const float mx, const float my, const float mz) {
@@ -161,6 +164,9 @@ __device__ __forceinline__ V mahalanobis_v(const Info& I, const V gx, const V gy
     const V v1 = wd0 * I.A01 + (wd1 * I.A11 + wd2 * I.A21);
     const V v2 = wd0 * I.A02 + (wd1 * I.A12 + wd2 * I.A22);
     return v0 * d0 + (v1 * d1 + v2 * d2);
+}
+__device__ __forceinline__ f2 mahalanobis_v(const Info& I, const f2 gx, const f2 gy, const f2 gz, const float mx, const float my, const float mz) {
+    return f2{mahalanobis_v<float>(I, gx.x, gy.x, gz.x, mx, my, mz), mahalanobis_v<float>(I, gx.y, gy.y, gz.y, mx, my, mz)};
 }
 
 }  // namespace
