@@ -251,6 +251,7 @@ struct dmsa_ctx {
     DevBuf d_loop_iter;    // LoopFlags | IterResult[num_iter]
     DevBuf d_panel_work;   // scratch of the blocked device solve for P > 64 (published panels, inverse, hand-over flags)
     uint32_t panel_epoch = 0;
+    DevBuf d_rot_same;     // per evaluation of the Jacobian batch: 1 = its control rotations are evaluation 0's bit for bit (pose-table kernels)
     DevBuf d_sync;         // counters of the device-side stream dependencies (dev_sync.h: SyncSlot), zeroed when the context is created
     uint32_t sync_sig[SYNC_SLOTS] = {};  // signals enqueued so far per slot = the value a wait enqueued now has to see
     bool tables_dev_sync = false;        // tables_pending is to be resolved through SYNC_TABLES, not ev_tables
@@ -361,6 +362,6 @@ void append_glob(const PoseChain& c, std::vector<double>& out);
 void host_set_params(dmsa_ctx* ctx, const double* p);
 int transform_points(dmsa_ctx* ctx, int b);
 int ensure_E(dmsa_ctx* ctx, int B);
-int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const double* d_extra = nullptr);
+int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const double* d_extra = nullptr, const uint32_t* rot_same = nullptr);
 int device_lm_step(dmsa_ctx* ctx, const double* d_Hp, int P, double lambda, double alpha, double max_step, double* d_step, LoopFlags* d_flags);
 int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep);

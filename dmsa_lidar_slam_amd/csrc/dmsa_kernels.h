@@ -81,9 +81,10 @@ void launch_shift_points(float4* pts, int64_t n, float ox, float oy, float oz, f
 // ---- K1: dense pose tables from global control poses (device variant) ------------------------------------
 // ctrl: B x C x 6 doubles (axis-angle, translation) ; stamps C ; fh_w C ; traj_time n_t ; out: B x (n_t+1) x 12 floats
 void launch_window_pose_tables(const double* ctrl, const double* stamps, const double* fh_w, const double* traj_time, int B, int C, int n_t,
-                               float* tables, float* tablesT /* may be null: the same rows as [row][B][12] */, hipStream_t s);
+                               float* tables, float* tablesT /* may be null: the same rows as [row][B][12] */, hipStream_t s,
+                               uint32_t* rot_same = nullptr /* [B], may be null: 1 where all control rotations of an evaluation equal evaluation 0's bit for bit */);
 // frames: B x F x 6 doubles global poses -> B x (F+1) x 12
-void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tables, float* tablesT, hipStream_t s);
+void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tables, float* tablesT, hipStream_t s, uint32_t* rot_same = nullptr);
 
 // include/dmsa_detmath.h evaluated on the device (parity tests): fn 0 sin, 1 cos, 2 acos, 3 atan2(y, x)
 void launch_detmath_eval(int fn, const double* x, const double* y, int64_t n, double* out, hipStream_t s);

@@ -211,7 +211,7 @@ constexpr int kMaxCtrl = 64;  // control poses per window the table kernel keeps
 
 __global__ __launch_bounds__(256) void k_window_pose_tables(const double* __restrict__ ctrl, const double* __restrict__ stamps,
                                                             const double* __restrict__ fh_w, const double* __restrict__ traj_time, int C, int n_t,
-                                                            float* __restrict__ tables, float* __restrict__ tablesT) {
+                                                            float* __restrict__ tables, float* __restrict__ tablesT, uint32_t* __restrict__ rot_same) {
     __shared__ double s_ctrl[kMaxCtrl * 6];
     __shared__ double s_stamp[kMaxCtrl];
     __shared__ double s_w[kMaxCtrl];
@@ -219,7 +219,20 @@ __global__ __launch_bounds__(256) void k_window_pose_tables(const double* __rest
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < C * 6; i += blockDim.x) s_ctrl[i] = ctrl[(size_t)b * C * 6 + i];
     for (int i = threadIdx.x; i < C; i += blockDim.x) s_stamp[i] = stamps[i], s_w[i] = fh_w[i];
-    __syncthreads();
+    if (rot_same != nullptr && blockIdx.x == 0) {
+        // rot_same[b] = 1: every control ROTATION of evaluation b has the bits of evaluation 0's (a forward difference of a translation
+        // parameter), so every dense rotation of its table has them too -- same inputs, same instructions (serial_kernels.hip shares the
+        // rotated coordinates of a member among such evaluations)
+        bool diff = false;
+        for (int i = threadIdx.x; i < C * 3; i += blockDim.x) {
+            const int c = i / 3, a = i - 3 * c;
+            diff = diff || __double_as_longlong(ctrl[(size_t)b * C * 6 + 6 * c + a]) != __double_as_longlong(ctrl[6 * c + a]);
+        }
+        const int any = __syncthreads_or(diff ? 1 : 0);
+        if (threadIdx.x == 0) rot_same[b] = any ? 0u : 1u;
+    } else {
+        __syncthreads();
+    }
     if (threadIdx.x < C) {
         const double* a = &s_ctrl[6 * threadIdx.x];
         d_quat_from_axang(D3{a[0], a[1], a[2]}, &s_quat[4 * threadIdx.x]);
@@ -278,8 +291,18 @@ __global__ __launch_bounds__(256) void k_window_pose_tables(const double* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void k_keyframe_pose_tables(const double* __restrict__ frames, int F, float* __restrict__ tables, float* __restrict__ tablesT) {
+__global__ __launch_bounds__(256) void k_keyframe_pose_tables(const double* __restrict__ frames, int F, float* __restrict__ tables, float* __restrict__ tablesT,
+                                                              uint32_t* __restrict__ rot_same) {
     const int b = blockIdx.y;
+    if (rot_same != nullptr && blockIdx.x == 0) {  // as in k_window_pose_tables: the frame rotations of evaluation b against evaluation 0's
+        bool diff = false;
+        for (int i = threadIdx.x; i < F * 3; i += blockDim.x) {
+            const int c = i / 3, a = i - 3 * c;
+            diff = diff || __double_as_longlong(frames[((size_t)b * F + c) * 6 + a]) != __double_as_longlong(frames[(size_t)c * 6 + a]);
+        }
+        const int any = __syncthreads_or(diff ? 1 : 0);
+        if (threadIdx.x == 0) rot_same[b] = any ? 0u : 1u;
+    }
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > F) return;
     float* out = tables + ((size_t)b * (F + 1) + k) * 12;
@@ -311,11 +334,11 @@ void launch_detmath_eval(int fn, const double* x, const double* y, int64_t n, do
 }
 
 void launch_window_pose_tables(const double* ctrl, const double* stamps, const double* fh_w, const double* traj_time, int B, int C, int n_t,
-                               float* tables, float* tablesT, hipStream_t s) {
-    hipLaunchKernelGGL(k_window_pose_tables, dim3((n_t + 1 + 255) / 256, B), dim3(256), 0, s, ctrl, stamps, fh_w, traj_time, C, n_t, tables, tablesT);
+                               float* tables, float* tablesT, hipStream_t s, uint32_t* rot_same) {
+    hipLaunchKernelGGL(k_window_pose_tables, dim3((n_t + 1 + 255) / 256, B), dim3(256), 0, s, ctrl, stamps, fh_w, traj_time, C, n_t, tables, tablesT, rot_same);
 }
-void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tables, float* tablesT, hipStream_t s) {
-    hipLaunchKernelGGL(k_keyframe_pose_tables, dim3((F + 1 + 255) / 256, B), dim3(256), 0, s, frames, F, tables, tablesT);
+void launch_keyframe_pose_tables(const double* frames, int B, int F, float* tables, float* tablesT, hipStream_t s, uint32_t* rot_same) {
+    hipLaunchKernelGGL(k_keyframe_pose_tables, dim3((F + 1 + 255) / 256, B), dim3(256), 0, s, frames, F, tables, tablesT, rot_same);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -130,7 +130,7 @@ int ensure_E(dmsa_ctx* ctx, int B) {
     HIPCHK(ctx->d_E.ensure((size_t)B * ld * 8));
     return DMSA_OK;
 }
-int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const double* d_extra) {
+int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const double* d_extra, const uint32_t* rot_same) {
     CHK(ensure_E(ctx, B));
     if (ctx->tables_pending) {  // the pose tables of this batch were built on another stream (and k_size_classes did not wait for them)
         if (ctx->tables_dev_sync)
@@ -198,14 +198,16 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
             // latency tier first (with the signal), then the waits in front of the other tiers
             launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
                                     ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree,
-                                    d_sync + SYNC_TIER_FORK, 1);
+                                    d_sync + SYNC_TIER_FORK, 1, rot_same);
             launch_sync_wait(d_sync + SYNC_TIER_FORK, ctx->sync_sig[SYNC_TIER_FORK], ctx->sync_timed_out(), ctx->stream2);
             if (three) launch_sync_wait(d_sync + SYNC_TIER_FORK, ctx->sync_sig[SYNC_TIER_FORK], ctx->sync_timed_out(), ctx->stream3);
             launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
-                                    ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree, nullptr, 6);
+                                    ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree, nullptr, 6,
+                                    rot_same);
         } else {
             launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
-                                    ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree);
+                                    ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree,
+                                    nullptr, 7, rot_same);
         }
         if (dev_sync) {
             launch_sync_signal(d_sync + SYNC_TIER_JOIN, ctx->stream2);
@@ -528,13 +530,13 @@ int pinned_doubles(dmsa_ctx* ctx, size_t count, double** out) {
     ctx->h_pin_next = (ctx->h_pin_next + 1) % kPinSlots;
     return DMSA_OK;
 }
-int device_tables(dmsa_ctx* ctx, int B, const double* d_ctrl, float* tables, float* tablesT, hipStream_t stream) {
+int device_tables(dmsa_ctx* ctx, int B, const double* d_ctrl, float* tables, float* tablesT, hipStream_t stream, uint32_t* rot_same = nullptr) {
     const int np = ctx->loop_model.n;
     if (ctx->model == MODEL_WINDOW)
         launch_window_pose_tables(d_ctrl, ctx->d_stamps.as<double>(), ctx->d_fhw.as<double>(), ctx->d_trajtime.as<double>(), B, np, ctx->rows - 1, tables, tablesT,
-                                  stream);
+                                  stream, rot_same);
     else
-        launch_keyframe_pose_tables(d_ctrl, B, np, tables, tablesT, stream);
+        launch_keyframe_pose_tables(d_ctrl, B, np, tables, tablesT, stream, rot_same);
     HIPCHK(hipGetLastError());
     return DMSA_OK;
 }
@@ -582,6 +584,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
     HIPCHK(ctx->d_tables.ensure((size_t)(P + 1) * ctx->rows * 48));  // never reallocated while kernels read it
     HIPCHK(ctx->d_tablesT.ensure((size_t)(P + 1) * ctx->rows * 48));
     HIPCHK(ctx->d_loop_extra.ensure((size_t)(1 + P + 9) * std::max(a, 1) * 8));
+    HIPCHK(ctx->d_rot_same.ensure((size_t)(1 + P) * 4));
     HIPCHK(ctx->d_loop_iter.ensure(sizeof(LoopFlags) + (size_t)(num_iter + 1) * sizeof(IterResult)));
     HIPCHK(ctx->d_Hp.ensure((size_t)(P + 1) * (P + 1) * 8));
     HIPCHK(ctx->d_sq_out.ensure(16 * 8));
@@ -650,7 +653,9 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             HIPCHK(hipStreamWaitEvent(side, ctx->ev_fork, 0));
         }
         launch_loop_chain(m, 0, S0, S1, d_param, d_step, increment, ctx->d_ctrl.as<double>(), d_extra_jac, d_flags, side);
-        CHK(device_tables(ctx, 1 + P, ctx->d_ctrl.as<double>(), ctx->d_tables.as<float>(), ctx->d_tablesT.as<float>(), side));
+        // with the flags that let the correspondence kernels share the rotated coordinates among the translation differences (serial_kernels.hip)
+        uint32_t* rot_same = ctx->dbg.shared_rotations != 0 ? ctx->d_rot_same.as<uint32_t>() : nullptr;
+        CHK(device_tables(ctx, 1 + P, ctx->d_ctrl.as<double>(), ctx->d_tables.as<float>(), ctx->d_tablesT.as<float>(), side, rot_same));
         ctx->batch = 1 + P, ctx->tablesT_batch = 1 + P;
         if (dev_sync) {  // the main stream picks the tables up in k_size_classes (or, if that kernel is not launched, in run_residuals)
             launch_sync_signal(ctx->sync_counter(SYNC_TABLES), side);
@@ -680,7 +685,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             break;
         }
         ctx->evaluations += 1 + P;
-        CHK(run_residuals(ctx, 1 + P, nullptr, d_extra_jac));
+        CHK(run_residuals(ctx, 1 + P, nullptr, d_extra_jac, rot_same));
         const int rowsE = ctx->M + ctx->extra_rows;
         {
             ScopedTimer tm(ctx, T_NORMAL);

@@ -33,7 +33,8 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
                              const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small,
                              int tree_mode = 1 /* dmsa_debug_options::serial_tree */,
                              uint32_t* start_signal = nullptr /* counter the latency tier adds one to once all its workgroups are placed (loop_kernels.h: launch_sync_wait) */,
-                             int tiers = 7 /* bit 0: latency tier, bit 1: throughput tier, bit 2: short tier */);
+                             int tiers = 7 /* bit 0: latency tier, bit 1: throughput tier, bit 2: short tier */,
+                             const uint32_t* rot_same = nullptr /* [B] from the pose-table kernels: evaluations whose rotations are evaluation 0's */);
 // LDS / shape parameters chosen for a batch of B evaluations (exposed for the bench's roofline notes and the tests)
 struct SerialShape {
     int nsub_long, Bs_long;  // latency tier: evaluation sub-batches per Gaussian, evaluations per sub-batch

@@ -405,7 +405,8 @@ template <int kProd, bool kSepLoader, int kChunk>
 #endif
 __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader ? DMSA_LONG_WAVES : DMSA_MID_WAVES) void k_residuals_chain(
     const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12, const float4* __restrict__ tabT, int B,
-    const uint32_t* __restrict__ order, int Bs, int nsub, int prio, int tree_mode, double* __restrict__ E, int64_t ldE, uint32_t* start_signal) {
+    const uint32_t* __restrict__ order, int Bs, int nsub, int prio, int tree_mode, double* __restrict__ E, int64_t ldE, uint32_t* start_signal,
+    const uint32_t* __restrict__ rot_same) {
     // tree_mode 0: second pass as a chain (the reference's loop, pipelined); 1: parallel second pass, chain only if the exactness test
     // fails; 2: parallel pass computed, then the chain anyway (test hook)
     constexpr int kProducers = kProd;
@@ -449,10 +450,54 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         Rows r2;
         r2.r0 = r2.r1 = r2.r2 = f4{0.0f, 0.0f, 0.0f, 0.0f};
         int r2_row = -1;
-        // every wave takes one contiguous block of the member list (consecutive members mostly share a pose-table row, so a lane
-        // changes rows about once per row of its block instead of once per step); members are fetched two steps ahead
         const int blk = ((n + kWaves - 1) / kWaves + mpl - 1) / mpl * mpl;
         const int jend = min(n, (wave + 1) * blk);
+        // ---- sub-batch of evaluations that share their ROTATIONS with evaluation 0 (forward differences of translation parameters: half
+        // of the Jacobian batch).  ((c0 x + c1 y) + c2 z) + c3 has the same first three terms for all of them: S = (c0 x + c1 y) + c2 z is
+        // computed ONCE per member, lane = member, from evaluation 0's rows, parked in a wave-private kilobyte of the idle ring, and a
+        // step is S + c3 of the lane's own evaluation and the quadratic form: 38 instead of 53 vector instructions per member step for
+        // the same operations on the same operands in the same order.  The flags come from the pose-table kernels, which compare the
+        // control rotations bit for bit -- nothing is assumed about the model (the window with IMU rows never qualifies: its round trip
+        // through the preintegration factors touches relative pose 0 in every evaluation).
+        bool shared_rot = false;
+        if (rot_same != nullptr && b0 > 0) shared_rot = __ballot(lane < nb && rot_same[b0 + lane] == 0u) == 0ull;
+        if (shared_rot) {
+            static_assert((size_t)kWaves * (48 + 64) * 16 <= sizeof(float) * kSlots * kSlotFloats, "second-pass staging does not fit the ring");
+            float4* stage = reinterpret_cast<float4*>(s_q) + kWaves * 48 + wave * 64;  // behind the reduction scratch (kWaves x 64 x 12 bytes)
+            const int CH = (64 / mpl) * mpl, steps = CH / mpl;  // members per chunk: a multiple of the members per step
+            const int wbeg = wave * blk;
+            float tx = 0.0f, ty = 0.0f, tz = 0.0f;  // translation column of the lane's evaluation at row t_row
+            int t_row = -1;
+            auto fetch_member = [&](int cs) { return memb[off0 + min(cs + lane, n - 1)]; };
+            float4 pre = fetch_member(wbeg);
+            for (int cs = wbeg; cs < jend; cs += CH) {
+                const float4 m = pre;
+                pre = fetch_member(cs + CH);
+                {
+                    const float4* t0 = tabT + (size_t)__float_as_int(m.w) * B * 3;  // evaluation 0 of the batch
+                    const float4 q0 = t0[0], q1 = t0[1], q2 = t0[2];
+                    stage[lane] = float4{(q0.x * m.x + q0.y * m.y) + q0.z * m.z, (q1.x * m.x + q1.y * m.y) + q1.z * m.z, (q2.x * m.x + q2.y * m.y) + q2.z * m.z, m.w};
+                }
+                __builtin_amdgcn_wave_barrier();  // (compiler only) one wave's LDS instructions execute in order; the lanes read each other's members
+                for (int st = 0; st < steps; ++st) {
+                    const int jl = st * mpl + ms2, jj = cs + jl;
+                    if (lane_on2 && jj < jend) {
+                        const float4 v = stage[jl];
+                        const int row = __float_as_int(v.w);
+                        if (row != t_row) {
+                            const float* tr = reinterpret_cast<const float*>(tabT + ((size_t)row * B + bcol2) * 3);
+                            tx = tr[3], ty = tr[7], tz = tr[11], t_row = row;
+                        }
+                        const float t = mahalanobis_v(I2, v.x + tx, v.y + ty, v.z + tz, mx2, my2, mz2);
+                        part += (double)t;
+                        key = min(key, __float_as_int(t));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // every wave takes one contiguous block of the member list (consecutive members mostly share a pose-table row, so a lane
+        // changes rows about once per row of its block instead of once per step); members are fetched two steps ahead
         int j = wave * blk + ms2;
         auto term = [&](const float4 m, int jj) {
             if (lane_on2 && jj < jend) {
@@ -470,7 +515,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         // register it replaces, so there is no rotation copy -- a copy of a freshly loaded register makes the step wait for its own load
         auto fetch = [&](int jj) { return memb[off0 + min(jj, n - 1)]; };
         float4 m_a = fetch(j), m_b = fetch(j + mpl), m_c = fetch(j + 2 * mpl), m_d = fetch(j + 3 * mpl);
-        for (int j0 = wave * blk; j0 < jend; j0 += 4 * mpl) {
+        for (int j0 = shared_rot ? jend : wave * blk; j0 < jend; j0 += 4 * mpl) {
             term(m_a, j), m_a = fetch(j + 4 * mpl);
             term(m_b, j + mpl), m_b = fetch(j + 5 * mpl);
             term(m_c, j + 2 * mpl), m_c = fetch(j + 6 * mpl);
@@ -761,7 +806,7 @@ void launch_transpose_tables(const float* tables, int rows, int B, float* tables
 }
 void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tablesT, int B, const uint32_t* order,
                              const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small, int tree_mode,
-                             uint32_t* start_signal, int tiers) {
+                             uint32_t* start_signal, int tiers, const uint32_t* rot_same) {
     if (B <= 0) return;
     const SerialShape sh = serial_shape(B);
     const float4* info = reinterpret_cast<const float4*>(info12);
@@ -770,10 +815,10 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
     // latency tier first (its longest chain bounds the batch), blocks in descending size; the other tiers fill the chip around it
     if (n_long > 0 && (tiers & 1))
         hipLaunchKernelGGL((k_residuals_chain<8, true, 64>), dim3((unsigned)n_long * sh.nsub_long), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
-                           sh.Bs_long, sh.nsub_long, 2, tree_mode, E, ldE, start_signal);
+                           sh.Bs_long, sh.nsub_long, 2, tree_mode, E, ldE, start_signal, rot_same);
     if (n_mid > 0 && (tiers & 2))
         hipLaunchKernelGGL((k_residuals_chain<4, false, 32>), dim3((unsigned)n_mid * sh.nsub), dim3(64 * 5), 0, s_rest, memb_local, seg_off, info, tabT, B,
-                           order + n_long, sh.Bs, sh.nsub, 0, tree_mode, E, ldE, (uint32_t*)nullptr);
+                           order + n_long, sh.Bs, sh.nsub, 0, tree_mode, E, ldE, (uint32_t*)nullptr, rot_same);
     if (sc.n_small > 0 && (tiers & 4)) {
         const int items = sc.n_small * sh.nsub_small;
         const int per_block = 4 * (64 / sh.lanes);

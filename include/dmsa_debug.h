@@ -40,6 +40,8 @@ typedef struct dmsa_debug_options {
                                      single-workgroup k_leaf_scan                                                                         */
     int32_t device_sync;     /* 1   fork / join of the three tier streams through counters in device memory (one-wave signal / wait
                                      kernels); 0: hipEventRecord / hipStreamWaitEvent                                                   */
+    int32_t shared_rotations; /* 1  forward differences of translation parameters share the rotated member coordinates of evaluation 0 in
+                                     the second pass of the chain tiers (serial_kernels.hip); 0: every evaluation transforms on its own     */
 } dmsa_debug_options;
 
 void dmsa_default_debug_options(dmsa_debug_options* o);

@@ -93,6 +93,7 @@ def test_early_exits_match_the_oracle_and_the_host_driven_loop(hip, orc, case):
     # the stream dependencies as HIP events instead of device counters (csrc/dev_sync.h), and the single-workgroup slot scan
     _same(dev, _run(hip, prob, s, debug={"device_sync": 0, "fused_leaf_scan": 0}))
     _same(dev, _run(hip, prob, s, debug={"device_loop": 0, "device_sync": 0}))
+    _same(dev, _run(hip, prob, s, debug={"shared_rotations": 0}))  # every evaluation of the Jacobian batch transforms its members itself
     if case == "window_runs_to_a_stop":
         assert dev[1].stop_reason != 0 and dev[1].iterations < s.num_iter  # the case really exercises a device-side stop
 
