@@ -254,7 +254,8 @@ int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
         int32_t timed_out[3] = {0, 0, 0};
         if (hipMemcpy(timed_out, ctx->sync_timed_out(), sizeof(timed_out), hipMemcpyDeviceToHost) != hipSuccess || timed_out[0] != 0) {
             ctx->err = "a device-side stream dependency timed out (launch_sync_wait): waited for " + std::to_string(timed_out[1]) + ", counter at " +
-                       std::to_string(timed_out[2]);
+                       std::to_string(timed_out[2]) +
+                       " -- a tool that serialises kernels across queues (hardware counter collection)? run with DMSA_DEBUG=device_sync=0";
             // start over: nothing is in flight after the failed call's final synchronisation
             (void)hipDeviceSynchronize();
             (void)hipMemset(ctx->d_sync.p, 0, SYNC_SLOTS * 4);

@@ -11,8 +11,11 @@ timeout 120 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $R
 python $R/scripts/iteration_timeline.py $(find $OUT/stats -name "*results.db" | head -1) 16 > $OUT/iteration_timeline.txt 2> $OUT/timeline.err
 DMSA_DEBUG=host_timeline=1 timeout 100 python $R/bench.py --steps 12 --warmup 3 --cpu-iters 0 --keyframe-steps 0 > /dev/null 2> $OUT/host_timeline.err < /dev/null
 KRE="${KRE:-k_residuals_chain|k_residuals_small}"
+# Counter collection serialises kernels ACROSS queues, in an order of its own: a one-wave wait of the device-side stream dependencies
+# (csrc/dev_sync.h) can then get the chip before the kernel that signals it, and gives up after seconds (DMSA_ERR_HIP, no counters).
+# The counters are those of the correspondence kernels, which do not care how the streams are ordered: events for these passes.
 run() {
-  timeout 120 rocprofv3 --kernel-trace --pmc $2 --kernel-include-regex "$KRE" --output-format csv -d $OUT/$1 -o $1 -- python $R/bench.py --steps 3 --warmup 1 --cpu-iters 0 --keyframe-steps 0 > $OUT/$1.log 2>&1 < /dev/null
+  DMSA_DEBUG=device_sync=0 timeout 120 rocprofv3 --kernel-trace --pmc $2 --kernel-include-regex "$KRE" --output-format csv -d $OUT/$1 -o $1 -- python $R/bench.py --steps 3 --warmup 1 --cpu-iters 0 --keyframe-steps 0 > $OUT/$1.log 2>&1 < /dev/null
 }
 run p1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 run p2 "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"
