@@ -8,7 +8,7 @@
 // Rules that make this deadlock-free: (1) every signal is ENQUEUED before the wait that needs it -- hardware queues are FIFO, so a
 // wait can only ever sit in front of packets that were enqueued after its signal, also when streams share a hardware queue;
 // (2) waits are single waves (a spinning grid could occupy the chip the producer needs); (3) every wait is bounded: it gives up after
-// seconds, flags the context, and the host returns DMSA_ERR_HIP -- never a hung GPU.
+// about ten seconds, flags the context, and the host returns DMSA_ERR_HIP -- never a hung GPU.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -44,13 +44,13 @@ __device__ __forceinline__ void dev_sync_signal(uint32_t* counter) {
 }
 __device__ __forceinline__ void dev_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out) {
     uint32_t v = 0;
-    for (int spin = 0; spin < (1 << 22); ++spin) {  // seconds
+    for (int spin = 0; spin < (1 << 23); ++spin) {  // ~10 s: three orders of magnitude above the longest legitimate wait (one iteration)
         v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int32_t)(v - target) >= 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             return;
         }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(spin < 4096 ? 1 : 8);  // poll tightly at first (a join is usually microseconds away), then back off
     }
     if (timed_out != nullptr) timed_out[0] = 1, timed_out[1] = (int32_t)target, timed_out[2] = (int32_t)v;
 }
