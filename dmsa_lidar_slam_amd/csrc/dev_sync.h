@@ -50,7 +50,10 @@ __device__ __forceinline__ void dev_sync_wait(const uint32_t* counter, uint32_t 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             return;
         }
-        __builtin_amdgcn_s_sleep(spin < 4096 ? 1 : 8);  // poll tightly at first (a join is usually microseconds away), then back off
+        if (spin < 4096)  // poll tightly at first (a join is usually microseconds away), then back off
+            __builtin_amdgcn_s_sleep(1);
+        else
+            __builtin_amdgcn_s_sleep(8);
     }
     if (timed_out != nullptr) timed_out[0] = 1, timed_out[1] = (int32_t)target, timed_out[2] = (int32_t)v;
 }
