@@ -324,7 +324,7 @@ def main():
             },
             "roofline": {
                 "kernel": ("correspondence kernels k_residuals_tiles + k_residuals_big" if args.fast_sums else
-                           "reference-order correspondence kernels (k_residuals_chain<8,true,64> + k_residuals_chain<4,false,32> + k_residuals_small, "
+                           "reference-order correspondence kernels (k_residuals_chain<8,true,128> + k_residuals_chain<4,false,32> + k_residuals_small, "
                            "three streams, fork / join by device counters, one HIP-event pair around the batch)") + ", B evaluations per launch",
                 "bound": "hbm",
                 # the brief's figure: per-unit algorithmic bytes x units per launch / launch time

@@ -388,10 +388,15 @@ constexpr int kSlots = 3;
 __device__ unsigned long long g_fallback_sums;  // (Gaussian, sub-batch) workgroups that failed the test (tree_mode 1) since the last reset
 __device__ __forceinline__ uint32_t hi_word(double x) { return (uint32_t)(__double_as_longlong(x) >> 32); }
 
+// members per phase of the latency tier: 128 (two LDS-DMA instructions per chunk, 82 KB of LDS, one workgroup per CU -- there are fewer
+// latency-tier workgroups than CUs) halves the barriers per member of the 64 the ring started with: 11 -> 9.8 cycles per member
+#ifndef DMSA_LONG_CHUNK
+#define DMSA_LONG_CHUNK 128
+#endif
 constexpr int kBL = 16;  // evaluation stride of the LDS ring layout (compile time: every ds_read of the chainer gets an immediate offset)
 
 // kProd producer waves; kSepLoader: one more wave that only feeds the member ring (otherwise the last producer does that too).
-//   <8, true, 64>  latency tier (the longest Gaussians): with Bs <= 8 every producer has ONE step per phase, so a phase lasts as
+//   <8, true, 128> latency tier (the longest Gaussians): with Bs <= 8 every producer has ONE step per phase, so a phase lasts as
 //              long as its chain segment even for the producer wave that loses the issue arbitration on the chainer's SIMD
 //   <4, false, 32> throughput tier: 5 waves and 20 KB of LDS per workgroup (32-member chunks), six workgroups per CU; phases are
 //              producer-bound, but the resident waves spend most of their time issuing instead of waiting at a barrier
@@ -674,19 +679,30 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     // end of the Gaussian hold copies of its last member (clamped addresses): whatever a lane computes from them is never read.
     const unsigned lds_m = (unsigned)(uintptr_t)&s_m[0][0];
     auto dma = [&](int P) {  // members of the chunk consumed in global phase P (pass 1: P = p, pass 2: P = nphases + p)
-        if (loader && lane < kChunk) {
+        if (loader) {
             const int c = P < nphases ? P : P - nphases;
-            const float4* src = memb + off0 + min(c * kChunk + lane, last);
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_m + (unsigned)(P & 3) * (kChunk * 16));
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(src), "s"(dst)
-                         : "memory");
+#pragma unroll
+            for (int hh = 0; hh < kChunk / 64 + (kChunk % 64 ? 1 : 0); ++hh) {  // 64 members (lanes) per LDS-DMA instruction
+                if (hh * 64 + lane < kChunk) {
+                    const float4* src = memb + off0 + min(c * kChunk + hh * 64 + lane, last);
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_m + (unsigned)(P & 3) * (kChunk * 16) + (unsigned)hh * 1024u);
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(src), "s"(dst)
+                                 : "memory");
+                }
+            }
         }
     };
-    auto landed = [&]() {  // every DMA but the newest has landed (one DMA is issued per phase, always)
-        if (loader) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    constexpr int kDmaPerChunk = kChunk / 64 + (kChunk % 64 ? 1 : 0);
+    auto landed = [&]() {  // every DMA but the newest chunk's has landed (one chunk is issued per phase, always)
+        if (loader) {
+            if constexpr (kDmaPerChunk == 1)
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
     };
     // the pair (jl, jl + 1) of ring slot `slot`, coordinates as member pairs: ds_read2_b32 with dword offsets (k, k + 4)
     struct Pair {
@@ -814,7 +830,7 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
     const int n_long = sc.n_long, n_mid = sc.n_chain - sc.n_long;
     // latency tier first (its longest chain bounds the batch), blocks in descending size; the other tiers fill the chip around it
     if (n_long > 0 && (tiers & 1))
-        hipLaunchKernelGGL((k_residuals_chain<8, true, 64>), dim3((unsigned)n_long * sh.nsub_long), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
+        hipLaunchKernelGGL((k_residuals_chain<8, true, DMSA_LONG_CHUNK>), dim3((unsigned)n_long * sh.nsub_long), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
                            sh.Bs_long, sh.nsub_long, 2, tree_mode, E, ldE, start_signal, rot_same);
     if (n_mid > 0 && (tiers & 2))
         hipLaunchKernelGGL((k_residuals_chain<4, false, 32>), dim3((unsigned)n_mid * sh.nsub), dim3(64 * 5), 0, s_rest, memb_local, seg_off, info, tabT, B,
