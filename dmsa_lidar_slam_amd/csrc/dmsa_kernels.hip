@@ -1647,7 +1647,8 @@ __global__ __launch_bounds__(256) void k_gauss_fit_finish(const int32_t* __restr
     for (int i = 0; i < 12; ++i)
         if (i != 9) dst[i] = o[i];  // slot 9 is the rebalancing weight (k_size_classes / k_rebalancing_weights write it)
 }
-int fit_small_max_blocks() { return 4; }  // short class: Gaussians up to serial_small_threshold() <= 256 members
+constexpr int kFitShortBlocks = 4;  // short class: Gaussians up to serial_small_threshold() <= 256 members, one wave each
+int fit_small_max_blocks() { return kFitShortBlocks; }
 // All three classes -- and the rebalancing weights -- in ONE launch of 1024-thread workgroups: a workgroup is one long Gaussian (16 waves),
 // four middle ones (4 waves each) or sixteen short ones (1 wave each); the last workgroup computes the weights.  Same block sums in the
 // same order as k_gauss_fit_tree; what changes is that nothing has to be forked to a second stream and joined again (a cross-stream
@@ -1740,7 +1741,7 @@ struct FitLaunch {
 __global__ __launch_bounds__(1024) void k_gauss_fit_all(const float4* __restrict__ memb_local, const int32_t* __restrict__ seg_off, const float4* __restrict__ table0,
                                                         const uint32_t* __restrict__ order, const int32_t* __restrict__ sc, FitLaunch fl, double* __restrict__ sums,
                                                         GaussCounts* __restrict__ counts, float* __restrict__ info12) {
-    __shared__ double s_blk[256][6];  // class 0: [256][6]; class 1: 4 x [64][6]; class 2: 16 x [4][6]
+    __shared__ double s_blk[256][6];  // class 0: [256][6]; class 1: 4 x [64][6]; class 2: 16 x [kFitShortBlocks][6]
     __shared__ double s_tot[16][6];
     __shared__ float s_mean[16][3];
     __shared__ int s_rounds;
@@ -1765,7 +1766,8 @@ __global__ __launch_bounds__(1024) void k_gauss_fit_all(const float4* __restrict
     bx -= fl.wg[1];
     if (bx < fl.wg[2]) {
         const int grp = tid >> 6;
-        fit_tree_group<1, 4>(memb_local, seg_off, table0, pick(2, bx * 16 + grp), tid & 63, s_blk + grp * 4, s_tot[grp], s_mean[grp], &s_rounds, sums);
+        fit_tree_group<1, kFitShortBlocks>(memb_local, seg_off, table0, pick(2, bx * 16 + grp), tid & 63, s_blk + grp * kFitShortBlocks, s_tot[grp], s_mean[grp],
+                                           &s_rounds, sums);
         return;
     }
     rebalancing_weights_mirror_body(seg_off, counts, info12, &s_blk[0][0], &s_tot[0][0], &s_mean[0][0]);

@@ -31,7 +31,7 @@ namespace dmsa {
 
 namespace {
 
-constexpr int kSmallMax = 256;    // upper limit of the small-Gaussian threshold (histogram size of k_size_classes)
+constexpr int kSmallMax = 256;    // upper limit of the small-Gaussian threshold (histogram size of k_size_classes; = the 4 blocks of the fit's short class)
 
 __device__ __forceinline__ float3 apply_row3s(const float4 r0, const float4 r1, const float4 r2, const float x, const float y, const float z) {
     float3 g;  // Matrix4f * Vector4f, column-wise like Eigen's packet product: ((c0*x + c1*y) + c2*z) + c3
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(1024) void k_size_classes(const int32_t* __restrict
     }
     atomicMax(&s_max, mx);
     __syncthreads();
-    if (threadIdx.x < 64) {  // exclusive prefix over the 64 chain bins, then over the ns <= 256 short bins (four per lane): one wave, two scans
+    if (threadIdx.x < 64) {  // exclusive prefix over the 64 chain bins, then over the ns <= 256 short bins (kSmallMax / 64 per lane): one wave, two scans
         const int lane = threadIdx.x;
         auto scan = [&](int v) {
 #pragma unroll
@@ -231,14 +231,15 @@ __global__ __launch_bounds__(1024) void k_size_classes(const int32_t* __restrict
         h_c[lane] = incl - c;
         const int n_chain = __shfl(incl, 63);
         const int n_long = __shfl(incl, 63 - 2 * long_log2);  // bins 0 .. 63 - 2 * long_log2 hold n >= 2^long_log2
-        int v[4], t = 0;
+        constexpr int kBinsPerLane = kSmallMax / 64;
+        int v[kBinsPerLane], t = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = 4 * lane + u < ns ? h_s[4 * lane + u] : 0, t += v[u];
+        for (int u = 0; u < kBinsPerLane; ++u) v[u] = kBinsPerLane * lane + u < ns ? h_s[kBinsPerLane * lane + u] : 0, t += v[u];
         const int ti = scan(t);
         int pos = n_chain + ti - t;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (4 * lane + u < ns) h_s[4 * lane + u] = pos;
+        for (int u = 0; u < kBinsPerLane; ++u) {
+            if (kBinsPerLane * lane + u < ns) h_s[kBinsPerLane * lane + u] = pos;
             pos += v[u];
         }
         const int n_small = __shfl(ti, 63);
@@ -787,7 +788,10 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-int serial_small_threshold() { return 128; }  // members; Gaussians up to this size go to the lane-per-evaluation kernel
+// members; Gaussians up to this size go to the lane-per-evaluation kernel, which spends fewer instructions per member than the chain
+// tiers (no ring, no barriers) as long as its waves stay short: measured 96 / 128 / 192 / 256 / 384 / 512 -> 1242 / 1256 / 1267 / 1272 /
+// 1241 / 1201 it/s on the bench window (128 until the end of round 3)
+int serial_small_threshold() { return 256; }
 static int serial_long_log2() { return 12; }  // Gaussians with >= 2^12 members go to the latency tier
 unsigned long long serial_fallback_sums(bool reset) {
     unsigned long long v = 0;
