@@ -167,6 +167,26 @@ int upload_common(dmsa_ctx* ctx) {
 }
 
 
+void enqueue_wait(dmsa_ctx* ctx, int slot, hipStream_t stream) {
+    ctx->wait_seq += 1;
+    uint32_t target = ctx->sync_sig[slot];
+    int spins = 1 << 23;
+    if (ctx->dbg.sync_fault > 0 && ctx->wait_seq == ctx->dbg.sync_fault) target += 1, spins = 1 << 12;  // test hook: a signal that never comes
+    launch_sync_wait(ctx->sync_counter(slot), target, ctx->sync_timed_out(), stream, spins);
+}
+bool sync_wait_timed_out(dmsa_ctx* ctx, std::string* what) {
+    if (!ctx->d_sync.p) return false;
+    int32_t t[3] = {0, 0, 0};
+    const bool read = hipDeviceSynchronize() == hipSuccess && hipMemcpy(t, ctx->sync_timed_out(), sizeof(t), hipMemcpyDeviceToHost) == hipSuccess;
+    if (read && t[0] == 0) return false;
+    if (what) *what = read ? "waited for " + std::to_string(t[1]) + ", counter at " + std::to_string(t[2]) : std::string("flag unreadable");
+    // start over: nothing is in flight after the synchronisation above
+    (void)hipMemset(ctx->d_sync.p, 0, SYNC_SLOTS * 4);
+    (void)hipDeviceSynchronize();
+    for (uint32_t& v : ctx->sync_sig) v = 0;
+    ctx->tables_pending = false;
+    return true;
+}
 void write_back_poses(const PoseChain& c, double* rel_o, double* rel_t) {
     std::copy(c.rel_o.begin(), c.rel_o.end(), rel_o);
     std::copy(c.rel_t.begin(), c.rel_t.end(), rel_t);
@@ -179,6 +199,7 @@ void dmsa_default_debug_options(dmsa_debug_options* o) {
     if (!o) return;
     o->device_loop = 1, o->dual_stream = 1, o->serial_streams = 3, o->merge_sort = -1, o->key_compress = 1, o->fused_segments = 1, o->sort_prehist = 0;
     o->library_sort = 0, o->overlap_batch = 1, o->serial_tree = 1, o->host_threads = 16, o->solve_threads = 12, o->host_timeline = 0, o->trace_time = 0, o->fused_leaf_scan = 1, o->device_sync = 1, o->shared_rotations = 1;
+    o->eval_skip = 1, o->sync_fault = 0, o->speculation_fault = 0;
 }
 // DMSA_DEBUG="name=value,name=value": the one environment variable of the library (include/dmsa_debug.h)
 static void apply_debug_env(dmsa_debug_options* o) {
@@ -191,7 +212,7 @@ static void apply_debug_env(dmsa_debug_options* o) {
                   {"key_compress", &o->key_compress},   {"fused_segments", &o->fused_segments}, {"sort_prehist", &o->sort_prehist}, {"library_sort", &o->library_sort},
                   {"overlap_batch", &o->overlap_batch}, {"serial_tree", &o->serial_tree},   {"host_threads", &o->host_threads},     {"solve_threads", &o->solve_threads},
                   {"host_timeline", &o->host_timeline}, {"trace_time", &o->trace_time},     {"fused_leaf_scan", &o->fused_leaf_scan}, {"device_sync", &o->device_sync},
-                  {"shared_rotations", &o->shared_rotations}};
+                  {"shared_rotations", &o->shared_rotations}, {"eval_skip", &o->eval_skip}, {"sync_fault", &o->sync_fault}, {"speculation_fault", &o->speculation_fault}};
     std::string text(e);
     size_t at = 0;
     while (at < text.size()) {
@@ -268,6 +289,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_rb) (void)hipHostFree(ctx->h_rb);
     if (ctx->h_Hp) (void)hipHostFree(ctx->h_Hp);
+    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
     DevBuf* bufs[] = {&ctx->d_local, &ctx->d_nlocal, &ctx->d_ring, &ctx->d_global, &ctx->d_nglobal, &ctx->d_tables, &ctx->d_ctrl, &ctx->d_stamps,
                       &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
                       &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],

@@ -42,9 +42,10 @@ __device__ __forceinline__ void dev_sync_signal(uint32_t* counter) {
     __threadfence();  // release at agent scope: what this kernel wrote so far is visible to every later reader
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void dev_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out) {
+constexpr int kSyncMaxSpins = 1 << 23;  // ~10 s: three orders of magnitude above the longest legitimate wait (one iteration)
+__device__ __forceinline__ void dev_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, int max_spins = kSyncMaxSpins) {
     uint32_t v = 0;
-    for (int spin = 0; spin < (1 << 23); ++spin) {  // ~10 s: three orders of magnitude above the longest legitimate wait (one iteration)
+    for (int spin = 0; spin < max_spins; ++spin) {
         v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int32_t)(v - target) >= 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -71,6 +72,6 @@ __device__ __forceinline__ void dev_sync_leave(const DevSync& sy) {
 
 // one-wave kernels for dependencies no existing kernel can carry (loop_kernels.hip)
 void launch_sync_signal(uint32_t* counter, hipStream_t s);
-void launch_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, hipStream_t s);
+void launch_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, hipStream_t s, int max_spins = 1 << 23);
 
 }  // namespace dmsa

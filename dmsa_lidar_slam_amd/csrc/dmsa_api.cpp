@@ -120,10 +120,23 @@ int dmsa_transform_points(dmsa_ctx* ctx, int32_t b, float* xyz_out) {
     return DMSA_OK;
 }
 
+// stage-level calls enqueue device-side waits as well: a wait that gave up fails the call (and leaves clean counters behind); only the whole
+// calls (optimize) start over by themselves
+static int stage_sync_check(dmsa_ctx* ctx, int rc) {
+    std::string what;
+    if (ctx->dbg.device_sync != 0 && sync_wait_timed_out(ctx, &what)) {
+        ctx->err = "a device-side stream dependency timed out (" + what + "): a tool that serialises kernels across queues (hardware counter collection)? "
+                   "run with DMSA_DEBUG=device_sync=0" + (rc == DMSA_OK ? std::string() : " | " + ctx->err);
+        return DMSA_ERR_HIP;
+    }
+    return rc;
+}
 int dmsa_build_gaussians(dmsa_ctx* ctx, const dmsa_settings* s, int32_t* M_out, int64_t* Mm_out) {
     if (!ctx || ctx->model == MODEL_NONE || !s) return DMSA_ERR_INVALID;
     CHK(set_device(ctx));
-    CHK(build_gaussians(ctx, *s));
+    ctx->wait_seq = 0, ctx->voxel_calls = 0;
+    const int rc = build_gaussians(ctx, *s);
+    CHK(stage_sync_check(ctx, rc));
     if (M_out) *M_out = ctx->M;
     if (Mm_out) *Mm_out = ctx->Mm;
     return DMSA_OK;
@@ -132,7 +145,9 @@ int dmsa_build_gaussians(dmsa_ctx* ctx, const dmsa_settings* s, int32_t* M_out, 
 int dmsa_eval_residuals(dmsa_ctx* ctx, double* e_out) {
     if (!ctx || ctx->model == MODEL_NONE || !ctx->gaussians_valid || ctx->batch <= 0 || ctx->M <= 0) return DMSA_ERR_INVALID;
     CHK(set_device(ctx));
-    CHK(run_residuals(ctx, ctx->batch, nullptr));
+    ctx->wait_seq = 0;
+    const int rc = run_residuals(ctx, ctx->batch, nullptr);
+    CHK(stage_sync_check(ctx, rc));
     if (e_out) {
         HIPCHK(hipMemcpy2DAsync(e_out, (size_t)ctx->M * 8, ctx->d_E.p, (size_t)ctx->ldE * 8, (size_t)ctx->M * 8, (size_t)ctx->batch, hipMemcpyDeviceToHost,
                                 ctx->stream));

@@ -255,6 +255,10 @@ struct dmsa_ctx {
     DevBuf d_sync;         // counters of the device-side stream dependencies (dev_sync.h: SyncSlot), zeroed when the context is created
     uint32_t sync_sig[SYNC_SLOTS] = {};  // signals enqueued so far per slot = the value a wait enqueued now has to see
     bool tables_dev_sync = false;        // tables_pending is to be resolved through SYNC_TABLES, not ev_tables
+    int wait_seq = 0;                    // waits enqueued by the current whole call (debug switch sync_fault withholds the signal of one of them)
+    int voxel_calls = 0;                 // voxelisations of the current whole call (debug switch speculation_fault plants a wrong guess in one of them)
+    int sync_retries = 0, speculation_retries = 0;  // since the context was created: calls re-run with events after a wait timed out; voxelisations re-run after a wrong guess
+    DevBuf d_static_keep;                // the static points as uploaded (a call that has to start over restores them: centralize / decentralize is no exact round trip)
     uint32_t* sync_counter(int slot) const { return d_sync.as<uint32_t>() + slot; }
     int32_t* sync_timed_out() const { return d_sync.as<int32_t>() + SYNC_TIMED_OUT; }
     IterResult* h_results = nullptr;  // pinned
@@ -330,6 +334,11 @@ struct ScopedTimer {
 void drain_timers(dmsa_ctx* ctx);
 hipError_t sync_spin(hipStream_t stream);
 int set_device(dmsa_ctx* ctx);
+// a one-wave wait on `stream` for everything signalled on `slot` so far (dev_sync.h)
+void enqueue_wait(dmsa_ctx* ctx, int slot, hipStream_t stream);
+// Did a device-side wait of the call that just ended give up?  Synchronises the device, clears the flag and the counters (whatever the
+// call's own status was: a stale flag or a half-counted signal must not reach the next call).  `what` receives the counter values.
+bool sync_wait_timed_out(dmsa_ctx* ctx, std::string* what);
 int num_params(const dmsa_ctx* ctx);
 PoseChain& chain(dmsa_ctx* ctx);
 int num_extra_rows(const dmsa_ctx* ctx);

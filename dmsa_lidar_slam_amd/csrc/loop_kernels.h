@@ -41,6 +41,8 @@ struct LoopFlags {
     int32_t pad[2];
 };
 
+// the chain kernels hold one chain state in LDS: false when the set has too many poses for that (optimize() then drives the loop from the host)
+bool loop_chain_fits(const LoopModel& m);
 // iteration start (:72-75): paramVec = getPoseParameters(); window model: relative2global; ctrl0 = global poses (n x 6: axis-angle | translation)
 void launch_loop_begin(const LoopModel& m, double* state0, double* paramVec, double* ctrl0, LoopFlags* flags, hipStream_t s,
                        uint32_t* state_ready = nullptr /* dev_sync.h: signalled when the state of the iteration start is in place */);

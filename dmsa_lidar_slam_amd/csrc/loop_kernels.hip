@@ -808,12 +808,25 @@ __global__ __launch_bounds__(kWave) void k_loop_finish(const LoopModel m, const 
 
 }  // namespace
 
+// The chain kernels keep one chain state (30 n + 2 P + rows doubles) in dynamic LDS.  Up to 64 KB that needs nothing; beyond, the limit of
+// the three kernels is raised once (gfx950: 160 KB per workgroup), and a set that does not fit even then (more than ~470 keyframes) is
+// left to the host-driven loop by optimize() -- loop_chain_fits() is what it asks.
+constexpr size_t kChainLdsMax = 160 * 1024 - 256;
+bool loop_chain_fits(const LoopModel& m) { return chain_lds_bytes(m) <= kChainLdsMax; }
+static void chain_lds_allow(size_t bytes) {
+    if (bytes <= 64 * 1024) return;  // (per launch: the attribute belongs to the current device, and sets this large are rare)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_loop_begin), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsMax);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_loop_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsMax);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_loop_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsMax);
+}
 void launch_loop_begin(const LoopModel& m, double* state0, double* paramVec, double* ctrl0, LoopFlags* flags, hipStream_t s, uint32_t* state_ready) {
+    chain_lds_allow(chain_lds_bytes(m));
     hipLaunchKernelGGL(k_loop_begin, dim3(1), dim3(kWave), chain_lds_bytes(m), s, m, state0, paramVec, ctrl0, flags, state_ready);
 }
 void launch_loop_chain(const LoopModel& m, int mode, const double* state_in, double* state_out, const double* paramVec, const double* step, double increment,
                        double* ctrl, double* extra, const LoopFlags* flags, hipStream_t s) {
     const int B = mode == 0 ? 1 + m.P : 9;
+    chain_lds_allow(chain_lds_bytes(m));
     hipLaunchKernelGGL(k_loop_chain, dim3(B), dim3(kWave), chain_lds_bytes(m), s, m, mode, state_in, state_out, paramVec, step, increment, ctrl, extra, flags);
 }
 void launch_loop_scatter_extra(const double* extra, int B, int a, double* E, int64_t ldE, int M, hipStream_t s) {
@@ -856,12 +869,12 @@ void launch_loop_lm_panels(const double* Hp, int P, double lambda, double alpha,
 __global__ __launch_bounds__(64) void k_sync_signal(uint32_t* counter) {
     if (threadIdx.x == 0) dev_sync_signal(counter);
 }
-__global__ __launch_bounds__(64) void k_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out) {
-    if (threadIdx.x == 0) dev_sync_wait(counter, target, timed_out);
+__global__ __launch_bounds__(64) void k_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, int max_spins) {
+    if (threadIdx.x == 0) dev_sync_wait(counter, target, timed_out, max_spins);
 }
 void launch_sync_signal(uint32_t* counter, hipStream_t s) { hipLaunchKernelGGL(k_sync_signal, dim3(1), dim3(64), 0, s, counter); }
-void launch_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_sync_wait, dim3(1), dim3(64), 0, s, counter, target, timed_out);
+void launch_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, hipStream_t s, int max_spins) {
+    hipLaunchKernelGGL(k_sync_wait, dim3(1), dim3(64), 0, s, counter, target, timed_out, max_spins);
 }
 void launch_loop_step_finish(int P, double max_step, double* step, LoopFlags* flags, hipStream_t s) {
     hipLaunchKernelGGL(k_loop_step_finish, dim3(1), dim3(64), 0, s, P, max_step, step, flags);
@@ -869,6 +882,7 @@ void launch_loop_step_finish(int P, double max_step, double* step, LoopFlags* fl
 void launch_loop_finish(const LoopModel& m, const double* state_jac, const double* state_trial, double* state0, double* paramVec, const double* step,
                         const double* error0, const double* trial_errs, int trial_nsplit, int fixed_iters, double epsilon, IterResult* result, LoopFlags* flags,
                         double* ctrl0, int chain_next, hipStream_t s, uint32_t* state_ready) {
+    chain_lds_allow(chain_lds_bytes(m));
     hipLaunchKernelGGL(k_loop_finish, dim3(1), dim3(kWave), chain_lds_bytes(m), s, m, state_jac, state_trial, state0, paramVec, step, error0, trial_errs,
                        trial_nsplit, fixed_iters, epsilon, result, flags, ctrl0, chain_next, state_ready);
 }

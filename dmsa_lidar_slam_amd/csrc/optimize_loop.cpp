@@ -8,7 +8,7 @@ int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs, hipStre
     if (stream == nullptr) stream = ctx->stream;
     if (ctx->tables_pending && stream == ctx->stream) {  // an earlier batch's tables may still be in flight on the second stream
         if (ctx->tables_dev_sync)
-            launch_sync_wait(ctx->sync_counter(SYNC_TABLES), ctx->sync_sig[SYNC_TABLES], ctx->sync_timed_out(), ctx->stream);
+            enqueue_wait(ctx, SYNC_TABLES, ctx->stream);
         else
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
         ctx->tables_pending = false;
@@ -52,7 +52,6 @@ int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs, hipStre
         if (globs.size() > ctx->h_pin_slot) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
             if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
-    if (ctx->h_results) (void)hipHostFree(ctx->h_results);
             ctx->h_pin = nullptr;
             ctx->h_pin_slot = globs.size() + globs.size() / 2 + 64;
             HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), ctx->h_pin_slot * kPinSlots * sizeof(double), hipHostMallocDefault));
@@ -134,7 +133,7 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
     CHK(ensure_E(ctx, B));
     if (ctx->tables_pending) {  // the pose tables of this batch were built on another stream (and k_size_classes did not wait for them)
         if (ctx->tables_dev_sync)
-            launch_sync_wait(ctx->sync_counter(SYNC_TABLES), ctx->sync_sig[SYNC_TABLES], ctx->sync_timed_out(), ctx->stream);
+            enqueue_wait(ctx, SYNC_TABLES, ctx->stream);
         else
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_tables, 0));
         ctx->tables_pending = false;
@@ -199,8 +198,8 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
             launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
                                     ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree,
                                     d_sync + SYNC_TIER_FORK, 1, rot_same);
-            launch_sync_wait(d_sync + SYNC_TIER_FORK, ctx->sync_sig[SYNC_TIER_FORK], ctx->sync_timed_out(), ctx->stream2);
-            if (three) launch_sync_wait(d_sync + SYNC_TIER_FORK, ctx->sync_sig[SYNC_TIER_FORK], ctx->sync_timed_out(), ctx->stream3);
+            enqueue_wait(ctx, SYNC_TIER_FORK, ctx->stream2);
+            if (three) enqueue_wait(ctx, SYNC_TIER_FORK, ctx->stream3);
             launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
                                     ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree, nullptr, 6,
                                     rot_same);
@@ -213,7 +212,7 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
             launch_sync_signal(d_sync + SYNC_TIER_JOIN, ctx->stream2);
             if (three) launch_sync_signal(d_sync + SYNC_TIER_JOIN, ctx->stream3);
             ctx->sync_sig[SYNC_TIER_JOIN] += three ? 2 : 1;
-            launch_sync_wait(d_sync + SYNC_TIER_JOIN, ctx->sync_sig[SYNC_TIER_JOIN], ctx->sync_timed_out(), ctx->stream);
+            enqueue_wait(ctx, SYNC_TIER_JOIN, ctx->stream);
         } else {
             // joins: the stream that finishes first is waited for first (its wait is through while `stream` still works)
             if (three) {
@@ -245,29 +244,65 @@ static int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep
 // A failure inside the loop (HIP error, lattice deeper than 21 levels, allocation) must not leave the resident problem in the centred
 // frame: the static points were shifted in place and the window origin lives only in the context.
 static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep);
+// What a whole call may have to start over from (a device-side wait that gave up means a consumer ran before its producers: nothing of
+// that run can be trusted): the host model state, and the static points as they were -- centralize / decentralize shifts them in float
+// and is no exact round trip, so a second run on the shifted-back points would not be the run the caller asked for.
+struct CallSnapshot {
+    bool taken = false;
+    WindowHost win;
+    KeyframeHost key;
+    bool centralized = false;
+};
+static int take_snapshot(dmsa_ctx* ctx, const dmsa_settings& s, CallSnapshot& snap) {
+    snap.win = ctx->win, snap.key = ctx->key, snap.centralized = ctx->centralized;
+    if (ctx->model == MODEL_WINDOW && s.use_centralization && ctx->S > 0) {
+        HIPCHK(ctx->d_static_keep.ensure((size_t)ctx->S * 16));
+        HIPCHK(hipMemcpyAsync(ctx->d_static_keep.p, ctx->d_local.as<float4>() + ctx->N, (size_t)ctx->S * 16, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    snap.taken = true;
+    return DMSA_OK;
+}
+static int restore_snapshot(dmsa_ctx* ctx, const dmsa_settings& s, const CallSnapshot& snap) {
+    ctx->win = snap.win, ctx->key = snap.key, ctx->centralized = snap.centralized;
+    if (ctx->model == MODEL_WINDOW && s.use_centralization && ctx->S > 0) {
+        HIPCHK(hipMemcpyAsync(ctx->d_local.as<float4>() + ctx->N, ctx->d_static_keep.p, (size_t)ctx->S * 16, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->gaussians_valid = false, ctx->order_valid = false, ctx->aabb_fresh = false;
+    return DMSA_OK;
+}
 int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
     // default path: the loop state lives on the device (one host wait per iteration); the host-driven loop remains for the opt-in fast
-    // sums and for host-built pose tables
-    const bool device_loop = (ctx->flags & DMSA_FLAG_MIRROR_SUMS) && !(ctx->flags & DMSA_FLAG_POSE_TABLE_HOST) && ctx->device_loop;
-    int rc = device_loop ? optimize_device_loop(ctx, s, rep) : optimize_impl(ctx, s, rep);
-    if (rc == DMSA_OK && ctx->d_sync.p) {  // a device-side wait that gave up means a consumer ran before its producers: nothing of this call can be trusted
-        int32_t timed_out[3] = {0, 0, 0};
-        if (hipMemcpy(timed_out, ctx->sync_timed_out(), sizeof(timed_out), hipMemcpyDeviceToHost) != hipSuccess || timed_out[0] != 0) {
-            ctx->err = "a device-side stream dependency timed out (launch_sync_wait): waited for " + std::to_string(timed_out[1]) + ", counter at " +
-                       std::to_string(timed_out[2]) +
-                       " -- a tool that serialises kernels across queues (hardware counter collection)? run with DMSA_DEBUG=device_sync=0";
-            // start over: nothing is in flight after the failed call's final synchronisation
-            (void)hipDeviceSynchronize();
-            (void)hipMemset(ctx->d_sync.p, 0, SYNC_SLOTS * 4);
-            (void)hipDeviceSynchronize();
-            for (uint32_t& v : ctx->sync_sig) v = 0;
-            rc = DMSA_ERR_HIP;
+    // sums, for host-built pose tables and for sets whose chain state does not fit the chain kernels' LDS (hundreds of keyframes)
+    const bool device_loop = (ctx->flags & DMSA_FLAG_MIRROR_SUMS) && !(ctx->flags & DMSA_FLAG_POSE_TABLE_HOST) && ctx->device_loop && loop_chain_fits(ctx->loop_model);
+    auto run = [&]() {
+        ctx->wait_seq = 0, ctx->voxel_calls = 0;
+        int rc = device_loop ? optimize_device_loop(ctx, s, rep) : optimize_impl(ctx, s, rep);
+        if (rc != DMSA_OK && ctx->centralized) {  // a failure inside the loop must not leave the resident problem in the centred frame
+            const std::string err = ctx->err;
+            (void)dmsa_decentralize(ctx);
+            ctx->err = err;
         }
-    }
-    if (rc != DMSA_OK && ctx->centralized) {
-        const std::string err = ctx->err;
-        (void)dmsa_decentralize(ctx);
-        ctx->err = err;
+        return rc;
+    };
+    CallSnapshot snap;
+    if (ctx->dbg.device_sync != 0) CHK(take_snapshot(ctx, s, snap));
+    int rc = run();
+    // The flag is looked at on EVERY exit: a call that failed for another reason after a wait gave up (or after a signal was counted but
+    // never enqueued) would otherwise hand a stale flag and mismatched targets to the next, healthy call.
+    std::string what;
+    if (ctx->dbg.device_sync != 0 && sync_wait_timed_out(ctx, &what)) {
+        // Counters in device memory need the producer's queue to make progress while the consumer's wait spins; a tool that serialises
+        // kernels across queues in an order of its own (hardware counter collection) breaks that.  The call is run again from the state it
+        // started from with event dependencies, and the context keeps them from now on.
+        const std::string first = rc == DMSA_OK ? std::string() : " (first attempt: " + ctx->err + ")";
+        ctx->dbg.device_sync = 0;
+        ctx->sync_retries += 1;
+        CHK(restore_snapshot(ctx, s, snap));
+        rc = run();
+        const std::string warn = "warning: a device-side stream dependency timed out (" + what + "); the call was run again with event dependencies, which this context "
+                                 "uses from now on (DMSA_DEBUG=device_sync=0 selects them from the start)" + first;
+        ctx->err = rc == DMSA_OK ? warn : ctx->err + " | " + warn;
     }
     return rc;
 }
@@ -648,7 +683,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         }
         // :99, :199-232 the 1 + P chains, rows and pose tables of the Jacobian batch: beside the voxelisation, they need nothing from it
         if (dev_sync) {
-            launch_sync_wait(ctx->sync_counter(SYNC_LOOP_STATE), ctx->sync_sig[SYNC_LOOP_STATE], ctx->sync_timed_out(), side);
+            enqueue_wait(ctx, SYNC_LOOP_STATE, side);
         } else if (side != ctx->stream) {
             HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(hipStreamWaitEvent(side, ctx->ev_fork, 0));

@@ -17,6 +17,12 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     if (!lvl_on[0]) ctx->level_res[0] = ctx->level_res[1];
     if (!lvl_on[1]) ctx->level_res[1] = ctx->level_res[0];
     const bool compress = ctx->compress_keys && allow_compression;
+    ctx->voxel_calls += 1;
+    if (allow_speculation && ctx->dbg.speculation_fault > 0 && ctx->voxel_calls == ctx->dbg.speculation_fault)  // test hook: a guess one level too shallow
+        for (int l = 0; l < 2; ++l) {
+            if (ctx->depth_guess[l] > 1) ctx->depth_guess[l] -= 1;
+            if (ctx->bits_guess[l] > 3) ctx->bits_guess[l] -= 3;
+        }
     const bool speculate = allow_speculation && ctx->depth_guess[0] >= 0 && ctx->depth_guess[1] >= 0 && ctx->depth_guess[0] < 20 && ctx->depth_guess[1] < 20 &&
                            (!compress || (ctx->bits_guess[0] >= 0 && ctx->bits_guess[1] >= 0));
     // the key kernels count the digits of the sort that follows (own sort, 32-bit codes): no clearing kernel, no histogram pass
@@ -190,7 +196,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                 launch_sync_signal(ctx->sync_counter(SYNC_LATTICE), ctx->stream);
                 ctx->sync_sig[SYNC_LATTICE] += 1;
             }
-            launch_sync_wait(ctx->sync_counter(SYNC_LATTICE), ctx->sync_sig[SYNC_LATTICE], ctx->sync_timed_out(), ctx->stream2);
+            enqueue_wait(ctx, SYNC_LATTICE, ctx->stream2);
         } else if (two) {
             HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
             HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
@@ -213,7 +219,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         }
         if (lvl_on[0]) stage_gather(0, ctx->stream);
         if (dev_sync)
-            launch_sync_wait(ctx->sync_counter(SYNC_LEVEL1), ctx->sync_sig[SYNC_LEVEL1], ctx->sync_timed_out(), ctx->stream);
+            enqueue_wait(ctx, SYNC_LEVEL1, ctx->stream);
         else if (two)
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         if (lvl_on[1]) stage_gather(1, ctx->stream);
@@ -254,7 +260,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                             reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts) + sizeof(TileCounts)), ctx->stream, sy);
     }
     if (rb_released) {
-        launch_sync_wait(ctx->sync_counter(SYNC_CLASSES), ctx->sync_sig[SYNC_CLASSES], ctx->sync_timed_out(), rb);
+        enqueue_wait(ctx, SYNC_CLASSES, rb);
     } else if (rb != ctx->stream) {
         HIPCHK(hipEventRecord(ctx->ev_scan0, ctx->stream));
         HIPCHK(hipStreamWaitEvent(rb, ctx->ev_scan0, 0));
@@ -318,10 +324,12 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         const int true_bits = compress ? ctx->h_lattice[l].total_bits : 3 * ctx->h_lattice[l].final_depth;
         if (lvl_on[l] && compress && ctx->h_lattice[l].out_of_range) {
             ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
+            ctx->speculation_retries += 1;
             return build_gaussians(ctx, s, nullptr, false, false);  // a key left the predicted range: redo with full-width codes
         }
         if (speculate && lvl_on[l] && (ctx->h_lattice[l].final_depth > sort_depth[l] || true_bits > sort_bits[l])) {
             ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
+            ctx->speculation_retries += 1;
             return build_gaussians(ctx, s, nullptr, false, allow_compression);  // mis-speculated: redo (overlap work already ran)
         }
         ctx->depth_guess[l] = ctx->h_lattice[l].final_depth;

@@ -27,8 +27,12 @@ int dmsa_window_ring_create(dmsa_ctx* ctx, const dmsa_window_ring_config* cfg) {
         ctx->h_stage_cap = stage;
     }
     // every buffer whose size depends on the point count, for the full window: nothing is allocated when the windows start to slide
-    const int64_t n_saved = ctx->n;
-    const int rows_saved = ctx->rows;
+    struct Restore {  // the sizes of an already uploaded problem come back on every exit path, a failed allocation included
+        dmsa_ctx* c;
+        int64_t n;
+        int rows;
+        ~Restore() { c->n = n, c->rows = rows; }
+    } restore{ctx, ctx->n, ctx->rows};
     ctx->n = (int64_t)slots + cfg->max_static_points, ctx->rows = cfg->max_n_total + 1;
     HIPCHK(ctx->d_local.ensure((size_t)ctx->n * 16 + 16));
     HIPCHK(ctx->d_ring.ensure((size_t)ctx->n * 4 + 16));
@@ -44,7 +48,6 @@ int dmsa_window_ring_create(dmsa_ctx* ctx, const dmsa_window_ring_config* cfg) {
         // residual batches: at most one Gaussian per two points and level
         HIPCHK(ctx->d_E.ensure((size_t)(P + 1) * (size_t)(ctx->n / 8 + 4096) * 8));
     }
-    ctx->n = n_saved, ctx->rows = rows_saved;
     return rc;
 }
 

@@ -42,6 +42,13 @@ typedef struct dmsa_debug_options {
                                      kernels); 0: hipEventRecord / hipStreamWaitEvent                                                   */
     int32_t shared_rotations; /* 1  forward differences of translation parameters share the rotated member coordinates of evaluation 0 in
                                      the second pass of the chain tiers (serial_kernels.hip); 0: every evaluation transforms on its own     */
+    int32_t eval_skip;       /* 1   a (Gaussian, evaluation) pair of the Jacobian batch whose pose-table rows all have evaluation 0's bits is not
+                                     computed: its residual IS evaluation 0's (csrc/serial_kernels.hip); 0: every pair is computed;
+                                     2: every pair is computed and the pairs 1 would have skipped are compared (dmsa_eval_skip_stats)       */
+    int32_t sync_fault;      /* 0   test hook: k > 0 withholds the signal of the k-th device-side wait of every whole call -- the wait
+                                     gives up, the library restores the state of the call's start and runs it again with events            */
+    int32_t speculation_fault; /* 0 test hook: k > 0 plants a tree depth one too small in the k-th voxelisation of every whole call, so the
+                                     speculative sort width is wrong and the voxelisation runs again                                       */
 } dmsa_debug_options;
 
 void dmsa_default_debug_options(dmsa_debug_options* o);

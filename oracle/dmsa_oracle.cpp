@@ -15,8 +15,10 @@
 //   * boost::math::barycentric_rational (Floater–Hormann, d = 2)                                   
 //   * Eigen: skew().exp() == Rodrigues, R.log() via the unit quaternion, Quaterniond::slerp,
 //     AngleAxisd(q), Matrix3f::inverse() (cofactors), fixed-size product evaluation order        
-// Where Eigen's summation order cannot be known (dynamic-size vectorised reductions: colwise().mean(),
-// centered^T*centered, VectorXf::mean(), MatrixXd products) this file accumulates in double and rounds
+// colwise().mean() and VectorXf::mean() (Gaussians.h:146, :176) ARE knowable: Eigen's linear vectorised redux on a contiguous float
+// column is a pure function of the length and of the column's offset inside its 16-byte aligned buffer (eigen_linear_sum_f32 below).
+// Where Eigen's summation order depends on the machine (centered^T*centered runs through the blocked GEMM, whose depth blocks are
+// sized from the CPU's cache sizes; MatrixXd products likewise, on up to four threads) this file accumulates in double and rounds
 // once — the correctly rounded value every float order approximates.  EigenSolver<Matrix3f> (general
 // QR) is replaced by a fixed-sweep symmetric Jacobi iteration in float.  Build with -ffp-contract=off.
 //
@@ -48,7 +50,12 @@
 //   ORC_VAR_TRANSFORM_PAIRWISE  Matrix4f * Vector4f as (c0 x + c1 y) + (c2 z + c3) instead of ((c0 x + c1 y) + c2 z) + c3
 //   ORC_VAR_SUM3_LEFT           3-term fixed-size redux as (x0 + x1) + x2 instead of x0 + (x1 + x2)
 //   ORC_VAR_MAHA_ASSOC          w * ((d^T A) d) instead of ((w d^T) A) d                       (DmsaOptimizer.h:263)
-//   ORC_VAR_FIT_FLOAT           fit sums / weight mean as float chains in member order instead of 64-wide trees in double
+//   ORC_VAR_FIT_FLOAT           every fit sum (mean, centred products, weight mean) as a scalar float chain in member order
+//   ORC_VAR_FIT_MEAN_TREE       colwise().mean() / VectorXf::mean() as 64-wide trees in double (this file's statement until round 4)
+//                               instead of Eigen's own float redux order
+//   ORC_VAR_FIT_COV_GEMM        centered^T * centered in the float order of Eigen 3.4's product kernels as recalled (coefficient-based
+//                               lazy product below 14 members, else gebp's scalar tail loops in depth blocks sized for a 32 KB L1)
+//                               instead of 64-wide trees in double
 //   ORC_VAR_JTJ_NOFMA           J^T J, J^T e, e^T e for P > 64 with separately rounded multiply and add (the reference has no FMA)
 //   ORC_VAR_GLIBC_TRIG          sin / cos / acos / atan2 from glibc instead of include/dmsa_detmath.h
 #ifdef ORC_VAR_GLIBC_TRIG
@@ -536,24 +543,110 @@ struct Gaussians {
         }
         return total;
     }
+    // DenseBase::sum() of a contiguous float vector of n entries whose first entry lies `offset` floats behind a 16-byte boundary:
+    // Eigen 3.4 Redux.h, redux_impl<scalar_sum_op, ..., LinearVectorizedTraversal, NoUnrolling> with SSE2's Packet4f (the reference
+    // is built without -march, CMakeLists.txt:13-17) --
+    //   alignedStart = entries up to the first aligned one (first_default_aligned), alignedSize = whole packets behind it,
+    //   alignedSize2 = whole PAIRS of packets;  two packet accumulators take the packets alternately, res0 += res1, one more packet
+    //   if their number is odd, predux = (a0 + a2) + (a1 + a3) (_mm_movehl_ps, then _mm_add_ss with lane 1), then the scalars in
+    //   front of alignedStart and the scalars behind the last packet, in index order;  fewer than one whole packet: a scalar loop.
+    // A pure function of (n, offset): column c of the n x 3 column-major `subset` starts c * n floats behind its aligned buffer
+    // (MatrixX3f, Gaussians.h:130,146; copyPointsIntoEigMatrix, DmsaOptimizer.h:352-363), `rebalancingWeights.head(M)` at offset 0.
+    template <typename Get>
+    static float eigen_linear_sum_f32(size_t n, size_t offset, Get x) {
+        if (n == 0) return 0.0f;  // DenseBase::sum() of an empty vector
+        const size_t first = (4 - (offset & 3)) & 3;
+        const size_t aStart = first < n ? first : n;
+        const size_t aSize = ((n - aStart) / 4) * 4, aSize2 = ((n - aStart) / 8) * 8;
+        const size_t aEnd = aStart + aSize, aEnd2 = aStart + aSize2;
+        float res;
+        if (aSize) {
+            float p0[4], p1[4];
+            for (int l = 0; l < 4; ++l) p0[l] = x(aStart + l);
+            if (aSize > 4) {
+                for (int l = 0; l < 4; ++l) p1[l] = x(aStart + 4 + l);
+                for (size_t i = aStart + 8; i < aEnd2; i += 8)
+                    for (int l = 0; l < 4; ++l) p0[l] = p0[l] + x(i + l), p1[l] = p1[l] + x(i + 4 + l);
+                for (int l = 0; l < 4; ++l) p0[l] = p0[l] + p1[l];
+                if (aEnd > aEnd2)
+                    for (int l = 0; l < 4; ++l) p0[l] = p0[l] + x(aEnd2 + l);
+            }
+            res = (p0[0] + p0[2]) + (p0[1] + p0[3]);
+            for (size_t i = 0; i < aStart; ++i) res = res + x(i);
+            for (size_t i = aEnd; i < n; ++i) res = res + x(i);
+        } else {
+            res = x(0);
+            for (size_t i = 1; i < n; ++i) res = res + x(i);
+        }
+        return res;
+    }
+    // mean of a contiguous float vector, Eigen's `sum() / Scalar(size)` (VectorwiseOp::mean, DenseBase::mean)
+    template <typename Get>
+    static float eigen_mean_f32(size_t n, size_t offset, Get x) {
+#if defined(ORC_VAR_FIT_FLOAT) || defined(ORC_VAR_FIT_MEAN_TREE)
+        (void)offset;
+        return (float)(blockedSum(n, [&](size_t j) { return (double)x(j); }) / (double)n);
+#else
+        return eigen_linear_sum_f32(n, offset, x) / (float)n;
+#endif
+    }
+#ifdef ORC_VAR_FIT_COV_GEMM
+    // centered.adjoint() * centered (Gaussians.h:147) as Eigen 3.4 evaluates it for a 3 x n by n x 3 float product -- RECALLED, and the
+    // depth blocking depends on the machine's L1 size (32 KB assumed): generic_product_impl<..., GemmProduct>::evalTo takes the
+    // coefficient-based lazy product while n + 6 < 20 (every coefficient a linear vectorised redux of the element-wise products,
+    // aligned start 0), else general_matrix_matrix_product, where 3 rows < LhsProgress and 3 columns < nr leave everything to gebp's
+    // scalar tail loops: per coefficient a float chain C = C + a_k b_k over one depth block, res += C block after block.
+    static size_t gemm_kc(size_t k) {
+        if (k < 48) return k;  // evaluateProductBlockingSizesHeuristic returns early for max(k, m, n) < 48
+        const size_t l1 = 32 * 1024, k_peeling = 8, k_div = 1 * (8 * 4 + 4 * 4), k_sub = 8 * 4 * 4;  // mr = 8, nr = 4 without FMA
+        const size_t max_kc = std::max<size_t>(((l1 - k_sub) / k_div) & ~(k_peeling - 1), 1);
+        if (k <= max_kc) return k;
+        return (k % max_kc) == 0 ? max_kc : max_kc - k_peeling * ((max_kc - 1 - (k % max_kc)) / (k_peeling * (k / max_kc + 1)));
+    }
+    template <typename A, typename B>
+    static float gemm_dot_f32(size_t n, A a, B b) {
+        if (n + 6 < 20) return eigen_linear_sum_f32(n, 0, [&](size_t k) { return a(k) * b(k); });
+        const size_t kc = gemm_kc(n);
+        float res = 0.0f;
+        for (size_t k0 = 0; k0 < n; k0 += kc) {
+            float C = 0.0f;
+            for (size_t k = k0; k < std::min(n, k0 + kc); ++k) C = C + a(k) * b(k);
+            res = res + 1.0f * C;
+        }
+        return res;
+    }
+#endif
     void addPointSet(const std::vector<int>& ids, const float* xyz4, float observationWeight) {
         const size_t n = ids.size();
-        float mean[3];
-        for (int c = 0; c < 3; ++c) mean[c] = (float)(blockedSum(n, [&](size_t j) { return (double)xyz4[4 * (size_t)ids[j] + c]; }) / (double)n);
+        float mean[3];  // subset.colwise().mean(), Gaussians.h:146
+        for (int c = 0; c < 3; ++c) mean[c] = eigen_mean_f32(n, (size_t)c * n, [&](size_t j) { return xyz4[4 * (size_t)ids[j] + c]; });
         double acc[6];  // xx xy xz yy yz zz
         for (int q = 0; q < 6; ++q) {
             static const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+#ifdef ORC_VAR_FIT_COV_GEMM
+            acc[q] = (double)gemm_dot_f32(
+                n, [&](size_t j) { return xyz4[4 * (size_t)ids[j] + ia[q]] - mean[ia[q]]; }, [&](size_t j) { return xyz4[4 * (size_t)ids[j] + ib[q]] - mean[ib[q]]; });
+#else
             acc[q] = blockedSum(n, [&](size_t j) {
                 const float* p = xyz4 + 4 * (size_t)ids[j];
                 const float ca = p[ia[q]] - mean[ia[q]], cb = p[ib[q]] - mean[ib[q]];
                 return (double)ca * (double)cb;
             });
+#endif
         }
         const double denom = (double)((long)n - 1);
         float cov[3][3];
+#ifdef ORC_VAR_FIT_COV_GEMM
+        const float fd = (float)((long)n - 1);  // (...) / float(subset.rows() - 1): a float division
+        cov[0][0] = (float)acc[0] / fd, cov[0][1] = cov[1][0] = (float)acc[1] / fd;
+        cov[0][2] = cov[2][0] = (float)acc[2] / fd, cov[1][1] = (float)acc[3] / fd;
+        cov[1][2] = cov[2][1] = (float)acc[4] / fd, cov[2][2] = (float)acc[5] / fd;
+        (void)denom;
+#else
         cov[0][0] = (float)(acc[0] / denom), cov[0][1] = cov[1][0] = (float)(acc[1] / denom);
         cov[0][2] = cov[2][0] = (float)(acc[2] / denom), cov[1][1] = (float)(acc[3] / denom);
         cov[1][2] = cov[2][1] = (float)(acc[4] / denom), cov[2][2] = (float)(acc[5] / denom);
+#endif
         limit_covariance(cov);
         float inv[3][3];
         inverse3f(cov, inv);
@@ -571,9 +664,8 @@ struct Gaussians {
             const float nk = (float)(segOffset[k + 1] - segOffset[k]);
             weights[k] = (1.0f / nk) * obsWeights[k];
         }
-        // VectorXf::mean() (Gaussians.h:176): Eigen's vectorised reduction, order unknowable -> same blocked double sum as the fit
-        const double s = blockedSum((size_t)numPointSets, [&](size_t k) { return (double)weights[k]; });
-        const float mean = (float)(s / (double)numPointSets);
+        // VectorXf::mean() (Gaussians.h:176): `rebalancingWeights.head(M)` starts at its aligned buffer
+        const float mean = eigen_mean_f32((size_t)numPointSets, 0, [&](size_t k) { return weights[k]; });
         for (int k = 0; k < numPointSets; ++k) weights[k] = weights[k] / mean;
     }
 };
@@ -1529,6 +1621,10 @@ void orc_gaussians_set_info(orc_gaussians* g, const float* info_mats, const floa
     if (weights) std::copy(weights, weights + (size_t)g->g.numPointSets, g->g.weights.begin());
 }
 void orc_eval_residuals(const orc_gaussians* g, const float* xyz4_global, double* e_out) { eval_residuals(g->g, xyz4_global, e_out); }
+// the mean of a contiguous float vector as the Gaussian fit states it (Gaussians::eigen_mean_f32): test hook
+float orc_eigen_mean_f32(const float* x, int64_t n, int64_t offset_floats) {
+    return Gaussians::eigen_mean_f32((size_t)n, (size_t)offset_floats, [&](size_t j) { return x[j]; });
+}
 
 int orc_optimize_window(dmsa_window_problem* p, const dmsa_settings* s, dmsa_report* rep, float* global_out, orc_iter_trace* trace,
                         int32_t trace_capacity, int32_t fixed_iters) {

@@ -60,6 +60,8 @@ void    orc_gaussians_get(const orc_gaussians* g, int32_t* seg_offset, int32_t* 
 /* overwrite information matrices / weights (stage-level parity: feed the HIP path's Gaussians to the oracle) */
 void    orc_gaussians_set_info(orc_gaussians* g, const float* info_mats, const float* weights);
 /* updateErrorTerms rows 0..M-1 (DmsaOptimizer.h:242-268) on the given global points */
+/* DenseBase::mean() of n contiguous floats whose first entry lies offset_floats behind a 16-byte boundary (Eigen 3.4 linear redux, SSE2) */
+float   orc_eigen_mean_f32(const float* x, int64_t n, int64_t offset_floats);
 void    orc_eval_residuals(const orc_gaussians* g, const float* xyz4_global, double* e_out);
 
 /* ---- whole optimizeSet ------------------------------------------------------------------- */

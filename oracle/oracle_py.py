@@ -59,6 +59,8 @@ def lib() -> C.CDLL:
     L.orc_gaussians_get.argtypes = [vp, ip, ip, fp, fp]
     L.orc_gaussians_set_info.argtypes = [vp, fp, fp]
     L.orc_eval_residuals.argtypes = [vp, fp, dp]
+    L.orc_eigen_mean_f32.argtypes = [fp, C.c_int64, C.c_int64]
+    L.orc_eigen_mean_f32.restype = C.c_float
     L.orc_optimize_window.argtypes = [C.POINTER(capi.WindowProblem), C.POINTER(capi.Settings), C.POINTER(capi.Report), fp,
                                       C.POINTER(IterTrace), C.c_int32, C.c_int32]
     L.orc_optimize_keyframes.argtypes = [C.POINTER(capi.KeyframeProblem), C.POINTER(capi.Settings), C.POINTER(capi.Report), fp,
@@ -201,6 +203,13 @@ class Gaussians:
         if getattr(self, "_h", None):
             lib().orc_gaussians_free(self._h)
             self._h = None
+
+
+def eigen_mean_f32(x, offset_floats=0):
+    """DenseBase::mean() of a contiguous float vector in Eigen 3.4's linear vectorised redux order (SSE2 packets); `offset_floats`: where the
+    vector starts behind a 16-byte boundary (column c of an n x 3 column-major matrix: c * n)."""
+    x = np.ascontiguousarray(x, np.float32)
+    return np.float32(lib().orc_eigen_mean_f32(x.ctypes.data_as(capi.c_float_p), x.size, int(offset_floats)))
 
 
 def _run(fn, prob, settings, fixed_iters, want_global, npts):
