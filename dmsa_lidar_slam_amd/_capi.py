@@ -156,6 +156,11 @@ class DebugOptions(C.Structure):
                                            "library_sort", "overlap_batch", "serial_tree", "host_threads", "solve_threads", "host_timeline", "trace_time", "fused_leaf_scan", "device_sync", "shared_rotations", "eval_skip", "sync_fault", "speculation_fault")]
 
 
+class DebugCounters(C.Structure):
+    """include/dmsa_debug.h: dmsa_debug_counters."""
+    _fields_ = [(n, C.c_int64) for n in ("sync_retries", "speculation_retries", "skip_pairs", "skip_pairs_equal", "skip_mismatches")]
+
+
 class RawImu(C.Structure):
     """include/dmsa_raw_sequence.h: dmsa_raw_imu."""
     _fields_ = [("stamp", C.c_double), ("ang_vel", C.c_double * 3), ("lin_acc", C.c_double * 3)]
@@ -279,6 +284,7 @@ def load_library() -> C.CDLL:
         "dmsa_serial_fallback_sums": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_uint64)]),
         "dmsa_default_debug_options": (None, [C.POINTER(DebugOptions)]),
         "dmsa_create_ex": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(DebugOptions), C.POINTER(vp)]),
+        "dmsa_get_debug_counters": (C.c_int, [vp, C.POINTER(DebugCounters)]),
         # include/dmsa_window_ring.h
         "dmsa_window_ring_create": (C.c_int, [vp, C.POINTER(WindowRingConfig)]),
         "dmsa_window_ring_push": (C.c_int, [vp, c_float_p, c_double_p, c_int32_p, C.c_int64]),
@@ -335,7 +341,7 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "dmsa_create dmsa_create_ex dmsa_default_debug_options dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
+    "dmsa_create dmsa_create_ex dmsa_default_debug_options dmsa_get_debug_counters dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
     "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
     "dmsa_set_params dmsa_additional_errors dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
     "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_detmath_eval dmsa_lm_solve dmsa_lm_solve_device dmsa_serial_fallback_sums dmsa_sort_pairs dmsa_leaf_segments dmsa_neighbourhood_ranges dmsa_submap_poses dmsa_update_poses_from_submap dmsa_optimize_resident dmsa_get_poses "

@@ -92,6 +92,17 @@ class DmsaOptimizer:
         self._check(self._lib.dmsa_optimize_resident(self._ctx, C.byref(cs), C.byref(rep)), "optimize_resident")
         return rep
 
+    def debugCounters(self) -> dict:
+        """include/dmsa_debug.h: dmsa_debug_counters (retries after a timed-out device-side wait / a wrong sort-width guess, pairs the
+        Jacobian batches left out because they equal evaluation 0)."""
+        c = capi.DebugCounters()
+        self._check(self._lib.dmsa_get_debug_counters(self._ctx, C.byref(c)), "get_debug_counters")
+        return {n: int(getattr(c, n)) for n, _ in c._fields_}
+
+    def lastError(self) -> str:
+        msg = self._lib.dmsa_last_error(self._ctx)
+        return msg.decode() if msg else ""
+
     def poses(self):
         """Current relative poses (n,3),(n,3) of the resident problem."""
         p = self._problem

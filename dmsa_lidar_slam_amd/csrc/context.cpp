@@ -98,6 +98,7 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
         // one entry per Gaussian, and M can approach 2n (see d_info12 above)
         HIPCHK(ctx->d_order.ensure((2 * n + 16) * 4));
         HIPCHK(ctx->d_fit_sums.ensure((2 * n + 16) * 6 * 8));
+        HIPCHK(ctx->d_gauss_rows.ensure((2 * n + 16) * 8));
     }
     // tiled correspondence kernels: windows of 3T/4 members plus own-tile Gaussians (> T/4 members each) and their
     // neighbours: tiles <= (4/3 + 8)*Mm/T + 1 with Mm <= 2n; one row list of `rows` entries per tile

@@ -279,6 +279,21 @@ int dmsa_get_global_points(dmsa_ctx* ctx, float* xyz_out, int64_t capacity_point
     return DMSA_OK;
 }
 
+int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out) {
+    if (!ctx || !out) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    unsigned long long st[3] = {(unsigned long long)ctx->skip_pairs, 0, 0};
+    if (ctx->d_skip_stats.p && ctx->skip_stats_evals > 0) {
+        std::vector<unsigned long long> per((size_t)ctx->skip_stats_evals * 2);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(per.data(), ctx->d_skip_stats.p, per.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < per.size(); k += 2) st[1] += per[k], st[2] += per[k + 1];
+    }
+    out->sync_retries = ctx->sync_retries, out->speculation_retries = ctx->speculation_retries;
+    out->skip_pairs = (int64_t)st[0], out->skip_pairs_equal = (int64_t)st[1], out->skip_mismatches = (int64_t)st[2];
+    return DMSA_OK;
+}
+
 int dmsa_get_timing(dmsa_ctx* ctx, dmsa_timing* t, int32_t reset) {
     if (!ctx) return DMSA_ERR_INVALID;
     CHK(set_device(ctx));

@@ -234,6 +234,11 @@ struct dmsa_ctx {
     DevBuf d_tablesT;                                          // pose tables of the current batch, transposed ([row][evaluation][12])
     bool order_valid = false;
     DevBuf d_fit_sums;           // six centred product sums per Gaussian (fit kernels -> finish kernel)
+    DevBuf d_gauss_rows;         // (smallest, largest) pose-table row among the members of every Gaussian, identity row excluded (fit kernel)
+    DevBuf d_row_range;          // per evaluation of the Jacobian batch: (first, last) pose-table row that can differ from evaluation 0's (loop chain + pose-table kernels)
+    DevBuf d_skip_stats;         // per evaluation of the Jacobian batch: pairs (Gaussian, evaluation) not computed, pairs that differed under eval_skip = 2
+    int skip_stats_evals = 0;
+    int64_t skip_pairs = 0;      // pairs the eval_skip logic looked at since the context was created
     bool fit_guess_valid = false;  // serial_counts of the previous voxelisation may size this one's speculative fit launches
     SerialCounts serial_counts{0, 0, 0, 0};
     bool E_is_jacobian = false;  // the matrix-core normal equations (P > 64) rewrote the residual batch as the columns of [J | e0]
@@ -371,6 +376,7 @@ void append_glob(const PoseChain& c, std::vector<double>& out);
 void host_set_params(dmsa_ctx* ctx, const double* p);
 int transform_points(dmsa_ctx* ctx, int b);
 int ensure_E(dmsa_ctx* ctx, int B);
-int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const double* d_extra = nullptr, const uint32_t* rot_same = nullptr);
+int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const double* d_extra = nullptr, const uint32_t* rot_same = nullptr,
+                  const int2* row_range = nullptr /* Jacobian batch of the device loop: pairs equal to evaluation 0 are left out (serial_kernels.h) */);
 int device_lm_step(dmsa_ctx* ctx, const double* d_Hp, int P, double lambda, double alpha, double max_step, double* d_step, LoopFlags* d_flags);
 int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep);

@@ -140,15 +140,16 @@ void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const flo
 void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, bool mirror, hipStream_t s);
 // ---- K4: correspondence kernel ------------------------------------------------------------------------------
 void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t* wg_seg, hipStream_t s);
-// default path: fit in the oracle's summation order (blocks of 64 members, pairwise tree inside a block, block sums in order).
-// `order` = Gaussians by descending size class, `sc` = the DEVICE copy of SerialCounts (class ranges); cls 0 / 1 / 2 = long / middle /
-// short class with 16 / 4 / 1 waves per Gaussian; workgroups [task0, task0 + tasks) of the class.  Writes the six centred product
-// sums per Gaussian; launch_gauss_fit_finish turns them into information matrices (max_gauss >= M threads).
-void launch_gauss_fit_tree(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, int cls,
-                           int task0, int tasks, double* sums, hipStream_t s);
-// the three classes and (with_weights) the rebalancing weights in one launch; tasks[c] Gaussians of class c starting at first[c] within the class
+// default path: fit in the oracle's summation order (the mean in Eigen's own linear-redux order; centred products in blocks of 64 members,
+// pairwise tree inside a block, block sums in order).  `order` = Gaussians by descending size class, `sc` = the DEVICE copy of
+// SerialCounts (class ranges); classes 0 / 1 / 2 = long / middle / short with 16 / 4 / 1 waves per Gaussian; tasks[c] Gaussians of class c
+// starting at first[c] within the class; with_weights: one more workgroup computes the rebalancing weights.  Writes the six centred
+// product sums per Gaussian (launch_gauss_fit_finish turns them into information matrices, max_gauss >= M threads) and, if asked,
+// gauss_rows[g] = (smallest, largest) pose-table row among the members of Gaussian g, the identity row `id_row` of the static points
+// left out ((INT_MAX, -1): static points only) -- what the correspondence kernels need to tell which evaluations of a Jacobian batch
+// can differ from evaluation 0 for that Gaussian.
 void launch_gauss_fit_all(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, const int first[3],
-                          const int tasks[3], double* sums, GaussCounts* counts, float* info12, bool with_weights, hipStream_t s);
+                          const int tasks[3], double* sums, GaussCounts* counts, float* info12, bool with_weights, int id_row, int2* gauss_rows, hipStream_t s);
 void launch_gauss_fit_finish(const int32_t* seg_off, const GaussCounts* counts, const double* sums, int max_gauss, float* info12, hipStream_t s);
 // streaming correspondence kernel of the opt-in fast sums (fallback of the tiled kernels)
 void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
@@ -178,7 +179,17 @@ struct NormalEqPartials {
     int nsplit, nt;
 };
 NormalEqPartials normal_equations_partials(int rows, int P);
-void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s, bool reduce = true);
+// which (Gaussian, evaluation) pairs of a Jacobian batch were left out by the correspondence kernels (serial_kernels.h): pair (r, k + 1)
+// with row_range[k + 1] and gauss_rows[r] disjoint has the residual of evaluation 0 (P > 64 only: the column kernel puts it in place)
+struct EvalSkip {
+    const int2* row_range = nullptr;      // [1 + P]
+    const int2* gauss_rows = nullptr;     // [M]
+    int M = 0;                            // rows below M are Gaussians; additional rows are always computed
+    int check = 0;                        // 1: the pairs WERE computed (debug switch eval_skip = 2) -- compare them with evaluation 0 instead
+    unsigned long long* stats = nullptr;  // [P][2] += per evaluation k + 1: pairs left out (check: that could have been), pairs that differed (check only)
+};
+void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s, bool reduce = true,
+                             const EvalSkip* skip = nullptr);
 int normal_equations_partial_doubles(int rows, int P);
 void launch_squared_sums(const double* E, int64_t ldE, int rows, int B, double* partial, double* out, hipStream_t s);
 int squared_sums_partial_doubles(int rows, int B);

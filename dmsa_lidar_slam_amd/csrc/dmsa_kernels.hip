@@ -1541,11 +1541,18 @@ __global__ __launch_bounds__(256) void k_gauss_fit(const int32_t* __restrict__ s
     }
 }
 
-// Default path: the fit's nine double sums in the order the oracle states (Gaussians::addPointSet there).  The reference sums with
-// Eigen's vectorised dynamic-size reductions (Gaussians.h:146-154), whose order cannot be known, so the oracle states one that a
-// wave computes in a handful of instructions: consecutive blocks of 64 members, each block reduced by the balanced pairwise tree
-// (exactly what wave_allsum's DPP steps do: v[i] += v[i - w] for w = 1, 2, .. 32), the block sums added in block order.  One
-// workgroup per Gaussian; its waves take blocks round by round, thread c adds the round's block sums of component c in order.
+// Default path: the fit's sums in the order the oracle states (Gaussians::addPointSet there).
+//  * subset.colwise().mean() (Gaussians.h:146) in Eigen's OWN order: the linear vectorised redux of a contiguous float column is a
+//    pure function of the member count and of the column's offset in its 16-byte aligned buffer (oracle: eigen_linear_sum_f32; SSE2
+//    Packet4f).  Per column: eight float chains (two packet accumulators of four lanes) over the aligned middle, res0 += res1, one odd
+//    packet, predux (a0 + a2) + (a1 + a3), then the scalars in front of the aligned start and behind the last packet.  The chains
+//    are serial, so the members' coordinates go through LDS in chunks: every wave of the group transforms members, 24 lanes (8 chains
+//    x 3 columns) add them up, 3 lanes finish.
+//  * centered^T * centered runs through Eigen's blocked GEMM, whose depth blocks depend on the machine's cache sizes: no order to
+//    follow, so the oracle states one that a wave computes in a handful of instructions -- double sums over consecutive blocks of 64
+//    members, each block reduced by the balanced pairwise tree (exactly what wave_allsum's DPP steps do: v[i] += v[i - w] for
+//    w = 1, 2, .. 32), the block sums added in block order.  The group's waves take blocks round by round, thread c adds the round's
+//    block sums of component c in order.
 // Members are read from the Gaussian-ordered copy of the LOCAL points and transformed with the base pose table (the same
 // operation sequence as k_transform, so the coordinates are the ones the voxelisation saw).
 constexpr int kSumBlock = 64;
@@ -1559,78 +1566,75 @@ __device__ __forceinline__ bool fit_task(const int32_t* __restrict__ sc /* n_cha
     index = first + task;
     return task < count;
 }
-template <int kFitWaves, int kMaxBlk>
-__global__ __launch_bounds__(64 * kFitWaves) void k_gauss_fit_tree(const float4* __restrict__ memb_local, const int32_t* __restrict__ seg_off,
-                                                                   const float4* __restrict__ table0, const uint32_t* __restrict__ order,
-                                                                   const int32_t* __restrict__ sc, int cls, int task0, double* __restrict__ sums) {
-    __shared__ double s_blk[kMaxBlk][6];
-    __shared__ double s_tot[6];
-    __shared__ float s_mean[3];
-    int index;
-    if (!fit_task(sc, cls, task0 + (int)blockIdx.x, index)) return;
-    const int g = (int)order[index];
-    const int b = seg_off[g], n = seg_off[g + 1] - b, nblk = (n + kSumBlock - 1) / kSumBlock;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    auto global_point = [&](int j) {
-        const float4 p = memb_local[b + j];
-        const int row = __float_as_int(p.w);
-        return apply_row3(table0[3 * row], table0[3 * row + 1], table0[3 * row + 2], p.x, p.y, p.z);
-    };
-    if (threadIdx.x < 6) s_tot[threadIdx.x] = 0.0;
-    __syncthreads();
-    // a super-round = kMaxBlk blocks: the waves reduce their blocks without meeting, then thread c adds the block sums of component c
-    // in block order
-    for (int sb = 0; sb < nblk; sb += kMaxBlk) {  // pass 1: sums of x, y, z
-        const int end = min(nblk, sb + kMaxBlk);
-        for (int blk = sb + wave; blk < end; blk += kFitWaves) {
-            const int j = blk * kSumBlock + lane;
-            double x = 0.0, y = 0.0, z = 0.0;
-            if (j < n) {
-                const float3 q = global_point(j);
-                x = (double)q.x, y = (double)q.y, z = (double)q.z;
-            }
-            x = wave_allsum(x), y = wave_allsum(y), z = wave_allsum(z);
-            if (lane == 0) s_blk[blk - sb][0] = x, s_blk[blk - sb][1] = y, s_blk[blk - sb][2] = z;
-        }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            double tot = s_tot[threadIdx.x];
-            for (int t = 0; t < end - sb; ++t) tot += s_blk[t][threadIdx.x];
-            s_tot[threadIdx.x] = tot;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < 3) s_mean[threadIdx.x] = (float)(s_tot[threadIdx.x] / (double)n);
-    __syncthreads();
-    const float mx = s_mean[0], my = s_mean[1], mz = s_mean[2];
-    if (threadIdx.x < 6) s_tot[threadIdx.x] = 0.0;
-    __syncthreads();
-    for (int sb = 0; sb < nblk; sb += kMaxBlk) {  // pass 2: xx xy xz yy yz zz of the centred members
-        const int end = min(nblk, sb + kMaxBlk);
-        for (int blk = sb + wave; blk < end; blk += kFitWaves) {
-            const int j = blk * kSumBlock + lane;
-            double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            if (j < n) {
-                const float3 q = global_point(j);
-                const float cx = q.x - mx, cy = q.y - my, cz = q.z - mz;
-                t[0] = (double)cx * (double)cx, t[1] = (double)cx * (double)cy, t[2] = (double)cx * (double)cz;
-                t[3] = (double)cy * (double)cy, t[4] = (double)cy * (double)cz, t[5] = (double)cz * (double)cz;
-            }
+// Eigen's linear redux of n contiguous floats that start `offset` floats behind a 16-byte boundary (Redux.h, LinearVectorizedTraversal):
+// [0, aS) scalars in front, [aS, aEnd2) pairs of packets (the eight chains), [aEnd2, aEnd) one odd packet, [aEnd, n) scalars behind
+struct ReduxPlan {
+    int aS, aEnd2, aEnd;
+    bool vec;  // at least one whole packet; otherwise a plain scalar loop
+};
+__device__ __forceinline__ ReduxPlan redux_plan(int n, int offset) {
+    ReduxPlan p;
+    p.aS = min((4 - (offset & 3)) & 3, n);
+    const int rem = n - p.aS;
+    p.vec = rem >= 4;
+    p.aEnd = p.aS + (rem & ~3), p.aEnd2 = p.aS + (rem & ~7);
+    return p;
+}
+// where element i of such a vector goes: -1 = chain (i - aS) & 7; otherwise a slot of the (at most ten) scalars the finish adds itself
+__device__ __forceinline__ int redux_slot(const ReduxPlan& p, int i) {
+    if (!p.vec) return i;  // n <= 6
+    if (i < p.aS) return i;
+    if (i >= p.aEnd2) return 3 + (i - p.aEnd2);
+    return -1;
+}
+__device__ __forceinline__ ReduxPlan my_plan_col(int n, int c) { return redux_plan(n, c * (n & 3)); }  // column c of an n x 3 column-major matrix
+constexpr int kReduxSlots = 10;
+// chain `k` (0..7) of the plan over the elements [m0, m0 + cnt) held in sx[0 .. cnt): acc += every eighth element, in order.  The adds are
+// a dependent chain (~8 cycles each); the LDS reads of the next eight elements are issued before the adds of the current eight, so the
+// chain never waits for LDS.
+__device__ __forceinline__ float redux_chain(const ReduxPlan& p, int k, int m0, int cnt, const float* __restrict__ sx, float acc) {
+    const int first = p.aS + k;
+    int i = m0 <= first ? first : first + ((m0 - first + 7) >> 3) * 8;
+    const int end = min(m0 + cnt, p.aEnd2);
+    if (i + 56 < end) {
+        float v[8], w[8];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const double v = wave_allsum(t[c]);
-                if (lane == 0) s_blk[blk - sb][c] = v;
-            }
+        for (int u = 0; u < 8; ++u) v[u] = sx[i - m0 + 8 * u];
+        i += 64;
+        for (; i + 56 < end; i += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = sx[i - m0 + 8 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = acc + v[u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = w[u];
         }
-        __syncthreads();
-        if (threadIdx.x < 6) {
-            double tot = s_tot[threadIdx.x];
-            for (int t = 0; t < end - sb; ++t) tot += s_blk[t][threadIdx.x];
-            s_tot[threadIdx.x] = tot;
-        }
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = acc + v[u];
     }
-    if (threadIdx.x < 6) sums[(size_t)g * 6 + threadIdx.x] = s_tot[threadIdx.x];
+    for (; i < end; i += 8) acc = acc + sx[i - m0];
+    return acc;
+}
+// the tail of the redux: chains c and c + 4 meet, the odd packet, predux, scalars in front and behind (acc8: the eight chains, sp: the slots)
+__device__ __forceinline__ float redux_finish(const ReduxPlan& p, int n, const float* __restrict__ acc8, const float* __restrict__ sp) {
+    float res;
+    if (!p.vec) {
+        res = -0.0f;  // (-0) + x == x for every x: the first element is taken as it is
+        for (int i = 0; i < n; ++i) res = res + sp[i];
+        return res;
+    }
+    float r[4];
+    const bool pairs = p.aEnd2 > p.aS;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) r[l] = pairs ? acc8[l] + acc8[4 + l] : sp[3 + l];
+    if (pairs && p.aEnd > p.aEnd2) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) r[l] = r[l] + sp[3 + l];
+    }
+    res = (r[0] + r[2]) + (r[1] + r[3]);
+    for (int i = 0; i < p.aS; ++i) res = res + sp[i];
+    for (int i = p.aEnd; i < n; ++i) res = res + sp[3 + (i - p.aEnd2)];
+    return res;
 }
 // covariance -> limitCovariance -> inverse (Gaussians.h:146-168, :181-201), one thread per Gaussian: the serial 3x3 work of all
 // Gaussians fills whole waves instead of trailing every fit workgroup on a single lane
@@ -1650,13 +1654,22 @@ __global__ __launch_bounds__(256) void k_gauss_fit_finish(const int32_t* __restr
 constexpr int kFitShortBlocks = 4;  // short class: Gaussians up to serial_small_threshold() <= 256 members, one wave each
 int fit_small_max_blocks() { return kFitShortBlocks; }
 // All three classes -- and the rebalancing weights -- in ONE launch of 1024-thread workgroups: a workgroup is one long Gaussian (16 waves),
-// four middle ones (4 waves each) or sixteen short ones (1 wave each); the last workgroup computes the weights.  Same block sums in the
-// same order as k_gauss_fit_tree; what changes is that nothing has to be forked to a second stream and joined again (a cross-stream
-// dependency costs ~15 us each way on this GPU, scripts/microbench/graph_edge.hip), and the weights no longer sit behind the long fit.
+// four middle ones (4 waves each) or sixteen short ones (1 wave each); the first workgroup computes the weights.  Nothing has to be
+// forked to a second stream and joined again (a cross-stream dependency costs ~15 us each way on this GPU,
+// scripts/microbench/graph_edge.hip), and the weights do not sit behind the long fit.
+// scratch of one group (a Gaussian's 16 / 4 / 1 waves) besides the block sums
+struct FitScratch {
+    float acc[3][8];              // the eight chains of each column
+    float sp[3][kReduxSlots];     // scalars in front of / behind the packets, and the odd packet
+    float mean[3];
+    int rows[2];                  // smallest / largest pose-table row of the members (identity row excluded)
+};
 template <int kFitWaves, int kMaxBlk>
 __device__ __forceinline__ void fit_tree_group(const float4* __restrict__ memb_local, const int32_t* __restrict__ seg_off, const float4* __restrict__ table0,
                                                int g /* -1: no Gaussian for this group */, int gtid, double (*s_blk)[6] /* [kMaxBlk] */, double* s_tot /* [6] */,
-                                               float* s_mean /* [3] */, int* s_rounds, double* __restrict__ sums) {
+                                               FitScratch* fs, float* sx /* [3][256 * kFitWaves] */, int* s_rounds /* [2]: block rounds, chunks */, int id_row,
+                                               double* __restrict__ sums, int2* __restrict__ gauss_rows) {
+    constexpr int CH = 256 * kFitWaves;  // members per chunk of the mean pass: four per lane
     const int b = g >= 0 ? seg_off[g] : 0, n = g >= 0 ? seg_off[g + 1] - b : 0, nblk = (n + kSumBlock - 1) / kSumBlock;
     const int wave = gtid >> 6, lane = gtid & 63;
     auto global_point = [&](int j) {
@@ -1666,7 +1679,7 @@ __device__ __forceinline__ void fit_tree_group(const float4* __restrict__ memb_l
     };
     // A group of ONE wave (the short class: sixteen Gaussians per workgroup) needs no workgroup barrier at all -- its LDS traffic is in
     // order, its scratch is its own -- so the sixteen waves run and end independently instead of meeting ten times at the pace of the
-    // slowest.  Groups of several waves meet at the same barriers: everybody runs as many super-rounds as the group with the most blocks.
+    // slowest.  Groups of several waves meet at the same barriers: everybody runs as many rounds as the group with the most.
     constexpr bool kSolo = kFitWaves == 1;
     auto sync = [&]() {
         if (kSolo) {
@@ -1676,42 +1689,77 @@ __device__ __forceinline__ void fit_tree_group(const float4* __restrict__ memb_l
             __syncthreads();
         }
     };
-    if (!kSolo && gtid == 0) atomicMax(s_rounds, (nblk + kMaxBlk - 1) / kMaxBlk);
+    if (!kSolo && gtid == 0) atomicMax(&s_rounds[0], (nblk + kMaxBlk - 1) / kMaxBlk), atomicMax(&s_rounds[1], (n + CH - 1) / CH);
     if (gtid < 6) s_tot[gtid] = 0.0;
+    if (gtid == 0) fs->rows[0] = INT_MAX, fs->rows[1] = -1;
     sync();
-    const int rounds = kSolo ? (nblk + kMaxBlk - 1) / kMaxBlk : *s_rounds;
-    for (int r = 0; r < rounds; ++r) {  // pass 1: sums of x, y, z
-        const int sb = r * kMaxBlk, end = min(nblk, sb + kMaxBlk);
-        for (int blk = sb + wave; blk < end; blk += kFitWaves) {
-            const int j = blk * kSumBlock + lane;
-            double x = 0.0, y = 0.0, z = 0.0;
-            if (j < n) {
-                const float3 q = global_point(j);
-                x = (double)q.x, y = (double)q.y, z = (double)q.z;
+    const int rounds = kSolo ? (nblk + kMaxBlk - 1) / kMaxBlk : s_rounds[0];
+    const int chunks = kSolo ? (n + CH - 1) / CH : s_rounds[1];
+    // ---- pass 1: subset.colwise().mean() in Eigen's order (see above) ----
+    ReduxPlan plan[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) plan[c] = redux_plan(n, c * (n & 3));
+    const int cc = gtid >> 3, ck = gtid & 7;  // chain lanes: gtid < 24 = (column, chain)
+    const ReduxPlan my_plan = redux_plan(n, min(cc, 2) * (n & 3));  // (no run-time index into plan[]: that would put it into scratch memory)
+    float acc = -0.0f;                         // (-0) + x == x: the chain starts with its first element as it is
+    int rmin = INT_MAX, rmax = -1;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const int m0 = ch * CH;
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = m0 + u * (64 * kFitWaves) + gtid;
+            p[u] = memb_local[b + min(i, max(n - 1, 0))];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int il = u * (64 * kFitWaves) + gtid, i = m0 + il;
+            if (i < n) {
+                const int row = __float_as_int(p[u].w);
+                if (row != id_row) rmin = min(rmin, row), rmax = max(rmax, row);
+                const float3 q = apply_row3(table0[3 * row], table0[3 * row + 1], table0[3 * row + 2], p[u].x, p[u].y, p[u].z);
+                sx[il] = q.x, sx[CH + il] = q.y, sx[2 * CH + il] = q.z;
+                if (i < 3 || i + 10 >= n || n <= 6) {  // one of the few scalars of some column's redux
+                    int slot = redux_slot(plan[0], i);
+                    if (slot >= 0) fs->sp[0][slot] = q.x;
+                    slot = redux_slot(plan[1], i);
+                    if (slot >= 0) fs->sp[1][slot] = q.y;
+                    slot = redux_slot(plan[2], i);
+                    if (slot >= 0) fs->sp[2][slot] = q.z;
+                }
             }
-            x = wave_allsum(x), y = wave_allsum(y), z = wave_allsum(z);
-            if (lane == 0) s_blk[blk - sb][0] = x, s_blk[blk - sb][1] = y, s_blk[blk - sb][2] = z;
         }
         sync();
-        if (gtid < 3) {
-            double tot = s_tot[gtid];
-            for (int t = 0; t < end - sb; ++t) tot += s_blk[t][gtid];
-            s_tot[gtid] = tot;
-        }
-        sync();
+        if (gtid < 24) acc = redux_chain(my_plan, ck, m0, min(CH, n - m0), sx + cc * CH, acc);
+        if (ch + 1 < chunks) sync();  // the next chunk overwrites the coordinates
     }
-    if (gtid < 3) s_mean[gtid] = (float)(s_tot[gtid] / (double)n);
+    if (gtid < 24) fs->acc[cc][ck] = acc;
+    {   // pose-table rows of the members (what evaluations of a Jacobian batch can differ from evaluation 0 for this Gaussian)
+        rmin = wave_allmin(rmin), rmax = -wave_allmin(-rmax);
+        if (lane == 0 && rmax >= 0) {
+            if (kSolo)
+                fs->rows[0] = rmin, fs->rows[1] = rmax;
+            else
+                atomicMin(&fs->rows[0], rmin), atomicMax(&fs->rows[1], rmax);
+        }
+    }
     sync();
-    const float mx = s_mean[0], my = s_mean[1], mz = s_mean[2];
-    if (gtid < 6) s_tot[gtid] = 0.0;
+    if (gtid < 3 && n > 0) fs->mean[gtid] = redux_finish(my_plan_col(n, gtid), n, fs->acc[gtid], fs->sp[gtid]) / (float)n;
+    if (gtid == 3 && g >= 0 && gauss_rows != nullptr) gauss_rows[g] = make_int2(fs->rows[0], fs->rows[1]);
     sync();
+    const float mx = fs->mean[0], my = fs->mean[1], mz = fs->mean[2];
+    const bool resident = chunks <= 1;  // the coordinates of every member are still in LDS
     for (int r = 0; r < rounds; ++r) {  // pass 2: xx xy xz yy yz zz of the centred members
         const int sb = r * kMaxBlk, end = min(nblk, sb + kMaxBlk);
         for (int blk = sb + wave; blk < end; blk += kFitWaves) {
             const int j = blk * kSumBlock + lane;
             double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if (j < n) {
-                const float3 q = global_point(j);
+                float3 q;
+                if (resident)
+                    q = make_float3(sx[j], sx[CH + j], sx[2 * CH + j]);
+                else
+                    q = global_point(j);
                 const float cx = q.x - mx, cy = q.y - my, cz = q.z - mz;
                 t[0] = (double)cx * (double)cx, t[1] = (double)cx * (double)cy, t[2] = (double)cx * (double)cz;
                 t[3] = (double)cy * (double)cy, t[4] = (double)cy * (double)cz, t[5] = (double)cz * (double)cz;
@@ -1732,65 +1780,70 @@ __device__ __forceinline__ void fit_tree_group(const float4* __restrict__ memb_l
     }
     if (g >= 0 && gtid < 6) sums[(size_t)g * 6 + gtid] = s_tot[gtid];
 }
-__device__ void rebalancing_weights_mirror_body(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts, float* __restrict__ info12, double* s_slot,
-                                                double* s_tot, float* s_mean);
+__device__ void rebalancing_weights_mirror_body(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts, float* __restrict__ info12, float* sx /* [8192] */,
+                                                FitScratch* fs);
 struct FitLaunch {
     int first[3], tasks[3];  // per class: index of the first Gaussian of the class covered by this launch, number covered
     int wg[3];               // workgroups per class
+    int weights;             // 1: workgroup 0 computes the rebalancing weights
+    int id_row;              // the pose-table row of the static points (identity)
 };
+constexpr int kFitLdsFloats = 3 * 4096;  // dynamic LDS of k_gauss_fit_all: member coordinates of a chunk, [group][column][256 x waves]
 __global__ __launch_bounds__(1024) void k_gauss_fit_all(const float4* __restrict__ memb_local, const int32_t* __restrict__ seg_off, const float4* __restrict__ table0,
                                                         const uint32_t* __restrict__ order, const int32_t* __restrict__ sc, FitLaunch fl, double* __restrict__ sums,
-                                                        GaussCounts* __restrict__ counts, float* __restrict__ info12) {
+                                                        GaussCounts* __restrict__ counts, float* __restrict__ info12, int2* __restrict__ gauss_rows) {
+    extern __shared__ float s_x[];    // kFitLdsFloats
     __shared__ double s_blk[256][6];  // class 0: [256][6]; class 1: 4 x [64][6]; class 2: 16 x [kFitShortBlocks][6]
     __shared__ double s_tot[16][6];
-    __shared__ float s_mean[16][3];
-    __shared__ int s_rounds;
-    if (threadIdx.x == 0) s_rounds = 0;
+    __shared__ FitScratch s_fs[16];
+    __shared__ int s_rounds[2];
+    if (threadIdx.x < 2) s_rounds[threadIdx.x] = 0;
     __syncthreads();
     const int tid = threadIdx.x;
     int bx = blockIdx.x;
+    // the weights first: their chains (M / 8 dependent float adds) then run beside the fit of the longest Gaussians instead of behind it
+    if (fl.weights) {
+        if (bx == 0) {
+            rebalancing_weights_mirror_body(seg_off, counts, info12, s_x, &s_fs[0]);
+            return;
+        }
+        bx -= 1;
+    }
     auto pick = [&](int cls, int task) {
         int index;
         return task < fl.tasks[cls] && fit_task(sc, cls, fl.first[cls] + task, index) ? (int)order[index] : -1;
     };
     if (bx < fl.wg[0]) {
-        fit_tree_group<16, 256>(memb_local, seg_off, table0, pick(0, bx), tid, s_blk, s_tot[0], s_mean[0], &s_rounds, sums);
+        fit_tree_group<16, 256>(memb_local, seg_off, table0, pick(0, bx), tid, s_blk, s_tot[0], &s_fs[0], s_x, s_rounds, fl.id_row, sums, gauss_rows);
         return;
     }
     bx -= fl.wg[0];
     if (bx < fl.wg[1]) {
         const int grp = tid >> 8;
-        fit_tree_group<4, 64>(memb_local, seg_off, table0, pick(1, bx * 4 + grp), tid & 255, s_blk + grp * 64, s_tot[grp], s_mean[grp], &s_rounds, sums);
+        fit_tree_group<4, 64>(memb_local, seg_off, table0, pick(1, bx * 4 + grp), tid & 255, s_blk + grp * 64, s_tot[grp], &s_fs[grp], s_x + grp * (3 * 1024), s_rounds,
+                              fl.id_row, sums, gauss_rows);
         return;
     }
     bx -= fl.wg[1];
     if (bx < fl.wg[2]) {
         const int grp = tid >> 6;
-        fit_tree_group<1, kFitShortBlocks>(memb_local, seg_off, table0, pick(2, bx * 16 + grp), tid & 63, s_blk + grp * kFitShortBlocks, s_tot[grp], s_mean[grp],
-                                           &s_rounds, sums);
+        fit_tree_group<1, kFitShortBlocks>(memb_local, seg_off, table0, pick(2, bx * 16 + grp), tid & 63, s_blk + grp * kFitShortBlocks, s_tot[grp], &s_fs[grp],
+                                           s_x + grp * (3 * 256), s_rounds, fl.id_row, sums, gauss_rows);
         return;
     }
-    rebalancing_weights_mirror_body(seg_off, counts, info12, &s_blk[0][0], &s_tot[0][0], &s_mean[0][0]);
-}
-void launch_gauss_fit_tree(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, int cls,
-                           int task0, int tasks, double* sums, hipStream_t s) {
-    if (tasks <= 0) return;
-    const float4* t0 = reinterpret_cast<const float4*>(table0);
-    if (cls == 0)
-        hipLaunchKernelGGL((k_gauss_fit_tree<16, 256>), dim3(tasks), dim3(1024), 0, s, memb_local, seg_off, t0, order, sc, cls, task0, sums);
-    else if (cls == 1)
-        hipLaunchKernelGGL((k_gauss_fit_tree<4, 64>), dim3(tasks), dim3(256), 0, s, memb_local, seg_off, t0, order, sc, cls, task0, sums);
-    else
-        hipLaunchKernelGGL((k_gauss_fit_tree<1, 4>), dim3(tasks), dim3(64), 0, s, memb_local, seg_off, t0, order, sc, cls, task0, sums);
 }
 void launch_gauss_fit_all(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, const int first[3],
-                          const int tasks[3], double* sums, GaussCounts* counts, float* info12, bool with_weights, hipStream_t s) {
+                          const int tasks[3], double* sums, GaussCounts* counts, float* info12, bool with_weights, int id_row, int2* gauss_rows, hipStream_t s) {
     FitLaunch fl;
     for (int c = 0; c < 3; ++c) fl.first[c] = first[c], fl.tasks[c] = tasks[c] > 0 ? tasks[c] : 0;
     fl.wg[0] = fl.tasks[0], fl.wg[1] = (fl.tasks[1] + 3) / 4, fl.wg[2] = (fl.tasks[2] + 15) / 16;
-    const int grid = fl.wg[0] + fl.wg[1] + fl.wg[2] + (with_weights ? 1 : 0);
+    fl.weights = with_weights ? 1 : 0, fl.id_row = id_row;
+    const int grid = fl.wg[0] + fl.wg[1] + fl.wg[2] + fl.weights;
     if (grid <= 0) return;
-    hipLaunchKernelGGL(k_gauss_fit_all, dim3(grid), dim3(1024), 0, s, memb_local, seg_off, reinterpret_cast<const float4*>(table0), order, sc, fl, sums, counts, info12);
+    // 48 KB of dynamic LDS on top of ~16 KB static: above the 64 KB a kernel gets without asking (per launch: the attribute belongs to the device)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gauss_fit_all), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFitLdsFloats * sizeof(float)));
+    hipLaunchKernelGGL(k_gauss_fit_all, dim3(grid), dim3(1024), kFitLdsFloats * sizeof(float), s, memb_local, seg_off, reinterpret_cast<const float4*>(table0), order, sc, fl,
+                       sums, counts, info12, gauss_rows);
 }
 void launch_gauss_fit_finish(const int32_t* seg_off, const GaussCounts* counts, const double* sums, int max_gauss, float* info12, hipStream_t s) {
     if (max_gauss > 0) hipLaunchKernelGGL(k_gauss_fit_finish, dim3((max_gauss + 255) / 256), dim3(256), 0, s, seg_off, counts, sums, info12);
@@ -1825,46 +1878,44 @@ __global__ __launch_bounds__(1024) void k_rebalancing_weights(const int32_t* __r
     if (threadIdx.x == 0) counts->weight_mean = mean;
     for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = info12[(size_t)g * 12 + 9] / mean;
 }
-// default path: VectorXf::mean() (Gaussians.h:176) in the oracle's order -- blocks of 64 weights reduced by the pairwise tree, block
-// sums added in order: the 16 waves take 16 blocks per round, thread 0 adds the round's sums
-__device__ void rebalancing_weights_mirror_body(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts, float* __restrict__ info12, double* s_slot /* [16] */,
-                                                double* s_tot /* [1] */, float* s_mean /* [1] */) {
+// default path: rebalancingWeights.head(M).mean() (Gaussians.h:176) in Eigen's own order -- the linear redux of M contiguous floats that
+// start at their aligned buffer (see fit_tree_group): the weights go through LDS 8192 at a time, eight lanes carry the chains
+__device__ void rebalancing_weights_mirror_body(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts, float* __restrict__ info12, float* sx /* [8192] */,
+                                                FitScratch* fs) {
+    constexpr int CH = 8192;
     const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
-    const int nblk = (M + kSumBlock - 1) / kSumBlock;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) *s_tot = 0.0;
-    __syncthreads();
-    for (int base = 0; base < nblk; base += 16) {
-        const int blk = base + wave;
-        if (blk < nblk) {
-            const int g = blk * kSumBlock + lane;
-            const double w = g < M ? (double)((1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f) : 0.0;
-            const double v = wave_allsum(w);
-            if (lane == 0) s_slot[wave] = v;
+    const ReduxPlan plan = redux_plan(M, 0);
+    float acc = -0.0f;
+    for (int m0 = 0; m0 < M; m0 += CH) {
+#pragma unroll
+        for (int u = 0; u < CH / 1024; ++u) {
+            const int il = u * 1024 + threadIdx.x, g = m0 + il;
+            if (g < M) {
+                const float w = (1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f;
+                sx[il] = w;
+                const int slot = redux_slot(plan, g);
+                if (slot >= 0) fs->sp[0][slot] = w;
+            }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double tot = *s_tot;
-            const int cnt = min(16, nblk - base);
-            for (int t = 0; t < cnt; ++t) tot += s_slot[t];
-            *s_tot = tot;
-        }
+        if (threadIdx.x < 8) acc = redux_chain(plan, threadIdx.x, m0, min(CH, M - m0), sx, acc);
         __syncthreads();
     }
+    if (threadIdx.x < 8) fs->acc[0][threadIdx.x] = acc;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        *s_mean = (float)(*s_tot / (double)M);
-        counts->weight_mean = *s_mean;
+        fs->mean[0] = redux_finish(plan, M, fs->acc[0], fs->sp[0]) / (float)M;
+        counts->weight_mean = fs->mean[0];
     }
     __syncthreads();
-    const float mean = *s_mean;
+    const float mean = fs->mean[0];
     for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = ((1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f) / mean;
 }
 __global__ __launch_bounds__(1024) void k_rebalancing_weights_mirror(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts,
                                                                      float* __restrict__ info12) {
-    __shared__ double s_slot[16];
-    __shared__ double s_tot;
-    __shared__ float s_mean;
-    rebalancing_weights_mirror_body(seg_off, counts, info12, s_slot, &s_tot, &s_mean);
+    __shared__ float s_x[8192];
+    __shared__ FitScratch s_fs;
+    rebalancing_weights_mirror_body(seg_off, counts, info12, s_x, &s_fs);
 }
 void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, bool mirror, hipStream_t s) {
     if (mirror)
@@ -2820,9 +2871,29 @@ typedef double d4v __attribute__((ext_vector_type(4)));
 constexpr int kMfmaRows = 64;
 // columns of A' = [J | e0] in place: E[k + 1][r] <- inv_h * (E[k + 1][r] - E[0][r]) (DmsaOptimizer.h:226), E[0] stays e0.  The residual
 // batch is consumed by the normal equations only, and every panel element is then ONE load for the 2 * nt tiles that need it.
-__global__ __launch_bounds__(256) void k_jacobian_columns(double* __restrict__ E, int64_t ldE, int rows, int P, double inv_h) {
+// With `skip` (serial_kernels.h: launch_eval_row_ranges / launch_gauss_fit_all), the pairs (Gaussian r, evaluation k + 1) whose pose-table
+// rows all have evaluation 0's bits were not computed: their residual IS E[0][r], so the column entry is inv_h * (e0 - e0).
+__global__ __launch_bounds__(256) void k_jacobian_columns(double* __restrict__ E, int64_t ldE, int rows, int P, double inv_h, const EvalSkip skip) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (r < rows) E[(size_t)(k + 1) * ldE + r] = inv_h * (E[(size_t)(k + 1) * ldE + r] - E[r]);
+    bool same = false;
+    if (skip.row_range != nullptr && r < skip.M) {
+        const int2 e = skip.row_range[k + 1], gr = skip.gauss_rows[r];
+        same = e.y < gr.x || e.x > gr.y;
+    }
+    bool bad = false;
+    if (r < rows) {
+        const double e0 = E[r];
+        double ek = same && !skip.check ? e0 : E[(size_t)(k + 1) * ldE + r];
+        if (same && skip.check) bad = __double_as_longlong(ek) != __double_as_longlong(e0);  // eval_skip = 2: the pair WAS computed and must agree
+        E[(size_t)(k + 1) * ldE + r] = inv_h * (ek - e0);
+    }
+    if (skip.stats != nullptr) {  // one counter pair per evaluation: thousands of waves adding to ONE address serialise (measured: +0.5 ms)
+        const unsigned long long n_same = __popcll(__ballot(same)), n_bad = __popcll(__ballot(bad));
+        if ((threadIdx.x & 63) == 0) {
+            if (n_same) atomicAdd(&skip.stats[2 * k], n_same);
+            if (n_bad) atomicAdd(&skip.stats[2 * k + 1], n_bad);
+        }
+    }
 }
 // element (column c of A', row r): c < P -> E[c + 1][r], c == P -> E[0][r], beyond -> 0
 __device__ __forceinline__ double ne_col_scaled(const double* __restrict__ E, int64_t ldE, int P, int c, int r) {
@@ -2891,12 +2962,12 @@ NormalEqPartials normal_equations_partials(int rows, int P) {
     q.nsplit = (rows + rs - 1) / rs;
     return q;
 }
-void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s, bool reduce) {
+void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s, bool reduce, const EvalSkip* skip) {
     const int nt = (P + 1 + kNeTile - 1) / kNeTile;
     const int rs = ne_rows_per_split(rows, P);
     const int nsplit = (rows + rs - 1) / rs;
     if (P > 64) {  // NOTE: turns the residual batch E into the columns of [J | e0] in place
-        hipLaunchKernelGGL(k_jacobian_columns, dim3((rows + 255) / 256, P), dim3(256), 0, s, const_cast<double*>(E), ldE, rows, P, inv_h);
+        hipLaunchKernelGGL(k_jacobian_columns, dim3((rows + 255) / 256, P), dim3(256), 0, s, const_cast<double*>(E), ldE, rows, P, inv_h, skip ? *skip : EvalSkip{});
         hipLaunchKernelGGL(k_normal_eq_mfma, dim3(nt * (nt + 1) / 2, nsplit), dim3(256), 0, s, E, ldE, rows, P, rs, nt, partial);
     } else
         hipLaunchKernelGGL(k_normal_eq_partial, dim3(nt * nt, nsplit, kNeQuarters), dim3(256), 0, s, E, ldE, rows, P, inv_h, rs, nt, partial);

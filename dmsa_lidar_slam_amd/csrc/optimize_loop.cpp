@@ -129,7 +129,7 @@ int ensure_E(dmsa_ctx* ctx, int B) {
     HIPCHK(ctx->d_E.ensure((size_t)B * ld * 8));
     return DMSA_OK;
 }
-int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const double* d_extra, const uint32_t* rot_same) {
+int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const double* d_extra, const uint32_t* rot_same, const int2* row_range) {
     CHK(ensure_E(ctx, B));
     if (ctx->tables_pending) {  // the pose tables of this batch were built on another stream (and k_size_classes did not wait for them)
         if (ctx->tables_dev_sync)
@@ -182,6 +182,7 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
         // fork and join of the tier streams: counters in device memory (loop_kernels.h) instead of events, whose barrier packets cost
         // 8-10 us per record / wait on `stream`; debug switch device_sync = 0 keeps the events
         const bool dev_sync = two && ctx->dbg.device_sync != 0;
+        const int2* gauss_rows = row_range ? ctx->d_gauss_rows.as<int2>() : nullptr;
         uint32_t* d_sync = nullptr;
         if (dev_sync) {
             d_sync = ctx->d_sync.as<uint32_t>();  // zeroed when the context was created
@@ -197,16 +198,16 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
             // latency tier first (with the signal), then the waits in front of the other tiers
             launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
                                     ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree,
-                                    d_sync + SYNC_TIER_FORK, 1, rot_same);
+                                    d_sync + SYNC_TIER_FORK, 1, rot_same, row_range, gauss_rows);
             enqueue_wait(ctx, SYNC_TIER_FORK, ctx->stream2);
             if (three) enqueue_wait(ctx, SYNC_TIER_FORK, ctx->stream3);
             launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
                                     ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree, nullptr, 6,
-                                    rot_same);
+                                    rot_same, row_range, gauss_rows);
         } else {
             launch_residuals_serial(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tablesT.as<float>(), B,
                                     ctx->d_order.as<uint32_t>(), ctx->serial_counts, ctx->d_E.as<double>(), ctx->ldE, s_long, s_mid, s_small, ctx->dbg.serial_tree,
-                                    nullptr, 7, rot_same);
+                                    nullptr, 7, rot_same, row_range, gauss_rows);
         }
         if (dev_sync) {
             launch_sync_signal(d_sync + SYNC_TIER_JOIN, ctx->stream2);
@@ -621,6 +622,18 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
     HIPCHK(ctx->d_tablesT.ensure((size_t)(P + 1) * ctx->rows * 48));
     HIPCHK(ctx->d_loop_extra.ensure((size_t)(1 + P + 9) * std::max(a, 1) * 8));
     HIPCHK(ctx->d_rot_same.ensure((size_t)(1 + P) * 4));
+    // Pairs (Gaussian, evaluation) whose pose-table rows all have evaluation 0's bits are not computed (serial_kernels.h).  Worth it where
+    // a Gaussian's evaluations fill several sub-batches of sixteen lanes, i.e. in the keyframe pass; the one consumer that then has to know
+    // is the Jacobian column kernel of the matrix-core normal equations (P > 64).
+    const int skip_mode = P > kLoopSolveMaxP ? ctx->dbg.eval_skip : 0;
+    if (skip_mode != 0) {
+        HIPCHK(ctx->d_row_range.ensure((size_t)(1 + P) * 8));
+        if ((size_t)P * 16 > ctx->d_skip_stats.cap) {  // per evaluation: pairs left out, pairs that differed under eval_skip = 2
+            HIPCHK(ctx->d_skip_stats.ensure((size_t)P * 16));
+            HIPCHK(hipMemsetAsync(ctx->d_skip_stats.p, 0, ctx->d_skip_stats.cap, ctx->stream));
+            ctx->skip_stats_evals = P;
+        }
+    }
     HIPCHK(ctx->d_loop_iter.ensure(sizeof(LoopFlags) + (size_t)(num_iter + 1) * sizeof(IterResult)));
     HIPCHK(ctx->d_Hp.ensure((size_t)(P + 1) * (P + 1) * 8));
     HIPCHK(ctx->d_sq_out.ensure(16 * 8));
@@ -693,6 +706,9 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         uint32_t* rot_same = ctx->dbg.shared_rotations != 0 ? ctx->d_rot_same.as<uint32_t>() : nullptr;
         CHK(device_tables(ctx, 1 + P, ctx->d_ctrl.as<double>(), ctx->d_tables.as<float>(), ctx->d_tablesT.as<float>(), side, rot_same));
         ctx->batch = 1 + P, ctx->tablesT_batch = 1 + P;
+        if (skip_mode != 0)
+            launch_eval_row_ranges(m.model, ctx->d_ctrl.as<double>(), 1 + P, n, ctx->d_stamps.as<double>(), ctx->d_trajtime.as<double>(), ctx->rows - 1,
+                                   ctx->d_row_range.as<int2>(), side);
         if (dev_sync) {  // the main stream picks the tables up in k_size_classes (or, if that kernel is not launched, in run_residuals)
             launch_sync_signal(ctx->sync_counter(SYNC_TABLES), side);
             ctx->sync_sig[SYNC_TABLES] += 1;
@@ -721,14 +737,19 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             break;
         }
         ctx->evaluations += 1 + P;
-        CHK(run_residuals(ctx, 1 + P, nullptr, d_extra_jac, rot_same));
+        if (skip_mode != 0) ctx->skip_pairs += (int64_t)ctx->M * P;
+        CHK(run_residuals(ctx, 1 + P, nullptr, d_extra_jac, rot_same, skip_mode == 1 ? ctx->d_row_range.as<int2>() : nullptr));
         const int rowsE = ctx->M + ctx->extra_rows;
         {
             ScopedTimer tm(ctx, T_NORMAL);
             HIPCHK(ctx->d_ne_partial.ensure((size_t)normal_equations_partial_doubles(rowsE, P) * 8));
+            EvalSkip skip;
+            if (skip_mode != 0)
+                skip.row_range = ctx->d_row_range.as<int2>(), skip.gauss_rows = ctx->d_gauss_rows.as<int2>(), skip.M = ctx->M, skip.check = skip_mode == 2 ? 1 : 0,
+                skip.stats = ctx->d_skip_stats.as<unsigned long long>();
             // P <= 64: the block sums stay unreduced, the solve kernel adds them while it loads the matrix
             launch_normal_equations(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, one_div_incr, ctx->d_ne_partial.as<double>(), ctx->d_Hp.as<double>(), ctx->stream,
-                                    P > kLoopSolveMaxP);
+                                    P > kLoopSolveMaxP, skip_mode != 0 ? &skip : nullptr);
         }
         bool host_nan = false;
         double* d_error0 = ctx->d_Hp.as<double>() + (size_t)P * (P + 1) + P;  // e0^T e0, element (P, P) of Hp

@@ -34,7 +34,16 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
                              int tree_mode = 1 /* dmsa_debug_options::serial_tree */,
                              uint32_t* start_signal = nullptr /* counter the latency tier adds one to once all its workgroups are placed (loop_kernels.h: launch_sync_wait) */,
                              int tiers = 7 /* bit 0: latency tier, bit 1: throughput tier, bit 2: short tier */,
-                             const uint32_t* rot_same = nullptr /* [B] from the pose-table kernels: evaluations whose rotations are evaluation 0's */);
+                             const uint32_t* rot_same = nullptr /* [B] from the pose-table kernels: evaluations whose rotations are evaluation 0's */,
+                             const int2* row_range = nullptr /* [B] launch_eval_row_ranges; with gauss_rows: (Gaussian, evaluation) pairs whose rows all equal
+                                                                evaluation 0's are NOT computed and their E entries are left untouched */,
+                             const int2* gauss_rows = nullptr /* [M] launch_gauss_fit_all */);
+// row_range[b] = (first, last) pose-table row of evaluation b whose INPUTS differ from evaluation 0's bit for bit -- (INT_MAX, -1) if
+// none, (0, INT_MAX) for b = 0 -- from the global poses of the batch, ctrl[B][np][6].  model 2 (keyframes): row k is a function of pose k
+// alone (MapManagement.h:120-149).  model 1 (window): the rotation of dense pose j is a function of the two control rotations around it,
+// its translation of ALL control translations (Floater-Hormann), ContinuousTrajectory.h:189-226.  Same inputs, same instructions, same
+// bits: a conservative test (a row whose inputs differ may still round to the same floats).
+void launch_eval_row_ranges(int model, const double* ctrl, int B, int np, const double* stamps, const double* traj_time, int n_t, int2* row_range, hipStream_t s);
 // LDS / shape parameters chosen for a batch of B evaluations (exposed for the bench's roofline notes and the tests)
 struct SerialShape {
     int nsub_long, Bs_long;  // latency tier: evaluation sub-batches per Gaussian, evaluations per sub-batch

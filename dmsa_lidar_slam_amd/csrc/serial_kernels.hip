@@ -171,6 +171,33 @@ __device__ __forceinline__ f2 mahalanobis_v(const Info& I, const f2 gx, const f2
 
 }  // namespace
 
+// ---- evaluations that need computing ------------------------------------------------------------------------------------------
+// Evaluation b of a Jacobian batch differs from evaluation 0 in a contiguous range of pose-table rows, row_range[b] (k_eval_row_ranges:
+// perturbing relative pose k of the keyframe chain leaves the frames in front of k untouched, ConsecutivePoses.h:26-43); a Gaussian
+// reads the rows gauss_rows[g] (fit kernel).  If the two do not meet, every operand of the pair (g, b) has the bits of evaluation 0's
+// and so has its residual: the pair is not computed (the Jacobian column kernel puts E[0][g] in its place).  The lanes of a group
+// therefore do not stand for evaluations sub * L .. sub * L + L - 1 but for the sub-th run of L evaluations that DO need computing.
+// Executed by the L lanes of a group (gshift: the group's first lane): list[r] = the evaluation of rank r0 + r among the active ones,
+// r < cap; returns how many of the cap slots are filled.
+template <int L>
+__device__ __forceinline__ int build_eval_list(const int2* __restrict__ row_range, const int2 gr, int B, int r0, int cap, int* list, int bl, int gshift) {
+    int base = 0;
+    for (int c0 = 0; c0 < B; c0 += L) {
+        const int b = c0 + bl;
+        bool act = false;
+        if (b < B) {
+            const int2 e = row_range[b];
+            act = b == 0 || !(e.y < gr.x || e.x > gr.y);
+        }
+        unsigned long long m = __ballot(act);
+        if (L < 64) m = (m >> gshift) & ((1ull << (L & 63)) - 1ull);
+        const int r = base + __popcll(m & ((1ull << bl) - 1ull)) - r0;
+        if (act && r >= 0 && r < cap) list[r] = b;
+        base += __popcll(m);
+    }
+    return min(max(base - r0, 0), cap);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // size classes: one workgroup sorts the Gaussians by descending size class (counting sort in LDS)
 // ------------------------------------------------------------------------------------------------------------
@@ -264,6 +291,50 @@ __global__ __launch_bounds__(1024) void k_size_classes(const int32_t* __restrict
     dev_sync_leave(sy);  // the counts are final: their read-back (another stream) may start
 }
 
+__global__ __launch_bounds__(64) void k_eval_row_ranges(int model, const double* __restrict__ ctrl, int np, const double* __restrict__ stamps,
+                                                        const double* __restrict__ traj_time, int n_t, int2* __restrict__ row_range) {
+    __shared__ int s_rot[64];  // window: control rotation c of this evaluation differs from evaluation 0's
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b == 0) {
+        if (lane == 0) row_range[0] = make_int2(0, INT_MAX);
+        return;
+    }
+    const double* mine = ctrl + (size_t)b * np * 6;
+    auto differs = [&](int pose, int first, int count) {
+        bool d = false;
+        for (int a = first; a < first + count; ++a) d = d || __double_as_longlong(mine[6 * pose + a]) != __double_as_longlong(ctrl[6 * pose + a]);
+        return d;
+    };
+    int lo = INT_MAX, hi = -1;
+    if (model == 2) {
+        for (int k = lane; k < np; k += 64)
+            if (differs(k, 0, 6)) lo = min(lo, k), hi = max(hi, k);
+    } else {
+        bool tr = false;
+        for (int c = lane; c < np; c += 64) tr = tr || differs(c, 3, 3);
+        const bool any_tr = __ballot(tr) != 0ull;
+        if (any_tr) {
+            lo = 0, hi = n_t - 1;  // every dense translation is a function of every control translation
+        } else {
+            for (int c = lane; c < min(np, 64); c += 64) s_rot[c] = differs(c, 0, 3) ? 1 : 0;
+            __syncthreads();
+            for (int j = lane; j < n_t; j += 64) {
+                const double t = traj_time[j];
+                int right = 0;  // getInterpRotation: lower_bound over stamps[0 .. C-2]
+                while (right < np - 1 && stamps[right] < t) ++right;
+                const bool d = right > 0 ? (s_rot[right - 1] | s_rot[right]) != 0 : s_rot[0] != 0;
+                if (d) lo = min(lo, j), hi = max(hi, j);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) lo = min(lo, __shfl_xor(lo, m)), hi = max(hi, __shfl_xor(hi, m));
+    if (lane == 0) row_range[b] = make_int2(lo, hi);
+}
+void launch_eval_row_ranges(int model, const double* ctrl, int B, int np, const double* stamps, const double* traj_time, int n_t, int2* row_range, hipStream_t s) {
+    if (B > 0) hipLaunchKernelGGL(k_eval_row_ranges, dim3(B), dim3(64), 0, s, model, ctrl, np, stamps, traj_time, n_t, row_range);
+}
+
 __global__ __launch_bounds__(256) void k_transpose_tables(const float4* __restrict__ tables, int rows, int B, float4* __restrict__ tablesT) {
     const int total = rows * B * 3;
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
@@ -278,14 +349,23 @@ __global__ __launch_bounds__(256) void k_transpose_tables(const float4* __restri
 template <int L>
 __device__ __forceinline__ void small_wave(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12,
                                            const float4* __restrict__ tabT, int B, const uint32_t* __restrict__ order, int n_items_g, int nsub,
-                                           double* __restrict__ E, int64_t ldE, int wave_index) {
+                                           double* __restrict__ E, int64_t ldE, int wave_index, const int2* __restrict__ row_range,
+                                           const int2* __restrict__ gauss_rows, int* list /* 64 ints of this wave */) {
     constexpr int G = 64 / L;  // Gaussians per wave
     const int lane = threadIdx.x & 63, grp = lane / L, bl = lane % L;
     const int item = wave_index * G + grp;
     const int gi = item / nsub, sub = item - gi * nsub;
-    const int b = sub * L + bl;
-    const bool on = gi < n_items_g && b < B;
     const int g = gi < n_items_g ? (int)order[gi] : 0;
+    int b = sub * L + bl;
+    bool on = gi < n_items_g && b < B;
+    if (row_range != nullptr) {  // the sub-th run of L evaluations that can differ from evaluation 0 for this Gaussian (build_eval_list)
+        const int2 gr = gi < n_items_g ? gauss_rows[g] : make_int2(INT_MAX, -1);
+        const int cnt = build_eval_list<L>(row_range, gr, B, sub * L, L, list + grp * L, bl, grp * L);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        on = gi < n_items_g && bl < cnt;
+        b = on ? list[grp * L + bl] : 0;
+    }
     const int off0 = gi < n_items_g ? seg_off[g] : 0;
     const int n = on ? seg_off[g + 1] - off0 : 0;
     int nmax = n;  // longest member list of the wave's groups (sorted by size: nearly equal)
@@ -347,8 +427,10 @@ template <int L>
 __global__ __launch_bounds__(256, DMSA_SMALL_WAVES) void k_residuals_small(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off,
                                                          const float4* __restrict__ info12, const float4* __restrict__ tabT, int B,
                                                          const uint32_t* __restrict__ order, int n_items_g, int nsub, double* __restrict__ E,
-                                                         int64_t ldE) {
-    small_wave<L>(memb, seg_off, info12, tabT, B, order, n_items_g, nsub, E, ldE, (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+                                                         int64_t ldE, const int2* __restrict__ row_range, const int2* __restrict__ gauss_rows) {
+    __shared__ int s_list[4][64];
+    small_wave<L>(memb, seg_off, info12, tabT, B, order, n_items_g, nsub, E, ldE, (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), row_range, gauss_rows,
+                  s_list[threadIdx.x >> 6]);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -412,7 +494,7 @@ template <int kProd, bool kSepLoader, int kChunk>
 __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader ? DMSA_LONG_WAVES : DMSA_MID_WAVES) void k_residuals_chain(
     const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12, const float4* __restrict__ tabT, int B,
     const uint32_t* __restrict__ order, int Bs, int nsub, int prio, int tree_mode, double* __restrict__ E, int64_t ldE, uint32_t* start_signal,
-    const uint32_t* __restrict__ rot_same) {
+    const uint32_t* __restrict__ rot_same, const int2* __restrict__ row_range, const int2* __restrict__ gauss_rows) {
     // tree_mode 0: second pass as a chain (the reference's loop, pipelined); 1: parallel second pass, chain only if the exactness test
     // fails; 2: parallel pass computed, then the chain anyway (test hook)
     constexpr int kProducers = kProd;
@@ -425,6 +507,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     __shared__ float s_mean[3 * kBL];
     __shared__ __attribute__((aligned(16))) float4 s_m[4][kChunk];  // member ring (filled by LDS-DMA)
     __shared__ int s_chain;  // the parallel second pass failed its test for some evaluation
+    __shared__ int s_evals[kBL], s_nb;  // the evaluations of this workgroup's lanes (build_eval_list) and how many there are
     double* s_t = reinterpret_cast<double*>(s_q);
 
     // Fork of the tier streams (launch_sync_wait in front of the other tiers): the LAST workgroup of the latency tier releases them, i.e.
@@ -435,8 +518,20 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     const int item = blockIdx.x, gi = item / nsub, sub = item - gi * nsub;
     const int g = (int)order[gi];
     const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
-    const int b0 = sub * Bs, nb = min(Bs, B - b0);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        int cnt;
+        if (row_range != nullptr) {  // the sub-th run of Bs evaluations that can differ from evaluation 0 for this Gaussian
+            cnt = build_eval_list<64>(row_range, gauss_rows[g], B, sub * Bs, Bs, s_evals, lane, 0);
+        } else {
+            cnt = min(Bs, B - sub * Bs);
+            if (lane < Bs) s_evals[lane] = sub * Bs + lane;
+        }
+        if (lane == 0) s_nb = cnt;
+    }
+    __syncthreads();
+    const int nb = s_nb;
+    if (nb <= 0) return;  // every evaluation of this sub-batch equals evaluation 0 for this Gaussian (or the Gaussian has fewer sub-batches)
     const int nchunks = (n + kChunk - 1) / kChunk;
     const int nphases = nchunks + 2;
 
@@ -447,7 +542,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         if (tree_mode == 0) return false;
         const int mpl = 64 / Bs, ms2 = lane / Bs, pb2 = lane - ms2 * Bs;  // members per wave step
         const bool lane_on2 = ms2 < mpl && pb2 < nb;
-        const int bcol2 = b0 + (pb2 < nb ? pb2 : 0);
+        const int bcol2 = s_evals[pb2 < nb ? pb2 : 0];
         const float mx2 = s_mean[pb2 & 15], my2 = s_mean[kBL + (pb2 & 15)], mz2 = s_mean[2 * kBL + (pb2 & 15)];
         const Info I2 = load_info(info12, g);
         if (threadIdx.x == 0) s_chain = 0;
@@ -466,7 +561,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         // control rotations bit for bit -- nothing is assumed about the model (the window with IMU rows never qualifies: its round trip
         // through the preintegration factors touches relative pose 0 in every evaluation).
         bool shared_rot = false;
-        if (rot_same != nullptr && b0 > 0) shared_rot = __ballot(lane < nb && rot_same[b0 + lane] == 0u) == 0ull;
+        if (rot_same != nullptr) shared_rot = __ballot(lane < nb && rot_same[s_evals[lane]] == 0u) == 0ull;
         if (shared_rot) {
             static_assert((size_t)kWaves * (48 + 64) * 16 <= sizeof(float) * kSlots * kSlotFloats, "second-pass staging does not fit the ring");
             float4* stage = reinterpret_cast<float4*>(s_q) + kWaves * 48 + wave * 64;  // behind the reduction scratch (kWaves x 64 x 12 bytes)
@@ -545,7 +640,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
             // rounded: < n 2^-53 relative
             const bool exact = k > 0 && U * (1.0 + 0x1p-30) < limit && tree_mode == 1;
             if (exact)
-                E[(size_t)(b0 + lane) * ldE + g] = sqrt(fabs(U));
+                E[(size_t)s_evals[lane] * ldE + g] = sqrt(fabs(U));
             else
                 s_chain = 1;
         }
@@ -645,7 +740,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
                 TL_BARRIER(1, p);
             }
         }
-        if (on2) E[(size_t)(b0 + lane) * ldE + g] = sqrt(fabs(dacc));
+        if (on2) E[(size_t)s_evals[lane] * ldE + g] = sqrt(fabs(dacc));
         return;
     }
 
@@ -662,7 +757,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     const int steps = (kChunk / 2 + mps - 1) / mps;       // steps per chunk
     const int ms = lane / Bs, pb = lane - ms * Bs;
     const bool lane_on = ms < mps && pb < nb;
-    const int bcol = b0 + (pb < nb ? pb : 0);
+    const int bcol = s_evals[pb < nb ? pb : 0];
     const int last = n - 1;
     Rows rc;  // the pose-table row of this lane's evaluation that the last member used, and its index
     int rc_row = -1;
@@ -826,7 +921,7 @@ void launch_transpose_tables(const float* tables, int rows, int B, float* tables
 }
 void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tablesT, int B, const uint32_t* order,
                              const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small, int tree_mode,
-                             uint32_t* start_signal, int tiers, const uint32_t* rot_same) {
+                             uint32_t* start_signal, int tiers, const uint32_t* rot_same, const int2* row_range, const int2* gauss_rows) {
     if (B <= 0) return;
     const SerialShape sh = serial_shape(B);
     const float4* info = reinterpret_cast<const float4*>(info12);
@@ -835,21 +930,21 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
     // latency tier first (its longest chain bounds the batch), blocks in descending size; the other tiers fill the chip around it
     if (n_long > 0 && (tiers & 1))
         hipLaunchKernelGGL((k_residuals_chain<8, true, DMSA_LONG_CHUNK>), dim3((unsigned)n_long * sh.nsub_long), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
-                           sh.Bs_long, sh.nsub_long, 2, tree_mode, E, ldE, start_signal, rot_same);
+                           sh.Bs_long, sh.nsub_long, 2, tree_mode, E, ldE, start_signal, rot_same, row_range, gauss_rows);
     if (n_mid > 0 && (tiers & 2))
         hipLaunchKernelGGL((k_residuals_chain<4, false, 32>), dim3((unsigned)n_mid * sh.nsub), dim3(64 * 5), 0, s_rest, memb_local, seg_off, info, tabT, B,
-                           order + n_long, sh.Bs, sh.nsub, 0, tree_mode, E, ldE, (uint32_t*)nullptr, rot_same);
+                           order + n_long, sh.Bs, sh.nsub, 0, tree_mode, E, ldE, (uint32_t*)nullptr, rot_same, row_range, gauss_rows);
     if (sc.n_small > 0 && (tiers & 4)) {
         const int items = sc.n_small * sh.nsub_small;
         const int per_block = 4 * (64 / sh.lanes);
         const dim3 grid((items + per_block - 1) / per_block);
         const uint32_t* ord = order + sc.n_chain;
         if (sh.lanes == 16)
-            hipLaunchKernelGGL(k_residuals_small<16>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
+            hipLaunchKernelGGL(k_residuals_small<16>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE, row_range, gauss_rows);
         else if (sh.lanes == 32)
-            hipLaunchKernelGGL(k_residuals_small<32>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
+            hipLaunchKernelGGL(k_residuals_small<32>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE, row_range, gauss_rows);
         else
-            hipLaunchKernelGGL(k_residuals_small<64>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE);
+            hipLaunchKernelGGL(k_residuals_small<64>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE, row_range, gauss_rows);
     }
 #ifdef DMSA_SERIAL_TIMELINE
     if (n_long > 0) {

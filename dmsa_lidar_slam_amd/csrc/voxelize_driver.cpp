@@ -285,7 +285,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         {
             // one launch for the three size classes and the rebalancing weights: no fork to a second stream, no join
             launch_gauss_fit_all(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, first, tasks,
-                                 ctx->d_fit_sums.as<double>(), counts, ctx->d_info12.as<float>(), true, ctx->stream);
+                                 ctx->d_fit_sums.as<double>(), counts, ctx->d_info12.as<float>(), true, ctx->rows - 1, ctx->d_gauss_rows.as<int2>(), ctx->stream);
         }
         launch_gauss_fit_finish(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_fit_sums.as<double>(), finish_gauss, ctx->d_info12.as<float>(), ctx->stream);
         HIPCHK(hipGetLastError());

@@ -51,6 +51,16 @@ typedef struct dmsa_debug_options {
                                      speculative sort width is wrong and the voxelisation runs again                                       */
 } dmsa_debug_options;
 
+/* what the switches above leave behind, since the context was created */
+typedef struct dmsa_debug_counters {
+    int64_t sync_retries;         /* whole calls run again with event dependencies after a device-side wait gave up           */
+    int64_t speculation_retries;  /* voxelisations run again because the speculated sort width was too small                  */
+    int64_t skip_pairs;           /* (Gaussian, evaluation) pairs of the Jacobian batches the eval_skip logic looked at       */
+    int64_t skip_pairs_equal;     /* ... of which had the pose-table rows of evaluation 0 (eval_skip = 1: were not computed) */
+    int64_t skip_mismatches;      /* eval_skip = 2 only: such pairs whose computed residual differed from evaluation 0's      */
+} dmsa_debug_counters;
+int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out);
+
 void dmsa_default_debug_options(dmsa_debug_options* o);
 /* dmsa_create with explicit switches (`options` may be NULL = defaults); DMSA_DEBUG still overrides by name. */
 int dmsa_create_ex(int device, uint32_t flags, const dmsa_debug_options* options, dmsa_ctx** out);

@@ -137,3 +137,133 @@ def test_many_contexts_in_one_process_share_hardware_queues(hip, orc):
         o.close()
     for p in results:
         assert np.array_equal(p.relOrientations, p_ref.relOrientations) and np.array_equal(p.relTranslations, p_ref.relTranslations)
+
+
+def _run_keep(hip, prob, s, debug=None):
+    p = prob.copy()
+    opt = hip.DmsaOptimizer(debug=debug)
+    rep = opt.optimizeSet(p, s)
+    return (p, rep, opt.trace()), opt
+
+
+def test_pairs_equal_to_evaluation_0_are_left_out_of_the_jacobian_batch(hip, orc):
+    """Perturbing relative pose k of the keyframe chain leaves the frames in front of k bit-identical (ConsecutivePoses.h:26-43,
+    MapManagement.h:197-202), so a Gaussian whose members all lie in earlier frames has the residual of evaluation 0 in that evaluation.
+    Default (eval_skip = 1): such (Gaussian, evaluation) pairs are not computed.  eval_skip = 0 computes every pair, eval_skip = 2 computes
+    every pair AND compares the ones 1 would have left out with evaluation 0 bit for bit.  Same poses, same traces, zero mismatches -- at
+    P = 72 and at the P = 186 of the bench's neighbourhoods, through the matrix-core normal equations."""
+    for frames, iters in ((13, 3), (32, 2)):
+        prob = synth.keyframe_problem(seed=4, frames=frames, rings=16, az_steps=96, arc=0.8 if frames == 13 else 2.0)
+        s = DmsaOptimSettings.keyframe_map(num_iter=iters)
+        p_ref = prob.copy()
+        rep_ref, _, tr_ref = orc.optimize_keyframes(p_ref, s)
+        skip, o1 = _run_keep(hip, prob, s)
+        full, o0 = _run_keep(hip, prob, s, debug={"eval_skip": 0})
+        both, o2 = _run_keep(hip, prob, s, debug={"eval_skip": 2})
+        _same(skip, (p_ref, rep_ref, tr_ref))
+        _same(skip, full)
+        _same(skip, both)
+        c1, c0, c2 = o1.debugCounters(), o0.debugCounters(), o2.debugCounters()
+        for o in (o0, o1, o2):
+            o.close()
+        P = 6 * (frames - 1)
+        assert c0["skip_pairs"] == 0  # switched off: nobody looks
+        assert c1["skip_pairs"] == c2["skip_pairs"] == sum(t["M"] for t in tr_ref[: rep_ref.iterations]) * P
+        assert c1["skip_pairs_equal"] == c2["skip_pairs_equal"] > 0.1 * c1["skip_pairs"], c1  # a real share of the batch (these frames overlap a lot)
+        assert c2["skip_mismatches"] == 0 and c1["skip_mismatches"] == 0
+        print(f"[eval_skip] frames={frames} P={P}: {c1['skip_pairs_equal']} of {c1['skip_pairs']} pairs left out ({100.0 * c1['skip_pairs_equal'] / c1['skip_pairs']:.1f} %)")
+
+
+def test_a_timed_out_device_side_wait_restarts_the_call_with_events(hip, orc):
+    """Debug switch sync_fault = k withholds the signal of the k-th device-side wait of a call (csrc/dev_sync.h): the wait gives up, its
+    consumer runs before its producer may have finished, nothing of the run can be trusted.  The library restores the state the call
+    started from (poses AND the static points, which centralize / decentralize does not round-trip exactly), switches the context to
+    event dependencies and runs the call again: same result as an undisturbed run, DMSA_OK with a warning, and the context keeps working."""
+    prob = synth.window_problem(seed=31, scans=3, rings=32, az_steps=256, num_static=4000)
+    s = DmsaOptimSettings.sliding_window(num_iter=5)
+    clean = _run(hip, prob, s)
+    for k in (1, 4, 9):
+        got, opt = _run_keep(hip, prob, s, debug={"sync_fault": k})
+        _same(clean, got)
+        c = opt.debugCounters()
+        assert c["sync_retries"] == 1, c
+        assert "warning" in opt.lastError() and "timed out" in opt.lastError()
+        p2 = prob.copy()  # the same context again: event dependencies now, no further retry
+        rep2 = opt.optimizeSet(p2, s)
+        _same(clean, (p2, rep2, opt.trace()))
+        assert opt.debugCounters()["sync_retries"] == 1
+        opt.close()
+    kf = synth.keyframe_problem(seed=4, frames=13, rings=16, az_steps=96, arc=0.8)
+    sk = DmsaOptimSettings.keyframe_map(num_iter=3)
+    got, opt = _run_keep(hip, kf, sk, debug={"sync_fault": 3})
+    _same(_run(hip, kf, sk), got)
+    assert opt.debugCounters()["sync_retries"] == 1
+    opt.close()
+
+
+def test_a_wrong_sort_width_guess_reruns_the_voxelisation(hip, orc):
+    """The radix sort of the voxel keys is sized from the PREVIOUS iteration's tree depth (csrc/voxelize_driver.cpp); a guess that turns
+    out too small is seen with the counts and the voxelisation runs again, synchronously.  Debug switch speculation_fault = k plants a
+    depth one too small in the k-th voxelisation of a call: same result, one retry counted; the cost of the branch is printed."""
+    import time
+
+    prob = synth.window_problem(seed=31, scans=3, rings=32, az_steps=256, num_static=4000)
+    s = DmsaOptimSettings.sliding_window(num_iter=5)
+    clean = _run(hip, prob, s)
+
+    def timed(debug):
+        opt = hip.DmsaOptimizer(fixed_iters=True, debug=debug)
+        best = 1e9
+        for _ in range(3):
+            p = prob.copy()
+            opt.upload(p)
+            t0 = time.perf_counter()
+            opt.optimizeResident(s)
+            best = min(best, time.perf_counter() - t0)
+        c = opt.debugCounters()
+        opt.close()
+        return best, c
+
+    for k in (2, 3):
+        got, opt = _run_keep(hip, prob, s, debug={"speculation_fault": k})
+        _same(clean, got)
+        assert opt.debugCounters()["speculation_retries"] == 1
+        opt.close()
+    t_clean, c_clean = timed(None)
+    t_fault, c_fault = timed({"speculation_fault": 3})
+    assert c_clean["speculation_retries"] == 0 and c_fault["speculation_retries"] == 3
+    print(f"[speculation] 5 iterations: {1e3 * t_clean:.3f} ms clean, {1e3 * t_fault:.3f} ms with one mis-speculated voxelisation "
+          f"(+{1e3 * (t_fault - t_clean):.3f} ms per wrong guess)")
+
+
+def test_optimize_pose_tables_optimize_on_one_context(hip, orc):
+    """Regression (advisor, round 3): a pose-table call that regrows the pinned control-pose ring between two optimize calls used to free
+    the pinned per-iteration result buffer of the device loop without forgetting it."""
+    prob = synth.keyframe_problem(seed=4, frames=13, rings=16, az_steps=96, arc=0.8)
+    s = DmsaOptimSettings.keyframe_map(num_iter=2)
+    p_ref = prob.copy()
+    rep_ref, _, tr_ref = orc.optimize_keyframes(p_ref, s)
+    opt = hip.DmsaOptimizer()
+    p = prob.copy()
+    rep = opt.optimizeSet(p, s)
+    _same((p, rep, opt.trace()), (p_ref, rep_ref, tr_ref))
+    P = 6 * (prob.numFrames - 1)
+    params = np.tile(np.concatenate([prob.relOrientations[1:].reshape(-1), prob.relTranslations[1:].reshape(-1)]), (1 + P, 1))
+    opt.poseTables(params)  # 1 + P evaluations: larger than anything the ring has held so far
+    for _ in range(2):
+        p = prob.copy()
+        rep = opt.optimizeSet(p, s)
+        _same((p, rep, opt.trace()), (p_ref, rep_ref, tr_ref))
+    opt.close()
+
+
+def test_a_keyframe_set_whose_chain_state_outgrows_64_kb_of_lds(hip):
+    """Regression (advisor, round 3): the chain kernels keep (30 n + 2 P + rows) doubles in dynamic LDS -- above ~185 frames that is more
+    than the 64 KB a kernel gets without asking, and every launch failed.  Now the limit is raised (160 KB: ~470 frames) and larger sets go
+    to the host-driven loop.  200 frames of a few hundred points: P = 1194, beyond the panel solve too (host solve inside the device loop).
+    Checked against the host-driven loop (which the smaller cases above pin to the oracle; the oracle itself needs minutes at this P)."""
+    prob = synth.keyframe_problem(seed=8, frames=200, rings=8, az_steps=48, arc=5.5)
+    s = DmsaOptimSettings.keyframe_map(num_iter=2)
+    dev = _run(hip, prob, s)
+    assert dev[1].iterations == 2 and dev[1].num_gaussians > 1000
+    _same(dev, _run(hip, prob, s, debug={"device_loop": 0}))

@@ -124,10 +124,11 @@ def test_gaussian_sets_bit_exact_and_info_close(hip, orc, small_window):
     seg, memb, info, w = opt.gaussians()
     assert np.array_equal(seg, ref.seg_offset)
     assert np.array_equal(memb, ref.members)
-    # same operation sequence (double accumulation, float Jacobi): equal up to the summation order of the double sums
+    # opt-in fast sums: double accumulation in a wave-parallel order against the oracle's Eigen-order float mean and blocked double sums
+    # -- equal up to the last bits of the mean (the drop-in path is compared bit for bit in test_golden.py / test_gpu_configs.py)
     scale = np.abs(ref.info).max(axis=1, keepdims=True)
     assert (np.abs(info - ref.info) / scale).max() < 1e-5
-    assert np.mean(info == ref.info) > 0.99
+    assert np.mean(info == ref.info) > 0.9
     assert np.abs(w - ref.weights).max() <= 1.2e-7 * np.abs(ref.weights).max()
 
 
@@ -230,7 +231,7 @@ def test_optimize_window_fast_path_equivalent(hip, orc, small_window, host_table
     assert rep.iterations == rep_ref.iterations and rep.stop_reason == rep_ref.stop_reason
     tr = opt.trace()
     assert (trace[0]["M"], trace[0]["Mm"]) == (tr[0]["M"], tr[0]["Mm"])
-    assert abs(trace[0]["error0"] - tr[0]["error0"]) <= 1e-8 * trace[0]["error0"]
+    assert abs(trace[0]["error0"] - tr[0]["error0"]) <= 5e-7 * trace[0]["error0"]  # (float means: the fit's in Eigen's order, the fast path's rounded from double)
     for a, b in zip(trace, tr):
         assert abs(a["error0"] - b["error0"]) <= 5e-3 * a["error0"]
     assert tr[-1]["error0"] < tr[0]["error0"]  # it optimises
