@@ -11,6 +11,14 @@ window        'DMSAWN01' | int32 C | int32 n_total | int64 N | int64 S | float32
               float32 xyz_local[4N] | int32 tform_idx[N] | int32 ring_id[N] | float32 xyz_static[4S] | int32 ring_id_static[S]
               (IMU rows are not dumped: use_imu must be 0 for the reference harness)
 poses         'DMSAPO01' | int32 F | int32 pad | float64 rel_orient[3F] | float64 rel_transl[3F]
+stage dump    'DMSAST01' | int32 model (1 window, 2 keyframes) | int32 P | int32 a | int32 M | int32 M_level1 | int32 table_rows | int64 Mm | int64 n |
+              float32 table[table_rows x 12] ([R | t] row-major per pose-table row, the start poses as the optimiser sees them) |
+              float32 global_xyz[4n] | float32 global_normal[4n] (keyframes only) | int32 seg_offset[M+1] | int32 members[Mm] |
+              float32 info_mats[9M] (column-major) | float32 weights[M] | float64 error_vec[M+a] | float64 jacobian[(M+a) x P] (column-major) |
+              float64 H[P x P] (lambda on the diagonal) | float64 step_raw[P] | float64 step_clamped[P] | float64 error0 | int32 best_k | int32 pad |
+              float64 params_after_line_search[P]
+              -- iteration 0 of optimizeSet, stage by stage: written by oracle/ref_harness/ref_main.cpp from the REAL reference (a class derived
+              from DmsaOptimizer reaches its protected members) and by the oracle (orc_stage_dump_*), compared in tests/test_ref_fixtures.py
 """
 from __future__ import annotations
 
@@ -53,3 +61,34 @@ def read_poses(path: str):
         ro = np.frombuffer(fh.read(24 * f), "<f8").reshape(f, 3).copy()
         rt = np.frombuffer(fh.read(24 * f), "<f8").reshape(f, 3).copy()
     return ro, rt
+
+
+def read_stage_dump(path: str) -> dict:
+    """'DMSAST01': every intermediate result of iteration 0 of optimizeSet (see the module docstring)."""
+    with open(path, "rb") as fh:
+        assert fh.read(8) == b"DMSAST01", path
+        model, P, a, M, M1, rows = struct.unpack("<6i", fh.read(24))
+        Mm, n = struct.unpack("<qq", fh.read(16))
+
+        def arr(dt, *shape):
+            count = int(np.prod(shape)) if shape else 1
+            return np.frombuffer(fh.read(count * np.dtype(dt).itemsize), dt).reshape(shape).copy()
+
+        d = dict(model=model, P=P, a=a, M=M, M1=M1, Mm=Mm, n=n)
+        d["table"] = arr("<f4", rows, 12)
+        d["global_xyz"] = arr("<f4", n, 4)
+        d["global_normal"] = arr("<f4", n, 4) if model == 2 else None
+        d["seg_offset"] = arr("<i4", M + 1)
+        d["members"] = arr("<i4", Mm)
+        d["info"] = arr("<f4", M, 9)
+        d["weights"] = arr("<f4", M)
+        d["error_vec"] = arr("<f8", M + a)
+        d["jacobian"] = arr("<f8", P, M + a).T.copy()  # column-major (M+a) x P on disk
+        d["H"] = arr("<f8", P, P).T.copy()
+        d["step_raw"] = arr("<f8", P)
+        d["step"] = arr("<f8", P)
+        d["error0"] = float(arr("<f8", 1)[0])
+        d["best_k"] = int(arr("<i4", 2)[0])
+        d["params_after"] = arr("<f8", P)
+        assert fh.read(1) == b"", "trailing bytes in " + path
+    return d

@@ -1297,6 +1297,68 @@ struct Optimizer {
         }
         return best;
     }
+    // Iteration 0 of optimizeSet (:62-128) stage by stage, every intermediate result written to `path` in the 'DMSAST01' layout of
+    // dmsa_lidar_slam_amd/dump.py -- the same file oracle/ref_harness/ref_main.cpp writes from the REAL reference, so that a run of the
+    // harness elsewhere can be compared with this restatement statement by statement (tests/test_ref_fixtures.py).  inject_info /
+    // inject_weights (optional, M x 9 / M floats): the reference's own information matrices and weights replace the fitted ones after
+    // the Gaussians are built, which isolates the residual / Jacobian statements from the fit's.
+    int stageDump(PointSet& set, const dmsa_settings& s, int model, const float* table, int table_rows, const float* inject_info,
+                  const float* inject_weights, int inject_M, const char* path) {
+        std::vector<double> paramVec, errorVec, optimStep;
+        if (s.use_centralization) set.centralize();
+        set.getPoseParameters(paramVec);
+        set.updateGlobalPoints();
+        currentGauss.reset();
+        const float* nrm = set.hasNormals ? set.globalNormals.data() : nullptr;
+        if (s.grid_size_1_factor > std::numeric_limits<float>::min()) {
+            const int rc = create_gaussian_sets(currentGauss, set.globalPoints.data(), nrm, set.ids.data(), set.numPoints(), s.grid_size_1_factor * set.minGridSize,
+                                                s.min_num_points_per_set, s.gauss_split != 0);
+            if (rc != DMSA_OK) return rc;
+        }
+        currentGauss.numLevel1 = currentGauss.numPointSets;
+        if (s.grid_size_2_factor > std::numeric_limits<float>::min()) {
+            const int rc = create_gaussian_sets(currentGauss, set.globalPoints.data(), nrm, set.ids.data(), set.numPoints(), s.grid_size_2_factor * set.minGridSize,
+                                                s.min_num_points_per_set, s.gauss_split != 0);
+            if (rc != DMSA_OK) return rc;
+        }
+        currentGauss.updateRebalancingWeights();
+        const int M = currentGauss.numPointSets;
+        if (inject_info || inject_weights) {
+            if (inject_M != M) return DMSA_ERR_INVALID;
+            if (inject_info) std::copy(inject_info, inject_info + 9 * (size_t)M, currentGauss.info.begin());
+            if (inject_weights) std::copy(inject_weights, inject_weights + (size_t)M, currentGauss.weights.begin());
+        }
+        const std::vector<float> global0 = set.globalPoints, normal0 = set.globalNormals;  // the Jacobian leaves the last perturbation behind (q2)
+        updateErrorTerms(set, errorVec);
+        const int P = (int)paramVec.size(), rows = (int)errorVec.size(), a = rows - M;
+        const double error0 = dotRows(errorVec, P);
+        calcNumericJacobian(errorVec, set);
+        std::vector<double> H, g;
+        lm_step(errorVec.data(), Jacobian.data(), rows, P, (double)s.lambda_diag, s.step_length_optim, H, g, optimStep);
+        const std::vector<double> stepRaw = optimStep;
+        double mx = -std::numeric_limits<double>::infinity(), mn = std::numeric_limits<double>::infinity();
+        for (double v : optimStep) mx = std::max(mx, v), mn = std::min(mn, v);
+        const double maxElem = std::max(mx, -mn);
+        if (maxElem > s.max_step)
+            for (double& v : optimStep) v = (s.max_step / maxElem) * v;
+        const int bestK = adaptiveStepSize(set, paramVec, optimStep, error0);
+        FILE* f = std::fopen(path, "wb");
+        if (!f) return DMSA_ERR_INVALID;
+        const int64_t Mm = (int64_t)currentGauss.members.size(), n = set.numPoints();
+        const int32_t hdr[6] = {model, P, a, M, currentGauss.numLevel1, table_rows};
+        std::fwrite("DMSAST01", 1, 8, f), std::fwrite(hdr, 4, 6, f), std::fwrite(&Mm, 8, 1, f), std::fwrite(&n, 8, 1, f);
+        std::fwrite(table, 4, (size_t)table_rows * 12, f);
+        std::fwrite(global0.data(), 4, (size_t)n * 4, f);
+        if (model == 2) std::fwrite(normal0.data(), 4, (size_t)n * 4, f);
+        std::fwrite(currentGauss.segOffset.data(), 4, (size_t)M + 1, f), std::fwrite(currentGauss.members.data(), 4, (size_t)Mm, f);
+        std::fwrite(currentGauss.info.data(), 4, (size_t)M * 9, f), std::fwrite(currentGauss.weights.data(), 4, (size_t)M, f);
+        std::fwrite(errorVec.data(), 8, (size_t)rows, f), std::fwrite(Jacobian.data(), 8, (size_t)rows * P, f);
+        std::fwrite(H.data(), 8, (size_t)P * P, f), std::fwrite(stepRaw.data(), 8, (size_t)P, f), std::fwrite(optimStep.data(), 8, (size_t)P, f);
+        const int32_t tail[2] = {bestK, 0};
+        std::fwrite(&error0, 8, 1, f), std::fwrite(tail, 4, 2, f), std::fwrite(paramVec.data(), 8, (size_t)P, f);
+        std::fclose(f);
+        return DMSA_OK;
+    }
     // :54-150
     int optimizeSet(PointSet& set, const dmsa_settings& s, dmsa_report* rep, orc_iter_trace* trace, int trace_cap, bool fixed_iters) {
         std::vector<double> paramVec, errorVec, optimStep;
@@ -1679,6 +1741,39 @@ int orc_keyframe_additional_errors(const dmsa_keyframe_problem* p, double* rows_
         std::copy(a.begin(), a.begin() + n, rows_out);
     }
     return n;
+}
+
+int orc_stage_dump_window(dmsa_window_problem* p, const dmsa_settings* s, const float* inject_info, const float* inject_weights, int32_t inject_M, const char* path) {
+    try {
+        WindowModel m(*p);
+        WindowModel t(*p);  // the table of the start poses as the optimiser sees them: after centralize()
+        if (s->use_centralization) t.centralize();
+        t.updateGlobalPoints();
+        Optimizer opt;
+        return opt.stageDump(m, *s, 1, t.denseTforms.data(), t.n_total, inject_info, inject_weights, inject_M, path);
+    } catch (...) {
+        return DMSA_ERR_INVALID;
+    }
+}
+int orc_stage_dump_keyframes(dmsa_keyframe_problem* p, const dmsa_settings* s, const float* inject_info, const float* inject_weights, int32_t inject_M, const char* path) {
+    try {
+        KeyframeModel m(*p);
+        KeyframeModel t(*p);
+        t.updateGlobalPoints();
+        Optimizer opt;
+        return opt.stageDump(m, *s, 2, t.tforms.data(), t.F, inject_info, inject_weights, inject_M, path);
+    } catch (...) {
+        return DMSA_ERR_INVALID;
+    }
+}
+// H = J^T J + lambda I and the step from a GIVEN Jacobian (col-major rows x P): isolates the normal-equation / solve statements
+int orc_lm_step_from_jacobian(const double* e0, const double* J, int32_t rows, int32_t P, double lambda, double alpha, double* H_out, double* g_out, double* step_out) {
+    std::vector<double> H, g, step;
+    lm_step(e0, J, rows, P, lambda, alpha, H, g, step);
+    if (H_out) std::copy(H.begin(), H.end(), H_out);
+    if (g_out) std::copy(g.begin(), g.end(), g_out);
+    if (step_out) std::copy(step.begin(), step.end(), step_out);
+    return DMSA_OK;
 }
 
 int orc_lm_step(const double* e0, const double* e_batch, int32_t rows, int32_t P, double h, double lambda, double alpha, double* H_out,

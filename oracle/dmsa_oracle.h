@@ -89,6 +89,13 @@ int orc_window_additional_errors(const dmsa_window_problem* p, double* rows_out)
 int orc_keyframe_additional_errors(const dmsa_keyframe_problem* p, double* rows_out);
 
 /* one numeric-Jacobian + LM step on given residual batches (DmsaOptimizer.h:107-113); for stage parity */
+/* iteration 0 of optimizeSet stage by stage into the 'DMSAST01' file of dmsa_lidar_slam_amd/dump.py (what oracle/ref_harness/ref_main.cpp
+   writes from the real reference); inject_info / inject_weights (or NULL, with inject_M = the expected number of Gaussians) replace the
+   fitted information matrices / weights before the residuals are evaluated */
+int orc_stage_dump_window(dmsa_window_problem* p, const dmsa_settings* s, const float* inject_info, const float* inject_weights, int32_t inject_M, const char* path);
+int orc_stage_dump_keyframes(dmsa_keyframe_problem* p, const dmsa_settings* s, const float* inject_info, const float* inject_weights, int32_t inject_M, const char* path);
+int orc_lm_step_from_jacobian(const double* e0, const double* J /* col-major rows x P */, int32_t rows, int32_t P, double lambda, double alpha, double* H_out,
+                              double* g_out, double* step_out);
 int orc_lm_step(const double* e0, const double* e_batch /* P x rows */, int32_t rows, int32_t P, double h, double lambda,
                 double alpha, double* H_out /* PxP col-major */, double* g_out, double* step_out);
 

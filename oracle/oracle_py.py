@@ -68,6 +68,9 @@ def lib() -> C.CDLL:
     L.orc_window_additional_errors.argtypes = [C.POINTER(capi.WindowProblem), dp]
     L.orc_keyframe_additional_errors.argtypes = [C.POINTER(capi.KeyframeProblem), dp]
     L.orc_lm_step.argtypes = [dp, dp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, dp, dp, dp]
+    L.orc_lm_step_from_jacobian.argtypes = [dp, dp, C.c_int32, C.c_int32, C.c_double, C.c_double, dp, dp, dp]
+    L.orc_stage_dump_window.argtypes = [C.POINTER(capi.WindowProblem), C.POINTER(capi.Settings), fp, fp, C.c_int32, C.c_char_p]
+    L.orc_stage_dump_keyframes.argtypes = [C.POINTER(capi.KeyframeProblem), C.POINTER(capi.Settings), fp, fp, C.c_int32, C.c_char_p]
     _lib = L
     return L
 
@@ -343,6 +346,37 @@ def keyframe_additional_errors(prob: MapManagement):
     cp = prob.to_c()
     n = lib().orc_keyframe_additional_errors(C.byref(cp), capi.ptr(out, C.c_double))
     return out[:n]
+
+
+def stage_dump(prob, settings: DmsaOptimSettings, path: str, inject_info=None, inject_weights=None):
+    """Iteration 0 of optimizeSet stage by stage into a 'DMSAST01' file (dmsa_lidar_slam_amd/dump.py: read_stage_dump); inject_info (M x 9) /
+    inject_weights (M) replace the fitted information matrices / weights before the residuals are evaluated.  `prob` is not modified."""
+    q = prob.copy()  # (kept alive: the C struct points into its arrays)
+    cp = q.to_c()
+    cs = settings.to_c()
+    ii = np.ascontiguousarray(inject_info, np.float32) if inject_info is not None else None
+    iw = np.ascontiguousarray(inject_weights, np.float32) if inject_weights is not None else None
+    m = ii.shape[0] if ii is not None else (iw.shape[0] if iw is not None else 0)
+    fn = lib().orc_stage_dump_window if isinstance(prob, ContinuousTrajectory) else lib().orc_stage_dump_keyframes
+    rc = fn(C.byref(cp), C.byref(cs), ii.ctypes.data_as(capi.c_float_p) if ii is not None else None, iw.ctypes.data_as(capi.c_float_p) if iw is not None else None,
+            int(m), path.encode())
+    if rc != capi.DMSA_OK:
+        raise RuntimeError(f"orc_stage_dump failed with {rc}")
+    from dmsa_lidar_slam_amd import dump
+
+    return dump.read_stage_dump(path)
+
+
+def lm_step_from_jacobian(e0, J, lam, alpha):
+    """H = J^T J + lambda I (damped), g = J^T e0 and the step of DmsaOptimizer.h:107-113 from a given Jacobian (rows x P)."""
+    e0 = _d(e0)
+    J = np.asarray(J, np.float64)
+    rows, P = J.shape
+    Jc = np.ascontiguousarray(J.T)  # column-major rows x P
+    H, g, step = np.zeros((P, P)), np.zeros(P), np.zeros(P)
+    lib().orc_lm_step_from_jacobian(capi.ptr(e0, C.c_double), capi.ptr(Jc, C.c_double), rows, P, float(lam), float(alpha), capi.ptr(H, C.c_double),
+                                    capi.ptr(g, C.c_double), capi.ptr(step, C.c_double))
+    return H.T.copy(), g, step
 
 
 def lm_step(e0, e_batch, h, lam, alpha):

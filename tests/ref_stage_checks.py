@@ -1,0 +1,152 @@
+"""Stage-by-stage comparison of a 'DMSAST01' dump of the REFERENCE (oracle/ref_harness/ref_main.cpp ... stage) with the oracle's
+restatement.  Every check conditions on the reference's own result of the stage before it, so a failure names ONE statement of the
+oracle -- and the hypothesis switch of oracle/dmsa_oracle.cpp (ORC_VAR_*) that would flip it:
+
+  stage                 given (from the reference)      compared                         bar                      decides
+  table                 start poses                     pose table                       <= 1 ulp, >= 90 % equal  GLIBC_TRIG; slerp / Floater-Hormann / Rodrigues restatements
+  global_points         pose table                      transformed points               bit-exact                TRANSFORM_PAIRWISE; centralize's float subtraction
+  member_lists          global points                   seg_offset, members, M1          bit-exact                PCL octree semantics, leaf acceptance, splitSet quirks
+  info_mats             global points + members         information matrices, weights    1e-4 of the largest      FIT_MEAN_TREE / FIT_COV_GEMM / FIT_FLOAT; EigenSolver vs Jacobi (H5)
+                                                                                         entry; weights 2 ulp
+  residuals             global points, info, weights    errorVec rows < M                bit-exact                SUM3_LEFT, MAHA_ASSOC, the float mean of :247-254
+  jacobian              info, weights                   Jacobian                         5e-3 of the largest      the evaluation chain (pose chain, tables, transform) under a
+                                                                                         entry (bit-exact with    forward difference; GLIBC_TRIG
+                                                                                         the machine's libm)
+  normal_equations      errorVec, Jacobian              H, raw step, clamp               1e-12 / 1e-9 relative    JTJ order (blocked sums, fma for P > 64), Gauss-Jordan vs PartialPivLU
+  line_search           step, parameters                best_k, parameters after         exact                    adaptiveStepSize's arithmetic; strict '<'
+Used by tests/test_ref_fixtures.py on the committed reference dumps (absent here: PARITY UNPINNED) and, as a check of the checks, on dumps the
+oracle and its hypothesis variants write themselves."""
+import os
+import tempfile
+
+import numpy as np
+
+STAGES = ["table", "global_points", "member_lists", "info_mats", "residuals", "jacobian", "normal_equations", "line_search"]
+HINT = {
+    "table": "GLIBC_TRIG (sin / cos / acos / atan2), or the slerp / Floater-Hormann / Rodrigues restatement",
+    "global_points": "TRANSFORM_PAIRWISE (order of Matrix4f * Vector4f), or centralize()'s float subtraction",
+    "member_lists": "PCL octree semantics (box growth, key generation, leaf order), leaf acceptance or the splitSet quirks -- no switch: a restatement bug",
+    "info_mats": "FIT_MEAN_TREE / FIT_COV_GEMM / FIT_FLOAT (summation orders of the fit), EigenSolver vs symmetric Jacobi",
+    "residuals": "SUM3_LEFT or MAHA_ASSOC (or the float mean of DmsaOptimizer.h:247-254)",
+    "jacobian": "the evaluation chain under a forward difference: relative2global / pose tables (GLIBC_TRIG) / transform",
+    "normal_equations": "JTJ_NOFMA / the blocked summation order of J^T J, or the Gauss-Jordan statement of H.inverse()",
+    "line_search": "adaptiveStepSize's arithmetic (0.1 * k * step) or the strict '<' of the arg-min",
+}
+
+
+def _ulp_diff(a, b):
+    """distance in float32 representable steps (same-sign finite values)"""
+    ia = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    ib = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, np.int64(-2**31) - ia, ia)
+    ib = np.where(ib < 0, np.int64(-2**31) - ib, ib)
+    return np.abs(ia - ib)
+
+
+def _rows_of_points(prob, window):
+    if window:
+        return np.ascontiguousarray(prob.tformIdPerPoint, np.int32)
+    return np.repeat(np.arange(prob.numFrames), np.diff(prob.frameOffsets)).astype(np.int32)
+
+
+def _ids(prob, window):
+    return np.concatenate([prob.ringIds, prob.staticRingIds]).astype(np.int32) if window else np.ascontiguousarray(prob.ringIds, np.int32)
+
+
+class StageChecks:
+    """ref: read_stage_dump() of the reference's file; prob / settings: the problem both sides started from."""
+
+    def __init__(self, orc, ref, prob, settings, window):
+        self.orc, self.ref, self.prob, self.s, self.window = orc, ref, prob, settings, window
+        self.tmp = tempfile.mkdtemp(prefix="dmsa_stage_")
+        self._own = None
+        self.report = {}
+
+    def own(self):
+        if self._own is None:
+            self._own = self.orc.stage_dump(self.prob, self.s, os.path.join(self.tmp, "own.bin"))
+        return self._own
+
+    def run(self, stage):
+        getattr(self, "check_" + stage)()
+
+    # ---- stages ----
+    def check_table(self):
+        a, b = self.own()["table"], self.ref["table"]
+        assert a.shape == b.shape
+        d = _ulp_diff(a, b)
+        self.report["table"] = dict(equal=float(np.mean(d == 0)), max_ulp=int(d.max()))
+        assert d.max() <= 1 and np.mean(d == 0) >= 0.9, self.report["table"]
+
+    def check_global_points(self):
+        ref, prob = self.ref, self.prob
+        rows = _rows_of_points(prob, self.window)
+        N = rows.shape[0]
+        got = self.orc.transform_points(ref["table"], prob.localPoints, rows)
+        assert np.array_equal(got[:, :3].view(np.int32), ref["global_xyz"][:N, :3].view(np.int32)), "transformed points differ GIVEN the reference's table"
+        if self.window and ref["n"] > N:  # static tail: centralize() subtracts the first control translation in float (ContinuousTrajectory.h:75-88)
+            assert np.array_equal(self.own()["global_xyz"][N:, :3].view(np.int32), ref["global_xyz"][N:, :3].view(np.int32)), "centralised static points differ"
+        if not self.window:  # normals = R * n with the same table rows: compared where the table rows agree bit for bit
+            same_row = np.all(self.own()["table"].view(np.int32) == ref["table"].view(np.int32), axis=1)[rows]
+            assert np.array_equal(self.own()["global_normal"][same_row, :3].view(np.int32), ref["global_normal"][same_row, :3].view(np.int32)), "rotated normals differ"
+
+    def _gaussians_on_ref_points(self):
+        ref = self.ref
+        return self.orc.Gaussians(ref["global_xyz"], _ids(self.prob, self.window), self.prob.minGridSize, self.s, normals4=ref["global_normal"])
+
+    def check_member_lists(self):
+        G, ref = self._gaussians_on_ref_points(), self.ref
+        assert (G.M, G.M1, G.Mm) == (ref["M"], ref["M1"], ref["Mm"]), ((G.M, G.M1, G.Mm), (ref["M"], ref["M1"], ref["Mm"]))
+        assert np.array_equal(G.seg_offset, ref["seg_offset"]) and np.array_equal(G.members, ref["members"])
+
+    def check_info_mats(self):
+        G, ref = self._gaussians_on_ref_points(), self.ref
+        assert G.M == ref["M"], "member lists differ: fix that stage first"
+        scale = np.abs(ref["info"]).max(axis=1, keepdims=True)
+        rel = np.abs(G.info - ref["info"]) / scale
+        wd = _ulp_diff(G.weights, ref["weights"])
+        self.report["info_mats"] = dict(max_rel=float(rel.max()), matrices_bit_equal=float(np.mean(np.all(G.info.view(np.int32) == ref["info"].view(np.int32), axis=1))),
+                                        weights_max_ulp=int(wd.max()))
+        assert rel.max() <= 1e-4 and wd.max() <= 2, self.report["info_mats"]
+
+    def check_residuals(self):
+        G, ref = self._gaussians_on_ref_points(), self.ref
+        assert G.M == ref["M"], "member lists differ: fix that stage first"
+        G.set_info(ref["info"], ref["weights"])
+        e = G.residuals(ref["global_xyz"])
+        M = ref["M"]
+        bad = np.flatnonzero(e.view(np.int64) != ref["error_vec"][:M].view(np.int64))
+        self.report["residuals"] = dict(rows_differing=int(bad.size), of=int(M))
+        assert bad.size == 0, (self.report["residuals"], e[bad[:3]], ref["error_vec"][bad[:3]])
+        if ref["a"] > 0:  # additional rows (gravity / odometry / IMU): double arithmetic on the poses
+            add, radd = self.own()["error_vec"][-ref["a"]:], ref["error_vec"][M:]
+            assert np.allclose(add, radd, rtol=1e-12, atol=1e-15), (add, radd)
+
+    def check_jacobian(self):
+        ref = self.ref
+        own = self.orc.stage_dump(self.prob, self.s, os.path.join(self.tmp, "own_inj.bin"), inject_info=ref["info"], inject_weights=ref["weights"])
+        assert own["jacobian"].shape == ref["jacobian"].shape, "member lists differ: fix that stage first"
+        J, Jr = own["jacobian"], ref["jacobian"]
+        scale = np.abs(Jr).max()
+        self.report["jacobian"] = dict(max_rel_of_largest=float(np.abs(J - Jr).max() / scale), entries_bit_equal=float(np.mean(J.view(np.int64) == Jr.view(np.int64))))
+        assert np.abs(J - Jr).max() <= 5e-3 * scale, self.report["jacobian"]
+
+    def check_normal_equations(self):
+        ref, s = self.ref, self.s
+        H, g, step = self.orc.lm_step_from_jacobian(ref["error_vec"], ref["jacobian"], float(np.float32(s.lambda_diag)), s.step_length_optim)
+        dH = np.abs(H - ref["H"]).max() / np.abs(ref["H"]).max()
+        dS = np.abs(step - ref["step_raw"]).max() / np.abs(ref["step_raw"]).max()
+        self.report["normal_equations"] = dict(H_rel=float(dH), step_rel=float(dS))
+        assert dH <= 1e-12 and dS <= 1e-9, self.report["normal_equations"]
+        raw = ref["step_raw"]
+        max_elem = max(raw.max(), -raw.min())
+        clamped = (s.max_step / max_elem) * raw if max_elem > s.max_step else raw
+        assert np.array_equal(clamped, ref["step"]), "the clamp of DmsaOptimizer.h:125-128"
+
+    def check_line_search(self):
+        ref, own = self.ref, self.own()
+        assert own["best_k"] == ref["best_k"], (own["best_k"], ref["best_k"])
+        assert abs(own["error0"] - ref["error0"]) <= 1e-6 * ref["error0"], (own["error0"], ref["error0"])
+        if ref["best_k"] > 0:  # params = raw + 0.1 * k * step (:160); raw = what getPoseParameters returned = own's start parameters
+            raw = own["params_after"] - 0.1 * float(own["best_k"]) * own["step"]
+            assert np.allclose(ref["params_after"], raw + 0.1 * float(ref["best_k"]) * ref["step"], rtol=0, atol=1e-12)
