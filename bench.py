@@ -13,9 +13,14 @@ N > 1: windows are sequentially dependent in a SLAM run, so the window pass shar
 ("weak" scaling: every rank optimises its own window); the one exchange step of the sharded path — an all-gather of
 the optimised poses (RCCL) — is inside the timed region.  value = total iterations of all ranks / max-over-ranks time.
 
-`--workload keyframes` is config 4, the pass that really shards: ONE ring-buffer map of (frames-1)*N+1 keyframes is cut
-into N neighbourhoods sharing a boundary frame (sharding.py), rank i keeps only its submap resident, and the timed region
-ends with the all-gather of relative poses + updatePosesFromSubmap on every rank.
+`--workload keyframes` is config 4, the pass that really shards, as a STRONG-scaling workload: ONE ring-buffer map of
+--map-frames keyframes (249) is cut into --neighbourhoods (8) neighbourhoods of 32 frames sharing their boundary frames
+(sharding.py) whatever N is; rank r keeps the submaps r, r + N, ... resident and optimises them one after the other, and the
+timed region ends with ONE all-gather of relative poses + updatePosesFromSubmap for all neighbourhoods on every rank.  N = 1
+does the same work as N = 8.  The line carries per-rank time / points / Gaussians and the max / mean ratio (load balance is
+what governs this curve: the collective is a few KB).  The same pass runs as a second, separately timed region of the
+default (window) workload and is reported there as `keyframe_pass`.  `--map-frames 0` is the weak-scaling layout of rounds
+1-3 (one neighbourhood of --frames keyframes per rank, the map grows with N).
 
 `DMSA_BENCH_BACKEND=gloo` rehearses the N > 1 control flow (barriers, gathers, max-over-ranks timing) with more ranks than
 GPUs: ranks share devices and the collectives run on CPU tensors (used to test the 2-rank paths on a 1-GPU box).
@@ -69,7 +74,9 @@ def parse():
     ap.add_argument("--rings", type=int, default=128)
     ap.add_argument("--az", type=int, default=1024)
     ap.add_argument("--static", type=int, default=200_000)
-    ap.add_argument("--frames", type=int, default=32, help="keyframes per rank for --workload keyframes")
+    ap.add_argument("--frames", type=int, default=32, help="keyframes per rank for --workload keyframes --map-frames 0 (weak scaling)")
+    ap.add_argument("--map-frames", type=int, default=249, help="keyframes of the ring-buffer map of the sharded keyframe pass (0: weak-scaling layout)")
+    ap.add_argument("--neighbourhoods", type=int, default=8, help="neighbourhoods the map is cut into, whatever --gpus is")
     ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations timed for cpu_baseline (0 disables)")
     ap.add_argument("--keyframe-steps", type=int, default=10, help="iterations of the secondary sharded-keyframe-pass measurement (0 disables)")
     ap.add_argument("--fast-sums", action="store_true", help="time the opt-in wave-parallel sums (DMSA_FLAG_FAST_SUMS) instead of the default path")
@@ -133,18 +140,29 @@ def main():
     else:
         # config 4: one ring-buffer map cut into `world` neighbourhoods of --frames keyframes sharing one boundary frame;
         # every rank builds the same map (same seed) and keeps only its own submap resident
-        from dmsa_lidar_slam_amd.sharding import gather_neighbourhood_poses, neighbourhood_ranges
+        from dmsa_lidar_slam_amd.sharding import gather_owned_neighbourhood_poses, neighbourhood_ranges, owned_neighbourhoods
 
-        total_frames = (args.frames - 1) * world + 1
-        full_map = synth.keyframe_problem(seed=1, frames=total_frames, arc=2 * np.pi * total_frames / 256.0)
-        ranges = neighbourhood_ranges(total_frames, world)
-        prob = full_map.getSubmap(*ranges[rank])
+        strong = args.map_frames > 0
+        if strong and args.neighbourhoods < world:
+            raise SystemExit(f"bench.py: {args.neighbourhoods} neighbourhoods cannot occupy {world} ranks")
+        total_frames = args.map_frames if strong else (args.frames - 1) * world + 1
+        full_map = bench_keyframe_map(total_frames, rank, world, dist)
+        ranges = neighbourhood_ranges(total_frames, args.neighbourhoods if strong else world)
+        owned = owned_neighbourhoods(len(ranges), rank, world)
+        subs = {nb: full_map.getSubmap(*ranges[nb]) for nb in owned}
+        prob = subs[owned[0]]
         settings = DmsaOptimSettings.keyframe_map(num_iter=1)
-        wl = f"keyframes{args.frames}x~{prob.localPoints.shape[0] // args.frames}"
-        n_points = prob.localPoints.shape[0]
+        wl = f"keyframes{total_frames}/{len(ranges)}x~{prob.localPoints.shape[0] // prob.numFrames}" if strong else f"keyframes{args.frames}x~{prob.localPoints.shape[0] // args.frames}"
+        n_points = sum(sb.localPoints.shape[0] for sb in subs.values())
 
     opt = DmsaOptimizer(device=local_rank, fixed_iters=True, fast_sums=args.fast_sums, pose_table_host=args.host_tables)
     opt.upload(prob)  # inputs resident in HBM before the timed region
+    opts = {}
+    if args.workload == "keyframes":  # one context per owned neighbourhood: all of them resident before the timed region
+        opts = {owned[0]: opt}
+        for nb in owned[1:]:
+            opts[nb] = DmsaOptimizer(device=local_rank, fixed_iters=True, fast_sums=args.fast_sums, pose_table_host=args.host_tables)
+            opts[nb].upload(subs[nb])
 
     def sync_all():
         if world > 1:
@@ -153,20 +171,31 @@ def main():
 
     settings.num_iter = max(1, args.warmup)
     if args.warmup > 0:
-        opt.optimizeResident(settings)
+        for o in (opts.values() if opts else [opt]):
+            o.optimizeResident(settings)
     if world > 1:
         # warm the collective the timed region ends with: the first all-gather on a fresh communicator sets up its xGMI peer
         # connections (tens of ms), which is start-up cost, not part of a step
         w = torch.zeros(64, dtype=torch.float64, device=coll_dev)
         dist.all_gather([torch.empty_like(w) for _ in range(world)], w)
-    opt.timing(reset=True)
+    for o in (opts.values() if opts else [opt]):
+        o.timing(reset=True)
     settings.num_iter = args.steps
+    per_rank = None
     sync_all()
     t0 = time.perf_counter()
-    rep = opt.optimizeResident(settings)
-    if args.workload == "keyframes":  # sharded keyframe pass: all-gather + updatePosesFromSubmap on every rank
-        prob.relOrientations[:], prob.relTranslations[:] = opt.poses()
-        gather_neighbourhood_poses(full_map, prob, ranges, rank, world, dist, coll_dev)
+    if args.workload == "keyframes":  # sharded keyframe pass: the owned neighbourhoods one after the other, all-gather + updatePosesFromSubmap on every rank
+        reps = {}
+        for nb in owned:
+            reps[nb] = opts[nb].optimizeResident(settings)
+            subs[nb].relOrientations[:], subs[nb].relTranslations[:] = opts[nb].poses()
+        t_own = time.perf_counter() - t0
+        gather_owned_neighbourhood_poses(full_map, subs, ranges, rank, world, dist, coll_dev)
+        rep = reps[owned[0]]
+    else:
+        rep = opt.optimizeResident(settings)
+    if args.workload == "keyframes":
+        pass
     elif world > 1:  # independent windows: the exchange step is an all-gather of the optimised poses over RCCL/xGMI
         ro, rt = opt.poses()
         mine = torch.from_numpy(np.concatenate([ro.ravel(), rt.ravel()])).to(coll_dev)
@@ -175,6 +204,12 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     tm = opt.timing()
+    if args.workload == "keyframes":
+        for nb in owned[1:]:  # the roofline figures cover every neighbourhood of this rank
+            t_nb = opts[nb].timing()
+            for k in ("residual_kernel_ms", "residual_launches", "residual_evaluations", "residual_algorithmic_bytes", "residual_unit_bytes"):
+                setattr(tm, k, getattr(tm, k) + getattr(t_nb, k))
+        per_rank = rank_telemetry(rank, world, dist, coll_dev, t_own, owned, subs, reps)
     # stage breakdown: a second, untimed pass with the per-stage HIP-event timers switched on (they cost GPU idle time)
     stage = None
     if rank == 0:
@@ -269,7 +304,8 @@ def main():
 
     if rank == 0:
         iters = rep.iterations
-        value = world * iters / elapsed
+        units = (len(ranges) if strong else world) if args.workload == "keyframes" else world  # problems optimised per step count
+        value = units * iters / elapsed
         launches = max(1, tm.residual_launches)
         evals = max(1, tm.residual_evaluations)
         avg_ms = tm.residual_kernel_ms / launches
@@ -303,7 +339,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / max(1, iters), 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (args.workload == "keyframes" and strong) else "weak",
             "vs_baseline": None,
             "dtype": "f32 points/Gaussians, f64 residual sums and normal equations",
             "data": "synthetic",
@@ -319,8 +355,8 @@ def main():
                         else "default: reference-order sums, device pose tables (poses bit-identical to the CPU restatement)",
                 "rank_device": placement,
                 "collective": {"backend": "rccl" if backend == "nccl" else backend, "world_size": coll_world},
-                "sharding": ("single GPU" if world == 1 else "independent windows per rank + pose all-gather" if args.workload == "window"
-                             else f"{world} keyframe neighbourhoods of one {total_frames}-frame map, one per GPU + pose all-gather"),
+                "sharding": (("single GPU" if world == 1 else "independent windows per rank + pose all-gather") if args.workload == "window"
+                             else f"{len(ranges)} keyframe neighbourhoods of one {total_frames}-frame map, rank r runs r, r + {world}, ... + one pose all-gather"),
             },
             "roofline": {
                 "kernel": ("correspondence kernels k_residuals_tiles + k_residuals_big" if args.fast_sums else
@@ -352,6 +388,7 @@ def main():
                 "valu": {"achieved_tflops": round(valu_tflops, 2), "peak_tflops_no_fma": 78.6,
                          "frac": round(valu_tflops / 78.6, 4)},
             },
+            "per_rank": per_rank,
             "stage_ms_per_step": stage,
             "fast_sums_path": fast,
             "keyframe_pass": keyframe_pass,
@@ -365,41 +402,88 @@ def main():
         dist.destroy_process_group()
 
 
-def sharded_keyframe_pass(args, rank, local_rank, world, dist, coll_dev, sync_all):
-    """BASELINE.json config 4 at this world size: one ring-buffer map of (frames - 1) * world + 1 keyframes cut into `world`
-    neighbourhoods, one per GPU, full optimizeSet per rank, ONE all-gather of relative poses, updatePosesFromSubmap on every rank."""
+def bench_keyframe_map(total_frames, rank, world, dist):
+    """The synthetic ring-buffer map of config 4 (k-NN normals included: ~14 s for 249 frames on one host thread), generated ONCE -- by
+    rank 0, cached as a flat dump (dmsa_lidar_slam_amd/dump.py) that the other ranks and later runs read."""
+    import tempfile
+
+    from dmsa_lidar_slam_amd import dump, synth
+
+    path = os.path.join(tempfile.gettempdir(), f"dmsa_bench_keyframe_map_{total_frames}.bin")
+    if rank == 0 and not os.path.exists(path):
+        m = synth.keyframe_problem(seed=1, frames=total_frames, arc=2 * np.pi * total_frames / 256.0)
+        dump.write_keyframe_map(path + f".{os.getpid()}", m)
+        os.replace(path + f".{os.getpid()}", path)
+    if world > 1:
+        dist.barrier()
+    return dump.read_keyframe_map(path)
+
+
+def rank_telemetry(rank, world, dist, coll_dev, t_own, owned, subs, reps):
+    """What governs the scaling curve of the sharded keyframe pass: every rank's own time (before the collective), points, Gaussians."""
     import torch
 
-    from dmsa_lidar_slam_amd import synth
+    mine = [float(rank), 1e3 * t_own, float(len(owned)), float(sum(subs[nb].localPoints.shape[0] for nb in owned)),
+            float(sum(reps[nb].num_gaussians for nb in owned)), float(sum(reps[nb].num_memberships for nb in owned))]
+    rows = [mine]
+    if world > 1:
+        t = torch.tensor(mine, dtype=torch.float64, device=coll_dev)
+        got = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        rows = [g.cpu().tolist() for g in got]
+    ms = [r[1] for r in rows]
+    return {"ranks": [{"rank": int(r[0]), "ms": round(r[1], 3), "neighbourhoods": int(r[2]), "points": int(r[3]), "gaussians": int(r[4]), "memberships": int(r[5])}
+                      for r in rows],
+            "max_over_mean_ms": round(max(ms) / (sum(ms) / len(ms)), 4), "slowest_rank": int(rows[int(np.argmax(ms))][0])}
+
+
+def sharded_keyframe_pass(args, rank, local_rank, world, dist, coll_dev, sync_all):
+    """BASELINE.json config 4 as a strong-scaling workload: ONE ring-buffer map of --map-frames keyframes cut into --neighbourhoods
+    neighbourhoods whatever the world size; rank r optimises neighbourhoods r, r + world, ... one after the other (full optimizeSet each),
+    ONE all-gather of relative poses, updatePosesFromSubmap for every neighbourhood on every rank."""
+    import torch
+
     from dmsa_lidar_slam_amd.api import DmsaOptimizer
     from dmsa_lidar_slam_amd.problems import DmsaOptimSettings
-    from dmsa_lidar_slam_amd.sharding import gather_neighbourhood_poses, neighbourhood_ranges
+    from dmsa_lidar_slam_amd.sharding import gather_owned_neighbourhood_poses, neighbourhood_ranges, owned_neighbourhoods
 
-    total_frames = (args.frames - 1) * world + 1
-    full_map = synth.keyframe_problem(seed=1, frames=total_frames, arc=2 * np.pi * total_frames / 256.0)
-    ranges = neighbourhood_ranges(total_frames, world)
-    sub = full_map.getSubmap(*ranges[rank])
+    strong = args.map_frames > 0 and args.neighbourhoods >= world
+    total_frames = args.map_frames if strong else (args.frames - 1) * world + 1
+    full_map = bench_keyframe_map(total_frames, rank, world, dist)
+    ranges = neighbourhood_ranges(total_frames, args.neighbourhoods if strong else world)
+    owned = owned_neighbourhoods(len(ranges), rank, world)
+    subs = {nb: full_map.getSubmap(*ranges[nb]) for nb in owned}
     s = DmsaOptimSettings.keyframe_map(num_iter=2)
-    opt = DmsaOptimizer(device=local_rank, fixed_iters=True)
-    opt.upload(sub)
-    opt.optimizeResident(s)
+    opts = {}
+    for nb in owned:
+        opts[nb] = DmsaOptimizer(device=local_rank, fixed_iters=True)
+        opts[nb].upload(subs[nb])
+        opts[nb].optimizeResident(s)
     s.num_iter = args.keyframe_steps
     sync_all()
     t0 = time.perf_counter()
-    rep = opt.optimizeResident(s)
-    sub.relOrientations[:], sub.relTranslations[:] = opt.poses()
-    gather_neighbourhood_poses(full_map, sub, ranges, rank, world, dist, coll_dev)
+    reps = {}
+    for nb in owned:
+        reps[nb] = opts[nb].optimizeResident(s)
+        subs[nb].relOrientations[:], subs[nb].relTranslations[:] = opts[nb].poses()
+    t_own = time.perf_counter() - t0
+    gather_owned_neighbourhood_poses(full_map, subs, ranges, rank, world, dist, coll_dev)
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    opt.close()
-    return {"metric": "DMSA iterations/sec (sharded keyframe pass, iterations of all neighbourhoods)", "value": round(world * rep.iterations / elapsed, 3),
+    per_rank = rank_telemetry(rank, world, dist, coll_dev, t_own, owned, subs, reps)
+    for o in opts.values():
+        o.close()
+    rep = reps[owned[0]]
+    return {"metric": "DMSA iterations/sec (sharded keyframe pass, iterations of all neighbourhoods)", "value": round(len(ranges) * rep.iterations / elapsed, 3),
             "unit": "iterations/s", "n_gpus": world, "steps": int(rep.iterations), "ms_per_step": round(1e3 * elapsed / max(1, rep.iterations), 4),
-            "scaling": "weak", "frames_total": int(total_frames), "frames_per_rank": int(args.frames), "points_per_rank": int(sub.localPoints.shape[0]),
-            "params_per_rank": int(sub.numParams), "exchange": "one all-gather of (frames - 1) x 6 doubles per rank" if world > 1 else "none (single GPU)"}
+            "ms_per_neighbourhood_iteration": round(1e3 * elapsed / max(1, rep.iterations) / max(1, len(owned)), 4),
+            "scaling": "strong" if strong else "weak", "frames_total": int(total_frames), "neighbourhoods": len(ranges),
+            "neighbourhoods_per_rank": len(owned), "params_per_neighbourhood": int(subs[owned[0]].numParams), "per_rank": per_rank,
+            "exchange": "one all-gather of ceil(neighbourhoods / ranks) x 32 x 6 doubles per rank" if world > 1 else "none (single GPU)"}
 
 
 def cpu_baseline(prob, settings, iters, workload):

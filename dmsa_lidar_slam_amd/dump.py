@@ -44,6 +44,26 @@ def write_keyframe_map(path: str, m: MapManagement) -> None:
             fh.write(np.ascontiguousarray(a, dt).tobytes())
 
 
+def read_keyframe_map(path: str) -> MapManagement:
+    """'DMSAKF01' back into a MapManagement (gravity rows as dumped, no odometry rows: the dump does not carry them)."""
+    with open(path, "rb") as fh:
+        assert fh.read(8) == b"DMSAKF01", path
+        f, use_gravity, n, min_grid, _ = struct.unpack("<iiqff", fh.read(24))
+
+        def arr(dt, *shape):
+            count = int(np.prod(shape))
+            return np.frombuffer(fh.read(count * np.dtype(dt).itemsize), dt).reshape(shape).copy()
+
+        gravity = arr("<f8", 3)
+        cov = arr("<f8", 3, 3).T.copy()
+        bal = float(arr("<f8", 1)[0])
+        ro, rt, off = arr("<f8", f, 3), arr("<f8", f, 3), arr("<i8", f + 1)
+        xyz, nrm, ring = arr("<f4", n, 4), arr("<f4", n, 4), arr("<i4", n)
+        mg, gp = arr("<f8", f, 3), arr("<i4", f)
+    return MapManagement(relOrientations=ro, relTranslations=rt, frameOffsets=off, localPoints=xyz, localNormals=nrm, ringIds=ring, minGridSize=np.float32(min_grid),
+                         useGravityErrorTerms=bool(use_gravity), measuredGravity=mg, gravityPlausible=gp, gravity=gravity, Cov_grav_inv=cov, balancingFactorGrav=bal)
+
+
 def write_window_problem(path: str, w: ContinuousTrajectory) -> None:
     c, nt, n, ns = w.numControlPoses, w.trajTime.shape[0], w.localPoints.shape[0], w.staticPoints.shape[0]
     with open(path, "wb") as fh:

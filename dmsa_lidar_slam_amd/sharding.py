@@ -56,6 +56,45 @@ def gather_neighbourhood_poses(full_map: MapManagement, sub: MapManagement, rang
         full_map.relTranslations[f + 1:t_ + 1] = part[:k, 3:]
 
 
+def owned_neighbourhoods(num_neighbourhoods: int, rank: int, world: int):
+    """Strong-scaling ownership: the map is cut into `num_neighbourhoods` whatever the world size; rank r runs r, r + world, ... one after
+    the other (world == num_neighbourhoods is the one-per-GPU layout above)."""
+    return list(range(rank, num_neighbourhoods, world))
+
+
+def gather_owned_neighbourhood_poses(full_map: MapManagement, subs: dict, ranges, rank: int, world: int, dist=None, device=None):
+    """gather_neighbourhood_poses for a FIXED cut (len(ranges) neighbourhoods, any world size): `subs` maps the indices this rank owns
+    (owned_neighbourhoods) to their optimised submaps.  Still ONE all-gather: every rank sends ceil(len(ranges) / world) slots of
+    (width x 6) doubles, a slot per owned neighbourhood; afterwards every rank holds the same relative poses, and they are the same for
+    every world size (updatePosesFromSubmap reads nothing but the submap and writes disjoint columns)."""
+    num = len(ranges)
+    width = max(t - f for f, t in ranges)
+    slots = (num + world - 1) // world
+    mine = np.zeros((slots, width, 6))
+    for j, nb in enumerate(owned_neighbourhoods(num, rank, world)):
+        f0, f1 = ranges[nb]
+        full_map.updatePosesFromSubmap(f0, f1, subs[nb])
+        mine[j, : f1 - f0, :3] = full_map.relOrientations[f0 + 1:f1 + 1]
+        mine[j, : f1 - f0, 3:] = full_map.relTranslations[f0 + 1:f1 + 1]
+    if world > 1:
+        import torch
+
+        t = torch.from_numpy(mine)
+        if device is not None:
+            t = t.to(device)
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        parts = [g.cpu().numpy() for g in gathered]
+    else:
+        parts = [mine]
+    for r, part in enumerate(parts):
+        for j, nb in enumerate(owned_neighbourhoods(num, r, world)):
+            f, t_ = ranges[nb]
+            k = t_ - f
+            full_map.relOrientations[f + 1:t_ + 1] = part[j, :k, :3]
+            full_map.relTranslations[f + 1:t_ + 1] = part[j, :k, 3:]
+
+
 def optimize_neighbourhoods(full_map: MapManagement, settings: DmsaOptimSettings, optimize_fn, rank: int = 0, world: int = 1,
                             dist=None, device=None):
     """Shard `full_map` over `world` ranks and optimise this rank's neighbourhood with `optimize_fn(submap, settings)`

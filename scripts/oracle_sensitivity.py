@@ -6,7 +6,7 @@ The reference cannot be built here, so wherever its arithmetic is not spelled ou
 builds one oracle per switch (make -C oracle hypotheses), runs the same problems through every build for the same number of
 iterations (early exits off) and reports how far the optimised GLOBAL poses move away from the default oracle's.
 
-    python scripts/oracle_sensitivity.py [--iters 5] [--out profiles/r03_oracle_sensitivity.json]
+    python scripts/oracle_sensitivity.py [--iters 5] [--out profiles/r04_oracle_sensitivity.json]
 
 CPU only; about two minutes (the P = 186 keyframe case dominates).  Test infrastructure: nothing here touches the product library.
 """
@@ -21,7 +21,10 @@ HYPOTHESES = {
     "TRANSFORM_PAIRWISE": "Matrix4f*Vector4f as (c0x+c1y)+(c2z+c3) instead of ((c0x+c1y)+c2z)+c3 (ContinuousTrajectory.h:151, MapManagement.h:142)",
     "SUM3_LEFT": "3-term fixed-size redux (x0+x1)+x2 instead of x0+(x1+x2) (DmsaOptimizer.h:263, Gaussians.h:52-75)",
     "MAHA_ASSOC": "w*((d^T A) d) instead of ((w d^T) A) d (DmsaOptimizer.h:263)",
-    "FIT_FLOAT": "fit sums and weight mean as float chains in member order instead of 64-wide trees in double (Gaussians.h:146-154, :176)",
+    "FIT_FLOAT": "every fit sum (column means, centred products, weight mean) as a scalar float chain in member order (Gaussians.h:146-154, :176)",
+    "FIT_MEAN_TREE": "colwise().mean() / VectorXf::mean() as 64-wide trees in double (the statement until round 4) instead of Eigen's own linear-redux float order",
+    "FIT_COV_GEMM": "centered^T*centered in the float order of Eigen 3.4's product kernels as recalled (lazy product below 14 members, gebp scalar tails in depth "
+                    "blocks for a 32 KB L1) instead of 64-wide trees in double (Gaussians.h:147)",
     "JTJ_NOFMA": "J^T J / J^T e / e^T e at P > 64 with separate multiply and add instead of the fma chain of v_mfma_f64 (DmsaOptimizer.h:107-113)",
     "GLIBC_TRIG": "sin/cos/acos/atan2 from glibc instead of include/dmsa_detmath.h (helpers.h:24-65)",
 }

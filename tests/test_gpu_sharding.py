@@ -168,14 +168,16 @@ def test_config4_full_shape_eight_neighbourhoods(tmp_path, orc):
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without a launcher must start two ranks itself (torch.distributed.run, 127.0.0.1) and say who ran
     where -- not quietly measure one GPU.  gloo collectives so that the two ranks can share the one GPU of this box; the line must
-    carry n_gpus = 2, both (rank, device) pairs, the collective's world size, and the sharded keyframe pass at the same world size."""
+    carry n_gpus = 2, both (rank, device) pairs, the collective's world size, and the sharded keyframe pass at the same world size -- as a
+    STRONG-scaling workload: a fixed map and a fixed cut (here 17 frames in 4 neighbourhoods), two neighbourhoods per rank, with the
+    per-rank telemetry that makes load imbalance visible."""
     import json
     import subprocess
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["DMSA_BENCH_BACKEND"] = "gloo"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-iters", "0", "--scans", "2", "--rings", "32",
-           "--az", "256", "--static", "2000", "--frames", "5", "--keyframe-steps", "2"]
+           "--az", "256", "--static", "2000", "--map-frames", "17", "--neighbourhoods", "4", "--keyframe-steps", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -184,7 +186,10 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
     assert sorted(p[0] for p in out["config"]["rank_device"]) == [0, 1]
     assert out["config"]["collective"] == {"backend": "gloo", "world_size": 2}
-    assert out["keyframe_pass"]["n_gpus"] == 2 and out["keyframe_pass"]["frames_total"] == 9
+    kp = out["keyframe_pass"]
+    assert kp["n_gpus"] == 2 and kp["frames_total"] == 17 and kp["neighbourhoods"] == 4 and kp["scaling"] == "strong" and kp["steps"] == 2
+    assert [(r["rank"], r["neighbourhoods"]) for r in kp["per_rank"]["ranks"]] == [(0, 2), (1, 2)]
+    assert all(r["ms"] > 0 and r["points"] > 0 and r["gaussians"] > 0 for r in kp["per_rank"]["ranks"]) and kp["per_rank"]["max_over_mean_ms"] >= 1.0
     # a launcher that disagrees with --gpus is an error, not a silent fallback
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env2)

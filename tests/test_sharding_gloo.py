@@ -41,6 +41,79 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _strong_map():
+    from dmsa_lidar_slam_amd import synth
+
+    return synth.keyframe_problem(seed=12, frames=25, rings=8, az_steps=64, arc=1.2)
+
+
+def _strong_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dmsa_lidar_slam_amd.problems import DmsaOptimSettings
+    from dmsa_lidar_slam_amd.sharding import gather_owned_neighbourhood_poses, neighbourhood_ranges, owned_neighbourhoods
+
+    m = _strong_map()
+    s = DmsaOptimSettings.keyframe_map(num_iter=1)
+    s.min_num_gaussians = 1
+    ranges = neighbourhood_ranges(m.numFrames, 8)
+    subs = {}
+    for nb in owned_neighbourhoods(8, rank, world):
+        subs[nb] = m.getSubmap(*ranges[nb])
+        _oracle_optimize(subs[nb], s)
+    gather_owned_neighbourhood_poses(m, subs, ranges, rank, world, dist)
+    np.savez(os.path.join(out_dir, f"w{world}_rank{rank}.npz"), ro=m.relOrientations, rt=m.relTranslations)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fixed_cut_gives_the_same_map_at_every_world_size(tmp_path):
+    """The strong-scaling layout of `bench.py --workload keyframes`: the map is cut into 8 neighbourhoods whatever the world size, rank r
+    runs r, r + N, ... and ONE all-gather carries ceil(8 / N) slots per rank.  N = 1 (no collective), 2, 4 and 8 gloo ranks end with
+    bit-identical relative poses on every rank -- the sequential composition of the eight updatePosesFromSubmap calls."""
+    sys.path.insert(0, ROOT)
+    from dmsa_lidar_slam_amd.problems import DmsaOptimSettings
+    from dmsa_lidar_slam_amd.sharding import gather_owned_neighbourhood_poses, neighbourhood_ranges, owned_neighbourhoods
+
+    assert owned_neighbourhoods(8, 1, 4) == [1, 5] and owned_neighbourhoods(8, 0, 1) == list(range(8)) and owned_neighbourhoods(8, 7, 8) == [7]
+    m = _strong_map()
+    s = DmsaOptimSettings.keyframe_map(num_iter=1)
+    s.min_num_gaussians = 1
+    ranges = neighbourhood_ranges(m.numFrames, 8)
+    seq = m.copy()
+    subs = {}
+    for nb, (f, t) in enumerate(ranges):
+        subs[nb] = m.getSubmap(f, t)
+        _oracle_optimize(subs[nb], s)
+        seq.updatePosesFromSubmap(f, t, subs[nb])
+    assert np.abs(seq.relTranslations - m.relTranslations).max() > 1e-6  # the pass changed something
+    one = m.copy()
+    gather_owned_neighbourhood_poses(one, subs, ranges, 0, 1)  # N = 1: the same function, no collective
+    assert np.array_equal(one.relOrientations, seq.relOrientations) and np.array_equal(one.relTranslations, seq.relTranslations)
+    for world in (2, 4, 8):
+        port = 29500 + ((os.getpid() + 11 * world) % 2000)
+        mp.spawn(_strong_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+        for r in range(world):
+            o = np.load(tmp_path / f"w{world}_rank{r}.npz")
+            assert np.array_equal(o["ro"], seq.relOrientations) and np.array_equal(o["rt"], seq.relTranslations), (world, r)
+
+
+def test_keyframe_map_dump_round_trip(tmp_path):
+    """bench.py generates the 249-frame map once (rank 0) and hands it to the other ranks as a flat dump (dump.py: 'DMSAKF01')."""
+    sys.path.insert(0, ROOT)
+    from dmsa_lidar_slam_amd import dump
+
+    m = _strong_map()
+    path = str(tmp_path / "map.bin")
+    dump.write_keyframe_map(path, m)
+    r = dump.read_keyframe_map(path)
+    for k in ("relOrientations", "relTranslations", "frameOffsets", "localPoints", "localNormals", "ringIds", "measuredGravity", "gravityPlausible", "gravity", "Cov_grav_inv"):
+        assert np.array_equal(getattr(m, k), getattr(r, k)), k
+    assert (m.minGridSize, m.useGravityErrorTerms, m.balancingFactorGrav) == (r.minGridSize, r.useGravityErrorTerms, r.balancingFactorGrav)
+
+
 def test_neighbourhood_ranges():
     from dmsa_lidar_slam_amd.sharding import neighbourhood_ranges
 
