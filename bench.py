@@ -285,13 +285,24 @@ def main():
             t_ring.append(time.perf_counter() - t)
         o_ring.close()
         n_all = prob.localPoints.shape[0]
+        cpp = cpp_aos_call(prob, len(off) - 1)
         pcie = {"iterations_per_call": 10,
                 "full_upload_call_ms": round(1e3 * min(t_full), 3), "full_upload_it_per_s": round(10 / min(t_full), 1),
                 "full_upload_h2d_bytes": int(20 * (n_all + prob.staticPoints.shape[0])),
                 "resident_ring_call_ms": round(1e3 * min(t_ring), 3), "resident_ring_it_per_s": round(10 / min(t_ring), 1),
                 "resident_ring_h2d_bytes": int(28 * per_scan + 20 * prob.staticPoints.shape[0]),
+                # the same call from C++ with the points in the reference's own containers (examples/aos_call_demo.cpp, include/dmsa_aos.h)
+                "cpp_aos_call_ms": cpp.get("aos_call_ms") if cpp else None, "cpp_aos_call_poses_only_ms": cpp.get("aos_call_poses_only_ms") if cpp else None,
+                "cpp_aos_ring_call_ms": cpp.get("aos_ring_call_ms") if cpp else None, "cpp_flat_call_ms": cpp.get("flat_call_ms") if cpp else None,
+                "cpp_host_repack_call_ms": cpp.get("host_repack_call_ms") if cpp else None,
+                "cpp_aos_bit_identical_to_flat": (cpp.get("poses_bit_identical") and cpp.get("global_points_bit_identical")) if cpp else None,
+                "cpp_aos_h2d_bytes": int(20 * n_all + 16 * prob.staticPoints.shape[0]),
                 "note": "wall time of whole calls through the Python ctypes layer, best of 3; (a) dmsa_optimize_window with host arrays, (b) one "
-                        "scan pushed into the resident ring + dmsa_window_upload_from_ring + dmsa_optimize_resident + dmsa_get_poses"}
+                        "scan pushed into the resident ring + dmsa_window_upload_from_ring + dmsa_optimize_resident + dmsa_get_poses; cpp_*: "
+                        "examples/aos_call_demo.cpp, the same 10-iteration call from C++ with one 32-byte-per-point array per scan (the layout of "
+                        "pcl::PointCloud<PointStampId>) -- aos: views handed to dmsa_optimize_window_aos + the global points written back into the "
+                        "strided container (poses_only: without that write-back), aos_ring: one scan pushed from its container into the resident "
+                        "ring, flat: arrays that are already flat, host_repack: the per-point repack a caller of the flat ABI needs"}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -484,6 +495,31 @@ def sharded_keyframe_pass(args, rank, local_rank, world, dist, coll_dev, sync_al
             "scaling": "strong" if strong else "weak", "frames_total": int(total_frames), "neighbourhoods": len(ranges),
             "neighbourhoods_per_rank": len(owned), "params_per_neighbourhood": int(subs[owned[0]].numParams), "per_rank": per_rank,
             "exchange": "one all-gather of ceil(neighbourhoods / ranks) x 32 x 6 doubles per rank" if world > 1 else "none (single GPU)"}
+
+
+def cpp_aos_call(prob, num_scans):
+    """examples/aos_call_demo: a 10-iteration drop-in call from C++ with one 32-byte-per-point array per scan (the layout of
+    pcl::PointCloud<PointStampId>), views handed to dmsa_optimize_window_aos, global points written back into the strided container."""
+    import subprocess
+    import tempfile
+
+    from dmsa_lidar_slam_amd import dump
+
+    exe = os.path.join(ROOT, "examples", "aos_call_demo")
+    if not os.path.exists(exe):
+        return None
+    path = os.path.join(tempfile.gettempdir(), f"dmsa_bench_window_{os.getpid()}.bin")
+    try:
+        dump.write_window_problem(path, prob)
+        r = subprocess.run([exe, path, str(num_scans), "10", "3"], capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            sys.stderr.write(f"[bench] aos_call_demo failed ({r.returncode}): {r.stderr[-500:]}\n")
+            return None
+        return json.loads(lines[-1])
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
 
 
 def cpu_baseline(prob, settings, iters, workload):

@@ -161,6 +161,11 @@ class DebugCounters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("sync_retries", "speculation_retries", "skip_pairs", "skip_pairs_equal", "skip_mismatches")]
 
 
+class AosView(C.Structure):
+    """include/dmsa_aos.h: dmsa_aos_view -- one strided cloud as it lies in memory."""
+    _fields_ = [("base", C.c_void_p), ("count", C.c_int64), ("stride", C.c_int32), ("xyz_offset", C.c_int32), ("aux_offset", C.c_int32), ("index", C.POINTER(C.c_int32))]
+
+
 class RawImu(C.Structure):
     """include/dmsa_raw_sequence.h: dmsa_raw_imu."""
     _fields_ = [("stamp", C.c_double), ("ang_vel", C.c_double * 3), ("lin_acc", C.c_double * 3)]
@@ -285,6 +290,15 @@ def load_library() -> C.CDLL:
         "dmsa_default_debug_options": (None, [C.POINTER(DebugOptions)]),
         "dmsa_create_ex": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(DebugOptions), C.POINTER(vp)]),
         "dmsa_get_debug_counters": (C.c_int, [vp, C.POINTER(DebugCounters)]),
+        # include/dmsa_aos.h
+        "dmsa_window_upload_aos": (C.c_int, [vp, C.POINTER(WindowProblem), C.POINTER(AosView), C.c_int32, C.POINTER(AosView)]),
+        "dmsa_keyframes_upload_aos": (C.c_int, [vp, C.POINTER(KeyframeProblem), C.POINTER(AosView), C.c_int32]),
+        "dmsa_optimize_window_aos": (C.c_int, [vp, C.POINTER(WindowProblem), C.POINTER(AosView), C.c_int32, C.POINTER(AosView), C.POINTER(Settings), C.POINTER(Report)]),
+        "dmsa_optimize_keyframes_aos": (C.c_int, [vp, C.POINTER(KeyframeProblem), C.POINTER(AosView), C.c_int32, C.POINTER(Settings), C.POINTER(Report)]),
+        "dmsa_get_global_points_aos": (C.c_int, [vp, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+        "dmsa_reserve": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32]),
+        "dmsa_window_ring_push_aos": (C.c_int, [vp, C.POINTER(AosView), C.c_int32]),
+        "dmsa_window_upload_from_ring_aos": (C.c_int, [vp, C.POINTER(WindowProblem), C.c_double, C.POINTER(AosView)]),
         # include/dmsa_window_ring.h
         "dmsa_window_ring_create": (C.c_int, [vp, C.POINTER(WindowRingConfig)]),
         "dmsa_window_ring_push": (C.c_int, [vp, c_float_p, c_double_p, c_int32_p, C.c_int64]),
@@ -341,6 +355,7 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
+    "dmsa_window_upload_aos dmsa_keyframes_upload_aos dmsa_optimize_window_aos dmsa_optimize_keyframes_aos dmsa_get_global_points_aos dmsa_reserve dmsa_window_ring_push_aos dmsa_window_upload_from_ring_aos "
     "dmsa_create dmsa_create_ex dmsa_default_debug_options dmsa_get_debug_counters dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
     "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
     "dmsa_set_params dmsa_additional_errors dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "

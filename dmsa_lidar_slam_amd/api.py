@@ -85,6 +85,93 @@ class DmsaOptimizer:
         self._problem, self._cprob = pointSetToOptimize, cp
         return rep
 
+    # -- include/dmsa_aos.h: the reference's own point containers -------------------------------------------------------
+    POINT_STAMP_ID = np.dtype({"names": ["x", "y", "z", "w", "stamp", "id", "isStatic"], "formats": ["<f4", "<f4", "<f4", "<f4", "<f8", "<i4", "<i4"],
+                               "offsets": [0, 4, 8, 12, 16, 24, 28], "itemsize": 32})   # PointStampId.h:33-45
+    POINT_NORMAL = np.dtype({"names": ["x", "y", "z", "w", "normal_x", "normal_y", "normal_z", "nw", "curvature"],
+                             "formats": ["<f4"] * 9, "offsets": [0, 4, 8, 12, 16, 20, 24, 28, 32], "itemsize": 48})  # pcl::PointNormal
+
+    @staticmethod
+    def _view(arr, aux_offset, index):
+        v = capi.AosView()
+        v.base, v.count, v.stride, v.xyz_offset, v.aux_offset = arr.ctypes.data, arr.shape[0], arr.dtype.itemsize, 0, aux_offset
+        v.index = index.ctypes.data_as(C.POINTER(C.c_int32)) if index is not None else None
+        return v
+
+    def optimizeSetAos(self, pointSetToOptimize, settings: DmsaOptimSettings | None = None, reserve: bool = False):
+        """optimizeSet with the points handed over as the reference holds them: one pcl::PointCloud<PointStampId> per scan of the ring buffer
+        (32-byte points) plus the static tail of globalPoints, or one pcl::PointCloud<PointNormal> per keyframe (48-byte points).  The
+        structured arrays built here stand in for cloud.points.data(); returns (report, clouds) -- after the call the first array
+        holds... nothing new: the global points are fetched with globalPointsAos()."""
+        settings = settings or DmsaOptimSettings()
+        cs, rep, p = settings.to_c(), capi.Report(), pointSetToOptimize
+        cp = p.to_c()
+        keep = []
+        if isinstance(p, ContinuousTrajectory):
+            off = getattr(p, "scanOffsets", None)
+            if off is None:
+                off = np.array([0, p.localPoints.shape[0]])
+            views = (capi.AosView * (len(off) - 1))()
+            for k in range(len(off) - 1):
+                a, b = int(off[k]), int(off[k + 1])
+                cloud = np.zeros(b - a, self.POINT_STAMP_ID)
+                cloud["x"], cloud["y"], cloud["z"], cloud["w"] = p.localPoints[a:b, 0], p.localPoints[a:b, 1], p.localPoints[a:b, 2], 1.0
+                cloud["id"], cloud["stamp"] = p.ringIds[a:b], 1.6e9
+                idx = np.ascontiguousarray(p.tformIdPerPoint[a:b], np.int32)
+                keep += [cloud, idx]
+                views[k] = self._view(cloud, 24, idx)
+            stat = np.zeros(p.staticPoints.shape[0], self.POINT_STAMP_ID)
+            stat["x"], stat["y"], stat["z"], stat["w"] = p.staticPoints[:, 0], p.staticPoints[:, 1], p.staticPoints[:, 2], 1.0
+            stat["id"], stat["stamp"], stat["isStatic"] = p.staticRingIds, -1000.0, 1
+            sv = self._view(stat, 24, None)
+            keep.append(stat)
+            if reserve:
+                self._check(self._lib.dmsa_reserve(self._ctx, p.localPoints.shape[0] + stat.shape[0], p.trajTime.shape[0], p.numParams), "reserve")
+            rc = self._lib.dmsa_optimize_window_aos(self._ctx, C.byref(cp), views, len(off) - 1, C.byref(sv), C.byref(cs), C.byref(rep))
+        else:
+            off = p.frameOffsets
+            views = (capi.AosView * p.numFrames)()
+            for k in range(p.numFrames):
+                a, b = int(off[k]), int(off[k + 1])
+                cloud = np.zeros(b - a, self.POINT_NORMAL)
+                cloud["x"], cloud["y"], cloud["z"], cloud["w"] = p.localPoints[a:b, 0], p.localPoints[a:b, 1], p.localPoints[a:b, 2], p.localPoints[a:b, 3]
+                cloud["normal_x"], cloud["normal_y"], cloud["normal_z"], cloud["nw"] = (p.localNormals[a:b, c] for c in range(4))
+                idx = np.ascontiguousarray(p.ringIds[a:b], np.int32)
+                keep += [cloud, idx]
+                views[k] = self._view(cloud, 16, idx)
+            rc = self._lib.dmsa_optimize_keyframes_aos(self._ctx, C.byref(cp), views, p.numFrames, C.byref(cs), C.byref(rep))
+        self._check(rc, "optimizeSetAos")
+        self._problem, self._cprob = p, cp
+        return rep
+
+    def ringPushAos(self, xyz_local, stamps, ring_ids):
+        """dmsa_window_ring_push_aos: the scan as a pcl::PointCloud<PointStampId> (32-byte points) instead of three flat arrays."""
+        cloud = np.zeros(len(stamps), self.POINT_STAMP_ID)
+        cloud["x"], cloud["y"], cloud["z"], cloud["w"] = xyz_local[:, 0], xyz_local[:, 1], xyz_local[:, 2], 1.0
+        cloud["stamp"], cloud["id"] = stamps, ring_ids
+        v = self._view(cloud, 24, None)
+        self._check(self._lib.dmsa_window_ring_push_aos(self._ctx, C.byref(v), 16), "window_ring_push_aos")
+
+    def uploadFromRingAos(self, window: ContinuousTrajectory, t0: float):
+        """dmsa_window_upload_from_ring_aos: the static points as the PointStampId tail of globalPoints."""
+        cp = window.to_c()
+        stat = np.zeros(window.staticPoints.shape[0], self.POINT_STAMP_ID)
+        stat["x"], stat["y"], stat["z"], stat["w"] = window.staticPoints[:, 0], window.staticPoints[:, 1], window.staticPoints[:, 2], 1.0
+        stat["id"], stat["stamp"], stat["isStatic"] = window.staticRingIds, -1000.0, 1
+        sv = self._view(stat, 24, None)
+        cp.num_points = 0
+        self._check(self._lib.dmsa_window_upload_from_ring_aos(self._ctx, C.byref(cp), float(t0), C.byref(sv)), "window_upload_from_ring_aos")
+        self._problem, self._cprob = window, cp
+
+    def globalPointsAos(self, keyframes: bool = False) -> np.ndarray:
+        """The final updateGlobalPoints written into a strided globalPoints container (PointStampId / PointNormal layout)."""
+        n = self._num_points()
+        out = np.zeros(n, self.POINT_NORMAL if keyframes else self.POINT_STAMP_ID)
+        if not keyframes:
+            out["stamp"], out["id"] = 7.0, 123  # fields the call must leave alone
+        self._check(self._lib.dmsa_get_global_points_aos(self._ctx, out.ctypes.data, n, out.dtype.itemsize, 0, 16 if keyframes else -1), "get_global_points_aos")
+        return out
+
     def optimizeResident(self, settings: DmsaOptimSettings) -> capi.Report:
         """optimizeSet on the problem already resident in HBM (after upload() or a previous optimizeSet)."""
         cs = settings.to_c()

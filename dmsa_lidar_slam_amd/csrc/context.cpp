@@ -188,6 +188,73 @@ bool sync_wait_timed_out(dmsa_ctx* ctx, std::string* what) {
     ctx->tables_pending = false;
     return true;
 }
+// ---- the parts of an upload that do not depend on how the points arrive (flat arrays: below; strided PCL containers: aos_upload.cpp) ----
+int ensure_stage(dmsa_ctx* ctx, size_t bytes) {
+    if (bytes > ctx->h_stage_cap) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // the old area may still feed a copy
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+        ctx->h_stage = nullptr, ctx->h_stage_cap = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), bytes + bytes / 8, hipHostMallocDefault));
+        ctx->h_stage_cap = bytes + bytes / 8;
+    }
+    return DMSA_OK;
+}
+int window_upload_begin(dmsa_ctx* ctx, const dmsa_window_problem* p, int64_t N, int64_t S) {
+    CHK(set_device(ctx));
+    if (!(p->min_grid_size > 0.0f)) {
+        ctx->err = "invalid window problem (min_grid_size <= 0)";
+        return DMSA_ERR_INVALID;
+    }
+    if (!ctx->win.init(*p)) {
+        ctx->err = "invalid window problem (fewer than 3 control poses, coincident stamps, null pose arrays or IMU parameter indices outside the time grid)";
+        return DMSA_ERR_INVALID;
+    }
+    if (ctx->win.ctrl.n > 64) {
+        ctx->err = "more than 64 control poses";
+        return DMSA_ERR_INVALID;
+    }
+    ctx->model = MODEL_WINDOW;
+    ctx->N = N, ctx->S = S, ctx->n = N + S;
+    ctx->rows = p->n_total + 1;
+    HIPCHK(ctx->d_local.ensure((size_t)ctx->n * 16 + 16));
+    HIPCHK(ctx->d_ring.ensure((size_t)ctx->n * 4 + 16));
+    return DMSA_OK;
+}
+int window_upload_finish(dmsa_ctx* ctx, const dmsa_window_problem* p) {
+    const int C = ctx->win.ctrl.n;
+    HIPCHK(ctx->d_stamps.ensure((size_t)C * 8));
+    HIPCHK(ctx->d_fhw.ensure((size_t)C * 8));
+    HIPCHK(ctx->d_trajtime.ensure((size_t)p->n_total * 8));
+    HIPCHK(hipMemcpy(ctx->d_stamps.p, ctx->win.stamps.data(), (size_t)C * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_fhw.p, ctx->win.fh.w.data(), (size_t)C * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_trajtime.p, ctx->win.traj_time.data(), (size_t)p->n_total * 8, hipMemcpyHostToDevice));
+    ctx->win.ctrl.relative_to_global();
+    ctx->min_grid_size = p->min_grid_size;
+    CHK(upload_loop_model(ctx));
+    return upload_common(ctx);
+}
+int keyframes_upload_begin(dmsa_ctx* ctx, const dmsa_keyframe_problem* p, int64_t n_points) {
+    if (!p->rel_orient || !p->rel_transl || !(p->min_grid_size > 0.0f)) {
+        ctx->err = "invalid keyframe problem (null pose arrays or min_grid_size <= 0)";
+        return DMSA_ERR_INVALID;
+    }
+    CHK(set_device(ctx));
+    if (!ctx->key.init(*p)) return DMSA_ERR_INVALID;
+    ctx->model = MODEL_KEYFRAMES;
+    ctx->n = n_points, ctx->N = ctx->n, ctx->S = 0;
+    ctx->rows = p->num_frames + 1;
+    const size_t n = (size_t)ctx->n;
+    HIPCHK(ctx->d_local.ensure(n * 16 + 16));
+    HIPCHK(ctx->d_nlocal.ensure(n * 16 + 16));
+    HIPCHK(ctx->d_nglobal.ensure(n * 16 + 16));
+    HIPCHK(ctx->d_ring.ensure(n * 4 + 16));
+    return DMSA_OK;
+}
+int keyframes_upload_finish(dmsa_ctx* ctx, const dmsa_keyframe_problem* p) {
+    ctx->min_grid_size = p->min_grid_size;
+    CHK(upload_loop_model(ctx));
+    return upload_common(ctx);
+}
 void write_back_poses(const PoseChain& c, double* rel_o, double* rel_t) {
     std::copy(c.rel_o.begin(), c.rel_o.end(), rel_o);
     std::copy(c.rel_t.begin(), c.rel_t.end(), rel_t);
@@ -327,33 +394,15 @@ void dmsa_default_settings(dmsa_settings* s) {
 
 int dmsa_window_upload(dmsa_ctx* ctx, const dmsa_window_problem* p) {
     if (!ctx || !p || p->num_points < 0 || p->num_static < 0) return DMSA_ERR_INVALID;
-    CHK(set_device(ctx));
-    if ((p->num_points > 0 && (!p->xyz_local || !p->tform_idx || !p->ring_id)) || (p->num_static > 0 && (!p->xyz_static || !p->ring_id_static)) ||
-        !(p->min_grid_size > 0.0f)) {
-        ctx->err = "invalid window problem (null point arrays or min_grid_size <= 0)";
+    if ((p->num_points > 0 && (!p->xyz_local || !p->tform_idx || !p->ring_id)) || (p->num_static > 0 && (!p->xyz_static || !p->ring_id_static))) {
+        ctx->err = "invalid window problem (null point arrays)";
         return DMSA_ERR_INVALID;
     }
-    if (!ctx->win.init(*p)) {
-        ctx->err = "invalid window problem (fewer than 3 control poses, coincident stamps, null pose arrays or IMU parameter indices outside the time grid)";
-        return DMSA_ERR_INVALID;
-    }
-    if (ctx->win.ctrl.n > 64) {
-        ctx->err = "more than 64 control poses";
-        return DMSA_ERR_INVALID;
-    }
-    ctx->model = MODEL_WINDOW;
-    ctx->N = p->num_points, ctx->S = p->num_static, ctx->n = ctx->N + ctx->S;
-    ctx->rows = p->n_total + 1;
+    CHK(window_upload_begin(ctx, p, p->num_points, p->num_static));
     const size_t n = (size_t)ctx->n;
     // local points: (x, y, z, row index); static points ride along with the identity row.  Packed into pinned memory by a few
     // host threads (the user's arrays are pageable), then one DMA per array.
-    const size_t stage_bytes = n * 20 + 64;
-    if (stage_bytes > ctx->h_stage_cap) {
-        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-        ctx->h_stage = nullptr, ctx->h_stage_cap = 0;
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), stage_bytes + stage_bytes / 8, hipHostMallocDefault));
-        ctx->h_stage_cap = stage_bytes + stage_bytes / 8;
-    }
+    CHK(ensure_stage(ctx, n * 20 + 64));
     float* loc = reinterpret_cast<float*>(ctx->h_stage);
     int32_t* ring = reinterpret_cast<int32_t*>(ctx->h_stage + n * 16);
     const int32_t id_row = p->n_total;
@@ -387,28 +436,16 @@ int dmsa_window_upload(dmsa_ctx* ctx, const dmsa_window_problem* p) {
         ctx->err = "tform_idx out of range";
         return DMSA_ERR_INVALID;
     }
-    HIPCHK(ctx->d_local.ensure(n * 16 + 16));
-    HIPCHK(ctx->d_ring.ensure(n * 4 + 16));
     HIPCHK(hipMemcpyAsync(ctx->d_local.p, loc, n * 16, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_ring.p, ring, n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next upload
-    const int C = ctx->win.ctrl.n;
-    HIPCHK(ctx->d_stamps.ensure((size_t)C * 8));
-    HIPCHK(ctx->d_fhw.ensure((size_t)C * 8));
-    HIPCHK(ctx->d_trajtime.ensure((size_t)p->n_total * 8));
-    HIPCHK(hipMemcpy(ctx->d_stamps.p, ctx->win.stamps.data(), (size_t)C * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->d_fhw.p, ctx->win.fh.w.data(), (size_t)C * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->d_trajtime.p, ctx->win.traj_time.data(), (size_t)p->n_total * 8, hipMemcpyHostToDevice));
-    ctx->win.ctrl.relative_to_global();
-    ctx->min_grid_size = p->min_grid_size;
-    CHK(upload_loop_model(ctx));
-    return upload_common(ctx);
+    return window_upload_finish(ctx, p);
 }
 
 int dmsa_keyframes_upload(dmsa_ctx* ctx, const dmsa_keyframe_problem* p) {
     if (!ctx || !p || p->num_frames < 2) return DMSA_ERR_INVALID;
-    if (!p->frame_offset || !p->xyz_local || !p->normal_local || !p->ring_id || !p->rel_orient || !p->rel_transl || !(p->min_grid_size > 0.0f)) {
-        ctx->err = "invalid keyframe problem (null arrays or min_grid_size <= 0)";
+    if (!p->frame_offset || !p->xyz_local || !p->normal_local || !p->ring_id) {
+        ctx->err = "invalid keyframe problem (null point arrays)";
         return DMSA_ERR_INVALID;
     }
     if (p->frame_offset[0] != 0) {
@@ -420,12 +457,8 @@ int dmsa_keyframes_upload(dmsa_ctx* ctx, const dmsa_keyframe_problem* p) {
             ctx->err = "invalid keyframe problem (frame_offset not non-decreasing)";
             return DMSA_ERR_INVALID;
         }
-    CHK(set_device(ctx));
-    if (!ctx->key.init(*p)) return DMSA_ERR_INVALID;
-    ctx->model = MODEL_KEYFRAMES;
     const int F = p->num_frames;
-    ctx->n = p->frame_offset[F], ctx->N = ctx->n, ctx->S = 0;
-    ctx->rows = F + 1;
+    CHK(keyframes_upload_begin(ctx, p, p->frame_offset[F]));
     const size_t n = (size_t)ctx->n;
     std::vector<float> loc(n * 4);
     for (int k = 0; k < F; ++k)
@@ -434,16 +467,10 @@ int dmsa_keyframes_upload(dmsa_ctx* ctx, const dmsa_keyframe_problem* p) {
             const int32_t row = k;
             std::memcpy(&loc[4 * i + 3], &row, 4);
         }
-    HIPCHK(ctx->d_local.ensure(n * 16 + 16));
-    HIPCHK(ctx->d_nlocal.ensure(n * 16 + 16));
-    HIPCHK(ctx->d_nglobal.ensure(n * 16 + 16));
-    HIPCHK(ctx->d_ring.ensure(n * 4 + 16));
     HIPCHK(hipMemcpy(ctx->d_local.p, loc.data(), n * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->d_nlocal.p, p->normal_local, n * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->d_ring.p, p->ring_id, n * 4, hipMemcpyHostToDevice));
-    ctx->min_grid_size = p->min_grid_size;
-    CHK(upload_loop_model(ctx));
-    return upload_common(ctx);
+    return keyframes_upload_finish(ctx, p);
 }
 
 

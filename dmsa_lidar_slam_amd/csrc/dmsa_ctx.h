@@ -29,6 +29,7 @@
 #include "../../include/dmsa_window_setup.h"
 #include "../../include/dmsa_wire_formats.h"
 #include "../../include/dmsa_keyframe_cloud.h"
+#include "../../include/dmsa_aos.h"
 #include "device_prims.h"
 #include "radix_sort_dev.h"
 #include "dmsa_kernels.h"
@@ -263,6 +264,7 @@ struct dmsa_ctx {
     int wait_seq = 0;                    // waits enqueued by the current whole call (debug switch sync_fault withholds the signal of one of them)
     int voxel_calls = 0;                 // voxelisations of the current whole call (debug switch speculation_fault plants a wrong guess in one of them)
     int sync_retries = 0, speculation_retries = 0;  // since the context was created: calls re-run with events after a wait timed out; voxelisations re-run after a wrong guess
+    DevBuf d_aos_raw, d_aos_idx;         // include/dmsa_aos.h: the caller's strided clouds as they lie in memory, and their per-point indices
     DevBuf d_static_keep;                // the static points as uploaded (a call that has to start over restores them: centralize / decentralize is no exact round trip)
     uint32_t* sync_counter(int slot) const { return d_sync.as<uint32_t>() + slot; }
     int32_t* sync_timed_out() const { return d_sync.as<int32_t>() + SYNC_TIMED_OUT; }
@@ -351,6 +353,11 @@ int alloc_point_buffers(dmsa_ctx* ctx);
 int upload_loop_model(dmsa_ctx* ctx);
 int upload_common(dmsa_ctx* ctx);
 void write_back_poses(const PoseChain& c, double* rel_o, double* rel_t);
+int ensure_stage(dmsa_ctx* ctx, size_t bytes);  // the pinned staging area of the uploads holds at least `bytes`
+int window_upload_begin(dmsa_ctx* ctx, const dmsa_window_problem* p, int64_t N, int64_t S);  // host model, sizes, point buffers (points themselves: the caller)
+int window_upload_finish(dmsa_ctx* ctx, const dmsa_window_problem* p);
+int keyframes_upload_begin(dmsa_ctx* ctx, const dmsa_keyframe_problem* p, int64_t n_points);
+int keyframes_upload_finish(dmsa_ctx* ctx, const dmsa_keyframe_problem* p);
 struct HostTimeline {
     bool on = false;  // dmsa_debug_options::host_timeline of the context that optimises
     std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> marks;

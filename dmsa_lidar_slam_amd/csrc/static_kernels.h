@@ -87,3 +87,17 @@ void launch_to_keyframe_frame(const float4* global, const int32_t* ids, const in
                               float4* local, int32_t* ring, hipStream_t s);
 
 }  // namespace dmsa
+
+namespace dmsa {
+// include/dmsa_aos.h: strided PCL containers packed on the device.  raw = `count` points of `stride` bytes as they lie in the caller's
+// cloud; out[i] = (x, y, z, row as int bits); window clouds: row = index[i] (tformIdPerPoint), must lie in [0, row_limit) or *bad is set;
+// static points: row = fixed_row; the int32 at aux_offset is the ring id.
+void launch_pack_aos_window(const uint8_t* raw, int64_t count, int stride, int xyz_offset, int aux_offset, const int32_t* index, int row_limit, int fixed_row,
+                            float4* local_out, int32_t* ring_out, int32_t* bad, hipStream_t s);
+// a scan for the resident ring (include/dmsa_window_ring.h): coordinates (w = 1), the double at stamp_offset, the int32 at id_offset
+void launch_unpack_ring_scan(const uint8_t* raw, int64_t count, int stride, int xyz_offset, int stamp_offset, int id_offset, float4* xyz_out, double* stamp_out,
+                             int32_t* id_out, hipStream_t s);
+// keyframe clouds: row = the frame, normal = the four floats at aux_offset
+void launch_pack_aos_keyframe(const uint8_t* raw, int64_t count, int stride, int xyz_offset, int aux_offset, int row, float4* local_out, float4* normal_out,
+                              hipStream_t s);
+}  // namespace dmsa

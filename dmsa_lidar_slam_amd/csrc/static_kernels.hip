@@ -703,4 +703,64 @@ void launch_to_keyframe_frame(const float4* global, const int32_t* ids, const in
     if (m > 0) hipLaunchKernelGGL(k_to_keyframe_frame, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, global, ids, pick, m, R, tx, ty, tz, local, ring);
 }
 
+// ---- include/dmsa_aos.h: the caller's strided clouds, packed on the device ---------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_pack_aos_window(const uint8_t* __restrict__ raw, int64_t count, int stride, int xyz_offset, int aux_offset,
+                                                            const int32_t* __restrict__ index, int row_limit, int fixed_row, float4* __restrict__ local_out,
+                                                            int32_t* __restrict__ ring_out, int32_t* __restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint8_t* pt = raw + (size_t)i * stride;
+    const float* xyz = reinterpret_cast<const float*>(pt + xyz_offset);  // stride and offsets are multiples of four
+    int row = fixed_row;
+    if (index != nullptr) {
+        row = index[i];
+        if (row < 0 || row >= row_limit) {
+            *bad = 1;
+            row = 0;
+        }
+    }
+    local_out[i] = make_float4(xyz[0], xyz[1], xyz[2], __int_as_float(row));
+    ring_out[i] = *reinterpret_cast<const int32_t*>(pt + aux_offset);
+}
+__global__ __launch_bounds__(kBlock) void k_pack_aos_keyframe(const uint8_t* __restrict__ raw, int64_t count, int stride, int xyz_offset, int aux_offset, int row,
+                                                              float4* __restrict__ local_out, float4* __restrict__ normal_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint8_t* pt = raw + (size_t)i * stride;
+    const float* xyz = reinterpret_cast<const float*>(pt + xyz_offset);
+    const float* nrm = reinterpret_cast<const float*>(pt + aux_offset);
+    local_out[i] = make_float4(xyz[0], xyz[1], xyz[2], __int_as_float(row));
+    normal_out[i] = make_float4(nrm[0], nrm[1], nrm[2], nrm[3]);
+}
+// the scan of a window as the ring keeps it (include/dmsa_window_ring.h): coordinates, stamps, ring ids out of a strided cloud
+__global__ __launch_bounds__(kBlock) void k_unpack_ring_scan(const uint8_t* __restrict__ raw, int64_t count, int stride, int xyz_offset, int stamp_offset, int id_offset,
+                                                             float4* __restrict__ xyz_out, double* __restrict__ stamp_out, int32_t* __restrict__ id_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint8_t* pt = raw + (size_t)i * stride;
+    const float* xyz = reinterpret_cast<const float*>(pt + xyz_offset);
+    xyz_out[i] = make_float4(xyz[0], xyz[1], xyz[2], 1.0f);
+    const uint32_t* sw = reinterpret_cast<const uint32_t*>(pt + stamp_offset);  // (4-byte aligned reads: the stride need not be a multiple of eight)
+    stamp_out[i] = __longlong_as_double((long long)(((unsigned long long)sw[1] << 32) | sw[0]));
+    id_out[i] = *reinterpret_cast<const int32_t*>(pt + id_offset);
+}
+void launch_unpack_ring_scan(const uint8_t* raw, int64_t count, int stride, int xyz_offset, int stamp_offset, int id_offset, float4* xyz_out, double* stamp_out,
+                             int32_t* id_out, hipStream_t s) {
+    if (count > 0)
+        hipLaunchKernelGGL(k_unpack_ring_scan, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, raw, count, stride, xyz_offset, stamp_offset, id_offset,
+                           xyz_out, stamp_out, id_out);
+}
+void launch_pack_aos_window(const uint8_t* raw, int64_t count, int stride, int xyz_offset, int aux_offset, const int32_t* index, int row_limit, int fixed_row,
+                            float4* local_out, int32_t* ring_out, int32_t* bad, hipStream_t s) {
+    if (count > 0)
+        hipLaunchKernelGGL(k_pack_aos_window, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, raw, count, stride, xyz_offset, aux_offset, index,
+                           row_limit, fixed_row, local_out, ring_out, bad);
+}
+void launch_pack_aos_keyframe(const uint8_t* raw, int64_t count, int stride, int xyz_offset, int aux_offset, int row, float4* local_out, float4* normal_out,
+                              hipStream_t s) {
+    if (count > 0)
+        hipLaunchKernelGGL(k_pack_aos_keyframe, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, raw, count, stride, xyz_offset, aux_offset, row,
+                           local_out, normal_out);
+}
+
 }  // namespace dmsa

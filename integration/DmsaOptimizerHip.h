@@ -2,13 +2,15 @@
 //
 // Keeps the class name pattern and the optimizeSet signatures of DmsaOptimizer<PointT> (include/DMSA/DmsaOptimizer.h:54), extracts the
 // state the OptimizablePointSet virtuals (OptimizablePointSet.h:18-56) would read from the two concrete models, and calls the C ABI
-// (include/dmsa_hip.h).  Needs Eigen / PCL like the rest of the reference, so it cannot be compiled in the graft image;
+// (include/dmsa_hip.h; the points through include/dmsa_aos.h: the PCL containers as they lie in memory).  Needs Eigen / PCL like the rest of the reference, so it cannot be compiled in the graft image;
 // scripts/build_ref_oracle.sh documents the environment.  flags = 0 is the path whose poses match the reference's summation order
 // (DMSA_FLAG_FAST_SUMS trades that for speed and is NOT a drop-in).
 #pragma once
 #include <stdexcept>
 #include <vector>
+#include <cstddef>
 #include <dmsa_hip.h>
+#include <dmsa_aos.h>
 #include "ContinuousTrajectory.h"
 #include "MapManagement.h"
 #include "DmsaOptimizer.h"          // DmsaOptimSettings
@@ -29,28 +31,24 @@ public:
     }
 
     // == DmsaOptimizer<PointStampId>::optimizeSet(ContinuousTrajectory&, settings)
+    // The clouds are handed over as they lie in memory (include/dmsa_aos.h): no per-point repacking on the host.
     void optimizeSet(ContinuousTrajectory& t, DmsaOptimSettings settings = DmsaOptimSettings()) {
-        std::vector<float> local, stat; std::vector<int32_t> tf, ring, ringS;
+        std::vector<dmsa_aos_view> scans;
+        size_t N = 0;
         for (int pc = 0; pc < t.regPcBuffer->getNumElements(); ++pc) {             // updateGlobalPoints order (:137-155)
             auto& c = t.regPcBuffer->at(pc);
-            for (size_t k = 0; k < c.size(); ++k) {
-                local.insert(local.end(), c.points[k].data, c.points[k].data + 4);
-                tf.push_back(t.tformIdPerPoint[pc][k]); ring.push_back(c.points[k].id);
-            }
+            scans.push_back({c.points.data(), (int64_t)c.points.size(), (int32_t)sizeof(PointStampId), (int32_t)offsetof(PointStampId, data),
+                             (int32_t)offsetof(PointStampId, id), t.tformIdPerPoint[pc].data()});
+            N += c.points.size();
         }
-        const size_t N = ring.size();
-        for (size_t k = N; k < t.globalPoints.size(); ++k) {                        // addStaticPoints tail (:158-172)
-            stat.insert(stat.end(), t.globalPoints.points[k].data, t.globalPoints.points[k].data + 4);
-            ringS.push_back(t.globalPoints.points[k].id);
-        }
+        const dmsa_aos_view stat{t.globalPoints.points.data() + N, (int64_t)(t.globalPoints.points.size() - N), (int32_t)sizeof(PointStampId),   // addStaticPoints tail (:158-172)
+                                 (int32_t)offsetof(PointStampId, data), (int32_t)offsetof(PointStampId, id), nullptr};
         dmsa_window_problem p{};
         p.num_control_poses = t.controlPoses.numPoses;
         p.rel_orient = t.controlPoses.relativePoses.Orientations.data();
         p.rel_transl = t.controlPoses.relativePoses.Translations.data();
         p.stamps = t.controlPoses.stamps.data();
         p.n_total = t.n_total;             p.traj_time = t.trajTime.data();
-        p.num_points = (int64_t)N;         p.xyz_local = local.data();  p.tform_idx = tf.data();  p.ring_id = ring.data();
-        p.num_static = (int64_t)ringS.size(); p.xyz_static = stat.data(); p.ring_id_static = ringS.data();
         p.min_grid_size = t.minGridSize;
         p.use_imu = t.useImuErrorTerms;    p.dt_res = t.dt_res;  p.balancing_imu = t.balancingImu;
         std::copy(t.gravity.data(), t.gravity.data() + 3, p.gravity);
@@ -64,21 +62,24 @@ public:
             p.preint_rot = rot.data(); p.preint_pos = pos.data(); p.preint_vel = vel.data(); p.cov_pvrot_inv = cov.data();
         }
         dmsa_settings s = convert(settings); dmsa_report rep{};
-        if (dmsa_optimize_window(ctx_, &p, &s, &rep) != DMSA_OK) throw std::runtime_error(dmsa_last_error(ctx_));
+        if (dmsa_optimize_window_aos(ctx_, &p, scans.data(), (int32_t)scans.size(), &stat, &s, &rep) != DMSA_OK) throw std::runtime_error(dmsa_last_error(ctx_));
         t.controlPoses.relative2global();                                           // poses were updated in place
-        std::vector<float> g(4 * t.globalPoints.size());                            // final updateGlobalPoints (:149)
-        dmsa_get_global_points(ctx_, g.data(), (int64_t)t.globalPoints.size());
-        for (size_t k = 0; k < t.globalPoints.size(); ++k) std::copy(&g[4 * k], &g[4 * k] + 3, t.globalPoints.points[k].data);
+        // final updateGlobalPoints (:149): x, y, z written into globalPoints, every other field of a point left alone
+        dmsa_get_global_points_aos(ctx_, t.globalPoints.points.data(), (int64_t)t.globalPoints.points.size(), (int32_t)sizeof(PointStampId),
+                                   (int32_t)offsetof(PointStampId, data), -1);
     }
 
     // == DmsaOptimizer<PointNormal>::optimizeSet(MapManagement&, settings)
     void optimizeSet(MapManagement& m, DmsaOptimSettings settings = DmsaOptimSettings()) {
         const int F = m.keyframeDataBuffer.getNumElements();
-        std::vector<int64_t> off(F + 1, 0); std::vector<float> xyz, nrm; std::vector<double> grav, otr, orm; std::vector<int32_t> plaus;
+        std::vector<dmsa_aos_view> frames; std::vector<double> grav, otr, orm; std::vector<int32_t> plaus;
+        int64_t first = 0;
         for (int k = 0; k < F; ++k) {
             auto& kd = m.keyframeDataBuffer.at(k);
-            for (auto& pt : *kd.pointCloudLocal) { xyz.insert(xyz.end(), pt.data, pt.data + 4); nrm.insert(nrm.end(), pt.data_n, pt.data_n + 4); }
-            off[k + 1] = off[k] + (int64_t)kd.pointCloudLocal->size();
+            auto& pts = kd.pointCloudLocal->points;                                // pcl::PointNormal: data[4] | data_n[4] | curvature, 48 bytes
+            frames.push_back({pts.data(), (int64_t)pts.size(), (int32_t)sizeof(pcl::PointNormal), (int32_t)offsetof(pcl::PointNormal, data),
+                              (int32_t)offsetof(pcl::PointNormal, data_n), m.ringIds.data() + first});   // MapManagement::ringIds is flat over the frames
+            first += (int64_t)pts.size();
             grav.insert(grav.end(), kd.measuredGravity.data(), kd.measuredGravity.data() + 3); plaus.push_back(kd.gravityPlausible);
             otr.insert(otr.end(), kd.relativeTransl.data(), kd.relativeTransl.data() + 3);
             orm.insert(orm.end(), kd.relativeOrientMat.data(), kd.relativeOrientMat.data() + 9);
@@ -87,7 +88,6 @@ public:
         p.num_frames = F;
         p.rel_orient = m.keyframePoses.relativePoses.Orientations.data();
         p.rel_transl = m.keyframePoses.relativePoses.Translations.data();
-        p.frame_offset = off.data(); p.xyz_local = xyz.data(); p.normal_local = nrm.data(); p.ring_id = m.ringIds.data();
         p.min_grid_size = m.minGridSize;
         p.use_gravity = m.useGravityErrorTerms; p.use_odometry = m.useOdometryErrorTerms;
         std::copy(m.gravity.data(), m.gravity.data() + 3, p.gravity);
@@ -98,8 +98,8 @@ public:
         std::copy(m.odometryTranslCovInv.data(), m.odometryTranslCovInv.data() + 9, p.odom_transl_cov_inv);
         std::copy(m.odometryOrientCovInv.data(), m.odometryOrientCovInv.data() + 9, p.odom_orient_cov_inv);
         dmsa_settings s = convert(settings); dmsa_report rep{};
-        if (dmsa_optimize_keyframes(ctx_, &p, &s, &rep) != DMSA_OK) throw std::runtime_error(dmsa_last_error(ctx_));
+        if (dmsa_optimize_keyframes_aos(ctx_, &p, frames.data(), F, &s, &rep) != DMSA_OK) throw std::runtime_error(dmsa_last_error(ctx_));
         m.keyframePoses.relative2global();
-        m.updateGlobalPoints();   // or dmsa_get_global_points as above
+        m.updateGlobalPoints();   // or dmsa_get_global_points_aos(ctx_, m.globalPoints.points.data(), n, sizeof(pcl::PointNormal), 0, offsetof(pcl::PointNormal, data_n))
     }
 };

@@ -23,7 +23,7 @@ def lib():
 
 
 def test_exports_every_declared_symbol(lib):
-    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("dmsa_hip.h", "dmsa_debug.h", "dmsa_window_ring.h", "dmsa_static_points.h", "dmsa_window_setup.h", "dmsa_wire_formats.h", "dmsa_raw_sequence.h", "dmsa_keyframe_cloud.h", "dmsa_keyframe_map.h"))
+    header = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("dmsa_hip.h", "dmsa_debug.h", "dmsa_window_ring.h", "dmsa_static_points.h", "dmsa_window_setup.h", "dmsa_wire_formats.h", "dmsa_raw_sequence.h", "dmsa_keyframe_cloud.h", "dmsa_keyframe_map.h", "dmsa_aos.h"))
     declared = set(re.findall(r"\b(dmsa_[a-z_0-9]+)\s*\(", header))
     assert declared, "no declarations parsed"
     assert declared == set(capi.EXPORTED_SYMBOLS)
@@ -44,6 +44,8 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(capi.PreprocessConfig) == 80
     assert C.sizeof(capi.TrajState) == 120  # dmsa_window_setup.h
     assert C.sizeof(capi.PointCloud2) == 56  # dmsa_wire_formats.h
+    assert C.sizeof(capi.AosView) == 40  # dmsa_aos.h
+    assert C.sizeof(capi.DebugCounters) == 40  # dmsa_debug.h
 
 
 def test_default_settings_match_reference_defaults(lib):
