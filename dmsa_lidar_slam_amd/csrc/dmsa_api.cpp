@@ -291,6 +291,12 @@ int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out) {
     }
     out->sync_retries = ctx->sync_retries, out->speculation_retries = ctx->speculation_retries;
     out->skip_pairs = (int64_t)st[0], out->skip_pairs_equal = (int64_t)st[1], out->skip_mismatches = (int64_t)st[2];
+    unsigned long long changed = 0;
+    if (ctx->d_coh_count.p) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(&changed, ctx->d_coh_count.p, 8, hipMemcpyDeviceToHost));
+    }
+    out->voxel_codes_compared = ctx->coh_compared, out->voxel_codes_changed = (int64_t)changed, out->voxel_lattice_changes = ctx->coh_lattice_changes;
     return DMSA_OK;
 }
 

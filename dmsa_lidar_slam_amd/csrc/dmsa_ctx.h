@@ -239,6 +239,11 @@ struct dmsa_ctx {
     DevBuf d_row_range;          // per evaluation of the Jacobian batch: (first, last) pose-table row that can differ from evaluation 0's (loop chain + pose-table kernels)
     DevBuf d_skip_stats;         // per evaluation of the Jacobian batch: pairs (Gaussian, evaluation) not computed, pairs that differed under eval_skip = 2
     int skip_stats_evals = 0;
+    DevBuf d_code_prev[2], d_coh_count;  // debug switch voxel_coherence: last voxelisation's leaf codes per level, and a counter of changed codes
+    LatticeTable coh_lattice[2]{};
+    bool coh_valid[2] = {false, false}, coh_key32[2] = {false, false}, coh_pending[2] = {false, false}, coh_count_zeroed = false;
+    int64_t coh_n[2] = {0, 0};
+    int64_t coh_compared = 0, coh_lattice_changes = 0;
     int64_t skip_pairs = 0;      // pairs the eval_skip logic looked at since the context was created
     bool fit_guess_valid = false;  // serial_counts of the previous voxelisation may size this one's speculative fit launches
     SerialCounts serial_counts{0, 0, 0, 0};

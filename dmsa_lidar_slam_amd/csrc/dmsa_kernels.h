@@ -128,6 +128,8 @@ int leaf_finalize_tiles(int64_t n);
 size_t leaf_finalize_state_bytes(int64_t n);
 void launch_leaf_finalize(const int32_t* slot_acc, const int32_t* slot_cnt, int64_t n /* leaf capacity */, int32_t* gauss_of_slot, int32_t* memb_of_slot,
                           int32_t* pslot_of_slot, LevelCounts* counts, unsigned long long* state, uint32_t epoch, uint32_t ticket_base, hipStream_t s);
+// debug switch voxel_coherence: count the points whose leaf code differs from `prev` (if compare), then prev <- now
+void launch_count_code_changes(const void* now, void* prev, bool key32, int64_t n, bool compare, unsigned long long* count, hipStream_t s);
 void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start, const uint32_t* idx_sorted, const void* code_sorted, bool key32,
                            const LatticeTable* table, const int32_t* slot_acc, const int32_t* gauss_of_slot, const int32_t* memb_of_slot,
                            const int32_t* pos_slot_rank /* or null */, const float4* local, const int32_t* slot_cnt, const GaussCounts* counts, int level,

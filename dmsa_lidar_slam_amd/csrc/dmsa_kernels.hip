@@ -756,6 +756,28 @@ void launch_voxel_keys(const float4* global, int64_t n, LatticeTable* table, dou
 // ------------------------------------------------------------------------------------------------------------
 // segmentation of the sorted arrays into leaves, acceptance, member gather
 // ------------------------------------------------------------------------------------------------------------
+// debug switch voxel_coherence: how many points changed their leaf code since the previous voxelisation (and keep this one's codes)
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_count_code_changes(const KeyT* __restrict__ now, KeyT* __restrict__ prev, int64_t n, int compare, unsigned long long* __restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool diff = false;
+    if (i < n) {
+        const KeyT c = now[i];
+        diff = compare && prev[i] != c;
+        prev[i] = c;
+    }
+    const unsigned long long m = __ballot(diff);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+void launch_count_code_changes(const void* now, void* prev, bool key32, int64_t n, bool compare, unsigned long long* count, hipStream_t s) {
+    if (n <= 0) return;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (key32)
+        hipLaunchKernelGGL(k_count_code_changes<uint32_t>, grid, dim3(256), 0, s, (const uint32_t*)now, (uint32_t*)prev, n, compare ? 1 : 0, count);
+    else
+        hipLaunchKernelGGL(k_count_code_changes<uint64_t>, grid, dim3(256), 0, s, (const uint64_t*)now, (uint64_t*)prev, n, compare ? 1 : 0, count);
+}
+
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_head_flags(const KeyT* __restrict__ code, int64_t n, const LatticeTable* __restrict__ table,
                                                     int32_t* __restrict__ head) {

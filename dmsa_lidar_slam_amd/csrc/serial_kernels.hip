@@ -351,10 +351,10 @@ __device__ __forceinline__ void small_wave(const float4* __restrict__ memb, cons
                                            const float4* __restrict__ tabT, int B, const uint32_t* __restrict__ order, int n_items_g, int nsub,
                                            double* __restrict__ E, int64_t ldE, int wave_index, const int2* __restrict__ row_range,
                                            const int2* __restrict__ gauss_rows, int* list /* 64 ints of this wave */) {
-    constexpr int G = 64 / L;  // Gaussians per wave
+    constexpr int G = 64 / L;  // Gaussians per wave (L = 9: seven, lane 63 idles)
     const int lane = threadIdx.x & 63, grp = lane / L, bl = lane % L;
     const int item = wave_index * G + grp;
-    const int gi = item / nsub, sub = item - gi * nsub;
+    const int gi = grp < G ? item / nsub : n_items_g, sub = item - (item / nsub) * nsub;
     const int g = gi < n_items_g ? (int)order[gi] : 0;
     int b = sub * L + bl;
     bool on = gi < n_items_g && b < B;
@@ -663,7 +663,11 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
             const float4* q4 = reinterpret_cast<const float4*>(s_q) + (cc < 3 ? cc * kBL + cb : 0);
             constexpr int gstride = 3 * kBL;       // float4 entries per group of four members
             constexpr int slot4 = kSlotFloats / 4;
-            constexpr int D = 8, S = kChunk / 4;   // prefetch depth and steps per chunk (one step = one float4 = four members)
+#ifndef DMSA_CHAIN_DEPTH_SHORT
+#define DMSA_CHAIN_DEPTH_SHORT 8
+#endif
+            // prefetch depth and steps per chunk (one step = one float4 = four members)
+            constexpr int S = kChunk / 4, D = kChunk >= 64 ? 8 : DMSA_CHAIN_DEPTH_SHORT;
             float4 r[D];
             lds_barrier();  // the member ring holds chunk 0
             lds_barrier();  // phase 0: the producers fill chunk 0
@@ -707,7 +711,12 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         {
             const double2* t2 = reinterpret_cast<const double2*>(s_t) + cb;
             constexpr int slot2 = kSlotDoubles / 2;
-            constexpr int D = 8, S = kChunk / 2;  // one step = one double2 = two members
+            // (depth 6 for the 32-member chunks of the throughput tier: with 8 the sixteen double2 registers of this ring pushed 23 VGPRs of the
+            // 64-register budget into scratch -- in this loop only, which runs when the exactness test of the parallel second pass fails)
+#ifndef DMSA_CHAIN2_DEPTH_SHORT
+#define DMSA_CHAIN2_DEPTH_SHORT 6
+#endif
+            constexpr int S = kChunk / 2, D = kChunk >= 64 ? 8 : DMSA_CHAIN2_DEPTH_SHORT;  // one step = one double2 = two members
             double2 r[D];
             lds_barrier();  // phase 0
             for (int p = 1; p < nphases; ++p) {
@@ -906,7 +915,11 @@ SerialShape serial_shape(int B) {
     SerialShape s;
     s.nsub_long = (B + bs_long - 1) / bs_long, s.Bs_long = (B + s.nsub_long - 1) / s.nsub_long;
     s.nsub = (B + bs_mid - 1) / bs_mid, s.Bs = (B + s.nsub - 1) / s.nsub;
-    s.lanes = B <= 16 ? 16 : (B <= 32 ? 32 : 64);
+#ifndef DMSA_SMALL_LANES_9
+#define DMSA_SMALL_LANES_9 1
+#endif
+    // the nine trials of the line search: seven Gaussians per wave with nine lanes each (63 of 64 lanes busy) instead of four with nine of sixteen
+    s.lanes = (DMSA_SMALL_LANES_9 && B == 9) ? 9 : (B <= 16 ? 16 : (B <= 32 ? 32 : 64));
     s.nsub_small = (B + s.lanes - 1) / s.lanes;
     return s;
 }
@@ -939,7 +952,9 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
         const int per_block = 4 * (64 / sh.lanes);
         const dim3 grid((items + per_block - 1) / per_block);
         const uint32_t* ord = order + sc.n_chain;
-        if (sh.lanes == 16)
+        if (sh.lanes == 9)
+            hipLaunchKernelGGL(k_residuals_small<9>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE, row_range, gauss_rows);
+        else if (sh.lanes == 16)
             hipLaunchKernelGGL(k_residuals_small<16>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE, row_range, gauss_rows);
         else if (sh.lanes == 32)
             hipLaunchKernelGGL(k_residuals_small<32>, grid, dim3(256), 0, s_small, memb_local, seg_off, info, tabT, B, ord, sc.n_small, sh.nsub_small, E, ldE, row_range, gauss_rows);

@@ -98,6 +98,16 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         if (merged && l == 1) pl.state_words = 0;  // the look-back words of the common sort are cleared once
         launch_voxel_keys(ctx->d_global.as<float4>(), n, ctx->d_lattice.as<LatticeTable>() + l, ctx->level_res[l], ctx->code_v[l], k32, ctx->idx_v[l],
                           l == 0 ? 0ull : (1ull << tag_bit), prepared ? &pl : nullptr, stream);
+        if (ctx->dbg.voxel_coherence != 0 && lvl_on[l]) {  // how many points changed leaf since the previous voxelisation of this context
+            const size_t ksz = k32 ? 4 : 8;
+            const bool compare = ctx->coh_valid[l] && ctx->d_code_prev[l].cap >= (size_t)n * ksz && ctx->coh_key32[l] == k32 && ctx->coh_n[l] == n;
+            if (ctx->d_code_prev[l].ensure((size_t)n * ksz) != hipSuccess || ctx->d_coh_count.ensure(8) != hipSuccess) return;
+            if (!ctx->coh_count_zeroed) (void)hipMemsetAsync(ctx->d_coh_count.p, 0, 8, stream), ctx->coh_count_zeroed = true;
+            launch_count_code_changes(ctx->code_v[l], ctx->d_code_prev[l].p, k32, n, compare, ctx->d_coh_count.as<unsigned long long>(), stream);
+            if (compare) ctx->coh_compared += n;
+            ctx->coh_pending[l] = compare;
+            ctx->coh_valid[l] = true, ctx->coh_key32[l] = k32, ctx->coh_n[l] = n;
+        }
     };
     auto stage_sort_both = [&]() -> int {
         stage_keys(0, ctx->stream), stage_keys(1, ctx->stream);
@@ -334,6 +344,13 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         }
         ctx->depth_guess[l] = ctx->h_lattice[l].final_depth;
         ctx->bits_guess[l] = ctx->h_lattice[l].total_bits;
+        if (ctx->dbg.voxel_coherence != 0 && lvl_on[l]) {  // a different lattice re-labels every leaf: such a voxelisation could not reuse the previous order
+            const LatticeTable &a = ctx->h_lattice[l], &b = ctx->coh_lattice[l];
+            const bool same = a.final_depth == b.final_depth && a.compressed == b.compressed && std::memcmp(a.final_mn, b.final_mn, sizeof(a.final_mn)) == 0 &&
+                              std::memcmp(a.nbits, b.nbits, sizeof(a.nbits)) == 0 && std::memcmp(a.key_base, b.key_base, sizeof(a.key_base)) == 0;
+            if (ctx->coh_pending[l] && !same) ctx->coh_lattice_changes += 1;
+            ctx->coh_lattice[l] = a, ctx->coh_pending[l] = false;
+        }
     }
     ctx->num_tiles = htc.num_tiles, ctx->num_fallback = htc.num_fallback, ctx->tile_max_rows = htc.max_rows, ctx->tile_max_gauss = htc.max_gauss;
     ctx->tiles_usable = !tiles_on || tiled_kernels_fit(htc.max_rows, htc.max_gauss);

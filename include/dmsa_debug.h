@@ -49,6 +49,8 @@ typedef struct dmsa_debug_options {
                                      gives up, the library restores the state of the call's start and runs it again with events            */
     int32_t speculation_fault; /* 0 test hook: k > 0 plants a tree depth one too small in the k-th voxelisation of every whole call, so the
                                      speculative sort width is wrong and the voxelisation runs again                                       */
+    int32_t voxel_coherence; /* 0   1: count, per voxelisation and level, the points whose leaf code differs from the previous voxelisation's of
+                                     the same context (dmsa_debug_counters: how much of last iteration's sorted order would survive)       */
 } dmsa_debug_options;
 
 /* what the switches above leave behind, since the context was created */
@@ -58,6 +60,10 @@ typedef struct dmsa_debug_counters {
     int64_t skip_pairs;           /* (Gaussian, evaluation) pairs of the Jacobian batches the eval_skip logic looked at       */
     int64_t skip_pairs_equal;     /* ... of which had the pose-table rows of evaluation 0 (eval_skip = 1: were not computed) */
     int64_t skip_mismatches;      /* eval_skip = 2 only: such pairs whose computed residual differed from evaluation 0's      */
+    int64_t voxel_codes_compared; /* voxel_coherence = 1: (point, level) pairs compared with the previous voxelisation            */
+    int64_t voxel_codes_changed;  /* ... whose leaf code changed                                                               */
+    int64_t voxel_lattice_changes;/* ... voxelisations (per level) whose lattice (origin, depth, code bits) differed from the previous one's:
+                                     every code of that level counts as changed                                                 */
 } dmsa_debug_counters;
 int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out);
 

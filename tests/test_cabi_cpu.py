@@ -33,7 +33,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_struct_sizes_match_header_layout():
     # natural-alignment layouts of the PODs in include/dmsa_hip.h (x86-64 SysV)
-    assert C.sizeof(capi.DebugOptions) == 20 * 4  # include/dmsa_debug.h: twenty int32 switches
+    assert C.sizeof(capi.DebugOptions) == 21 * 4  # include/dmsa_debug.h: twenty-one int32 switches
     assert C.sizeof(capi.Settings) == 72
     assert C.sizeof(capi.Report) == 48
     assert C.sizeof(capi.VoxelLevelInfo) == 56
@@ -45,7 +45,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(capi.TrajState) == 120  # dmsa_window_setup.h
     assert C.sizeof(capi.PointCloud2) == 56  # dmsa_wire_formats.h
     assert C.sizeof(capi.AosView) == 40  # dmsa_aos.h
-    assert C.sizeof(capi.DebugCounters) == 40  # dmsa_debug.h
+    assert C.sizeof(capi.DebugCounters) == 64  # dmsa_debug.h
 
 
 def test_default_settings_match_reference_defaults(lib):
