@@ -1,7 +1,8 @@
 // aos_upload.cpp — include/dmsa_aos.h: the reference's point containers (pcl::PointCloud<PointStampId>, 32-byte points,
 // PointStampId.h:33-45; pcl::PointCloud<pcl::PointNormal>, 48-byte points, KeyframeData.h:20) handed over as they lie in memory.
-// Host side: plain memcpy of every cloud into pinned staging (a few threads, no per-point work), one DMA per cloud that overlaps the
-// memcpy of the next one, and a pack kernel per cloud (static_kernels.hip) that writes the layouts of dmsa_ctx.h.
+// Host side: the worker threads move what the device needs into pinned staging -- of a window point the 16 bytes x, y, z, id plus its
+// tform index, so that a scan crosses PCIe as 20 bytes per point like the flat arrays (measured: the whole 32-byte points cost 0.7 ms more
+// per call than the gather saves) -- and the pack kernels (static_kernels.hip) write the layouts of dmsa_ctx.h.
 #include "dmsa_ctx.h"
 
 #include "../../include/dmsa_window_ring.h"
@@ -26,23 +27,6 @@ void copy_parallel(dmsa_ctx* ctx, char* dst, const char* src, size_t total) {
     });
 }
 
-// the 16 bytes of a window point the device needs -- x, y, z and the ring id -- gathered by the worker threads into pinned staging: the scan
-// crosses PCIe as 16 + 4 (tform index) bytes per point instead of the 32 + 4 of the whole PointStampId
-void gather_xyz_id(dmsa_ctx* ctx, char* dst, const dmsa_aos_view& v) {
-    const char* src = static_cast<const char*>(v.base);
-    auto run = [&](int64_t a, int64_t b) {
-        for (int64_t i = a; i < b; ++i) {
-            const char* pt = src + (size_t)i * v.stride;
-            std::memcpy(dst + (size_t)i * 16, pt + v.xyz_offset, 12);
-            std::memcpy(dst + (size_t)i * 16 + 12, pt + v.aux_offset, 4);
-        }
-    };
-    if (v.count < 131072)
-        run(0, v.count);
-    else
-        workers(ctx).run_all([&](int t, int nt) { run(v.count * t / nt, v.count * (t + 1) / nt); });
-}
-
 }  // namespace
 
 extern "C" {
@@ -65,7 +49,8 @@ int dmsa_window_upload_aos(dmsa_ctx* ctx, const dmsa_window_problem* p, const dm
     }
     if (S > 0) raw_bytes += (size_t)S * 16;
     CHK(window_upload_begin(ctx, p, N, S));
-    // staging: [x y z id of every cloud | of the static points | tform indices]
+    // staging: [x y z id of every window point | of the static points | tform indices]: ONE pass of the worker threads over all clouds, two
+    // DMAs, one pack kernel for the window points and one for the static points
     const size_t idx_off = (raw_bytes + 15) & ~(size_t)15;
     CHK(ensure_stage(ctx, idx_off + (size_t)N * 4 + 64));
     HIPCHK(ctx->d_aos_raw.ensure(idx_off + 64));
@@ -73,26 +58,37 @@ int dmsa_window_upload_aos(dmsa_ctx* ctx, const dmsa_window_problem* p, const dm
     int32_t* d_bad = ctx->d_aos_idx.as<int32_t>() + N;  // one flag word behind the indices
     HIPCHK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
     char* st = ctx->h_stage;
-    size_t at = 0;
-    int64_t first = 0;
-    for (int c = 0; c <= num_clouds; ++c) {
-        const bool is_static = c == num_clouds;
-        if (is_static && S == 0) break;
-        const dmsa_aos_view& v = is_static ? *static_points : clouds[c];
-        if (v.count == 0) continue;
-        const size_t bytes = (size_t)v.count * 16;
-        gather_xyz_id(ctx, st + at, v);
-        HIPCHK(hipMemcpyAsync(ctx->d_aos_raw.as<char>() + at, st + at, bytes, hipMemcpyHostToDevice, ctx->stream));  // overlaps the next cloud's gather
-        const int32_t* d_index = nullptr;
-        if (!is_static) {
-            std::memcpy(st + idx_off + (size_t)first * 4, v.index, (size_t)v.count * 4);
-            HIPCHK(hipMemcpyAsync(ctx->d_aos_idx.as<int32_t>() + first, st + idx_off + (size_t)first * 4, (size_t)v.count * 4, hipMemcpyHostToDevice, ctx->stream));
-            d_index = ctx->d_aos_idx.as<int32_t>() + first;
+    std::vector<int64_t> first((size_t)num_clouds + 2, 0);  // prefix of the point counts: clouds, then the static points
+    for (int c = 0; c < num_clouds; ++c) first[(size_t)c + 1] = first[(size_t)c] + clouds[c].count;
+    first[(size_t)num_clouds + 1] = N + S;
+    auto gather = [&](int64_t a, int64_t b) {  // points [a, b) of the concatenation
+        int c = (int)(std::upper_bound(first.begin(), first.end(), a) - first.begin()) - 1;
+        for (int64_t i = a; i < b;) {
+            while (c <= num_clouds && first[(size_t)c + 1] <= i) ++c;
+            const dmsa_aos_view& v = c == num_clouds ? *static_points : clouds[c];
+            const int64_t end = std::min(b, first[(size_t)c + 1]);
+            const char* src = static_cast<const char*>(v.base);
+            for (; i < end; ++i) {
+                const int64_t k = i - first[(size_t)c];
+                const char* pt = src + (size_t)k * v.stride;
+                std::memcpy(st + (size_t)i * 16, pt + v.xyz_offset, 12);
+                std::memcpy(st + (size_t)i * 16 + 12, pt + v.aux_offset, 4);
+                if (c < num_clouds) std::memcpy(st + idx_off + (size_t)i * 4, v.index + k, 4);
+            }
         }
-        launch_pack_aos_window(ctx->d_aos_raw.as<uint8_t>() + at, v.count, 16, 0, 12, d_index, p->n_total, p->n_total, ctx->d_local.as<float4>() + first,
-                               ctx->d_ring.as<int32_t>() + first, d_bad, ctx->stream);
-        at += bytes, first += v.count;
-    }
+    };
+    const int64_t total = N + S;
+    if (total < 131072)
+        gather(0, total);
+    else
+        workers(ctx).run_all([&](int t, int nt) { gather(total * t / nt, total * (t + 1) / nt); });
+    HIPCHK(hipMemcpyAsync(ctx->d_aos_raw.p, st, (size_t)total * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_aos_idx.p, st + idx_off, (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_pack_aos_window(ctx->d_aos_raw.as<uint8_t>(), N, 16, 0, 12, ctx->d_aos_idx.as<int32_t>(), p->n_total, p->n_total, ctx->d_local.as<float4>(),
+                           ctx->d_ring.as<int32_t>(), d_bad, ctx->stream);
+    launch_pack_aos_window(ctx->d_aos_raw.as<uint8_t>() + (size_t)N * 16, S, 16, 0, 12, nullptr, p->n_total, p->n_total, ctx->d_local.as<float4>() + N,
+                           ctx->d_ring.as<int32_t>() + N, d_bad, ctx->stream);
+    HIPCHK(hipGetLastError());
     int32_t bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging area is reused by the next upload

@@ -668,6 +668,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
 #endif
             // prefetch depth and steps per chunk (one step = one float4 = four members)
             constexpr int S = kChunk / 4, D = kChunk >= 64 ? 8 : DMSA_CHAIN_DEPTH_SHORT;
+            static_assert(S % D == 0, "the register ring r[k % D] runs on across chunk boundaries: D must divide the steps of a chunk");
             float4 r[D];
             lds_barrier();  // the member ring holds chunk 0
             lds_barrier();  // phase 0: the producers fill chunk 0
@@ -711,12 +712,13 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         {
             const double2* t2 = reinterpret_cast<const double2*>(s_t) + cb;
             constexpr int slot2 = kSlotDoubles / 2;
-            // (depth 6 for the 32-member chunks of the throughput tier: with 8 the sixteen double2 registers of this ring pushed 23 VGPRs of the
+            // (depth 4 for the 32-member chunks of the throughput tier: with 8 the sixteen double2 registers of this ring pushed 23 VGPRs of the
             // 64-register budget into scratch -- in this loop only, which runs when the exactness test of the parallel second pass fails)
 #ifndef DMSA_CHAIN2_DEPTH_SHORT
-#define DMSA_CHAIN2_DEPTH_SHORT 6
+#define DMSA_CHAIN2_DEPTH_SHORT 4
 #endif
             constexpr int S = kChunk / 2, D = kChunk >= 64 ? 8 : DMSA_CHAIN2_DEPTH_SHORT;  // one step = one double2 = two members
+            static_assert(S % D == 0, "the register ring r[k % D] runs on across chunk boundaries: D must divide the steps of a chunk");
             double2 r[D];
             lds_barrier();  // phase 0
             for (int p = 1; p < nphases; ++p) {
@@ -916,9 +918,10 @@ SerialShape serial_shape(int B) {
     s.nsub_long = (B + bs_long - 1) / bs_long, s.Bs_long = (B + s.nsub_long - 1) / s.nsub_long;
     s.nsub = (B + bs_mid - 1) / bs_mid, s.Bs = (B + s.nsub - 1) / s.nsub;
 #ifndef DMSA_SMALL_LANES_9
-#define DMSA_SMALL_LANES_9 1
+#define DMSA_SMALL_LANES_9 0
 #endif
-    // the nine trials of the line search: seven Gaussians per wave with nine lanes each (63 of 64 lanes busy) instead of four with nine of sixteen
+    // (experiment, off: the nine trials of the line search as seven Gaussians per wave with nine lanes each -- 63 of 64 lanes busy instead of
+    // four groups with nine of sixteen -- measured 1 % SLOWER per iteration: the waves carry seven member lists instead of four and end later)
     s.lanes = (DMSA_SMALL_LANES_9 && B == 9) ? 9 : (B <= 16 ? 16 : (B <= 32 ? 32 : 64));
     s.nsub_small = (B + s.lanes - 1) / s.lanes;
     return s;
