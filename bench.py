@@ -41,7 +41,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json")  # newest first
+TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first
 
 
 def spawn_ranks(n, backend, visible):
@@ -374,12 +374,16 @@ def main():
                            "reference-order correspondence kernels (k_residuals_chain<8,true,128> + k_residuals_chain<4,false,32> + k_residuals_small, "
                            "three streams, fork / join by device counters, one HIP-event pair around the batch)") + ", B evaluations per launch",
                 "bound": "hbm",
-                # the brief's figure: per-unit algorithmic bytes x units per launch / launch time
+                # SURVEY 8(d) bytes(B) / t: what a launch of B evaluations MUST move when it reads the members once, over the launch time --
+                # the HBM roofline figure proper (the kernels are nowhere near it and cannot be: bound_stated)
+                "frac_hbm": round(compulsory_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_ms > 0 else None,
+                # the brief's figure: per-unit algorithmic bytes (bytes(1)) x units per launch / launch time -- an EFFECTIVE rate, a launch
+                # reads the members once per pass for all its evaluations
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                # BASELINE.md section 2 / SURVEY 8(d) bytes(B): what a launch of B evaluations MUST move when it reads the members once
+                "frac_effective": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_compulsory": round(compulsory_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_ms > 0 else None,
                 # HBM bytes the PMC passes counted (profiles/r02_traffic.json), same launch time
                 "frac_counters": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and avg_ms > 0) else None,

@@ -22,8 +22,10 @@ run p2 "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD 
 run p3 "FETCH_SIZE"
 run p4 "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
 # keyframe set (BASELINE config 4 at shard size): kernel stats + timeline
-timeout 120 rocprofv3 --kernel-trace --stats -d $OUT/kfstats -o stats -- python $R/bench.py --workload keyframes --frames 32 --steps 6 --warmup 2 --cpu-iters 0 > $OUT/kfstats.log 2>&1 < /dev/null
+timeout 120 rocprofv3 --kernel-trace --stats -d $OUT/kfstats -o stats -- python $R/bench.py --workload keyframes --map-frames 0 --frames 32 --steps 6 --warmup 2 --cpu-iters 0 > $OUT/kfstats.log 2>&1 < /dev/null
 python $R/scripts/iteration_timeline.py $(find $OUT/kfstats -name "*results.db" | head -1) 4 > $OUT/keyframes_iteration_timeline.txt 2>> $OUT/timeline.err
+# the keyframe workload's own bench line (strong-scaling layout: the 249-frame map in 8 neighbourhoods on this one GPU)
+timeout 300 python $R/bench.py --workload keyframes --steps 30 --warmup 2 --cpu-iters 0 > $OUT/bench_keyframes.json 2> $OUT/bench_keyframes.err < /dev/null
 # repeated bench lines
 for i in 1 2 3; do timeout 100 python $R/bench.py --steps 200 --warmup 5 --cpu-iters 0 --keyframe-steps 0 2>/dev/null < /dev/null | tail -1 >> $OUT/bench_runs.jsonl; done
 tail -c 400 $OUT/bench.json

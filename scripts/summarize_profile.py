@@ -18,15 +18,22 @@ def stats(db_path):
     cur = db.cursor()
     rows = cur.execute(
         "select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
-    tot = sum(r[2] for r in rows)
+    # k_sync_wait is a one-wave kernel that SPINS until another stream has caught up (csrc/dev_sync.h): its "duration" is idle time of a
+    # stream, not work.  It is listed, but the pct column is taken over the kernels that compute.
+    def waits(name):
+        return "k_sync_wait" in name
+
+    tot = sum(r[2] for r in rows if not waits(r[0]))
     print(f"# rocprofv3 --kernel-trace --stats summary of {os.path.basename(db_path)} (durations in us)")
-    print(f"# total kernel time {tot / 1e3:.1f} us over {sum(r[1] for r in rows)} dispatches")
+    print(f"# total kernel time {tot / 1e3:.1f} us over {sum(r[1] for r in rows if not waits(r[0]))} dispatches "
+          f"(+ {sum(r[2] for r in rows if waits(r[0])) / 1e3:.1f} us of stream waits in {sum(r[1] for r in rows if waits(r[0]))} k_sync_wait dispatches, not in pct)")
     print(f"{'kernel':72s} {'calls':>6s} {'total_us':>10s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
     for name, n, total, avg, mn, mx in rows:
         short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         if "rocprim" in short:
             short = "rocprim::" + short.split("::")[-1][:48] + "<...>"
-        print(f"{short[:72]:72s} {n:6d} {total / 1e3:10.1f} {avg / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * total / tot:6.2f}")
+        pct = "  wait" if waits(name) else f"{100 * total / tot:6.2f}"
+        print(f"{short[:72]:72s} {n:6d} {total / 1e3:10.1f} {avg / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {pct}")
     # the correspondence kernels by batch kind: an iteration launches every kernel family twice (P + 1 evaluations for the
     # Jacobian, 9 for the line search); the workgroup count follows the iteration's Gaussian count, so launches are bucketed
     # at the midpoint of each kernel's workgroup range (grid_x is in THREADS in rocprofv3's tables)
