@@ -402,157 +402,6 @@ __global__ __launch_bounds__(kSolveWaves* kWave) void k_loop_lm_step(const HpSou
     if (lane < P) step[lane] = s;
 }
 
-// The same step with the matrix in REGISTERS (round 4).  k_loop_lm_step above keeps [A | I] in LDS and moves every row through registers
-// and back in every pivot step (plus the two rows that swap): 1.4 us per step, 41 us at P = 30.  Here four waves (one per SIMD) hold the
-// matrix for good -- lane = column, wave w the rows w, w + 4, ... -- and rows never move: a row's position in the serial algorithm (its
-// LOGICAL index after the swaps so far) is tracked per physical row, as the panel kernel below does.  Per step the waves exchange two things
-// through LDS, each behind one barrier: the pivot COLUMN (for the search and as multipliers; one lane per wave writes its rows' entries)
-// and the pivot ROW (the owner writes, every lane divides the entry of its own column).  Search, division and the choice of the pivot are
-// computed redundantly by every wave from the same numbers.  Element operations and their order are those of lm_solve's serial branch
-// (host_math.cpp): pivot row x / d, other rows x - f s (skipped for f == 0), first strict maximum of |x| from the diagonal down, a NaN
-// never wins, a NaN on the diagonal keeps the diagonal.
-constexpr int kRegWaves = 4;
-template <int kColsPerLane, int kRows /* rows per wave: P <= kRows * kRegWaves */>
-__global__ __launch_bounds__(kRegWaves* kWave) void k_loop_lm_step_regs(const HpSource hp, int P, double lambda, double alpha, double max_step,
-                                                                        double* __restrict__ step, LoopFlags* __restrict__ flags, double* __restrict__ error0_out) {
-    extern __shared__ double sm[];
-    if (flags->stop != 0) return;
-    const int W = 2 * P, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, n1 = P + 1;
-    double* s_col = sm;                // [64] column c0 by physical row
-    double* s_prow = sm + 64;          // [128] the pivot row, all W columns
-    double* g = sm + 192;              // [P]
-    double* Minv = sm + 192 + 64;      // [P][P] the inverse by LOGICAL row, for the product with g at the end
-    double x[kRows][kColsPerLane];
-#pragma unroll
-    for (int j = 0; j < kRows; ++j) {
-        const int r = wave + j * kRegWaves;
-#pragma unroll
-        for (int q = 0; q < kColsPerLane; ++q) {
-            const int c = lane + q * kWave;
-            double v = 0.0;
-            if (r < P && c < P) {
-                v = hp_element(hp, n1, r, c);  // H(r, c), damped on the diagonal (:110)
-                if (r == c) v += lambda;
-            } else if (r < P && c < W) {
-                v = (c - P) == r ? 1.0 : 0.0;
-            }
-            x[j][q] = v;
-        }
-    }
-    for (int i = threadIdx.x; i <= P; i += kRegWaves * kWave) {  // g = J^T e0 (last column of Hp), e0^T e0 for the end of the iteration
-        const double v = hp_element(hp, n1, i, P);
-        if (i < P)
-            g[i] = v;
-        else if (error0_out)
-            *error0_out = v;
-    }
-    int logical = lane;                 // lane = physical row: its position in the serial algorithm (identical in every wave)
-    unsigned long long pivoted = 0ull;  // physical rows that have been pivot rows
-    for (int c0 = 0; c0 < P; ++c0) {
-        // ---- the pivot column: every wave contributes the entries of its rows (they sit in the lane of column c0) ----
-        if (lane == (c0 & (kWave - 1))) {
-#pragma unroll
-            for (int j = 0; j < kRows; ++j) {
-                const int r = wave + j * kRegWaves;
-                if (r < P) s_col[r] = kColsPerLane == 1 ? x[j][0] : (c0 < kWave ? x[j][0] : x[j][kColsPerLane - 1]);
-            }
-        }
-        __syncthreads();
-        const bool cand = lane < P && !((pivoted >> lane) & 1ull);
-        const double fcol = lane < P ? s_col[lane] : 0.0;
-        // first strict maximum of |x| over the positions c0 .. P-1 = the rows not yet pivoted, ties to the smallest position
-        double v = cand ? fabs(fcol) : -1.0;
-        if (isnan(v)) v = -1.0;
-        const double mx = wave_max_nonneg(v);
-        unsigned long long hit = __ballot(cand && v == mx);
-        const int diag_lane = __builtin_ctzll(__ballot(lane < P && logical == c0));  // the row at position c0
-        const double diag = readlane_f64(fcol, diag_lane);
-        int pp = diag_lane;
-        if (!isnan(diag) && hit != 0ull) {
-            pp = __builtin_ctzll(hit);
-            int best = __builtin_amdgcn_readlane(logical, pp);
-            hit &= hit - 1ull;
-            while (hit != 0ull) {  // equal |x| in two rows (rare): the smaller position wins
-                const int o = __builtin_ctzll(hit), ol = __builtin_amdgcn_readlane(logical, o);
-                if (ol < best) best = ol, pp = o;
-                hit &= hit - 1ull;
-            }
-        }
-        const double d = readlane_f64(fcol, pp);  // the pivot
-        {   // the swap of positions c0 and position(pp)
-            const int lp = __builtin_amdgcn_readlane(logical, pp);
-            if (lane == pp)
-                logical = c0;
-            else if (lane == diag_lane)
-                logical = lp;
-            pivoted |= 1ull << pp;
-        }
-        // ---- the pivot row: its owner publishes it, every lane scales the entry of its own column ----
-        if (wave == (pp & (kRegWaves - 1))) {
-            const int jp = pp / kRegWaves;
-#pragma unroll
-            for (int j = 0; j < kRows; ++j)
-                if (j == jp) {
-#pragma unroll
-                    for (int q = 0; q < kColsPerLane; ++q)
-                        if (lane + q * kWave < W) s_prow[lane + q * kWave] = x[j][q];
-                }
-        }
-        __syncthreads();
-        double srow[kColsPerLane];
-#pragma unroll
-        for (int q = 0; q < kColsPerLane; ++q) srow[q] = lane + q * kWave < W ? s_prow[lane + q * kWave] / d : 0.0;
-#pragma unroll
-        for (int j = 0; j < kRows; ++j) {
-            const int r = wave + j * kRegWaves;
-            if (r >= P) continue;
-            if (r == pp) {
-#pragma unroll
-                for (int q = 0; q < kColsPerLane; ++q) x[j][q] = srow[q];
-            } else {
-                const double f = readlane_f64(fcol, r);
-                if (f != 0.0) {
-#pragma unroll
-                    for (int q = 0; q < kColsPerLane; ++q) x[j][q] -= f * srow[q];
-                }
-            }
-        }
-        // (no barrier here: the next step writes s_col, which everybody has read before the barrier above, and s_prow only after its own first barrier)
-    }
-    // ---- the inverse by logical row, then :113 step = (-alpha H^-1) g row by row and the NaN test / clamp of :116-128 (as above) ----
-#pragma unroll
-    for (int j = 0; j < kRows; ++j) {
-        const int r = wave + j * kRegWaves;
-        if (r >= P) continue;
-        const int lr = __builtin_amdgcn_readlane(logical, r);
-#pragma unroll
-        for (int q = 0; q < kColsPerLane; ++q) {
-            const int c = lane + q * kWave;
-            if (c >= P && c < W) Minv[(size_t)lr * P + (c - P)] = x[j][q];
-        }
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    double s = 0.0;
-    if (lane < P)
-        for (int j = 0; j < P; ++j) s += (-alpha * Minv[(size_t)lane * P + j]) * g[j];
-    if (__ballot(lane < P && isnan(s)) != 0ull) {
-        if (lane == 0) flags->nan = 1;
-        return;
-    }
-    double mx = lane < P ? s : -INFINITY, mn = lane < P ? s : INFINITY;  // max / min do not depend on the order
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
-        mx = mx < a ? a : mx;
-        mn = c < mn ? c : mn;
-    }
-    const double neg = -mn;
-    const double max_elem = mx < neg ? neg : mx;  // std::max(mx, -mn)
-    if (max_elem > max_step) s = (max_step / max_elem) * s;
-    if (lane < P) step[lane] = s;
-}
-
 // ---- P > 64: the same Gauss-Jordan inverse, blocked over column blocks of the augmented matrix [A | I], one workgroup per block ------
 // Every element sees the operations of the serial algorithm in step order -- pivot row: x / d_k, other rows: x - f_rk * s_kc (skipped
 // for f_rk == 0) -- so the result is the serial one bit for bit (as host_math.cpp's blocked lm_solve argues).  What a step needs, the
@@ -991,16 +840,6 @@ static void launch_lm_step(const HpSource& hp, int P, double lambda, double alph
     if (bytes > 48 * 1024 && !raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_loop_lm_step<2, kSolveRows>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         raised = true;
-    }
-#ifndef DMSA_LM_REGS
-#define DMSA_LM_REGS 1
-#endif
-    if (DMSA_LM_REGS && P <= 32) {  // the default window (P = 30): the matrix in registers, one column per lane, eight rows per wave
-        // (-DDMSA_LM_REGS=0 keeps the LDS version for A/B timing; with two columns per lane and sixteen rows per wave the compiler runs out of
-        // scalar registers for the multipliers and spills them to memory, so 32 < P <= 64 stays on the LDS version)
-        const size_t rb = (192 + 64 + (size_t)P * P) * sizeof(double);
-        hipLaunchKernelGGL((k_loop_lm_step_regs<1, 8>), dim3(1), dim3(kRegWaves * kWave), rb, s, hp, P, lambda, alpha, max_step, step, flags, error0_out);
-        return;
     }
     if (P <= 4 * kSolveWaves)  // the default window (P = 30): one column per lane, four rows per wave
         hipLaunchKernelGGL((k_loop_lm_step<1, 4>), dim3(1), dim3(kSolveWaves * kWave), bytes, s, hp, P, lambda, alpha, max_step, step, flags, error0_out);
