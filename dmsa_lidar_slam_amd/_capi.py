@@ -158,7 +158,7 @@ class DebugOptions(C.Structure):
 
 class DebugCounters(C.Structure):
     """include/dmsa_debug.h: dmsa_debug_counters."""
-    _fields_ = [(n, C.c_int64) for n in ("sync_retries", "speculation_retries", "skip_pairs", "skip_pairs_equal", "skip_mismatches", "voxel_codes_compared", "voxel_codes_changed",
+    _fields_ = [(n, C.c_int64) for n in ("sync_retries", "speculation_retries", "skip_pairs", "skip_pairs_equal", "skip_mismatches", "split_blocks", "split_blocks_skipped", "voxel_codes_compared", "voxel_codes_changed",
                                            "voxel_lattice_changes")]
 
 

@@ -291,6 +291,13 @@ int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out) {
     }
     out->sync_retries = ctx->sync_retries, out->speculation_retries = ctx->speculation_retries;
     out->skip_pairs = (int64_t)st[0], out->skip_pairs_equal = (int64_t)st[1], out->skip_mismatches = (int64_t)st[2];
+    unsigned long long sp[2] = {0, 0};
+    if (ctx->d_split_stats.p) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream2));
+        HIPCHK(hipMemcpy(sp, ctx->d_split_stats.p, 16, hipMemcpyDeviceToHost));
+    }
+    out->split_blocks = (int64_t)sp[0], out->split_blocks_skipped = (int64_t)sp[1];
     unsigned long long changed = 0;
     if (ctx->d_coh_count.p) {
         HIPCHK(hipStreamSynchronize(ctx->stream));

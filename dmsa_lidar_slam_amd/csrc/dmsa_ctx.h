@@ -244,6 +244,7 @@ struct dmsa_ctx {
     bool coh_valid[2] = {false, false}, coh_key32[2] = {false, false}, coh_pending[2] = {false, false}, coh_count_zeroed = false;
     int64_t coh_n[2] = {0, 0};
     int64_t coh_compared = 0, coh_lattice_changes = 0;
+    DevBuf d_split_stats;        // splitSet search: 64 x 64 pair blocks looked at / skipped by the cone bound (k_split_pairs)
     int64_t skip_pairs = 0;      // pairs the eval_skip logic looked at since the context was created
     bool fit_guess_valid = false;  // serial_counts of the previous voxelisation may size this one's speculative fit launches
     SerialCounts serial_counts{0, 0, 0, 0};

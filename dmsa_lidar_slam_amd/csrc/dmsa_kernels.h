@@ -119,7 +119,8 @@ void launch_leaf_accept(const int32_t* leaf_start, const uint32_t* idx_sorted, c
 size_t split_scratch_bytes(int64_t n);  // pair_best[n] + task list + counter
 void launch_leaf_split(const int32_t* leaf_incl, const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const float4* nglobal,
                        const LevelCounts* counts, int min_pts, int64_t n, float4* nsorted /* n */, unsigned long long* pair_best /* split_scratch_bytes(n) */,
-                       int32_t* slot_acc, int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s);
+                       int32_t* slot_acc, int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s,
+                       unsigned long long* block_stats = nullptr /* [2] += 64 x 64 pair blocks looked at / skipped by the cone bound (debug counters) */);
 void launch_leaf_scan(const int32_t* slot_acc, const int32_t* slot_cnt, int32_t* gauss_of_slot, int32_t* memb_of_slot,
                       int32_t* pslot_of_slot /* prefix of the member counts rounded up to 8: tile slots */, LevelCounts* counts, hipStream_t s);
 // launch_leaf_scan as a multi-workgroup single-pass kernel.  `state`: leaf_finalize_state_bytes(n) bytes zeroed once when allocated;

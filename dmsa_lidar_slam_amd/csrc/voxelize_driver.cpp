@@ -60,6 +60,11 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     GaussCounts* counts = ctx->d_counts.as<GaussCounts>();
     const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS);
     const bool split = s.gauss_split != 0 && ctx->model == MODEL_KEYFRAMES;
+    if (split && !ctx->d_split_stats.p) {
+        HIPCHK(ctx->d_split_stats.ensure(16));
+        HIPCHK(hipMemsetAsync(ctx->d_split_stats.p, 0, 16, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // (both level streams add to it)
+    }
     if (split)
         for (int l = 0; l < 2; ++l) {
             HIPCHK(ctx->d_pos_slot_rank[l].ensure((size_t)n * 4));
@@ -180,7 +185,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             launch_leaf_split(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->idx_s_v[l], ctx->d_ring.as<int32_t>(),
                               ctx->d_nglobal.as<float4>(), &counts->level[l], s.min_num_points_per_set, n, ctx->d_nsorted[l].as<float4>(),
                               ctx->d_pair_d[l].as<unsigned long long>(), ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(),
-                              ctx->d_pos_slot_rank[l].as<int32_t>(), st[l]);
+                              ctx->d_pos_slot_rank[l].as<int32_t>(), st[l], ctx->d_split_stats.as<unsigned long long>());
         if (ctx->dbg.fused_leaf_scan != 0)
             CHK(finalize());
         else

@@ -60,6 +60,8 @@ typedef struct dmsa_debug_counters {
     int64_t skip_pairs;           /* (Gaussian, evaluation) pairs of the Jacobian batches the eval_skip logic looked at       */
     int64_t skip_pairs_equal;     /* ... of which had the pose-table rows of evaluation 0 (eval_skip = 1: were not computed) */
     int64_t skip_mismatches;      /* eval_skip = 2 only: such pairs whose computed residual differed from evaluation 0's      */
+    int64_t split_blocks;         /* splitSet search (gauss_split): blocks of 64 positions x 64 partners looked at ...       */
+    int64_t split_blocks_skipped; /* ... and skipped because their normals cannot be within 0.5 of anti-parallel       */
     int64_t voxel_codes_compared; /* voxel_coherence = 1: (point, level) pairs compared with the previous voxelisation            */
     int64_t voxel_codes_changed;  /* ... whose leaf code changed                                                               */
     int64_t voxel_lattice_changes;/* ... voxelisations (per level) whose lattice (origin, depth, code bits) differed from the previous one's:

@@ -97,6 +97,19 @@ def test_keyframes_ragged_frames(hip, orc):
     _parity_run(hip, orc, prob, DmsaOptimSettings.keyframe_map(num_iter=2), window=False)
 
 
+def test_split_search_skips_pair_blocks_that_cannot_be_antiparallel(hip):
+    """splitSet's O(n^2) search (Gaussians.h:36-51) only matters for pairs with |n_a + n_c| <= 0.5 (:54).  k_split_pairs bounds every block of
+    64 positions x 64 partners by the cone of the partners' normals and skips the blocks that cannot reach 0.5; the results are the ones the
+    exhaustive oracle gives (every keyframe parity test runs through it) -- here: that the skipping really happens at the bench shape."""
+    full = synth.keyframe_problem(seed=1, frames=32, arc=2 * np.pi * 32 / 256.0)
+    opt = hip.DmsaOptimizer()
+    opt.optimizeSet(full.getSubmap(0, 31), DmsaOptimSettings.keyframe_map(num_iter=1))
+    c = opt.debugCounters()
+    opt.close()
+    print(f"[splitSet] {c['split_blocks_skipped']} of {c['split_blocks']} 64 x 64 pair blocks skipped ({100.0 * c['split_blocks_skipped'] / c['split_blocks']:.1f} %)")
+    assert c["split_blocks"] > 10_000 and c["split_blocks_skipped"] > 0.3 * c["split_blocks"]
+
+
 def test_config4_at_the_shard_size_bench_times(hip, orc):
     """One neighbourhood exactly as `bench.py --workload keyframes` / the keyframe_pass key shards it: 32 keyframes x ~10^4 points
     (P = 186 parameters, 197 evaluations per iteration), gauss_split, gravity rows -- the default path against the oracle for two
