@@ -293,9 +293,11 @@ int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out) {
     out->skip_pairs = (int64_t)st[0], out->skip_pairs_equal = (int64_t)st[1], out->skip_mismatches = (int64_t)st[2];
     unsigned long long sp[2] = {0, 0};
     if (ctx->d_split_stats.p) {
+        unsigned long long stripes[128];
         HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream2));
-        HIPCHK(hipMemcpy(sp, ctx->d_split_stats.p, 16, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(stripes, ctx->d_split_stats.p, sizeof(stripes), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 64; ++k) sp[0] += stripes[2 * k], sp[1] += stripes[2 * k + 1];
     }
     out->split_blocks = (int64_t)sp[0], out->split_blocks_skipped = (int64_t)sp[1];
     unsigned long long changed = 0;

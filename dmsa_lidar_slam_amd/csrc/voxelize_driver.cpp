@@ -61,8 +61,8 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS);
     const bool split = s.gauss_split != 0 && ctx->model == MODEL_KEYFRAMES;
     if (split && !ctx->d_split_stats.p) {
-        HIPCHK(ctx->d_split_stats.ensure(16));
-        HIPCHK(hipMemsetAsync(ctx->d_split_stats.p, 0, 16, ctx->stream));
+        HIPCHK(ctx->d_split_stats.ensure(64 * 16));  // 64 stripes of (blocks looked at, blocks skipped)
+        HIPCHK(hipMemsetAsync(ctx->d_split_stats.p, 0, 64 * 16, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));  // (both level streams add to it)
     }
     if (split)
