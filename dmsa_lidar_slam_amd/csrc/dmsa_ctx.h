@@ -263,6 +263,7 @@ struct dmsa_ctx {
     DevBuf d_loop_iter;    // LoopFlags | IterResult[num_iter]
     DevBuf d_panel_work;   // scratch of the blocked device solve for P > 64 (published panels, inverse, hand-over flags)
     uint32_t panel_epoch = 0;
+    int panel_P = -1;       // parameter count the scratch is laid out for
     DevBuf d_rot_same;     // per evaluation of the Jacobian batch: 1 = its control rotations are evaluation 0's bit for bit (pose-table kernels)
     DevBuf d_sync;         // counters of the device-side stream dependencies (dev_sync.h: SyncSlot), zeroed when the context is created
     uint32_t sync_sig[SYNC_SLOTS] = {};  // signals enqueued so far per slot = the value a wait enqueued now has to see

@@ -64,8 +64,14 @@ void launch_loop_lm_step_partials(const double* partial, int nsplit, int nt, int
 // owner).  `work`: loop_panel_solve_doubles(P) doubles of device scratch, zeroed once when allocated; `epoch` > 0 differs from call to
 // call on the same scratch (published panels and counters carry it, nothing is cleared between calls).
 constexpr int kLoopPanelMaxP = 1024;
+constexpr int kLoopStreamMaxP = 192;   // k_loop_lm_stream: up to three rows per lane (four would spill)
 size_t loop_panel_solve_doubles(int P);
 void launch_loop_lm_panels(const double* Hp, int P, double lambda, double alpha, double max_step, double* work, unsigned int epoch, double* step,
+                           LoopFlags* flags, hipStream_t s);
+// The same step for 64 < P <= kLoopStreamMaxP as a stream of pivot-step records (k_loop_lm_stream + k_loop_lm_stream_tail): one wave per 16
+// columns of [A | I], the factorisation stays inside a workgroup for 64 steps at a time.  Same scratch, same epoch rule.
+bool loop_lm_stream_fits(int P);
+void launch_loop_lm_stream(const double* Hp, int P, double lambda, double alpha, double max_step, double* work, unsigned int epoch, double* step,
                            LoopFlags* flags, hipStream_t s);
 // the same tail (NaN test, clamp) for a step the host solved (P > 64)
 void launch_loop_step_finish(int P, double max_step, double* step, LoopFlags* flags, hipStream_t s);

@@ -686,6 +686,460 @@ __global__ __launch_bounds__(1024) void k_loop_lm_panels(const double* __restric
     }
 }
 
+// ---- 64 < P <= 192: the same Gauss-Jordan inverse as a STREAM of pivot steps (round 4) ---------------------------------------------------
+// k_loop_lm_panels pays, per panel of 8 pivot steps, one hand-over through global memory (~3 us) and three workgroup barriers per step
+// (~1.3 us): 24 x (3 + 8 x 1.3) = 310 us at P = 186, all of it on the critical path.  Here a pivot step is the work of ONE wave and the
+// critical path never leaves the compute unit it is on for 64 steps at a time:
+//   * a WORKER wave owns 8 columns of [A | I] for all rows (lane = row mod 64, R rows per lane, everything in registers) -- no workgroup
+//     barrier anywhere, what the lanes of a wave exchange goes through a few LDS words in program order;
+//   * what a pivot step needs from the outside is its RECORD: the physical pivot row and, for every row r, the entry x(r, k) as it was
+//     before the step (the multiplier f_rk; for the pivot row that is the pivot d_k).  The worker that owns column k makes the record
+//     (pivot search in its own registers: the column is up to date because it has applied every earlier record), every other worker
+//     only applies records: pivot row of its own columns / d_k, x - f_rk * s_kc for the rest -- the element operations of the serial
+//     algorithm in step order, bit for bit (skipped where f_rk == 0, like there);
+//   * records travel through a ring in LDS to the other workers of the workgroup (eight workers = 64 columns: the next owner is one
+//     LDS round trip behind, not one global hand-over) and, copied out by a HELPER wave, through global memory to the other workgroups
+//     (`published` counts them; the helper of a receiving workgroup copies them into its own ring).  Workgroups of A columns take over
+//     the factorisation one after the other (two global hand-overs at P = 186 instead of 23); the workgroups of I columns only follow;
+//   * A columns left of the pivot are dead (unit vectors nobody reads again): a worker retires when its last column has been the pivot.
+// The inverse leaves the kernel transposed (inv_t[c][r], coalesced for the product with g that k_loop_lm_stream_tail computes row by
+// row in column order).  Deadlock freedom as for the panels: a workgroup only waits for workgroups with smaller block indices, which
+// the dispatcher places first, and inside a workgroup for waves that never wait for it.
+#ifndef DMSA_STREAM_W
+#define DMSA_STREAM_W 8
+#endif
+#ifndef DMSA_STREAM_WORKERS
+#define DMSA_STREAM_WORKERS 8
+#endif
+constexpr int kStreamW = DMSA_STREAM_W;              // columns per worker wave (8 or 16)
+constexpr int kStreamWorkers = DMSA_STREAM_WORKERS;  // worker waves per workgroup (+ one helper wave); <= 15
+constexpr int kStreamD = 24;        // ring slots (pivot steps a consumer may lag behind its producer)
+constexpr int kStreamBatch = 8;     // records a helper moves per round; the producer checks the ring for room every kStreamBatch steps
+constexpr int kStreamNever = 0x7fffffff;
+template <int R>
+struct StreamLds {
+    double ring_f[kStreamD][64 * R];                 // records: x(r, k) before step k (f_rk; d_k in the pivot row's place)
+    double scr[kStreamWorkers][2 * kStreamW];        // per worker: its pivot row's entries, raw | scaled
+    int ring_pp[kStreamD];                           // records: physical pivot row
+    int produced;                                    // records [.., produced) are in the ring
+    int consumed[16];                                // per consumer (workers, then the helper): records it needs no more; kStreamNever = none
+};
+struct StreamWork {   // carved from the solve scratch (loop_panel_solve_doubles covers both layouts)
+    double* mult;                  // [P][64 R]
+    double* inv_t;                 // [P][64 R]: column c of the inverse, physical rows
+    int* gpp;                      // [P]
+    int* iperm;                    // [64 R]: logical row of every physical row after the last step
+    unsigned long long* published; // (epoch << 32) | records published
+};
+__device__ __host__ __forceinline__ StreamWork stream_work(double* work, int P, int RN) {
+    StreamWork w;
+    w.mult = work;
+    w.inv_t = work + (size_t)P * RN;
+    w.published = reinterpret_cast<unsigned long long*>(w.inv_t + (size_t)P * RN);
+    w.gpp = reinterpret_cast<int*>(w.published + 2);
+    w.iperm = w.gpp + ((P + 1) / 2) * 2;
+    return w;
+}
+// every wait of the stream kernel is for a wave that never waits for the waiter (records only flow forward; workgroups with smaller block
+// indices are placed first), so a wait that does not end is a bug: after ~seconds of polling the wave traps -- the dispatch dies with an
+// error instead of hanging the device
+constexpr int kStreamSpinLimit = 1 << 25;
+__device__ __forceinline__ void stream_spin(int& spins) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > kStreamSpinLimit) __builtin_trap();
+}
+__device__ __forceinline__ int lds_load_acquire(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store_release(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// A count that follows LDS WRITES of the same wave needs no wait: the LDS takes a wave's instructions in order, so whoever sees the count
+// sees the writes issued before it.  (A release store would first wait for those writes to come back: ~100 cycles on the critical path
+// of every pivot step.)  Only the compiler has to be kept from moving the writes below the count.
+__device__ __forceinline__ void lds_store_after_writes(int* p, int v) {
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+// smallest entry of consumed[0..15] (every lane returns it)
+__device__ __forceinline__ int stream_min_consumed(const int* consumed, int lane) {
+    int v = lds_load_acquire(consumed + (lane & 15));
+    v = min(v, __shfl_xor(v, 1));
+    v = min(v, __shfl_xor(v, 2));
+    v = min(v, __shfl_xor(v, 4));
+    v = min(v, __shfl_xor(v, 8));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+// Which of a lane's R rows a (wave-uniform) slot number means, as R separate flags the optimiser cannot see through: written as
+// `ps == i` inside the unrolled loops below, the compiler folds the if-chains into x[ps][c] -- a dynamically indexed array, i.e. the
+// whole register block of a worker in scratch memory.
+template <int R>
+struct SlotFlags {
+    bool is[R];
+};
+template <int R>
+__device__ __forceinline__ SlotFlags<R> slot_flags(int ps) {
+    SlotFlags<R> s;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        int hit = __builtin_amdgcn_readfirstlane(ps == i ? 1 : 0);
+        asm volatile("" : "+s"(hit));
+        s.is[i] = hit != 0;
+    }
+    return s;
+}
+// One pivot step applied to a worker's columns c >= kFirst: pivot row (lane pl, slot `sel`) -> x / d, every other row x - f * s.
+template <int R, int kFirst>
+__device__ __forceinline__ void stream_apply(double (&x)[R][kStreamW], const double (&f)[R], double d, int pl, const SlotFlags<R>& sel, int lane, double* scr) {
+    if (lane == pl) {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+            if (sel.is[i]) {
+#pragma unroll
+                for (int c = kFirst; c < kStreamW; ++c) scr[c] = x[i][c];
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // one lane per column divides (one fp64 division is ~40 dependent instructions)
+    if (lane >= kFirst && lane < kStreamW) scr[kStreamW + lane] = scr[lane] / d;
+    __builtin_amdgcn_wave_barrier();
+    double q[kStreamW];
+#pragma unroll
+    for (int c = kFirst; c < kStreamW; ++c) q[c] = scr[kStreamW + c];
+    __builtin_amdgcn_wave_barrier();   // the next step's writes to scr come after these reads
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (lane == pl && sel.is[i]) {
+#pragma unroll
+            for (int c = kFirst; c < kStreamW; ++c) x[i][c] = q[c];
+        } else if (f[i] != 0.0) {
+#pragma unroll
+            for (int c = kFirst; c < kStreamW; ++c) x[i][c] -= f[i] * q[c];
+        }
+    }
+}
+// the row bookkeeping of a step: the pivot row (lane pl, slot `sel`) becomes logical row k, the row that was logical row k takes its place
+template <int R>
+__device__ __forceinline__ void stream_swap_rows(int (&logical)[R], unsigned& pivoted, int k, int pl, const SlotFlags<R>& sel, int lane) {
+    int bl = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int li = __builtin_amdgcn_readlane(logical[i], pl);   // (scalars: nothing to index)
+        bl = sel.is[i] ? li : bl;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (lane == pl && sel.is[i]) logical[i] = k, pivoted |= 1u << i;
+        else if (logical[i] == k) logical[i] = bl;
+    }
+}
+// Pivot step k = local column J of the worker that owns it: search, record, then the step itself on the columns right of J.
+template <int R, int J>
+__device__ __forceinline__ void stream_factor_step(double (&x)[R][kStreamW], int (&logical)[R], unsigned& pivoted, int k, int n, int lane, StreamLds<R>& sm, double* scr) {
+    int spins = 0;
+    if (J % kStreamBatch == 0)   // room for the next kStreamBatch records: every consumer is done with the ones they overwrite
+        while (stream_min_consumed(sm.consumed, lane) < min(k + kStreamBatch, n) - kStreamD) stream_spin(spins);
+    // pivot: largest |x| among the rows not yet pivoted, ties to the smallest logical row (= the serial search from row k down)
+    double vm = -1.0;
+    int lm = kStreamNever, sl = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const double a = fabs(x[i][J]);
+        const bool cand = ((pivoted >> i) & 1u) == 0u && !isnan(a);
+        if (cand && (a > vm || (a == vm && logical[i] < lm))) vm = a, lm = logical[i], sl = i;
+    }
+    double bv = vm;
+    int bl = lm;
+    wave_best(bv, bl);
+    int pl = 0, ps = 0;
+    if (bv >= 0.0) {
+        const unsigned long long hit = __ballot(vm == bv && lm == bl);
+        pl = __builtin_ctzll(hit);
+        ps = __builtin_amdgcn_readlane(sl, pl);
+    } else {
+        // nothing comparable (NaNs): keep the diagonal like the serial search
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const unsigned long long hit = __ballot(logical[i] == k);
+            if (hit != 0ull) pl = __builtin_ctzll(hit), ps = i;
+        }
+    }
+    // the record: the column as it stands; the pivot row's entry is the pivot
+    double f[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) f[i] = x[i][J];
+    pl = __builtin_amdgcn_readfirstlane(pl), ps = __builtin_amdgcn_readfirstlane(ps);   // (uniform already; now the compiler knows)
+    const SlotFlags<R> sel = slot_flags<R>(ps);
+    double d = 0.0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const double di = readlane_f64(f[i], pl);
+        d = sel.is[i] ? di : d;
+    }
+    const int slot = k % kStreamD;
+#pragma unroll
+    for (int i = 0; i < R; ++i) sm.ring_f[slot][lane + 64 * i] = f[i];
+    if (lane == 0) sm.ring_pp[slot] = pl + 64 * ps;
+    __builtin_amdgcn_wave_barrier();
+    lds_store_after_writes(&sm.produced, k + 1);
+    stream_swap_rows<R>(logical, pivoted, k, pl, sel, lane);
+    // columns <= J of this worker are dead after the step (unit vectors nobody reads again)
+    stream_apply<R, (J + 1 < kStreamW ? J + 1 : kStreamW)>(x, f, d, pl, sel, lane, scr);
+}
+template <int R>
+__global__ __launch_bounds__((kStreamWorkers + 1) * kWave) void k_loop_lm_stream(const double* __restrict__ Hp, int P, double lambda, double* __restrict__ work,
+                                                                                  unsigned int epoch, const LoopFlags* __restrict__ flags) {
+    if (flags->stop != 0) return;
+    constexpr int RN = 64 * R, W = kStreamW;
+    const int n = P, n1 = P + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
+    const int nA = (n + W - 1) / W;                                   // worker waves of A columns (and as many of I columns)
+    const int GA = (nA + kStreamWorkers - 1) / kStreamWorkers;        // workgroups of A columns
+    const bool a_part = b < GA;
+    const StreamWork gw = stream_work(work, P, RN);
+    __shared__ StreamLds<R> sm;
+    // records this workgroup makes itself: [s0, s1); everything before s0 arrives through global memory
+    const int s0 = a_part ? min(n, b * kStreamWorkers * W) : n;
+    const int s1 = a_part ? min(n, s0 + kStreamWorkers * W) : n;
+    const int wi = (a_part ? b : b - GA) * kStreamWorkers + wave;     // worker index within its part
+    const int c0 = wi * W;                                            // first column (of A or of I)
+    const bool worker = wave < kStreamWorkers && c0 < n;
+    if (threadIdx.x == 0) sm.produced = 0;
+    if (threadIdx.x < 16) {
+        // workers start at record 0 (set HERE, before anybody may write the ring), the helper reads no record before s0
+        const int t = threadIdx.x;
+        const bool valid = t < kStreamWorkers && ((a_part ? b : b - GA) * kStreamWorkers + t) * W < n;
+        sm.consumed[t] = t == kStreamWorkers ? s0 : valid ? 0 : kStreamNever;
+    }
+    __syncthreads();   // the only workgroup barrier: nobody has left yet
+    if (wave < kStreamWorkers && !worker) return;
+
+    if (wave == kStreamWorkers) {
+        // ---- helper: records of earlier workgroups global -> ring, then this workgroup's records ring -> global ----
+        int fetched = 0, spins = 0;
+#ifdef DMSA_STREAM_TIMING
+        const long long th0 = wall_clock64();
+        long long t_poll = 0;
+        int rounds_f = 0, rounds_p = 0;
+#endif
+        while (fetched < s0) {
+            unsigned long long seen;
+#ifdef DMSA_STREAM_TIMING
+            const long long tp = wall_clock64();
+            ++rounds_f;
+#endif
+            if (lane == 0) {
+                do {
+                    seen = __hip_atomic_load(gw.published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((seen >> 32) == (unsigned long long)epoch && (int)(seen & 0xffffffffull) > fetched) break;
+                    stream_spin(spins);
+                } while (true);
+            }
+            int avail = __builtin_amdgcn_readfirstlane(lane == 0 ? (int)(seen & 0xffffffffull) : 0);
+            avail = min(avail, s0);
+#ifdef DMSA_STREAM_TIMING
+            t_poll += wall_clock64() - tp;
+#endif
+            __threadfence();   // acquire: the records below were stored before `published` moved
+            while (fetched < avail) {
+                const int m = min(kStreamBatch, avail - fetched);
+                double v[kStreamBatch][R];
+                int pp[kStreamBatch];
+#pragma unroll
+                for (int u = 0; u < kStreamBatch; ++u) {
+                    if (u < m) {
+#pragma unroll
+                        for (int i = 0; i < R; ++i) v[u][i] = gw.mult[(size_t)(fetched + u) * RN + lane + 64 * i];
+                        pp[u] = gw.gpp[fetched + u];
+                    }
+                }
+                // room in the ring: every worker is done with the records these overwrite
+                while (stream_min_consumed(sm.consumed, lane) < fetched + m - kStreamD) stream_spin(spins);
+#pragma unroll
+                for (int u = 0; u < kStreamBatch; ++u) {
+                    if (u < m) {
+                        const int slot = (fetched + u) % kStreamD;
+#pragma unroll
+                        for (int i = 0; i < R; ++i) sm.ring_f[slot][lane + 64 * i] = v[u][i];
+                        if (lane == 0) sm.ring_pp[slot] = pp[u];
+                    }
+                }
+                fetched += m;
+                __builtin_amdgcn_wave_barrier();
+                lds_store_after_writes(&sm.produced, fetched);   // (every lane stores the same value)
+            }
+        }
+        int copied = s0;
+#ifdef DMSA_STREAM_TIMING
+        const long long th1 = wall_clock64();
+#endif
+        while (copied < s1) {
+#ifdef DMSA_STREAM_TIMING
+            ++rounds_p;
+#endif
+            int have;
+            while ((have = lds_load_acquire(&sm.produced)) <= copied) stream_spin(spins);
+            have = __builtin_amdgcn_readfirstlane(have);
+            for (int k = copied; k < have; ++k) {
+                const int slot = k % kStreamD;
+#pragma unroll
+                for (int i = 0; i < R; ++i) gw.mult[(size_t)k * RN + lane + 64 * i] = sm.ring_f[slot][lane + 64 * i];
+                if (lane == 0) gw.gpp[k] = sm.ring_pp[slot];
+            }
+            __threadfence();   // release, once: the records are written back before `published` moves (it also waits for the ring reads)
+            if (lane == 0) {
+                __hip_atomic_store(gw.published, ((unsigned long long)epoch << 32) | (unsigned long long)have, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&sm.consumed[kStreamWorkers], have, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            copied = have;
+        }
+#ifdef DMSA_STREAM_TIMING
+        if (lane == 0)
+            printf("[stream timing] helper of block %d: %d records fetched in %d rounds, %lld (polling %lld); %d published in %d rounds, %lld (x10 ns)\n", b, s0, rounds_f,
+                   th1 - th0, t_poll, s1 - s0, rounds_p, wall_clock64() - th1);
+#endif
+        return;
+    }
+
+    // ---- worker ----
+    double x[R][W];
+    int logical[R];
+    unsigned pivoted = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int r = lane + 64 * i;
+        logical[i] = r < n ? r : -1;
+        if (r >= n) pivoted |= 1u << i;   // padding rows: never candidates, all zero
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            const int col = c0 + c;
+            double v = 0.0;
+            if (r < n && col < n) {
+                if (a_part) {
+                    v = Hp[(size_t)col * n1 + r];   // H(r, col), damped on the diagonal (:110)
+                    if (col == r) v += lambda;
+                } else {
+                    v = col == r ? 1.0 : 0.0;
+                }
+            }
+            x[i][c] = v;
+        }
+    }
+    double* scr = sm.scr[wave];
+    // ---- apply the records of the steps before this worker's own columns (all of them for a worker of I columns) ----
+    const int k_end = a_part ? c0 : n;
+    int seen = 0, spins = 0;
+#ifdef DMSA_STREAM_TIMING
+    const long long t_begin = wall_clock64();
+    long long t_wait = 0;
+#endif
+    for (int k = 0; k < k_end; ++k) {
+        if (k >= seen) {
+#ifdef DMSA_STREAM_TIMING
+            const long long tw = wall_clock64();
+#endif
+            while ((seen = lds_load_acquire(&sm.produced)) <= k) stream_spin(spins);
+            seen = __builtin_amdgcn_readfirstlane(seen);
+#ifdef DMSA_STREAM_TIMING
+            t_wait += wall_clock64() - tw;
+#endif
+        }
+        const int slot = k % kStreamD;
+        const int pp = __builtin_amdgcn_readfirstlane(sm.ring_pp[slot]);
+        double f[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) f[i] = sm.ring_f[slot][lane + 64 * i];
+        const double d = sm.ring_f[slot][pp];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) lds_store_release(&sm.consumed[wave], k + 1);   // (release waits for the reads above)
+        const int pl = pp & 63;
+        const SlotFlags<R> sel = slot_flags<R>(pp >> 6);
+        stream_swap_rows<R>(logical, pivoted, k, pl, sel, lane);
+        stream_apply<R, 0>(x, f, d, pl, sel, lane, scr);
+    }
+#ifdef DMSA_STREAM_TIMING
+    const long long t_consumed = wall_clock64();
+    if (lane == 0 && !a_part && (wi == 0 || wi == 11))
+        printf("[stream timing] I worker %d: %d records in %lld (x10 ns), of which waiting %lld, spins %d\n", wi, k_end, t_consumed - t_begin, t_wait, spins);
+#endif
+    if (!a_part) {
+        // ---- columns of the inverse, transposed; the row permutation once ----
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+            if (c0 + c < n) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) gw.inv_t[(size_t)(c0 + c) * RN + lane + 64 * i] = x[i][c];
+            }
+        }
+        if (wi == 0) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) gw.iperm[lane + 64 * i] = logical[i];
+        }
+        return;
+    }
+    // ---- this worker's columns are the pivot columns now: it makes the records ----
+    if (lane == 0) lds_store_release(&sm.consumed[wave], kStreamNever);   // it reads the ring no more
+#define DMSA_STREAM_STEP(J) \
+    if (c0 + J < n) stream_factor_step<R, J>(x, logical, pivoted, c0 + J, n, lane, sm, scr);
+    DMSA_STREAM_STEP(0) DMSA_STREAM_STEP(1) DMSA_STREAM_STEP(2) DMSA_STREAM_STEP(3) DMSA_STREAM_STEP(4) DMSA_STREAM_STEP(5) DMSA_STREAM_STEP(6) DMSA_STREAM_STEP(7)
+#if DMSA_STREAM_W > 8
+    DMSA_STREAM_STEP(8) DMSA_STREAM_STEP(9) DMSA_STREAM_STEP(10) DMSA_STREAM_STEP(11) DMSA_STREAM_STEP(12) DMSA_STREAM_STEP(13) DMSA_STREAM_STEP(14) DMSA_STREAM_STEP(15)
+#endif
+#undef DMSA_STREAM_STEP
+#ifdef DMSA_STREAM_TIMING
+    if (lane == 0)
+        printf("[stream timing] A worker %d (block %d): start %lld, %d records applied in %lld (waiting %lld, spins %d), own columns factored in %lld (x10 ns)\n", wi, b,
+               t_begin, k_end, t_consumed - t_begin, t_wait, spins, wall_clock64() - t_consumed);
+#endif
+}
+// :113-128 behind k_loop_lm_stream: step = (-alpha H^-1) g row by row in column order (thread = physical row; the transposed inverse makes
+// every load a coalesced one), logical order through iperm, NaN test and max_step clamp.
+__global__ __launch_bounds__(256) void k_loop_lm_stream_tail(const double* __restrict__ Hp, int P, int RN, double alpha, double max_step, const double* __restrict__ work,
+                                                             double* __restrict__ step, LoopFlags* __restrict__ flags) {
+    if (flags->stop != 0) return;
+    const int n = P, n1 = P + 1, r = threadIdx.x, lane = r & 63, wave = r >> 6;
+    const StreamWork gw = stream_work(const_cast<double*>(work), P, RN);
+    __shared__ double s_step[256];
+    if (r < n) {
+        const double* gv = Hp + (size_t)P * n1;
+        double sres = 0.0;
+        int j = 0;
+        for (; j + 16 <= n; j += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = gw.inv_t[(size_t)(j + u) * RN + r];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sres += (-alpha * v[u]) * gv[j + u];
+        }
+        for (; j < n; ++j) sres += (-alpha * gw.inv_t[(size_t)j * RN + r]) * gv[j];
+        s_step[gw.iperm[r]] = sres;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        bool any_nan = false;
+        double mx = -INFINITY, mn = INFINITY;
+        for (int i = lane; i < n; i += 64) {
+            const double v = s_step[i];
+            any_nan = any_nan || isnan(v);
+            mx = mx < v ? v : mx;
+            mn = v < mn ? v : mn;
+        }
+        if (__ballot(any_nan) != 0ull) {
+            if (lane == 0) flags->nan = 1;
+        } else {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double a = __shfl_xor(mx, o), c = __shfl_xor(mn, o);
+                mx = mx < a ? a : mx;
+                mn = c < mn ? c : mn;
+            }
+            const double neg = -mn;
+            const double max_elem = mx < neg ? neg : mx;
+            for (int i = lane; i < n; i += 64) {
+                const double v = s_step[i];
+                step[i] = max_elem > max_step ? (max_step / max_elem) * v : v;
+            }
+        }
+    }
+}
+
 // the same tail for a step the host solved (P > 64): one wave, NaN test and extrema as wave reductions (max / min are order independent)
 __global__ __launch_bounds__(kWave) void k_loop_step_finish(int P, double max_step, double* __restrict__ step, LoopFlags* __restrict__ flags) {
     if (flags->stop != 0) return;
@@ -853,10 +1307,26 @@ void launch_loop_lm_step_partials(const double* partial, int nsplit, int nt, int
                                   double* error0_out, hipStream_t s) {
     launch_lm_step(HpSource{nullptr, partial, nsplit, nt}, P, lambda, alpha, max_step, step, flags, error0_out, s);
 }
+static int stream_rows_per_lane(int P) { return (P + 63) / 64; }
 size_t loop_panel_solve_doubles(int P) {
     const size_t panels = ((size_t)P + kPanel - 1) / kPanel;
-    return panels * (size_t)P * kPanel /* published panels */ + (size_t)P * P /* inverse */ + panels + 2 /* flags, done counter (as 8-byte words) */ +
-           (size_t)P / 2 + 2 /* final row permutation (ints) */;
+    const size_t blocked = panels * (size_t)P * kPanel /* published panels */ + (size_t)P * P /* inverse */ + panels + 2 /* flags, done counter (as 8-byte words) */ +
+                           (size_t)P / 2 + 2 /* final row permutation (ints) */;
+    const size_t RN = 64 * (size_t)stream_rows_per_lane(P);
+    const size_t stream = 2 * (size_t)P * RN /* records, transposed inverse */ + 2 /* published */ + (size_t)P / 2 + 2 /* pivot rows (ints) */ + RN / 2 + 2 /* permutation */;
+    return blocked > stream ? blocked : stream;
+}
+bool loop_lm_stream_fits(int P) { return P > kLoopSolveMaxP && P <= kLoopStreamMaxP; }
+void launch_loop_lm_stream(const double* Hp, int P, double lambda, double alpha, double max_step, double* work, unsigned int epoch, double* step,
+                           LoopFlags* flags, hipStream_t s) {
+    const int R = stream_rows_per_lane(P), RN = 64 * R;
+    const int nA = (P + kStreamW - 1) / kStreamW, GA = (nA + kStreamWorkers - 1) / kStreamWorkers;
+    const dim3 grid(2 * GA), block((kStreamWorkers + 1) * kWave);
+    if (R <= 2)
+        hipLaunchKernelGGL(k_loop_lm_stream<2>, grid, block, 0, s, Hp, P, lambda, work, epoch, flags);
+    else
+        hipLaunchKernelGGL(k_loop_lm_stream<3>, grid, block, 0, s, Hp, P, lambda, work, epoch, flags);
+    hipLaunchKernelGGL(k_loop_lm_stream_tail, dim3(1), dim3(RN), 0, s, Hp, P, RN, alpha, max_step, work, step, flags);
 }
 void launch_loop_lm_panels(const double* Hp, int P, double lambda, double alpha, double max_step, double* work, unsigned int epoch, double* step,
                            LoopFlags* flags, hipStream_t s) {

@@ -584,14 +584,18 @@ int device_lm_step(dmsa_ctx* ctx, const double* d_Hp, int P, double lambda, doub
         launch_loop_lm_step(d_Hp, P, lambda, alpha, max_step, d_step, d_flags, ctx->stream);
     } else {
         const size_t bytes = loop_panel_solve_doubles(P) * 8;
-        if (bytes > ctx->d_panel_work.cap) {
+        if (bytes > ctx->d_panel_work.cap || P != ctx->panel_P) {
+            // a new size moves the epoch-tagged words (hand-over flags, record counter) onto what used to be data: start from zeros
             HIPCHK(ctx->d_panel_work.ensure(bytes));
             HIPCHK(hipMemsetAsync(ctx->d_panel_work.p, 0, ctx->d_panel_work.cap, ctx->stream));
-            ctx->panel_epoch = 0;
+            ctx->panel_epoch = 0, ctx->panel_P = P;
         }
         ctx->panel_epoch += 1;
         if (ctx->panel_epoch == 0) ctx->panel_epoch = 1;
-        launch_loop_lm_panels(d_Hp, P, lambda, alpha, max_step, ctx->d_panel_work.as<double>(), ctx->panel_epoch, d_step, d_flags, ctx->stream);
+        if (ctx->dbg.lm_stream != 0 && loop_lm_stream_fits(P))
+            launch_loop_lm_stream(d_Hp, P, lambda, alpha, max_step, ctx->d_panel_work.as<double>(), ctx->panel_epoch, d_step, d_flags, ctx->stream);
+        else
+            launch_loop_lm_panels(d_Hp, P, lambda, alpha, max_step, ctx->d_panel_work.as<double>(), ctx->panel_epoch, d_step, d_flags, ctx->stream);
     }
     HIPCHK(hipGetLastError());
     return DMSA_OK;

@@ -51,6 +51,8 @@ typedef struct dmsa_debug_options {
                                      speculative sort width is wrong and the voxelisation runs again                                       */
     int32_t voxel_coherence; /* 0   1: count, per voxelisation and level, the points whose leaf code differs from the previous voxelisation's of
                                      the same context (dmsa_debug_counters: how much of last iteration's sorted order would survive)       */
+    int32_t lm_stream;       /* 1   LM solve for 64 < P <= 192 as a stream of pivot-step records (one wave per 8 columns, csrc/loop_kernels.hip:
+                                     k_loop_lm_stream); 0: column-block workgroups handing panels over (k_loop_lm_panels).  Same bits.        */
 } dmsa_debug_options;
 
 /* what the switches above leave behind, since the context was created */

@@ -22,10 +22,13 @@ def _system(orc, P, seed):
     return orc.lm_step(e0, eb, h, float(np.float32(1e-5)), 0.2)  # H (damped), g, step
 
 
-@pytest.mark.parametrize("P", [6, 12, 30, 31, 63, 64, 65, 72, 96, 184, 186, 187, 200, 594])
-def test_device_lm_step_equals_the_oracle_step(hip, orc, P):
+@pytest.mark.parametrize("P,lm_stream", [(P, 1) for P in (6, 12, 30, 31, 63, 64, 65, 72, 96, 127, 128, 129, 184, 186, 187, 192, 193, 200, 594)]
+                         + [(P, 0) for P in (65, 72, 186, 192)])
+def test_device_lm_step_equals_the_oracle_step(hip, orc, P, lm_stream):
+    """P <= 64: one workgroup (k_loop_lm_step); 64 < P <= 192: the stream of pivot-step records (k_loop_lm_stream; lm_stream = 0 selects the
+    column-block panels, k_loop_lm_panels, which also serve P > 192) -- every path the oracle's step bit for bit."""
     H, g, step_ref = _system(orc, P, 300 + P)
-    opt = hip.DmsaOptimizer()
+    opt = hip.DmsaOptimizer(debug={"lm_stream": lm_stream})
     for rep in range(2):  # the panel solve reuses its scratch with a new epoch
         step, nan = opt.lmSolveDevice(H.reshape(P, P), g, 0.2)
         assert not nan
