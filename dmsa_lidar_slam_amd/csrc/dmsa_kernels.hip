@@ -962,16 +962,6 @@ void launch_leaf_accept(const int32_t* leaf_start, const uint32_t* idx_sorted, c
 // The quadratic part of splitSet (Gaussians.h:36-51), position-parallel: every sorted position a of an accepted leaf scans
 // all members c of its leaf (normals pre-gathered in sorted order, so a wave inside one big leaf reads the same address)
 // and keeps its first best partner.  Work per leaf is n^2 / 64 wave-iterations spread over n / 64 waves instead of one.
-__global__ __launch_bounds__(256) void k_split_gather_normals(const uint32_t* __restrict__ idx_sorted, const float4* __restrict__ nglobal,
-                                                              const int32_t* __restrict__ ring, int64_t n, float4* __restrict__ nsorted) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t pi = idx_sorted[i];
-        float4 v = nglobal[pi];
-        v.w = __int_as_float(ring[pi]);  // the normal's w is unused: carry the ring id in sorted order
-        nsorted[i] = v;
-    }
-}
 // Work decomposition: a TASK is (wave block of 64 consecutive sorted positions) x (one chunk of the partner range).  The
 // union of the leaves touched by the 64 positions is contiguous; it is cut into at most kSplitMaxChunks chunks of >=
 // kSplitChunk partners, so a 17 000-point leaf becomes ~275 x 64 tasks that fill the chip, while the task list stays <= n
@@ -979,6 +969,7 @@ __global__ __launch_bounds__(256) void k_split_gather_normals(const uint32_t* __
 // k_split_pairs walks it with persistent waves.
 constexpr int kSplitChunk = 256;
 constexpr int kSplitMaxChunks = 64;
+constexpr int kSplitStripes = 256;   // ticket counters of k_split_pairs (= threads of a k_split_prepare workgroup, which clears them)
 struct SplitTask {
     int32_t wave_block;  // positions 64*wave_block .. +63
     int32_t c0, c1;      // partner positions [c0, c1)
@@ -1039,12 +1030,7 @@ __global__ __launch_bounds__(1024) void k_split_tasks(const int32_t* __restrict_
 // half-angle phi).  For a position a at angle alpha from the axis every partner b of the block is at most min(pi, alpha + phi) away from
 // a, hence |a + b|^2 >= |a|^2 + bmin^2 + 2 |a| bmax cos(min(pi, alpha + phi)) (the last term only counts when negative).  cone[blk] =
 // (axis, cos phi), norms[blk] = (bmin, bmax); a block with a non-finite or vanishing sum gets cos phi = -1: never skipped.
-__global__ __launch_bounds__(256) void k_split_cones(const float4* __restrict__ nsorted, int64_t n, float4* __restrict__ cone, float2* __restrict__ norms) {
-    const int lane = threadIdx.x & 63;
-    const int64_t blk = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, i = blk * 64 + lane;
-    if (blk * 64 >= n) return;
-    const bool in = i < n;
-    const float4 v = in ? nsorted[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+__device__ __forceinline__ void split_block_cone(const float4 v, bool in, int lane, int64_t blk, float4* __restrict__ cone, float2* __restrict__ norms) {
     const float sx = wave_allsum(v.x), sy = wave_allsum(v.y), sz = wave_allsum(v.z);
     const float s2 = sum3f(sx * sx, sy * sy, sz * sz), nv = sqrtf(sum3f(v.x * v.x, v.y * v.y, v.z * v.z));
     float cx = 0.f, cy = 0.f, cz = 0.f, cosphi = -1.0f;
@@ -1060,6 +1046,30 @@ __global__ __launch_bounds__(256) void k_split_cones(const float4* __restrict__ 
     if (!(nmin <= nmax)) nmin = 0.0f, nmax = FLT_MAX, cosphi = -1.0f;
     if (lane == 0) cone[blk] = make_float4(cx, cy, cz, cosphi), norms[blk] = make_float2(nmin, nmax);
 }
+// Everything the pair search needs, in ONE pass over the sorted positions (four launches until round 4: gather, two fills, cones): the
+// normals in sorted order (ring id in w), pair_best = "no partner", the task counter = 0, and the cone of every 64 consecutive normals.
+__global__ __launch_bounds__(256) void k_split_prepare(const uint32_t* __restrict__ idx_sorted, const float4* __restrict__ nglobal,
+                                                       const int32_t* __restrict__ ring, int64_t n, float4* __restrict__ nsorted,
+                                                       unsigned long long* __restrict__ pair_best, int32_t* __restrict__ num_tasks,
+                                                       float4* __restrict__ cone, float2* __restrict__ norms, int32_t* __restrict__ tickets) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;   // a multiple of 64: a wave always holds one aligned block of 64 positions
+    if (blockIdx.x == 0 && threadIdx.x == 0) *num_tasks = 0;
+    if (blockIdx.x == 0) tickets[threadIdx.x * 16] = 0;       // kSplitStripes = blockDim.x counters, 64 bytes apart
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n; base += stride) {
+        const int64_t i = base + lane;
+        const bool in = i < n;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) {
+            const uint32_t pi = idx_sorted[i];
+            v = nglobal[pi];
+            v.w = __int_as_float(ring[pi]);  // the normal's w is unused: carry the ring id in sorted order
+            nsorted[i] = v;
+            pair_best[i] = ~0ull;
+        }
+        split_block_cone(v, in, lane, base >> 6, cone, norms);
+    }
+}
 
 // A task's 64 positions meet its partners 64 at a time: one coalesced vector load puts partner c0 + lane into every lane
 // (the next 64 are prefetched meanwhile), then the partners are broadcast lane by lane with v_readlane.  No LDS and no scalar
@@ -1071,15 +1081,24 @@ __global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__
                                                      const int32_t* __restrict__ slot_acc, const float4* __restrict__ nsorted, int64_t n_valid_cap,
                                                      const LevelCounts* __restrict__ counts, const SplitTask* __restrict__ tasks,
                                                      const int32_t* __restrict__ num_tasks, unsigned long long* __restrict__ pair_best,
-                                                     const float4* __restrict__ cone, const float2* __restrict__ norms, unsigned long long* __restrict__ skipped) {
+                                                     const float4* __restrict__ cone, const float2* __restrict__ norms, unsigned long long* __restrict__ skipped,
+                                                     int32_t* __restrict__ tickets) {
     const int nl = counts->num_leaves;
     const int64_t nvalid = min((int64_t)leaf_start[nl], n_valid_cap);
     const int ntasks = *num_tasks;
     unsigned long long n_blocks = 0, n_skipped = 0;
     const int lane = threadIdx.x & 63;
-    const int wave_global = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
     const float kFar = 3.0e19f;  // (n_a + kFar)^2 overflows to +inf: padding partners can never win
-    for (int t = wave_global; t < ntasks; t += nwaves) {
+    // Tasks differ by a factor of ten in cost (a chunk of partners is either skipped block by block or searched pair by pair), so a fixed
+    // share per wave left the chip waiting for the unlucky waves.  Stripe q holds tasks q, q + kSplitStripes, ... (neighbouring tasks are
+    // alike, so the stripes get the same mix) and is handed out task by task, through its own counter (64 bytes apart: one counter for
+    // all waves would serialise ~10^5 atomics), to the waves of the workgroups q, q + kSplitStripes, ...
+    const int stripe = (int)(blockIdx.x % kSplitStripes);
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = stripe + kSplitStripes * atomicAdd(&tickets[stripe * 16], 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= ntasks) break;
         const SplitTask task = tasks[t];
         const int64_t i = (int64_t)task.wave_block * 64 + lane;
         const int c0 = __builtin_amdgcn_readfirstlane(task.c0), c1 = __builtin_amdgcn_readfirstlane(task.c1);
@@ -1095,13 +1114,19 @@ __global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__
         const float4 na = active ? nsorted[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         // The reference compares norms (sqrt) with a strict '<'.  sqrt is monotone, so a candidate whose SQUARED norm is not
         // below the best squared norm can never win; the (correctly rounded, expensive) sqrt is only taken for the rest.
-        float best = FLT_MAX, best_sq = active ? FLT_MAX : -1.0f;
-        int best_c = 0;
+        // best_sq starts AT the bound: a candidate above it changes nothing downstream (k_leaf_split only looks at minima <= 0.5), so the
+        // ordered update below never runs for the ~parallel pairs that make up almost every block that is not skipped outright
+        float best_sq = active ? bound : -1.0f;
+        int best_c = -1;
         const int self = (int)i;
-        auto exact = [&](float sq, int j) {  // the reference's update, in partner order
+        // The reference's update, in partner order: `norm < min` on the ROUNDED square roots.  Two squares more than 2^-21 apart (relative)
+        // have square roots more than one float step apart, so their roundings compare like the squares: no sqrt on that branch.  Inside
+        // the band the roots are taken and compared as the reference does (equal roots: the earlier partner stays).  A task starts without
+        // a minimum of its own, and in the blocks that survive the cone test (walls seen from both sides: every pair is a candidate) some
+        // lane improves in nearly every step -- with a correctly rounded sqrt per candidate that branch was two thirds of the kernel.
+        auto exact = [&](float sq, int j) {
             if (sq < best_sq && j != self) {
-                const float d = sqrtf(sq);
-                if (d < best) best = d, best_sq = sq, best_c = j - b;
+                if (sq < best_sq * 0.9999995f /* 1 - 2^-21 */ || sqrtf(sq) < sqrtf(best_sq)) best_sq = sq, best_c = j - b;
             }
         };
         auto load64 = [&](int j) {
@@ -1129,6 +1154,9 @@ __global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__
                     continue;
                 }
             }
+            // (A pre-test on the inner product a.c -- three instructions per candidate instead of eight -- was measured: 135 -> 230 us.  The
+            // blocks that survive the cone test are walls seen from both sides, where EVERY pair is within 1e-6 of the running minimum:
+            // a conservative margin lets them all through and the exact sum is computed on top of the pre-test.)
 #pragma unroll
             for (int k = 0; k < 64; k += 4) {  // four independent candidates per step; the ordered exact update only if one can win
                 float q[4];
@@ -1145,8 +1173,8 @@ __global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__
             }
             cur = nxt;
         }
-        if (active && best < FLT_MAX)
-            atomicMin(&pair_best[i], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(uint32_t)best_c);
+        if (active && best_c >= 0)
+            atomicMin(&pair_best[i], ((unsigned long long)__float_as_uint(sqrtf(best_sq)) << 32) | (unsigned long long)(uint32_t)best_c);
     }
     // statistics (debug counters): 64 stripes of two words, one pair of atomics per workgroup -- every wave adding to ONE pair of words cost
     // 0.4 ms per voxelisation
@@ -1169,17 +1197,16 @@ __global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__
 // set, sign bit set for the second set.
 constexpr int kSplitBigLeaf = 1024;
 template <int kThreads>
-__global__ __launch_bounds__(kThreads) void k_leaf_split(const int32_t* __restrict__ leaf_start, const float4* __restrict__ nsorted,
-                                                         const LevelCounts* __restrict__ counts, int min_pts,
-                                                         const unsigned long long* __restrict__ pair_best, int32_t* __restrict__ slot_acc,
-                                                         int32_t* __restrict__ slot_cnt, int32_t* __restrict__ pos_slot_rank) {
+__device__ __forceinline__ void leaf_split_groups(int group, int ngroups, int tid, const int32_t* __restrict__ leaf_start, const float4* __restrict__ nsorted,
+                                                  const LevelCounts* __restrict__ counts, int min_pts, const unsigned long long* __restrict__ pair_best,
+                                                  int32_t* __restrict__ slot_acc, int32_t* __restrict__ slot_cnt, int32_t* __restrict__ pos_slot_rank) {
     constexpr int kWaves = kThreads / 64;
     __shared__ float s_best[kWaves];
     __shared__ long long s_pair[kWaves];
-    __shared__ int s_c1[kWaves], s_c2[kWaves], s_mn[kWaves], s_mx[kWaves];
+    __shared__ int s_c1[kWaves], s_c2[kWaves], s_mn[kWaves], s_mx[kWaves];   // (only the workgroup-wide groups, kWaves > 1, touch these)
     const int nl = counts->num_leaves;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int l = blockIdx.x; l < nl; l += gridDim.x) {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int l = group; l < nl; l += ngroups) {
         if (!slot_acc[2 * l]) continue;  // group-uniform
         const int b = leaf_start[l], e = leaf_start[l + 1], cnt = e - b;
         if ((cnt > kSplitBigLeaf) != (kWaves > 1)) continue;  // the other launch owns this leaf
@@ -1270,30 +1297,43 @@ __global__ __launch_bounds__(kThreads) void k_leaf_split(const int32_t* __restri
         }
     }
 }
+// One launch for both kinds of group (two until round 4, the second waiting for the first): the first kSplitBigBlocks workgroups take the
+// leaves above kSplitBigLeaf members as 1024-thread groups, every wave of the other workgroups is a group of its own for the rest.
+constexpr int kSplitBigBlocks = 256, kSplitSmallBlocks = 256;
+__global__ __launch_bounds__(1024) void k_leaf_split(const int32_t* __restrict__ leaf_start, const float4* __restrict__ nsorted, const LevelCounts* __restrict__ counts,
+                                                     int min_pts, const unsigned long long* __restrict__ pair_best, int32_t* __restrict__ slot_acc,
+                                                     int32_t* __restrict__ slot_cnt, int32_t* __restrict__ pos_slot_rank) {
+    if (blockIdx.x < kSplitBigBlocks)
+        leaf_split_groups<1024>((int)blockIdx.x, kSplitBigBlocks, (int)threadIdx.x, leaf_start, nsorted, counts, min_pts, pair_best, slot_acc, slot_cnt, pos_slot_rank);
+    else
+        leaf_split_groups<64>((int)(blockIdx.x - kSplitBigBlocks) * 16 + (int)(threadIdx.x >> 6), kSplitSmallBlocks * 16, (int)(threadIdx.x & 63), leaf_start, nsorted,
+                              counts, min_pts, pair_best, slot_acc, slot_cnt, pos_slot_rank);
+}
 // pair_best[n] | counter (own 64-byte slot) | task list.  k_split_tasks emits up to 64 tasks per 64-position wave block, i.e. up to
 // 64 * ceil(n / 64) entries when n is not a multiple of 64: the list is sized for that, and the counter no longer sits behind it.
 static inline size_t split_task_capacity(int64_t n) { return (size_t)((n + 63) / 64) * 64 + 64; }
 // ... | block cones (float4 + float2 per 64 sorted positions)
 static inline size_t split_cone_blocks(int64_t n) { return (size_t)((n + 63) / 64) + 1; }
-size_t split_scratch_bytes(int64_t n) { return (size_t)n * 8 + 64 + split_task_capacity(n) * sizeof(SplitTask) + 64 + split_cone_blocks(n) * 24 + 64; }
+size_t split_scratch_bytes(int64_t n) {
+    return (size_t)n * 8 + 64 + split_task_capacity(n) * sizeof(SplitTask) + 64 + split_cone_blocks(n) * 24 + 64 + (size_t)kSplitStripes * 64 + 64;
+}
 void launch_leaf_split(const int32_t* leaf_incl, const int32_t* leaf_start, const uint32_t* idx_sorted, const int32_t* ring, const float4* nglobal,
                        const LevelCounts* counts, int min_pts, int64_t n, float4* nsorted, unsigned long long* pair_best, int32_t* slot_acc,
                        int32_t* slot_cnt, int32_t* pos_slot_rank, hipStream_t s, unsigned long long* block_stats) {
-    hipLaunchKernelGGL(k_split_gather_normals, dim3(grid_for(n, 256)), dim3(256), 0, s, idx_sorted, nglobal, ring, n, nsorted);
-    (void)hipMemsetAsync(pair_best, 0xFF, (size_t)n * 8, s);
     // the task counter (own slot) and the task list live behind the n pair_best entries
     int32_t* num_tasks = reinterpret_cast<int32_t*>(pair_best + n);
     SplitTask* tasks = reinterpret_cast<SplitTask*>(reinterpret_cast<char*>(pair_best + n) + 64);
-    (void)hipMemsetAsync(num_tasks, 0, sizeof(int32_t), s);
     char* behind = reinterpret_cast<char*>(tasks) + split_task_capacity(n) * sizeof(SplitTask) + 64;
     float4* cone = reinterpret_cast<float4*>(behind);
     float2* norms = reinterpret_cast<float2*>(behind + split_cone_blocks(n) * 16);
-    hipLaunchKernelGGL(k_split_cones, dim3((unsigned)((split_cone_blocks(n) * 64 + 255) / 256)), dim3(256), 0, s, nsorted, n, cone, norms);
+    int32_t* tickets = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(behind + split_cone_blocks(n) * 24) + 63) & ~(uintptr_t)63);
+    static_assert(kSplitStripes == 256, "k_split_prepare clears one ticket per thread of its first workgroup");
+    hipLaunchKernelGGL(k_split_prepare, dim3(grid_for(n, 256)), dim3(256), 0, s, idx_sorted, nglobal, ring, n, nsorted, pair_best, num_tasks, cone, norms, tickets);
     hipLaunchKernelGGL(k_split_tasks, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, leaf_incl, leaf_start, slot_acc, n, counts, tasks, num_tasks);
     hipLaunchKernelGGL(k_split_pairs, dim3(4096), dim3(256), 0, s, leaf_incl, leaf_start, slot_acc, nsorted, n, counts, tasks, num_tasks, pair_best, cone, norms,
-                       block_stats);
-    hipLaunchKernelGGL(k_leaf_split<64>, dim3(4096), dim3(64), 0, s, leaf_start, nsorted, counts, min_pts, pair_best, slot_acc, slot_cnt, pos_slot_rank);
-    hipLaunchKernelGGL(k_leaf_split<1024>, dim3(256), dim3(1024), 0, s, leaf_start, nsorted, counts, min_pts, pair_best, slot_acc, slot_cnt, pos_slot_rank);
+                       block_stats, tickets);
+    hipLaunchKernelGGL(k_leaf_split, dim3(kSplitBigBlocks + kSplitSmallBlocks), dim3(1024), 0, s, leaf_start, nsorted, counts, min_pts, pair_best, slot_acc, slot_cnt,
+                       pos_slot_rank);
 }
 
 // Exclusive prefix sums of (accepted, accepted member count) over the two slots of every leaf.  The leaf count lives on the
