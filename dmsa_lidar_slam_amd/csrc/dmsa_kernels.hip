@@ -938,12 +938,20 @@ __global__ __launch_bounds__(256) void k_leaf_accept(const int32_t* __restrict__
             const int b = leaf_start[l], e = leaf_start[l + 1];
             cnt = e - b;
             if (cnt >= min_pts) {
+                // Members are sorted by point index, and neighbouring points of a scan line share their ring id: the walk to the first
+                // different id is tens of steps in the coarse leaves, each one two dependent loads.  Eight members per round, their
+                // loads independent of each other (the answer is an OR, the order of the tests does not matter).
                 const int first = ring[idx_sorted[b]];
-                for (int j = b + 1; j < e; ++j)
-                    if (ring[idx_sorted[j]] != first) {
-                        acc = 1;
-                        break;
-                    }
+                for (int j = b + 1; j < e && !acc; j += 8) {
+                    uint32_t pi[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) pi[u] = idx_sorted[min(j + u, e - 1)];
+                    int id[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) id[u] = ring[pi[u]];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc |= id[u] != first ? 1 : 0;
+                }
             }
         }
         slot_acc[2 * l] = acc;

@@ -898,7 +898,10 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
 // tiers (no ring, no barriers) as long as its waves stay short: measured 96 / 128 / 192 / 256 / 384 / 512 -> 1242 / 1256 / 1267 / 1272 /
 // 1241 / 1201 it/s on the bench window (128 until the end of round 3)
 int serial_small_threshold() { return 256; }
-static int serial_long_log2() { return 12; }  // Gaussians with >= 2^12 members go to the latency tier
+#ifndef DMSA_LONG_LOG2
+#define DMSA_LONG_LOG2 12
+#endif
+static int serial_long_log2() { return DMSA_LONG_LOG2; }  // Gaussians with >= 2^12 members go to the latency tier
 unsigned long long serial_fallback_sums(bool reset) {
     unsigned long long v = 0;
     (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_fallback_sums), sizeof(v));
