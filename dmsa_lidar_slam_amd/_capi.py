@@ -153,7 +153,7 @@ class StaticSelectResult(C.Structure):
 class DebugOptions(C.Structure):
     """include/dmsa_debug.h: dmsa_debug_options (fill with dmsa_default_debug_options first)."""
     _fields_ = [(n, C.c_int32) for n in ("device_loop", "dual_stream", "serial_streams", "merge_sort", "key_compress", "fused_segments", "sort_prehist",
-                                           "library_sort", "overlap_batch", "serial_tree", "host_threads", "solve_threads", "host_timeline", "trace_time", "fused_leaf_scan", "device_sync", "shared_rotations", "eval_skip", "sync_fault", "speculation_fault", "voxel_coherence", "lm_stream")]
+                                           "library_sort", "overlap_batch", "serial_tree", "host_threads", "solve_threads", "host_timeline", "trace_time", "fused_leaf_scan", "device_sync", "shared_rotations", "eval_skip", "sync_fault", "speculation_fault", "voxel_coherence", "lm_stream", "stream_priority")]
 
 
 class DebugCounters(C.Structure):

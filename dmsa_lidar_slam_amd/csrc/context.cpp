@@ -267,7 +267,7 @@ void dmsa_default_debug_options(dmsa_debug_options* o) {
     if (!o) return;
     o->device_loop = 1, o->dual_stream = 1, o->serial_streams = 3, o->merge_sort = -1, o->key_compress = 1, o->fused_segments = 1, o->sort_prehist = 0;
     o->library_sort = 0, o->overlap_batch = 1, o->serial_tree = 1, o->host_threads = 16, o->solve_threads = 12, o->host_timeline = 0, o->trace_time = 0, o->fused_leaf_scan = 1, o->device_sync = 1, o->shared_rotations = 1;
-    o->eval_skip = 1, o->sync_fault = 0, o->speculation_fault = 0, o->voxel_coherence = 0, o->lm_stream = 1;
+    o->eval_skip = 1, o->sync_fault = 0, o->speculation_fault = 0, o->voxel_coherence = 0, o->lm_stream = 1, o->stream_priority = 0;
 }
 // DMSA_DEBUG="name=value,name=value": the one environment variable of the library (include/dmsa_debug.h)
 static void apply_debug_env(dmsa_debug_options* o) {
@@ -280,7 +280,7 @@ static void apply_debug_env(dmsa_debug_options* o) {
                   {"key_compress", &o->key_compress},   {"fused_segments", &o->fused_segments}, {"sort_prehist", &o->sort_prehist}, {"library_sort", &o->library_sort},
                   {"overlap_batch", &o->overlap_batch}, {"serial_tree", &o->serial_tree},   {"host_threads", &o->host_threads},     {"solve_threads", &o->solve_threads},
                   {"host_timeline", &o->host_timeline}, {"trace_time", &o->trace_time},     {"fused_leaf_scan", &o->fused_leaf_scan}, {"device_sync", &o->device_sync},
-                  {"shared_rotations", &o->shared_rotations}, {"eval_skip", &o->eval_skip}, {"sync_fault", &o->sync_fault}, {"speculation_fault", &o->speculation_fault}, {"voxel_coherence", &o->voxel_coherence}, {"lm_stream", &o->lm_stream}};
+                  {"shared_rotations", &o->shared_rotations}, {"eval_skip", &o->eval_skip}, {"sync_fault", &o->sync_fault}, {"speculation_fault", &o->speculation_fault}, {"voxel_coherence", &o->voxel_coherence}, {"lm_stream", &o->lm_stream}, {"stream_priority", &o->stream_priority}};
     std::string text(e);
     size_t at = 0;
     while (at < text.size()) {
@@ -321,11 +321,18 @@ int dmsa_create_ex(int device, uint32_t flags, const dmsa_debug_options* options
     ctx->fused_segments = dbg.fused_segments != 0, ctx->prehist = dbg.sort_prehist != 0, ctx->dual_stream = dbg.dual_stream != 0;
     ctx->merge_sort = dbg.merge_sort < 0 ? -1 : (dbg.merge_sort != 0 ? 1 : 0);
     ctx->serial_two_streams = dbg.serial_streams != 1, ctx->serial_three_streams = dbg.serial_streams >= 3;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+    // stream_priority: bit 0 / 1 / 2 = main / second / third stream at the device's highest priority (the wave dispatcher then serves that
+    // queue first when kernels of several streams compete for the CUs)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    auto make_stream = [&](hipStream_t* st, int bit) {
+        return hipStreamCreateWithPriority(st, hipStreamNonBlocking, ((dbg.stream_priority >> bit) & 1) ? prio_greatest : prio_least / 2 + prio_greatest / 2);
+    };
+    if (make_stream(&ctx->stream, 0) != hipSuccess || make_stream(&ctx->stream2, 1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_scan0, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_counts, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess ||
+        make_stream(&ctx->stream3, 2) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_tables, hipEventDisableTiming) != hipSuccess) {
         delete ctx;
         return DMSA_ERR_HIP;

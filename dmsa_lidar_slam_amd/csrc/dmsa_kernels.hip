@@ -1249,10 +1249,9 @@ __device__ __forceinline__ void leaf_split_groups(int group, int ngroups, int ti
         const float4 r1 = nsorted[b + ia], r2 = nsorted[b + ic];
         int mn1 = INT_MAX, mx1 = INT_MIN;
         int rank_base1 = 0, rank_base2 = 0;
-        for (int j0 = b; j0 < e; j0 += kThreads) {
-            const int j = j0 + tid;
-            bool in = j < e, first = false;
-            int id = 0;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        auto classify = [&](int j, bool in, bool& first, int& id) {   // Gaussians.h:58-75: nearer to the first normal of the pair?
+            first = false, id = 0;
             if (in) {
                 const float4 v = nsorted[j];
                 const float d1 = sqrtf(sum3f((r1.x - v.x) * (r1.x - v.x), (r1.y - v.y) * (r1.y - v.y), (r1.z - v.z) * (r1.z - v.z)));
@@ -1260,29 +1259,64 @@ __device__ __forceinline__ void leaf_split_groups(int group, int ngroups, int ti
                 first = d1 < d2;
                 id = __float_as_int(v.w);
             }
-            const unsigned long long m1 = __ballot(in && first), m2 = __ballot(in && !first);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            int off1 = 0, off2 = 0, tot1 = __popcll(m1), tot2 = __popcll(m2);
-            if (kWaves > 1) {  // ranks continue across the waves of the group in position order
-                __syncthreads();
-                if (lane == 0) s_c1[wave] = tot1, s_c2[wave] = tot2;
-                __syncthreads();
-                tot1 = 0, tot2 = 0;
-                for (int w = 0; w < kWaves; ++w) {
-                    if (w == wave) off1 = tot1, off2 = tot2;
-                    tot1 += s_c1[w], tot2 += s_c2[w];
+        };
+        if (kWaves > 1) {
+            // Ranks run in position order through the whole leaf.  Every wave takes ONE contiguous run of positions and ranks inside it
+            // with counts of its own; the runs' bases need a single exchange, and a second sweep adds them.  (Until round 4 the waves took
+            // the positions round by round and exchanged their counts in every round: two workgroup barriers per 1024 members, 35 us for
+            // the coarse level's largest leaves.)
+            const int run = ((cnt + kWaves - 1) / kWaves + 63) & ~63;
+            const int wb = min(e, b + wave * run), we = min(e, wb + run);
+            int c1 = 0, c2 = 0;
+            for (int j0 = wb; j0 < we; j0 += 64) {
+                const int j = j0 + lane;
+                const bool in = j < we;
+                bool first;
+                int id;
+                classify(j, in, first, id);
+                const unsigned long long m1 = __ballot(in && first), m2 = __ballot(in && !first);
+                if (in) {
+                    if (first) {
+                        pos_slot_rank[j] = c1 + __popcll(m1 & below);
+                        mn1 = min(mn1, id), mx1 = max(mx1, id);
+                    } else {
+                        pos_slot_rank[j] = (int32_t)(0x80000000u | (uint32_t)(c2 + __popcll(m2 & below)));
+                    }
                 }
+                c1 += __popcll(m1), c2 += __popcll(m2);
             }
-            if (in) {
-                if (first) {
-                    pos_slot_rank[j] = rank_base1 + off1 + __popcll(m1 & below);
-                    mn1 = min(mn1, id), mx1 = max(mx1, id);
-                } else {
-                    pos_slot_rank[j] = (int32_t)(0x80000000u | (uint32_t)(rank_base2 + off2 + __popcll(m2 & below)));
+            __syncthreads();  // the previous leaf's readers of s_c1 / s_c2 are done
+            if (lane == 0) s_c1[wave] = c1, s_c2[wave] = c2;
+            __syncthreads();
+            int base1 = 0, base2 = 0;
+            for (int w = 0; w < kWaves; ++w) {
+                if (w == wave) base1 = rank_base1, base2 = rank_base2;
+                rank_base1 += s_c1[w], rank_base2 += s_c2[w];
+            }
+            if ((base1 | base2) != 0)
+                for (int j = wb + lane; j < we; j += 64) {  // the lane that wrote the rank reads it back
+                    const int r = pos_slot_rank[j];
+                    pos_slot_rank[j] = r < 0 ? r + base2 : r + base1;
                 }
+        } else {
+            for (int j0 = b; j0 < e; j0 += kThreads) {
+                const int j = j0 + tid;
+                const bool in = j < e;
+                bool first;
+                int id;
+                classify(j, in, first, id);
+                const unsigned long long m1 = __ballot(in && first), m2 = __ballot(in && !first);
+                if (in) {
+                    if (first) {
+                        pos_slot_rank[j] = rank_base1 + __popcll(m1 & below);
+                        mn1 = min(mn1, id), mx1 = max(mx1, id);
+                    } else {
+                        pos_slot_rank[j] = (int32_t)(0x80000000u | (uint32_t)(rank_base2 + __popcll(m2 & below)));
+                    }
+                }
+                rank_base1 += __popcll(m1);
+                rank_base2 += __popcll(m2);
             }
-            rank_base1 += tot1;
-            rank_base2 += tot2;
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {

@@ -53,6 +53,8 @@ typedef struct dmsa_debug_options {
                                      the same context (dmsa_debug_counters: how much of last iteration's sorted order would survive)       */
     int32_t lm_stream;       /* 1   LM solve for 64 < P <= 192 as a stream of pivot-step records (one wave per 8 columns, csrc/loop_kernels.hip:
                                      k_loop_lm_stream); 0: column-block workgroups handing panels over (k_loop_lm_panels).  Same bits.        */
+    int32_t stream_priority; /* 0   bit 0 / 1 / 2: the main / second / third stream of the context is created at the device's highest priority
+                                     (which of the concurrent kernels of an iteration the wave dispatcher serves first)                      */
 } dmsa_debug_options;
 
 /* what the switches above leave behind, since the context was created */
