@@ -15,6 +15,7 @@
 
 #include <cfloat>
 #include <climits>
+#include <type_traits>
 #include <cmath>
 #include <cstdlib>
 
@@ -1085,6 +1086,12 @@ __global__ __launch_bounds__(256) void k_split_prepare(const uint32_t* __restric
 // chunks of a position are merged with a 64-bit atomicMin on (float bits of the distance, partner rank): distances are >= 0,
 // so the unsigned order of the bits is the float order, and the smaller rank wins a tie -- the reference's first strict minimum.
 __device__ __forceinline__ float bcast_lane(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+// lane K of every row of 16 lanes, for all lanes of that row (row_newbcast); as the source of an add the compiler folds it into the
+// instruction (v_add_f32_dpp)
+template <int K>
+__device__ __forceinline__ float dpp_row_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, false));
+}
 __global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__ leaf_incl, const int32_t* __restrict__ leaf_start,
                                                      const int32_t* __restrict__ slot_acc, const float4* __restrict__ nsorted, int64_t n_valid_cap,
                                                      const LevelCounts* __restrict__ counts, const SplitTask* __restrict__ tasks,
@@ -1125,27 +1132,33 @@ __global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__
         // best_sq starts AT the bound: a candidate above it changes nothing downstream (k_leaf_split only looks at minima <= 0.5), so the
         // ordered update below never runs for the ~parallel pairs that make up almost every block that is not skipped outright
         float best_sq = active ? bound : -1.0f;
-        int best_c = -1;
+        int best_c = INT_MAX;   // sorted position of the best partner so far
         const int self = (int)i;
         // The reference's update, in partner order: `norm < min` on the ROUNDED square roots.  Two squares more than 2^-21 apart (relative)
         // have square roots more than one float step apart, so their roundings compare like the squares: no sqrt on that branch.  Inside
-        // the band the roots are taken and compared as the reference does (equal roots: the earlier partner stays).  A task starts without
-        // a minimum of its own, and in the blocks that survive the cone test (walls seen from both sides: every pair is a candidate) some
-        // lane improves in nearly every step -- with a correctly rounded sqrt per candidate that branch was two thirds of the kernel.
-        auto exact = [&](float sq, int j) {
-            if (sq < best_sq && j != self) {
-                if (sq < best_sq * 0.9999995f /* 1 - 2^-21 */ || sqrtf(sq) < sqrtf(best_sq)) best_sq = sq, best_c = j - b;
+        // the band the roots are taken and compared as the reference does (equal roots: the earlier partner stays).
+        auto exact = [&](float sq, int c) {
+            if (sq < best_sq && c != self) {
+                if (sq < best_sq * 0.9999995f /* 1 - 2^-21 */ || sqrtf(sq) < sqrtf(best_sq)) best_sq = sq, best_c = c;
             }
         };
-        auto load64 = [&](int j) {
-            const int jj = j + lane;
-            return jj < c1 ? nsorted[jj] : make_float4(kFar, kFar, kFar, 0.f);
+        struct Block {
+            float4 row[4];   // partners 16 m + (lane & 15) of a block of 64, m = 0 .. 3: every row of 16 lanes holds the same sixteen
+        };
+        auto load_block = [&](int j) {
+            Block blk;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int jj = j + 16 * m + (lane & 15);
+                blk.row[m] = jj < c1 ? nsorted[jj] : make_float4(kFar, kFar, kFar, 0.f);
+            }
+            return blk;
         };
         // for the block bound (k_split_cones): |a|^2, 1 / |a|
         const float na2 = sum3f(na.x * na.x, na.y * na.y, na.z * na.z), na_len = sqrtf(na2), na_inv = 1.0f / na_len;
-        float4 cur = load64(c0);
+        Block cur = load_block(c0);
         for (int j = c0; j < c1; j += 64) {
-            const float4 nxt = j + 64 < c1 ? load64(j + 64) : make_float4(kFar, kFar, kFar, 0.f);
+            const Block nxt = load_block(j + 64);   // (beyond c1: padding, no load)
             {   // can any pair of (these 64 positions) x (this partner block) have a norm <= 0.5?  If certainly not: skip the 4096 pairs.
                 const float4 cn = cone[j >> 6];
                 const float2 nb = norms[j >> 6];
@@ -1165,24 +1178,34 @@ __global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__
             // (A pre-test on the inner product a.c -- three instructions per candidate instead of eight -- was measured: 135 -> 230 us.  The
             // blocks that survive the cone test are walls seen from both sides, where EVERY pair is within 1e-6 of the running minimum:
             // a conservative margin lets them all through and the exact sum is computed on top of the pre-test.)
-#pragma unroll
-            for (int k = 0; k < 64; k += 4) {  // four independent candidates per step; the ordered exact update only if one can win
+            // The kernel is bound by vector instruction issue (93 % of the slots, scripts/pmc_kernel.sh), and a quarter of its instructions were
+            // v_readlane broadcasts of the partners.  Now a partner reaches the lanes as a MODIFIER of the add that consumes it (row_newbcast:
+            // lane k of a row of 16 to all lanes of the row); four loads put partners 16 m .. 16 m + 15 of the block into every row.  All
+            // lanes still see the partners in ascending order, which the strict '<' of `exact` relies on.
+            auto four = [&](auto kc, const float4& pm, int m) {  // partners 16 m + k .. + 3 of the block, k = kc.value
+                constexpr int k = decltype(kc)::value;
                 float q[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float sx = na.x + bcast_lane(cur.x, k + u), sy = na.y + bcast_lane(cur.y, k + u), sz = na.z + bcast_lane(cur.z, k + u);
+                auto one = [&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    const float sx = na.x + dpp_row_bcast<k + u>(pm.x), sy = na.y + dpp_row_bcast<k + u>(pm.y), sz = na.z + dpp_row_bcast<k + u>(pm.z);
                     q[u] = sum3f(sx * sx, sy * sy, sz * sz);
-                    if (!uniform) q[u] = (j + k + u >= b && j + k + u < e) ? q[u] : INFINITY;  // partner of another leaf
-                }
+                    if (!uniform) q[u] = (j + 16 * m + k + u >= b && j + 16 * m + k + u < e) ? q[u] : INFINITY;  // partner of another leaf
+                };
+                one(std::integral_constant<int, 0>{}), one(std::integral_constant<int, 1>{}), one(std::integral_constant<int, 2>{}), one(std::integral_constant<int, 3>{});
                 if (fminf(fminf(q[0], q[1]), fminf(q[2], q[3])) < best_sq) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) exact(q[u], j + k + u);
+                    for (int u = 0; u < 4; ++u) exact(q[u], j + 16 * m + k + u);
                 }
+            };
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                four(std::integral_constant<int, 0>{}, cur.row[m], m), four(std::integral_constant<int, 4>{}, cur.row[m], m);
+                four(std::integral_constant<int, 8>{}, cur.row[m], m), four(std::integral_constant<int, 12>{}, cur.row[m], m);
             }
             cur = nxt;
         }
-        if (active && best_c >= 0)
-            atomicMin(&pair_best[i], ((unsigned long long)__float_as_uint(sqrtf(best_sq)) << 32) | (unsigned long long)(uint32_t)best_c);
+        if (active && best_c != INT_MAX)
+            atomicMin(&pair_best[i], ((unsigned long long)__float_as_uint(sqrtf(best_sq)) << 32) | (unsigned long long)(uint32_t)(best_c - b));
     }
     // statistics (debug counters): 64 stripes of two words, one pair of atomics per workgroup -- every wave adding to ONE pair of words cost
     // 0.4 ms per voxelisation
