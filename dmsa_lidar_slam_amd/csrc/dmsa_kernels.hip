@@ -3074,25 +3074,38 @@ constexpr int kMfmaRows = 64;
 // batch is consumed by the normal equations only, and every panel element is then ONE load for the 2 * nt tiles that need it.
 // With `skip` (serial_kernels.h: launch_eval_row_ranges / launch_gauss_fit_all), the pairs (Gaussian r, evaluation k + 1) whose pose-table
 // rows all have evaluation 0's bits were not computed: their residual IS E[0][r], so the column entry is inv_h * (e0 - e0).
+constexpr int kJacColsPerThread = 8;   // evaluations per thread: e0 and the Gaussian's row range are loaded once for all of them
 __global__ __launch_bounds__(256) void k_jacobian_columns(double* __restrict__ E, int64_t ldE, int rows, int P, double inv_h, const EvalSkip skip) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    bool same = false;
-    if (skip.row_range != nullptr && r < skip.M) {
-        const int2 e = skip.row_range[k + 1], gr = skip.gauss_rows[r];
-        same = e.y < gr.x || e.x > gr.y;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, k0 = blockIdx.y * kJacColsPerThread;
+    const bool in = r < rows, sparse = skip.row_range != nullptr && r < skip.M;
+    const double e0 = in ? E[r] : 0.0;
+    const int2 gr = sparse ? skip.gauss_rows[r] : make_int2(0, 0);
+    double ek[kJacColsPerThread];
+    bool same[kJacColsPerThread];
+#pragma unroll
+    for (int u = 0; u < kJacColsPerThread; ++u) {  // the loads of all eight evaluations in flight together
+        const int k = k0 + u;
+        same[u] = false;
+        if (k < P && sparse) {
+            const int2 e = skip.row_range[k + 1];
+            same[u] = e.y < gr.x || e.x > gr.y;
+        }
+        ek[u] = e0;
+        if (k < P && in && (!same[u] || skip.check)) ek[u] = E[(size_t)(k + 1) * ldE + r];
     }
-    bool bad = false;
-    if (r < rows) {
-        const double e0 = E[r];
-        double ek = same && !skip.check ? e0 : E[(size_t)(k + 1) * ldE + r];
-        if (same && skip.check) bad = __double_as_longlong(ek) != __double_as_longlong(e0);  // eval_skip = 2: the pair WAS computed and must agree
-        E[(size_t)(k + 1) * ldE + r] = inv_h * (ek - e0);
-    }
-    if (skip.stats != nullptr) {  // one counter pair per evaluation: thousands of waves adding to ONE address serialise (measured: +0.5 ms)
-        const unsigned long long n_same = __popcll(__ballot(same)), n_bad = __popcll(__ballot(bad));
-        if ((threadIdx.x & 63) == 0) {
-            if (n_same) atomicAdd(&skip.stats[2 * k], n_same);
-            if (n_bad) atomicAdd(&skip.stats[2 * k + 1], n_bad);
+#pragma unroll
+    for (int u = 0; u < kJacColsPerThread; ++u) {
+        const int k = k0 + u;
+        if (k >= P) break;
+        // eval_skip = 2: the pair WAS computed and must agree
+        const bool bad = in && same[u] && skip.check && __double_as_longlong(ek[u]) != __double_as_longlong(e0);
+        if (in) E[(size_t)(k + 1) * ldE + r] = inv_h * ((same[u] && !skip.check ? e0 : ek[u]) - e0);
+        if (skip.stats != nullptr) {  // one counter pair per evaluation: thousands of waves adding to ONE address serialise (measured: +0.5 ms)
+            const unsigned long long n_same = __popcll(__ballot(same[u])), n_bad = __popcll(__ballot(bad));
+            if ((threadIdx.x & 63) == 0) {
+                if (n_same) atomicAdd(&skip.stats[2 * k], n_same);
+                if (n_bad) atomicAdd(&skip.stats[2 * k + 1], n_bad);
+            }
         }
     }
 }
@@ -3168,7 +3181,7 @@ void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, doub
     const int rs = ne_rows_per_split(rows, P);
     const int nsplit = (rows + rs - 1) / rs;
     if (P > 64) {  // NOTE: turns the residual batch E into the columns of [J | e0] in place
-        hipLaunchKernelGGL(k_jacobian_columns, dim3((rows + 255) / 256, P), dim3(256), 0, s, const_cast<double*>(E), ldE, rows, P, inv_h, skip ? *skip : EvalSkip{});
+        hipLaunchKernelGGL(k_jacobian_columns, dim3((rows + 255) / 256, (P + kJacColsPerThread - 1) / kJacColsPerThread), dim3(256), 0, s, const_cast<double*>(E), ldE, rows, P, inv_h, skip ? *skip : EvalSkip{});
         hipLaunchKernelGGL(k_normal_eq_mfma, dim3(nt * (nt + 1) / 2, nsplit), dim3(256), 0, s, E, ldE, rows, P, rs, nt, partial);
     } else
         hipLaunchKernelGGL(k_normal_eq_partial, dim3(nt * nt, nsplit, kNeQuarters), dim3(256), 0, s, E, ldE, rows, P, inv_h, rs, nt, partial);

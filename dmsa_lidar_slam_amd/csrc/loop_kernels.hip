@@ -1101,12 +1101,19 @@ __global__ __launch_bounds__(256) void k_loop_lm_stream_tail(const double* __res
         const double* gv = Hp + (size_t)P * n1;
         double sres = 0.0;
         int j = 0;
-        for (; j + 16 <= n; j += 16) {
-            double v[16];
+        for (; j + 32 <= n; j += 32) {   // thirty-two loads in flight; the sum itself is a chain in column order
+            double v[32];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = gw.inv_t[(size_t)(j + u) * RN + r];
+            for (int u = 0; u < 32; ++u) v[u] = gw.inv_t[(size_t)(j + u) * RN + r];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) sres += (-alpha * v[u]) * gv[j + u];
+            for (int u = 0; u < 32; ++u) sres += (-alpha * v[u]) * gv[j + u];
+        }
+        for (; j + 8 <= n; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = gw.inv_t[(size_t)(j + u) * RN + r];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sres += (-alpha * v[u]) * gv[j + u];
         }
         for (; j < n; ++j) sres += (-alpha * gw.inv_t[(size_t)j * RN + r]) * gv[j];
         s_step[gw.iperm[r]] = sres;
