@@ -75,3 +75,20 @@ def test_resident_ring_fed_from_strided_scans(hip):
     ro, rt = o2.poses()
     assert np.array_equal(flat.relOrientations, ro) and np.array_equal(flat.relTranslations, rt)
     o1.close(), o2.close()
+
+
+def test_a_window_large_enough_for_sliced_transfers(hip):
+    """Above 2^18 points the upload gathers and copies slice by slice and the write-back of the global points comes down in pieces
+    (csrc/aos_upload.cpp): same poses and the same global points as the flat call, every piece in its place."""
+    prob = synth.window_problem(seed=5, scans=3, rings=128, az_steps=1024, num_static=30_000)
+    assert prob.localPoints.shape[0] + prob.staticPoints.shape[0] > (1 << 18) + 4096
+    s = DmsaOptimSettings.sliding_window(num_iter=2)
+    flat, aos = prob.copy(), prob.copy()
+    o1, o2 = hip.DmsaOptimizer(), hip.DmsaOptimizer()
+    o1.optimizeSet(flat, s)
+    o2.optimizeSetAos(aos, s)
+    assert np.array_equal(flat.relOrientations, aos.relOrientations) and np.array_equal(flat.relTranslations, aos.relTranslations)
+    g1, g2 = o1.globalPoints(), o2.globalPointsAos()
+    assert np.array_equal(g1[:, 0], g2["x"]) and np.array_equal(g1[:, 1], g2["y"]) and np.array_equal(g1[:, 2], g2["z"])
+    assert np.all(g2["stamp"] == 7.0) and np.all(g2["id"] == 123)
+    o1.close(), o2.close()
