@@ -524,8 +524,9 @@ __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __res
     __shared__ float s_glob[kWaves][6];
     __shared__ LatticeRun st;
     __shared__ uint32_t s_shift[kMaxLatticeEvents][3];
-    __shared__ int s_red[kWaves];
+    __shared__ int s_red[2][kWaves];
     __shared__ float s_bb[kLatticeLdsBlocks][6];
+    int red_phase = 0;
     LatticeTable* tab = tables + blockIdx.x;
     const double res = blockIdx.x == 0 ? res0 : res1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -549,15 +550,16 @@ __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __res
             for (int a = 0; a < 6; ++a) s_glob[wave][a] = g6[a];
     }
     __syncthreads();
-    // minimum of an int over the workgroup (every thread gets it)
+    // minimum of an int over the workgroup (every thread gets it).  ONE barrier: the slots alternate, and the call after next, which
+    // writes this call's slots again, lies behind the next call's barrier.
     auto block_min = [&](int v) {
         v = wave_allmin(v);
-        if (lane == 0) s_red[wave] = v;
+        if (lane == 0) s_red[red_phase][wave] = v;
         __syncthreads();
-        int m = s_red[0];
+        int m = s_red[red_phase][0];
 #pragma unroll
-        for (int w = 1; w < kWaves; ++w) m = min(m, s_red[w]);
-        __syncthreads();
+        for (int w = 1; w < kWaves; ++w) m = min(m, s_red[red_phase][w]);
+        red_phase ^= 1;
         return m;
     };
     int cursor = 0;
