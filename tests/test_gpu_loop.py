@@ -270,3 +270,14 @@ def test_a_keyframe_set_whose_chain_state_outgrows_64_kb_of_lds(hip):
     dev = _run(hip, prob, s)
     assert dev[1].iterations == 2 and dev[1].num_gaussians > 1000
     _same(dev, _run(hip, prob, s, debug={"device_loop": 0}))
+
+
+def test_the_two_device_lm_solves_give_the_same_keyframe_pass(hip, orc):
+    """64 < P <= 192 (the keyframe pass): the stream of pivot-step records (k_loop_lm_stream, default) and the column-block panels
+    (lm_stream = 0) inside whole optimizeSet calls -- same poses, same line-search decisions, iteration by iteration."""
+    prob = synth.keyframe_problem(seed=4, frames=13, rings=16, az_steps=96, arc=0.8)  # P = 72
+    s = DmsaOptimSettings.keyframe_map(num_iter=5)
+    _same(_run(hip, prob, s, debug={"lm_stream": 1}), _run(hip, prob, s, debug={"lm_stream": 0}))
+    big = synth.keyframe_problem(seed=9, frames=32, rings=16, az_steps=128, arc=1.2)  # P = 186: three workgroups of A columns
+    s2 = DmsaOptimSettings.keyframe_map(num_iter=3)
+    _same(_run(hip, big, s2, debug={"lm_stream": 1}), _run(hip, big, s2, debug={"lm_stream": 0}))
