@@ -831,29 +831,71 @@ __device__ __forceinline__ void stream_swap_rows(int (&logical)[R], unsigned& pi
     }
 }
 // Pivot step k = local column J of the worker that owns it: search, record, then the step itself on the columns right of J.
+#ifdef DMSA_STREAM_TIMING
+__device__ long long g_stream_phase[4];   // clock64 ticks of all factor steps: search, record, bookkeeping, apply
+#endif
+// The pivot search on integer keys.  |x| of a double orders like its bit pattern, so the maximum over the wave is two 32-bit max-scans
+// (high words, then the low words of the lanes that hold the largest high word), each stage ONE instruction: v_max_u32 with the DPP
+// shift as a modifier of its operand.  (wave_best does the same on doubles: two DPP moves, a 64-bit compare and two selects per stage,
+// every one waiting for the one before -- measured as 45 % of a pivot step of the stream solve.)  key = bits(|x|) + 1 for a candidate,
+// 0 for a lane without one.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, kRowMask, 0xf, true);   // lanes the shift does not reach: 0
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = dpp_max_u32<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_max_u32<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_max_u32<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_max_u32<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_max_u32<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+    v = dpp_max_u32<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Every lane brings (key, logical row); returns the lane of the winner -- largest key, among equals the smallest logical row -- or -1
+// when no lane has a candidate.
+__device__ __forceinline__ int wave_best_key(unsigned long long key, int l) {
+    const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+    const unsigned mhi = wave_max_u32(hi);
+    const unsigned mlo = wave_max_u32(hi == mhi ? lo : 0u);
+    if ((mhi | mlo) == 0u) return -1;
+    unsigned long long hit = __ballot(hi == mhi && lo == mlo);
+    int best_lane = __builtin_ctzll(hit);
+    hit &= hit - 1ull;
+    if (hit != 0ull) {  // equal |x| in several rows (rare): the smallest logical row wins
+        int best = __builtin_amdgcn_readlane(l, best_lane);
+        while (hit != 0ull) {
+            const int ln = __builtin_ctzll(hit), other = __builtin_amdgcn_readlane(l, ln);
+            if (other < best) best = other, best_lane = ln;
+            hit &= hit - 1ull;
+        }
+    }
+    return best_lane;
+}
 template <int R, int J>
 __device__ __forceinline__ void stream_factor_step(double (&x)[R][kStreamW], int (&logical)[R], unsigned& pivoted, int k, int n, int lane, StreamLds<R>& sm, double* scr) {
     int spins = 0;
+#ifdef DMSA_STREAM_TIMING
+    const long long tp0 = clock64();
+#endif
     if (J % kStreamBatch == 0)   // room for the next kStreamBatch records: every consumer is done with the ones they overwrite
         while (stream_min_consumed(sm.consumed, lane) < min(k + kStreamBatch, n) - kStreamD) stream_spin(spins);
     // pivot: largest |x| among the rows not yet pivoted, ties to the smallest logical row (= the serial search from row k down)
-    double vm = -1.0;
+    unsigned long long km = 0ull;
     int lm = kStreamNever, sl = 0;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const double a = fabs(x[i][J]);
         const bool cand = ((pivoted >> i) & 1u) == 0u && !isnan(a);
-        if (cand && (a > vm || (a == vm && logical[i] < lm))) vm = a, lm = logical[i], sl = i;
+        const unsigned long long key = cand ? (unsigned long long)__double_as_longlong(a) + 1ull : 0ull;
+        if (key > km || (key == km && key != 0ull && logical[i] < lm)) km = key, lm = logical[i], sl = i;
     }
-    double bv = vm;
-    int bl = lm;
-    wave_best(bv, bl);
-    int pl = 0, ps = 0;
-    if (bv >= 0.0) {
-        const unsigned long long hit = __ballot(vm == bv && lm == bl);
-        pl = __builtin_ctzll(hit);
+    int pl = wave_best_key(km, lm), ps = 0;
+    if (pl >= 0) {
         ps = __builtin_amdgcn_readlane(sl, pl);
     } else {
+        pl = 0;
         // nothing comparable (NaNs): keep the diagonal like the serial search
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -861,6 +903,9 @@ __device__ __forceinline__ void stream_factor_step(double (&x)[R][kStreamW], int
             if (hit != 0ull) pl = __builtin_ctzll(hit), ps = i;
         }
     }
+#ifdef DMSA_STREAM_TIMING
+    const long long tp1 = clock64();
+#endif
     // the record: the column as it stands; the pivot row's entry is the pivot
     double f[R];
 #pragma unroll
@@ -879,9 +924,22 @@ __device__ __forceinline__ void stream_factor_step(double (&x)[R][kStreamW], int
     if (lane == 0) sm.ring_pp[slot] = pl + 64 * ps;
     __builtin_amdgcn_wave_barrier();
     lds_store_after_writes(&sm.produced, k + 1);
+#ifdef DMSA_STREAM_TIMING
+    const long long tp2 = clock64();
+#endif
     stream_swap_rows<R>(logical, pivoted, k, pl, sel, lane);
+#ifdef DMSA_STREAM_TIMING
+    const long long tp3 = clock64();
+#endif
     // columns <= J of this worker are dead after the step (unit vectors nobody reads again)
     stream_apply<R, (J + 1 < kStreamW ? J + 1 : kStreamW)>(x, f, d, pl, sel, lane, scr);
+#ifdef DMSA_STREAM_TIMING
+    if (lane == 0) {
+        const long long tp4 = clock64();
+        atomicAdd((unsigned long long*)&g_stream_phase[0], (unsigned long long)(tp1 - tp0)), atomicAdd((unsigned long long*)&g_stream_phase[1], (unsigned long long)(tp2 - tp1));
+        atomicAdd((unsigned long long*)&g_stream_phase[2], (unsigned long long)(tp3 - tp2)), atomicAdd((unsigned long long*)&g_stream_phase[3], (unsigned long long)(tp4 - tp3));
+    }
+#endif
 }
 template <int R>
 __global__ __launch_bounds__((kStreamWorkers + 1) * kWave) void k_loop_lm_stream(const double* __restrict__ Hp, int P, double lambda, double* __restrict__ work,
@@ -1084,6 +1142,9 @@ __global__ __launch_bounds__((kStreamWorkers + 1) * kWave) void k_loop_lm_stream
 #endif
 #undef DMSA_STREAM_STEP
 #ifdef DMSA_STREAM_TIMING
+    if (lane == 0 && c0 + kStreamW >= n)
+        printf("[stream timing] factor steps so far (clock64 ticks, all workers): search %lld  record %lld  bookkeeping %lld  apply %lld\n", g_stream_phase[0], g_stream_phase[1],
+               g_stream_phase[2], g_stream_phase[3]);
     if (lane == 0)
         printf("[stream timing] A worker %d (block %d): start %lld, %d records applied in %lld (waiting %lld, spins %d), own columns factored in %lld (x10 ns)\n", wi, b,
                t_begin, k_end, t_consumed - t_begin, t_wait, spins, wall_clock64() - t_consumed);
