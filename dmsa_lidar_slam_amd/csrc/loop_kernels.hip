@@ -995,7 +995,7 @@ __global__ __launch_bounds__((kStreamWorkers + 1) * kWave) void k_loop_lm_stream
 #ifdef DMSA_STREAM_TIMING
             t_poll += wall_clock64() - tp;
 #endif
-            __threadfence();   // acquire: the records below were stored before `published` moved
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the records below were stored before `published` moved (no write-back needed here)
             while (fetched < avail) {
                 const int m = min(kStreamBatch, avail - fetched);
                 double v[kStreamBatch][R];
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__((kStreamWorkers + 1) * kWave) void k_loop_lm_stream
                 for (int i = 0; i < R; ++i) gw.mult[(size_t)k * RN + lane + 64 * i] = sm.ring_f[slot][lane + 64 * i];
                 if (lane == 0) gw.gpp[k] = sm.ring_pp[slot];
             }
-            __threadfence();   // release, once: the records are written back before `published` moves (it also waits for the ring reads)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // once: the records are written back before `published` moves (it also waits for the ring reads; nothing to invalidate)
             if (lane == 0) {
                 __hip_atomic_store(gw.published, ((unsigned long long)epoch << 32) | (unsigned long long)have, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&sm.consumed[kStreamWorkers], have, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1050,8 +1050,8 @@ __global__ __launch_bounds__((kStreamWorkers + 1) * kWave) void k_loop_lm_stream
         }
 #ifdef DMSA_STREAM_TIMING
         if (lane == 0)
-            printf("[stream timing] helper of block %d: %d records fetched in %d rounds, %lld (polling %lld); %d published in %d rounds, %lld (x10 ns)\n", b, s0, rounds_f,
-                   th1 - th0, t_poll, s1 - s0, rounds_p, wall_clock64() - th1);
+            printf("[stream timing] helper of block %d: start %lld, %d records fetched in %d rounds, %lld (polling %lld); %d published in %d rounds, %lld, end %lld (x10 ns)\n", b,
+                   th0, s0, rounds_f, th1 - th0, t_poll, s1 - s0, rounds_p, wall_clock64() - th1, wall_clock64());
 #endif
         return;
     }
@@ -1068,14 +1068,15 @@ __global__ __launch_bounds__((kStreamWorkers + 1) * kWave) void k_loop_lm_stream
 #pragma unroll
         for (int c = 0; c < W; ++c) {
             const int col = c0 + c;
+            const bool in = r < n && col < n;
             double v = 0.0;
-            if (r < n && col < n) {
-                if (a_part) {
-                    v = Hp[(size_t)col * n1 + r];   // H(r, col), damped on the diagonal (:110)
-                    if (col == r) v += lambda;
-                } else {
-                    v = col == r ? 1.0 : 0.0;
-                }
+            if (a_part) {
+                // (loads without a branch around them -- the index is clamped, the value masked: behind branches the 24 loads of a lane
+                // went out one after the other, 9 us before the first pivot step)
+                const double h = Hp[(size_t)min(col, n - 1) * n1 + min(r, n - 1)];   // H(r, col), damped on the diagonal (:110)
+                v = in ? (col == r ? h + lambda : h) : 0.0;
+            } else {
+                v = in && col == r ? 1.0 : 0.0;
             }
             x[i][c] = v;
         }
@@ -1115,7 +1116,8 @@ __global__ __launch_bounds__((kStreamWorkers + 1) * kWave) void k_loop_lm_stream
 #ifdef DMSA_STREAM_TIMING
     const long long t_consumed = wall_clock64();
     if (lane == 0 && !a_part && (wi == 0 || wi == 11))
-        printf("[stream timing] I worker %d: %d records in %lld (x10 ns), of which waiting %lld, spins %d\n", wi, k_end, t_consumed - t_begin, t_wait, spins);
+        printf("[stream timing] I worker %d: start %lld end %lld, %d records in %lld (x10 ns), of which waiting %lld, spins %d\n", wi, t_begin, t_consumed, k_end,
+               t_consumed - t_begin, t_wait, spins);
 #endif
     if (!a_part) {
         // ---- columns of the inverse, transposed; the row permutation once ----
