@@ -1060,6 +1060,18 @@ __global__ __launch_bounds__((kStreamWorkers + 1) * kWave) void k_loop_lm_stream
     double x[R][W];
     int logical[R];
     unsigned pivoted = 0;
+    // All loads of the worker's columns first, then the arithmetic on them: with the masking in between, the compiler waited for every
+    // column before it asked for the next one -- eight memory latencies in a row, 8 us before the first pivot step.  (The index is
+    // clamped instead of the load being skipped, so there is no branch around a load either.)
+    if (a_part) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int r = min(lane + 64 * i, n - 1);
+#pragma unroll
+            for (int c = 0; c < W; ++c) x[i][c] = Hp[(size_t)min(c0 + c, n - 1) * n1 + r];   // H(r, col)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const int r = lane + 64 * i;
@@ -1069,16 +1081,10 @@ __global__ __launch_bounds__((kStreamWorkers + 1) * kWave) void k_loop_lm_stream
         for (int c = 0; c < W; ++c) {
             const int col = c0 + c;
             const bool in = r < n && col < n;
-            double v = 0.0;
-            if (a_part) {
-                // (loads without a branch around them -- the index is clamped, the value masked: behind branches the 24 loads of a lane
-                // went out one after the other, 9 us before the first pivot step)
-                const double h = Hp[(size_t)min(col, n - 1) * n1 + min(r, n - 1)];   // H(r, col), damped on the diagonal (:110)
-                v = in ? (col == r ? h + lambda : h) : 0.0;
-            } else {
-                v = in && col == r ? 1.0 : 0.0;
-            }
-            x[i][c] = v;
+            if (a_part)
+                x[i][c] = in ? (col == r ? x[i][c] + lambda : x[i][c]) : 0.0;   // damped on the diagonal (:110)
+            else
+                x[i][c] = in && col == r ? 1.0 : 0.0;
         }
     }
     double* scr = sm.scr[wave];
