@@ -1247,10 +1247,15 @@ __device__ __forceinline__ void leaf_split_groups(int group, int ngroups, int ti
         // k_split_pairs already found, for every member a, its first best partner c; reduce over a (ties -> smallest a).
         float best = FLT_MAX;
         long long best_pair = LLONG_MAX;
-        for (int j = b + tid; j < e; j += kThreads) {
-            const unsigned long long v = pair_best[j];  // ~0 = no partner at all
-            const float d = v == ~0ull ? FLT_MAX : __uint_as_float((uint32_t)(v >> 32));
-            if (d < best) best = d, best_pair = (long long)(j - b) * cnt + (long long)(uint32_t)v;  // j ascends per thread
+        for (int j0 = b + tid; j0 < e; j0 += 8 * kThreads) {  // eight loads in flight per thread (one at a time: 17 memory latencies for the largest leaves)
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = j0 + u * kThreads < e ? pair_best[j0 + u * kThreads] : ~0ull;  // ~0 = no partner at all
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float d = v[u] == ~0ull ? FLT_MAX : __uint_as_float((uint32_t)(v[u] >> 32));
+                if (d < best) best = d, best_pair = (long long)(j0 + u * kThreads - b) * cnt + (long long)(uint32_t)v[u];  // positions ascend per thread
+            }
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
@@ -1275,7 +1280,16 @@ __device__ __forceinline__ void leaf_split_groups(int group, int ngroups, int ti
         int mn1 = INT_MAX, mx1 = INT_MIN;
         int rank_base1 = 0, rank_base2 = 0;
         const unsigned long long below = (1ull << lane) - 1ull;
-        auto classify = [&](int j, bool in, bool& first, int& id) {   // Gaussians.h:58-75: nearer to the first normal of the pair?
+        auto classify_v = [&](const float4 v, bool in, bool& first, int& id) {   // Gaussians.h:58-75: nearer to the first normal of the pair?
+            first = false, id = 0;
+            if (in) {
+                const float d1 = sqrtf(sum3f((r1.x - v.x) * (r1.x - v.x), (r1.y - v.y) * (r1.y - v.y), (r1.z - v.z) * (r1.z - v.z)));
+                const float d2 = sqrtf(sum3f((r2.x - v.x) * (r2.x - v.x), (r2.y - v.y) * (r2.y - v.y), (r2.z - v.z) * (r2.z - v.z)));
+                first = d1 < d2;
+                id = __float_as_int(v.w);
+            }
+        };
+        auto classify = [&](int j, bool in, bool& first, int& id) {
             first = false, id = 0;
             if (in) {
                 const float4 v = nsorted[j];
@@ -1293,22 +1307,28 @@ __device__ __forceinline__ void leaf_split_groups(int group, int ngroups, int ti
             const int run = ((cnt + kWaves - 1) / kWaves + 63) & ~63;
             const int wb = min(e, b + wave * run), we = min(e, wb + run);
             int c1 = 0, c2 = 0;
-            for (int j0 = wb; j0 < we; j0 += 64) {
-                const int j = j0 + lane;
-                const bool in = j < we;
-                bool first;
-                int id;
-                classify(j, in, first, id);
-                const unsigned long long m1 = __ballot(in && first), m2 = __ballot(in && !first);
-                if (in) {
-                    if (first) {
-                        pos_slot_rank[j] = c1 + __popcll(m1 & below);
-                        mn1 = min(mn1, id), mx1 = max(mx1, id);
-                    } else {
-                        pos_slot_rank[j] = (int32_t)(0x80000000u | (uint32_t)(c2 + __popcll(m2 & below)));
+            for (int jb = wb; jb < we; jb += 4 * 64) {  // four rows of 64 positions: their loads together, their ranks in order
+                float4 vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) vv[u] = jb + 64 * u + lane < we ? nsorted[jb + 64 * u + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = jb + 64 * u + lane;
+                    const bool in = j < we;
+                    bool first;
+                    int id;
+                    classify_v(vv[u], in, first, id);
+                    const unsigned long long m1 = __ballot(in && first), m2 = __ballot(in && !first);
+                    if (in) {
+                        if (first) {
+                            pos_slot_rank[j] = c1 + __popcll(m1 & below);
+                            mn1 = min(mn1, id), mx1 = max(mx1, id);
+                        } else {
+                            pos_slot_rank[j] = (int32_t)(0x80000000u | (uint32_t)(c2 + __popcll(m2 & below)));
+                        }
                     }
+                    c1 += __popcll(m1), c2 += __popcll(m2);
                 }
-                c1 += __popcll(m1), c2 += __popcll(m2);
             }
             __syncthreads();  // the previous leaf's readers of s_c1 / s_c2 are done
             if (lane == 0) s_c1[wave] = c1, s_c2[wave] = c2;
@@ -1319,9 +1339,13 @@ __device__ __forceinline__ void leaf_split_groups(int group, int ngroups, int ti
                 rank_base1 += s_c1[w], rank_base2 += s_c2[w];
             }
             if ((base1 | base2) != 0)
-                for (int j = wb + lane; j < we; j += 64) {  // the lane that wrote the rank reads it back
-                    const int r = pos_slot_rank[j];
-                    pos_slot_rank[j] = r < 0 ? r + base2 : r + base1;
+                for (int jb = wb + lane; jb < we; jb += 8 * 64) {  // the lane that wrote the rank reads it back; eight loads in flight
+                    int rr[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) rr[u] = jb + 64 * u < we ? pos_slot_rank[jb + 64 * u] : 0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (jb + 64 * u < we) pos_slot_rank[jb + 64 * u] = rr[u] < 0 ? rr[u] + base2 : rr[u] + base1;
                 }
         } else {
             for (int j0 = b; j0 < e; j0 += kThreads) {
