@@ -713,8 +713,14 @@ __global__ __launch_bounds__(1024) void k_loop_lm_panels(const double* __restric
 #endif
 constexpr int kStreamW = DMSA_STREAM_W;              // columns per worker wave (8 or 16)
 constexpr int kStreamWorkers = DMSA_STREAM_WORKERS;  // worker waves per workgroup (+ one helper wave); <= 15
-constexpr int kStreamD = 24;        // ring slots (pivot steps a consumer may lag behind its producer)
-constexpr int kStreamBatch = 8;     // records a helper moves per round; the producer checks the ring for room every kStreamBatch steps
+#ifndef DMSA_STREAM_D
+#define DMSA_STREAM_D 24
+#endif
+#ifndef DMSA_STREAM_BATCH
+#define DMSA_STREAM_BATCH 8
+#endif
+constexpr int kStreamD = DMSA_STREAM_D;          // ring slots (pivot steps a consumer may lag behind its producer)
+constexpr int kStreamBatch = DMSA_STREAM_BATCH;  // records a helper moves per round; the producer checks the ring for room every kStreamBatch steps
 constexpr int kStreamNever = 0x7fffffff;
 template <int R>
 struct StreamLds {
