@@ -46,3 +46,18 @@ for rep in range(3):
     opt.optimizeResident(s)
     t1 = time.perf_counter()
     print(f"20 again: {1e3 * (t1 - t0) / 20:.4f} ms per iteration")
+# what a call that follows a SHORTER call pays: retries?
+for rep in range(4):
+    s.num_iter = 5
+    opt.optimizeResident(s)
+    c0 = opt.debugCounters()
+    s.num_iter = 20
+    opt.synchronize()
+    t0 = time.perf_counter()
+    r = opt.optimizeResident(s)
+    opt.synchronize()
+    t1 = time.perf_counter()
+    c1 = opt.debugCounters()
+    tm = opt.timing()
+    print(f"5 then 20: {1e3 * (t1 - t0):.3f} ms, speculation retries {c1['speculation_retries'] - c0['speculation_retries']}, sync retries {c1['sync_retries'] - c0['sync_retries']}, "
+          f"iterations {r.iterations}")
