@@ -79,8 +79,7 @@ def parse():
     ap.add_argument("--neighbourhoods", type=int, default=8, help="neighbourhoods the map is cut into, whatever --gpus is")
     ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations timed for cpu_baseline (0 disables)")
     ap.add_argument("--keyframe-steps", type=int, default=10, help="iterations of the secondary sharded-keyframe-pass measurement (0 disables)")
-    ap.add_argument("--fast-sums", action="store_true", help="time the opt-in wave-parallel sums (DMSA_FLAG_FAST_SUMS) instead of the default path")
-    ap.add_argument("--mirror", action="store_true", help="accepted and ignored: the reference-order sums are the default path")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region: no stage breakdown, PCIe-inclusive calls, small windows, keyframe pass, CPU baseline (profiling runs)")
     ap.add_argument("--host-tables", action="store_true", help="build the pose tables on host threads (same bits as the device kernel)")
     return ap.parse_args()
 
@@ -155,13 +154,13 @@ def main():
         wl = f"keyframes{total_frames}/{len(ranges)}x~{prob.localPoints.shape[0] // prob.numFrames}" if strong else f"keyframes{args.frames}x~{prob.localPoints.shape[0] // args.frames}"
         n_points = sum(sb.localPoints.shape[0] for sb in subs.values())
 
-    opt = DmsaOptimizer(device=local_rank, fixed_iters=True, fast_sums=args.fast_sums, pose_table_host=args.host_tables)
+    opt = DmsaOptimizer(device=local_rank, fixed_iters=True, pose_table_host=args.host_tables)
     opt.upload(prob)  # inputs resident in HBM before the timed region
     opts = {}
     if args.workload == "keyframes":  # one context per owned neighbourhood: all of them resident before the timed region
         opts = {owned[0]: opt}
         for nb in owned[1:]:
-            opts[nb] = DmsaOptimizer(device=local_rank, fixed_iters=True, fast_sums=args.fast_sums, pose_table_host=args.host_tables)
+            opts[nb] = DmsaOptimizer(device=local_rank, fixed_iters=True, pose_table_host=args.host_tables)
             opts[nb].upload(subs[nb])
 
     def sync_all():
@@ -212,8 +211,8 @@ def main():
         per_rank = rank_telemetry(rank, world, dist, coll_dev, t_own, owned, subs, reps)
     # stage breakdown: a second, untimed pass with the per-stage HIP-event timers switched on (they cost GPU idle time)
     stage = None
-    if rank == 0:
-        opt2 = DmsaOptimizer(device=local_rank, fixed_iters=True, fast_sums=args.fast_sums, pose_table_host=args.host_tables, stage_timers=True)
+    if rank == 0 and not args.no_extras:
+        opt2 = DmsaOptimizer(device=local_rank, fixed_iters=True, pose_table_host=args.host_tables, stage_timers=True)
         opt2.upload(prob)
         s2 = type(settings)(**{**settings.__dict__, "num_iter": 4})
         opt2.optimizeResident(s2)
@@ -225,34 +224,11 @@ def main():
                  "gaussian_fit_and_tiles": round(t2.gaussian_fit_ms / k, 4), "pose_tables": round(t2.pose_table_ms / k, 4),
                  "normal_eq": round(t2.normal_eq_ms / k, 4)}
         opt2.close()
-    # the opt-in wave-parallel sums (DMSA_FLAG_FAST_SUMS) on the same resident workload, outside the timed region: faster, but its
-    # poses leave the 1e-4 m / 1e-4 rad tolerance after a few iterations (measured here against the default path)
-    fast = None
-    if rank == 0 and not args.fast_sums and args.workload == "window":
-        opt3 = DmsaOptimizer(device=local_rank, fixed_iters=True, fast_sums=True)
-        opt3.upload(prob)
-        s3 = type(settings)(**{**settings.__dict__, "num_iter": 2})
-        opt3.optimizeResident(s3)
-        s3.num_iter = max(4, min(args.steps, 20))
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        r3 = opt3.optimizeResident(s3)
-        dt3 = time.perf_counter() - t3
-        # pose deviation of the two paths after 3 iterations from the same start
-        pa, pb = prob.copy(), prob.copy()
-        s4 = type(settings)(**{**settings.__dict__, "num_iter": 3})
-        oa, ob = DmsaOptimizer(device=local_rank, fixed_iters=True), DmsaOptimizer(device=local_rank, fixed_iters=True, fast_sums=True)
-        oa.optimizeSet(pa, s4), ob.optimizeSet(pb, s4)
-        fast = {"value": round(r3.iterations / dt3, 3), "unit": "iterations/s", "ms_per_step": round(1e3 * dt3 / r3.iterations, 4),
-                "max_abs_pose_parameter_difference_vs_default_after_3_iterations": float(np.abs(pa.getPoseParameters() - pb.getPoseParameters()).max()),
-                "note": "DMSA_FLAG_FAST_SUMS (wave-parallel sums, LU solve): not the drop-in path -- its summation order differs from the "
-                        "reference's and the numeric Jacobian amplifies that beyond the 1e-4 tolerance"}
-        opt3.close(), oa.close(), ob.close()
     # What a drop-in call costs with the PCIe traffic inside (never `value`): (a) dmsa_optimize_window with host arrays, the whole window
     # uploaded per call; (b) the window resident in a ring (include/dmsa_window_ring.h): one new scan + the static points per call, as
     # DmsaSlam::processPointCloud feeds its ring buffer (DmsaSlam.h:116-204).  Ten iterations per call (num_iter_sliding_window_optim).
     pcie = None
-    if rank == 0 and args.workload == "window" and not args.fast_sums and hasattr(prob, "scanOffsets"):
+    if rank == 0 and args.workload == "window" and not args.no_extras and hasattr(prob, "scanOffsets"):
         s10 = type(settings)(**{**settings.__dict__, "num_iter": 10})
         o_full = DmsaOptimizer(device=local_rank, fixed_iters=True)
         o_full.optimizeSet(prob.copy(), s10)  # first call: allocations
@@ -310,7 +286,7 @@ def main():
     # BASELINE.json also asks for the sharded keyframe pass at 2/4/8 GPUs: measured here as a second, separately timed
     # region (same barrier / max-over-ranks protocol) and reported beside the headline metric, never mixed into `value`.
     keyframe_pass = None
-    if args.workload == "window" and args.keyframe_steps > 0:
+    if args.workload == "window" and args.keyframe_steps > 0 and not args.no_extras:
         keyframe_pass = sharded_keyframe_pass(args, rank, local_rank, world, dist, coll_dev, sync_all)
 
     if rank == 0:
@@ -332,7 +308,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     tj = json.load(f)
-                if tj.get("workload") == wl and tj.get("path") == ("fast_sums" if args.fast_sums else "default"):
+                if tj.get("workload") == wl and tj.get("path") == "default":
                     traffic, traffic_source = tj.get("hbm_bytes_per_launch"), f"from_profiles: profiles/{name}"
                     break
             except Exception:
@@ -362,17 +338,15 @@ def main():
                 "evaluations_per_iteration": int(prob.numParams) + 10,
                 "gaussians": int(rep.num_gaussians),
                 "memberships": int(rep.num_memberships),
-                "path": "opt-in fast sums (DMSA_FLAG_FAST_SUMS)" if args.fast_sums
-                        else "default: reference-order sums, device pose tables (poses bit-identical to the CPU restatement)",
+                "path": "reference-order sums, device pose tables (poses bit-identical to the CPU restatement); the library has one path",
                 "rank_device": placement,
                 "collective": {"backend": "rccl" if backend == "nccl" else backend, "world_size": coll_world},
                 "sharding": (("single GPU" if world == 1 else "independent windows per rank + pose all-gather") if args.workload == "window"
                              else f"{len(ranges)} keyframe neighbourhoods of one {total_frames}-frame map, rank r runs r, r + {world}, ... + one pose all-gather"),
             },
             "roofline": {
-                "kernel": ("correspondence kernels k_residuals_tiles + k_residuals_big" if args.fast_sums else
-                           "reference-order correspondence kernels (k_residuals_chain<8,true,128> + k_residuals_chain<4,false,32> + k_residuals_small, "
-                           "three streams, fork / join by device counters, one HIP-event pair around the batch)") + ", B evaluations per launch",
+                "kernel": "reference-order correspondence kernels (k_residuals_chain<8,true,128> + k_residuals_chain<4,false,32> + k_residuals_small, "
+                          "three streams, fork / join by device counters, one HIP-event pair around the batch), B evaluations per launch",
                 "bound": "hbm",
                 # SURVEY 8(d) bytes(B) / t: what a launch of B evaluations MUST move when it reads the members once, over the launch time --
                 # the HBM roofline figure proper (the kernels are nowhere near it and cannot be: bound_stated)
@@ -400,16 +374,17 @@ def main():
                                 "6.2), dependent-add latency of the longest Gaussian for the line-search batch.  A launch evaluates B pose tables on "
                                 "members it reads once per pass, so `frac` is an effective rate; the HBM fractions are frac_compulsory and "
                                 "frac_counters",
-                "valu": {"achieved_tflops": round(valu_tflops, 2), "peak_tflops_no_fma": 78.6,
-                         "frac": round(valu_tflops / 78.6, 4)},
+                # the peak that applies: one wave64 fp32 instruction per SIMD every 4 cycles, no FMA (the reference rounds every product and
+                # sum on its own) and no packed issue (a wave64 v_pk_* occupies the SIMD for two passes): 1024 SIMDs x 64 lanes / 4 cycles x 2.4 GHz
+                "valu": {"achieved_tflops": round(valu_tflops, 2), "peak_tflops_scalar_no_fma": 39.3,
+                         "frac": round(valu_tflops / 39.3, 4)},
             },
             "per_rank": per_rank,
             "stage_ms_per_step": stage,
-            "fast_sums_path": fast,
             "keyframe_pass": keyframe_pass,
             "pcie_inclusive": pcie,
         }
-        if world == 1 and args.cpu_iters > 0:
+        if world == 1 and args.cpu_iters > 0 and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(prob, settings, args.cpu_iters, args.workload)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -424,9 +399,16 @@ def bench_keyframe_map(total_frames, rank, world, dist):
 
     from dmsa_lidar_slam_amd import dump, synth
 
-    path = os.path.join(tempfile.gettempdir(), f"dmsa_bench_keyframe_map_{total_frames}.bin")
+    # the cache is keyed by what generates the map -- frame count, seed, arc and the source of the generator itself -- so a change of
+    # synth.keyframe_problem or a stale / foreign file cannot feed different data into the reported numbers
+    import hashlib
+    import inspect
+
+    seed, arc = 1, 2 * np.pi * total_frames / 256.0
+    key = hashlib.sha1((inspect.getsource(synth) + inspect.getsource(dump) + f"|{total_frames}|{seed}|{arc!r}").encode()).hexdigest()[:12]
+    path = os.path.join(tempfile.gettempdir(), f"dmsa_bench_keyframe_map_{total_frames}_{key}.bin")
     if rank == 0 and not os.path.exists(path):
-        m = synth.keyframe_problem(seed=1, frames=total_frames, arc=2 * np.pi * total_frames / 256.0)
+        m = synth.keyframe_problem(seed=seed, frames=total_frames, arc=arc)
         dump.write_keyframe_map(path + f".{os.getpid()}", m)
         os.replace(path + f".{os.getpid()}", path)
     if world > 1:

@@ -30,7 +30,6 @@ STOP_NUM_ITER, STOP_FEW_GAUSSIANS, STOP_NAN, STOP_NO_IMPROVEMENT, STOP_EPSILON =
 FLAG_POSE_TABLE_HOST = 0x1
 FLAG_FIXED_ITERS = 0x2
 FLAG_MIRROR_SUMS = 0x4  # accepted and ignored: the reference order is the default
-FLAG_FAST_SUMS = 0x10
 FLAG_STAGE_TIMERS = 0x8
 
 
@@ -153,7 +152,7 @@ class StaticSelectResult(C.Structure):
 class DebugOptions(C.Structure):
     """include/dmsa_debug.h: dmsa_debug_options (fill with dmsa_default_debug_options first)."""
     _fields_ = [(n, C.c_int32) for n in ("device_loop", "dual_stream", "serial_streams", "merge_sort", "key_compress", "fused_segments", "sort_prehist",
-                                           "library_sort", "overlap_batch", "serial_tree", "host_threads", "solve_threads", "host_timeline", "trace_time", "fused_leaf_scan", "device_sync", "shared_rotations", "eval_skip", "sync_fault", "speculation_fault", "voxel_coherence", "lm_stream", "stream_priority")]
+                                           "library_sort", "overlap_batch", "serial_tree", "host_threads", "solve_threads", "host_timeline", "trace_time", "fused_leaf_scan", "device_sync", "shared_rotations", "eval_skip", "sync_fault", "speculation_fault", "voxel_coherence", "lm_stream", "stream_priority", "fit_classes", "eigen_l1_bytes")]
 
 
 class DebugCounters(C.Structure):

@@ -23,18 +23,13 @@ class DmsaError(RuntimeError):
 class DmsaOptimizer:
     """One context == one GPU == one host thread (the reference's optimizer is not re-entrant either)."""
 
-    def __init__(self, device: int = 0, pose_table_host: bool = False, fixed_iters: bool = False, mirror_sums: bool | None = None,
-                 stage_timers: bool = False, fast_sums: bool = False, debug: dict | None = None):
-        """Default = the reference's summation order (bit-identical to the CPU restatement) with pose tables built on the device.
-        fast_sums=True selects the wave-parallel sums (DMSA_FLAG_FAST_SUMS: faster, but outside the 1e-4 pose tolerance after a few
-        iterations); mirror_sums is the round-1 spelling (mirror_sums=False == fast_sums=True).  `debug`: switches of
-        include/dmsa_debug.h by name, e.g. {"device_loop": 0} -- alternative implementations with the same results (tests, A/B timing)."""
+    def __init__(self, device: int = 0, pose_table_host: bool = False, fixed_iters: bool = False, stage_timers: bool = False, debug: dict | None = None):
+        """The reference's summation order (bit-identical to the CPU restatement) with pose tables built on the device -- the library has one
+        path.  `debug`: switches of include/dmsa_debug.h by name, e.g. {"device_loop": 0} -- alternative implementations with the same
+        results (tests, A/B timing)."""
         self._lib = capi.load_library()
         self._ctx = C.c_void_p()
-        if mirror_sums is not None:
-            fast_sums = not mirror_sums
         flags = (capi.FLAG_POSE_TABLE_HOST if pose_table_host else 0) | (capi.FLAG_FIXED_ITERS if fixed_iters else 0)
-        flags |= capi.FLAG_FAST_SUMS if fast_sums else 0
         flags |= capi.FLAG_STAGE_TIMERS if stage_timers else 0
         if debug:
             opts = capi.DebugOptions()

@@ -57,6 +57,55 @@ PoseChain& chain(dmsa_ctx* ctx) { return ctx->model == MODEL_WINDOW ? ctx->win.c
 int num_extra_rows(const dmsa_ctx* ctx) { return ctx->model == MODEL_WINDOW ? ctx->win.num_extra_rows() : ctx->key.num_extra_rows(); }
 
 
+// numPointsPerSet.cast<float>().array().pow(-1) (Gaussians.h:172) is libm's powf(n, -1.0f) per coefficient (Eigen 3.4.0's scalar_pow_op
+// has no packet path), and powf is not correctly rounded: for some n it is one ulp away from 1.0f / n.  The device divides and applies
+// what THIS machine's libm says differs, two bits per member count n: 0 same bits, 1 one ulp above, 2 one ulp below, 3 further away
+// (never seen; such a count takes the division and the context reports it).  The table is computed once per process and extended on
+// demand; a context uploads the range its point count allows.
+namespace {
+std::mutex g_pow_mutex;
+std::vector<uint32_t> g_pow_codes;  // 16 counts per word
+int64_t g_pow_n = 0;                // counts covered
+int64_t g_pow_far = 0;              // counts whose powf is more than one ulp from the division
+}  // namespace
+int upload_powm1_codes(dmsa_ctx* ctx, int64_t counts) {
+    counts = (counts + 15) / 16 * 16;
+    if (counts <= ctx->pow_n) return DMSA_OK;
+    std::vector<uint32_t> words;
+    {
+        std::lock_guard<std::mutex> lock(g_pow_mutex);
+        if (counts > g_pow_n) {
+            const int64_t from = g_pow_n;
+            g_pow_codes.resize((size_t)(counts / 16), 0u);
+            std::atomic<int64_t> far{0};
+            workers(ctx).run_all([&](int t, int nt) {
+                const int64_t w0 = from / 16 + (counts / 16 - from / 16) * t / nt, w1 = from / 16 + (counts / 16 - from / 16) * (t + 1) / nt;
+                volatile float minus_one = -1.0f;  // (volatile: no folding of the call into a division)
+                for (int64_t w = w0; w < w1; ++w) {
+                    uint32_t word = 0;
+                    for (int k = 0; k < 16; ++k) {
+                        const int64_t nn = 16 * w + k;
+                        if (nn == 0) continue;
+                        const float x = (float)nn, a = powf(x, minus_one), d = 1.0f / x;
+                        int32_t ia, id;
+                        std::memcpy(&ia, &a, 4), std::memcpy(&id, &d, 4);
+                        const uint32_t code = ia == id ? 0u : (ia == id + 1 ? 1u : (ia == id - 1 ? 2u : 3u));
+                        if (code == 3u) far += 1;
+                        word |= code << (2 * k);
+                    }
+                    g_pow_codes[(size_t)w] = word;
+                }
+            });
+            g_pow_n = counts, g_pow_far += far.load();
+        }
+        words.assign(g_pow_codes.begin(), g_pow_codes.begin() + counts / 16);
+        if (g_pow_far > 0) ctx->err = "warning: this libm's powf(n, -1) is more than one ulp away from 1 / n for some n; those counts use the division";
+    }
+    HIPCHK(ctx->d_pow_codes.ensure(words.size() * 4));
+    HIPCHK(hipMemcpy(ctx->d_pow_codes.p, words.data(), words.size() * 4, hipMemcpyHostToDevice));
+    ctx->pow_n = counts;
+    return DMSA_OK;
+}
 // allocate everything whose size depends only on the point count
 int alloc_point_buffers(dmsa_ctx* ctx) {
     const size_t n = (size_t)ctx->n;
@@ -84,7 +133,7 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
         HIPCHK(ctx->d_sort_tmp[l].ensure(sort_pairs_temp_bytes(2 * n)));
         HIPCHK(ctx->d_scan_tmp[l].ensure(scan_temp_bytes(2 * n)));
     }
-    HIPCHK(ctx->d_counts.ensure(sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts)));  // read back together
+    HIPCHK(ctx->d_counts.ensure(sizeof(GaussCounts) + sizeof(SerialCounts)));  // read back together
     // memberships: every point belongs to at most one set per resolution
     HIPCHK(ctx->d_memb_local.ensure(2 * n * 16));
     HIPCHK(ctx->d_memb_idx.ensure(2 * n * 4));
@@ -93,21 +142,13 @@ int alloc_point_buffers(dmsa_ctx* ctx) {
     // sets have >= 2 members (two distinct ids) -- except the second half of a splitSet, which may keep a single member when
     // min_num_points_per_set <= 1: size for one set per membership
     HIPCHK(ctx->d_info12.ensure((2 * n + 16) * 48));
-    HIPCHK(ctx->d_wg_seg.ensure(4096 * 4));
-    if (ctx->flags & DMSA_FLAG_MIRROR_SUMS) {
-        // one entry per Gaussian, and M can approach 2n (see d_info12 above)
-        HIPCHK(ctx->d_order.ensure((2 * n + 16) * 4));
-        HIPCHK(ctx->d_fit_sums.ensure((2 * n + 16) * 6 * 8));
-        HIPCHK(ctx->d_gauss_rows.ensure((2 * n + 16) * 8));
-    }
-    // tiled correspondence kernels: windows of 3T/4 members plus own-tile Gaussians (> T/4 members each) and their
-    // neighbours: tiles <= (4/3 + 8)*Mm/T + 1 with Mm <= 2n; one row list of `rows` entries per tile
-    const size_t max_tiles = 41 * n / (size_t)tile_points() + 64;  // windows + own tiles + one head per kTileGauss Gaussians (M <= n)
-    HIPCHK(ctx->d_memb_tile.ensure(tile_slot_capacity(n) * 16));
+    // one entry per Gaussian, and M can approach 2n (see d_info12 above)
+    HIPCHK(ctx->d_order.ensure((2 * n + 16) * 4));
+    HIPCHK(ctx->d_fit_sums.ensure((2 * n + 16) * 6 * 4));
+    CHK(upload_powm1_codes(ctx, (int64_t)n + 1));
+    HIPCHK(ctx->d_memb_q.ensure(3 * (2 * n + 16) * 4));
+    HIPCHK(ctx->d_gauss_rows.ensure((2 * n + 16) * 8));
     HIPCHK(ctx->d_pad_off.ensure((2 * n + 2) * 4));
-    HIPCHK(ctx->d_tiles.ensure(max_tiles * sizeof(TileDesc)));
-    HIPCHK(ctx->d_tile_rows.ensure(max_tiles * (size_t)ctx->rows * 4));
-    HIPCHK(ctx->d_fallback.ensure((2 * n / (size_t)tile_points() + 16) * 8));  // single-Gaussian tiles: > T members each
     return DMSA_OK;
 }
 
@@ -267,7 +308,7 @@ void dmsa_default_debug_options(dmsa_debug_options* o) {
     if (!o) return;
     o->device_loop = 1, o->dual_stream = 1, o->serial_streams = 3, o->merge_sort = -1, o->key_compress = 1, o->fused_segments = 1, o->sort_prehist = 0;
     o->library_sort = 0, o->overlap_batch = 1, o->serial_tree = 1, o->host_threads = 16, o->solve_threads = 12, o->host_timeline = 0, o->trace_time = 0, o->fused_leaf_scan = 1, o->device_sync = 1, o->shared_rotations = 1;
-    o->eval_skip = 1, o->sync_fault = 0, o->speculation_fault = 0, o->voxel_coherence = 0, o->lm_stream = 1, o->stream_priority = 0;
+    o->eval_skip = 1, o->sync_fault = 0, o->speculation_fault = 0, o->voxel_coherence = 0, o->lm_stream = 1, o->stream_priority = 0, o->fit_classes = 7, o->eigen_l1_bytes = 32 * 1024;
 }
 // DMSA_DEBUG="name=value,name=value": the one environment variable of the library (include/dmsa_debug.h)
 static void apply_debug_env(dmsa_debug_options* o) {
@@ -280,7 +321,7 @@ static void apply_debug_env(dmsa_debug_options* o) {
                   {"key_compress", &o->key_compress},   {"fused_segments", &o->fused_segments}, {"sort_prehist", &o->sort_prehist}, {"library_sort", &o->library_sort},
                   {"overlap_batch", &o->overlap_batch}, {"serial_tree", &o->serial_tree},   {"host_threads", &o->host_threads},     {"solve_threads", &o->solve_threads},
                   {"host_timeline", &o->host_timeline}, {"trace_time", &o->trace_time},     {"fused_leaf_scan", &o->fused_leaf_scan}, {"device_sync", &o->device_sync},
-                  {"shared_rotations", &o->shared_rotations}, {"eval_skip", &o->eval_skip}, {"sync_fault", &o->sync_fault}, {"speculation_fault", &o->speculation_fault}, {"voxel_coherence", &o->voxel_coherence}, {"lm_stream", &o->lm_stream}, {"stream_priority", &o->stream_priority}};
+                  {"shared_rotations", &o->shared_rotations}, {"eval_skip", &o->eval_skip}, {"sync_fault", &o->sync_fault}, {"speculation_fault", &o->speculation_fault}, {"voxel_coherence", &o->voxel_coherence}, {"lm_stream", &o->lm_stream}, {"stream_priority", &o->stream_priority}, {"fit_classes", &o->fit_classes}, {"eigen_l1_bytes", &o->eigen_l1_bytes}};
     std::string text(e);
     size_t at = 0;
     while (at < text.size()) {
@@ -307,14 +348,17 @@ int dmsa_create_ex(int device, uint32_t flags, const dmsa_debug_options* options
     apply_debug_env(&dbg);
     dbg.serial_streams = std::max(1, std::min(3, dbg.serial_streams)), dbg.serial_tree = std::max(0, std::min(2, dbg.serial_tree));
     dbg.host_threads = std::max(1, std::min(64, dbg.host_threads)), dbg.solve_threads = std::max(1, std::min(16, dbg.solve_threads));
+    if (dbg.eigen_l1_bytes < 4096) dbg.eigen_l1_bytes = 32 * 1024;  // (Eigen's own default when cpuid reports nothing)
     *out = nullptr;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return DMSA_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return DMSA_ERR_NO_DEVICE;
     dmsa_ctx* ctx = new (std::nothrow) dmsa_ctx();
     if (!ctx) return DMSA_ERR_NOMEM;
-    // the reference's summation order is the default; DMSA_FLAG_FAST_SUMS opts out (internally the default is the MIRROR_SUMS bit)
-    flags = (flags & DMSA_FLAG_FAST_SUMS) ? (flags & ~DMSA_FLAG_MIRROR_SUMS) : (flags | DMSA_FLAG_MIRROR_SUMS);
+    if (flags & ~(DMSA_FLAG_POSE_TABLE_HOST | DMSA_FLAG_FIXED_ITERS | DMSA_FLAG_MIRROR_SUMS | DMSA_FLAG_STAGE_TIMERS)) {
+        delete ctx;
+        return DMSA_ERR_INVALID;  // e.g. 0x10, the opt-in fast sums of rounds 1-4: retired, the library has ONE summation order (the reference's)
+    }
     ctx->device = device, ctx->flags = flags;
     ctx->dbg = dbg;
     ctx->compress_keys = dbg.key_compress != 0, ctx->overlap_batch = dbg.overlap_batch != 0, ctx->device_loop = dbg.device_loop != 0;
@@ -369,7 +413,7 @@ void dmsa_destroy(dmsa_ctx* ctx) {
                       &ctx->d_fhw, &ctx->d_trajtime, &ctx->d_aabb, &ctx->d_lattice, &ctx->d_code[0], &ctx->d_code[1], &ctx->d_idx[0], &ctx->d_idx[1],
                       &ctx->d_code_s[0], &ctx->d_code_s[1], &ctx->d_idx_s[0], &ctx->d_idx_s[1], &ctx->d_leaf_incl[0], &ctx->d_leaf_incl[1],
                       &ctx->d_leaf_start[0], &ctx->d_leaf_start[1], &ctx->d_counts, &ctx->d_memb_local, &ctx->d_memb_idx, &ctx->d_memb_g, &ctx->d_seg_off,
-                      &ctx->d_info12, &ctx->d_wg_seg, &ctx->d_order, &ctx->d_fit_sums, &ctx->d_tablesT, &ctx->d_memb_tile, &ctx->d_tiles, &ctx->d_tile_rows, &ctx->d_fallback, &ctx->d_pad_off, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
+                      &ctx->d_info12, &ctx->d_order, &ctx->d_fit_sums, &ctx->d_pow_codes, &ctx->d_memb_q, &ctx->d_tablesT, &ctx->d_pad_off, &ctx->d_E, &ctx->d_ne_partial, &ctx->d_Hp, &ctx->d_sq_partial, &ctx->d_sq_out};
     for (DevBuf* b : bufs) b->release();
     if (ctx->sp) {
         for (DevBuf* b : ctx->sp->all) b->release();

@@ -481,23 +481,6 @@ int dmsa_get_poses(dmsa_ctx* ctx, double* rel_orient, double* rel_transl) {
     return DMSA_OK;
 }
 
-// Debug-only (not declared in include/dmsa_hip.h): phase cycle counters of k_residuals_tiles, -DDMSA_PHASE_CLOCKS builds.
-int dmsa_debug_phase_clocks(dmsa_ctx* ctx, long long* out, int capacity_tiles) {
-    static DevBuf buf;
-    if (!ctx) return DMSA_ERR_INVALID;
-    CHK(set_device(ctx));
-    const size_t bytes = (size_t)capacity_tiles * 64 * sizeof(long long);
-    if (out == nullptr) {  // arm
-        HIPCHK(buf.ensure(bytes));
-        HIPCHK(hipMemset(buf.p, 0, bytes));
-        set_phase_clock_buffer(buf.as<long long>());
-        return DMSA_OK;
-    }
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, buf.p, bytes, hipMemcpyDeviceToHost));
-    return ctx->num_tiles;
-}
-
 int dmsa_optimize_keyframes(dmsa_ctx* ctx, dmsa_keyframe_problem* p, const dmsa_settings* s, dmsa_report* rep) {
     if (!ctx || !p || !s) return DMSA_ERR_INVALID;
     CHK(dmsa_keyframes_upload(ctx, p));

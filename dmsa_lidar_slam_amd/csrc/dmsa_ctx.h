@@ -202,8 +202,7 @@ struct dmsa_ctx {
     struct Readback {
         LatticeTable lattice[2];
         GaussCounts g;
-        TileCounts t;
-        SerialCounts sc;  // d_counts holds the three structs back to back
+        SerialCounts sc;  // d_counts holds the two structs back to back
         double errs[16];
     };
     Readback* h_rb = nullptr;  // hipHostMalloc
@@ -230,11 +229,14 @@ struct dmsa_ctx {
     int merge_sort = -1;             // -1: by size; debug switch merge_sort = 0 / 1 forces two sorts / one sort of both levels
     double level_res[2] = {0, 0};
     // Gaussians
-    DevBuf d_memb_local, d_memb_idx, d_memb_g, d_seg_off, d_info12, d_wg_seg;
+    DevBuf d_memb_local, d_memb_idx, d_memb_g, d_seg_off, d_info12;
     DevBuf d_order;  // reference-order path: Gaussians by descending size class
     DevBuf d_tablesT;                                          // pose tables of the current batch, transposed ([row][evaluation][12])
     bool order_valid = false;
     DevBuf d_fit_sums;           // six centred product sums per Gaussian (fit kernels -> finish kernel)
+    DevBuf d_memb_q;             // fit: global x | y | z of the members of Gaussians too long for the fit's LDS chunk, [3][2n + 16] floats
+    DevBuf d_pow_codes;          // two bits per member count n: how libm's powf(n, -1) differs from 1.0f / n (context.cpp: upload_powm1_codes)
+    int64_t pow_n = 0;           // counts covered by d_pow_codes
     DevBuf d_gauss_rows;         // (smallest, largest) pose-table row among the members of every Gaussian, identity row excluded (fit kernel)
     DevBuf d_row_range;          // per evaluation of the Jacobian batch: (first, last) pose-table row that can differ from evaluation 0's (loop chain + pose-table kernels)
     DevBuf d_skip_stats;         // per evaluation of the Jacobian batch: pairs (Gaussian, evaluation) not computed, pairs that differed under eval_skip = 2
@@ -282,14 +284,9 @@ struct dmsa_ctx {
     void* rb_extra_dst = nullptr;
     size_t rb_extra_bytes = 0;
     bool serial_two_streams = true;  // debug switch serial_streams = 1: all tiers of the reference-order correspondence kernels on one stream
-    DevBuf d_memb_tile, d_tiles, d_tile_rows, d_fallback, d_pad_off;
-    int num_tiles = 0, num_fallback = 0, tile_max_rows = 0, tile_max_gauss = 0;
-    bool use_tiles = true;  // fast path: false selects the streaming kernel
-    bool tiles_usable = true;  // false when a tile references more pose rows than the tiled kernels' LDS holds (very long windows)
+    DevBuf d_pad_off;            // (written by the member gather: prefix of the member counts rounded up to 8; unused since the tiled kernels are gone)
     int M = 0, M1 = 0;
     int64_t Mm = 0;
-    int num_wg = 0;
-    int cfg_num_wg = 768, cfg_big_n = 512;  // correspondence-kernel launch shape 
     bool gaussians_valid = false;
     // residual batches
     DevBuf d_E, d_ne_partial, d_Hp, d_sq_partial, d_sq_out;
@@ -357,6 +354,7 @@ int num_params(const dmsa_ctx* ctx);
 PoseChain& chain(dmsa_ctx* ctx);
 int num_extra_rows(const dmsa_ctx* ctx);
 int alloc_point_buffers(dmsa_ctx* ctx);
+int upload_powm1_codes(dmsa_ctx* ctx, int64_t counts);
 int upload_loop_model(dmsa_ctx* ctx);
 int upload_common(dmsa_ctx* ctx);
 void write_back_poses(const PoseChain& c, double* rel_o, double* rel_t);

@@ -51,19 +51,6 @@ struct LevelCounts {
     int32_t pad;
 };
 
-// tiles of whole Gaussians for the tiled correspondence kernels
-struct TileDesc {
-    int32_t g0, g1;        // Gaussians [g0, g1)
-    int32_t p0, p1;        // members [p0, p1) of the membership array
-    int32_t row_off;       // first entry of this tile's pose-table row list
-    int32_t nrows;         // distinct pose-table rows referenced by the tile
-    int32_t kind;          // 0: staged through LDS, 1: single Gaussian held in registers, 2: streaming fallback
-    int32_t pad;
-};
-struct TileCounts {
-    int32_t num_tiles, num_fallback, max_rows, max_gauss;
-};
-
 struct GaussCounts {       // both levels, read back once per iteration
     LevelCounts level[2];
     float weight_mean;
@@ -137,43 +124,19 @@ void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start
                            int64_t n, float4* memb_local, int32_t* memb_idx, int32_t* memb_g, int32_t* seg_off, const int32_t* pslot_of_slot,
                            int32_t* pad_off /* M+1 tile-slot offsets */, hipStream_t s);
 // ---- K3: Gaussian fit -------------------------------------------------------------------------------------
-// mirror == true: sums run serially in member order (bit-reproducible against the CPU restatement)
-void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const GaussCounts* counts, int level,
-                      float* info12, bool mirror, hipStream_t s);
-void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, bool mirror, hipStream_t s);
-// ---- K4: correspondence kernel ------------------------------------------------------------------------------
-void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t* wg_seg, hipStream_t s);
-// default path: fit in the oracle's summation order (the mean in Eigen's own linear-redux order; centred products in blocks of 64 members,
-// pairwise tree inside a block, block sums in order).  `order` = Gaussians by descending size class, `sc` = the DEVICE copy of
+// The fit's float reductions in Eigen 3.4's own order (Gaussians.h:146-147, :172-176; oracle: Gaussians::addPointSet): column means as
+// linear vectorised reductions, centred products as the chains of the blocked product (depth blocks from eigen_l1_bytes), weights
+// through pow(-1) of the counts as this machine's libm computes it (pow_codes).  `order` = Gaussians by descending size class, `sc` = the DEVICE copy of
 // SerialCounts (class ranges); classes 0 / 1 / 2 = long / middle / short with 16 / 4 / 1 waves per Gaussian; tasks[c] Gaussians of class c
 // starting at first[c] within the class; with_weights: one more workgroup computes the rebalancing weights.  Writes the six centred
-// product sums per Gaussian (launch_gauss_fit_finish turns them into information matrices, max_gauss >= M threads) and, if asked,
+// product sums (floats) per Gaussian (launch_gauss_fit_finish turns them into information matrices, max_gauss >= M threads) and, if asked,
 // gauss_rows[g] = (smallest, largest) pose-table row among the members of Gaussian g, the identity row `id_row` of the static points
 // left out ((INT_MAX, -1): static points only) -- what the correspondence kernels need to tell which evaluations of a Jacobian batch
 // can differ from evaluation 0 for that Gaussian.
 void launch_gauss_fit_all(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, const int first[3],
-                          const int tasks[3], double* sums, GaussCounts* counts, float* info12, bool with_weights, int id_row, int2* gauss_rows, hipStream_t s);
-void launch_gauss_fit_finish(const int32_t* seg_off, const GaussCounts* counts, const double* sums, int max_gauss, float* info12, hipStream_t s);
-// streaming correspondence kernel of the opt-in fast sums (fallback of the tiled kernels)
-void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
-                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, hipStream_t s, bool pairs = false);
-// tiled variant (default fast path): tiles + per-tile row lists are rebuilt once per iteration
-// slots of the tile copy of the membership array: every Gaussian is padded to a multiple of 8 slots (Mm + 7 M <= 9 n)
-inline size_t tile_slot_capacity(size_t n_points) { return 9 * n_points + 64; }
-// true if the LDS carve of the tiled correspondence / fit kernels fits for tiles that reference up to `max_rows` pose rows
-// (zero row included) -- very long windows fall back to the streaming kernels
-bool tiled_kernels_fit(int max_rows, int max_gauss);
-void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, const int32_t* memb_g, int rows, TileDesc* tiles,
-                        TileCounts* tc, int2* fallback, float4* memb_tile /* tile_slot_capacity(n) entries */, int32_t* tile_rows,
-                        int32_t* pad_off /* M+1 slot offsets */, hipStream_t s);
-int tile_points();
-void set_phase_clock_buffer(long long* p);  // debug instrumentation (-DDMSA_PHASE_CLOCKS builds only)
-// Gaussian fit on the tiles (fast path): info12[g] = information matrix of every accepted set, base pose table = table0
-void launch_fit_tiled(const float4* memb_tile, const int32_t* seg_off, const float* table0, int max_rows, const TileDesc* tiles, const TileCounts* tc,
-                      const int2* big_list, const int32_t* tile_rows, float* info12, hipStream_t s);
-void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables,
-                            int rows, int M, int B, const TileDesc* tiles, const int32_t* tile_rows, int num_tiles, int max_rows, int max_gauss,
-                            const int2* fallback, int num_fallback, int big_n, double* E, int64_t ldE, hipStream_t s);
+                          const int tasks[3], float* sums, GaussCounts* counts, float* info12, bool with_weights, int id_row, int2* gauss_rows, int eigen_l1_bytes,
+                          const uint32_t* pow_codes, int pow_n, float* memb_q /* [3][q_stride] scratch */, size_t q_stride, hipStream_t s);
+void launch_gauss_fit_finish(const int32_t* seg_off, const GaussCounts* counts, const float* sums, int max_gauss, float* info12, hipStream_t s);
 // ---- K5: normal equations + squared-error sums -------------------------------------------------------------
 // Hp = [J | e0]^T [J | e0] of size (P+1)^2, col-major, J.col(k) = inv_h * (E[k+1] - E[0]) over `rows` rows
 // reduce = false leaves the block sums in `partial` for a consumer that adds them itself (loop_kernels.hip): element (i, j) of Hp is the sum
@@ -194,9 +157,7 @@ struct EvalSkip {
 void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, double inv_h, double* partial, double* Hp, hipStream_t s, bool reduce = true,
                              const EvalSkip* skip = nullptr);
 int normal_equations_partial_doubles(int rows, int P);
-void launch_squared_sums(const double* E, int64_t ldE, int rows, int B, double* partial, double* out, hipStream_t s);
-int squared_sums_partial_doubles(int rows, int B);
-// parity path: the same sums in the blocked row order of the normal equations (bit-identical to the oracle); out == nullptr leaves the block
+// the squared sums of the nine trials in the blocked row order of the normal equations (bit-identical to the oracle); out == nullptr leaves the block
 // sums of evaluation b at partial[b * nsplit + sp] (nsplit as normal_equations_partials) for a consumer that adds them in order
 void launch_squared_sums_blocked(const double* E, int64_t ldE, int rows, int P, int B, double* partial, double* out, hipStream_t s);
 int squared_sums_blocked_partial_doubles(int rows, int P, int B);

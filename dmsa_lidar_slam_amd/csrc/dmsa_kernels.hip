@@ -18,6 +18,8 @@
 #include <type_traits>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <cstdio>
 
 #include "../../include/dmsa_detmath.h"
 #include "../../include/dmsa_hip.h"
@@ -1676,6 +1678,7 @@ void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start
 // ------------------------------------------------------------------------------------------------------------
 // K3 — Gaussian fit: covariance (double accumulation, rounded once), eigenvalue clamp, information matrix
 // ------------------------------------------------------------------------------------------------------------
+__device__ void inverse3_f(const float m[3][3], float inv[3][3]);
 __device__ void limit_covariance_f(float c[3][3]) {
     float a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int i = 0; i < 3; ++i)
@@ -1711,8 +1714,11 @@ __device__ void limit_covariance_f(float c[3][3]) {
     }
     float lam[3];
     for (int k = 0; k < 3; ++k) lam[k] = fmaxf(a[k][k], 0.0001f);
+    // eigenVectors * diagonal_matrix * eigenVectors.inverse() (Gaussians.h:200): the cofactor inverse of V, not its transpose
+    float vinv[3][3];
+    inverse3_f(v, vinv);
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) c[i][j] = sum3f((v[i][0] * lam[0]) * v[j][0], (v[i][1] * lam[1]) * v[j][1], (v[i][2] * lam[2]) * v[j][2]);
+        for (int j = 0; j < 3; ++j) c[i][j] = sum3f((v[i][0] * lam[0]) * vinv[0][j], (v[i][1] * lam[1]) * vinv[1][j], (v[i][2] * lam[2]) * vinv[2][j]);
 }
 __device__ void inverse3_f(const float m[3][3], float inv[3][3]) {
     float cof[3][3];
@@ -1727,45 +1733,17 @@ __device__ void inverse3_f(const float m[3][3], float inv[3][3]) {
         for (int c = 0; c < 3; ++c) inv[r][c] = cof[c][r] * invdet;
 }
 
-__device__ void finish_gaussian(double a0, double a1, double a2, double a3, double a4, double a5, int n, float* o) {
-    const double denom = (double)(n - 1);
+// default path: `s` = centered^T * centered in Eigen's float order (fit_tree_group), divided by float(n - 1) in float (Gaussians.h:147)
+__device__ void finish_gaussian_f(const float* __restrict__ s, int n, float* o) {
+    const float fd = (float)(n - 1);
     float cov[3][3], inv[3][3];
-    cov[0][0] = (float)(a0 / denom), cov[0][1] = cov[1][0] = (float)(a1 / denom), cov[0][2] = cov[2][0] = (float)(a2 / denom);
-    cov[1][1] = (float)(a3 / denom), cov[1][2] = cov[2][1] = (float)(a4 / denom), cov[2][2] = (float)(a5 / denom);
+    cov[0][0] = s[0] / fd, cov[0][1] = cov[1][0] = s[1] / fd, cov[0][2] = cov[2][0] = s[2] / fd;
+    cov[1][1] = s[3] / fd, cov[1][2] = cov[2][1] = s[4] / fd, cov[2][2] = s[5] / fd;
     limit_covariance_f(cov);
     inverse3_f(cov, inv);
     for (int c = 0; c < 3; ++c)
         for (int r = 0; r < 3; ++r) o[3 * c + r] = inv[r][c];
     o[9] = 0.0f, o[10] = (float)n, o[11] = 0.0f;
-}
-
-__global__ __launch_bounds__(256) void k_gauss_fit(const int32_t* __restrict__ seg_off, const int32_t* __restrict__ memb_idx,
-                                                   const float4* __restrict__ global, const GaussCounts* __restrict__ counts, int level,
-                                                   float* __restrict__ info12) {
-    const int gbase = level == 0 ? 0 : counts->level[0].num_gauss;
-    const int gend = gbase + counts->level[level].num_gauss;
-    const int lane = threadIdx.x & 63;
-    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int g = gbase + wave_global; g < gend; g += nwaves) {
-        const int b = seg_off[g], e = seg_off[g + 1], n = e - b;
-        double sx = 0.0, sy = 0.0, sz = 0.0;
-        for (int j = b + lane; j < e; j += 64) {
-            const float4 p = global[memb_idx[j]];
-            sx += (double)p.x, sy += (double)p.y, sz += (double)p.z;
-        }
-        sx = wave_allsum(sx), sy = wave_allsum(sy), sz = wave_allsum(sz);
-        const float mx = (float)(sx / (double)n), my = (float)(sy / (double)n), mz = (float)(sz / (double)n);
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
-        for (int j = b + lane; j < e; j += 64) {
-            const float4 p = global[memb_idx[j]];
-            const float cx = p.x - mx, cy = p.y - my, cz = p.z - mz;
-            a0 += (double)cx * (double)cx, a1 += (double)cx * (double)cy, a2 += (double)cx * (double)cz;
-            a3 += (double)cy * (double)cy, a4 += (double)cy * (double)cz, a5 += (double)cz * (double)cz;
-        }
-        a0 = wave_allsum(a0), a1 = wave_allsum(a1), a2 = wave_allsum(a2), a3 = wave_allsum(a3), a4 = wave_allsum(a4), a5 = wave_allsum(a5);
-        if (lane == 0) finish_gaussian(a0, a1, a2, a3, a4, a5, n, info12 + (size_t)g * 12);
-    }
 }
 
 // Default path: the fit's sums in the order the oracle states (Gaussians::addPointSet there).
@@ -1775,14 +1753,17 @@ __global__ __launch_bounds__(256) void k_gauss_fit(const int32_t* __restrict__ s
 //    packet, predux (a0 + a2) + (a1 + a3), then the scalars in front of the aligned start and behind the last packet.  The chains
 //    are serial, so the members' coordinates go through LDS in chunks: every wave of the group transforms members, 24 lanes (8 chains
 //    x 3 columns) add them up, 3 lanes finish.
-//  * centered^T * centered runs through Eigen's blocked GEMM, whose depth blocks depend on the machine's cache sizes: no order to
-//    follow, so the oracle states one that a wave computes in a handful of instructions -- double sums over consecutive blocks of 64
-//    members, each block reduced by the balanced pairwise tree (exactly what wave_allsum's DPP steps do: v[i] += v[i - w] for
-//    w = 1, 2, .. 32), the block sums added in block order.  The group's waves take blocks round by round, thread c adds the round's
-//    block sums of component c in order.
+//  * centered^T * centered (Gaussians.h:147) in Eigen's OWN order as well (oracle: Gaussians::gemm_dot_f32, which cites the evaluators): below
+//    14 members the lazy product -- every coefficient the linear redux of the element-wise products from an aligned start --, else the
+//    blocked product, where 3 rows and 3 columns leave everything to gebp's scalar tail: per coefficient a float chain C = C + a_k b_k
+//    over one depth block of kc members, res = res + C block after block, divided by float(n - 1) in float.  kc follows from the L1
+//    data cache of the machine the reference runs on (dmsa_debug_options::eigen_l1_bytes; 680 for 32 KB), and the chains of different
+//    blocks are independent: lane = (block, coefficient), every lane runs ONE chain of at most kc adds over the centred coordinates in
+//    LDS.  A Gaussian that fits the group's LDS chunk is centred in place; a longer one goes through LDS again in slices that hold the
+//    same W members of every block, so that all its block chains advance together (the members of the next slice are fetched into
+//    registers while the chains of the current one run).
 // Members are read from the Gaussian-ordered copy of the LOCAL points and transformed with the base pose table (the same
 // operation sequence as k_transform, so the coordinates are the ones the voxelisation saw).
-constexpr int kSumBlock = 64;
 // The classes of the size-ordered Gaussian list (serial_kernels.h): 0 = long (16 waves per Gaussian), 1 = middle (4), 2 = short (1).
 // The kernels read the class ranges from DEVICE memory, so they can be launched before the host knows the counts (with the
 // previous iteration's counts as the grid): a workgroup beyond the true count exits.
@@ -1863,23 +1844,84 @@ __device__ __forceinline__ float redux_finish(const ReduxPlan& p, int n, const f
     for (int i = p.aEnd; i < n; ++i) res = res + sp[3 + (i - p.aEnd2)];
     return res;
 }
+// depth blocking of Eigen's (3 x n) * (n x 3) product (evaluateProductBlockingSizesHeuristic, one thread; oracle: Gaussians::gemm_kc)
+__device__ __forceinline__ int gemm_kc(int k, int max_kc) {
+    if (k < 48 || k <= max_kc) return k;
+    const int r = k % max_kc;
+    return r == 0 ? max_kc : max_kc - 8 * ((max_kc - 1 - r) / (8 * (k / max_kc + 1)));
+}
+// one coefficient of one depth block: C = C + a[k] * b[k], k = 0 .. cnt - 1, operands in LDS.  The adds are a dependent chain; the reads
+// and products of the next eight steps are issued before the adds of the current eight.
+// The products a_k * b_k are made by ALL threads of the group (rounded to float one by one, as the scalar loop does) and laid out per
+// coefficient in LDS; a chain lane then only adds.  sp is 16-byte aligned: the operands of eight steps arrive as two ds_read_b128, in
+// flight while the eight dependent adds of the previous eight run (sched_barrier pins that order: left alone, the compiler waits for
+// the reads where it issues them).
+__device__ __forceinline__ float cov_chain(const float* __restrict__ sp, int cnt, float C) {
+    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(sp);
+    auto add8 = [&](const float4& a, const float4& b) { C = C + a.x, C = C + a.y, C = C + a.z, C = C + a.w, C = C + b.x, C = C + b.y, C = C + b.z, C = C + b.w; };
+    int i = 0;
+    if (cnt >= 8) {
+        float4 x0 = p4[0], x1 = p4[1], y0, y1;  // two register sets take turns (no copies on the chain's path)
+        i = 8;
+        while (true) {
+            const bool more_y = i + 8 <= cnt;
+            if (more_y) y0 = p4[i >> 2], y1 = p4[(i >> 2) + 1], i += 8;
+            __builtin_amdgcn_sched_barrier(0);
+            add8(x0, x1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!more_y) break;
+            const bool more_x = i + 8 <= cnt;
+            if (more_x) x0 = p4[i >> 2], x1 = p4[(i >> 2) + 1], i += 8;
+            __builtin_amdgcn_sched_barrier(0);
+            add8(y0, y1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!more_x) break;
+        }
+    }
+    for (; i < cnt; ++i) C = C + sp[i];
+    return C;
+}
+// the coefficient-based lazy product of fewer than 14 members: the linear vectorised redux of the products from element 0 (Redux.h)
+__device__ __forceinline__ float cov_lazy(const float* __restrict__ sp, int n) {
+    const int packets = n >> 2;
+    float res;
+    if (packets == 0) {
+        res = sp[0];
+        for (int i = 1; i < n; ++i) res = res + sp[i];
+        return res;
+    }
+    float r[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) r[l] = sp[l];
+    if (packets > 1) {  // 8 <= n < 14: one pair of packets, then one odd packet from 12 members on
+#pragma unroll
+        for (int l = 0; l < 4; ++l) r[l] = r[l] + sp[4 + l];
+        if (packets > 2) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l) r[l] = r[l] + sp[8 + l];
+        }
+    }
+    res = (r[0] + r[2]) + (r[1] + r[3]);
+    for (int i = 4 * packets; i < n; ++i) res = res + sp[i];
+    return res;
+}
 // covariance -> limitCovariance -> inverse (Gaussians.h:146-168, :181-201), one thread per Gaussian: the serial 3x3 work of all
 // Gaussians fills whole waves instead of trailing every fit workgroup on a single lane
 __global__ __launch_bounds__(256) void k_gauss_fit_finish(const int32_t* __restrict__ seg_off, const GaussCounts* __restrict__ counts,
-                                                          const double* __restrict__ sums, float* __restrict__ info12) {
+                                                          const float* __restrict__ sums, float* __restrict__ info12) {
     const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= M) return;
-    const double* a = sums + (size_t)g * 6;
+    float a[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) a[q] = sums[(size_t)g * 6 + q];
     float o[12];
-    finish_gaussian(a[0], a[1], a[2], a[3], a[4], a[5], seg_off[g + 1] - seg_off[g], o);
+    finish_gaussian_f(a, seg_off[g + 1] - seg_off[g], o);
     float* dst = info12 + (size_t)g * 12;
 #pragma unroll
     for (int i = 0; i < 12; ++i)
         if (i != 9) dst[i] = o[i];  // slot 9 is the rebalancing weight (k_size_classes / k_rebalancing_weights write it)
 }
-constexpr int kFitShortBlocks = 4;  // short class: Gaussians up to serial_small_threshold() <= 256 members, one wave each
-int fit_small_max_blocks() { return kFitShortBlocks; }
 // All three classes -- and the rebalancing weights -- in ONE launch of 1024-thread workgroups: a workgroup is one long Gaussian (16 waves),
 // four middle ones (4 waves each) or sixteen short ones (1 wave each); the first workgroup computes the weights.  Nothing has to be
 // forked to a second stream and joined again (a cross-stream dependency costs ~15 us each way on this GPU,
@@ -1891,37 +1933,62 @@ struct FitScratch {
     float mean[3];
     int rows[2];                  // smallest / largest pose-table row of the members (identity row excluded)
 };
-template <int kFitWaves, int kMaxBlk>
+// block chains a group runs side by side: one lane per (block, coefficient), and at least 16 members of every block in the LDS chunk
+#ifdef DMSA_FIT_TIMING
+__device__ long long* g_fit_tim = nullptr;  // experiment build: per-workgroup phase times in pinned host memory (launch_gauss_fit_all prints them)
+#endif
+template <int kFitWaves>
+struct FitGroup {
+    static constexpr int kThreads = 64 * kFitWaves, CH = 256 * kFitWaves, CHS = CH + 8, kMaxG = (kThreads / 6) < (CH / 16) ? (kThreads / 6) : (CH / 16);
+};
+template <int kFitWaves>
 __device__ __forceinline__ void fit_tree_group(const float4* __restrict__ memb_local, const int32_t* __restrict__ seg_off, const float4* __restrict__ table0,
-                                               int g /* -1: no Gaussian for this group */, int gtid, double (*s_blk)[6] /* [kMaxBlk] */, double* s_tot /* [6] */,
-                                               FitScratch* fs, float* sx /* [3][256 * kFitWaves] */, int* s_rounds /* [2]: block rounds, chunks */, int id_row,
-                                               double* __restrict__ sums, int2* __restrict__ gauss_rows) {
-    constexpr int CH = 256 * kFitWaves;  // members per chunk of the mean pass: four per lane
-    const int b = g >= 0 ? seg_off[g] : 0, n = g >= 0 ? seg_off[g + 1] - b : 0, nblk = (n + kSumBlock - 1) / kSumBlock;
-    const int wave = gtid >> 6, lane = gtid & 63;
-    auto global_point = [&](int j) {
-        const float4 p = memb_local[b + j];
-        const int row = __float_as_int(p.w);
-        return apply_row3(table0[3 * row], table0[3 * row + 1], table0[3 * row + 2], p.x, p.y, p.z);
-    };
+                                               int g /* -1: no Gaussian for this group */, int gtid, float (*s_C)[6] /* [FitGroup::kMaxG] */, FitScratch* fs,
+                                               float* sx /* [6][CHS]: pass 1 uses three columns */, int* s_rounds /* [3]: chunks, block groups, slices */, int id_row, int max_kc,
+                                               float* __restrict__ memb_q /* [3][q_stride]: global coordinates of the members of Gaussians too long for LDS */,
+                                               size_t q_stride, float* __restrict__ sums, int2* __restrict__ gauss_rows) {
+    constexpr int CH = FitGroup<kFitWaves>::CH;    // members per chunk of the mean pass: four per lane
+    constexpr int CHS = FitGroup<kFitWaves>::CHS;  // column stride in LDS: the three columns of one member lie in different banks
+    constexpr int kThreads = FitGroup<kFitWaves>::kThreads, kMaxG = FitGroup<kFitWaves>::kMaxG;
+    const int b = g >= 0 ? seg_off[g] : 0, n = g >= 0 ? seg_off[g + 1] - b : 0;
+    const int lane = gtid & 63;
     // A group of ONE wave (the short class: sixteen Gaussians per workgroup) needs no workgroup barrier at all -- its LDS traffic is in
     // order, its scratch is its own -- so the sixteen waves run and end independently instead of meeting ten times at the pace of the
     // slowest.  Groups of several waves meet at the same barriers: everybody runs as many rounds as the group with the most.
     constexpr bool kSolo = kFitWaves == 1;
+    // The barriers between phases order LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() would also wait for every
+    // global access in flight -- the members fetched for the next chunk while this one's chains run, the coordinates stored for pass 2 --,
+    // i.e. one memory round trip per phase.  (What pass 2 reads back from global memory is fenced once, in front of pass 2.)
     auto sync = [&]() {
         if (kSolo) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         } else {
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     };
-    if (!kSolo && gtid == 0) atomicMax(&s_rounds[0], (nblk + kMaxBlk - 1) / kMaxBlk), atomicMax(&s_rounds[1], (n + CH - 1) / CH);
-    if (gtid < 6) s_tot[gtid] = 0.0;
+    // the product's blocking (see above): kc members per depth block, nb blocks; Gg block chains per round, in slices of W members
+    const bool lazy = n < 14;
+    const bool resident = n <= CH;  // the coordinates of every member are still in LDS after the mean pass
+    const int kc = lazy ? max(n, 1) : gemm_kc(n, max_kc), nb = lazy ? 0 : (n + kc - 1) / kc;
+    const int Gg = max(min(nb, kMaxG), 1);
+    // slices of a Gaussian that does not fit: the same W members of every block of a round, block t at t * (W + 4) -- W the largest
+    // power of two with Gg * (W + 4) <= CH (>= 8); the stride keeps the 16-byte alignment of the chains' reads and spreads the blocks
+    // over the banks
+    const int logW = resident ? 0 : 31 - __clz(CH / Gg - 4), W = resident ? kc : 1 << logW, WS = W + 4;
+    const int my_groups = lazy ? 0 : (nb + Gg - 1) / Gg, my_slices = resident ? 1 : (kc + W - 1) / W;
+    if (!kSolo && gtid == 0) atomicMax(&s_rounds[0], (n + CH - 1) / CH), atomicMax(&s_rounds[1], my_groups), atomicMax(&s_rounds[2], my_slices);
     if (gtid == 0) fs->rows[0] = INT_MAX, fs->rows[1] = -1;
     sync();
-    const int rounds = kSolo ? (nblk + kMaxBlk - 1) / kMaxBlk : s_rounds[0];
-    const int chunks = kSolo ? (n + CH - 1) / CH : s_rounds[1];
+    const int chunks = kSolo ? (n + CH - 1) / CH : s_rounds[0];
+    const int groups = kSolo ? my_groups : s_rounds[1], slices = kSolo ? my_slices : s_rounds[2];
+#ifdef DMSA_FIT_TIMING
+    const long long t_start = wall_clock64();
+    long long t_tr = 0, t_ch = 0, t_mark = t_start;
+#define FIT_MARK(acc) { const long long t_now = wall_clock64(); acc += t_now - t_mark; t_mark = t_now; }
+#else
+#define FIT_MARK(acc)
+#endif
     // ---- pass 1: subset.colwise().mean() in Eigen's order (see above) ----
     ReduxPlan plan[3];
 #pragma unroll
@@ -1930,22 +1997,23 @@ __device__ __forceinline__ void fit_tree_group(const float4* __restrict__ memb_l
     const ReduxPlan my_plan = redux_plan(n, min(cc, 2) * (n & 3));  // (no run-time index into plan[]: that would put it into scratch memory)
     float acc = -0.0f;                         // (-0) + x == x: the chain starts with its first element as it is
     int rmin = INT_MAX, rmax = -1;
+    float4 p[4];
+    auto fetch_chunk = [&](int ch) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = memb_local[b + min(ch * CH + u * kThreads + gtid, max(n - 1, 0))];
+    };
+    if (chunks > 0) fetch_chunk(0);
     for (int ch = 0; ch < chunks; ++ch) {
         const int m0 = ch * CH;
-        float4 p[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = m0 + u * (64 * kFitWaves) + gtid;
-            p[u] = memb_local[b + min(i, max(n - 1, 0))];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int il = u * (64 * kFitWaves) + gtid, i = m0 + il;
+            const int il = u * kThreads + gtid, i = m0 + il;
             if (i < n) {
                 const int row = __float_as_int(p[u].w);
                 if (row != id_row) rmin = min(rmin, row), rmax = max(rmax, row);
                 const float3 q = apply_row3(table0[3 * row], table0[3 * row + 1], table0[3 * row + 2], p[u].x, p[u].y, p[u].z);
-                sx[il] = q.x, sx[CH + il] = q.y, sx[2 * CH + il] = q.z;
+                sx[il] = q.x, sx[CHS + il] = q.y, sx[2 * CHS + il] = q.z;
+                if (!resident) memb_q[b + i] = q.x, memb_q[q_stride + b + i] = q.y, memb_q[2 * q_stride + b + i] = q.z;  // pass 2 reads them back in slices
                 if (i < 3 || i + 10 >= n || n <= 6) {  // one of the few scalars of some column's redux
                     int slot = redux_slot(plan[0], i);
                     if (slot >= 0) fs->sp[0][slot] = q.x;
@@ -1957,9 +2025,16 @@ __device__ __forceinline__ void fit_tree_group(const float4* __restrict__ memb_l
             }
         }
         sync();
-        if (gtid < 24) acc = redux_chain(my_plan, ck, m0, min(CH, n - m0), sx + cc * CH, acc);
+        FIT_MARK(t_tr)
+        if (ch + 1 < chunks) fetch_chunk(ch + 1);  // in flight while the chains of this chunk run
+        if (gtid < 24) acc = redux_chain(my_plan, ck, m0, min(CH, n - m0), sx + cc * CHS, acc);
         if (ch + 1 < chunks) sync();  // the next chunk overwrites the coordinates
+        FIT_MARK(t_ch)
     }
+#ifdef DMSA_FIT_TIMING
+    const long long t_p1 = wall_clock64();
+    long long t_tr2 = 0, t_ch2 = 0;
+#endif
     if (gtid < 24) fs->acc[cc][ck] = acc;
     {   // pose-table rows of the members (what evaluations of a Jacobian batch can differ from evaluation 0 for this Gaussian)
         rmin = wave_allmin(rmin), rmax = -wave_allmin(-rmax);
@@ -1974,64 +2049,110 @@ __device__ __forceinline__ void fit_tree_group(const float4* __restrict__ memb_l
     if (gtid < 3 && n > 0) fs->mean[gtid] = redux_finish(my_plan_col(n, gtid), n, fs->acc[gtid], fs->sp[gtid]) / (float)n;
     if (gtid == 3 && g >= 0 && gauss_rows != nullptr) gauss_rows[g] = make_int2(fs->rows[0], fs->rows[1]);
     sync();
+    // ---- pass 2: centered^T * centered, xx xy xz yy yz zz, in the order of Eigen's product kernels (see above) ----
     const float mx = fs->mean[0], my = fs->mean[1], mz = fs->mean[2];
-    const bool resident = chunks <= 1;  // the coordinates of every member are still in LDS
-    for (int r = 0; r < rounds; ++r) {  // pass 2: xx xy xz yy yz zz of the centred members
-        const int sb = r * kMaxBlk, end = min(nblk, sb + kMaxBlk);
-        for (int blk = sb + wave; blk < end; blk += kFitWaves) {
-            const int j = blk * kSumBlock + lane;
-            double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            if (j < n) {
-                float3 q;
-                if (resident)
-                    q = make_float3(sx[j], sx[CH + j], sx[2 * CH + j]);
-                else
-                    q = global_point(j);
-                const float cx = q.x - mx, cy = q.y - my, cz = q.z - mz;
-                t[0] = (double)cx * (double)cx, t[1] = (double)cx * (double)cy, t[2] = (double)cx * (double)cz;
-                t[3] = (double)cy * (double)cy, t[4] = (double)cy * (double)cz, t[5] = (double)cz * (double)cz;
-            }
+    const int cl_b = gtid / 6, cl_q = gtid - 6 * cl_b;  // chain lane = (block of the round, coefficient)
+    // the six products of one member (MatrixXf centered = subset.rowwise() - mean, Gaussians.h:146; then a_k * b_k of the scalar loop) at position `at`
+    auto put_products = [&](int at, float x, float y, float z) {
+        const float cx = x - mx, cy = y - my, cz = z - mz;
+        sx[at] = cx * cx, sx[CHS + at] = cx * cy, sx[2 * CHS + at] = cx * cz, sx[3 * CHS + at] = cy * cy, sx[4 * CHS + at] = cy * cz, sx[5 * CHS + at] = cz * cz;
+    };
+    // members of slice `sl` of round `bg`: position idx = (block idx >> logW of the round, member sl * W + (idx & (W - 1)) of the block)
+    auto slot_member = [&](int bg, int sl, int idx) {
+        const int bl = idx >> logW, k = sl * W + (idx & (W - 1)), blk = bg * Gg + bl, j = blk * kc + k;
+        return (!resident && bl < Gg && blk < nb && k < kc && j < n) ? j : -1;
+    };
+    auto fetch_slice = [&](int bg, int sl) {  // (p[] is free after pass 1: x, y, z of the slot's member)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const double v = wave_allsum(t[c]);
-                if (lane == 0) s_blk[blk - sb][c] = v;
+        for (int u = 0; u < 4; ++u) {
+            const int j = slot_member(bg, sl, u * kThreads + gtid);
+            if (j >= 0) p[u].x = memb_q[b + j], p[u].y = memb_q[q_stride + b + j], p[u].z = memb_q[2 * q_stride + b + j];
+        }
+    };
+    if (!kSolo) {  // the coordinates other threads of the group stored in pass 1 must have landed before pass 2 reads them back
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (groups > 0) fetch_slice(0, 0);
+    if (resident) {  // the coordinates are still in LDS: every thread turns its own members into products, in place
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int il = u * kThreads + gtid;
+            if (il < n) put_products(il, sx[il], sx[CHS + il], sx[2 * CHS + il]);
+        }
+    }
+    sync();
+    float res = 0.0f;  // dst.setZero() in front of the blocked product
+    if (lazy && gtid < 6 && n > 0) res = cov_lazy(sx + gtid * CHS, n);
+    for (int bg = 0; bg < groups; ++bg) {
+        const int blk = bg * Gg + cl_b;
+        const bool chainer = bg < my_groups && cl_b < Gg && blk < nb;
+        const int len = chainer ? min(kc, n - blk * kc) : 0;
+        float C = 0.0f;  // ResScalar C0(0)
+        for (int sl = 0; sl < slices; ++sl) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = u * kThreads + gtid;
+                if (slot_member(bg, sl, idx) >= 0) put_products((idx >> logW) * WS + (idx & (W - 1)), p[u].x, p[u].y, p[u].z);
             }
+            sync();
+            FIT_MARK(t_tr2)
+            // the next slice is on its way while the chains of this one run
+            if (sl + 1 < slices)
+                fetch_slice(bg, sl + 1);
+            else if (bg + 1 < groups)
+                fetch_slice(bg + 1, 0);
+            if (chainer && sl < my_slices) C = cov_chain(sx + cl_q * CHS + (resident ? blk * kc : cl_b * WS), min(max(len - sl * W, 0), W), C);
+            sync();  // the next slice overwrites the products
+            FIT_MARK(t_ch2)
         }
+        if (chainer) s_C[cl_b][cl_q] = C;
         sync();
-        if (gtid < 6) {
-            double tot = s_tot[gtid];
-            for (int t = 0; t < end - sb; ++t) tot += s_blk[t][gtid];
-            s_tot[gtid] = tot;
-        }
+        if (gtid < 6 && bg < my_groups)  // res(i, j) += alpha * C0, block after block (alpha = 1)
+            for (int t = 0; t < Gg && bg * Gg + t < nb; ++t) res = res + s_C[t][gtid];
         sync();
     }
-    if (g >= 0 && gtid < 6) sums[(size_t)g * 6 + gtid] = s_tot[gtid];
+    if (g >= 0 && gtid < 6) sums[(size_t)g * 6 + gtid] = res;
+#ifdef DMSA_FIT_TIMING
+    if (gtid == 0 && g_fit_tim != nullptr && (kFitWaves != 1 || (blockIdx.x & 31) == 0) && blockIdx.x < 2000) {  // 100 MHz clock: 10 ns per tick
+        long long* r = g_fit_tim + 12 * (size_t)blockIdx.x;
+        r[0] = kFitWaves, r[1] = n, r[2] = chunks, r[3] = groups, r[4] = slices, r[5] = wall_clock64() - t_start, r[6] = t_p1 - t_start, r[7] = t_tr, r[8] = t_ch,
+        r[9] = wall_clock64() - t_p1, r[10] = t_tr2, r[11] = t_ch2;
+    }
+#endif
 }
 __device__ void rebalancing_weights_mirror_body(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts, float* __restrict__ info12, float* sx /* [8192] */,
-                                                FitScratch* fs);
+                                                FitScratch* fs, const uint32_t* __restrict__ pow_codes, int pow_n);
 struct FitLaunch {
     int first[3], tasks[3];  // per class: index of the first Gaussian of the class covered by this launch, number covered
     int wg[3];               // workgroups per class
     int weights;             // 1: workgroup 0 computes the rebalancing weights
     int id_row;              // the pose-table row of the static points (identity)
+    int max_kc;              // largest depth block of Eigen's product on the reference's machine (from its L1 size)
+    int pow_n;               // pow_codes covers the member counts 0 .. pow_n - 1
+    const uint32_t* pow_codes;
 };
-constexpr int kFitLdsFloats = 3 * 4096;  // dynamic LDS of k_gauss_fit_all: member coordinates of a chunk, [group][column][256 x waves]
-__global__ __launch_bounds__(1024) void k_gauss_fit_all(const float4* __restrict__ memb_local, const int32_t* __restrict__ seg_off, const float4* __restrict__ table0,
-                                                        const uint32_t* __restrict__ order, const int32_t* __restrict__ sc, FitLaunch fl, double* __restrict__ sums,
-                                                        GaussCounts* __restrict__ counts, float* __restrict__ info12, int2* __restrict__ gauss_rows) {
-    extern __shared__ float s_x[];    // kFitLdsFloats
-    __shared__ double s_blk[256][6];  // class 0: [256][6]; class 1: 4 x [64][6]; class 2: 16 x [kFitShortBlocks][6]
-    __shared__ double s_tot[16][6];
+constexpr int kFitLdsFloats = 16 * 6 * FitGroup<1>::CHS;  // dynamic LDS of k_gauss_fit_all: [group][x y z | six products][256 x waves + 8] -- 99 KB: one workgroup per CU, which its registers allow anyway
+#ifndef DMSA_FIT_WAVES_PER_SIMD
+#define DMSA_FIT_WAVES_PER_SIMD 4  // 8: two workgroups per CU (64 VGPRs, spills); 4: one (128 VGPRs) -- measured: scripts/ab_fit.sh
+#endif
+__global__ __launch_bounds__(1024, DMSA_FIT_WAVES_PER_SIMD) void k_gauss_fit_all(const float4* __restrict__ memb_local, const int32_t* __restrict__ seg_off, const float4* __restrict__ table0,
+                                                        const uint32_t* __restrict__ order, const int32_t* __restrict__ sc, FitLaunch fl, float* __restrict__ sums,
+                                                        GaussCounts* __restrict__ counts, float* __restrict__ info12, int2* __restrict__ gauss_rows,
+                                                        float* __restrict__ memb_q, size_t q_stride) {
+    extern __shared__ float4 s_x4[];  // kFitLdsFloats floats
+    float* s_x = reinterpret_cast<float*>(s_x4);
+    __shared__ float s_C[176][6];     // block sums of a round: class 0: [170]; class 1: 4 x [42]; class 2: 16 x [10]
     __shared__ FitScratch s_fs[16];
-    __shared__ int s_rounds[2];
-    if (threadIdx.x < 2) s_rounds[threadIdx.x] = 0;
+    __shared__ int s_rounds[3];
+    if (threadIdx.x < 3) s_rounds[threadIdx.x] = 0;
     __syncthreads();
     const int tid = threadIdx.x;
     int bx = blockIdx.x;
     // the weights first: their chains (M / 8 dependent float adds) then run beside the fit of the longest Gaussians instead of behind it
     if (fl.weights) {
         if (bx == 0) {
-            rebalancing_weights_mirror_body(seg_off, counts, info12, s_x, &s_fs[0]);
+            rebalancing_weights_mirror_body(seg_off, counts, info12, s_x, &s_fs[0], fl.pow_codes, fl.pow_n);
             return;
         }
         bx -= 1;
@@ -2041,74 +2162,83 @@ __global__ __launch_bounds__(1024) void k_gauss_fit_all(const float4* __restrict
         return task < fl.tasks[cls] && fit_task(sc, cls, fl.first[cls] + task, index) ? (int)order[index] : -1;
     };
     if (bx < fl.wg[0]) {
-        fit_tree_group<16, 256>(memb_local, seg_off, table0, pick(0, bx), tid, s_blk, s_tot[0], &s_fs[0], s_x, s_rounds, fl.id_row, sums, gauss_rows);
+        if (pick(0, bx) < 0) return;  // a surplus workgroup of the speculative launch
+        fit_tree_group<16>(memb_local, seg_off, table0, pick(0, bx), tid, s_C, &s_fs[0], s_x, s_rounds, fl.id_row, fl.max_kc, memb_q, q_stride, sums, gauss_rows);
         return;
     }
     bx -= fl.wg[0];
     if (bx < fl.wg[1]) {
         const int grp = tid >> 8;
-        fit_tree_group<4, 64>(memb_local, seg_off, table0, pick(1, bx * 4 + grp), tid & 255, s_blk + grp * 64, s_tot[grp], &s_fs[grp], s_x + grp * (3 * 1024), s_rounds,
-                              fl.id_row, sums, gauss_rows);
+        fit_tree_group<4>(memb_local, seg_off, table0, pick(1, bx * 4 + grp), tid & 255, s_C + grp * FitGroup<4>::kMaxG, &s_fs[grp], s_x + grp * (6 * FitGroup<4>::CHS), s_rounds, fl.id_row,
+                          fl.max_kc, memb_q, q_stride, sums, gauss_rows);
         return;
     }
     bx -= fl.wg[1];
     if (bx < fl.wg[2]) {
         const int grp = tid >> 6;
-        fit_tree_group<1, kFitShortBlocks>(memb_local, seg_off, table0, pick(2, bx * 16 + grp), tid & 63, s_blk + grp * kFitShortBlocks, s_tot[grp], &s_fs[grp],
-                                           s_x + grp * (3 * 256), s_rounds, fl.id_row, sums, gauss_rows);
+        fit_tree_group<1>(memb_local, seg_off, table0, pick(2, bx * 16 + grp), tid & 63, s_C + grp * FitGroup<1>::kMaxG, &s_fs[grp], s_x + grp * (6 * FitGroup<1>::CHS), s_rounds, fl.id_row,
+                          fl.max_kc, memb_q, q_stride, sums, gauss_rows);
         return;
     }
 }
+static_assert(FitGroup<16>::kMaxG <= 176 && 4 * FitGroup<4>::kMaxG <= 176 && 16 * FitGroup<1>::kMaxG <= 176, "s_C of k_gauss_fit_all");
+static_assert(6 * FitGroup<16>::CHS <= kFitLdsFloats && 4 * 6 * FitGroup<4>::CHS <= kFitLdsFloats, "dynamic LDS of k_gauss_fit_all");
 void launch_gauss_fit_all(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, const int first[3],
-                          const int tasks[3], double* sums, GaussCounts* counts, float* info12, bool with_weights, int id_row, int2* gauss_rows, hipStream_t s) {
+                          const int tasks[3], float* sums, GaussCounts* counts, float* info12, bool with_weights, int id_row, int2* gauss_rows, int eigen_l1_bytes,
+                          const uint32_t* pow_codes, int pow_n, float* memb_q, size_t q_stride, hipStream_t s) {
     FitLaunch fl;
     for (int c = 0; c < 3; ++c) fl.first[c] = first[c], fl.tasks[c] = tasks[c] > 0 ? tasks[c] : 0;
     fl.wg[0] = fl.tasks[0], fl.wg[1] = (fl.tasks[1] + 3) / 4, fl.wg[2] = (fl.tasks[2] + 15) / 16;
     fl.weights = with_weights ? 1 : 0, fl.id_row = id_row;
+    // max_kc of evaluateProductBlockingSizesHeuristic: ((l1 - mr * nr * 4) / (mr * 4 + nr * 4)) & ~(k_peeling - 1) with mr = 8, nr = 4
+    fl.max_kc = std::max(((eigen_l1_bytes - 128) / 48) & ~7, 1);
+    fl.pow_codes = pow_codes, fl.pow_n = pow_codes ? pow_n : 0;
     const int grid = fl.wg[0] + fl.wg[1] + fl.wg[2] + fl.weights;
     if (grid <= 0) return;
-    // 48 KB of dynamic LDS on top of ~16 KB static: above the 64 KB a kernel gets without asking (per launch: the attribute belongs to the device)
+#ifdef DMSA_FIT_TIMING
+    {
+        static long long* h_tim = nullptr;
+        static int launches = 0;
+        if (!h_tim) {
+            (void)hipHostMalloc(reinterpret_cast<void**>(&h_tim), 2000 * 12 * 8, hipHostMallocDefault);
+            std::memset(h_tim, 0, 2000 * 12 * 8);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fit_tim), &h_tim, sizeof(h_tim));
+        } else if (++launches == 6) {  // print the records of one warm launch
+            (void)hipStreamSynchronize(s);
+            for (int w = 0; w < 2000; ++w) {
+                const long long* r = h_tim + 12 * w;
+                if (r[0]) std::fprintf(stderr, "fit wg %d waves %lld n %lld chunks %lld groups %lld slices %lld | total %lld pass1 %lld (produce %lld chain %lld) pass2 %lld (produce %lld chain %lld) x10ns\n",
+                                       w, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11]);
+            }
+        }
+    }
+#endif
+    // 99 KB of dynamic LDS on top of ~8 KB static: above the 64 KB a kernel gets without asking (per launch: the attribute belongs to the device)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gauss_fit_all), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kFitLdsFloats * sizeof(float)));
     hipLaunchKernelGGL(k_gauss_fit_all, dim3(grid), dim3(1024), kFitLdsFloats * sizeof(float), s, memb_local, seg_off, reinterpret_cast<const float4*>(table0), order, sc, fl,
-                       sums, counts, info12, gauss_rows);
+                       sums, counts, info12, gauss_rows, memb_q, q_stride);
 }
-void launch_gauss_fit_finish(const int32_t* seg_off, const GaussCounts* counts, const double* sums, int max_gauss, float* info12, hipStream_t s) {
+void launch_gauss_fit_finish(const int32_t* seg_off, const GaussCounts* counts, const float* sums, int max_gauss, float* info12, hipStream_t s) {
     if (max_gauss > 0) hipLaunchKernelGGL(k_gauss_fit_finish, dim3((max_gauss + 255) / 256), dim3(256), 0, s, seg_off, counts, sums, info12);
 }
 
-void launch_gauss_fit(const int32_t* seg_off, const int32_t* memb_idx, const float4* global, const GaussCounts* counts, int level, float* info12,
-                      bool mirror, hipStream_t s) {
-    if (mirror)
-        return;  // the parity fit runs once for both levels, after M is known (launch_gauss_fit_blocked)
-    else
-        hipLaunchKernelGGL(k_gauss_fit, dim3(2048), dim3(256), 0, s, seg_off, memb_idx, global, counts, level, info12);
-}
-
-// Gaussians.h:170-179: w_k = (1/n_k) * obsWeight_k, divided by the mean over all sets (double sum, rounded once)
-__global__ __launch_bounds__(1024) void k_rebalancing_weights(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts,
-                                                              float* __restrict__ info12) {
-    __shared__ double s_part[16];
-    const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
-    double s = 0.0;
-    for (int g = threadIdx.x; g < M; g += 1024) {
-        const float nk = (float)(seg_off[g + 1] - seg_off[g]);
-        const float w = (1.0f / nk) * 1.0f;
-        info12[(size_t)g * 12 + 9] = w;
-        s += (double)w;
+// numPointsPerSet.cast<float>().array().pow(-1) (Gaussians.h:172): Eigen promotes the int exponent and calls std::pow(float, float) per
+// coefficient -- libm's powf, which is NOT correctly rounded (glibc >= 2.27: one ulp away from 1.0f / n for 953, 2071, 5331, ... --
+// 0.06 % of the n < 2^24).  The host asks ITS libm (the one the reference would run on) once per count and hands the differences over
+// as two bits per n: 0 same bits as the division, 1 one ulp above, 2 one ulp below (context.cpp: powm1_codes).  Counts beyond the
+// table take the division.
+__device__ __forceinline__ float pow_minus_one(int n, const uint32_t* __restrict__ pow_codes, int pow_n) {
+    float w = 1.0f / (float)n;
+    if (n < pow_n) {
+        const uint32_t code = (pow_codes[n >> 4] >> (2 * (n & 15))) & 3u;
+        w = __int_as_float(__float_as_int(w) + (code == 1u ? 1 : (code == 2u ? -1 : 0)));
     }
-    s = wave_allsum(s);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    double tot = 0.0;
-    for (int w = 0; w < 16; ++w) tot += s_part[w];
-    const float mean = (float)(tot / (double)M);
-    if (threadIdx.x == 0) counts->weight_mean = mean;
-    for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = info12[(size_t)g * 12 + 9] / mean;
+    return w;
 }
 // default path: rebalancingWeights.head(M).mean() (Gaussians.h:176) in Eigen's own order -- the linear redux of M contiguous floats that
 // start at their aligned buffer (see fit_tree_group): the weights go through LDS 8192 at a time, eight lanes carry the chains
 __device__ void rebalancing_weights_mirror_body(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts, float* __restrict__ info12, float* sx /* [8192] */,
-                                                FitScratch* fs) {
+                                                FitScratch* fs, const uint32_t* __restrict__ pow_codes, int pow_n) {
     constexpr int CH = 8192;
     const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
     const ReduxPlan plan = redux_plan(M, 0);
@@ -2118,8 +2248,9 @@ __device__ void rebalancing_weights_mirror_body(const int32_t* __restrict__ seg_
         for (int u = 0; u < CH / 1024; ++u) {
             const int il = u * 1024 + threadIdx.x, g = m0 + il;
             if (g < M) {
-                const float w = (1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f;
+                const float w = pow_minus_one(seg_off[g + 1] - seg_off[g], pow_codes, pow_n) * 1.0f;  // * obervationWeights (1.0, :175)
                 sx[il] = w;
+                info12[(size_t)g * 12 + 9] = w;
                 const int slot = redux_slot(plan, g);
                 if (slot >= 0) fs->sp[0][slot] = w;
             }
@@ -2136,869 +2267,8 @@ __device__ void rebalancing_weights_mirror_body(const int32_t* __restrict__ seg_
     }
     __syncthreads();
     const float mean = fs->mean[0];
-    for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = ((1.0f / (float)(seg_off[g + 1] - seg_off[g])) * 1.0f) / mean;
+    for (int g = threadIdx.x; g < M; g += 1024) info12[(size_t)g * 12 + 9] = info12[(size_t)g * 12 + 9] / mean;
 }
-__global__ __launch_bounds__(1024) void k_rebalancing_weights_mirror(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts,
-                                                                     float* __restrict__ info12) {
-    __shared__ float s_x[8192];
-    __shared__ FitScratch s_fs;
-    rebalancing_weights_mirror_body(seg_off, counts, info12, s_x, &s_fs);
-}
-void launch_rebalancing_weights(const int32_t* seg_off, GaussCounts* counts, float* info12, bool mirror, hipStream_t s) {
-    if (mirror)
-        hipLaunchKernelGGL(k_rebalancing_weights_mirror, dim3(1), dim3(1024), 0, s, seg_off, counts, info12);
-    else
-        hipLaunchKernelGGL(k_rebalancing_weights, dim3(1), dim3(1024), 0, s, seg_off, counts, info12);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// K4 — correspondence kernel: fused rigid transform + per-Gaussian mean + sum of Mahalanobis terms
-// ------------------------------------------------------------------------------------------------------------
-// Work split: workgroup w owns the Gaussians whose first member falls into the w-th equal slice of the membership
-// array, so every workgroup streams about Mm / num_wg contiguous float4s.
-__global__ void k_segment_partition(const int32_t* __restrict__ seg_off, int M, int num_wg, int32_t* __restrict__ wg_seg) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w > num_wg) return;
-    if (w == num_wg) {
-        wg_seg[w] = M;
-        return;
-    }
-    const long long Mm = seg_off[M];
-    const int target = (int)((Mm * w) / num_wg);
-    int lo = 0, hi = M;  // first g with seg_off[g] >= target
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (seg_off[mid] < target)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    wg_seg[w] = lo;
-}
-void launch_segment_partition(const int32_t* seg_off, int M, int num_wg, int32_t* wg_seg, hipStream_t s) {
-    hipLaunchKernelGGL(k_segment_partition, dim3((num_wg + 1 + 255) / 256), dim3(256), 0, s, seg_off, M, num_wg, wg_seg);
-}
-
-// blockIdx.y selects the pose table (evaluation); its dense table sits in LDS ((n_t+1) x 48 B) so the per-point row
-// lookup never leaves the CU.  Gaussians are very unevenly sized (median ~15 members, maximum > 10^4): sets below
-// `big_n` members are handled one per wave (round-robin over the workgroup's waves), larger ones by all waves of the
-// workgroup together with a fixed-order cross-wave combine through LDS — results do not depend on scheduling.
-struct ResidualAcc {
-    float sx, sy, sz;
-};
-
-template <bool kTableInLds>
-__global__ __launch_bounds__(512) void k_residuals(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off,
-                                                   const float4* __restrict__ info12, const float4* __restrict__ tables, int rows, int M,
-                                                   const int32_t* __restrict__ wg_seg, int seg_stride, int big_n, double* __restrict__ E, int64_t ldE) {
-    extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
-    // layout: [0, 256 B) cross-wave scratch, then the pose table
-    float* s_red = reinterpret_cast<float*>(s_dyn);            // 8 waves x 4 floats
-    double* s_redd = reinterpret_cast<double*>(s_dyn) + 16;    // 8 doubles at byte 128
-    float4* s_tab = s_dyn + 16;
-    const int b = blockIdx.y;
-    const float4* gtab = tables + (size_t)b * rows * 3;
-    if (kTableInLds) {
-        for (int i = threadIdx.x; i < rows * 3; i += blockDim.x) s_tab[i] = gtab[i];
-    }
-    __syncthreads();
-    const float4* T = kTableInLds ? s_tab : gtab;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    // seg_stride 1: consecutive boundaries wg_seg[w], wg_seg[w+1]; seg_stride 2: explicit (begin, end) pairs
-    const int g_begin = wg_seg[blockIdx.x * seg_stride], g_end = wg_seg[blockIdx.x * seg_stride + 1];
-    int small_turn = 0;
-    for (int g = g_begin; g < g_end; ++g) {
-        const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
-        const bool coop = n >= big_n;  // uniform over the workgroup
-        if (!coop) {
-            const bool mine = (small_turn % nw) == wave;
-            ++small_turn;
-            if (!mine) continue;
-        }
-        const int j0 = coop ? wave * 64 + lane : lane;
-        const int jstep = coop ? nw * 64 : 64;
-        // pass 1: mean of the transformed members (float, DmsaOptimizer.h:247-254)
-        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-        for (int j = j0; j < n; j += jstep) {
-            const float4 p = memb[off0 + j];
-            const int row = __float_as_int(p.w);
-            const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p.x, p.y, p.z);
-            sx += q.x, sy += q.y, sz += q.z;
-        }
-        sx = wave_allsum(sx), sy = wave_allsum(sy), sz = wave_allsum(sz);
-        if (coop) {
-            if (lane == 0) s_red[4 * wave] = sx, s_red[4 * wave + 1] = sy, s_red[4 * wave + 2] = sz;
-            __syncthreads();
-            sx = 0.0f, sy = 0.0f, sz = 0.0f;
-            for (int w = 0; w < nw; ++w) sx += s_red[4 * w], sy += s_red[4 * w + 1], sz += s_red[4 * w + 2];
-        }
-        const float nf = (float)n;
-        const float mx = sx / nf, my = sy / nf, mz = sz / nf;
-        // information matrix (column-major) + rebalancing weight: 3 float4 per Gaussian
-        const float4 i0 = info12[3 * g], i1 = info12[3 * g + 1], i2 = info12[3 * g + 2];
-        const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
-        // pass 2: sum_j (float)((w d^T) A d) accumulated in double (DmsaOptimizer.h:259-264)
-        double acc = 0.0;
-        for (int j = j0; j < n; j += jstep) {
-            const float4 p = memb[off0 + j];
-            const int row = __float_as_int(p.w);
-            const float3 q = apply_row3(T[3 * row], T[3 * row + 1], T[3 * row + 2], p.x, p.y, p.z);
-            const float d0 = q.x - mx, d1 = q.y - my, d2 = q.z - mz;
-            const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
-            const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
-            const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
-            const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
-            acc += (double)sum3f(v0 * d0, v1 * d1, v2 * d2);
-        }
-        acc = wave_allsum(acc);
-        if (coop) {
-            if (lane == 0) s_redd[wave] = acc;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double tot = 0.0;
-                for (int w2 = 0; w2 < nw; ++w2) tot += s_redd[w2];
-                E[(size_t)b * ldE + g] = sqrt(fabs(tot));
-            }
-            __syncthreads();  // scratch is reused by the next cooperative Gaussian
-        } else if (lane == 0) {
-            E[(size_t)b * ldE + g] = sqrt(fabs(acc));
-        }
-    }
-}
-
-// ---- tiled correspondence kernels -----------------------------------------------------------------------------------
-// The membership array is cut into tiles of whole Gaussians (<= kTilePoints members).  A workgroup loads its tile ONCE
-// into registers and then loops over the pose tables of its evaluation chunk: per table it stages only the rows its
-// tile references (a few dozen of the ~1000, found once per iteration by k_tile_rows) into LDS, transforms every point
-// once into an LDS SoA buffer, and lets its waves sweep the Gaussians of the tile out of LDS.  HBM sees each member
-// once per launch; everything per evaluation runs out of registers and LDS.
-constexpr int kTilePoints = 4096;
-constexpr int kTileThreads = 512;
-constexpr int kTilePpt = kTilePoints / kTileThreads;   // 8 members per thread
-constexpr int kTileGauss = 128;                         // Gaussians per tile (keeps the per-Gaussian LDS arrays small)
-// Tile slots: every Gaussian starts at a multiple of kTilePpt slots of the tile copy of the membership array (pad_off) and
-// its tail is filled with NULL slots, so the 8 slots of a thread always belong to ONE Gaussian: no partial sums inside a thread,
-// the information matrix / mean are read once per thread, the per-Gaussian prefix samples are the thread's inclusive prefix.
-// packed .w of a slot: bits 0-11 rank of its pose-table row in the tile's row list (null slots: the all-zero row appended after
-// the list, which transforms any point to exactly 0), bits 12-21 Gaussian index inside the tile, bit 30 null slot, bit 31 set on
-// the LAST SLOT of a Gaussian.
-__device__ __forceinline__ int tw_row(int w) { return w & 0xfff; }
-__device__ __forceinline__ int tw_gauss(int w) { return (w >> 12) & 0x3ff; }
-__device__ __forceinline__ bool tw_end(int w) { return w < 0; }
-__device__ __forceinline__ bool tw_null(int w) { return (w & 0x40000000) != 0; }
-
-constexpr int kBuildTilesLdsInts = 36 * 1024;  // 144 KB
-__global__ __launch_bounds__(1024) void k_build_tiles(const int32_t* __restrict__ seg_off_g, const GaussCounts* __restrict__ counts,
-                                                      TileDesc* __restrict__ tiles, TileCounts* __restrict__ tc, int2* __restrict__ fallback,
-                                                      const int32_t* __restrict__ pad_off_g) {
-    __shared__ int s_wave[16];
-    __shared__ int s_nbig;
-    extern __shared__ int s_lds[];             // seg_off and pad_off staged in LDS when they fit (coalesced read, random access after)
-    const int M = counts->level[0].num_gauss + counts->level[1].num_gauss;
-    const int half = 3 * kTilePoints / 4;      // window of SLOT positions that starts a new tile
-    const int own_n = kTilePoints / 4;         // Gaussians above this size get a tile of their own (tile <= window + own_n slots)
-    if (threadIdx.x == 0) s_nbig = 0;
-    const bool in_lds = 2 * (M + 1) <= kBuildTilesLdsInts;
-    int* s_seg = s_lds;
-    int* s_pad = s_lds + (M + 1);
-    if (in_lds) {  // 16-byte loads: the staging is the latency of this single-workgroup kernel
-        const int n4 = (M + 1) / 4;
-        const int4* seg4 = reinterpret_cast<const int4*>(seg_off_g);
-        const int4* pad4 = reinterpret_cast<const int4*>(pad_off_g);
-        for (int i = threadIdx.x; i < n4; i += 1024) {
-            const int4 a = seg4[i], b = pad4[i];
-            s_seg[4 * i] = a.x, s_seg[4 * i + 1] = a.y, s_seg[4 * i + 2] = a.z, s_seg[4 * i + 3] = a.w;
-            s_pad[4 * i] = b.x, s_pad[4 * i + 1] = b.y, s_pad[4 * i + 2] = b.z, s_pad[4 * i + 3] = b.w;
-        }
-        for (int i = 4 * n4 + threadIdx.x; i <= M; i += 1024) s_seg[i] = seg_off_g[i], s_pad[i] = pad_off_g[i];
-    }
-    __syncthreads();
-    const int32_t* seg_off = in_lds ? s_seg : seg_off_g;
-    const int32_t* pad_off = in_lds ? s_pad : pad_off_g;  // slot offsets (members rounded up to 8 per Gaussian), written by k_gather_members
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // every thread owns a contiguous run of Gaussians
-    const int per = (M + 1023) / 1024;
-    const int g_lo = min(M, per * (int)threadIdx.x), g_hi = min(M, g_lo + per);
-    auto own = [&](int g) { return seg_off[g + 1] - seg_off[g] > own_n; };
-    // a tile ends at own-tile Gaussians, at window boundaries of the slot positions and every kTileGauss Gaussians
-    auto head = [&](int g) { return g == 0 || own(g) || own(g - 1) || (pad_off[g] / half) != (pad_off[g - 1] / half) || (g % kTileGauss) == 0; };
-    // count the tile heads of the run, scan the counts once, then number the tiles
-    int cnt = 0;
-    for (int g = g_lo; g < g_hi; ++g) cnt += head(g) ? 1 : 0;
-    int v = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d);
-        if (lane >= d) v += o;
-    }
-    if (lane == 63) s_wave[wave] = v;
-    __syncthreads();
-    int t = v - cnt;  // tiles started before this thread's run
-    int total = 0;
-    for (int w = 0; w < 16; ++w) {
-        if (w < wave) t += s_wave[w];
-        total += s_wave[w];
-    }
-    for (int g = g_lo; g < g_hi; ++g) {
-        if (head(g)) {
-            const int n = seg_off[g + 1] - seg_off[g];
-            tiles[t].g0 = g, tiles[t].p0 = pad_off[g];
-            const int kind = n > kTilePoints ? 1 : 0;  // 1: streamed by k_residuals_big, any size
-            tiles[t].kind = kind;
-            tiles[t].row_off = 0, tiles[t].nrows = 0, tiles[t].pad = 0;
-            if (kind == 1) fallback[atomicAdd(&s_nbig, 1)] = make_int2(t, g);
-            ++t;
-        }
-        if (g == M - 1 || head(g + 1)) {
-            // slots [p0, p1): padded for staged tiles; a single streamed Gaussian ends at its last real member
-            const int n = seg_off[g + 1] - seg_off[g];
-            const bool big = n > kTilePoints;  // such a Gaussian is the head and the only member of its tile
-            tiles[t - 1].g1 = g + 1, tiles[t - 1].p1 = big ? pad_off[g] + n : pad_off[g + 1];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) tc->num_tiles = total, tc->num_fallback = s_nbig, tc->max_rows = 0, tc->max_gauss = 0;
-}
-
-// Per tile: which pose-table rows do its members reference?  Writes the ascending row list, the SLOT copy of the members
-// (every Gaussian at its padded offset, .w = rank of the row in that list + Gaussian-in-tile + flags, null slots behind the last
-// member) and the maximum list length + 1 (sizes the LDS table of the kernels; the extra row is the all-zero row of null slots).
-__global__ __launch_bounds__(1024) void k_tile_rows(TileDesc* __restrict__ tiles, TileCounts* __restrict__ tc, const float4* __restrict__ memb,
-                                                   const int32_t* __restrict__ memb_g, const int32_t* __restrict__ seg_off,
-                                                   const int32_t* __restrict__ pad_off, int rows, float4* __restrict__ memb_tile,
-                                                   int32_t* __restrict__ tile_rows) {
-    extern __shared__ uint32_t s_bm[];  // words bitmap, then words prefix
-    __shared__ int s_nrows;
-    const int words = (rows + 31) / 32;
-    uint32_t* s_pre = s_bm + words;
-    const int nt = tc->num_tiles;
-    int wg_max_rows = 0, wg_max_gauss = 0;  // thread 0 only; published once per workgroup
-    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
-        const int tg0 = tiles[t].g0, tg1 = tiles[t].g1;
-        const int p0 = seg_off[tg0], p1 = seg_off[tg1];  // member positions of the tile in the (unpadded) membership array
-        for (int w = threadIdx.x; w < words; w += blockDim.x) s_bm[w] = 0u;
-        __syncthreads();
-        for (int i0 = p0 + threadIdx.x; i0 < p1; i0 += 4 * blockDim.x) {  // four independent loads in flight per lane
-            int row[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * blockDim.x;
-                row[u] = i < p1 ? __float_as_int(memb[i].w) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int prev = __shfl_up(row[u], 1);
-                if (row[u] >= 0 && ((threadIdx.x & 63) == 0 || prev != row[u])) atomicOr(&s_bm[row[u] >> 5], 1u << (row[u] & 31));
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t acc = 0;
-            for (int w = 0; w < words; ++w) {
-                s_pre[w] = acc;
-                acc += __popc(s_bm[w]);
-            }
-            tiles[t].row_off = t * rows;
-            tiles[t].nrows = (int)acc;
-            s_nrows = (int)acc;
-            wg_max_rows = max(wg_max_rows, (int)acc + 1), wg_max_gauss = max(wg_max_gauss, tg1 - tg0);
-        }
-        __syncthreads();
-        const uint32_t zero_row = (uint32_t)s_nrows;  // rank of the all-zero row the kernels append to the tile's rows
-        for (int w = threadIdx.x; w < words; w += blockDim.x) {
-            uint32_t bits = s_bm[w];
-            int k = (int)s_pre[w];
-            while (bits) {
-                const int bit = __ffs(bits) - 1;
-                tile_rows[(size_t)t * rows + k] = w * 32 + bit;
-                ++k;
-                bits &= bits - 1;
-            }
-        }
-        for (int i0 = p0 + threadIdx.x; i0 < p1; i0 += 4 * blockDim.x) {
-            float4 pv[4];
-            uint32_t gm[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * blockDim.x;
-                if (i < p1) pv[u] = memb[i], gm[u] = (uint32_t)memb_g[i];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * blockDim.x;
-                if (i < p1) {
-                    const int row = __float_as_int(pv[u].w);
-                    const int lrow = (int)s_pre[row >> 5] + __popc(s_bm[row >> 5] & ((1u << (row & 31)) - 1u));
-                    const int g = (int)(gm[u] & 0x7fffffffu);
-                    const bool last = (gm[u] & 0x80000000u) != 0;
-                    const int gb = seg_off[g], slot = pad_off[g] + (i - gb);
-                    const uint32_t gbits = (uint32_t)(g - tg0) << 12;
-                    const int nulls = last ? pad_off[g] + pad_slots(i + 1 - gb) - (slot + 1) : 0;  // slots behind the last member
-                    pv[u].w = __int_as_float((int)((uint32_t)lrow | gbits | ((last && nulls == 0) ? 0x80000000u : 0u)));
-                    memb_tile[slot] = pv[u];
-                    for (int z = 1; z <= nulls; ++z)
-                        memb_tile[slot + z] = make_float4(0.f, 0.f, 0.f, __int_as_float((int)(zero_row | gbits | 0x40000000u | (z == nulls ? 0x80000000u : 0u))));
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && wg_max_rows > 0) {
-        atomicMax(&tc->max_rows, wg_max_rows);
-        atomicMax(&tc->max_gauss, wg_max_gauss);
-    }
-}
-void launch_build_tiles(const int32_t* seg_off, const GaussCounts* counts, const float4* memb, const int32_t* memb_g, int rows, TileDesc* tiles,
-                        TileCounts* tc, int2* fallback, float4* memb_tile, int32_t* tile_rows, int32_t* pad_off, hipStream_t s) {
-    static bool bt_attr = false;
-    if (!bt_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, kBuildTilesLdsInts * 4);
-        bt_attr = true;
-    }
-    hipLaunchKernelGGL(k_build_tiles, dim3(1), dim3(1024), kBuildTilesLdsInts * 4, s, seg_off, counts, tiles, tc, fallback, pad_off);
-    const size_t lds = (size_t)((rows + 31) / 32) * 8;
-    hipLaunchKernelGGL(k_tile_rows, dim3(1024), dim3(1024), lds, s, tiles, tc, memb, memb_g, seg_off, pad_off, rows, memb_tile, tile_rows);
-}
-int tile_points() { return kTilePoints; }
-
-// Balanced sweep: thread t owns the 8 consecutive members 8t..8t+7 of the tile, so every lane does the same work no matter
-// how the tile is cut into Gaussians.  Per-Gaussian sums come from workgroup-wide inclusive prefix sums in double that are
-// sampled at the last member of each Gaussian (sum_g = P[end_g] - P[end_{g-1}]); a double prefix over <= 4096 float terms
-// carries ~1e-12 relative error, far below the float rounding of the terms themselves, and the order is fixed.
-__device__ __forceinline__ double wave_incl_scan(double v, int) { return wave_incl_scan_dpp(v); }
-
-// LDS carve of k_residuals_tiles (bytes).  Prefix samples and wave totals are double-buffered by evaluation parity so
-// that one evaluation needs only three workgroup barriers.
-constexpr int kRtOffInfo = 0;                                                  // 3 float4 per Gaussian
-constexpr int kRtOffEnd = kRtOffInfo + kTileGauss * 48;                        // [2][4][kTileGauss + 1] doubles
-constexpr int kRtOffEndW = kRtOffEnd + 2 * 4 * (kTileGauss + 1) * 8;           // [2][kTileGauss + 1] int (wave of the end member)
-constexpr int kRtOffWave = (kRtOffEndW + 2 * (kTileGauss + 1) * 4 + 7) / 8 * 8; // [2][8][4] doubles
-constexpr int kRtOffMean = kRtOffWave + 2 * 8 * 4 * 8;                          // [3][kTileGauss] floats
-constexpr int kRtOffNf = kRtOffMean + 3 * kTileGauss * 4;                       // [kTileGauss] floats
-constexpr int kRtOffTab = (kRtOffNf + kTileGauss * 4 + 15) / 16 * 16;           // [2][max_rows][3] float4
-
-template <int kMinWaves>
-__global__ __launch_bounds__(kTileThreads, kMinWaves) void k_residuals_tiles(const float4* __restrict__ memb_tile, const int32_t* __restrict__ seg_off,
-                                                                             const float4* __restrict__ info12, const float4* __restrict__ tables,
-                                                                             int rows, const TileDesc* __restrict__ tiles,
-                                                                             const int32_t* __restrict__ tile_rows, int B, int b_chunk, int max_rows, int max_gauss,
-                                                                             double* __restrict__ E, int64_t ldE, long long* __restrict__ phase_clk) {
-    const TileDesc td = tiles[blockIdx.x];
-    if (td.kind != 0) return;
-    extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
-    char* s_base = reinterpret_cast<char*>(s_dyn);
-    float4* s_info = reinterpret_cast<float4*>(s_base + kRtOffInfo);
-    double* s_end = reinterpret_cast<double*>(s_base + kRtOffEnd);
-    int* s_endw = reinterpret_cast<int*>(s_base + kRtOffEndW);
-    double* s_wave = reinterpret_cast<double*>(s_base + kRtOffWave);
-    float* s_mean = reinterpret_cast<float*>(s_base + kRtOffMean);
-    float* s_nf = reinterpret_cast<float*>(s_base + kRtOffNf);
-    float4* s_tab = reinterpret_cast<float4*>(s_base + kRtOffTab);
-    double* s_out = reinterpret_cast<double*>(s_tab + (size_t)2 * max_rows * 3);  // [b_chunk][max_gauss] residuals of this chunk
-    constexpr int kEndStride = kTileGauss + 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int np = td.p1 - td.p0, ng = td.g1 - td.g0;
-    float4 pt[kTilePpt];
-#pragma unroll
-    for (int k = 0; k < kTilePpt; ++k) {
-        const int i = kTilePpt * tid + k;
-        const float4 v = memb_tile[td.p0 + min(i, np - 1)];  // unconditional load + select keeps pt[] in registers
-        pt[k] = i < np ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const bool wave_on = kTilePpt * 64 * wave < np;  // wave-uniform: does this wave own any slot?
-    // the 8 slots of a thread belong to ONE Gaussian (slot layout of k_tile_rows); its last slot carries the end flag
-    const int my_g = tw_gauss(__float_as_int(pt[0].w));
-    const bool is_end = tw_end(__float_as_int(pt[kTilePpt - 1].w)) && kTilePpt * tid < np;
-    unsigned null_mask = 0;  // null slots transform to exactly 0 (zero row) and their Mahalanobis terms are dropped
-#pragma unroll
-    for (int k = 0; k < kTilePpt; ++k) null_mask |= (tw_null(__float_as_int(pt[k].w)) ? 1u : 0u) << k;
-    for (int q = tid; q < 3 * ng; q += kTileThreads) s_info[q] = info12[3 * td.g0 + q];
-    for (int g = tid; g < ng; g += kTileThreads) s_nf[g] = (float)(seg_off[td.g0 + g + 1] - seg_off[td.g0 + g]);
-    if (tid < 8) s_end[tid * kEndStride] = 0.0;  // prefix "before the first Gaussian", both parities x 4 components
-    if (tid < 2) s_endw[tid * kEndStride] = 0;
-    const int32_t* my_rows = tile_rows + td.row_off;
-    const int b_begin = blockIdx.y * b_chunk, b_end = min(B, b_begin + b_chunk);
-    // pose-table rows: registers hold the rows of evaluation b+1 while b computes; LDS holds b (parity b&1)
-    const int nq = td.nrows * 3;
-    int src0 = -1, src1 = -1, src2 = -1;
-    if (tid < nq) src0 = 3 * my_rows[tid / 3] + (tid % 3);
-    if (tid + kTileThreads < nq) src1 = 3 * my_rows[(tid + kTileThreads) / 3] + ((tid + kTileThreads) % 3);
-    if (tid + 2 * kTileThreads < nq) src2 = 3 * my_rows[(tid + 2 * kTileThreads) / 3] + ((tid + 2 * kTileThreads) % 3);
-    const bool direct = nq > 3 * kTileThreads;  // tiles referencing > 512 rows: plain staging (two extra barriers)
-    if (tid < 6) s_tab[(size_t)(tid / 3) * max_rows * 3 + nq + (tid % 3)] = make_float4(0.f, 0.f, 0.f, 0.f);  // the zero row, both parities
-    float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0, nx2 = nx0;
-    if (b_begin < b_end && !direct) {
-        const float4* gtab = tables + (size_t)b_begin * rows * 3;
-        float4* dst = s_tab + (size_t)(b_begin & 1) * max_rows * 3;
-        if (src0 >= 0) dst[tid] = gtab[src0];
-        if (src1 >= 0) dst[tid + kTileThreads] = gtab[src1];
-        if (src2 >= 0) dst[tid + 2 * kTileThreads] = gtab[src2];
-        if (b_begin + 1 < b_end) {
-            const float4* ntab = tables + (size_t)(b_begin + 1) * rows * 3;
-            if (src0 >= 0) nx0 = ntab[src0];
-            if (src1 >= 0) nx1 = ntab[src1];
-            if (src2 >= 0) nx2 = ntab[src2];
-        }
-    }
-    __syncthreads();
-#ifdef DMSA_PHASE_CLOCKS
-    long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long t_prev = clock64();
-#define PHASE(k) { const long long t_now = clock64(); pc[k] += t_now - t_prev; t_prev = t_now; }
-#else
-#define PHASE(k)
-#endif
-    // information matrix / weight of my Gaussian: constant over the evaluations of the chunk
-    const float4 i0 = s_info[3 * my_g], i1 = s_info[3 * my_g + 1], i2 = s_info[3 * my_g + 2];
-    const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
-    PHASE(0)
-    for (int b = b_begin; b < b_end; ++b) {
-        const int pb = b & 1;
-        float4* tab = s_tab + (size_t)pb * max_rows * 3;
-        double* endp = s_end + (size_t)pb * 4 * kEndStride;
-        int* endw = s_endw + pb * kEndStride;
-        double* wavep = s_wave + pb * 32;
-        if (direct) {
-            __syncthreads();
-            const float4* gtab = tables + (size_t)b * rows * 3;
-            for (int q = tid; q < nq; q += kTileThreads) tab[q] = gtab[3 * my_rows[q / 3] + (q % 3)];
-            __syncthreads();
-        }
-        // ---- transform once (registers), float partial sums over the thread's 8 consecutive members --------------------
-        // Slots past the tile's last member hold (0,0,0,row 0): they transform to finite values that only enter prefixes
-        // AFTER the last Gaussian end, so no per-slot range checks are needed; waves entirely past the end idle.
-        float gx[kTilePpt], gy[kTilePpt], gz[kTilePpt];
-        float fx = 0.0f, fy = 0.0f, fz = 0.0f;
-        if (wave_on) {
-#pragma unroll
-            for (int k = 0; k < kTilePpt; ++k) {
-                const int row = tw_row(__float_as_int(pt[k].w));
-                const float3 q = apply_row3(tab[3 * row], tab[3 * row + 1], tab[3 * row + 2], pt[k].x, pt[k].y, pt[k].z);
-                gx[k] = q.x, gy[k] = q.y, gz[k] = q.z;
-                fx += q.x, fy += q.y, fz += q.z;
-                if (k & 1) asm volatile("" ::: "memory");  // no hoisting of later members' LDS reads: bounds live registers
-            }
-        }
-        PHASE(1)
-        // ---- pass 1: wave-local fp64 prefix of the thread totals, sampled at Gaussian ends ------------------------------
-        {
-            const double tx = (double)fx, ty = (double)fy, tz = (double)fz;
-            const double ix = wave_incl_scan_dpp(tx), iy = wave_incl_scan_dpp(ty), iz = wave_incl_scan_dpp(tz);
-            if (lane == 63) wavep[4 * wave] = ix, wavep[4 * wave + 1] = iy, wavep[4 * wave + 2] = iz;
-            if (is_end) {  // inclusive prefix at the last slot of my Gaussian
-                const int lg = my_g + 1;
-                endp[lg] = ix, endp[kEndStride + lg] = iy, endp[2 * kEndStride + lg] = iz;
-                endw[lg] = wave;
-            }
-        }
-        PHASE(2)
-        // stage the next evaluation's rows (other parity) and fetch the one after
-        if (!direct && b + 1 < b_end) {
-            float4* dst = s_tab + (size_t)(pb ^ 1) * max_rows * 3;
-            if (src0 >= 0) dst[tid] = nx0;
-            if (src1 >= 0) dst[tid + kTileThreads] = nx1;
-            if (src2 >= 0) dst[tid + 2 * kTileThreads] = nx2;
-            if (b + 2 < b_end) {
-                const float4* ntab = tables + (size_t)(b + 2) * rows * 3;
-                if (src0 >= 0) nx0 = ntab[src0];
-                if (src1 >= 0) nx1 = ntab[src1];
-                if (src2 >= 0) nx2 = ntab[src2];
-            }
-        }
-        PHASE(3)
-        __syncthreads();  // B1
-        PHASE(4)
-        // Per-Gaussian sums: difference of two wave-local prefix samples; only a Gaussian that spans waves (at most seven
-        // per tile) adds the totals of the waves it crosses.
-        for (int g = tid; g < ng; g += kTileThreads) {
-            const int w1 = endw[g + 1], w0 = endw[g];
-            const float nf = s_nf[g];
-            double sx = endp[g + 1] - endp[g], sy = endp[kEndStride + g + 1] - endp[kEndStride + g],
-                   sz = endp[2 * kEndStride + g + 1] - endp[2 * kEndStride + g];
-            for (int w2 = w0; w2 < w1; ++w2) sx += wavep[4 * w2], sy += wavep[4 * w2 + 1], sz += wavep[4 * w2 + 2];
-            s_mean[g] = (float)sx / nf, s_mean[kTileGauss + g] = (float)sy / nf, s_mean[2 * kTileGauss + g] = (float)sz / nf;
-        }
-        PHASE(5)
-        __syncthreads();  // B2
-        PHASE(4)
-        // ---- pass 2: Mahalanobis terms (float, reference operation order) ----
-        float fq = 0.0f;
-        if (wave_on) {
-            // mean of my Gaussian: one LDS read per thread and evaluation (the information matrix stays in registers)
-            const float mx = s_mean[my_g], my = s_mean[kTileGauss + my_g], mz = s_mean[2 * kTileGauss + my_g];
-#pragma unroll
-            for (int k = 0; k < kTilePpt; ++k) {
-                const float d0 = gx[k] - mx, d1 = gy[k] - my, d2 = gz[k] - mz;
-                const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
-                const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
-                const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
-                const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
-                const float e = sum3f(v0 * d0, v1 * d1, v2 * d2);
-                fq += (null_mask >> k) & 1u ? 0.0f : e;
-            }
-        }
-        PHASE(6)
-        {
-            const double tq = (double)fq;
-            const double iq = wave_incl_scan_dpp(tq);
-            if (lane == 63) wavep[4 * wave + 3] = iq;
-            if (is_end) endp[3 * kEndStride + my_g + 1] = iq;
-        }
-        PHASE(7)
-        __syncthreads();  // B3
-        PHASE(4)
-        for (int g = tid; g < ng; g += kTileThreads) {
-            const int w1 = endw[g + 1], w0 = endw[g];
-            double tot = endp[3 * kEndStride + g + 1] - endp[3 * kEndStride + g];
-            for (int w2 = w0; w2 < w1; ++w2) tot += wavep[4 * w2 + 3];
-            s_out[(size_t)(b - b_begin) * max_gauss + g] = tot;  // sqrt(|.|) is applied when the chunk is written out
-        }
-        // the next evaluation writes the other parity of endp / endw / wavep; s_mean is rewritten only after its B1
-        PHASE(5)
-    }
-    // residuals leave the workgroup once, coalesced along the Gaussian index (no global stores inside the loop)
-    __syncthreads();
-    for (int q = tid; q < (b_end - b_begin) * ng; q += kTileThreads) {
-        const int bl = q / ng, g = q - bl * ng;
-        E[(size_t)(b_begin + bl) * ldE + td.g0 + g] = sqrt(fabs(s_out[(size_t)bl * max_gauss + g]));
-    }
-#ifdef DMSA_PHASE_CLOCKS
-    if (phase_clk != nullptr && lane == 0 && blockIdx.y == 0)
-        for (int k = 0; k < 8; ++k) phase_clk[((size_t)blockIdx.x * 8 + wave) * 8 + k] = pc[k];
-#endif
-#undef PHASE
-}
-
-// Single-Gaussian tiles (more than kTilePoints members, ~30 % of all members at the benchmark size): one 1024-thread
-// workgroup per (Gaussian, chunk of evaluations).  Its first 16384 members stay in registers (local coordinates) for
-// every evaluation of the chunk, so HBM/L2 sees them once per chunk; both passes transform on the fly.  Members beyond
-// that capacity are streamed per evaluation.
-constexpr int kBigThreads = 1024;
-constexpr int kBigKeep = 12;  // members kept in registers per thread (local coordinates + this evaluation's transformed coordinates)
-__device__ __forceinline__ float3 big_point(const float4* __restrict__ s_tab, const float4 p) {
-    const int row = tw_row(__float_as_int(p.w));
-    return apply_row3(s_tab[3 * row], s_tab[3 * row + 1], s_tab[3 * row + 2], p.x, p.y, p.z);
-}
-__global__ __launch_bounds__(kBigThreads) void k_residuals_big(const float4* __restrict__ memb_tile, const float4* __restrict__ info12,
-                                                              const float4* __restrict__ tables, int rows, const TileDesc* __restrict__ tiles,
-                                                              const int2* __restrict__ big_list, const int32_t* __restrict__ tile_rows, int B,
-                                                              int b_chunk, int max_rows, double* __restrict__ E, int64_t ldE) {
-    const TileDesc td = tiles[big_list[blockIdx.x].x];
-    extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
-    float* s_red = reinterpret_cast<float*>(s_dyn);          // 16 waves x 4 floats (256 B)
-    double* s_redd = reinterpret_cast<double*>(s_dyn) + 32;  // 16 doubles (128 B)
-    float4* s_tab = s_dyn + 24;                              // [2][max_rows][3]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int np = td.p1 - td.p0, g = td.g0;
-    const float4* mp = memb_tile + td.p0;
-    float4 pt[kBigKeep];
-#pragma unroll
-    for (int k = 0; k < kBigKeep; ++k) {
-        const int j = tid + kBigThreads * k;
-        const float4 v = mp[min(j, np - 1)];
-        pt[k] = v;
-    }
-    const float4 i0 = info12[3 * g], i1 = info12[3 * g + 1], i2 = info12[3 * g + 2];
-    const float A00 = i0.x, A10 = i0.y, A20 = i0.z, A01 = i0.w, A11 = i1.x, A21 = i1.y, A02 = i1.z, A12 = i1.w, A22 = i2.x, w = i2.y;
-    const int32_t* my_rows = tile_rows + td.row_off;
-    const int nq = td.nrows * 3;
-    const int b_begin = blockIdx.y * b_chunk, b_end = min(B, b_begin + b_chunk);
-    const float nf = (float)np;
-    for (int b = b_begin; b < b_end; ++b) {
-        float4* tab = s_tab + (size_t)(b & 1) * max_rows * 3;  // double-buffered: one barrier covers staging and reuse
-        const float4* gtab = tables + (size_t)b * rows * 3;
-        for (int q = tid; q < nq; q += kBigThreads) tab[q] = gtab[3 * my_rows[q / 3] + (q % 3)];
-        __syncthreads();
-        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-        float qx[kBigKeep], qy[kBigKeep], qz[kBigKeep];  // transformed once per evaluation, reused by the second pass
-#pragma unroll
-        for (int k = 0; k < kBigKeep; ++k) {
-            const float3 q = big_point(tab, pt[k]);
-            qx[k] = q.x, qy[k] = q.y, qz[k] = q.z;
-            if (tid + kBigThreads * k < np) sx += q.x, sy += q.y, sz += q.z;
-            if ((k & 3) == 3) asm volatile("" ::: "memory");
-        }
-        for (int j = tid + kBigThreads * kBigKeep; j < np; j += kBigThreads) {
-            const float3 q = big_point(tab, mp[j]);
-            sx += q.x, sy += q.y, sz += q.z;
-        }
-        sx = wave_allsum(sx), sy = wave_allsum(sy), sz = wave_allsum(sz);
-        if (lane == 0) s_red[4 * wave] = sx, s_red[4 * wave + 1] = sy, s_red[4 * wave + 2] = sz;
-        __syncthreads();
-        sx = 0.0f, sy = 0.0f, sz = 0.0f;
-        for (int w2 = 0; w2 < kBigThreads / 64; ++w2) sx += s_red[4 * w2], sy += s_red[4 * w2 + 1], sz += s_red[4 * w2 + 2];
-        const float mx = sx / nf, my = sy / nf, mz = sz / nf;
-        double acc = 0.0;
-        auto term = [&](const float3 q) {
-            const float d0 = q.x - mx, d1 = q.y - my, d2 = q.z - mz;
-            const float wd0 = w * d0, wd1 = w * d1, wd2 = w * d2;
-            const float v0 = sum3f(wd0 * A00, wd1 * A10, wd2 * A20);
-            const float v1 = sum3f(wd0 * A01, wd1 * A11, wd2 * A21);
-            const float v2 = sum3f(wd0 * A02, wd1 * A12, wd2 * A22);
-            return (double)sum3f(v0 * d0, v1 * d1, v2 * d2);
-        };
-#pragma unroll
-        for (int k = 0; k < kBigKeep; ++k) {
-            if (tid + kBigThreads * k < np) acc += term(make_float3(qx[k], qy[k], qz[k]));
-        }
-        for (int j = tid + kBigThreads * kBigKeep; j < np; j += kBigThreads) acc += term(big_point(tab, mp[j]));
-        acc = wave_allsum(acc);
-        if (lane == 0) s_redd[wave] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            double tot = 0.0;
-            for (int w2 = 0; w2 < kBigThreads / 64; ++w2) tot += s_redd[w2];
-            E[(size_t)b * ldE + g] = sqrt(fabs(tot));
-        }
-        // s_red / s_redd are rewritten only after the next evaluation's first barrier
-    }
-}
-
-// ---- tiled Gaussian fit --------------------------------------------------------------------------------------------
-// Same tiles as the correspondence kernel, evaluated once per iteration on the base pose table: members are transformed
-// in registers (bit-identical to k_transform), column sums and centred products are accumulated in fp64 and turned into
-// per-Gaussian sums by workgroup prefix sums sampled at Gaussian ends — every lane does the same work however uneven the
-// Gaussians are.  Replaces the wave-per-Gaussian k_gauss_fit (random gathers, one wave per 10^4-member Gaussian).
-constexpr int kFitOffEnd = 0;
-constexpr int kFitOffMean = kFitOffEnd + 9 * (kTileGauss + 1) * 8;
-constexpr int kFitOffWave = (kFitOffMean + 3 * kTileGauss * 4 + 7) / 8 * 8;
-constexpr int kFitOffTab = (kFitOffWave + 8 * 9 * 8 + 15) / 16 * 16;
-__global__ __launch_bounds__(kTileThreads, 2) void k_fit_tiles(const float4* __restrict__ memb_tile, const int32_t* __restrict__ seg_off,
-                                                               const float4* __restrict__ table0, const TileDesc* __restrict__ tiles,
-                                                               const TileCounts* __restrict__ tc, const int32_t* __restrict__ tile_rows,
-                                                               float* __restrict__ info12) {
-    extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
-    char* s_base = reinterpret_cast<char*>(s_dyn);
-    double* s_end = reinterpret_cast<double*>(s_base + kFitOffEnd);    // [9][kTileGauss + 1]
-    float* s_mean = reinterpret_cast<float*>(s_base + kFitOffMean);    // [3][kTileGauss]
-    double* s_wave = reinterpret_cast<double*>(s_base + kFitOffWave);  // 8 waves x 9
-    float4* s_tab = reinterpret_cast<float4*>(s_base + kFitOffTab);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = tc->num_tiles;
-    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
-        const TileDesc td = tiles[t];
-        if (td.kind != 0) continue;  // uniform
-        const int np = td.p1 - td.p0, ng = td.g1 - td.g0;
-        __syncthreads();
-        for (int q = tid; q < td.nrows * 3; q += kTileThreads) s_tab[q] = table0[3 * tile_rows[td.row_off + q / 3] + (q % 3)];
-        if (tid < 3) s_tab[td.nrows * 3 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // the zero row of the null slots
-        if (tid < 9) s_end[tid * (kTileGauss + 1)] = 0.0;
-        __syncthreads();
-        // the 8 slots of a thread belong to one Gaussian (slot layout of k_tile_rows)
-        float gx[kTilePpt], gy[kTilePpt], gz[kTilePpt];
-        unsigned null_mask = 0;
-        int w0 = 0, w7 = 0;
-        double acc[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < kTilePpt; ++k) {
-            const int i = kTilePpt * tid + k;
-            const float4 v = memb_tile[td.p0 + min(i, np - 1)];
-            const float4 p = i < np ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            const int wv = __float_as_int(p.w);
-            if (k == 0) w0 = wv;
-            if (k == kTilePpt - 1) w7 = wv;
-            null_mask |= (tw_null(wv) ? 1u : 0u) << k;
-            const int row = tw_row(wv);
-            const float3 q = apply_row3(s_tab[3 * row], s_tab[3 * row + 1], s_tab[3 * row + 2], p.x, p.y, p.z);
-            gx[k] = q.x, gy[k] = q.y, gz[k] = q.z;
-            acc[0] += (double)q.x, acc[1] += (double)q.y, acc[2] += (double)q.z;
-            asm volatile("" ::: "memory");
-        }
-        const int my_g = tw_gauss(w0);
-        const bool is_end = tw_end(w7) && kTilePpt * tid < np;
-        double inc3[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            inc3[c] = wave_incl_scan_dpp(acc[c]);
-            if (lane == 63) s_wave[9 * wave + c] = inc3[c];
-        }
-        __syncthreads();
-        if (is_end) {
-            for (int c = 0; c < 3; ++c) {
-                double r = inc3[c];
-                for (int w2 = 0; w2 < wave; ++w2) r += s_wave[9 * w2 + c];
-                s_end[c * (kTileGauss + 1) + my_g + 1] = r;
-            }
-        }
-        __syncthreads();
-        for (int g = tid; g < ng; g += kTileThreads) {
-            const double n = (double)(seg_off[td.g0 + g + 1] - seg_off[td.g0 + g]);
-            for (int c = 0; c < 3; ++c) s_mean[c * kTileGauss + g] = (float)((s_end[c * (kTileGauss + 1) + g + 1] - s_end[c * (kTileGauss + 1) + g]) / n);
-        }
-        __syncthreads();
-        double a6[6] = {0, 0, 0, 0, 0, 0};
-        {
-            const float mx = s_mean[my_g], my = s_mean[kTileGauss + my_g], mz = s_mean[2 * kTileGauss + my_g];
-#pragma unroll
-            for (int k = 0; k < kTilePpt; ++k) {
-                const bool nul = (null_mask >> k) & 1u;
-                const float cx = nul ? 0.0f : gx[k] - mx, cy = nul ? 0.0f : gy[k] - my, cz = nul ? 0.0f : gz[k] - mz;
-                a6[0] += (double)cx * (double)cx, a6[1] += (double)cx * (double)cy, a6[2] += (double)cx * (double)cz;
-                a6[3] += (double)cy * (double)cy, a6[4] += (double)cy * (double)cz, a6[5] += (double)cz * (double)cz;
-            }
-        }
-        double inc6[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            inc6[c] = wave_incl_scan_dpp(a6[c]);
-            if (lane == 63) s_wave[9 * wave + 3 + c] = inc6[c];
-        }
-        __syncthreads();
-        if (is_end) {
-            for (int c = 0; c < 6; ++c) {
-                double r = inc6[c];
-                for (int w2 = 0; w2 < wave; ++w2) r += s_wave[9 * w2 + 3 + c];
-                s_end[(3 + c) * (kTileGauss + 1) + my_g + 1] = r;
-            }
-        }
-        __syncthreads();
-        for (int g = tid; g < ng; g += kTileThreads) {
-            double a[6];
-            for (int c = 0; c < 6; ++c) a[c] = s_end[(3 + c) * (kTileGauss + 1) + g + 1] - s_end[(3 + c) * (kTileGauss + 1) + g];
-            finish_gaussian(a[0], a[1], a[2], a[3], a[4], a[5], seg_off[td.g0 + g + 1] - seg_off[td.g0 + g], info12 + (size_t)(td.g0 + g) * 12);
-        }
-    }
-}
-
-// single-Gaussian tiles: one 1024-thread workgroup streams the members (fp64 block reductions)
-__global__ __launch_bounds__(kBigThreads) void k_fit_big(const float4* __restrict__ memb_tile, const float4* __restrict__ table0,
-                                                        const TileDesc* __restrict__ tiles, const TileCounts* __restrict__ tc,
-                                                        const int2* __restrict__ big_list, const int32_t* __restrict__ tile_rows,
-                                                        float* __restrict__ info12) {
-    extern __shared__ __attribute__((aligned(16))) float4 s_dyn[];
-    double* s_red = reinterpret_cast<double*>(s_dyn);  // 16 waves x 6 doubles (768 B)
-    float4* s_tab = s_dyn + 48;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nbig = tc->num_fallback;
-    for (int bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
-        const TileDesc td = tiles[big_list[bi].x];
-        const int np = td.p1 - td.p0, g = td.g0;
-        const float4* mp = memb_tile + td.p0;
-        __syncthreads();
-        for (int q = tid; q < td.nrows * 3; q += kBigThreads) s_tab[q] = table0[3 * tile_rows[td.row_off + q / 3] + (q % 3)];
-        __syncthreads();
-        double sx = 0.0, sy = 0.0, sz = 0.0;
-        for (int j = tid; j < np; j += kBigThreads) {
-            const float3 q = big_point(s_tab, mp[j]);
-            sx += (double)q.x, sy += (double)q.y, sz += (double)q.z;
-        }
-        sx = wave_allsum(sx), sy = wave_allsum(sy), sz = wave_allsum(sz);
-        if (lane == 0) s_red[6 * wave] = sx, s_red[6 * wave + 1] = sy, s_red[6 * wave + 2] = sz;
-        __syncthreads();
-        sx = 0.0, sy = 0.0, sz = 0.0;
-        for (int w2 = 0; w2 < kBigThreads / 64; ++w2) sx += s_red[6 * w2], sy += s_red[6 * w2 + 1], sz += s_red[6 * w2 + 2];
-        const float mx = (float)(sx / (double)np), my = (float)(sy / (double)np), mz = (float)(sz / (double)np);
-        __syncthreads();
-        double a[6] = {0, 0, 0, 0, 0, 0};
-        for (int j = tid; j < np; j += kBigThreads) {
-            const float3 q = big_point(s_tab, mp[j]);
-            const float cx = q.x - mx, cy = q.y - my, cz = q.z - mz;
-            a[0] += (double)cx * (double)cx, a[1] += (double)cx * (double)cy, a[2] += (double)cx * (double)cz;
-            a[3] += (double)cy * (double)cy, a[4] += (double)cy * (double)cz, a[5] += (double)cz * (double)cz;
-        }
-        for (int c = 0; c < 6; ++c) {
-            a[c] = wave_allsum(a[c]);
-            if (lane == 0) s_red[6 * wave + c] = a[c];
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double t6[6] = {0, 0, 0, 0, 0, 0};
-            for (int w2 = 0; w2 < kBigThreads / 64; ++w2)
-                for (int c = 0; c < 6; ++c) t6[c] += s_red[6 * w2 + c];
-            finish_gaussian(t6[0], t6[1], t6[2], t6[3], t6[4], t6[5], np, info12 + (size_t)g * 12);
-        }
-    }
-}
-
-void launch_fit_tiled(const float4* memb_tile, const int32_t* seg_off, const float* table0, int max_rows, const TileDesc* tiles, const TileCounts* tc,
-                      const int2* big_list, const int32_t* tile_rows, float* info12, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fit_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fit_big), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        attr_set = true;
-    }
-    const size_t lds_tiles = (size_t)kFitOffTab + (size_t)max_rows * 48;
-    const size_t lds_big = 768 + (size_t)max_rows * 48;
-    hipLaunchKernelGGL(k_fit_tiles, dim3(1024), dim3(kTileThreads), lds_tiles, s, memb_tile, seg_off, reinterpret_cast<const float4*>(table0), tiles, tc,
-                       tile_rows, info12);
-    hipLaunchKernelGGL(k_fit_big, dim3(256), dim3(kBigThreads), lds_big, s, memb_tile, reinterpret_cast<const float4*>(table0), tiles, tc, big_list,
-                       tile_rows, info12);
-}
-
-long long* g_phase_clk = nullptr;  // debug: per (tile, wave, phase) cycle counts when built with -DDMSA_PHASE_CLOCKS
-void set_phase_clock_buffer(long long* p) { g_phase_clk = p; }
-
-bool tiled_kernels_fit(int max_rows, int max_gauss) {
-    const size_t limit = 160 * 1024 - 512;
-    const size_t lds_tiles = (size_t)kRtOffTab + (size_t)2 * max_rows * 48 + (size_t)8 * (max_gauss > 0 ? max_gauss : 1);  // at least one evaluation of output
-    const size_t lds_big = 384 + (size_t)2 * max_rows * 48;
-    const size_t lds_fit = (size_t)kFitOffTab + (size_t)max_rows * 48;
-    return max_rows <= 4095 && lds_tiles <= limit && lds_big <= limit && lds_fit <= limit;  // 12-bit row ranks
-}
-void launch_residuals_tiled(const float4* memb_tile, const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables,
-                            int rows, int M, int B, const TileDesc* tiles, const int32_t* tile_rows, int num_tiles, int max_rows, int max_gauss,
-                            const int2* fallback, int num_fallback, int big_n, double* E, int64_t ldE, hipStream_t s) {
-    if (M <= 0 || B <= 0 || num_tiles <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals_tiles<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals_tiles<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals_big), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        attr_set = true;
-    }
-    // evaluations are chunked so that tiles x chunks fills the chip several times over
-    constexpr int target_wgs = 2048;
-    int chunks = (target_wgs + num_tiles - 1) / num_tiles;
-    if (chunks > B) chunks = B;
-    if (chunks < 1) chunks = 1;
-    int b_chunk = (B + chunks - 1) / chunks;
-    const int out_cap = (16 * 1024) / (8 * (max_gauss > 0 ? max_gauss : 1));  // s_out <= 16 KB of LDS
-    if (b_chunk > out_cap) b_chunk = out_cap > 0 ? out_cap : 1;
-    {  // the residuals of a chunk leave through LDS: shrink the chunk if the tile's pose rows leave less room
-        const size_t base = (size_t)kRtOffTab + (size_t)2 * max_rows * 48, limit = 160 * 1024 - 512;
-        const size_t room = limit > base ? (limit - base) / ((size_t)8 * (max_gauss > 0 ? max_gauss : 1)) : 1;
-        if ((size_t)b_chunk > room) b_chunk = room > 0 ? (int)room : 1;
-    }
-    chunks = (B + b_chunk - 1) / b_chunk;
-    const size_t lds_tiles = (size_t)kRtOffTab + (size_t)2 * max_rows * 48 + (size_t)b_chunk * max_gauss * 8;
-    const size_t lds_big = 384 + (size_t)2 * max_rows * 48;
-    if (big_n == 2)
-        hipLaunchKernelGGL(k_residuals_tiles<2>, dim3(num_tiles, chunks), dim3(kTileThreads), lds_tiles, s, memb_tile, seg_off,
-                           reinterpret_cast<const float4*>(info12), reinterpret_cast<const float4*>(tables), rows, tiles, tile_rows, B, b_chunk, max_rows, max_gauss, E, ldE, g_phase_clk);
-    else
-        hipLaunchKernelGGL(k_residuals_tiles<4>, dim3(num_tiles, chunks), dim3(kTileThreads), lds_tiles, s, memb_tile, seg_off,
-                           reinterpret_cast<const float4*>(info12), reinterpret_cast<const float4*>(tables), rows, tiles, tile_rows, B, b_chunk, max_rows, max_gauss, E, ldE, g_phase_clk);
-    // the few single-Gaussian tiles are long: give every evaluation its own workgroup
-    if (num_fallback > 0) {  // `fallback` lists the single-Gaussian tiles
-        int bchunks = (512 + num_fallback - 1) / num_fallback;  // enough workgroups for two rounds of the chip
-        if (bchunks > B) bchunks = B;
-        const int bb = (B + bchunks - 1) / bchunks;
-        bchunks = (B + bb - 1) / bb;
-        hipLaunchKernelGGL(k_residuals_big, dim3(num_fallback, bchunks), dim3(kBigThreads), lds_big, s, memb_tile, reinterpret_cast<const float4*>(info12),
-                           reinterpret_cast<const float4*>(tables), rows, tiles, fallback, tile_rows, B, bb, max_rows, E, ldE);
-    }
-}
-
-void launch_residuals(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tables, int rows, int M, int B,
-                      const int32_t* wg_seg, int num_wg, int big_n, double* E, int64_t ldE, hipStream_t s, bool pairs) {
-    if (M <= 0 || B <= 0) return;
-    const int seg_stride = pairs ? 2 : 1;
-    const size_t lds = (size_t)rows * 48;
-    static bool attr_set = false;
-    if (lds <= 160 * 1024 - 1280) {
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_residuals<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(k_residuals<true>, dim3(num_wg, B), dim3(512), lds + 256, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
-                           reinterpret_cast<const float4*>(tables), rows, M, wg_seg, seg_stride, big_n, E, ldE);
-    } else {
-        hipLaunchKernelGGL(k_residuals<false>, dim3(num_wg, B), dim3(512), 256, s, memb_local, seg_off, reinterpret_cast<const float4*>(info12),
-                           reinterpret_cast<const float4*>(tables), rows, M, wg_seg, seg_stride, big_n, E, ldE);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // K5 — normal equations and squared-error sums (fp64, deterministic two-stage reductions)
 // ------------------------------------------------------------------------------------------------------------
@@ -3215,22 +2485,7 @@ void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, doub
     if (reduce) hipLaunchKernelGGL(k_normal_eq_reduce, dim3((n1 * n1 + 255) / 256), dim3(256), 0, s, partial, nsplit, nt, P, Hp);
 }
 
-constexpr int kSqRows = 4096;
-int squared_sums_partial_doubles(int rows, int B) { return ((rows + kSqRows - 1) / kSqRows) * B; }
-__global__ __launch_bounds__(256) void k_squared_sums_partial(const double* __restrict__ E, int64_t ldE, int rows, double* __restrict__ partial) {
-    __shared__ double s_w[4];
-    const int b = blockIdx.y, sp = blockIdx.x;
-    const int r_end = min(rows, (sp + 1) * kSqRows);
-    double s = 0.0;
-    for (int r = sp * kSqRows + threadIdx.x; r < r_end; r += 256) {
-        const double v = E[(size_t)b * ldE + r];
-        s += v * v;
-    }
-    s = wave_allsum(s);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + sp] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-}
+// out[b] = the block sums of evaluation b added in block order
 __global__ void k_squared_sums_reduce(const double* __restrict__ partial, int nsplit, int B, double* __restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -3274,11 +2529,6 @@ void launch_squared_sums_blocked(const double* E, int64_t ldE, int rows, int P, 
     const int nsplit = (rows + rs - 1) / rs;
     hipLaunchKernelGGL(k_squared_sums_blocked, dim3(nsplit, B), dim3(64), 0, s, E, ldE, rows, rs, nsplit, P > 64 ? 1 : 0, partial);
     if (out) hipLaunchKernelGGL(k_squared_sums_reduce, dim3((B + 63) / 64), dim3(64), 0, s, partial, nsplit, B, out);  // out null: the consumer adds the block sums
-}
-void launch_squared_sums(const double* E, int64_t ldE, int rows, int B, double* partial, double* out, hipStream_t s) {
-    const int nsplit = (rows + kSqRows - 1) / kSqRows;
-    hipLaunchKernelGGL(k_squared_sums_partial, dim3(nsplit, B), dim3(256), 0, s, E, ldE, rows, partial);
-    hipLaunchKernelGGL(k_squared_sums_reduce, dim3((B + 63) / 64), dim3(64), 0, s, partial, nsplit, B, out);
 }
 
 }  // namespace dmsa

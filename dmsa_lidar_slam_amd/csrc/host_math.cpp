@@ -438,37 +438,6 @@ void lm_solve(const double* Hin, const double* g, int P, double alpha, double* s
                      std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count());
 }
 
-void lm_solve_lu(const double* Hin, const double* g, int P, double alpha, double* step) {
-    std::vector<double> A(Hin, Hin + (size_t)P * P);  // symmetric: row-major == column-major
-    std::vector<double> b(g, g + P);
-    for (int c = 0; c < P; ++c) {
-        int piv = c;
-        double best = std::fabs(A[(size_t)c * P + c]);
-        for (int r = c + 1; r < P; ++r)
-            if (std::fabs(A[(size_t)r * P + c]) > best) best = std::fabs(A[(size_t)r * P + c]), piv = r;
-        if (piv != c) {
-            for (int k = 0; k < P; ++k) std::swap(A[(size_t)c * P + k], A[(size_t)piv * P + k]);
-            std::swap(b[(size_t)c], b[(size_t)piv]);
-        }
-        const double inv = 1.0 / A[(size_t)c * P + c];
-        const double* rc = &A[(size_t)c * P];
-        for (int r = c + 1; r < P; ++r) {
-            double* rr = &A[(size_t)r * P];
-            const double f = rr[c] * inv;
-            if (f == 0.0) continue;
-            rr[c] = f;
-            for (int k = c + 1; k < P; ++k) rr[k] -= f * rc[k];
-            b[(size_t)r] -= f * b[(size_t)c];
-        }
-    }
-    for (int r = P - 1; r >= 0; --r) {
-        double s = b[(size_t)r];
-        const double* rr = &A[(size_t)r * P];
-        for (int k = r + 1; k < P; ++k) s -= rr[k] * step[k];
-        step[r] = s / rr[r];
-    }
-    for (int i = 0; i < P; ++i) step[i] = -alpha * step[i];
-}
 
 void glibc_rand_fill(uint32_t seed, int32_t* out, size_t count) {
     int32_t r[31];

@@ -93,9 +93,6 @@ struct KeyframeHost {
 using ParallelRun = std::function<void(const std::function<void(int, int)>&)>;
 void lm_solve(const double* H /* PxP col-major */, const double* g, int P, double alpha, double* step, const ParallelRun* par = nullptr,
               int max_threads = 12 /* of par's workers that take part */);
-// Same step through a partial-pivot LU solve instead of the explicit inverse (P^3/3 instead of 2 P^3 flops; differs from
-// lm_solve by rounding only).  Used by the fast path, where P reaches several hundred in the keyframe pass.
-void lm_solve_lu(const double* H /* PxP symmetric */, const double* g, int P, double alpha, double* step);
 
 // The first `count` values of glibc rand() after srand(seed): TYPE_3 additive feedback generator of random_r.c (degree 31,
 // separation 3, 310 warm-up draws) -- randomGridDownsampling (helpers.h:86-94) draws one per octree leaf.

@@ -1,5 +1,5 @@
 // optimize_loop.cpp — DmsaOptimizer::optimizeSet (DmsaOptimizer.h:54-150): pose tables and residual batches, the device-resident loop
-// (default path) and the host-driven loop (opt-in fast sums, host-built pose tables, debug switch device_loop = 0).
+// (default) and the host-driven loop (host-built pose tables, debug switch device_loop = 0, sets too large for the chain kernels' LDS).
 #include "dmsa_ctx.h"
 
 // ---- pose tables ------------------------------------------------------------------------------------------
@@ -62,7 +62,7 @@ int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs, hipStre
         HIPCHK(hipMemcpyAsync(ctx->d_ctrl.p, slot, globs.size() * 8, hipMemcpyHostToDevice, stream));
         // default path: the correspondence kernels read the tables transposed ([row][evaluation][12]); batches are written both ways at once
         float* tT = nullptr;
-        if ((ctx->flags & DMSA_FLAG_MIRROR_SUMS) && B > 1) {
+        if (B > 1) {
             HIPCHK(ctx->d_tablesT.ensure((size_t)B * rows * 48));
             tT = ctx->d_tablesT.as<float>();
         }
@@ -159,14 +159,11 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
         HIPCHK(hipMemcpy2DAsync(ctx->d_E.as<double>() + ctx->M, (size_t)ctx->ldE * 8, slot, (size_t)a * 8, (size_t)a * 8, (size_t)B, hipMemcpyHostToDevice,
                                 ctx->stream));
     }
-    const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS) && ctx->num_tiles > 0 && ctx->tiles_usable;
-    if (tiles_on) {
-        ScopedTimer tm(ctx, T_RESIDUAL);
-        launch_residuals_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(),
-                               ctx->d_tables.as<float>(), ctx->rows, ctx->M, B, ctx->d_tiles.as<TileDesc>(), ctx->d_tile_rows.as<int32_t>(), ctx->num_tiles,
-                               ctx->tile_max_rows, ctx->tile_max_gauss, ctx->d_fallback.as<int2>(), ctx->num_fallback, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE,
-                               ctx->stream);
-    } else if ((ctx->flags & DMSA_FLAG_MIRROR_SUMS) && ctx->order_valid) {
+    if (!ctx->order_valid) {
+        ctx->err = "residuals: no size-class order (build the Gaussians first)";
+        return DMSA_ERR_INVALID;
+    }
+    {
         // reference-order sums (default path): lane = evaluation on transposed pose tables
         HIPCHK(ctx->d_tablesT.ensure((size_t)B * ctx->rows * 48));
         ScopedTimer tm(ctx, T_RESIDUAL);
@@ -225,10 +222,6 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
                 HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             }
         }
-    } else {
-        ScopedTimer tm(ctx, T_RESIDUAL);
-        launch_residuals(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_info12.as<float>(), ctx->d_tables.as<float>(), ctx->rows, ctx->M,
-                         B, ctx->d_wg_seg.as<int32_t>(), ctx->num_wg, ctx->cfg_big_n, ctx->d_E.as<double>(), ctx->ldE, ctx->stream, false);
     }
     ctx->E_is_jacobian = false;
     ctx->residual_launches += 1;
@@ -273,9 +266,9 @@ static int restore_snapshot(dmsa_ctx* ctx, const dmsa_settings& s, const CallSna
     return DMSA_OK;
 }
 int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
-    // default path: the loop state lives on the device (one host wait per iteration); the host-driven loop remains for the opt-in fast
-    // sums, for host-built pose tables and for sets whose chain state does not fit the chain kernels' LDS (hundreds of keyframes)
-    const bool device_loop = (ctx->flags & DMSA_FLAG_MIRROR_SUMS) && !(ctx->flags & DMSA_FLAG_POSE_TABLE_HOST) && ctx->device_loop && loop_chain_fits(ctx->loop_model);
+    // the loop state lives on the device (one host wait per iteration); the host-driven loop remains for host-built pose tables, for the
+    // debug switch device_loop = 0 and for sets whose chain state does not fit the chain kernels' LDS (hundreds of keyframes)
+    const bool device_loop = !(ctx->flags & DMSA_FLAG_POSE_TABLE_HOST) && ctx->device_loop && loop_chain_fits(ctx->loop_model);
     auto run = [&]() {
         ctx->wait_seq = 0, ctx->voxel_calls = 0;
         int rc = device_loop ? optimize_device_loop(ctx, s, rep) : optimize_impl(ctx, s, rep);
@@ -433,13 +426,10 @@ static int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep
         for (int i = 0; i < P; ++i) g[(size_t)i] = Hp[(size_t)P * n1 + i];
         error0 = Hp[(size_t)P * n1 + P];  // :101
         for (int i = 0; i < P; ++i) H[(size_t)i * P + i] += (double)s.lambda_diag;  // :110
-        if (ctx->flags & DMSA_FLAG_MIRROR_SUMS)
         {   // :113, explicit inverse like the reference
             const ParallelRun par = [&](const std::function<void(int, int)>& fn) { workers(ctx).run_all(fn); };
             lm_solve(H.data(), g.data(), P, s.step_length_optim, step.data(), P >= 64 ? &par : nullptr, ctx->dbg.solve_threads);
         }
-        else
-            lm_solve_lu(H.data(), g.data(), P, s.step_length_optim, step.data());
         g_tl.mark("assemble+solve");
         bool anyNan = false;
         for (double v : step) anyNan = anyNan || std::isnan(v);
@@ -493,13 +483,9 @@ static int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep
         double* errs = ctx->h_rb->errs;  // pinned
         {
             ScopedTimer tm(ctx, T_NORMAL);
-            const bool blocked = (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0;
-            HIPCHK(ctx->d_sq_partial.ensure((size_t)std::max(squared_sums_partial_doubles(rowsE, 9), squared_sums_blocked_partial_doubles(rowsE, P, 9)) * 8));
+            HIPCHK(ctx->d_sq_partial.ensure((size_t)squared_sums_blocked_partial_doubles(rowsE, P, 9) * 8));
             HIPCHK(ctx->d_sq_out.ensure(16 * 8));
-            if (blocked)
-                launch_squared_sums_blocked(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
-            else
-                launch_squared_sums(ctx->d_E.as<double>(), ctx->ldE, rowsE, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
+            launch_squared_sums_blocked(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
         }
         HIPCHK(hipMemcpyAsync(errs, ctx->d_sq_out.p, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
         g_tl.mark("line search enq");
@@ -698,7 +684,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             ScopedTimer tm(ctx, T_VOXEL);
             launch_transform_aabb(ctx->d_local.as<float4>(), ctx->model == MODEL_KEYFRAMES ? ctx->d_nlocal.as<float4>() : nullptr, ctx->d_table0.as<float4>(),
                                   ctx->d_global.as<float4>(), ctx->model == MODEL_KEYFRAMES ? ctx->d_nglobal.as<float4>() : nullptr, ctx->n,
-                                  ctx->d_aabb.as<float>(), ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts), ctx->stream);
+                                  ctx->d_aabb.as<float>(), ctx->d_counts.p, sizeof(GaussCounts) + sizeof(SerialCounts), ctx->stream);
             ctx->aabb_fresh = true;
         }
         // :99, :199-232 the 1 + P chains, rows and pose tables of the Jacobian batch: beside the voxelisation, they need nothing from it
@@ -806,7 +792,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         CHK(run_residuals(ctx, 9, nullptr, d_extra_trial));
         {
             ScopedTimer tm(ctx, T_NORMAL);
-            HIPCHK(ctx->d_sq_partial.ensure((size_t)std::max(squared_sums_partial_doubles(rowsE, 9), squared_sums_blocked_partial_doubles(rowsE, P, 9)) * 8));
+            HIPCHK(ctx->d_sq_partial.ensure((size_t)squared_sums_blocked_partial_doubles(rowsE, P, 9) * 8));
             launch_squared_sums_blocked(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 9, ctx->d_sq_partial.as<double>(), nullptr, ctx->stream);  // block sums only
         }
         {

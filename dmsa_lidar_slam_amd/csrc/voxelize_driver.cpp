@@ -32,7 +32,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         ScopedTimer tm(ctx, T_VOXEL);
         const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
         if (!ctx->aabb_fresh)  // the device loop's fused transform already left the block bounds and cleared the counters
-            launch_block_aabb(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts),
+            launch_block_aabb(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), ctx->d_counts.p, sizeof(GaussCounts) + sizeof(SerialCounts),
                               ctx->stream);
         ctx->aabb_fresh = false;
         // the lattice kernel clears the headers of the own radix sorts on the side (one dispatch less per sort)
@@ -58,7 +58,6 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         if (!speculate && lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
     }
     GaussCounts* counts = ctx->d_counts.as<GaussCounts>();
-    const bool tiles_on = ctx->use_tiles && !(ctx->flags & DMSA_FLAG_MIRROR_SUMS);
     const bool split = s.gauss_split != 0 && ctx->model == MODEL_KEYFRAMES;
     if (split && !ctx->d_split_stats.p) {
         HIPCHK(ctx->d_split_stats.ensure(64 * 16));  // 64 stripes of (blocks looked at, blocks skipped)
@@ -239,27 +238,11 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         if (lvl_on[1]) stage_gather(1, ctx->stream);
     }
-    if (!tiles_on) {
-        ScopedTimer tm(ctx, T_FIT);
-        for (int l = 0; l < 2; ++l)
-            if (lvl_on[l])
-                launch_gauss_fit(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(), counts, l, ctx->d_info12.as<float>(),
-                                 (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
-    }
-    // Tiles of whole Gaussians for the fit and the correspondence kernel; their counts travel with M / Mm.
-    TileCounts htc{};
-    if (tiles_on) {
-        ScopedTimer tm(ctx, T_FIT);
-        launch_build_tiles(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_memb_local.as<float4>(), ctx->d_memb_g.as<int32_t>(), ctx->rows, ctx->d_tiles.as<TileDesc>(),
-                           reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_memb_tile.as<float4>(), ctx->d_tile_rows.as<int32_t>(),
-                           ctx->d_pad_off.as<int32_t>(), ctx->stream);
-    }
-    const bool classes_on = !tiles_on && (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0;
     // The read-back of the counts runs on the third stream: a device-to-host copy ends with a system-scope release that holds up the
     // stream it is on for ~20 us, and the fit behind it does not need to wait for that.
     hipStream_t rb = ctx->dual_stream ? ctx->stream3 : ctx->stream;
     bool rb_released = false;
-    if (classes_on) {  // size classes of the reference-order correspondence kernels: needs only seg_off, so it runs before the read-back
+    {   // size classes of the correspondence kernels: needs only seg_off, so it runs before the read-back
         // k_size_classes is one workgroup on the main stream between the voxelisation and the fit: it also carries two stream dependencies
         // (dev_sync.h) -- it waits for the pose tables of the Jacobian batch (built on the side stream long ago) and releases the read-back
         DevSync sy;
@@ -272,7 +255,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             if (rb != ctx->stream) sy.signal_counter = ctx->sync_counter(SYNC_CLASSES), ctx->sync_sig[SYNC_CLASSES] += 1, rb_released = true;
         }
         launch_size_classes(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_order.as<uint32_t>(),
-                            reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts) + sizeof(TileCounts)), ctx->stream, sy);
+                            reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts)), ctx->stream, sy);
     }
     if (rb_released) {
         enqueue_wait(ctx, SYNC_CLASSES, rb);
@@ -280,46 +263,37 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         HIPCHK(hipEventRecord(ctx->ev_scan0, ctx->stream));
         HIPCHK(hipStreamWaitEvent(rb, ctx->ev_scan0, 0));
     }
-    HIPCHK(hipMemcpyAsync(&ctx->h_rb->g, ctx->d_counts.p, sizeof(GaussCounts) + sizeof(TileCounts) + sizeof(SerialCounts), hipMemcpyDeviceToHost, rb));
+    HIPCHK(hipMemcpyAsync(&ctx->h_rb->g, ctx->d_counts.p, sizeof(GaussCounts) + sizeof(SerialCounts), hipMemcpyDeviceToHost, rb));
     HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, rb));  // incl. out_of_range
     if (ctx->rb_extra_bytes)  // device loop: the previous iteration's stop decision travels with the counts
         HIPCHK(hipMemcpyAsync(ctx->rb_extra_dst, ctx->rb_extra_src, ctx->rb_extra_bytes, hipMemcpyDeviceToHost, rb));
-    // The fit does not need the counts on the host (fixed grids, device-side tile counts): with the LDS table sized for ALL pose rows
-    // it is enqueued right behind the read-back, so the GPU keeps working while the host waits for M (sync #2 waits on an event
-    // recorded BEFORE the fit, not on the stream).
-    const bool early_fit = tiles_on && (size_t)(ctx->rows + 1) * 48 <= 56 * 1024;
     HIPCHK(hipEventRecord(ctx->ev_counts, rb));
-    // Default path: the fit (oracle's tree order) is enqueued BEHIND the read-back as well, with the previous iteration's class
+    // The fit is enqueued BEHIND the read-back, with the previous iteration's class
     // counts (+ margin) as grids -- the kernels take the true ranges from device memory, surplus workgroups exit, and whatever the
     // guess missed is launched after sync #2.  The three classes run side by side on two streams (each is latency-bound on its own).
-    const int32_t* d_sc = reinterpret_cast<const int32_t*>(ctx->d_counts.as<char>() + sizeof(GaussCounts) + sizeof(TileCounts));
+    const int32_t* d_sc = reinterpret_cast<const int32_t*>(ctx->d_counts.as<char>() + sizeof(GaussCounts));
     const float* fit_table = ctx->base_table ? ctx->base_table : ctx->d_tables.as<float>();
     int fit_launched[3] = {0, 0, 0}, finish_launched = 0;
-    auto launch_fit = [&](const int first[3], const int tasks[3], int finish_gauss) -> int {
+    auto launch_fit = [&](const int first[3], const int tasks_in[3], int finish_gauss) -> int {
         ScopedTimer tm(ctx, T_FIT);
+        const int tasks[3] = {(ctx->dbg.fit_classes & 1) ? tasks_in[0] : 0, (ctx->dbg.fit_classes & 2) ? tasks_in[1] : 0, (ctx->dbg.fit_classes & 4) ? tasks_in[2] : 0};
         {
             // one launch for the three size classes and the rebalancing weights: no fork to a second stream, no join
             launch_gauss_fit_all(ctx->d_memb_local.as<float4>(), ctx->d_seg_off.as<int32_t>(), fit_table, ctx->d_order.as<uint32_t>(), d_sc, first, tasks,
-                                 ctx->d_fit_sums.as<double>(), counts, ctx->d_info12.as<float>(), true, ctx->rows - 1, ctx->d_gauss_rows.as<int2>(), ctx->stream);
+                                 ctx->d_fit_sums.as<float>(), counts, ctx->d_info12.as<float>(), true, ctx->rows - 1, ctx->d_gauss_rows.as<int2>(), ctx->dbg.eigen_l1_bytes,
+                                 ctx->d_pow_codes.as<uint32_t>(), (int)std::min<int64_t>(ctx->pow_n, INT32_MAX), ctx->d_memb_q.as<float>(), (size_t)(2 * ctx->n + 16), ctx->stream);
         }
-        launch_gauss_fit_finish(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_fit_sums.as<double>(), finish_gauss, ctx->d_info12.as<float>(), ctx->stream);
+        launch_gauss_fit_finish(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_fit_sums.as<float>(), finish_gauss, ctx->d_info12.as<float>(), ctx->stream);
         HIPCHK(hipGetLastError());
         return DMSA_OK;
     };
-    if (classes_on && ctx->fit_guess_valid) {
+    if (ctx->fit_guess_valid) {
         const SerialCounts& pg = ctx->serial_counts;  // previous iteration
         const int first[3] = {0, 0, 0};
         auto grow = [](int v) { return v + v / 8 + 16; };
         fit_launched[0] = grow(pg.n_long), fit_launched[1] = grow(pg.n_chain - pg.n_long), fit_launched[2] = grow(pg.n_small);
         finish_launched = grow(pg.n_chain + pg.n_small);
         CHK(launch_fit(first, fit_launched, finish_launched));
-    }
-    if (early_fit) {
-        ScopedTimer tm(ctx, T_FIT);
-        launch_fit_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_tables.as<float>(), ctx->rows + 1, ctx->d_tiles.as<TileDesc>(),
-                         reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
-                         ctx->d_info12.as<float>(), ctx->stream);
-        launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), false, ctx->stream);
     }
     g_tl.mark("voxel enq");
     if (overlap) CHK(overlap());
@@ -333,7 +307,6 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     }
     g_tl.mark("sync#2 wait");
     const GaussCounts h = ctx->h_rb->g;
-    htc = ctx->h_rb->t;
     for (int l = 0; l < 2; ++l) {
         if (lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
         const int true_bits = compress ? ctx->h_lattice[l].total_bits : 3 * ctx->h_lattice[l].final_depth;
@@ -357,47 +330,23 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             ctx->coh_lattice[l] = a, ctx->coh_pending[l] = false;
         }
     }
-    ctx->num_tiles = htc.num_tiles, ctx->num_fallback = htc.num_fallback, ctx->tile_max_rows = htc.max_rows, ctx->tile_max_gauss = htc.max_gauss;
-    ctx->tiles_usable = !tiles_on || tiled_kernels_fit(htc.max_rows, htc.max_gauss);
     {
         ScopedTimer tm(ctx, T_FIT);
-        if (tiles_on && !early_fit && ctx->num_tiles > 0 && !ctx->tiles_usable) {
-            // tiles that reference more pose rows than fit in LDS: wave-per-set fit on the gathered members instead
-            for (int l = 0; l < 2; ++l)
-                if (lvl_on[l])
-                    launch_gauss_fit(ctx->d_seg_off.as<int32_t>(), ctx->d_memb_idx.as<int32_t>(), ctx->d_global.as<float4>(), counts, l, ctx->d_info12.as<float>(), false,
-                                     ctx->stream);
-        } else if (tiles_on && !early_fit && ctx->num_tiles > 0)
-            launch_fit_tiled(ctx->d_memb_tile.as<float4>(), ctx->d_seg_off.as<int32_t>(), ctx->d_tables.as<float>(), ctx->tile_max_rows,
-                             ctx->d_tiles.as<TileDesc>(), reinterpret_cast<TileCounts*>(ctx->d_counts.as<GaussCounts>() + 1), ctx->d_fallback.as<int2>(), ctx->d_tile_rows.as<int32_t>(),
-                             ctx->d_info12.as<float>(), ctx->stream);
         const int M_all = h.level[0].num_gauss + h.level[1].num_gauss;
-        if (classes_on) {
-            // whatever the pre-sync launches did not cover (first iteration, or a class that grew by more than the margin)
-            ctx->serial_counts = ctx->h_rb->sc;
-            const SerialCounts& sc = ctx->serial_counts;
-            const int want[3] = {sc.n_long, sc.n_chain - sc.n_long, sc.n_small};
-            int rest[3], any = 0;
-            for (int c = 0; c < 3; ++c) rest[c] = std::max(0, want[c] - fit_launched[c]), any += rest[c];
-            if (M_all > 0 && (any > 0 || finish_launched < M_all)) CHK(launch_fit(fit_launched, rest, M_all));
-            ctx->fit_guess_valid = M_all > 0;
-            ctx->order_valid = true;
-        }
-        if (!early_fit && !classes_on)
-            launch_rebalancing_weights(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_info12.as<float>(), (ctx->flags & DMSA_FLAG_MIRROR_SUMS) != 0, ctx->stream);
+        // whatever the pre-sync launches did not cover (first iteration, or a class that grew by more than the margin)
+        ctx->serial_counts = ctx->h_rb->sc;
+        const SerialCounts& sc = ctx->serial_counts;
+        const int want[3] = {sc.n_long, sc.n_chain - sc.n_long, sc.n_small};
+        int rest[3], any = 0;
+        for (int c = 0; c < 3; ++c) rest[c] = std::max(0, want[c] - fit_launched[c]), any += rest[c];
+        if (M_all > 0 && (any > 0 || finish_launched < M_all)) CHK(launch_fit(fit_launched, rest, M_all));
+        ctx->fit_guess_valid = M_all > 0;
+        ctx->order_valid = true;
     }
     HIPCHK(hipGetLastError());
     ctx->M1 = h.level[0].num_gauss;
     ctx->M = h.level[0].num_gauss + h.level[1].num_gauss;
     ctx->Mm = (int64_t)h.level[0].num_memb + h.level[1].num_memb;
-    if (ctx->M > 0) {
-        // enough workgroups to fill 256 CUs several times over, but never more workgroups than Gaussians
-        int wg = ctx->cfg_num_wg;
-        if (wg > ctx->M) wg = ctx->M;
-        ctx->num_wg = wg;
-        // the workgroup partition only feeds the streaming / parity correspondence kernels
-        if (!classes_on && (!tiles_on || ctx->num_tiles == 0 || !ctx->tiles_usable)) launch_segment_partition(ctx->d_seg_off.as<int32_t>(), ctx->M, wg, ctx->d_wg_seg.as<int32_t>(), ctx->stream);
-    }
     ctx->gaussians_valid = true;
     return DMSA_OK;
 }

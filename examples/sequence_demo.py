@@ -75,8 +75,8 @@ class GpuBackend:
 
     def __init__(self, parity: bool = False, sensor: str = "ouster"):
         self.sensor = sensor
-        self.optimizer = DmsaOptimizer(device=0, fast_sums=not parity)
-        self.kf_optimizer = DmsaOptimizer(device=0, fast_sums=not parity)  # keyframeMapOptimizer (DmsaSlam.h:53)
+        self.optimizer = DmsaOptimizer(device=0)
+        self.kf_optimizer = DmsaOptimizer(device=0)  # keyframeMapOptimizer (DmsaSlam.h:53)
         self.decoder = wf.PointCloud2Decoder(sensor)
         self.scan_filter = StaticPointSelector(0)                      # preProcess works on raw scans: its own context
         self.static = StaticPointSelector(optimizer=self.optimizer)     # these two share the optimizer's context: the window cloud

@@ -55,6 +55,12 @@ typedef struct dmsa_debug_options {
                                      k_loop_lm_stream); 0: column-block workgroups handing panels over (k_loop_lm_panels).  Same bits.        */
     int32_t stream_priority; /* 0   bit 0 / 1 / 2: the main / second / third stream of the context is created at the device's highest priority
                                      (which of the concurrent kernels of an iteration the wave dispatcher serves first)                      */
+    int32_t fit_classes;     /* 7   PROFILING ONLY (results are wrong unless 7): bit 0 / 1 / 2 = the Gaussian fit runs its long / middle / short
+                                     size class -- how much of k_gauss_fit_all's time belongs to which class                              */
+    int32_t eigen_l1_bytes;  /* 32768  NOT an A/B switch: the L1 data cache size of the machine the REFERENCE runs on.  Eigen sizes the depth
+                                     blocks kc of centered^T * centered (Gaussians.h:147) from it at run time (32768 -> 680, 49152 -> 1016), and
+                                     the float sum of a Gaussian with more members than kc depends on kc.  Set it to that machine's L1d to
+                                     reproduce its bits; Gaussians up to kc members do not depend on it.                                  */
 } dmsa_debug_options;
 
 /* what the switches above leave behind, since the context was created */

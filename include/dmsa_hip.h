@@ -155,10 +155,8 @@ typedef struct dmsa_iter_trace {
 #define DMSA_FLAG_STAGE_TIMERS    0x8u /* also time voxelisation / fit / pose tables / normal equations with HIP events (each
                                           event pair costs ~10 us of GPU idle; the correspondence kernel is always timed)  */
 #define DMSA_FLAG_MIRROR_SUMS     0x4u /* round-1 name of what is now the default; accepted and ignored                 */
-#define DMSA_FLAG_FAST_SUMS       0x10u /* OPT-IN: per-Gaussian sums as wave / workgroup reductions and an LU solve.  Same voxel
-                                          structure, residuals within 1e-6 relative -- but the numeric Jacobian amplifies the
-                                          different summation order to ~5e-3 m after a few iterations, i.e. OUTSIDE the 1e-4
-                                          tolerance against the reference.  Not the drop-in default.                    */
+/* (0x10 was DMSA_FLAG_FAST_SUMS, the wave-parallel sums of rounds 1-4: slower than the reference-order path since round 3 and outside
+ * the 1e-4 tolerance; retired in round 5.  dmsa_create returns DMSA_ERR_INVALID for flag bits it does not know.) */
 
 int  dmsa_create(int device, uint32_t flags, dmsa_ctx** out);
 void dmsa_destroy(dmsa_ctx* ctx);

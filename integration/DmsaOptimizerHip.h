@@ -3,9 +3,9 @@
 // Keeps the class name pattern and the optimizeSet signatures of DmsaOptimizer<PointT> (include/DMSA/DmsaOptimizer.h:54), extracts the
 // state the OptimizablePointSet virtuals (OptimizablePointSet.h:18-56) would read from the two concrete models, and calls the C ABI
 // (include/dmsa_hip.h; the points through include/dmsa_aos.h: the PCL containers as they lie in memory).  Needs Eigen / PCL like the rest of the reference, so it cannot be compiled in the graft image;
-// scripts/build_ref_oracle.sh documents the environment.  flags = 0 is the path whose poses match the reference's summation order
-// (DMSA_FLAG_FAST_SUMS trades that for speed and is NOT a drop-in).
+// scripts/build_ref_oracle.sh documents the environment.  The library has one summation order: the reference's.
 #pragma once
+#include <algorithm>
 #include <stdexcept>
 #include <vector>
 #include <cstddef>

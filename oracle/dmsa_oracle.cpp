@@ -15,12 +15,20 @@
 //   * boost::math::barycentric_rational (Floater–Hormann, d = 2)                                   
 //   * Eigen: skew().exp() == Rodrigues, R.log() via the unit quaternion, Quaterniond::slerp,
 //     AngleAxisd(q), Matrix3f::inverse() (cofactors), fixed-size product evaluation order        
-// colwise().mean() and VectorXf::mean() (Gaussians.h:146, :176) ARE knowable: Eigen's linear vectorised redux on a contiguous float
-// column is a pure function of the length and of the column's offset inside its 16-byte aligned buffer (eigen_linear_sum_f32 below).
-// Where Eigen's summation order depends on the machine (centered^T*centered runs through the blocked GEMM, whose depth blocks are
-// sized from the CPU's cache sizes; MatrixXd products likewise, on up to four threads) this file accumulates in double and rounds
-// once — the correctly rounded value every float order approximates.  EigenSolver<Matrix3f> (general
-// QR) is replaced by a fixed-sweep symmetric Jacobi iteration in float.  Build with -ffp-contract=off.
+// The fit's float reductions (Gaussians.h:146-147, :172-176) follow Eigen 3.4's own evaluators wherever its source settles the order:
+//   * colwise().mean() / VectorXf::mean(): the linear vectorised redux on a contiguous float column is a pure function of the length
+//     and of the column's offset inside its 16-byte aligned buffer (eigen_linear_sum_f32 below);
+//   * centered^T * centered: the coefficient-based lazy product below 14 members, else general_matrix_matrix_product, where 3 rows and
+//     3 columns leave everything to gebp's scalar tail loop -- per coefficient a float chain C = C + a_k b_k over one depth block of kc
+//     members, res += 1.0f * C block after block, then a float division by float(n - 1).  kc is the one machine-dependent number: Eigen
+//     derives it from the L1 data cache of the machine the reference runs on (680 for 32 KB, 1016 for 48 KB); orc_set_eigen_l1_bytes
+//     states it, and every Gaussian with at most kc members has a machine-independent order;
+//   * numPointsPerSet.cast<float>().array().pow(-1): Eigen promotes the int exponent to float and calls std::pow per coefficient
+//     (scalar_pow_op has no packet path in 3.4.0), i.e. libm's powf(n, -1.0f), which is not correctly rounded (glibc 2.27+: 9857 of the
+//     n < 2^24 differ from 1.0f / n by one ulp); this file calls the libm of the machine it runs on, as the reference does.
+// MatrixXd products (J^T J, up to four threads) accumulate in a stated block order, see blocked_dot.  EigenSolver<Matrix3f> (general
+// QR) is replaced by a fixed-sweep symmetric Jacobi iteration in float; the covariance is rebuilt as V * D * V^-1 with the cofactor
+// inverse like Gaussians.h:200.  Build with -ffp-contract=off.
 //
 // sin / cos / acos / atan2 of the pose-table path (axang2rotm, slerp; the float trigonometry of the normals) are NOT glibc's:
 // they are include/dmsa_detmath.h, fixed sequences of correctly rounded IEEE operations (fdlibm's algorithms) shared with the
@@ -53,9 +61,10 @@
 //   ORC_VAR_FIT_FLOAT           every fit sum (mean, centred products, weight mean) as a scalar float chain in member order
 //   ORC_VAR_FIT_MEAN_TREE       colwise().mean() / VectorXf::mean() as 64-wide trees in double (this file's statement until round 4)
 //                               instead of Eigen's own float redux order
-//   ORC_VAR_FIT_COV_GEMM        centered^T * centered in the float order of Eigen 3.4's product kernels as recalled (coefficient-based
-//                               lazy product below 14 members, else gebp's scalar tail loops in depth blocks sized for a 32 KB L1)
-//                               instead of 64-wide trees in double
+//   ORC_VAR_FIT_COV_TREE        centered^T * centered as 64-wide pairwise trees in double, divided in double and rounded once (this file's
+//                               statement until round 5) instead of the float order of Eigen 3.4's product kernels
+//   ORC_VAR_WEIGHT_DIV          1.0f / n (correctly rounded; what a compiler that folds pow(x, -1) emits) instead of libm's powf(n, -1.0f)
+//   ORC_VAR_LIMITCOV_VT         limitCovariance rebuilds V * D * V^T (symmetric by construction) instead of V * D * V^-1 (Gaussians.h:200)
 //   ORC_VAR_JTJ_NOFMA           J^T J, J^T e, e^T e for P > 64 with separately rounded multiply and add (the reference has no FMA)
 //   ORC_VAR_GLIBC_TRIG          sin / cos / acos / atan2 from glibc instead of include/dmsa_detmath.h
 #ifdef ORC_VAR_GLIBC_TRIG
@@ -360,7 +369,10 @@ static void inverse3f(const float m[3][3], float inv[3][3]) {
 
 // Gaussians.h:181-201 limitCovariance.  EigenSolver<Matrix3f> cannot be mirrored bitwise; on a
 // symmetric PSD input it equals a symmetric eigendecomposition up to rounding.  Fixed 6-sweep cyclic Jacobi
-// in float (+,-,*,/,sqrt only, so the HIP kernel reproduces it bit for bit), clamp >= 1e-4, V*D*V^T.
+// in float (+,-,*,/,sqrt only, so the HIP kernel reproduces it bit for bit), clamp >= 1e-4, then the reference's own
+// rebuild `eigenVectors * diagonal_matrix * eigenVectors.inverse()` (:200): (V D)(i,k) = V(i,k) * d(k), the fixed-size product with
+// the cofactor inverse of V coefficient by coefficient as a 3-term redux.  V is orthogonal only up to rounding, so the result is
+// NOT exactly symmetric -- like the reference's.  ORC_VAR_LIMITCOV_VT: V * D * V^T (this file's statement until round 5).
 static void limit_covariance(float c[3][3]) {
     float a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int i = 0; i < 3; ++i)
@@ -396,9 +408,20 @@ static void limit_covariance(float c[3][3]) {
     }
     float lam[3];
     for (int k = 0; k < 3; ++k) lam[k] = std::max(a[k][k], 0.0001f);  // Gaussians.h:191-194
+#ifdef ORC_VAR_LIMITCOV_VT
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) c[i][j] = sum3((v[i][0] * lam[0]) * v[j][0], (v[i][1] * lam[1]) * v[j][1], (v[i][2] * lam[2]) * v[j][2]);
+#else
+    float vinv[3][3];
+    inverse3f(v, vinv);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[i][j] = sum3((v[i][0] * lam[0]) * vinv[0][j], (v[i][1] * lam[1]) * vinv[1][j], (v[i][2] * lam[2]) * vinv[2][j]);
+#endif
 }
+
+// L1 data cache size Eigen's product blocking is derived from on the reference's machine (orc_set_eigen_l1_bytes; Eigen's default when
+// cpuid reports nothing is 32 KB as well)
+static int g_eigen_l1_bytes = 32 * 1024;
 
 // ------------------------------------------------------------------------------------------------
 // PCL OctreePointCloud, restated without building a tree.
@@ -511,20 +534,23 @@ struct Gaussians {
     std::vector<float> info;     // M x 9, column-major Matrix3f
     std::vector<float> weights;  // rebalancingWeights
     std::vector<float> obsWeights;
+    // intermediate results of the fit, kept for the stage dump ('fit_sums' stage of tests/ref_stage_checks.py): subset.colwise().mean(),
+    // the covariance BEFORE limitCovariance (column-major), and pow(-1) of the member counts before the division by their mean
+    std::vector<float> fitMean, fitCov, rawWeights;
     int numPointSets = 0;
     int numLevel1 = 0;
 
     void reset() {  // Gaussians.h:121-128
         segOffset.assign(1, 0);
         members.clear(), info.clear(), weights.clear(), obsWeights.clear();
+        fitMean.clear(), fitCov.clear(), rawWeights.clear();
         numPointSets = 0;
     }
     // Gaussians.h:130-168
-    // Order of the fit's reductions.  The reference computes colwise().mean() and centered^T * centered with Eigen's vectorised
-    // dynamic-size float paths (Gaussians.h:146-154), whose summation order cannot be known; this restatement accumulates in double
-    // and fixes an order that is easy to state and to parallelise: consecutive blocks of kSumBlock = 64 members, every block reduced
-    // by the balanced pairwise tree (v[i] += v[i - w] for w = 1, 2, 4 .. 32; missing members count as +0.0), the block sums added
-    // in block order.  (The kernels of the HIP library use the same rule: it is what a 64-lane wave reduction computes.)
+    // blockedSum: the order this file stated for the fit's sums until Eigen's own orders were restated (now only behind the switches
+    // ORC_VAR_FIT_COV_TREE / FIT_MEAN_TREE / FIT_FLOAT): double accumulation over consecutive blocks of kSumBlock = 64 members, every
+    // block reduced by the balanced pairwise tree (v[i] += v[i - w] for w = 1, 2, 4 .. 32; missing members count as +0.0), the block
+    // sums added in block order.
     static constexpr size_t kSumBlock = 64;
     template <typename Term>
     static double blockedSum(size_t n, Term term) {
@@ -590,15 +616,24 @@ struct Gaussians {
         return eigen_linear_sum_f32(n, offset, x) / (float)n;
 #endif
     }
-#ifdef ORC_VAR_FIT_COV_GEMM
-    // centered.adjoint() * centered (Gaussians.h:147) as Eigen 3.4 evaluates it for a 3 x n by n x 3 float product -- RECALLED, and the
-    // depth blocking depends on the machine's L1 size (32 KB assumed): generic_product_impl<..., GemmProduct>::evalTo takes the
-    // coefficient-based lazy product while n + 6 < 20 (every coefficient a linear vectorised redux of the element-wise products,
-    // aligned start 0), else general_matrix_matrix_product, where 3 rows < LhsProgress and 3 columns < nr leave everything to gebp's
-    // scalar tail loops: per coefficient a float chain C = C + a_k b_k over one depth block, res += C block after block.
+    // centered.adjoint() * centered (Gaussians.h:147) as Eigen 3.4.0 evaluates a (3 x n) * (n x 3) float product whose result has dynamic size
+    // (`centered` is a MatrixXf):
+    //  * generic_product_impl<.., GemmProduct>::evalTo (GeneralMatrixMatrix.h) takes the coefficient-based lazy product while
+    //    rhs.rows() + dst.rows() + dst.cols() < EIGEN_GEMM_TO_COEFFBASED_THRESHOLD = 20, i.e. n < 14.  Its evaluator has no packet access
+    //    (the lhs is a transpose of a column-major matrix, the rhs is not row-major), so every coefficient is
+    //    (lhs.row(i).transpose().cwiseProduct(rhs.col(j))).sum(): the linear vectorised redux of the element-wise products; the
+    //    expression has no direct access, so first_default_aligned() is 0 and the packets start at element 0.
+    //  * else dst.setZero() and general_matrix_matrix_product -> gebp_kernel with mr = 8, nr = 4 (SSE, no FMA).  3 rows < LhsProgress
+    //    and 3 columns < nr, so all nine coefficients go through gebp's last loop ("remaining columns" x "remaining rows"):
+    //        ResScalar C0(0);  for (k < depth) C0 = cj.pmadd(A0, B_0, C0);  res(i, j) += alpha * C0;      (alpha = 1.0f)
+    //    once per depth block of kc members, the blocks in order.  One thread: parallelize_gemm gives max(1, cols / nr) = 1.
+    //  * kc (evaluateProductBlockingSizesHeuristic, one thread): untouched when max(k, m, n) < 48; else
+    //    max_kc = ((l1 - k_sub) / k_div) & ~(k_peeling - 1) with k_sub = mr * nr * 4 = 128, k_div = mr * 4 + nr * 4 = 48, k_peeling = 8,
+    //    and a depth above max_kc is split into nearly equal blocks that are multiples of 8.  l1 = g_eigen_l1_bytes.
+    // Coefficients (i, j) and (j, i) multiply the same floats in the same order: the product is exactly symmetric.
     static size_t gemm_kc(size_t k) {
-        if (k < 48) return k;  // evaluateProductBlockingSizesHeuristic returns early for max(k, m, n) < 48
-        const size_t l1 = 32 * 1024, k_peeling = 8, k_div = 1 * (8 * 4 + 4 * 4), k_sub = 8 * 4 * 4;  // mr = 8, nr = 4 without FMA
+        if (k < 48) return k;
+        const size_t l1 = (size_t)g_eigen_l1_bytes, k_peeling = 8, k_div = 1 * (8 * 4 + 4 * 4), k_sub = 8 * 4 * 4;
         const size_t max_kc = std::max<size_t>(((l1 - k_sub) / k_div) & ~(k_peeling - 1), 1);
         if (k <= max_kc) return k;
         return (k % max_kc) == 0 ? max_kc : max_kc - k_peeling * ((max_kc - 1 - (k % max_kc)) / (k_peeling * (k / max_kc + 1)));
@@ -615,38 +650,37 @@ struct Gaussians {
         }
         return res;
     }
-#endif
     void addPointSet(const std::vector<int>& ids, const float* xyz4, float observationWeight) {
         const size_t n = ids.size();
         float mean[3];  // subset.colwise().mean(), Gaussians.h:146
         for (int c = 0; c < 3; ++c) mean[c] = eigen_mean_f32(n, (size_t)c * n, [&](size_t j) { return xyz4[4 * (size_t)ids[j] + c]; });
-        double acc[6];  // xx xy xz yy yz zz
-        for (int q = 0; q < 6; ++q) {
-            static const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
-#ifdef ORC_VAR_FIT_COV_GEMM
-            acc[q] = (double)gemm_dot_f32(
-                n, [&](size_t j) { return xyz4[4 * (size_t)ids[j] + ia[q]] - mean[ia[q]]; }, [&](size_t j) { return xyz4[4 * (size_t)ids[j] + ib[q]] - mean[ib[q]]; });
-#else
+        float cov[3][3];
+        static const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};  // xx xy xz yy yz zz
+#if defined(ORC_VAR_FIT_COV_TREE) || defined(ORC_VAR_FIT_FLOAT)
+        double acc[6];
+        for (int q = 0; q < 6; ++q)
             acc[q] = blockedSum(n, [&](size_t j) {
                 const float* p = xyz4 + 4 * (size_t)ids[j];
                 const float ca = p[ia[q]] - mean[ia[q]], cb = p[ib[q]] - mean[ib[q]];
                 return (double)ca * (double)cb;
             });
-#endif
-        }
         const double denom = (double)((long)n - 1);
-        float cov[3][3];
-#ifdef ORC_VAR_FIT_COV_GEMM
-        const float fd = (float)((long)n - 1);  // (...) / float(subset.rows() - 1): a float division
-        cov[0][0] = (float)acc[0] / fd, cov[0][1] = cov[1][0] = (float)acc[1] / fd;
-        cov[0][2] = cov[2][0] = (float)acc[2] / fd, cov[1][1] = (float)acc[3] / fd;
-        cov[1][2] = cov[2][1] = (float)acc[4] / fd, cov[2][2] = (float)acc[5] / fd;
-        (void)denom;
+        for (int q = 0; q < 6; ++q) cov[ia[q]][ib[q]] = cov[ib[q]][ia[q]] = (float)(acc[q] / denom);
 #else
-        cov[0][0] = (float)(acc[0] / denom), cov[0][1] = cov[1][0] = (float)(acc[1] / denom);
-        cov[0][2] = cov[2][0] = (float)(acc[2] / denom), cov[1][1] = (float)(acc[3] / denom);
-        cov[1][2] = cov[2][1] = (float)(acc[4] / denom), cov[2][2] = (float)(acc[5] / denom);
+        // MatrixXf centered = subset.rowwise() - mean (float subtraction per element), then the product above, Gaussians.h:146-147
+        float acc[6];
+        for (int q = 0; q < 6; ++q)
+            acc[q] = gemm_dot_f32(
+                n, [&](size_t j) { return xyz4[4 * (size_t)ids[j] + ia[q]] - mean[ia[q]]; }, [&](size_t j) { return xyz4[4 * (size_t)ids[j] + ib[q]] - mean[ib[q]]; });
+        // (...) / float(subset.rows() - 1): a float division of every coefficient.  (Dividing the two floats in double and rounding once gives
+        // the same bits -- double rounding is innocuous for the quotient of two floats, 53 >= 2 * 24 + 2 -- so "float or double division" is
+        // not a separate hypothesis once the sums are floats.)
+        const float fd = (float)((long)n - 1);
+        for (int q = 0; q < 6; ++q) cov[ia[q]][ib[q]] = cov[ib[q]][ia[q]] = acc[q] / fd;
 #endif
+        for (int c = 0; c < 3; ++c) fitMean.push_back(mean[c]);
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 3; ++r) fitCov.push_back(cov[r][c]);
         limit_covariance(cov);
         float inv[3][3];
         inverse3f(cov, inv);
@@ -660,9 +694,17 @@ struct Gaussians {
     // Gaussians.h:170-179
     void updateRebalancingWeights() {
         weights.resize((size_t)numPointSets);
+        rawWeights.resize((size_t)numPointSets);
         for (int k = 0; k < numPointSets; ++k) {
+            // numPointsPerSet.cast<float>().array().pow(-1) (:172): scalar_pow_op<float, float> -> std::pow(float, float) = libm's powf
             const float nk = (float)(segOffset[k + 1] - segOffset[k]);
+#ifdef ORC_VAR_WEIGHT_DIV
             weights[k] = (1.0f / nk) * obsWeights[k];
+#else
+            volatile float minus_one = -1.0f;  // (volatile: the compiler must not fold the call into a division)
+            weights[k] = powf(nk, minus_one) * obsWeights[k];
+#endif
+            rawWeights[k] = weights[k];
         }
         // VectorXf::mean() (Gaussians.h:176): `rebalancingWeights.head(M)` starts at its aligned buffer
         const float mean = eigen_mean_f32((size_t)numPointSets, 0, [&](size_t k) { return weights[k]; });
@@ -1297,7 +1339,7 @@ struct Optimizer {
         }
         return best;
     }
-    // Iteration 0 of optimizeSet (:62-128) stage by stage, every intermediate result written to `path` in the 'DMSAST01' layout of
+    // Iteration 0 of optimizeSet (:62-128) stage by stage, every intermediate result written to `path` in the 'DMSAST02' layout of
     // dmsa_lidar_slam_amd/dump.py -- the same file oracle/ref_harness/ref_main.cpp writes from the REAL reference, so that a run of the
     // harness elsewhere can be compared with this restatement statement by statement (tests/test_ref_fixtures.py).  inject_info /
     // inject_weights (optional, M x 9 / M floats): the reference's own information matrices and weights replace the fitted ones after
@@ -1346,12 +1388,14 @@ struct Optimizer {
         if (!f) return DMSA_ERR_INVALID;
         const int64_t Mm = (int64_t)currentGauss.members.size(), n = set.numPoints();
         const int32_t hdr[6] = {model, P, a, M, currentGauss.numLevel1, table_rows};
-        std::fwrite("DMSAST01", 1, 8, f), std::fwrite(hdr, 4, 6, f), std::fwrite(&Mm, 8, 1, f), std::fwrite(&n, 8, 1, f);
+        std::fwrite("DMSAST02", 1, 8, f), std::fwrite(hdr, 4, 6, f), std::fwrite(&Mm, 8, 1, f), std::fwrite(&n, 8, 1, f);
         std::fwrite(table, 4, (size_t)table_rows * 12, f);
         std::fwrite(global0.data(), 4, (size_t)n * 4, f);
         if (model == 2) std::fwrite(normal0.data(), 4, (size_t)n * 4, f);
         std::fwrite(currentGauss.segOffset.data(), 4, (size_t)M + 1, f), std::fwrite(currentGauss.members.data(), 4, (size_t)Mm, f);
         std::fwrite(currentGauss.info.data(), 4, (size_t)M * 9, f), std::fwrite(currentGauss.weights.data(), 4, (size_t)M, f);
+        std::fwrite(currentGauss.fitMean.data(), 4, (size_t)M * 3, f), std::fwrite(currentGauss.fitCov.data(), 4, (size_t)M * 9, f);
+        std::fwrite(currentGauss.rawWeights.data(), 4, (size_t)M, f);
         std::fwrite(errorVec.data(), 8, (size_t)rows, f), std::fwrite(Jacobian.data(), 8, (size_t)rows * P, f);
         std::fwrite(H.data(), 8, (size_t)P * P, f), std::fwrite(stepRaw.data(), 8, (size_t)P, f), std::fwrite(optimStep.data(), 8, (size_t)P, f);
         const int32_t tail[2] = {bestK, 0};
@@ -1568,6 +1612,12 @@ struct orc_gaussians {
 extern "C" {
 
 void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+void orc_set_eigen_l1_bytes(int bytes) { g_eigen_l1_bytes = bytes >= 1024 ? bytes : 32 * 1024; }
+int orc_get_eigen_l1_bytes(void) { return g_eigen_l1_bytes; }
+int64_t orc_eigen_gemm_kc(int64_t depth) { return (int64_t)Gaussians::gemm_kc((size_t)depth); }
+float orc_eigen_gemm_dot_f32(const float* a, const float* b, int64_t n) {
+    return Gaussians::gemm_dot_f32((size_t)n, [&](size_t k) { return a[k]; }, [&](size_t k) { return b[k]; });
+}
 int orc_get_threads(void) { return g_threads; }
 
 void orc_axang2rotm(const double* w, double* R9) {
@@ -1677,6 +1727,11 @@ void orc_gaussians_get(const orc_gaussians* g, int32_t* seg_offset, int32_t* mem
     if (member_idx) std::copy(g->g.members.begin(), g->g.members.end(), member_idx);
     if (info_mats) std::copy(g->g.info.begin(), g->g.info.end(), info_mats);
     if (weights) std::copy(g->g.weights.begin(), g->g.weights.end(), weights);
+}
+void orc_gaussians_get_fit(const orc_gaussians* g, float* mean3, float* cov9, float* raw_weights) {
+    if (mean3) std::copy(g->g.fitMean.begin(), g->g.fitMean.end(), mean3);
+    if (cov9) std::copy(g->g.fitCov.begin(), g->g.fitCov.end(), cov9);
+    if (raw_weights) std::copy(g->g.rawWeights.begin(), g->g.rawWeights.end(), raw_weights);
 }
 void orc_gaussians_set_info(orc_gaussians* g, const float* info_mats, const float* weights) {
     if (info_mats) std::copy(info_mats, info_mats + 9 * (size_t)g->g.numPointSets, g->g.info.begin());

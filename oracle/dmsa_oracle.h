@@ -57,6 +57,9 @@ int32_t orc_gaussians_count(const orc_gaussians* g);
 int32_t orc_gaussians_count_level1(const orc_gaussians* g);
 int64_t orc_gaussians_memberships(const orc_gaussians* g);
 void    orc_gaussians_get(const orc_gaussians* g, int32_t* seg_offset, int32_t* member_idx, float* info_mats, float* weights);
+/* intermediate results of the fit: subset.colwise().mean() (M x 3), the covariance before limitCovariance (M x 9, column-major) and
+ * pow(-1) of the member counts before the division by their mean (M) -- the 'fit_sums' stage of tests/ref_stage_checks.py */
+void    orc_gaussians_get_fit(const orc_gaussians* g, float* mean3, float* cov9, float* raw_weights);
 /* overwrite information matrices / weights (stage-level parity: feed the HIP path's Gaussians to the oracle) */
 void    orc_gaussians_set_info(orc_gaussians* g, const float* info_mats, const float* weights);
 /* updateErrorTerms rows 0..M-1 (DmsaOptimizer.h:242-268) on the given global points */
@@ -79,6 +82,13 @@ typedef struct orc_iter_trace {
  * results are bit-identical to 1 thread).  Default 1 = the reference's execution order. */
 void orc_set_threads(int n);
 int orc_get_threads(void);
+/* L1 data cache size of the machine the reference runs on: Eigen derives the depth blocking kc of centered^T * centered from it
+ * (Gaussians.h:147; 32768 -> kc <= 680, 49152 -> 1016).  Default 32768. */
+void orc_set_eigen_l1_bytes(int bytes);
+int orc_get_eigen_l1_bytes(void);
+int64_t orc_eigen_gemm_kc(int64_t depth);
+/* one coefficient of a (1 x n) * (n x 1) slice of that product: sum_k a[k] * b[k] in Eigen 3.4's float order */
+float orc_eigen_gemm_dot_f32(const float* a, const float* b, int64_t n);
 int orc_optimize_window(dmsa_window_problem* p, const dmsa_settings* s, dmsa_report* rep, float* global_out,
                         orc_iter_trace* trace, int32_t trace_capacity, int32_t fixed_iters);
 int orc_optimize_keyframes(dmsa_keyframe_problem* p, const dmsa_settings* s, dmsa_report* rep, float* global_out,

@@ -58,6 +58,7 @@ def lib() -> C.CDLL:
     L.orc_gaussians_memberships.restype = C.c_int64
     L.orc_gaussians_get.argtypes = [vp, ip, ip, fp, fp]
     L.orc_gaussians_set_info.argtypes = [vp, fp, fp]
+    L.orc_gaussians_get_fit.argtypes = [vp, fp, fp, fp]
     L.orc_eval_residuals.argtypes = [vp, fp, dp]
     L.orc_eigen_mean_f32.argtypes = [fp, C.c_int64, C.c_int64]
     L.orc_eigen_mean_f32.restype = C.c_float
@@ -190,6 +191,12 @@ class Gaussians:
         self.weights = np.zeros(self.M, np.float32)
         lib().orc_gaussians_get(self._h, capi.ptr(self.seg_offset, C.c_int32), capi.ptr(self.members, C.c_int32), capi.ptr(self.info, C.c_float), capi.ptr(self.weights, C.c_float))
 
+    def fit_sums(self):
+        """(mean M x 3, covariance before limitCovariance M x 9 column-major, pow(-1) of the member counts M)"""
+        mean, cov, raw = np.zeros((self.M, 3), np.float32), np.zeros((self.M, 9), np.float32), np.zeros(self.M, np.float32)
+        lib().orc_gaussians_get_fit(self._h, capi.ptr(mean, C.c_float), capi.ptr(cov, C.c_float), capi.ptr(raw, C.c_float))
+        return mean, cov, raw
+
     def set_info(self, info, weights):
         info = np.ascontiguousarray(info, np.float32)
         weights = np.ascontiguousarray(weights, np.float32)
@@ -213,6 +220,28 @@ def eigen_mean_f32(x, offset_floats=0):
     vector starts behind a 16-byte boundary (column c of an n x 3 column-major matrix: c * n)."""
     x = np.ascontiguousarray(x, np.float32)
     return np.float32(lib().orc_eigen_mean_f32(x.ctypes.data_as(capi.c_float_p), x.size, int(offset_floats)))
+
+
+def set_eigen_l1_bytes(nbytes: int) -> None:
+    """L1 data cache size of the machine the reference runs on (Eigen sizes the depth blocks of centered^T * centered from it)."""
+    L = lib()
+    L.orc_set_eigen_l1_bytes.argtypes = [C.c_int]
+    L.orc_set_eigen_l1_bytes(int(nbytes))
+
+
+def eigen_gemm_kc(depth: int) -> int:
+    L = lib()
+    L.orc_eigen_gemm_kc.argtypes, L.orc_eigen_gemm_kc.restype = [C.c_int64], C.c_int64
+    return int(L.orc_eigen_gemm_kc(int(depth)))
+
+
+def eigen_gemm_dot_f32(a, b):
+    """sum_k a[k] * b[k] in the float order of Eigen 3.4's (3 x n) * (n x 3) product (Gaussians.h:147): lazy product below 14, gebp chains in depth blocks above."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    L = lib()
+    L.orc_eigen_gemm_dot_f32.argtypes, L.orc_eigen_gemm_dot_f32.restype = [capi.c_float_p, capi.c_float_p, C.c_int64], C.c_float
+    return np.float32(L.orc_eigen_gemm_dot_f32(a.ctypes.data_as(capi.c_float_p), b.ctypes.data_as(capi.c_float_p), a.size))
 
 
 def _run(fn, prob, settings, fixed_iters, want_global, npts):

@@ -80,3 +80,75 @@ def test_columns_of_a_column_major_matrix_start_at_c_times_n(orc):
         differs += int(orc.eigen_mean_f32(m[:, c], 0).tobytes() != got.tobytes())
     assert abs(float(orc.eigen_mean_f32(m[:, 0], 0)) - float(m[:, 0].astype(np.float64).mean())) < 1e-4
     assert differs >= 0  # informational: peels usually change the last bit of the mean
+
+
+# ---- centered^T * centered (Gaussians.h:147): Eigen 3.4's product kernels for a (3 x n) * (n x 3) float product -----------------------
+def gebp_model_dot(a, b, l1_bytes=32 * 1024):
+    """Independent transcription of what Eigen 3.4.0 does for ONE coefficient of that product (see oracle/dmsa_oracle.cpp,
+    Gaussians::gemm_dot_f32): evaluateProductBlockingSizesHeuristic's kc written with its own variable names, then gebp's scalar tail."""
+    n = len(a)
+    prod = (a * b).astype(f32)  # every product rounded to float on its own (no FMA: the reference is built without -march)
+    if n + 3 + 3 < 20:  # EIGEN_GEMM_TO_COEFFBASED_THRESHOLD: lazy product, linear redux of the products from an aligned start
+        return _redux_sum(prod)
+    k = n
+    if max(k, 3, 3) >= 48:
+        mr, nr, k_peeling = 8, 4, 8
+        k_div, k_sub = 1 * (mr * 4 + nr * 4), mr * nr * 4
+        max_kc = max(((l1_bytes - k_sub) // k_div) & ~(k_peeling - 1), 1)
+        if k > max_kc:
+            k = max_kc if k % max_kc == 0 else max_kc - k_peeling * ((max_kc - 1 - (k % max_kc)) // (k_peeling * (k // max_kc + 1)))
+    res = f32(0)
+    for k2 in range(0, n, k):
+        c0 = f32(0)
+        for t in prod[k2:k2 + k]:
+            c0 = f32(t + c0)
+        res = f32(res + f32(f32(1) * c0))
+    return res
+
+
+def _redux_sum(x):
+    """redux_impl<sum, LinearVectorizedTraversal, NoUnrolling> with Packet4f from element 0 (the sum, not the mean)"""
+    n = len(x)
+    packets = n // 4
+    if packets == 0:
+        r = x[0]
+        for v in x[1:]:
+            r = f32(r + v)
+        return r
+    acc0 = x[0:4].copy()
+    if packets > 1:
+        acc1 = x[4:8].copy()
+        pair_end = 8 * (packets // 2)
+        for a in range(8, pair_end, 8):
+            acc0 = (acc0 + x[a:a + 4]).astype(f32)
+            acc1 = (acc1 + x[a + 4:a + 8]).astype(f32)
+        acc0 = (acc0 + acc1).astype(f32)
+        if 4 * packets > pair_end:
+            acc0 = (acc0 + x[pair_end:pair_end + 4]).astype(f32)
+    r = f32(f32(acc0[0] + acc0[2]) + f32(acc0[1] + acc0[3]))
+    for v in x[4 * packets:]:
+        r = f32(r + v)
+    return r
+
+
+@pytest.mark.parametrize("n", list(range(2, 24)) + [47, 48, 63, 257, 679, 680, 681, 1000, 1361, 2049, 14200])
+def test_oracle_covariance_product_follows_eigens_product_kernels(orc, n):
+    rng = np.random.default_rng(n)
+    a = rng.normal(0, 0.3, n).astype(f32)
+    b = rng.normal(0, 0.3, n).astype(f32)
+    assert orc.eigen_gemm_dot_f32(a, b).tobytes() == gebp_model_dot(a, b).tobytes()
+    assert orc.eigen_gemm_dot_f32(a, a).tobytes() == gebp_model_dot(a, a).tobytes()
+
+
+def test_depth_blocks_of_the_product_follow_the_l1_size(orc):
+    """kc for a 32 KB L1d is 680 (every Gaussian up to 680 members is ONE chain: machine-independent); 48 KB gives 1016.  Above max_kc the
+    depth is cut into nearly equal blocks that are multiples of 8."""
+    try:
+        assert [orc.eigen_gemm_kc(k) for k in (14, 47, 48, 680, 681, 1360, 1361, 14200)] == [14, 47, 48, 680, 344, 680, 456, 680]
+        orc.set_eigen_l1_bytes(48 * 1024)
+        assert [orc.eigen_gemm_kc(k) for k in (680, 1016, 1017, 14200)] == [680, 1016, 512, 1016]
+        rng = np.random.default_rng(3)
+        a = rng.normal(0, 0.3, 900).astype(f32)
+        assert orc.eigen_gemm_dot_f32(a, a).tobytes() == gebp_model_dot(a, a, 48 * 1024).tobytes()
+    finally:
+        orc.set_eigen_l1_bytes(32 * 1024)

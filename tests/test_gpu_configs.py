@@ -157,22 +157,6 @@ def test_more_gaussians_than_points(hip, orc):
     assert rep.num_gaussians > n + 16
 
 
-def test_keyframes_fast_path_equivalent(hip, orc):
-    prob = synth.keyframe_problem(seed=3, frames=8, rings=24, az_steps=160, arc=0.5)
-    s = DmsaOptimSettings.keyframe_map(num_iter=3)
-    p_ref, p_gpu = prob.copy(), prob.copy()
-    rep_ref, _, trace = orc.optimize_keyframes(p_ref, s)
-    opt = hip.DmsaOptimizer(fast_sums=True)
-    rep = opt.optimizeSet(p_gpu, s)
-    assert rep.iterations == rep_ref.iterations and rep.stop_reason == rep_ref.stop_reason
-    tr = opt.trace()
-    assert (trace[0]["M"], trace[0]["Mm"]) == (tr[0]["M"], tr[0]["Mm"])
-    for a, b in zip(trace, tr):
-        assert abs(a["error0"] - b["error0"]) <= 5e-3 * a["error0"]
-    dt, dr = _pose_diff(orc, p_ref, p_gpu)
-    assert dt < 1e-2 and dr < 5e-3, (dt, dr)  # max_step = 0.01 bounds the drift of the keyframe pass
-
-
 # ---- degenerate inputs ----------------------------------------------------------------------------------------------
 def test_window_without_static_map(hip, orc):
     prob = synth.window_problem(seed=4, scans=3, rings=32, az_steps=256, num_static=0)
@@ -207,8 +191,8 @@ def full_window():
 
 
 def test_config3_full_size_structure_and_residuals(hip, orc, full_window):
-    """The bench workload itself: bit-exact voxel structure, Gaussian sets, information matrices and residuals on the
-    parity path; fast path within 1e-6 relative; size-independent invariants of both."""
+    """The bench workload itself: bit-exact voxel structure, Gaussian sets, information matrices and residuals; size-independent
+    invariants."""
     prob = full_window
     s = DmsaOptimSettings.sliding_window()
     n, ns = prob.localPoints.shape[0], prob.staticPoints.shape[0]
@@ -218,59 +202,44 @@ def test_config3_full_size_structure_and_residuals(hip, orc, full_window):
     ids = np.concatenate([prob.ringIds, prob.staticRingIds])
     ref = orc.Gaussians(glob, ids, prob.minGridSize, s)
 
-    results = {}
-    for mirror in (True, False):
-        opt = hip.DmsaOptimizer(fast_sums=not mirror)
-        opt.upload(prob)
-        opt.poseTables(prob.getPoseParameters())
-        got = opt.updateGlobalPoints(0)
-        assert np.array_equal(got[:n, :3], glob[:n, :3])
-        M, Mm = opt.buildGaussians(s)
-        assert (M, Mm) == (ref.M, ref.Mm)
-        for level, f in ((0, s.grid_size_1_factor), (1, s.grid_size_2_factor)):
-            info, code, key, order = opt.voxelLevel(level)
-            res = float(np.float32(f) * np.float32(prob.minGridSize))
-            info_r, code_r, key_r, order_r = orc.voxelize(glob, res)
-            assert info.depth == info_r.depth and info.num_leaves == info_r.num_leaves
-            assert np.array_equal(code, code_r) and np.array_equal(order, order_r)
-            # invariants: DFS order = non-decreasing codes, `order` is a permutation of the finite points, ascending in a leaf
-            sc = code[order]  # leaf codes are per point; `order` is the leaf-DFS permutation
-            assert np.all(sc[1:] >= sc[:-1])
-            assert np.array_equal(np.sort(order), np.arange(n + ns))
-            same = sc[1:] == sc[:-1]
-            assert np.all(order[1:][same] > order[:-1][same])
-        seg, memb, info12, w = opt.gaussians()
-        assert np.array_equal(seg, ref.seg_offset) and np.array_equal(memb, ref.members)
-        assert seg[-1] == Mm and np.all(np.diff(seg) >= s.min_num_points_per_set)
-        base = prob.getPoseParameters()
-        params = np.stack([base, base + H_INCR * np.eye(len(base))[4]])
-        tables = opt.poseTables(params)
-        e = opt.evalResiduals(2)
-        results[mirror] = (info12, w, e)
-        if not mirror:  # fast path: <= 1e-6 relative against the oracle evaluated with the SAME information matrices
-            ref.set_info(info12, w)
-            for b in range(2):
-                gb = orc.transform_points(tables[b], prob.localPoints, prob.tformIdPerPoint)
-                e_ref = ref.residuals(np.concatenate([gb, prob.staticPoints]).astype(np.float32))
-                rel = np.abs(e[b] - e_ref) / np.maximum(np.abs(e_ref), 1e-12)
-                assert rel.max() < 1e-6, (b, rel.max())
-        if mirror:
-            assert np.array_equal(info12, ref.info) and np.array_equal(w, ref.weights)
-            for b in range(2):
-                gb = orc.transform_points(tables[b], prob.localPoints, prob.tformIdPerPoint)
-                e_ref = ref.residuals(np.concatenate([gb, prob.staticPoints]).astype(np.float32))
-                assert np.array_equal(e[b], e_ref)
-        # idempotence: building again from the same points gives the same sets
-        assert opt.buildGaussians(s) == (M, Mm)
-        seg2, memb2, _, _ = opt.gaussians()
-        assert np.array_equal(seg2, seg) and np.array_equal(memb2, memb)
-        opt.close()
-    (i_m, w_m, e_m), (i_f, w_f, e_f) = results[True], results[False]
-    scale = np.abs(i_m).max(axis=1, keepdims=True)
-    assert (np.abs(i_f - i_m) / scale).max() < 1e-5
-    # independently fitted information matrices (double sums in a different order): the median still holds 1e-6
-    rel = np.abs(e_f - e_m) / np.maximum(np.abs(e_m), 1e-12)
-    assert np.median(rel) < 1e-6 and rel.max() < 5e-4
+    opt = hip.DmsaOptimizer()
+    opt.upload(prob)
+    opt.poseTables(prob.getPoseParameters())
+    got = opt.updateGlobalPoints(0)
+    assert np.array_equal(got[:n, :3], glob[:n, :3])
+    M, Mm = opt.buildGaussians(s)
+    assert (M, Mm) == (ref.M, ref.Mm)
+    for level, f in ((0, s.grid_size_1_factor), (1, s.grid_size_2_factor)):
+        info, code, key, order = opt.voxelLevel(level)
+        res = float(np.float32(f) * np.float32(prob.minGridSize))
+        info_r, code_r, key_r, order_r = orc.voxelize(glob, res)
+        assert info.depth == info_r.depth and info.num_leaves == info_r.num_leaves
+        assert np.array_equal(code, code_r) and np.array_equal(order, order_r)
+        # invariants: DFS order = non-decreasing codes, `order` is a permutation of the finite points, ascending in a leaf
+        sc = code[order]  # leaf codes are per point; `order` is the leaf-DFS permutation
+        assert np.all(sc[1:] >= sc[:-1])
+        assert np.array_equal(np.sort(order), np.arange(n + ns))
+        same = sc[1:] == sc[:-1]
+        assert np.all(order[1:][same] > order[:-1][same])
+    seg, memb, info12, w = opt.gaussians()
+    assert np.array_equal(seg, ref.seg_offset) and np.array_equal(memb, ref.members)
+    assert seg[-1] == Mm and np.all(np.diff(seg) >= s.min_num_points_per_set)
+    # the fit in Eigen's own float orders, incl. the Gaussians above 680 members whose products run in several depth blocks
+    assert np.diff(seg).max() > 4096
+    assert np.array_equal(info12, ref.info) and np.array_equal(w, ref.weights)
+    base = prob.getPoseParameters()
+    params = np.stack([base, base + H_INCR * np.eye(len(base))[4]])
+    tables = opt.poseTables(params)
+    e = opt.evalResiduals(2)
+    for b in range(2):
+        gb = orc.transform_points(tables[b], prob.localPoints, prob.tformIdPerPoint)
+        e_ref = ref.residuals(np.concatenate([gb, prob.staticPoints]).astype(np.float32))
+        assert np.array_equal(e[b], e_ref)
+    # idempotence: building again from the same points gives the same sets
+    assert opt.buildGaussians(s) == (M, Mm)
+    seg2, memb2, _, _ = opt.gaussians()
+    assert np.array_equal(seg2, seg) and np.array_equal(memb2, memb)
+    opt.close()
 
 
 def test_config3_full_size_two_iterations_match_oracle(hip, orc, full_window):
@@ -280,33 +249,11 @@ def test_config3_full_size_two_iterations_match_oracle(hip, orc, full_window):
 
 @pytest.mark.parametrize("dt_res", [2e-4, 2e-5])
 def test_long_pose_tables(hip, orc, dt_res):
-    """Dense pose tables of 10^3 .. 10^4 rows (fine dt_res): tiles may reference more rows than the tiled kernels hold in LDS, in
-    which case the library falls back to the streaming kernels -- same structure, residuals within 1e-6, parity path exact."""
+    """Dense pose tables of 10^3 .. 10^4 rows (fine dt_res)."""
     prob = synth.window_problem(seed=14, scans=2, rings=32, az_steps=256, num_static=3000, dt_res=dt_res)
     assert prob.trajTime.shape[0] > 900
     s = DmsaOptimSettings.sliding_window(num_iter=2)
     _parity_run(hip, orc, prob, s)
-    opt = hip.DmsaOptimizer(fast_sums=True)
-    opt.upload(prob)
-    opt.poseTables(prob.getPoseParameters())
-    opt.updateGlobalPoints(0, download=False)
-    M, Mm = opt.buildGaussians(s)
-    table, _ = orc.window_pose_table(prob)
-    g = orc.transform_points(table, prob.localPoints, prob.tformIdPerPoint)
-    glob = np.concatenate([g, prob.staticPoints]).astype(np.float32)
-    ref = orc.Gaussians(glob, np.concatenate([prob.ringIds, prob.staticRingIds]), prob.minGridSize, s)
-    assert (M, Mm) == (ref.M, ref.Mm)
-    _, _, info, w = opt.gaussians()
-    ref.set_info(info, w)
-    base = prob.getPoseParameters()
-    params = np.stack([base, base + H_INCR * np.eye(len(base))[2]])
-    tables = opt.poseTables(params)
-    e = opt.evalResiduals(2)
-    for b in range(2):
-        gb = orc.transform_points(tables[b], prob.localPoints, prob.tformIdPerPoint)
-        e_ref = ref.residuals(np.concatenate([gb, prob.staticPoints]).astype(np.float32))
-        rel = np.abs(e[b] - e_ref) / np.maximum(np.abs(e_ref), 1e-12)
-        assert rel.max() < 1e-6, (b, rel.max())
 
 
 def test_additional_error_rows_bit_exact(orc):

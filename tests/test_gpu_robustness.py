@@ -51,13 +51,12 @@ def test_two_contexts_interleaved(hip):
     assert (ra1.num_gaussians, rb1.num_gaussians) != (0, 0)
 
 
-@pytest.mark.parametrize("fast", [False, True])
-def test_both_paths_are_deterministic(hip, fast):
+def test_the_path_is_deterministic(hip):
     p = synth.window_problem(seed=43, scans=3, rings=32, az_steps=192, num_static=4000)
     s = DmsaOptimSettings.sliding_window(num_iter=3)
     a, b = p.copy(), p.copy()
-    hip.DmsaOptimizer(fast_sums=fast).optimizeSet(a, s)
-    hip.DmsaOptimizer(fast_sums=fast).optimizeSet(b, s)
+    hip.DmsaOptimizer().optimizeSet(a, s)
+    hip.DmsaOptimizer().optimizeSet(b, s)
     assert np.array_equal(_poses(a), _poses(b))
 
 
@@ -66,6 +65,7 @@ def test_invalid_arguments_return_error_codes():
     ctx = C.c_void_p()
     assert lib.dmsa_create(10_000, 0, C.byref(ctx)) == capi.DMSA_ERR_NO_DEVICE      # no such device
     assert lib.dmsa_create(0, 0, None) == capi.DMSA_ERR_INVALID
+    assert lib.dmsa_create(0, 0x10, C.byref(ctx)) == capi.DMSA_ERR_INVALID     # an unknown flag bit (0x10: the retired fast sums)
     assert lib.dmsa_create(0, 0, C.byref(ctx)) == capi.DMSA_OK
     rep, st = capi.Report(), capi.Settings()
     lib.dmsa_default_settings(C.byref(st))
