@@ -69,7 +69,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed iterations (default: a timed region of >= 0.2 s)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="window", choices=["window", "keyframes"])
+    ap.add_argument("--workload", default="window", choices=["window", "keyframes", "small_imu", "small_rosette"],
+                    help="window / keyframes: BASELINE.json configs 3 / 4; small_imu / small_rosette: only the small-window measurement of configs 2 / 5 "
+                         "(the reference's everyday problem size), e.g. under rocprofv3")
     ap.add_argument("--scans", type=int, default=10)
     ap.add_argument("--rings", type=int, default=128)
     ap.add_argument("--az", type=int, default=1024)
@@ -131,6 +133,11 @@ def main():
     from dmsa_lidar_slam_amd.api import DmsaOptimizer
     from dmsa_lidar_slam_amd.problems import DmsaOptimSettings
 
+    if args.workload.startswith("small_"):
+        if rank == 0:
+            print(json.dumps({"small_window": small_windows(local_rank, [args.workload[6:]], args.steps, 0 if args.no_extras else min(args.cpu_iters, 10),
+                                                            calls=not args.no_extras)}), flush=True)
+        return
     if args.workload == "window":
         prob = synth.window_problem(seed=1 + rank, scans=args.scans, rings=args.rings, az_steps=args.az, num_static=args.static)
         settings = DmsaOptimSettings.sliding_window(num_iter=1)
@@ -288,6 +295,8 @@ def main():
     keyframe_pass = None
     if args.workload == "window" and args.keyframe_steps > 0 and not args.no_extras:
         keyframe_pass = sharded_keyframe_pass(args, rank, local_rank, world, dist, coll_dev, sync_all)
+    # the reference's everyday problem size (configs 2 and 5: five scans of a few thousand points): launch-latency territory
+    small = small_windows(local_rank, ["imu", "rosette"], 100, min(args.cpu_iters, 10)) if (rank == 0 and args.workload == "window" and not args.no_extras) else None
 
     if rank == 0:
         iters = rep.iterations
@@ -382,6 +391,7 @@ def main():
             "per_rank": per_rank,
             "stage_ms_per_step": stage,
             "keyframe_pass": keyframe_pass,
+            "small_window": small,
             "pcie_inclusive": pcie,
         }
         if world == 1 and args.cpu_iters > 0 and not args.no_extras:
@@ -508,7 +518,61 @@ def cpp_aos_call(prob, num_scans):
             os.remove(path)
 
 
-def cpu_baseline(prob, settings, iters, workload):
+def small_windows(device, which, steps, cpu_iters, calls=True):
+    """Configs 2 and 5 of BASELINE.json at their real shapes (config/slam_settings.yaml:6,24-28, config/livox.yaml:43 of the reference): five
+    scans of ~3 000 points after preProcess + 10^4 static map points with IMU rows ('imu', Hilti-like, 32 rings), and five rosette
+    scans of 24 000 points without IMU ('rosette', Livox-like).  At this size an iteration is ~60 dependent launches of microseconds each:
+    the GPU is launch-latency bound, and the number next to the CPU oracle's says how much of the headline ratio survives."""
+    from dmsa_lidar_slam_amd import synth
+    from dmsa_lidar_slam_amd.api import DmsaOptimizer
+    from dmsa_lidar_slam_amd.problems import DmsaOptimSettings
+    import torch
+
+    out = {}
+    for name in which:
+        if name == "imu":
+            prob = synth.window_problem(seed=5, scans=5, rings=32, az_steps=96, num_static=10_000, use_imu=True)
+            settings = DmsaOptimSettings.sliding_window(use_imu=True, num_iter=1)
+            shape = "5 x 3 072 points (32 rings) + 10 000 static, IMU rows"
+        else:
+            prob = synth.rosette_window_problem(seed=2, scans=5, pts_per_scan=24_000, num_static=20_000)
+            settings = DmsaOptimSettings.sliding_window(num_iter=1)
+            shape = "5 x 24 000 rosette points + 20 000 static, no IMU"
+        opt = DmsaOptimizer(device=device, fixed_iters=True)
+        opt.upload(prob)
+        settings.num_iter = 5
+        opt.optimizeResident(settings)
+        opt.timing(reset=True)
+        settings.num_iter = steps
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rep = opt.optimizeResident(settings)
+        dt = time.perf_counter() - t0
+        # one call of ten iterations with the upload inside: what DmsaSlam::processPointCloud pays per scan at this size
+        s10 = type(settings)(**{**settings.__dict__, "num_iter": 10})
+        call_ms = []
+        for _ in range(5 if calls else 0):
+            pc = prob.copy()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            opt.optimizeSet(pc, s10)
+            call_ms.append(time.perf_counter() - t1)
+        opt.close()
+        entry = {"shape": shape, "points": int(prob.localPoints.shape[0] + prob.staticPoints.shape[0]), "params": int(prob.numParams),
+                 "gaussians": int(rep.num_gaussians), "memberships": int(rep.num_memberships),
+                 "value": round(rep.iterations / dt, 2), "unit": "iterations/s", "ms_per_step": round(1e3 * dt / max(1, rep.iterations), 4),
+                 "drop_in_call_10_iterations_ms": round(1e3 * min(call_ms), 3) if call_ms else None}
+        if cpu_iters > 0:
+            cb = cpu_baseline(prob, settings, cpu_iters, "window", parallel=False)
+            entry["cpu_oracle_it_per_s"] = cb["value"]
+            entry["gpu_over_cpu"] = round(entry["value"] / cb["value"], 1) if cb["value"] > 0 else None
+        out[name] = entry
+    out["note"] = ("launch-latency bound: see profiles/r05_small_window_*.txt for the launch count and the sum of kernel time against wall time per "
+                   "iteration (DESIGN.md 6.3)")
+    return out
+
+
+def cpu_baseline(prob, settings, iters, workload, parallel=True):
     """The CPU oracle (the repo's restatement of the reference's single-threaded -O2 loop; the reference itself cannot
     be built here) timed on the SAME workload for a bounded number of iterations."""
     from oracle import oracle_py as orc
@@ -527,6 +591,8 @@ def cpu_baseline(prob, settings, iters, workload):
             orc.set_threads(1)
 
     it1, dt1 = timed(1)
+    if not parallel:
+        return {"value": round(it1 / dt1, 4), "unit": "iterations/s", "cores": 1, "kind": "port"}
     threads = max(1, min(32, os.cpu_count() or 1))
     itp, dtp = timed(threads)
     return {

@@ -122,6 +122,9 @@ class DmsaOptimizer:
             keep.append(stat)
             if reserve:
                 self._check(self._lib.dmsa_reserve(self._ctx, p.localPoints.shape[0] + stat.shape[0], p.trajTime.shape[0], p.numParams), "reserve")
+            # what integration/DmsaOptimizerHip.h hands over: NO flat point arrays -- the AoS calls must not look at them
+            cp.num_points, cp.xyz_local, cp.tform_idx, cp.ring_id = 0, None, None, None
+            cp.num_static, cp.xyz_static, cp.ring_id_static = 0, None, None
             rc = self._lib.dmsa_optimize_window_aos(self._ctx, C.byref(cp), views, len(off) - 1, C.byref(sv), C.byref(cs), C.byref(rep))
         else:
             off = p.frameOffsets
@@ -134,6 +137,7 @@ class DmsaOptimizer:
                 idx = np.ascontiguousarray(p.ringIds[a:b], np.int32)
                 keep += [cloud, idx]
                 views[k] = self._view(cloud, 16, idx)
+            cp.xyz_local, cp.normal_local, cp.ring_id, cp.frame_offset = None, None, None, None
             rc = self._lib.dmsa_optimize_keyframes_aos(self._ctx, C.byref(cp), views, p.numFrames, C.byref(cs), C.byref(rep))
         self._check(rc, "optimizeSetAos")
         self._problem, self._cprob = p, cp
@@ -154,7 +158,8 @@ class DmsaOptimizer:
         stat["x"], stat["y"], stat["z"], stat["w"] = window.staticPoints[:, 0], window.staticPoints[:, 1], window.staticPoints[:, 2], 1.0
         stat["id"], stat["stamp"], stat["isStatic"] = window.staticRingIds, -1000.0, 1
         sv = self._view(stat, 24, None)
-        cp.num_points = 0
+        cp.num_points, cp.xyz_local, cp.tform_idx, cp.ring_id = 0, None, None, None
+        cp.num_static, cp.xyz_static, cp.ring_id_static = 0, None, None
         self._check(self._lib.dmsa_window_upload_from_ring_aos(self._ctx, C.byref(cp), float(t0), C.byref(sv)), "window_upload_from_ring_aos")
         self._problem, self._cprob = window, cp
 

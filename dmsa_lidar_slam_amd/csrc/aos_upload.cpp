@@ -43,7 +43,7 @@ int dmsa_window_upload_aos(dmsa_ctx* ctx, const dmsa_window_problem* p, const dm
         N += clouds[c].count, raw_bytes += (size_t)clouds[c].count * 16;
     }
     const int64_t S = static_points ? static_points->count : 0;
-    if (S > 0 && !view_ok(*static_points, 4)) {
+    if (S < 0 || (S > 0 && !view_ok(*static_points, 4))) {
         ctx->err = "invalid static point view";
         return DMSA_ERR_INVALID;
     }
@@ -240,10 +240,11 @@ int dmsa_window_ring_push_aos(dmsa_ctx* ctx, const dmsa_aos_view* scan, int32_t 
 int dmsa_window_upload_from_ring_aos(dmsa_ctx* ctx, const dmsa_window_problem* p, double t0, const dmsa_aos_view* static_points) {
     if (!ctx || !p) return DMSA_ERR_INVALID;
     const int64_t S = static_points ? static_points->count : 0;
-    if (S > 0 && !view_ok(*static_points, 4)) return DMSA_ERR_INVALID;
+    if (S < 0 || (S > 0 && !view_ok(*static_points, 4))) return DMSA_ERR_INVALID;
     // the static tail of globalPoints as flat arrays in pinned staging (x y z 1 | id): what dmsa_window_upload_from_ring reads
     dmsa_window_problem q = *p;
     q.num_static = S, q.xyz_static = nullptr, q.ring_id_static = nullptr;
+    q.num_points = 0, q.xyz_local = nullptr, q.tform_idx = nullptr, q.ring_id = nullptr;  // the window points come from the ring: p's point arrays are ignored
     std::vector<float> xyz;
     std::vector<int32_t> ids;
     if (S > 0) {

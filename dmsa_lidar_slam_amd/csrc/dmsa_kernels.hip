@@ -1167,7 +1167,9 @@ __global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__
                 const float4 cn = cone[j >> 6];
                 const float2 nb = norms[j >> 6];
                 const float ca = sum3f(na.x * cn.x, na.y * cn.y, na.z * cn.z) * na_inv;      // cos alpha
-                const float sa = sqrtf(fmaxf(0.0f, 1.0f - ca * ca)), sp = sqrtf(fmaxf(0.0f, 1.0f - cn.w * cn.w));
+                // sin alpha must not be UNDERestimated: ca carries ~1e-7 of error (normalised axis x 1 / |a|), which near ca = 1 is up to 4.5e-4 in
+                // sqrt(1 - ca^2) -- more than the slack of the bound.  1 - ca^2 is off by at most 2 |ca| 1e-7 + eps < 4e-7: add that before the root.
+                const float sa = sqrtf(fmaxf(0.0f, 1.0f - ca * ca) + 4e-7f), sp = sqrtf(fmaxf(0.0f, 1.0f - cn.w * cn.w) + 4e-7f);
                 const float cmin = ca <= -cn.w ? -1.0f : ca * cn.w - sa * sp - 2e-6f;        // cos(min(pi, alpha + phi)), rounded down
                 const float lb = na2 + nb.x * nb.x + (cmin < 0.0f ? 2.0f * na_len * nb.y * cmin : 0.0f);
                 // inactive lanes agree to anything

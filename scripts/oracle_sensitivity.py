@@ -6,7 +6,7 @@ The reference cannot be built here, so wherever its arithmetic is not spelled ou
 builds one oracle per switch (make -C oracle hypotheses), runs the same problems through every build for the same number of
 iterations (early exits off) and reports how far the optimised GLOBAL poses move away from the default oracle's.
 
-    python scripts/oracle_sensitivity.py [--iters 5] [--out profiles/r04_oracle_sensitivity.json]
+    python scripts/oracle_sensitivity.py [--iters 5] [--out profiles/r05_oracle_sensitivity.json]
 
 CPU only; about two minutes (the P = 186 keyframe case dominates).  Test infrastructure: nothing here touches the product library.
 """
@@ -23,8 +23,11 @@ HYPOTHESES = {
     "MAHA_ASSOC": "w*((d^T A) d) instead of ((w d^T) A) d (DmsaOptimizer.h:263)",
     "FIT_FLOAT": "every fit sum (column means, centred products, weight mean) as a scalar float chain in member order (Gaussians.h:146-154, :176)",
     "FIT_MEAN_TREE": "colwise().mean() / VectorXf::mean() as 64-wide trees in double (the statement until round 4) instead of Eigen's own linear-redux float order",
-    "FIT_COV_GEMM": "centered^T*centered in the float order of Eigen 3.4's product kernels as recalled (lazy product below 14 members, gebp scalar tails in depth "
-                    "blocks for a 32 KB L1) instead of 64-wide trees in double (Gaussians.h:147)",
+    "FIT_COV_TREE": "centered^T*centered as 64-wide pairwise trees in double, divided in double (the statement until round 5) instead of the float order of "
+                    "Eigen 3.4's product kernels (lazy product below 14 members, gebp scalar chains in depth blocks for a 32 KB L1, float division) (Gaussians.h:147)",
+    "WEIGHT_DIV": "pow(-1) of the member counts as the correctly rounded 1.0f / n instead of libm's powf(n, -1.0f) (Gaussians.h:172)",
+    "LIMITCOV_VT": "limitCovariance rebuilds V*D*V^T instead of V*D*V^-1 with the cofactor inverse (Gaussians.h:200)",
+    "EIGEN_L1_48K": "the same product order for a reference machine with a 48 KB L1d: depth blocks of 1016 instead of 680 members (run-time: orc_set_eigen_l1_bytes)",
     "JTJ_NOFMA": "J^T J / J^T e / e^T e at P > 64 with separate multiply and add instead of the fma chain of v_mfma_f64 (DmsaOptimizer.h:107-113)",
     "GLIBC_TRIG": "sin/cos/acos/atan2 from glibc instead of include/dmsa_detmath.h (helpers.h:24-65)",
 }
@@ -64,6 +67,8 @@ def worker(case, iters):
 
     prob, s, window = make_case(case)
     s.num_iter = iters
+    if os.environ.get("DMSA_ORACLE_L1"):
+        orc.set_eigen_l1_bytes(int(os.environ["DMSA_ORACLE_L1"]))
     fn = orc.optimize_window if window else orc.optimize_keyframes
     rep, _, trace = fn(prob, s, fixed_iters=True)
     go, gt = orc.relative2global(prob.relOrientations, prob.relTranslations)
@@ -78,8 +83,11 @@ def worker(case, iters):
                       "structure": [[int(t["M"]), int(t["Mm"]), int(t["best_k"])] for t in trace[: rep.iterations]]}))
 
 
-def run(case, lib, iters):
+def run(case, lib, iters, l1=None):
     env = dict(os.environ)
+    env.pop("DMSA_ORACLE_L1", None)
+    if l1:
+        env["DMSA_ORACLE_L1"] = str(l1)
     if lib:
         env["DMSA_ORACLE_LIB"] = lib
     else:
@@ -108,7 +116,7 @@ def main():
         base = run(case, None, args.iters)
         row = {"default": {"max_abs_dt_to_truth_m": base["max_abs_dt_to_truth_m"]}}
         for h in hyps:
-            v = run(case, os.path.join(ROOT, "oracle", "_variants", f"libdmsa_oracle_{h}.so"), args.iters)
+            v = run(case, None, args.iters, l1=48 * 1024) if h == "EIGEN_L1_48K" else run(case, os.path.join(ROOT, "oracle", "_variants", f"libdmsa_oracle_{h}.so"), args.iters)
             row[h] = {"max_abs_dt_m": float(np.abs(np.array(v["gt"]) - np.array(base["gt"])).max()),
                       "max_abs_dr_rad": float(np.abs(np.array(v["go"]) - np.array(base["go"])).max()),
                       "same_structure_and_line_search": v["structure"] == base["structure"], "max_abs_dt_to_truth_m": v["max_abs_dt_to_truth_m"]}
