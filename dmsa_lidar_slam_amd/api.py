@@ -172,6 +172,13 @@ class DmsaOptimizer:
         self._check(self._lib.dmsa_get_global_points_aos(self._ctx, out.ctypes.data, n, out.dtype.itemsize, 0, 16 if keyframes else -1), "get_global_points_aos")
         return out
 
+    def powMinusOne(self, counts) -> np.ndarray:
+        """Test hook: pow(-1) of member counts as the fit computes it on the device (the host libm's powf through its difference table)."""
+        n = np.ascontiguousarray(counts, np.int32)
+        out = np.zeros(n.shape[0], np.float32)
+        self._check(self._lib.dmsa_debug_pow_minus_one(self._ctx, capi.ptr(n, C.c_int32), n.shape[0], capi.ptr(out, C.c_float)), "debug_pow_minus_one")
+        return out
+
     def optimizeResident(self, settings: DmsaOptimSettings) -> capi.Report:
         """optimizeSet on the problem already resident in HBM (after upload() or a previous optimizeSet)."""
         cs = settings.to_c()
@@ -355,6 +362,22 @@ class DmsaOptimizer:
         self._check(self._lib.dmsa_sort_pairs(self._ctx, capi.ptr(k, C.c_uint32), capi.ptr(v, C.c_uint32), k.size, int(end_bit), capi.ptr(ko, C.c_uint32),
                                               capi.ptr(vo, C.c_uint32)), "dmsa_sort_pairs")
         return ko, vo
+
+    def sortPairs64(self, keys, values, end_bit: int = 64):
+        """The stable sort of (u64 key, u32 value) pairs that leaf codes wider than 32 bits go through (two 32-bit halves) -- test hook."""
+        k = np.ascontiguousarray(keys, np.uint64)
+        v = np.ascontiguousarray(values, np.uint32)
+        ko, vo = np.zeros_like(k), np.zeros_like(v)
+        self._check(self._lib.dmsa_sort_pairs64(self._ctx, capi.ptr(k, C.c_uint64), capi.ptr(v, C.c_uint32), k.size, int(end_bit), capi.ptr(ko, C.c_uint64),
+                                                capi.ptr(vo, C.c_uint32)), "dmsa_sort_pairs64")
+        return ko, vo
+
+    def scan(self, values, inclusive: bool):
+        """Prefix scan of an int32 array by the library's single-pass kernel -- test hook."""
+        x = np.ascontiguousarray(values, np.int32)
+        out = np.zeros_like(x)
+        self._check(self._lib.dmsa_scan_i32(self._ctx, capi.ptr(x, C.c_int32), x.size, 1 if inclusive else 0, capi.ptr(out, C.c_int32)), "dmsa_scan_i32")
+        return out
 
     def leafSegments(self, codes_sorted, code_bits: int):
         """Segmentation of sorted leaf codes by the single-pass kernel -- test hook.  Returns (leaf_of_pos, leaf_start[:num_leaves + 1])."""

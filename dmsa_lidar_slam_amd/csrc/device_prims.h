@@ -1,5 +1,5 @@
-// device_prims.h — thin wrappers over rocPRIM device-wide primitives (radix sort, prefix scans).
-// Kept in their own translation unit because the rocPRIM templates dominate compile time.
+// device_prims.h — the device-wide primitives of the voxelisation (radix sort of pairs, prefix scans), all hand-written: radix_sort.hip.
+// (Rounds 1-4 kept rocPRIM behind the 64-bit sort and the scans of the rows before the hot path; round 5 removed the library.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>
@@ -12,9 +12,8 @@ size_t scan_temp_bytes(size_t n);
 // stable LSD radix sort of (key u64, value u32) pairs on bits [0, end_bit)
 hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in,
                               uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream);
-// library_sort = false: the hand-written onesweep sort of radix_sort.hip; true: rocPRIM (dmsa_debug_options::library_sort)
 hipError_t sort_pairs_u32_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                              uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream, bool library_sort = false, bool header_zeroed = false);
+                              uint32_t* vals_out, size_t n, unsigned end_bit, hipStream_t stream, bool header_zeroed = false);
 // radix_sort.hip: the hand-written onesweep sort behind sort_pairs_u32_u32
 size_t sort_pairs_u32_workspace_bytes(size_t n);
 hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,

@@ -279,6 +279,22 @@ int dmsa_get_global_points(dmsa_ctx* ctx, float* xyz_out, int64_t capacity_point
     return DMSA_OK;
 }
 
+int dmsa_debug_pow_minus_one(dmsa_ctx* ctx, const int32_t* counts, int32_t count, float* out) {
+    if (!ctx || !counts || !out || count < 0) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    int32_t mx = 0;
+    for (int32_t i = 0; i < count; ++i) mx = std::max(mx, counts[i]);
+    CHK(upload_powm1_codes(ctx, (int64_t)mx + 1));
+    DevBuf d_n, d_o;
+    HIPCHK(d_n.ensure((size_t)count * 4 + 16));
+    HIPCHK(d_o.ensure((size_t)count * 4 + 16));
+    HIPCHK(hipMemcpy(d_n.p, counts, (size_t)count * 4, hipMemcpyHostToDevice));
+    launch_pow_minus_one(d_n.as<int32_t>(), count, ctx->d_pow_codes.as<uint32_t>(), (int)std::min<int64_t>(ctx->pow_n, INT32_MAX), d_o.as<float>(), ctx->stream);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out, d_o.p, (size_t)count * 4, hipMemcpyDeviceToHost));
+    d_n.release(), d_o.release();
+    return DMSA_OK;
+}
 int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out) {
     if (!ctx || !out) return DMSA_ERR_INVALID;
     CHK(set_device(ctx));
@@ -342,6 +358,45 @@ int dmsa_sort_pairs(dmsa_ctx* ctx, const uint32_t* keys, const uint32_t* values,
     HIPCHK(hipMemcpyAsync(keys_sorted, kout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(values_sorted, vout.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return DMSA_OK;
+}
+
+int dmsa_sort_pairs64(dmsa_ctx* ctx, const uint64_t* keys, const uint32_t* values, int64_t n, uint32_t end_bit, uint64_t* keys_sorted, uint32_t* values_sorted) {
+    if (!ctx || n < 0 || end_bit > 64 || (n > 0 && (!keys || !values || !keys_sorted || !values_sorted))) return DMSA_ERR_INVALID;
+    if (n == 0) return DMSA_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf kin, vin, kout, vout, tmp;
+    HIPCHK(kin.ensure((size_t)n * 8));
+    HIPCHK(kout.ensure((size_t)n * 8));
+    HIPCHK(vin.ensure((size_t)n * 4));
+    HIPCHK(vout.ensure((size_t)n * 4));
+    HIPCHK(tmp.ensure(sort_pairs_temp_bytes((size_t)n)));
+    HIPCHK(hipMemcpyAsync(kin.p, keys, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(vin.p, values, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(sort_pairs_u64_u32(tmp.p, tmp.cap, kin.as<uint64_t>(), kout.as<uint64_t>(), vin.as<uint32_t>(), vout.as<uint32_t>(), (size_t)n, end_bit, ctx->stream));
+    HIPCHK(hipMemcpyAsync(keys_sorted, kout.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(values_sorted, vout.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (DevBuf* b : {&kin, &vin, &kout, &vout, &tmp}) b->release();
+    return DMSA_OK;
+}
+
+int dmsa_scan_i32(dmsa_ctx* ctx, const int32_t* in, int64_t n, int32_t inclusive, int32_t* out) {
+    if (!ctx || n < 0 || (n > 0 && (!in || !out))) return DMSA_ERR_INVALID;
+    if (n == 0) return DMSA_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf din, dout, tmp;
+    HIPCHK(din.ensure((size_t)n * 4));
+    HIPCHK(dout.ensure((size_t)n * 4));
+    HIPCHK(tmp.ensure(scan_temp_bytes((size_t)n)));
+    HIPCHK(hipMemcpyAsync(din.p, in, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (inclusive)
+        HIPCHK(inclusive_scan_i32(tmp.p, tmp.cap, din.as<int32_t>(), dout.as<int32_t>(), (size_t)n, ctx->stream));
+    else
+        HIPCHK(exclusive_scan_i32(tmp.p, tmp.cap, din.as<int32_t>(), dout.as<int32_t>(), (size_t)n, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (DevBuf* b : {&din, &dout, &tmp}) b->release();
     return DMSA_OK;
 }
 

@@ -136,6 +136,7 @@ void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start
 void launch_gauss_fit_all(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, const int first[3],
                           const int tasks[3], float* sums, GaussCounts* counts, float* info12, bool with_weights, int id_row, int2* gauss_rows, int eigen_l1_bytes,
                           const uint32_t* pow_codes, int pow_n, float* memb_q /* [3][q_stride] scratch */, size_t q_stride, hipStream_t s);
+void launch_pow_minus_one(const int32_t* n, int count, const uint32_t* pow_codes, int pow_n, float* out, hipStream_t s);  // test hook (dmsa_debug_pow_minus_one)
 void launch_gauss_fit_finish(const int32_t* seg_off, const GaussCounts* counts, const float* sums, int max_gauss, float* info12, hipStream_t s);
 // ---- K5: normal equations + squared-error sums -------------------------------------------------------------
 // Hp = [J | e0]^T [J | e0] of size (P+1)^2, col-major, J.col(k) = inv_h * (E[k+1] - E[0]) over `rows` rows

@@ -2237,6 +2237,13 @@ __device__ __forceinline__ float pow_minus_one(int n, const uint32_t* __restrict
     }
     return w;
 }
+__global__ void k_pow_minus_one(const int32_t* __restrict__ n, int count, const uint32_t* __restrict__ pow_codes, int pow_n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = pow_minus_one(n[i], pow_codes, pow_n);
+}
+void launch_pow_minus_one(const int32_t* n, int count, const uint32_t* pow_codes, int pow_n, float* out, hipStream_t s) {
+    if (count > 0) hipLaunchKernelGGL(k_pow_minus_one, dim3((count + 255) / 256), dim3(256), 0, s, n, count, pow_codes, pow_n, out);
+}
 // default path: rebalancingWeights.head(M).mean() (Gaussians.h:176) in Eigen's own order -- the linear redux of M contiguous floats that
 // start at their aligned buffer (see fit_tree_group): the weights go through LDS 8192 at a time, eight lanes carry the chains
 __device__ void rebalancing_weights_mirror_body(const int32_t* __restrict__ seg_off, GaussCounts* __restrict__ counts, float* __restrict__ info12, float* sx /* [8192] */,

@@ -1,4 +1,5 @@
-// radix_sort.hip — hand-written stable LSD radix sort of (u32 key, u32 value) pairs for gfx950 (voxelisation stage).
+// radix_sort.hip — hand-written stable LSD radix sort of (u32 or u64 key, u32 value) pairs and the prefix scans of int32 arrays for gfx950
+// (voxelisation stage and the rows before it).  No vendor library: the path from the points to the Gaussians is this repository's code.
 //
 // The voxelisation sorts 1.5 M (leaf code, point index) pairs per resolution and iteration on 17..24 key bits.  A library sort
 // spends more dispatches on bookkeeping (memset fills of its histograms and look-back state, a separate scan) than on the three
@@ -16,6 +17,7 @@
 #include "device_prims.h"
 #include "radix_sort_dev.h"
 
+#include <algorithm>
 #include <cstdint>
 
 namespace dmsa {
@@ -289,5 +291,138 @@ hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t
     }
     return hipGetLastError();
 }
+
+// ---- 64-bit keys -----------------------------------------------------------------------------------------------------------------
+// Leaf codes wider than 32 bits (octrees deeper than ten levels with the key compression off or exhausted) are rare and not on the timed
+// path; they are sorted as two stable 32-bit sorts that carry the POSITION of a pair instead of the pair: low words first, then the high
+// words gathered in that order -- an LSD radix sort over eight digits with a gather between the halves.  keys_out / vals_out are gathered once.
+namespace {
+__global__ __launch_bounds__(256) void k_u64_low_iota(const uint64_t* __restrict__ keys, size_t n, uint32_t* __restrict__ lo, uint32_t* __restrict__ pos) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) lo[i] = (uint32_t)keys[i], pos[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void k_u64_high_gather(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, size_t n, uint32_t* __restrict__ hi) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) hi[i] = (uint32_t)(keys[pos[i]] >> 32);
+}
+__global__ __launch_bounds__(256) void k_u64_pairs_gather(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ pos, size_t n,
+                                                          uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t q = pos[i];
+        keys_out[i] = keys[q], vals_out[i] = vals[q];
+    }
+}
+unsigned blocks_for(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16); }
+}  // namespace
+
+size_t sort_pairs_temp_bytes(size_t n) { return sort_pairs_u32_workspace_bytes(n) + 4 * align_up(n * 4, 256); }
+
+hipError_t sort_pairs_u64_u32(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
+                              unsigned end_bit, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (end_bit > 64 || n >= (size_t)kValMask || temp_bytes < sort_pairs_temp_bytes(n)) return hipErrorInvalidValue;
+    const size_t ws = sort_pairs_u32_workspace_bytes(n);
+    char* w = static_cast<char*>(temp) + ws;
+    uint32_t* word = reinterpret_cast<uint32_t*>(w);
+    uint32_t* word_s = reinterpret_cast<uint32_t*>(w + align_up(n * 4, 256));
+    uint32_t* pos = reinterpret_cast<uint32_t*>(w + 2 * align_up(n * 4, 256));
+    uint32_t* pos_s = reinterpret_cast<uint32_t*>(w + 3 * align_up(n * 4, 256));
+    hipLaunchKernelGGL(k_u64_low_iota, dim3(blocks_for(n)), dim3(256), 0, stream, keys_in, n, word, pos);
+    hipError_t e = sort_pairs_u32_onesweep(temp, ws, word, word_s, pos, pos_s, n, end_bit < 32 ? end_bit : 32u, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t* order = pos_s;
+    if (end_bit > 32) {
+        hipLaunchKernelGGL(k_u64_high_gather, dim3(blocks_for(n)), dim3(256), 0, stream, keys_in, pos_s, n, word);
+        e = sort_pairs_u32_onesweep(temp, ws, word, word_s, pos_s, pos, n, end_bit - 32u, stream);
+        if (e != hipSuccess) return e;
+        order = pos;
+    }
+    hipLaunchKernelGGL(k_u64_pairs_gather, dim3(blocks_for(n)), dim3(256), 0, stream, keys_in, vals_in, order, n, keys_out, vals_out);
+    return hipGetLastError();
+}
+
+hipError_t sort_pairs_u32_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
+                              unsigned end_bit, hipStream_t stream, bool header_zeroed) {
+    return sort_pairs_u32_onesweep(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, end_bit, stream, header_zeroed ? 1 : 0);
+}
+
+// ---- prefix scans of int32 arrays: one single-pass kernel, chained through decoupled look-back ------------------------------------------
+// A tile of 4096 elements per workgroup, handed out by an atomic ticket; tile t publishes its sum (flag 1) and, once it knows what lies in
+// front of it, its inclusive prefix (flag 2); a wave follows the earlier tiles 64 at a time.  State = 1 + tiles words, zeroed per call.
+namespace {
+constexpr int kScanThreads = 256, kScanItems = 16, kScanTile = kScanThreads * kScanItems;
+__global__ __launch_bounds__(kScanThreads) void k_scan_i32(const int32_t* __restrict__ in, int32_t* __restrict__ out, size_t n, int inclusive, unsigned long long* __restrict__ state) {
+    __shared__ uint32_t s_tile;
+    __shared__ int s_wave[kScanThreads / 64];
+    __shared__ int s_excl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = (uint32_t)atomicAdd(state, 1ull);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const size_t base = (size_t)tile * kScanTile + (size_t)tid * kScanItems;
+    int v[kScanItems], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) v[k] = base + k < n ? in[base + k] : 0, sum += v[k];
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+        if (w < wave) before += s_wave[w];
+        total += s_wave[w];
+    }
+    if (wave == 0) {
+        unsigned long long* st = state + 1;
+        int excl = 0;
+        if (tile != 0) {
+            if (lane == 0) __hip_atomic_store(st + tile, (1ull << 32) | (uint32_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t t = (int64_t)tile - 1;
+            while (true) {
+                const int64_t mine = t - lane;
+                const unsigned long long w = mine >= 0 ? __hip_atomic_load(st + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 32);
+                const uint32_t flag = (uint32_t)(w >> 32);
+                const unsigned long long ready = __ballot(flag != 0u), prefix = __ballot(flag == 2u);
+                const int first_missing = ready == ~0ull ? 64 : __builtin_ctzll(~ready);
+                const int first_prefix = prefix == 0ull ? 64 : __builtin_ctzll(prefix);
+                const bool done = first_prefix < first_missing;
+                const int stop = done ? first_prefix + 1 : first_missing;
+                int part = lane < stop ? (int)(uint32_t)w : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+                excl += part;
+                if (done) break;
+                t -= stop;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(st + tile, (2ull << 32) | (uint32_t)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+        }
+    }
+    __syncthreads();
+    int run = s_excl + before + incl - sum;  // everything in front of this thread's first element
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = inclusive ? run + v[k] : run;
+        run += v[k];
+    }
+}
+hipError_t scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, int inclusive, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const size_t tiles = (n + kScanTile - 1) / kScanTile;
+    if (temp_bytes < (tiles + 1) * 8) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(temp, 0, (tiles + 1) * 8, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_scan_i32, dim3((unsigned)tiles), dim3(kScanThreads), 0, stream, in, out, n, inclusive, static_cast<unsigned long long*>(temp));
+    return hipGetLastError();
+}
+}  // namespace
+size_t scan_temp_bytes(size_t n) { return ((n + kScanTile - 1) / kScanTile + 2) * 8; }
+hipError_t inclusive_scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t stream) { return scan_i32(temp, temp_bytes, in, out, n, 1, stream); }
+hipError_t exclusive_scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t stream) { return scan_i32(temp, temp_bytes, in, out, n, 0, stream); }
 
 }  // namespace dmsa

@@ -26,8 +26,8 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     const bool speculate = allow_speculation && ctx->depth_guess[0] >= 0 && ctx->depth_guess[1] >= 0 && ctx->depth_guess[0] < 20 && ctx->depth_guess[1] < 20 &&
                            (!compress || (ctx->bits_guess[0] >= 0 && ctx->bits_guess[1] >= 0));
     // the key kernels count the digits of the sort that follows (own sort, 32-bit codes): no clearing kernel, no histogram pass
-    const bool prehist = !ctx->dbg.library_sort && ctx->prehist;
-    const bool headers_zeroed = !ctx->dbg.library_sort;
+    const bool prehist = ctx->prehist;
+    const bool headers_zeroed = true;
     {
         ScopedTimer tm(ctx, T_VOXEL);
         const int nb = (int)((n + kAabbBlock - 1) / kAabbBlock);
@@ -120,7 +120,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                                            ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream, 2));
         else if (k32)
             HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_code[0].as<uint32_t>(), ctx->d_code_s[0].as<uint32_t>(),
-                                      ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream, ctx->dbg.library_sort != 0, headers_zeroed));
+                                      ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream, headers_zeroed));
         else
             HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp[0].p, ctx->d_sort_tmp[0].cap, ctx->d_code[0].as<uint64_t>(), ctx->d_code_s[0].as<uint64_t>(),
                                       ctx->d_idx[0].as<uint32_t>(), ctx->d_idx_s[0].as<uint32_t>(), (size_t)(2 * n), end_bit, ctx->stream));
@@ -134,7 +134,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                                            ctx->idx_s_v[l], (size_t)n, eb, st[l], 2));
         else if (k32)
             HIPCHK(sort_pairs_u32_u32(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, (const uint32_t*)ctx->code_v[l], (uint32_t*)ctx->code_s_v[l], ctx->idx_v[l],
-                                      ctx->idx_s_v[l], (size_t)n, eb, st[l], ctx->dbg.library_sort != 0, headers_zeroed));
+                                      ctx->idx_s_v[l], (size_t)n, eb, st[l], headers_zeroed));
         else
             HIPCHK(sort_pairs_u64_u32(ctx->d_sort_tmp[l].p, ctx->d_sort_tmp[l].cap, (const uint64_t*)ctx->code_v[l], (uint64_t*)ctx->code_s_v[l], ctx->idx_v[l],
                                       ctx->idx_s_v[l], (size_t)n, eb, st[l]));

@@ -25,10 +25,9 @@ typedef struct dmsa_debug_options {
     int32_t serial_streams;  /* 3   streams the three tiers of the reference-order correspondence kernels run on (1, 2 or 3)              */
     int32_t merge_sort;      /* -1  both voxel levels in ONE radix sort (1), one sort per level (0), or by point count (-1: <= 2^20 merged) */
     int32_t key_compress;    /* 1   drop the key bits that are equal for all points before sorting; 0: full 3 x depth bit leaf codes
-                                     (64-bit codes and the library sort from depth 11 on -- also the fallback of a mis-predicted range)   */
-    int32_t fused_segments;  /* 1   head flags + scan + leaf starts in one single-pass kernel; 0: three kernels with a library scan      */
+                                     (64-bit codes, sorted as two 32-bit halves, from depth 11 on -- also the fallback of a mis-predicted range) */
+    int32_t fused_segments;  /* 1   head flags + scan + leaf starts in one single-pass kernel; 0: three kernels (csrc/radix_sort.hip's scan)  */
     int32_t sort_prehist;    /* 0   the key kernels count the sort digits (measured 1.5 % slower than the sort's own histogram pass)     */
-    int32_t library_sort;    /* 0   rocPRIM's radix sort instead of csrc/radix_sort.hip                                                  */
     int32_t overlap_batch;   /* 1   host-driven loop only: host math of the Jacobian batch while the GPU voxelises                        */
     int32_t serial_tree;     /* 1   double sum of the chain tiers: 1 parallel reduction when the exactness test allows it,
                                      0 always the member-order chain, 2 both and keep the chain's result (test hook)                      */
@@ -78,6 +77,13 @@ typedef struct dmsa_debug_counters {
                                      every code of that level counts as changed                                                 */
 } dmsa_debug_counters;
 int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out);
+/* Test hook: pow(-1) of `count` member counts as the Gaussian fit computes it on the device (Gaussians.h:172: libm's powf(n, -1.0f) through
+ * the difference table of the host's libm; counts[] and out[] are host arrays). */
+int dmsa_debug_pow_minus_one(dmsa_ctx* ctx, const int32_t* counts, int32_t count, float* out);
+/* Test hooks of csrc/radix_sort.hip on caller data (host arrays): the stable sort of (u64 key, u32 value) pairs on the key bits
+ * [0, end_bit) that wide leaf codes go through, and the inclusive (1) / exclusive (0) prefix scan of an int32 array. */
+int dmsa_sort_pairs64(dmsa_ctx* ctx, const uint64_t* keys, const uint32_t* values, int64_t n, uint32_t end_bit, uint64_t* keys_sorted, uint32_t* values_sorted);
+int dmsa_scan_i32(dmsa_ctx* ctx, const int32_t* in, int64_t n, int32_t inclusive, int32_t* out);
 
 void dmsa_default_debug_options(dmsa_debug_options* o);
 /* dmsa_create with explicit switches (`options` may be NULL = defaults); DMSA_DEBUG still overrides by name. */

@@ -431,4 +431,50 @@ def test_separate_level_sorts_on_an_odd_point_count(hip, orc):
     prob = synth.window_problem(seed=23, scans=3, rings=32, az_steps=256, num_static=5001)
     assert (prob.localPoints.shape[0] + prob.staticPoints.shape[0]) % 2 == 1
     _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=3), debug={"merge_sort": 0})
-    _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=2), debug={"merge_sort": 0, "library_sort": 1, "fused_segments": 0, "dual_stream": 0, "fused_leaf_scan": 0})
+    _parity_run(hip, orc, prob, DmsaOptimSettings.sliding_window(num_iter=2), debug={"merge_sort": 0, "fused_segments": 0, "dual_stream": 0, "fused_leaf_scan": 0})
+
+
+def test_pow_minus_one_of_the_counts_is_the_host_libms_powf(hip):
+    """Gaussians.h:172: Eigen evaluates pow(-1) of the member counts with libm's powf per coefficient, which is one ulp away from the
+    correctly rounded 1.0f / n for some counts (953, 2071, ... with glibc >= 2.27).  The device divides and applies the differences the
+    host's libm reports: every count up to 2^21, bit for bit."""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.powf.argtypes, libm.powf.restype = [C.c_float, C.c_float], C.c_float
+    n = np.arange(1, 1 << 21, dtype=np.int32)
+    want = np.array([libm.powf(float(v), -1.0) for v in n[:200_000]], np.float32)
+    got = hip.DmsaOptimizer().powMinusOne(n)
+    assert np.array_equal(got[:200_000].view(np.int32), want.view(np.int32))
+    div = (np.float32(1.0) / n.astype(np.float32)).astype(np.float32)
+    differing = n[got.view(np.int32) != div.view(np.int32)]
+    for v in differing[:50].tolist() + differing[-50:].tolist():  # the counts where the table matters, also beyond the first 200 000
+        assert np.float32(libm.powf(float(v), -1.0)).view(np.int32) == got[v - 1].view(np.int32), v
+    print(f"[powf] {differing.size} of {n.size} counts differ from the division on this libm, first {differing[:6].tolist()}")
+
+
+def test_fit_follows_the_l1_size_of_the_reference_machine(hip, orc):
+    """Eigen sizes the depth blocks of centered^T * centered from the L1d of the machine it runs on: with eigen_l1_bytes = 48 KB (blocks of 1016
+    members instead of 680) the device's information matrices are the oracle's for that size -- and differ from the 32 KB ones."""
+    prob = synth.rosette_window_problem(seed=2, scans=4, pts_per_scan=6000, num_static=3000)
+    s = DmsaOptimSettings.sliding_window()
+    table, _ = orc.window_pose_table(prob)
+    g = orc.transform_points(table, prob.localPoints, prob.tformIdPerPoint)
+    glob = np.concatenate([g, prob.staticPoints]).astype(np.float32)
+    ids = np.concatenate([prob.ringIds, prob.staticRingIds])
+    ref32 = orc.Gaussians(glob, ids, prob.minGridSize, s)
+    assert np.diff(ref32.seg_offset).max() > 680
+    try:
+        orc.set_eigen_l1_bytes(48 * 1024)
+        ref48 = orc.Gaussians(glob, ids, prob.minGridSize, s)
+    finally:
+        orc.set_eigen_l1_bytes(32 * 1024)
+    assert not np.array_equal(ref32.info, ref48.info)
+    for l1, ref in ((32 * 1024, ref32), (48 * 1024, ref48)):
+        opt = hip.DmsaOptimizer(debug={"eigen_l1_bytes": l1})
+        opt.upload(prob)
+        opt.poseTables(prob.getPoseParameters(), download=False)
+        opt.updateGlobalPoints(0, download=False)
+        assert opt.buildGaussians(s) == (ref.M, ref.Mm)
+        _, _, info, w = opt.gaussians()
+        assert np.array_equal(info, ref.info) and np.array_equal(w, ref.weights), l1
+        opt.close()

@@ -1,5 +1,5 @@
-"""The voxelisation's hand-written device primitives on caller data (test hooks of the C ABI): the onesweep radix sort and the
-single-pass leaf segmentation.  Bit-exact against numpy: a stable sort is unique, and so is the run-length structure of a sorted
+"""The voxelisation's hand-written device primitives on caller data (test hooks of the C ABI): the onesweep radix sort (32-bit keys, and
+64-bit keys as two halves), the prefix scans and the single-pass leaf segmentation -- no vendor library is linked.  Bit-exact against numpy: a stable sort is unique, and so is the run-length structure of a sorted
 array.  Sizes straddle the tile sizes (8192 pairs per sort tile, 8192 positions per segmentation tile)."""
 import numpy as np
 import pytest
@@ -78,4 +78,35 @@ def test_leaf_segments_match_run_lengths(hip, n):
         ref_start = np.concatenate([np.flatnonzero(head), [nv]]).astype(np.int32)
         assert np.array_equal(of_pos[:nv], ref_of_pos)
         assert np.array_equal(start, ref_start)
+    opt.close()
+
+
+@pytest.mark.parametrize("n", [1, 65, 8193, 100_003, 1_510_720])
+def test_radix_sort_of_64_bit_keys_is_the_stable_sort(hip, n):
+    """Leaf codes of trees deeper than ten levels: sorted as two stable 32-bit sorts that carry positions (csrc/radix_sort.hip)."""
+    rng = np.random.default_rng(3 * n + 5)
+    opt = hip.DmsaOptimizer()
+    for bits in (20, 32, 33, 40, 47, 63, 64):
+        hi = (1 << bits) - 1
+        keys = rng.integers(0, hi, n, dtype=np.uint64, endpoint=True)
+        if n > 100:  # long runs of equal upper words, like leaf codes
+            keys = (keys & np.uint64(0xFFFF_FFFF_FFFF_FFFF ^ 0x3FFF_FF00)) | (keys & np.uint64(0xFF))
+        keys |= rng.integers(0, 1 << (64 - bits), n, dtype=np.uint64) << np.uint64(bits) if bits < 64 else np.uint64(0)  # bits above end_bit: ignored
+        vals = rng.permutation(n).astype(np.uint32)
+        ks, vs = opt.sortPairs64(keys, vals, bits)
+        order = np.argsort(keys & np.uint64(hi), kind="stable")
+        assert np.array_equal(ks, keys[order]), (n, bits)
+        assert np.array_equal(vs, vals[order]), (n, bits)
+    opt.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 4095, 4096, 4097, 100_003, 3_021_440])
+def test_prefix_scans(hip, n):
+    rng = np.random.default_rng(n)
+    opt = hip.DmsaOptimizer()
+    for kind in ("flags", "counts"):
+        x = (rng.random(n) < 0.3).astype(np.int32) if kind == "flags" else rng.integers(0, 700, n).astype(np.int32)
+        incl = np.cumsum(x, dtype=np.int64).astype(np.int32)
+        assert np.array_equal(opt.scan(x, True), incl), (n, kind)
+        assert np.array_equal(opt.scan(x, False), incl - x), (n, kind)
     opt.close()
