@@ -322,6 +322,7 @@ int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out) {
         HIPCHK(hipMemcpy(&changed, ctx->d_coh_count.p, 8, hipMemcpyDeviceToHost));
     }
     out->voxel_codes_compared = ctx->coh_compared, out->voxel_codes_changed = (int64_t)changed, out->voxel_lattice_changes = ctx->coh_lattice_changes;
+    out->lattice_hints_held = ctx->lattice_hints_held, out->lattice_replays = ctx->lattice_replays;
     return DMSA_OK;
 }
 

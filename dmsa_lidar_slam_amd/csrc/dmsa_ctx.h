@@ -233,6 +233,8 @@ struct dmsa_ctx {
     DevBuf d_order;  // reference-order path: Gaussians by descending size class
     DevBuf d_tablesT;                                          // pose tables of the current batch, transposed ([row][evaluation][12])
     bool order_valid = false;
+    bool lattice_hint_valid = false;  // d_lattice holds the tables of an earlier voxelisation of this context (k_lattice verifies them before it replays)
+    int64_t lattice_hints_held = 0, lattice_replays = 0;
     DevBuf d_fit_sums;           // six centred product sums per Gaussian (fit kernels -> finish kernel)
     DevBuf d_memb_q;             // fit: global x | y | z of the members of Gaussians too long for the fit's LDS chunk, [3][2n + 16] floats
     DevBuf d_pow_codes;          // two bits per member count n: how libm's powf(n, -1) differs from 1.0f / n (context.cpp: upload_powm1_codes)

@@ -84,7 +84,9 @@ void launch_transform_aabb(const float4* local, const float4* nlocal, const floa
 void launch_block_aabb(const float4* global, int64_t n, float* aabb /* nb x 8 */, void* zero, size_t zero_bytes, hipStream_t s);
 // sort_header0/1 (may be null): sort headers (radix_sort_dev.h) cleared on the side, for key kernels that count the sort digits
 void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, bool compress, LatticeTable* tables /* [2] */,
-                    void* sort_header0, void* sort_header1, hipStream_t s, uint32_t* done = nullptr /* dev_sync.h counter: += 2 when both tables are written */);
+                    void* sort_header0, void* sort_header1, hipStream_t s, uint32_t* done = nullptr /* dev_sync.h counter: += 2 when both tables are written */,
+                    bool use_hint = false /* `tables` still hold the events of the previous voxelisation of (nearly) the same points: they are verified in
+                                             parallel first and the sequential replay only runs if they no longer hold; LatticeTable::pad3 = 1 says they held */);
 // leaf codes are 32-bit (key32) when 3*depth + 1 <= 32, else 64-bit; the buffers are sized for 64-bit keys either way
 // `sort` (may be null; 32-bit keys only): the plan of the sort that follows -- the kernel then clears its look-back words and adds the
 // digit histograms of the keys it writes to its (cleared) header, and the sort is started with prepared = true

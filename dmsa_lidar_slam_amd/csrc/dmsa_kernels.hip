@@ -515,8 +515,15 @@ constexpr int kLatticeThreads = 1024;            // = kAabbBlock: one point of t
 constexpr int kLatticeLdsBlocks = 2048;           // block bounds kept in LDS (48 KB); larger clouds read the rest from global memory
 __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __restrict__ global, int64_t n, const float* __restrict__ aabb, int nb, double res0,
                                                             double res1, int compress, LatticeTable* __restrict__ tables, uint32_t* __restrict__ sort_header0,
-                                                            uint32_t* __restrict__ sort_header1, uint32_t* done /* dev_sync.h: both workgroups add one */) {
+                                                            uint32_t* __restrict__ sort_header1, uint32_t* done /* dev_sync.h: both workgroups add one */,
+                                                            int use_hint /* the table still holds the previous voxelisation's events: verify them first */) {
     static_assert(kLatticeThreads == kAabbBlock, "one thread per point of a block");
+#ifdef DMSA_LATTICE_TIMING  // experiment build: phase stamps (100 MHz ticks since the kernel's start) in the unused tail of the table's mn array
+    const long long lt0 = wall_clock64();
+#define LAT_STAMP(k) if (threadIdx.x == 0) tables[blockIdx.x].mn[kMaxLatticeEvents - 8 + (k)][0] = (double)(wall_clock64() - lt0);
+#else
+#define LAT_STAMP(k)
+#endif
     {  // the key kernels that follow count the sort digits into these headers
         uint32_t* h = blockIdx.x == 0 ? sort_header0 : sort_header1;
         if (h != nullptr)
@@ -535,7 +542,25 @@ __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __res
     if (tid == 0) {
         st.defined = 0, st.depth = 0, st.nev = 0, st.status = 0;
         for (int a = 0; a < 3; ++a) st.mn[a] = 0.0, st.mx[a] = 0.0;
-        tab->first_idx = -1;
+        if (!use_hint) tab->first_idx = -1;  // (with a hint the table is read first; the replay resets it if the hint fails)
+    }
+    // the recorded table of the previous voxelisation (use_hint), staged by the last waves together with the block bounds of the others: one
+    // lane reading it entry by entry from global memory would pay a round trip each
+    __shared__ int s_ok, s_E, s_nown;
+    __shared__ long long s_ev[kMaxLatticeEvents + 1];               // [0] first finite point, [1 + e] trigger of event e
+    __shared__ long long s_own[kMaxLatticeEvents + 1];              // distinct blocks that hold the first point or a trigger
+    __shared__ float4 s_q[kMaxLatticeEvents + 1];
+    __shared__ double s_bmn[kMaxLatticeEvents + 1][3], s_bmx[kMaxLatticeEvents + 1][3];  // box of epoch e (after e events)
+    __shared__ double s_tmn[kMaxLatticeEvents + 1][3];
+    __shared__ int s_tdepth[kMaxLatticeEvents + 1], s_hdr[3];
+    __shared__ int s_e0[kMaxLatticeEvents + 2];                      // events [s_e0[k], s_e0[k + 1]) have their trigger in special block k
+    __shared__ float s_fmn[kMaxLatticeEvents + 1][3], s_fmx[kMaxLatticeEvents + 1][3];  // the boxes rounded INWARD to float (a cheap sufficient test)
+    if (use_hint && tid >= kLatticeThreads - 128 && tid - (kLatticeThreads - 128) <= kMaxLatticeEvents) {
+        const int t = tid - (kLatticeThreads - 128);
+        s_tdepth[t] = tab->depth[t];
+        for (int a = 0; a < 3; ++a) s_tmn[t][a] = tab->mn[t][a];
+        if (t < kMaxLatticeEvents) s_ev[1 + t] = tab->event_idx[t];
+        if (t == 0) s_hdr[0] = tab->num_events, s_hdr[1] = tab->status, s_hdr[2] = tab->defined, s_ev[0] = tab->first_idx;
     }
     {  // stage the block bounds; bounds of all finite points (for the key-range compression)
         float g6[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -564,7 +589,187 @@ __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __res
         red_phase ^= 1;
         return m;
     };
-    int cursor = 0;
+    // ---- fast path: are the events of the PREVIOUS voxelisation still what the replay would find? ----
+    // Between two iterations of optimizeSet the points move by millimetres: the same point defines the box, the same points push it
+    // outward.  Whether they do is checked in PARALLEL, which the replay itself cannot be: (1) one lane re-applies PCL's growth steps to the
+    // recorded trigger points (the first finite point, then event by event) and compares every box with the recorded one bit for bit;
+    // (2) every other finite point must fit the box in force when it is inserted -- whole 1024-point blocks through their bounds, the few
+    // blocks that hold a trigger point by point.  By induction over the insertion order the replay then produces exactly this table.
+    // Any mismatch (another problem, moved events, garbage in a fresh buffer) falls through to the replay below.
+    LAT_STAMP(0)
+    constexpr int kHintBlocks = 12;  // blocks checked point by point (their points are fetched while the one lane works): more -> replay
+    bool verified = false;
+    if (use_hint) {
+        if (tid == 0) {
+            const int E = s_hdr[0];
+            const long long first = s_ev[0];
+            int ok = s_hdr[1] == 0 && s_hdr[2] == 1 && E >= 0 && E <= kMaxLatticeEvents && first >= 0 && first < n && n < (1ll << 31) - kAabbBlock;
+            int nown = 0;
+            if (ok) {
+                long long prev = first;
+                s_own[nown] = first / kAabbBlock, s_e0[nown] = 0, nown += 1;
+                for (int e = 0; e < E; ++e) {
+                    const long long ie = s_ev[1 + e];
+                    ok = ok && ie > first && ie >= prev && ie < n;
+                    if (ok && ie / kAabbBlock != s_own[nown - 1]) s_own[nown] = ie / kAabbBlock, s_e0[nown] = e, nown += 1;  // (ascending: equal blocks are neighbours)
+                    prev = ie;
+                }
+                s_e0[nown] = E;
+            }
+            ok = ok && nown <= kHintBlocks;
+            s_ok = ok, s_E = ok ? E : 0, s_nown = ok ? nown : 0;
+        }
+        __syncthreads();
+        LAT_STAMP(1)
+        // everybody's loads first: the trigger points for the one lane, one point of every special block for each thread
+        if (s_ok && tid <= s_E) s_q[tid] = global[s_ev[tid]];
+        float4 own_pt[kHintBlocks];
+        const int nown = s_nown;
+#pragma unroll
+        for (int k = 0; k < kHintBlocks; ++k) {
+            const long long pi = k < nown ? s_own[k] * kAabbBlock + tid : n;
+            own_pt[k] = pi < n ? global[pi] : make_float4(NAN, NAN, NAN, 0.0f);  // (a non-finite point is skipped like in the replay)
+        }
+        __syncthreads();
+        LAT_STAMP(2)
+        if (s_ok && tid == 0) {
+            const int E = s_E;
+            const double eps = (double)FLT_EPSILON;
+            LatticeRun c;
+            c.defined = 0, c.depth = 0, c.nev = 0, c.status = 0;
+            int ok = 1;
+            {   // the first finite point defines the box (lattice_adopt's first branch, same operations)
+                const float4 q = s_q[0];
+                const float pc[3] = {q.x, q.y, q.z};
+                ok = ok && isfinite(q.x) && isfinite(q.y) && isfinite(q.z);
+                for (int a = 0; a < 3; ++a) c.mn[a] = (double)pc[a] - res / 2, c.mx[a] = (double)pc[a] + res / 2;
+                unsigned mk[3];
+                for (int a = 0; a < 3; ++a) mk[a] = (unsigned)ceil((c.mx[a] - c.mn[a] - eps) / res);
+                const unsigned mv = max(max(max(mk[0], mk[1]), mk[2]), 2u);
+                c.depth = (int)max(min(32u, (unsigned)ceil(log((double)mv) / log(2.0) - eps)), 0u);
+                const double side = (double)(1u << c.depth) * res;
+                for (int a = 0; a < 3; ++a) {
+                    const double over = (side - (c.mx[a] - c.mn[a])) / 2.0;
+                    if (over > eps) c.mn[a] -= over, c.mx[a] += over;
+                }
+                c.defined = 1;
+                for (int a = 0; a < 3; ++a) ok = ok && __double_as_longlong(c.mn[a]) == __double_as_longlong(s_tmn[0][a]);
+                ok = ok && c.depth == s_tdepth[0];
+                for (int a = 0; a < 3; ++a) s_bmn[0][a] = c.mn[a], s_bmx[0][a] = c.mx[a];
+            }
+            for (int e = 0; e < E && ok; ++e) {  // one growth step per recorded event, on its recorded trigger point
+                const float4 q = s_q[1 + e];
+                const float pc[3] = {q.x, q.y, q.z};
+                ok = ok && isfinite(q.x) && isfinite(q.y) && isfinite(q.z);
+                bool lo[3], hi[3], viol = false;
+                for (int a = 0; a < 3; ++a) lo[a] = (double)pc[a] < c.mn[a], hi[a] = (double)pc[a] >= c.mx[a], viol = viol || lo[a] || hi[a];
+                ok = ok && viol && c.depth < 21;
+                double side = (double)(1u << c.depth) * res;
+                for (int a = 0; a < 3; ++a) {
+                    uint32_t sh = 0;
+                    if (!hi[a]) c.mn[a] -= side, sh = 1u << c.depth;
+                    s_shift[e][a] = sh;
+                }
+                c.depth += 1;
+                side = (double)(1u << c.depth) * res - eps;
+                for (int a = 0; a < 3; ++a) c.mx[a] = c.mn[a] + side;
+                for (int a = 0; a < 3; ++a) ok = ok && __double_as_longlong(c.mn[a]) == __double_as_longlong(s_tmn[e + 1][a]);
+                ok = ok && c.depth == s_tdepth[e + 1];
+                for (int a = 0; a < 3; ++a) s_bmn[e + 1][a] = c.mn[a], s_bmx[e + 1][a] = c.mx[a];
+                if (e + 1 == E || s_ev[2 + e] != s_ev[1 + e]) {  // the trigger's last event: now it fits (else the replay would grow once more)
+                    for (int a = 0; a < 3; ++a) ok = ok && !((double)pc[a] < c.mn[a]) && !((double)pc[a] >= c.mx[a]);
+                }
+            }
+            s_ok = ok;
+            if (ok) {
+                st.defined = 1, st.depth = c.depth, st.nev = E, st.status = 0;
+                for (int a = 0; a < 3; ++a) st.mn[a] = c.mn[a], st.mx[a] = c.mx[a];
+            }
+        }
+        __syncthreads();
+        if (s_ok && tid < 3 * (s_E + 1)) {  // the boxes rounded inward to float, one entry per thread
+            const int e = tid / 3, a = tid - 3 * e;
+            s_fmn[e][a] = __double2float_ru(s_bmn[e][a]), s_fmx[e][a] = __double2float_rd(s_bmx[e][a]);
+        }
+        __syncthreads();
+        LAT_STAMP(3)
+        if (s_ok) {
+            const int E = s_E;
+            const long long first = s_ev[0];
+            int bad = 0;
+            // A point or a block fits box e iff lo >= mn and hi < mx in DOUBLE (the replay's comparisons).  First in float against the box
+            // rounded inward -- lo >= ru(mn) implies lo >= mn, hi < rd(mx) implies hi < mx -- and only what fails that goes through the
+            // doubles: points within a float step of a face.
+            auto fits = [&](const float lo3[3], const float hi3[3], int e) {
+                bool f = true;
+                for (int a = 0; a < 3; ++a) f = f && lo3[a] >= s_fmn[e][a] && hi3[a] < s_fmx[e][a];
+                if (f) return true;
+                f = true;
+                for (int a = 0; a < 3; ++a) f = f && !((double)lo3[a] < s_bmn[e][a]) && !((double)hi3[a] >= s_bmx[e][a]);
+                return f;
+            };
+            const int first32 = (int)first;
+            for (int blk = tid; blk < nb; blk += kLatticeThreads) {  // whole blocks through their bounds
+                float bb[6];
+                if (blk < kLatticeLdsBlocks) {
+                    for (int a = 0; a < 6; ++a) bb[a] = s_bb[blk][a];
+                } else {
+                    for (int a = 0; a < 6; ++a) bb[a] = aabb[(size_t)blk * 8 + a];
+                }
+                if (!(bb[0] <= bb[3])) continue;  // no finite point
+                // epoch of a block that holds no trigger: events triggered in earlier blocks; a block that holds one is checked point by point
+                int e = E;
+                bool special = false;
+                for (int k = nown - 1; k >= 0; --k) {
+                    const int ob = (int)s_own[k];
+                    special = special || ob == blk;
+                    if (ob > blk) e = s_e0[k];
+                }
+                if (special) continue;
+                if ((blk + 1) * kAabbBlock - 1 < first32)
+                    bad = 1;  // a finite point in front of the recorded first one
+                else if (!fits(bb, bb + 3, e))
+                    bad = 1;
+            }
+            // the blocks that hold the first point or a trigger: point by point, from registers; epoch of a point = the events before its block
+            // + the events of its block with a smaller index (usually one)
+            // (the boxes only grow: a point inside the box in force at the START of its block is inside the box of its own epoch, and that
+            // first box is the same for the whole block -- six float compares against uniform bounds settle all but the points around a trigger)
+#pragma unroll
+            for (int k = 0; k < kHintBlocks; ++k) {
+                if (k < nown) {
+                    const float4 q = own_pt[k];
+                    const int base = (int)s_own[k] * kAabbBlock, e0 = s_e0[k], e1 = s_e0[k + 1];
+                    const bool inside0 = base + tid > first32 && q.x >= s_fmn[e0][0] && q.x < s_fmx[e0][0] && q.y >= s_fmn[e0][1] && q.y < s_fmx[e0][1] && q.z >= s_fmn[e0][2] &&
+                                         q.z < s_fmx[e0][2];
+                    if (!inside0 && isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) {
+                        int ep = e0;
+                        bool trig = base + tid == first32;
+                        for (int e = e0; e < e1; ++e) {
+                            const int le = (int)s_ev[1 + e] - base;
+                            ep += le < tid ? 1 : 0, trig = trig || le == tid;
+                        }
+                        const float c3[3] = {q.x, q.y, q.z};
+                        if (base + tid < first32)
+                            bad = 1;
+                        else if (!trig && !fits(c3, c3, ep))  // (the triggers were checked by the one lane)
+                            bad = 1;
+                    }
+                }
+            }
+            verified = block_min(bad ? 0 : 1) == 1;
+        }
+        LAT_STAMP(4)
+        __syncthreads();
+        if (!verified && tid == 0) {  // the replay starts from nothing
+            st.defined = 0, st.depth = 0, st.nev = 0, st.status = 0;
+            for (int a = 0; a < 3; ++a) st.mn[a] = 0.0, st.mx[a] = 0.0;
+            tab->first_idx = -1;
+        }
+        __syncthreads();
+    }
+    LAT_STAMP(5)
+    int cursor = verified ? nb : 0;
     while (cursor < nb) {
         // first block >= cursor whose bounds do not fit the current box
         int found = INT_MAX;
@@ -621,6 +826,7 @@ __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __res
         cursor = found + 1;
     }
     __syncthreads();
+    LAT_STAMP(6)
     if (tid == 0) {
         tab->num_events = st.nev;
         tab->final_depth = st.depth;
@@ -647,6 +853,7 @@ __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __res
             total += bits;
         }
         tab->compressed = compress, tab->out_of_range = 0, tab->code_or = 0;
+        tab->pad3 = verified ? 1 : 0;  // (telemetry: the previous voxelisation's events were verified instead of replayed)
         tab->total_bits = total;
         uint32_t acc[3] = {0, 0, 0};
         for (int a = 0; a < 3; ++a) tab->suffix_shift[st.nev][a] = 0;
@@ -656,15 +863,16 @@ __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __res
                 tab->suffix_shift[e][a] = acc[a];
             }
     }
+    LAT_STAMP(7)
     if (done != nullptr) {  // the key kernels of the other level run on another stream
         __syncthreads();
         if (threadIdx.x == 0) dev_sync_signal(done);
     }
 }
 void launch_lattice(const float4* global, int64_t n, const float* aabb, int nb, double res0, double res1, bool compress, LatticeTable* tables,
-                    void* sort_header0, void* sort_header1, hipStream_t s, uint32_t* done) {
+                    void* sort_header0, void* sort_header1, hipStream_t s, uint32_t* done, bool use_hint) {
     hipLaunchKernelGGL(k_lattice, dim3(2), dim3(kLatticeThreads), 0, s, global, n, aabb, nb, res0, res1, compress ? 1 : 0, tables,
-                       static_cast<uint32_t*>(sort_header0), static_cast<uint32_t*>(sort_header1), done);
+                       static_cast<uint32_t*>(sort_header0), static_cast<uint32_t*>(sort_header1), done, use_hint ? 1 : 0);
 }
 
 // (c) genOctreeKeyforPoint with the bounding box in force when the point was inserted, plus the integer shifts of

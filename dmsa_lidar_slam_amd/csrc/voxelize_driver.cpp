@@ -40,7 +40,8 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         const bool dev_sync_lattice = ctx->dbg.device_sync != 0 && ctx->dual_stream && lvl_on[0] && lvl_on[1];
         launch_lattice(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), nb, ctx->level_res[0], ctx->level_res[1], compress,
                        ctx->d_lattice.as<LatticeTable>(), headers_zeroed ? ctx->d_sort_tmp[0].p : nullptr, headers_zeroed ? ctx->d_sort_tmp[1].p : nullptr, ctx->stream,
-                       dev_sync_lattice ? ctx->sync_counter(SYNC_LATTICE) : nullptr);
+                       dev_sync_lattice ? ctx->sync_counter(SYNC_LATTICE) : nullptr, ctx->dbg.lattice_hint != 0 && ctx->lattice_hint_valid);
+        ctx->lattice_hint_valid = true;  // (a table of another problem is harmless: it fails the verification and the replay runs)
         if (dev_sync_lattice) ctx->sync_sig[SYNC_LATTICE] += 2;  // one per resolution
         if (!speculate) {  // sync #1: tree depths select the radix-sort bit range (speculation reads them with the counts instead)
             HIPCHK(hipMemcpyAsync(ctx->h_lattice, ctx->d_lattice.p, 2 * sizeof(LatticeTable), hipMemcpyDeviceToHost, ctx->stream));
@@ -320,6 +321,14 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             ctx->speculation_retries += 1;
             return build_gaussians(ctx, s, nullptr, false, allow_compression);  // mis-speculated: redo (overlap work already ran)
         }
+        if (lvl_on[l]) (ctx->h_lattice[l].pad3 ? ctx->lattice_hints_held : ctx->lattice_replays) += 1;
+#ifdef DMSA_LATTICE_TIMING
+        if (ctx->dbg.host_timeline != 0 && lvl_on[l]) {
+            std::fprintf(stderr, "[k_lattice level %d hint %d] x10ns:", l, ctx->h_lattice[l].pad3);
+            for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %.0f", ctx->h_lattice[l].mn[kMaxLatticeEvents - 8 + k][0]);
+            std::fprintf(stderr, "\n");
+        }
+#endif
         ctx->depth_guess[l] = ctx->h_lattice[l].final_depth;
         ctx->bits_guess[l] = ctx->h_lattice[l].total_bits;
         if (ctx->dbg.voxel_coherence != 0 && lvl_on[l]) {  // a different lattice re-labels every leaf: such a voxelisation could not reuse the previous order

@@ -54,6 +54,9 @@ typedef struct dmsa_debug_options {
                                      k_loop_lm_stream); 0: column-block workgroups handing panels over (k_loop_lm_panels).  Same bits.        */
     int32_t stream_priority; /* 0   bit 0 / 1 / 2: the main / second / third stream of the context is created at the device's highest priority
                                      (which of the concurrent kernels of an iteration the wave dispatcher serves first)                      */
+    int32_t lattice_hint;    /* 1   k_lattice first checks, in parallel, whether the bounding-box growth events of the previous voxelisation of this
+                                     context still hold for the moved points (same result as the replay, proved per launch); 0: always the
+                                     sequential replay of PCL's adoptBoundingBoxToPoint                                                    */
     int32_t fit_classes;     /* 7   PROFILING ONLY (results are wrong unless 7): bit 0 / 1 / 2 = the Gaussian fit runs its long / middle / short
                                      size class -- how much of k_gauss_fit_all's time belongs to which class                              */
     int32_t eigen_l1_bytes;  /* 32768  NOT an A/B switch: the L1 data cache size of the machine the REFERENCE runs on.  Eigen sizes the depth
@@ -73,6 +76,8 @@ typedef struct dmsa_debug_counters {
     int64_t split_blocks_skipped; /* ... and skipped because their normals cannot be within 0.5 of anti-parallel       */
     int64_t voxel_codes_compared; /* voxel_coherence = 1: (point, level) pairs compared with the previous voxelisation            */
     int64_t voxel_codes_changed;  /* ... whose leaf code changed                                                               */
+    int64_t lattice_hints_held;   /* lattice_hint: (voxelisation, level) pairs whose previous growth events were verified instead of replayed ... */
+    int64_t lattice_replays;      /* ... and pairs that went through the sequential replay                                       */
     int64_t voxel_lattice_changes;/* ... voxelisations (per level) whose lattice (origin, depth, code bits) differed from the previous one's:
                                      every code of that level counts as changed                                                 */
 } dmsa_debug_counters;

@@ -281,3 +281,27 @@ def test_the_two_device_lm_solves_give_the_same_keyframe_pass(hip, orc):
     big = synth.keyframe_problem(seed=9, frames=32, rings=16, az_steps=128, arc=1.2)  # P = 186: three workgroups of A columns
     s2 = DmsaOptimSettings.keyframe_map(num_iter=3)
     _same(_run(hip, big, s2, debug={"lm_stream": 1}), _run(hip, big, s2, debug={"lm_stream": 0}))
+
+
+def test_lattice_events_of_the_previous_voxelisation_are_verified_instead_of_replayed(hip, orc):
+    """k_lattice (PCL's sequential adoptBoundingBoxToPoint) first checks IN PARALLEL whether the growth events of the previous voxelisation
+    of the context still hold for the moved points; only if not does it replay.  Same bits either way (lattice_hint = 0: always replay), the
+    counters show that the later iterations of a call take the fast path, and a context that moves on to ANOTHER problem replays."""
+    prob = synth.window_problem(seed=23, scans=3, rings=32, az_steps=256, num_static=4000)
+    other = synth.rosette_window_problem(seed=3, scans=3, pts_per_scan=5000, num_static=2000)
+    s = DmsaOptimSettings.sliding_window(num_iter=5)
+    ref, ref_other = prob.copy(), other.copy()
+    orc.optimize_window(ref, s)
+    orc.optimize_window(ref_other, s)
+    for hint in (1, 0):
+        opt = hip.DmsaOptimizer(debug={"lattice_hint": hint})
+        a, b, c = prob.copy(), other.copy(), prob.copy()
+        opt.optimizeSet(a, s), opt.optimizeSet(b, s), opt.optimizeSet(c, s)  # the same context: prob, another problem, prob again
+        assert np.array_equal(a.getPoseParameters(), ref.getPoseParameters()) and np.array_equal(c.getPoseParameters(), ref.getPoseParameters())
+        assert np.array_equal(b.getPoseParameters(), ref_other.getPoseParameters())
+        cnt = opt.debugCounters()
+        if hint:
+            assert cnt["lattice_hints_held"] >= 2 * 3 * 3 and cnt["lattice_replays"] >= 2 * 3, cnt  # the first voxelisation of another problem replays
+        else:
+            assert cnt["lattice_hints_held"] == 0 and cnt["lattice_replays"] > 0
+        opt.close()
