@@ -41,7 +41,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
-TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first
+TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first
 
 
 def spawn_ranks(n, backend, visible):

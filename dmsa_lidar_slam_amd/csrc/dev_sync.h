@@ -72,6 +72,7 @@ __device__ __forceinline__ void dev_sync_leave(const DevSync& sy) {
 
 // one-wave kernels for dependencies no existing kernel can carry (loop_kernels.hip)
 void launch_sync_signal(uint32_t* counter, hipStream_t s);
+void launch_stamp(long long* slot, hipStream_t s);  // debug switch gap_stamps: wall_clock64() of the device at this point of the stream
 void launch_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, hipStream_t s, int max_spins = 1 << 23);
 
 }  // namespace dmsa

@@ -233,6 +233,7 @@ struct dmsa_ctx {
     DevBuf d_order;  // reference-order path: Gaussians by descending size class
     DevBuf d_tablesT;                                          // pose tables of the current batch, transposed ([row][evaluation][12])
     bool order_valid = false;
+    DevBuf d_gap_stamps;         // debug switch gap_stamps: 16 wall-clock slots
     bool lattice_hint_valid = false;  // d_lattice holds the tables of an earlier voxelisation of this context (k_lattice verifies them before it replays)
     int64_t lattice_hints_held = 0, lattice_replays = 0;
     DevBuf d_fit_sums;           // six centred product sums per Gaussian (fit kernels -> finish kernel)

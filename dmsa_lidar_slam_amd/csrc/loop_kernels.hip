@@ -1424,6 +1424,11 @@ __global__ __launch_bounds__(64) void k_sync_signal(uint32_t* counter) {
 __global__ __launch_bounds__(64) void k_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, int max_spins) {
     if (threadIdx.x == 0) dev_sync_wait(counter, target, timed_out, max_spins);
 }
+// debug switch gap_stamps: the device's 100 MHz wall clock at this point of a stream (a one-thread kernel between the kernels in question)
+__global__ __launch_bounds__(64) void k_stamp(long long* slot) {
+    if (threadIdx.x == 0) *slot = wall_clock64();
+}
+void launch_stamp(long long* slot, hipStream_t s) { hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, s, slot); }
 void launch_sync_signal(uint32_t* counter, hipStream_t s) { hipLaunchKernelGGL(k_sync_signal, dim3(1), dim3(64), 0, s, counter); }
 void launch_sync_wait(const uint32_t* counter, uint32_t target, int32_t* timed_out, hipStream_t s, int max_spins) {
     hipLaunchKernelGGL(k_sync_wait, dim3(1), dim3(64), 0, s, counter, target, timed_out, max_spins);

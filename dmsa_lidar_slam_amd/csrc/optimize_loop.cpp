@@ -733,6 +733,11 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         if (skip_mode != 0) ctx->skip_pairs += (int64_t)ctx->M * P;
         CHK(run_residuals(ctx, 1 + P, nullptr, d_extra_jac, rot_same, skip_mode == 1 ? ctx->d_row_range.as<int2>() : nullptr));
         const int rowsE = ctx->M + ctx->extra_rows;
+        const bool stamps = ctx->dbg.gap_stamps != 0;
+        if (stamps) {
+            HIPCHK(ctx->d_gap_stamps.ensure(16 * 8));
+            launch_stamp(ctx->d_gap_stamps.as<long long>() + 0, ctx->stream);  // the Jacobian batch has joined
+        }
         {
             ScopedTimer tm(ctx, T_NORMAL);
             HIPCHK(ctx->d_ne_partial.ensure((size_t)normal_equations_partial_doubles(rowsE, P) * 8));
@@ -744,6 +749,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             launch_normal_equations(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, one_div_incr, ctx->d_ne_partial.as<double>(), ctx->d_Hp.as<double>(), ctx->stream,
                                     P > kLoopSolveMaxP, skip_mode != 0 ? &skip : nullptr);
         }
+        if (stamps) launch_stamp(ctx->d_gap_stamps.as<long long>() + 1, ctx->stream);  // normal equations done
         bool host_nan = false;
         double* d_error0 = ctx->d_Hp.as<double>() + (size_t)P * (P + 1) + P;  // e0^T e0, element (P, P) of Hp
         if (P <= kLoopSolveMaxP) {
@@ -780,6 +786,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             launch_loop_step_finish(P, s.max_step, d_step, d_flags, ctx->stream);  // NaN test, clamp
             g_tl.mark("solve");
         }
+        if (stamps) launch_stamp(ctx->d_gap_stamps.as<long long>() + 2, ctx->stream);  // LM step done
         // :152-182 nine trials, :130-143 decision
         launch_loop_chain(m, 1, S1, S2, d_param, d_step, increment, ctx->d_ctrl.as<double>(), d_extra_trial, d_flags, ctx->stream);
         {
@@ -787,6 +794,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             CHK(device_tables(ctx, 9, ctx->d_ctrl.as<double>(), ctx->d_tables.as<float>(), ctx->d_tablesT.as<float>(), ctx->stream));
             ctx->batch = 9, ctx->tablesT_batch = 9;
         }
+        if (stamps) launch_stamp(ctx->d_gap_stamps.as<long long>() + 3, ctx->stream);  // trial chains and pose tables done
         if (!host_nan) ctx->evaluations += 9;
         nan_evals = host_nan ? 0 : 9;
         CHK(run_residuals(ctx, 9, nullptr, d_extra_trial));
@@ -818,6 +826,12 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         std::copy(pin, pin + st, fin.begin());
     }
     drain_timers(ctx);
+    if (ctx->dbg.gap_stamps != 0 && ctx->d_gap_stamps.p && iters > 0) {
+        long long t[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpy(t, ctx->d_gap_stamps.p, sizeof(t), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[gap_stamps] last iteration, P = %d, %d rows: Jacobian batch joined -> normal equations done %.1f us -> LM step done %.1f us -> trial chains + tables done %.1f us "
+                             "(device wall clock, unprofiled; each stamp kernel adds its own ~3 us)\n", P, ctx->M + ctx->extra_rows, (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01);
+    }
     {
         PoseChain& c = chain(ctx);
         std::copy(fin.begin(), fin.begin() + 3 * n, c.rel_o.begin());

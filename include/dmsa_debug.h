@@ -23,7 +23,9 @@ typedef struct dmsa_debug_options {
                                      (three waits per iteration, as in rounds 1-2)                                                        */
     int32_t dual_stream;     /* 1   the two voxel resolutions and the count read-back on their own streams; 0: everything on one stream   */
     int32_t serial_streams;  /* 3   streams the three tiers of the reference-order correspondence kernels run on (1, 2 or 3)              */
-    int32_t merge_sort;      /* -1  both voxel levels in ONE radix sort (1), one sort per level (0), or by point count (-1: <= 2^20 merged) */
+    int32_t merge_sort;      /* 0   one radix sort per voxel level, on two streams; 1: both levels in ONE sort of 2 n pairs (level 1 tagged above the
+                                     widest code); -1: merged up to 2^20 points (the rule of rounds 2-4, from before the stream dependencies moved
+                                     to device counters: round 5 measured separate sorts 1-2.5 % faster at every size, profiles/r05_ab_merge_sort.txt) */
     int32_t key_compress;    /* 1   drop the key bits that are equal for all points before sorting; 0: full 3 x depth bit leaf codes
                                      (64-bit codes, sorted as two 32-bit halves, from depth 11 on -- also the fallback of a mis-predicted range) */
     int32_t fused_segments;  /* 1   head flags + scan + leaf starts in one single-pass kernel; 0: three kernels (csrc/radix_sort.hip's scan)  */
@@ -54,6 +56,10 @@ typedef struct dmsa_debug_options {
                                      k_loop_lm_stream); 0: column-block workgroups handing panels over (k_loop_lm_panels).  Same bits.        */
     int32_t stream_priority; /* 0   bit 0 / 1 / 2: the main / second / third stream of the context is created at the device's highest priority
                                      (which of the concurrent kernels of an iteration the wave dispatcher serves first)                      */
+    int32_t gap_stamps;      /* 0   1: one-thread kernels write the device's wall clock in front of, between and behind the kernels of the normal
+                                     equations and the LM solve of every iteration; the gaps of the LAST iteration of a call are printed to stderr
+                                     -- what the kernel trace of a profiler cannot tell: whether the holes it shows between those kernels
+                                     exist when no profiler slows the host's launches                                                      */
     int32_t lattice_hint;    /* 1   k_lattice first checks, in parallel, whether the bounding-box growth events of the previous voxelisation of this
                                      context still hold for the moved points (same result as the replay, proved per launch); 0: always the
                                      sequential replay of PCL's adoptBoundingBoxToPoint                                                    */
