@@ -45,7 +45,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(capi.TrajState) == 120  # dmsa_window_setup.h
     assert C.sizeof(capi.PointCloud2) == 56  # dmsa_wire_formats.h
     assert C.sizeof(capi.AosView) == 40  # dmsa_aos.h
-    assert C.sizeof(capi.DebugCounters) == 80  # dmsa_debug.h
+    assert C.sizeof(capi.DebugCounters) == 96  # dmsa_debug.h: twelve int64 counters
 
 
 def test_default_settings_match_reference_defaults(lib):
