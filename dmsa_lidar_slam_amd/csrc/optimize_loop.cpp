@@ -589,6 +589,15 @@ int device_lm_step(dmsa_ctx* ctx, const double* d_Hp, int P, double lambda, doub
 
 static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep) {
     ScopedTimer total(ctx, T_TOTAL);
+    // debug switch trace_time: where a call's time outside its iterations goes (host clock, microseconds since the call began)
+    const auto call_t0 = std::chrono::steady_clock::now();
+    std::string call_trace;
+    auto mark = [&](const char* what) {
+        if (ctx->dbg.trace_time == 0) return;
+        char buf[96];
+        std::snprintf(buf, sizeof(buf), " %s %.0f", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - call_t0).count());
+        call_trace += buf;
+    };
     const bool fixed = (ctx->flags & DMSA_FLAG_FIXED_ITERS) != 0;
     const LoopModel& m = ctx->loop_model;
     const int P = m.P, n = m.n, a = m.extra > 0 ? m.extra : 0;
@@ -658,6 +667,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         HIPCHK(hipMemcpyAsync(S0, pin, st * 8, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->d_loop_iter.p, 0, sizeof(LoopFlags) + (size_t)(num_iter + 1) * sizeof(IterResult), ctx->stream));
     }
+    mark("seeded");
     std::vector<double> Hp, H, g, step;
     if (P > kLoopPanelMaxP) Hp.resize((size_t)(P + 1) * (P + 1)), H.resize((size_t)P * P), g.resize((size_t)P), step.resize((size_t)P);
     // what the report says about the Gaussians belongs to the last iteration that really ran
@@ -721,6 +731,8 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         CHK(rc);
         drain_timers(ctx);  // everything the previous iteration timed has completed
         g_tl.mark("build_gaussians (incl. sync A)");
+        if (iter == 0) mark("first-counts");
+        if (iter == 1) mark("second-counts");
         if (iter > 0 && ctx->h_results[iter - 1].stop != 0) break;  // the loop ended in the previous iteration: this one never started
         ++iters;
         last_M = ctx->M, last_M1 = ctx->M1, last_Mm = ctx->Mm;
@@ -815,6 +827,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         if (host_nan) break;  // the device takes the same decision; nothing more to enqueue
     }
     g_tl.print();
+    mark("all-enqueued");
     // final state and the results not yet seen
     std::vector<double> fin(st);
     {
@@ -825,6 +838,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         HIPCHK(hipStreamSynchronize(ctx->stream));
         std::copy(pin, pin + st, fin.begin());
     }
+    mark("state-back");
     drain_timers(ctx);
     if (ctx->dbg.gap_stamps != 0 && ctx->d_gap_stamps.p && iters > 0) {
         long long t[4] = {0, 0, 0, 0};
@@ -862,6 +876,8 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
     CHK(build_tables(ctx, 1, globs));
     CHK(transform_points(ctx, 0));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    mark("final-points");
+    if (ctx->dbg.trace_time != 0) std::fprintf(stderr, "[call] %d iterations, us since the call began:%s\n", iters, call_trace.c_str());
     if (rep) {
         rep->iterations = iters, rep->stop_reason = stop;
         rep->num_gaussians = ctx->M, rep->num_gaussians_l1 = ctx->M1, rep->num_memberships = ctx->Mm;
