@@ -733,6 +733,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         g_tl.mark("build_gaussians (incl. sync A)");
         if (iter == 0) mark("first-counts");
         if (iter == 1) mark("second-counts");
+        if (iter > 1 && ctx->dbg.trace_time >= 2) mark("counts");  // every iteration's: the host's iteration period is the device's
         if (iter > 0 && ctx->h_results[iter - 1].stop != 0) break;  // the loop ended in the previous iteration: this one never started
         ++iters;
         last_M = ctx->M, last_M1 = ctx->M1, last_Mm = ctx->Mm;
