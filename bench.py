@@ -467,6 +467,8 @@ def sharded_keyframe_pass(args, rank, local_rank, world, dist, coll_dev, sync_al
         opts[nb].upload(subs[nb])
         opts[nb].optimizeResident(s)
     s.num_iter = args.keyframe_steps
+    for o in opts.values():
+        o.timing(reset=True)
     sync_all()
     t0 = time.perf_counter()
     reps = {}
@@ -477,6 +479,31 @@ def sharded_keyframe_pass(args, rank, local_rank, world, dist, coll_dev, sync_al
     gather_owned_neighbourhood_poses(full_map, subs, ranges, rank, world, dist, coll_dev)
     sync_all()
     elapsed = time.perf_counter() - t0
+    # roofline of the pass's dominant kernels (the correspondence batches of this rank's neighbourhoods), HIP events on their streams
+    acc = {k: 0.0 for k in ("residual_kernel_ms", "residual_launches", "residual_evaluations", "residual_algorithmic_bytes", "residual_unit_bytes")}
+    for o in opts.values():
+        t_nb = o.timing()
+        for k in acc:
+            acc[k] += getattr(t_nb, k)
+    launches, evals = max(1.0, acc["residual_launches"]), max(1.0, acc["residual_evaluations"])
+    avg_ms = acc["residual_kernel_ms"] / launches
+    eff = acc["residual_unit_bytes"] / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    comp = acc["residual_algorithmic_bytes"] / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    memb = sum(int(r.num_memberships) for r in reps.values())
+    flops = 48.0 * memb / max(1, len(reps)) * evals  # 48 flop per member and evaluation (mean memberships of this rank's neighbourhoods)
+    valu = flops / (acc["residual_kernel_ms"] * 1e-3) / 1e12 if acc["residual_kernel_ms"] > 0 else 0.0
+    roofline = {"kernel": "reference-order correspondence kernels of the neighbourhoods of rank 0 (B = P + 1 = 187 and B = 9 evaluations per launch)",
+                "bound": "hbm", "achieved": round(eff, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(eff / HBM_PEAK_GBS, 4),
+                "frac_compulsory": round(comp / HBM_PEAK_GBS, 4), "traffic": None,
+                "traffic_source": "no PMC pass for this workload (profiles/r05_traffic.json covers the window)",
+                "avg_launch_ms": round(avg_ms, 5), "launches": int(launches), "evaluations": int(evals),
+                "algorithmic_bytes_per_launch": round(acc["residual_unit_bytes"] / launches, 1),
+                "compulsory_bytes_per_launch": round(acc["residual_algorithmic_bytes"] / launches, 1),
+                "share_of_pass": round(acc["residual_kernel_ms"] * 1e-3 / max(t_own, 1e-9), 4),
+                "valu": {"achieved_tflops": round(valu, 2), "peak_tflops_scalar_no_fma": 39.3, "frac": round(valu / 39.3, 4)},
+                "bound_stated": "an effective rate (a launch evaluates B pose tables on members it reads once per pass); the kernels are bound by "
+                                "vector issue, and the pass as a whole by its dependent single-workgroup kernels: LM solve 223 us of 1.1 ms per "
+                                "neighbourhood iteration (DESIGN.md, where the time is)"}
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -489,7 +516,7 @@ def sharded_keyframe_pass(args, rank, local_rank, world, dist, coll_dev, sync_al
             "unit": "iterations/s", "n_gpus": world, "steps": int(rep.iterations), "ms_per_step": round(1e3 * elapsed / max(1, rep.iterations), 4),
             "ms_per_neighbourhood_iteration": round(1e3 * elapsed / max(1, rep.iterations) / max(1, len(owned)), 4),
             "scaling": "strong" if strong else "weak", "frames_total": int(total_frames), "neighbourhoods": len(ranges),
-            "neighbourhoods_per_rank": len(owned), "params_per_neighbourhood": int(subs[owned[0]].numParams), "per_rank": per_rank,
+            "neighbourhoods_per_rank": len(owned), "params_per_neighbourhood": int(subs[owned[0]].numParams), "roofline": roofline, "per_rank": per_rank,
             "exchange": "one all-gather of ceil(neighbourhoods / ranks) x 32 x 6 doubles per rank" if world > 1 else "none (single GPU)"}
 
 

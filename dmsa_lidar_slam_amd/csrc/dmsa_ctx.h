@@ -51,6 +51,7 @@ struct DevBuf {
     ~DevBuf() { release(); }  // every buffer of a context is released with it, whether or not dmsa_destroy lists it
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
+        ++reallocations();  // (hipFree waits for the device: a buffer that grows inside the loop costs an iteration its overlap)
         if (p) (void)hipFree(p);
         p = nullptr, cap = 0;
         const size_t want = bytes + bytes / 8 + 256;
@@ -61,6 +62,10 @@ struct DevBuf {
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr, cap = 0;
+    }
+    static long long& reallocations() {  // process-wide count of growing ensure() calls (debug switch trace_time prints it per iteration)
+        static long long n = 0;
+        return n;
     }
     template <class T>
     T* as() const { return reinterpret_cast<T*>(p); }
@@ -274,6 +279,8 @@ struct dmsa_ctx {
     uint32_t sync_sig[SYNC_SLOTS] = {};  // signals enqueued so far per slot = the value a wait enqueued now has to see
     bool tables_dev_sync = false;        // tables_pending is to be resolved through SYNC_TABLES, not ev_tables
     int wait_seq = 0;                    // waits enqueued by the current whole call (debug switch sync_fault withholds the signal of one of them)
+    long long* stamp_voxel = nullptr;    // debug switch gap_stamps = 2: where build_gaussians stamps "voxelisation done" / "fit done"
+    long long* stamp_fit = nullptr;
     int voxel_calls = 0;                 // voxelisations of the current whole call (debug switch speculation_fault plants a wrong guess in one of them)
     int sync_retries = 0, speculation_retries = 0;  // since the context was created: calls re-run with events after a wait timed out; voxelisations re-run after a wrong guess
     DevBuf d_aos_raw, d_aos_idx;         // include/dmsa_aos.h: the caller's strided clouds as they lie in memory, and their per-point indices

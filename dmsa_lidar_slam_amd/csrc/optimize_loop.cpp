@@ -594,7 +594,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
     std::string call_trace;
     auto mark = [&](const char* what) {
         if (ctx->dbg.trace_time == 0) return;
-        char buf[96];
+        char buf[160];
         std::snprintf(buf, sizeof(buf), " %s %.0f", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - call_t0).count());
         call_trace += buf;
     };
@@ -668,6 +668,15 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         HIPCHK(hipMemsetAsync(ctx->d_loop_iter.p, 0, sizeof(LoopFlags) + (size_t)(num_iter + 1) * sizeof(IterResult), ctx->stream));
     }
     mark("seeded");
+    // debug switch gap_stamps: one-thread kernels write the device's wall clock; 2 = eight stamps per iteration, printed as a table
+    long long* iter_stamps = nullptr;
+    if (ctx->dbg.gap_stamps != 0) {
+        HIPCHK(ctx->d_gap_stamps.ensure((size_t)(16 + 8 * (ctx->dbg.gap_stamps >= 2 ? num_iter : 0)) * 8));
+        if (ctx->dbg.gap_stamps >= 2) {
+            iter_stamps = ctx->d_gap_stamps.as<long long>() + 16;
+            HIPCHK(hipMemsetAsync(iter_stamps, 0, (size_t)8 * num_iter * 8, ctx->stream));
+        }
+    }
     std::vector<double> Hp, H, g, step;
     if (P > kLoopPanelMaxP) Hp.resize((size_t)(P + 1) * (P + 1)), H.resize((size_t)P * P), g.resize((size_t)P), step.resize((size_t)P);
     // what the report says about the Gaussians belongs to the last iteration that really ran
@@ -681,6 +690,10 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         // the Jacobian chains on the side stream start when the state of the iteration start is in place: signalled by k_loop_begin /
         // the previous k_loop_finish themselves (dev_sync.h) -- no event on the main stream
         const bool dev_sync = ctx->dbg.device_sync != 0 && side != ctx->stream;
+        if (iter_stamps) {
+            launch_stamp(iter_stamps + 8 * iter + 0, ctx->stream);  // the iteration begins
+            ctx->stamp_voxel = iter_stamps + 8 * iter + 1, ctx->stamp_fit = iter_stamps + 8 * iter + 2;
+        }
         if (iter == 0) {  // later iterations: done by loop_finish
             launch_loop_begin(m, S0, d_param, ctx->d_ctrl0.as<double>(), d_flags, ctx->stream, dev_sync ? ctx->sync_counter(SYNC_LOOP_STATE) : nullptr);
             if (dev_sync) ctx->sync_sig[SYNC_LOOP_STATE] += 1;
@@ -733,7 +746,11 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         g_tl.mark("build_gaussians (incl. sync A)");
         if (iter == 0) mark("first-counts");
         if (iter == 1) mark("second-counts");
-        if (iter > 1 && ctx->dbg.trace_time >= 2) mark("counts");  // every iteration's: the host's iteration period is the device's
+        if (iter > 1 && ctx->dbg.trace_time >= 2) {  // every iteration's: the host's iteration period is the device's
+            char what[96];
+            std::snprintf(what, sizeof(what), "[M %d Mm %lld grown %lld] counts", ctx->M, (long long)ctx->Mm, DevBuf::reallocations());
+            mark(what);
+        }
         if (iter > 0 && ctx->h_results[iter - 1].stop != 0) break;  // the loop ended in the previous iteration: this one never started
         ++iters;
         last_M = ctx->M, last_M1 = ctx->M1, last_Mm = ctx->Mm;
@@ -748,8 +765,8 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         const int rowsE = ctx->M + ctx->extra_rows;
         const bool stamps = ctx->dbg.gap_stamps != 0;
         if (stamps) {
-            HIPCHK(ctx->d_gap_stamps.ensure(16 * 8));
             launch_stamp(ctx->d_gap_stamps.as<long long>() + 0, ctx->stream);  // the Jacobian batch has joined
+            if (iter_stamps) launch_stamp(iter_stamps + 8 * iter + 3, ctx->stream);
         }
         {
             ScopedTimer tm(ctx, T_NORMAL);
@@ -763,6 +780,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
                                     P > kLoopSolveMaxP, skip_mode != 0 ? &skip : nullptr);
         }
         if (stamps) launch_stamp(ctx->d_gap_stamps.as<long long>() + 1, ctx->stream);  // normal equations done
+        if (iter_stamps) launch_stamp(iter_stamps + 8 * iter + 4, ctx->stream);
         bool host_nan = false;
         double* d_error0 = ctx->d_Hp.as<double>() + (size_t)P * (P + 1) + P;  // e0^T e0, element (P, P) of Hp
         if (P <= kLoopSolveMaxP) {
@@ -800,6 +818,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             g_tl.mark("solve");
         }
         if (stamps) launch_stamp(ctx->d_gap_stamps.as<long long>() + 2, ctx->stream);  // LM step done
+        if (iter_stamps) launch_stamp(iter_stamps + 8 * iter + 5, ctx->stream);
         // :152-182 nine trials, :130-143 decision
         launch_loop_chain(m, 1, S1, S2, d_param, d_step, increment, ctx->d_ctrl.as<double>(), d_extra_trial, d_flags, ctx->stream);
         {
@@ -808,6 +827,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             ctx->batch = 9, ctx->tablesT_batch = 9;
         }
         if (stamps) launch_stamp(ctx->d_gap_stamps.as<long long>() + 3, ctx->stream);  // trial chains and pose tables done
+        if (iter_stamps) launch_stamp(iter_stamps + 8 * iter + 6, ctx->stream);
         if (!host_nan) ctx->evaluations += 9;
         nan_evals = host_nan ? 0 : 9;
         CHK(run_residuals(ctx, 9, nullptr, d_extra_trial));
@@ -823,6 +843,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
                                sig ? ctx->sync_counter(SYNC_LOOP_STATE) : nullptr);
             if (sig) ctx->sync_sig[SYNC_LOOP_STATE] += 1;
         }
+        if (iter_stamps) launch_stamp(iter_stamps + 8 * iter + 7, ctx->stream);  // the iteration's last kernel (k_loop_finish) is done
         HIPCHK(hipGetLastError());
         g_tl.mark("iteration enq");
         if (host_nan) break;  // the device takes the same decision; nothing more to enqueue
@@ -841,6 +862,19 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
     }
     mark("state-back");
     drain_timers(ctx);
+    ctx->stamp_voxel = ctx->stamp_fit = nullptr;
+    if (iter_stamps && iters > 0) {
+        std::vector<long long> t((size_t)8 * iters);
+        HIPCHK(hipMemcpy(t.data(), iter_stamps, t.size() * 8, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[gap_stamps] per iteration, us on the device's wall clock (each stamp kernel adds ~3 us): voxelisation | fit | Jacobian batch | normal equations | LM step | "
+                             "trial chains + tables | trial batch + decision | whole iteration\n");
+        for (int i = 0; i < iters; ++i) {
+            const long long* r = t.data() + 8 * i;
+            std::fprintf(stderr, "[gap_stamps] %3d:", i);
+            for (int k = 1; k < 8; ++k) std::fprintf(stderr, " %6.1f", (r[k] - r[k - 1]) * 0.01);
+            std::fprintf(stderr, " | %6.1f\n", i + 1 < iters ? (t[(size_t)8 * (i + 1)] - r[0]) * 0.01 : (r[7] - r[0]) * 0.01);
+        }
+    }
     if (ctx->dbg.gap_stamps != 0 && ctx->d_gap_stamps.p && iters > 0) {
         long long t[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpy(t, ctx->d_gap_stamps.p, sizeof(t), hipMemcpyDeviceToHost));

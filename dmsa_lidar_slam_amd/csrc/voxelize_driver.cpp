@@ -261,6 +261,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         launch_size_classes(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_order.as<uint32_t>(),
                             reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts)), ctx->stream, sy);
     }
+    if (ctx->stamp_voxel) launch_stamp(ctx->stamp_voxel, ctx->stream);
     if (rb_released) {
         enqueue_wait(ctx, SYNC_CLASSES, rb);
     } else if (rb != ctx->stream) {
@@ -298,6 +299,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         fit_launched[0] = grow(pg.n_long), fit_launched[1] = grow(pg.n_chain - pg.n_long), fit_launched[2] = grow(pg.n_small);
         finish_launched = grow(pg.n_chain + pg.n_small);
         CHK(launch_fit(first, fit_launched, finish_launched));
+        if (ctx->stamp_fit) launch_stamp(ctx->stamp_fit, ctx->stream);
     }
     g_tl.mark("voxel enq");
     if (overlap) CHK(overlap());

@@ -59,7 +59,8 @@ typedef struct dmsa_debug_options {
     int32_t gap_stamps;      /* 0   1: one-thread kernels write the device's wall clock in front of, between and behind the kernels of the normal
                                      equations and the LM solve of every iteration; the gaps of the LAST iteration of a call are printed to stderr
                                      -- what the kernel trace of a profiler cannot tell: whether the holes it shows between those kernels
-                                     exist when no profiler slows the host's launches                                                      */
+                                     exist when no profiler slows the host's launches.  2: also eight stamps per iteration (begin, voxelisation,
+                                     fit, Jacobian batch, normal equations, LM step, trial chains + tables, end), printed as a table             */
     int32_t lattice_hint;    /* 1   k_lattice first checks, in parallel, whether the bounding-box growth events of the previous voxelisation of this
                                      context still hold for the moved points (same result as the replay, proved per launch); 0: always the
                                      sequential replay of PCL's adoptBoundingBoxToPoint                                                    */
