@@ -1451,10 +1451,14 @@ __device__ __forceinline__ void leaf_split_groups(int group, int ngroups, int ti
     __shared__ int s_c1[kWaves], s_c2[kWaves], s_mn[kWaves], s_mx[kWaves];   // (only the workgroup-wide groups, kWaves > 1, touch these)
     const int nl = counts->num_leaves;
     const int lane = tid & 63, wave = tid >> 6;
-    for (int l = group; l < nl; l += ngroups) {
-        if (!slot_acc[2 * l]) continue;  // group-uniform
-        const int b = leaf_start[l], e = leaf_start[l + 1], cnt = e - b;
-        if ((cnt > kSplitBigLeaf) != (kWaves > 1)) continue;  // the other launch owns this leaf
+    // Which leaves are this group's?  Accepted ones of its size class -- a small minority of the fine level's ~10^5 leaves.  Asking leaf by
+    // leaf (`if (!slot_acc[2 * l]) continue;`) is one dependent memory round trip per leaf and group: the 256 workgroup-wide groups each
+    // walked nl / 256 leaves to find no big leaf at all, 100 us at the fine level while their 8192 waves held every wave slot of the chip
+    // against the coarse level's pair search on the other stream.  Now a group looks at kThreads of its leaves per round trip -- one leaf per
+    // thread, (accepted, begin, end) loaded together -- and only walks the ones that qualify.
+    __shared__ unsigned long long s_mask[kWaves];
+    auto process = [&](const int l, const int b, const int e) {
+        const int cnt = e - b;
         // most anti-parallel normal pair: min over ordered pairs (a outer, c inner, a != c) of |n_a + n_c|, first minimum wins.
         // k_split_pairs already found, for every member a, its first best partner c; reduce over a (ties -> smallest a).
         float best = FLT_MAX;
@@ -1485,7 +1489,7 @@ __device__ __forceinline__ void leaf_split_groups(int group, int ngroups, int ti
         }
         if (!(best <= 0.5f)) {  // `minDiffFromZero > 0.5f` -> no split (also when there was no pair at all)
             for (int j = b + tid; j < e; j += kThreads) pos_slot_rank[j] = j - b;
-            continue;  // slot 2l stays as accepted by k_leaf_accept
+            return;  // slot 2l stays as accepted by k_leaf_accept
         }
         const int ia = (int)(best_pair / cnt), ic = (int)(best_pair % cnt);
         const float4 r1 = nsorted[b + ia], r2 = nsorted[b + ic];
@@ -1597,6 +1601,40 @@ __device__ __forceinline__ void leaf_split_groups(int group, int ngroups, int ti
             const int a2 = (rank_base2 > min_pts && div1) ? 1 : 0;
             slot_acc[2 * l] = a1, slot_cnt[2 * l] = a1 ? rank_base1 : 0;
             slot_acc[2 * l + 1] = a2, slot_cnt[2 * l + 1] = a2 ? rank_base2 : 0;
+        }
+    };
+    // leaf l belongs to group l % ngroups (neighbouring leaves are alike: consecutive leaves for one group would hand all leaves of a wall to the
+    // same group); thread t of the group looks at the group's t-th leaf of the round
+    for (int r0 = 0; group + (int64_t)ngroups * r0 < nl; r0 += kThreads) {
+        const int64_t l64 = group + (int64_t)ngroups * (r0 + tid);
+        const int l = l64 < nl ? (int)l64 : nl;
+        int b = 0, e = 0;
+        bool mine = false;
+        if (l < nl) {
+            const int acc = slot_acc[2 * l];
+            b = leaf_start[l], e = leaf_start[l + 1];
+            mine = acc != 0 && ((e - b > kSplitBigLeaf) == (kWaves > 1));  // the other kind of group owns the rest
+        }
+        unsigned long long m = __ballot(mine);
+        if (kWaves == 1) {
+            while (m != 0ull) {
+                const int k = __builtin_ctzll(m);
+                m &= m - 1ull;
+                process(group + ngroups * (r0 + k), __builtin_amdgcn_readlane(b, k), __builtin_amdgcn_readlane(e, k));
+            }
+        } else {
+            __syncthreads();  // the previous round's readers of s_mask are done
+            if (lane == 0) s_mask[wave] = m;
+            __syncthreads();
+            for (int w = 0; w < kWaves; ++w) {
+                unsigned long long mw = s_mask[w];
+                while (mw != 0ull) {  // (workgroup-uniform: process() meets at barriers)
+                    const int k = __builtin_ctzll(mw);
+                    mw &= mw - 1ull;
+                    const int lk = group + ngroups * (r0 + 64 * w + k);
+                    process(lk, leaf_start[lk], leaf_start[lk + 1]);
+                }
+            }
         }
     }
 }
