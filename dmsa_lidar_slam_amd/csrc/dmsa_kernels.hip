@@ -1223,6 +1223,10 @@ __global__ __launch_bounds__(1024) void k_split_tasks(const int32_t* __restrict_
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) lo = min(lo, __shfl_xor(lo, m)), hi = max(hi, __shfl_xor(hi, m));
     if (hi > lo) lo &= ~63;  // partner blocks are the 64-aligned blocks of the sorted array (k_split_cones bounds them); positions in front of the leaf are masked
+    // Only partners BEHIND a position are searched (k_split_pairs): |n_a + n_c| has the same bits as |n_c + n_a|, so the leaf's first minimal
+    // pair in the reference's (a outer, c inner) order has a < c -- a minimal pair with c < a would make (c, a) an earlier one.  The partner
+    // range of a wave block therefore starts at the block itself: half the pairs.
+    lo = max(lo, (int)((i >> 6) << 6));
     const int len = max(0, hi - lo);
     int chunk = max(kSplitChunk, (len + kSplitMaxChunks - 1) / kSplitMaxChunks);
     chunk = (chunk + 63) & ~63;
@@ -1292,6 +1296,7 @@ __global__ __launch_bounds__(256) void k_split_prepare(const uint32_t* __restric
     }
 }
 
+// (Partners c <= a are never looked at: see k_split_tasks.  pair_best[a] is the first best partner BEHIND a.)
 // A task's 64 positions meet its partners 64 at a time: one coalesced vector load puts partner c0 + lane into every lane
 // (the next 64 are prefetched meanwhile), then the partners are broadcast lane by lane with v_readlane.  No LDS and no scalar
 // cache in the loop (an LDS-staged loop was bound by LDS read bandwidth, a scalar-load loop by scalar-cache misses).  The
@@ -1337,7 +1342,8 @@ __global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__
         // reference's own norm.  (A bound that follows the smallest norm found in the leaf so far -- one word per leaf, atomicMin -- was
         // measured as well: 3.8 ms per voxelisation with one atomic per lane, 0.51 ms with one per wave, against 0.43 ms with this constant.)
         const float bound = 0.2501f;
-        const bool uniform = __ballot(active && b <= c0 && e >= c1) == ~0ull;  // every position may pair with the whole chunk
+        // every position may pair with the whole chunk: the chunk lies inside the position's leaf and BEHIND the position (see k_split_tasks)
+        const bool uniform = __ballot(active && b <= c0 && e >= c1 && i < c0) == ~0ull;
         const float4 na = active ? nsorted[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         // The reference compares norms (sqrt) with a strict '<'.  sqrt is monotone, so a candidate whose SQUARED norm is not
         // below the best squared norm can never win; the (correctly rounded, expensive) sqrt is only taken for the rest.
@@ -1403,7 +1409,7 @@ __global__ __launch_bounds__(256) void k_split_pairs(const int32_t* __restrict__
                     constexpr int u = decltype(uc)::value;
                     const float sx = na.x + dpp_row_bcast<k + u>(pm.x), sy = na.y + dpp_row_bcast<k + u>(pm.y), sz = na.z + dpp_row_bcast<k + u>(pm.z);
                     q[u] = sum3f(sx * sx, sy * sy, sz * sz);
-                    if (!uniform) q[u] = (j + 16 * m + k + u >= b && j + 16 * m + k + u < e) ? q[u] : INFINITY;  // partner of another leaf
+                    if (!uniform) q[u] = (j + 16 * m + k + u > max(b - 1, self) && j + 16 * m + k + u < e) ? q[u] : INFINITY;  // partner of another leaf, or not behind a
                 };
                 one(std::integral_constant<int, 0>{}), one(std::integral_constant<int, 1>{}), one(std::integral_constant<int, 2>{}), one(std::integral_constant<int, 3>{});
                 if (fminf(fminf(q[0], q[1]), fminf(q[2], q[3])) < best_sq) {
@@ -1460,7 +1466,8 @@ __device__ __forceinline__ void leaf_split_groups(int group, int ngroups, int ti
     auto process = [&](const int l, const int b, const int e) {
         const int cnt = e - b;
         // most anti-parallel normal pair: min over ordered pairs (a outer, c inner, a != c) of |n_a + n_c|, first minimum wins.
-        // k_split_pairs already found, for every member a, its first best partner c; reduce over a (ties -> smallest a).
+        // k_split_pairs already found, for every member a, its first best partner c BEHIND a (the leaf's first minimal pair has a < c);
+        // reduce over a (ties -> smallest a).
         float best = FLT_MAX;
         long long best_pair = LLONG_MAX;
         for (int j0 = b + tid; j0 < e; j0 += 8 * kThreads) {  // eight loads in flight per thread (one at a time: 17 memory latencies for the largest leaves)
