@@ -241,6 +241,54 @@ def test_keyframe_tables_and_split_gaussians(hip, orc, small_keyframes):
     assert ref.M != ref_nosplit.M or ref.Mm != ref_nosplit.Mm
 
 
+@pytest.mark.parametrize("case", ["noisy", "duplicates", "flipped_tail"])
+def test_split_pair_search_takes_only_partners_behind_a_position(hip, orc, small_keyframes, case):
+    """splitSet's double loop (Gaussians.h:36-51) keeps the FIRST minimal pair in (a outer, c inner) order; k_split_pairs only looks at
+    partners c > a because |n_a + n_c| has the bits of |n_c + n_a|, so that pair has a < c.  Normals that make the minimum fall anywhere:
+    noise (no ties, the best partner of most members lies in front of them), exact duplicates and exact opposites (ties at the minimum,
+    also with the value 0), and opposites only among the LAST members of every frame (the minimal pairs sit at the end of the leaves)."""
+    prob = small_keyframes.copy()
+    rng = np.random.default_rng({"noisy": 1, "duplicates": 2, "flipped_tail": 3}[case])
+    f = np.float32
+    nl = prob.localNormals.copy()
+    n = nl.shape[0]
+    if case == "noisy":
+        nl[:, :3] += rng.normal(0, 0.3, (n, 3)).astype(f)
+        nl[rng.random(n) < 0.35, :3] *= f(-1)
+    elif case == "duplicates":
+        nl[:, :3] = np.round(nl[:, :3] * f(4)) / f(4)       # a handful of distinct directions: ties everywhere
+        nl[rng.random(n) < 0.5, :3] *= f(-1)                # and exact opposites: |n_a + n_c| = 0 for many pairs
+        nl[(nl[:, :3] == 0).all(axis=1), 2] = 1
+    else:
+        for k in range(prob.numFrames):
+            a, b = prob.frameOffsets[k], prob.frameOffsets[k + 1]
+            nl[b - (b - a) // 5:b, :3] *= f(-1)
+        nl[:, :3] += rng.normal(0, 0.02, (n, 3)).astype(f)
+    nrm = np.linalg.norm(nl[:, :3].astype(np.float64), axis=1)
+    nl[:, :3] = (nl[:, :3] / np.maximum(nrm, 1e-6)[:, None]).astype(f)
+    prob.localNormals = nl
+    s = DmsaOptimSettings.keyframe_map()
+    opt = hip.DmsaOptimizer()
+    opt.upload(prob)
+    ref_tab = orc.keyframe_pose_table(prob)
+    assert np.array_equal(opt.poseTables(prob.getPoseParameters())[0], ref_tab)
+    rows = np.repeat(np.arange(prob.numFrames, dtype=np.int32), np.diff(prob.frameOffsets))
+    g_ref = orc.transform_points(ref_tab, prob.localPoints, rows)
+    assert np.array_equal(opt.updateGlobalPoints(0)[:, :3], g_ref[:, :3])
+    R = ref_tab.reshape(-1, 3, 4)[rows][:, :, :3]
+    t = (R * nl[:, None, :3]).astype(f)
+    n_ref = (t[:, :, 0] + (t[:, :, 1] + t[:, :, 2]).astype(f)).astype(f)
+    n4 = np.concatenate([n_ref, np.zeros((n, 1), f)], axis=1)
+    M, Mm = opt.buildGaussians(s)
+    ref = orc.Gaussians(g_ref, prob.ringIds, prob.minGridSize, s, normals4=n4)
+    assert (M, Mm) == (ref.M, ref.Mm)
+    seg, memb, info, w = opt.gaussians()
+    opt.close()
+    assert np.array_equal(seg, ref.seg_offset) and np.array_equal(memb, ref.members)
+    ref_nosplit = orc.Gaussians(g_ref, prob.ringIds, prob.minGridSize, DmsaOptimSettings(min_num_points_per_set=10), normals4=n4)
+    assert ref.M != ref_nosplit.M or ref.Mm != ref_nosplit.Mm  # leaves were split
+
+
 def test_optimize_keyframes_matches_oracle(hip, orc, small_keyframes):
     s = DmsaOptimSettings.keyframe_map(num_iter=3)
     p_ref, p_gpu = small_keyframes.copy(), small_keyframes.copy()
