@@ -92,5 +92,29 @@ if os.path.exists(runs):
     rr = [json.loads(l) for l in open(runs) if l.strip().startswith("{")]
     keep = [{k: r[k] for k in ("value", "ms_per_step", "steps", "stage_ms_per_step") if k in r} | {"roofline_avg_launch_ms": r["roofline"]["avg_launch_ms"]} for r in rr]
     open(os.path.join(dst, f"{tag}_bench_runs.json"), "w").write(json.dumps(keep, indent=1) + "\n")
+# 4. files the round script wrote in their final form: timelines, the keyframe workload's own line, the driver's command, small windows, gap stamps
+import shutil
+for name, out_name in (("iteration_timeline.txt", "iteration_timeline.txt"), ("keyframes_iteration_timeline.txt", "keyframes_iteration_timeline.txt"),
+                       ("small_window_imu.txt", "small_window_imu.txt"), ("small_window_rosette.txt", "small_window_rosette.txt")):
+    if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 0:
+        shutil.copyfile(os.path.join(src, name), os.path.join(dst, f"{tag}_{out_name}"))
+kfb = os.path.join(src, "bench_keyframes.json")
+if os.path.exists(kfb):
+    lines = [l for l in open(kfb).read().splitlines() if l.startswith("{")]
+    if lines:
+        open(os.path.join(dst, f"{tag}_bench_keyframes.json"), "w").write(lines[-1] + "\n")
+drv = os.path.join(src, "bench_driver_command.jsonl")
+if os.path.exists(drv):
+    rr = [json.loads(l) for l in open(drv) if l.strip().startswith("{")]
+    open(os.path.join(dst, f"{tag}_bench_driver_command.json"), "w").write(json.dumps([{k: r[k] for k in ("value", "ms_per_step", "steps", "warmup")} for r in rr], indent=1) + "\n")
+gs = os.path.join(src, "gap_stamps.txt")
+if os.path.exists(gs) and os.path.getsize(gs) > 0:
+    head = ("# DMSA_DEBUG=gap_stamps=1: one-thread kernels write the device's 100 MHz wall clock in front of, between and behind the kernels of the\n"
+            "# normal equations and the LM solve (unprofiled runs, last iteration of a call).  The rocprofv3 kernel trace of round 4\n"
+            "# (profiles/r04_keyframes_iteration_timeline.txt) shows three ~40 us holes between k_sync_wait -> k_jacobian_columns -> k_normal_eq_mfma ->\n"
+            "# k_normal_eq_reduce; the kernels themselves take 20 + 25 + 9 = 54 us.  Without the profiler slowing the host's launches:\n")
+    tail = ("# ~55-60 us for 54 us of kernels (+ the stamp kernels' own ~3 us each): the holes are the profiler's (every HIP launch costs tens of\n"
+            "# microseconds of host time under rocprofv3, and at that point of the iteration the host enqueues just in time).  They do not exist in a plain run.\n")
+    open(os.path.join(dst, f"{tag}_keyframes_gap_stamps.txt"), "w").write(head + open(gs).read() + tail)
 print(open(os.path.join(dst, f"{tag}_kernel_stats.txt")).read()[:2500])
 print(tj)
