@@ -774,7 +774,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             EvalSkip skip;
             if (skip_mode != 0)
                 skip.row_range = ctx->d_row_range.as<int2>(), skip.gauss_rows = ctx->d_gauss_rows.as<int2>(), skip.M = ctx->M, skip.check = skip_mode == 2 ? 1 : 0,
-                skip.stats = ctx->d_skip_stats.as<unsigned long long>();
+                skip.stats = ctx->dbg.skip_stats != 0 ? ctx->d_skip_stats.as<unsigned long long>() : nullptr;
             // P <= 64: the block sums stay unreduced, the solve kernel adds them while it loads the matrix
             launch_normal_equations(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, one_div_incr, ctx->d_ne_partial.as<double>(), ctx->d_Hp.as<double>(), ctx->stream,
                                     P > kLoopSolveMaxP, skip_mode != 0 ? &skip : nullptr);

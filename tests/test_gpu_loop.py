@@ -160,9 +160,9 @@ def test_pairs_equal_to_evaluation_0_are_left_out_of_the_jacobian_batch(hip, orc
         s = DmsaOptimSettings.keyframe_map(num_iter=iters)
         p_ref = prob.copy()
         rep_ref, _, tr_ref = orc.optimize_keyframes(p_ref, s)
-        skip, o1 = _run_keep(hip, prob, s)
-        full, o0 = _run_keep(hip, prob, s, debug={"eval_skip": 0})
-        both, o2 = _run_keep(hip, prob, s, debug={"eval_skip": 2})
+        skip, o1 = _run_keep(hip, prob, s, debug={"skip_stats": 1})
+        full, o0 = _run_keep(hip, prob, s, debug={"eval_skip": 0, "skip_stats": 1})
+        both, o2 = _run_keep(hip, prob, s, debug={"eval_skip": 2, "skip_stats": 1})
         _same(skip, (p_ref, rep_ref, tr_ref))
         _same(skip, full)
         _same(skip, both)
