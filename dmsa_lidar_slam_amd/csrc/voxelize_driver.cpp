@@ -185,7 +185,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             launch_leaf_split(ctx->d_leaf_incl[l].as<int32_t>(), ctx->d_leaf_start[l].as<int32_t>(), ctx->idx_s_v[l], ctx->d_ring.as<int32_t>(),
                               ctx->d_nglobal.as<float4>(), &counts->level[l], s.min_num_points_per_set, n, ctx->d_nsorted[l].as<float4>(),
                               ctx->d_pair_d[l].as<unsigned long long>(), ctx->d_slot_acc[l].as<int32_t>(), ctx->d_slot_cnt[l].as<int32_t>(),
-                              ctx->d_pos_slot_rank[l].as<int32_t>(), st[l], ctx->d_split_stats.as<unsigned long long>());
+                              ctx->d_pos_slot_rank[l].as<int32_t>(), st[l], ctx->dbg.skip_stats != 0 ? ctx->d_split_stats.as<unsigned long long>() : nullptr);
         if (ctx->dbg.fused_leaf_scan != 0)
             CHK(finalize());
         else

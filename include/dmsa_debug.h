@@ -71,8 +71,9 @@ typedef struct dmsa_debug_options {
                                      the float sum of a Gaussian with more members than kc depends on kc.  Set it to that machine's L1d to
                                      reproduce its bits; Gaussians up to kc members do not depend on it.                                  */
     int32_t skip_stats;      /* 0   1: k_jacobian_columns counts, per evaluation, the (Gaussian, evaluation) pairs eval_skip left out and (eval_skip = 2)
-                                     the ones that differed after all -> counters skip_pairs_equal / skip_mismatches.  Off by default: two
-                                     atomics per wave and evaluation on the path of every iteration                                       */
+                                     the ones that differed after all -> counters skip_pairs_equal / skip_mismatches; k_split_pairs counts the pair
+                                     blocks it looked at and skipped -> split_blocks / split_blocks_skipped.  Off by default: atomics on the
+                                     path of every iteration (two per wave and evaluation in k_jacobian_columns)                          */
 } dmsa_debug_options;
 
 /* what the switches above leave behind, since the context was created */

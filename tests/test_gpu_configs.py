@@ -102,7 +102,7 @@ def test_split_search_skips_pair_blocks_that_cannot_be_antiparallel(hip):
     64 positions x 64 partners by the cone of the partners' normals and skips the blocks that cannot reach 0.5; the results are the ones the
     exhaustive oracle gives (every keyframe parity test runs through it) -- here: that the skipping really happens at the bench shape."""
     full = synth.keyframe_problem(seed=1, frames=32, arc=2 * np.pi * 32 / 256.0)
-    opt = hip.DmsaOptimizer()
+    opt = hip.DmsaOptimizer(debug={"skip_stats": 1})
     opt.optimizeSet(full.getSubmap(0, 31), DmsaOptimSettings.keyframe_map(num_iter=1))
     c = opt.debugCounters()
     opt.close()
