@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
 TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first
+KF_TRAFFIC_FILES = ("r05_traffic_keyframes.json",)
 
 
 def spawn_ranks(n, backend, visible):
@@ -492,10 +493,20 @@ def sharded_keyframe_pass(args, rank, local_rank, world, dist, coll_dev, sync_al
     memb = sum(int(r.num_memberships) for r in reps.values())
     flops = 48.0 * memb / max(1, len(reps)) * evals  # 48 flop per member and evaluation (mean memberships of this rank's neighbourhoods)
     valu = flops / (acc["residual_kernel_ms"] * 1e-3) / 1e12 if acc["residual_kernel_ms"] > 0 else 0.0
+    # HBM bytes per launch from the committed PMC passes of one neighbourhood of this shape (scripts/kf_pmc.sh -> profiles/rNN_traffic_keyframes.json)
+    traffic, traffic_source = None, "no PMC pass for this workload"
+    for name in KF_TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic, traffic_source = json.load(f).get("hbm_bytes_per_launch"), f"from_profiles: profiles/{name}"
+            break
+        except Exception:
+            continue
     roofline = {"kernel": "reference-order correspondence kernels of the neighbourhoods of rank 0 (B = P + 1 = 187 and B = 9 evaluations per launch)",
                 "bound": "hbm", "achieved": round(eff, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(eff / HBM_PEAK_GBS, 4),
-                "frac_compulsory": round(comp / HBM_PEAK_GBS, 4), "traffic": None,
-                "traffic_source": "no PMC pass for this workload (profiles/r05_traffic.json covers the window)",
+                "frac_compulsory": round(comp / HBM_PEAK_GBS, 4),
+                "frac_counters": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and avg_ms > 0) else None,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": round(avg_ms, 5), "launches": int(launches), "evaluations": int(evals),
                 "algorithmic_bytes_per_launch": round(acc["residual_unit_bytes"] / launches, 1),
                 "compulsory_bytes_per_launch": round(acc["residual_algorithmic_bytes"] / launches, 1),

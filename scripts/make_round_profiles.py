@@ -92,6 +92,36 @@ if os.path.exists(runs):
     rr = [json.loads(l) for l in open(runs) if l.strip().startswith("{")]
     keep = [{k: r[k] for k in ("value", "ms_per_step", "steps", "stage_ms_per_step") if k in r} | {"roofline_avg_launch_ms": r["roofline"]["avg_launch_ms"]} for r in rr]
     open(os.path.join(dst, f"{tag}_bench_runs.json"), "w").write(json.dumps(keep, indent=1) + "\n")
+# 3b. HBM traffic of the correspondence kernels on one keyframe neighbourhood (scripts/kf_pmc.sh: kp3 = FETCH_SIZE, kp4 = WRITE_SIZE)
+kf_rows = []
+for f in sorted(glob.glob(os.path.join(src, "kp*", "*_counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        kf_rows.append((short(r["Kernel_Name"]), int(r["Dispatch_Id"]) if "Dispatch_Id" in r else 0, r["Counter_Name"], float(r["Counter_Value"])))
+if kf_rows:
+    tot = collections.defaultdict(lambda: collections.defaultdict(list))
+    for kn, _, cn, v in kf_rows:
+        tot[kn][cn].append(v)
+    # every iteration launches each chain tier twice (Jacobian batch, line-search batch) and the lane-per-evaluation kernel once per batch
+    # width: sum of the mean bytes of a launch over ALL launches of the run / number of evaluation batches
+    n_batches = len(tot["k_residuals_chain<4, false, 32>"]["FETCH_SIZE"])
+    rd = sum(sum(c["FETCH_SIZE"]) for c in tot.values()) * 1024 * 2
+    wr = sum(sum(c.get("WRITE_SIZE", [0.0])) for c in tot.values()) * 1024
+    nb_w = len(tot["k_residuals_chain<4, false, 32>"].get("WRITE_SIZE", [])) or n_batches
+    per_launch = rd / n_batches + wr / nb_w
+    lines = ["# rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of `python bench.py --workload keyframes --map-frames 0 --frames 32 --steps 3 --warmup 1`",
+             "# one neighbourhood of 32 keyframes, P = 186: evaluation batches of 187 and 9; KiB per dispatch, means over the dispatches of a kernel"]
+    for kn in sorted(tot):
+        c = tot[kn]
+        f_ = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
+        w_ = sum(c.get("WRITE_SIZE", [0.0])) / max(1, len(c.get("WRITE_SIZE", [0.0])))
+        lines.append(f"{kn:40s} dispatches {len(c['FETCH_SIZE']):3d}   FETCH_SIZE {f_:10.1f} KiB (x2 on gfx950: {2 * f_ * 1024 / 1e6:7.2f} MB)   WRITE_SIZE {w_:10.1f} KiB ({w_ * 1024 / 1e6:7.2f} MB)")
+    lines.append(f"# per evaluation batch (all tiers): {per_launch / 1e6:.1f} MB")
+    lines.append("# k_residuals_small<64> writes ~48 MB per Jacobian batch for ~12 MB of residuals: lane = evaluation, so the 8-byte stores of a wave go to 64")
+    lines.append("# different columns of E (32-byte write granules); E is indexed by Gaussian because the normal equations sum its rows in that order.")
+    open(os.path.join(dst, f"{tag}_pmc_keyframes.txt"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(dst, f"{tag}_traffic_keyframes.json"), "w").write(json.dumps(
+        {"workload": "keyframes: one neighbourhood of 32 frames, P = 186", "hbm_bytes_per_launch": round(per_launch),
+         "source": f"profiles/{tag}_pmc_keyframes.txt (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, all correspondence kernels / evaluation batches)"}, indent=1) + "\n")
 # 4. files the round script wrote in their final form: timelines, the keyframe workload's own line, the driver's command, small windows, gap stamps
 import shutil
 for name, out_name in (("iteration_timeline.txt", "iteration_timeline.txt"), ("keyframes_iteration_timeline.txt", "keyframes_iteration_timeline.txt"),

@@ -26,6 +26,8 @@ timeout 120 rocprofv3 --kernel-trace --stats -d $OUT/kfstats -o stats -- python 
 python $R/scripts/iteration_timeline.py $(find $OUT/kfstats -name "*results.db" | head -1) 4 > $OUT/keyframes_iteration_timeline.txt 2>> $OUT/timeline.err
 # the keyframe workload's own bench line (strong-scaling layout: the 249-frame map in 8 neighbourhoods on this one GPU)
 timeout 300 python $R/bench.py --workload keyframes --steps 30 --warmup 2 --cpu-iters 0 > $OUT/bench_keyframes.json 2> $OUT/bench_keyframes.err < /dev/null
+# HBM traffic of the correspondence kernels on a keyframe neighbourhood (two PMC passes)
+bash $R/scripts/kf_pmc.sh ${1:-r01} > /dev/null 2>&1
 # repeated bench lines
 for i in 1 2 3; do timeout 100 python $R/bench.py --steps 200 --warmup 5 --no-extras 2>/dev/null < /dev/null | tail -1 >> $OUT/bench_runs.jsonl; done
 tail -c 400 $OUT/bench.json
