@@ -98,12 +98,16 @@ __device__ Pose0 pose0_orbit(Pose0 p0, int j) {
 }
 
 // additional rows of the CURRENT chain in LDS -> rows[0 .. extra); the window model's updateImuError runs global2relative first
-__device__ void wave_extra_rows(const LoopModel& m, double* rel_o, double* rel_t, const double* glob_o, const double* glob_t, double* rows) {
+__device__ void wave_extra_rows(const LoopModel& m, double* rel_o, double* rel_t, const double* glob_o, const double* glob_t, double* rows, double* dense) {
     const int lane = threadIdx.x;
     if (m.extra <= 0) return;
     if (m.model == 1) {
         wave_global_to_relative(m.n, glob_o, glob_t, rel_o, rel_t);
-        for (int k = 1 + lane; k < m.n; k += kWave) rows[k - 1] = imu_row(k, m.n, m.stamps, m.fhw, m.traj_time, m.imu, glob_o, glob_t, col3(rel_o, k));
+        // the twelve dense-trajectory values of every row on twelve lanes (independent Floater-Hormann evaluations, six divisions each),
+        // then one lane per row: the same operations as imu_row()
+        for (int i = lane; i < 12 * (m.n - 1); i += kWave) dense[i] = imu_dense_value(1 + i / 12, i % 12, m.n, m.stamps, m.fhw, m.traj_time, m.imu, glob_t);
+        __syncthreads();
+        for (int k = 1 + lane; k < m.n; k += kWave) rows[k - 1] = imu_row_from_dense(k, dense + 12 * (k - 1), m.stamps, m.imu, glob_o, glob_t, col3(rel_o, k));
     } else {
         int at = 0;
         if (m.key.use_gravity) {
@@ -136,12 +140,13 @@ __device__ __forceinline__ void store_ctrl(double* ctrl, int n, const double* gl
 }
 
 struct ChainLds {
-    double *rel_o, *rel_t, *glob_o, *glob_t, *E, *R, *par, *org, *rows;
+    double *rel_o, *rel_t, *glob_o, *glob_t, *E, *R, *par, *org, *rows, *dense;
 };
 __device__ __forceinline__ ChainLds carve(double* sm, int n, int P) {
     ChainLds c;
     c.rel_o = sm, c.rel_t = sm + 3 * n, c.glob_o = sm + 6 * n, c.glob_t = sm + 9 * n, c.E = sm + 12 * n, c.R = sm + 21 * n;
     c.par = sm + 30 * n, c.org = c.par + P, c.rows = c.org + P;
+    c.dense = sm + 12 * n;  // the window's IMU rows: twelve dense-trajectory values per row in E (9 n doubles, free between two chains) and the head of R
     return c;
 }
 size_t chain_lds_bytes(const LoopModel& m) { return (30 * (size_t)m.n + 2 * (size_t)m.P + (size_t)(m.extra > 0 ? m.extra : 1)) * sizeof(double); }
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(kWave) void k_loop_chain(const LoopModel m, int mod
         // its additional rows; the window model's round trip also decides `origin` (:204 reads the parameters AFTER it), so every
         // evaluation of that model repeats it
         if (b == 0 || carries) {
-            wave_extra_rows(m, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.rows);
+            wave_extra_rows(m, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.rows, c.dense);
             if (b == 0)
                 for (int i = threadIdx.x; i < a; i += kWave) my_rows[i] = c.rows[i];
         }
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(kWave) void k_loop_chain(const LoopModel m, int mod
         set_params_lds(n, c.par, c.rel_o, c.rel_t);
         wave_relative_to_global(n, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.E, c.R);
         store_ctrl(my_ctrl, n, c.glob_o, c.glob_t);
-        wave_extra_rows(m, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.rows);
+        wave_extra_rows(m, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.rows, c.dense);
         for (int i = threadIdx.x; i < a; i += kWave) my_rows[i] = c.rows[i];
     }
     if (b == B - 1) {

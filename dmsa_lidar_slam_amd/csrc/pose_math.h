@@ -170,18 +170,21 @@ struct ImuConsts {
     const double* preint_vel;     // C x 3
     const double* cov_inv;        // C x 81 column-major
 };
-DMSA_HD double imu_row(int k, int C, const double* stamps, const double* fhw, const double* traj_time, const ImuConsts& c, const double* glob_o,
-                       const double* glob_t, Vec3 rel_o_k) {
-    auto dense_t = [&](int j) {
-        const double t = traj_time[j];
-        return Vec3{fh2_eval(C, stamps, fhw, glob_t + 0, 3, t), fh2_eval(C, stamps, fhw, glob_t + 1, 3, t), fh2_eval(C, stamps, fhw, glob_t + 2, 3, t)};
-    };
+// the twelve dense-trajectory values row k needs, e = 3 * point + axis with the points (i0 + 1, i0, i1, i1 - 1) in the order the row uses them:
+// independent Floater-Hormann evaluations (the device computes them on twelve lanes, k_loop_chain)
+DMSA_HD double imu_dense_value(int k, int e, int C, const double* stamps, const double* fhw, const double* traj_time, const ImuConsts& c, const double* glob_t) {
+    const int i0 = c.param_indices[k - 1], i1 = c.param_indices[k];
+    const int pt = e / 3, a = e - 3 * pt;
+    const int j = pt == 0 ? i0 + 1 : pt == 1 ? i0 : pt == 2 ? i1 : i1 - 1;
+    return fh2_eval(C, stamps, fhw, glob_t + a, 3, traj_time[j]);
+}
+// row k from its twelve dense values d[e]
+DMSA_HD double imu_row_from_dense(int k, const double* d, const double* stamps, const ImuConsts& c, const double* glob_o, const double* glob_t, Vec3 rel_o_k) {
     const double inv_dt = 1.0 / c.dt_res;
     const Mat3 Rst = transposed(so3_exp(col3(glob_o, k - 1)));
     const double delta_t = stamps[k] - stamps[k - 1];
-    const int i0 = c.param_indices[k - 1], i1 = c.param_indices[k];
-    const Vec3 v_start = inv_dt * (dense_t(i0 + 1) - dense_t(i0));
-    const Vec3 v_end = inv_dt * (dense_t(i1) - dense_t(i1 - 1));
+    const Vec3 v_start = inv_dt * (Vec3{d[0], d[1], d[2]} - Vec3{d[3], d[4], d[5]});
+    const Vec3 v_end = inv_dt * (Vec3{d[6], d[7], d[8]} - Vec3{d[9], d[10], d[11]});
     const double half_dt2 = 0.5 * (delta_t * delta_t);  // std::pow(delta_t, 2): exact square, correctly rounded
     const Vec3 pk = col3(glob_t, k), pk1 = col3(glob_t, k - 1);
     const Vec3 tmp_p{pk.x - pk1.x - v_start.x * delta_t - half_dt2 * c.gravity[0], pk.y - pk1.y - v_start.y * delta_t - half_dt2 * c.gravity[1],
@@ -206,6 +209,12 @@ DMSA_HD double imu_row(int k, int C, const double* stamps, const double* fhw, co
     for (int j = 0; j < 9; ++j) q += left[j] * ce[j];
     q *= c.balancing_imu;
     return sqrt(q);
+}
+DMSA_HD double imu_row(int k, int C, const double* stamps, const double* fhw, const double* traj_time, const ImuConsts& c, const double* glob_o,
+                       const double* glob_t, Vec3 rel_o_k) {
+    double d[12];
+    for (int e = 0; e < 12; ++e) d[e] = imu_dense_value(k, e, C, stamps, fhw, traj_time, c, glob_t);
+    return imu_row_from_dense(k, d, stamps, c, glob_o, glob_t, rel_o_k);
 }
 
 // ---- gravity / odometry rows of the keyframe model (MapManagement.h:210-252) ----
