@@ -23,7 +23,8 @@ struct SerialCounts {
 int serial_small_threshold();  // members; Gaussians up to this size go to the lane-per-evaluation kernel
 // one workgroup: counting sort of the M = counts->level[0..1].num_gauss Gaussians by size class
 void launch_size_classes(const int32_t* seg_off, const GaussCounts* counts, uint32_t* order /* M */, SerialCounts* out, hipStream_t s,
-                         const DevSync& sy = DevSync() /* waits / signals of the stream dependencies around the kernel (dev_sync.h) */);
+                         const DevSync& sy = DevSync() /* waits / signals of the stream dependencies around the kernel (dev_sync.h) */,
+                         int small_threshold = 0 /* 0: serial_small_threshold() */);
 // tables [B][rows][12] -> tablesT [rows][B][12]: the B evaluations of one pose row are contiguous (lane = evaluation reads coalesce)
 void launch_transpose_tables(const float* tables, int rows, int B, float* tablesT, hipStream_t s);
 // updateErrorTerms for B pose tables, bit-identical to the reference's serial loops.  E[b * ldE + g] = sqrt(|sum|).

@@ -929,8 +929,9 @@ SerialShape serial_shape(int B) {
     s.nsub_small = (B + s.lanes - 1) / s.lanes;
     return s;
 }
-void launch_size_classes(const int32_t* seg_off, const GaussCounts* counts, uint32_t* order, SerialCounts* out, hipStream_t s, const DevSync& sy) {
-    hipLaunchKernelGGL(k_size_classes, dim3(1), dim3(1024), 0, s, seg_off, counts, serial_small_threshold(), serial_long_log2(), order, out, sy);
+void launch_size_classes(const int32_t* seg_off, const GaussCounts* counts, uint32_t* order, SerialCounts* out, hipStream_t s, const DevSync& sy, int small_threshold) {
+    const int ns = small_threshold > 0 ? (small_threshold < kSmallMax ? small_threshold : kSmallMax) : serial_small_threshold();
+    hipLaunchKernelGGL(k_size_classes, dim3(1), dim3(1024), 0, s, seg_off, counts, ns, serial_long_log2(), order, out, sy);
 }
 void launch_transpose_tables(const float* tables, int rows, int B, float* tablesT, hipStream_t s) {
     const int total = rows * B * 3;

@@ -246,6 +246,13 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     // stream it is on for ~20 us, and the fit behind it does not need to wait for that.
     hipStream_t rb = ctx->dual_stream ? ctx->stream3 : ctx->stream;
     bool rb_released = false;
+    // Which Gaussians walk their members on one lane group (k_residuals_small, the fit's one-wave class) and which get a workgroup
+    // (chain tiers, the fit's four-wave class)?  The lane-per-evaluation kernel spends the fewest instructions per member, but a wave of
+    // it walks up to `threshold` members one after the other: with a few thousand Gaussians (the reference's everyday windows, small
+    // keyframe sets) its few hundred waves leave the chip idle while the longest of them runs -- measured on the config-2 window:
+    // 2580 it/s at 256, 2980 at 64, 3090 at 32; on the bench window (13 000 Gaussians) 1262 at 256, 1196 at 64.  Every tier computes
+    // the same bits, so the rule may follow the size of the previous voxelisation.
+    const int small_threshold = ctx->dbg.small_threshold > 0 ? ctx->dbg.small_threshold : ((ctx->M > 0 ? ctx->M < 4096 : n < 200000) ? 32 : 0);
     {   // size classes of the correspondence kernels: needs only seg_off, so it runs before the read-back
         // k_size_classes is one workgroup on the main stream between the voxelisation and the fit: it also carries two stream dependencies
         // (dev_sync.h) -- it waits for the pose tables of the Jacobian batch (built on the side stream long ago) and releases the read-back
@@ -259,7 +266,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             if (rb != ctx->stream) sy.signal_counter = ctx->sync_counter(SYNC_CLASSES), ctx->sync_sig[SYNC_CLASSES] += 1, rb_released = true;
         }
         launch_size_classes(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_order.as<uint32_t>(),
-                            reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts)), ctx->stream, sy);
+                            reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts)), ctx->stream, sy, small_threshold);
     }
     if (ctx->stamp_voxel) launch_stamp(ctx->stamp_voxel, ctx->stream);
     if (rb_released) {

@@ -97,6 +97,10 @@ def test_early_exits_match_the_oracle_and_the_host_driven_loop(hip, orc, case):
     _same(dev, _run(hip, prob, s, debug={"device_sync": 0, "fused_leaf_scan": 0}))
     _same(dev, _run(hip, prob, s, debug={"device_loop": 0, "device_sync": 0}))
     _same(dev, _run(hip, prob, s, debug={"shared_rotations": 0}))  # every evaluation of the Jacobian batch transforms its members itself
+    # where the lane-per-evaluation tier ends and the workgroup tiers begin (the default follows the problem size: 32 members for these
+    # small sets, 256 for large ones) changes nothing: every tier of the correspondence kernels and of the fit computes the same bits
+    for thr in (256, 8, 100):
+        _same(dev, _run(hip, prob, s, debug={"small_threshold": thr}))
     if case == "window_runs_to_a_stop":
         assert dev[1].stop_reason != 0 and dev[1].iterations < s.num_iter  # the case really exercises a device-side stop
 
