@@ -249,10 +249,13 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     // Which Gaussians walk their members on one lane group (k_residuals_small, the fit's one-wave class) and which get a workgroup
     // (chain tiers, the fit's four-wave class)?  The lane-per-evaluation kernel spends the fewest instructions per member, but a wave of
     // it walks up to `threshold` members one after the other: with a few thousand Gaussians (the reference's everyday windows, small
-    // keyframe sets) its few hundred waves leave the chip idle while the longest of them runs -- measured on the config-2 window:
-    // 2580 it/s at 256, 2980 at 64, 3090 at 32; on the bench window (13 000 Gaussians) 1262 at 256, 1196 at 64.  Every tier computes
-    // the same bits, so the rule may follow the size of the previous voxelisation.
-    const int small_threshold = ctx->dbg.small_threshold > 0 ? ctx->dbg.small_threshold : ((ctx->M > 0 ? ctx->M < 4096 : n < 200000) ? 32 : 0);
+    // keyframe sets) its few hundred waves leave the chip idle while the longest of them runs.  Measured (it/s at thresholds 8 = nobody /
+    // 32 / 256, scripts/threshold_ab.sh): config-2 window, 1100 Gaussians 3450 / 3090 / 2580; 8 keyframes, 2465: 1965 / 1955 / 1906;
+    // 12 keyframes, 3823: 1672 / 1782 / 1726; 16 keyframes, 4920: 1353 / 1534 / 1502; 24 keyframes, 6906: 910 / 1080 / 1213; the bench
+    // window, 13 000: - / 1196 (64) / 1262.  Every tier computes the same bits, so the rule may follow the size of the previous
+    // voxelisation (the first one of a context goes by the number of points).
+    const int auto_threshold = ctx->M > 0 ? (ctx->M < 2000 ? 8 : ctx->M < 6000 ? 32 : 0) : (n < 60000 ? 8 : n < 200000 ? 32 : 0);
+    const int small_threshold = ctx->dbg.small_threshold > 0 ? ctx->dbg.small_threshold : auto_threshold;
     {   // size classes of the correspondence kernels: needs only seg_off, so it runs before the read-back
         // k_size_classes is one workgroup on the main stream between the voxelisation and the fit: it also carries two stream dependencies
         // (dev_sync.h) -- it waits for the pose tables of the Jacobian batch (built on the side stream long ago) and releases the read-back

@@ -71,7 +71,7 @@ typedef struct dmsa_debug_options {
                                      the float sum of a Gaussian with more members than kc depends on kc.  Set it to that machine's L1d to
                                      reproduce its bits; Gaussians up to kc members do not depend on it.                                  */
     int32_t small_threshold; /* 0   members up to which a Gaussian goes to the lane-per-evaluation correspondence kernel (and the fit's one-wave class);
-                                     0 = the built-in rule (32 when the previous voxelisation had fewer than 4096 Gaussians, else 256), else 1 .. 256.
+                                     0 = the built-in rule (previous voxelisation: < 2000 Gaussians nobody, < 6000 up to 32 members, else 256), else 1 .. 256.
                                      Every tier computes the same bits.                                                                  */
     int32_t skip_stats;      /* 0   1: k_jacobian_columns counts, per evaluation, the (Gaussian, evaluation) pairs eval_skip left out and (eval_skip = 2)
                                      the ones that differed after all -> counters skip_pairs_equal / skip_mismatches; k_split_pairs counts the pair
