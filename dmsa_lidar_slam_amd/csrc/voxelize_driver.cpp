@@ -78,6 +78,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     bool k32v[2] = {false, false};
     // Both resolutions are keyed into one array of 2n (code, point) pairs -- level 1 carries a tag bit above the widest code --
     // and sorted by ONE radix sort: half the launches, twice the parallelism per pass, and the sorted halves are the two levels.
+    if (ctx->dbg.trace_time >= 3) std::fprintf(stderr, "[voxelize] key bits (without the marker of non-finite points): level 0 %d, level 1 %d\n", sort_bits[0], sort_bits[1]);
     const int tag_bit = std::max(sort_bits[0], sort_bits[1]) + 1;  // bit `sort_bits` is the marker of non-finite points
     const unsigned end_bit = (unsigned)(tag_bit + 1);
     const bool k32 = end_bit <= 32;
