@@ -179,6 +179,19 @@ class DmsaOptimizer:
         self._check(self._lib.dmsa_debug_pow_minus_one(self._ctx, capi.ptr(n, C.c_int32), n.shape[0], capi.ptr(out, C.c_float)), "debug_pow_minus_one")
         return out
 
+    def limitCovariance(self, cov):
+        """Test hook: Gaussians::limitCovariance on an (n, 3, 3) array [row, col] as the fit computes it on the device.  Returns the limited
+        covariances, eigenvalues().real(), eigenvectors().real() [row, col], Francis QR steps and info of the EigenSolver behind it."""
+        A = np.ascontiguousarray(np.asarray(cov, np.float32).reshape(-1, 3, 3))
+        n = A.shape[0]
+        At = np.ascontiguousarray(A.transpose(0, 2, 1))
+        out, Vt = np.zeros_like(At), np.zeros_like(At)
+        ev = np.zeros((n, 3), np.float32)
+        it, info = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self._check(self._lib.dmsa_debug_limit_covariance(self._ctx, capi.ptr(At, C.c_float), n, capi.ptr(out, C.c_float), capi.ptr(ev, C.c_float),
+                                                          capi.ptr(Vt, C.c_float), capi.ptr(it, C.c_int32), capi.ptr(info, C.c_int32)), "debug_limit_covariance")
+        return np.ascontiguousarray(out.transpose(0, 2, 1)), ev, np.ascontiguousarray(Vt.transpose(0, 2, 1)), it, info
+
     def optimizeResident(self, settings: DmsaOptimSettings) -> capi.Report:
         """optimizeSet on the problem already resident in HBM (after upload() or a previous optimizeSet)."""
         cs = settings.to_c()

@@ -284,6 +284,7 @@ int dmsa_debug_pow_minus_one(dmsa_ctx* ctx, const int32_t* counts, int32_t count
     CHK(set_device(ctx));
     int32_t mx = 0;
     for (int32_t i = 0; i < count; ++i) mx = std::max(mx, counts[i]);
+    if (mx > (1 << 24)) return DMSA_ERR_INVALID;  // the difference table holds one powf call per count up to the largest: bounded (a Gaussian has < 2^24 members)
     CHK(upload_powm1_codes(ctx, (int64_t)mx + 1));
     DevBuf d_n, d_o;
     HIPCHK(d_n.ensure((size_t)count * 4 + 16));
@@ -293,6 +294,28 @@ int dmsa_debug_pow_minus_one(dmsa_ctx* ctx, const int32_t* counts, int32_t count
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(out, d_o.p, (size_t)count * 4, hipMemcpyDeviceToHost));
     d_n.release(), d_o.release();
+    return DMSA_OK;
+}
+int dmsa_debug_limit_covariance(dmsa_ctx* ctx, const float* cov9, int64_t count, float* out9, float* evals3, float* V9, int32_t* iterations, int32_t* info) {
+    if (!ctx || !cov9 || !out9 || count < 0) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    DevBuf d_in, d_out, d_ev, d_v, d_it, d_info;
+    const size_t n = (size_t)count;
+    HIPCHK(d_in.ensure(n * 36 + 16));
+    HIPCHK(d_out.ensure(n * 36 + 16));
+    HIPCHK(d_ev.ensure(n * 12 + 16));
+    HIPCHK(d_v.ensure(n * 36 + 16));
+    HIPCHK(d_it.ensure(n * 4 + 16));
+    HIPCHK(d_info.ensure(n * 4 + 16));
+    HIPCHK(hipMemcpy(d_in.p, cov9, n * 36, hipMemcpyHostToDevice));
+    launch_debug_limit_covariance(d_in.as<float>(), count, d_out.as<float>(), d_ev.as<float>(), d_v.as<float>(), d_it.as<int32_t>(), d_info.as<int32_t>(), ctx->stream);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out9, d_out.p, n * 36, hipMemcpyDeviceToHost));
+    if (evals3) HIPCHK(hipMemcpy(evals3, d_ev.p, n * 12, hipMemcpyDeviceToHost));
+    if (V9) HIPCHK(hipMemcpy(V9, d_v.p, n * 36, hipMemcpyDeviceToHost));
+    if (iterations) HIPCHK(hipMemcpy(iterations, d_it.p, n * 4, hipMemcpyDeviceToHost));
+    if (info) HIPCHK(hipMemcpy(info, d_info.p, n * 4, hipMemcpyDeviceToHost));
+    d_in.release(), d_out.release(), d_ev.release(), d_v.release(), d_it.release(), d_info.release();
     return DMSA_OK;
 }
 int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out) {

@@ -138,6 +138,7 @@ void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start
 void launch_gauss_fit_all(const float4* memb_local, const int32_t* seg_off, const float* table0, const uint32_t* order, const int32_t* sc, const int first[3],
                           const int tasks[3], float* sums, GaussCounts* counts, float* info12, bool with_weights, int id_row, int2* gauss_rows, int eigen_l1_bytes,
                           const uint32_t* pow_codes, int pow_n, float* memb_q /* [3][q_stride] scratch */, size_t q_stride, hipStream_t s);
+void launch_debug_limit_covariance(const float* cov9, int64_t count, float* out9, float* evals3, float* V9, int32_t* iters, int32_t* info, hipStream_t s);  // test hook (dmsa_debug_limit_covariance)
 void launch_pow_minus_one(const int32_t* n, int count, const uint32_t* pow_codes, int pow_n, float* out, hipStream_t s);  // test hook (dmsa_debug_pow_minus_one)
 void launch_gauss_fit_finish(const int32_t* seg_off, const GaussCounts* counts, const float* sums, int max_gauss, float* info12, hipStream_t s);
 // ---- K5: normal equations + squared-error sums -------------------------------------------------------------

@@ -1934,41 +1934,483 @@ void launch_gather_members(const int32_t* leaf_of_pos, const int32_t* leaf_start
 // K3 — Gaussian fit: covariance (double accumulation, rounded once), eigenvalue clamp, information matrix
 // ------------------------------------------------------------------------------------------------------------
 __device__ void inverse3_f(const float m[3][3], float inv[3][3]);
-__device__ void limit_covariance_f(float c[3][3]) {
-    float a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) a[i][j] = c[i][j];
-    for (int sweep = 0; sweep < 6; ++sweep) {
+
+// ---- EigenSolver<Matrix3f> as Eigen 3.4.0 runs it on the reference's covariances (Gaussians.h:184-188) ----------------------------------
+// One lane = one Gaussian.  The statements are those of Eigen's RealSchur / HessenbergDecomposition / Householder / Jacobi / EigenSolver
+// sources, hand-specialised for a 3 x 3 matrix (indices are compile-time constants, the matrices live in registers):
+//   scale by the largest |coefficient|; ONE Householder reflector brings the matrix to Hessenberg form (the second reflector of
+//   HessenbergDecomposition::_compute acts on a vector of one coefficient: tau = 0, multiplications by 1.0f); U = the reflector applied to I;
+//   RealSchur::computeFromHessenberg: while the active window is the full matrix (il = 0, iu = 2) Francis double-shift steps -- shift from the
+//   trailing 2 x 2 block (Wilkinson's / MATLAB's exceptional shifts at the 10th / 30th step), a reflector of the 3-vector, a reflector of the
+//   2-vector below it --, then a trailing row deflates (il = 2) or the trailing 2 x 2 block splits off by a Givens rotation (il = 1), and the
+//   remaining 2 x 2 / 1 x 1 part does the same; T *= scale; eigenvalues off T's diagonal in that order; EigenSolver::doComputeEigenvectors:
+//   back substitution on T, then eivec = U * T column by column (the 3-term column sequentially); eigenvectors(): columns divided by their norm.
+// Every multiply, add, divide and sqrt rounds once (no FMA: -ffp-contract=off; IEEE division and sqrt), reflector updates multiply
+// (tau * essential_i) * tmp_j from the left and (tau * tmp_i) * essential_j from the right as Eigen's expressions associate.  A complex pair
+// (a trailing block of pure rounding noise) follows EigenSolver's complex branch with libgcc 9's float Smith division; the real parts of the
+// two eigenvectors then coincide, V is singular and the Gaussian's information matrix is not finite -- in the reference as well.
+// std::max / numext::maxi: (a < b) ? b : a -- a NaN in the first place stays, one in the second is dropped
+__device__ __forceinline__ float eig3_max(float a, float b) { return a < b ? b : a; }
+struct Eig3 {
+    float t[3][3], u[3][3];
+};
+// Householder.h makeHouseholder for a 3-vector / 2-vector: essential part, tau, beta
+__device__ __forceinline__ void eig3_householder3(float c0, float v1, float v2, float& e0, float& e1, float& tau, float& beta) {
+    const float tail = v1 * v1 + v2 * v2;
+    if (tail <= FLT_MIN) {
+        tau = 0.0f, beta = c0, e0 = 0.0f, e1 = 0.0f;
+    } else {
+        float b = sqrtf(c0 * c0 + tail);
+        if (c0 >= 0.0f) b = -b;
+        const float d = c0 - b;
+        e0 = v1 / d, e1 = v2 / d;
+        tau = (b - c0) / b, beta = b;
+    }
+}
+__device__ __forceinline__ void eig3_householder2(float c0, float v1, float& e, float& tau, float& beta) {
+    const float tail = v1 * v1;
+    if (tail <= FLT_MIN) {
+        tau = 0.0f, beta = c0, e = 0.0f;
+    } else {
+        float b = sqrtf(c0 * c0 + tail);
+        if (c0 >= 0.0f) b = -b;
+        e = v1 / (c0 - b);
+        tau = (b - c0) / b, beta = b;
+    }
+}
+// reflector (1, e) on rows R, R + 1 of m, columns C0 .. 2 (applyHouseholderOnTheLeft of a 2-row block)
+template <int R, int C0>
+__device__ __forceinline__ void eig3_left2(float (&m)[3][3], float e, float tau) {
+    if (tau == 0.0f) return;
+    const float te = tau * e;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int p = r == 2 ? 1 : 0, q = r == 0 ? 1 : 2;
-            const float apq = a[p][q];
-            if (apq == 0.0f) continue;
-            const float theta = (a[q][q] - a[p][p]) / (2.0f * apq);
-            const float at = fabsf(theta);
-            float t = 1.0f / (at + sqrtf(theta * theta + 1.0f));
-            if (theta < 0.0f) t = -t;
-            const float cs = 1.0f / sqrtf(t * t + 1.0f);
-            const float sn = t * cs;
-            const int k = 3 - p - q;
-            const float app = a[p][p], aqq = a[q][q];
-            a[p][p] = app - t * apq;
-            a[q][q] = aqq + t * apq;
-            a[p][q] = 0.0f, a[q][p] = 0.0f;
-            const float akp = a[k][p], akq = a[k][q];
-            a[k][p] = cs * akp - sn * akq;
-            a[p][k] = a[k][p];
-            a[k][q] = sn * akp + cs * akq;
-            a[q][k] = a[k][q];
-            for (int i = 0; i < 3; ++i) {
-                const float vip = v[i][p], viq = v[i][q];
-                v[i][p] = cs * vip - sn * viq;
-                v[i][q] = sn * vip + cs * viq;
+    for (int j = C0; j < 3; ++j) {
+        float tmp = e * m[R + 1][j];
+        tmp = tmp + m[R][j];
+        m[R][j] = m[R][j] - tau * tmp;
+        m[R + 1][j] = m[R + 1][j] - te * tmp;
+    }
+}
+// reflector (1, e) on columns C, C + 1 of m, all three rows (applyHouseholderOnTheRight of a 2-column block)
+template <int C>
+__device__ __forceinline__ void eig3_right2(float (&m)[3][3], float e, float tau) {
+    if (tau == 0.0f) return;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float tmp = m[i][C + 1] * e;
+        tmp = tmp + m[i][C];
+        const float tt = tau * tmp;
+        m[i][C] = m[i][C] - tt;
+        m[i][C + 1] = m[i][C + 1] - tt * e;
+    }
+}
+// reflector (1, e0, e1) on the whole matrix from the left / from the right
+__device__ __forceinline__ void eig3_left3(float (&m)[3][3], float e0, float e1, float tau) {
+    if (tau == 0.0f) return;
+    const float te0 = tau * e0, te1 = tau * e1;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float tmp = e0 * m[1][j] + e1 * m[2][j];
+        tmp = tmp + m[0][j];
+        m[0][j] = m[0][j] - tau * tmp;
+        m[1][j] = m[1][j] - te0 * tmp;
+        m[2][j] = m[2][j] - te1 * tmp;
+    }
+}
+__device__ __forceinline__ void eig3_right3(float (&m)[3][3], float e0, float e1, float tau) {
+    if (tau == 0.0f) return;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float tmp = m[i][1] * e0 + m[i][2] * e1;
+        tmp = tmp + m[i][0];
+        const float tt = tau * tmp;
+        m[i][0] = m[i][0] - tt;
+        m[i][1] = m[i][1] - tt * e0;
+        m[i][2] = m[i][2] - tt * e1;
+    }
+}
+// RealSchur::splitOffTwoRows(IU): the block of rows / columns IU - 1, IU decouples
+template <int IU>
+__device__ __forceinline__ void eig3_split(Eig3& s, float exshift) {
+    constexpr int A = IU - 1, B = IU;
+    const float p = 0.5f * (s.t[A][A] - s.t[B][B]);
+    const float q = p * p + s.t[B][A] * s.t[A][B];
+    s.t[B][B] = s.t[B][B] + exshift;
+    s.t[A][A] = s.t[A][A] + exshift;
+    if (q >= 0.0f) {
+        const float z = sqrtf(fabsf(q));
+        // JacobiRotation::makeGivens(p +- z, T(iu, iu - 1))
+        const float gp = p >= 0.0f ? p + z : p - z, gq = s.t[B][A];
+        float c, sn;
+        if (gq == 0.0f) {
+            c = gp < 0.0f ? -1.0f : 1.0f, sn = 0.0f;
+        } else if (gp == 0.0f) {
+            c = 0.0f, sn = gq < 0.0f ? 1.0f : -1.0f;
+        } else if (fabsf(gp) > fabsf(gq)) {
+            const float t = gq / gp;
+            float w = sqrtf(1.0f + t * t);
+            if (gp < 0.0f) w = -w;
+            c = 1.0f / w;
+            sn = -t * c;
+        } else {
+            const float t = gp / gq;
+            float w = sqrtf(1.0f + t * t);
+            if (gq < 0.0f) w = -w;
+            sn = -1.0f / w;
+            c = -t * sn;
+        }
+        // both applications use the rotation (c, -s): x <- c x + (-s) y, y <- s x + c y; the identity rotation is skipped
+        const float ms = -sn;
+        if (!(c == 1.0f && ms == 0.0f)) {
+#pragma unroll
+            for (int j = A; j < 3; ++j) {  // rightCols(size - iu + 1).applyOnTheLeft(iu - 1, iu, rot.adjoint())
+                const float x = s.t[A][j], y = s.t[B][j];
+                s.t[A][j] = c * x + ms * y;
+                s.t[B][j] = -ms * x + c * y;
+            }
+#pragma unroll
+            for (int i = 0; i <= B; ++i) {  // topRows(iu + 1).applyOnTheRight(iu - 1, iu, rot)
+                const float x = s.t[i][A], y = s.t[i][B];
+                s.t[i][A] = c * x + ms * y;
+                s.t[i][B] = -ms * x + c * y;
+            }
+        }
+        s.t[B][A] = 0.0f;
+        if (!(c == 1.0f && ms == 0.0f)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {  // m_matU.applyOnTheRight(iu - 1, iu, rot)
+                const float x = s.u[i][A], y = s.u[i][B];
+                s.u[i][A] = c * x + ms * y;
+                s.u[i][B] = -ms * x + c * y;
             }
         }
     }
-    float lam[3];
-    for (int k = 0; k < 3; ++k) lam[k] = fmaxf(a[k][k], 0.0001f);
+    if (IU > 1) s.t[1][0] = 0.0f;
+}
+// std::complex<float> division, libgcc 9's __divsc3 (Smith) without its NaN-recovery tail
+__device__ __forceinline__ void eig3_cdiv(float a, float b, float c, float d, float& x, float& y) {
+    if (fabsf(c) < fabsf(d)) {
+        const float ratio = c / d;
+        const float denom = (c * ratio) + d;
+        x = ((a * ratio) + b) / denom;
+        y = ((b * ratio) - a) / denom;
+    } else {
+        const float ratio = d / c;
+        const float denom = (d * ratio) + c;
+        x = ((b * ratio) + a) / denom;
+        y = (b - (a * ratio)) / denom;
+    }
+}
+// returns 0 (Success), 1 (NumericalIssue), 2 (NoConvergence); lam = eigenvalues().real(), v = eigenvectors().real(); *iters = Francis steps
+__device__ int eigensolver3f(const float c[3][3], float v[3][3], float lam[3], int* iters) {
+    Eig3 s;
+    float scale = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) scale = eig3_max(scale, fabsf(c[i][j]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s.u[i][j] = i == j ? 1.0f : 0.0f;
+    if (iters) *iters = 0;
+    if (scale < FLT_MIN) {  // T = 0, U = I: eigenvalues 0, doComputeEigenvectors returns at once, the columns of I are normalised by 1
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            lam[i] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[i][j] = s.u[i][j] / 1.0f;
+        }
+        return 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s.t[i][j] = c[i][j] / scale;
+    {   // HessenbergDecomposition::_compute, i = 0 (i = 1 multiplies by 1.0f) and matrixQ().evalTo
+        float e, tau, beta;
+        eig3_householder2(s.t[1][0], s.t[2][0], e, tau, beta);
+        s.t[1][0] = beta;
+        eig3_left2<1, 1>(s.t, e, tau);
+        eig3_right2<1>(s.t, e, tau);
+        s.t[2][0] = 0.0f;  // matrixH(): below the subdiagonal cleared (the essential part lived there)
+        eig3_left2<1, 1>(s.u, e, tau);
+    }
+    // RealSchur::computeFromHessenberg
+    float norm = 0.0f;
+    norm = norm + (fabsf(s.t[0][0]) + fabsf(s.t[1][0]));
+    norm = norm + ((fabsf(s.t[0][1]) + fabsf(s.t[1][1])) + fabsf(s.t[2][1]));
+    norm = norm + ((fabsf(s.t[0][2]) + fabsf(s.t[1][2])) + fabsf(s.t[2][2]));
+    const float caz = eig3_max(norm * (FLT_EPSILON * FLT_EPSILON), FLT_MIN);
+    float exshift = 0.0f;
+    int total = 0;
+    if (norm != 0.0f) {
+        int iter = 0, il;
+        for (;;) {  // active window = rows 0 .. 2
+            {       // findSmallSubdiagEntry(2)
+                float sm = eig3_max((fabsf(s.t[1][1]) + fabsf(s.t[2][2])) * FLT_EPSILON, caz);
+                if (fabsf(s.t[2][1]) <= sm)
+                    il = 2;
+                else {
+                    sm = eig3_max((fabsf(s.t[0][0]) + fabsf(s.t[1][1])) * FLT_EPSILON, caz);
+                    il = fabsf(s.t[1][0]) <= sm ? 1 : 0;
+                }
+            }
+            if (il != 0) break;
+            // computeShift(2, iter)
+            float s0 = s.t[2][2], s1 = s.t[1][1], s2 = s.t[2][1] * s.t[1][2];
+            if (iter == 10) {
+                exshift = exshift + s0;
+                s.t[0][0] = s.t[0][0] - s0, s.t[1][1] = s.t[1][1] - s0, s.t[2][2] = s.t[2][2] - s0;
+                const float w = fabsf(s.t[2][1]) + fabsf(s.t[1][0]);
+                s0 = 0.75f * w, s1 = 0.75f * w, s2 = -0.4375f * w * w;
+            }
+            if (iter == 30) {
+                float w = (s1 - s0) / 2.0f;
+                w = w * w + s2;
+                if (w > 0.0f) {
+                    w = sqrtf(w);
+                    if (s1 < s0) w = -w;
+                    w = w + (s1 - s0) / 2.0f;
+                    w = s0 - s2 / w;
+                    exshift = exshift + w;
+                    s.t[0][0] = s.t[0][0] - w, s.t[1][1] = s.t[1][1] - w, s.t[2][2] = s.t[2][2] - w;
+                    s0 = s1 = s2 = 0.964f;
+                }
+            }
+            iter = iter + 1;
+            total = total + 1;
+            if (total > 120) break;
+            // initFrancisQRStep: im = il = 0
+            float e0, e1, tau, beta;
+            {
+                const float Tmm = s.t[0][0];
+                const float r = s0 - Tmm, q = s1 - Tmm;
+                const float v0 = (r * q - s2) / s.t[1][0] + s.t[0][1];
+                const float v1 = s.t[1][1] - Tmm - r - q;
+                const float v2 = s.t[2][1];
+                eig3_householder3(v0, v1, v2, e0, e1, tau, beta);
+            }
+            // performFrancisQRStep: k = 0, then the 2-vector below
+            if (beta != 0.0f) {
+                eig3_left3(s.t, e0, e1, tau);
+                eig3_right3(s.t, e0, e1, tau);
+                eig3_right3(s.u, e0, e1, tau);
+            }
+            float e;
+            eig3_householder2(s.t[1][0], s.t[2][0], e, tau, beta);
+            if (beta != 0.0f) {
+                s.t[1][0] = beta;
+                eig3_left2<1, 1>(s.t, e, tau);
+                eig3_right2<1>(s.t, e, tau);
+                eig3_right2<1>(s.u, e, tau);
+            }
+            s.t[2][0] = 0.0f;
+        }
+        if (total > 120) {
+            if (iters) *iters = total;
+            return 2;
+        }
+        if (il == 2) {  // one root found: the rest is the leading 2 x 2 block
+            s.t[2][2] = s.t[2][2] + exshift;
+            s.t[2][1] = 0.0f;
+            const float sm = eig3_max((fabsf(s.t[0][0]) + fabsf(s.t[1][1])) * FLT_EPSILON, caz);
+            if (fabsf(s.t[1][0]) <= sm) {
+                s.t[1][1] = s.t[1][1] + exshift;
+                s.t[1][0] = 0.0f;
+                s.t[0][0] = s.t[0][0] + exshift;
+            } else {
+                eig3_split<1>(s, exshift);
+            }
+        } else {  // two roots found: rows 1, 2 split off, row 0 is a root
+            eig3_split<2>(s, exshift);
+            s.t[0][0] = s.t[0][0] + exshift;
+        }
+    }
+    if (iters) *iters = total;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s.t[i][j] = s.t[i][j] * scale;
+    // EigenSolver::compute: eigenvalues from T.  kind 0: three real; 1: a pair in rows 0, 1; 2: a pair in rows 1, 2
+    float re[3], im[3] = {0.0f, 0.0f, 0.0f};
+    int kind = 0;
+    auto pair_values = [&](float taa, float tab, float tba, float tbb, float& r, float& z) {
+        const float p = 0.5f * (taa - tbb);
+        float t0 = tba, t1 = tab;
+        const float maxval = eig3_max(fabsf(p), eig3_max(fabsf(t0), fabsf(t1)));
+        t0 = t0 / maxval, t1 = t1 / maxval;
+        const float p0 = p / maxval;
+        z = maxval * sqrtf(fabsf(p0 * p0 + t0 * t1));
+        r = tbb + p;
+    };
+    if (s.t[1][0] != 0.0f) {
+        kind = 1;
+        float r, z;
+        pair_values(s.t[0][0], s.t[0][1], s.t[1][0], s.t[1][1], r, z);
+        re[0] = r, im[0] = z, re[1] = r, im[1] = -z, re[2] = s.t[2][2];
+    } else if (s.t[2][1] != 0.0f) {
+        kind = 2;
+        float r, z;
+        pair_values(s.t[1][1], s.t[1][2], s.t[2][1], s.t[2][2], r, z);
+        re[0] = s.t[0][0], re[1] = r, im[1] = z, re[2] = r, im[2] = -z;
+    } else {
+        re[0] = s.t[0][0], re[1] = s.t[1][1], re[2] = s.t[2][2];
+    }
+    {
+        bool fin = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) fin &= isfinite(re[k]) && isfinite(im[k]);
+        if (!fin) return 1;
+    }
+    // doComputeEigenvectors
+    float nrm = 0.0f;
+    nrm = nrm + ((fabsf(s.t[0][0]) + fabsf(s.t[0][1])) + fabsf(s.t[0][2]));
+    nrm = nrm + ((fabsf(s.t[1][0]) + fabsf(s.t[1][1])) + fabsf(s.t[1][2]));
+    nrm = nrm + (fabsf(s.t[2][1]) + fabsf(s.t[2][2]));
+    float ev[3][3];  // m_eivec
+    if (nrm == 0.0f) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ev[i][j] = s.u[i][j];
+    } else {
+        const float eps = FLT_EPSILON;
+        if (kind == 0) {
+            {   // n = 2
+                const float p = re[2];
+                s.t[2][2] = 1.0f;
+                float w = s.t[1][1] - p;
+                float r = s.t[1][2] * s.t[2][2];
+                s.t[1][2] = w != 0.0f ? -r / w : -r / (eps * nrm);
+                float t = fabsf(s.t[1][2]);
+                if ((eps * t) * t > 1.0f) s.t[1][2] = s.t[1][2] / t, s.t[2][2] = s.t[2][2] / t;
+                w = s.t[0][0] - p;
+                r = s.t[0][1] * s.t[1][2] + s.t[0][2] * s.t[2][2];
+                s.t[0][2] = w != 0.0f ? -r / w : -r / (eps * nrm);
+                t = fabsf(s.t[0][2]);
+                if ((eps * t) * t > 1.0f) s.t[0][2] = s.t[0][2] / t, s.t[1][2] = s.t[1][2] / t, s.t[2][2] = s.t[2][2] / t;
+            }
+            {   // n = 1
+                const float p = re[1];
+                s.t[1][1] = 1.0f;
+                const float w = s.t[0][0] - p;
+                const float r = s.t[0][1] * s.t[1][1];
+                s.t[0][1] = w != 0.0f ? -r / w : -r / (eps * nrm);
+                const float t = fabsf(s.t[0][1]);
+                if ((eps * t) * t > 1.0f) s.t[0][1] = s.t[0][1] / t, s.t[1][1] = s.t[1][1] / t, s.t[2][1] = s.t[2][1] / t;
+            }
+            s.t[0][0] = 1.0f;  // n = 0
+        } else if (kind == 2) {
+            {   // n = 2: the complex vector of the pair in rows 1, 2
+                const float p = re[2], q = im[2];
+                if (fabsf(s.t[2][1]) > fabsf(s.t[1][2])) {
+                    s.t[1][1] = q / s.t[2][1];
+                    s.t[1][2] = -(s.t[2][2] - p) / s.t[2][1];
+                } else {
+                    float cr, ci;
+                    eig3_cdiv(0.0f, -s.t[1][2], s.t[1][1] - p, q, cr, ci);
+                    s.t[1][1] = cr, s.t[1][2] = ci;
+                }
+                s.t[2][1] = 0.0f;
+                s.t[2][2] = 1.0f;
+                const float ra = s.t[0][1] * s.t[1][1] + s.t[0][2] * s.t[2][1];
+                const float sa = s.t[0][1] * s.t[1][2] + s.t[0][2] * s.t[2][2];
+                const float w = s.t[0][0] - p;
+                float cr, ci;
+                eig3_cdiv(-ra, -sa, w, q, cr, ci);
+                s.t[0][1] = cr, s.t[0][2] = ci;
+                const float t = eig3_max(fabsf(s.t[0][1]), fabsf(s.t[0][2]));
+                if ((eps * t) * t > 1.0f) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) s.t[k][1] = s.t[k][1] / t, s.t[k][2] = s.t[k][2] / t;
+                }
+            }
+            s.t[0][0] = 1.0f;  // n = 0
+        } else {
+            {   // n = 2: a real vector above the pair in rows 0, 1
+                const float p = re[2];
+                s.t[2][2] = 1.0f;
+                const float lastw = s.t[1][1] - p;
+                const float lastr = s.t[1][2] * s.t[2][2];
+                const float w = s.t[0][0] - p;
+                const float r = s.t[0][2] * s.t[2][2];
+                const float x = s.t[0][1], y = s.t[1][0];
+                const float denom = (re[0] - p) * (re[0] - p) + im[0] * im[0];
+                const float t = (x * lastr - lastw * r) / denom;
+                s.t[0][2] = t;
+                if (fabsf(x) > fabsf(lastw))
+                    s.t[1][2] = (-r - w * t) / x;
+                else
+                    s.t[1][2] = (-lastr - y * t) / lastw;
+                const float t2 = fabsf(s.t[0][2]);
+                if ((eps * t2) * t2 > 1.0f) s.t[0][2] = s.t[0][2] / t2, s.t[1][2] = s.t[1][2] / t2, s.t[2][2] = s.t[2][2] / t2;
+            }
+            {   // n = 1: the complex vector of the pair
+                const float p = re[1], q = im[1];
+                if (fabsf(s.t[1][0]) > fabsf(s.t[0][1])) {
+                    s.t[0][0] = q / s.t[1][0];
+                    s.t[0][1] = -(s.t[1][1] - p) / s.t[1][0];
+                } else {
+                    float cr, ci;
+                    eig3_cdiv(0.0f, -s.t[0][1], s.t[0][0] - p, q, cr, ci);
+                    s.t[0][0] = cr, s.t[0][1] = ci;
+                }
+                s.t[1][0] = 0.0f;
+                s.t[1][1] = 1.0f;
+            }
+        }
+        // back transformation: column j of U * T's leading (j + 1) x (j + 1) part, the products summed from the first
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ev[i][2] = (s.u[i][0] * s.t[0][2] + s.u[i][1] * s.t[1][2]) + s.u[i][2] * s.t[2][2];
+            ev[i][1] = s.u[i][0] * s.t[0][1] + s.u[i][1] * s.t[1][1];
+            ev[i][0] = s.u[i][0] * s.t[0][0];
+        }
+    }
+    // eigenvectors(): columns normalised (abs2 of a complex coefficient = re * re + im * im, summed x0 + (x1 + x2)); .real()
+    const float precision = 2.0f * FLT_EPSILON;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) lam[j] = re[j];
+    bool pair_here[3] = {false, false, false};  // column j starts a pair that eigenvectors() treats as one
+    if (kind == 1) pair_here[0] = !(fabsf(im[0]) <= fabsf(re[0]) * precision);
+    if (kind == 2) pair_here[1] = !(fabsf(im[1]) <= fabsf(re[1]) * precision);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const bool second = j > 0 && pair_here[j - 1];
+        const int a = second ? j - 1 : j;               // column with the real parts
+        const bool two = second || (j < 2 && pair_here[j]);
+        const int b = second ? j : (j < 2 ? j + 1 : j);  // column with the imaginary parts
+        float x[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float rp = a == 0 ? ev[r][0] : (a == 1 ? ev[r][1] : ev[r][2]);
+            const float ip = two ? (b == 1 ? ev[r][1] : ev[r][2]) : 0.0f;
+            x[r] = rp * rp + ip * ip;
+        }
+        const float z = x[0] + (x[1] + x[2]);
+        const float d = sqrtf(z);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float rp = a == 0 ? ev[r][0] : (a == 1 ? ev[r][1] : ev[r][2]);
+            v[r][j] = z > 0.0f ? rp / d : rp;
+        }
+    }
+    return 0;
+}
+// Gaussians::limitCovariance (Gaussians.h:181-201)
+__device__ void limit_covariance_f(float c[3][3]) {
+    float v[3][3], lam[3];
+    if (eigensolver3f(c, v, lam, nullptr) != 0) {  // not a state the reference defines (its solver's members stay uninitialised): keep the diagonal
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            lam[i] = c[i][i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[i][j] = i == j ? 1.0f : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lam[k] = lam[k] < 0.0001f ? 0.0001f : lam[k];  // std::max(eigenValues(k), 0.0001f), :191-194
     // eigenVectors * diagonal_matrix * eigenVectors.inverse() (Gaussians.h:200): the cofactor inverse of V, not its transpose
     float vinv[3][3];
     inverse3_f(v, vinv);
@@ -2493,6 +2935,36 @@ __device__ __forceinline__ float pow_minus_one(int n, const uint32_t* __restrict
 __global__ void k_pow_minus_one(const int32_t* __restrict__ n, int count, const uint32_t* __restrict__ pow_codes, int pow_n, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) out[i] = pow_minus_one(n[i], pow_codes, pow_n);
+}
+// test hook (dmsa_debug_limit_covariance): Gaussians::limitCovariance and its EigenSolver on caller matrices (column-major 3 x 3 each)
+__global__ __launch_bounds__(256) void k_debug_limit_covariance(const float* __restrict__ cov9, int64_t count, float* __restrict__ out9, float* __restrict__ evals3,
+                                                                float* __restrict__ V9, int32_t* __restrict__ iters, int32_t* __restrict__ info) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count) return;
+    float c[3][3], v[3][3], lam[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[r][k] = cov9[9 * g + 3 * k + r];
+    int it = 0;
+    const int st = eigensolver3f(c, v, lam, &it);
+    if (iters) iters[g] = it;
+    if (info) info[g] = st;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (evals3) evals3[3 * g + k] = st == 0 ? lam[k] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            if (V9) V9[9 * g + 3 * k + r] = st == 0 ? v[r][k] : (r == k ? 1.0f : 0.0f);
+    }
+    limit_covariance_f(c);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out9[9 * g + 3 * k + r] = c[r][k];
+}
+void launch_debug_limit_covariance(const float* cov9, int64_t count, float* out9, float* evals3, float* V9, int32_t* iters, int32_t* info, hipStream_t s) {
+    if (count > 0) hipLaunchKernelGGL(k_debug_limit_covariance, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, cov9, count, out9, evals3, V9, iters, info);
 }
 void launch_pow_minus_one(const int32_t* n, int count, const uint32_t* pow_codes, int pow_n, float* out, hipStream_t s) {
     if (count > 0) hipLaunchKernelGGL(k_pow_minus_one, dim3((count + 255) / 256), dim3(256), 0, s, n, count, pow_codes, pow_n, out);

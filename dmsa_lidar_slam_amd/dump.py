@@ -11,12 +11,14 @@ window        'DMSAWN01' | int32 C | int32 n_total | int64 N | int64 S | float32
               float32 xyz_local[4N] | int32 tform_idx[N] | int32 ring_id[N] | float32 xyz_static[4S] | int32 ring_id_static[S]
               (IMU rows are not dumped: use_imu must be 0 for the reference harness)
 poses         'DMSAPO01' | int32 F | int32 pad | float64 rel_orient[3F] | float64 rel_transl[3F]
-stage dump    'DMSAST02' | int32 model (1 window, 2 keyframes) | int32 P | int32 a | int32 M | int32 M_level1 | int32 table_rows | int64 Mm | int64 n |
+stage dump    'DMSAST03' | int32 model (1 window, 2 keyframes) | int32 P | int32 a | int32 M | int32 M_level1 | int32 table_rows | int64 Mm | int64 n |
               float32 table[table_rows x 12] ([R | t] row-major per pose-table row, the start poses as the optimiser sees them) |
               float32 global_xyz[4n] | float32 global_normal[4n] (keyframes only) | int32 seg_offset[M+1] | int32 members[Mm] |
               float32 info_mats[9M] (column-major) | float32 weights[M] |
               float32 fit_mean[3M] | float32 fit_cov[9M] (column-major, before limitCovariance) | float32 weights_raw[M] (pow(-1) of the counts)
-              ('DMSAST01', the layout of round 4, lacks these three arrays) | float64 error_vec[M+a] | float64 jacobian[(M+a) x P] (column-major) |
+              ('DMSAST01', the layout of round 4, lacks these three arrays) |
+              float32 eig_values[3M] | float32 eig_vectors[9M] (eigensolver.eigenvalues().real() / eigenvectors().real() of fit_cov, column-major,
+              Gaussians.h:184-188; 'DMSAST02', the layout of round 5, lacks these two) | float64 error_vec[M+a] | float64 jacobian[(M+a) x P] (column-major) |
               float64 H[P x P] (lambda on the diagonal) | float64 step_raw[P] | float64 step_clamped[P] | float64 error0 | int32 best_k | int32 pad |
               float64 params_after_line_search[P]
               -- iteration 0 of optimizeSet, stage by stage: written by oracle/ref_harness/ref_main.cpp from the REAL reference (a class derived
@@ -86,10 +88,10 @@ def read_poses(path: str):
 
 
 def read_stage_dump(path: str) -> dict:
-    """'DMSAST02' (or round 4's 'DMSAST01'): every intermediate result of iteration 0 of optimizeSet (see the module docstring)."""
+    """'DMSAST03' (or round 5's 'DMSAST02' / round 4's 'DMSAST01'): every intermediate result of iteration 0 of optimizeSet (see the module docstring)."""
     with open(path, "rb") as fh:
         magic = fh.read(8)
-        assert magic in (b"DMSAST01", b"DMSAST02"), path
+        assert magic in (b"DMSAST01", b"DMSAST02", b"DMSAST03"), path
         model, P, a, M, M1, rows = struct.unpack("<6i", fh.read(24))
         Mm, n = struct.unpack("<qq", fh.read(16))
 
@@ -105,10 +107,12 @@ def read_stage_dump(path: str) -> dict:
         d["members"] = arr("<i4", Mm)
         d["info"] = arr("<f4", M, 9)
         d["weights"] = arr("<f4", M)
-        v2 = magic == b"DMSAST02"
+        v2, v3 = magic != b"DMSAST01", magic == b"DMSAST03"
         d["fit_mean"] = arr("<f4", M, 3) if v2 else None
         d["fit_cov"] = arr("<f4", M, 9) if v2 else None
         d["weights_raw"] = arr("<f4", M) if v2 else None
+        d["eig_values"] = arr("<f4", M, 3) if v3 else None
+        d["eig_vectors"] = arr("<f4", M, 9) if v3 else None
         d["error_vec"] = arr("<f8", M + a)
         d["jacobian"] = arr("<f8", P, M + a).T.copy()  # column-major (M+a) x P on disk
         d["H"] = arr("<f8", P, P).T.copy()

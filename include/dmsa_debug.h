@@ -97,8 +97,12 @@ typedef struct dmsa_debug_counters {
 } dmsa_debug_counters;
 int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out);
 /* Test hook: pow(-1) of `count` member counts as the Gaussian fit computes it on the device (Gaussians.h:172: libm's powf(n, -1.0f) through
- * the difference table of the host's libm; counts[] and out[] are host arrays). */
+ * the difference table of the host's libm; counts[] and out[] are host arrays; counts above 2^24 are refused). */
 int dmsa_debug_pow_minus_one(dmsa_ctx* ctx, const int32_t* counts, int32_t count, float* out);
+/* Test hook: Gaussians::limitCovariance (Gaussians.h:181-201) as the fit computes it on the device, on `count` column-major 3 x 3 matrices (host arrays):
+ * out9 = V max(D, 1e-4) V^-1; optionally the EigenSolver<Matrix3f> behind it -- eigenvalues().real() in the order of the Schur form's diagonal,
+ * eigenvectors().real() column-major, Francis QR steps, info (0 Success, 1 NumericalIssue, 2 NoConvergence).  NULL = not wanted. */
+int dmsa_debug_limit_covariance(dmsa_ctx* ctx, const float* cov9, int64_t count, float* out9, float* evals3, float* V9, int32_t* iterations, int32_t* info);
 /* Test hooks of csrc/radix_sort.hip on caller data (host arrays): the stable sort of (u64 key, u32 value) pairs on the key bits
  * [0, end_bit) that wide leaf codes go through, and the inclusive (1) / exclusive (0) prefix scan of an int32 array. */
 int dmsa_sort_pairs64(dmsa_ctx* ctx, const uint64_t* keys, const uint32_t* values, int64_t n, uint32_t end_bit, uint64_t* keys_sorted, uint32_t* values_sorted);

@@ -27,8 +27,9 @@
 //     (scalar_pow_op has no packet path in 3.4.0), i.e. libm's powf(n, -1.0f), which is not correctly rounded (glibc 2.27+: 9857 of the
 //     n < 2^24 differ from 1.0f / n by one ulp); this file calls the libm of the machine it runs on, as the reference does.
 // MatrixXd products (J^T J, up to four threads) accumulate in a stated block order, see blocked_dot.  EigenSolver<Matrix3f> (general
-// QR) is replaced by a fixed-sweep symmetric Jacobi iteration in float; the covariance is rebuilt as V * D * V^-1 with the cofactor
-// inverse like Gaussians.h:200.  Build with -ffp-contract=off.
+// QR, Gaussians.h:184-188) follows Eigen 3.4.0's RealSchur / HessenbergDecomposition / Householder / EigenSolver sources statement by
+// statement (oracle/eigensolver3f.h, round 6); the covariance is rebuilt as V * D * V^-1 with the cofactor inverse like Gaussians.h:200.
+// Build with -ffp-contract=off.
 //
 // sin / cos / acos / atan2 of the pose-table path (axang2rotm, slerp; the float trigonometry of the normals) are NOT glibc's:
 // they are include/dmsa_detmath.h, fixed sequences of correctly rounded IEEE operations (fdlibm's algorithms) shared with the
@@ -39,6 +40,7 @@
 #include "dmsa_oracle.h"
 
 #include "../include/dmsa_detmath.h"
+#include "eigensolver3f.h"
 
 #include <algorithm>
 #include <cmath>
@@ -65,6 +67,11 @@
 //                               statement until round 5) instead of the float order of Eigen 3.4's product kernels
 //   ORC_VAR_WEIGHT_DIV          1.0f / n (correctly rounded; what a compiler that folds pow(x, -1) emits) instead of libm's powf(n, -1.0f)
 //   ORC_VAR_LIMITCOV_VT         limitCovariance rebuilds V * D * V^T (symmetric by construction) instead of V * D * V^-1 (Gaussians.h:200)
+//   ORC_VAR_LIMITCOV_JACOBI     limitCovariance's eigenpairs from a fixed 6-sweep cyclic Jacobi iteration in float (this file's statement until round 6)
+//                               instead of EigenSolver<Matrix3f> as Eigen 3.4.0 evaluates it (oracle/eigensolver3f.h)
+//   ORC_VAR_EIG_BACK_HALVES     the one 3-term sum of that solver (back transformation of the last eigenvector) as x0 + (x1 + x2) instead of (x0 + x1) + x2
+//   ORC_VAR_STEP_LEFT_ASSOC     the LM step as Eigen associates it, ((-alpha H^-1) J^T) e with a P x rows temporary, instead of (-alpha H^-1)(J^T e)
+//   ORC_VAR_LM_BLOCKED_LU       H^-1 from a right-looking LU in 8-column panels (the shape of Eigen's PartialPivLU) instead of Gauss-Jordan on [H | I]
 //   ORC_VAR_JTJ_NOFMA           J^T J, J^T e, e^T e for P > 64 with separately rounded multiply and add (the reference has no FMA)
 //   ORC_VAR_GLIBC_TRIG          sin / cos / acos / atan2 from glibc instead of include/dmsa_detmath.h
 #ifdef ORC_VAR_GLIBC_TRIG
@@ -367,16 +374,22 @@ static void inverse3f(const float m[3][3], float inv[3][3]) {
         for (int c = 0; c < 3; ++c) inv[r][c] = cof(c, r) * invdet;
 }
 
-// Gaussians.h:181-201 limitCovariance.  EigenSolver<Matrix3f> cannot be mirrored bitwise; on a
-// symmetric PSD input it equals a symmetric eigendecomposition up to rounding.  Fixed 6-sweep cyclic Jacobi
-// in float (+,-,*,/,sqrt only, so the HIP kernel reproduces it bit for bit), clamp >= 1e-4, then the reference's own
-// rebuild `eigenVectors * diagonal_matrix * eigenVectors.inverse()` (:200): (V D)(i,k) = V(i,k) * d(k), the fixed-size product with
-// the cofactor inverse of V coefficient by coefficient as a 3-term redux.  V is orthogonal only up to rounding, so the result is
-// NOT exactly symmetric -- like the reference's.  ORC_VAR_LIMITCOV_VT: V * D * V^T (this file's statement until round 5).
-static void limit_covariance(float c[3][3]) {
-    float a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+// Gaussians.h:181-201 limitCovariance: EigenSolver<Matrix3f> as Eigen 3.4.0 evaluates it (oracle/eigensolver3f.h: scaling, one Householder
+// reflector to Hessenberg form, Francis QR steps to the real Schur form, eigenvalues off T's diagonal IN THAT ORDER, back substitution, back
+// transformation, normalised columns, real parts), the clamp >= 1e-4 (:191-194), then the reference's own rebuild
+// `eigenVectors * diagonal_matrix * eigenVectors.inverse()` (:200): (V D)(i,k) = V(i,k) * d(k), the fixed-size product with the cofactor
+// inverse of V coefficient by coefficient as a 3-term redux.  V is orthogonal only up to rounding, so the result is NOT exactly symmetric --
+// like the reference's.  Hypotheses: ORC_VAR_LIMITCOV_JACOBI (this file's statement until round 6: a fixed 6-sweep cyclic Jacobi iteration in
+// float -- same mathematics, other eigenvalue order, other rounding), ORC_VAR_LIMITCOV_VT (V * D * V^T), ORC_VAR_EIG_BACK_HALVES.
+struct LimitCovStats {
+    int64_t calls = 0, qr_iterations = 0, max_iterations = 0, complex_pairs = 0, not_converged = 0;
+};
+static LimitCovStats g_limitcov_stats;  // test telemetry (orc_limitcov_stats); updated under omp critical
+#ifdef ORC_VAR_LIMITCOV_JACOBI
+static void limit_covariance_eig(const float c[3][3], float v[3][3], float lam[3]) {
+    float a[3][3];
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) a[i][j] = c[i][j];
+        for (int j = 0; j < 3; ++j) a[i][j] = c[i][j], v[i][j] = i == j ? 1.0f : 0.0f;
     static const int PQ[3][2] = {{0, 1}, {0, 2}, {1, 2}};
     for (int sweep = 0; sweep < 6; ++sweep) {
         for (int r = 0; r < 3; ++r) {
@@ -406,8 +419,36 @@ static void limit_covariance(float c[3][3]) {
             }
         }
     }
-    float lam[3];
-    for (int k = 0; k < 3; ++k) lam[k] = std::max(a[k][k], 0.0001f);  // Gaussians.h:191-194
+    for (int k = 0; k < 3; ++k) lam[k] = a[k][k];
+}
+#else
+static void limit_covariance_eig(const float c[3][3], float v[3][3], float lam[3]) {
+    eigen34::Matrix3f A;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A(i, j) = c[i][j];
+    eigen34::EigenSolver3f es;
+    eigen34::eigensolver_compute(A, es);
+#pragma omp critical(limitcov_stats)
+    {
+        g_limitcov_stats.calls++, g_limitcov_stats.qr_iterations += es.iterations, g_limitcov_stats.complex_pairs += es.complex_pairs;
+        g_limitcov_stats.max_iterations = std::max<int64_t>(g_limitcov_stats.max_iterations, es.iterations);
+        g_limitcov_stats.not_converged += es.info != 0;
+    }
+    if (es.info != 0) {  // not restated (see eigensolver3f.h): keep the diagonal
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) v[i][j] = i == j ? 1.0f : 0.0f;
+        for (int k = 0; k < 3; ++k) lam[k] = c[k][k];
+        return;
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) v[i][j] = es.V_re(i, j);
+    for (int k = 0; k < 3; ++k) lam[k] = es.eivalues_re[k];
+}
+#endif
+static void limit_covariance(float c[3][3]) {
+    float v[3][3], lam[3];
+    limit_covariance_eig(c, v, lam);
+    for (int k = 0; k < 3; ++k) lam[k] = std::max(lam[k], 0.0001f);  // Gaussians.h:191-194
 #ifdef ORC_VAR_LIMITCOV_VT
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) c[i][j] = sum3((v[i][0] * lam[0]) * v[j][0], (v[i][1] * lam[1]) * v[j][1], (v[i][2] * lam[2]) * v[j][2]);
@@ -1129,6 +1170,7 @@ struct KeyframeModel : PointSet {
 // dense double algebra for the LM step (DmsaOptimizer.h:107-113)
 // ------------------------------------------------------------------------------------------------
 // MatrixXd::inverse() == partial-pivot LU; Gauss-Jordan with partial pivoting on [H | I]
+#ifndef ORC_VAR_LM_BLOCKED_LU
 static bool invert_dense(std::vector<double> A /* col-major PxP */, int P, std::vector<double>& inv) {
     inv.assign((size_t)P * P, 0.0);
     for (int i = 0; i < P; ++i) inv[(size_t)i * P + i] = 1.0;
@@ -1151,6 +1193,86 @@ static bool invert_dense(std::vector<double> A /* col-major PxP */, int P, std::
     }
     return true;
 }
+#else
+// ORC_VAR_LM_BLOCKED_LU: the shape of Eigen 3.4's PartialPivLU behind MatrixXd::inverse() (Eigen/src/LU/PartialPivLU.h: partial_lu_impl::
+// blocked_lu) -- right-looking LU in column panels of blockSize = min(max((size / 8 / 16) * 16, 8), 256) columns (8 for P = 30 .. 255; at most
+// 16 columns are factored unblocked), each panel factored by rank-1 updates with partial pivoting, A12 <- L11^-1 A12 by forward substitution,
+// A22 <- A22 - A21 * A12 with the PRODUCT summed first over the panel's depth and subtracted once (what gebp's `res += alpha * C` does with
+// alpha = -1); then inverse() = U^-1 L^-1 P by two triangular solves on the permuted identity.  The sums inside the solves and the products
+// are sequential in the depth index; Eigen's register blocking is not restated -- this switch measures what the blocked ORDER is worth.
+static bool invert_dense(std::vector<double> A /* col-major PxP */, int P, std::vector<double>& inv) {
+    auto at = [&](std::vector<double>& M, int r, int c) -> double& { return M[(size_t)c * P + r]; };
+    std::vector<int> transp((size_t)P);
+    auto unblocked = [&](int k0, int bs) {  // unblocked_lu on rows k0 .. P-1, columns k0 .. k0+bs-1
+        for (int k = k0; k < k0 + bs; ++k) {
+            int piv = k;
+            double best = std::fabs(at(A, k, k));
+            for (int r = k + 1; r < P; ++r)
+                if (std::fabs(at(A, r, k)) > best) best = std::fabs(at(A, r, k)), piv = r;
+            transp[(size_t)k] = piv;
+            if (best != 0.0) {
+                if (piv != k)
+                    for (int c = k0; c < k0 + bs; ++c) std::swap(at(A, k, c), at(A, piv, c));
+                const double d = at(A, k, k);
+                for (int r = k + 1; r < P; ++r) at(A, r, k) /= d;
+            }
+            for (int c = k + 1; c < k0 + bs; ++c)
+                for (int r = k + 1; r < P; ++r) at(A, r, c) -= at(A, r, k) * at(A, k, c);
+        }
+    };
+    int blockSize = P / 8;
+    blockSize = (blockSize / 16) * 16;
+    blockSize = std::min(std::max(blockSize, 8), 256);
+    if (P <= 16) blockSize = P;
+    for (int k = 0; k < P; k += blockSize) {
+        const int bs = std::min(P - k, blockSize);
+        for (int kk = k; kk < k + bs; kk += 16) unblocked(kk, std::min(16, k + bs - kk));  // (a 16-column inner blocking would recurse the same way; bs <= 16 here for P <= 255)
+        for (int i = k; i < k + bs; ++i) {  // the panel's row swaps on the columns left and right of it
+            const int piv = transp[(size_t)i];
+            if (piv == i) continue;
+            for (int c = 0; c < k; ++c) std::swap(at(A, i, c), at(A, piv, c));
+            for (int c = k + bs; c < P; ++c) std::swap(at(A, i, c), at(A, piv, c));
+        }
+        for (int c = k + bs; c < P; ++c) {  // A12 = L11^-1 A12 (unit lower), then A22 -= A21 * A12
+            for (int i = k; i < k + bs; ++i) {
+                const double b = at(A, i, c);
+                for (int r = i + 1; r < k + bs; ++r) at(A, r, c) -= b * at(A, r, i);
+            }
+            for (int r = k + bs; r < P; ++r) {
+                double C = 0.0;
+                for (int i = k; i < k + bs; ++i) C = at(A, r, i) * at(A, i, c) + C;
+                at(A, r, c) += -1.0 * C;
+            }
+        }
+    }
+    // inverse(): dst = P * I; L (unit lower) solve; U solve
+    inv.assign((size_t)P * P, 0.0);
+    // P * I: the transpositions applied to the identity's rows in order
+    std::vector<double> B((size_t)P * P, 0.0);
+    for (int i = 0; i < P; ++i) B[(size_t)i * P + i] = 1.0;
+    for (int i = 0; i < P; ++i) {
+        const int piv = transp[(size_t)i];
+        if (piv != i)
+            for (int c = 0; c < P; ++c) std::swap(B[(size_t)c * P + i], B[(size_t)c * P + piv]);
+    }
+    for (int c = 0; c < P; ++c) {
+        double* x = &B[(size_t)c * P];
+        for (int i = 0; i < P; ++i) {  // forward, unit diagonal, column-oriented like Eigen's small-panel kernel
+            const double b = x[i];
+            if (b != 0.0)
+                for (int r = i + 1; r < P; ++r) x[r] -= b * at(A, r, i);
+        }
+        for (int i = P - 1; i >= 0; --i) {  // backward
+            x[i] /= at(A, i, i);
+            const double b = x[i];
+            if (b != 0.0)
+                for (int r = 0; r < i; ++r) x[r] -= b * at(A, r, i);
+        }
+    }
+    inv = B;
+    return true;
+}
+#endif
 
 // Summation order of H = J^T J, g = J^T e and e^T e (DmsaOptimizer.h:101-113).  The reference computes them with Eigen's blocked,
 // vectorised (and up to 4-thread) GEMM / GEMV / dot, whose order cannot be known; this restatement fixes one that is easy to state
@@ -1204,11 +1326,37 @@ static void lm_step(const double* e0, const double* J /* col-major rows x P */, 
     invert_dense(H, P, Hinv);
     // :113  step = -alpha * H^-1 * J^T * e   (evaluated as (-alpha*H^-1) * (J^T e))
     step.assign((size_t)P, 0.0);
+#ifdef ORC_VAR_STEP_LEFT_ASSOC
+    // Eigen evaluates the chain left to right: T1 = (-alpha) * H^-1 coefficient-wise (an Inverse has no direct access, the scaled expression is
+    // evaluated into a temporary), T2 = T1 * J^T by the general matrix product (P x P by P x rows: per coefficient one chain over the depth
+    // P < kc, starting from the first product, stored as 0 + 1 * C), step = T2 * e by the column-major matrix-vector kernel: columns in blocks
+    // of 16 (rows * 8 bytes < 32000), per block a chain c = c + T2(i, j) e(j), res(i) = res(i) + 1 * c.
+    {
+        std::vector<double> T1((size_t)P * P), T2((size_t)P * rows);
+        for (size_t k = 0; k < T1.size(); ++k) T1[k] = -alpha * Hinv[k];
+        for (int r = 0; r < rows; ++r)
+            for (int i = 0; i < P; ++i) {
+                double C = 0.0;
+                for (int k = 0; k < P; ++k) C = T1[(size_t)k * P + i] * J[(size_t)k * rows + r] + C;
+                T2[(size_t)r * P + i] = 0.0 + 1.0 * C;
+            }
+        for (int i = 0; i < P; ++i) {
+            double res = 0.0;
+            for (int j0 = 0; j0 < rows; j0 += 16) {
+                double c = 0.0;
+                for (int j = j0; j < std::min(rows, j0 + 16); ++j) c = T2[(size_t)j * P + i] * e0[j] + c;
+                res = c * 1.0 + res;
+            }
+            step[(size_t)i] = res;
+        }
+    }
+#else
     for (int i = 0; i < P; ++i) {
         double s = 0.0;
         for (int j = 0; j < P; ++j) s += (-alpha * Hinv[(size_t)j * P + i]) * g[(size_t)j];
         step[(size_t)i] = s;
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1339,7 +1487,7 @@ struct Optimizer {
         }
         return best;
     }
-    // Iteration 0 of optimizeSet (:62-128) stage by stage, every intermediate result written to `path` in the 'DMSAST02' layout of
+    // Iteration 0 of optimizeSet (:62-128) stage by stage, every intermediate result written to `path` in the 'DMSAST03' layout of
     // dmsa_lidar_slam_amd/dump.py -- the same file oracle/ref_harness/ref_main.cpp writes from the REAL reference, so that a run of the
     // harness elsewhere can be compared with this restatement statement by statement (tests/test_ref_fixtures.py).  inject_info /
     // inject_weights (optional, M x 9 / M floats): the reference's own information matrices and weights replace the fitted ones after
@@ -1388,7 +1536,7 @@ struct Optimizer {
         if (!f) return DMSA_ERR_INVALID;
         const int64_t Mm = (int64_t)currentGauss.members.size(), n = set.numPoints();
         const int32_t hdr[6] = {model, P, a, M, currentGauss.numLevel1, table_rows};
-        std::fwrite("DMSAST02", 1, 8, f), std::fwrite(hdr, 4, 6, f), std::fwrite(&Mm, 8, 1, f), std::fwrite(&n, 8, 1, f);
+        std::fwrite("DMSAST03", 1, 8, f), std::fwrite(hdr, 4, 6, f), std::fwrite(&Mm, 8, 1, f), std::fwrite(&n, 8, 1, f);
         std::fwrite(table, 4, (size_t)table_rows * 12, f);
         std::fwrite(global0.data(), 4, (size_t)n * 4, f);
         if (model == 2) std::fwrite(normal0.data(), 4, (size_t)n * 4, f);
@@ -1396,6 +1544,20 @@ struct Optimizer {
         std::fwrite(currentGauss.info.data(), 4, (size_t)M * 9, f), std::fwrite(currentGauss.weights.data(), 4, (size_t)M, f);
         std::fwrite(currentGauss.fitMean.data(), 4, (size_t)M * 3, f), std::fwrite(currentGauss.fitCov.data(), 4, (size_t)M * 9, f);
         std::fwrite(currentGauss.rawWeights.data(), 4, (size_t)M, f);
+        {   // 'DMSAST03': eigensolver.eigenvalues().real() and eigensolver.eigenvectors().real() (column-major) of every covariance (Gaussians.h:184-188)
+            std::vector<float> eigVal((size_t)M * 3), eigVec((size_t)M * 9);
+            for (int k = 0; k < M; ++k) {
+                float c[3][3], v[3][3], lam[3];
+                for (int cc = 0; cc < 3; ++cc)
+                    for (int r = 0; r < 3; ++r) c[r][cc] = currentGauss.fitCov[(size_t)k * 9 + 3 * cc + r];
+                limit_covariance_eig(c, v, lam);
+                for (int cc = 0; cc < 3; ++cc) {
+                    eigVal[(size_t)k * 3 + cc] = lam[cc];
+                    for (int r = 0; r < 3; ++r) eigVec[(size_t)k * 9 + 3 * cc + r] = v[r][cc];
+                }
+            }
+            std::fwrite(eigVal.data(), 4, eigVal.size(), f), std::fwrite(eigVec.data(), 4, eigVec.size(), f);
+        }
         std::fwrite(errorVec.data(), 8, (size_t)rows, f), std::fwrite(Jacobian.data(), 8, (size_t)rows * P, f);
         std::fwrite(H.data(), 8, (size_t)P * P, f), std::fwrite(stepRaw.data(), 8, (size_t)P, f), std::fwrite(optimStep.data(), 8, (size_t)P, f);
         const int32_t tail[2] = {bestK, 0};
@@ -1619,6 +1781,72 @@ float orc_eigen_gemm_dot_f32(const float* a, const float* b, int64_t n) {
     return Gaussians::gemm_dot_f32((size_t)n, [&](size_t k) { return a[k]; }, [&](size_t k) { return b[k]; });
 }
 int orc_get_threads(void) { return g_threads; }
+
+// EigenSolver<Matrix3f> (oracle/eigensolver3f.h) on `count` matrices (column-major 3 x 3): eigenvalues in T's diagonal order, real parts of the
+// normalised eigenvectors, Francis QR iterations, info (0 Success / 1 NumericalIssue / 2 NoConvergence), complex pairs.  Outputs may be NULL.
+void orc_eigensolver3f(const float* A9, int64_t count, float* evals_re, float* evals_im, float* V9, int32_t* iterations, int32_t* info, int32_t* pairs) {
+    for (int64_t g = 0; g < count; ++g) {
+        eigen34::Matrix3f A;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) A(r, c) = A9[9 * g + 3 * c + r];
+        eigen34::EigenSolver3f es;
+        eigen34::eigensolver_compute(A, es);
+        for (int k = 0; k < 3; ++k) {
+            if (evals_re) evals_re[3 * g + k] = es.eivalues_re[k];
+            if (evals_im) evals_im[3 * g + k] = es.eivalues_im[k];
+        }
+        if (V9)
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) V9[9 * g + 3 * c + r] = es.V_re(r, c);
+        if (iterations) iterations[g] = es.iterations;
+        if (info) info[g] = es.info;
+        if (pairs) pairs[g] = es.complex_pairs;
+    }
+}
+// Gaussians::limitCovariance (Gaussians.h:181-201) on `count` covariances (column-major), in place semantics: out9 = V max(D, 1e-4) V^-1
+void orc_limit_covariance(const float* cov9, int64_t count, float* out9) {
+    for (int64_t g = 0; g < count; ++g) {
+        float c[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k) c[r][k] = cov9[9 * g + 3 * k + r];
+        limit_covariance(c);
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k) out9[9 * g + 3 * k + r] = c[r][k];
+    }
+}
+// covariance -> limitCovariance -> inverse = the information matrix (Gaussians.h:150-154), on `count` column-major covariances
+void orc_info_from_covariance(const float* cov9, int64_t count, float* info9) {
+    for (int64_t g = 0; g < count; ++g) {
+        float c[3][3], inv[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k) c[r][k] = cov9[9 * g + 3 * k + r];
+        limit_covariance(c);
+        inverse3f(c, inv);
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k) info9[9 * g + 3 * k + r] = inv[r][k];
+    }
+}
+// what limitCovariance decomposes with (the EigenSolver restatement, or the hypothesis the library was built with): eigenvalues, eigenvectors (column-major)
+void orc_limitcov_eigenpairs(const float* cov9, int64_t count, float* evals3, float* V9) {
+    for (int64_t g = 0; g < count; ++g) {
+        float c[3][3], v[3][3], lam[3];
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k) c[r][k] = cov9[9 * g + 3 * k + r];
+        limit_covariance_eig(c, v, lam);
+        for (int k = 0; k < 3; ++k) {
+            evals3[3 * g + k] = lam[k];
+            for (int r = 0; r < 3; ++r) V9[9 * g + 3 * k + r] = v[r][k];
+        }
+    }
+}
+// telemetry of limitCovariance since the library was loaded (or since reset != 0): calls, QR iterations (sum, max), complex pairs, not converged
+void orc_limitcov_stats(int64_t* out5, int reset) {
+    if (out5) {
+        out5[0] = g_limitcov_stats.calls, out5[1] = g_limitcov_stats.qr_iterations, out5[2] = g_limitcov_stats.max_iterations;
+        out5[3] = g_limitcov_stats.complex_pairs, out5[4] = g_limitcov_stats.not_converged;
+    }
+    if (reset) g_limitcov_stats = LimitCovStats{};
+}
 
 void orc_axang2rotm(const double* w, double* R9) {
     const M3 R = axang2rotm(w);

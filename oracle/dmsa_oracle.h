@@ -89,6 +89,13 @@ int orc_get_eigen_l1_bytes(void);
 int64_t orc_eigen_gemm_kc(int64_t depth);
 /* one coefficient of a (1 x n) * (n x 1) slice of that product: sum_k a[k] * b[k] in Eigen 3.4's float order */
 float orc_eigen_gemm_dot_f32(const float* a, const float* b, int64_t n);
+/* EigenSolver<Matrix3f> of Eigen 3.4.0 as restated in oracle/eigensolver3f.h (Gaussians.h:184-188), limitCovariance (:181-201), telemetry */
+void orc_eigensolver3f(const float* A9_colmajor, int64_t count, float* evals_re, float* evals_im, float* V9_colmajor, int32_t* iterations, int32_t* info,
+                       int32_t* pairs);
+void orc_limit_covariance(const float* cov9_colmajor, int64_t count, float* out9_colmajor);
+void orc_limitcov_stats(int64_t* out5, int reset);
+void orc_info_from_covariance(const float* cov9_colmajor, int64_t count, float* info9_colmajor);
+void orc_limitcov_eigenpairs(const float* cov9_colmajor, int64_t count, float* evals3, float* V9_colmajor);
 int orc_optimize_window(dmsa_window_problem* p, const dmsa_settings* s, dmsa_report* rep, float* global_out,
                         orc_iter_trace* trace, int32_t trace_capacity, int32_t fixed_iters);
 int orc_optimize_keyframes(dmsa_keyframe_problem* p, const dmsa_settings* s, dmsa_report* rep, float* global_out,
@@ -99,7 +106,7 @@ int orc_window_additional_errors(const dmsa_window_problem* p, double* rows_out)
 int orc_keyframe_additional_errors(const dmsa_keyframe_problem* p, double* rows_out);
 
 /* one numeric-Jacobian + LM step on given residual batches (DmsaOptimizer.h:107-113); for stage parity */
-/* iteration 0 of optimizeSet stage by stage into the 'DMSAST01' file of dmsa_lidar_slam_amd/dump.py (what oracle/ref_harness/ref_main.cpp
+/* iteration 0 of optimizeSet stage by stage into the 'DMSAST03' file of dmsa_lidar_slam_amd/dump.py (what oracle/ref_harness/ref_main.cpp
    writes from the real reference); inject_info / inject_weights (or NULL, with inject_M = the expected number of Gaussians) replace the
    fitted information matrices / weights before the residuals are evaluated */
 int orc_stage_dump_window(dmsa_window_problem* p, const dmsa_settings* s, const float* inject_info, const float* inject_weights, int32_t inject_M, const char* path);

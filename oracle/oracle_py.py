@@ -244,6 +244,64 @@ def eigen_gemm_dot_f32(a, b):
     return np.float32(L.orc_eigen_gemm_dot_f32(a.ctypes.data_as(capi.c_float_p), b.ctypes.data_as(capi.c_float_p), a.size))
 
 
+def eigensolver3f(A):
+    """EigenSolver<Matrix3f> (Eigen 3.4.0, oracle/eigensolver3f.h) on an (n, 3, 3) array of matrices: eigenvalues (re, im) in the order of T's
+    diagonal, real parts of the normalised eigenvectors (n, 3, 3) [row, col], Francis QR iterations, info, complex pairs."""
+    A = np.ascontiguousarray(np.asarray(A, np.float32).reshape(-1, 3, 3))
+    n = A.shape[0]
+    At = np.ascontiguousarray(A.transpose(0, 2, 1))  # column-major per matrix
+    re, im = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    Vt = np.zeros((n, 3, 3), np.float32)
+    it, info, pairs = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    L = lib()
+    L.orc_eigensolver3f.argtypes = [capi.c_float_p, C.c_int64, capi.c_float_p, capi.c_float_p, capi.c_float_p, capi.c_int32_p, capi.c_int32_p, capi.c_int32_p]
+    L.orc_eigensolver3f.restype = None
+    L.orc_eigensolver3f(At.ctypes.data_as(capi.c_float_p), n, re.ctypes.data_as(capi.c_float_p), im.ctypes.data_as(capi.c_float_p),
+                        Vt.ctypes.data_as(capi.c_float_p), it.ctypes.data_as(capi.c_int32_p), info.ctypes.data_as(capi.c_int32_p),
+                        pairs.ctypes.data_as(capi.c_int32_p))
+    return re, im, np.ascontiguousarray(Vt.transpose(0, 2, 1)), it, info, pairs
+
+
+def limit_covariance(cov):
+    """Gaussians::limitCovariance (Gaussians.h:181-201) on an (n, 3, 3) array [row, col]."""
+    A = np.ascontiguousarray(np.asarray(cov, np.float32).reshape(-1, 3, 3))
+    At = np.ascontiguousarray(A.transpose(0, 2, 1))
+    out = np.zeros_like(At)
+    L = lib()
+    L.orc_limit_covariance.argtypes, L.orc_limit_covariance.restype = [capi.c_float_p, C.c_int64, capi.c_float_p], None
+    L.orc_limit_covariance(At.ctypes.data_as(capi.c_float_p), A.shape[0], out.ctypes.data_as(capi.c_float_p))
+    return np.ascontiguousarray(out.transpose(0, 2, 1))
+
+
+def info_from_covariance(cov9):
+    """limitCovariance + inverse (Gaussians.h:150-154) on an (M, 9) array of column-major covariances -> (M, 9) column-major information matrices."""
+    c = np.ascontiguousarray(cov9, np.float32).reshape(-1, 9)
+    out = np.zeros_like(c)
+    L = lib()
+    L.orc_info_from_covariance.argtypes, L.orc_info_from_covariance.restype = [capi.c_float_p, C.c_int64, capi.c_float_p], None
+    L.orc_info_from_covariance(c.ctypes.data_as(capi.c_float_p), c.shape[0], out.ctypes.data_as(capi.c_float_p))
+    return out
+
+
+def limitcov_eigenpairs(cov9):
+    """(eigenvalues M x 3, eigenvectors M x 9 column-major) that limitCovariance decomposes an (M, 9) array of column-major covariances with."""
+    c = np.ascontiguousarray(cov9, np.float32).reshape(-1, 9)
+    ev, V = np.zeros((c.shape[0], 3), np.float32), np.zeros_like(c)
+    L = lib()
+    L.orc_limitcov_eigenpairs.argtypes, L.orc_limitcov_eigenpairs.restype = [capi.c_float_p, C.c_int64, capi.c_float_p, capi.c_float_p], None
+    L.orc_limitcov_eigenpairs(c.ctypes.data_as(capi.c_float_p), c.shape[0], ev.ctypes.data_as(capi.c_float_p), V.ctypes.data_as(capi.c_float_p))
+    return ev, V
+
+
+def limitcov_stats(reset=False):
+    """(calls, QR iterations, max iterations of one call, complex pairs, not converged) of limitCovariance since load / the last reset."""
+    out = (C.c_int64 * 5)()
+    L = lib()
+    L.orc_limitcov_stats.argtypes, L.orc_limitcov_stats.restype = [C.POINTER(C.c_int64), C.c_int], None
+    L.orc_limitcov_stats(out, 1 if reset else 0)
+    return dict(calls=out[0], qr_iterations=out[1], max_iterations=out[2], complex_pairs=out[3], not_converged=out[4])
+
+
 def _run(fn, prob, settings, fixed_iters, want_global, npts):
     cp = prob.to_c()
     cs = settings.to_c()
@@ -378,7 +436,7 @@ def keyframe_additional_errors(prob: MapManagement):
 
 
 def stage_dump(prob, settings: DmsaOptimSettings, path: str, inject_info=None, inject_weights=None):
-    """Iteration 0 of optimizeSet stage by stage into a 'DMSAST01' file (dmsa_lidar_slam_amd/dump.py: read_stage_dump); inject_info (M x 9) /
+    """Iteration 0 of optimizeSet stage by stage into a 'DMSAST03' file (dmsa_lidar_slam_amd/dump.py: read_stage_dump); inject_info (M x 9) /
     inject_weights (M) replace the fitted information matrices / weights before the residuals are evaluated.  `prob` is not modified."""
     q = prob.copy()  # (kept alive: the C struct points into its arrays)
     cp = q.to_c()

@@ -10,7 +10,7 @@
 //
 //   ref_main window    <window.bin> <poses_out.bin> <num_iter>     DmsaOptimizer<PointStampId>::optimizeSet(ContinuousTrajectory&)
 //   ref_main keyframes <map.bin>    <poses_out.bin> <num_iter>     DmsaOptimizer<PointNormal>::optimizeSet(MapManagement&)
-//   ref_main window    <window.bin> <stage_out.bin> stage          iteration 0 of the same call STAGE BY STAGE ('DMSAST02', dump.py): pose table,
+//   ref_main window    <window.bin> <stage_out.bin> stage          iteration 0 of the same call STAGE BY STAGE ('DMSAST03', dump.py): pose table,
 //   ref_main keyframes <map.bin>    <stage_out.bin> stage          global points, member lists, information matrices, weights, errorVec, Jacobian,
 //                                                                  H, raw and clamped step, line-search result -- through StageProbe below, a class
 //                                                                  DERIVED from the reference's DmsaOptimizer (its members and helpers are
@@ -68,7 +68,7 @@ struct StageProbe : public DmsaOptimizer<PointT> {
         // The fit's intermediate results, which Gaussians::addPointSet / updateRebalancingWeights do not keep: the SAME Eigen expressions on
         // the same types as Gaussians.h:146-147 and :172, evaluated here on the member lists the reference just built (identical template
         // instantiations, same flags).  They make the summation orders of the fit checkable bit for bit, independent of EigenSolver.
-        std::vector<float> fitMean, fitCov, rawW;
+        std::vector<float> fitMean, fitCov, rawW, eigVal, eigVec;
         {
             Eigen::MatrixX3f subset;
             for (int k = 0; k < M; ++k) {
@@ -81,6 +81,14 @@ struct StageProbe : public DmsaOptimizer<PointT> {
                 for (int c = 0; c < 3; ++c) fitMean.push_back(mean(c));
                 for (int c = 0; c < 3; ++c)
                     for (int r = 0; r < 3; ++r) fitCov.push_back(cov(r, c));
+                // the first three statements of Gaussians::limitCovariance (Gaussians.h:184-188) on that covariance
+                Eigen::EigenSolver<Eigen::Matrix3f> eigensolver;
+                eigensolver.compute(cov);
+                Eigen::Vector3f eigenValues = eigensolver.eigenvalues().real();
+                Eigen::Matrix3f eigenVectors = eigensolver.eigenvectors().real();
+                for (int c = 0; c < 3; ++c) eigVal.push_back(eigenValues(c));
+                for (int c = 0; c < 3; ++c)
+                    for (int r = 0; r < 3; ++r) eigVec.push_back(eigenVectors(r, c));
             }
             Eigen::VectorXf raw = this->currentGauss.numPointsPerSet.head(M).template cast<float>().array().pow(-1).matrix();  // Gaussians.h:172
             for (int k = 0; k < M; ++k) rawW.push_back(raw(k));
@@ -95,7 +103,7 @@ struct StageProbe : public DmsaOptimizer<PointT> {
         const double maxElem = std::max(step.maxCoeff(), -step.minCoeff());  // :126
         if (maxElem > s.max_step) step = (s.max_step / maxElem) * step;      // :128-129
         const int32_t bestK = this->adaptiveStepSize(set, paramVec, step, error0);  // :131
-        // ---- 'DMSAST02' (dmsa_lidar_slam_amd/dump.py) ----
+        // ---- 'DMSAST03' (dmsa_lidar_slam_amd/dump.py) ----
         const int32_t P = (int32_t)paramVec.size(), rows = (int32_t)errorVec.size(), a = rows - M, table_rows = (int32_t)(tab.size() / 12);
         std::vector<int32_t> seg(1, 0), members;
         std::vector<float> info, weights;
@@ -112,12 +120,13 @@ struct StageProbe : public DmsaOptimizer<PointT> {
         FILE* f = std::fopen(path, "wb");
         if (!f) return 2;
         const int32_t hdr[6] = {model, P, a, M, M1, table_rows};
-        std::fwrite("DMSAST02", 1, 8, f), std::fwrite(hdr, 4, 6, f), std::fwrite(&Mm, 8, 1, f), std::fwrite(&n, 8, 1, f);
+        std::fwrite("DMSAST03", 1, 8, f), std::fwrite(hdr, 4, 6, f), std::fwrite(&Mm, 8, 1, f), std::fwrite(&n, 8, 1, f);
         std::fwrite(tab.data(), 4, tab.size(), f), std::fwrite(gxyz.data(), 4, gxyz.size(), f);
         if (model == 2) std::fwrite(gnrm.data(), 4, gnrm.size(), f);
         std::fwrite(seg.data(), 4, seg.size(), f), std::fwrite(members.data(), 4, members.size(), f);
         std::fwrite(info.data(), 4, info.size(), f), std::fwrite(weights.data(), 4, weights.size(), f);
         std::fwrite(fitMean.data(), 4, fitMean.size(), f), std::fwrite(fitCov.data(), 4, fitCov.size(), f), std::fwrite(rawW.data(), 4, rawW.size(), f);
+        std::fwrite(eigVal.data(), 4, eigVal.size(), f), std::fwrite(eigVec.data(), 4, eigVec.size(), f);
         std::fwrite(errorVec.data(), 8, (size_t)rows, f);
         const Eigen::MatrixXd J = this->Jacobian.topLeftCorner(rows, P);  // column-major, contiguous
         std::fwrite(J.data(), 8, (size_t)rows * P, f);

@@ -6,7 +6,7 @@ The reference cannot be built here, so wherever its arithmetic is not spelled ou
 builds one oracle per switch (make -C oracle hypotheses), runs the same problems through every build for the same number of
 iterations (early exits off) and reports how far the optimised GLOBAL poses move away from the default oracle's.
 
-    python scripts/oracle_sensitivity.py [--iters 5] [--out profiles/r05_oracle_sensitivity.json]
+    python scripts/oracle_sensitivity.py [--iters 5] [--out profiles/r06_oracle_sensitivity.json]
 
 CPU only; about two minutes (the P = 186 keyframe case dominates).  Test infrastructure: nothing here touches the product library.
 """
@@ -27,6 +27,11 @@ HYPOTHESES = {
                     "Eigen 3.4's product kernels (lazy product below 14 members, gebp scalar chains in depth blocks for a 32 KB L1, float division) (Gaussians.h:147)",
     "WEIGHT_DIV": "pow(-1) of the member counts as the correctly rounded 1.0f / n instead of libm's powf(n, -1.0f) (Gaussians.h:172)",
     "LIMITCOV_VT": "limitCovariance rebuilds V*D*V^T instead of V*D*V^-1 with the cofactor inverse (Gaussians.h:200)",
+    "LIMITCOV_JACOBI": "limitCovariance's eigenpairs from a fixed 6-sweep cyclic float Jacobi iteration (the statement of rounds 1-5, 'H5') instead of "
+                       "EigenSolver<Matrix3f> restated from Eigen 3.4.0 (Hessenberg + Francis QR + back substitution, oracle/eigensolver3f.h) (Gaussians.h:184-188)",
+    "EIG_BACK_HALVES": "the one 3-term sum inside that solver (back transformation of the last eigenvector, EigenSolver.h doComputeEigenvectors) as x0+(x1+x2) instead of (x0+x1)+x2",
+    "STEP_LEFT_ASSOC": "the LM step as Eigen associates it, ((-alpha H^-1) J^T) e with a P x rows temporary and the GEMV's 16-column blocks, instead of (-alpha H^-1)(J^T e) (DmsaOptimizer.h:113)",
+    "LM_BLOCKED_LU": "H^-1 from a right-looking partial-pivot LU in 8-column panels + two triangular solves (the shape of Eigen's PartialPivLU::inverse) instead of Gauss-Jordan on [H | I] (DmsaOptimizer.h:113)",
     "EIGEN_L1_48K": "the same product order for a reference machine with a 48 KB L1d: depth blocks of 1016 instead of 680 members (run-time: orc_set_eigen_l1_bytes)",
     "JTJ_NOFMA": "J^T J / J^T e / e^T e at P > 64 with separate multiply and add instead of the fma chain of v_mfma_f64 (DmsaOptimizer.h:107-113)",
     "GLIBC_TRIG": "sin/cos/acos/atan2 from glibc instead of include/dmsa_detmath.h (helpers.h:24-65)",

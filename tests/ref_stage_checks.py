@@ -1,4 +1,4 @@
-"""Stage-by-stage comparison of a 'DMSAST02' dump of the REFERENCE (oracle/ref_harness/ref_main.cpp ... stage) with the oracle's
+"""Stage-by-stage comparison of a 'DMSAST03' dump of the REFERENCE (oracle/ref_harness/ref_main.cpp ... stage) with the oracle's
 restatement.  Every check conditions on the reference's own result of the stage before it, so a failure names ONE statement of the
 oracle -- and the hypothesis switch of oracle/dmsa_oracle.cpp (ORC_VAR_*) that would flip it:
 
@@ -9,8 +9,10 @@ oracle -- and the hypothesis switch of oracle/dmsa_oracle.cpp (ORC_VAR_*) that w
   fit_sums              global points + members         colwise().mean(), covariance     bit-exact                FIT_MEAN_TREE / FIT_FLOAT (mean); FIT_COV_TREE, the L1 size           
                                                         before limitCovariance,                                   behind Eigen's depth blocks (eigen_l1_bytes) for Gaussians above 680
                                                         pow(-1) of the counts                                     members (covariance); WEIGHT_DIV / the machine's libm (powf)
-  info_mats             global points + members         information matrices, weights    1e-4 of the largest      LIMITCOV_VT; EigenSolver vs Jacobi (H5); the weights' mean (VectorXf::mean)
-                                                                                         entry; weights bit-exact
+  eigen_solver          the reference's covariances     eigenvalues().real(),            bit-exact                LIMITCOV_JACOBI (any other eigen-decomposition), EIG_BACK_HALVES, the restatement of
+                                                        eigenvectors().real()                                     Eigen 3.4.0's RealSchur / EigenSolver (oracle/eigensolver3f.h); libgcc's complex division
+  info_mats             the reference's covariances,    information matrices, weights    bit-exact                LIMITCOV_VT (the rebuild V D V^-1), Matrix3f::inverse(); the weights' mean (VectorXf::mean)
+                        members
   residuals             global points, info, weights    errorVec rows < M                bit-exact                SUM3_LEFT, MAHA_ASSOC, the float mean of :247-254
   jacobian              info, weights                   Jacobian                         5e-3 of the largest      the evaluation chain (pose chain, tables, transform) under a
                                                                                          entry (bit-exact with    forward difference; GLIBC_TRIG
@@ -24,14 +26,16 @@ import tempfile
 
 import numpy as np
 
-STAGES = ["table", "global_points", "member_lists", "fit_sums", "info_mats", "residuals", "jacobian", "normal_equations", "line_search"]
+STAGES = ["table", "global_points", "member_lists", "fit_sums", "eigen_solver", "info_mats", "residuals", "jacobian", "normal_equations", "line_search"]
 HINT = {
     "table": "GLIBC_TRIG (sin / cos / acos / atan2), or the slerp / Floater-Hormann / Rodrigues restatement",
     "global_points": "TRANSFORM_PAIRWISE (order of Matrix4f * Vector4f), or centralize()'s float subtraction",
     "member_lists": "PCL octree semantics (box growth, key generation, leaf order), leaf acceptance or the splitSet quirks -- no switch: a restatement bug",
     "fit_sums": "mean: FIT_MEAN_TREE / FIT_FLOAT; covariance: FIT_COV_TREE, or -- if only Gaussians above 680 members differ -- the L1 size behind "
                 "Eigen's depth blocks (orc_set_eigen_l1_bytes / dmsa_debug_options::eigen_l1_bytes = the reference machine's L1d); pow(-1): WEIGHT_DIV, or another libm",
-    "info_mats": "LIMITCOV_VT (V D V^T instead of V D V^-1), EigenSolver vs symmetric Jacobi (stated deviation H5: bounded, not bit-equal); weights: the order of "
+    "eigen_solver": "the restatement of EigenSolver<Matrix3f> (oracle/eigensolver3f.h: scaling, Hessenberg reflector, Francis QR steps, back substitution, back "
+                    "transformation order EIG_BACK_HALVES, normalisation) -- LIMITCOV_JACOBI is what ANY other eigen-decomposition looks like here; pairs: libgcc's __divsc3",
+    "info_mats": "LIMITCOV_VT (V D V^T instead of V D V^-1) or the cofactor order of Matrix3f::inverse() once 'eigen_solver' has pinned the eigenpairs; weights: the order of "
                  "VectorXf::mean() (FIT_MEAN_TREE / FIT_FLOAT) once 'fit_sums' has pinned pow(-1)",
     "residuals": "SUM3_LEFT or MAHA_ASSOC (or the float mean of DmsaOptimizer.h:247-254)",
     "jacobian": "the evaluation chain under a forward difference: relative2global / pose tables (GLIBC_TRIG) / transform",
@@ -123,17 +127,47 @@ class StageChecks:
                                        pow_minus_one_bit_equal=float(np.mean(eq_raw)), counts_where_pow_differs=counts[~eq_raw][:8].tolist())
         assert eq_mean.all() and eq_cov.all() and eq_raw.all(), self.report["fit_sums"]
 
+    @staticmethod
+    def _same_bits(a, b):
+        a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+        return (a.view(np.int32) == b.view(np.int32)) | (np.isnan(a) & np.isnan(b))
+
+    def check_eigen_solver(self):
+        """EigenSolver<Matrix3f> on the REFERENCE's covariances (Gaussians.h:184-188): eigenvalues in the Schur form's order and the real parts of the
+        normalised eigenvectors must be the reference's bits."""
+        ref = self.ref
+        if ref.get("eig_values") is None:
+            raise AssertionError("the dump has no eigenpairs ('DMSAST02' of round 5): write it again with this round's ref_main.cpp")
+        if ref.get("fit_cov") is None:
+            raise AssertionError("the dump has no fit sums ('DMSAST01' of round 4): write it again with this round's ref_main.cpp")
+        ev, V = self.orc.limitcov_eigenpairs(ref["fit_cov"])
+        eq_val = np.all(self._same_bits(ev, ref["eig_values"]), axis=1)
+        eq_vec = np.all(self._same_bits(V, ref["eig_vectors"]), axis=1)
+        # the same eigenvalues in another order (what a symmetric solver would return) is reported apart from different values
+        same_set = np.all(np.sort(ev, 1).view(np.int32) == np.sort(ref["eig_values"], 1).view(np.int32), axis=1)
+        self.report["eigen_solver"] = dict(eigenvalues_bit_equal=float(np.mean(eq_val)), eigenvectors_bit_equal=float(np.mean(eq_vec)),
+                                           eigenvalues_equal_as_a_set=float(np.mean(same_set)),
+                                           max_rel_eigenvalue=float((np.abs(np.sort(ev, 1) - np.sort(ref["eig_values"], 1)).max(1) /
+                                                                     np.maximum(np.abs(ref["eig_values"]).max(1), 1e-30)).max()))
+        assert eq_val.all() and eq_vec.all(), self.report["eigen_solver"]
+
     def check_info_mats(self):
+        """limitCovariance's rebuild and the inverse GIVEN the reference's covariances (the stage before pinned the eigenpairs), and the weights."""
         G, ref = self._gaussians_on_ref_points(), self.ref
         assert G.M == ref["M"], "member lists differ: fix that stage first"
-        scale = np.abs(ref["info"]).max(axis=1, keepdims=True)
-        rel = np.abs(G.info - ref["info"]) / scale
+        if ref.get("fit_cov") is None:
+            raise AssertionError("the dump has no fit sums ('DMSAST01' of round 4): write it again with this round's ref_main.cpp")
+        info = self.orc.info_from_covariance(ref["fit_cov"])
+        eq = np.all(self._same_bits(info, ref["info"]), axis=1)
+        scale = np.maximum(np.abs(ref["info"]).max(axis=1, keepdims=True), 1e-30)
+        with np.errstate(invalid="ignore"):
+            rel = np.nan_to_num(np.abs(info - ref["info"]) / scale, nan=0.0, posinf=0.0)
         wd = _ulp_diff(G.weights, ref["weights"])
-        self.report["info_mats"] = dict(max_rel=float(rel.max()), matrices_bit_equal=float(np.mean(np.all(G.info.view(np.int32) == ref["info"].view(np.int32), axis=1))),
+        self.report["info_mats"] = dict(max_rel=float(rel.max()), matrices_bit_equal=float(np.mean(eq)),
                                         weights_max_ulp=int(wd.max()), weights_bit_equal=float(np.mean(wd == 0)))
-        # the matrices pass through EigenSolver (general QR) on the reference's side and a symmetric Jacobi here: bounded, not bit-equal (H5);
-        # the weights are pow(-1) / mean with both factors restated in Eigen's order: the reference's bits, no tolerance
-        assert rel.max() <= 1e-4 and wd.max() == 0, self.report["info_mats"]
+        # every statement between the covariance and the information matrix is restated from Eigen's sources (EigenSolver, V D V^-1, cofactor inverse):
+        # the reference's bits, no tolerance (round 6; rounds 1-5 allowed 1e-4 for a Jacobi stand-in); the weights likewise
+        assert eq.all() and wd.max() == 0, self.report["info_mats"]
 
     def check_residuals(self):
         G, ref = self._gaussians_on_ref_points(), self.ref

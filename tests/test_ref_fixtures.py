@@ -144,22 +144,24 @@ def test_stage_checks_pass_on_the_oracles_own_dump(orc, name, tmp_path):
 
 
 @pytest.mark.parametrize("variant,fails,passes", [
-    ("TRANSFORM_PAIRWISE", ["global_points"], ["table", "member_lists", "fit_sums", "info_mats", "residuals", "normal_equations"]),
-    ("SUM3_LEFT", ["residuals"], ["table", "global_points", "member_lists", "fit_sums", "normal_equations"]),
-    ("MAHA_ASSOC", ["residuals"], ["table", "global_points", "member_lists", "fit_sums", "info_mats", "normal_equations"]),
-    ("FIT_FLOAT", ["fit_sums", "info_mats"], ["table", "global_points", "member_lists", "residuals", "normal_equations"]),
-    ("FIT_MEAN_TREE", ["fit_sums"], ["table", "global_points", "member_lists", "residuals", "normal_equations"]),
-    ("FIT_COV_TREE", ["fit_sums"], ["table", "global_points", "member_lists", "info_mats", "residuals", "normal_equations"]),
-    ("LIMITCOV_VT", [], ["table", "global_points", "member_lists", "fit_sums", "info_mats", "residuals", "normal_equations"]),
+    ("TRANSFORM_PAIRWISE", ["global_points"], ["table", "member_lists", "fit_sums", "eigen_solver", "info_mats", "residuals", "normal_equations"]),
+    ("SUM3_LEFT", ["residuals"], ["table", "global_points", "member_lists", "fit_sums", "eigen_solver", "normal_equations"]),
+    ("MAHA_ASSOC", ["residuals"], ["table", "global_points", "member_lists", "fit_sums", "eigen_solver", "info_mats", "normal_equations"]),
+    ("FIT_FLOAT", ["fit_sums", "info_mats"], ["table", "global_points", "member_lists", "eigen_solver", "residuals", "normal_equations"]),
+    ("FIT_MEAN_TREE", ["fit_sums"], ["table", "global_points", "member_lists", "eigen_solver", "residuals", "normal_equations"]),
+    ("FIT_COV_TREE", ["fit_sums"], ["table", "global_points", "member_lists", "eigen_solver", "info_mats", "residuals", "normal_equations"]),
+    ("LIMITCOV_VT", ["info_mats"], ["table", "global_points", "member_lists", "fit_sums", "eigen_solver", "residuals", "normal_equations"]),
+    ("LIMITCOV_JACOBI", ["eigen_solver", "info_mats"], ["table", "global_points", "member_lists", "fit_sums", "residuals", "normal_equations"]),
+    ("EIG_BACK_HALVES", ["eigen_solver"], ["table", "global_points", "member_lists", "fit_sums", "residuals", "normal_equations"]),
 ])
 def test_every_float_order_hypothesis_is_decided_by_one_stage(orc, tmp_path, variant, fails, passes):
     """A dump written by the oracle built with ONE alternative reading stands in for "the reference turned out to evaluate it the other
     way": exactly the stage that owns the statement fails (stages condition on the reference's result of the stage before), the stages
     before and the independent ones pass.  The fit's summation orders are decided bit for bit by 'fit_sums' (mean, covariance before
     limitCovariance, pow(-1) of the counts -- computed by the harness with the reference's own Eigen expressions); FIT_FLOAT also fails
-    'info_mats' through the weights (their mean as a scalar chain is ulps away from Eigen's redux order).  LIMITCOV_VT stays inside the bound of
-    the information matrices (the reference's side of that stage goes through EigenSolver anyway) but leaves hardly any matrix bit-equal: the report line
-    tells the two readings apart."""
+    'info_mats' through the weights (their mean as a scalar chain is ulps away from Eigen's redux order).  Round 6: the eigen-decomposition has its
+    own stage ('eigen_solver', on the reference's covariances: LIMITCOV_JACOBI -- any solver that is not Eigen's -- and the order of its one 3-term
+    sum fail there), and 'info_mats' is bit-exact given those covariances, so LIMITCOV_VT now FAILS it instead of hiding inside a 1e-4 bound."""
     name = "window_static"
     ref = _variant_dump(variant, name, str(tmp_path / f"{variant}.bin"))
     s = _one_iteration(name)
@@ -177,6 +179,13 @@ def test_every_float_order_hypothesis_is_decided_by_one_stage(orc, tmp_path, var
         assert chk.report["fit_sums"]["means_bit_equal"] == 1.0 and chk.report["fit_sums"]["covariances_bit_equal"] < 1.0, chk.report["fit_sums"]
     if variant == "LIMITCOV_VT":
         assert chk.report["info_mats"]["matrices_bit_equal"] < 0.5 and chk.report["info_mats"]["weights_bit_equal"] == 1.0, chk.report["info_mats"]
+        assert chk.report["info_mats"]["max_rel"] < 1e-4  # ... which the bound of rounds 1-5 would have let through
+    if variant == "LIMITCOV_JACOBI":
+        r = chk.report["eigen_solver"]
+        assert r["eigenvalues_bit_equal"] < 0.5 and r["max_rel_eigenvalue"] < 1e-4, r  # the same mathematics, other order / other last bits
+    if variant == "EIG_BACK_HALVES":
+        r = chk.report["eigen_solver"]
+        assert r["eigenvalues_bit_equal"] == 1.0 and r["eigenvectors_bit_equal"] < 1.0, r  # only the last eigenvector's back transformation moves
 
 
 def test_a_gaussian_count_where_powf_is_not_the_division_is_decided_by_fit_sums(orc):
