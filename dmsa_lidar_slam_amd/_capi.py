@@ -152,13 +152,13 @@ class StaticSelectResult(C.Structure):
 class DebugOptions(C.Structure):
     """include/dmsa_debug.h: dmsa_debug_options (fill with dmsa_default_debug_options first)."""
     _fields_ = [(n, C.c_int32) for n in ("device_loop", "dual_stream", "serial_streams", "merge_sort", "key_compress", "fused_segments", "sort_prehist",
-                                           "overlap_batch", "serial_tree", "host_threads", "solve_threads", "host_timeline", "trace_time", "fused_leaf_scan", "device_sync", "shared_rotations", "eval_skip", "sync_fault", "speculation_fault", "voxel_coherence", "lm_stream", "stream_priority", "gap_stamps", "lattice_hint", "fit_classes", "eigen_l1_bytes", "small_threshold", "skip_stats")]
+                                           "overlap_batch", "serial_tree", "host_threads", "solve_threads", "host_timeline", "trace_time", "fused_leaf_scan", "device_sync", "shared_rotations", "eval_skip", "sync_fault", "speculation_fault", "voxel_coherence", "lm_stream", "stream_priority", "gap_stamps", "lattice_hint", "fit_classes", "eigen_l1_bytes", "small_threshold", "skip_stats", "small_voxel", "fused_solve")]
 
 
 class DebugCounters(C.Structure):
     """include/dmsa_debug.h: dmsa_debug_counters."""
     _fields_ = [(n, C.c_int64) for n in ("sync_retries", "speculation_retries", "skip_pairs", "skip_pairs_equal", "skip_mismatches", "split_blocks", "split_blocks_skipped", "voxel_codes_compared", "voxel_codes_changed",
-                                           "lattice_hints_held", "lattice_replays", "voxel_lattice_changes")]
+                                           "lattice_hints_held", "lattice_replays", "voxel_lattice_changes", "small_voxel_launches", "small_voxel_fallbacks")]
 
 
 class AosView(C.Structure):
@@ -289,6 +289,7 @@ def load_library() -> C.CDLL:
         "dmsa_serial_fallback_sums": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_uint64)]),
         "dmsa_default_debug_options": (None, [C.POINTER(DebugOptions)]),
         "dmsa_create_ex": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(DebugOptions), C.POINTER(vp)]),
+        "dmsa_create_ex2": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(DebugOptions), C.c_uint32, C.POINTER(vp)]),
         "dmsa_get_debug_counters": (C.c_int, [vp, C.POINTER(DebugCounters)]),
         "dmsa_debug_pow_minus_one": (C.c_int, [vp, c_int32_p, C.c_int32, c_float_p]),
         "dmsa_debug_limit_covariance": (C.c_int, [vp, c_float_p, C.c_int64, c_float_p, c_float_p, c_float_p, c_int32_p, c_int32_p]),
@@ -360,7 +361,7 @@ def load_library() -> C.CDLL:
 
 EXPORTED_SYMBOLS = (
     "dmsa_window_upload_aos dmsa_keyframes_upload_aos dmsa_optimize_window_aos dmsa_optimize_keyframes_aos dmsa_get_global_points_aos dmsa_reserve dmsa_window_ring_push_aos dmsa_window_upload_from_ring_aos "
-    "dmsa_create dmsa_create_ex dmsa_default_debug_options dmsa_get_debug_counters dmsa_debug_pow_minus_one dmsa_debug_limit_covariance dmsa_sort_pairs64 dmsa_scan_i32 dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
+    "dmsa_create dmsa_create_ex dmsa_create_ex2 dmsa_default_debug_options dmsa_get_debug_counters dmsa_debug_pow_minus_one dmsa_debug_limit_covariance dmsa_sort_pairs64 dmsa_scan_i32 dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
     "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
     "dmsa_set_params dmsa_additional_errors dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
     "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_detmath_eval dmsa_lm_solve dmsa_lm_solve_device dmsa_serial_fallback_sums dmsa_sort_pairs dmsa_leaf_segments dmsa_neighbourhood_ranges dmsa_submap_poses dmsa_update_poses_from_submap dmsa_optimize_resident dmsa_get_poses "

@@ -34,6 +34,7 @@ enum SyncSlot : int {
     SYNC_CLASSES = 7,     // k_size_classes -> read-back of the counts
     SYNC_LATTICE = 8,     // k_lattice -> level 1 of the voxelisation on its own stream
     SYNC_LEVEL1 = 9,      // level 1 leaves done -> its member gather on the main stream
+    SYNC_SMALL_L0 = 10,   // small_voxel.hip: level 0's totals -> the workgroup of level 1 (inside one kernel)
     SYNC_SLOTS = 16
 };
 

@@ -346,6 +346,7 @@ int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out) {
     }
     out->voxel_codes_compared = ctx->coh_compared, out->voxel_codes_changed = (int64_t)changed, out->voxel_lattice_changes = ctx->coh_lattice_changes;
     out->lattice_hints_held = ctx->lattice_hints_held, out->lattice_replays = ctx->lattice_replays;
+    out->small_voxel_launches = ctx->small_voxel_launches, out->small_voxel_fallbacks = ctx->small_voxel_fallbacks;
     return DMSA_OK;
 }
 

@@ -282,6 +282,7 @@ struct dmsa_ctx {
     long long* stamp_voxel = nullptr;    // debug switch gap_stamps = 2: where build_gaussians stamps "voxelisation done" / "fit done"
     long long* stamp_fit = nullptr;
     int voxel_calls = 0;                 // voxelisations of the current whole call (debug switch speculation_fault plants a wrong guess in one of them)
+    int small_voxel_launches = 0, small_voxel_fallbacks = 0;  // voxelisations on the one-launch path; voxelisations the small path (small_voxel.hip) handed back to the general path (codes wider than 32 bits)
     int sync_retries = 0, speculation_retries = 0;  // since the context was created: calls re-run with events after a wait timed out; voxelisations re-run after a wrong guess
     DevBuf d_aos_raw, d_aos_idx;         // include/dmsa_aos.h: the caller's strided clouds as they lie in memory, and their per-point indices
     DevBuf d_static_keep;                // the static points as uploaded (a call that has to start over restores them: centralize / decentralize is no exact round trip)
@@ -391,7 +392,7 @@ struct HostTimeline {
 extern HostTimeline g_tl;
 // ---- voxelize_driver.cpp ----
 int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<int()>& overlap = nullptr, bool allow_speculation = true,
-                    bool allow_compression = true);
+                    bool allow_compression = true, bool allow_small = true);
 // ---- optimize_loop.cpp ----
 int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs, hipStream_t stream = nullptr);
 void append_glob(const PoseChain& c, std::vector<double>& out);

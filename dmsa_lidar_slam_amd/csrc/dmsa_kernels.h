@@ -57,6 +57,31 @@ struct GaussCounts {       // both levels, read back once per iteration
     int32_t pad[3];
 };
 
+// ---- K2 for small point sets: both resolutions from the lattice to the member lists in ONE launch (small_voxel.hip) --------------
+struct SmallVoxelArgs {
+    const float4* global;      // transformed points (n)
+    const float4* local;       // local points, .w = pose-table row
+    const int32_t* ring;       // getIdOfPoint per point
+    int n;
+    int min_pts;               // min_num_points_per_set
+    LatticeTable* tables;      // [2], written by k_lattice in front of this launch
+    double res[2];
+    uint32_t* code[2];         // leaf codes per point, unsorted / sorted, and the point indices (dmsa_get_voxel_level reads them)
+    uint32_t* idx[2];
+    uint32_t* code_s[2];
+    uint32_t* idx_s[2];
+    GaussCounts* counts;       // level[l] = leaves, Gaussians, members; pad[l] = 1: level l needs the general path (codes wider than 32 bits)
+    float4* memb_local;
+    int32_t* memb_idx;
+    int32_t* memb_g;
+    int32_t* seg_off;
+    uint32_t* sync;            // dev_sync.h counter: level 0's totals are published
+    uint32_t sync_target;
+    int32_t* timed_out;
+};
+int small_voxel_max_points();
+void launch_voxel_small(const SmallVoxelArgs& a, hipStream_t s);
+
 // ---- K0: rigid transforms -------------------------------------------------------------------------------
 // global[i] = T[row(i)] * local[i]  (Matrix4f*Vector4f order), local.w carries the row index as int bits.
 void launch_transform(const float4* local, const float4* table, float4* global, int64_t n, hipStream_t s);

@@ -5,7 +5,7 @@
 // ---- Gaussians (DmsaOptimizer.h:78-96) ---------------------------------------------------------------------
 // `overlap` (optional) runs on the host after every voxelisation kernel has been enqueued and before the counts are read
 // back: host work placed there hides behind the GPU.
-int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<int()>& overlap, bool allow_speculation, bool allow_compression) {
+int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<int()>& overlap, bool allow_speculation, bool allow_compression, bool allow_small) {
     const int64_t n = ctx->n;
     ctx->gaussians_valid = false;
     ctx->order_valid = false;
@@ -17,13 +17,18 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     if (!lvl_on[0]) ctx->level_res[0] = ctx->level_res[1];
     if (!lvl_on[1]) ctx->level_res[1] = ctx->level_res[0];
     const bool compress = ctx->compress_keys && allow_compression;
+    // The reference's everyday size (5 scans x <= 3000 points + static points): ONE launch from the lattice to the member lists, a workgroup per
+    // resolution (small_voxel.hip).  The kernel takes the tree depths and code widths from the lattice table on the device: nothing to
+    // speculate on, no second stream, no joins.  Codes wider than 32 bits make it give up (counts.pad) and the general path runs.
+    const bool small = allow_small && ctx->dbg.small_voxel != 0 && n <= small_voxel_max_points() && lvl_on[0] && lvl_on[1] &&
+                       !(s.gauss_split != 0 && ctx->model == MODEL_KEYFRAMES) && ctx->dbg.voxel_coherence == 0;
     ctx->voxel_calls += 1;
     if (allow_speculation && ctx->dbg.speculation_fault > 0 && ctx->voxel_calls == ctx->dbg.speculation_fault)  // test hook: a guess one level too shallow
         for (int l = 0; l < 2; ++l) {
             if (ctx->depth_guess[l] > 1) ctx->depth_guess[l] -= 1;
             if (ctx->bits_guess[l] > 3) ctx->bits_guess[l] -= 3;
         }
-    const bool speculate = allow_speculation && ctx->depth_guess[0] >= 0 && ctx->depth_guess[1] >= 0 && ctx->depth_guess[0] < 20 && ctx->depth_guess[1] < 20 &&
+    const bool speculate = small || allow_speculation && ctx->depth_guess[0] >= 0 && ctx->depth_guess[1] >= 0 && ctx->depth_guess[0] < 20 && ctx->depth_guess[1] < 20 &&
                            (!compress || (ctx->bits_guess[0] >= 0 && ctx->bits_guess[1] >= 0));
     // the key kernels count the digits of the sort that follows (own sort, 32-bit codes): no clearing kernel, no histogram pass
     const bool prehist = ctx->prehist;
@@ -37,7 +42,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         ctx->aabb_fresh = false;
         // the lattice kernel clears the headers of the own radix sorts on the side (one dispatch less per sort)
         // device-side stream dependencies (dev_sync.h) instead of events where a kernel of this sequence can carry the signal
-        const bool dev_sync_lattice = ctx->dbg.device_sync != 0 && ctx->dual_stream && lvl_on[0] && lvl_on[1];
+        const bool dev_sync_lattice = !small && ctx->dbg.device_sync != 0 && ctx->dual_stream && lvl_on[0] && lvl_on[1];
         launch_lattice(ctx->d_global.as<float4>(), n, ctx->d_aabb.as<float>(), nb, ctx->level_res[0], ctx->level_res[1], compress,
                        ctx->d_lattice.as<LatticeTable>(), headers_zeroed ? ctx->d_sort_tmp[0].p : nullptr, headers_zeroed ? ctx->d_sort_tmp[1].p : nullptr, ctx->stream,
                        dev_sync_lattice ? ctx->sync_counter(SYNC_LATTICE) : nullptr, ctx->dbg.lattice_hint != 0 && ctx->lattice_hint_valid);
@@ -81,7 +86,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     if (ctx->dbg.trace_time >= 3) std::fprintf(stderr, "[voxelize] key bits (without the marker of non-finite points): level 0 %d, level 1 %d\n", sort_bits[0], sort_bits[1]);
     const int tag_bit = std::max(sort_bits[0], sort_bits[1]) + 1;  // bit `sort_bits` is the marker of non-finite points
     const unsigned end_bit = (unsigned)(tag_bit + 1);
-    const bool k32 = end_bit <= 32;
+    const bool k32 = small || end_bit <= 32;  // (the small path writes 32-bit codes or gives up)
     {
         const size_t ksz = k32 ? 4 : 8;
         for (int l = 0; l < 2; ++l) {
@@ -96,7 +101,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     const bool merged = ctx->merge_sort < 0 ? n <= (int64_t)(1 << 20) : ctx->merge_sort != 0;
     const bool prepared = prehist && k32;
     SortPlan plan[2];  // merged: one sort of 2n pairs in workspace 0, both key kernels count into its header
-    for (int l = 0; l < 2; ++l)
+    for (int l = 0; l < 2 && !small; ++l)
         plan[l] = merged ? sort_pairs_u32_plan(ctx->d_sort_tmp[0].p, (size_t)(2 * n), end_bit)
                          : sort_pairs_u32_plan(ctx->d_sort_tmp[l].p, (size_t)n, (unsigned)(sort_bits[l] + 1));
     auto stage_keys = [&](int l, hipStream_t stream) {  // a disabled level is keyed with the other level's lattice (level_res is aliased) and ignored later
@@ -202,7 +207,27 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
                               ctx->d_slot_cnt[l].as<int32_t>(), counts, l, n, ctx->d_memb_local.as<float4>(), ctx->d_memb_idx.as<int32_t>(),
                               ctx->d_memb_g.as<int32_t>(), ctx->d_seg_off.as<int32_t>(), ctx->d_pslot_of_slot[l].as<int32_t>(), ctx->d_pad_off.as<int32_t>(), gs);
     };
-    {
+    if (small) {
+        ScopedTimer tm(ctx, T_VOXEL);
+        SmallVoxelArgs a{};
+        a.global = ctx->d_global.as<float4>(), a.local = ctx->d_local.as<float4>(), a.ring = ctx->d_ring.as<int32_t>();
+        a.n = (int)n, a.min_pts = s.min_num_points_per_set;
+        a.tables = ctx->d_lattice.as<LatticeTable>();
+        for (int l = 0; l < 2; ++l) {
+            a.res[l] = ctx->level_res[l];
+            a.code[l] = (uint32_t*)ctx->code_v[l], a.idx[l] = ctx->idx_v[l], a.code_s[l] = (uint32_t*)ctx->code_s_v[l], a.idx_s[l] = ctx->idx_s_v[l];
+        }
+        a.counts = counts;
+        a.memb_local = ctx->d_memb_local.as<float4>(), a.memb_idx = ctx->d_memb_idx.as<int32_t>(), a.memb_g = ctx->d_memb_g.as<int32_t>();
+        a.seg_off = ctx->d_seg_off.as<int32_t>();
+        a.sync = ctx->sync_counter(SYNC_SMALL_L0);
+        ctx->sync_sig[SYNC_SMALL_L0] += 1;
+        a.sync_target = ctx->sync_sig[SYNC_SMALL_L0];
+        a.timed_out = ctx->sync_timed_out();
+        launch_voxel_small(a, ctx->stream);
+        ctx->small_voxel_launches += 1;
+        HIPCHK(hipGetLastError());
+    } else {
         ScopedTimer tm(ctx, T_VOXEL);
         const bool dev_sync = two && ctx->dbg.device_sync != 0;
         if (merged) CHK(stage_sort_both());
@@ -324,18 +349,25 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     }
     g_tl.mark("sync#2 wait");
     const GaussCounts h = ctx->h_rb->g;
+    if (small && (h.pad[0] != 0 || h.pad[1] != 0)) {  // codes wider than 32 bits (or a lattice error): the general path sorts them out
+        if (ctx->h_lattice[0].status != 0) return ctx->h_lattice[0].status;
+        if (ctx->h_lattice[1].status != 0) return ctx->h_lattice[1].status;
+        ctx->small_voxel_fallbacks += 1;
+        ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
+        return build_gaussians(ctx, s, nullptr, false, allow_compression, false);
+    }
     for (int l = 0; l < 2; ++l) {
         if (lvl_on[l] && ctx->h_lattice[l].status != 0) return ctx->h_lattice[l].status;
         const int true_bits = compress ? ctx->h_lattice[l].total_bits : 3 * ctx->h_lattice[l].final_depth;
         if (lvl_on[l] && compress && ctx->h_lattice[l].out_of_range) {
             ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
             ctx->speculation_retries += 1;
-            return build_gaussians(ctx, s, nullptr, false, false);  // a key left the predicted range: redo with full-width codes
+            return build_gaussians(ctx, s, nullptr, false, false, allow_small);  // a key left the predicted range: redo with full-width codes
         }
-        if (speculate && lvl_on[l] && (ctx->h_lattice[l].final_depth > sort_depth[l] || true_bits > sort_bits[l])) {
+        if (!small && speculate && lvl_on[l] && (ctx->h_lattice[l].final_depth > sort_depth[l] || true_bits > sort_bits[l])) {
             ctx->depth_guess[0] = ctx->depth_guess[1] = -1;
             ctx->speculation_retries += 1;
-            return build_gaussians(ctx, s, nullptr, false, allow_compression);  // mis-speculated: redo (overlap work already ran)
+            return build_gaussians(ctx, s, nullptr, false, allow_compression, allow_small);  // mis-speculated: redo (overlap work already ran)
         }
         if (lvl_on[l]) (ctx->h_lattice[l].pad3 ? ctx->lattice_hints_held : ctx->lattice_replays) += 1;
 #ifdef DMSA_LATTICE_TIMING

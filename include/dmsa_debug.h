@@ -77,6 +77,13 @@ typedef struct dmsa_debug_options {
                                      the ones that differed after all -> counters skip_pairs_equal / skip_mismatches; k_split_pairs counts the pair
                                      blocks it looked at and skipped -> split_blocks / split_blocks_skipped.  Off by default: atomics on the
                                      path of every iteration (two per wave and evaluation in k_jacobian_columns)                          */
+    /* ---- appended in round 6; from here on the struct is APPEND-ONLY (no field is removed or moved) and dmsa_create_ex2 takes its size ---- */
+    int32_t small_voxel;     /* 1   point sets of at most 32 768 points (the reference's everyday windows: 5 scans x <= 3000 points + static points) are
+                                     voxelised by ONE launch -- a workgroup per resolution keeps its (code, point) pairs in registers from the leaf codes to
+                                     the member lists (csrc/small_voxel.hip) -- instead of ten dependent kernels per level; 0: always the general path.
+                                     Same bits.                                                                                              */
+    int32_t fused_solve;     /* 1   P <= 64: normal-equation block sums, LM step, the nine trial chains and their pose tables in ONE single-workgroup
+                                     kernel (csrc/loop_kernels.hip: k_loop_solve_trials) instead of four; 0: the separate kernels.  Same bits. */
 } dmsa_debug_options;
 
 /* what the switches above leave behind, since the context was created */
@@ -94,6 +101,9 @@ typedef struct dmsa_debug_counters {
     int64_t lattice_replays;      /* ... and pairs that went through the sequential replay                                       */
     int64_t voxel_lattice_changes;/* ... voxelisations (per level) whose lattice (origin, depth, code bits) differed from the previous one's:
                                      every code of that level counts as changed                                                 */
+    /* appended in round 6 (append-only like the options) */
+    int64_t small_voxel_launches; /* small_voxel: voxelisations that went through the one-launch path (csrc/small_voxel.hip) ...        */
+    int64_t small_voxel_fallbacks;/* ... and how many of them it handed back to the general path (leaf codes wider than 32 bits) */
 } dmsa_debug_counters;
 int dmsa_get_debug_counters(dmsa_ctx* ctx, dmsa_debug_counters* out);
 /* Test hook: pow(-1) of `count` member counts as the Gaussian fit computes it on the device (Gaussians.h:172: libm's powf(n, -1.0f) through
@@ -109,8 +119,12 @@ int dmsa_sort_pairs64(dmsa_ctx* ctx, const uint64_t* keys, const uint32_t* value
 int dmsa_scan_i32(dmsa_ctx* ctx, const int32_t* in, int64_t n, int32_t inclusive, int32_t* out);
 
 void dmsa_default_debug_options(dmsa_debug_options* o);
-/* dmsa_create with explicit switches (`options` may be NULL = defaults); DMSA_DEBUG still overrides by name. */
+/* dmsa_create with explicit switches (`options` may be NULL = defaults); DMSA_DEBUG still overrides by name.  `options` must be THIS header's
+ * struct; a caller that may have been built against an older header passes the size of the struct it knows to dmsa_create_ex2. */
 int dmsa_create_ex(int device, uint32_t flags, const dmsa_debug_options* options, dmsa_ctx** out);
+/* The same with the size of the caller's struct in bytes (a multiple of 4, at least 4): only that many leading bytes are read, the fields
+ * behind them keep their defaults; a size larger than the library's struct is refused (DMSA_ERR_INVALID). */
+int dmsa_create_ex2(int device, uint32_t flags, const dmsa_debug_options* options, uint32_t options_bytes, dmsa_ctx** out);
 
 #ifdef __cplusplus
 }
