@@ -309,7 +309,7 @@ void dmsa_default_debug_options(dmsa_debug_options* o) {
     o->device_loop = 1, o->dual_stream = 1, o->serial_streams = 3, o->merge_sort = 0, o->key_compress = 1, o->fused_segments = 1, o->sort_prehist = 0;
     o->overlap_batch = 1, o->serial_tree = 1, o->host_threads = 16, o->solve_threads = 12, o->host_timeline = 0, o->trace_time = 0, o->fused_leaf_scan = 1, o->device_sync = 1, o->shared_rotations = 1;
     o->eval_skip = 1, o->sync_fault = 0, o->speculation_fault = 0, o->voxel_coherence = 0, o->lm_stream = 1, o->stream_priority = 0, o->gap_stamps = 0, o->lattice_hint = 1, o->fit_classes = 7, o->eigen_l1_bytes = 32 * 1024, o->small_threshold = 0, o->skip_stats = 0;
-    o->small_voxel = 1, o->fused_solve = 1;
+    o->small_voxel = 0, o->fused_solve = 1;
 }
 // DMSA_DEBUG="name=value,name=value": the one environment variable of the library (include/dmsa_debug.h)
 static void apply_debug_env(dmsa_debug_options* o) {

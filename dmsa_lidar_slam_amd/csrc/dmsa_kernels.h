@@ -78,6 +78,7 @@ struct SmallVoxelArgs {
     uint32_t* sync;            // dev_sync.h counter: level 0's totals are published
     uint32_t sync_target;
     int32_t* timed_out;
+    long long* stamps;         // debug (gap_stamps = 3), may be null: [2][16] device wall-clock stamps (100 MHz) of the kernel's phases
 };
 int small_voxel_max_points();
 void launch_voxel_small(const SmallVoxelArgs& a, hipStream_t s);

@@ -1038,12 +1038,15 @@ void launch_leaf_starts(const int32_t* head, const int32_t* leaf_of_pos, const v
 // map).  Single-pass chained scan: tiles of 8192 positions are handed out by an atomic ticket, a tile publishes its number of leaf
 // heads and looks back over the earlier tiles.  Nothing is cleared between calls: every published word carries the call's epoch
 // (other epochs read as "not there yet") and the ticket counter runs on, the host passing the value it had when the call started.
-constexpr int kSegThreads = 512, kSegItems = 16, kSegTile = kSegThreads * kSegItems;
-template <typename KeyT>
+constexpr int kSegThreads = 512;
+// positions per thread of a tile: small inputs get small tiles (a window of 25 000 points would be four tiles of 8192 on four compute units)
+static inline int seg_items_for(int64_t n) { return n <= (1 << 16) ? 2 : n <= (1 << 18) ? 4 : 16; }
+template <typename KeyT, int kSegItems>
 __global__ __launch_bounds__(kSegThreads) void k_leaf_segments(const KeyT* __restrict__ code, int64_t n, const LatticeTable* __restrict__ table,
                                                                 int32_t* __restrict__ leaf_incl, int32_t* __restrict__ leaf_start,
                                                                 LevelCounts* __restrict__ counts, unsigned long long* __restrict__ state /* [0]: ticket, [1 + tile] */,
                                                                 uint32_t epoch, uint32_t ticket_base) {
+    constexpr int kSegTile = kSegThreads * kSegItems;
     __shared__ uint32_t s_tile;
     __shared__ int s_wave_total[kSegThreads / 64];
     __shared__ int s_excl;
@@ -1129,15 +1132,32 @@ __global__ __launch_bounds__(kSegThreads) void k_leaf_segments(const KeyT* __res
 void launch_leaf_segments(const void* code_sorted, bool key32, int64_t n, const LatticeTable* table, int32_t* leaf_incl, int32_t* leaf_start, LevelCounts* counts,
                           unsigned long long* state, uint32_t epoch, uint32_t ticket_base, hipStream_t s) {
     if (n <= 0) return;
-    const unsigned tiles = (unsigned)((n + kSegTile - 1) / kSegTile);
-    if (key32)
-        hipLaunchKernelGGL(k_leaf_segments<uint32_t>, dim3(tiles), dim3(kSegThreads), 0, s, (const uint32_t*)code_sorted, n, table, leaf_incl, leaf_start, counts, state,
-                           epoch, ticket_base);
-    else
-        hipLaunchKernelGGL(k_leaf_segments<uint64_t>, dim3(tiles), dim3(kSegThreads), 0, s, (const uint64_t*)code_sorted, n, table, leaf_incl, leaf_start, counts, state,
-                           epoch, ticket_base);
+    const unsigned tiles = (unsigned)leaf_segment_tiles(n);
+#define DMSA_LAUNCH_SEG(KEY, ITEMS)                                                                                                                       \
+    hipLaunchKernelGGL((k_leaf_segments<KEY, ITEMS>), dim3(tiles), dim3(kSegThreads), 0, s, (const KEY*)code_sorted, n, table, leaf_incl, leaf_start, counts, state, \
+                       epoch, ticket_base)
+    const int items = seg_items_for(n);
+    if (key32) {
+        if (items == 2)
+            DMSA_LAUNCH_SEG(uint32_t, 2);
+        else if (items == 4)
+            DMSA_LAUNCH_SEG(uint32_t, 4);
+        else
+            DMSA_LAUNCH_SEG(uint32_t, 16);
+    } else {
+        if (items == 2)
+            DMSA_LAUNCH_SEG(uint64_t, 2);
+        else if (items == 4)
+            DMSA_LAUNCH_SEG(uint64_t, 4);
+        else
+            DMSA_LAUNCH_SEG(uint64_t, 16);
+    }
+#undef DMSA_LAUNCH_SEG
 }
-int leaf_segment_tiles(int64_t n) { return (int)((n + kSegTile - 1) / kSegTile); }
+int leaf_segment_tiles(int64_t n) {
+    const int64_t tile = (int64_t)kSegThreads * seg_items_for(n);
+    return (int)((n + tile - 1) / tile);
+}
 
 // DmsaOptimizer.h:302-307: a leaf becomes a point set iff size >= minNumberPts and max(id) != min(id)
 __global__ __launch_bounds__(256) void k_leaf_accept(const int32_t* __restrict__ leaf_start, const uint32_t* __restrict__ idx_sorted,

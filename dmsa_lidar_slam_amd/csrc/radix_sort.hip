@@ -31,10 +31,15 @@ constexpr int kBins = kSortBins;
 #ifndef DMSA_SORT_LOOKBACK
 #define DMSA_SORT_LOOKBACK 16
 #endif
-constexpr int kSortThreads = DMSA_SORT_THREADS, kSortWaves = kSortThreads / 64, kItems = 16, kTile = kSortThreads * kItems;  // pairs per tile
+constexpr int kSortThreads = DMSA_SORT_THREADS, kSortWaves = kSortThreads / 64;
+// Pairs per thread of a tile.  16 (8192-pair tiles) is tuned for 10^6 pairs; a window of the reference's everyday size (25 000 points) would be
+// FOUR such tiles -- four compute units each ranking 8192 pairs (~8 us of vector issue) while 252 idle.  Small inputs get small tiles: the
+// per-tile work shrinks with the tile, the look-back chain stays a round trip or two (kLook predecessors at once).
+__host__ __device__ constexpr int sort_items_for(size_t n) { return n <= (size_t(1) << 16) ? 2 : n <= (size_t(1) << 18) ? 4 : 16; }
+__host__ __device__ constexpr size_t sort_tile_for(size_t n) { return (size_t)kSortThreads * sort_items_for(n); }
 constexpr int kLook = DMSA_SORT_LOOKBACK;  // predecessors inspected per round trip of the look-back
 static_assert(kSortThreads >= kBins && kSortThreads % 64 == 0, "one thread per digit");
-constexpr int kHistItems = 32;                                                                                   // 8192 keys per histogram workgroup
+__host__ __device__ constexpr int hist_items_for(size_t n) { return n <= (size_t(1) << 16) ? 4 : n <= (size_t(1) << 18) ? 8 : 32; }  // keys per thread of a histogram workgroup (256 threads)
 constexpr int kMaxPasses = kSortMaxPasses;
 constexpr uint32_t kFlagPartial = 1u << 30, kFlagPrefix = 2u << 30, kValMask = (1u << 30) - 1;
 
@@ -43,6 +48,7 @@ __global__ __launch_bounds__(256) void k_sort_zero(SortHeader* h) {
     for (unsigned i = threadIdx.x; i < sizeof(SortHeader) / 4; i += 256) w[i] = 0;
 }
 
+template <int kHistItems>
 __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ keys, size_t n, int passes, uint32_t last_mask, SortHeader* __restrict__ h,
                                                    uint32_t* __restrict__ tile_state, size_t state_words) {
     __shared__ uint32_t s_h[kMaxPasses][kBins];
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
         for (size_t k4 = 0; k4 < m; k4 += 4) {
             uint32_t kk[4];
             if (k4 + 4 <= m && aligned16) {
-                const uint4 v = *reinterpret_cast<const uint4*>(keys + base + k4);  // base is a multiple of 32 keys
+                const uint4 v = *reinterpret_cast<const uint4*>(keys + base + k4);  // base is a multiple of four keys
                 kk[0] = v.x, kk[1] = v.y, kk[2] = v.z, kk[3] = v.w;
             } else {
                 for (int u = 0; u < 4; ++u) kk[u] = k4 + u < m ? keys[base + k4 + u] : 0u;
@@ -117,9 +123,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     return before + incl - v;
 }
 
+template <int kItems>
 __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                             uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int pass, int shift, uint32_t digit_mask,
                                                             SortHeader* __restrict__ h, uint32_t* __restrict__ tile_state /* [tiles][256] of this pass */) {
+    constexpr int kTile = kSortThreads * kItems;
     __shared__ uint32_t s_cnt[kSortWaves][kBins];  // per wave and digit: running count while ranking, then the wave's offset inside the digit
     __shared__ uint32_t s_base[kBins];              // where the digit's run of this tile starts in the output
     __shared__ uint32_t s_excl[kBins];              // where it starts inside the tile
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_pass(const uint32_t* __re
     const uint32_t tile = s_tile;
     const size_t base = (size_t)tile * kTile;
 
-    // ---- load: wave w owns rows [16 w, 16 w + 16) of 64 consecutive pairs; memory order = (row, lane) ----
+    // ---- load: wave w owns rows [kItems w, kItems w + kItems) of 64 consecutive pairs; memory order = (row, lane) ----
     uint32_t key[kItems], val[kItems], rank[kItems];
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
@@ -240,11 +248,13 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace
 
 size_t sort_pairs_u32_workspace_bytes(size_t n) {
-    const size_t tiles = (n + kTile - 1) / kTile;
+    // sized for the smallest tile any n' <= n may choose (a workspace is allocated once for the largest problem and reused for smaller ones)
+    const size_t tiles = (n + (size_t)kSortThreads * 2 - 1) / ((size_t)kSortThreads * 2);
     return align_up(sizeof(SortHeader), 256) + align_up(tiles * kBins * kMaxPasses * 4, 256) + 2 * align_up(n * 4, 256);
 }
 
 SortPlan sort_pairs_u32_plan(void* temp, size_t n, unsigned end_bit) {
+    const size_t kTile = sort_tile_for(n);
     const size_t tiles = (n + kTile - 1) / kTile;
     const int passes = end_bit == 0 ? 1 : (int)((end_bit + 7) / 8);
     char* w = static_cast<char*>(temp);
@@ -266,8 +276,10 @@ hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t
     const SortPlan plan = sort_pairs_u32_plan(temp, n, end_bit);
     const int passes = plan.passes;
     if (passes > kMaxPasses) return hipErrorInvalidValue;
+    const size_t kTile = sort_tile_for(n);
     const size_t tiles = (n + kTile - 1) / kTile;
-    char* w = static_cast<char*>(temp) + align_up(sizeof(SortHeader), 256) + align_up(tiles * kBins * kMaxPasses * 4, 256);
+    const size_t max_tiles = (n + (size_t)kSortThreads * 2 - 1) / ((size_t)kSortThreads * 2);  // (the layout of sort_pairs_u32_workspace_bytes)
+    char* w = static_cast<char*>(temp) + align_up(sizeof(SortHeader), 256) + align_up(max_tiles * kBins * kMaxPasses * 4, 256);
     uint32_t* keys_tmp = reinterpret_cast<uint32_t*>(w);
     w += align_up(n * 4, 256);
     uint32_t* vals_tmp = reinterpret_cast<uint32_t*>(w);
@@ -275,8 +287,14 @@ hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t
     uint32_t* state = plan.tile_state;
     if (prepared < 2) {  // 2: the producer of the keys cleared the header and the look-back words and counted the digits
         if (prepared < 1) hipLaunchKernelGGL(k_sort_zero, dim3(1), dim3(256), 0, stream, h);  // 1: an earlier kernel of the stream cleared the header
-        const unsigned hist_blocks = (unsigned)((n + 256 * kHistItems - 1) / (256 * kHistItems));
-        hipLaunchKernelGGL(k_sort_hist, dim3(hist_blocks), dim3(256), 0, stream, keys_in, n, passes, plan.last_mask, h, state, plan.state_words);
+        const int hi = hist_items_for(n);
+        const unsigned hist_blocks = (unsigned)((n + 256 * (size_t)hi - 1) / (256 * (size_t)hi));
+        if (hi == 4)
+            hipLaunchKernelGGL(k_sort_hist<4>, dim3(hist_blocks), dim3(256), 0, stream, keys_in, n, passes, plan.last_mask, h, state, plan.state_words);
+        else if (hi == 8)
+            hipLaunchKernelGGL(k_sort_hist<8>, dim3(hist_blocks), dim3(256), 0, stream, keys_in, n, passes, plan.last_mask, h, state, plan.state_words);
+        else
+            hipLaunchKernelGGL(k_sort_hist<32>, dim3(hist_blocks), dim3(256), 0, stream, keys_in, n, passes, plan.last_mask, h, state, plan.state_words);
     }
     // ping-pong so that the last pass writes the caller's output arrays
     const uint32_t* kin = keys_in;
@@ -285,8 +303,13 @@ hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t
         const bool to_out = ((passes - 1 - p) & 1) == 0;
         uint32_t* kout = to_out ? keys_out : keys_tmp;
         uint32_t* vout = to_out ? vals_out : vals_tmp;
-        hipLaunchKernelGGL(k_sort_pass, dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, p, 8 * p, p == passes - 1 ? plan.last_mask : 255u, h,
-                           state + (size_t)p * tiles * kBins);
+        const uint32_t dm = p == passes - 1 ? plan.last_mask : 255u;
+        uint32_t* st = state + (size_t)p * tiles * kBins;
+        switch (sort_items_for(n)) {
+            case 2: hipLaunchKernelGGL(k_sort_pass<2>, dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, p, 8 * p, dm, h, st); break;
+            case 4: hipLaunchKernelGGL(k_sort_pass<4>, dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, p, 8 * p, dm, h, st); break;
+            default: hipLaunchKernelGGL(k_sort_pass<16>, dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, p, 8 * p, dm, h, st); break;
+        }
         kin = kout, vin = vout;
     }
     return hipGetLastError();

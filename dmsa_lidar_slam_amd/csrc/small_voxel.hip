@@ -59,25 +59,47 @@ __device__ __forceinline__ uint64_t sv_spread3(uint32_t v) {  // 21 bits -> ever
 
 constexpr int kSvThreads = 1024, kSvWaves = 16;
 
-// LDS behind the exchange buffer (uint32 words)
+// LDS behind the exchange buffer
 struct SvShared {
-    uint32_t cnt[kSvWaves][256];  // per wave: running digit counters, then the wave's offset inside its digit
-    uint32_t base[256];           // first position of every digit
-    int wtot[6][kSvWaves];        // wave totals of the block-wide scans
+    uint32_t cnt[8][kSvThreads];   // per thread: sixteen 16-bit digit counters (two per word), then its sixteen target offsets; [word][thread]: no bank conflicts
+    uint32_t wtot[8][kSvWaves];    // wave totals of the packed counters, then their exclusive prefixes over the waves
+    uint32_t tot[8];               // digit totals (packed)
+    int scan[4][kSvWaves + 1];     // wave totals of the block-wide scans of the leaf stage
     uint32_t edge[4][kSvWaves + 1];
-    int lvl0[2];                  // level 0's totals (Gaussians, members) as level 1 read them
+    int lvl0[2];                   // level 0's totals (Gaussians, members) as level 1 read them
     int fail;
     LatticeTable t;
 };
 
+__device__ __forceinline__ uint32_t sv_scan_add_u(uint32_t v) { return (uint32_t)sv_scan_add((int)v); }
+// inclusive scan inside each row of 16 lanes
+__device__ __forceinline__ uint32_t sv_row_scan_add(uint32_t v) {
+    int x = (int)v;
+    x += sv_dpp<0x111, 0xf>(x);
+    x += sv_dpp<0x112, 0xf>(x);
+    x += sv_dpp<0x114, 0xf>(x);
+    x += sv_dpp<0x118, 0xf>(x);
+    return (uint32_t)x;
+}
+
+// K (odd: the blocked reads of the exchange buffer then hit every bank once) positions per thread; thread t owns the positions t K .. t K + K - 1.
 template <int K>
 __global__ __launch_bounds__(kSvThreads) void k_voxel_small(const SmallVoxelArgs a) {
+    static_assert(K % 2 == 1 && K <= 31, "odd, and the flags of a thread's positions are bits of one word");
+    constexpr int KH = (K + 1) / 2, KQ = (K + 3) / 4;
     extern __shared__ __align__(16) unsigned char sv_smem[];
     uint32_t* s_buf = reinterpret_cast<uint32_t*>(sv_smem);  // [1024 * K]
+    uint16_t* s_buf16 = reinterpret_cast<uint16_t*>(sv_smem);
     SvShared& sh = *reinterpret_cast<SvShared*>(sv_smem + (size_t)kSvThreads * K * 4);
     const int level = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n = a.n;
-    const int wbase = wave * 64 * K;
+    const int n = a.n, ntot = kSvThreads * K;
+    const int p0 = tid * K;
+    int stamp_at = 0;
+    auto stamp = [&]() {
+        if (a.stamps != nullptr && tid == 0) a.stamps[level * 16 + stamp_at] = (long long)wall_clock64();
+        ++stamp_at;
+    };
+    stamp();  // 0: start
     LatticeTable* table = a.tables + level;
     // (selected, not indexed: a dynamic index into the by-value argument struct would copy it to scratch memory)
     uint32_t* const g_code = level == 0 ? a.code[0] : a.code[1];
@@ -89,7 +111,6 @@ __global__ __launch_bounds__(kSvThreads) void k_voxel_small(const SmallVoxelArgs
         const uint32_t* src = reinterpret_cast<const uint32_t*>(table);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&sh.t);
         for (int i = tid; i < words; i += kSvThreads) dst[i] = src[i];
-        for (int q = tid; q < kSvWaves * 256; q += kSvThreads) (&sh.cnt[0][0])[q] = 0u;
         if (tid == 0) sh.fail = 0;
     }
     __syncthreads();
@@ -103,27 +124,70 @@ __global__ __launch_bounds__(kSvThreads) void k_voxel_small(const SmallVoxelArgs
     if (t.status != 0 || end_bit > 32 || total_bits < 0) {
         // codes wider than 32 bits (or a tree deeper than PCL allows): the host runs the general path again
         if (tid == 0) {
-            if (level == 0) a.counts->pad[0] = 1; else a.counts->pad[1] = 1;
+            if (level == 0)
+                a.counts->pad[0] = 1;
+            else
+                a.counts->pad[1] = 1;
             if (level == 0) dev_sync_signal(a.sync);
         }
         return;
     }
-    __syncthreads();
-    const uint32_t invalid = total_bits >= 32 ? 0u : (1u << total_bits);
+    const uint32_t invalid = 1u << total_bits;
     const double res = level == 0 ? a.res[0] : a.res[1];
 
-    // ---- leaf codes (k_voxel_keys) ----
-    // (computed in a rolled loop -- three fp64 divisions per point, and fully unrolled the compiler keeps every point of the lane in flight --
-    // and parked in the exchange buffer; every lane reads back what it wrote itself)
+    // ---- leaf codes (k_voxel_keys), point i = r * 1024 + thread: coalesced loads, codes parked in the exchange buffer ----
     {
         const int nev = t.num_events;
         const int nx = t.nbits[0], ny = t.nbits[1], nz = t.nbits[2];
         const int maxb = max(nx, max(ny, nz));
         const int64_t last_ev = nev > 0 ? t.event_idx[nev - 1] : -1;
+        // Compressed codes interleave the low nbits of the three keys level by level: one table per axis (key bits -> their places in the code),
+        // in the counters' LDS (free until the sort), instead of a loop over the bits per point.
+        uint32_t* sp = &sh.cnt[0][0];
+        const bool tables = t.compressed && maxb <= 10;
+        if (tables) {
+            for (int q = tid; q < 3 * 1024; q += kSvThreads) {
+                const int ax = q >> 10, v = q & 1023;
+                uint32_t out = 0;
+                int cur = 0;
+                for (int l = 0; l < maxb; ++l) {  // places from the least significant end: z, y, x of level l (the code appends x, y, z from the top)
+                    if (l < nz) {
+                        if (ax == 2) out |= ((uint32_t)(v >> l) & 1u) << cur;
+                        ++cur;
+                    }
+                    if (l < ny) {
+                        if (ax == 1) out |= ((uint32_t)(v >> l) & 1u) << cur;
+                        ++cur;
+                    }
+                    if (l < nx) {
+                        if (ax == 0) out |= ((uint32_t)(v >> l) & 1u) << cur;
+                        ++cur;
+                    }
+                }
+                sp[q] = out;
+            }
+        }
+        __syncthreads();
+        // (double)p - min) / resolution, three divisions per point, is most of this stage on ONE compute unit.  q' = d * (1 / res) differs from
+        // the correctly rounded quotient by less than 4e-16 q: wherever q' is further than 1e-9 max(q', 1) from an integer, both truncate to the
+        // same key; the division itself only runs for the (one in 10^8) others.
+        const double rinv = 1.0 / res;
+        auto key_of = [&](float x, double mn, uint32_t mask, uint32_t shiftv) -> uint32_t {
+            const double d = (double)x - mn;
+            const double q = d * rinv;
+            const double f = q - floor(q);
+            const double tol = 1e-9 * fmax(q, 1.0);
+            uint32_t k;
+            if (f > tol && f < 1.0 - tol && q >= 0.0 && q < 4.0e9)
+                k = (uint32_t)q;
+            else
+                k = (uint32_t)(d / res);
+            return (k & mask) + shiftv;
+        };
         bool oor = false;
 #pragma unroll 2
-        for (int j = 0; j < K; ++j) {
-            const int p = wbase + j * 64 + lane;
+        for (int r = 0; r < K; ++r) {
+            const int p = r * kSvThreads + tid;
             uint32_t c = 0xffffffffu;  // padding behind the last point: sorts behind everything
             if (p < n) {
                 const float4 g = a.global[p];
@@ -135,18 +199,22 @@ __global__ __launch_bounds__(kSvThreads) void k_voxel_small(const SmallVoxelArgs
                         while (e < nev && t.event_idx[e] <= p) ++e;
                     }
                     const uint32_t mask = (1u << t.depth[e]) - 1u;
-                    const uint32_t kx = ((uint32_t)(((double)g.x - t.mn[e][0]) / res) & mask) + t.suffix_shift[e][0];
-                    const uint32_t ky = ((uint32_t)(((double)g.y - t.mn[e][1]) / res) & mask) + t.suffix_shift[e][1];
-                    const uint32_t kz = ((uint32_t)(((double)g.z - t.mn[e][2]) / res) & mask) + t.suffix_shift[e][2];
+                    const uint32_t kx = key_of(g.x, t.mn[e][0], mask, t.suffix_shift[e][0]);
+                    const uint32_t ky = key_of(g.y, t.mn[e][1], mask, t.suffix_shift[e][1]);
+                    const uint32_t kz = key_of(g.z, t.mn[e][2], mask, t.suffix_shift[e][2]);
                     if (t.compressed) {
                         if ((kx >> nx) != t.key_base[0] || (ky >> ny) != t.key_base[1] || (kz >> nz) != t.key_base[2]) oor = true;
-                        uint32_t cc = 0;
-                        for (int l = maxb - 1; l >= 0; --l) {
-                            if (l < nx) cc = (cc << 1) | ((kx >> l) & 1u);
-                            if (l < ny) cc = (cc << 1) | ((ky >> l) & 1u);
-                            if (l < nz) cc = (cc << 1) | ((kz >> l) & 1u);
+                        if (tables) {
+                            c = sp[kx & ((1u << nx) - 1u)] | sp[1024 + (ky & ((1u << ny) - 1u))] | sp[2048 + (kz & ((1u << nz) - 1u))];
+                        } else {
+                            uint32_t cc = 0;
+                            for (int l = maxb - 1; l >= 0; --l) {
+                                if (l < nx) cc = (cc << 1) | ((kx >> l) & 1u);
+                                if (l < ny) cc = (cc << 1) | ((ky >> l) & 1u);
+                                if (l < nz) cc = (cc << 1) | ((kz >> l) & 1u);
+                            }
+                            c = cc;
                         }
-                        c = cc;
                     } else {
                         c = (uint32_t)((sv_spread3(kx) << 2) | (sv_spread3(ky) << 1) | sv_spread3(kz));
                     }
@@ -158,230 +226,220 @@ __global__ __launch_bounds__(kSvThreads) void k_voxel_small(const SmallVoxelArgs
         }
         if (oor) table->out_of_range = 1;
     }
-    // From here on the loops over a lane's K positions are ROLLED (the register arrays are indexed through the GPR index register, j is
-    // uniform): unrolled, the scheduler interleaves the positions and a kernel of 1024 threads (128 registers each) spills by the hundred.
-    // Point indices, target positions and start positions are all below 2^15: two per register.
-    uint32_t key[K], idx2[K / 2];
+    __syncthreads();
+    stamp();  // 1: codes
+    // The loops over a thread's K positions are ROLLED (register arrays indexed through the GPR index register, j is uniform): unrolled, the
+    // scheduler interleaves the positions and a kernel of 1024 threads (128 registers each) spills by the hundred.  Point indices and
+    // positions are below 2^15: two per register; ranks inside a (thread, digit) are below 32: four per register.
+    uint32_t key[K], idx2[KH];
 #pragma unroll 1
     for (int j = 0; j < K; ++j) {
-        const int p = wbase + j * 64 + lane;
-        key[j] = s_buf[p];
+        key[j] = s_buf[p0 + j];
         const int h16 = (j & 1) * 16;
-        idx2[j >> 1] = (idx2[j >> 1] & ~(0xffffu << h16)) | ((uint32_t)p << h16);
+        idx2[j >> 1] = (idx2[j >> 1] & ~(0xffffu << h16)) | ((uint32_t)(p0 + j) << h16);
     }
     __syncthreads();
-    uint16_t* s_buf16 = reinterpret_cast<uint16_t*>(s_buf);
 
-    // ---- LSD radix sort of the (code, point) pairs on the code bits [0, end_bit) ----
-    const int passes = (end_bit + 7) >> 3;
-    const uint64_t lanes_below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    // ---- LSD radix sort of the (code, point) pairs on the code bits [0, end_bit), four bits per pass ----
+    // Every thread counts the digits of its own K consecutive positions in sixteen private 16-bit counters (ds_add_rtn returns the rank inside
+    // (thread, digit)); the sixteen counter columns are scanned over the threads (two digits per packed word), the digit bases added, and the
+    // thread's counters become its target offsets.  Thread-major order inside a digit = position order: stable.
+    const int passes = (end_bit + 3) >> 2;
     for (int pass = 0; pass < passes; ++pass) {
-        const int shift = 8 * pass;
-        const uint32_t dmask = pass == passes - 1 ? ((end_bit - shift) >= 8 ? 255u : ((1u << (end_bit - shift)) - 1u)) : 255u;
-        uint32_t* cnt = sh.cnt[wave];
-        uint32_t pk[K / 2];  // rank inside (wave, digit), then the target position
-#pragma unroll 2
+        const int shift = 4 * pass;
+        const uint32_t dmask = pass == passes - 1 ? ((end_bit - shift) >= 4 ? 15u : ((1u << (end_bit - shift)) - 1u)) : 15u;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sh.cnt[w][tid] = 0u;
+        uint32_t rk4[KQ], pk[KH];
+#pragma unroll 4
         for (int j = 0; j < K; ++j) {
             const uint32_t d = (key[j] >> shift) & dmask;
-            uint64_t m = ~0ull;
+            const int h16 = (int)(d & 1u) * 16;
+            const uint32_t old = atomicAdd(&sh.cnt[d >> 1][tid], 1u << h16);
+            const uint32_t r = (old >> h16) & 0xffffu;
+            const int b8 = (j & 3) * 8;
+            rk4[j >> 2] = (rk4[j >> 2] & ~(0xffu << b8)) | (r << b8);
+        }
+        uint32_t c[8], incl[8];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const uint64_t bal = __ballot(bit);
-                m &= bit ? bal : ~bal;
-            }
-            const int rk = __popcll(m & lanes_below);
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t first = 0;
-            if (lane == leader) {
-                first = cnt[d];
-                cnt[d] = first + (uint32_t)__popcll(m);
-            }
-            first = (uint32_t)__shfl((int)first, leader);
-            const uint32_t r = first + (uint32_t)rk;
-            const int h16 = (j & 1) * 16;
-            pk[j >> 1] = (pk[j >> 1] & ~(0xffffu << h16)) | (r << h16);
+        for (int w = 0; w < 8; ++w) {
+            c[w] = sh.cnt[w][tid];
+            incl[w] = sv_scan_add_u(c[w]);
+            if (lane == 63) sh.wtot[w][wave] = incl[w];
         }
         __syncthreads();
-        // offsets: digit-major, wave-minor
-        int tot = 0, incl = 0;
-        if (tid < 256) {
-            uint32_t run = 0;
+        if (tid < 8 * kSvWaves) {  // (word, wave) = (tid / 16, tid % 16): exclusive prefix over the waves inside a row of 16 lanes, total of the word
+            const int w = tid >> 4, wv = tid & 15;
+            const uint32_t v = sh.wtot[w][wv];
+            const uint32_t in = sv_row_scan_add(v);
+            sh.wtot[w][wv] = in - v;
+            if (wv == 15) sh.tot[w] = in;
+        }
+        __syncthreads();
+        {
+            uint32_t run = 0;  // base of the digit: total of all smaller digits
 #pragma unroll
-            for (int w = 0; w < kSvWaves; ++w) {
-                const uint32_t c = sh.cnt[w][tid];
-                sh.cnt[w][tid] = run;
-                run += c;
+            for (int w = 0; w < 8; ++w) {
+                const uint32_t tw = sh.tot[w];
+                const uint32_t lo = run, hi = run + (tw & 0xffffu);
+                run = hi + (tw >> 16);
+                const uint32_t off = (lo | (hi << 16)) + sh.wtot[w][wave] + (incl[w] - c[w]);  // packed: both halves stay below 2^15
+                sh.cnt[w][tid] = off;
             }
-            tot = (int)run;
-            incl = sv_scan_add(tot);
-            if (lane == 63) sh.wtot[0][wave] = incl;
         }
-        __syncthreads();
-        if (tid < 256) {
-            int before = 0;
-            for (int w = 0; w < wave; ++w) before += sh.wtot[0][w];
-            sh.base[tid] = (uint32_t)(before + incl - tot);
-        }
-        __syncthreads();
-#pragma unroll 2
+#pragma unroll 4
         for (int j = 0; j < K; ++j) {
             const uint32_t d = (key[j] >> shift) & dmask;
-            const int h16 = (j & 1) * 16;
-            const uint32_t r = (pk[j >> 1] >> h16) & 0xffffu;
-            const uint32_t pos = sh.base[d] + cnt[d] + r;
+            const uint32_t off = (sh.cnt[d >> 1][tid] >> ((d & 1u) * 16)) & 0xffffu;
+            const uint32_t pos = off + ((rk4[j >> 2] >> ((j & 3) * 8)) & 0xffu);
             s_buf[pos] = key[j];
+            const int h16 = (j & 1) * 16;
             pk[j >> 1] = (pk[j >> 1] & ~(0xffffu << h16)) | (pos << h16);
         }
         __syncthreads();
+        if (pass == 0) stamp();  // 2: first pass up to the scatter of the codes
 #pragma unroll 4
-        for (int j = 0; j < K; ++j) key[j] = s_buf[wbase + j * 64 + lane];
-        for (int q = tid; q < kSvWaves * 256; q += kSvThreads) (&sh.cnt[0][0])[q] = 0u;  // for the next pass
+        for (int j = 0; j < K; ++j) key[j] = s_buf[p0 + j];
+        if (pass == passes - 1)
+            for (int i = tid; i < n; i += kSvThreads) g_code_s[i] = s_buf[i];
         __syncthreads();
-#pragma unroll 2
+#pragma unroll 4
         for (int j = 0; j < K; ++j) {
             const int h16 = (j & 1) * 16;
             s_buf16[(pk[j >> 1] >> h16) & 0xffffu] = (uint16_t)(idx2[j >> 1] >> h16);
         }
         __syncthreads();
-#pragma unroll 2
-        for (int j = 0; j < K; j += 2)
-            idx2[j >> 1] = (uint32_t)s_buf16[wbase + j * 64 + lane] | ((uint32_t)s_buf16[wbase + (j + 1) * 64 + lane] << 16);
-        __syncthreads();
-    }
-    auto idx_of = [&](int j) -> uint32_t { return (idx2[j >> 1] >> ((j & 1) * 16)) & 0xffffu; };
-#pragma unroll 2
-    for (int j = 0; j < K; ++j) {
-        const int p = wbase + j * 64 + lane;
-        if (p < n) g_code_s[p] = key[j], g_idx_s[p] = idx_of(j);
-    }
-
-    // ---- leaves: head flags from the codes ----
-    uint32_t validm = 0, headm = 0, diffm = 0, tailm = 0;  // bit j: flag of position (j, lane)
-    if (lane == 63) sh.edge[0][wave + 1] = key[K - 1];
-    {   // the last position's ring id goes to the next wave as well
-        const bool v = key[K - 1] < invalid;
-        const int idl = v ? a.ring[idx_of(K - 1)] : 0;
-        if (lane == 63) sh.edge[1][wave + 1] = (uint32_t)idl;
+#pragma unroll 1
+        for (int j = 0; j < K; ++j) {
+            const int h16 = (j & 1) * 16;
+            idx2[j >> 1] = (idx2[j >> 1] & ~(0xffffu << h16)) | ((uint32_t)s_buf16[p0 + j] << h16);
+        }
+        if (pass == passes - 1)
+            for (int i = tid; i < n; i += kSvThreads) g_idx_s[i] = (uint32_t)s_buf16[i];
+        if (pass == 0) stamp();  // 3: first pass done
     }
     __syncthreads();
-    int heads = 0;
+    stamp();  // 4: sorted
+    auto idx_of = [&](int j) -> uint32_t { return (idx2[j >> 1] >> ((j & 1) * 16)) & 0xffffu; };
+
+    // ---- leaves.  A thread walks its K consecutive positions; what it needs from the threads in front comes from block-wide scans. ----
+    uint32_t validm = 0, headm = 0, diffm = 0, tailm = 0;  // bit j: flag of position p0 + j
     {
-        uint32_t carry = wave > 0 ? sh.edge[0][wave] : 0u;  // code of the position in front of (j, lane 0)
-#pragma unroll 2
-        for (int j = 0; j < K; ++j) {
-            const int p = wbase + j * 64 + lane;
-            const uint32_t kj = key[j];
-            uint32_t pkey = (uint32_t)__shfl_up((int)kj, 1);
-            if (lane == 0) pkey = carry;
-            carry = (uint32_t)__builtin_amdgcn_readlane((int)kj, 63);
-            const bool v = kj < invalid;
-            const bool h = v && (p == 0 || pkey != kj);
-            validm |= v ? (1u << j) : 0u;
-            headm |= h ? (1u << j) : 0u;
-            heads += __popcll(__ballot(h));
-        }
-    }
-    // ---- "differs from the position before" from the ring ids, four positions of the lane in flight ----
-    {
-        int carry = wave > 0 ? (int)sh.edge[1][wave] : 0;  // id of the position in front of (j, lane 0)
+        const uint32_t lastk = key[K - 1];
+        const bool lastv = lastk < invalid;
+        const int lastid = lastv ? a.ring[idx_of(K - 1)] : 0;
+        uint32_t pkey = (uint32_t)__shfl_up((int)lastk, 1);
+        int pid = __shfl_up(lastid, 1);
+        if (lane == 63) sh.edge[0][wave + 1] = lastk, sh.edge[1][wave + 1] = (uint32_t)lastid;
+        __syncthreads();
+        if (lane == 0 && wave > 0) pkey = sh.edge[0][wave], pid = (int)sh.edge[1][wave];
+        // (thread 0's position 0 is a head whatever pkey holds)
 #pragma unroll 1
         for (int j0 = 0; j0 < K; j0 += 4) {
             int idc[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) idc[u] = ((validm >> (j0 + u)) & 1u) ? a.ring[idx_of(j0 + u)] : 0;
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                idc[u] = (j < K && key[j < K ? j : 0] < invalid) ? a.ring[idx_of(j < K ? j : 0)] : 0;
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int j = j0 + u;
-                int pid = __shfl_up(idc[u], 1);
-                if (lane == 0) pid = carry;
-                carry = __builtin_amdgcn_readlane(idc[u], 63);
-                const bool v = (validm >> j) & 1u, h = (headm >> j) & 1u;
-                diffm |= (v && !h && pid != idc[u]) ? (1u << j) : 0u;
+                if (j < K) {
+                    const uint32_t kj = key[j];
+                    const bool v = kj < invalid;
+                    const bool h = v && ((p0 + j) == 0 || pkey != kj);
+                    validm |= v ? (1u << j) : 0u;
+                    headm |= h ? (1u << j) : 0u;
+                    diffm |= (v && !h && pid != idc[u]) ? (1u << j) : 0u;
+                    pkey = kj, pid = idc[u];
+                }
             }
         }
     }
-    // ---- start position of the leaf of every position: inclusive max-scan of (head ? position : 0); kept 16 bits wide ----
-    uint32_t st2[K / 2];
+    stamp();  // 5: head flags, ring ids
+    // carry-in 1: start position of the leaf that holds the position in front of the thread's first (exclusive max-scan of the threads' last heads)
+    int carry_start;
     {
-        int run = 0;
-#pragma unroll 2
-        for (int j = 0; j < K; ++j) {
-            const int p = wbase + j * 64 + lane;
-            const int sc = sv_scan_max(((headm >> j) & 1u) ? p : 0);
-            const uint32_t stj = (uint32_t)max(run, sc);
-            run = max(run, __builtin_amdgcn_readlane(sc, 63));
-            const int h16 = (j & 1) * 16;
-            st2[j >> 1] = (st2[j >> 1] & ~(0xffffu << h16)) | (stj << h16);
-        }
-        if (lane == 0) sh.wtot[1][wave] = run, sh.wtot[2][wave] = heads;
-        if (lane == 0) sh.edge[2][wave] = headm & 1u, sh.edge[3][wave] = validm & 1u;  // first position of the wave: head? valid?
-        if (tid == 0) sh.edge[2][kSvWaves] = 1u, sh.edge[3][kSvWaves] = 0u;           // behind the last position: nothing
-    }
-    __syncthreads();
-    int num_leaves = 0, before_start = 0;
-    for (int w = 0; w < kSvWaves; ++w) {
-        if (w < wave) before_start = max(before_start, sh.wtot[1][w]);
-        num_leaves += sh.wtot[2][w];
-    }
-    // (a leaf that began in an earlier wave: the wave's own scan says 0 until its first head)
-    auto start_of = [&](int j) -> int { return max((int)((st2[j >> 1] >> ((j & 1) * 16)) & 0xffffu), before_start); };
-
-    // "ids differ inside the leaf so far": inclusive max-scan of (start << 1 | differs from the position before).  Only the low bit is kept
-    // (mixm): the part of the leaf that lies in earlier waves is added from the waves' carries below.  Tails: the position behind is a head or
-    // no valid position at all.
-    uint32_t mixm = 0;
-    {
-        int run = 0;
-        const uint32_t head0 = (uint32_t)__builtin_amdgcn_readlane((int)headm, 0), valid0 = (uint32_t)__builtin_amdgcn_readlane((int)validm, 0);
-        const uint32_t next_h = sh.edge[2][wave + 1], next_v = sh.edge[3][wave + 1];
-#pragma unroll 2
-        for (int j = 0; j < K; ++j) {
-            const bool v = (validm >> j) & 1u;
-            const int sc = sv_scan_max(v ? ((start_of(j) << 1) | (int)((diffm >> j) & 1u)) : 0);
-            const int mx = max(run, sc);  // (mx >> 1) == start for every valid position: its own entry takes part
-            mixm |= (mx & 1) ? (1u << j) : 0u;
-            run = max(run, __builtin_amdgcn_readlane(sc, 63));
-            uint32_t nh = (uint32_t)__shfl_down((int)((headm >> j) & 1u), 1), nv = (uint32_t)__shfl_down((int)((validm >> j) & 1u), 1);
-            if (lane == 63) {
-                nh = j + 1 < K ? ((head0 >> (j + 1)) & 1u) : next_h;
-                nv = j + 1 < K ? ((valid0 >> (j + 1)) & 1u) : next_v;
-            }
-            tailm |= (v && (nh != 0u || nv == 0u)) ? (1u << j) : 0u;
-        }
-        if (lane == 0) sh.wtot[3][wave] = run;
-    }
-    __syncthreads();
-    // acceptance at the leaf's last position (DmsaOptimizer.h:302-307)
-    uint32_t accm = 0;
-    {
+        const int last_head = headm != 0u ? p0 + (31 - __builtin_clz(headm)) : 0;
+        const int in = sv_scan_max(last_head);
+        if (lane == 63) sh.scan[0][wave + 1] = in;
+        const int heads_w = sv_scan_add(__popc(headm));
+        if (lane == 63) sh.scan[1][wave] = heads_w;
+        // the position behind the thread's last: a head, or not a valid position?
+        if (lane == 0) sh.edge[2][wave] = headm & 1u, sh.edge[3][wave] = validm & 1u;
+        if (tid == 0) sh.edge[2][kSvWaves] = 1u, sh.edge[3][kSvWaves] = 0u, sh.scan[0][0] = 0;
+        __syncthreads();
         int before = 0;
-        for (int w = 0; w < wave; ++w) before = max(before, sh.wtot[3][w]);
-        int run = 0;
-#pragma unroll 2
-        for (int j = 0; j < K; ++j) {
-            const int p = wbase + j * 64 + lane;
-            const bool tl = (tailm >> j) & 1u;
-            const int stj = start_of(j);
-            const int size = p - stj + 1;
-            const bool mixed = ((mixm >> j) & 1u) != 0u || ((before >> 1) == stj && (before & 1) != 0);
-            const bool acc = tl && size >= a.min_pts && mixed;
-            accm |= acc ? (1u << j) : 0u;
-            const int v = acc ? (1 | (size << 15)) : 0;  // accepted leaves in bits 0 .. 14 (<= n / 2), their members above
-            run += __builtin_amdgcn_readlane(sv_scan_add(v), 63);
-        }
-        if (lane == 0) sh.wtot[4][wave] = run;
+        for (int w = 0; w <= wave; ++w) before = max(before, sh.scan[0][w]);
+        int ex = __shfl_up(in, 1);
+        if (lane == 0) ex = 0;
+        carry_start = max(before, ex);
     }
-    __syncthreads();
-    int gbase = 0, mbase = 0, num_gauss, num_memb, before_acc = 0;
+    int num_leaves = 0;
+    for (int w = 0; w < kSvWaves; ++w) num_leaves += sh.scan[1][w];
+    // tails: the position behind is a head or no valid position at all
     {
-        int total = 0;
-        for (int w = 0; w < kSvWaves; ++w) {
-            if (w < wave) before_acc += sh.wtot[4][w];
-            total += sh.wtot[4][w];
+        uint32_t nh = (uint32_t)__shfl_down((int)(headm & 1u), 1), nv = (uint32_t)__shfl_down((int)(validm & 1u), 1);
+        if (lane == 63) nh = sh.edge[2][wave + 1], nv = sh.edge[3][wave + 1];
+        const uint32_t next_head = (headm >> 1) | (nh << (K - 1)), next_valid = (validm >> 1) | (nv << (K - 1));
+        tailm = validm & (next_head | ~next_valid) & ((K == 32) ? 0xffffffffu : ((1u << K) - 1u));
+    }
+    // carry-in 2: have the ids of that leaf differed so far?  Every thread offers (start of its last position's leaf << 1 | ids differed in the part
+    // of that leaf it holds); the exclusive max-scan ORs the bits of the threads that share the leaf.
+    int carry_mixed;
+    {
+        int cur = carry_start;
+        uint32_t dif = 0;
+#pragma unroll 1
+        for (int j = 0; j < K; ++j) {
+            if ((headm >> j) & 1u) cur = p0 + j, dif = 0;
+            dif |= (diffm >> j) & 1u;
         }
+        const int val = (validm & 1u) ? ((cur << 1) | (int)dif) : 0;  // (threads behind the last valid position offer nothing)
+        const int in = sv_scan_max(val);
+        if (lane == 63) sh.scan[2][wave + 1] = in;
+        if (tid == 0) sh.scan[2][0] = 0;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w <= wave; ++w) before = max(before, sh.scan[2][w]);
+        int ex = __shfl_up(in, 1);
+        if (lane == 0) ex = 0;
+        const int c = max(before, ex);
+        carry_mixed = ((c >> 1) == carry_start) ? (c & 1) : 0;
+    }
+    stamp();  // 6: carries
+    // acceptance at the leaf's last position (DmsaOptimizer.h:302-307): the thread's accepted leaves and their members, packed
+    uint32_t accm = 0;
+    int mine = 0;
+    {
+        int cur = carry_start;
+        int dif = carry_mixed;
+#pragma unroll 1
+        for (int j = 0; j < K; ++j) {
+            if ((headm >> j) & 1u) cur = p0 + j, dif = 0;
+            dif |= (int)((diffm >> j) & 1u);
+            if ((tailm >> j) & 1u) {
+                const int size = p0 + j - cur + 1;
+                if (size >= a.min_pts && dif != 0) accm |= 1u << j, mine += 1 | (size << 15);  // accepted leaves in bits 0 .. 14 (<= n / 2), members above
+            }
+        }
+    }
+    int before_acc, num_gauss, num_memb;
+    {
+        const int in = sv_scan_add(mine);
+        if (lane == 63) sh.scan[3][wave] = in;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < kSvWaves; ++w) {
+            if (w < wave) before += sh.scan[3][w];
+            total += sh.scan[3][w];
+        }
+        before_acc = before + in - mine;
         num_gauss = total & 0x7fff, num_memb = total >> 15;
     }
+    stamp();  // 7: acceptance
+    int gbase = 0, mbase = 0;
     if (level == 0) {
         if (tid == 0) {
             a.counts->level[0].num_leaves = num_leaves, a.counts->level[0].num_gauss = num_gauss, a.counts->level[0].num_memb = num_memb;
@@ -396,20 +454,19 @@ __global__ __launch_bounds__(kSvThreads) void k_voxel_small(const SmallVoxelArgs
             sh.fail = __hip_atomic_load(&a.counts->pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    // Gaussian index and member offset of every accepted leaf (exclusive sum-scan over the positions), left at the leaf's start position in
-    // the exchange buffer for all its positions: accepted | Gaussian (15 bits) | member offset (16 bits)
+    stamp();  // 8: level 0 published / level 1 has waited
+    // Gaussian index and member offset of every accepted leaf, left at the leaf's start position in the exchange buffer for the threads that hold
+    // its other positions: accepted | Gaussian (15 bits) | member offset (16 bits)
     {
-        int run = before_acc;
-#pragma unroll 2
+        int cur = carry_start, run = before_acc;
+#pragma unroll 1
         for (int j = 0; j < K; ++j) {
-            const int p = wbase + j * 64 + lane;
-            const bool acc = (accm >> j) & 1u;
-            const int stj = start_of(j);
-            const int v = acc ? (1 | ((p - stj + 1) << 15)) : 0;
-            const int sc = sv_scan_add(v);
-            const int ex = run + sc - v;
-            run += __builtin_amdgcn_readlane(sc, 63);
-            if ((tailm >> j) & 1u) s_buf[stj] = acc ? (0x80000000u | ((uint32_t)(ex & 0x7fff) << 16) | (uint32_t)(ex >> 15)) : 0u;
+            if ((headm >> j) & 1u) cur = p0 + j;
+            if ((tailm >> j) & 1u) {
+                const bool acc = (accm >> j) & 1u;
+                s_buf[cur] = acc ? (0x80000000u | ((uint32_t)(run & 0x7fff) << 16) | (uint32_t)(run >> 15)) : 0u;
+                if (acc) run += 1 | ((p0 + j - cur + 1) << 15);
+            }
         }
     }
     __syncthreads();
@@ -417,28 +474,28 @@ __global__ __launch_bounds__(kSvThreads) void k_voxel_small(const SmallVoxelArgs
         if (sh.fail != 0) return;  // level 0 gave up: the host repeats the voxelisation on the general path
         gbase = sh.lvl0[0], mbase = sh.lvl0[1];
     }
-    // ---- member lists (k_gather_members), four positions per lane in flight (named variables: a small array indexed in an inner loop
-    // ends up in scratch memory here) ----
-    auto member_info = [&](int j) -> uint32_t { return ((validm >> j) & 1u) ? s_buf[start_of(j)] : 0u; };
-    auto member_load = [&](int j, uint32_t info) -> float4 { return (info >> 31) ? a.local[idx_of(j)] : make_float4(0.f, 0.f, 0.f, 0.f); };
-    auto member_store = [&](int j, uint32_t info, const float4 loc) {
-        if (info >> 31) {
-            const int p = wbase + j * 64 + lane;
-            const int g = gbase + (int)((info >> 16) & 0x7fffu);
-            const int rank = p - start_of(j);
-            const int dst = mbase + (int)(info & 0xffffu) + rank;
-            a.memb_local[dst] = loc;
-            a.memb_idx[dst] = (int32_t)idx_of(j);
-            a.memb_g[dst] = (int32_t)((uint32_t)g | (((tailm >> j) & 1u) ? 0x80000000u : 0u));
-            if (rank == 0) a.seg_off[g] = dst;
+    stamp();  // 9: offsets
+    // ---- member lists (k_gather_members) ----
+    {
+        int cur = carry_start;
+        uint32_t info = (validm & 1u) ? s_buf[carry_start] : 0u;
+#pragma unroll 2
+        for (int j = 0; j < K; ++j) {
+            if ((headm >> j) & 1u) cur = p0 + j, info = s_buf[cur];
+            if (((validm >> j) & 1u) && (info >> 31)) {
+                const uint32_t pi = idx_of(j);
+                const float4 loc = a.local[pi];
+                const int g = gbase + (int)((info >> 16) & 0x7fffu);
+                const int rank = p0 + j - cur;
+                const int dst = mbase + (int)(info & 0xffffu) + rank;
+                a.memb_local[dst] = loc;
+                a.memb_idx[dst] = (int32_t)pi;
+                a.memb_g[dst] = (int32_t)((uint32_t)g | (((tailm >> j) & 1u) ? 0x80000000u : 0u));
+                if (rank == 0) a.seg_off[g] = dst;
+            }
         }
-    };
-#pragma unroll 1
-    for (int j0 = 0; j0 < K; j0 += 4) {
-        const uint32_t i0 = member_info(j0), i1 = member_info(j0 + 1), i2 = member_info(j0 + 2), i3 = member_info(j0 + 3);
-        const float4 l0 = member_load(j0, i0), l1 = member_load(j0 + 1, i1), l2 = member_load(j0 + 2, i2), l3 = member_load(j0 + 3, i3);
-        member_store(j0, i0, l0), member_store(j0 + 1, i1, l1), member_store(j0 + 2, i2, l2), member_store(j0 + 3, i3, l3);
     }
+    stamp();  // 10: member lists
     if (tid == 0) {
         a.seg_off[gbase + num_gauss] = mbase + num_memb;
         if (level == 1) {
@@ -461,20 +518,18 @@ void launch_k(const SmallVoxelArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int small_voxel_max_points() { return kSvThreads * 32; }
+int small_voxel_max_points() { return kSvThreads * 29; }  // 29 positions per thread: 116 KB of exchange buffer + 37 KB of counters and tables in 160 KB of LDS
 
 void launch_voxel_small(const SmallVoxelArgs& a, hipStream_t s) {
     const int k = (a.n + kSvThreads - 1) / kSvThreads;
-    if (k <= 8)
-        launch_k<8>(a, s);
-    else if (k <= 16)
-        launch_k<16>(a, s);
-    else if (k <= 24)
-        launch_k<24>(a, s);
-    else if (k <= 28)
-        launch_k<28>(a, s);
+    if (k <= 9)
+        launch_k<9>(a, s);
+    else if (k <= 17)
+        launch_k<17>(a, s);
+    else if (k <= 25)
+        launch_k<25>(a, s);
     else
-        launch_k<32>(a, s);
+        launch_k<29>(a, s);
 }
 
 }  // namespace dmsa

@@ -224,6 +224,10 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
         ctx->sync_sig[SYNC_SMALL_L0] += 1;
         a.sync_target = ctx->sync_sig[SYNC_SMALL_L0];
         a.timed_out = ctx->sync_timed_out();
+        if (ctx->dbg.gap_stamps == 3) {  // phase stamps of the kernel (device wall clock, 100 MHz), printed after the counts have arrived
+            HIPCHK(ctx->d_sv_stamps.ensure(2 * 16 * 8));
+            a.stamps = ctx->d_sv_stamps.as<long long>();
+        }
         launch_voxel_small(a, ctx->stream);
         ctx->small_voxel_launches += 1;
         HIPCHK(hipGetLastError());
@@ -349,6 +353,19 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
     }
     g_tl.mark("sync#2 wait");
     const GaussCounts h = ctx->h_rb->g;
+    if (small && ctx->dbg.gap_stamps == 3 && ctx->d_sv_stamps.p) {
+        long long st[32];
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(st, ctx->d_sv_stamps.p, sizeof(st), hipMemcpyDeviceToHost));
+        static int printed = 0;
+        if (printed++ % 16 == 8) {
+            for (int l = 0; l < 2; ++l) {
+                std::fprintf(stderr, "[k_voxel_small level %d] us since its start:", l);
+                for (int k = 1; k < 12; ++k) std::fprintf(stderr, " %.1f", (double)(st[l * 16 + k] - st[l * 16]) / 100.0);
+                std::fprintf(stderr, "   (level start offset %.1f us)\n", (double)(st[l * 16] - st[0]) / 100.0);
+            }
+        }
+    }
     if (small && (h.pad[0] != 0 || h.pad[1] != 0)) {  // codes wider than 32 bits (or a lattice error): the general path sorts them out
         if (ctx->h_lattice[0].status != 0) return ctx->h_lattice[0].status;
         if (ctx->h_lattice[1].status != 0) return ctx->h_lattice[1].status;

@@ -45,7 +45,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(capi.TrajState) == 120  # dmsa_window_setup.h
     assert C.sizeof(capi.PointCloud2) == 56  # dmsa_wire_formats.h
     assert C.sizeof(capi.AosView) == 40  # dmsa_aos.h
-    assert C.sizeof(capi.DebugCounters) == 96  # dmsa_debug.h: twelve int64 counters
+    assert C.sizeof(capi.DebugCounters) == 112  # dmsa_debug.h: fourteen int64 counters (append-only since round 6)
 
 
 def test_default_settings_match_reference_defaults(lib):

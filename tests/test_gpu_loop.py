@@ -217,9 +217,10 @@ def test_a_wrong_sort_width_guess_reruns_the_voxelisation(hip, orc):
     prob = synth.window_problem(seed=31, scans=3, rings=32, az_steps=256, num_static=4000)
     s = DmsaOptimSettings.sliding_window(num_iter=5)
     clean = _run(hip, prob, s)
+    general = {"small_voxel": 0}  # (28 576 points: the one-launch path of small_voxel.hip has no sort width to guess -- this is about the general path)
 
     def timed(debug):
-        opt = hip.DmsaOptimizer(fixed_iters=True, debug=debug)
+        opt = hip.DmsaOptimizer(fixed_iters=True, debug=dict(general, **(debug or {})))
         best = 1e9
         for _ in range(3):
             p = prob.copy()
@@ -232,7 +233,7 @@ def test_a_wrong_sort_width_guess_reruns_the_voxelisation(hip, orc):
         return best, c
 
     for k in (2, 3):
-        got, opt = _run_keep(hip, prob, s, debug={"speculation_fault": k})
+        got, opt = _run_keep(hip, prob, s, debug=dict(general, speculation_fault=k))
         _same(clean, got)
         assert opt.debugCounters()["speculation_retries"] == 1
         opt.close()

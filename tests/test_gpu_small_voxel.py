@@ -14,12 +14,12 @@ def _cases():
     out = []
     # the reference's everyday shape (config 2): 5 x 3072 points + 10^4 static points, IMU rows
     out.append(("imu", synth.window_problem(seed=5, scans=5, rings=32, az_steps=96, num_static=10_000, use_imu=True), DmsaOptimSettings.sliding_window(use_imu=True)))
-    # close to the limit of 32 768 points; 28 and 32 positions per lane
-    out.append(("k28", synth.window_problem(seed=3, scans=3, rings=32, az_steps=256, num_static=4000), DmsaOptimSettings.sliding_window()))
-    out.append(("k32", synth.window_problem(seed=4, scans=2, rings=64, az_steps=224, num_static=4000), DmsaOptimSettings.sliding_window()))
-    # few points: 8 and 16 positions per lane, an odd count
-    out.append(("k8", synth.window_problem(seed=6, scans=2, rings=16, az_steps=128, num_static=1501), DmsaOptimSettings.sliding_window()))
-    out.append(("k16", synth.window_problem(seed=7, scans=3, rings=16, az_steps=200, num_static=3333), DmsaOptimSettings.sliding_window()))
+    # close to the limit of 29 696 points (29 positions per thread)
+    out.append(("k29a", synth.window_problem(seed=3, scans=3, rings=32, az_steps=256, num_static=4000), DmsaOptimSettings.sliding_window()))
+    out.append(("k29b", synth.window_problem(seed=4, scans=2, rings=64, az_steps=200, num_static=4095), DmsaOptimSettings.sliding_window()))
+    # few points: 9 and 17 positions per thread, an odd count
+    out.append(("k9", synth.window_problem(seed=6, scans=2, rings=16, az_steps=128, num_static=1501), DmsaOptimSettings.sliding_window()))
+    out.append(("k17", synth.window_problem(seed=7, scans=3, rings=16, az_steps=200, num_static=3333), DmsaOptimSettings.sliding_window()))
     # irregular scan pattern, ids = index % 1000 (config 5 at the size livox.yaml prescribes: 1500 points per scan)
     out.append(("rosette", synth.rosette_window_problem(seed=2, scans=5, pts_per_scan=1500, num_static=6000), DmsaOptimSettings.sliding_window()))
     # a keyframe set without splitSet
@@ -49,7 +49,7 @@ def _voxelise(hip, prob, s, small, poke=None):
 def test_small_path_equals_general_path(hip, case):
     name, prob, s = _cases()[case]
     n = prob.localPoints.shape[0] + (prob.staticPoints.shape[0] if hasattr(prob, "staticPoints") else 0)
-    assert n <= 32768, (name, n)
+    assert n <= 29696, (name, n)
     a = _voxelise(hip, prob, s, 1)
     b = _voxelise(hip, prob, s, 0)
     assert a[0] == b[0] and a[3] == b[3] and a[0][0] > 30, (name, a[0], b[0])
@@ -86,7 +86,7 @@ def test_whole_calls_match_the_oracle_on_the_small_path(hip, orc, case):
     p_ref = prob.copy()
     rep_ref, _, trace = orc.optimize_window(p_ref, s)
     p = prob.copy()
-    opt = hip.DmsaOptimizer(device=0)
+    opt = hip.DmsaOptimizer(device=0, debug={"small_voxel": 1})
     rep = opt.optimizeSet(p, s)
     assert (rep.iterations, rep.stop_reason, rep.num_gaussians, rep.num_memberships) == (rep_ref.iterations, rep_ref.stop_reason, rep_ref.num_gaussians, rep_ref.num_memberships)
     assert np.array_equal(p.relOrientations, p_ref.relOrientations) and np.array_equal(p.relTranslations, p_ref.relTranslations), name
