@@ -18,6 +18,7 @@ hipError_t sort_pairs_u32_u32(void* temp, size_t temp_bytes, const uint32_t* key
 size_t sort_pairs_u32_workspace_bytes(size_t n);
 hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                                    size_t n, unsigned end_bit, hipStream_t stream, int prepared = 0 /* 1: header already zeroed, 2: header + look-back state + histograms done */);
+void sort_set_items_override(int items);  // debug switch sort_items: pairs per thread of a sort tile (2, 4, 8, 16; 0 = by size), process-wide
 hipError_t inclusive_scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t stream);
 hipError_t exclusive_scan_i32(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n, hipStream_t stream);
 }  // namespace dmsa

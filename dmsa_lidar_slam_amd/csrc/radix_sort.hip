@@ -35,8 +35,12 @@ constexpr int kSortThreads = DMSA_SORT_THREADS, kSortWaves = kSortThreads / 64;
 // Pairs per thread of a tile.  16 (8192-pair tiles) is tuned for 10^6 pairs; a window of the reference's everyday size (25 000 points) would be
 // FOUR such tiles -- four compute units each ranking 8192 pairs (~8 us of vector issue) while 252 idle.  Small inputs get small tiles: the
 // per-tile work shrinks with the tile, the look-back chain stays a round trip or two (kLook predecessors at once).
-__host__ __device__ constexpr int sort_items_for(size_t n) { return n <= (size_t(1) << 16) ? 2 : n <= (size_t(1) << 18) ? 4 : 16; }
-__host__ __device__ constexpr size_t sort_tile_for(size_t n) { return (size_t)kSortThreads * sort_items_for(n); }
+int g_sort_items_override = 0;  // debug switch sort_items (2, 4, 8, 16; 0 = by size): process-wide, experiments only
+inline int sort_items_for(size_t n) {
+    if (g_sort_items_override == 2 || g_sort_items_override == 4 || g_sort_items_override == 8 || g_sort_items_override == 16) return g_sort_items_override;
+    return n <= (size_t(1) << 16) ? 2 : n <= (size_t(1) << 18) ? 4 : 16;
+}
+inline size_t sort_tile_for(size_t n) { return (size_t)kSortThreads * sort_items_for(n); }
 constexpr int kLook = DMSA_SORT_LOOKBACK;  // predecessors inspected per round trip of the look-back
 static_assert(kSortThreads >= kBins && kSortThreads % 64 == 0, "one thread per digit");
 __host__ __device__ constexpr int hist_items_for(size_t n) { return n <= (size_t(1) << 16) ? 4 : n <= (size_t(1) << 18) ? 8 : 32; }  // keys per thread of a histogram workgroup (256 threads)
@@ -247,6 +251,8 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+void sort_set_items_override(int items) { g_sort_items_override = items; }
+
 size_t sort_pairs_u32_workspace_bytes(size_t n) {
     // sized for the smallest tile any n' <= n may choose (a workspace is allocated once for the largest problem and reused for smaller ones)
     const size_t tiles = (n + (size_t)kSortThreads * 2 - 1) / ((size_t)kSortThreads * 2);
@@ -308,6 +314,7 @@ hipError_t sort_pairs_u32_onesweep(void* temp, size_t temp_bytes, const uint32_t
         switch (sort_items_for(n)) {
             case 2: hipLaunchKernelGGL(k_sort_pass<2>, dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, p, 8 * p, dm, h, st); break;
             case 4: hipLaunchKernelGGL(k_sort_pass<4>, dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, p, 8 * p, dm, h, st); break;
+            case 8: hipLaunchKernelGGL(k_sort_pass<8>, dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, p, 8 * p, dm, h, st); break;
             default: hipLaunchKernelGGL(k_sort_pass<16>, dim3((unsigned)tiles), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, p, 8 * p, dm, h, st); break;
         }
         kin = kout, vin = vout;

@@ -30,6 +30,16 @@ void launch_transpose_tables(const float* tables, int rows, int B, float* tables
 // updateErrorTerms for B pose tables, bit-identical to the reference's serial loops.  E[b * ldE + g] = sqrt(|sum|).
 // The latency tier runs on s_long, the throughput tier on s_rest, the short tier on s_small (pass a stream twice to serialise tiers); the caller joins
 // the streams.
+// scratch of the latency tier's wide second pass (k_second_pass_wide), sized by serial_long_split_bytes(); null pointers: the second pass stays in
+// the chain kernel's workgroup
+struct LongSplit {
+    float* means = nullptr;     // [items][3][16]
+    double* partial = nullptr;  // [items][helpers][16]
+    int* partial_key = nullptr; // [items][helpers][16]
+    uint32_t* done = nullptr;   // [items], zero between launches
+    int32_t* redo = nullptr;    // [items]
+    int helpers = 16;
+};
 void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tablesT, int B, const uint32_t* order,
                              const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small,
                              int tree_mode = 1 /* dmsa_debug_options::serial_tree */,
@@ -38,7 +48,8 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
                              const uint32_t* rot_same = nullptr /* [B] from the pose-table kernels: evaluations whose rotations are evaluation 0's */,
                              const int2* row_range = nullptr /* [B] launch_eval_row_ranges; with gauss_rows: (Gaussian, evaluation) pairs whose rows all equal
                                                                 evaluation 0's are NOT computed and their E entries are left untouched */,
-                             const int2* gauss_rows = nullptr /* [M] launch_gauss_fit_all */);
+                             const int2* gauss_rows = nullptr /* [M] launch_gauss_fit_all */,
+                             const LongSplit* split = nullptr /* the latency tier's second pass on many compute units */);
 // row_range[b] = (first, last) pose-table row of evaluation b whose INPUTS differ from evaluation 0's bit for bit -- (INT_MAX, -1) if
 // none, (0, INT_MAX) for b = 0 -- from the global poses of the batch, ctrl[B][np][6].  model 2 (keyframes): row k is a function of pose k
 // alone (MapManagement.h:120-149).  model 1 (window): the rotation of dense pose j is a function of the two control rotations around it,

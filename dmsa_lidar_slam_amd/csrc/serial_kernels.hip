@@ -494,7 +494,10 @@ template <int kProd, bool kSepLoader, int kChunk>
 __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader ? DMSA_LONG_WAVES : DMSA_MID_WAVES) void k_residuals_chain(
     const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12, const float4* __restrict__ tabT, int B,
     const uint32_t* __restrict__ order, int Bs, int nsub, int prio, int tree_mode, double* __restrict__ E, int64_t ldE, uint32_t* start_signal,
-    const uint32_t* __restrict__ rot_same, const int2* __restrict__ row_range, const int2* __restrict__ gauss_rows) {
+    const uint32_t* __restrict__ rot_same, const int2* __restrict__ row_range, const int2* __restrict__ gauss_rows,
+    float* __restrict__ long_means /* not null: the workgroup ENDS with its float chain -- the means go here ([item][3][kBL]) and k_second_pass_wide
+                                      computes the second pass on many compute units */,
+    const int32_t* __restrict__ redo /* not null: only the items flagged here run (the wide second pass failed its exactness test) */) {
     // tree_mode 0: second pass as a chain (the reference's loop, pipelined); 1: parallel second pass, chain only if the exactness test
     // fails; 2: parallel pass computed, then the chain anyway (test hook)
     constexpr int kProducers = kProd;
@@ -516,6 +519,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     if (start_signal != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
         __hip_atomic_fetch_add(start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int item = blockIdx.x, gi = item / nsub, sub = item - gi * nsub;
+    if (redo != nullptr && redo[item] == 0) return;
     const int g = (int)order[gi];
     const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -706,6 +710,10 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         }
         if (on1) s_mean[cc * kBL + cb] = acc / (float)n;
         lds_barrier();
+        if (long_means != nullptr) {  // the second pass is somebody else's work (k_second_pass_wide, behind this kernel on its stream)
+            if (on1) long_means[(size_t)item * (3 * kBL) + cc * kBL + cb] = acc / (float)n;
+            return;
+        }
         if (parallel_second_pass()) return;
         const bool on2 = lane < nb;  // coordinate slot 0
         double dacc = 0.0;
@@ -854,6 +862,10 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     // ---- pass 2: Mahalanobis terms (needs the mean of pass 1) ----
     const Info I = load_info(info12, g);
     lds_barrier();  // s_mean is complete
+    if (long_means != nullptr) {
+        if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the member DMAs issued ahead
+        return;
+    }
     if (parallel_second_pass()) {
         if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the member DMAs issued ahead for a chained second pass
         return;
@@ -889,6 +901,128 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         TL_BARRIER(1, p);
     }
     if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in LDS after the workgroup has released it
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// latency tier, second pass on many compute units
+// ------------------------------------------------------------------------------------------------------------
+// The longest Gaussian bounds a batch: its float chain (pass 1) is ~8 cycles x 14 000 members on ONE wave, 57 us that no arrangement
+// shortens -- but the second pass behind it used to run on the same workgroup (ten waves on one compute unit, ~40 us) while most of the chip
+// idled.  With `long_means` the chain kernel ends with the means; this kernel gives every (Gaussian, sub-batch) kHelpers workgroups that sum
+// a slice of the members each (the parallel second pass of k_residuals_chain, same lane layout, same exactness argument: when the integer
+// bounds hold no addition rounds, so ANY order is the reference's chain), the last one to arrive adds the slices in a fixed order, tests
+// the bounds and writes E -- or flags the item, and the chain kernel runs again for the flagged items only (redo), member by member.
+__global__ __launch_bounds__(256) void k_second_pass_wide(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12,
+                                                          const float4* __restrict__ tabT, int B, const uint32_t* __restrict__ order, int Bs, int nsub,
+                                                          double* __restrict__ E, int64_t ldE, const int2* __restrict__ row_range, const int2* __restrict__ gauss_rows,
+                                                          const float* __restrict__ long_means, double* __restrict__ partial /* [item][helper][kBL] */,
+                                                          int* __restrict__ partial_key, uint32_t* __restrict__ done /* [item], zero between launches */,
+                                                          int32_t* __restrict__ redo /* [item] */, int helpers) {
+    constexpr int kWavesW = 4;
+    __shared__ int s_evals[kBL], s_nb, s_last, s_fail;
+    __shared__ double s_red[kWavesW * 64];
+    __shared__ int s_redk[kWavesW * 64];
+    const int item = blockIdx.x / helpers, h = blockIdx.x - item * helpers;
+    const int gi = item / nsub, sub = item - gi * nsub;
+    const int g = (int)order[gi];
+    const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        int cnt;
+        if (row_range != nullptr) {
+            cnt = build_eval_list<64>(row_range, gauss_rows[g], B, sub * Bs, Bs, s_evals, lane, 0);
+        } else {
+            cnt = min(Bs, B - sub * Bs);
+            if (lane < Bs) s_evals[lane] = sub * Bs + lane;
+        }
+        if (lane == 0) s_nb = cnt, s_fail = 0;
+    }
+    __syncthreads();
+    const int nb = s_nb;
+    if (nb <= 0) return;  // (the chain kernel left this item alone as well)
+    const int mpl = 64 / Bs, ms2 = lane / Bs, pb2 = lane - ms2 * Bs;  // members per wave step
+    const bool lane_on2 = ms2 < mpl && pb2 < nb;
+    const int bcol2 = s_evals[pb2 < nb ? pb2 : 0];
+    const float* mean = long_means + (size_t)item * (3 * kBL);
+    const float mx2 = mean[pb2 & 15], my2 = mean[kBL + (pb2 & 15)], mz2 = mean[2 * kBL + (pb2 & 15)];
+    const Info I2 = load_info(info12, g);
+    double part = 0.0;
+    int key = 0x7fffffff;  // bits of the smallest term; <= 0: a zero or negative term (or -NaN)
+    Rows r2;
+    r2.r0 = r2.r1 = r2.r2 = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    int r2_row = -1;
+    // this workgroup's slice of the member list, a contiguous block of it per wave (consecutive members mostly share a pose-table row)
+    const int blk_h = ((n + helpers - 1) / helpers + mpl - 1) / mpl * mpl;
+    const int hbeg = h * blk_h, hend = min(n, hbeg + blk_h);
+    const int blk = ((max(hend - hbeg, 0) + kWavesW - 1) / kWavesW + mpl - 1) / mpl * mpl;
+    const int wbeg = hbeg + wave * blk, jend = min(hend, wbeg + blk);
+    int j = wbeg + ms2;
+    auto term = [&](const float4 m, int jj) {
+        if (lane_on2 && jj < jend) {
+            const int row = __float_as_int(m.w);
+            if (row != r2_row) r2 = load_rows(tabT, B, bcol2, row), r2_row = row;
+            float gx, gy, gz;
+            transform_v(r2, m.x, m.y, m.z, gx, gy, gz);
+            const float t = mahalanobis_v(I2, gx, gy, gz, mx2, my2, mz2);
+            part += (double)t;
+            key = min(key, __float_as_int(t));
+        }
+    };
+    auto fetch = [&](int jj) { return memb[off0 + min(jj, n - 1)]; };
+    float4 m_a = fetch(j), m_b = fetch(j + mpl), m_c = fetch(j + 2 * mpl), m_d = fetch(j + 3 * mpl);
+    for (int j0 = wbeg; j0 < jend; j0 += 4 * mpl) {
+        term(m_a, j), m_a = fetch(j + 4 * mpl);
+        term(m_b, j + mpl), m_b = fetch(j + 5 * mpl);
+        term(m_c, j + 2 * mpl), m_c = fetch(j + 6 * mpl);
+        term(m_d, j + 3 * mpl), m_d = fetch(j + 7 * mpl);
+        j += 4 * mpl;
+    }
+    s_red[wave * 64 + lane] = part, s_redk[wave * 64 + lane] = key;
+    __syncthreads();
+    if (wave == 0 && lane < nb) {
+        double U = 0.0;
+        int k = 0x7fffffff;
+        for (int w = 0; w < kWavesW; ++w)
+            for (int s2 = 0; s2 < mpl; ++s2) U += s_red[w * 64 + s2 * Bs + lane], k = min(k, s_redk[w * 64 + s2 * Bs + lane]);
+        const size_t at = ((size_t)item * helpers + h) * kBL + lane;
+        __hip_atomic_store(partial + at, U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(partial_key + at, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();  // this workgroup's slice is visible before its ticket
+        const uint32_t t = __hip_atomic_fetch_add(done + item, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == (uint32_t)helpers - 1u ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last == 0) return;
+    // the last slice of the item: add the slices (fixed order), test the integer bounds, write E or flag the item for the chain
+    if (wave == 0) {
+        bool fail = false;
+        if (lane < nb) {
+            double U = 0.0;
+            int k = 0x7fffffff;
+            for (int hh = 0; hh < helpers; ++hh) {
+                const size_t at = ((size_t)item * helpers + hh) * kBL + lane;
+                U += __hip_atomic_load(partial + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                k = min(k, __hip_atomic_load(partial_key + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            const int q = ((k >> 23) & 0xff) - 127 - 23;  // every term is a multiple of 2^q (see parallel_second_pass of k_residuals_chain)
+            const int pe = min(max(q + 53 + 1023, 0), 2046);
+            const double limit = __hiloint2double(pe << 20, 0);
+            const bool exact = k > 0 && U * (1.0 + 0x1p-30) < limit;
+            if (exact)
+                E[(size_t)s_evals[lane] * ldE + g] = sqrt(fabs(U));
+            else
+                fail = true;
+        }
+        const bool any = __ballot(fail) != 0ull;
+        if (lane == 0) {
+            redo[item] = any ? 1 : 0;
+            __hip_atomic_store(done + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (any) atomicAdd(&g_fallback_sums, 1ull);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -941,19 +1075,32 @@ void launch_transpose_tables(const float* tables, int rows, int B, float* tables
 }
 void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tablesT, int B, const uint32_t* order,
                              const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small, int tree_mode,
-                             uint32_t* start_signal, int tiers, const uint32_t* rot_same, const int2* row_range, const int2* gauss_rows) {
+                             uint32_t* start_signal, int tiers, const uint32_t* rot_same, const int2* row_range, const int2* gauss_rows, const LongSplit* split) {
     if (B <= 0) return;
     const SerialShape sh = serial_shape(B);
     const float4* info = reinterpret_cast<const float4*>(info12);
     const float4* tabT = reinterpret_cast<const float4*>(tablesT);
     const int n_long = sc.n_long, n_mid = sc.n_chain - sc.n_long;
     // latency tier first (its longest chain bounds the batch), blocks in descending size; the other tiers fill the chip around it
-    if (n_long > 0 && (tiers & 1))
-        hipLaunchKernelGGL((k_residuals_chain<8, true, DMSA_LONG_CHUNK>), dim3((unsigned)n_long * sh.nsub_long), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
-                           sh.Bs_long, sh.nsub_long, 2, tree_mode, E, ldE, start_signal, rot_same, row_range, gauss_rows);
+    if (n_long > 0 && (tiers & 1)) {
+        const unsigned items = (unsigned)n_long * sh.nsub_long;
+        const bool wide = split != nullptr && split->means != nullptr && tree_mode == 1;
+        hipLaunchKernelGGL((k_residuals_chain<8, true, DMSA_LONG_CHUNK>), dim3(items), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
+                           sh.Bs_long, sh.nsub_long, 2, tree_mode, E, ldE, start_signal, rot_same, row_range, gauss_rows, wide ? split->means : (float*)nullptr,
+                           (const int32_t*)nullptr);
+        if (wide) {
+            // second pass on many compute units, then the chain again for whatever failed the exactness test (normally nothing: the
+            // workgroups of that launch read one flag and leave)
+            hipLaunchKernelGGL(k_second_pass_wide, dim3(items * (unsigned)split->helpers), dim3(256), 0, s_long, memb_local, seg_off, info, tabT, B, order, sh.Bs_long,
+                               sh.nsub_long, E, ldE, row_range, gauss_rows, split->means, split->partial, split->partial_key, split->done, split->redo, split->helpers);
+            hipLaunchKernelGGL((k_residuals_chain<8, true, DMSA_LONG_CHUNK>), dim3(items), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
+                               sh.Bs_long, sh.nsub_long, 2, 0, E, ldE, (uint32_t*)nullptr, rot_same, row_range, gauss_rows, (float*)nullptr, split->redo);
+        }
+    }
     if (n_mid > 0 && (tiers & 2))
         hipLaunchKernelGGL((k_residuals_chain<4, false, 32>), dim3((unsigned)n_mid * sh.nsub), dim3(64 * 5), 0, s_rest, memb_local, seg_off, info, tabT, B,
-                           order + n_long, sh.Bs, sh.nsub, 0, tree_mode, E, ldE, (uint32_t*)nullptr, rot_same, row_range, gauss_rows);
+                           order + n_long, sh.Bs, sh.nsub, 0, tree_mode, E, ldE, (uint32_t*)nullptr, rot_same, row_range, gauss_rows, (float*)nullptr,
+                           (const int32_t*)nullptr);
     if (sc.n_small > 0 && (tiers & 4)) {
         const int items = sc.n_small * sh.nsub_small;
         const int per_block = 4 * (64 / sh.lanes);

@@ -84,6 +84,12 @@ typedef struct dmsa_debug_options {
                                      Same bits.                                                                                              */
     int32_t fused_solve;     /* 1   P <= 64: normal-equation block sums, LM step, the nine trial chains and their pose tables in ONE single-workgroup
                                      kernel (csrc/loop_kernels.hip: k_loop_solve_trials) instead of four; 0: the separate kernels.  Same bits. */
+    int32_t long_split;      /* 1   latency tier (Gaussians of >= 4096 members) when it has at most 64 (Gaussian, sub-batch) items and B <= 32: the workgroup of
+                                     an item ends with its float chain and the second pass runs as 16 workgroups per item on whatever compute units are
+                                     free (k_second_pass_wide; the chain kernel runs again for items that fail the exactness test); 2: for any B; 3: always;
+                                     0: the second pass stays in the chain's workgroup.  Same bits.                                            */
+    int32_t sort_items;      /* 0   EXPERIMENTS ONLY, process-wide: pairs per thread of a tile of the onesweep sort (512 threads): 2, 4, 8 or 16; 0 = by
+                                     size (2 up to 2^16 pairs, 4 up to 2^18, else 16).  Same bits.                                           */
 } dmsa_debug_options;
 
 /* what the switches above leave behind, since the context was created */
