@@ -238,6 +238,7 @@ struct dmsa_ctx {
     DevBuf d_sv_stamps;  // debug switch gap_stamps = 3: phase stamps of k_voxel_small
     DevBuf d_long_split;  // scratch of the latency tier's wide second pass (serial_kernels.h: LongSplit)
     size_t long_split_items = 0;
+    uint32_t long_split_epoch = 0;
     DevBuf d_order;  // reference-order path: Gaussians by descending size class
     DevBuf d_tablesT;                                          // pose tables of the current batch, transposed ([row][evaluation][12])
     bool order_valid = false;

@@ -2,14 +2,6 @@
 // (default) and the host-driven loop (host-built pose tables, debug switch device_loop = 0, sets too large for the chain kernels' LDS).
 #include "dmsa_ctx.h"
 
-static void trace_split_once(dmsa_ctx* ctx, int B, size_t items) {
-    static int shown = 0;
-    if (ctx->dbg.trace_time >= 3 && shown < 4) {
-        std::fprintf(stderr, "[residual batch] B = %d: %d latency-tier Gaussians, %zu (Gaussian, sub-batch) items\n", B, ctx->serial_counts.n_long, items);
-        ++shown;
-    }
-}
-
 // ---- pose tables ------------------------------------------------------------------------------------------
 // `globs`: B x (C or F) x 6 doubles (axis-angle | translation) of the GLOBAL poses of every evaluation in the batch.
 int build_tables(dmsa_ctx* ctx, int B, const std::vector<double>& globs, hipStream_t stream) {
@@ -199,24 +191,26 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
             HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
             if (three) HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
         }
-        // the latency tier's second pass on many compute units (serial_kernels.hip: k_second_pass_wide): scratch per (long Gaussian, sub-batch)
+        // the second pass of the longest Gaussians shared out to helper workgroups (serial_kernels.hip: k_residuals_chain, LongHelp)
         LongSplit split_store;
         const LongSplit* split = nullptr;
-        // Worth it where a FEW long Gaussians bound the batch and the chip has room (the rosette window: 2 - 3 Gaussians of > 4096 members, both
-        // batches end with their chains: 2070 -> 2270 it/s).  The bench window has 110 of them: their second passes are a third of all the work of
-        // a batch and run side by side on ~220 compute units; moved behind the LONGEST chain they no longer overlap anything (1250 -> 923 it/s with
-        // the split everywhere, 1068 with the split in the line-search batch only).  Rule: at most 64 (Gaussian, sub-batch) items, B <= 32
-        // (long_split = 2: any B; 3: always).
-        const size_t split_items = (size_t)ctx->serial_counts.n_long * serial_shape(B).nsub_long;
-        const bool split_here = ctx->dbg.long_split == 3 || (ctx->dbg.long_split == 2 && split_items <= 64) || (ctx->dbg.long_split == 1 && B <= 32 && split_items <= 64);
-        trace_split_once(ctx, B, split_items);
-        if (split_here && ctx->serial_counts.n_long > 0 && ctx->dbg.serial_tree == 1) {
+        // Measured (round 6): where a FEW long Gaussians end a batch (the rosette window: 2 - 3 of them) the helpers take 10 % off the iteration; the
+        // bench window's 110 long Gaussians keep ~220 compute units busy side by side and the helpers of the longest ones gain nothing there
+        // (1235 -> 1200-1218 it/s), nor for the keyframe sets (4 long Gaussians, B = 187 and 9: 985 -> 953).  Rule: at most 8 long Gaussians, B <= 32;
+        // long_split >= 2 = that many members as the threshold, everywhere (experiments).
+        const bool split_auto = ctx->dbg.long_split == 1 && ctx->serial_counts.n_long <= 8 && B <= 32 && ctx->model == MODEL_WINDOW;
+        if ((split_auto || ctx->dbg.long_split >= 2) && ctx->serial_counts.n_long > 0 && ctx->dbg.serial_tree != 0) {
             const SerialShape shp = serial_shape(B);
-            const size_t items = (size_t)ctx->serial_counts.n_long * shp.nsub_long, H = 16;
+            const size_t items = (size_t)ctx->serial_counts.n_long * shp.nsub_long;
+            split_store.helpers = 8;
+            split_store.lead_gaussians = 16;
+            // few long Gaussians (rosette window, keyframe sets): every one of them may hand over; many (the bench window has 110): the longest
+            split_store.min_members = ctx->dbg.long_split >= 2 ? ctx->dbg.long_split : 4096;
+            const size_t H = (size_t)split_store.helpers;
             if (items > ctx->long_split_items) {  // layout by CAPACITY: the tickets keep their place (and their zeros) when the item count changes between batches
                 const size_t cap = items + items / 2 + 16;
                 HIPCHK(ctx->d_long_split.ensure(cap * (8 + 48 * 4 + H * 16 * 12) + 64));
-                HIPCHK(hipMemsetAsync(ctx->d_long_split.p, 0, ctx->d_long_split.cap, ctx->stream));  // the tickets start at zero (their last taker resets them)
+                HIPCHK(hipMemsetAsync(ctx->d_long_split.p, 0, ctx->d_long_split.cap, ctx->stream));  // tickets at zero, flags below every epoch
                 ctx->long_split_items = cap;
             }
             const size_t cap = ctx->long_split_items;
@@ -225,8 +219,11 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
             split_store.means = reinterpret_cast<float*>(w), w += cap * 48 * 4;
             split_store.partial_key = reinterpret_cast<int*>(w), w += cap * H * 16 * 4;
             split_store.done = reinterpret_cast<uint32_t*>(w), w += cap * 4;
-            split_store.redo = reinterpret_cast<int32_t*>(w);
-            split_store.helpers = (int)H;
+            split_store.ready = reinterpret_cast<uint32_t*>(w);
+            split_store.timed_out = ctx->sync_timed_out();
+            ctx->long_split_epoch += 1;
+            if (ctx->long_split_epoch == 0) ctx->long_split_epoch = 1;
+            split_store.epoch = ctx->long_split_epoch;
             split = &split_store;
         }
         if (dev_sync) {

@@ -30,15 +30,19 @@ void launch_transpose_tables(const float* tables, int rows, int B, float* tables
 // updateErrorTerms for B pose tables, bit-identical to the reference's serial loops.  E[b * ldE + g] = sqrt(|sum|).
 // The latency tier runs on s_long, the throughput tier on s_rest, the short tier on s_small (pass a stream twice to serialise tiers); the caller joins
 // the streams.
-// scratch of the latency tier's wide second pass (k_second_pass_wide), sized by serial_long_split_bytes(); null pointers: the second pass stays in
-// the chain kernel's workgroup
+// scratch of the latency tier's helper workgroups (k_residuals_chain: the second pass of the longest Gaussians shared out), owned by the caller;
+// means == null: every workgroup does its own second pass
 struct LongSplit {
-    float* means = nullptr;     // [items][3][16]
-    double* partial = nullptr;  // [items][helpers][16]
-    int* partial_key = nullptr; // [items][helpers][16]
-    uint32_t* done = nullptr;   // [items], zero between launches
-    int32_t* redo = nullptr;    // [items]
-    int helpers = 16;
+    float* means = nullptr;      // [items][3][16]
+    uint32_t* ready = nullptr;   // [items], any value but `epoch`
+    double* partial = nullptr;   // [items][helpers][16]
+    int* partial_key = nullptr;  // [items][helpers][16]
+    uint32_t* done = nullptr;    // [items], zero between launches
+    int32_t* timed_out = nullptr;  // dev_sync.h: a wait that gave up
+    uint32_t epoch = 1;          // a value no earlier launch on this scratch used
+    int helpers = 8;
+    int min_members = 8192;      // Gaussians from this size on hand their second pass to helpers
+    int lead_gaussians = 16;     // helpers are launched for this many Gaussians from the front of the (descending) order
 };
 void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, const float* info12, const float* tablesT, int B, const uint32_t* order,
                              const SerialCounts& sc, double* E, int64_t ldE, hipStream_t s_long, hipStream_t s_rest, hipStream_t s_small,

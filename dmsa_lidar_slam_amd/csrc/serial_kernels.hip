@@ -22,6 +22,8 @@
 // Everything is compiled with -ffp-contract=off: separate multiplies and adds like the reference's -O1 build without FMA.
 #include "serial_kernels.h"
 
+#include "dev_sync.h"
+
 #include <climits>
 #include <cstdint>
 #include <cstdio>
@@ -477,6 +479,30 @@ __device__ __forceinline__ uint32_t hi_word(double x) { return (uint32_t)(__doub
 #define DMSA_LONG_CHUNK 128
 #endif
 constexpr int kBL = 16;  // evaluation stride of the LDS ring layout (compile time: every ds_read of the chainer gets an immediate offset)
+// what k_residuals_chain needs to share the second pass of the longest Gaussians out to helper workgroups (host side: LongSplit)
+struct LongHelp {
+    float* means = nullptr;      // [item][3][kBL], written by the item's chain workgroup
+    uint32_t* ready = nullptr;   // [item]: == epoch once the means of this launch are there
+    double* partial = nullptr;   // [item][helper][kBL]
+    int* partial_key = nullptr;  // [item][helper][kBL]
+    uint32_t* done = nullptr;    // [item]: tickets of the helpers, back to zero when the item is finished
+    int32_t* timed_out = nullptr;
+    uint32_t epoch = 0;
+    int min_members = 0, helpers = 0, items = 0;  // items: the chain workgroups of the launch (the helpers follow them in the grid)
+    int lead = 0;                                 // only the first `lead` Gaussians of the order have helpers
+};
+__device__ __forceinline__ void dev_sync_wait_eq(const uint32_t* word, uint32_t want, int32_t* timed_out) {
+    uint32_t v = 0;
+    for (int spin = 0; spin < kSyncMaxSpins; ++spin) {
+        v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == want) return;
+        if (spin < 4096)
+            __builtin_amdgcn_s_sleep(2);
+        else
+            __builtin_amdgcn_s_sleep(16);
+    }
+    if (timed_out != nullptr) timed_out[0] = 1, timed_out[1] = (int32_t)want, timed_out[2] = (int32_t)v;
+}
 
 // kProd producer waves; kSepLoader: one more wave that only feeds the member ring (otherwise the last producer does that too).
 //   <8, true, 128> latency tier (the longest Gaussians): with Bs <= 8 every producer has ONE step per phase, so a phase lasts as
@@ -495,9 +521,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12, const float4* __restrict__ tabT, int B,
     const uint32_t* __restrict__ order, int Bs, int nsub, int prio, int tree_mode, double* __restrict__ E, int64_t ldE, uint32_t* start_signal,
     const uint32_t* __restrict__ rot_same, const int2* __restrict__ row_range, const int2* __restrict__ gauss_rows,
-    float* __restrict__ long_means /* not null: the workgroup ENDS with its float chain -- the means go here ([item][3][kBL]) and k_second_pass_wide
-                                      computes the second pass on many compute units */,
-    const int32_t* __restrict__ redo /* not null: only the items flagged here run (the wide second pass failed its exactness test) */) {
+    const LongHelp help /* means != null: the longest Gaussians' second pass is shared out to HELPER workgroups at the end of this launch's grid */) {
     // tree_mode 0: second pass as a chain (the reference's loop, pipelined); 1: parallel second pass, chain only if the exactness test
     // fails; 2: parallel pass computed, then the chain anyway (test hook)
     constexpr int kProducers = kProd;
@@ -510,18 +534,34 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     __shared__ float s_mean[3 * kBL];
     __shared__ __attribute__((aligned(16))) float4 s_m[4][kChunk];  // member ring (filled by LDS-DMA)
     __shared__ int s_chain;  // the parallel second pass failed its test for some evaluation
+    __shared__ int s_last;   // helper: this workgroup took the item's last ticket
     __shared__ int s_evals[kBL], s_nb;  // the evaluations of this workgroup's lanes (build_eval_list) and how many there are
     double* s_t = reinterpret_cast<double*>(s_q);
 
     // Fork of the tier streams (launch_sync_wait in front of the other tiers): the LAST workgroup of the latency tier releases them, i.e.
     // they start once every workgroup of this launch has its CU -- released any earlier, thousands of their workgroups get in first and
     // the longest Gaussians, which bound the batch, queue behind them (+60 us per line-search batch).
-    if (start_signal != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+    // Helpers.  The longest Gaussian bounds a batch twice over: its float chain (pass 1: ~8 cycles x 14 000 members on ONE wave, 57 us that no
+    // arrangement shortens) and, behind it, its second pass on the same ten waves (40 us for 5 evaluations, 165 us for 16) while its neighbours have
+    // long finished.  With `help`, the workgroup of a Gaussian of at least help.min_members members ENDS with its chain: it leaves the means in
+    // device memory and raises a flag; help.helpers more workgroups per such item -- the blocks behind the help.items chain workgroups of this
+    // launch, dispatched after them -- wait for the flag and sum a slice of the members each (the parallel second pass below: same lanes, same
+    // exactness argument -- when the integer bounds hold no addition rounds, so ANY order is the reference's chain).  The last helper to arrive
+    // adds the slices in a fixed order, tests the bounds and writes E, or runs the member-by-member chain itself if the test fails.
+    const bool helping = help.means != nullptr;
+    const bool helper = helping && (int)blockIdx.x >= help.items;
+    if (start_signal != nullptr && (int)blockIdx.x == (helping ? help.items : (int)gridDim.x) - 1 && threadIdx.x == 0)
         __hip_atomic_fetch_add(start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int item = blockIdx.x, gi = item / nsub, sub = item - gi * nsub;
-    if (redo != nullptr && redo[item] == 0) return;
+    int item = blockIdx.x, hslot = 0;
+    if (helper) {
+        const int hb = (int)blockIdx.x - help.items;
+        item = hb / help.helpers, hslot = hb - item * help.helpers;
+    }
+    const int gi = item / nsub, sub = item - gi * nsub;
     const int g = (int)order[gi];
     const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
+    const bool hand_over = helping && n >= help.min_members && gi < help.lead;  // this item's second pass belongs to its helpers
+    if (helper && !hand_over) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {
         int cnt;
@@ -555,8 +595,15 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         Rows r2;
         r2.r0 = r2.r1 = r2.r2 = f4{0.0f, 0.0f, 0.0f, 0.0f};
         int r2_row = -1;
-        const int blk = ((n + kWaves - 1) / kWaves + mpl - 1) / mpl * mpl;
-        const int jend = min(n, (wave + 1) * blk);
+        // the members this workgroup sums: all of them, or the helper's slice; a contiguous block of that range per wave
+        int rb = 0, re = n;
+        if (helper) {
+            const int blk_h = ((n + help.helpers - 1) / help.helpers + mpl - 1) / mpl * mpl;
+            rb = min(n, hslot * blk_h), re = min(n, rb + blk_h);
+        }
+        const int blk = ((re - rb + kWaves - 1) / kWaves + mpl - 1) / mpl * mpl;
+        const int wbeg0 = rb + wave * blk;
+        const int jend = min(re, wbeg0 + blk);
         // ---- sub-batch of evaluations that share their ROTATIONS with evaluation 0 (forward differences of translation parameters: half
         // of the Jacobian batch).  ((c0 x + c1 y) + c2 z) + c3 has the same first three terms for all of them: S = (c0 x + c1 y) + c2 z is
         // computed ONCE per member, lane = member, from evaluation 0's rows, parked in a wave-private kilobyte of the idle ring, and a
@@ -570,7 +617,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
             static_assert((size_t)kWaves * (48 + 64) * 16 <= sizeof(float) * kSlots * kSlotFloats, "second-pass staging does not fit the ring");
             float4* stage = reinterpret_cast<float4*>(s_q) + kWaves * 48 + wave * 64;  // behind the reduction scratch (kWaves x 64 x 12 bytes)
             const int CH = (64 / mpl) * mpl, steps = CH / mpl;  // members per chunk: a multiple of the members per step
-            const int wbeg = wave * blk;
+            const int wbeg = wbeg0;
             float tx = 0.0f, ty = 0.0f, tz = 0.0f;  // translation column of the lane's evaluation at row t_row
             int t_row = -1;
             auto fetch_member = [&](int cs) { return memb[off0 + min(cs + lane, n - 1)]; };
@@ -603,7 +650,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         }
         // every wave takes one contiguous block of the member list (consecutive members mostly share a pose-table row, so a lane
         // changes rows about once per row of its block instead of once per step); members are fetched two steps ahead
-        int j = wave * blk + ms2;
+        int j = wbeg0 + ms2;
         auto term = [&](const float4 m, int jj) {
             if (lane_on2 && jj < jend) {
                 const int row = __float_as_int(m.w);
@@ -620,7 +667,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         // register it replaces, so there is no rotation copy -- a copy of a freshly loaded register makes the step wait for its own load
         auto fetch = [&](int jj) { return memb[off0 + min(jj, n - 1)]; };
         float4 m_a = fetch(j), m_b = fetch(j + mpl), m_c = fetch(j + 2 * mpl), m_d = fetch(j + 3 * mpl);
-        for (int j0 = shared_rot ? jend : wave * blk; j0 < jend; j0 += 4 * mpl) {
+        for (int j0 = shared_rot ? jend : wbeg0; j0 < jend; j0 += 4 * mpl) {
             term(m_a, j), m_a = fetch(j + 4 * mpl);
             term(m_b, j + mpl), m_b = fetch(j + 5 * mpl);
             term(m_c, j + 2 * mpl), m_c = fetch(j + 6 * mpl);
@@ -631,11 +678,47 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         int* redk = reinterpret_cast<int*>(s_t + kWaves * 64);
         red[wave * 64 + lane] = part, redk[wave * 64 + lane] = key;
         lds_barrier();
+        if (helper) {
+            // the slice goes to device memory; the workgroup that takes the item's last ticket adds all slices (fixed order) and goes on
+            if (wave == 0 && lane < nb) {
+                double U = 0.0;
+                int k = 0x7fffffff;
+                for (int w = 0; w < kWaves; ++w)
+                    for (int s2 = 0; s2 < mpl; ++s2) U += red[w * 64 + s2 * Bs + lane], k = min(k, redk[w * 64 + s2 * Bs + lane]);
+                const size_t at = ((size_t)item * help.helpers + hslot) * kBL + lane;
+                __hip_atomic_store(help.partial + at, U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(help.partial_key + at, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (wave == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) {
+                    const uint32_t tk = __hip_atomic_fetch_add(help.done + item, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    s_last = tk == (uint32_t)help.helpers - 1u ? 1 : 0;
+                }
+            }
+            lds_barrier();
+            if (s_last == 0) return true;  // somebody else finishes the item
+            if (wave == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (lane == 0) __hip_atomic_store(help.done + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+                if (lane < nb) {
+                    for (int hh = 0; hh < help.helpers; ++hh) {
+                        const size_t at = ((size_t)item * help.helpers + hh) * kBL + lane;
+                        red[hh * 64 + lane] = __hip_atomic_load(help.partial + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        redk[hh * 64 + lane] = __hip_atomic_load(help.partial_key + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
         if (wave == 0 && lane < nb) {
             double U = 0.0;
             int k = 0x7fffffff;
-            for (int w = 0; w < kWaves; ++w)
-                for (int s2 = 0; s2 < mpl; ++s2) U += red[w * 64 + s2 * Bs + lane], k = min(k, redk[w * 64 + s2 * Bs + lane]);
+            if (helper) {
+                for (int hh = 0; hh < help.helpers; ++hh) U += red[hh * 64 + lane], k = min(k, redk[hh * 64 + lane]);
+            } else {
+                for (int w = 0; w < kWaves; ++w)
+                    for (int s2 = 0; s2 < mpl; ++s2) U += red[w * 64 + s2 * Bs + lane], k = min(k, redk[w * 64 + s2 * Bs + lane]);
+            }
             const int q = ((k >> 23) & 0xff) - 127 - 23;        // every term is a multiple of 2^q (a denormal smallest term: of 2^-149, so also of 2^-150)
             const int pe = min(max(q + 53 + 1023, 0), 2046);
             const double limit = __hiloint2double(pe << 20, 0);  // 2^(q+53); 0 when that is below the normal range: the test fails
@@ -663,7 +746,13 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         const int cc = lane >> 4, cb = lane & 15;
         const bool on1 = cc < 3 && cb < nb;
         float acc = 0.0f;
-        {
+        if (helper) {
+            // wait for the chain workgroup of this item (it was dispatched before this block), then take its means
+            if (lane == 0) dev_sync_wait_eq(help.ready + item, help.epoch, help.timed_out);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (lane < 3 * kBL) s_mean[lane] = __hip_atomic_load(help.means + (size_t)item * (3 * kBL) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
             const float4* q4 = reinterpret_cast<const float4*>(s_q) + (cc < 3 ? cc * kBL + cb : 0);
             constexpr int gstride = 3 * kBL;       // float4 entries per group of four members
             constexpr int slot4 = kSlotFloats / 4;
@@ -708,13 +797,17 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
                 TL_BARRIER(0, p);
             }
         }
-        if (on1) s_mean[cc * kBL + cb] = acc / (float)n;
+        if (!helper && on1) s_mean[cc * kBL + cb] = acc / (float)n;
         lds_barrier();
-        if (long_means != nullptr) {  // the second pass is somebody else's work (k_second_pass_wide, behind this kernel on its stream)
-            if (on1) long_means[(size_t)item * (3 * kBL) + cc * kBL + cb] = acc / (float)n;
+        if (!helper && hand_over) {  // the second pass is the helpers' work: publish the means, raise the flag, leave
+            if (on1) __hip_atomic_store(help.means + (size_t)item * (3 * kBL) + cc * kBL + cb, acc / (float)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) __hip_atomic_store(help.ready + item, help.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
         if (parallel_second_pass()) return;
+        if (helper) lds_barrier();  // (pairs with the producers' "the member ring holds chunk 0 again")
         const bool on2 = lane < nb;  // coordinate slot 0
         double dacc = 0.0;
         {
@@ -829,6 +922,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         return Pair{f2{m[0], m[4]}, f2{m[1], m[5]}, f2{m[2], m[6]}, __float_as_int(m[3]), __float_as_int(m[7])};
     };
     // ---- pass 1: transformed coordinates of every member ----
+    if (!helper) {
     dma(0), dma(1);
     landed();
     lds_barrier();  // chunk 0 of the member ring is visible
@@ -859,16 +953,22 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         landed();
         TL_BARRIER(0, p);
     }
+    }  // (!helper)
     // ---- pass 2: Mahalanobis terms (needs the mean of pass 1) ----
     const Info I = load_info(info12, g);
     lds_barrier();  // s_mean is complete
-    if (long_means != nullptr) {
+    if (!helper && hand_over) {
         if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the member DMAs issued ahead
         return;
     }
     if (parallel_second_pass()) {
-        if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the member DMAs issued ahead for a chained second pass
+        if (loader && !helper) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the member DMAs issued ahead for a chained second pass
         return;
+    }
+    if (helper) {  // the chain after all: what pass 1 would have left in flight -- the first two chunks of the member ring
+        dma(nphases), dma(nphases + 1);
+        landed();
+        lds_barrier();
     }
     const float mx = s_mean[pb & 15], my = s_mean[kBL + (pb & 15)], mz = s_mean[2 * kBL + (pb & 15)];
     for (int p = 0; p < nphases; ++p) {
@@ -901,128 +1001,6 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         TL_BARRIER(1, p);
     }
     if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in LDS after the workgroup has released it
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// latency tier, second pass on many compute units
-// ------------------------------------------------------------------------------------------------------------
-// The longest Gaussian bounds a batch: its float chain (pass 1) is ~8 cycles x 14 000 members on ONE wave, 57 us that no arrangement
-// shortens -- but the second pass behind it used to run on the same workgroup (ten waves on one compute unit, ~40 us) while most of the chip
-// idled.  With `long_means` the chain kernel ends with the means; this kernel gives every (Gaussian, sub-batch) kHelpers workgroups that sum
-// a slice of the members each (the parallel second pass of k_residuals_chain, same lane layout, same exactness argument: when the integer
-// bounds hold no addition rounds, so ANY order is the reference's chain), the last one to arrive adds the slices in a fixed order, tests
-// the bounds and writes E -- or flags the item, and the chain kernel runs again for the flagged items only (redo), member by member.
-__global__ __launch_bounds__(256) void k_second_pass_wide(const float4* __restrict__ memb, const int32_t* __restrict__ seg_off, const float4* __restrict__ info12,
-                                                          const float4* __restrict__ tabT, int B, const uint32_t* __restrict__ order, int Bs, int nsub,
-                                                          double* __restrict__ E, int64_t ldE, const int2* __restrict__ row_range, const int2* __restrict__ gauss_rows,
-                                                          const float* __restrict__ long_means, double* __restrict__ partial /* [item][helper][kBL] */,
-                                                          int* __restrict__ partial_key, uint32_t* __restrict__ done /* [item], zero between launches */,
-                                                          int32_t* __restrict__ redo /* [item] */, int helpers) {
-    constexpr int kWavesW = 4;
-    __shared__ int s_evals[kBL], s_nb, s_last, s_fail;
-    __shared__ double s_red[kWavesW * 64];
-    __shared__ int s_redk[kWavesW * 64];
-    const int item = blockIdx.x / helpers, h = blockIdx.x - item * helpers;
-    const int gi = item / nsub, sub = item - gi * nsub;
-    const int g = (int)order[gi];
-    const int off0 = seg_off[g], n = seg_off[g + 1] - off0;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave == 0) {
-        int cnt;
-        if (row_range != nullptr) {
-            cnt = build_eval_list<64>(row_range, gauss_rows[g], B, sub * Bs, Bs, s_evals, lane, 0);
-        } else {
-            cnt = min(Bs, B - sub * Bs);
-            if (lane < Bs) s_evals[lane] = sub * Bs + lane;
-        }
-        if (lane == 0) s_nb = cnt, s_fail = 0;
-    }
-    __syncthreads();
-    const int nb = s_nb;
-    if (nb <= 0) return;  // (the chain kernel left this item alone as well)
-    const int mpl = 64 / Bs, ms2 = lane / Bs, pb2 = lane - ms2 * Bs;  // members per wave step
-    const bool lane_on2 = ms2 < mpl && pb2 < nb;
-    const int bcol2 = s_evals[pb2 < nb ? pb2 : 0];
-    const float* mean = long_means + (size_t)item * (3 * kBL);
-    const float mx2 = mean[pb2 & 15], my2 = mean[kBL + (pb2 & 15)], mz2 = mean[2 * kBL + (pb2 & 15)];
-    const Info I2 = load_info(info12, g);
-    double part = 0.0;
-    int key = 0x7fffffff;  // bits of the smallest term; <= 0: a zero or negative term (or -NaN)
-    Rows r2;
-    r2.r0 = r2.r1 = r2.r2 = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    int r2_row = -1;
-    // this workgroup's slice of the member list, a contiguous block of it per wave (consecutive members mostly share a pose-table row)
-    const int blk_h = ((n + helpers - 1) / helpers + mpl - 1) / mpl * mpl;
-    const int hbeg = h * blk_h, hend = min(n, hbeg + blk_h);
-    const int blk = ((max(hend - hbeg, 0) + kWavesW - 1) / kWavesW + mpl - 1) / mpl * mpl;
-    const int wbeg = hbeg + wave * blk, jend = min(hend, wbeg + blk);
-    int j = wbeg + ms2;
-    auto term = [&](const float4 m, int jj) {
-        if (lane_on2 && jj < jend) {
-            const int row = __float_as_int(m.w);
-            if (row != r2_row) r2 = load_rows(tabT, B, bcol2, row), r2_row = row;
-            float gx, gy, gz;
-            transform_v(r2, m.x, m.y, m.z, gx, gy, gz);
-            const float t = mahalanobis_v(I2, gx, gy, gz, mx2, my2, mz2);
-            part += (double)t;
-            key = min(key, __float_as_int(t));
-        }
-    };
-    auto fetch = [&](int jj) { return memb[off0 + min(jj, n - 1)]; };
-    float4 m_a = fetch(j), m_b = fetch(j + mpl), m_c = fetch(j + 2 * mpl), m_d = fetch(j + 3 * mpl);
-    for (int j0 = wbeg; j0 < jend; j0 += 4 * mpl) {
-        term(m_a, j), m_a = fetch(j + 4 * mpl);
-        term(m_b, j + mpl), m_b = fetch(j + 5 * mpl);
-        term(m_c, j + 2 * mpl), m_c = fetch(j + 6 * mpl);
-        term(m_d, j + 3 * mpl), m_d = fetch(j + 7 * mpl);
-        j += 4 * mpl;
-    }
-    s_red[wave * 64 + lane] = part, s_redk[wave * 64 + lane] = key;
-    __syncthreads();
-    if (wave == 0 && lane < nb) {
-        double U = 0.0;
-        int k = 0x7fffffff;
-        for (int w = 0; w < kWavesW; ++w)
-            for (int s2 = 0; s2 < mpl; ++s2) U += s_red[w * 64 + s2 * Bs + lane], k = min(k, s_redk[w * 64 + s2 * Bs + lane]);
-        const size_t at = ((size_t)item * helpers + h) * kBL + lane;
-        __hip_atomic_store(partial + at, U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(partial_key + at, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();  // this workgroup's slice is visible before its ticket
-        const uint32_t t = __hip_atomic_fetch_add(done + item, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == (uint32_t)helpers - 1u ? 1 : 0;
-    }
-    __syncthreads();
-    if (s_last == 0) return;
-    // the last slice of the item: add the slices (fixed order), test the integer bounds, write E or flag the item for the chain
-    if (wave == 0) {
-        bool fail = false;
-        if (lane < nb) {
-            double U = 0.0;
-            int k = 0x7fffffff;
-            for (int hh = 0; hh < helpers; ++hh) {
-                const size_t at = ((size_t)item * helpers + hh) * kBL + lane;
-                U += __hip_atomic_load(partial + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                k = min(k, __hip_atomic_load(partial_key + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            }
-            const int q = ((k >> 23) & 0xff) - 127 - 23;  // every term is a multiple of 2^q (see parallel_second_pass of k_residuals_chain)
-            const int pe = min(max(q + 53 + 1023, 0), 2046);
-            const double limit = __hiloint2double(pe << 20, 0);
-            const bool exact = k > 0 && U * (1.0 + 0x1p-30) < limit;
-            if (exact)
-                E[(size_t)s_evals[lane] * ldE + g] = sqrt(fabs(U));
-            else
-                fail = true;
-        }
-        const bool any = __ballot(fail) != 0ull;
-        if (lane == 0) {
-            redo[item] = any ? 1 : 0;
-            __hip_atomic_store(done + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (any) atomicAdd(&g_fallback_sums, 1ull);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1084,23 +1062,22 @@ void launch_residuals_serial(const float4* memb_local, const int32_t* seg_off, c
     // latency tier first (its longest chain bounds the batch), blocks in descending size; the other tiers fill the chip around it
     if (n_long > 0 && (tiers & 1)) {
         const unsigned items = (unsigned)n_long * sh.nsub_long;
-        const bool wide = split != nullptr && split->means != nullptr && tree_mode == 1;
-        hipLaunchKernelGGL((k_residuals_chain<8, true, DMSA_LONG_CHUNK>), dim3(items), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
-                           sh.Bs_long, sh.nsub_long, 2, tree_mode, E, ldE, start_signal, rot_same, row_range, gauss_rows, wide ? split->means : (float*)nullptr,
-                           (const int32_t*)nullptr);
-        if (wide) {
-            // second pass on many compute units, then the chain again for whatever failed the exactness test (normally nothing: the
-            // workgroups of that launch read one flag and leave)
-            hipLaunchKernelGGL(k_second_pass_wide, dim3(items * (unsigned)split->helpers), dim3(256), 0, s_long, memb_local, seg_off, info, tabT, B, order, sh.Bs_long,
-                               sh.nsub_long, E, ldE, row_range, gauss_rows, split->means, split->partial, split->partial_key, split->done, split->redo, split->helpers);
-            hipLaunchKernelGGL((k_residuals_chain<8, true, DMSA_LONG_CHUNK>), dim3(items), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
-                               sh.Bs_long, sh.nsub_long, 2, 0, E, ldE, (uint32_t*)nullptr, rot_same, row_range, gauss_rows, (float*)nullptr, split->redo);
+        LongHelp help{};
+        unsigned grid = items;
+        if (split != nullptr && split->means != nullptr && tree_mode != 0) {
+            help.means = split->means, help.ready = split->ready, help.partial = split->partial, help.partial_key = split->partial_key, help.done = split->done;
+            help.timed_out = split->timed_out;
+            help.epoch = split->epoch, help.min_members = split->min_members, help.helpers = split->helpers, help.items = (int)items;
+            // helpers for the leading Gaussians of the order (descending size): the ones that may reach min_members
+            help.lead = std::min(n_long, split->lead_gaussians);
+            grid += (unsigned)help.lead * sh.nsub_long * (unsigned)split->helpers;
         }
+        hipLaunchKernelGGL((k_residuals_chain<8, true, DMSA_LONG_CHUNK>), dim3(grid), dim3(64 * 10), 0, s_long, memb_local, seg_off, info, tabT, B, order,
+                           sh.Bs_long, sh.nsub_long, 2, tree_mode, E, ldE, start_signal, rot_same, row_range, gauss_rows, help);
     }
     if (n_mid > 0 && (tiers & 2))
         hipLaunchKernelGGL((k_residuals_chain<4, false, 32>), dim3((unsigned)n_mid * sh.nsub), dim3(64 * 5), 0, s_rest, memb_local, seg_off, info, tabT, B,
-                           order + n_long, sh.Bs, sh.nsub, 0, tree_mode, E, ldE, (uint32_t*)nullptr, rot_same, row_range, gauss_rows, (float*)nullptr,
-                           (const int32_t*)nullptr);
+                           order + n_long, sh.Bs, sh.nsub, 0, tree_mode, E, ldE, (uint32_t*)nullptr, rot_same, row_range, gauss_rows, LongHelp{});
     if (sc.n_small > 0 && (tiers & 4)) {
         const int items = sc.n_small * sh.nsub_small;
         const int per_block = 4 * (64 / sh.lanes);

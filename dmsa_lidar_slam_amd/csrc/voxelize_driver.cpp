@@ -28,8 +28,8 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             if (ctx->depth_guess[l] > 1) ctx->depth_guess[l] -= 1;
             if (ctx->bits_guess[l] > 3) ctx->bits_guess[l] -= 3;
         }
-    const bool speculate = small || allow_speculation && ctx->depth_guess[0] >= 0 && ctx->depth_guess[1] >= 0 && ctx->depth_guess[0] < 20 && ctx->depth_guess[1] < 20 &&
-                           (!compress || (ctx->bits_guess[0] >= 0 && ctx->bits_guess[1] >= 0));
+    const bool speculate = small || (allow_speculation && ctx->depth_guess[0] >= 0 && ctx->depth_guess[1] >= 0 && ctx->depth_guess[0] < 20 && ctx->depth_guess[1] < 20 &&
+                                     (!compress || (ctx->bits_guess[0] >= 0 && ctx->bits_guess[1] >= 0)));
     // the key kernels count the digits of the sort that follows (own sort, 32-bit codes): no clearing kernel, no histogram pass
     const bool prehist = ctx->prehist;
     const bool headers_zeroed = true;

@@ -84,10 +84,11 @@ typedef struct dmsa_debug_options {
                                      Same bits.                                                                                              */
     int32_t fused_solve;     /* 1   P <= 64: normal-equation block sums, LM step, the nine trial chains and their pose tables in ONE single-workgroup
                                      kernel (csrc/loop_kernels.hip: k_loop_solve_trials) instead of four; 0: the separate kernels.  Same bits. */
-    int32_t long_split;      /* 1   latency tier (Gaussians of >= 4096 members) when it has at most 64 (Gaussian, sub-batch) items and B <= 32: the workgroup of
-                                     an item ends with its float chain and the second pass runs as 16 workgroups per item on whatever compute units are
-                                     free (k_second_pass_wide; the chain kernel runs again for items that fail the exactness test); 2: for any B; 3: always;
-                                     0: the second pass stays in the chain's workgroup.  Same bits.                                            */
+    int32_t long_split;      /* 1   latency tier (Gaussians of >= 4096 members) of a window with at most 8 of them, B <= 32: the workgroup of a (Gaussian,
+                                     sub-batch) ends with its float chain, leaves the means in device memory, and 8 HELPER workgroups per item -- blocks at the
+                                     end of the same launch -- sum a slice of the members each (the parallel second pass; the last one to arrive tests the
+                                     exactness bounds and runs the member-by-member chain itself if they fail).  >= 2: that many members as the threshold, in
+                                     every batch of every model (experiments); 0: every workgroup does its own second pass.  Same bits.             */
     int32_t sort_items;      /* 0   EXPERIMENTS ONLY, process-wide: pairs per thread of a tile of the onesweep sort (512 threads): 2, 4, 8 or 16; 0 = by
                                      size (2 up to 2^16 pairs, 4 up to 2^18, else 16).  Same bits.                                           */
 } dmsa_debug_options;

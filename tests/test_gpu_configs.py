@@ -342,8 +342,10 @@ def test_parallel_second_pass_of_the_chain_tiers(hip, orc, full_window, monkeypa
         pbase = prob.getPoseParameters()
         params = np.stack([pbase] + [pbase + H_INCR * np.eye(len(pbase))[k] for k in range(8)])  # 9 evaluations: two sub-batches
         e_ref = None
-        for mode in ("1", "2", "0"):
-            opt = hip.DmsaOptimizer(debug={"serial_tree": int(mode)})
+        # long_split = 4096: every Gaussian of the latency tier hands its second pass to helper workgroups (serial_kernels.hip) -- the last helper
+        # tests the bounds and, where they fail (`adv`), runs the chain itself
+        for mode, split in (("1", 0), ("2", 0), ("0", 0), ("1", 4096), ("2", 4096)):
+            opt = hip.DmsaOptimizer(debug={"serial_tree": int(mode), "long_split": split})
             opt.upload(prob)
             opt.poseTables(pbase[None, :], download=False)
             opt.updateGlobalPoints(0, download=False)
@@ -358,7 +360,7 @@ def test_parallel_second_pass_of_the_chain_tiers(hip, orc, full_window, monkeypa
                     gb = orc.transform_points(tables[b], prob.localPoints, prob.tformIdPerPoint)
                     e_ref.append(ref.residuals(np.concatenate([gb, prob.staticPoints]).astype(np.float32)))
                 e_ref = np.array(e_ref)
-            assert np.array_equal(e, e_ref), (mode, np.abs(e - e_ref).max())
+            assert np.array_equal(e, e_ref), (mode, split, np.abs(e - e_ref).max())
             if mode == "1":
                 chained = int((np.diff(ref.seg_offset) > 128).sum())  # Gaussians of the chain tiers, one or two sub-batches each
                 assert (fallbacks > 0) == expect_fallbacks and fallbacks < 0.02 * chained, (fallbacks, chained)
