@@ -287,6 +287,7 @@ def load_library() -> C.CDLL:
         "dmsa_sort_pairs": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "dmsa_leaf_segments": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_int64, C.c_uint32, c_int32_p, c_int32_p, c_int32_p]),
         "dmsa_serial_fallback_sums": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_uint64)]),
+        "dmsa_adaptive_step_size": (C.c_int, [vp, c_double_p, c_double_p, C.c_double, c_int32_p]),
         "dmsa_default_debug_options": (None, [C.POINTER(DebugOptions)]),
         "dmsa_create_ex": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(DebugOptions), C.POINTER(vp)]),
         "dmsa_create_ex2": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(DebugOptions), C.c_uint32, C.POINTER(vp)]),
@@ -364,7 +365,7 @@ EXPORTED_SYMBOLS = (
     "dmsa_create dmsa_create_ex dmsa_create_ex2 dmsa_default_debug_options dmsa_get_debug_counters dmsa_debug_pow_minus_one dmsa_debug_limit_covariance dmsa_sort_pairs64 dmsa_scan_i32 dmsa_destroy dmsa_last_error dmsa_default_settings dmsa_optimize_window dmsa_optimize_keyframes "
     "dmsa_get_global_points dmsa_window_upload dmsa_keyframes_upload dmsa_centralize dmsa_decentralize dmsa_get_params "
     "dmsa_set_params dmsa_additional_errors dmsa_pose_tables dmsa_set_pose_tables dmsa_num_table_rows dmsa_transform_points dmsa_build_gaussians "
-    "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_detmath_eval dmsa_lm_solve dmsa_lm_solve_device dmsa_serial_fallback_sums dmsa_sort_pairs dmsa_leaf_segments dmsa_neighbourhood_ranges dmsa_submap_poses dmsa_update_poses_from_submap dmsa_optimize_resident dmsa_get_poses "
+    "dmsa_eval_residuals dmsa_normal_equations dmsa_get_voxel_level dmsa_get_gaussians dmsa_get_timing dmsa_synchronize dmsa_get_trace dmsa_detmath_eval dmsa_lm_solve dmsa_lm_solve_device dmsa_serial_fallback_sums dmsa_sort_pairs dmsa_leaf_segments dmsa_neighbourhood_ranges dmsa_submap_poses dmsa_update_poses_from_submap dmsa_optimize_resident dmsa_adaptive_step_size dmsa_get_poses "
     "dmsa_select_static_points dmsa_get_overlap dmsa_random_grid_downsampling dmsa_radius_exists dmsa_preprocess_scan "
     "dmsa_imu_buffer_create dmsa_imu_buffer_destroy dmsa_imu_buffer_add dmsa_imu_buffer_closest dmsa_imu_buffer_state dmsa_traj_dims dmsa_traj_grids "
     "dmsa_traj_tform_indices dmsa_traj_transfer_imu dmsa_traj_preint_factors dmsa_traj_update_initial_guess dmsa_traj_submap_gravity_estimate "

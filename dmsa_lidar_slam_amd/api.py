@@ -199,6 +199,14 @@ class DmsaOptimizer:
         self._check(self._lib.dmsa_optimize_resident(self._ctx, C.byref(cs), C.byref(rep)), "optimize_resident")
         return rep
 
+    def adaptiveStepSize(self, params, step, error0: float):
+        """DmsaOptimizer::adaptiveStepSize (DmsaOptimizer.h:152-182) on the resident problem and its current Gaussians -> (parameters chosen, best_k)."""
+        p = np.ascontiguousarray(params, np.float64).copy()
+        st = np.ascontiguousarray(step, np.float64)
+        k = C.c_int32()
+        self._check(self._lib.dmsa_adaptive_step_size(self._ctx, capi.ptr(p, C.c_double), capi.ptr(st, C.c_double), float(error0), C.byref(k)), "adaptive_step_size")
+        return p, int(k.value)
+
     def debugCounters(self) -> dict:
         """include/dmsa_debug.h: dmsa_debug_counters (retries after a timed-out device-side wait / a wrong sort-width guess, pairs the
         Jacobian batches left out because they equal evaluation 0)."""

@@ -555,6 +555,12 @@ int dmsa_optimize_resident(dmsa_ctx* ctx, const dmsa_settings* s, dmsa_report* r
     return optimize(ctx, *s, rep);
 }
 
+int dmsa_adaptive_step_size(dmsa_ctx* ctx, double* params, const double* step, double error0, int32_t* best_k) {
+    if (!ctx || !params || !step || !best_k) return DMSA_ERR_INVALID;
+    CHK(set_device(ctx));
+    return adaptive_step_size(ctx, params, step, error0, best_k);
+}
+
 int dmsa_get_poses(dmsa_ctx* ctx, double* rel_orient, double* rel_transl) {
     if (!ctx || ctx->model == MODEL_NONE || !rel_orient || !rel_transl) return DMSA_ERR_INVALID;
     write_back_poses(chain(ctx), rel_orient, rel_transl);

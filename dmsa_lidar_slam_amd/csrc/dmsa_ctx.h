@@ -407,3 +407,4 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
                   const int2* row_range = nullptr /* Jacobian batch of the device loop: pairs equal to evaluation 0 are left out (serial_kernels.h) */);
 int device_lm_step(dmsa_ctx* ctx, const double* d_Hp, int P, double lambda, double alpha, double max_step, double* d_step, LoopFlags* d_flags);
 int optimize(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep);
+int adaptive_step_size(dmsa_ctx* ctx, double* params, const double* step, double error0, int32_t* best_k);

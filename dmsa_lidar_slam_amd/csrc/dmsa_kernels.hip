@@ -733,15 +733,20 @@ __global__ __launch_bounds__(kLatticeThreads) void k_lattice(const float4* __res
             }
             // the blocks that hold the first point or a trigger: point by point, from registers; epoch of a point = the events before its block
             // + the events of its block with a smaller index (usually one)
-            // (the boxes only grow: a point inside the box in force at the START of its block is inside the box of its own epoch, and that
-            // first box is the same for the whole block -- six float compares against uniform bounds settle all but the points around a trigger)
+            // (Shortcut: a point inside EVERY box that is in force somewhere in its block -- the intersection of the inward-rounded boxes of the
+            // epochs e0 .. e1 -- is inside the box of its own epoch, whichever that is; the bounds are uniform over the block, six float compares
+            // settle all but the points around a trigger.  The intersection, not the first box: a box that grows downward keeps its maximum only
+            // up to FLT_EPSILON (max = min + side - eps, PCL's adoptBoundingBoxToPoint), so "inside the first box" does not quite imply "inside
+            // the later ones" -- round 5's shortcut tested the first box only.)
 #pragma unroll
             for (int k = 0; k < kHintBlocks; ++k) {
                 if (k < nown) {
                     const float4 q = own_pt[k];
                     const int base = (int)s_own[k] * kAabbBlock, e0 = s_e0[k], e1 = s_e0[k + 1];
-                    const bool inside0 = base + tid > first32 && q.x >= s_fmn[e0][0] && q.x < s_fmx[e0][0] && q.y >= s_fmn[e0][1] && q.y < s_fmx[e0][1] && q.z >= s_fmn[e0][2] &&
-                                         q.z < s_fmx[e0][2];
+                    float imn[3] = {s_fmn[e0][0], s_fmn[e0][1], s_fmn[e0][2]}, imx[3] = {s_fmx[e0][0], s_fmx[e0][1], s_fmx[e0][2]};
+                    for (int e = e0 + 1; e <= e1; ++e)
+                        for (int a = 0; a < 3; ++a) imn[a] = fmaxf(imn[a], s_fmn[e][a]), imx[a] = fminf(imx[a], s_fmx[e][a]);
+                    const bool inside0 = base + tid > first32 && q.x >= imn[0] && q.x < imx[0] && q.y >= imn[1] && q.y < imx[1] && q.z >= imn[2] && q.z < imx[2];
                     if (!inside0 && isfinite(q.x) && isfinite(q.y) && isfinite(q.z)) {
                         int ep = e0;
                         bool trig = base + tid == first32;

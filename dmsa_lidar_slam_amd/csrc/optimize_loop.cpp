@@ -268,6 +268,87 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
 }
 
 
+// adaptiveStepSize (DmsaOptimizer.h:152-182) on the resident problem and its current Gaussians, host-driven: nine trial evaluations at
+// raw + 0.1 k step in one batch; `paramVec` (in: raw) becomes the arg-min if it beats error0 (strict '<'), *bestK its k (0: none -- the set is
+// then left at the LAST trial, raw + 0.9 step, like the reference's object, :160-165).  Used by the host-driven loop and by the C ABI's
+// dmsa_adaptive_step_size (the reference's method is public, DmsaOptimizer.h:152).
+static int host_adaptive_step_size(dmsa_ctx* ctx, int P, int rowsE, std::vector<double>& paramVec, const std::vector<double>& step, double error0, int* bestK_out) {
+    std::vector<double> globs, extra, test((size_t)P);
+    int bestK = 0;
+        globs.clear(), extra.clear();
+        if (ctx->model == MODEL_KEYFRAMES && P >= 48) {
+            // like the Jacobian batch: the keyframe model carries nothing from one evaluation to the next, so the nine trial chains are
+            // built side by side; the chain is left where the serial loop leaves it (last trial evaluated)
+            const int a = num_extra_rows(ctx);
+            const size_t gsz = (size_t)chain(ctx).n * 6;
+            globs.resize(9 * gsz);
+            extra.resize((size_t)9 * a);
+            const KeyframeHost base = ctx->key;
+            workers(ctx).run_all([&](int t, int nthr) {
+                KeyframeHost kh = base;
+                std::vector<double> tp((size_t)P), g;
+                for (int k = 1 + t; k < 10; k += nthr) {
+                    for (int i = 0; i < P; ++i) tp[(size_t)i] = paramVec[(size_t)i] + 0.1 * (double)k * step[(size_t)i];
+                    kh.frames.set_params(tp.data());
+                    kh.frames.relative_to_global();
+                    g.clear();
+                    append_glob(kh.frames, g);
+                    std::copy(g.begin(), g.end(), globs.begin() + (size_t)(k - 1) * gsz);
+                    if (a > 0) kh.additional_rows(&extra[(size_t)(k - 1) * a]);
+                }
+            });
+            ctx->evaluations += 9;
+            for (int i = 0; i < P; ++i) test[(size_t)i] = paramVec[(size_t)i] + 0.1 * 9.0 * step[(size_t)i];
+            host_set_params(ctx, test.data());
+        } else {
+            for (int k = 1; k < 10; ++k) {
+                for (int i = 0; i < P; ++i) test[(size_t)i] = paramVec[(size_t)i] + 0.1 * (double)k * step[(size_t)i];
+                host_set_params(ctx, test.data());
+                host_eval(ctx, globs, extra);
+            }
+        }
+        g_tl.mark("trial chains");
+        CHK(build_tables(ctx, 9, globs));
+        CHK(run_residuals(ctx, 9, &extra));
+        double* errs = ctx->h_rb->errs;  // pinned
+        {
+            ScopedTimer tm(ctx, T_NORMAL);
+            HIPCHK(ctx->d_sq_partial.ensure((size_t)squared_sums_blocked_partial_doubles(rowsE, P, 9) * 8));
+            HIPCHK(ctx->d_sq_out.ensure(16 * 8));
+            launch_squared_sums_blocked(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
+        }
+        HIPCHK(hipMemcpyAsync(errs, ctx->d_sq_out.p, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        g_tl.mark("line search enq");
+        HIPCHK(sync_spin(ctx->stream));  // sync #4
+        g_tl.mark("sync#4 wait");
+        drain_timers(ctx);
+        double minError = error0;
+        bestK = 0;
+        const std::vector<double> raw = paramVec;
+        for (int k = 1; k < 10; ++k)
+            if (errs[k - 1] < minError) {
+                for (int i = 0; i < P; ++i) paramVec[(size_t)i] = raw[(size_t)i] + 0.1 * (double)k * step[(size_t)i];
+                minError = errs[k - 1], bestK = k;
+            }
+    *bestK_out = bestK;
+    return DMSA_OK;
+}
+
+// C ABI seam of adaptiveStepSize (include/dmsa_hip.h: dmsa_adaptive_step_size)
+int adaptive_step_size(dmsa_ctx* ctx, double* params, const double* step, double error0, int32_t* best_k) {
+    if (ctx->model == MODEL_NONE || !ctx->gaussians_valid || !ctx->order_valid) {
+        ctx->err = "adaptive_step_size: no Gaussians (dmsa_build_gaussians or an optimize call first)";
+        return DMSA_ERR_INVALID;
+    }
+    const int P = num_params(ctx);
+    std::vector<double> pv(params, params + P), st(step, step + P);
+    int k = 0;
+    CHK(host_adaptive_step_size(ctx, P, ctx->M + ctx->extra_rows, pv, st, error0, &k));
+    std::copy(pv.begin(), pv.end(), params);
+    *best_k = k;
+    return DMSA_OK;
+}
+
 // ---- the optimizeSet loop (DmsaOptimizer.h:54-150) -------------------------------------------------------------
 static int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep);
 // A failure inside the loop (HIP error, lattice deeper than 21 levels, allocation) must not leave the resident problem in the centred
@@ -480,61 +561,7 @@ static int optimize_impl(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_report* rep
         if (maxElem > s.max_step)
             for (double& v : step) v = (s.max_step / maxElem) * v;
         // adaptiveStepSize (:152-182): nine trial evaluations in one batch
-        globs.clear(), extra.clear();
-        if (ctx->model == MODEL_KEYFRAMES && P >= 48) {
-            // like the Jacobian batch: the keyframe model carries nothing from one evaluation to the next, so the nine trial chains are
-            // built side by side; the chain is left where the serial loop leaves it (last trial evaluated)
-            const int a = num_extra_rows(ctx);
-            const size_t gsz = (size_t)chain(ctx).n * 6;
-            globs.resize(9 * gsz);
-            extra.resize((size_t)9 * a);
-            const KeyframeHost base = ctx->key;
-            workers(ctx).run_all([&](int t, int nthr) {
-                KeyframeHost kh = base;
-                std::vector<double> tp((size_t)P), g;
-                for (int k = 1 + t; k < 10; k += nthr) {
-                    for (int i = 0; i < P; ++i) tp[(size_t)i] = paramVec[(size_t)i] + 0.1 * (double)k * step[(size_t)i];
-                    kh.frames.set_params(tp.data());
-                    kh.frames.relative_to_global();
-                    g.clear();
-                    append_glob(kh.frames, g);
-                    std::copy(g.begin(), g.end(), globs.begin() + (size_t)(k - 1) * gsz);
-                    if (a > 0) kh.additional_rows(&extra[(size_t)(k - 1) * a]);
-                }
-            });
-            ctx->evaluations += 9;
-            for (int i = 0; i < P; ++i) test[(size_t)i] = paramVec[(size_t)i] + 0.1 * 9.0 * step[(size_t)i];
-            host_set_params(ctx, test.data());
-        } else {
-            for (int k = 1; k < 10; ++k) {
-                for (int i = 0; i < P; ++i) test[(size_t)i] = paramVec[(size_t)i] + 0.1 * (double)k * step[(size_t)i];
-                host_set_params(ctx, test.data());
-                host_eval(ctx, globs, extra);
-            }
-        }
-        g_tl.mark("trial chains");
-        CHK(build_tables(ctx, 9, globs));
-        CHK(run_residuals(ctx, 9, &extra));
-        double* errs = ctx->h_rb->errs;  // pinned
-        {
-            ScopedTimer tm(ctx, T_NORMAL);
-            HIPCHK(ctx->d_sq_partial.ensure((size_t)squared_sums_blocked_partial_doubles(rowsE, P, 9) * 8));
-            HIPCHK(ctx->d_sq_out.ensure(16 * 8));
-            launch_squared_sums_blocked(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 9, ctx->d_sq_partial.as<double>(), ctx->d_sq_out.as<double>(), ctx->stream);
-        }
-        HIPCHK(hipMemcpyAsync(errs, ctx->d_sq_out.p, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
-        g_tl.mark("line search enq");
-        HIPCHK(sync_spin(ctx->stream));  // sync #4
-        g_tl.mark("sync#4 wait");
-        drain_timers(ctx);
-        double minError = error0;
-        bestK = 0;
-        const std::vector<double> raw = paramVec;
-        for (int k = 1; k < 10; ++k)
-            if (errs[k - 1] < minError) {
-                for (int i = 0; i < P; ++i) paramVec[(size_t)i] = raw[(size_t)i] + 0.1 * (double)k * step[(size_t)i];
-                minError = errs[k - 1], bestK = k;
-            }
+        CHK(host_adaptive_step_size(ctx, P, rowsE, paramVec, step, error0, &bestK));
         double ss = 0.0;
         for (double v : step) ss += v * v;
         stepNorm = std::sqrt(ss);
@@ -809,7 +836,7 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
             EvalSkip skip;
             if (skip_mode != 0)
                 skip.row_range = ctx->d_row_range.as<int2>(), skip.gauss_rows = ctx->d_gauss_rows.as<int2>(), skip.M = ctx->M, skip.check = skip_mode == 2 ? 1 : 0,
-                skip.stats = ctx->dbg.skip_stats != 0 ? ctx->d_skip_stats.as<unsigned long long>() : nullptr;
+                skip.stats = (ctx->dbg.skip_stats != 0 || ctx->dbg.eval_skip == 2) ? ctx->d_skip_stats.as<unsigned long long>() : nullptr;
             // P <= 64: the block sums stay unreduced, the solve kernel adds them while it loads the matrix
             launch_normal_equations(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, one_div_incr, ctx->d_ne_partial.as<double>(), ctx->d_Hp.as<double>(), ctx->stream,
                                     P > kLoopSolveMaxP, skip_mode != 0 ? &skip : nullptr);

@@ -171,6 +171,11 @@ int dmsa_optimize_keyframes(dmsa_ctx* ctx, dmsa_keyframe_problem* p, const dmsa_
 /* Same loop on the problem already resident in HBM (dmsa_window_upload / dmsa_keyframes_upload or a previous optimize
  * call); poses continue from the context's current state and are returned through dmsa_get_poses. */
 int dmsa_optimize_resident(dmsa_ctx* ctx, const dmsa_settings* s, dmsa_report* rep);
+/* DmsaOptimizer<PointT>::adaptiveStepSize (DmsaOptimizer.h:152-182; public in the reference, called by optimizeSet only) on the resident problem
+ * and its current Gaussians: nine trial evaluations at params + 0.1 k step, k = 1 .. 9; `params` (P doubles, the raw parameters on entry) becomes
+ * the trial with the smallest e^T e if that beats error0 (strict '<'), *best_k its k -- 0 if none does.  Like the reference's object, the resident
+ * poses are left at the LAST trial (raw + 0.9 step), whatever the outcome.  Needs Gaussians (dmsa_build_gaussians or a previous optimize call). */
+int dmsa_adaptive_step_size(dmsa_ctx* ctx, double* params, const double* step, double error0, int32_t* best_k);
 /* current relative poses of the resident problem: 3 x n col-major doubles each (n = control poses / keyframes) */
 int dmsa_get_poses(dmsa_ctx* ctx, double* rel_orient, double* rel_transl);
 /* final globalPoints of the last optimize call (DmsaOptimizer.h:149); n x 4 floats */

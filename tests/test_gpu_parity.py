@@ -162,6 +162,32 @@ def test_normal_equations(hip, orc, small_window):
     assert np.abs(g - g_ref).max() / np.abs(g_ref).max() < 1e-12
 
 
+def test_adaptive_step_size_entry(hip, orc, small_window):
+    """dmsa_adaptive_step_size = DmsaOptimizer::adaptiveStepSize (DmsaOptimizer.h:152-182, public in the reference): the arg-min over the nine
+    trials 0.1 k step of e^T e, strictly below error0, from residuals the library evaluates itself -- checked against the same nine
+    evaluations made through the stage calls; 0 and untouched parameters when nothing beats error0."""
+    s = DmsaOptimSettings.sliding_window()
+    opt, glob, ids, table, M, Mm = _stage_setup(hip, orc, small_window, s)
+    base = small_window.getPoseParameters()
+    P = len(base)
+    params = np.concatenate([base[None], base[None] + H_INCR * np.eye(P)])
+    opt.poseTables(params, download=False)
+    e = opt.evalResiduals(P + 1)
+    _, _, step = orc.lm_step(e[0], e[1:], H_INCR, float(np.float32(1e-5)), 0.2)
+    trials = np.stack([base + 0.1 * k * step for k in range(1, 10)])
+    opt.poseTables(trials, download=False)
+    errs = (opt.evalResiduals(9) ** 2).sum(1)
+    error0 = float((e[0] ** 2).sum())
+    want = int(np.argmin(errs)) + 1 if errs.min() < error0 else 0
+    got_params, k = opt.adaptiveStepSize(base, step, error0)
+    assert k == want and 1 <= k <= 9
+    assert np.array_equal(got_params, base + 0.1 * k * step)
+    # an error0 nothing can beat: best_k = 0, parameters as they came
+    got_params, k = opt.adaptiveStepSize(base, step, 0.0)
+    assert k == 0 and np.array_equal(got_params, base)
+    opt.close()
+
+
 def _pose_diff(orc, a, b):
     ga_o, ga_t = orc.relative2global(a.relOrientations, a.relTranslations)
     gb_o, gb_t = orc.relative2global(b.relOrientations, b.relTranslations)
