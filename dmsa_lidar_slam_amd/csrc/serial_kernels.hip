@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     // launch, dispatched after them -- wait for the flag and sum a slice of the members each (the parallel second pass below: same lanes, same
     // exactness argument -- when the integer bounds hold no addition rounds, so ANY order is the reference's chain).  The last helper to arrive
     // adds the slices in a fixed order, tests the bounds and writes E, or runs the member-by-member chain itself if the test fails.
-    const bool helping = help.means != nullptr;
+    const bool helping = kSepLoader && help.means != nullptr;  // (the latency tier only: compile-time dead in the throughput tier)
     const bool helper = helping && (int)blockIdx.x >= help.items;
     if (start_signal != nullptr && (int)blockIdx.x == (helping ? help.items : (int)gridDim.x) - 1 && threadIdx.x == 0)
         __hip_atomic_fetch_add(start_signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -970,24 +970,37 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         landed();
         lds_barrier();
     }
-    const float mx = s_mean[pb & 15], my = s_mean[kBL + (pb & 15)], mz = s_mean[2 * kBL + (pb & 15)];
+    // The chained second pass is the rare path (a failed exactness test).  What it needs of the lane -- its member slot, its evaluation, its
+    // steps -- is derived AGAIN here from an opaque copy of the lane index, and the pose-table row cache starts empty: nothing of the producers'
+    // per-lane state stays live across the parallel second pass above.  (At 64 registers the compiler otherwise parks six VGPRs in scratch
+    // memory around it, in every producer wave of every workgroup: 10 MB of stores per launch of the throughput tier in round 5.)
+    int lane2;
+    asm volatile("v_and_b32 %0, 63, %1" : "=v"(lane2) : "v"(threadIdx.x));
+    const int ms_2 = lane2 / Bs, pb_2 = lane2 - ms_2 * Bs;
+    const bool lane_on_2 = ms_2 < mps && pb_2 < nb;
+    const int bcol_2 = s_evals[pb_2 < nb ? pb_2 : 0];
+    Rows rc2;
+    rc2.r0 = rc2.r1 = rc2.r2 = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    int rc2_row = -1;
+    const float mx = s_mean[pb_2 & 15], my = s_mean[kBL + (pb_2 & 15)], mz = s_mean[2 * kBL + (pb_2 & 15)];
     for (int p = 0; p < nphases; ++p) {
         const int P = nphases + p;
         dma(P + 2);
         if (p < nchunks) {
-            double* slot = s_t + (p % kSlots) * kSlotDoubles + pb * 2;
+            double* slot = s_t + (p % kSlots) * kSlotDoubles + pb_2 * 2;
             const int left = n - p * kChunk;
 #pragma unroll
             for (int u = 0; u < kMaxSteps; ++u) {
-                if (jl_u[u] < left && jl_u[u] < kChunk) {
-                    const int jl = jl_u[u];
+                const int t_2 = pw + u * kProducers, jl_2 = 2 * (t_2 * mps + ms_2);
+                const int jl = (works && t_2 < steps && lane_on_2 && jl_2 < kChunk) ? jl_2 : kChunk;  // (jl_u[u] of pass 1)
+                if (jl < left && jl < kChunk) {
                     const Pair m = read_pair(P & 3, jl);
                     double* dst = slot + (jl >> 1) * (kBL * 2);  // jl even: the pair is one double2
-                    if (m.row0 != rc_row) rc = load_rows(tabT, B, bcol, m.row0), rc_row = m.row0;
+                    if (m.row0 != rc2_row) rc2 = load_rows(tabT, B, bcol_2, m.row0), rc2_row = m.row0;
                     f2 gx, gy, gz;
-                    transform_v(rc, m.x, m.y, m.z, gx, gy, gz);
+                    transform_v(rc2, m.x, m.y, m.z, gx, gy, gz);
                     if (m.row1 != m.row0) {
-                        const Rows r1 = load_rows(tabT, B, bcol, m.row1);
+                        const Rows r1 = load_rows(tabT, B, bcol_2, m.row1);
                         float hx, hy, hz;
                         transform_v(r1, m.x.y, m.y.y, m.z.y, hx, hy, hz);
                         gx.y = hx, gy.y = hy, gz.y = hz;
