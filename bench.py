@@ -41,8 +41,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
-TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first
-KF_TRAFFIC_FILES = ("r05_traffic_keyframes.json",)
+TRAFFIC_FILES = ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json")  # newest first
+KF_TRAFFIC_FILES = ("r06_traffic_keyframes.json", "r05_traffic_keyframes.json")
 
 
 def spawn_ranks(n, backend, visible):
@@ -357,7 +357,9 @@ def main():
             "roofline": {
                 "kernel": "reference-order correspondence kernels (k_residuals_chain<8,true,128> + k_residuals_chain<4,false,32> + k_residuals_small, "
                           "three streams, fork / join by device counters, one HIP-event pair around the batch), B evaluations per launch",
-                "bound": "hbm",
+                # what bounds the kernels is vector instruction issue (bound_stated, valu); achieved / peak / frac below are still the brief's
+                # HBM-referred figures, and frac_hbm / frac_counters say how far from an HBM bound the launches are
+                "bound": "valu",
                 # SURVEY 8(d) bytes(B) / t: what a launch of B evaluations MUST move when it reads the members once, over the launch time --
                 # the HBM roofline figure proper (the kernels are nowhere near it and cannot be: bound_stated)
                 "frac_hbm": round(compulsory_per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if avg_ms > 0 else None,
@@ -380,10 +382,10 @@ def main():
                 "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
                 "compulsory_bytes_per_launch": round(compulsory_per_launch, 1),
                 "us_per_evaluation": round(1e3 * tm.residual_kernel_ms / evals, 3),
-                "bound_stated": "not HBM: vector instruction issue for the Jacobian batch (its three kernels use 86 % of the issue slots, DESIGN.md "
-                                "6.2), dependent-add latency of the longest Gaussian for the line-search batch.  A launch evaluates B pose tables on "
-                                "members it reads once per pass, so `frac` is an effective rate; the HBM fractions are frac_compulsory and "
-                                "frac_counters",
+                "bound_stated": "not HBM: vector instruction issue (the three tier kernels use 86 - 89 % of the issue slots; in both batches the "
+                                "throughput tier ends last, the latency tier's 110 long Gaussians keep ~220 compute units busy beside it: "
+                                "profiles/r06_iteration_timeline.txt).  A launch evaluates B pose tables on members it reads once per pass, so "
+                                "`achieved` / `frac` are an effective rate; the HBM fractions are frac_compulsory and frac_counters",
                 # the peak that applies: one wave64 fp32 instruction per SIMD every 4 cycles, no FMA (the reference rounds every product and
                 # sum on its own) and no packed issue (a wave64 v_pk_* occupies the SIMD for two passes): 1024 SIMDs x 64 lanes / 4 cycles x 2.4 GHz
                 "valu": {"achieved_tflops": round(valu_tflops, 2), "peak_tflops_scalar_no_fma": 39.3,
@@ -503,7 +505,7 @@ def sharded_keyframe_pass(args, rank, local_rank, world, dist, coll_dev, sync_al
         except Exception:
             continue
     roofline = {"kernel": "reference-order correspondence kernels of the neighbourhoods of rank 0 (B = P + 1 = 187 and B = 9 evaluations per launch)",
-                "bound": "hbm", "achieved": round(eff, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(eff / HBM_PEAK_GBS, 4),
+                "bound": "valu", "achieved": round(eff, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(eff / HBM_PEAK_GBS, 4),
                 "frac_compulsory": round(comp / HBM_PEAK_GBS, 4),
                 "frac_counters": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and avg_ms > 0) else None,
                 "traffic": traffic, "traffic_source": traffic_source,
@@ -605,7 +607,7 @@ def small_windows(device, which, steps, cpu_iters, calls=True):
             entry["cpu_oracle_it_per_s"] = cb["value"]
             entry["gpu_over_cpu"] = round(entry["value"] / cb["value"], 1) if cb["value"] > 0 else None
         out[name] = entry
-    out["note"] = ("launch-latency bound: see profiles/r05_small_window_*.txt for the launch count and the sum of kernel time against wall time per "
+    out["note"] = ("launch-latency bound: see profiles/r06_small_window_*.txt for the launch count and the sum of kernel time against wall time per "
                    "iteration (DESIGN.md 6.3)")
     return out
 

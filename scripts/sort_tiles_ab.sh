@@ -10,7 +10,7 @@ mkdir -p $OUT
 echo "# onesweep tile = 512 threads x items pairs; 0 = the rule (2 up to 2^16 pairs, 4 up to 2^18, else 16)"
 for items in 0 2 4 8 16; do
   opt="sort_items=$items"
-  DMSA_DEBUG=$opt python $R/bench.py --steps 200 --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('window[$opt]', d['value'], 'it/s  voxelize', d['stage_ms_per_step']['voxelize'], 'ms')"
+  DMSA_DEBUG=$opt python $R/bench.py --steps 200 --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('window[$opt]', d['value'], 'it/s')"
   DMSA_DEBUG=$opt python $R/bench.py --workload keyframes --steps 10 --cpu-iters 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('keyframe pass[$opt]', d['value'], 'it/s')"
   for w in small_imu small_rosette; do
     DMSA_DEBUG=$opt python $R/bench.py --workload $w --steps 200 --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1])['small_window']; k=[x for x in d if x!='note'][0]; print('$w[$opt]', d[k]['value'], 'it/s')"
@@ -23,7 +23,7 @@ rows = db.execute("select name, end - start from kernels").fetchall()
 agg = {}
 for n, d in rows:
     if "k_sort_pass" in n or "k_sort_hist" in n or "k_leaf_segments" in n:
-        k = n.split("(")[0].replace("void ", "").replace("dmsa::", "").replace("(anonymous namespace)::", "")
+        k = n.replace("void ", "").replace("dmsa::", "").replace("(anonymous namespace)::", "").split("(")[0]
         a = agg.setdefault(k, [0, 0]); a[0] += 1; a[1] += d
 for k, (c, t) in sorted(agg.items()):
     print(f"    window[sort_items={sys.argv[2]}] {k}: {c} launches, {t / c / 1e3:.2f} us each")
