@@ -82,8 +82,6 @@ typedef struct dmsa_debug_options {
                                      voxelised by ONE launch -- a workgroup per resolution keeps its (code, point) pairs in registers from the leaf codes to
                                      the member lists (csrc/small_voxel.hip) -- instead of ten dependent kernels per level; 0: always the general path.
                                      Same bits.                                                                                              */
-    int32_t fused_solve;     /* 1   P <= 64: normal-equation block sums, LM step, the nine trial chains and their pose tables in ONE single-workgroup
-                                     kernel (csrc/loop_kernels.hip: k_loop_solve_trials) instead of four; 0: the separate kernels.  Same bits. */
     int32_t long_split;      /* 1   latency tier (Gaussians of >= 4096 members) of a window with at most 8 of them, B <= 32: the workgroup of a (Gaussian,
                                      sub-batch) ends with its float chain, leaves the means in device memory, and 8 HELPER workgroups per item -- blocks at the
                                      end of the same launch -- sum a slice of the members each (the parallel second pass; the last one to arrive tests the
