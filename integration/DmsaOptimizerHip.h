@@ -69,6 +69,14 @@ public:
                                    (int32_t)offsetof(PointStampId, data), -1);
     }
 
+    // == DmsaOptimizer<PointT>::adaptiveStepSize(set, params, step, error0) (DmsaOptimizer.h:152-182; public, called by optimizeSet only): on the
+    // problem that the last optimizeSet left resident and its current Gaussians.  `params` becomes the best of the nine trials if it beats error0.
+    int adaptiveStepSize(Eigen::VectorXd& params, const Eigen::VectorXd& step, double error0) {
+        int32_t k = 0;
+        if (dmsa_adaptive_step_size(ctx_, params.data(), step.data(), error0, &k) != DMSA_OK) throw std::runtime_error(dmsa_last_error(ctx_));
+        return k;
+    }
+
     // == DmsaOptimizer<PointNormal>::optimizeSet(MapManagement&, settings)
     void optimizeSet(MapManagement& m, DmsaOptimSettings settings = DmsaOptimSettings()) {
         const int F = m.keyframeDataBuffer.getNumElements();
