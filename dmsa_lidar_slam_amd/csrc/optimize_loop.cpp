@@ -196,16 +196,16 @@ int run_residuals(dmsa_ctx* ctx, int B, const std::vector<double>* extra, const 
         const LongSplit* split = nullptr;
         // Measured (round 6): where a FEW long Gaussians end a batch (the rosette window: 2 - 3 of them) the helpers take 10 % off the iteration; the
         // bench window's 110 long Gaussians keep ~220 compute units busy side by side and the helpers of the longest ones gain nothing there
-        // (1235 -> 1200-1218 it/s), nor for the keyframe sets (4 long Gaussians, B = 187 and 9: 985 -> 953).  Rule: at most 8 long Gaussians, B <= 32;
+        // (1235 -> 1200-1218 it/s), nor for the keyframe sets (4 long Gaussians, B = 187 and 9: 985 -> 953).  Rule: window model, at most 16 long Gaussians (= the Gaussians that get helper blocks), B <= 32;
         // long_split >= 2 = that many members as the threshold, everywhere (experiments).
-        const bool split_auto = ctx->dbg.long_split == 1 && ctx->serial_counts.n_long <= 8 && B <= 32 && ctx->model == MODEL_WINDOW;
+        const bool split_auto = ctx->dbg.long_split == 1 && ctx->serial_counts.n_long <= 16 && B <= 32 && ctx->model == MODEL_WINDOW;
         if ((split_auto || ctx->dbg.long_split >= 2) && ctx->serial_counts.n_long > 0 && ctx->dbg.serial_tree != 0) {
             const SerialShape shp = serial_shape(B);
             const size_t items = (size_t)ctx->serial_counts.n_long * shp.nsub_long;
             split_store.helpers = 8;
             split_store.lead_gaussians = 16;
             // few long Gaussians (rosette window, keyframe sets): every one of them may hand over; many (the bench window has 110): the longest
-            split_store.min_members = ctx->dbg.long_split >= 2 ? ctx->dbg.long_split : 4096;
+            split_store.min_members = ctx->dbg.long_split >= 2 ? ctx->dbg.long_split : 0;  // (auto: every Gaussian of the latency tier)
             const size_t H = (size_t)split_store.helpers;
             if (items > ctx->long_split_items) {  // layout by CAPACITY: the tickets keep their place (and their zeros) when the item count changes between batches
                 const size_t cap = items + items / 2 + 16;

@@ -24,7 +24,8 @@ int serial_small_threshold();  // members; Gaussians up to this size go to the l
 // one workgroup: counting sort of the M = counts->level[0..1].num_gauss Gaussians by size class
 void launch_size_classes(const int32_t* seg_off, const GaussCounts* counts, uint32_t* order /* M */, SerialCounts* out, hipStream_t s,
                          const DevSync& sy = DevSync() /* waits / signals of the stream dependencies around the kernel (dev_sync.h) */,
-                         int small_threshold = 0 /* 0: serial_small_threshold() */);
+                         int small_threshold = 0 /* 0: serial_small_threshold() */,
+                         int long_log2 = 0 /* Gaussians of >= 2^long_log2 members go to the latency tier; 0: the built-in 12 */);
 // tables [B][rows][12] -> tablesT [rows][B][12]: the B evaluations of one pose row are contiguous (lane = evaluation reads coalesce)
 void launch_transpose_tables(const float* tables, int rows, int B, float* tablesT, hipStream_t s);
 // updateErrorTerms for B pose tables, bit-identical to the reference's serial loops.  E[b * ldE + g] = sqrt(|sum|).

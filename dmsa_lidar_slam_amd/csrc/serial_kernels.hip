@@ -1054,9 +1054,11 @@ SerialShape serial_shape(int B) {
     s.nsub_small = (B + s.lanes - 1) / s.lanes;
     return s;
 }
-void launch_size_classes(const int32_t* seg_off, const GaussCounts* counts, uint32_t* order, SerialCounts* out, hipStream_t s, const DevSync& sy, int small_threshold) {
+void launch_size_classes(const int32_t* seg_off, const GaussCounts* counts, uint32_t* order, SerialCounts* out, hipStream_t s, const DevSync& sy, int small_threshold,
+                         int long_log2) {
     const int ns = small_threshold > 0 ? (small_threshold < kSmallMax ? small_threshold : kSmallMax) : serial_small_threshold();
-    hipLaunchKernelGGL(k_size_classes, dim3(1), dim3(1024), 0, s, seg_off, counts, ns, serial_long_log2(), order, out, sy);
+    const int ll = long_log2 >= 9 && long_log2 <= 20 ? long_log2 : serial_long_log2();
+    hipLaunchKernelGGL(k_size_classes, dim3(1), dim3(1024), 0, s, seg_off, counts, ns, ll, order, out, sy);
 }
 void launch_transpose_tables(const float* tables, int rows, int B, float* tablesT, hipStream_t s) {
     const int total = rows * B * 3;

@@ -299,7 +299,7 @@ int build_gaussians(dmsa_ctx* ctx, const dmsa_settings& s, const std::function<i
             if (rb != ctx->stream) sy.signal_counter = ctx->sync_counter(SYNC_CLASSES), ctx->sync_sig[SYNC_CLASSES] += 1, rb_released = true;
         }
         launch_size_classes(ctx->d_seg_off.as<int32_t>(), counts, ctx->d_order.as<uint32_t>(),
-                            reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts)), ctx->stream, sy, small_threshold);
+                            reinterpret_cast<SerialCounts*>(ctx->d_counts.as<char>() + sizeof(GaussCounts)), ctx->stream, sy, small_threshold, ctx->dbg.long_log2);
     }
     if (ctx->stamp_voxel) launch_stamp(ctx->stamp_voxel, ctx->stream);
     if (rb_released) {

@@ -82,11 +82,13 @@ typedef struct dmsa_debug_options {
                                      voxelised by ONE launch -- a workgroup per resolution keeps its (code, point) pairs in registers from the leaf codes to
                                      the member lists (csrc/small_voxel.hip) -- instead of ten dependent kernels per level; 0: always the general path.
                                      Same bits.                                                                                              */
-    int32_t long_split;      /* 1   latency tier (Gaussians of >= 4096 members) of a window with at most 8 of them, B <= 32: the workgroup of a (Gaussian,
+    int32_t long_split;      /* 1   latency tier (Gaussians of >= 4096 members) of a window with at most 16 of them, B <= 32: the workgroup of a (Gaussian,
                                      sub-batch) ends with its float chain, leaves the means in device memory, and 8 HELPER workgroups per item -- blocks at the
                                      end of the same launch -- sum a slice of the members each (the parallel second pass; the last one to arrive tests the
                                      exactness bounds and runs the member-by-member chain itself if they fail).  >= 2: that many members as the threshold, in
                                      every batch of every model (experiments); 0: every workgroup does its own second pass.  Same bits.             */
+    int32_t long_log2;       /* 0   Gaussians of at least 2^long_log2 members go to the latency tier of the correspondence kernels (10 waves per workgroup,
+                                     helpers); 0 = the built-in rule (12), else 9 .. 20.  Every tier computes the same bits.                          */
     int32_t sort_items;      /* 0   EXPERIMENTS ONLY, process-wide: pairs per thread of a tile of the onesweep sort (512 threads): 2, 4, 8 or 16; 0 = by
                                      size (2 up to 2^16 pairs, 4 up to 2^18, else 16).  Same bits.                                           */
 } dmsa_debug_options;
