@@ -152,7 +152,7 @@ class StaticSelectResult(C.Structure):
 class DebugOptions(C.Structure):
     """include/dmsa_debug.h: dmsa_debug_options (fill with dmsa_default_debug_options first)."""
     _fields_ = [(n, C.c_int32) for n in ("device_loop", "dual_stream", "serial_streams", "merge_sort", "key_compress", "fused_segments", "sort_prehist",
-                                           "overlap_batch", "serial_tree", "host_threads", "solve_threads", "host_timeline", "trace_time", "fused_leaf_scan", "device_sync", "shared_rotations", "eval_skip", "sync_fault", "speculation_fault", "voxel_coherence", "lm_stream", "stream_priority", "gap_stamps", "lattice_hint", "fit_classes", "eigen_l1_bytes", "small_threshold", "skip_stats", "small_voxel", "long_split", "long_log2", "sort_items")]
+                                           "overlap_batch", "serial_tree", "host_threads", "solve_threads", "host_timeline", "trace_time", "fused_leaf_scan", "device_sync", "shared_rotations", "eval_skip", "sync_fault", "speculation_fault", "voxel_coherence", "lm_stream", "stream_priority", "gap_stamps", "lattice_hint", "fit_classes", "eigen_l1_bytes", "small_threshold", "skip_stats", "small_voxel", "long_split", "long_log2", "sort_items", "trial_rows_aside")]
 
 
 class DebugCounters(C.Structure):

@@ -309,7 +309,7 @@ void dmsa_default_debug_options(dmsa_debug_options* o) {
     o->device_loop = 1, o->dual_stream = 1, o->serial_streams = 3, o->merge_sort = 0, o->key_compress = 1, o->fused_segments = 1, o->sort_prehist = 0;
     o->overlap_batch = 1, o->serial_tree = 1, o->host_threads = 16, o->solve_threads = 12, o->host_timeline = 0, o->trace_time = 0, o->fused_leaf_scan = 1, o->device_sync = 1, o->shared_rotations = 1;
     o->eval_skip = 1, o->sync_fault = 0, o->speculation_fault = 0, o->voxel_coherence = 0, o->lm_stream = 1, o->stream_priority = 0, o->gap_stamps = 0, o->lattice_hint = 1, o->fit_classes = 7, o->eigen_l1_bytes = 32 * 1024, o->small_threshold = 0, o->skip_stats = 0;
-    o->small_voxel = 0, o->long_split = 1, o->long_log2 = 0, o->sort_items = 0;
+    o->small_voxel = 0, o->long_split = 1, o->long_log2 = 0, o->sort_items = 0, o->trial_rows_aside = 1;
 }
 // DMSA_DEBUG="name=value,name=value": the one environment variable of the library (include/dmsa_debug.h)
 static void apply_debug_env(dmsa_debug_options* o) {
@@ -322,7 +322,7 @@ static void apply_debug_env(dmsa_debug_options* o) {
                   {"key_compress", &o->key_compress},   {"fused_segments", &o->fused_segments}, {"sort_prehist", &o->sort_prehist},
                   {"overlap_batch", &o->overlap_batch}, {"serial_tree", &o->serial_tree},   {"host_threads", &o->host_threads},     {"solve_threads", &o->solve_threads},
                   {"host_timeline", &o->host_timeline}, {"trace_time", &o->trace_time},     {"fused_leaf_scan", &o->fused_leaf_scan}, {"device_sync", &o->device_sync},
-                  {"shared_rotations", &o->shared_rotations}, {"eval_skip", &o->eval_skip}, {"sync_fault", &o->sync_fault}, {"speculation_fault", &o->speculation_fault}, {"voxel_coherence", &o->voxel_coherence}, {"lm_stream", &o->lm_stream}, {"stream_priority", &o->stream_priority}, {"gap_stamps", &o->gap_stamps}, {"lattice_hint", &o->lattice_hint}, {"fit_classes", &o->fit_classes}, {"eigen_l1_bytes", &o->eigen_l1_bytes}, {"small_threshold", &o->small_threshold}, {"skip_stats", &o->skip_stats}, {"small_voxel", &o->small_voxel}, {"long_split", &o->long_split}, {"long_log2", &o->long_log2}, {"sort_items", &o->sort_items}};
+                  {"shared_rotations", &o->shared_rotations}, {"eval_skip", &o->eval_skip}, {"sync_fault", &o->sync_fault}, {"speculation_fault", &o->speculation_fault}, {"voxel_coherence", &o->voxel_coherence}, {"lm_stream", &o->lm_stream}, {"stream_priority", &o->stream_priority}, {"gap_stamps", &o->gap_stamps}, {"lattice_hint", &o->lattice_hint}, {"fit_classes", &o->fit_classes}, {"eigen_l1_bytes", &o->eigen_l1_bytes}, {"small_threshold", &o->small_threshold}, {"skip_stats", &o->skip_stats}, {"small_voxel", &o->small_voxel}, {"long_split", &o->long_split}, {"long_log2", &o->long_log2}, {"sort_items", &o->sort_items}, {"trial_rows_aside", &o->trial_rows_aside}};
     std::string text(e);
     size_t at = 0;
     while (at < text.size()) {

@@ -35,6 +35,8 @@ enum SyncSlot : int {
     SYNC_LATTICE = 8,     // k_lattice -> level 1 of the voxelisation on its own stream
     SYNC_LEVEL1 = 9,      // level 1 leaves done -> its member gather on the main stream
     SYNC_SMALL_L0 = 10,   // small_voxel.hip: level 0's totals -> the workgroup of level 1 (inside one kernel)
+    SYNC_TRIAL_STEP = 11, // the trial chains' control-pose kernel runs (= the LM step is done) -> their additional rows on the side stream
+    SYNC_TRIAL_ROWS = 12, // those rows are in E -> the squared sums on the main stream
     SYNC_SLOTS = 16
 };
 

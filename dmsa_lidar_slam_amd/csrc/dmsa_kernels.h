@@ -189,7 +189,8 @@ void launch_normal_equations(const double* E, int64_t ldE, int rows, int P, doub
 int normal_equations_partial_doubles(int rows, int P);
 // the squared sums of the nine trials in the blocked row order of the normal equations (bit-identical to the oracle); out == nullptr leaves the block
 // sums of evaluation b at partial[b * nsplit + sp] (nsplit as normal_equations_partials) for a consumer that adds them in order
-void launch_squared_sums_blocked(const double* E, int64_t ldE, int rows, int P, int B, double* partial, double* out, hipStream_t s);
+void launch_squared_sums_blocked(const double* E, int64_t ldE, int rows, int P, int B, double* partial, double* out, hipStream_t s,
+                                 const DevSync* sy = nullptr /* a dependency every workgroup waits for before it reads E (dev_sync.h) */);
 int squared_sums_blocked_partial_doubles(int rows, int P, int B);
 
 }  // namespace dmsa

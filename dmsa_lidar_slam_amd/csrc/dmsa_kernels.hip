@@ -3256,10 +3256,14 @@ __global__ void k_squared_sums_reduce(const double* __restrict__ partial, int ns
 // consecutive rows summed row by row, block sums added in order) -- the order the oracle states, so that the line search compares
 // bit-identical numbers.
 __global__ __launch_bounds__(64) void k_squared_sums_blocked(const double* __restrict__ E, int64_t ldE, int rows, int rs, int nsplit, int fused,
-                                                             double* __restrict__ partial) {
+                                                             double* __restrict__ partial, const DevSync sy) {
     // one wave per (row block, evaluation): the block's values arrive by coalesced loads, lane 0 adds their squares row by row
     __shared__ double s_v[1024];
     const int sp = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    if (sy.wait_counter != nullptr) {  // the additional rows of the trial batch come from the side stream (optimize_loop.cpp); long there by now
+        dev_sync_enter(sy);
+        __syncthreads();
+    }
     const int r0 = sp * rs, r_end = min(rows, r0 + rs);
     double s = 0.0;
     for (int c0 = r0; c0 < r_end; c0 += 1024) {
@@ -3283,10 +3287,10 @@ int squared_sums_blocked_partial_doubles(int rows, int P, int B) {
     const int rs = ne_rows_per_split(rows, P);
     return ((rows + rs - 1) / rs) * B;
 }
-void launch_squared_sums_blocked(const double* E, int64_t ldE, int rows, int P, int B, double* partial, double* out, hipStream_t s) {
+void launch_squared_sums_blocked(const double* E, int64_t ldE, int rows, int P, int B, double* partial, double* out, hipStream_t s, const DevSync* sy) {
     const int rs = ne_rows_per_split(rows, P);
     const int nsplit = (rows + rs - 1) / rs;
-    hipLaunchKernelGGL(k_squared_sums_blocked, dim3(nsplit, B), dim3(64), 0, s, E, ldE, rows, rs, nsplit, P > 64 ? 1 : 0, partial);
+    hipLaunchKernelGGL(k_squared_sums_blocked, dim3(nsplit, B), dim3(64), 0, s, E, ldE, rows, rs, nsplit, P > 64 ? 1 : 0, partial, sy ? *sy : DevSync{});
     if (out) hipLaunchKernelGGL(k_squared_sums_reduce, dim3((B + 63) / 64), dim3(64), 0, s, partial, nsplit, B, out);  // out null: the consumer adds the block sums
 }
 

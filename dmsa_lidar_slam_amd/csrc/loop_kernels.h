@@ -49,7 +49,9 @@ void launch_loop_begin(const LoopModel& m, double* state0, double* paramVec, dou
 // mode 0: the 1 + P evaluations of calcNumericJacobian (:199-232) from state_in (after loop_begin) -> ctrl[1+P][n][6], extra[1+P][a], state_out
 // mode 1: the 9 trials of adaptiveStepSize (:152-182), paramVec + 0.1 k step, from state_in (after the Jacobian batch) -> ctrl[9][n][6], extra[9][a], state_out
 void launch_loop_chain(const LoopModel& m, int mode, const double* state_in, double* state_out, const double* paramVec, const double* step, double increment,
-                       double* ctrl, double* extra, const LoopFlags* flags, hipStream_t s);
+                       double* ctrl, double* extra, const LoopFlags* flags, hipStream_t s,
+                       int part = 0 /* mode 1 only: 1 = control poses only, 2 = additional rows and state_out only (loop_kernels.hip) */,
+                       uint32_t* start_signal = nullptr /* dev_sync.h: raised when the kernel starts */);
 // additional rows of a batch below the Gaussian rows of the residual batch: E[b * ldE + M + r] = extra[b * a + r]
 void launch_loop_scatter_extra(const double* extra, int B, int a, double* E, int64_t ldE, int M, hipStream_t s);
 // LM step (:107-128) for P <= 64 from Hp = [J | e0]^T [J | e0] ((P+1)^2, column-major): H + lambda I, Gauss-Jordan inverse with partial

@@ -181,8 +181,15 @@ __global__ __launch_bounds__(kWave) void k_loop_begin(const LoopModel m, double*
 // the window model with IMU rows (pose0_orbit); everything else an evaluation reads is the incoming state and its own parameters.
 __global__ __launch_bounds__(kWave) void k_loop_chain(const LoopModel m, int mode, const double* __restrict__ state_in, double* __restrict__ state_out,
                                                       const double* __restrict__ paramVec, const double* __restrict__ step, double increment,
-                                                      double* __restrict__ ctrl, double* __restrict__ extra, const LoopFlags* __restrict__ flags) {
+                                                      double* __restrict__ ctrl, double* __restrict__ extra, const LoopFlags* __restrict__ flags, int part,
+                                                      uint32_t* start_signal) {
+    // part 0: everything.  The nine trials of a window with IMU rows are launched twice (optimize_loop.cpp): part 1 -- the control poses only,
+    // on the main stream, where the pose tables and the trial batch wait for them -- and part 2 -- the additional rows and the state the
+    // last trial leaves, on the side stream beside the trial batch (the rows are half of the chain kernel's time and nobody reads them before
+    // the squared sums).  start_signal: raised as soon as the kernel runs, i.e. once everything in front of it on its stream (the LM step)
+    // is done -- the side stream's part 2 waits for it.
     extern __shared__ double sm[];
+    if (start_signal != nullptr && blockIdx.x == 0 && threadIdx.x == 0) dev_sync_signal(start_signal);
     if (flags->stop != 0 || (mode == 1 && flags->nan != 0)) return;
     const int n = m.n, P = m.P, a = m.extra > 0 ? m.extra : 0;
     const int b = blockIdx.x, B = gridDim.x;
@@ -229,11 +236,13 @@ __global__ __launch_bounds__(kWave) void k_loop_chain(const LoopModel m, int mod
         }
         set_params_lds(n, c.par, c.rel_o, c.rel_t);
         wave_relative_to_global(n, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.E, c.R);
-        store_ctrl(my_ctrl, n, c.glob_o, c.glob_t);
-        wave_extra_rows(m, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.rows, c.dense);
-        for (int i = threadIdx.x; i < a; i += kWave) my_rows[i] = c.rows[i];
+        if (part != 2) store_ctrl(my_ctrl, n, c.glob_o, c.glob_t);
+        if (part != 1) {
+            wave_extra_rows(m, c.rel_o, c.rel_t, c.glob_o, c.glob_t, c.rows, c.dense);
+            for (int i = threadIdx.x; i < a; i += kWave) my_rows[i] = c.rows[i];
+        }
     }
-    if (b == B - 1) {
+    if (b == B - 1 && part != 1) {
         // the state the serial loop leaves behind: the last evaluation of the batch; the Jacobian batch then restores the parameters (:231)
         if (mode == 0) set_params_lds(n, c.org, c.rel_o, c.rel_t);
         store_state(state_out, n, c.rel_o, c.rel_t, c.glob_o, c.glob_t);
@@ -1365,10 +1374,11 @@ void launch_loop_begin(const LoopModel& m, double* state0, double* paramVec, dou
     hipLaunchKernelGGL(k_loop_begin, dim3(1), dim3(kWave), chain_lds_bytes(m), s, m, state0, paramVec, ctrl0, flags, state_ready);
 }
 void launch_loop_chain(const LoopModel& m, int mode, const double* state_in, double* state_out, const double* paramVec, const double* step, double increment,
-                       double* ctrl, double* extra, const LoopFlags* flags, hipStream_t s) {
+                       double* ctrl, double* extra, const LoopFlags* flags, hipStream_t s, int part, uint32_t* start_signal) {
     const int B = mode == 0 ? 1 + m.P : 9;
     chain_lds_allow(chain_lds_bytes(m));
-    hipLaunchKernelGGL(k_loop_chain, dim3(B), dim3(kWave), chain_lds_bytes(m), s, m, mode, state_in, state_out, paramVec, step, increment, ctrl, extra, flags);
+    hipLaunchKernelGGL(k_loop_chain, dim3(B), dim3(kWave), chain_lds_bytes(m), s, m, mode, state_in, state_out, paramVec, step, increment, ctrl, extra, flags,
+                       mode == 1 ? part : 0, start_signal);
 }
 void launch_loop_scatter_extra(const double* extra, int B, int a, double* E, int64_t ldE, int M, hipStream_t s) {
     if (a <= 0 || B <= 0) return;

@@ -882,7 +882,23 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         if (stamps) launch_stamp(ctx->d_gap_stamps.as<long long>() + 2, ctx->stream);  // LM step done
         if (iter_stamps) launch_stamp(iter_stamps + 8 * iter + 5, ctx->stream);
         // :152-182 nine trials, :130-143 decision
-        launch_loop_chain(m, 1, S1, S2, d_param, d_step, increment, ctx->d_ctrl.as<double>(), d_extra_trial, d_flags, ctx->stream);
+        // A window with IMU rows: the rows (updateImuError: a dozen Floater-Hormann evaluations per row) are half of the chain kernel's time and nobody
+        // reads them before the squared sums -- the main stream computes the control poses only (part 1), the side stream the rows and the state the
+        // last trial leaves (part 2) beside the pose tables and the trial batch.  26 + 4 us -> 11 us in front of the trial batch of a config-2 window.
+        const bool rows_aside = ctx->dbg.trial_rows_aside != 0 && a > 0 && ctx->model == MODEL_WINDOW && dev_sync;
+        if (rows_aside) {
+            CHK(ensure_E(ctx, 9));  // (the scatter below needs ldE; the Jacobian batch's E is at least as large)
+            launch_loop_chain(m, 1, S1, S2, d_param, d_step, increment, ctx->d_ctrl.as<double>(), d_extra_trial, d_flags, ctx->stream, 1,
+                              ctx->sync_counter(SYNC_TRIAL_STEP));
+            ctx->sync_sig[SYNC_TRIAL_STEP] += 1;
+            enqueue_wait(ctx, SYNC_TRIAL_STEP, side);
+            launch_loop_chain(m, 1, S1, S2, d_param, d_step, increment, ctx->d_ctrl.as<double>(), d_extra_trial, d_flags, side, 2);
+            launch_loop_scatter_extra(d_extra_trial, 9, a, ctx->d_E.as<double>(), ctx->ldE, ctx->M, side);
+            launch_sync_signal(ctx->sync_counter(SYNC_TRIAL_ROWS), side);
+            ctx->sync_sig[SYNC_TRIAL_ROWS] += 1;
+        } else {
+            launch_loop_chain(m, 1, S1, S2, d_param, d_step, increment, ctx->d_ctrl.as<double>(), d_extra_trial, d_flags, ctx->stream);
+        }
         {
             ScopedTimer tm(ctx, T_TABLE);
             CHK(device_tables(ctx, 9, ctx->d_ctrl.as<double>(), ctx->d_tables.as<float>(), ctx->d_tablesT.as<float>(), ctx->stream));
@@ -892,11 +908,15 @@ static int optimize_device_loop(dmsa_ctx* ctx, const dmsa_settings& s, dmsa_repo
         if (iter_stamps) launch_stamp(iter_stamps + 8 * iter + 6, ctx->stream);
         if (!host_nan) ctx->evaluations += 9;
         nan_evals = host_nan ? 0 : 9;
-        CHK(run_residuals(ctx, 9, nullptr, d_extra_trial));
+        CHK(run_residuals(ctx, 9, nullptr, rows_aside ? nullptr : d_extra_trial));
         {
             ScopedTimer tm(ctx, T_NORMAL);
             HIPCHK(ctx->d_sq_partial.ensure((size_t)squared_sums_blocked_partial_doubles(rowsE, P, 9) * 8));
-            launch_squared_sums_blocked(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 9, ctx->d_sq_partial.as<double>(), nullptr, ctx->stream);  // block sums only
+            DevSync rows_in;  // the side stream's rows: waited for by the kernel that reads them (a one-wave wait kernel in front of it costs 3 us)
+            if (rows_aside)
+                rows_in.wait_counter = ctx->sync_counter(SYNC_TRIAL_ROWS), rows_in.wait_target = ctx->sync_sig[SYNC_TRIAL_ROWS], rows_in.timed_out = ctx->sync_timed_out();
+            launch_squared_sums_blocked(ctx->d_E.as<double>(), ctx->ldE, rowsE, P, 9, ctx->d_sq_partial.as<double>(), nullptr, ctx->stream,
+                                        rows_aside ? &rows_in : nullptr);  // block sums only
         }
         {
             const bool sig = ctx->dbg.device_sync != 0 && side != ctx->stream;  // for the next iteration's chains, if there is one (a signal nobody waits for is harmless)

@@ -91,6 +91,8 @@ typedef struct dmsa_debug_options {
                                      helpers); 0 = the built-in rule (12), else 9 .. 20.  Every tier computes the same bits.                          */
     int32_t sort_items;      /* 0   EXPERIMENTS ONLY, process-wide: pairs per thread of a tile of the onesweep sort (512 threads): 2, 4, 8 or 16; 0 = by
                                      size (2 up to 2^16 pairs, 4 up to 2^18, else 16).  Same bits.                                           */
+    int32_t trial_rows_aside; /* 1  window with IMU rows, device loop: the nine trial chains of the line search write their control poses on the main stream
+                                     and compute their additional rows on the side stream, beside the trial batch (0: one kernel, in front of it).  Same bits. */
 } dmsa_debug_options;
 
 /* what the switches above leave behind, since the context was created */

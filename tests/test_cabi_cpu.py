@@ -33,7 +33,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_struct_sizes_match_header_layout():
     # natural-alignment layouts of the PODs in include/dmsa_hip.h (x86-64 SysV)
-    assert C.sizeof(capi.DebugOptions) == 32 * 4  # include/dmsa_debug.h: thirty-two int32 fields (append-only since round 6)
+    assert C.sizeof(capi.DebugOptions) == 33 * 4  # include/dmsa_debug.h: thirty-three int32 fields (append-only since round 6)
     assert C.sizeof(capi.Settings) == 72
     assert C.sizeof(capi.Report) == 48
     assert C.sizeof(capi.VoxelLevelInfo) == 56
