@@ -97,6 +97,8 @@ def test_early_exits_match_the_oracle_and_the_host_driven_loop(hip, orc, case):
     _same(dev, _run(hip, prob, s, debug={"device_sync": 0, "fused_leaf_scan": 0}))
     _same(dev, _run(hip, prob, s, debug={"device_loop": 0, "device_sync": 0}))
     _same(dev, _run(hip, prob, s, debug={"shared_rotations": 0}))  # every evaluation of the Jacobian batch transforms its members itself
+    if case == "window_imu":  # the trial chains' IMU rows in ONE kernel in front of the trial batch instead of on the side stream beside it
+        _same(dev, _run(hip, prob, s, debug={"trial_rows_aside": 0}))
     # where the lane-per-evaluation tier ends and the workgroup tiers begin (the default follows the problem size: 32 members for these
     # small sets, 256 for large ones) changes nothing: every tier of the correspondence kernels and of the fit computes the same bits
     for thr in (256, 8, 100):
