@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kSvThreads) void k_voxel_small(const SmallVoxelArgs
     uint16_t* s_buf16 = reinterpret_cast<uint16_t*>(sv_smem);
     SvShared& sh = *reinterpret_cast<SvShared*>(sv_smem + (size_t)kSvThreads * K * 4);
     const int level = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n = a.n, ntot = kSvThreads * K;
+    const int n = a.n;
     const int p0 = tid * K;
     int stamp_at = 0;
     auto stamp = [&]() {
