@@ -2418,7 +2418,18 @@ __device__ int eigensolver3f(const float c[3][3], float v[3][3], float lam[3], i
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const float rp = a == 0 ? ev[r][0] : (a == 1 ? ev[r][1] : ev[r][2]);
-            v[r][j] = z > 0.0f ? rp / d : rp;
+            const float ip0 = two ? (b == 1 ? ev[r][1] : ev[r][2]) : 0.0f;
+            const float ip = second ? -ip0 : ip0;  // the second column of a pair is the conjugate
+            // normalize() divides the complex column by (d, 0): rows 0 and 1 as ONE Packet2cf -- SSE's pdiv = pmul(a, pconj(b)) / |b|^2 --, row 2
+            // as a scalar complex division (libgcc's __divsc3, Smith); see oracle/eigensolver3f.h: normalized_real_part
+            float q;
+            if (r < 2) {
+                q = (rp * d + (-(ip * -0.0f))) / (d * d + 0.0f * 0.0f);
+            } else {
+                const float ratio = 0.0f / d, denom = 0.0f * ratio + d;
+                q = (ip * ratio + rp) / denom;
+            }
+            v[r][j] = z > 0.0f ? q : rp;
         }
     }
     return 0;

@@ -70,6 +70,7 @@
 //   ORC_VAR_LIMITCOV_JACOBI     limitCovariance's eigenpairs from a fixed 6-sweep cyclic Jacobi iteration in float (this file's statement until round 6)
 //                               instead of EigenSolver<Matrix3f> as Eigen 3.4.0 evaluates it (oracle/eigensolver3f.h)
 //   ORC_VAR_EIG_BACK_HALVES     the one 3-term sum of that solver (back transformation of the last eigenvector) as x0 + (x1 + x2) instead of (x0 + x1) + x2
+//   ORC_VAR_EIG_NORMALIZE_SCALAR eigenvectors()'s normalize() as re / nrm in every row instead of Eigen's Packet2cf division (re * nrm) / (nrm * nrm) in rows 0, 1
 //   ORC_VAR_STEP_LEFT_ASSOC     the LM step as Eigen associates it, ((-alpha H^-1) J^T) e with a P x rows temporary, instead of (-alpha H^-1)(J^T e)
 //   ORC_VAR_LM_BLOCKED_LU       H^-1 from a right-looking LU in 8-column panels (the shape of Eigen's PartialPivLU) instead of Gauss-Jordan on [H | I]
 //   ORC_VAR_JTJ_NOFMA           J^T J, J^T e, e^T e for P > 64 with separately rounded multiply and add (the reference has no FMA)
@@ -380,7 +381,7 @@ static void inverse3f(const float m[3][3], float inv[3][3]) {
 // `eigenVectors * diagonal_matrix * eigenVectors.inverse()` (:200): (V D)(i,k) = V(i,k) * d(k), the fixed-size product with the cofactor
 // inverse of V coefficient by coefficient as a 3-term redux.  V is orthogonal only up to rounding, so the result is NOT exactly symmetric --
 // like the reference's.  Hypotheses: ORC_VAR_LIMITCOV_JACOBI (this file's statement until round 6: a fixed 6-sweep cyclic Jacobi iteration in
-// float -- same mathematics, other eigenvalue order, other rounding), ORC_VAR_LIMITCOV_VT (V * D * V^T), ORC_VAR_EIG_BACK_HALVES.
+// float -- same mathematics, other eigenvalue order, other rounding), ORC_VAR_LIMITCOV_VT (V * D * V^T), ORC_VAR_EIG_BACK_HALVES, ORC_VAR_EIG_NORMALIZE_SCALAR.
 struct LimitCovStats {
     int64_t calls = 0, qr_iterations = 0, max_iterations = 0, complex_pairs = 0, not_converged = 0;
 };

@@ -27,6 +27,13 @@
 //   * `bottom -= tau * essential * tmp` multiplies (tau * essential_i) * tmp_j, `right -= tau * tmp * essential.adjoint()` multiplies
 //     (tau * tmp_i) * essential_j: C++ associates left to right and the scalar multiple is evaluated first;
 //   * squaredNorm() of a fixed 3-vector (eigenvectors()'s normalize) is Eigen's unrolled redux x0 + (x1 + x2);
+//   * normalize() then runs `derived() /= numext::sqrt(z)` on a COMPLEX column: DenseBase::operator/=(const Scalar&) takes the real norm as
+//     std::complex<float>(nrm, 0) and assigns with div_assign_op over a fixed 3-vector of complex<float>.  packet_traits<complex<float>> has
+//     HasDiv, a column of a column-major Matrix3cf has PacketAccessBit and LinearAccessBit, EIGEN_UNALIGNED_VECTORIZE is on: the traversal is
+//     LinearVectorizedTraversal with complete unrolling -- ONE Packet2cf (rows 0 and 1) and one scalar (row 2).  SSE's pdiv<Packet2cf> is
+//     pmul(a, pconj(b)) / (b.re^2 + b.im^2) per component, so rows 0 and 1 get re' = (re * nrm + 0) / (nrm * nrm + 0); row 2 is
+//     std::complex's operator/= = libgcc's __divsc3 = re / nrm for a zero imaginary divisor.  Two DIFFERENT roundings inside one column
+//     (EIG_NORMALIZE_SCALAR is the other reading: every row re / nrm);
 //   * a complex-conjugate pair (possible only when a trailing 2 x 2 block is pure rounding noise) divides std::complex<float> values:
 //     libgcc's __divsc3.  GCC 9 (Ubuntu 20.04, the reference's platform) implements Smith's algorithm in float, stated below without
 //     its NaN-recovery tail; GCC >= 11 widens to double instead.  `complex_pairs` counts how often a problem gets there (tests: never).
@@ -386,6 +393,17 @@ static inline void complex_div(Scalar a, Scalar b, Scalar c, Scalar d, Scalar& x
 }
 
 // ---- EigenSolver.h ---------------------------------------------------------------------------------------------------------
+// real part of (re, im) / (nrm, 0) as row `row` of matV.col(j).normalize() computes it (see the header): rows 0 and 1 through SSE's
+// pdiv<Packet2cf> -- pmul(a, pconj(b)) gives re * nrm + (-(im * -0)), the divisor is nrm * nrm + 0 * 0 --, row 2 through __divsc3 (Smith:
+// ratio = 0 / nrm, denom = 0 * ratio + nrm, x = (im * ratio + re) / denom)
+static inline Scalar normalized_real_part(Scalar re, Scalar im, Scalar nrm, int row) {
+#ifndef ORC_VAR_EIG_NORMALIZE_SCALAR
+    if (row < 2) return (re * nrm + (-(im * Scalar(-0.0f)))) / (nrm * nrm + Scalar(0) * Scalar(0));
+#endif
+    const Scalar ratio = Scalar(0) / nrm;
+    const Scalar denom = Scalar(0) * ratio + nrm;
+    return (im * ratio + re) / denom;
+}
 // row(i).segment(l, len).dot(col(n).segment(l, len)): sequential (see the header)
 static inline Scalar row_dot_col(const Matrix3f& T, int i, int n, int l, int len) {
     Scalar r = T(i, l) * T(l, n);
@@ -558,7 +576,7 @@ static inline void eigensolver_compute(const Matrix3f& matrix, EigenSolver3f& es
             for (int r = 0; r < N; ++r) es.V_re(r, j) = es.eivec(r, j);
             if (z > Scalar(0)) {
                 const Scalar nrm = std::sqrt(z);
-                for (int r = 0; r < N; ++r) es.V_re(r, j) = es.eivec(r, j) / nrm;
+                for (int r = 0; r < N; ++r) es.V_re(r, j) = normalized_real_part(es.eivec(r, j), Scalar(0), nrm, r);
             }
         } else {
             // a pair: matV(i, j) = (eivec(i, j), eivec(i, j+1)), matV(i, j+1) = its conjugate; both normalised; the real parts coincide
@@ -569,8 +587,10 @@ static inline void eigensolver_compute(const Matrix3f& matrix, EigenSolver3f& es
                 for (int r = 0; r < N; ++r) es.V_re(r, c) = es.eivec(r, j);
             if (z > Scalar(0)) {
                 const Scalar nrm = std::sqrt(z);
-                for (int c = j; c <= j + 1; ++c)
-                    for (int r = 0; r < N; ++r) es.V_re(r, c) = es.eivec(r, j) / nrm;
+                for (int r = 0; r < N; ++r) {  // the conjugate column divides (re, -im): the same real part up to the sign of a zero
+                    es.V_re(r, j) = normalized_real_part(es.eivec(r, j), es.eivec(r, j + 1), nrm, r);
+                    es.V_re(r, j + 1) = normalized_real_part(es.eivec(r, j), -es.eivec(r, j + 1), nrm, r);
+                }
             }
             ++j;
         }

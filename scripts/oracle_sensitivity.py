@@ -29,6 +29,7 @@ HYPOTHESES = {
     "LIMITCOV_VT": "limitCovariance rebuilds V*D*V^T instead of V*D*V^-1 with the cofactor inverse (Gaussians.h:200)",
     "LIMITCOV_JACOBI": "limitCovariance's eigenpairs from a fixed 6-sweep cyclic float Jacobi iteration (the statement of rounds 1-5, 'H5') instead of "
                        "EigenSolver<Matrix3f> restated from Eigen 3.4.0 (Hessenberg + Francis QR + back substitution, oracle/eigensolver3f.h) (Gaussians.h:184-188)",
+    "EIG_NORMALIZE_SCALAR": "eigenvectors()'s normalize() dividing every row as re/nrm instead of Eigen's Packet2cf division (re*nrm)/(nrm*nrm) in rows 0 and 1 (scalar complex division in row 2)",
     "EIG_BACK_HALVES": "the one 3-term sum inside that solver (back transformation of the last eigenvector, EigenSolver.h doComputeEigenvectors) as x0+(x1+x2) instead of (x0+x1)+x2",
     "STEP_LEFT_ASSOC": "the LM step as Eigen associates it, ((-alpha H^-1) J^T) e with a P x rows temporary and the GEMV's 16-column blocks, instead of (-alpha H^-1)(J^T e) (DmsaOptimizer.h:113)",
     "LM_BLOCKED_LU": "H^-1 from a right-looking partial-pivot LU in 8-column panels + two triangular solves (the shape of Eigen's PartialPivLU::inverse) instead of Gauss-Jordan on [H | I] (DmsaOptimizer.h:113)",

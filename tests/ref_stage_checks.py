@@ -9,7 +9,7 @@ oracle -- and the hypothesis switch of oracle/dmsa_oracle.cpp (ORC_VAR_*) that w
   fit_sums              global points + members         colwise().mean(), covariance     bit-exact                FIT_MEAN_TREE / FIT_FLOAT (mean); FIT_COV_TREE, the L1 size           
                                                         before limitCovariance,                                   behind Eigen's depth blocks (eigen_l1_bytes) for Gaussians above 680
                                                         pow(-1) of the counts                                     members (covariance); WEIGHT_DIV / the machine's libm (powf)
-  eigen_solver          the reference's covariances     eigenvalues().real(),            bit-exact                LIMITCOV_JACOBI (any other eigen-decomposition), EIG_BACK_HALVES, the restatement of
+  eigen_solver          the reference's covariances     eigenvalues().real(),            bit-exact                LIMITCOV_JACOBI (any other eigen-decomposition), EIG_BACK_HALVES, EIG_NORMALIZE_SCALAR, the restatement of
                                                         eigenvectors().real()                                     Eigen 3.4.0's RealSchur / EigenSolver (oracle/eigensolver3f.h); libgcc's complex division
   info_mats             the reference's covariances,    information matrices, weights    bit-exact                LIMITCOV_VT (the rebuild V D V^-1), Matrix3f::inverse(); the weights' mean (VectorXf::mean)
                         members
@@ -34,7 +34,7 @@ HINT = {
     "fit_sums": "mean: FIT_MEAN_TREE / FIT_FLOAT; covariance: FIT_COV_TREE, or -- if only Gaussians above 680 members differ -- the L1 size behind "
                 "Eigen's depth blocks (orc_set_eigen_l1_bytes / dmsa_debug_options::eigen_l1_bytes = the reference machine's L1d); pow(-1): WEIGHT_DIV, or another libm",
     "eigen_solver": "the restatement of EigenSolver<Matrix3f> (oracle/eigensolver3f.h: scaling, Hessenberg reflector, Francis QR steps, back substitution, back "
-                    "transformation order EIG_BACK_HALVES, normalisation) -- LIMITCOV_JACOBI is what ANY other eigen-decomposition looks like here; pairs: libgcc's __divsc3",
+                    "transformation order EIG_BACK_HALVES, normalisation EIG_NORMALIZE_SCALAR) -- LIMITCOV_JACOBI is what ANY other eigen-decomposition looks like here; pairs: libgcc's __divsc3",
     "info_mats": "LIMITCOV_VT (V D V^T instead of V D V^-1) or the cofactor order of Matrix3f::inverse() once 'eigen_solver' has pinned the eigenpairs; weights: the order of "
                  "VectorXf::mean() (FIT_MEAN_TREE / FIT_FLOAT) once 'fit_sums' has pinned pow(-1)",
     "residuals": "SUM3_LEFT or MAHA_ASSOC (or the float mean of DmsaOptimizer.h:247-254)",

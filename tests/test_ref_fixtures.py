@@ -153,6 +153,7 @@ def test_stage_checks_pass_on_the_oracles_own_dump(orc, name, tmp_path):
     ("LIMITCOV_VT", ["info_mats"], ["table", "global_points", "member_lists", "fit_sums", "eigen_solver", "residuals", "normal_equations"]),
     ("LIMITCOV_JACOBI", ["eigen_solver", "info_mats"], ["table", "global_points", "member_lists", "fit_sums", "residuals", "normal_equations"]),
     ("EIG_BACK_HALVES", ["eigen_solver"], ["table", "global_points", "member_lists", "fit_sums", "residuals", "normal_equations"]),
+    ("EIG_NORMALIZE_SCALAR", ["eigen_solver"], ["table", "global_points", "member_lists", "fit_sums", "residuals", "normal_equations"]),
 ])
 def test_every_float_order_hypothesis_is_decided_by_one_stage(orc, tmp_path, variant, fails, passes):
     """A dump written by the oracle built with ONE alternative reading stands in for "the reference turned out to evaluate it the other
@@ -186,6 +187,9 @@ def test_every_float_order_hypothesis_is_decided_by_one_stage(orc, tmp_path, var
     if variant == "EIG_BACK_HALVES":
         r = chk.report["eigen_solver"]
         assert r["eigenvalues_bit_equal"] == 1.0 and r["eigenvectors_bit_equal"] < 1.0, r  # only the last eigenvector's back transformation moves
+    if variant == "EIG_NORMALIZE_SCALAR":
+        r = chk.report["eigen_solver"]
+        assert r["eigenvalues_bit_equal"] == 1.0 and r["eigenvectors_bit_equal"] < 1.0, r  # rows 0 and 1 of the normalised eigenvectors move by an ulp
 
 
 def test_a_gaussian_count_where_powf_is_not_the_division_is_decided_by_fit_sums(orc):
