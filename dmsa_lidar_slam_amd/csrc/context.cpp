@@ -354,7 +354,7 @@ int dmsa_create_ex2(int device, uint32_t flags, const dmsa_debug_options* option
         std::memcpy(&dbg, options, options_bytes);
     }
     apply_debug_env(&dbg);
-    dbg.serial_streams = std::max(1, std::min(3, dbg.serial_streams)), dbg.serial_tree = std::max(0, std::min(2, dbg.serial_tree));
+    dbg.serial_streams = std::max(1, std::min(3, dbg.serial_streams)), dbg.serial_tree = std::max(0, std::min(3, dbg.serial_tree));
     dbg.host_threads = std::max(1, std::min(64, dbg.host_threads)), dbg.solve_threads = std::max(1, std::min(16, dbg.solve_threads));
     if (dbg.eigen_l1_bytes < 4096) dbg.eigen_l1_bytes = 32 * 1024;  // (Eigen's own default when cpuid reports nothing)
     *out = nullptr;

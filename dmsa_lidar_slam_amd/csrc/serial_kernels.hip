@@ -535,6 +535,11 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     __shared__ __attribute__((aligned(16))) float4 s_m[4][kChunk];  // member ring (filled by LDS-DMA)
     __shared__ int s_chain;  // the parallel second pass failed its test for some evaluation
     __shared__ int s_last;   // helper: this workgroup took the item's last ticket
+    // latency tier: the sums and smallest terms of the BLOCKS of the member list (a wave's share of the parallel second pass, or a helper's
+    // slice), kept for the block-wise fall-back below when the test on the whole Gaussian fails
+    constexpr int kBlocks = kSepLoader ? (kWaves > 8 ? kWaves : 8) : 1;
+    __shared__ double s_bsum[kBlocks][kBL];
+    __shared__ int s_bkey[kBlocks][kBL];
     __shared__ int s_evals[kBL], s_nb;  // the evaluations of this workgroup's lanes (build_eval_list) and how many there are
     double* s_t = reinterpret_cast<double*>(s_q);
 
@@ -714,10 +719,19 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
             double U = 0.0;
             int k = 0x7fffffff;
             if (helper) {
-                for (int hh = 0; hh < help.helpers; ++hh) U += red[hh * 64 + lane], k = min(k, redk[hh * 64 + lane]);
+                for (int hh = 0; hh < help.helpers; ++hh) {
+                    U += red[hh * 64 + lane], k = min(k, redk[hh * 64 + lane]);
+                    if constexpr (kSepLoader)
+                        if (hh < kBlocks) s_bsum[hh][lane] = red[hh * 64 + lane], s_bkey[hh][lane] = redk[hh * 64 + lane];
+                }
             } else {
-                for (int w = 0; w < kWaves; ++w)
-                    for (int s2 = 0; s2 < mpl; ++s2) U += red[w * 64 + s2 * Bs + lane], k = min(k, redk[w * 64 + s2 * Bs + lane]);
+                for (int w = 0; w < kWaves; ++w) {
+                    double ub = 0.0;
+                    int kb = 0x7fffffff;
+                    for (int s2 = 0; s2 < mpl; ++s2) ub += red[w * 64 + s2 * Bs + lane], kb = min(kb, redk[w * 64 + s2 * Bs + lane]);
+                    U += ub, k = min(k, kb);
+                    if constexpr (kSepLoader) s_bsum[w][lane] = ub, s_bkey[w][lane] = kb;
+                }
             }
             const int q = ((k >> 23) & 0xff) - 127 - 23;        // every term is a multiple of 2^q (a denormal smallest term: of 2^-149, so also of 2^-150)
             const int pe = min(max(q + 53 + 1023, 0), 2046);
@@ -807,10 +821,11 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
             return;
         }
         if (parallel_second_pass()) return;
-        if (helper) lds_barrier();  // (pairs with the producers' "the member ring holds chunk 0 again")
         const bool on2 = lane < nb;  // coordinate slot 0
-        double dacc = 0.0;
-        {
+        // the chained second pass over `sn` members (a segment of the list, or all of it), continuing the sums `dacc`: the phases the
+        // producers run in produce_pass2 below, barrier for barrier
+        auto chain_pass2 = [&](const int sn, double dacc, const bool primed) __attribute__((always_inline)) -> double {
+            const int sphases = (sn + kChunk - 1) / kChunk + 2;
             const double2* t2 = reinterpret_cast<const double2*>(s_t) + cb;
             constexpr int slot2 = kSlotDoubles / 2;
             // (depth 4 for the 32-member chunks of the throughput tier: with 8 the sixteen double2 registers of this ring pushed 23 VGPRs of the
@@ -821,8 +836,9 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
             constexpr int S = kChunk / 2, D = kChunk >= 64 ? 8 : DMSA_CHAIN2_DEPTH_SHORT;  // one step = one double2 = two members
             static_assert(S % D == 0, "the register ring r[k % D] runs on across chunk boundaries: D must divide the steps of a chunk");
             double2 r[D];
+            if (primed) lds_barrier();  // (pairs with the producers' "the member ring holds the segment's chunk 0")
             lds_barrier();  // phase 0
-            for (int p = 1; p < nphases; ++p) {
+            for (int p = 1; p < sphases; ++p) {
                 const int c = p - 2;
                 if (p == 1) {
 #pragma unroll
@@ -830,7 +846,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
                 } else {
                     const double2* cs = t2 + (c % kSlots) * slot2;
                     const double2* ns = t2 + ((c + 1) % kSlots) * slot2;
-                    const int cnt = min(kChunk, n - c * kChunk);
+                    const int cnt = min(kChunk, sn - c * kChunk);
                     if (cnt == kChunk) {
 #pragma unroll
                         for (int k = 0; k < S; ++k) {
@@ -851,7 +867,59 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
                 }
                 TL_BARRIER(1, p);
             }
+            return dacc;
+        };
+        if constexpr (kSepLoader) {
+            if ((tree_mode == 1 || tree_mode == 3) && (!helper || help.helpers <= kBlocks)) {
+                // ---- block-wise fall-back (latency tier).  The test on the whole Gaussian failed: some term is too small beside the sum (or not
+                // positive).  The parallel pass left the sum s_b and the smallest term of every BLOCK of the member list (a wave's share, a
+                // helper's slice), blocks in member order.  Walking the blocks with the running sum S of the reference's chain: if S is a
+                // multiple of 2^a, every term of the block a multiple of 2^q_b (positive floats), g = min(a, q_b) and S + s_b < 2^(g+53), then
+                // every partial sum of the chain through this block is a multiple of 2^g below 2^(g+53) -- a representable double: no addition
+                // rounds, the chain leaves the block with exactly S + s_b (and s_b itself is exact by the same bound).  A block that fails --
+                // the one with the tiny term; a block in which S, carrying low bits from an earlier rounding, crosses a power of two -- is
+                // chained member by member from S on.  One ill-placed member of a 14 000-member Gaussian then costs a tenth of its chain, not
+                // all of it (measured on the bench window: a fixed point with such a member ran 7 % slower per iteration).
+                // tree_mode 3 (test hook): every block through the chain.
+                const int mplb = 64 / Bs, nblk = helper ? help.helpers : kWaves;
+                const int bsz = ((n + nblk - 1) / nblk + mplb - 1) / mplb * mplb;
+                double S = 0.0;
+                for (int w = 0; w < nblk; ++w) {
+                    const int beg = min(n, w * bsz), cntm = min(n, beg + bsz) - beg;
+                    if (cntm <= 0) continue;
+                    double sb = 0.0;
+                    bool ok = true;
+                    if (on2) {
+                        sb = s_bsum[w][lane];
+                        const int key = s_bkey[w][lane];
+                        ok = key > 0;
+                        int gq = ((key >> 23) & 0xff) - 127 - 23;  // every term of the block is a multiple of 2^gq ...
+                        if (S != 0.0) {                             // ... and so is S, once gq is lowered to its lowest set bit
+                            const long long bits = __double_as_longlong(S);
+                            const int e = (int)((bits >> 52) & 0x7ff);
+                            const unsigned long long m = ((unsigned long long)bits & 0xfffffffffffffull) | (1ull << 52);
+                            gq = min(gq, e - 1023 - 52 + (int)__builtin_ctzll(m));
+                            ok = ok && e != 0 && e != 0x7ff && bits > 0;  // a denormal, infinite, NaN or negative S: the chain decides
+                        }
+                        const int pe = min(max(gq + 53 + 1023, 0), 2046);
+                        const double limit = __hiloint2double(pe << 20, 0);  // 2^(gq+53)
+                        ok = ok && (S + sb) * (1.0 + 0x1p-30) < limit;       // (sb may be rounded if the block is not exact: < n 2^-53 relative; NaN fails)
+                    }
+                    const bool bad = tree_mode == 3 || __ballot(on2 && !ok) != 0ull;
+                    if (lane == 0) s_chain = bad ? 1 : 0;
+                    lds_barrier();  // A: the producers read the verdict
+                    if (bad)
+                        S = chain_pass2(cntm, S, true);
+                    else
+                        S = S + sb;
+                    lds_barrier();  // B: ... before the next block's overwrites it
+                }
+                if (on2) E[(size_t)s_evals[lane] * ldE + g] = sqrt(fabs(S));
+                return;
+            }
         }
+        if (helper) lds_barrier();  // (pairs with the producers' "the member ring holds chunk 0 again")
+        const double dacc = chain_pass2(n, 0.0, false);
         if (on2) E[(size_t)s_evals[lane] * ldE + g] = sqrt(fabs(dacc));
         return;
     }
@@ -965,11 +1033,6 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         if (loader && !helper) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the member DMAs issued ahead for a chained second pass
         return;
     }
-    if (helper) {  // the chain after all: what pass 1 would have left in flight -- the first two chunks of the member ring
-        dma(nphases), dma(nphases + 1);
-        landed();
-        lds_barrier();
-    }
     // The chained second pass is the rare path (a failed exactness test).  What it needs of the lane -- its member slot, its evaluation, its
     // steps -- is derived AGAIN here from an opaque copy of the lane index, and the pose-table row cache starts empty: nothing of the producers'
     // per-lane state stays live across the parallel second pass above.  (At 64 registers the compiler otherwise parks six VGPRs in scratch
@@ -983,36 +1046,86 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
     rc2.r0 = rc2.r1 = rc2.r2 = f4{0.0f, 0.0f, 0.0f, 0.0f};
     int rc2_row = -1;
     const float mx = s_mean[pb_2 & 15], my = s_mean[kBL + (pb_2 & 15)], mz = s_mean[2 * kBL + (pb_2 & 15)];
-    for (int p = 0; p < nphases; ++p) {
-        const int P = nphases + p;
-        dma(P + 2);
-        if (p < nchunks) {
-            double* slot = s_t + (p % kSlots) * kSlotDoubles + pb_2 * 2;
-            const int left = n - p * kChunk;
+    // the terms of the members [sbeg, sbeg + sn) of the Gaussian into the ring, phase by phase (chain_pass2 of the chainer consumes them).
+    // pbase: the global phase the segment's first chunk was (or is) loaded for -- the whole list after pass 1: nphases, its first two chunks
+    // are in flight since the last phases of pass 1; a segment of the block-wise fall-back (prime): 0, the ring is drained and loaded afresh
+    auto produce_pass2 = [&](const int sbeg, const int sn, const int pbase, const bool prime) __attribute__((always_inline)) {
+        const int schunks = (sn + kChunk - 1) / kChunk, sphases = schunks + 2, slast = sbeg + sn - 1;
+        auto sdma = [&](int P, int c) {  // chunk c of the segment for global phase P
+            if (loader) {
 #pragma unroll
-            for (int u = 0; u < kMaxSteps; ++u) {
-                const int t_2 = pw + u * kProducers, jl_2 = 2 * (t_2 * mps + ms_2);
-                const int jl = (works && t_2 < steps && lane_on_2 && jl_2 < kChunk) ? jl_2 : kChunk;  // (jl_u[u] of pass 1)
-                if (jl < left && jl < kChunk) {
-                    const Pair m = read_pair(P & 3, jl);
-                    double* dst = slot + (jl >> 1) * (kBL * 2);  // jl even: the pair is one double2
-                    if (m.row0 != rc2_row) rc2 = load_rows(tabT, B, bcol_2, m.row0), rc2_row = m.row0;
-                    f2 gx, gy, gz;
-                    transform_v(rc2, m.x, m.y, m.z, gx, gy, gz);
-                    if (m.row1 != m.row0) {
-                        const Rows r1 = load_rows(tabT, B, bcol_2, m.row1);
-                        float hx, hy, hz;
-                        transform_v(r1, m.x.y, m.y.y, m.z.y, hx, hy, hz);
-                        gx.y = hx, gy.y = hy, gz.y = hz;
+                for (int hh = 0; hh < kChunk / 64 + (kChunk % 64 ? 1 : 0); ++hh) {
+                    if (hh * 64 + lane < kChunk) {
+                        const float4* src = memb + off0 + min(sbeg + c * kChunk + hh * 64 + lane, slast);
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_m + (unsigned)(P & 3) * (kChunk * 16) + (unsigned)hh * 1024u);
+                        unsigned keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep)
+                                     : "v"(src), "s"(dst)
+                                     : "memory");
                     }
-                    const f2 t = mahalanobis_v(I, gx, gy, gz, mx, my, mz);
-                    *reinterpret_cast<double2*>(dst) = double2{(double)t.x, (double)t.y};
                 }
             }
+        };
+        if (prime) {
+            if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // whatever was loaded ahead for another range
+            sdma(pbase, 0), sdma(pbase + 1, 1);
+            landed();
+            lds_barrier();  // the member ring holds the segment's chunk 0
         }
-        landed();
-        TL_BARRIER(1, p);
+        for (int p = 0; p < sphases; ++p) {
+            const int P = pbase + p;
+            sdma(P + 2, p + 2);
+            if (p < schunks) {
+                double* slot = s_t + (p % kSlots) * kSlotDoubles + pb_2 * 2;
+                const int left = sn - p * kChunk;
+#pragma unroll
+                for (int u = 0; u < kMaxSteps; ++u) {
+                    const int t_2 = pw + u * kProducers, jl_2 = 2 * (t_2 * mps + ms_2);
+                    const int jl = (works && t_2 < steps && lane_on_2 && jl_2 < kChunk) ? jl_2 : kChunk;  // (jl_u[u] of pass 1)
+                    if (jl < left && jl < kChunk) {
+                        const Pair m = read_pair(P & 3, jl);
+                        double* dst = slot + (jl >> 1) * (kBL * 2);  // jl even: the pair is one double2
+                        if (m.row0 != rc2_row) rc2 = load_rows(tabT, B, bcol_2, m.row0), rc2_row = m.row0;
+                        f2 gx, gy, gz;
+                        transform_v(rc2, m.x, m.y, m.z, gx, gy, gz);
+                        if (m.row1 != m.row0) {
+                            const Rows r1 = load_rows(tabT, B, bcol_2, m.row1);
+                            float hx, hy, hz;
+                            transform_v(r1, m.x.y, m.y.y, m.z.y, hx, hy, hz);
+                            gx.y = hx, gy.y = hy, gz.y = hz;
+                        }
+                        const f2 t = mahalanobis_v(I, gx, gy, gz, mx, my, mz);
+                        *reinterpret_cast<double2*>(dst) = double2{(double)t.x, (double)t.y};
+                    }
+                }
+            }
+            landed();
+            TL_BARRIER(1, p);
+        }
+    };
+    if constexpr (kSepLoader) {
+        if ((tree_mode == 1 || tree_mode == 3) && (!helper || help.helpers <= kBlocks)) {  // the block-wise fall-back (see the chainer)
+            const int mplb = 64 / Bs, nblk = helper ? help.helpers : kWaves;
+            const int bsz = ((n + nblk - 1) / nblk + mplb - 1) / mplb * mplb;
+            for (int w = 0; w < nblk; ++w) {
+                const int beg = min(n, w * bsz), cntm = min(n, beg + bsz) - beg;
+                if (cntm <= 0) continue;
+                lds_barrier();  // A
+                const bool bad = s_chain != 0;
+                if (bad) produce_pass2(beg, cntm, 0, true);
+                lds_barrier();  // B
+            }
+            if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in LDS after the workgroup has released it
+            return;
+        }
     }
+    if (helper) {  // the chain after all: what pass 1 would have left in flight -- the first two chunks of the member ring
+        dma(nphases), dma(nphases + 1);
+        landed();
+        lds_barrier();
+    }
+    produce_pass2(0, n, nphases, false);
     if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land in LDS after the workgroup has released it
 }
 

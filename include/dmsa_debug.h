@@ -32,7 +32,9 @@ typedef struct dmsa_debug_options {
     int32_t sort_prehist;    /* 0   the key kernels count the sort digits (measured 1.5 % slower than the sort's own histogram pass)     */
     int32_t overlap_batch;   /* 1   host-driven loop only: host math of the Jacobian batch while the GPU voxelises                        */
     int32_t serial_tree;     /* 1   double sum of the chain tiers: 1 parallel reduction when the exactness test allows it,
-                                     0 always the member-order chain, 2 both and keep the chain's result (test hook)                      */
+                                     0 always the member-order chain, 2 both and keep the chain's result (test hook).  Where the test fails
+                                     for a Gaussian of the latency tier, only the BLOCKS of its member list whose own bounds fail are chained
+                                     (csrc/serial_kernels.hip); 3 (test hook): every block through that chain                               */
     int32_t host_threads;    /* 16  worker threads of the context (upload packing, host-built pose tables, host solve)                   */
     int32_t solve_threads;   /* 12  of which the blocked host LM solve uses at most this many                                            */
     int32_t host_timeline;   /* 0   print host-side time stamps of the last iteration of every optimize call to stderr                   */

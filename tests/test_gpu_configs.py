@@ -344,7 +344,9 @@ def test_parallel_second_pass_of_the_chain_tiers(hip, orc, full_window, monkeypa
         e_ref = None
         # long_split = 4096: every Gaussian of the latency tier hands its second pass to helper workgroups (serial_kernels.hip) -- the last helper
         # tests the bounds and, where they fail (`adv`), runs the chain itself
-        for mode, split in (("1", 0), ("2", 0), ("0", 0), ("1", 4096), ("2", 4096)):
+        # serial_tree = 3: the latency tier's block-wise fall-back with EVERY block of every long Gaussian chained member by member from the running
+        # sum of the blocks before it (the live path, mode 1, chains only the blocks whose bounds fail -- on `adv` the ones with the planted members)
+        for mode, split in (("1", 0), ("2", 0), ("0", 0), ("3", 0), ("1", 4096), ("2", 4096), ("3", 4096)):
             opt = hip.DmsaOptimizer(debug={"serial_tree": int(mode), "long_split": split})
             opt.upload(prob)
             opt.poseTables(pbase[None, :], download=False)
