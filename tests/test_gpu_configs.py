@@ -336,8 +336,29 @@ def test_parallel_second_pass_of_the_chain_tiers(hip, orc, full_window, monkeypa
     adv.staticPoints = np.concatenate([adv.staticPoints, pts]).astype(np.float32)
     adv.staticRingIds = np.concatenate([adv.staticRingIds, np.full(len(extra), 7, adv.staticRingIds.dtype)])
 
-    for prob, expect_fallbacks in ((base, False), (adv, True)):
-        glob_p = np.concatenate([g, prob.staticPoints]).astype(np.float32)
+    # ... and WINDOW points moved onto the mean of the other members of a large Gaussian, near the front, the middle and three quarters of its
+    # member list: tiny terms in different blocks of the list, so that the block-wise fall-back of the latency tier (serial_kernels.hip) has to
+    # chain blocks in the middle and carry a running sum with low bits into the blocks behind them
+    adv_mid = base.copy()
+    N = base.localPoints.shape[0]
+    T = np.asarray(table, np.float64).reshape(-1, 3, 4)
+    moved = 0
+    for gi in big[:4]:
+        mem = np.asarray(G.members[G.seg_offset[gi]:G.seg_offset[gi + 1]])
+        for frac in (0.03, 0.5, 0.77):
+            k = int(frac * len(mem))
+            i = int(mem[k])
+            if i >= N:
+                continue  # a static member: `adv` covers those
+            m = glob[np.delete(mem, k), :3].astype(np.float64).mean(0)
+            R, t = T[base.tformIdPerPoint[i]][:, :3], T[base.tformIdPerPoint[i]][:, 3]
+            adv_mid.localPoints[i, :3] = (R.T @ (m - t)).astype(np.float32)
+            moved += 1
+    assert moved >= 6
+
+    for prob, expect_fallbacks in ((base, False), (adv, True), (adv_mid, True)):
+        g_p = g if prob is not adv_mid else orc.transform_points(table, prob.localPoints, prob.tformIdPerPoint)
+        glob_p = np.concatenate([g_p, prob.staticPoints]).astype(np.float32)
         ref = orc.Gaussians(glob_p, np.concatenate([prob.ringIds, prob.staticRingIds]), prob.minGridSize, s)
         pbase = prob.getPoseParameters()
         params = np.stack([pbase] + [pbase + H_INCR * np.eye(len(pbase))[k] for k in range(8)])  # 9 evaluations: two sub-batches
