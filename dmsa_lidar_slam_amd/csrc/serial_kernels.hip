@@ -883,6 +883,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
                 // tree_mode 3 (test hook): every block through the chain.
                 const int mplb = 64 / Bs, nblk = helper ? help.helpers : kWaves;
                 const int bsz = ((n + nblk - 1) / nblk + mplb - 1) / mplb * mplb;
+                lds_barrier();  // every wave has read the verdict on the whole Gaussian (s_chain) before the blocks' verdicts overwrite it
                 double S = 0.0;
                 for (int w = 0; w < nblk; ++w) {
                     const int beg = min(n, w * bsz), cntm = min(n, beg + bsz) - beg;
@@ -1108,6 +1109,7 @@ __global__ __launch_bounds__(64 * (kProd + 1 + (kSepLoader ? 1 : 0)), kSepLoader
         if ((tree_mode == 1 || tree_mode == 3) && (!helper || help.helpers <= kBlocks)) {  // the block-wise fall-back (see the chainer)
             const int mplb = 64 / Bs, nblk = helper ? help.helpers : kWaves;
             const int bsz = ((n + nblk - 1) / nblk + mplb - 1) / mplb * mplb;
+            lds_barrier();  // (the chainer's "every wave has read the verdict on the whole Gaussian")
             for (int w = 0; w < nblk; ++w) {
                 const int beg = min(n, w * bsz), cntm = min(n, beg + bsz) - beg;
                 if (cntm <= 0) continue;
