@@ -38,7 +38,7 @@ from dmsa_lidar_slam_amd.problems import ContinuousTrajectory  # noqa: E402
 from dmsa_lidar_slam_amd.static_points import StaticSelectProblem  # noqa: E402
 
 nw = p.windowPoints.shape[0]
-ident = ContinuousTrajectory(relOrientations=np.zeros((2, 3)), relTranslations=np.zeros((2, 3)), stamps=np.array([0.0, 1.0]), trajTime=np.linspace(0.0, 1.0, 11),
+ident = ContinuousTrajectory(relOrientations=np.zeros((3, 3)), relTranslations=np.zeros((3, 3)), stamps=np.array([0.0, 0.5, 1.0]), trajTime=np.linspace(0.0, 1.0, 11),
                              localPoints=p.windowPoints, tformIdPerPoint=np.zeros(nw, np.int32), ringIds=np.zeros(nw, np.int32), minGridSize=p.minGridSize)
 opt = DmsaOptimizer(device=0)
 opt.upload(ident)
