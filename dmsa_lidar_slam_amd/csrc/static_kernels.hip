@@ -317,17 +317,32 @@ __global__ void k_pick_offsets(const int32_t* __restrict__ scan_excl, const int3
 void launch_pick_offsets(const int32_t* scan_excl, const int32_t* sel, const int64_t* offsets, int K, int64_t n, int32_t* out, hipStream_t s) {
     hipLaunchKernelGGL(k_pick_offsets, dim3((unsigned)((K + 1 + 63) / 64)), dim3(64), 0, s, scan_excl, sel, offsets, K, n, out);
 }
+// flags are bytes of value 0 or 1 (k_radius_exists): sixteen of them per load, summed as packed bytes; one atomic per workgroup
 __global__ __launch_bounds__(kBlock) void k_count_flags(const uint8_t* __restrict__ flag, int64_t n, unsigned long long* __restrict__ count) {
+    __shared__ unsigned s_c[kBlock / 64];
     unsigned c = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) c += flag[i];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, n16 = n >> 4;
+    const uint4* f16 = reinterpret_cast<const uint4*>(flag);  // (hipMalloc'd: 256-byte aligned)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const uint4 w = f16[i];
+        const unsigned t = (w.x & 0x01010101u) + (w.y & 0x01010101u) + (w.z & 0x01010101u) + (w.w & 0x01010101u);  // four byte lanes, each <= 4
+        c += (t * 0x01010101u) >> 24;
+    }
+    for (int64_t i = (n16 << 4) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) c += flag[i] & 1u;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) c += (unsigned)__shfl_xor((int)c, m);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) t += s_c[w];
+        if (t) atomicAdd(count, (unsigned long long)t);
+    }
 }
 void launch_count_flags(const uint8_t* flag, int64_t n, unsigned long long* count, hipStream_t s) {
     (void)hipMemsetAsync(count, 0, sizeof(unsigned long long), s);
-    if (n > 0) hipLaunchKernelGGL(k_count_flags, dim3(grid_for(n, kBlock, 1024)), dim3(kBlock), 0, s, flag, n, count);
+    if (n > 0) hipLaunchKernelGGL(k_count_flags, dim3(grid_for((n + 15) / 16, kBlock, 256)), dim3(kBlock), 0, s, flag, n, count);
 }
 __global__ __launch_bounds__(kBlock) void k_leaf_pick(const int32_t* __restrict__ leaf_start, const uint32_t* __restrict__ idx_sorted,
                                                       const int32_t* __restrict__ rnd, int num_leaves, int32_t* __restrict__ out) {
