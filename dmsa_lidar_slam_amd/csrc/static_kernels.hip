@@ -253,8 +253,10 @@ __global__ __launch_bounds__(kBlock) void k_radius_exists_wave(const float4* __r
 void launch_radius_exists(const float4* query, int64_t nq, CellGrid g, const float4* pts_sorted, const void* code_sorted, bool key32, int64_t n,
                           const CellHashEntry* table, uint32_t table_mask, float r2, uint8_t* flag, hipStream_t s) {
     if (nq <= 0) return;
-    // a wave per query while that still fills the chip with few enough workgroups (measured: scripts/static_time.py); beyond, a thread per query
-    if (nq <= (int64_t)1 << 20) {
+    // A wave per query costs ~0.4 ns per query whatever the cells hold; a thread per query costs as much as its slowest thread, which walks
+    // the points of up to 27 cells one by one.  Measured (scripts/static_time.py): 30 720 queries against the 1.3 M-point window cloud 323 ->
+    // 27 us with waves; 1.3 M queries against 18 210 static points 72 us with threads, 550 us with waves.
+    if (nq <= ((int64_t)1 << 17) || n >= 4 * nq) {
         const unsigned wgrid = (unsigned)((nq * 64 + kBlock - 1) / kBlock);
         if (key32)
             hipLaunchKernelGGL(k_radius_exists_wave<uint32_t>, dim3(wgrid), dim3(kBlock), 0, s, query, nq, g, pts_sorted, (const uint32_t*)code_sorted, n, table,
